@@ -1,0 +1,37 @@
+# Builds libbscall_amd.so (gfx950 kernels + C host code) in-tree, and the CPU oracle used by the tests.
+ROCM ?= /opt/rocm
+HIPCC ?= $(ROCM)/bin/hipcc
+CC ?= gcc
+ARCH ?= gfx950
+CSRC = bs_call_amd/csrc
+LIBDIR = bs_call_amd/lib
+
+# -ffp-contract=off: the reference's arithmetic has no fused operations (x86-64 baseline build); every
+# fused multiply-add in the kernels is an explicit __builtin_fma in bsmath.h.
+HIPFLAGS = -O3 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-function
+CFLAGS = -O2 -fPIC -Wall -ffp-contract=off -std=gnu11 -I$(ROCM)/include -D__HIP_PLATFORM_AMD__
+
+all: $(LIBDIR)/libbscall_amd.so oracle
+
+$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/bsmath.h $(CSRC)/devtables.h $(CSRC)/synth.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/bscall_api.o: $(CSRC)/bscall_api.c include/bscall_amd.h $(CSRC)/devtables.h $(CSRC)/synth.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/bscall_api.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
+
+oracle:
+	$(MAKE) -C oracle liboracle.so
+
+asm: $(CSRC)/kernels.hip
+	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -Rpass-analysis=kernel-resource-usage $< -o $(LIBDIR)/kernels.s
+
+clean:
+	rm -f $(LIBDIR)/*.o $(LIBDIR)/*.so $(LIBDIR)/*.s
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle asm clean

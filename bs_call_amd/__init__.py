@@ -1,0 +1,9 @@
+"""bs_call_amd — MI355X-native per-site genotype + methylation caller (bs_call calc-path drop-in).
+
+The compute lives in bs_call_amd/lib/libbscall_amd.so (gfx950 HIP kernels behind the C ABI of
+include/bscall_amd.h).  This package is the thin Python host mirror used by tests and bench.py.
+"""
+from .abi import GENOTYPES, GT_HET, GT_METH, PILEUP, TEMPLATE  # noqa: F401
+from .caller import BscError, SiteCaller, synth_pileup_host  # noqa: F401
+
+__all__ = ["SiteCaller", "BscError", "synth_pileup_host", "PILEUP", "GT_METH", "TEMPLATE", "GENOTYPES", "GT_HET"]

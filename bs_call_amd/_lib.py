@@ -1,0 +1,94 @@
+"""ctypes binding of libbscall_amd.so (include/bscall_amd.h).  No fallback: a missing library is an error."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libbscall_amd.so")
+
+# every symbol include/bscall_amd.h declares
+EXPORTS = (
+    "bsc_abi_version",
+    "bsc_last_error",
+    "bsc_params_default",
+    "bsc_create",
+    "bsc_destroy",
+    "bsc_get_tables",
+    "bsc_call_sites",
+    "bsc_call_sites_device",
+    "bsc_set_profiling",
+    "bsc_last_kernel_ms",
+    "bsc_synchronize",
+    "bsc_get_stats",
+    "bsc_reset_stats",
+    "bsc_synth_pileup_device",
+    "bsc_synth_pileup_host",
+)
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("under_conv", C.c_double),
+        ("over_conv", C.c_double),
+        ("ref_bias", C.c_double),
+        ("min_qual", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("sites", C.c_uint64),
+        ("covered", C.c_uint64),
+        ("gt_hist", C.c_uint64 * 10),
+        ("het_calls", C.c_uint64),
+        ("reserved", C.c_uint64 * 3),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library; raise (never fall back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "bs_call_amd: %s is missing. Build it with `make` at the repository root "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    L.bsc_abi_version.restype = i32
+    L.bsc_abi_version.argtypes = []
+    L.bsc_last_error.restype = C.c_char_p
+    L.bsc_last_error.argtypes = []
+    L.bsc_params_default.restype = None
+    L.bsc_params_default.argtypes = [C.POINTER(Params)]
+    L.bsc_create.restype = i32
+    L.bsc_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.bsc_destroy.restype = i32
+    L.bsc_destroy.argtypes = [vp]
+    L.bsc_get_tables.restype = i32
+    L.bsc_get_tables.argtypes = [vp, vp, vp]
+    L.bsc_call_sites.restype = i32
+    L.bsc_call_sites.argtypes = [vp, vp, vp, u64, vp, u32, vp]
+    L.bsc_call_sites_device.restype = i32
+    L.bsc_call_sites_device.argtypes = [vp, vp, vp, u64, vp, u32, vp, vp]
+    L.bsc_set_profiling.restype = i32
+    L.bsc_set_profiling.argtypes = [vp, i32]
+    L.bsc_last_kernel_ms.restype = i32
+    L.bsc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.bsc_synchronize.restype = i32
+    L.bsc_synchronize.argtypes = [vp]
+    L.bsc_get_stats.restype = i32
+    L.bsc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.bsc_reset_stats.restype = i32
+    L.bsc_reset_stats.argtypes = [vp]
+    L.bsc_synth_pileup_device.restype = i32
+    L.bsc_synth_pileup_device.argtypes = [vp, u64, u64, u64, u32, u32, vp, vp, vp]
+    L.bsc_synth_pileup_host.restype = i32
+    L.bsc_synth_pileup_host.argtypes = [u64, u64, u64, u32, u32, vp, vp]
+    _lib = L
+    return L

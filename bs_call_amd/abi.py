@@ -1,0 +1,51 @@
+"""Binary layouts shared with the C ABI (include/bscall_amd.h).
+
+These numpy dtypes are byte-for-byte the reference's structs, so arrays of them can be handed to the
+library (or memcpy'd to the device) without conversion:
+  PILEUP   = `pileup`   include/bs_call.h:174-182   (104 B)
+  GT_METH  = `gt_meth`  include/bs_call.h:152-160   (200 B)
+  TEMPLATE = one read pair flattened out of `align_details` (include/bs_call.h:64-73), 40 B
+"""
+import numpy as np
+
+PILEUP = np.dtype(
+    {
+        "names": ["counts", "n", "quality", "mapq2"],
+        "formats": [("<u4", (2, 8)), "<u4", ("<f4", (8,)), "<f4"],
+        "offsets": [0, 64, 68, 100],
+        "itemsize": 104,
+    }
+)
+
+GT_METH = np.dtype(
+    {
+        "names": ["counts", "qual", "gt_prob", "fisher_strand", "mq", "aq", "max_gt"],
+        "formats": [("<u8", (8,)), ("<i4", (8,)), ("<f8", (10,)), "<f8", "<i4", "<i4", "u1"],
+        "offsets": [0, 64, 96, 176, 184, 188, 192],
+        "itemsize": 200,
+    }
+)
+
+TEMPLATE = np.dtype(
+    {
+        "names": ["pos", "len", "off", "mapq", "orientation", "bs_strand"],
+        "formats": [("<u4", (2,)), ("<u4", (2,)), ("<u8", (2,)), ("u1", (2,)), "u1", "u1"],
+        "offsets": [0, 8, 16, 32, 34, 35],
+        "itemsize": 40,
+    }
+)
+
+# genotype order of gt_prob[] (src/genotype_model.c:110-121)
+GENOTYPES = ("AA", "AC", "AG", "AT", "CC", "CG", "CT", "GG", "GT", "TT")
+# heterozygous genotypes (src/init_param.c:16)
+GT_HET = np.array([0, 1, 1, 1, 0, 1, 1, 0, 1, 0], dtype=bool)
+
+MAX_QUAL = 43
+FLT_QUAL = 63
+DEFAULT_UNDER_CONVERSION = 0.01
+DEFAULT_OVER_CONVERSION = 0.05
+DEFAULT_REF_BIAS = 2.0
+DEFAULT_MIN_QUAL = 20
+
+# strand -> pile-up class (src/call_genotypes.c:17-19), 0-based
+BASE_TAB_ST = np.array([[0, 1, 2, 3], [0, 5, 2, 7], [4, 1, 6, 3]], dtype=np.int8)

@@ -1,0 +1,127 @@
+"""Host-side mirror of bs_call's calc API over the C ABI (include/bscall_amd.h).
+
+`SiteCaller` plays the role of the reference's calc-thread pool: create it once (init_calc_threads +
+fill_base_prob_table, src/process.c:165-166), feed it blocks of pile-ups (the call_thread loop,
+src/call_genotypes.c:43-115), close it at the end (join_calc_threads).  Everything is computed by the
+gfx950 kernels; nothing here computes on the CPU or uses the CPU checker.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .abi import GT_METH, PILEUP
+
+SYNTH_NRUNS = 1
+
+
+class BscError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bscall_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _check(rc):
+    if rc != 0:
+        raise BscError(rc, _lib.load().bsc_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class SiteCaller:
+    def __init__(self, under_conv=0.01, over_conv=0.05, ref_bias=2.0, min_qual=20, device=-1):
+        self._L = _lib.load()
+        p = _lib.Params(under_conv, over_conv, ref_bias, min_qual, device)
+        h = C.c_void_p()
+        _check(self._L.bsc_create(C.byref(p), C.byref(h)))
+        self._h = h
+
+    # -- lifecycle ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bsc_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- tables -----------------------------------------------------------------------------------
+    def tables(self):
+        q = np.zeros((44, 5), dtype=np.float64)
+        lf = np.zeros(256, dtype=np.float64)
+        _check(self._L.bsc_get_tables(self._h, _ptr(q), _ptr(lf)))
+        return q, lf
+
+    # -- host blocks ------------------------------------------------------------------------------
+    def call_sites(self, pile, ref, out_stride=200):
+        """pile: PILEUP[n], ref: uint8[n] codes 0..4 -> (GT_METH[n] or raw uint8[n, stride], skip uint8[n])."""
+        pile = np.ascontiguousarray(pile, dtype=PILEUP)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        n = len(pile)
+        if len(ref) != n:
+            raise ValueError("pile and ref differ in length")
+        if out_stride == 200:
+            out = np.zeros(n, dtype=GT_METH)
+        else:
+            out = np.zeros((n, out_stride), dtype=np.uint8)
+        skip = np.zeros(n, dtype=np.uint8)
+        _check(self._L.bsc_call_sites(self._h, _ptr(pile), _ptr(ref), n, _ptr(out), out_stride, _ptr(skip)))
+        return out, skip
+
+    # -- device-resident blocks (raw device pointers, e.g. torch tensor .data_ptr()) ---------------
+    def call_sites_device(self, d_cts, d_ref, n, d_out, d_skip, out_stride=200, stream=None):
+        _check(self._L.bsc_call_sites_device(self._h, d_cts, d_ref, n, d_out, out_stride, d_skip, stream))
+
+    def synth_device(self, seed, first_site, n, coverage, d_cts, d_ref, flags=0, stream=None):
+        _check(self._L.bsc_synth_pileup_device(self._h, seed, first_site, n, coverage, flags, d_cts, d_ref, stream))
+
+    def set_profiling(self, enable=True):
+        _check(self._L.bsc_set_profiling(self._h, 1 if enable else 0))
+
+    def last_kernel_ms(self):
+        """(calling kernel ms, Fisher kernel ms) of the most recent launch, from HIP events on its stream."""
+        a, b = C.c_float(), C.c_float()
+        _check(self._L.bsc_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def synchronize(self):
+        _check(self._L.bsc_synchronize(self._h))
+
+    # -- counters ---------------------------------------------------------------------------------
+    def stats(self):
+        s = _lib.Stats()
+        _check(self._L.bsc_get_stats(self._h, C.byref(s)))
+        return {
+            "sites": int(s.sites),
+            "covered": int(s.covered),
+            "gt_hist": [int(x) for x in s.gt_hist],
+            "het_calls": int(s.het_calls),
+        }
+
+    def stats_vector(self):
+        """The counters as a flat int64 vector (the block ranks all-reduce at the end of a sharded run)."""
+        s = self.stats()
+        return np.array([s["sites"], s["covered"]] + s["gt_hist"] + [s["het_calls"]], dtype=np.int64)
+
+    def reset_stats(self):
+        _check(self._L.bsc_reset_stats(self._h))
+
+
+def synth_pileup_host(seed, first_site, n, coverage, flags=0):
+    """Host twin of the device generator (bsc_synth_pileup_host): identical bits, no GPU needed."""
+    L = _lib.load()
+    pile = np.zeros(n, dtype=PILEUP)
+    ref = np.zeros(n, dtype=np.uint8)
+    _check(L.bsc_synth_pileup_host(seed, first_site, n, coverage, flags, _ptr(pile), _ptr(ref)))
+    return pile, ref

@@ -1,0 +1,339 @@
+/*
+ * bscall_api.c — host side of libbscall_amd.so, plain C (the reference's host code is C and stays C).
+ * Owns the context (tables, HIP stream, grow-only device workspaces, counters) and moves host blocks
+ * through the gfx950 kernels in kernels.hip.  See include/bscall_amd.h for what each entry point replaces.
+ *
+ * No CPU fallback lives here: if HIP reports no usable device the context cannot be created.
+ */
+#ifndef __HIP_PLATFORM_AMD__
+#define __HIP_PLATFORM_AMD__ 1
+#endif
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/bscall_amd.h"
+#include "devtables.h"
+#include "synth.h"
+
+/* launchers implemented in kernels.hip */
+int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n, void *out, uint32_t out_dw, void *skip,
+                        const void *tb, void *het_list, void *counters, int num_cus, void *stream, void *ev_start,
+                        void *ev_mid, void *ev_stop);
+int bsc_dev_launch_synth(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags, void *cts,
+                         void *ref, int num_cus, void *stream);
+
+#define BSC_LN10 (2.30258509299404568402) /* the reference's LOG10 literal (include/bs_call.h:36) */
+#define BSC_HOST_CHUNK (4u << 20)         /* sites per host->device round trip (4 Mi sites = 1.2 GiB of records) */
+#define BSC_MAX_LAUNCH (1ull << 31)       /* sites per launch: site indices in the het list are 32-bit */
+
+struct bsc_context {
+  bsc_params params;
+  int device;
+  int num_cus;
+  hipStream_t stream;
+  double q_prob[44][5];
+  bsc_dev_tables host_tables;
+  void *d_tables;
+  unsigned long long *d_counters; /* BSC_CNT_WORDS */
+  uint64_t sites;                 /* positions processed (host-side count) */
+  /* grow-only workspaces (the reference's pileupv / gt_resv are grow-only too, src/call_genotypes.c:172-175) */
+  void *d_cts, *d_ref, *d_out, *d_skip;
+  size_t cap_cts, cap_ref, cap_out, cap_skip;
+  void *d_het;
+  size_t cap_het;
+  /* optional per-launch timing of the calling kernel (bsc_set_profiling) */
+  int profiling;
+  hipEvent_t ev[3];
+  int ev_valid;
+};
+
+static __thread char bsc_errbuf[512];
+
+static int bsc_fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(bsc_errbuf, sizeof bsc_errbuf, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(call)                                                                                        \
+  do {                                                                                                       \
+    hipError_t e_ = (call);                                                                                  \
+    if (e_ != hipSuccess) return bsc_fail(BSC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                               \
+  } while (0)
+
+int bsc_abi_version(void) { return BSC_ABI_VERSION; }
+const char *bsc_last_error(void) { return bsc_errbuf; }
+
+void bsc_params_default(bsc_params *p) {
+  p->under_conv = 0.01; /* DEFAULT_UNDER_CONVERSION, include/bs_call.h:16 */
+  p->over_conv = 0.05;  /* DEFAULT_OVER_CONVERSION,  include/bs_call.h:17 */
+  p->ref_bias = 2.0;    /* DEFAULT_REF_BIAS,         include/bs_call.h:18 */
+  p->min_qual = 20;     /* MIN_QUAL,                 include/bs_call.h:28 */
+  p->device = -1;
+}
+
+/* fill_base_prob_table (src/genotype_model.c:10-21) + lfact_store_init (src/stats_utils.c:14-21) + the two
+ * prior logs (src/genotype_model.c:88-89), with libm as in the reference. */
+static void bsc_build_tables(bsc_context *ctx) {
+  bsc_dev_tables *t = &ctx->host_tables;
+  for (int q = 0; q <= 43; q++) {
+    double e = exp(-.1 * (double)q * BSC_LN10);
+    if (e > .5) e = .5;
+    double k = e / (3.0 - 4.0 * e);
+    ctx->q_prob[q][0] = e;
+    ctx->q_prob[q][1] = t->k[q] = k;
+    ctx->q_prob[q][2] = t->ln_k[q] = log(k);
+    ctx->q_prob[q][3] = t->ln_k_half[q] = log(0.5 + k);
+    ctx->q_prob[q][4] = t->ln_k_one[q] = log(1.0 + k);
+  }
+  t->lfact[0] = t->lfact[1] = 0.0;
+  double l = 0.0;
+  for (int i = 2; i < 256; i++) {
+    l += log((double)i);
+    t->lfact[i] = l;
+  }
+  t->under_conv = ctx->params.under_conv;
+  t->over_conv = ctx->params.over_conv;
+  t->lrb = log(ctx->params.ref_bias);
+  t->lrb1 = log(0.5 * (1.0 + ctx->params.ref_bias));
+}
+
+int bsc_create(const bsc_params *params, bsc_context **out) {
+  if (!out) return bsc_fail(BSC_ERR_ARG, "bsc_create: out is NULL");
+  *out = NULL;
+  bsc_params p;
+  if (params) p = *params;
+  else bsc_params_default(&p);
+  if (!(p.under_conv >= 0.0 && p.under_conv < 1.0) || !(p.over_conv >= 0.0 && p.over_conv < 1.0) || !(p.ref_bias > 0.0))
+    return bsc_fail(BSC_ERR_ARG, "bsc_create: conversion rates must be in [0,1) and ref_bias > 0");
+  if (p.min_qual < 1) p.min_qual = 1; /* src/parse_args.c:170-171 */
+  if (p.min_qual > 43) p.min_qual = 43;
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return bsc_fail(BSC_ERR_NO_DEVICE, "bsc_create: no HIP device (%s); this library has no CPU path",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  int dev = p.device;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= ndev) return bsc_fail(BSC_ERR_ARG, "bsc_create: device %d out of range (%d devices)", dev, ndev);
+  HIP_TRY(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return bsc_fail(BSC_ERR_NO_DEVICE, "bsc_create: device %d is %s; the kernels are built for gfx950 only", dev,
+                    prop.gcnArchName);
+
+  bsc_context *ctx = calloc(1, sizeof *ctx);
+  if (!ctx) return bsc_fail(BSC_ERR_NOMEM, "bsc_create: out of host memory");
+  ctx->params = p;
+  ctx->device = dev;
+  ctx->num_cus = prop.multiProcessorCount;
+  bsc_build_tables(ctx);
+  int rc = BSC_OK;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(&ctx->d_tables, sizeof(bsc_dev_tables)) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_counters, BSC_CNT_WORDS * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemcpy(ctx->d_tables, &ctx->host_tables, sizeof(bsc_dev_tables), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(ctx->d_counters, 0, BSC_CNT_WORDS * sizeof(unsigned long long)) != hipSuccess) {
+    rc = bsc_fail(BSC_ERR_HIP, "bsc_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
+    bsc_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return BSC_OK;
+}
+
+int bsc_destroy(bsc_context *ctx) {
+  if (!ctx) return BSC_OK;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    hipStreamSynchronize(ctx->stream);
+    hipStreamDestroy(ctx->stream);
+  }
+  hipFree(ctx->d_tables);
+  hipFree(ctx->d_counters);
+  hipFree(ctx->d_cts);
+  hipFree(ctx->d_ref);
+  hipFree(ctx->d_out);
+  hipFree(ctx->d_skip);
+  hipFree(ctx->d_het);
+  for (int i = 0; i < 3; i++)
+    if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+  free(ctx);
+  return BSC_OK;
+}
+
+int bsc_get_tables(const bsc_context *ctx, double *q_prob_44x5, double *lfact_256) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_get_tables: ctx is NULL");
+  if (q_prob_44x5) memcpy(q_prob_44x5, ctx->q_prob, sizeof ctx->q_prob);
+  if (lfact_256) memcpy(lfact_256, ctx->host_tables.lfact, sizeof ctx->host_tables.lfact);
+  return BSC_OK;
+}
+
+static int bsc_reserve(void **p, size_t *cap, size_t need) {
+  if (need <= *cap) return BSC_OK;
+  if (*p) {
+    hipError_t e = hipFree(*p);
+    *p = NULL;
+    *cap = 0;
+    if (e != hipSuccess) return bsc_fail(BSC_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e));
+  }
+  size_t sz = need + need / 4; /* grow-only with slack */
+  hipError_t e = hipMalloc(p, sz);
+  if (e != hipSuccess) {
+    sz = need;
+    e = hipMalloc(p, sz);
+  }
+  if (e != hipSuccess) return bsc_fail(BSC_ERR_NOMEM, "hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e));
+  *cap = sz;
+  return BSC_OK;
+}
+
+static int bsc_check_stride(uint32_t out_stride) {
+  if (out_stride != 200 && out_stride != 208)
+    return bsc_fail(BSC_ERR_ARG, "out_stride must be 200 (gt_meth[]) or 208 (gt_vcf[]), got %u", out_stride);
+  return BSC_OK;
+}
+
+int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref, uint64_t n, void *d_out,
+                          uint32_t out_stride, void *d_skip, void *stream) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_call_sites_device: ctx is NULL");
+  int rc = bsc_check_stride(out_stride);
+  if (rc) return rc;
+  if (n == 0) return BSC_OK;
+  if (!d_cts || !d_ref || !d_out || !d_skip) return bsc_fail(BSC_ERR_ARG, "bsc_call_sites_device: NULL buffer");
+  if (((uintptr_t)d_cts & 15u) || ((uintptr_t)d_out & 15u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_call_sites_device: d_cts and d_out must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  uint64_t done = 0;
+  while (done < n) {
+    uint64_t m = n - done;
+    if (m > BSC_MAX_LAUNCH) m = BSC_MAX_LAUNCH; /* multiple of 2 sites: keeps the 16-byte alignment of both arrays */
+    rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, (size_t)m * 4u);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_HET_LIST, 0, sizeof(unsigned long long), s));
+    int e = bsc_dev_launch_call((const char *)d_cts + done * 104u, (const char *)d_ref + done, m,
+                                (char *)d_out + done * out_stride, out_stride / 4u, (char *)d_skip + done,
+                                ctx->d_tables, ctx->d_het, ctx->d_counters, ctx->num_cus, s,
+                                ctx->profiling ? ctx->ev[0] : NULL, ctx->profiling ? ctx->ev[1] : NULL,
+                                ctx->profiling ? ctx->ev[2] : NULL);
+    if (ctx->profiling) ctx->ev_valid = 1;
+    if (e) return bsc_fail(BSC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    done += m;
+  }
+  ctx->sites += n;
+  return BSC_OK;
+}
+
+int bsc_call_sites(bsc_context *ctx, const bsc_pileup *cts, const uint8_t *ref, uint64_t n, void *out,
+                   uint32_t out_stride, uint8_t *skip) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_call_sites: ctx is NULL");
+  int rc = bsc_check_stride(out_stride);
+  if (rc) return rc;
+  if (n == 0) return BSC_OK;
+  if (!cts || !ref || !out || !skip) return bsc_fail(BSC_ERR_ARG, "bsc_call_sites: NULL buffer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const uint64_t chunk = n < BSC_HOST_CHUNK ? n : BSC_HOST_CHUNK;
+  if ((rc = bsc_reserve(&ctx->d_cts, &ctx->cap_cts, (size_t)chunk * 104u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)chunk))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)chunk * out_stride))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)chunk))) return rc;
+  for (uint64_t done = 0; done < n; done += chunk) {
+    const uint64_t m = (n - done) < chunk ? (n - done) : chunk;
+    HIP_TRY(hipMemcpyAsync(ctx->d_cts, cts + done, (size_t)m * 104u, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref + done, (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+    rc = bsc_call_sites_device(ctx, ctx->d_cts, ctx->d_ref, m, ctx->d_out, out_stride, ctx->d_skip, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync((char *)out + done * out_stride, ctx->d_out, (size_t)m * out_stride, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipMemcpyAsync(skip + done, ctx->d_skip, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return BSC_OK;
+}
+
+int bsc_set_profiling(bsc_context *ctx, int enable) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_set_profiling: ctx is NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (enable && !ctx->ev[0])
+    for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&ctx->ev[i]));
+  ctx->profiling = enable != 0;
+  ctx->ev_valid = 0;
+  return BSC_OK;
+}
+
+int bsc_last_kernel_ms(bsc_context *ctx, float *call_ms, float *fisher_ms) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_last_kernel_ms: ctx is NULL");
+  if (!ctx->profiling || !ctx->ev_valid) return bsc_fail(BSC_ERR_ARG, "bsc_last_kernel_ms: no profiled launch yet");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipEventSynchronize(ctx->ev[2]));
+  float a = 0.f, b = 0.f;
+  HIP_TRY(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+  if (call_ms) *call_ms = a;
+  if (fisher_ms) *fisher_ms = b;
+  return BSC_OK;
+}
+
+int bsc_synchronize(bsc_context *ctx) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_synchronize: ctx is NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return BSC_OK;
+}
+
+int bsc_get_stats(bsc_context *ctx, bsc_stats *out) {
+  if (!ctx || !out) return bsc_fail(BSC_ERR_ARG, "bsc_get_stats: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long c[BSC_CNT_WORDS];
+  HIP_TRY(hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof *out);
+  out->sites = ctx->sites;
+  out->covered = c[BSC_CNT_COVERED];
+  for (int g = 0; g < 10; g++) out->gt_hist[g] = c[BSC_CNT_COVERED + 1 + g];
+  out->het_calls = c[BSC_CNT_COVERED + 11];
+  return BSC_OK;
+}
+
+int bsc_reset_stats(bsc_context *ctx) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_reset_stats: ctx is NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(ctx->d_counters, 0, BSC_CNT_WORDS * sizeof(unsigned long long)));
+  ctx->sites = 0;
+  return BSC_OK;
+}
+
+int bsc_synth_pileup_device(bsc_context *ctx, uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage,
+                            uint32_t flags, void *d_cts, void *d_ref, void *stream) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_synth_pileup_device: ctx is NULL");
+  if (n && (!d_cts || !d_ref)) return bsc_fail(BSC_ERR_ARG, "bsc_synth_pileup_device: NULL buffer");
+  if (coverage > 4000) return bsc_fail(BSC_ERR_ARG, "bsc_synth_pileup_device: coverage %u > 4000", coverage);
+  HIP_TRY(hipSetDevice(ctx->device));
+  int e = bsc_dev_launch_synth(seed, first_site, n, coverage, flags, d_cts, d_ref, ctx->num_cus,
+                               stream ? stream : (void *)ctx->stream);
+  if (e) return bsc_fail(BSC_ERR_HIP, "synth launch failed: %s", hipGetErrorString((hipError_t)e));
+  return BSC_OK;
+}
+
+int bsc_synth_pileup_host(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags,
+                          bsc_pileup *cts, uint8_t *ref) {
+  if (n && (!cts || !ref)) return bsc_fail(BSC_ERR_ARG, "bsc_synth_pileup_host: NULL buffer");
+  if (coverage > 4000) return bsc_fail(BSC_ERR_ARG, "bsc_synth_pileup_host: coverage %u > 4000", coverage);
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t rf;
+    syn_site(seed, first_site + i, coverage, flags, &cts[i].counts[0][0], &cts[i].n, cts[i].quality, &cts[i].mapq2, &rf);
+    ref[i] = (uint8_t)rf;
+  }
+  return BSC_OK;
+}

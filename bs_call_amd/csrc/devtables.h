@@ -1,0 +1,20 @@
+/* devtables.h — device-side constant block and counter indices shared by kernels.hip and bscall_api.c. */
+#ifndef BSCALL_AMD_DEVTABLES_H
+#define BSCALL_AMD_DEVTABLES_H
+
+/* q_prob columns (include/bs_call.h:148-150) as separate arrays, lfact_store (src/stats_utils.c:14-21) and
+ * the per-run scalars of calc_gt_prob (src/genotype_model.c:47-48,88-89).  Built on the host with libm,
+ * exactly as the reference builds them, and uploaded verbatim. */
+typedef struct {
+  double k[44], ln_k[44], ln_k_half[44], ln_k_one[44];
+  double lfact[256];
+  double under_conv, over_conv;
+  double lrb, lrb1; /* log(ref_bias), log(0.5 * (1 + ref_bias)) */
+} bsc_dev_tables;
+
+/* unsigned long long counters[BSC_CNT_WORDS] in device memory */
+#define BSC_CNT_HET_LIST 0 /* length of the heterozygous-site list of the current launch (reset per launch) */
+#define BSC_CNT_COVERED 1  /* then gt_hist[10] at 2..11, het_calls at 12 */
+#define BSC_CNT_WORDS 16
+
+#endif

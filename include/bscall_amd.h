@@ -1,0 +1,158 @@
+/*
+ * bscall_amd.h — C ABI of libbscall_amd.so: bs_call's per-site genotype + methylation calling path
+ * (pile-up -> gt_meth) as hand-written gfx950 (MI355X) HIP kernels.
+ *
+ * Plain C, plain pointers and sizes; no C++/torch types.  Every entry point names the piece of the
+ * reference (heathsc/bs_call v2.1.7) it stands in for; INTEGRATION.md shows the replacement
+ * src/call_genotypes.c a maintainer would compile inside the reference tree against this header.
+ *
+ * The record layouts are the reference's own, byte for byte, so host arrays of the reference's
+ * `pileup` / `gt_meth` can be passed without conversion.
+ *
+ * All functions return BSC_OK (0) or a negative BSC_ERR_* code; bsc_last_error() gives the text.
+ * There is NO CPU fallback: without a usable gfx950 device bsc_create() fails with BSC_ERR_NO_DEVICE.
+ */
+#ifndef BSCALL_AMD_H
+#define BSCALL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSC_ABI_VERSION 1
+
+#define BSC_OK 0
+#define BSC_ERR_ARG (-1)       /* bad argument (the reference would assert: src/call_genotypes.c:158,186,188) */
+#define BSC_ERR_HIP (-2)       /* a HIP runtime call failed */
+#define BSC_ERR_NOMEM (-3)     /* host or device allocation failed */
+#define BSC_ERR_NO_DEVICE (-4) /* no gfx950 device / kernels not loadable */
+
+/* `pileup`, include/bs_call.h:174-182 — 104 bytes */
+typedef struct {
+  uint32_t counts[2][8]; /* [orientation][class]; classes 0-3 non-informative ACGT, 4-7 informative ACGT */
+  uint32_t n;            /* bases that passed the quality filter */
+  float quality[8];      /* sum of base qualities per class */
+  float mapq2;           /* sum of MAPQ^2 */
+} bsc_pileup;
+
+/* `gt_meth`, include/bs_call.h:152-160 — 200 bytes */
+typedef struct {
+  uint64_t counts[8];
+  int32_t qual[8];      /* rounded mean quality per class */
+  double gt_prob[10];   /* log10 posterior, order AA AC AG AT CC CG CT GG GT TT */
+  double fisher_strand; /* log10 Fisher strand-bias p (0 for homozygous calls) */
+  int32_t mq;           /* RMS mapping quality */
+  int32_t aq;           /* mean base quality */
+  uint8_t max_gt;       /* argmax of gt_prob (first maximum) */
+} bsc_gt_meth;
+
+/* One template (read pair) flattened out of `align_details`, include/bs_call.h:64-73 — 40 bytes.
+ * Read k holds len[k] bytes of base|qual<<2 (GET_BASE/GET_QUAL, include/bs_call.h:41-42) at seq+off[k],
+ * already trimmed/clipped/normalised by the host so that byte j sits at genome position pos[k]+j. */
+typedef struct {
+  uint32_t pos[2];     /* forward_position, reverse_position; 0 = none */
+  uint32_t len[2];     /* 0 = read absent */
+  uint64_t off[2];     /* byte offsets into the block's concatenated read buffer */
+  uint8_t mapq[2];
+  uint8_t orientation; /* gt_strand: 0 FORWARD, 1 REVERSE */
+  uint8_t bs_strand;   /* gt_bs_strand: 0 NON_CONVERTED, 1 STRAND_C2T, 2 STRAND_G2A */
+  uint32_t _pad;
+} bsc_template;
+
+/* Model parameters: sr_param.under_conv/over_conv/ref_bias/min_qual (include/bs_call.h:320-324;
+ * defaults src/init_param.c:26-31 = 0.01, 0.05, 2, 20; min_qual is clamped to [1,43] as in
+ * src/parse_args.c:170-171). */
+typedef struct {
+  double under_conv;
+  double over_conv;
+  double ref_bias;
+  int32_t min_qual;
+  int32_t device; /* HIP device ordinal; -1 = current device */
+} bsc_params;
+
+/* Per-context counters, summed over every call since creation / bsc_reset_stats().  These are the
+ * fixed-size blocks that ranks all-reduce at the end of a sharded run. */
+#define BSC_STATS_WORDS 16
+typedef struct {
+  uint64_t sites;      /* positions processed */
+  uint64_t covered;    /* positions with n > 0 (not skipped) */
+  uint64_t gt_hist[10];/* called genotype histogram over covered positions */
+  uint64_t het_calls;  /* covered positions whose call is heterozygous (Fisher test evaluated) */
+  uint64_t reserved[3];
+} bsc_stats;
+
+typedef struct bsc_context bsc_context;
+
+int bsc_abi_version(void);
+const char *bsc_last_error(void);
+void bsc_params_default(bsc_params *p);
+
+/*
+ * bsc_create: replaces fill_base_prob_table() + init_calc_threads() (src/process.c:165-166;
+ * src/genotype_model.c:10-21; src/call_genotypes.c:124-138) and the lfact_store / gt_het tables of
+ * init_param() (src/init_param.c:16,52-55).  Builds the tables on the host with libm exactly as the
+ * reference does, uploads them verbatim, creates the context's HIP stream and workspaces.
+ */
+int bsc_create(const bsc_params *params, bsc_context **out);
+
+/* bsc_destroy: replaces join_calc_threads() (src/call_genotypes.c:140-153). */
+int bsc_destroy(bsc_context *ctx);
+
+/* Copies the host-built tables out: q_prob as [44][5] doubles (e,k,ln_k,ln_k_half,ln_k_one;
+ * include/bs_call.h:148-150) and lfact_store[256] (src/stats_utils.c:14-21). */
+int bsc_get_tables(const bsc_context *ctx, double *q_prob_44x5, double *lfact_256);
+
+/*
+ * bsc_call_sites: the call_thread() loop over one block (src/call_genotypes.c:43-115): per site the
+ * quality/MAPQ summary, calc_gt_prob(), the strand table + fisher() for heterozygous calls.
+ *   cts[n]  pile-ups (host memory)
+ *   ref[n]  reference codes 0..4 = N,A,C,G,T for the same positions (src/get_sequence.c:20-54)
+ *   out     n records of `out_stride` bytes each (>= 200, multiple of 8); the first 200 bytes of
+ *           record i are the gt_meth of site i (all zero for a skipped site).  out_stride = 208 writes
+ *           straight into a gt_vcf array (include/bs_call.h:162-166).
+ *   skip[n] 1 where n == 0 (gt_vcf.skip), else 0
+ * Synchronous: returns when `out` and `skip` are filled.
+ */
+int bsc_call_sites(bsc_context *ctx, const bsc_pileup *cts, const uint8_t *ref, uint64_t n, void *out,
+                   uint32_t out_stride, uint8_t *skip);
+
+/*
+ * Same computation on device-resident buffers; asynchronous on `stream` (a hipStream_t, NULL = the
+ * context's own stream).  d_cts/d_out must be 16-byte aligned.  Used by bench.py and by pipelines that
+ * keep pile-ups in HBM.
+ */
+int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref, uint64_t n, void *d_out,
+                          uint32_t out_stride, void *d_skip, void *stream);
+
+/* Per-launch kernel timing with HIP events recorded on the launch stream (measurement support):
+ * after bsc_set_profiling(ctx, 1), bsc_last_kernel_ms() returns the device time of the most recent
+ * calling kernel and of its Fisher pass (it waits for that launch to finish).  With n > 2^31 sites per
+ * call only the last sub-launch is reported. */
+int bsc_set_profiling(bsc_context *ctx, int enable);
+int bsc_last_kernel_ms(bsc_context *ctx, float *call_ms, float *fisher_ms);
+
+/* Blocks until everything queued on the context's own stream has finished. */
+int bsc_synchronize(bsc_context *ctx);
+
+/* Counters (device -> host; synchronises the context's stream). */
+int bsc_get_stats(bsc_context *ctx, bsc_stats *out);
+int bsc_reset_stats(bsc_context *ctx);
+
+/*
+ * Synthetic 'L-pileup' generator: fills d_cts[n] and d_ref[n] on
+ * the device for absolute site indices first_site .. first_site+n-1 of a synthetic contig.  Deterministic
+ * in (seed, site index) only, so any window can be regenerated independently.  Bench/test support.
+ */
+#define BSC_SYNTH_NRUNS 1u /* flags: 1 % of 10-kb runs are N (reference code 0) with no reads */
+int bsc_synth_pileup_device(bsc_context *ctx, uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage,
+                            uint32_t flags, void *d_cts, void *d_ref, void *stream);
+/* Host twin of the generator (same bits), for feeding the same inputs to a CPU checker. */
+int bsc_synth_pileup_host(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags,
+                          bsc_pileup *cts, uint8_t *ref);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSCALL_AMD_H */

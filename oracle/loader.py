@@ -1,0 +1,135 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE.  Import only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+
+LIBM, BSM = 0, 1
+
+TABLES_BYTES = 44 * 40 + 256 * 8 + 5 * 8 + 8
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", HERE, "liboracle.so"] + (["-B"] if force else []))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        L.orc_log.restype = C.c_double
+        L.orc_log.argtypes = [C.c_double, C.c_int]
+        L.orc_exp.restype = C.c_double
+        L.orc_exp.argtypes = [C.c_double, C.c_int]
+        L.orc_lfact.restype = C.c_double
+        L.orc_lfact.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.orc_fisher.restype = C.c_double
+        L.orc_fisher.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_calc_gt_prob.restype = None
+        L.orc_calc_gt_prob.argtypes = [C.c_void_p, C.c_void_p, C.c_char, C.c_int]
+        L.orc_tables_init.restype = None
+        L.orc_tables_init.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.orc_call_sites.restype = C.c_int
+        L.orc_call_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_accumulate.restype = C.c_int
+        L.orc_accumulate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        for f in ("orc_log_array", "orc_exp_array"):
+            getattr(L, f).restype = None
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        assert L.orc_sizeof_tables() == TABLES_BYTES, (L.orc_sizeof_tables(), TABLES_BYTES)
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Tables:
+    """orc_tables: q_prob[44], lfact_store[256] and the model parameters (reference defaults)."""
+
+    def __init__(self, under_conv=0.01, over_conv=0.05, ref_bias=2.0, min_qual=20):
+        self.buf = np.zeros(TABLES_BYTES, dtype=np.uint8)
+        lib().orc_tables_init(_ptr(self.buf), under_conv, over_conv, ref_bias, min_qual)
+        self.params = (under_conv, over_conv, ref_bias, min_qual)
+
+    @property
+    def q_prob(self):
+        return self.buf[: 44 * 40].view("<f8").reshape(44, 5)
+
+    @property
+    def lfact_store(self):
+        return self.buf[44 * 40 : 44 * 40 + 2048].view("<f8")
+
+    @property
+    def ptr(self):
+        return _ptr(self.buf)
+
+
+def calc_gt_prob(counts, quals, rf, tables=None, flavour=LIBM):
+    from bs_call_amd.abi import GT_METH
+
+    tables = tables or Tables()
+    g = np.zeros(1, dtype=GT_METH)
+    g["counts"][0] = counts
+    g["qual"][0] = quals
+    lib().orc_calc_gt_prob(_ptr(g), tables.ptr, bytes([rf]), flavour)
+    return g[0]
+
+
+def fisher(c, tables=None, flavour=LIBM):
+    tables = tables or Tables()
+    arr = np.array(c, dtype=np.int32)
+    return lib().orc_fisher(_ptr(arr), tables.ptr, flavour)
+
+
+def call_sites(pile, ref, tables=None, flavour=LIBM, nthreads=1):
+    """pile: PILEUP[n]; ref: uint8[n] codes 0..4 -> (GT_METH[n], skip uint8[n])."""
+    from bs_call_amd.abi import GT_METH, PILEUP
+
+    tables = tables or Tables()
+    pile = np.ascontiguousarray(pile, dtype=PILEUP)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    n = len(pile)
+    assert len(ref) == n
+    out = np.zeros(n, dtype=GT_METH)
+    skip = np.zeros(n, dtype=np.uint8)
+    rc = lib().orc_call_sites(_ptr(pile), _ptr(ref), n, tables.ptr, _ptr(out), _ptr(skip), flavour, nthreads)
+    assert rc == 0
+    return out, skip
+
+
+def accumulate(templates, seq, x, y, min_qual=20):
+    from bs_call_amd.abi import PILEUP, TEMPLATE
+
+    templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    out = np.zeros(max(int(y) - int(x) + 1, 0), dtype=PILEUP)
+    rc = lib().orc_accumulate(_ptr(templates), len(templates), _ptr(seq), x, y, min_qual, _ptr(out))
+    return rc, out
+
+
+def log_array(x, flavour):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    lib().orc_log_array(_ptr(x), _ptr(y), x.size, flavour)
+    return y
+
+
+def exp_array(x, flavour):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    lib().orc_exp_array(_ptr(x), _ptr(y), x.size, flavour)
+    return y
