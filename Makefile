@@ -13,11 +13,11 @@ CFLAGS = -O2 -fPIC -Wall -ffp-contract=off -std=gnu11 -I$(ROCM)/include -D__HIP_
 
 all: $(LIBDIR)/libbscall_amd.so oracle
 
-$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/bsmath.h $(CSRC)/devtables.h $(CSRC)/synth.h
+$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h $(CSRC)/devtables.h $(CSRC)/synth.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/bscall_api.o: $(CSRC)/bscall_api.c include/bscall_amd.h $(CSRC)/devtables.h $(CSRC)/synth.h
+$(LIBDIR)/bscall_api.o: $(CSRC)/bscall_api.c include/bscall_amd.h $(CSRC)/bsmath_tables.h $(CSRC)/devtables.h $(CSRC)/synth.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 

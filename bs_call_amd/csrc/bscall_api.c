@@ -17,6 +17,7 @@
 
 #include "../../include/bscall_amd.h"
 #include "devtables.h"
+#include "bsmath_tables.h"
 #include "synth.h"
 
 /* launchers implemented in kernels.hip */
@@ -99,6 +100,8 @@ static void bsc_build_tables(bsc_context *ctx) {
     l += log((double)i);
     t->lfact[i] = l;
   }
+  memcpy(t->log_tab, bsm_log_tab, sizeof t->log_tab);
+  memcpy(t->exp_tab, bsm_exp_tab, sizeof t->exp_tab);
   t->under_conv = ctx->params.under_conv;
   t->over_conv = ctx->params.over_conv;
   t->lrb = log(ctx->params.ref_bias);

@@ -8,6 +8,8 @@
 typedef struct {
   double k[44], ln_k[44], ln_k_half[44], ln_k_one[44];
   double lfact[256];
+  double log_tab[256];             /* bsm_log_tab: {invc, logc} x 128 (bsmath_tables.h) */
+  unsigned long long exp_tab[256]; /* bsm_exp_tab: {tail, scale} x 128 */
   double under_conv, over_conv;
   double lrb, lrb1; /* log(ref_bias), log(0.5 * (1 + ref_bias)) */
 } bsc_dev_tables;

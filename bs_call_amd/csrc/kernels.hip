@@ -74,8 +74,8 @@ __device__ static __forceinline__ void get_Z(double x1, double x2, double k1, do
 }
 
 /* n * ln(arg) for a Z-dependent term; +0.0 when the class is empty (arg may then be garbage / negative). */
-__device__ static __forceinline__ double zterm(bool has, double arg, double n) {
-  double v = bsm_log(has ? arg : 1.0) * n;
+__device__ static __forceinline__ double zterm(bool has, double arg, double n, const double *logtab) {
+  double v = bsm_log_t(has ? arg : 2.0, logtab) * n;
   return has ? v : 0.0;
 }
 
@@ -90,6 +90,8 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
    * Static, 16-byte aligned (no dynamic LDS behind static arrays: programming guide, guideline 17). */
   __shared__ __attribute__((aligned(16))) uint32_t lds_tile[TILE * MAX_OUT_DW];
   __shared__ double s_k[44], s_lnk[44], s_half[44], s_one[44];
+  __shared__ double s_logtab[256];
+  __shared__ unsigned long long s_exptab[256];
   __shared__ unsigned int s_cnt[12]; /* covered, hist[10], het */
 
   const unsigned tid = threadIdx.x;
@@ -99,6 +101,8 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
     s_half[tid] = tb->ln_k_half[tid];
     s_one[tid] = tb->ln_k_one[tid];
   }
+  s_logtab[tid] = tb->log_tab[tid];
+  s_exptab[tid] = tb->exp_tab[tid];
   if (tid < 12) s_cnt[tid] = 0;
   const double l = 1.0 - tb->under_conv;
   const double t = tb->over_conv;
@@ -223,9 +227,9 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
       v[T_LNK] = has ? nd[4] * s_lnk[qi[4]] : 0.0;
       v[T_ONE] = has ? nd[4] * s_one[qi[4]] : 0.0;
       v[T_HALF] = has ? nd[4] * s_half[qi[4]] : 0.0;
-      v[T_ZA] = zterm(has, 1.0 - 0.5 * Z4 + k4, nd[4]);   /* AG */
-      v[T_ZB] = zterm(has, 1.0 - Z3 + k4, nd[4]);         /* GG */
-      v[T_ZC] = zterm(has, 0.5 * (1.0 - Z5) + k4, nd[4]); /* CG, GT */
+      v[T_ZA] = zterm(has, 1.0 - 0.5 * Z4 + k4, nd[4], s_logtab);   /* AG */
+      v[T_ZB] = zterm(has, 1.0 - Z3 + k4, nd[4], s_logtab);         /* GG */
+      v[T_ZC] = zterm(has, 0.5 * (1.0 - Z5) + k4, nd[4], s_logtab); /* CG, GT */
 #pragma unroll
       for (int g = 0; g < 10; g++) ll[g] += v[TERM[4][g]];
     }
@@ -235,9 +239,9 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
       v[T_LNK] = has ? nd[5] * s_lnk[qi[5]] : 0.0;
       v[T_ONE] = 0.0;
       v[T_HALF] = 0.0;
-      v[T_ZA] = zterm(has, Z0 + k5, nd[5]);       /* CC */
-      v[T_ZB] = zterm(has, 0.5 * Z1 + k5, nd[5]); /* CT */
-      v[T_ZC] = zterm(has, 0.5 * Z2 + k5, nd[5]); /* AC, CG */
+      v[T_ZA] = zterm(has, Z0 + k5, nd[5], s_logtab);       /* CC */
+      v[T_ZB] = zterm(has, 0.5 * Z1 + k5, nd[5], s_logtab); /* CT */
+      v[T_ZC] = zterm(has, 0.5 * Z2 + k5, nd[5], s_logtab); /* AC, CG */
 #pragma unroll
       for (int g = 0; g < 10; g++) ll[g] += v[TERM[5][g]];
     }
@@ -247,9 +251,9 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
       v[T_LNK] = has ? nd[6] * s_lnk[qi[6]] : 0.0;
       v[T_ONE] = 0.0;
       v[T_HALF] = 0.0;
-      v[T_ZA] = zterm(has, Z3 + k6, nd[6]);       /* GG */
-      v[T_ZB] = zterm(has, 0.5 * Z4 + k6, nd[6]); /* AG */
-      v[T_ZC] = zterm(has, 0.5 * Z5 + k6, nd[6]); /* CG, GT */
+      v[T_ZA] = zterm(has, Z3 + k6, nd[6], s_logtab);       /* GG */
+      v[T_ZB] = zterm(has, 0.5 * Z4 + k6, nd[6], s_logtab); /* AG */
+      v[T_ZC] = zterm(has, 0.5 * Z5 + k6, nd[6], s_logtab); /* CG, GT */
 #pragma unroll
       for (int g = 0; g < 10; g++) ll[g] += v[TERM[6][g]];
     }
@@ -259,9 +263,9 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
       v[T_LNK] = has ? nd[7] * s_lnk[qi[7]] : 0.0;
       v[T_ONE] = has ? nd[7] * s_one[qi[7]] : 0.0;
       v[T_HALF] = has ? nd[7] * s_half[qi[7]] : 0.0;
-      v[T_ZA] = zterm(has, 1.0 - Z0 + k7, nd[7]);         /* CC */
-      v[T_ZB] = zterm(has, 1.0 - 0.5 * Z1 + k7, nd[7]);   /* CT */
-      v[T_ZC] = zterm(has, 0.5 * (1.0 - Z2) + k7, nd[7]); /* AC, CG */
+      v[T_ZA] = zterm(has, 1.0 - Z0 + k7, nd[7], s_logtab);         /* CC */
+      v[T_ZB] = zterm(has, 1.0 - 0.5 * Z1 + k7, nd[7], s_logtab);   /* CT */
+      v[T_ZC] = zterm(has, 0.5 * (1.0 - Z2) + k7, nd[7], s_logtab); /* AC, CG */
 #pragma unroll
       for (int g = 0; g < 10; g++) ll[g] += v[TERM[7][g]];
     }
@@ -277,8 +281,8 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
     /* normalise (:240-245) */
     double sum = 0.0;
 #pragma unroll
-    for (int g = 0; g < 10; g++) sum += bsm_exp(ll[g] - mx);
-    const double lsum = bsm_log(sum);
+    for (int g = 0; g < 10; g++) sum += bsm_exp_t(ll[g] - mx, (const uint64_t *)s_exptab);
+    const double lsum = bsm_log_t(sum, s_logtab);
     double gp[10];
 #pragma unroll
     for (int g = 0; g < 10; g++) gp[g] = div_ln10(ll[g] - mx - lsum);
@@ -351,18 +355,20 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
 }
 
 /* lfact2 (include/bs_call.h:335) */
-__device__ static __forceinline__ double lfact_dev(int x, const double *__restrict__ lf) {
-  return x < 256 ? lf[x] : bsm_lfact_big(x);
+__device__ static __forceinline__ double lfact_dev(int x, const double *lf, const double *logtab) {
+  return x < 256 ? lf[x] : bsm_lfact_big_t(x, logtab);
 }
 
 /* fisher() (src/stats_utils.c:25-91) */
-__device__ static double fisher_dev(int c0, int c1, int c2, int c3, const double *__restrict__ lf) {
+__device__ static double fisher_dev(int c0, int c1, int c2, int c3, const double *lf, const double *logtab,
+                                    const uint64_t *exptab) {
+#define LF(x) lfact_dev((x), lf, logtab)
   const int row0 = c0 + c1, row1 = c2 + c3, col0 = c0 + c2, col1 = c1 + c3;
   const int n = row0 + row1;
   if (n == 0) return 1.0;
   const double delta = (double)c0 - (double)(row0 * col0) / (double)n;
-  const double knst = lfact_dev(col0, lf) + lfact_dev(col1, lf) + lfact_dev(row0, lf) + lfact_dev(row1, lf) - lfact_dev(n, lf);
-  double l = bsm_exp(knst - lfact_dev(c0, lf) - lfact_dev(c1, lf) - lfact_dev(c2, lf) - lfact_dev(c3, lf));
+  const double knst = LF(col0) + LF(col1) + LF(row0) + LF(row1) - LF(n);
+  double l = bsm_exp_t(knst - LF(c0) - LF(c1) - LF(c2) - LF(c3), exptab);
   double p = l;
   if (delta > 0.0) {
     int mn = c1 < c2 ? c1 : c2;
@@ -374,7 +380,7 @@ __device__ static double fisher_dev(int c0, int c1, int c2, int c3, const double
     const int k = (int)ceil(2.0 * delta);
     if (k <= mn) {
       c0 -= k; c3 -= k; c1 += k; c2 += k;
-      l = bsm_exp(knst - lfact_dev(c0, lf) - lfact_dev(c1, lf) - lfact_dev(c2, lf) - lfact_dev(c3, lf));
+      l = bsm_exp_t(knst - LF(c0) - LF(c1) - LF(c2) - LF(c3), exptab);
       p += l;
       for (int i = 0; i < mn - k; i++) {
         l *= (double)((c0 - i) * (c3 - i)) / (double)((c1 + i + 1) * (c2 + i + 1));
@@ -392,7 +398,7 @@ __device__ static double fisher_dev(int c0, int c1, int c2, int c3, const double
     if (!k) k = 1;
     if (k <= mn) {
       c0 += k; c3 += k; c1 -= k; c2 -= k;
-      l = bsm_exp(knst - lfact_dev(c0, lf) - lfact_dev(c1, lf) - lfact_dev(c2, lf) - lfact_dev(c3, lf));
+      l = bsm_exp_t(knst - LF(c0) - LF(c1) - LF(c2) - LF(c3), exptab);
       p += l;
       for (int i = 0; i < mn - k; i++) {
         l *= (double)((c1 - i) * (c2 - i)) / (double)((c0 + i + 1) * (c3 + i + 1));
@@ -401,6 +407,7 @@ __device__ static double fisher_dev(int c0, int c1, int c2, int c3, const double
     }
   }
   return p;
+#undef LF
 }
 
 /* One thread per heterozygous site of the compact list. */
@@ -410,7 +417,11 @@ extern "C" __global__ __launch_bounds__(256) void bsc_fisher_kernel(const uint32
                                                                     const uint32_t *__restrict__ het_list,
                                                                     const unsigned long long *__restrict__ counters) {
   __shared__ double s_lf[256];
+  __shared__ double s_logtab[256];
+  __shared__ unsigned long long s_exptab[256];
   s_lf[threadIdx.x] = tb->lfact[threadIdx.x];
+  s_logtab[threadIdx.x] = tb->log_tab[threadIdx.x];
+  s_exptab[threadIdx.x] = tb->exp_tab[threadIdx.x];
   __syncthreads();
   const unsigned nhet = (unsigned)counters[BSC_CNT_HET_LIST];
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nhet; i += gridDim.x * blockDim.x) {
@@ -447,9 +458,9 @@ extern "C" __global__ __launch_bounds__(256) void bsc_fisher_kernel(const uint32
       default:
         break;
     }
-    double z = fisher_dev(t0, t1, t2, t3, s_lf);
+    double z = fisher_dev(t0, t1, t2, t3, s_lf, s_logtab, (const uint64_t *)s_exptab);
     if (z < 1.0e-20) z = 1.0e-20;
-    const double fs = bsm_log(z) / BSM_LN10;
+    const double fs = bsm_log_t(z, s_logtab) / BSM_LN10;
     const uint64_t b = bsm_bits(fs);
     reinterpret_cast<uint2 *>(rec)[22] = make_uint2((uint32_t)b, (uint32_t)(b >> 32));
   }

@@ -1,10 +1,12 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
 
 Bars (north star): integer / index fields bit-exact; floating fields within 1e-4 of the reference.
-What is actually asserted is much tighter:
-  * vs the oracle's "bsm" flavour (same fixed-order log/exp as the kernels): EVERY byte identical;
-  * vs the oracle's "libm" flavour (the restatement of the reference, pinned by the SURVEY 8c vectors):
-    integers identical, log10 posteriors within 1e-11 absolute.
+What is actually asserted is much tighter: EVERY byte of every gt_meth record equals the oracle's
+"libm" flavour — the restatement of the reference that calls the host's libm log/exp/lgamma and is pinned
+by the SURVEY 8c vectors — because the kernels reproduce glibc's log/exp/lgamma bit for bit
+(bs_call_amd/csrc/bsmath.h).  On a host whose libm is not glibc's FMA variant (conftest `libm_exact`
+is False) the libm comparison degrades to integers-exact + 1e-11 and the byte comparison is made against
+the oracle's "bsm" flavour (the same replica compiled for the CPU).
 """
 import json
 import os
@@ -38,38 +40,52 @@ def _assert_exact(got, skip, exp, exp_skip):
 
 
 def _assert_close(got, exp):
-    for f in ("counts", "qual", "mq", "aq", "max_gt"):
+    for f in ("counts", "qual", "mq", "aq"):
         assert (got[f] == exp[f]).all(), f
+    same = got["max_gt"] == exp["max_gt"]
+    # a different libm may break exact likelihood ties differently; anything else must agree
+    tie = np.abs(np.take_along_axis(exp["gt_prob"], got["max_gt"][:, None].astype(np.int64), 1)[:, 0]
+                 - np.take_along_axis(exp["gt_prob"], exp["max_gt"][:, None].astype(np.int64), 1)[:, 0]) < 1e-12
+    assert (same | tie).all()
     np.testing.assert_allclose(got["gt_prob"], exp["gt_prob"], rtol=0, atol=1e-11)
-    np.testing.assert_allclose(got["fisher_strand"], exp["fisher_strand"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(got["fisher_strand"][same], exp["fisher_strand"][same], rtol=1e-11, atol=1e-11)
     assert 1e-11 < FLOAT_TOL
 
 
-@pytest.mark.parametrize("cov,n,flags", [(10, 100_000, 0), (30, 300_000, 0), (30, 100_000, 1), (200, 60_000, 0), (1, 50_000, 0)])
-def test_synth_parity(caller, oracle, tables, cov, n, flags):
+def _check(oracle, tables, libm_exact, pile, ref, got, skip, threads=-8):
+    """GPU output vs the oracle: bytes vs the bsm flavour always; bytes vs the libm flavour (= the reference's
+    arithmetic) where the host libm is glibc's FMA variant, else integers exact + 1e-11."""
+    exp, eskip = oracle.call_sites(pile, ref, tables, oracle.BSM, threads)
+    _assert_exact(got, skip, exp, eskip)
+    ref_out, rskip = oracle.call_sites(pile, ref, tables, oracle.LIBM, threads)
+    if libm_exact:
+        _assert_exact(got, skip, ref_out, rskip)
+    else:
+        assert (rskip == skip).all()
+        _assert_close(got, ref_out)
+    return ref_out
+
+
+@pytest.mark.parametrize("cov,n,flags", [(10, 100_000, 0), (30, 300_000, 0), (30, 100_000, 1), (200, 60_000, 0), (300, 40_000, 0), (1, 50_000, 0)])
+def test_synth_parity(caller, oracle, tables, libm_exact, cov, n, flags):
     pile, ref = B.synth_pileup_host(SEED + cov, 12345, n, cov, flags)
     got, skip = caller.call_sites(pile, ref)
-    exp, eskip = oracle.call_sites(pile, ref, tables, oracle.BSM, -8)
-    _assert_exact(got, skip, exp, eskip)
-    ref_out, rskip = oracle.call_sites(pile, ref, tables, oracle.LIBM, -8)
-    assert (rskip == skip).all()
-    _assert_close(got, ref_out)
-    if cov == 200:  # the lgamma branch of lfact2 must have been exercised by some het site
+    _check(oracle, tables, libm_exact, pile, ref, got, skip)
+    if cov == 300:  # the lgamma branch of lfact2 must have been exercised by some het site
         het = B.GT_HET[got["max_gt"]] & (skip == 0)
         assert (pile["n"][het] >= 256).any()
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 256, 257, 511, 513, 1023])
-def test_ragged_sizes(caller, oracle, tables, n):
+def test_ragged_sizes(caller, oracle, tables, libm_exact, n):
     pile, ref = B.synth_pileup_host(SEED, 777, n, 30)
     got, skip = caller.call_sites(pile, ref)
     assert len(got) == n and len(skip) == n
     if n:
-        exp, eskip = oracle.call_sites(pile, ref, tables, oracle.BSM, 1)
-        _assert_exact(got, skip, exp, eskip)
+        _check(oracle, tables, libm_exact, pile, ref, got, skip, 1)
 
 
-def test_all_uncovered_and_ref_N(caller, oracle, tables):
+def test_all_uncovered_and_ref_N(caller, oracle, tables, libm_exact):
     pile = np.zeros(1000, dtype=B.PILEUP)
     ref = np.zeros(1000, dtype=np.uint8)
     got, skip = caller.call_sites(pile, ref)
@@ -78,12 +94,11 @@ def test_all_uncovered_and_ref_N(caller, oracle, tables):
     pile, _ = B.synth_pileup_host(SEED, 0, 5000, 30)
     ref = np.zeros(5000, dtype=np.uint8)
     got, skip = caller.call_sites(pile, ref)
-    exp, eskip = oracle.call_sites(pile, ref, tables, oracle.BSM, 1)
-    _assert_exact(got, skip, exp, eskip)
+    _check(oracle, tables, libm_exact, pile, ref, got, skip, 1)
 
 
-def test_known_answer_vectors(caller, oracle, tables):
-    """The reference's own outputs: max_gt exact, log10 posterior within 1e-12."""
+def test_known_answer_vectors(caller, oracle, tables, libm_exact):
+    """The reference's own outputs: max_gt exact, log10 posteriors bit-exact (1e-12 on a foreign libm)."""
     kav = json.load(open(os.path.join(HERE, "golden", "kav_survey8c.json")))
     cases = kav["calc_gt_prob"]
     pile = np.zeros(len(cases), dtype=B.PILEUP)
@@ -101,12 +116,12 @@ def test_known_answer_vectors(caller, oracle, tables):
     for i, c in enumerate(cases):
         assert int(got["max_gt"][i]) == c["max_gt"], c["name"]
         assert list(got["qual"][i]) == c["qual"] and got["mq"][i] == 60
-        assert abs(got["gt_prob"][i][c["max_gt"]] - float.fromhex(c["gt_prob_max_hex"])) <= 1e-12
+        assert got["gt_prob"][i][c["max_gt"]] == float.fromhex(c["gt_prob_max_hex"])  # bit-exact vs the reference
         for name, val in c["gt_prob"].items():
-            assert abs(got["gt_prob"][i][B.GENOTYPES.index(name)] - val) <= 1e-12 * max(1.0, abs(val))
+            assert got["gt_prob"][i][B.GENOTYPES.index(name)] == val
 
 
-def test_fisher_known_answers(caller, oracle, tables):
+def test_fisher_known_answers(caller, oracle, tables, libm_exact):
     """Strand tables that reproduce the SURVEY 8c fisher vectors through an AC call."""
     kav = json.load(open(os.path.join(HERE, "golden", "kav_survey8c.json")))
     for c in kav["fisher"]:
@@ -123,15 +138,18 @@ def test_fisher_known_answers(caller, oracle, tables):
         pile["mapq2"][0] = 3600.0 * sum(t)
         ref = np.array([1], dtype=np.uint8)
         got, skip = caller.call_sites(pile, ref)
-        exp, _ = oracle.call_sites(pile, ref, tables, oracle.BSM, 1)
-        assert got.tobytes() == exp.tobytes()
+        _check(oracle, tables, libm_exact, pile, ref, got, skip, 1)
         if got["max_gt"][0] == 1:
             p = float.fromhex(c["p_hex"])
-            assert abs(got["fisher_strand"][0] - np.log10(max(p, 1e-20))) < 1e-11
+            import math
+
+            assert got["fisher_strand"][0] == math.log(max(p, 1e-20)) / 2.30258509299404568402
 
 
-def test_adversarial_random_pileups(caller, oracle, tables):
-    """Uniformly random class counts / qualities (not WGBS-like): every class combination, ties, deep sites."""
+def test_adversarial_random_pileups(caller, oracle, tables, libm_exact):
+    """Uniformly random class counts / qualities (not WGBS-like): every class combination, deep sites and exact
+    likelihood ties (e.g. only classes 5 and 7 present: CC-partially-methylated vs CT), which are decided by
+    the last bit of log() — the reason the kernels reproduce libm exactly."""
     rng = np.random.default_rng(7)
     n = 200_000
     pile = np.zeros(n, dtype=B.PILEUP)
@@ -148,28 +166,23 @@ def test_adversarial_random_pileups(caller, oracle, tables):
     pile["mapq2"] = (pile["n"] * rng.choice([0, 1, 400, 3600, 65025], size=n)).astype(np.float32)
     ref = rng.integers(0, 5, size=n).astype(np.uint8)
     got, skip = caller.call_sites(pile, ref)
-    exp, eskip = oracle.call_sites(pile, ref, tables, oracle.BSM, -8)
-    _assert_exact(got, skip, exp, eskip)
-    ref_out, _ = oracle.call_sites(pile, ref, tables, oracle.LIBM, -8)
-    for f in ("counts", "qual", "mq", "aq"):
-        assert (got[f] == ref_out[f]).all(), f
-    flips = int((got["max_gt"] != ref_out["max_gt"]).sum())
-    assert flips == 0, "max_gt flips vs libm flavour: %d" % flips
-    np.testing.assert_allclose(got["gt_prob"], ref_out["gt_prob"], rtol=0, atol=1e-9)
+    ref_out = _check(oracle, tables, libm_exact, pile, ref, got, skip)
+    gp = np.sort(ref_out["gt_prob"], axis=1)
+    assert ((gp[:, -1] - gp[:, -2] < 1e-12) & (skip == 0)).sum() > 5  # the input does contain near-exact ties
 
 
-def test_gt_vcf_stride(caller, oracle, tables):
+def test_gt_vcf_stride(caller, oracle, tables, libm_exact):
     """out_stride = 208 writes straight into a gt_vcf[] image: gtm at 0, ready(=0) at 200, skip at 201."""
     pile, ref = B.synth_pileup_host(SEED, 0, 10_001, 30)
     raw, skip = caller.call_sites(pile, ref, out_stride=208)
-    exp, eskip = oracle.call_sites(pile, ref, tables, oracle.BSM, 1)
+    exp, eskip = oracle.call_sites(pile, ref, tables, oracle.LIBM if libm_exact else oracle.BSM, 1)
     assert raw.shape == (10_001, 208)
     assert raw[:, :200].tobytes() == exp.tobytes()
     assert (raw[:, 200] == 0).all() and (raw[:, 201] == eskip).all() and (raw[:, 202:] == 0).all()
     assert (skip == eskip).all()
 
 
-def test_other_parameters(oracle):
+def test_other_parameters(oracle, libm_exact):
     pile, ref = B.synth_pileup_host(SEED, 5000, 50_000, 30)
     for params in [(0.02, 0.01, 1.0, 20), (0.0, 0.0, 5.0, 10), (0.2, 0.3, 0.5, 43)]:
         tb = oracle.Tables(*params)
@@ -177,8 +190,7 @@ def test_other_parameters(oracle):
             q, lf = c.tables()
             assert q.tobytes() == tb.q_prob.tobytes() and lf.tobytes() == tb.lfact_store.tobytes()
             got, skip = c.call_sites(pile, ref)
-        exp, eskip = oracle.call_sites(pile, ref, tb, oracle.BSM, -8)
-        _assert_exact(got, skip, exp, eskip)
+        _check(oracle, tb, libm_exact, pile, ref, got, skip)
 
 
 def test_stats_counters(oracle, tables):
@@ -197,7 +209,7 @@ def test_stats_counters(oracle, tables):
         assert c.stats()["sites"] == 0 and c.stats()["covered"] == 0
 
 
-def test_device_resident_api_and_generator(caller, oracle, tables):
+def test_device_resident_api_and_generator(caller, oracle, tables, libm_exact):
     """bsc_call_sites_device on torch-owned HBM buffers + the device generator equals its host twin."""
     import torch
 
@@ -217,8 +229,7 @@ def test_device_resident_api_and_generator(caller, oracle, tables):
     assert pile.tobytes() == hp.tobytes() and (ref == hr).all()
     got = d_out.cpu().numpy().view(B.GT_METH)
     skip = d_skip.cpu().numpy()
-    exp, eskip = oracle.call_sites(hp, hr, tables, oracle.BSM, -8)
-    _assert_exact(got, skip, exp, eskip)
+    _check(oracle, tables, libm_exact, hp, hr, got, skip)
     # idempotence: a second pass over the same resident input gives the same bytes
     d_out2 = torch.zeros_like(d_out)
     caller.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out2.data_ptr(), d_skip.data_ptr(), 200, st)
