@@ -48,6 +48,31 @@ class Stats(C.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7; if this library
+    pulled in /opt/rocm's copy first, a later `import torch` would mix the two runtimes and find no GPU.
+    When torch is installed (it owns device memory and streams in bench.py and the tests), load its copy
+    first so that libbscall_amd.so's NEEDED libamdhip64.so.7 resolves to it.  Without torch the system
+    runtime is used."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # torch already loaded its runtime; the dynamic linker will reuse it by SONAME
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the shared library; raise (never fall back) when it has not been built."""
     global _lib
@@ -58,6 +83,7 @@ def load():
             "bs_call_amd: %s is missing. Build it with `make` at the repository root "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH
         )
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     L.bsc_abi_version.restype = i32
