@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libbscall_amd.so")
+# BSCALL_AMD_LIB: developer override used to A/B kernel build variants (tools/ab_variants.sh)
+LIB_PATH = os.environ.get("BSCALL_AMD_LIB") or os.path.join(HERE, "lib", "libbscall_amd.so")
 
 # every symbol include/bscall_amd.h declares
 EXPORTS = (

@@ -12,11 +12,8 @@
  * Design (DESIGN.md has the numbers): the kernel is a streaming scan, 104 B + 1 B in and 200 B out per
  * site with no reuse, so HBM bandwidth bounds it (FP64 VALU is the second bound, within 2x).
  * The reference's records are arrays of structs; a wave reading its 64 structs directly would touch
- * each 128-B line from 2 lanes in 7 separate instructions.  Instead each 256-thread workgroup moves a tile
- * of 256 sites with fully coalesced 16-B-per-lane loads into LDS, every lane then picks its own record
- * out of LDS (13 x ds_read_b64 at a 26-dword stride: conflict-free), computes in registers, writes its
- * 200-B result back to LDS (25 x ds_write_b64 at a 50-dword stride: conflict-free) and the tile leaves
- * with coalesced 16-B-per-lane stores.
+ * each 128-B line from 2 lanes in 7 separate instructions.  Instead each wave moves its 64 records with
+ * fully coalesced 16-B-per-lane transfers through a private LDS slot (see bsc_call_kernel).
  *
  * Numerics: FP64 throughout, no contraction (-ffp-contract=off), the transcendental functions are
  * bsmath.h (fixed operation order, shared with the host), tables come verbatim from the host.  The order
@@ -32,28 +29,122 @@
 #include "synth.h"
 
 #define TILE 256
+#ifndef BSC_WAVES_PER_SIMD
+#define BSC_WAVES_PER_SIMD 4 /* occupancy target of bsc_call_kernel: bounds its VGPR budget (512 / waves) */
+#endif
 #define IN_DW 26  /* dwords per pileup  (104 B) */
 #define OUT_DW 50 /* dwords per gt_meth (200 B) */
 #define MAX_OUT_DW 52 /* gt_vcf stride (208 B) */
-
-/* term kinds of the likelihood matrix */
-enum { T_LNK = 0, T_ONE = 1, T_HALF = 2, T_ZA = 3, T_ZB = 4, T_ZC = 5 };
-
-/* TERM[c][g]: which of class c's values goes into genotype g; g order AA AC AG AT CC CG CT GG GT TT */
-__device__ static constexpr unsigned char TERM[8][10] = {
-    /*            AA      AC      AG      AT      CC      CG      CT      GG      GT      TT   */
-    /* 0 A   */ {T_ONE, T_HALF, T_HALF, T_HALF, T_LNK, T_LNK, T_LNK, T_LNK, T_LNK, T_LNK},
-    /* 1 C   */ {T_LNK, T_HALF, T_LNK, T_LNK, T_ONE, T_HALF, T_HALF, T_LNK, T_LNK, T_LNK},
-    /* 2 G   */ {T_LNK, T_LNK, T_HALF, T_LNK, T_LNK, T_HALF, T_LNK, T_ONE, T_HALF, T_LNK},
-    /* 3 T   */ {T_LNK, T_LNK, T_LNK, T_HALF, T_LNK, T_LNK, T_HALF, T_LNK, T_HALF, T_ONE},
-    /* 4 A*  */ {T_ONE, T_HALF, T_ZA, T_HALF, T_LNK, T_ZC, T_LNK, T_ZB, T_ZC, T_LNK},
-    /* 5 C*  */ {T_LNK, T_ZC, T_LNK, T_LNK, T_ZA, T_ZC, T_ZB, T_LNK, T_LNK, T_LNK},
-    /* 6 G*  */ {T_LNK, T_LNK, T_ZB, T_LNK, T_LNK, T_ZC, T_LNK, T_ZA, T_ZC, T_LNK},
-    /* 7 T*  */ {T_LNK, T_ZC, T_LNK, T_HALF, T_ZA, T_ZC, T_ZB, T_LNK, T_HALF, T_ONE},
-};
+#define SLOT_DW (64 * IN_DW) /* per-wave LDS slot: 64 pile-ups = 6 656 B >= 32 results (6 400 / 6 656 B) */
 
 /* x / ln(10) as a true IEEE division (the reference divides by the LOG10 macro, genotype_model.c:244). */
 __device__ static __forceinline__ double div_ln10(double x) { return x / BSM_LN10; }
+
+
+/* ---- branch-free device forms of bsmath.h -------------------------------------------------------------
+ * Same operations in the same order as bsm_log_t / bsm_exp_t, hence the same bits, but without per-lane
+ * branches: both polynomial paths of log() are evaluated and one is selected, the rare special cases are
+ * left to a wave-uniform fallback onto the full functions.  64-bit integer steps are done on the high
+ * word where the constants' low words are zero. */
+
+/* log(x) for positive, normal, finite x */
+__device__ static __forceinline__ double log_pn(double x, const double *tab) {
+  const uint64_t ix = bsm_bits(x);
+  const uint32_t hx = (uint32_t)(ix >> 32);
+  /* main path: x = 2^k z, z in [0x1.6p-1, 0x1.6p0), table of 1/c and log(c) */
+  const uint32_t tmp = hx - 0x3fe60000u;
+  const uint32_t i = (tmp >> 13) & 127u;
+  const int k = (int)tmp >> 20;
+  const uint32_t hz = hx - (tmp & 0xfff00000u);
+  const double z = bsm_from_bits(((uint64_t)hz << 32) | (uint32_t)ix);
+  const double2 ic = *reinterpret_cast<const double2 *>(tab + 2 * i);
+  const double r = BSM_FMA(z, ic.x, -1.0);
+  const double kd = (double)k;
+  const double w = BSM_FMA(kd, BSM_LOG_LN2HI, ic.y);
+  const double hi = r + w;
+  double lo = BSM_FMA(kd, BSM_LOG_LN2LO, (w - hi) + r);
+  const double r2 = r * r;
+  const double r3 = r * r2;
+  const double q1 = BSM_FMA(r, BSM_LOG_A2, BSM_LOG_A1);
+  const double q3 = BSM_FMA(r, BSM_LOG_A4, BSM_LOG_A3);
+  lo = BSM_FMA(r2, BSM_LOG_A0, lo);
+  const double q = BSM_FMA(q3, r2, q1);
+  const double ym = BSM_FMA(q, r3, lo) + hi;
+  /* near-1 path: 1 - 2^-4 <= x < 1 + 0x1.09p-4 (x == 1 gives +0 through the same operations) */
+  const double s = x - 1.0;
+  const double s2 = s * s;
+  const double s3 = s * s2;
+  double t7 = BSM_FMA(s, BSM_LOG_B8, BSM_LOG_B7);
+  t7 = BSM_FMA(s2, BSM_LOG_B9, t7);
+  t7 = BSM_FMA(s3, BSM_LOG_B10, t7);
+  double t4 = BSM_FMA(s, BSM_LOG_B5, BSM_LOG_B4);
+  t4 = BSM_FMA(s2, BSM_LOG_B6, t4);
+  double t1 = BSM_FMA(s, BSM_LOG_B2, BSM_LOG_B1);
+  t1 = BSM_FMA(s2, BSM_LOG_B3, t1);
+  const double p = BSM_FMA(BSM_FMA(t7, s3, t4), s3, t1);
+  const double a = BSM_FMA(s, 0x1p27, s);
+  const double shi = BSM_FMA(-0x1p27, s, a);
+  const double slo = s - shi;
+  const double shi2 = shi * shi;
+  const double nhi = BSM_FMA(shi2, BSM_LOG_B0, s);
+  double nlo = BSM_FMA(shi2, BSM_LOG_B0, s - nhi);
+  nlo = BSM_FMA(s + shi, slo * BSM_LOG_B0, nlo);
+  const double yn = nhi + BSM_FMA(p, s3, nlo);
+  return (hx - 0x3fee0000u < 0x3ff10900u - 0x3fee0000u) ? yn : ym;
+}
+
+/* log(x) with the wave-uniform escape for x that is not positive-normal-finite */
+__device__ static __forceinline__ double log_dev(double x, const double *tab) {
+  const uint32_t hx = (uint32_t)(bsm_bits(x) >> 32);
+  const bool ok = hx - 0x00100000u < 0x7fe00000u;
+  double y = log_pn(x, tab);
+  if (__builtin_expect(__any(!ok), 0)) y = ok ? y : bsm_log_t(x, tab);
+  return y;
+}
+
+/* exp(x) where x == 0 or 2^-54 <= |x| < 512 (no over/underflow handling, no tiny-x shortcut) */
+__device__ static __forceinline__ double exp_mid(double x, const uint64_t *tab) {
+  const double kd0 = BSM_FMA(x, BSM_EXP_INVLN2N, BSM_EXP_SHIFT);
+  const uint32_t ki = (uint32_t)bsm_bits(kd0);
+  const double kd = kd0 - BSM_EXP_SHIFT;
+  const double r = BSM_FMA(kd, BSM_EXP_NEGLN2LON, BSM_FMA(kd, BSM_EXP_NEGLN2HIN, x));
+  const ulonglong2 ts = *reinterpret_cast<const ulonglong2 *>(tab + 2u * (ki & 127u));
+  const double tail = bsm_from_bits(ts.x);
+  const uint64_t sbits = ts.y + ((uint64_t)(ki << 13) << 32); /* + (ki << 45): only the high word changes */
+  const double r2 = r * r;
+  const double p23 = BSM_FMA(r, BSM_EXP_C3, BSM_EXP_C2);
+  const double p45 = BSM_FMA(r, BSM_EXP_C5, BSM_EXP_C4);
+  const double t = BSM_FMA(p23, r2, tail + r);
+  const double tmp = BSM_FMA(r2 * r2, p45, t);
+  const double scale = bsm_from_bits(sbits);
+  return BSM_FMA(scale, tmp, scale);
+}
+
+__device__ static __forceinline__ double exp_dev(double x, const uint64_t *tab) {
+  const uint32_t abstop = (uint32_t)(bsm_bits(x) >> 52) & 0x7ffu;
+  const bool ok = (abstop - 0x3c9u < 0x408u - 0x3c9u) || x == 0.0;
+  double y = exp_mid(x, tab);
+  if (__builtin_expect(__any(!ok), 0)) y = ok ? y : bsm_exp_t(x, tab);
+  return y;
+}
+
+/*
+ * x / ln(10), correctly rounded (the reference divides by its LOG10 macro, src/genotype_model.c:244).
+ * Markstein's theorem: with rc = RN(1/c), q0 = RN(x*rc), r = x - c*q0 (exact in an fma) the value
+ * RN(q0 + r*rc) is the correctly rounded quotient, barring underflow in r.  tools/check_div.c compares this
+ * against true division on 2e9 arguments: the only differences are x = -0 and |x| < 2^-1000, which take
+ * the true division below (neither occurs for (ll - max) - log(sum)).
+ */
+#define BSC_RLN10 0x1.bcb7b1526e50dp-2 /* RN(1 / 2.30258509299404568402) */
+__device__ static __forceinline__ double div_ln10_dev(double x) {
+  const uint32_t ax = (uint32_t)(bsm_bits(x) >> 32) & 0x7fffffffu;
+  const bool ok = (ax - 0x01700000u < 0x7ff00000u - 0x01700000u) || bsm_bits(x) == 0; /* 2^-1000 <= |x| < inf, or +0 */
+  const double q0 = x * BSC_RLN10;
+  const double r = BSM_FMA(-BSM_LN10, q0, x);
+  double q = BSM_FMA(r, BSC_RLN10, q0);
+  if (__builtin_expect(__any(!ok), 0)) q = ok ? q : x / BSM_LN10;
+  return q;
+}
 
 /* get_Z (src/genotype_model.c:23-42); the caller discards the result when x1 + x2 == 0. */
 __device__ static __forceinline__ void get_Z(double x1, double x2, double k1, double k2, double l, double t, double &Z0,
@@ -76,25 +167,47 @@ __device__ static __forceinline__ void get_Z(double x1, double x2, double k1, do
 /* n * ln(arg) for a Z-dependent term; +0.0 when the class is empty (arg may then be garbage / negative). */
 __device__ static __forceinline__ double zterm(bool has, double arg, double n, const double *logtab) {
   double v = bsm_log_t(has ? arg : 2.0, logtab) * n;
+#ifdef BSC_SCHED_FENCE
+  __builtin_amdgcn_sched_barrier(0); /* keep the independent log chains from being interleaved (VGPR pressure) */
+#endif
   return has ? v : 0.0;
 }
 
-extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_t *__restrict__ cts,
-                                                                   const uint8_t *__restrict__ ref, uint64_t n_sites,
-                                                                   uint32_t *__restrict__ out, uint32_t out_dw,
-                                                                   uint8_t *__restrict__ skip,
-                                                                   const bsc_dev_tables *__restrict__ tb,
-                                                                   uint32_t *__restrict__ het_list,
-                                                                   unsigned long long *__restrict__ counters) {
-  /* LDS: staging tile (input then output alias the same bytes) + the q_prob columns + block counters.
-   * Static, 16-byte aligned (no dynamic LDS behind static arrays: programming guide, guideline 17). */
-  __shared__ __attribute__((aligned(16))) uint32_t lds_tile[TILE * MAX_OUT_DW];
+/* LDS-DMA: 16 bytes per lane, global (per-lane address) -> LDS (wave-uniform base + lane * 16). */
+__device__ static __forceinline__ void dma16(const void *g, void *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+/*
+ * The calling kernel.  No workgroup barrier after the table set-up: every wave owns a 6 656-byte LDS slot
+ * and walks its own 64-site wave-tiles.
+ *   in : the wave-tile's 64 pile-ups are 6 656 contiguous bytes in HBM; 6.5 LDS-DMA instructions (1 KiB
+ *        each, no VGPRs) land them in the slot; lane i then reads record i (13 x ds_read_b64, stride 26
+ *        dwords: conflict-free).
+ *   out: results leave in two halves of 32 records (6 400 contiguous bytes, or 6 656 for gt_vcf stride):
+ *        the owning lanes write their record to the slot (25 x ds_write_b64, stride 50 dwords:
+ *        conflict-free), then all 64 lanes copy the slot out with 16-byte stores (6.25 KiB-wide
+ *        instructions).
+ * LDS of one wave is touched only by that wave and a wave's LDS operations execute in order, so the
+ * hand-over inside a wave needs no barrier — only the vmcnt wait that retires the DMA.
+ */
+extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_kernel(const uint32_t *__restrict__ cts,
+                                                                      const uint8_t *__restrict__ ref,
+                                                                      uint64_t n_sites, uint32_t *__restrict__ out,
+                                                                      uint32_t out_dw, uint8_t *__restrict__ skip,
+                                                                      const bsc_dev_tables *__restrict__ tb,
+                                                                      uint32_t *__restrict__ het_list,
+                                                                      unsigned long long *__restrict__ counters) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_slot[TILE / 64][SLOT_DW];
   __shared__ double s_k[44], s_lnk[44], s_half[44], s_one[44];
   __shared__ double s_logtab[256];
   __shared__ unsigned long long s_exptab[256];
   __shared__ unsigned int s_cnt[12]; /* covered, hist[10], het */
 
   const unsigned tid = threadIdx.x;
+  const unsigned lane = tid & 63u;
+  const unsigned wid = tid >> 6;
   if (tid < 44) {
     s_k[tid] = tb->k[tid];
     s_lnk[tid] = tb->ln_k[tid];
@@ -109,183 +222,184 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
   const double lrb = tb->lrb, lrb1 = tb->lrb1;
   __syncthreads();
 
-  const uint64_t n_tiles = (n_sites + TILE - 1) / TILE;
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint64_t site0 = tile * TILE;
-    const unsigned nvalid = (unsigned)((n_sites - site0) < TILE ? (n_sites - site0) : TILE);
-
-    /* ---- stage in: coalesced 16 B per lane ---- */
-    {
-      const uint4 *src = reinterpret_cast<const uint4 *>(cts + site0 * IN_DW);
-      uint4 *dst = reinterpret_cast<uint4 *>(lds_tile);
-      const unsigned nvec = nvalid * IN_DW / 4; /* 104 B = 6.5 x 16 B; nvalid*26 is even, so /4 may leave 2 dwords */
-      for (unsigned v = tid; v < nvec; v += TILE) dst[v] = src[v];
-      if ((nvalid * IN_DW) & 3u) { /* odd number of sites: last 8 bytes */
-        if (tid == 0) {
-          const unsigned o = nvec * 4;
-          lds_tile[o] = cts[site0 * IN_DW + o];
-          lds_tile[o + 1] = cts[site0 * IN_DW + o + 1];
-        }
-      }
-    }
-    const uint64_t site = site0 + tid;
-    const bool valid = tid < nvalid;
+  uint32_t *slot = lds_slot[wid];
+  const uint64_t n_wt = (n_sites + 63) / 64;
+  const uint64_t wave_stride = (uint64_t)gridDim.x * (TILE / 64);
+  for (uint64_t wt = (uint64_t)blockIdx.x * (TILE / 64) + wid; wt < n_wt; wt += wave_stride) {
+    const uint64_t site0 = wt * 64;
+    const unsigned nvalid = (unsigned)((n_sites - site0) < 64 ? (n_sites - site0) : 64);
+    const bool full = nvalid == 64; /* wave-uniform */
+    const uint64_t site = site0 + lane;
+    const bool valid = lane < nvalid;
     const unsigned rf = valid ? ref[site] : 0u;
-    __syncthreads();
 
-    /* ---- my record: 13 x ds_read_b64 ---- */
-    uint32_t c0[8], c1[8];
-    uint32_t n_reads = 0;
-    float qsum[8], mapq2 = 0.f;
-    {
-      const uint2 *rec = reinterpret_cast<const uint2 *>(lds_tile + tid * IN_DW);
-      uint32_t w[IN_DW];
+    /* ---- my record ---- */
+    uint32_t w[IN_DW];
+    if (full) {
+      const char *src = reinterpret_cast<const char *>(cts + site0 * IN_DW) + lane * 16;
+#pragma unroll
+      for (int j = 0; j < 6; j++) dma16(src + j * 1024, slot + j * 256);
+      if (lane < 32) dma16(src + 6 * 1024, slot + 6 * 256);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint2 *rec = reinterpret_cast<const uint2 *>(slot + lane * IN_DW);
 #pragma unroll
       for (int i = 0; i < IN_DW / 2; i++) {
-        uint2 v = valid ? rec[i] : make_uint2(0u, 0u);
+        const uint2 v = rec[i];
         w[2 * i] = v.x;
         w[2 * i + 1] = v.y;
       }
+    } else { /* last, partial wave-tile of the launch: plain guarded loads (no 16-byte over-read) */
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        c0[j] = w[j];
-        c1[j] = w[8 + j];
-        qsum[j] = __uint_as_float(w[17 + j]);
-      }
-      n_reads = w[16];
-      mapq2 = __uint_as_float(w[25]);
+      for (int i = 0; i < IN_DW; i++) w[i] = valid ? cts[site * IN_DW + i] : 0u;
     }
-    __syncthreads(); /* everyone has its input in registers: the tile may be overwritten with results */
-
+    const uint32_t n_reads = w[16];
+    const float mapq2 = __uint_as_float(w[25]);
     const bool covered = valid && n_reads != 0;
 
-    /* ---- per-site summary (src/call_genotypes.c:45-59) ---- */
-    int qual[8];
-    double nd[8];
+    /* ---- per-site summary (src/call_genotypes.c:45-59) ----
+     * Register diet: the eight class counts stay as u32 (converted to f64 where used), the eight rounded
+     * mean qualities are packed one per byte until the result record is written.  Precondition (holds for
+     * every pile-up the accumulate stage can produce: base qualities are <= 43, src/input_sam.c:76-86): each
+     * class's mean quality is in [0,43].  The reference indexes q_prob[] out of bounds otherwise; here the
+     * index is clamped (QI) so that garbage cannot read outside the table. */
     uint32_t cnt[8];
+    uint32_t qpack0 = 0, qpack1 = 0; /* qual[0..3], qual[4..7] one byte each (0..255) */
     float tot_qual = 0.0f;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      cnt[j] = c0[j] + c1[j];
-      float nn = (float)cnt[j];
-      int q = 0;
-      if (nn > 0) {
-        tot_qual += qsum[j];
-        /* f32 divide, promoted to f64 for the +0.5, rounded back to f32 by floorf's parameter */
-        q = (int)floorf((float)(0.5 + (double)(qsum[j] / nn)));
-      }
-      qual[j] = q;
-      nd[j] = (double)cnt[j];
+      cnt[j] = w[j] + w[8 + j];
+      const float qs = __uint_as_float(w[17 + j]);
+      const bool has = cnt[j] != 0;
+      const float nn = has ? (float)cnt[j] : 1.0f;
+      tot_qual += has ? qs : 0.0f;
+      /* f32 divide, promoted to f64 for the +0.5, rounded back to f32 by floorf's parameter */
+      const int q = has ? (int)floorf((float)(0.5 + (double)(qs / nn))) : 0;
+      const uint32_t qb = (uint32_t)q & 0xffu;
+      if (j < 4) qpack0 |= qb << (8 * j);
+      else qpack1 |= qb << (8 * (j - 4));
     }
     const float nf = covered ? (float)n_reads : 1.0f;
     const int aq = (int)floorf((float)(0.5 + (double)(tot_qual / nf)));
     const int mq = (int)(0.5 + sqrt((double)(mapq2 / nf)));
+/* table index of class j: its packed quality, clamped to the table (only garbage input exceeds 43) */
+#define QI(j) min(((j) < 4 ? (qpack0 >> (8 * (j))) : (qpack1 >> (8 * ((j)-4)))) & 0xffu, 43u)
+#define ND(j) ((double)cnt[j])
 
-    /* table index: qual is in [0,43] for real data (q <= 43 per base); clamp so garbage cannot read outside */
-    int qi[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) qi[j] = qual[j] < 0 ? 0 : (qual[j] > 43 ? 43 : qual[j]);
+    /* ---- calc_gt_prob ----
+     * The 12 methylation-dependent log() arguments of classes 4..7 are parked in this lane's own 104 bytes of
+     * the slot (13 doubles; its pile-up record is in registers by now) and evaluated by ONE rolled loop, the
+     * 10 exp() of the normalisation likewise: one code instance each instead of 23, a fraction of the
+     * registers, and the independent chains of the other waves on the SIMD hide the latency. */
+    double *la = reinterpret_cast<double *>(slot + lane * IN_DW);
+    const bool has4 = cnt[4] != 0, has5 = cnt[5] != 0, has6 = cnt[6] != 0, has7 = cnt[7] != 0;
+    {
+      /* methylation estimates (src/genotype_model.c:165-171); Z of an empty class pair is never used */
+      const double k4 = s_k[QI(4)], k5 = s_k[QI(5)], k6 = s_k[QI(6)], k7 = s_k[QI(7)];
+      double Z0, Z1, Z2, Z3, Z4, Z5;
+      get_Z(ND(5), ND(7), k5, k7, l, t, Z0, Z1, Z2);
+      get_Z(ND(6), ND(4), k6, k4, l, t, Z3, Z4, Z5);
+      /* class 4 (A on G2A reads, :173-187): AG, GG, CG/GT */
+      la[0] = has4 ? 1.0 - 0.5 * Z4 + k4 : 2.0;
+      la[1] = has4 ? 1.0 - Z3 + k4 : 2.0;
+      la[2] = has4 ? 0.5 * (1.0 - Z5) + k4 : 2.0;
+      /* class 5 (C on C2T reads, :188-201): CC, CT, AC/CG */
+      la[3] = has5 ? Z0 + k5 : 2.0;
+      la[4] = has5 ? 0.5 * Z1 + k5 : 2.0;
+      la[5] = has5 ? 0.5 * Z2 + k5 : 2.0;
+      /* class 6 (G on G2A reads, :202-215): GG, AG, CG/GT */
+      la[6] = has6 ? Z3 + k6 : 2.0;
+      la[7] = has6 ? 0.5 * Z4 + k6 : 2.0;
+      la[8] = has6 ? 0.5 * Z5 + k6 : 2.0;
+      /* class 7 (T on C2T reads, :216-230): CC, CT, AC/CG */
+      la[9] = has7 ? 1.0 - Z0 + k7 : 2.0;
+      la[10] = has7 ? 1.0 - 0.5 * Z1 + k7 : 2.0;
+      la[11] = has7 ? 0.5 * (1.0 - Z2) + k7 : 2.0;
+    }
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) la[i] = log_dev(la[i], s_logtab);
 
-    /* ---- calc_gt_prob ---- */
-    double ll[10];
-#pragma unroll
-    for (int g = 0; g < 10; g++) ll[g] = 0.0;
-    /* prior from the reference base (src/genotype_model.c:87-108) */
-    {
-      const bool rA = rf == 1, rC = rf == 2, rG = rf == 3, rT = rf == 4;
-      ll[0] = rA ? lrb : 0.0;
-      ll[4] = rC ? lrb : 0.0;
-      ll[7] = rG ? lrb : 0.0;
-      ll[9] = rT ? lrb : 0.0;
-      ll[1] = (rA || rC) ? lrb1 : 0.0; /* AC */
-      ll[2] = (rA || rG) ? lrb1 : 0.0; /* AG */
-      ll[3] = (rA || rT) ? lrb1 : 0.0; /* AT */
-      ll[5] = (rC || rG) ? lrb1 : 0.0; /* CG */
-      ll[6] = (rC || rT) ? lrb1 : 0.0; /* CT */
-      ll[8] = (rG || rT) ? lrb1 : 0.0; /* GT */
+    /* prior from the reference base (src/genotype_model.c:87-108); genotype order AA AC AG AT CC CG CT GG GT TT */
+    const bool rA = rf == 1, rC = rf == 2, rG = rf == 3, rT = rf == 4;
+    double ll0 = rA ? lrb : 0.0, ll4 = rC ? lrb : 0.0, ll7 = rG ? lrb : 0.0, ll9 = rT ? lrb : 0.0;
+    double ll1 = (rA || rC) ? lrb1 : 0.0, ll2 = (rA || rG) ? lrb1 : 0.0, ll3 = (rA || rT) ? lrb1 : 0.0;
+    double ll5 = (rC || rG) ? lrb1 : 0.0, ll6 = (rC || rT) ? lrb1 : 0.0, ll8 = (rG || rT) ? lrb1 : 0.0;
+    /*
+     * One term per class and genotype, classes in order 0..7 (the order of the reference's += statements;
+     * SURVEY.md appendix A gives the matrix).  An empty class has n = +0, so each of its terms is n*finite
+     * = +-0 and the addition leaves ll unchanged, exactly as the reference's skipped `if (n[c])` block does
+     * (ll is never -0: every contribution is n*ln(..) with n > 0, and the priors are >= +0).
+     */
+#define ACC10(a0, a1, a2, a3, a4, a5, a6, a7, a8, a9) \
+  ll0 += (a0); ll1 += (a1); ll2 += (a2); ll3 += (a3); ll4 += (a4); ll5 += (a5); ll6 += (a6); ll7 += (a7); ll8 += (a8); ll9 += (a9)
+    { /* class 0, A non-informative (:109-122): AA one; AC AG AT half */
+      const double n = ND(0);
+      const unsigned qi = QI(0);
+      const double one = n * s_one[qi], half = n * s_half[qi], lnk = n * s_lnk[qi];
+      ACC10(one, half, half, half, lnk, lnk, lnk, lnk, lnk, lnk);
     }
-    /* classes 0..3: table terms only */
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const bool has = cnt[c] != 0;
-      double v[3];
-      v[T_LNK] = has ? nd[c] * s_lnk[qi[c]] : 0.0;
-      v[T_ONE] = has ? nd[c] * s_one[qi[c]] : 0.0;
-      v[T_HALF] = has ? nd[c] * s_half[qi[c]] : 0.0;
-#pragma unroll
-      for (int g = 0; g < 10; g++) ll[g] += v[TERM[c][g]];
+    { /* class 1, C (:123-136): CC one; AC CG CT half */
+      const double n = ND(1);
+      const unsigned qi = QI(1);
+      const double one = n * s_one[qi], half = n * s_half[qi], lnk = n * s_lnk[qi];
+      ACC10(lnk, half, lnk, lnk, one, half, half, lnk, lnk, lnk);
     }
-    /* methylation estimates (src/genotype_model.c:165-171) */
-    const double k4 = s_k[qi[4]], k5 = s_k[qi[5]], k6 = s_k[qi[6]], k7 = s_k[qi[7]];
-    double Z0, Z1, Z2, Z3, Z4, Z5;
-    get_Z(nd[5], nd[7], k5, k7, l, t, Z0, Z1, Z2);
-    get_Z(nd[6], nd[4], k6, k4, l, t, Z3, Z4, Z5);
-    /* (Z is only read by classes that are non-empty, which implies its get_Z ran on a non-zero divisor) */
-    {
-      const bool has = cnt[4] != 0; /* class 4: A on G2A reads, :173-187 */
-      double v[6];
-      v[T_LNK] = has ? nd[4] * s_lnk[qi[4]] : 0.0;
-      v[T_ONE] = has ? nd[4] * s_one[qi[4]] : 0.0;
-      v[T_HALF] = has ? nd[4] * s_half[qi[4]] : 0.0;
-      v[T_ZA] = zterm(has, 1.0 - 0.5 * Z4 + k4, nd[4], s_logtab);   /* AG */
-      v[T_ZB] = zterm(has, 1.0 - Z3 + k4, nd[4], s_logtab);         /* GG */
-      v[T_ZC] = zterm(has, 0.5 * (1.0 - Z5) + k4, nd[4], s_logtab); /* CG, GT */
-#pragma unroll
-      for (int g = 0; g < 10; g++) ll[g] += v[TERM[4][g]];
+    { /* class 2, G (:137-150): GG one; AG CG GT half */
+      const double n = ND(2);
+      const unsigned qi = QI(2);
+      const double one = n * s_one[qi], half = n * s_half[qi], lnk = n * s_lnk[qi];
+      ACC10(lnk, lnk, half, lnk, lnk, half, lnk, one, half, lnk);
     }
-    {
-      const bool has = cnt[5] != 0; /* class 5: C on C2T reads, :188-201 */
-      double v[6];
-      v[T_LNK] = has ? nd[5] * s_lnk[qi[5]] : 0.0;
-      v[T_ONE] = 0.0;
-      v[T_HALF] = 0.0;
-      v[T_ZA] = zterm(has, Z0 + k5, nd[5], s_logtab);       /* CC */
-      v[T_ZB] = zterm(has, 0.5 * Z1 + k5, nd[5], s_logtab); /* CT */
-      v[T_ZC] = zterm(has, 0.5 * Z2 + k5, nd[5], s_logtab); /* AC, CG */
-#pragma unroll
-      for (int g = 0; g < 10; g++) ll[g] += v[TERM[5][g]];
+    { /* class 3, T (:151-164): TT one; AT CT GT half */
+      const double n = ND(3);
+      const unsigned qi = QI(3);
+      const double one = n * s_one[qi], half = n * s_half[qi], lnk = n * s_lnk[qi];
+      ACC10(lnk, lnk, lnk, half, lnk, lnk, half, lnk, half, one);
     }
-    {
-      const bool has = cnt[6] != 0; /* class 6: G on G2A reads, :202-215 */
-      double v[6];
-      v[T_LNK] = has ? nd[6] * s_lnk[qi[6]] : 0.0;
-      v[T_ONE] = 0.0;
-      v[T_HALF] = 0.0;
-      v[T_ZA] = zterm(has, Z3 + k6, nd[6], s_logtab);       /* GG */
-      v[T_ZB] = zterm(has, 0.5 * Z4 + k6, nd[6], s_logtab); /* AG */
-      v[T_ZC] = zterm(has, 0.5 * Z5 + k6, nd[6], s_logtab); /* CG, GT */
-#pragma unroll
-      for (int g = 0; g < 10; g++) ll[g] += v[TERM[6][g]];
+    { /* class 4, A on G2A reads (:173-187): AA one; AC AT half; AG za; GG zb; CG GT zc */
+      const double n = ND(4);
+      const unsigned qi = QI(4);
+      const double one = n * s_one[qi], half = n * s_half[qi], lnk = n * s_lnk[qi];
+      const double za = la[0] * n, zb = la[1] * n, zc = la[2] * n;
+      ACC10(one, half, za, half, lnk, zc, lnk, zb, zc, lnk);
     }
-    {
-      const bool has = cnt[7] != 0; /* class 7: T on C2T reads, :216-230 */
-      double v[6];
-      v[T_LNK] = has ? nd[7] * s_lnk[qi[7]] : 0.0;
-      v[T_ONE] = has ? nd[7] * s_one[qi[7]] : 0.0;
-      v[T_HALF] = has ? nd[7] * s_half[qi[7]] : 0.0;
-      v[T_ZA] = zterm(has, 1.0 - Z0 + k7, nd[7], s_logtab);         /* CC */
-      v[T_ZB] = zterm(has, 1.0 - 0.5 * Z1 + k7, nd[7], s_logtab);   /* CT */
-      v[T_ZC] = zterm(has, 0.5 * (1.0 - Z2) + k7, nd[7], s_logtab); /* AC, CG */
-#pragma unroll
-      for (int g = 0; g < 10; g++) ll[g] += v[TERM[7][g]];
+    { /* class 5, C on C2T reads (:188-201): CC za; CT zb; AC CG zc */
+      const double n = ND(5);
+      const double lnk = n * s_lnk[QI(5)];
+      const double za = la[3] * n, zb = la[4] * n, zc = la[5] * n;
+      ACC10(lnk, zc, lnk, lnk, za, zc, zb, lnk, lnk, lnk);
     }
+    { /* class 6, G on G2A reads (:202-215): GG za; AG zb; CG GT zc */
+      const double n = ND(6);
+      const double lnk = n * s_lnk[QI(6)];
+      const double za = la[6] * n, zb = la[7] * n, zc = la[8] * n;
+      ACC10(lnk, lnk, zb, lnk, lnk, zc, lnk, za, zc, lnk);
+    }
+    { /* class 7, T on C2T reads (:216-230): TT one; AT GT half; CC za; CT zb; AC CG zc */
+      const double n = ND(7);
+      const unsigned qi = QI(7);
+      const double one = n * s_one[qi], half = n * s_half[qi], lnk = n * s_lnk[qi];
+      const double za = la[9] * n, zb = la[10] * n, zc = la[11] * n;
+      ACC10(lnk, zc, lnk, half, za, zc, zb, lnk, half, one);
+    }
+#undef ACC10
     /* first-max argmax (:231-239) */
-    double mx = ll[0];
+    double mx = ll0;
     int mxi = 0;
-#pragma unroll
-    for (int g = 1; g < 10; g++) {
-      const bool gt = ll[g] > mx;
-      mx = gt ? ll[g] : mx;
-      mxi = gt ? g : mxi;
-    }
-    /* normalise (:240-245) */
+#define AMAX(g) { const bool gt_ = ll##g > mx; mx = gt_ ? ll##g : mx; mxi = gt_ ? g : mxi; }
+    AMAX(1) AMAX(2) AMAX(3) AMAX(4) AMAX(5) AMAX(6) AMAX(7) AMAX(8) AMAX(9)
+#undef AMAX
+    la[0] = ll0 - mx; la[1] = ll1 - mx; la[2] = ll2 - mx; la[3] = ll3 - mx; la[4] = ll4 - mx;
+    la[5] = ll5 - mx; la[6] = ll6 - mx; la[7] = ll7 - mx; la[8] = ll8 - mx; la[9] = ll9 - mx;
+    /* normalise (:240-245): sum of exp(ll - max) in index order, rolled */
     double sum = 0.0;
-#pragma unroll
-    for (int g = 0; g < 10; g++) sum += bsm_exp_t(ll[g] - mx, (const uint64_t *)s_exptab);
-    const double lsum = bsm_log_t(sum, s_logtab);
+#pragma unroll 1
+    for (int g = 0; g < 10; g++) sum += exp_dev(la[g], (const uint64_t *)s_exptab);
+    const double lsum = log_dev(sum, s_logtab);
+#pragma unroll 1
+    for (int g = 0; g < 10; g++) la[g] = div_ln10_dev(la[g] - lsum);
     double gp[10];
 #pragma unroll
-    for (int g = 0; g < 10; g++) gp[g] = div_ln10(ll[g] - mx - lsum);
+    for (int g = 0; g < 10; g++) gp[g] = la[g];
 
     /* ---- heterozygous calls go to the Fisher list; block counters ---- */
     const bool het = covered && ((0x16Eu >> mxi) & 1u); /* gt_het: AC AG AT CG CT GT = bits 1,2,3,5,6,8 */
@@ -296,7 +410,6 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
     {
       const unsigned long long m = __ballot(het);
       if (m) {
-        const unsigned lane = tid & 63u;
         unsigned base = 0;
         if (lane == 0) base = atomicAdd((unsigned int *)&counters[BSC_CNT_HET_LIST], (unsigned)__popcll(m));
         base = __shfl(base, 0);
@@ -304,49 +417,47 @@ extern "C" __global__ __launch_bounds__(TILE) void bsc_call_kernel(const uint32_
         if (lane == 0) atomicAdd(&s_cnt[11], (unsigned)__popcll(m));
       }
     }
+    if (valid) skip[site] = covered ? 0 : 1;
 
-    /* ---- my result record: 25 x ds_write_b64 ---- */
-    if (valid) {
-      uint2 *rec = reinterpret_cast<uint2 *>(lds_tile + tid * out_dw);
-      if (covered) {
+    /* ---- results: two halves of 32 records through the slot ---- */
+#pragma unroll 1
+    for (unsigned half = 0; half < 2; half++) {
+      const bool mine = valid && (lane >> 5) == half;
+      uint2 *rec = reinterpret_cast<uint2 *>(full ? slot + (lane & 31u) * out_dw : out + site * out_dw);
+      if (mine) {
+        if (covered) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) rec[j] = make_uint2(cnt[j], 0u); /* counts[j] as u64 */
+          for (int j = 0; j < 8; j++) rec[j] = make_uint2(cnt[j], 0u); /* counts[j] as u64 */
+          rec[8] = make_uint2(qpack0 & 0xffu, (qpack0 >> 8) & 0xffu); /* qual[0..7] as i32 */
+          rec[9] = make_uint2((qpack0 >> 16) & 0xffu, qpack0 >> 24);
+          rec[10] = make_uint2(qpack1 & 0xffu, (qpack1 >> 8) & 0xffu);
+          rec[11] = make_uint2((qpack1 >> 16) & 0xffu, qpack1 >> 24);
 #pragma unroll
-        for (int j = 0; j < 4; j++) rec[8 + j] = make_uint2((uint32_t)qual[2 * j], (uint32_t)qual[2 * j + 1]);
+          for (int g = 0; g < 10; g++) {
+            const uint64_t b = bsm_bits(gp[g]);
+            rec[12 + g] = make_uint2((uint32_t)b, (uint32_t)(b >> 32));
+          }
+          rec[22] = make_uint2(0u, 0u); /* fisher_strand = 0.0; bsc_fisher_kernel fills heterozygous sites */
+          rec[23] = make_uint2((uint32_t)mq, (uint32_t)aq);
+          rec[24] = make_uint2((uint32_t)mxi, 0u); /* max_gt + zero padding */
+        } else {
 #pragma unroll
-        for (int g = 0; g < 10; g++) {
-          const uint64_t b = bsm_bits(gp[g]);
-          rec[12 + g] = make_uint2((uint32_t)b, (uint32_t)(b >> 32));
+          for (int j = 0; j < 25; j++) rec[j] = make_uint2(0u, 0u); /* skipped site: the reference's memset, :179 */
         }
-        rec[22] = make_uint2(0u, 0u); /* fisher_strand = 0.0; bsc_fisher_kernel fills heterozygous sites */
-        rec[23] = make_uint2((uint32_t)mq, (uint32_t)aq);
-        rec[24] = make_uint2((uint32_t)mxi, 0u); /* max_gt + zero padding */
-      } else {
-#pragma unroll
-        for (int j = 0; j < 25; j++) rec[j] = make_uint2(0u, 0u); /* skipped site: the reference's memset, :179 */
+        /* out_dw == 52 (gt_vcf): bytes 200.. = {ready = 0, skip, pad} */
+        if (out_dw > OUT_DW) rec[25] = make_uint2(covered ? 0u : 0x100u, 0u);
       }
-      /* out_dw > 50 (e.g. 52 = gt_vcf): bytes 200.. = {ready = 0, skip, pad} */
-      for (unsigned j = 25; j < out_dw / 2; j++) rec[j] = make_uint2(j == 25 ? (covered ? 0u : 0x100u) : 0u, 0u);
-      skip[site] = covered ? 0 : 1;
-    }
-    __syncthreads();
-
-    /* ---- stage out: coalesced 16 B per lane ---- */
-    {
-      uint4 *dst = reinterpret_cast<uint4 *>(out + site0 * out_dw);
-      const uint4 *src = reinterpret_cast<const uint4 *>(lds_tile);
-      const unsigned ndw = nvalid * out_dw;
-      const unsigned nvec = ndw / 4;
-      for (unsigned v = tid; v < nvec; v += TILE) dst[v] = src[v];
-      if (ndw & 3u) {
-        if (tid == 0) {
-          const unsigned o = nvec * 4;
-          out[site0 * out_dw + o] = lds_tile[o];
-          out[site0 * out_dw + o + 1] = lds_tile[o + 1];
+      if (full) { /* copy the 32 records out: 16 bytes per lane, contiguous */
+        const unsigned nvec = 32u * out_dw / 4u; /* 400 or 416 */
+        uint4 *dst = reinterpret_cast<uint4 *>(out + (site0 + half * 32u) * out_dw);
+        const uint4 *srcv = reinterpret_cast<const uint4 *>(slot);
+#pragma unroll
+        for (unsigned v = 0; v < 7; v++) {
+          const unsigned idx = v * 64u + lane;
+          if (idx < nvec) dst[idx] = srcv[idx];
         }
       }
     }
-    __syncthreads(); /* tile is free again */
   }
 
   /* block counters -> global */
@@ -497,8 +608,8 @@ extern "C" int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n,
   hipStream_t s = (hipStream_t)stream;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, s);
   const uint64_t n_tiles = (n + TILE - 1) / TILE;
-  /* 3 workgroups fit one CU (53 KB LDS each); 8 rounds of them keep the tail short */
-  uint64_t grid = (uint64_t)num_cus * 3u * 8u;
+  /* 4 workgroups fit one CU (32 KB LDS, <= 128 VGPRs); 8 rounds of them keep the tail short */
+  uint64_t grid = (uint64_t)num_cus * BSC_WAVES_PER_SIMD * 8u;
   if (grid > n_tiles) grid = n_tiles;
   hipLaunchKernelGGL(bsc_call_kernel, dim3((unsigned)grid), dim3(TILE), 0, s, (const uint32_t *)cts,
                      (const uint8_t *)ref, n, (uint32_t *)out, out_dw, (uint8_t *)skip, (const bsc_dev_tables *)tb,

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Build a kernel variant next to the main library: tools/build_variant.sh <name> <extra hipcc flags...>
+# -> bs_call_amd/lib/variants/lib_<name>.so  (select with BSCALL_AMD_LIB=...)
+set -e
+NAME=$1; shift
+D=bs_call_amd/lib/variants
+mkdir -p $D
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wno-unused-function "$@" -c bs_call_amd/csrc/kernels.hip -o $D/k_$NAME.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A6 "Function Name: bsc_call_kernel" | grep -E "VGPRs:|Scratch|Occupancy" | sed "s/^.*remark: */[$NAME] /"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/lib_$NAME.so $D/k_$NAME.o bs_call_amd/lib/bscall_api.o -lm
