@@ -29,6 +29,9 @@
 #include "synth.h"
 
 #define TILE 256
+#ifndef BSC_UNROLL
+#define BSC_UNROLL 1 /* unroll factor of the rolled log / exp loops */
+#endif
 #ifndef BSC_WAVES_PER_SIMD
 #define BSC_WAVES_PER_SIMD 4 /* occupancy target of bsc_call_kernel: bounds its VGPR budget (512 / waves) */
 #endif
@@ -37,8 +40,6 @@
 #define MAX_OUT_DW 52 /* gt_vcf stride (208 B) */
 #define SLOT_DW (64 * IN_DW) /* per-wave LDS slot: 64 pile-ups = 6 656 B >= 32 results (6 400 / 6 656 B) */
 
-/* x / ln(10) as a true IEEE division (the reference divides by the LOG10 macro, genotype_model.c:244). */
-__device__ static __forceinline__ double div_ln10(double x) { return x / BSM_LN10; }
 
 
 /* ---- branch-free device forms of bsmath.h -------------------------------------------------------------
@@ -47,11 +48,10 @@ __device__ static __forceinline__ double div_ln10(double x) { return x / BSM_LN1
  * left to a wave-uniform fallback onto the full functions.  64-bit integer steps are done on the high
  * word where the constants' low words are zero. */
 
-/* log(x) for positive, normal, finite x */
-__device__ static __forceinline__ double log_pn(double x, const double *tab) {
+/* log(x) for positive, normal, finite x: the table path (x = 2^k z, z in [0x1.6p-1, 0x1.6p0)) */
+__device__ static __forceinline__ double log_main(double x, const double *tab) {
   const uint64_t ix = bsm_bits(x);
   const uint32_t hx = (uint32_t)(ix >> 32);
-  /* main path: x = 2^k z, z in [0x1.6p-1, 0x1.6p0), table of 1/c and log(c) */
   const uint32_t tmp = hx - 0x3fe60000u;
   const uint32_t i = (tmp >> 13) & 127u;
   const int k = (int)tmp >> 20;
@@ -69,8 +69,11 @@ __device__ static __forceinline__ double log_pn(double x, const double *tab) {
   const double q3 = BSM_FMA(r, BSM_LOG_A4, BSM_LOG_A3);
   lo = BSM_FMA(r2, BSM_LOG_A0, lo);
   const double q = BSM_FMA(q3, r2, q1);
-  const double ym = BSM_FMA(q, r3, lo) + hi;
-  /* near-1 path: 1 - 2^-4 <= x < 1 + 0x1.09p-4 (x == 1 gives +0 through the same operations) */
+  return BSM_FMA(q, r3, lo) + hi;
+}
+
+/* log(x) for 1 - 2^-4 <= x < 1 + 0x1.09p-4 (x == 1 gives +0 through the same operations) */
+__device__ static __forceinline__ double log_near1(double x) {
   const double s = x - 1.0;
   const double s2 = s * s;
   const double s3 = s * s2;
@@ -89,15 +92,24 @@ __device__ static __forceinline__ double log_pn(double x, const double *tab) {
   const double nhi = BSM_FMA(shi2, BSM_LOG_B0, s);
   double nlo = BSM_FMA(shi2, BSM_LOG_B0, s - nhi);
   nlo = BSM_FMA(s + shi, slo * BSM_LOG_B0, nlo);
-  const double yn = nhi + BSM_FMA(p, s3, nlo);
-  return (hx - 0x3fee0000u < 0x3ff10900u - 0x3fee0000u) ? yn : ym;
+  return nhi + BSM_FMA(p, s3, nlo);
 }
 
-/* log(x) with the wave-uniform escape for x that is not positive-normal-finite */
+/*
+ * log(x) on the device: table path for every lane; the near-1 polynomial only when some lane of the wave needs
+ * it (wave-uniform branch: of the 12 methylation terms only 4 are near 1 with any frequency, so most
+ * evaluations skip it); the full bsm_log_t only when some lane is not positive-normal-finite (never, for valid
+ * parameters).
+ */
 __device__ static __forceinline__ double log_dev(double x, const double *tab) {
   const uint32_t hx = (uint32_t)(bsm_bits(x) >> 32);
+  const bool near = hx - 0x3fee0000u < 0x3ff10900u - 0x3fee0000u;
   const bool ok = hx - 0x00100000u < 0x7fe00000u;
-  double y = log_pn(x, tab);
+  double y = log_main(x, tab);
+  if (__any(near)) {
+    const double yn = log_near1(x);
+    y = near ? yn : y;
+  }
   if (__builtin_expect(__any(!ok), 0)) y = ok ? y : bsm_log_t(x, tab);
   return y;
 }
@@ -146,7 +158,9 @@ __device__ static __forceinline__ double div_ln10_dev(double x) {
   return q;
 }
 
-/* get_Z (src/genotype_model.c:23-42); the caller discards the result when x1 + x2 == 0. */
+/* get_Z (src/genotype_model.c:23-42); the caller never uses the result when x1 + x2 == 0 (d = 0 -> inf/nan).
+ * (A shared-reciprocal Markstein form of the three quotients was tried: exact — tools/check_div_getz.c, 2.7e9
+ * quotients — but it raised register pressure and lost time at 4 waves/SIMD, so the plain divisions stay.) */
 __device__ static __forceinline__ void get_Z(double x1, double x2, double k1, double k2, double l, double t, double &Z0,
                                              double &Z1, double &Z2) {
   double lpt = l + t;
@@ -164,14 +178,6 @@ __device__ static __forceinline__ void get_Z(double x1, double x2, double k1, do
   Z2 = 0.5 * (lmt * s2 + 2.0 - lpt);
 }
 
-/* n * ln(arg) for a Z-dependent term; +0.0 when the class is empty (arg may then be garbage / negative). */
-__device__ static __forceinline__ double zterm(bool has, double arg, double n, const double *logtab) {
-  double v = bsm_log_t(has ? arg : 2.0, logtab) * n;
-#ifdef BSC_SCHED_FENCE
-  __builtin_amdgcn_sched_barrier(0); /* keep the independent log chains from being interleaved (VGPR pressure) */
-#endif
-  return has ? v : 0.0;
-}
 
 /* LDS-DMA: 16 bytes per lane, global (per-lane address) -> LDS (wave-uniform base + lane * 16). */
 __device__ static __forceinline__ void dma16(const void *g, void *lds_wave_base) {
@@ -315,7 +321,7 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
       la[10] = has7 ? 1.0 - 0.5 * Z1 + k7 : 2.0;
       la[11] = has7 ? 0.5 * (1.0 - Z2) + k7 : 2.0;
     }
-#pragma unroll 1
+#pragma unroll BSC_UNROLL
     for (int i = 0; i < 12; i++) la[i] = log_dev(la[i], s_logtab);
 
     /* prior from the reference base (src/genotype_model.c:87-108); genotype order AA AC AG AT CC CG CT GG GT TT */
@@ -392,7 +398,7 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
     la[5] = ll5 - mx; la[6] = ll6 - mx; la[7] = ll7 - mx; la[8] = ll8 - mx; la[9] = ll9 - mx;
     /* normalise (:240-245): sum of exp(ll - max) in index order, rolled */
     double sum = 0.0;
-#pragma unroll 1
+#pragma unroll BSC_UNROLL
     for (int g = 0; g < 10; g++) sum += exp_dev(la[g], (const uint64_t *)s_exptab);
     const double lsum = log_dev(sum, s_logtab);
 #pragma unroll 1
