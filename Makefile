@@ -21,7 +21,15 @@ $(LIBDIR)/bscall_api.o: $(CSRC)/bscall_api.c include/bscall_amd.h $(CSRC)/bsmath
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/bscall_api.o
+$(LIBDIR)/accumulate.o: $(CSRC)/accumulate.hip $(CSRC)/devtables.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/synth_reads.o: $(CSRC)/synth_reads.c include/bscall_amd.h $(CSRC)/synth.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/accumulate.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
 
 oracle:

@@ -4,6 +4,7 @@ The compute lives in bs_call_amd/lib/libbscall_amd.so (gfx950 HIP kernels behind
 include/bscall_amd.h).  This package is the thin Python host mirror used by tests and bench.py.
 """
 from .abi import GENOTYPES, GT_HET, GT_METH, PILEUP, TEMPLATE  # noqa: F401
-from .caller import BscError, SiteCaller, synth_pileup_host  # noqa: F401
+from .caller import (BscError, BscInexactWarning, SiteCaller, synth_pileup_host, synth_reads_host,  # noqa: F401
+                     synth_ref_host)
 
-__all__ = ["SiteCaller", "BscError", "synth_pileup_host", "PILEUP", "GT_METH", "TEMPLATE", "GENOTYPES", "GT_HET"]
+__all__ = ["SiteCaller", "BscError", "BscInexactWarning", "synth_pileup_host", "synth_reads_host", "synth_ref_host", "PILEUP", "GT_METH", "TEMPLATE", "GENOTYPES", "GT_HET"]

@@ -16,6 +16,9 @@ EXPORTS = (
     "bsc_get_tables",
     "bsc_call_sites",
     "bsc_call_sites_device",
+    "bsc_accumulate",
+    "bsc_call_block",
+    "bsc_synth_reads_host",
     "bsc_set_profiling",
     "bsc_last_kernel_ms",
     "bsc_synchronize",
@@ -103,6 +106,12 @@ def load():
     L.bsc_call_sites.argtypes = [vp, vp, vp, u64, vp, u32, vp]
     L.bsc_call_sites_device.restype = i32
     L.bsc_call_sites_device.argtypes = [vp, vp, vp, u64, vp, u32, vp, vp]
+    L.bsc_accumulate.restype = i32
+    L.bsc_accumulate.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp]
+    L.bsc_call_block.restype = i32
+    L.bsc_call_block.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, u32, vp]
+    L.bsc_synth_reads_host.restype = C.c_int64
+    L.bsc_synth_reads_host.argtypes = [u64, u32, u32, u32, u32, vp, u64, vp, u64, C.POINTER(u64)]
     L.bsc_set_profiling.restype = i32
     L.bsc_set_profiling.argtypes = [vp, i32]
     L.bsc_last_kernel_ms.restype = i32

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .abi import GT_METH, PILEUP
+from .abi import GT_METH, PILEUP, TEMPLATE
 
 SYNTH_NRUNS = 1
 
@@ -21,7 +21,16 @@ class BscError(RuntimeError):
         self.code = code
 
 
+class BscInexactWarning(UserWarning):
+    """Some pile-up sums left the range where the reference's float sums are exact (BSC_WARN_INEXACT)."""
+
+
 def _check(rc):
+    if rc == 1:  # BSC_WARN_INEXACT: results are written
+        import warnings
+
+        warnings.warn(_lib.load().bsc_last_error().decode("utf-8", "replace"), BscInexactWarning, stacklevel=3)
+        return
     if rc != 0:
         raise BscError(rc, _lib.load().bsc_last_error().decode("utf-8", "replace"))
 
@@ -79,6 +88,29 @@ class SiteCaller:
         _check(self._L.bsc_call_sites(self._h, _ptr(pile), _ptr(ref), n, _ptr(out), out_stride, _ptr(skip)))
         return out, skip
 
+    # -- reads -> pile-up (HOT LOOP A) and whole blocks ------------------------------------------------
+    def accumulate(self, templates, seq, x, y):
+        """templates: TEMPLATE[nr]; seq: uint8 read bytes; positions x..y inclusive -> PILEUP[y-x+1]."""
+        templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        out = np.zeros(max(int(y) - int(x) + 1, 1), dtype=PILEUP)
+        _check(self._L.bsc_accumulate(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(out)))
+        return out[: max(int(y) - int(x) + 1, 0)]
+
+    def call_block(self, templates, seq, x, y, ref, out_stride=200):
+        """One call_genotypes_ML block: accumulate + call.  ref: uint8[y-x+1] codes -> (GT_METH[..], skip)."""
+        templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        n = int(y) - int(x) + 1
+        if len(ref) != n:
+            raise ValueError("ref must have y - x + 1 entries")
+        out = np.zeros(n, dtype=GT_METH) if out_stride == 200 else np.zeros((n, out_stride), dtype=np.uint8)
+        skip = np.zeros(n, dtype=np.uint8)
+        _check(self._L.bsc_call_block(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref),
+                                      _ptr(out), out_stride, _ptr(skip)))
+        return out, skip
+
     # -- device-resident blocks (raw device pointers, e.g. torch tensor .data_ptr()) ---------------
     def call_sites_device(self, d_cts, d_ref, n, d_out, d_skip, out_stride=200, stream=None):
         _check(self._L.bsc_call_sites_device(self._h, d_cts, d_ref, n, d_out, out_stride, d_skip, stream))
@@ -125,3 +157,23 @@ def synth_pileup_host(seed, first_site, n, coverage, flags=0):
     ref = np.zeros(n, dtype=np.uint8)
     _check(L.bsc_synth_pileup_host(seed, first_site, n, coverage, flags, _ptr(pile), _ptr(ref)))
     return pile, ref
+
+
+def synth_reads_host(seed, x, n_sites, coverage, flags=0):
+    """Synthetic read pairs over positions x .. x+n_sites-1 (bsc_synth_reads_host) -> (TEMPLATE[nt], seq uint8[])."""
+    L = _lib.load()
+    max_t = int(n_sites) * int(coverage) // 150 + 64
+    cap = max_t * 200 + 1024
+    tpl = np.zeros(max_t, dtype=TEMPLATE)
+    seq = np.zeros(cap, dtype=np.uint8)
+    used = C.c_uint64(0)
+    nt = L.bsc_synth_reads_host(seed, x, n_sites, coverage, flags, _ptr(tpl), max_t, _ptr(seq), cap, C.byref(used))
+    if nt < 0:
+        raise BscError(-3, "bsc_synth_reads_host: buffer too small")
+    return tpl[:nt].copy(), seq[: used.value].copy()
+
+
+def synth_ref_host(seed, first_site, n, flags=0):
+    """Reference codes of the synthetic genome (the ref[] of synth_pileup_host without the pile-ups)."""
+    _, ref = synth_pileup_host(seed, first_site, n, 0, flags)
+    return ref

@@ -24,6 +24,8 @@
 int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n, void *out, uint32_t out_dw, void *skip,
                         const void *tb, void *het_list, void *counters, int num_cus, void *stream, void *ev_start,
                         void *ev_mid, void *ev_stop);
+int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint32_t x, uint32_t y, uint32_t min_qual,
+                              void *rd, void *x1, void *tile_lo, void *cts, void *counters, int num_cus, void *stream);
 int bsc_dev_launch_synth(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags, void *cts,
                          void *ref, int num_cus, void *stream);
 
@@ -46,6 +48,11 @@ struct bsc_context {
   size_t cap_cts, cap_ref, cap_out, cap_skip;
   void *d_het;
   size_t cap_het;
+  /* accumulate stage */
+  void *d_tpl, *d_seq, *d_rd, *d_x1, *d_lo;
+  size_t cap_tpl, cap_seq, cap_rd, cap_x1, cap_lo;
+  bsc_template *h_sorted; /* host scratch for an unsorted template list */
+  size_t cap_sorted;
   /* optional per-launch timing of the calling kernel (bsc_set_profiling) */
   int profiling;
   hipEvent_t ev[3];
@@ -168,6 +175,12 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_out);
   hipFree(ctx->d_skip);
   hipFree(ctx->d_het);
+  hipFree(ctx->d_tpl);
+  hipFree(ctx->d_seq);
+  hipFree(ctx->d_rd);
+  hipFree(ctx->d_x1);
+  hipFree(ctx->d_lo);
+  free(ctx->h_sorted);
   for (int i = 0; i < 3; i++)
     if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   free(ctx);
@@ -262,6 +275,112 @@ int bsc_call_sites(bsc_context *ctx, const bsc_pileup *cts, const uint8_t *ref, 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   return BSC_OK;
+}
+
+/* leftmost position of a template (src/call_genotypes.c:183-185) */
+static uint32_t bsc_leftmost(const bsc_template *t) {
+  uint32_t x1 = t->pos[0];
+  if (x1 == 0) x1 = t->pos[1];
+  else if (t->pos[1] > 0 && t->pos[1] < x1) x1 = t->pos[1];
+  return x1;
+}
+
+static int bsc_cmp_leftmost(const void *a, const void *b) {
+  const uint32_t xa = bsc_leftmost((const bsc_template *)a), xb = bsc_leftmost((const bsc_template *)b);
+  return xa < xb ? -1 : (xa > xb ? 1 : 0);
+}
+
+/* Validates the block (the reference's asserts), uploads it and queues the accumulate kernels: the pile-up of
+ * x..y ends up in ctx->d_cts.  *inexact_before receives the counter value to compare against afterwards. */
+static int bsc_accumulate_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq,
+                                uint64_t seq_bytes, uint32_t x, uint32_t y) {
+  if (y < x) return bsc_fail(BSC_ERR_ARG, "accumulate: y (%u) < x (%u) (reference asserts y >= x)", y, x);
+  if (nr && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "accumulate: NULL template or read buffer");
+  int sorted = 1;
+  uint32_t prev = 0;
+  for (uint32_t i = 0; i < nr; i++) {
+    const bsc_template *t = tpl + i;
+    const uint32_t x1 = bsc_leftmost(t);
+    if (x1 < x) return bsc_fail(BSC_ERR_ARG, "accumulate: template %u starts at %u, left of the block start %u", i, x1, x);
+    if (t->orientation > 1) return bsc_fail(BSC_ERR_ARG, "accumulate: template %u has orientation %u (reference asserts ori < 2)", i, t->orientation);
+    if (t->bs_strand > 2) return bsc_fail(BSC_ERR_ARG, "accumulate: template %u has bs_strand %u", i, t->bs_strand);
+    for (int k = 0; k < 2; k++)
+      if (t->len[k] && (t->off[k] > seq_bytes || t->len[k] > seq_bytes - t->off[k]))
+        return bsc_fail(BSC_ERR_ARG, "accumulate: read %d of template %u lies outside the read buffer", k, i);
+    if (x1 < prev) sorted = 0;
+    prev = x1;
+  }
+  if (!sorted) { /* the sums do not depend on the order: sort a copy by leftmost position */
+    if (ctx->cap_sorted < nr) {
+      free(ctx->h_sorted);
+      ctx->h_sorted = malloc((size_t)nr * sizeof(bsc_template));
+      ctx->cap_sorted = ctx->h_sorted ? nr : 0;
+      if (!ctx->h_sorted) return bsc_fail(BSC_ERR_NOMEM, "accumulate: out of host memory");
+    }
+    memcpy(ctx->h_sorted, tpl, (size_t)nr * sizeof(bsc_template));
+    qsort(ctx->h_sorted, nr, sizeof(bsc_template), bsc_cmp_leftmost);
+    tpl = ctx->h_sorted;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const uint64_t sz = (uint64_t)y - x + 1;
+  const uint64_t n_wt = (sz + 63) / 64;
+  int rc;
+  if ((rc = bsc_reserve(&ctx->d_cts, &ctx->cap_cts, (size_t)n_wt * 64u * 104u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_lo, &ctx->cap_lo, (size_t)n_wt * 4u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_rd, &ctx->cap_rd, (size_t)(nr ? nr : 1) * 48u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_x1, &ctx->cap_x1, (size_t)(nr ? nr : 1) * 4u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
+  if (nr) {
+    HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  int e = bsc_dev_launch_accumulate(ctx->d_tpl, nr, ctx->d_seq, x, y, (uint32_t)ctx->params.min_qual, ctx->d_rd,
+                                    ctx->d_x1, ctx->d_lo, ctx->d_cts, ctx->d_counters, ctx->num_cus, ctx->stream);
+  if (e) return bsc_fail(BSC_ERR_HIP, "accumulate launch failed: %s", hipGetErrorString((hipError_t)e));
+  return BSC_OK;
+}
+
+static int bsc_inexact_status(bsc_context *ctx) {
+  unsigned long long v = 0;
+  HIP_TRY(hipMemcpy(&v, ctx->d_counters + BSC_CNT_INEXACT, sizeof v, hipMemcpyDeviceToHost));
+  if (v) {
+    bsc_fail(BSC_WARN_INEXACT, "accumulate: %llu position(s) with a quality or MAPQ^2 sum >= 2^24: the reference's float "
+             "sums depend on read order there", v);
+    return BSC_WARN_INEXACT;
+  }
+  return BSC_OK;
+}
+
+int bsc_accumulate(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                   uint32_t x, uint32_t y, bsc_pileup *out) {
+  if (!ctx || !out) return bsc_fail(BSC_ERR_ARG, "bsc_accumulate: NULL argument");
+  int rc = bsc_accumulate_queue(ctx, tpl, nr, seq, seq_bytes, x, y);
+  if (rc) return rc;
+  const uint64_t sz = (uint64_t)y - x + 1;
+  HIP_TRY(hipMemcpyAsync(out, ctx->d_cts, (size_t)sz * 104u, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return bsc_inexact_status(ctx);
+}
+
+int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                   uint32_t x, uint32_t y, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip) {
+  if (!ctx || !ref || !out || !skip) return bsc_fail(BSC_ERR_ARG, "bsc_call_block: NULL argument");
+  int rc = bsc_check_stride(out_stride);
+  if (rc) return rc;
+  if ((rc = bsc_accumulate_queue(ctx, tpl, nr, seq, seq_bytes, x, y))) return rc;
+  const uint64_t sz = (uint64_t)y - x + 1;
+  if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)sz))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)sz * out_stride))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)sz))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = bsc_call_sites_device(ctx, ctx->d_cts, ctx->d_ref, sz, ctx->d_out, out_stride, ctx->d_skip, ctx->stream)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(out, ctx->d_out, (size_t)sz * out_stride, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(skip, ctx->d_skip, (size_t)sz, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return bsc_inexact_status(ctx);
 }
 
 int bsc_set_profiling(bsc_context *ctx, int enable) {

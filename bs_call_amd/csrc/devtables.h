@@ -17,6 +17,8 @@ typedef struct {
 /* unsigned long long counters[BSC_CNT_WORDS] in device memory */
 #define BSC_CNT_HET_LIST 0 /* length of the heterozygous-site list of the current launch (reset per launch) */
 #define BSC_CNT_COVERED 1  /* then gt_hist[10] at 2..11, het_calls at 12 */
+#define BSC_CNT_SPAN 13    /* accumulate: largest template extent of the current block (reset per block) */
+#define BSC_CNT_INEXACT 14 /* accumulate: lanes whose quality / MAPQ^2 sums left the exact-float range */
 #define BSC_CNT_WORDS 16
 
 #endif

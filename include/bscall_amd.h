@@ -28,6 +28,7 @@ extern "C" {
 #define BSC_ERR_HIP (-2)       /* a HIP runtime call failed */
 #define BSC_ERR_NOMEM (-3)     /* host or device allocation failed */
 #define BSC_ERR_NO_DEVICE (-4) /* no gfx950 device / kernels not loadable */
+#define BSC_WARN_INEXACT 1     /* results written, but some pile-up sums left the range where float sums are exact */
 
 /* `pileup`, include/bs_call.h:174-182 — 104 bytes */
 typedef struct {
@@ -126,6 +127,29 @@ int bsc_call_sites(bsc_context *ctx, const bsc_pileup *cts, const uint8_t *ref, 
 int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref, uint64_t n, void *d_out,
                           uint32_t out_stride, void *d_skip, void *stream);
 
+/*
+ * bsc_accumulate: HOT LOOP A of call_genotypes_ML (src/call_genotypes.c:178-226) on the device: scatter the
+ * block's reads into the pile-up of positions x..y (inclusive, 1-based genome positions as in the reference).
+ *   tpl[nr]   templates, sorted by leftmost position as the reference's align_list is (an unsorted list is
+ *             accepted and sorted internally: the sums do not depend on the order)
+ *   seq       the concatenated read bytes the templates point into (seq_bytes long)
+ *   out       y - x + 1 pile-ups (host memory), zero where nothing is covered
+ * Returns BSC_ERR_ARG where the reference asserts (y < x; a template starting left of x; orientation > 1) or
+ * where a template points outside seq; BSC_WARN_INEXACT if a position's quality or MAPQ^2 sum exceeded 2^24
+ * (the reference's float sums are order-dependent there).  Uses ctx min_qual.
+ */
+int bsc_accumulate(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                   uint32_t x, uint32_t y, bsc_pileup *out);
+
+/*
+ * bsc_call_block: the compute of one call_genotypes_ML() invocation (src/call_genotypes.c:155-273) without its
+ * thread hand-offs: accumulate (above) followed by the per-site calling of bsc_call_sites(), the pile-up never
+ * leaving the device.  ref[i] is the reference code of position x + i; out / out_stride / skip as in
+ * bsc_call_sites().  INTEGRATION.md shows the replacement call_genotypes_ML() built on this.
+ */
+int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                   uint32_t x, uint32_t y, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip);
+
 /* Per-launch kernel timing with HIP events recorded on the launch stream (measurement support):
  * after bsc_set_profiling(ctx, 1), bsc_last_kernel_ms() returns the device time of the most recent
  * calling kernel and of its Fisher pass (it waits for that launch to finish).  With n > 2^31 sites per
@@ -148,6 +172,13 @@ int bsc_reset_stats(bsc_context *ctx);
 #define BSC_SYNTH_NRUNS 1u /* flags: 1 % of 10-kb runs are N (reference code 0) with no reads */
 int bsc_synth_pileup_device(bsc_context *ctx, uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage,
                             uint32_t flags, void *d_cts, void *d_ref, void *stream);
+/* Host generator of synthetic read pairs over positions x .. x+n_sites-1 ('L-reads'; see
+ * bs_call_amd/csrc/synth_reads.c): fills tpl[] (sorted by leftmost position) and seq[]; returns the number of
+ * templates, or -1 if a buffer is too small.  Reference bases come from the same synthetic genome as the
+ * L-pileup generator (site index = position). */
+int64_t bsc_synth_reads_host(uint64_t seed, uint32_t x, uint32_t n_sites, uint32_t coverage, uint32_t flags,
+                             bsc_template *tpl, uint64_t max_templates, uint8_t *seq, uint64_t seq_cap,
+                             uint64_t *seq_used);
 /* Host twin of the generator (same bits), for feeding the same inputs to a CPU checker. */
 int bsc_synth_pileup_host(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags,
                           bsc_pileup *cts, uint8_t *ref);

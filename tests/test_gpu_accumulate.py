@@ -1,0 +1,139 @@
+"""GPU parity of the accumulate stage (reference HOT LOOP A, src/call_genotypes.c:178-226) and of whole blocks
+(accumulate + call), through the C ABI, against the CPU oracle: every byte of every pile-up / gt_meth record."""
+import numpy as np
+import pytest
+
+import bs_call_amd as B
+
+pytestmark = pytest.mark.gpu
+SEED = 88172645463325252
+
+
+@pytest.fixture(scope="module")
+def caller():
+    c = B.SiteCaller()
+    yield c
+    c.close()
+
+
+def _block(seed, x0, n, cov, pad=2):
+    tpl, seq = B.synth_reads_host(seed, x0, n, cov)
+    x = max(1, x0 - pad)  # the reference starts the block 2 positions left of the first read (process_template.c:24-28)
+    y = int(max((tpl["pos"] + tpl["len"]).max(), x0)) - 1 if len(tpl) else x0
+    return tpl, seq, x, y
+
+
+@pytest.mark.parametrize("cov,n,x0", [(10, 100_000, 1000), (30, 200_000, 5_000_000), (200, 30_000, 77), (2, 50_000, 3)])
+def test_accumulate_parity(caller, oracle, cov, n, x0):
+    tpl, seq, x, y = _block(SEED + cov, x0, n, cov)
+    rc, exp = oracle.accumulate(tpl, seq, x, y, 20)
+    assert rc == 0
+    got = caller.accumulate(tpl, seq, x, y)
+    assert got.tobytes() == exp.tobytes()
+    assert abs(got["n"][100:-400].mean() - cov * 0.935) < cov * 0.05  # 3 % low quality, 1 % N, trimmed ends
+
+
+@pytest.mark.parametrize("y_cut", [0, 1, 63, 64, 65, 150, 1000])
+def test_window_clipping_and_ragged_tiles(caller, oracle, y_cut):
+    """y inside the reads (pos <= y clipping, :214) and block sizes around the 64-position wave tile."""
+    tpl, seq, x, y = _block(SEED, 10_000, 3_000, 30)
+    y2 = x + y_cut
+    keep = np.minimum(np.where(tpl["pos"][:, 0] > 0, tpl["pos"][:, 0], tpl["pos"][:, 1]),
+                      np.where(tpl["pos"][:, 1] > 0, tpl["pos"][:, 1], tpl["pos"][:, 0])) <= y2 + 500
+    rc, exp = oracle.accumulate(tpl[keep], seq, x, y2, 20)
+    assert rc == 0
+    got = caller.accumulate(tpl[keep], seq, x, y2)
+    assert len(got) == y_cut + 1 and got.tobytes() == exp.tobytes()
+
+
+def test_empty_single_end_and_unsorted(caller, oracle):
+    # no templates at all
+    got = caller.accumulate(np.zeros(0, dtype=B.TEMPLATE), np.zeros(0, dtype=np.uint8), 100, 300)
+    assert len(got) == 201 and not got.tobytes().strip(b"\0")
+    tpl, seq, x, y = _block(SEED + 3, 500, 20_000, 30)
+    rc, exp = oracle.accumulate(tpl, seq, x, y, 20)
+    # the sums do not depend on template order: a shuffled list gives the same pile-up
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(tpl))
+    got = caller.accumulate(tpl[perm], seq, x, y)
+    assert got.tobytes() == exp.tobytes()
+    # reverse-read-only templates and the "skipped read 0 does not flip the orientation" quirk (:204,224)
+    t2 = tpl.copy()
+    sel = np.zeros(len(t2), dtype=bool)
+    sel[::3] = True
+    sel &= t2["len"][:, 1] > 0  # keep at least one read per template
+    t2["len"][sel, 0] = 0
+    t2["pos"][sel, 0] = 0
+    seq2 = seq.copy()
+    for t in t2[1::7]:  # read 0 entirely trimmed: q = 63 everywhere
+        if t["len"][0]:
+            o, l = int(t["off"][0]), int(t["len"][0])
+            seq2[o : o + l] = (seq2[o : o + l] & 3) | (63 << 2)
+    rc, exp2 = oracle.accumulate(t2, seq2, x, y, 20)
+    assert rc == 0
+    got2 = caller.accumulate(t2, seq2, x, y)
+    assert got2.tobytes() == exp2.tobytes()
+    assert got2.tobytes() != exp.tobytes()
+
+
+def test_min_qual_parameter(oracle):
+    tpl, seq, x, y = _block(SEED + 5, 2_000, 20_000, 30)
+    for mq in (1, 10, 30, 43):
+        rc, exp = oracle.accumulate(tpl, seq, x, y, mq)
+        with B.SiteCaller(min_qual=mq) as c:
+            got = c.accumulate(tpl, seq, x, y)
+        assert got.tobytes() == exp.tobytes(), mq
+
+
+def test_reference_asserts_become_errors(caller):
+    tpl, seq, x, y = _block(SEED, 1_000, 2_000, 10)
+    with pytest.raises(B.BscError) as e:  # assert(y >= x), :158
+        caller.accumulate(tpl, seq, 500, 499)
+    assert e.value.code == -1
+    with pytest.raises(B.BscError):  # assert(x1 >= x), :186
+        caller.accumulate(tpl, seq, int(tpl["pos"][0, 0]) + 1, y)
+    bad = tpl.copy()
+    bad["orientation"][5] = 2
+    with pytest.raises(B.BscError):  # assert(ori < 2), :188
+        caller.accumulate(bad, seq, x, y)
+    bad = tpl.copy()
+    bad["off"][7, 1] = len(seq)
+    with pytest.raises(B.BscError):
+        caller.accumulate(bad, seq, x, y)
+
+
+def test_inexact_range_is_reported(caller, oracle):
+    """MAPQ 255 at depth > 258: the float sum of MAPQ^2 leaves the exact range; results are still produced and the
+    call says so (BSC_WARN_INEXACT)."""
+    n_t = 400
+    tpl = np.zeros(n_t, dtype=B.TEMPLATE)
+    tpl["pos"][:, 0] = 1000
+    tpl["len"][:, 0] = 50
+    tpl["off"][:, 0] = np.arange(n_t) * 50
+    tpl["mapq"][:, 0] = 255
+    tpl["bs_strand"] = 1
+    seq = np.full(n_t * 50, 1 | (30 << 2), dtype=np.uint8)
+    with pytest.warns(B.BscInexactWarning):
+        got = caller.accumulate(tpl, seq, 998, 1060)
+    assert got["n"][2] == n_t and got["counts"][2].sum() == n_t  # the integer fields are exact regardless
+    # 258 reads stay exact and silent
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = caller.accumulate(tpl[:258], seq, 998, 1060)
+    rc, exp = oracle.accumulate(tpl[:258], seq, 998, 1060, 20)
+    assert got.tobytes() == exp.tobytes()
+
+
+def test_call_block_parity(caller, oracle, tables, libm_exact):
+    """One whole call_genotypes_ML block: reads in, gt_meth out, pile-up never on the host."""
+    for cov, n, x0 in ((30, 150_000, 20_000), (300, 8_000, 64)):
+        tpl, seq, x, y = _block(SEED + 11 + cov, x0, n, cov)
+        ref = B.synth_ref_host(SEED + 11 + cov, x, y - x + 1)
+        rc, pile = oracle.accumulate(tpl, seq, x, y, 20)
+        exp, eskip = oracle.call_sites(pile, ref, tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
+        got, skip = caller.call_block(tpl, seq, x, y, ref)
+        assert (skip == eskip).all() and got.tobytes() == exp.tobytes()
+        raw, skip2 = caller.call_block(tpl, seq, x, y, ref, out_stride=208)
+        assert raw[:, :200].tobytes() == exp.tobytes() and (raw[:, 201] == eskip).all()
