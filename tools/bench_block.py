@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Host-inclusive throughput of bsc_accumulate / bsc_call_block on synthetic reads (L-reads generator).
+The host buffers cross PCIe here, so this is the end-to-end figure DESIGN.md quotes next to the HBM-resident
+kernel number of bench.py — it is never bench.py's `value`.   usage: python tools/bench_block.py [sites] [cov]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+import bs_call_amd as B
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+cov = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+t0 = time.time()
+tpl, seq = B.synth_reads_host(88172645463325252, 1000, n, cov)
+x, y = 998, int((tpl["pos"] + tpl["len"]).max()) - 1
+ref = B.synth_ref_host(88172645463325252, x, y - x + 1)
+print("generated %d templates, %d bases for %d positions in %.1f s" % (len(tpl), len(seq), y - x + 1, time.time() - t0))
+with B.SiteCaller() as c:
+    c.accumulate(tpl, seq, x, y)  # warm-up: allocations
+    c.call_block(tpl, seq, x, y, ref)
+    for name, fn in (("accumulate", lambda: c.accumulate(tpl, seq, x, y)), ("call_block", lambda: c.call_block(tpl, seq, x, y, ref))):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        t = min(ts)
+        print("%-11s %.1f ms  -> %.1f M positions/s, %.1f M bases/s (host buffers, PCIe included)" % (
+            name, t * 1e3, (y - x + 1) / t / 1e6, len(seq) / t / 1e6))
