@@ -152,7 +152,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": profiled_traffic(n, args.coverage),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms_avg": k_ms,
                 "fisher_kernel_ms_avg": float(np.mean(fisher_ms)),
@@ -165,6 +165,19 @@ def main():
     caller.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def profiled_traffic(n, coverage):
+    """HBM bytes per bsc_call_kernel launch from the committed PMC passes (profiles/traffic.json, written from
+    `tools/profile_bench.sh`: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
+    doubled per the gfx950 rule).  Counters cannot be read inside this process; None if the workload differs."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if t.get("positions") == n and t.get("coverage") == coverage:
+            return t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(args, d_cts, d_ref, d_out, d_skip):

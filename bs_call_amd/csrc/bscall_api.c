@@ -123,6 +123,9 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
   else bsc_params_default(&p);
   if (!(p.under_conv >= 0.0 && p.under_conv < 1.0) || !(p.over_conv >= 0.0 && p.over_conv < 1.0) || !(p.ref_bias > 0.0))
     return bsc_fail(BSC_ERR_ARG, "bsc_create: conversion rates must be in [0,1) and ref_bias > 0");
+  /* get_Z divides by (1 - under_conv - over_conv) (src/genotype_model.c:25-26): it must be positive and finite */
+  if (!((1.0 - p.under_conv) - p.over_conv >= 0x1p-20))
+    return bsc_fail(BSC_ERR_ARG, "bsc_create: under_conv + over_conv must be < 1 (by at least 2^-20)");
   if (p.min_qual < 1) p.min_qual = 1; /* src/parse_args.c:170-171 */
   if (p.min_qual > 43) p.min_qual = 43;
 
@@ -229,7 +232,7 @@ int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref
   if (((uintptr_t)d_cts & 15u) || ((uintptr_t)d_out & 15u))
     return bsc_fail(BSC_ERR_ARG, "bsc_call_sites_device: d_cts and d_out must be 16-byte aligned");
   HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  hipStream_t s = (hipStream_t)stream; /* NULL = HIP's default stream, as everywhere in HIP */
   uint64_t done = 0;
   while (done < n) {
     uint64_t m = n - done;
@@ -442,8 +445,7 @@ int bsc_synth_pileup_device(bsc_context *ctx, uint64_t seed, uint64_t first_site
   if (n && (!d_cts || !d_ref)) return bsc_fail(BSC_ERR_ARG, "bsc_synth_pileup_device: NULL buffer");
   if (coverage > 4000) return bsc_fail(BSC_ERR_ARG, "bsc_synth_pileup_device: coverage %u > 4000", coverage);
   HIP_TRY(hipSetDevice(ctx->device));
-  int e = bsc_dev_launch_synth(seed, first_site, n, coverage, flags, d_cts, d_ref, ctx->num_cus,
-                               stream ? stream : (void *)ctx->stream);
+  int e = bsc_dev_launch_synth(seed, first_site, n, coverage, flags, d_cts, d_ref, ctx->num_cus, stream);
   if (e) return bsc_fail(BSC_ERR_HIP, "synth launch failed: %s", hipGetErrorString((hipError_t)e));
   return BSC_OK;
 }

@@ -158,26 +158,43 @@ __device__ static __forceinline__ double div_ln10_dev(double x) {
   return q;
 }
 
-/* get_Z (src/genotype_model.c:23-42); the caller never uses the result when x1 + x2 == 0 (d = 0 -> inf/nan).
- * (A shared-reciprocal Markstein form of the three quotients was tried: exact — tools/check_div_getz.c, 2.7e9
- * quotients — but it raised register pressure and lost time at 4 waves/SIMD, so the plain divisions stay.) */
+/*
+ * get_Z (src/genotype_model.c:23-42).  The three quotients share the divisor d = (x1 + x2)(l - t): one true
+ * division gives y = RN(1/d), then each quotient is a Markstein step (q0 = RN(n*y), r = n - d*q0 exact in an
+ * fma, q = RN(q0 + r*y)), which is the correctly rounded n/d when y is the correctly rounded reciprocal, except for a
+ * divisor whose significand is all ones — those lanes take the true divisions (wave-uniform fallback).  No
+ * over/underflow can interfere: bsc_create bounds l - t to [2^-20, 1], counts are < 2^33, so |n|, d, q are in
+ * [2^-60, 2^70].  tools/check_div_getz.c: 2.7e9 quotients over the model's operand ranges, all equal to IEEE
+ * division.  An empty class pair (x1 + x2 == 0) gives inf/nan here; the caller never uses that result.
+ */
 __device__ static __forceinline__ void get_Z(double x1, double x2, double k1, double k2, double l, double t, double &Z0,
                                              double &Z1, double &Z2) {
-  double lpt = l + t;
-  double lmt = l - t;
-  double d = (x1 + x2) * lmt;
-  double a2 = 2.0 - lpt;
-  double s0 = (x1 * (lpt + 2.0 * k2) - x2 * (a2 + 2.0 * k1)) / d;
+  const double lpt = l + t;
+  const double lmt = l - t;
+  const double d = (x1 + x2) * lmt;
+  const double a2 = 2.0 - lpt;
+  const double n0 = x1 * (lpt + 2.0 * k2) - x2 * (a2 + 2.0 * k1);
+  const double n1 = x1 * (2.0 + lpt + 4.0 * k2) - x2 * (a2 + 4.0 * k1);
+  const double n2 = x1 * (lpt + 4.0 * k2) - x2 * (a2 + 4.0 * k1);
+  const double y = 1.0 / d;
+  double s0 = n0 * y, s1 = n1 * y, s2 = n2 * y;
+  s0 = BSM_FMA(BSM_FMA(-d, s0, n0), y, s0);
+  s1 = BSM_FMA(BSM_FMA(-d, s1, n1), y, s1);
+  s2 = BSM_FMA(BSM_FMA(-d, s2, n2), y, s2);
+  const uint64_t db = bsm_bits(d);
+  const bool allones = ((uint32_t)db & ((uint32_t)(db >> 32) | 0xfff00000u)) == 0xffffffffu;
+  if (__builtin_expect(__any(allones), 0)) {
+    s0 = allones ? n0 / d : s0;
+    s1 = allones ? n1 / d : s1;
+    s2 = allones ? n2 / d : s2;
+  }
   s0 = s0 < -1.0 ? -1.0 : (s0 > 1.0 ? 1.0 : s0);
   Z0 = 0.5 * (lmt * s0 + 2.0 - lpt);
-  double s1 = (x1 * (2.0 + lpt + 4.0 * k2) - x2 * (a2 + 4.0 * k1)) / d;
   s1 = s1 < -1.0 ? -1.0 : (s1 > 1.0 ? 1.0 : s1);
   Z1 = 0.5 * (lmt * s1 + 2.0 - lpt);
-  double s2 = (x1 * (lpt + 4.0 * k2) - x2 * (a2 + 4.0 * k1)) / d;
   s2 = s2 < -1.0 ? -1.0 : (s2 > 1.0 ? 1.0 : s2);
   Z2 = 0.5 * (lmt * s2 + 2.0 - lpt);
 }
-
 
 /* LDS-DMA: 16 bytes per lane, global (per-lane address) -> LDS (wave-uniform base + lane * 16). */
 __device__ static __forceinline__ void dma16(const void *g, void *lds_wave_base) {
@@ -298,28 +315,28 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
      * registers, and the independent chains of the other waves on the SIMD hide the latency. */
     double *la = reinterpret_cast<double *>(slot + lane * IN_DW);
     const bool has4 = cnt[4] != 0, has5 = cnt[5] != 0, has6 = cnt[6] != 0, has7 = cnt[7] != 0;
-    {
-      /* methylation estimates (src/genotype_model.c:165-171); Z of an empty class pair is never used */
-      const double k4 = s_k[QI(4)], k5 = s_k[QI(5)], k6 = s_k[QI(6)], k7 = s_k[QI(7)];
-      double Z0, Z1, Z2, Z3, Z4, Z5;
+    { /* methylation estimates (src/genotype_model.c:165-171), one strand at a time to keep few values live;
+       * the Z of an empty class pair is never used.  C2T reads: classes 5 (C) and 7 (T) */
+      const double k5 = s_k[QI(5)], k7 = s_k[QI(7)];
+      double Z0, Z1, Z2;
       get_Z(ND(5), ND(7), k5, k7, l, t, Z0, Z1, Z2);
+      la[3] = has5 ? Z0 + k5 : 2.0;                 /* class 5 (:188-201): CC */
+      la[4] = has5 ? 0.5 * Z1 + k5 : 2.0;           /*                     CT */
+      la[5] = has5 ? 0.5 * Z2 + k5 : 2.0;           /*                     AC, CG */
+      la[9] = has7 ? 1.0 - Z0 + k7 : 2.0;           /* class 7 (:216-230): CC */
+      la[10] = has7 ? 1.0 - 0.5 * Z1 + k7 : 2.0;    /*                     CT */
+      la[11] = has7 ? 0.5 * (1.0 - Z2) + k7 : 2.0;  /*                     AC, CG */
+    }
+    { /* G2A reads: classes 6 (G) and 4 (A) */
+      const double k6 = s_k[QI(6)], k4 = s_k[QI(4)];
+      double Z3, Z4, Z5;
       get_Z(ND(6), ND(4), k6, k4, l, t, Z3, Z4, Z5);
-      /* class 4 (A on G2A reads, :173-187): AG, GG, CG/GT */
-      la[0] = has4 ? 1.0 - 0.5 * Z4 + k4 : 2.0;
-      la[1] = has4 ? 1.0 - Z3 + k4 : 2.0;
-      la[2] = has4 ? 0.5 * (1.0 - Z5) + k4 : 2.0;
-      /* class 5 (C on C2T reads, :188-201): CC, CT, AC/CG */
-      la[3] = has5 ? Z0 + k5 : 2.0;
-      la[4] = has5 ? 0.5 * Z1 + k5 : 2.0;
-      la[5] = has5 ? 0.5 * Z2 + k5 : 2.0;
-      /* class 6 (G on G2A reads, :202-215): GG, AG, CG/GT */
-      la[6] = has6 ? Z3 + k6 : 2.0;
-      la[7] = has6 ? 0.5 * Z4 + k6 : 2.0;
-      la[8] = has6 ? 0.5 * Z5 + k6 : 2.0;
-      /* class 7 (T on C2T reads, :216-230): CC, CT, AC/CG */
-      la[9] = has7 ? 1.0 - Z0 + k7 : 2.0;
-      la[10] = has7 ? 1.0 - 0.5 * Z1 + k7 : 2.0;
-      la[11] = has7 ? 0.5 * (1.0 - Z2) + k7 : 2.0;
+      la[0] = has4 ? 1.0 - 0.5 * Z4 + k4 : 2.0;     /* class 4 (:173-187): AG */
+      la[1] = has4 ? 1.0 - Z3 + k4 : 2.0;           /*                     GG */
+      la[2] = has4 ? 0.5 * (1.0 - Z5) + k4 : 2.0;   /*                     CG, GT */
+      la[6] = has6 ? Z3 + k6 : 2.0;                 /* class 6 (:202-215): GG */
+      la[7] = has6 ? 0.5 * Z4 + k6 : 2.0;           /*                     AG */
+      la[8] = has6 ? 0.5 * Z5 + k6 : 2.0;           /*                     CG, GT */
     }
 #pragma unroll BSC_UNROLL
     for (int i = 0; i < 12; i++) la[i] = log_dev(la[i], s_logtab);

@@ -120,9 +120,10 @@ int bsc_call_sites(bsc_context *ctx, const bsc_pileup *cts, const uint8_t *ref, 
                    uint32_t out_stride, uint8_t *skip);
 
 /*
- * Same computation on device-resident buffers; asynchronous on `stream` (a hipStream_t, NULL = the
- * context's own stream).  d_cts/d_out must be 16-byte aligned.  Used by bench.py and by pipelines that
- * keep pile-ups in HBM.
+ * Same computation on device-resident buffers; asynchronous on `stream` (a hipStream_t; NULL = HIP's default
+ * stream, e.g. what torch.cuda.current_stream().cuda_stream returns for PyTorch's default stream).  The caller
+ * orders its own work against that stream.  d_cts/d_out must be 16-byte aligned.  Used by bench.py and by
+ * pipelines that keep pile-ups in HBM.
  */
 int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref, uint64_t n, void *d_out,
                           uint32_t out_stride, void *d_skip, void *stream);
@@ -157,7 +158,7 @@ int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
 int bsc_set_profiling(bsc_context *ctx, int enable);
 int bsc_last_kernel_ms(bsc_context *ctx, float *call_ms, float *fisher_ms);
 
-/* Blocks until everything queued on the context's own stream has finished. */
+/* Blocks until everything queued on the context's own stream (the host-buffer entries) has finished. */
 int bsc_synchronize(bsc_context *ctx);
 
 /* Counters (device -> host; synchronises the context's stream). */

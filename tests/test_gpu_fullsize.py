@@ -1,0 +1,72 @@
+"""Full-size (BASELINE.json configs[1]: 50 M positions at 30x) checks of the HBM-resident path through properties
+that do not need a 50 M-site CPU run: idempotence, window independence, counters = a census of the output, and a
+random 1 M-site window against the oracle."""
+import numpy as np
+import pytest
+
+import bs_call_amd as B
+
+pytestmark = pytest.mark.gpu
+SEED = 88172645463325252 + 2
+N = 50_000_000
+COV = 30
+
+
+def test_full_contig_properties(oracle, tables, libm_exact):
+    import torch
+
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    with B.SiteCaller() as c:
+        d_cts = torch.empty(N * 104, dtype=torch.uint8, device=dev)
+        d_ref = torch.empty(N, dtype=torch.uint8, device=dev)
+        d_out = torch.empty(N * 200, dtype=torch.uint8, device=dev)
+        d_skip = torch.empty(N, dtype=torch.uint8, device=dev)
+        c.synth_device(SEED, 0, N, COV, d_cts.data_ptr(), d_ref.data_ptr(), 0, st)
+        c.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), N, d_out.data_ptr(), d_skip.data_ptr(), 200, st)
+        torch.cuda.synchronize()
+        s = c.stats()
+
+        # (1) the counters are a census of the output records
+        rec = d_out.view(N, 200)
+        skip = d_skip.bool()
+        assert s["sites"] == N and s["covered"] == int((~skip).sum())
+        mx = rec[:, 192][~skip].long()
+        hist = torch.bincount(mx, minlength=10).cpu().tolist()
+        assert s["gt_hist"] == hist
+        het = torch.tensor(B.GT_HET.astype(np.uint8), device=dev)[mx].sum().item()
+        assert s["het_calls"] == het
+        # skipped records are all zero; covered records carry n > 0 counts
+        assert int(rec[skip].sum()) == 0
+        # fisher_strand is non-zero only on heterozygous calls
+        fs = rec[:, 176:184].contiguous().view(torch.float64).view(-1)
+        hetmask = torch.tensor(B.GT_HET, device=dev)[rec[:, 192].long()] & ~skip
+        assert int((fs[~hetmask] != 0).sum()) == 0
+
+        # (2) idempotence
+        d_out2 = torch.zeros_like(d_out)
+        c.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), N, d_out2.data_ptr(), d_skip.data_ptr(), 200, st)
+        torch.cuda.synchronize()
+        assert torch.equal(d_out, d_out2)
+        del d_out2
+
+        # (3) window independence: sub-windows (ragged starts and lengths) give the same bytes as the full run
+        for a, m in ((0, 4_194_304), (12_345_679, 1_000_001), (N - 777, 777), (33_333_333, 63)):
+            w_out = torch.zeros(m * 200, dtype=torch.uint8, device=dev)
+            w_skip = torch.zeros(m, dtype=torch.uint8, device=dev)
+            # pile-up windows must be 16-byte aligned for the device entry: copy odd-offset windows
+            w_cts = d_cts[a * 104 : (a + m) * 104].clone()
+            w_ref = d_ref[a : a + m].clone()
+            c.call_sites_device(w_cts.data_ptr(), w_ref.data_ptr(), m, w_out.data_ptr(), w_skip.data_ptr(), 200, st)
+            torch.cuda.synchronize()
+            assert torch.equal(w_out, d_out[a * 200 : (a + m) * 200]) and torch.equal(w_skip, d_skip[a : a + m])
+
+        # (4) a 1 M-site window against the oracle, byte for byte
+        a, m = 27_182_818, 1_000_000
+        pile = d_cts[a * 104 : (a + m) * 104].cpu().numpy().view(B.PILEUP)
+        ref = d_ref[a : a + m].cpu().numpy()
+        hp, hr = B.synth_pileup_host(SEED, a, m, COV)
+        assert pile.tobytes() == hp.tobytes() and (ref == hr).all()  # device generator == host twin
+        exp, eskip = oracle.call_sites(pile, ref, tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
+        got = d_out[a * 200 : (a + m) * 200].cpu().numpy().view(B.GT_METH)
+        assert got.tobytes() == exp.tobytes() and (d_skip[a : a + m].cpu().numpy() == eskip).all()
