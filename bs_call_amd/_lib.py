@@ -19,6 +19,8 @@ EXPORTS = (
     "bsc_accumulate",
     "bsc_call_block",
     "bsc_synth_reads_host",
+    "bsc_vcf_records",
+    "bsc_vcf_records_device",
     "bsc_set_profiling",
     "bsc_last_kernel_ms",
     "bsc_synchronize",
@@ -37,6 +39,10 @@ class Params(C.Structure):
         ("min_qual", C.c_int32),
         ("device", C.c_int32),
     ]
+
+
+class VcfParams(C.Structure):
+    _fields_ = [("all_positions", C.c_int32), ("reg_start", C.c_uint32), ("reg_stop", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -112,6 +118,10 @@ def load():
     L.bsc_call_block.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, u32, vp]
     L.bsc_synth_reads_host.restype = C.c_int64
     L.bsc_synth_reads_host.argtypes = [u64, u32, u32, u32, u32, vp, u64, vp, u64, C.POINTER(u64)]
+    L.bsc_vcf_records.restype = i32
+    L.bsc_vcf_records.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, C.POINTER(VcfParams), vp]
+    L.bsc_vcf_records_device.restype = i32
+    L.bsc_vcf_records_device.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, C.POINTER(VcfParams), vp, vp]
     L.bsc_set_profiling.restype = i32
     L.bsc_set_profiling.argtypes = [vp, i32]
     L.bsc_last_kernel_ms.restype = i32

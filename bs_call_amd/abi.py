@@ -49,3 +49,15 @@ DEFAULT_MIN_QUAL = 20
 
 # strand -> pile-up class (src/call_genotypes.c:17-19), 0-based
 BASE_TAB_ST = np.array([[0, 1, 2, 3], [0, 5, 2, 7], [4, 1, 6, 3]], dtype=np.int8)
+
+# bsc_vcf_core (include/bscall_amd.h): what the printer derives per position (src/print_vcf.c:32-381), 64 B
+VCF_CORE = np.dtype(
+    {
+        "names": ["pos", "emit", "gt", "ref_code", "gt_enc", "flt", "phred", "n_gl", "cg", "alt", "cx_ref", "cx_gt",
+                  "fs", "qd", "dp", "gl"],
+        "formats": ["<u4", "u1", "u1", "u1", "u1", "u1", "u1", "u1", "S1", "S2", "S5", "S5", "<i4", "<u4", "<u4",
+                    ("<f4", (6,))],
+        "offsets": [0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 19, 24, 28, 32, 36],
+        "itemsize": 64,
+    }
+)

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .abi import GT_METH, PILEUP, TEMPLATE
+from .abi import GT_METH, PILEUP, TEMPLATE, VCF_CORE
 
 SYNTH_NRUNS = 1
 
@@ -110,6 +110,28 @@ class SiteCaller:
         _check(self._L.bsc_call_block(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref),
                                       _ptr(out), out_stride, _ptr(skip)))
         return out, skip
+
+    # -- VCF record formation (src/print_vcf.c:32-381) -------------------------------------------------
+    def vcf_records(self, gtm, skip, ref, x, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None):
+        """gtm: GT_METH[n] (or uint8[n, 208]) for positions x..x+n-1; ref: uint8[n+2] codes of x..x+n+1 -> VCF_CORE[n]."""
+        n = len(gtm)
+        stride = 200 if gtm.dtype == GT_METH else gtm.shape[1]
+        gtm = np.ascontiguousarray(gtm)
+        skip = np.ascontiguousarray(skip, dtype=np.uint8)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        if len(skip) != n or len(ref) != n + 2:
+            raise ValueError("skip must have n and ref n + 2 entries")
+        db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+        out = np.zeros(n, dtype=VCF_CORE)
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        _check(self._L.bsc_vcf_records(self._h, _ptr(gtm), stride, _ptr(skip), _ptr(ref), None if db is None else _ptr(db),
+                                       n, x, C.byref(p), _ptr(out)))
+        return out
+
+    def vcf_records_device(self, d_gtm, stride, d_skip, d_ref, n, x, d_out, all_positions=False, reg_start=1,
+                           reg_stop=0xFFFFFFFF, d_dbsnp=None, stream=None):
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        _check(self._L.bsc_vcf_records_device(self._h, d_gtm, stride, d_skip, d_ref, d_dbsnp, n, x, C.byref(p), d_out, stream))
 
     # -- device-resident blocks (raw device pointers, e.g. torch tensor .data_ptr()) ---------------
     def call_sites_device(self, d_cts, d_ref, n, d_out, d_skip, out_stride=200, stream=None):

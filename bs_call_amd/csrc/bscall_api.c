@@ -26,6 +26,9 @@ int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n, void *out,
                         void *ev_mid, void *ev_stop);
 int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint32_t x, uint32_t y, uint32_t min_qual,
                               void *rd, void *x1, void *tile_lo, void *cts, void *counters, int num_cus, void *stream);
+int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const void *ref, const void *dbsnp, uint32_t n,
+                       uint32_t x, int all_positions, uint32_t reg_start, uint32_t reg_stop, const void *tb, void *g,
+                       void *out, int num_cus, void *stream);
 int bsc_dev_launch_synth(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags, void *cts,
                          void *ref, int num_cus, void *stream);
 
@@ -51,6 +54,8 @@ struct bsc_context {
   /* accumulate stage */
   void *d_tpl, *d_seq, *d_rd, *d_x1, *d_lo;
   size_t cap_tpl, cap_seq, cap_rd, cap_x1, cap_lo;
+  void *d_vg, *d_vout, *d_vdb; /* VCF record formation: called genotypes, records, dbSNP flags */
+  size_t cap_vg, cap_vout, cap_vdb;
   bsc_template *h_sorted; /* host scratch for an unsorted template list */
   size_t cap_sorted;
   /* optional per-launch timing of the calling kernel (bsc_set_profiling) */
@@ -183,6 +188,9 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_rd);
   hipFree(ctx->d_x1);
   hipFree(ctx->d_lo);
+  hipFree(ctx->d_vg);
+  hipFree(ctx->d_vout);
+  hipFree(ctx->d_vdb);
   free(ctx->h_sorted);
   for (int i = 0; i < 3; i++)
     if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
@@ -384,6 +392,49 @@ int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
   HIP_TRY(hipMemcpyAsync(skip, ctx->d_skip, (size_t)sz, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return bsc_inexact_status(ctx);
+}
+
+int bsc_vcf_records_device(bsc_context *ctx, const void *d_gtm, uint32_t gtm_stride, const void *d_skip,
+                           const void *d_ref, const void *d_dbsnp, uint32_t n, uint32_t x,
+                           const bsc_vcf_params *params, void *d_out, void *stream) {
+  if (!ctx || !params) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_records_device: NULL argument");
+  int rc = bsc_check_stride(gtm_stride);
+  if (rc) return rc;
+  if (n == 0) return BSC_OK;
+  if (!d_gtm || !d_skip || !d_ref || !d_out) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_records_device: NULL buffer");
+  if (((uintptr_t)d_gtm & 7u) || ((uintptr_t)d_out & 15u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_vcf_records_device: d_gtm must be 8-byte and d_out 16-byte aligned");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if ((rc = bsc_reserve(&ctx->d_vg, &ctx->cap_vg, (size_t)n))) return rc;
+  int e = bsc_dev_launch_vcf(d_gtm, gtm_stride, d_skip, d_ref, d_dbsnp, n, x, params->all_positions != 0,
+                             params->reg_start, params->reg_stop, ctx->d_tables, ctx->d_vg, d_out, ctx->num_cus, stream);
+  if (e) return bsc_fail(BSC_ERR_HIP, "vcf launch failed: %s", hipGetErrorString((hipError_t)e));
+  return BSC_OK;
+}
+
+int bsc_vcf_records(bsc_context *ctx, const void *gtm, uint32_t gtm_stride, const uint8_t *skip, const uint8_t *ref,
+                    const uint8_t *dbsnp, uint32_t n, uint32_t x, const bsc_vcf_params *params, bsc_vcf_core *out) {
+  if (!ctx || !params) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_records: NULL argument");
+  int rc = bsc_check_stride(gtm_stride);
+  if (rc) return rc;
+  if (n == 0) return BSC_OK;
+  if (!gtm || !skip || !ref || !out) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_records: NULL buffer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)n * gtm_stride))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)n))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)n + 2))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)n * sizeof(bsc_vcf_core)))) return rc;
+  if (dbsnp && (rc = bsc_reserve(&ctx->d_vdb, &ctx->cap_vdb, (size_t)n))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->d_out, gtm, (size_t)n * gtm_stride, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->d_skip, skip, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)n + 2, hipMemcpyHostToDevice, ctx->stream));
+  if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, dbsnp, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  rc = bsc_vcf_records_device(ctx, ctx->d_out, gtm_stride, ctx->d_skip, ctx->d_ref, dbsnp ? ctx->d_vdb : NULL, n, x, params,
+                              ctx->d_vout, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, ctx->d_vout, (size_t)n * sizeof(bsc_vcf_core), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return BSC_OK;
 }
 
 int bsc_set_profiling(bsc_context *ctx, int enable) {

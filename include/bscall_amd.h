@@ -151,6 +151,48 @@ int bsc_accumulate(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
 int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                    uint32_t x, uint32_t y, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip);
 
+/*
+ * VCF record formation: what the reference's print thread derives from a block's gt_meth records before it hands a
+ * record to htslib (_print_vcf_entry, src/print_vcf.c:32-381, with the 5-site window of print_vcf_entry /
+ * flush_vcf_entries, :529-594).  One 64-byte bsc_vcf_core per position; a host formatter turns the records with
+ * emit = 1 into VCF/BCF lines.  Not covered: dbSNP names (pass rs_found per position in `dbsnp`, or NULL), the JSON
+ * statistics, the header.
+ */
+typedef struct {
+  uint32_t pos;     /* 1-based position; 0 in an all-zero record = nothing called here */
+  uint8_t emit;     /* 1: the reference would write a record (not hom-ref AA/TT unless all_positions or dbSNP, in region) */
+  uint8_t gt;       /* called genotype 0..9 (first-max argmax of gt_prob, src/print_vcf.c:584-591) */
+  uint8_t ref_code; /* REF base code 0..4 as the printer sees it (an N up to two positions before blanks it, :570-577) */
+  uint8_t gt_enc;   /* FORMAT GT: two BCF allele codes ((allele+1)<<1), high and low nibble (reference gt_int table) */
+  uint8_t flt;      /* 1 q20, 2 qd2, 4 fs60, 8 mq40 (FILTER fail / FT names), 128 mac1; 0 = PASS */
+  uint8_t phred;    /* QUAL and FORMAT GQ */
+  uint8_t n_gl;     /* number of FORMAT GL values */
+  char cg;          /* FORMAT CG: 'C' (= "CG"), 'H', 'N', '?', '.' */
+  char alt[2];      /* ALT alleles, 0-padded */
+  char cx_ref[5];   /* INFO CX: reference context */
+  char cx_gt[5];    /* FORMAT CX: IUPAC context of the called genotypes */
+  int32_t fs;       /* FORMAT FS (the reference writes it for heterozygous genotypes only) */
+  uint32_t qd;      /* FORMAT QD */
+  uint32_t dp;      /* FORMAT DP (non-informative depth) */
+  float gl[6];      /* FORMAT GL */
+  uint32_t _pad;
+} bsc_vcf_core;
+
+typedef struct {
+  int32_t all_positions; /* sr_param.all_positions (-A) */
+  uint32_t reg_start;    /* emit only reg_start <= position <= reg_stop: ctg->curr_reg, or 1 .. ctg->end_pos */
+  uint32_t reg_stop;
+} bsc_vcf_params;
+
+/* Host buffers: gtm = n records of gtm_stride bytes (200 or 208) for positions x .. x+n-1, skip[n], ref[n+2] = the
+ * reference codes of x .. x+n+1 (work->ref), dbsnp[n] = rs_found (0/1/3) per position or NULL; out[n]. */
+int bsc_vcf_records(bsc_context *ctx, const void *gtm, uint32_t gtm_stride, const uint8_t *skip, const uint8_t *ref,
+                    const uint8_t *dbsnp, uint32_t n, uint32_t x, const bsc_vcf_params *params, bsc_vcf_core *out);
+/* Same on device-resident buffers, asynchronous on `stream` (chains behind bsc_call_sites_device). */
+int bsc_vcf_records_device(bsc_context *ctx, const void *d_gtm, uint32_t gtm_stride, const void *d_skip,
+                           const void *d_ref, const void *d_dbsnp, uint32_t n, uint32_t x,
+                           const bsc_vcf_params *params, void *d_out, void *stream);
+
 /* Per-launch kernel timing with HIP events recorded on the launch stream (measurement support):
  * after bsc_set_profiling(ctx, 1), bsc_last_kernel_ms() returns the device time of the most recent
  * calling kernel and of its Fisher pass (it waits for that launch to finish).  With n > 2^31 sites per

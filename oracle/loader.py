@@ -45,6 +45,11 @@ def lib():
         L.orc_call_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_accumulate.restype = C.c_int
         L.orc_accumulate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_vcf_block.restype = None
+        L.orc_vcf_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_vcf_tables.restype = None
+        L.orc_vcf_tables.argtypes = [C.c_void_p] * 4
+        assert L.orc_sizeof_vcf_core() == 64
         for f in ("orc_log_array", "orc_exp_array"):
             getattr(L, f).restype = None
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
@@ -133,3 +138,28 @@ def exp_array(x, flavour):
     y = np.empty_like(x)
     lib().orc_exp_array(_ptr(x), _ptr(y), x.size, flavour)
     return y
+
+
+def vcf_block(gtm, skip, ref, x, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None):
+    """print_thread over one block (src/process.c:87-104): gtm GT_METH[n], skip[n], ref codes of x..x+n+1 -> VCF_CORE[n]."""
+    from bs_call_amd.abi import GT_METH, VCF_CORE
+
+    gtm = np.ascontiguousarray(gtm, dtype=GT_METH)
+    skip = np.ascontiguousarray(skip, dtype=np.uint8)
+    n = len(gtm)
+    refz = np.zeros(n + 3, dtype=np.uint8)  # the reference reads work->ref as a C string: keep a terminator
+    refz[: n + 2] = ref
+    par = np.array([1 if all_positions else 0, reg_start, reg_stop], dtype=np.uint32)
+    out = np.zeros(n, dtype=VCF_CORE)
+    db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+    lib().orc_vcf_block(_ptr(gtm), _ptr(skip), _ptr(refz), n, x, _ptr(par), None if db is None else _ptr(db), _ptr(out))
+    return out
+
+
+def vcf_tables():
+    ref_alt = np.zeros((10, 5, 3), dtype="S1")
+    all_idx = np.zeros((10, 5, 2), dtype=np.int32)
+    gt_int = np.zeros((10, 5), dtype=np.uint8)
+    gt_flag = np.zeros((10, 5), dtype=np.uint8)
+    lib().orc_vcf_tables(_ptr(ref_alt), _ptr(all_idx), _ptr(gt_int), _ptr(gt_flag))
+    return ref_alt, all_idx, gt_int, gt_flag
