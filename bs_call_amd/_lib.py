@@ -15,6 +15,8 @@ EXPORTS = (
     "bsc_destroy",
     "bsc_get_tables",
     "bsc_call_sites",
+    "bsc_alloc_host",
+    "bsc_free_host",
     "bsc_call_sites_device",
     "bsc_accumulate",
     "bsc_call_block",
@@ -110,6 +112,10 @@ def load():
     L.bsc_get_tables.argtypes = [vp, vp, vp]
     L.bsc_call_sites.restype = i32
     L.bsc_call_sites.argtypes = [vp, vp, vp, u64, vp, u32, vp]
+    L.bsc_alloc_host.restype = vp
+    L.bsc_alloc_host.argtypes = [u64]
+    L.bsc_free_host.restype = None
+    L.bsc_free_host.argtypes = [vp]
     L.bsc_call_sites_device.restype = i32
     L.bsc_call_sites_device.argtypes = [vp, vp, vp, u64, vp, u32, vp, vp]
     L.bsc_accumulate.restype = i32

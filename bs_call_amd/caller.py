@@ -73,18 +73,20 @@ class SiteCaller:
         return q, lf
 
     # -- host blocks ------------------------------------------------------------------------------
-    def call_sites(self, pile, ref, out_stride=200):
-        """pile: PILEUP[n], ref: uint8[n] codes 0..4 -> (GT_METH[n] or raw uint8[n, stride], skip uint8[n])."""
+    def call_sites(self, pile, ref, out_stride=200, out=None, skip=None):
+        """pile: PILEUP[n], ref: uint8[n] codes 0..4 -> (GT_METH[n] or raw uint8[n, stride], skip uint8[n]).
+        `out` / `skip` may be preallocated (e.g. pinned, see pinned_empty) arrays of the right size."""
         pile = np.ascontiguousarray(pile, dtype=PILEUP)
         ref = np.ascontiguousarray(ref, dtype=np.uint8)
         n = len(pile)
         if len(ref) != n:
             raise ValueError("pile and ref differ in length")
-        if out_stride == 200:
-            out = np.zeros(n, dtype=GT_METH)
-        else:
-            out = np.zeros((n, out_stride), dtype=np.uint8)
-        skip = np.zeros(n, dtype=np.uint8)
+        if out is None:
+            out = np.zeros(n, dtype=GT_METH) if out_stride == 200 else np.zeros((n, out_stride), dtype=np.uint8)
+        if skip is None:
+            skip = np.zeros(n, dtype=np.uint8)
+        if out.nbytes != n * out_stride or skip.nbytes != n:
+            raise ValueError("out / skip have the wrong size")
         _check(self._L.bsc_call_sites(self._h, _ptr(pile), _ptr(ref), n, _ptr(out), out_stride, _ptr(skip)))
         return out, skip
 
@@ -199,3 +201,30 @@ def synth_ref_host(seed, first_site, n, flags=0):
     """Reference codes of the synthetic genome (the ref[] of synth_pileup_host without the pile-ups)."""
     _, ref = synth_pileup_host(seed, first_site, n, 0, flags)
     return ref
+
+
+class PinnedBuffer:
+    """A page-locked host allocation (bsc_alloc_host) viewed as a numpy array; freed with the object."""
+
+    def __init__(self, shape, dtype):
+        self._L = _lib.load()
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) if not isinstance(shape, int) else int(shape)
+        self.nbytes = max(n * dt.itemsize, 1)
+        self._p = self._L.bsc_alloc_host(self.nbytes)
+        if not self._p:
+            raise BscError(-3, self._L.bsc_last_error().decode("utf-8", "replace"))
+        raw = (C.c_uint8 * self.nbytes).from_address(self._p)
+        self.array = np.frombuffer(raw, dtype=np.uint8, count=n * dt.itemsize).view(dt).reshape(shape)
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._L.bsc_free_host(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -58,6 +58,12 @@ struct bsc_context {
   size_t cap_vg, cap_vout, cap_vdb;
   bsc_template *h_sorted; /* host scratch for an unsorted template list */
   size_t cap_sorted;
+  /* host-buffer pipeline of bsc_call_sites: two chunk buffers, copy streams, events */
+  hipStream_t s_in, s_out;
+  hipEvent_t ev_in[2], ev_k[2], ev_out[2];
+  void *p_cts[2], *p_ref[2], *p_out[2], *p_skip[2];
+  size_t p_cap_cts[2], p_cap_ref[2], p_cap_out[2], p_cap_skip[2];
+  int pipe_ready;
   /* optional per-launch timing of the calling kernel (bsc_set_profiling) */
   int profiling;
   hipEvent_t ev[3];
@@ -188,6 +194,17 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_rd);
   hipFree(ctx->d_x1);
   hipFree(ctx->d_lo);
+  for (int b = 0; b < 2; b++) {
+    hipFree(ctx->p_cts[b]);
+    hipFree(ctx->p_ref[b]);
+    hipFree(ctx->p_out[b]);
+    hipFree(ctx->p_skip[b]);
+    if (ctx->ev_in[b]) hipEventDestroy(ctx->ev_in[b]);
+    if (ctx->ev_k[b]) hipEventDestroy(ctx->ev_k[b]);
+    if (ctx->ev_out[b]) hipEventDestroy(ctx->ev_out[b]);
+  }
+  if (ctx->s_in) hipStreamDestroy(ctx->s_in);
+  if (ctx->s_out) hipStreamDestroy(ctx->s_out);
   hipFree(ctx->d_vg);
   hipFree(ctx->d_vout);
   hipFree(ctx->d_vdb);
@@ -261,6 +278,24 @@ int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref
   return BSC_OK;
 }
 
+#define BSC_PIPE_CHUNK (1u << 20) /* sites per pipeline stage of bsc_call_sites (1 Mi sites = 305 MiB of records) */
+
+static int bsc_pipe_init(bsc_context *ctx) {
+  if (ctx->pipe_ready) return BSC_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
+  for (int b = 0; b < 2; b++) {
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_in[b], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_k[b], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_out[b], hipEventDisableTiming));
+  }
+  ctx->pipe_ready = 1;
+  return BSC_OK;
+}
+
+/* Three-stage pipeline over chunks of the block: H2D copy of chunk k+1 (stream s_in), kernels of chunk k (the
+ * context's stream), D2H copy of chunk k-1 (stream s_out), two buffer sets.  With pinned host buffers
+ * (bsc_alloc_host) the copies are true DMA and overlap the kernels; with pageable memory the runtime stages them. */
 int bsc_call_sites(bsc_context *ctx, const bsc_pileup *cts, const uint8_t *ref, uint64_t n, void *out,
                    uint32_t out_stride, uint8_t *skip) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_call_sites: ctx is NULL");
@@ -269,23 +304,53 @@ int bsc_call_sites(bsc_context *ctx, const bsc_pileup *cts, const uint8_t *ref, 
   if (n == 0) return BSC_OK;
   if (!cts || !ref || !out || !skip) return bsc_fail(BSC_ERR_ARG, "bsc_call_sites: NULL buffer");
   HIP_TRY(hipSetDevice(ctx->device));
-  const uint64_t chunk = n < BSC_HOST_CHUNK ? n : BSC_HOST_CHUNK;
-  if ((rc = bsc_reserve(&ctx->d_cts, &ctx->cap_cts, (size_t)chunk * 104u))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)chunk))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)chunk * out_stride))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)chunk))) return rc;
-  for (uint64_t done = 0; done < n; done += chunk) {
-    const uint64_t m = (n - done) < chunk ? (n - done) : chunk;
-    HIP_TRY(hipMemcpyAsync(ctx->d_cts, cts + done, (size_t)m * 104u, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref + done, (size_t)m, hipMemcpyHostToDevice, ctx->stream));
-    rc = bsc_call_sites_device(ctx, ctx->d_cts, ctx->d_ref, m, ctx->d_out, out_stride, ctx->d_skip, ctx->stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync((char *)out + done * out_stride, ctx->d_out, (size_t)m * out_stride, hipMemcpyDeviceToHost,
-                           ctx->stream));
-    HIP_TRY(hipMemcpyAsync(skip + done, ctx->d_skip, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if ((rc = bsc_pipe_init(ctx))) return rc;
+  const uint64_t chunk = n < BSC_PIPE_CHUNK ? n : BSC_PIPE_CHUNK;
+  const int nbuf = n > chunk ? 2 : 1;
+  for (int b = 0; b < nbuf; b++) {
+    if ((rc = bsc_reserve(&ctx->p_cts[b], &ctx->p_cap_cts[b], (size_t)chunk * 104u))) return rc;
+    if ((rc = bsc_reserve(&ctx->p_ref[b], &ctx->p_cap_ref[b], (size_t)chunk))) return rc;
+    if ((rc = bsc_reserve(&ctx->p_out[b], &ctx->p_cap_out[b], (size_t)chunk * out_stride))) return rc;
+    if ((rc = bsc_reserve(&ctx->p_skip[b], &ctx->p_cap_skip[b], (size_t)chunk))) return rc;
   }
+  uint64_t k = 0;
+  for (uint64_t done = 0; done < n; done += chunk, k++) {
+    const int b = (int)(k & 1);
+    const uint64_t m = (n - done) < chunk ? (n - done) : chunk;
+    /* buffer set b is free for new input once the kernels of chunk k-2 have run */
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->s_in, ctx->ev_k[b], 0));
+    HIP_TRY(hipMemcpyAsync(ctx->p_cts[b], cts + done, (size_t)m * 104u, hipMemcpyHostToDevice, ctx->s_in));
+    HIP_TRY(hipMemcpyAsync(ctx->p_ref[b], ref + done, (size_t)m, hipMemcpyHostToDevice, ctx->s_in));
+    HIP_TRY(hipEventRecord(ctx->ev_in[b], ctx->s_in));
+    /* kernels: need the input, and the output buffer of chunk k-2 must have left */
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_in[b], 0));
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_out[b], 0));
+    rc = bsc_call_sites_device(ctx, ctx->p_cts[b], ctx->p_ref[b], m, ctx->p_out[b], out_stride, ctx->p_skip[b], ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_k[b], ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->s_out, ctx->ev_k[b], 0));
+    HIP_TRY(hipMemcpyAsync((char *)out + done * out_stride, ctx->p_out[b], (size_t)m * out_stride, hipMemcpyDeviceToHost,
+                           ctx->s_out));
+    HIP_TRY(hipMemcpyAsync(skip + done, ctx->p_skip[b], (size_t)m, hipMemcpyDeviceToHost, ctx->s_out));
+    HIP_TRY(hipEventRecord(ctx->ev_out[b], ctx->s_out));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->s_out));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return BSC_OK;
+}
+
+/* Pinned host memory for the buffers handed to the host-buffer entries (hipHostMalloc / hipHostFree). */
+void *bsc_alloc_host(uint64_t bytes) {
+  void *p = NULL;
+  if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+    bsc_fail(BSC_ERR_NOMEM, "bsc_alloc_host(%llu) failed", (unsigned long long)bytes);
+    return NULL;
+  }
+  return p;
+}
+
+void bsc_free_host(void *p) {
+  if (p) hipHostFree(p);
 }
 
 /* leftmost position of a template (src/call_genotypes.c:183-185) */

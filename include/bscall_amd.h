@@ -119,6 +119,12 @@ int bsc_get_tables(const bsc_context *ctx, double *q_prob_44x5, double *lfact_25
 int bsc_call_sites(bsc_context *ctx, const bsc_pileup *cts, const uint8_t *ref, uint64_t n, void *out,
                    uint32_t out_stride, uint8_t *skip);
 
+/* Pinned (page-locked) host memory for buffers passed to the host-buffer entries: with it the copies of
+ * bsc_call_sites are true DMA transfers that overlap the kernels (three-stage pipeline over 1 Mi-site chunks);
+ * pageable memory works too but is staged by the runtime.  E.g. allocate work->vcf with it. */
+void *bsc_alloc_host(uint64_t bytes);
+void bsc_free_host(void *p);
+
 /*
  * Same computation on device-resident buffers; asynchronous on `stream` (a hipStream_t; NULL = HIP's default
  * stream, e.g. what torch.cuda.current_stream().cuda_stream returns for PyTorch's default stream).  The caller
