@@ -54,8 +54,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # BENCH_REHEARSAL=1: all ranks share cuda:0 and talk over gloo — lets the N > 1 code path be rehearsed on a
+        # one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver; the numbers mean nothing.
+        rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
