@@ -29,6 +29,9 @@
 #include "synth.h"
 
 #define TILE 256
+#ifndef BSC_DMA_AUX
+#define BSC_DMA_AUX 2 /* cache policy bits of the LDS-DMA loads: nt — every pile-up is read exactly once */
+#endif
 #ifndef BSC_UNROLL
 #define BSC_UNROLL 1 /* unroll factor of the rolled log / exp loops */
 #endif
@@ -199,7 +202,7 @@ __device__ static __forceinline__ void get_Z(double x1, double x2, double k1, do
 /* LDS-DMA: 16 bytes per lane, global (per-lane address) -> LDS (wave-uniform base + lane * 16). */
 __device__ static __forceinline__ void dma16(const void *g, void *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, BSC_DMA_AUX);
 }
 
 /*
@@ -305,7 +308,7 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
     const int aq = (int)floorf((float)(0.5 + (double)(tot_qual / nf)));
     const int mq = (int)(0.5 + sqrt((double)(mapq2 / nf)));
 /* table index of class j: its packed quality, clamped to the table (only garbage input exceeds 43) */
-#define QI(j) min(((j) < 4 ? (qpack0 >> (8 * (j))) : (qpack1 >> (8 * ((j)-4)))) & 0xffu, 43u)
+#define QI(j) min((((j) < 4 ? qpack0 : qpack1) >> (8 * ((j)&3))) & 0xffu, 43u)
 #define ND(j) ((double)cnt[j])
 
     /* ---- calc_gt_prob ----
@@ -477,7 +480,10 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
 #pragma unroll
         for (unsigned v = 0; v < 7; v++) {
           const unsigned idx = v * 64u + lane;
-          if (idx < nvec) dst[idx] = srcv[idx];
+          if (idx < nvec) { /* written once, never re-read by this kernel: non-temporal (-2 % kernel time) */
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(srcv)[idx], reinterpret_cast<u32x4 *>(dst) + idx);
+          }
         }
       }
     }
