@@ -230,6 +230,7 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
   __shared__ double s_logtab[256];
   __shared__ unsigned long long s_exptab[256];
   __shared__ unsigned int s_cnt[12]; /* covered, hist[10], het */
+  __shared__ uint8_t s_pairs[TILE / 64][256]; /* per wave: the (lane, class) pairs whose logs are needed */
 
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
@@ -341,9 +342,43 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
       la[7] = has6 ? 0.5 * Z4 + k6 : 2.0;           /*                     AG */
       la[8] = has6 ? 0.5 * Z5 + k6 : 2.0;           /*                     CG, GT */
     }
+#ifdef BSC_NO_COMPACT
 #pragma unroll BSC_UNROLL
     for (int i = 0; i < 12; i++) la[i] = log_dev(la[i], s_logtab);
-
+#else
+    /*
+     * Only the non-empty classes need their three logs (an empty class contributes n * anything = 0), and a site has
+     * 1-2 of the 4 informative classes (A/T sites one, C/G sites two, plus the odd error read).  The (lane, class)
+     * pairs that need evaluating are listed in a 256-byte LDS index (ballot + prefix count, one byte per pair:
+     * class << 6 | lane) and the wave then evaluates 64 pairs at a time, each lane fetching "its" pair's arguments
+     * from the owner lane's area and putting the logs back there: ~2 dense rounds of 3 logs instead of 12 sparse ones.
+     */
+    {
+      uint8_t *lst = s_pairs[wid];
+      unsigned n_pairs = 0; /* wave-uniform */
+      {
+        const bool hasc[4] = {has4, has5, has6, has7};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const unsigned long long m = __ballot(hasc[c]);
+          if (hasc[c]) lst[n_pairs + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)((c << 6) | lane);
+          n_pairs += (unsigned)__popcll(m);
+        }
+      }
+#pragma unroll 1
+      for (unsigned k = 0; k < n_pairs; k += 64) {
+        const bool act = k + lane < n_pairs;
+        const unsigned e = act ? lst[k + lane] : 0u;
+        double *pa = reinterpret_cast<double *>(slot + (e & 63u) * IN_DW) + 3u * (e >> 6);
+#pragma unroll 1
+        for (int t3 = 0; t3 < 3; t3++) {
+          const double xa = act ? pa[t3] : 2.0;
+          const double ya = log_dev(xa, s_logtab);
+          if (act) pa[t3] = ya;
+        }
+      }
+    }
+#endif
     /* prior from the reference base (src/genotype_model.c:87-108); genotype order AA AC AG AT CC CG CT GG GT TT */
     const bool rA = rf == 1, rC = rf == 2, rG = rf == 3, rT = rf == 4;
     double ll0 = rA ? lrb : 0.0, ll4 = rC ? lrb : 0.0, ll7 = rG ? lrb : 0.0, ll9 = rT ? lrb : 0.0;
