@@ -32,6 +32,9 @@
 #ifndef BSC_DMA_AUX
 #define BSC_DMA_AUX 2 /* cache policy bits of the LDS-DMA loads: nt — every pile-up is read exactly once */
 #endif
+#ifndef BSC_T3_UNROLL
+#define BSC_T3_UNROLL 1
+#endif
 #ifndef BSC_UNROLL
 #define BSC_UNROLL 1 /* unroll factor of the rolled log / exp loops */
 #endif
@@ -370,7 +373,7 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
         const bool act = k + lane < n_pairs;
         const unsigned e = act ? lst[k + lane] : 0u;
         double *pa = reinterpret_cast<double *>(slot + (e & 63u) * IN_DW) + 3u * (e >> 6);
-#pragma unroll 1
+#pragma unroll BSC_T3_UNROLL
         for (int t3 = 0; t3 < 3; t3++) {
           const double xa = act ? pa[t3] : 2.0;
           const double ya = log_dev(xa, s_logtab);
