@@ -235,3 +235,22 @@ def test_device_resident_api_and_generator(caller, oracle, tables, libm_exact):
     caller.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out2.data_ptr(), d_skip.data_ptr(), 200, st)
     torch.cuda.synchronize()
     assert torch.equal(d_out, d_out2)
+
+
+def test_pipelined_host_path_multi_chunk(caller, oracle, tables, libm_exact):
+    """bsc_call_sites pipelines 1 Mi-site chunks over two buffer sets: 3 chunks (last one ragged), pageable and pinned
+    buffers, both gt_meth and gt_vcf strides."""
+    n = 2 * (1 << 20) + 12_345
+    pile, ref = B.synth_pileup_host(SEED + 77, 0, n, 10)
+    exp, eskip = oracle.call_sites(pile, ref, tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
+    got, skip = caller.call_sites(pile, ref)
+    _assert_exact(got, skip, exp, eskip)
+    bufs = [B.PinnedBuffer(n, B.PILEUP), B.PinnedBuffer(n, np.uint8), B.PinnedBuffer((n, 208), np.uint8), B.PinnedBuffer(n, np.uint8)]
+    try:
+        bufs[0].array[:] = pile
+        bufs[1].array[:] = ref
+        raw, skip2 = caller.call_sites(bufs[0].array, bufs[1].array, out_stride=208, out=bufs[2].array, skip=bufs[3].array)
+        assert raw[:, :200].tobytes() == exp.tobytes() and (skip2 == eskip).all() and (raw[:, 201] == eskip).all()
+    finally:
+        for b in bufs:
+            b.free()
