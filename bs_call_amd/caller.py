@@ -113,6 +113,24 @@ class SiteCaller:
                                       _ptr(out), out_stride, _ptr(skip)))
         return out, skip
 
+    def block_submit(self, templates, seq, x, y, ref, out_stride=200):
+        """Queue one block (accumulate + call) and return at once; the inputs may be reused immediately."""
+        templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        if len(ref) != int(y) - int(x) + 1:
+            raise ValueError("ref must have y - x + 1 entries")
+        _check(self._L.bsc_block_submit(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref), out_stride))
+        self._pending = (int(y) - int(x) + 1, out_stride)
+
+    def block_fetch(self):
+        """Wait for the submitted block and return (GT_METH[n] or uint8[n, stride], skip)."""
+        n, stride = self._pending
+        out = np.zeros(n, dtype=GT_METH) if stride == 200 else np.zeros((n, stride), dtype=np.uint8)
+        skip = np.zeros(n, dtype=np.uint8)
+        _check(self._L.bsc_block_fetch(self._h, _ptr(out), _ptr(skip)))
+        return out, skip
+
     # -- VCF record formation (src/print_vcf.c:32-381) -------------------------------------------------
     def vcf_records(self, gtm, skip, ref, x, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None):
         """gtm: GT_METH[n] (or uint8[n, 208]) for positions x..x+n-1; ref: uint8[n+2] codes of x..x+n+1 -> VCF_CORE[n]."""

@@ -56,6 +56,10 @@ struct bsc_context {
   size_t cap_tpl, cap_seq, cap_rd, cap_x1, cap_lo;
   void *d_vg, *d_vout, *d_vdb; /* VCF record formation: called genotypes, records, dbSNP flags */
   size_t cap_vg, cap_vout, cap_vdb;
+  void *h_stage;     /* pinned staging of a submitted block's inputs (templates, reads, ref codes) */
+  size_t cap_stage;
+  uint64_t pending_sz;      /* positions of the submitted, not yet fetched block (0 = none) */
+  uint32_t pending_stride;
   bsc_template *h_sorted; /* host scratch for an unsorted template list */
   size_t cap_sorted;
   /* host-buffer pipeline of bsc_call_sites: two chunk buffers, copy streams, events */
@@ -209,6 +213,7 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_vout);
   hipFree(ctx->d_vdb);
   free(ctx->h_sorted);
+  if (ctx->h_stage) hipHostFree(ctx->h_stage);
   for (int i = 0; i < 3; i++)
     if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   free(ctx);
@@ -368,8 +373,30 @@ static int bsc_cmp_leftmost(const void *a, const void *b) {
 
 /* Validates the block (the reference's asserts), uploads it and queues the accumulate kernels: the pile-up of
  * x..y ends up in ctx->d_cts.  *inexact_before receives the counter value to compare against afterwards. */
+static int bsc_stage_reserve(bsc_context *ctx, size_t need) {
+  if (need <= ctx->cap_stage) return BSC_OK;
+  if (ctx->h_stage) hipHostFree(ctx->h_stage);
+  ctx->h_stage = NULL;
+  ctx->cap_stage = 0;
+  size_t sz = need + need / 4;
+  if (hipHostMalloc(&ctx->h_stage, sz, hipHostMallocDefault) != hipSuccess)
+    return bsc_fail(BSC_ERR_NOMEM, "hipHostMalloc(%zu) failed", sz);
+  ctx->cap_stage = sz;
+  return BSC_OK;
+}
+
+/* `stage` != 0: the inputs are first copied into the context's pinned staging area so that the caller's buffers can be
+ * recycled as soon as the call returns and the H2D copies are true asynchronous DMA (bsc_block_submit). */
+static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq,
+                                 uint64_t seq_bytes, uint32_t x, uint32_t y, const uint8_t *ref, int stage);
+
 static int bsc_accumulate_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq,
                                 uint64_t seq_bytes, uint32_t x, uint32_t y) {
+  return bsc_accumulate_queue2(ctx, tpl, nr, seq, seq_bytes, x, y, NULL, 0);
+}
+
+static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq,
+                                 uint64_t seq_bytes, uint32_t x, uint32_t y, const uint8_t *ref, int stage) {
   if (y < x) return bsc_fail(BSC_ERR_ARG, "accumulate: y (%u) < x (%u) (reference asserts y >= x)", y, x);
   if (nr && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "accumulate: NULL template or read buffer");
   int sorted = 1;
@@ -407,6 +434,24 @@ static int bsc_accumulate_queue(bsc_context *ctx, const bsc_template *tpl, uint3
   if ((rc = bsc_reserve(&ctx->d_rd, &ctx->cap_rd, (size_t)(nr ? nr : 1) * 48u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_x1, &ctx->cap_x1, (size_t)(nr ? nr : 1) * 4u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
+  if (stage) {
+    /* the previous block's copies out of the staging area have completed: bsc_block_fetch synchronised the stream */
+    const size_t b_tpl = (size_t)nr * sizeof(bsc_template), b_seq = (size_t)seq_bytes, b_ref = ref ? (size_t)sz : 0;
+    const size_t o_seq = (b_tpl + 63u) & ~(size_t)63u, o_ref = (o_seq + b_seq + 63u) & ~(size_t)63u;
+    if ((rc = bsc_stage_reserve(ctx, o_ref + b_ref + 64u))) return rc;
+    char *st = ctx->h_stage;
+    if (nr) {
+      memcpy(st, tpl, b_tpl);
+      memcpy(st + o_seq, seq, b_seq);
+      tpl = (const bsc_template *)st;
+      seq = (const uint8_t *)(st + o_seq);
+    }
+    if (ref) {
+      memcpy(st + o_ref, ref, b_ref);
+      if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)sz))) return rc;
+      HIP_TRY(hipMemcpyAsync(ctx->d_ref, st + o_ref, b_ref, hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
   if (nr) {
     HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -500,6 +545,37 @@ int bsc_vcf_records(bsc_context *ctx, const void *gtm, uint32_t gtm_stride, cons
   HIP_TRY(hipMemcpyAsync(out, ctx->d_vout, (size_t)n * sizeof(bsc_vcf_core), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return BSC_OK;
+}
+
+/* Asynchronous form of bsc_call_block: queue the block and return; the results stay in HBM until bsc_block_fetch. */
+int bsc_block_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                     uint32_t x, uint32_t y, const uint8_t *ref, uint32_t out_stride) {
+  if (!ctx || !ref) return bsc_fail(BSC_ERR_ARG, "bsc_block_submit: NULL argument");
+  if (ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_submit: the previous block has not been fetched");
+  int rc = bsc_check_stride(out_stride);
+  if (rc) return rc;
+  if (y < x) return bsc_fail(BSC_ERR_ARG, "bsc_block_submit: y (%u) < x (%u)", y, x);
+  if ((rc = bsc_accumulate_queue2(ctx, tpl, nr, seq, seq_bytes, x, y, ref, 1))) return rc;
+  const uint64_t sz = (uint64_t)y - x + 1;
+  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)sz * out_stride))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)sz))) return rc;
+  if ((rc = bsc_call_sites_device(ctx, ctx->d_cts, ctx->d_ref, sz, ctx->d_out, out_stride, ctx->d_skip, ctx->stream)))
+    return rc;
+  ctx->pending_sz = sz;
+  ctx->pending_stride = out_stride;
+  return BSC_OK;
+}
+
+int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
+  if (!ctx || !out || !skip) return bsc_fail(BSC_ERR_ARG, "bsc_block_fetch: NULL argument");
+  if (!ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_fetch: no block was submitted");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const uint64_t sz = ctx->pending_sz;
+  ctx->pending_sz = 0;
+  HIP_TRY(hipMemcpyAsync(out, ctx->d_out, (size_t)sz * ctx->pending_stride, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(skip, ctx->d_skip, (size_t)sz, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return bsc_inexact_status(ctx);
 }
 
 int bsc_set_profiling(bsc_context *ctx, int enable) {

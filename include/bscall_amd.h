@@ -158,6 +158,19 @@ int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
                    uint32_t x, uint32_t y, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip);
 
 /*
+ * Asynchronous form of bsc_call_block, mirroring how call_genotypes_ML() dispatches a block to the calc threads and
+ * returns at once (src/call_genotypes.c:260-272) so that the process thread can prepare the next block meanwhile:
+ *   bsc_block_submit  validates, copies the block's inputs into pinned staging (tpl / seq / ref may be recycled when it
+ *                     returns, as the reference's align_list is), queues copy + accumulate + call, returns;
+ *   bsc_block_fetch   waits for that block and copies its records into out / skip (sizes as submitted); returns
+ *                     BSC_WARN_INEXACT like bsc_accumulate.
+ * One block in flight per context, as in the reference (src/call_genotypes.c:161-168).
+ */
+int bsc_block_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                     uint32_t x, uint32_t y, const uint8_t *ref, uint32_t out_stride);
+int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip);
+
+/*
  * VCF record formation: what the reference's print thread derives from a block's gt_meth records before it hands a
  * record to htslib (_print_vcf_entry, src/print_vcf.c:32-381, with the 5-site window of print_vcf_entry /
  * flush_vcf_entries, :529-594).  One 64-byte bsc_vcf_core per position; a host formatter turns the records with

@@ -137,3 +137,29 @@ def test_call_block_parity(caller, oracle, tables, libm_exact):
         assert (skip == eskip).all() and got.tobytes() == exp.tobytes()
         raw, skip2 = caller.call_block(tpl, seq, x, y, ref, out_stride=208)
         assert raw[:, :200].tobytes() == exp.tobytes() and (raw[:, 201] == eskip).all()
+
+
+def test_async_block_submit_fetch(caller, oracle, tables, libm_exact):
+    """bsc_block_submit / bsc_block_fetch: the inputs are staged at submit (the caller may scribble over them right
+    away, as bs_call recycles its align_list), one block in flight, results as bsc_call_block."""
+    flav = oracle.LIBM if libm_exact else oracle.BSM
+    blocks = []
+    for i, (cov, n, x0) in enumerate(((30, 60_000, 5_000), (10, 100_000, 900_000), (30, 777, 2_000_000))):
+        tpl, seq, x, y = _block(SEED + 40 + i, x0, n, cov)
+        ref = B.synth_ref_host(SEED + 40 + i, x, y - x + 1)
+        rc, pile = oracle.accumulate(tpl, seq, x, y, 20)
+        exp, eskip = oracle.call_sites(pile, ref, tables, flav, -8)
+        blocks.append((tpl, seq, x, y, ref, exp, eskip))
+    for tpl, seq, x, y, ref, exp, eskip in blocks:
+        t2, s2, r2 = tpl.copy(), seq.copy(), ref.copy()
+        caller.block_submit(t2, s2, x, y, r2)
+        t2["pos"][:] = 0  # recycle the inputs while the block is in flight
+        s2[:] = 0
+        r2[:] = 0
+        with pytest.raises(B.BscError):  # one block in flight
+            caller.block_submit(tpl, seq, x, y, ref)
+        got, skip = caller.block_fetch()
+        assert (skip == eskip).all() and got.tobytes() == exp.tobytes()
+    with pytest.raises(B.BscError):
+        caller._pending = (1, 200)
+        caller.block_fetch()
