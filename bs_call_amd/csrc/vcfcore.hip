@@ -5,9 +5,10 @@
  *
  * The reference walks a block position by position with static window state.  Inside a block that state is a pure
  * function of the position, so the work is per-site parallel:
- *   pass 1 (bsc_vcf_gt_kernel):   g[i] = 0 for a skipped position, else 1 + first-max argmax of gt_prob[] (the
+ *   pass 1 (fused, per 256-position tile + 2 halo positions each side, through LDS):
+ *                                 g[i] = 0 for a skipped position, else 1 + first-max argmax of gt_prob[] (the
  *                                 printer recomputes the argmax from gt_prob, :584-591);
- *   pass 2 (bsc_vcf_core_kernel): window of called genotypes [g(i-2) .. g(i+2)], where positions outside the block
+ *   pass 2:                       window of called genotypes [g(i-2) .. g(i+2)], where positions outside the block
  *                                 read 0 — except that the two positions flushed at the end of a block see the LAST
  *                                 genotype repeated to their right (flush_vcf_entries shifts its 5-byte window with a
  *                                 4-byte memmove and never clears the vacated slot, :540);
@@ -49,42 +50,52 @@ __device__ static __forceinline__ void alleles(int g, int &a, int &b) {
 __device__ static __forceinline__ bool has_c(int g) { int a, b; alleles(g, a, b); return a == 2 || b == 2; }
 __device__ static __forceinline__ bool has_g(int g) { int a, b; alleles(g, a, b); return a == 3 || b == 3; }
 
-extern "C" __global__ __launch_bounds__(256) void bsc_vcf_gt_kernel(const uint8_t *__restrict__ gtm, uint32_t stride,
-                                                                    const uint8_t *__restrict__ skip, uint32_t n,
-                                                                    uint8_t *__restrict__ g) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    uint8_t r = 0;
-    if (!skip[i]) {
-      const double *gp = reinterpret_cast<const double *>(gtm + (uint64_t)i * stride + 96);
-      double z = gp[0];
-      int gt = 0;
+/* 0 for a skipped position, else 1 + first-max argmax of gt_prob[] (src/print_vcf.c:584-591) */
+__device__ static __forceinline__ int called_gt(const uint8_t *__restrict__ gtm, uint32_t stride,
+                                                const uint8_t *__restrict__ skip, uint32_t i) {
+  if (skip[i]) return 0;
+  const double *gp = reinterpret_cast<const double *>(gtm + (uint64_t)i * stride + 96);
+  double z = gp[0];
+  int gt = 0;
 #pragma unroll
-      for (int k = 1; k < 10; k++) {
-        const double v = gp[k];
-        if (v > z) { z = v; gt = k; }
-      }
-      r = (uint8_t)(gt + 1);
-    }
-    g[i] = r;
+  for (int k = 1; k < 10; k++) {
+    const double v = gp[k];
+    if (v > z) { z = v; gt = k; }
   }
+  return gt + 1;
 }
 
-extern "C" __global__ __launch_bounds__(256) void bsc_vcf_core_kernel(
-    const uint8_t *__restrict__ gtm, uint32_t stride, const uint8_t *__restrict__ g, const uint8_t *__restrict__ ref,
+#define VT 256 /* positions per workgroup */
+
+extern "C" __global__ __launch_bounds__(VT) void bsc_vcf_core_kernel(
+    const uint8_t *__restrict__ gtm, uint32_t stride, const uint8_t *__restrict__ skip, const uint8_t *__restrict__ ref,
     const uint8_t *__restrict__ dbsnp, uint32_t n, uint32_t x, int all_positions, uint32_t reg_start, uint32_t reg_stop,
     const bsc_dev_tables *__restrict__ tb, bsc_vcf_core_dev *__restrict__ out) {
   __shared__ double s_logtab[256];
   __shared__ unsigned long long s_exptab[256];
+  __shared__ uint8_t s_g[VT + 4]; /* called genotypes of the tile and of 2 positions on either side */
   s_logtab[threadIdx.x] = tb->log_tab[threadIdx.x];
   s_exptab[threadIdx.x] = tb->exp_tab[threadIdx.x];
-  __syncthreads();
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  const uint32_t n_tiles = (n + VT - 1) / VT;
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t base = tile * VT;
+    const uint32_t i = base + threadIdx.x;
+    __syncthreads(); /* tables on the first pass; s_g free again on later ones */
+    /* pass 1 (fused): every thread calls its own position; four threads also call the halo */
+    s_g[threadIdx.x + 2] = i < n ? (uint8_t)called_gt(gtm, stride, skip, i) : 0;
+    if (threadIdx.x < 4) {
+      const int64_t j = threadIdx.x < 2 ? (int64_t)base - 2 + threadIdx.x : (int64_t)base + VT + (threadIdx.x - 2);
+      s_g[threadIdx.x < 2 ? threadIdx.x : VT + threadIdx.x] = (j >= 0 && j < (int64_t)n) ? (uint8_t)called_gt(gtm, stride, skip, (uint32_t)j) : 0;
+    }
+    __syncthreads();
+    if (i >= n) continue;
+#define G(j) s_g[(int64_t)(j) - (int64_t)base + 2] /* valid for base-2 <= j < base+VT+2 */
     bsc_vcf_core_dev o;
     {
       uint4 *z4 = reinterpret_cast<uint4 *>(&o);
       z4[0] = z4[1] = z4[2] = z4[3] = make_uint4(0, 0, 0, 0);
     }
-    const int gt1 = g[i];
+    const int gt1 = G(i);
     const uint8_t *rec = gtm + (uint64_t)i * stride;
     const uint64_t *counts = reinterpret_cast<const uint64_t *>(rec);
     uint32_t dp1 = 0, d_inf = 0;
@@ -100,8 +111,9 @@ extern "C" __global__ __launch_bounds__(256) void bsc_vcf_core_kernel(
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         const int64_t j = (int64_t)i - 2 + k;
-        int v = (j >= 0 && j <= (int64_t)last) ? g[j] : 0;
-        if (j > (int64_t)last && i + 2 > last) v = g[last]; /* the flushed positions see the last genotype repeated */
+        int v = (j >= 0 && j <= (int64_t)last) ? G(j) : 0;
+        if (j > (int64_t)last && i + 2 > last) v = G(last); /* the flushed positions see the last genotype repeated
+                                                               (last is i or i+1 here: inside this tile's halo) */
         gs[k] = v;
       }
       int rc[5];
@@ -238,18 +250,17 @@ extern "C" __global__ __launch_bounds__(256) void bsc_vcf_core_kernel(
   }
 }
 
+#undef G
+
 extern "C" int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const void *ref, const void *dbsnp,
                                   uint32_t n, uint32_t x, int all_positions, uint32_t reg_start, uint32_t reg_stop,
-                                  const void *tb, void *g, void *out, int num_cus, void *stream) {
+                                  const void *tb, void *g_unused, void *out, int num_cus, void *stream) {
+  (void)g_unused;
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  unsigned grid = (n + 255u) / 256u;
+  unsigned grid = (n + VT - 1u) / VT;
   if (grid > (unsigned)num_cus * 16u) grid = (unsigned)num_cus * 16u;
-  hipLaunchKernelGGL(bsc_vcf_gt_kernel, dim3(grid), dim3(256), 0, s, (const uint8_t *)gtm, stride, (const uint8_t *)skip, n,
-                     (uint8_t *)g);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(bsc_vcf_core_kernel, dim3(grid), dim3(256), 0, s, (const uint8_t *)gtm, stride, (const uint8_t *)g,
+  hipLaunchKernelGGL(bsc_vcf_core_kernel, dim3(grid), dim3(VT), 0, s, (const uint8_t *)gtm, stride, (const uint8_t *)skip,
                      (const uint8_t *)ref, (const uint8_t *)dbsnp, n, x, all_positions, reg_start, reg_stop,
                      (const bsc_dev_tables *)tb, (bsc_vcf_core_dev *)out);
   return (int)hipGetLastError();
