@@ -300,11 +300,14 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
       cnt[j] = w[j] + w[8 + j];
       const float qs = __uint_as_float(w[17 + j]);
       const bool has = cnt[j] != 0;
-      const float nn = has ? (float)cnt[j] : 1.0f;
+      const float nn = (float)max(cnt[j], 1u);
+      /* f32 divide, promoted to f64 for the +0.5, rounded back to f32 by floorf's parameter.  Evaluated for every
+       * lane (the empty asm keeps the compiler from wrapping each of the eight divisions in its own exec-mask
+       * branch: every class is non-empty somewhere in a 64-site tile, so the branches never skip anything). */
+      int q = (int)floorf((float)(0.5 + (double)(qs / nn)));
+      asm volatile("" : "+v"(q));
       tot_qual += has ? qs : 0.0f;
-      /* f32 divide, promoted to f64 for the +0.5, rounded back to f32 by floorf's parameter */
-      const int q = has ? (int)floorf((float)(0.5 + (double)(qs / nn))) : 0;
-      const uint32_t qb = (uint32_t)q & 0xffu;
+      const uint32_t qb = has ? ((uint32_t)q & 0xffu) : 0u;
       if (j < 4) qpack0 |= qb << (8 * j);
       else qpack1 |= qb << (8 * (j - 4));
     }
@@ -321,7 +324,13 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
      * 10 exp() of the normalisation likewise: one code instance each instead of 23, a fraction of the
      * registers, and the independent chains of the other waves on the SIMD hide the latency. */
     double *la = reinterpret_cast<double *>(slot + lane * IN_DW);
-    const bool has4 = cnt[4] != 0, has5 = cnt[5] != 0, has6 = cnt[6] != 0, has7 = cnt[7] != 0;
+    bool has4, has5, has6, has7;
+    { /* recomputed from laundered copies: otherwise the compiler keeps the summary's eight compare masks alive in
+       * SGPR pairs that it then spills to VGPR lanes (4 extra VALU per class) */
+      uint32_t c4 = cnt[4], c5 = cnt[5], c6 = cnt[6], c7 = cnt[7];
+      asm volatile("" : "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7));
+      has4 = c4 != 0; has5 = c5 != 0; has6 = c6 != 0; has7 = c7 != 0;
+    }
     { /* methylation estimates (src/genotype_model.c:165-171), one strand at a time to keep few values live;
        * the Z of an empty class pair is never used.  C2T reads: classes 5 (C) and 7 (T) */
       const double k5 = s_k[QI(5)], k7 = s_k[QI(7)];
