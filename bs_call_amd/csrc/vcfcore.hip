@@ -5,7 +5,7 @@
  *
  * The reference walks a block position by position with static window state.  Inside a block that state is a pure
  * function of the position, so the work is per-site parallel:
- *   pass 1 (fused, per 256-position tile + 2 halo positions each side, through LDS):
+ *   pass 1 (fused, per 64-position wave-tile + 2 halo positions each side, through LDS):
  *                                 g[i] = 0 for a skipped position, else 1 + first-max argmax of gt_prob[] (the
  *                                 printer recomputes the argmax from gt_prob, :584-591);
  *   pass 2:                       window of called genotypes [g(i-2) .. g(i+2)], where positions outside the block
@@ -50,11 +50,9 @@ __device__ static __forceinline__ void alleles(int g, int &a, int &b) {
 __device__ static __forceinline__ bool has_c(int g) { int a, b; alleles(g, a, b); return a == 2 || b == 2; }
 __device__ static __forceinline__ bool has_g(int g) { int a, b; alleles(g, a, b); return a == 3 || b == 3; }
 
-/* 0 for a skipped position, else 1 + first-max argmax of gt_prob[] (src/print_vcf.c:584-591) */
-__device__ static __forceinline__ int called_gt(const uint8_t *__restrict__ gtm, uint32_t stride,
-                                                const uint8_t *__restrict__ skip, uint32_t i) {
-  if (skip[i]) return 0;
-  const double *gp = reinterpret_cast<const double *>(gtm + (uint64_t)i * stride + 96);
+/* first-max argmax of gt_prob[] + 1 (src/print_vcf.c:584-591); gp points at the record's gt_prob (LDS or global) */
+template <typename P>
+__device__ static __forceinline__ int argmax1(P gp) {
   double z = gp[0];
   int gt = 0;
 #pragma unroll
@@ -65,38 +63,82 @@ __device__ static __forceinline__ int called_gt(const uint8_t *__restrict__ gtm,
   return gt + 1;
 }
 
-#define VT 256 /* positions per workgroup */
+/* 0 for a skipped or out-of-block position, else the called genotype + 1, read from global memory (halo positions) */
+__device__ static __forceinline__ int called_gt_global(const uint8_t *__restrict__ gtm, uint32_t stride,
+                                                       const uint8_t *__restrict__ skip, int64_t j, uint32_t n) {
+  if (j < 0 || j >= (int64_t)n || skip[j]) return 0;
+  return argmax1(reinterpret_cast<const double *>(gtm + (uint64_t)j * stride + 96));
+}
 
-extern "C" __global__ __launch_bounds__(VT) void bsc_vcf_core_kernel(
+#define VW 4                 /* waves per workgroup */
+#define VSLOT_DW (64 * 52)   /* per-wave record slot: 64 records of up to 208 bytes */
+
+/* LDS-DMA: 16 bytes per lane, global (per-lane address) -> LDS (wave-uniform base + lane * 16); nt: read once */
+__device__ static __forceinline__ void vdma16(const void *g, void *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2);
+}
+
+/*
+ * One wave per 64-position wave-tile, no workgroup barrier after the table set-up.  The tile's 64 records (12 800 or
+ * 13 312 contiguous bytes) arrive in the wave's LDS slot by LDS-DMA and each lane works on its own record there (stride
+ * 50 / 52 dwords: at most 2-way conflicts); the 64-byte results are collected in a second LDS area and leave with
+ * 16-byte-per-lane stores.  The called genotypes of the tile go through 68 LDS bytes (2 halo positions each side, which
+ * four lanes fetch from global memory).
+ */
+extern "C" __global__ __launch_bounds__(64 * VW) void bsc_vcf_core_kernel(
     const uint8_t *__restrict__ gtm, uint32_t stride, const uint8_t *__restrict__ skip, const uint8_t *__restrict__ ref,
     const uint8_t *__restrict__ dbsnp, uint32_t n, uint32_t x, int all_positions, uint32_t reg_start, uint32_t reg_stop,
     const bsc_dev_tables *__restrict__ tb, bsc_vcf_core_dev *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_slot[VW][VSLOT_DW];
+  __shared__ __attribute__((aligned(16))) uint32_t s_out[VW][64 * 16];
   __shared__ double s_logtab[256];
   __shared__ unsigned long long s_exptab[256];
-  __shared__ uint8_t s_g[VT + 4]; /* called genotypes of the tile and of 2 positions on either side */
+  __shared__ uint8_t s_gw[VW][72];
   s_logtab[threadIdx.x] = tb->log_tab[threadIdx.x];
   s_exptab[threadIdx.x] = tb->exp_tab[threadIdx.x];
-  const uint32_t n_tiles = (n + VT - 1) / VT;
-  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint32_t base = tile * VT;
-    const uint32_t i = base + threadIdx.x;
-    __syncthreads(); /* tables on the first pass; s_g free again on later ones */
-    /* pass 1 (fused): every thread calls its own position; four threads also call the halo */
-    s_g[threadIdx.x + 2] = i < n ? (uint8_t)called_gt(gtm, stride, skip, i) : 0;
-    if (threadIdx.x < 4) {
-      const int64_t j = threadIdx.x < 2 ? (int64_t)base - 2 + threadIdx.x : (int64_t)base + VT + (threadIdx.x - 2);
-      s_g[threadIdx.x < 2 ? threadIdx.x : VT + threadIdx.x] = (j >= 0 && j < (int64_t)n) ? (uint8_t)called_gt(gtm, stride, skip, (uint32_t)j) : 0;
+  __syncthreads();
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t *slot = s_slot[wid];
+  uint8_t *sg = s_gw[wid];
+  const uint32_t sdw = stride / 4u;
+  const uint32_t n_wt = (n + 63u) / 64u;
+  const bool aligned = ((uintptr_t)gtm & 15u) == 0;
+  for (uint32_t wt = blockIdx.x * VW + wid; wt < n_wt; wt += gridDim.x * VW) {
+    const uint32_t site0 = wt * 64u;
+    const uint32_t i = site0 + lane;
+    const bool valid = i < n;
+    const bool full = site0 + 64u <= n && aligned; /* wave-uniform */
+    /* ---- the tile's records -> slot ---- */
+    if (full) {
+      const char *src = reinterpret_cast<const char *>(gtm + (uint64_t)site0 * stride) + lane * 16;
+      const uint32_t n16 = 64u * stride / 16u; /* 800 or 832 */
+#pragma unroll
+      for (int j = 0; j < 13; j++)
+        if (j * 64u + lane < n16) vdma16(src + j * 1024, slot + j * 256);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (valid) { /* ragged last tile / unaligned base: each lane copies its own record */
+      const uint32_t *g32 = reinterpret_cast<const uint32_t *>(gtm + (uint64_t)i * stride);
+      for (uint32_t k = 0; k < 50u; k++) slot[lane * sdw + k] = g32[k];
     }
-    __syncthreads();
-    if (i >= n) continue;
-#define G(j) s_g[(int64_t)(j) - (int64_t)base + 2] /* valid for base-2 <= j < base+VT+2 */
+    const uint32_t *rec32 = slot + lane * sdw;
+    const double *gp = reinterpret_cast<const double *>(rec32 + 24);
+    /* ---- called genotypes of the tile + halo ---- */
+    const int g_own = (valid && !skip[i]) ? argmax1(gp) : 0;
+    sg[lane + 2] = (uint8_t)g_own;
+    if (lane < 4) {
+      const int64_t j = lane < 2 ? (int64_t)site0 - 2 + lane : (int64_t)site0 + 62 + lane;
+      sg[lane < 2 ? lane : 64 + lane] = (uint8_t)called_gt_global(gtm, stride, skip, j, n);
+    }
+#define G(j) sg[(int64_t)(j) - (int64_t)site0 + 2] /* valid for site0-2 <= j < site0+66 */
     bsc_vcf_core_dev o;
     {
       uint4 *z4 = reinterpret_cast<uint4 *>(&o);
       z4[0] = z4[1] = z4[2] = z4[3] = make_uint4(0, 0, 0, 0);
     }
-    const int gt1 = G(i);
-    const uint8_t *rec = gtm + (uint64_t)i * stride;
+    const int gt1 = valid ? (int)G(i) : 0;
+    const uint8_t *rec = reinterpret_cast<const uint8_t *>(rec32); /* my record, in LDS */
     const uint64_t *counts = reinterpret_cast<const uint64_t *>(rec);
     uint32_t dp1 = 0, d_inf = 0;
 #pragma unroll
@@ -141,7 +183,6 @@ extern "C" __global__ __launch_bounds__(VT) void bsc_vcf_core_kernel(
       const bool het = ga != gb;
       bool skip = !all_positions && !(rs_found & 2) && ((gt == 0 && rfix == 1) || (gt == 9 && rfix == 4));
       /* ---- phred (:140-148) ---- */
-      const double *gp = reinterpret_cast<const double *>(rec + 96);
       const double z1 = bsm_exp_t(gp[gt] * BSM_LN10, (const uint64_t *)s_exptab);
       int phred;
       if (z1 >= 1.0) phred = 255;
@@ -242,10 +283,19 @@ extern "C" __global__ __launch_bounds__(VT) void bsc_vcf_core_kernel(
         for (int k = 0; k < 6; k++) o.gl[k] = k < ngl ? gl[k] : 0.0f;
       }
     }
+    /* ---- results: own 64-byte record -> LDS, then the tile's 4 KiB leave contiguously ---- */
     {
-      uint4 *d4 = reinterpret_cast<uint4 *>(out + i);
+      uint4 *so = reinterpret_cast<uint4 *>(s_out[wid]);
       const uint4 *s4 = reinterpret_cast<const uint4 *>(&o);
-      d4[0] = s4[0]; d4[1] = s4[1]; d4[2] = s4[2]; d4[3] = s4[3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) so[lane * 4 + k] = s4[k];
+      const uint32_t nvec = (n - site0 < 64u ? n - site0 : 64u) * 4u;
+      uint4 *d4 = reinterpret_cast<uint4 *>(out + site0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t idx = k * 64u + lane;
+        if (idx < nvec) d4[idx] = so[idx];
+      }
     }
   }
 }
@@ -258,10 +308,11 @@ extern "C" int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *
   (void)g_unused;
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  unsigned grid = (n + VT - 1u) / VT;
-  if (grid > (unsigned)num_cus * 16u) grid = (unsigned)num_cus * 16u;
-  hipLaunchKernelGGL(bsc_vcf_core_kernel, dim3(grid), dim3(VT), 0, s, (const uint8_t *)gtm, stride, (const uint8_t *)skip,
-                     (const uint8_t *)ref, (const uint8_t *)dbsnp, n, x, all_positions, reg_start, reg_stop,
-                     (const bsc_dev_tables *)tb, (bsc_vcf_core_dev *)out);
+  const unsigned n_wt = (n + 63u) / 64u;
+  unsigned grid = (n_wt + VW - 1u) / VW;
+  if (grid > (unsigned)num_cus * 2u * 8u) grid = (unsigned)num_cus * 2u * 8u; /* 2 workgroups (74 KB LDS) per CU */
+  hipLaunchKernelGGL(bsc_vcf_core_kernel, dim3(grid), dim3(64 * VW), 0, s, (const uint8_t *)gtm, stride,
+                     (const uint8_t *)skip, (const uint8_t *)ref, (const uint8_t *)dbsnp, n, x, all_positions, reg_start,
+                     reg_stop, (const bsc_dev_tables *)tb, (bsc_vcf_core_dev *)out);
   return (int)hipGetLastError();
 }
