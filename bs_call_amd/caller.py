@@ -91,15 +91,17 @@ class SiteCaller:
         return out, skip
 
     # -- reads -> pile-up (HOT LOOP A) and whole blocks ------------------------------------------------
-    def accumulate(self, templates, seq, x, y):
-        """templates: TEMPLATE[nr]; seq: uint8 read bytes; positions x..y inclusive -> PILEUP[y-x+1]."""
+    def accumulate(self, templates, seq, x, y, out=None):
+        """templates: TEMPLATE[nr]; seq: uint8 read bytes; positions x..y inclusive -> PILEUP[y-x+1].
+        `out`: optional preallocated PILEUP array (reusing one avoids first-touch page faults in timing loops)."""
         templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
-        out = np.zeros(max(int(y) - int(x) + 1, 1), dtype=PILEUP)
+        if out is None:
+            out = np.zeros(max(int(y) - int(x) + 1, 1), dtype=PILEUP)
         _check(self._L.bsc_accumulate(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(out)))
         return out[: max(int(y) - int(x) + 1, 0)]
 
-    def call_block(self, templates, seq, x, y, ref, out_stride=200):
+    def call_block(self, templates, seq, x, y, ref, out_stride=200, out=None, skip=None):
         """One call_genotypes_ML block: accumulate + call.  ref: uint8[y-x+1] codes -> (GT_METH[..], skip)."""
         templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
@@ -107,8 +109,10 @@ class SiteCaller:
         n = int(y) - int(x) + 1
         if len(ref) != n:
             raise ValueError("ref must have y - x + 1 entries")
-        out = np.zeros(n, dtype=GT_METH) if out_stride == 200 else np.zeros((n, out_stride), dtype=np.uint8)
-        skip = np.zeros(n, dtype=np.uint8)
+        if out is None:
+            out = np.zeros(n, dtype=GT_METH) if out_stride == 200 else np.zeros((n, out_stride), dtype=np.uint8)
+        if skip is None:
+            skip = np.zeros(n, dtype=np.uint8)
         _check(self._L.bsc_call_block(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref),
                                       _ptr(out), out_stride, _ptr(skip)))
         return out, skip

@@ -485,6 +485,38 @@ int bsc_accumulate(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
   return bsc_inexact_status(ctx);
 }
 
+/* Calls n device-resident pile-ups (queued behind whatever is on the context's stream) in chunks and copies each
+ * chunk's records to the host while the next chunk is being called (two output buffer sets, copy stream s_out). */
+static int bsc_call_resident_to_host(bsc_context *ctx, const void *d_cts, const void *d_ref, uint64_t n, void *out,
+                                     uint32_t out_stride, uint8_t *skip) {
+  int rc = bsc_pipe_init(ctx);
+  if (rc) return rc;
+  const uint64_t chunk = n < BSC_PIPE_CHUNK ? n : BSC_PIPE_CHUNK;
+  const int nbuf = n > chunk ? 2 : 1;
+  for (int b = 0; b < nbuf; b++) {
+    if ((rc = bsc_reserve(&ctx->p_out[b], &ctx->p_cap_out[b], (size_t)chunk * out_stride))) return rc;
+    if ((rc = bsc_reserve(&ctx->p_skip[b], &ctx->p_cap_skip[b], (size_t)chunk))) return rc;
+  }
+  uint64_t k = 0;
+  for (uint64_t done = 0; done < n; done += chunk, k++) {
+    const int b = (int)(k & 1);
+    const uint64_t m = (n - done) < chunk ? (n - done) : chunk;
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_out[b], 0)); /* buffer set b has left */
+    rc = bsc_call_sites_device(ctx, (const char *)d_cts + done * 104u, (const char *)d_ref + done, m, ctx->p_out[b],
+                               out_stride, ctx->p_skip[b], ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_k[b], ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->s_out, ctx->ev_k[b], 0));
+    HIP_TRY(hipMemcpyAsync((char *)out + done * out_stride, ctx->p_out[b], (size_t)m * out_stride, hipMemcpyDeviceToHost,
+                           ctx->s_out));
+    HIP_TRY(hipMemcpyAsync(skip + done, ctx->p_skip[b], (size_t)m, hipMemcpyDeviceToHost, ctx->s_out));
+    HIP_TRY(hipEventRecord(ctx->ev_out[b], ctx->s_out));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->s_out));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return BSC_OK;
+}
+
 int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                    uint32_t x, uint32_t y, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip) {
   if (!ctx || !ref || !out || !skip) return bsc_fail(BSC_ERR_ARG, "bsc_call_block: NULL argument");
@@ -493,14 +525,10 @@ int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
   if ((rc = bsc_accumulate_queue(ctx, tpl, nr, seq, seq_bytes, x, y))) return rc;
   const uint64_t sz = (uint64_t)y - x + 1;
   if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)sz))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)sz * out_stride))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)sz))) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz, hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = bsc_call_sites_device(ctx, ctx->d_cts, ctx->d_ref, sz, ctx->d_out, out_stride, ctx->d_skip, ctx->stream)))
-    return rc;
-  HIP_TRY(hipMemcpyAsync(out, ctx->d_out, (size_t)sz * out_stride, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(skip, ctx->d_skip, (size_t)sz, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  /* the pile-up of the whole block is in ctx->d_cts once the stream reaches this point; call it chunk by chunk and
+   * stream the records out while the next chunk is computed */
+  if ((rc = bsc_call_resident_to_host(ctx, ctx->d_cts, ctx->d_ref, sz, out, out_stride, skip))) return rc;
   return bsc_inexact_status(ctx);
 }
 
