@@ -10,13 +10,14 @@
  *   bsc_synth_kernel   synthetic L-pileup generator (synth.h) — bench/test support.
  *
  * Design (DESIGN.md has the numbers): the kernel is a streaming scan, 104 B + 1 B in and 200 B out per
- * site with no reuse, so HBM bandwidth bounds it (FP64 VALU is the second bound, within 2x).
+ * site with no reuse, so HBM bandwidth is its roofline; in practice instruction issue (mostly FP64 VALU) is the
+ * nearer bound, so the structure below is about issuing fewer instructions as much as about moving bytes well.
  * The reference's records are arrays of structs; a wave reading its 64 structs directly would touch
  * each 128-B line from 2 lanes in 7 separate instructions.  Instead each wave moves its 64 records with
  * fully coalesced 16-B-per-lane transfers through a private LDS slot (see bsc_call_kernel).
  *
  * Numerics: FP64 throughout, no contraction (-ffp-contract=off), the transcendental functions are
- * bsmath.h (fixed operation order, shared with the host), tables come verbatim from the host.  The order
+ * bsmath.h (bit-exact replicas of glibc's log/exp/lgamma, shared with the host), tables come verbatim from the host.  The order
  * of the additions into ll[g] is the reference's: prior first, then one term per class in class order
  * 0..7; a class with n == 0 contributes +0.0, which leaves ll[g] unchanged exactly as skipping does
  * (no ll[g] can be -0.0: every term is n*ln(...) with n > 0 and no ln() argument path yields -0).
@@ -32,12 +33,6 @@
 #ifndef BSC_DMA_AUX
 #define BSC_DMA_AUX 2 /* cache policy bits of the LDS-DMA loads: nt — every pile-up is read exactly once */
 #endif
-#ifndef BSC_T3_UNROLL
-#define BSC_T3_UNROLL 1
-#endif
-#ifndef BSC_UNROLL
-#define BSC_UNROLL 1 /* unroll factor of the rolled log / exp loops */
-#endif
 #ifndef BSC_WAVES_PER_SIMD
 #define BSC_WAVES_PER_SIMD 4 /* occupancy target of bsc_call_kernel: bounds its VGPR budget (512 / waves) */
 #endif
@@ -46,12 +41,10 @@
 #define MAX_OUT_DW 52 /* gt_vcf stride (208 B) */
 #define SLOT_DW (64 * IN_DW) /* per-wave LDS slot: 64 pile-ups = 6 656 B >= 32 results (6 400 / 6 656 B) */
 
-
-
-/* ---- branch-free device forms of bsmath.h -------------------------------------------------------------
+/* ---- device forms of bsmath.h with wave-uniform branches only -------------------------------------------
  * Same operations in the same order as bsm_log_t / bsm_exp_t, hence the same bits, but without per-lane
- * branches: both polynomial paths of log() are evaluated and one is selected, the rare special cases are
- * left to a wave-uniform fallback onto the full functions.  64-bit integer steps are done on the high
+ * branches: the table path of log() runs for every lane, its near-1 polynomial only when some lane of the wave
+ * needs it, and the rare special cases are left to a wave-uniform fallback onto the full functions.  64-bit integer steps are done on the high
  * word where the constants' low words are zero. */
 
 /* log(x) for positive, normal, finite x: the table path (x = 2^k z, z in [0x1.6p-1, 0x1.6p0)) */
@@ -354,10 +347,6 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
       la[7] = has6 ? 0.5 * Z4 + k6 : 2.0;           /*                     AG */
       la[8] = has6 ? 0.5 * Z5 + k6 : 2.0;           /*                     CG, GT */
     }
-#ifdef BSC_NO_COMPACT
-#pragma unroll BSC_UNROLL
-    for (int i = 0; i < 12; i++) la[i] = log_dev(la[i], s_logtab);
-#else
     /*
      * Only the non-empty classes need their three logs (an empty class contributes n * anything = 0), and a site has
      * 1-2 of the 4 informative classes (A/T sites one, C/G sites two, plus the odd error read).  The (lane, class)
@@ -382,7 +371,7 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
         const bool act = k + lane < n_pairs;
         const unsigned e = act ? lst[k + lane] : 0u;
         double *pa = reinterpret_cast<double *>(slot + (e & 63u) * IN_DW) + 3u * (e >> 6);
-#pragma unroll BSC_T3_UNROLL
+#pragma unroll 1
         for (int t3 = 0; t3 < 3; t3++) {
           const double xa = act ? pa[t3] : 2.0;
           const double ya = log_dev(xa, s_logtab);
@@ -390,7 +379,6 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
         }
       }
     }
-#endif
     /* prior from the reference base (src/genotype_model.c:87-108); genotype order AA AC AG AT CC CG CT GG GT TT */
     const bool rA = rf == 1, rC = rf == 2, rG = rf == 3, rT = rf == 4;
     double ll0 = rA ? lrb : 0.0, ll4 = rC ? lrb : 0.0, ll7 = rG ? lrb : 0.0, ll9 = rT ? lrb : 0.0;
@@ -465,7 +453,7 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
     la[5] = ll5 - mx; la[6] = ll6 - mx; la[7] = ll7 - mx; la[8] = ll8 - mx; la[9] = ll9 - mx;
     /* normalise (:240-245): sum of exp(ll - max) in index order, rolled */
     double sum = 0.0;
-#pragma unroll BSC_UNROLL
+#pragma unroll 1
     for (int g = 0; g < 10; g++) sum += exp_dev(la[g], (const uint64_t *)s_exptab);
     const double lsum = log_dev(sum, s_logtab);
 #pragma unroll 1

@@ -142,7 +142,7 @@ static void orc_vcf_entry(orc_vcf_state *st, const orc_gt_meth *gtm, const char 
   }
   const char *alt = t_ref_alt[gt][rfix];
   const int fs = (int)(-gtm->fisher_strand * 10.0 + 0.5);
-  const uint32_t qd = dp1 > 0 ? phred / dp1 : phred;
+  const uint32_t qd = dp1 > 0 ? (uint32_t)phred / dp1 : (uint32_t)phred; /* int / uint32 is unsigned in the reference too */
   uint32_t flt = 0;
   if (!skip) skip = (x < st->par->reg_start || x > st->par->reg_stop);
   if (!skip) {
