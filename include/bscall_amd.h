@@ -9,7 +9,10 @@
  * The record layouts are the reference's own, byte for byte, so host arrays of the reference's
  * `pileup` / `gt_meth` can be passed without conversion.
  *
- * All functions return BSC_OK (0) or a negative BSC_ERR_* code; bsc_last_error() gives the text.
+ * All functions return BSC_OK (0) or a negative BSC_ERR_* code; bsc_last_error() gives the text (per thread).
+ * Threading: a context is used by one thread at a time, like the reference's calc pool is driven by its single
+ * process thread; calls on one context must be ordered on one stream (the context owns a heterozygous-site list and
+ * counters that successive launches reuse).  Independent work = independent contexts (e.g. one per GPU).
  * There is NO CPU fallback: without a usable gfx950 device bsc_create() fails with BSC_ERR_NO_DEVICE.
  */
 #ifndef BSCALL_AMD_H
