@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sites", type=int, default=50_000_000, help="positions per rank (config 2: 50 Mb)")
     ap.add_argument("--coverage", type=int, default=30)
-    ap.add_argument("--cpu-sites", type=int, default=16_000_000, help="sample size of the CPU baseline")
+    ap.add_argument("--cpu-sites", type=int, default=32_000_000, help="sample size of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -209,7 +209,7 @@ def cpu_baseline(args, d_cts, d_ref, d_out, d_skip):
     t0 = time.perf_counter()
     L.orc_call_sites(pile.ctypes.data, ref.ctypes.data, m, tb.ptr, out.ctypes.data, skip.ctypes.data, O.LIBM, -cores)
     t_all = time.perf_counter() - t0
-    m1 = min(m, 2_000_000)
+    m1 = min(m, 4_000_000)
     t0 = time.perf_counter()
     L.orc_call_sites(pile.ctypes.data, ref.ctypes.data, m1, tb.ptr, out.ctypes.data, skip.ctypes.data, O.LIBM, 1)
     t_one = time.perf_counter() - t0
