@@ -11,7 +11,7 @@ LIBDIR = bs_call_amd/lib
 HIPFLAGS = -O3 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-function
 CFLAGS = -O2 -fPIC -Wall -ffp-contract=off -std=gnu11 -I$(ROCM)/include -D__HIP_PLATFORM_AMD__
 
-all: $(LIBDIR)/libbscall_amd.so oracle
+all: $(LIBDIR)/libbscall_amd.so oracle demo
 
 $(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h $(CSRC)/devtables.h $(CSRC)/synth.h
 	@mkdir -p $(LIBDIR)
@@ -39,11 +39,16 @@ $(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/accumulate.o $(LIBDIR)
 oracle:
 	$(MAKE) -C oracle liboracle.so
 
+# a plain-C host program against the C ABI: gcc only, links the shared library like bs_call would
+demo: $(LIBDIR)/demo_block
+$(LIBDIR)/demo_block: integration/demo_block.c include/bscall_amd.h $(LIBDIR)/libbscall_amd.so
+	$(CC) -O2 -Wall -std=gnu11 -Iinclude $< -o $@ -L$(LIBDIR) -lbscall_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
+
 asm: $(CSRC)/kernels.hip
 	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -Rpass-analysis=kernel-resource-usage $< -o $(LIBDIR)/kernels.s
 
 clean:
-	rm -f $(LIBDIR)/*.o $(LIBDIR)/*.so $(LIBDIR)/*.s
+	rm -f $(LIBDIR)/*.o $(LIBDIR)/*.so $(LIBDIR)/*.s $(LIBDIR)/demo_block
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle asm clean
+.PHONY: all oracle demo asm clean

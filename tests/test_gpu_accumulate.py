@@ -163,3 +163,17 @@ def test_async_block_submit_fetch(caller, oracle, tables, libm_exact):
     with pytest.raises(B.BscError):
         caller._pending = (1, 200)
         caller.block_fetch()
+
+
+def test_plain_c_host_program():
+    """integration/demo_block.c: a gcc-built C program drives the library through the C ABI alone."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bs_call_amd", "lib", "demo_block")
+    assert os.path.exists(exe), "run `make demo`"
+    r = subprocess.run([exe, "50000", "30"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    last = r.stdout.strip().splitlines()[-1]
+    assert "positions called" in last and "VCF records" in last
+    assert any(ln.startswith("chrS\t") for ln in r.stdout.splitlines())
