@@ -113,9 +113,9 @@ int bsc_get_tables(const bsc_context *ctx, double *q_prob_44x5, double *lfact_25
  * quality/MAPQ summary, calc_gt_prob(), the strand table + fisher() for heterozygous calls.
  *   cts[n]  pile-ups (host memory)
  *   ref[n]  reference codes 0..4 = N,A,C,G,T for the same positions (src/get_sequence.c:20-54)
- *   out     n records of `out_stride` bytes each (>= 200, multiple of 8); the first 200 bytes of
- *           record i are the gt_meth of site i (all zero for a skipped site).  out_stride = 208 writes
- *           straight into a gt_vcf array (include/bs_call.h:162-166).
+ *   out     n records of `out_stride` bytes each, out_stride = 200 (a gt_meth array) or 208 (a gt_vcf array,
+ *           include/bs_call.h:162-166: gt_meth, then ready = 0 at byte 200 and skip at byte 201); the first 200
+ *           bytes of record i are the gt_meth of site i (all zero for a skipped site).
  *   skip[n] 1 where n == 0 (gt_vcf.skip), else 0
  * Synchronous: returns when `out` and `skip` are filled.
  */

@@ -19,8 +19,9 @@
  * Two flavours of the transcendental functions, same statements otherwise:
  *   flavour 0 "libm": log/exp/lgamma from libm, exactly what the reference links.  This is the
  *                     restatement of the reference and the CPU baseline that bench.py times.
- *   flavour 1 "bsm" : the fixed-operation-order functions of bs_call_amd/csrc/bsmath.h.  The gfx950
- *                     kernels use the same header, so GPU output must equal this flavour bit for bit.
+ *   flavour 1 "bsm" : the explicit-FMA replicas of glibc's log/exp/lgamma in bs_call_amd/csrc/bsmath.h.  The gfx950
+ *                     kernels use the same header, so GPU output must equal this flavour bit for bit — and on a host
+ *                     whose libm is glibc's FMA variant the two flavours are themselves identical (tests/test_bsmath.py).
  *
  * Pinning status: the reference's own sources for this path all include include/bs_call.h, which
  * includes <htslib/sam.h>, <htslib/vcf.h>, <htslib/faidx.h>; htslib is not in this image and writing
