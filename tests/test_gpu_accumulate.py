@@ -177,3 +177,41 @@ def test_plain_c_host_program():
     last = r.stdout.strip().splitlines()[-1]
     assert "positions called" in last and "VCF records" in last
     assert any(ln.startswith("chrS\t") for ln in r.stdout.splitlines())
+
+
+def test_large_block_multi_chunk_copy_out(caller, oracle, tables, libm_exact):
+    """A block longer than the 1 Mi-position copy-out chunk of bsc_call_block (3 chunks, last one ragged)."""
+    tpl, seq, x, y = _block(SEED + 91, 3_000_000, 2_300_000, 10)
+    ref = B.synth_ref_host(SEED + 91, x, y - x + 1)
+    rc, pile = oracle.accumulate(tpl, seq, x, y, 20)
+    assert rc == 0
+    exp, eskip = oracle.call_sites(pile, ref, tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
+    got, skip = caller.call_block(tpl, seq, x, y, ref)
+    assert (skip == eskip).all() and got.tobytes() == exp.tobytes()
+    caller.block_submit(tpl, seq, x, y, ref, out_stride=208)
+    raw, skip2 = caller.block_fetch()
+    assert raw[:, :200].tobytes() == exp.tobytes() and (skip2 == eskip).all()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_parameters_and_blocks(oracle, seed, libm_exact):
+    """Random model parameters x random small blocks (coverage, length, start, min_qual)."""
+    rng = np.random.default_rng(1000 + seed)
+    under, over = float(rng.uniform(0, 0.3)), float(rng.uniform(0, 0.3))
+    rb = float(rng.choice([0.5, 1.0, 2.0, 7.5]))
+    mq = int(rng.integers(1, 44))
+    cov = int(rng.choice([1, 3, 15, 40, 120]))
+    n = int(rng.integers(100, 40_000))
+    x0 = int(rng.integers(3, 50_000_000))
+    tb = oracle.Tables(under, over, rb, mq)
+    tpl, seq, x, y = _block(SEED + seed, x0, n, cov)
+    ref = B.synth_ref_host(SEED + seed, x, y - x + 1, flags=1 if seed % 2 else 0)
+    rc, pile = oracle.accumulate(tpl, seq, x, y, mq)
+    exp, eskip = oracle.call_sites(pile, ref, tb, oracle.LIBM if libm_exact else oracle.BSM, -8)
+    with B.SiteCaller(under, over, rb, mq) as c:
+        assert c.accumulate(tpl, seq, x, y).tobytes() == pile.tobytes()
+        got, skip = c.call_block(tpl, seq, x, y, ref)
+        assert (skip == eskip).all() and got.tobytes() == exp.tobytes()
+        rec = c.vcf_records(got, skip, np.concatenate([ref, [1, 2]]).astype(np.uint8), x)
+    if libm_exact:
+        assert rec.tobytes() == oracle.vcf_block(exp, eskip, np.concatenate([ref, [1, 2]]).astype(np.uint8), x).tobytes()
