@@ -164,6 +164,15 @@ void orc_calc_gt_prob(orc_gt_meth *gt, const orc_tables *tb, char rf, int flavou
   if (flavour) orc_calc_gt_prob_bsm(gt, tb, rf);
   else orc_calc_gt_prob_libm(gt, tb, rf);
 }
+/* calc_gt_prob() over an array of prepared gt_meth records (counts, qual filled): the "model only" CPU timing of
+ * SURVEY.md section 8d (i).  Single thread. */
+void orc_calc_gt_prob_array(orc_gt_meth *gt, const char *ref, uint64_t n, const orc_tables *tb, int flavour) {
+  if (flavour)
+    for (uint64_t i = 0; i < n; i++) orc_calc_gt_prob_bsm(gt + i, tb, ref[i]);
+  else
+    for (uint64_t i = 0; i < n; i++) orc_calc_gt_prob_libm(gt + i, tb, ref[i]);
+}
+
 /* c[4] is modified, as in the reference */
 double orc_fisher(int *c, const orc_tables *tb, int flavour) {
   return flavour ? orc_fisher_bsm(c, tb->lfact_store) : orc_fisher_libm(c, tb->lfact_store);

@@ -45,6 +45,8 @@ def lib():
         L.orc_call_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_accumulate.restype = C.c_int
         L.orc_accumulate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_calc_gt_prob_array.restype = None
+        L.orc_calc_gt_prob_array.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.orc_vcf_block.restype = None
         L.orc_vcf_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_vcf_tables.restype = None
