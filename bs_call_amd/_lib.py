@@ -25,6 +25,7 @@ EXPORTS = (
     "bsc_synth_reads_host",
     "bsc_vcf_records",
     "bsc_vcf_records_device",
+    "bsc_vcf_format",
     "bsc_set_profiling",
     "bsc_last_kernel_ms",
     "bsc_synchronize",
@@ -134,6 +135,8 @@ def load():
     L.bsc_vcf_records.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, C.POINTER(VcfParams), vp]
     L.bsc_vcf_records_device.restype = i32
     L.bsc_vcf_records_device.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, C.POINTER(VcfParams), vp, vp]
+    L.bsc_vcf_format.restype = i32
+    L.bsc_vcf_format.argtypes = [vp, vp, C.c_char_p, C.c_char_p, vp, C.c_size_t]
     L.bsc_set_profiling.restype = i32
     L.bsc_set_profiling.argtypes = [vp, i32]
     L.bsc_last_kernel_ms.restype = i32

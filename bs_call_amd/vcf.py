@@ -46,3 +46,27 @@ def format_record(core, gtm, contig, rs_id="."):
 def format_block(cores, gtms, contig):
     """VCF data lines of one block, in position order (records with emit == 0 produce nothing)."""
     return [format_record(c, g, contig) for c, g in zip(cores, gtms) if c["emit"]]
+
+
+def format_block_c(cores, gtms, contig):
+    """The same lines through the library's C formatter (bsc_vcf_format)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+    from .abi import GT_METH, VCF_CORE
+
+    L = _lib.load()
+    cores = np.ascontiguousarray(cores, dtype=VCF_CORE)
+    gtms = np.ascontiguousarray(gtms, dtype=GT_METH)
+    buf = C.create_string_buffer(1024)
+    out = []
+    cb, gb = cores.ctypes.data, gtms.ctypes.data
+    for i in range(len(cores)):
+        n = L.bsc_vcf_format(cb + 64 * i, gb + 200 * i, contig.encode(), None, buf, 1024)
+        if n < 0:
+            raise RuntimeError("bsc_vcf_format: buffer too small")
+        if n:
+            out.append(buf.raw[:n].decode())
+    return out

@@ -18,6 +18,7 @@
 #ifndef BSCALL_AMD_H
 #define BSCALL_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -214,6 +215,12 @@ int bsc_vcf_records(bsc_context *ctx, const void *gtm, uint32_t gtm_stride, cons
 int bsc_vcf_records_device(bsc_context *ctx, const void *d_gtm, uint32_t gtm_stride, const void *d_skip,
                            const void *d_ref, const void *d_dbsnp, uint32_t n, uint32_t x,
                            const bsc_vcf_params *params, void *d_out, void *stream);
+
+/* Host-side text rendering of one record as a VCF data line ("CHROM POS ID REF ALT QUAL FILTER INFO FORMAT SAMPLE",
+ * tab separated, no newline): the field layout of the record the reference hands to htslib (src/print_vcf.c:160-380).
+ * Returns the length written, 0 when c->emit == 0, -1 when buf is too small.  `id` NULL/"" prints ".". */
+int bsc_vcf_format(const bsc_vcf_core *c, const bsc_gt_meth *g, const char *contig, const char *id, char *buf,
+                   size_t cap);
 
 /* Per-launch kernel timing with HIP events recorded on the launch stream (measurement support):
  * after bsc_set_profiling(ctx, 1), bsc_last_kernel_ms() returns the device time of the most recent

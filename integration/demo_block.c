@@ -71,13 +71,9 @@ int main(int argc, char **argv) {
     const int het = GT_NAME[c->gt][0] != GT_NAME[c->gt][1];
     hets += het;
     if (het && shown < 5) {
+      char line[1024];
+      if (bsc_vcf_format(c, gtm + i, "chrS", NULL, line, sizeof line) > 0) puts(line);
       shown++;
-      char alt[4] = {c->alt[0] ? c->alt[0] : '.', 0, 0, 0};
-      if (c->alt[1]) { alt[1] = ','; alt[2] = c->alt[1]; }
-      printf("chrS\t%u\t.\t%c\t%s\t%u\t%s\tCX=%.5s\tGT:DP:MQ:GQ:QD:CG:CX\t%d/%d:%u:%d:%u:%u:%c:%.5s\n", c->pos,
-             c->cx_ref[2], alt, c->phred,
-             c->flt == 0 ? "PASS" : (c->flt & 128 ? "mac1" : "fail"), c->cx_ref, ((c->gt_enc >> 4) >> 1) - 1,
-             ((c->gt_enc & 15) >> 1) - 1, c->dp, gtm[i].mq, c->phred, c->qd, c->cg, c->cx_gt);
     }
   }
   bsc_stats st;

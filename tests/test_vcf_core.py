@@ -141,3 +141,15 @@ def test_text_rendering_of_oracle_records(oracle, tables):
         assert int(kv["GQ"]) == int(f[5]) == int(rec["phred"][i]) and len(kv["MC8"].split(",")) == 8
         assert sum(map(int, kv["MC8"].split(",")[:4])) == int(kv["DP"])
         assert ("FS" in kv) == bool(B.GT_HET[rec["gt"][i]])
+
+
+def test_c_formatter_equals_python_formatter(oracle, tables):
+    """bsc_vcf_format (host C, in the library) renders the same lines as bs_call_amd/vcf.py."""
+    from bs_call_amd import vcf
+
+    out, skip, ref = _called_block(oracle, tables, SEED + 4, 5000, 20_000, 30)
+    rec = oracle.vcf_block(out, skip, ref, 5000, all_positions=True)
+    a = vcf.format_block(rec, out, "chr7")
+    b = vcf.format_block_c(rec, out, "chr7")
+    assert len(a) == len(b) == int(rec["emit"].sum())
+    assert a == b
