@@ -33,6 +33,9 @@
 #ifndef BSC_DMA_AUX
 #define BSC_DMA_AUX 2 /* cache policy bits of the LDS-DMA loads: nt — every pile-up is read exactly once */
 #endif
+#ifndef BSC_TILES_PER_WAVE
+#define BSC_TILES_PER_WAVE 8 /* launch heuristic: wave-tiles per wave (8 measured best over 1 M .. 50 M positions) */
+#endif
 #ifndef BSC_WAVES_PER_SIMD
 #define BSC_WAVES_PER_SIMD 4 /* occupancy target of bsc_call_kernel: bounds its VGPR budget (512 / waves) */
 #endif
@@ -672,8 +675,16 @@ extern "C" int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n,
   hipStream_t s = (hipStream_t)stream;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, s);
   const uint64_t n_tiles = (n + TILE - 1) / TILE;
-  /* 4 workgroups fit one CU (32 KB LDS, <= 128 VGPRs); 8 rounds of them keep the tail short */
-  uint64_t grid = (uint64_t)num_cus * BSC_WAVES_PER_SIMD * 8u;
+  /* Grid: the workgroups resident at once (BSC_WAVES_PER_SIMD per CU: 33 KB LDS, <= 128 VGPRs each) times a number of
+   * rounds chosen so that a wave walks about BSC_TILES_PER_WAVE wave-tiles.  Measured (gpurun_out/ab*.txt):
+   * a fully persistent grid (1 round) is best for small blocks (the table set-up is paid once per wave slot) but 7 %
+   * slower at 50 M positions than 8-16 rounds, whose workgroup turnover keeps the waves of a CU out of phase;
+   * beyond 32 rounds the set-up cost shows again. */
+  const uint64_t resident = (uint64_t)num_cus * BSC_WAVES_PER_SIMD;
+  const uint64_t n_wt = (n + 63) / 64;
+  uint64_t rounds = n_wt / (resident * (TILE / 64) * BSC_TILES_PER_WAVE);
+  rounds = rounds < 1 ? 1 : (rounds > 16 ? 16 : rounds);
+  uint64_t grid = resident * rounds;
   if (grid > n_tiles) grid = n_tiles;
   hipLaunchKernelGGL(bsc_call_kernel, dim3((unsigned)grid), dim3(TILE), 0, s, (const uint32_t *)cts,
                      (const uint8_t *)ref, n, (uint32_t *)out, out_dw, (uint8_t *)skip, (const bsc_dev_tables *)tb,
