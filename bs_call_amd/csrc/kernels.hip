@@ -29,7 +29,9 @@
 #include "devtables.h"
 #include "synth.h"
 
-#define TILE 256
+#ifndef TILE
+#define TILE 256 /* threads per workgroup of bsc_call_kernel (a multiple of 64) */
+#endif
 #ifndef BSC_DMA_AUX
 #define BSC_DMA_AUX 2 /* cache policy bits of the LDS-DMA loads: nt — every pile-up is read exactly once */
 #endif
@@ -240,8 +242,10 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
     s_half[tid] = tb->ln_k_half[tid];
     s_one[tid] = tb->ln_k_one[tid];
   }
-  s_logtab[tid] = tb->log_tab[tid];
-  s_exptab[tid] = tb->exp_tab[tid];
+  for (unsigned i = tid; i < 256; i += TILE) {
+    s_logtab[i] = tb->log_tab[i];
+    s_exptab[i] = tb->exp_tab[i];
+  }
   if (tid < 12) s_cnt[tid] = 0;
   const double l = 1.0 - tb->under_conv;
   const double t = tb->over_conv;
@@ -680,7 +684,7 @@ extern "C" int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n,
    * a fully persistent grid (1 round) is best for small blocks (the table set-up is paid once per wave slot) but 7 %
    * slower at 50 M positions than 8-16 rounds, whose workgroup turnover keeps the waves of a CU out of phase;
    * beyond 32 rounds the set-up cost shows again. */
-  const uint64_t resident = (uint64_t)num_cus * BSC_WAVES_PER_SIMD;
+  const uint64_t resident = (uint64_t)num_cus * BSC_WAVES_PER_SIMD * (256 / TILE);
   const uint64_t n_wt = (n + 63) / 64;
   uint64_t rounds = n_wt / (resident * (TILE / 64) * BSC_TILES_PER_WAVE);
   rounds = rounds < 1 ? 1 : (rounds > 16 ? 16 : rounds);
