@@ -67,6 +67,16 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
     x1[t] = left;
     uint32_t ori = tp.orientation & 1u;
     uint32_t reach = left;
+    /* the end bytes of both reads, fetched together: almost every read starts and ends on a countable base, so
+     * the scans below rarely need another load and the thread waits for memory once, not four times */
+    uint32_t e_first[2], e_last[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const uint32_t rl = tp.len[k];
+      e_first[k] = rl ? seq[tp.off[k]] : 0u;
+      e_last[k] = rl ? seq[tp.off[k] + rl - 1] : 0u;
+    }
+#pragma unroll
     for (int k = 0; k < 2; k++) {
       bsc_read_desc d;
       d.a = 1;
@@ -79,13 +89,13 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
         const uint8_t *sp = seq + tp.off[k];
         uint32_t j = 0;
         for (; j < rl; j++) { /* :198-201 */
-          const uint32_t q = sp[j] >> 2;
+          const uint32_t q = (j == 0 ? e_first[k] : (uint32_t)sp[j]) >> 2;
           if (q > 0 && q != 63u) break;
         }
         if (j < rl) {
           const uint32_t first = j;
           for (j = rl; j > 0; j--) { /* :205-208 */
-            const uint32_t q = sp[j - 1] >> 2;
+            const uint32_t q = (j == rl ? e_last[k] : (uint32_t)sp[j - 1]) >> 2;
             if (q > 0 && q != 63u) break;
           }
           const uint32_t last = j - 1;
@@ -109,7 +119,12 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
     const uint32_t v = __shfl_xor(span_max, o);
     span_max = v > span_max ? v : span_max;
   }
-  if ((threadIdx.x & 63u) == 0 && span_max) atomicMax(&counters[BSC_CNT_SPAN], (unsigned long long)span_max);
+  /* Same-address device-scope atomics serialise at the memory side (measured: ~6 ns each, 19 k waves), and most
+   * waves see the same largest extent: look first (the counter only grows, so a stale smaller value costs an
+   * atomic, never a wrong skip). */
+  if ((threadIdx.x & 63u) == 0 && span_max &&
+      __hip_atomic_load(&counters[BSC_CNT_SPAN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < span_max)
+    atomicMax(&counters[BSC_CNT_SPAN], (unsigned long long)span_max);
 }
 
 extern "C" __global__ __launch_bounds__(256) void bsc_tile_lo_kernel(const uint32_t *__restrict__ x1, uint32_t nr,
@@ -130,13 +145,21 @@ extern "C" __global__ __launch_bounds__(256) void bsc_tile_lo_kernel(const uint3
   }
 }
 
-/* strand -> class, 0-based (reference base_tab_st, src/call_genotypes.c:17-19): [strand][base] packed 4 bits each */
-__device__ static __forceinline__ uint32_t class_of(uint32_t strand, uint32_t base) {
-  /* NON_CONVERTED 0 1 2 3 ; C2T 0 5 2 7 ; G2A 4 1 6 3 */
-  const uint32_t lut = strand == 0 ? 0x3210u : (strand == 1 ? 0x7250u : 0x3614u);
-  return (lut >> (4u * base)) & 7u;
-}
+/* strand -> 4 * class, one byte per base code (reference base_tab_st, src/call_genotypes.c:17-19):
+ * NON_CONVERTED 0 1 2 3 ; C2T 0 5 2 7 ; G2A 4 1 6 3.  Byte-indexed so that one v_perm_b32 turns a base code into
+ * the byte offset of its class inside a pile-up row. */
+#define LUT4(c0, c1, c2, c3) ((uint32_t)(4 * (c0)) | ((uint32_t)(4 * (c1)) << 8) | ((uint32_t)(4 * (c2)) << 16) | ((uint32_t)(4 * (c3)) << 24))
 
+#ifndef ACC_DEPTH
+#define ACC_DEPTH 4 /* reads whose byte loads are in flight together */
+#endif
+
+/*
+ * The kernel is VALU-issue bound (a wave64 VALU instruction occupies its SIMD for 4 cycles; without the byte loads
+ * or without the LDS updates it runs exactly as long), so everything that is the same for all lanes — the read's
+ * extent, its sequence base, orientation, strand, MAPQ^2 — is kept in SGPRs (v_readlane results, SALU arithmetic)
+ * and the per-lane work per read is: clamp, load, range test, quality test, class lookup, two LDS adds, one add.
+ */
 extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel(
     const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ x1, uint32_t nr,
     const uint8_t *__restrict__ seq, uint32_t x, uint32_t y, uint32_t min_qual, const uint32_t *__restrict__ tile_lo,
@@ -148,21 +171,24 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
   uint32_t *row = slot + lane * IN_DW;
   const uint32_t n_sites = y - x + 1;
   const uint32_t n_wt = (n_sites + 63u) / 64u;
+  /* q counts iff min_qual <= q < 63 (:217)  <=>  (q - min_qual) <u q_span */
+  const uint32_t q_span = min_qual < 63u ? 63u - min_qual : 0u;
   unsigned inexact = 0;
   for (uint32_t wt = blockIdx.x * ACC_WAVES + wid; wt < n_wt; wt += gridDim.x * ACC_WAVES) {
-    const uint64_t p0 = (uint64_t)x + (uint64_t)wt * 64u; /* position of lane 0 */
-    const uint64_t p_last = p0 + 63u;
-    const uint64_t p = p0 + lane;
-    const bool valid = p <= y;
+    /* x + 64 wt <= y: the tile's first position fits 32 bits; its last one is clipped to y */
+    const uint32_t p0 = x + wt * 64u;
+    const uint32_t p_last = y - p0 < 63u ? y : p0 + 63u;
+    const bool valid = lane <= p_last - p0;
 #pragma unroll
     for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
+    uint32_t m2sum = 0; /* mapq2 of this lane's position */
 
     uint32_t t0 = tile_lo[wt];
     bool more = true;
     while (more) {
       /* 64 candidate templates per pass: lane i holds the two read descriptors of template t0 + i */
       const uint32_t t = t0 + lane;
-      const bool cand = t < nr && (uint64_t)x1[t < nr ? t : 0] <= p_last;
+      const bool cand = t < nr && x1[t < nr ? t : 0] <= p_last;
       bsc_read_desc d0, d1;
       d0.a = d1.a = 1;
       d0.b = d1.b = 0;
@@ -177,30 +203,58 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
       for (int k = 0; k < 2; k++) {
         const bsc_read_desc &d = k ? d1 : d0;
         /* reads that overlap the tile at all */
-        unsigned long long m = __ballot(d.b >= d.a && (uint64_t)d.b >= p0 && (uint64_t)d.a <= p_last);
+        unsigned long long m = __ballot(d.b >= d.a && d.b >= p0 && d.a <= p_last);
+        /* ACC_DEPTH reads per group: their byte loads are issued back to back and consumed afterwards, so the
+         * wave waits for memory once per group; slots past the end of the list are skipped by scalar branches */
         while (m) {
-          const int src = __builtin_ctzll(m);
-          m &= m - 1;
-          const uint32_t a = __builtin_amdgcn_readlane(d.a, src);
-          const uint32_t b = __builtin_amdgcn_readlane(d.b, src);
-          const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)d.base, src);
-          const uint32_t bhi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)d.base >> 32), src);
-          const uint32_t meta = __builtin_amdgcn_readlane(d.meta, src);
-          const int64_t base = (int64_t)(((uint64_t)bhi << 32) | blo);
-          if (valid && p >= a && p <= b) {
-            const uint32_t byte = seq[base + (int64_t)p];
-            const uint32_t q = byte >> 2;
-            if (q >= min_qual && q != 63u) { /* :217 */
-              const uint32_t c = class_of((meta >> 1) & 3u, byte & 3u);
-              row[(meta & 1u) * 8u + c] += 1u;  /* counts[ori][c]++ */
-              row[17u + c] += q;                /* quality[c] += q (integer; converted below) */
-              row[25u] += meta >> 8;            /* mapq2 += mapq^2 */
+          const int cnt = __popcll(m);
+          uint32_t g_byte[ACC_DEPTH], g_lo[ACC_DEPTH], g_len[ACC_DEPTH], g_meta[ACC_DEPTH];
+#pragma unroll
+          for (int u = 0; u < ACC_DEPTH; u++) {
+            if (u < cnt) {
+              const int src = __builtin_ctzll(m);
+              m &= m - 1;
+              const uint32_t a = __builtin_amdgcn_readlane(d.a, src);
+              const uint32_t b = __builtin_amdgcn_readlane(d.b, src);
+              const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)d.base, src);
+              const uint32_t bhi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)d.base >> 32), src);
+              g_meta[u] = __builtin_amdgcn_readlane(d.meta, src);
+              /* the read's part of the tile, as lane numbers lo..hi (0 <= lo <= hi <= 63) */
+              const uint32_t lo = (a > p0 ? a : p0) - p0;
+              const uint32_t hi = (b < p_last ? b : p_last) - p0;
+              g_lo[u] = lo;
+              g_len[u] = hi - lo;
+              /* byte of position p0 + i is sp[i]; lanes outside the read fetch its nearest byte (always a valid
+               * address, same cache lines) and drop it */
+              const uint8_t *sp = seq + ((int64_t)(((uint64_t)bhi << 32) | blo) + (int64_t)p0);
+              const uint32_t pc = lane < lo ? lo : (lane > hi ? hi : lane);
+              g_byte[u] = sp[pc];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < ACC_DEPTH; u++) {
+            if (u < cnt) {
+              const uint32_t byte = g_byte[u], meta = g_meta[u];
+              const uint32_t q = byte >> 2;
+              if (lane - g_lo[u] <= g_len[u] && q - min_qual < q_span) {
+                const uint32_t strand = (meta >> 1) & 3u; /* uniform */
+                const uint32_t lut = strand == 0 ? LUT4(0, 1, 2, 3) : (strand == 1 ? LUT4(0, 5, 2, 7) : LUT4(4, 1, 6, 3));
+                /* selector bytes 1..3 = 0x0c: constant 0 */
+                const uint32_t c4 = __builtin_amdgcn_perm(0u, lut, (byte & 3u) | 0x0c0c0c00u);
+                uint32_t *rc = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(row) + c4);
+                /* fire-and-forget ds_add_u32: the row has a single writer (this lane), no contention */
+                if (meta & 1u) atomicAdd(rc + 8, 1u); /* counts[ori][c]++ */
+                else atomicAdd(rc, 1u);
+                atomicAdd(rc + 17, q); /* quality[c] += q (integer; converted below) */
+                m2sum += meta >> 8;    /* mapq2 += mapq^2 */
+              }
             }
           }
         }
       }
       t0 += 64u;
     }
+    row[25] = m2sum;
 
     /* n = sum of counts; integer sums -> float */
     {
@@ -219,7 +273,7 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
       row[25] = __float_as_uint((float)m2);
     }
     /* the slot is the tile's pileup[] image: copy it out */
-    const uint32_t nvalid = (uint32_t)((uint64_t)y - p0 + 1u < 64u ? (uint64_t)y - p0 + 1u : 64u);
+    const uint32_t nvalid = p_last - p0 + 1u;
     uint32_t *dst = cts + (uint64_t)wt * SLOT_DW;
     if (nvalid == 64u) {
       const uint4 *s4 = reinterpret_cast<const uint4 *>(slot);
