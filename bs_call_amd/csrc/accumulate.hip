@@ -38,9 +38,14 @@ struct __attribute__((aligned(8))) bsc_read_desc {
   uint32_t a;    /* first countable position (absolute) */
   uint32_t b;    /* last countable position (absolute, already clipped to y) */
   int64_t base;  /* seq offset of position 0: byte of position p is seq[base + p] */
-  uint32_t meta; /* bit0 orientation the read is counted with, bits 1-2 bs_strand, bits 8-23 mapq^2 */
-  uint32_t _pad;
+  uint32_t meta; /* bit 5: orientation the read is counted with (= byte offset of counts[ori]), bits 8-23 mapq^2 */
+  uint32_t lut;  /* 4 * class of base codes 0..3 on the read's bisulfite strand, one byte each (LUT4 below) */
 };
+
+/* strand -> 4 * class, one byte per base code (reference base_tab_st, src/call_genotypes.c:17-19):
+ * NON_CONVERTED 0 1 2 3 ; C2T 0 5 2 7 ; G2A 4 1 6 3.  Byte-indexed so that one v_perm_b32 turns a base code into
+ * the byte offset of its class inside a pile-up row. */
+#define LUT4(c0, c1, c2, c3) ((uint32_t)(4 * (c0)) | ((uint32_t)(4 * (c1)) << 8) | ((uint32_t)(4 * (c2)) << 16) | ((uint32_t)(4 * (c3)) << 24))
 
 /* bsc_template (include/bscall_amd.h) as the kernels read it */
 struct bsc_template_dev {
@@ -83,7 +88,7 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
       d.b = 0;
       d.base = 0;
       d.meta = 0;
-      d._pad = 0;
+      d.lut = 0;
       const uint32_t rl = tp.len[k];
       if (rl != 0) {
         const uint8_t *sp = seq + tp.off[k];
@@ -104,7 +109,8 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
           d.b = pb > y ? y : (uint32_t)pb; /* pos <= y, :214 */
           if (pa > y) { d.a = 1; d.b = 0; }
           d.base = (int64_t)tp.off[k] - (int64_t)tp.pos[k];
-          d.meta = ori | ((uint32_t)tp.bs_strand << 1) | (((uint32_t)tp.mapq[k] * tp.mapq[k]) << 8);
+          d.meta = (ori << 5) | (((uint32_t)tp.mapq[k] * tp.mapq[k]) << 8);
+          d.lut = tp.bs_strand == 0 ? LUT4(0, 1, 2, 3) : (tp.bs_strand == 1 ? LUT4(0, 5, 2, 7) : LUT4(4, 1, 6, 3));
           if (d.b >= d.a && d.b > reach) reach = d.b;
           ori ^= 1u; /* :224 — only a read that was walked flips the orientation */
         }
@@ -145,20 +151,15 @@ extern "C" __global__ __launch_bounds__(256) void bsc_tile_lo_kernel(const uint3
   }
 }
 
-/* strand -> 4 * class, one byte per base code (reference base_tab_st, src/call_genotypes.c:17-19):
- * NON_CONVERTED 0 1 2 3 ; C2T 0 5 2 7 ; G2A 4 1 6 3.  Byte-indexed so that one v_perm_b32 turns a base code into
- * the byte offset of its class inside a pile-up row. */
-#define LUT4(c0, c1, c2, c3) ((uint32_t)(4 * (c0)) | ((uint32_t)(4 * (c1)) << 8) | ((uint32_t)(4 * (c2)) << 16) | ((uint32_t)(4 * (c3)) << 24))
-
-#ifndef ACC_DEPTH
-#define ACC_DEPTH 4 /* reads whose byte loads are in flight together */
-#endif
+/* a pointer the compiler knows to be global memory (a plain pointer rebuilt from two registers would be flat) */
+typedef const __attribute__((address_space(1))) uint8_t *global_bytes;
 
 /*
- * The kernel is VALU-issue bound (a wave64 VALU instruction occupies its SIMD for 4 cycles; without the byte loads
- * or without the LDS updates it runs exactly as long), so everything that is the same for all lanes — the read's
- * extent, its sequence base, orientation, strand, MAPQ^2 — is kept in SGPRs (v_readlane results, SALU arithmetic)
- * and the per-lane work per read is: clamp, load, range test, quality test, class lookup, two LDS adds, one add.
+ * The kernel is instruction-issue bound (profiles/: VALU and scalar units each busy ~2/3 of the time, memory and LDS
+ * far from their limits), so the work per (read, tile) pair is kept to a minimum: what depends on the read and the
+ * tile but not on the lane — the read's lane range, the address of its first byte in the tile — is computed once per
+ * descriptor lane, 64 reads at a time, and reaches the scalar registers with v_readlane; per lane that leaves
+ * clamp, load, range test, quality test, class lookup (v_alignbyte on the strand's table), two LDS adds, one add.
  */
 extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel(
     const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ x1, uint32_t nr,
@@ -174,85 +175,120 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
   /* q counts iff min_qual <= q < 63 (:217)  <=>  (q - min_qual) <u q_span */
   const uint32_t q_span = min_qual < 63u ? 63u - min_qual : 0u;
   unsigned inexact = 0;
-  for (uint32_t wt = blockIdx.x * ACC_WAVES + wid; wt < n_wt; wt += gridDim.x * ACC_WAVES) {
+  /* 64 candidate templates per batch: lane i gets the leftmost position and the two read descriptors of template
+   * tb + i.  All three loads are independent of each other (a template right of the tile overlaps nothing). */
+  auto fetch = [&](uint32_t tb, uint32_t &xv, bsc_read_desc &e0, bsc_read_desc &e1) {
+    const uint32_t t = tb + lane;
+    xv = 0;
+    e0.a = e1.a = 1;
+    e0.b = e1.b = 0;
+    e0.base = e1.base = 0;
+    e0.meta = e1.meta = 0;
+    e0.lut = e1.lut = 0;
+    if (t < nr) {
+      xv = x1[t];
+      e0 = rd[2 * (uint64_t)t];
+      e1 = rd[2 * (uint64_t)t + 1];
+    }
+  };
+  /* Software pipeline over the wave's tiles: while tile i is processed, the first batch of tile i+1 and the start
+   * index of tile i+2 are on their way, so the tile_lo -> x1/descriptor chain of dependent loads is off the
+   * critical path. */
+  const uint32_t wt_step = gridDim.x * ACC_WAVES;
+  uint32_t wt = blockIdx.x * ACC_WAVES + wid;
+  uint32_t t0 = 0, t0_next = 0, xv = 0;
+  bsc_read_desc d0, d1;
+  if (wt < n_wt) {
+    t0 = tile_lo[wt];
+    if (wt + wt_step < n_wt && wt + wt_step > wt) t0_next = tile_lo[wt + wt_step];
+    fetch(t0, xv, d0, d1);
+  }
+  for (; wt < n_wt; wt += wt_step) {
     /* x + 64 wt <= y: the tile's first position fits 32 bits; its last one is clipped to y */
     const uint32_t p0 = x + wt * 64u;
     const uint32_t p_last = y - p0 < 63u ? y : p0 + 63u;
     const bool valid = lane <= p_last - p0;
+    const uint32_t wt1 = wt + wt_step, wt2 = wt1 + wt_step;
+    const bool have1 = wt1 < n_wt && wt1 > wt, have2 = have1 && wt2 < n_wt && wt2 > wt1;
+    uint32_t xv_n = 0, t0_nn = 0;
+    bsc_read_desc n0, n1;
+    n0.a = n1.a = 1;
+    n0.b = n1.b = 0;
+    n0.base = n1.base = 0;
+    n0.meta = n1.meta = 0;
+    n0.lut = n1.lut = 0;
+    if (have1) fetch(t0_next, xv_n, n0, n1);
+    if (have2) t0_nn = tile_lo[wt2];
 #pragma unroll
     for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
     uint32_t m2sum = 0; /* mapq2 of this lane's position */
 
-    uint32_t t0 = tile_lo[wt];
     bool more = true;
     while (more) {
-      /* 64 candidate templates per pass: lane i holds the two read descriptors of template t0 + i */
-      const uint32_t t = t0 + lane;
-      const bool cand = t < nr && x1[t < nr ? t : 0] <= p_last;
-      bsc_read_desc d0, d1;
-      d0.a = d1.a = 1;
-      d0.b = d1.b = 0;
-      d0.base = d1.base = 0;
-      d0.meta = d1.meta = 0;
-      if (cand) {
-        d0 = rd[2 * (uint64_t)t];
-        d1 = rd[2 * (uint64_t)t + 1];
-      }
+      const bool cand = t0 + lane < nr && xv <= p_last;
       more = __all(cand); /* templates are sorted by x1: the candidates are a prefix of the batch */
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const bsc_read_desc &d = k ? d1 : d0;
         /* reads that overlap the tile at all */
         unsigned long long m = __ballot(d.b >= d.a && d.b >= p0 && d.a <= p_last);
-        /* ACC_DEPTH reads per group: their byte loads are issued back to back and consumed afterwards, so the
-         * wave waits for memory once per group; slots past the end of the list are skipped by scalar branches */
-        while (m) {
-          const int cnt = __popcll(m);
-          uint32_t g_byte[ACC_DEPTH], g_lo[ACC_DEPTH], g_len[ACC_DEPTH], g_meta[ACC_DEPTH];
-#pragma unroll
-          for (int u = 0; u < ACC_DEPTH; u++) {
-            if (u < cnt) {
-              const int src = __builtin_ctzll(m);
-              m &= m - 1;
-              const uint32_t a = __builtin_amdgcn_readlane(d.a, src);
-              const uint32_t b = __builtin_amdgcn_readlane(d.b, src);
-              const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)d.base, src);
-              const uint32_t bhi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)d.base >> 32), src);
-              g_meta[u] = __builtin_amdgcn_readlane(d.meta, src);
-              /* the read's part of the tile, as lane numbers lo..hi (0 <= lo <= hi <= 63) */
-              const uint32_t lo = (a > p0 ? a : p0) - p0;
-              const uint32_t hi = (b < p_last ? b : p_last) - p0;
-              g_lo[u] = lo;
-              g_len[u] = hi - lo;
-              /* byte of position p0 + i is sp[i]; lanes outside the read fetch its nearest byte (always a valid
-               * address, same cache lines) and drop it */
-              const uint8_t *sp = seq + ((int64_t)(((uint64_t)bhi << 32) | blo) + (int64_t)p0);
-              const uint32_t pc = lane < lo ? lo : (lane > hi ? hi : lane);
-              g_byte[u] = sp[pc];
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < ACC_DEPTH; u++) {
-            if (u < cnt) {
-              const uint32_t byte = g_byte[u], meta = g_meta[u];
-              const uint32_t q = byte >> 2;
-              if (lane - g_lo[u] <= g_len[u] && q - min_qual < q_span) {
-                const uint32_t strand = (meta >> 1) & 3u; /* uniform */
-                const uint32_t lut = strand == 0 ? LUT4(0, 1, 2, 3) : (strand == 1 ? LUT4(0, 5, 2, 7) : LUT4(4, 1, 6, 3));
-                /* selector bytes 1..3 = 0x0c: constant 0 */
-                const uint32_t c4 = __builtin_amdgcn_perm(0u, lut, (byte & 3u) | 0x0c0c0c00u);
-                uint32_t *rc = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(row) + c4);
-                /* fire-and-forget ds_add_u32: the row has a single writer (this lane), no contention */
-                if (meta & 1u) atomicAdd(rc + 8, 1u); /* counts[ori][c]++ */
-                else atomicAdd(rc, 1u);
-                atomicAdd(rc + 17, q); /* quality[c] += q (integer; converted below) */
-                m2sum += meta >> 8;    /* mapq2 += mapq^2 */
-              }
-            }
-          }
+        /* per descriptor lane: the read's part of the tile as lane numbers lo .. lo + len (0 <= lo, lo + len <= 63;
+         * meaningless where the read does not overlap, never used there), and the address of the byte of lane lo */
+        const uint32_t lo = (d.a > p0 ? d.a : p0) - p0;
+        const uint32_t lolen = lo | (((d.b < p_last ? d.b : p_last) - p0 - lo) << 8);
+        const uint64_t sp = (uint64_t)(uintptr_t)seq + (uint64_t)(d.base + (int64_t)p0 + (int64_t)lo);
+        /* Groups of 4, then 2, then 1 reads: the byte loads of a group are issued back to back and consumed
+         * afterwards, so the wave waits for memory once per group.  Straight-line code per group size: slot
+         * conditions inside a group would be evaluated on the VALU. */
+        uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+        uint32_t g_byte[4], g_t[4], g_len[4], g_meta[4], g_lut[4];
+#define ACC_LOAD(u)                                                                                              \
+  {                                                                                                              \
+    const int src = __builtin_ctzll(m);                                                                          \
+    m &= m - 1;                                                                                                  \
+    const uint32_t ll = (uint32_t)__builtin_amdgcn_readlane(lolen, src);                                         \
+    /* v_readlane returns int: without the casts the low word would be sign-extended into the high one */        \
+    const uint32_t sp_lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)sp, src);                               \
+    const uint32_t sp_hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(sp >> 32), src);                       \
+    const global_bytes p = (global_bytes)(uintptr_t)(((uint64_t)sp_hi << 32) | sp_lo);                           \
+    g_meta[u] = (uint32_t)__builtin_amdgcn_readlane(d.meta, src);                                                \
+    g_lut[u] = (uint32_t)__builtin_amdgcn_readlane(d.lut, src);                                                  \
+    g_len[u] = ll >> 8;                                                                                          \
+    g_t[u] = lane - (ll & 0xffu); /* lanes below the read wrap to huge values */                                 \
+    /* lanes outside the read fetch its last byte in the tile (a valid address, same cache lines) and drop it */ \
+    g_byte[u] = p[g_t[u] < g_len[u] ? g_t[u] : g_len[u]];                                                        \
+  }
+#define ACC_UPDATE(u)                                                                                            \
+  {                                                                                                              \
+    const uint32_t byte = g_byte[u], meta = g_meta[u];                                                           \
+    const uint32_t q = byte >> 2;                                                                                \
+    if (g_t[u] <= g_len[u] && q - min_qual < q_span) {                                                           \
+      /* v_alignbyte_b32 shifts by 8 * (byte & 3): the class offset of this base arrives in the low byte */      \
+      const uint32_t c4 = __builtin_amdgcn_alignbyte(0u, g_lut[u], byte) & 0xffu;                                \
+      char *rc = reinterpret_cast<char *>(row) + c4;                                                             \
+      /* fire-and-forget ds_add_u32: the row has a single writer (this lane), no contention */                   \
+      atomicAdd(reinterpret_cast<uint32_t *>(rc + (meta & 32u)), 1u); /* counts[ori][c]++ */                     \
+      atomicAdd(reinterpret_cast<uint32_t *>(rc + 68), q); /* quality[c] += q (integer; converted below) */      \
+      m2sum += meta >> 8;                                  /* mapq2 += mapq^2 */                                 \
+    }                                                                                                            \
+  }
+        for (; cnt >= 4u; cnt -= 4u) {
+          ACC_LOAD(0) ACC_LOAD(1) ACC_LOAD(2) ACC_LOAD(3)
+          ACC_UPDATE(0) ACC_UPDATE(1) ACC_UPDATE(2) ACC_UPDATE(3)
         }
+        if (cnt & 2u) {
+          ACC_LOAD(0) ACC_LOAD(1)
+          ACC_UPDATE(0) ACC_UPDATE(1)
+        }
+        if (cnt & 1u) {
+          ACC_LOAD(0)
+          ACC_UPDATE(0)
+        }
+#undef ACC_LOAD
+#undef ACC_UPDATE
       }
       t0 += 64u;
+      if (more) fetch(t0, xv, d0, d1); /* a second batch is rare (deep or long-insert data) */
     }
     row[25] = m2sum;
 
@@ -285,6 +321,11 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
 #pragma unroll
       for (int i = 0; i < IN_DW; i++) dst[lane * IN_DW + i] = row[i];
     }
+    t0 = t0_next;
+    t0_next = t0_nn;
+    xv = xv_n;
+    d0 = n0;
+    d1 = n1;
   }
   if (__any(inexact)) {
     const unsigned long long m = __ballot(inexact);
