@@ -25,6 +25,11 @@ $(LIBDIR)/accumulate.o: $(CSRC)/accumulate.hip $(CSRC)/devtables.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+# rocPRIM's device radix sort (ROCm's primitive library): orders a block's templates by leftmost position
+$(LIBDIR)/sort.o: $(CSRC)/sort.hip
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -Wno-deprecated-declarations -c $< -o $@
+
 $(LIBDIR)/vcfcore.o: $(CSRC)/vcfcore.hip $(CSRC)/devtables.h $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -37,7 +42,7 @@ $(LIBDIR)/synth_reads.o: $(CSRC)/synth_reads.c include/bscall_amd.h $(CSRC)/synt
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/accumulate.o $(LIBDIR)/vcfcore.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o
+$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
 
 oracle:

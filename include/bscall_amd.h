@@ -146,7 +146,8 @@ int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref
  *   seq       the concatenated read bytes the templates point into (seq_bytes long)
  *   out       y - x + 1 pile-ups (host memory), zero where nothing is covered
  * Returns BSC_ERR_ARG where the reference asserts (y < x; a template starting left of x; orientation > 1) or
- * where a template points outside seq; BSC_WARN_INEXACT if a position's quality or MAPQ^2 sum exceeded 2^24
+ * where a template points outside seq — the templates are checked by the kernel that reads them, before anything
+ * they point at is touched, and nothing is written to `out` for a bad block; BSC_WARN_INEXACT if a position's quality or MAPQ^2 sum exceeded 2^24
  * (the reference's float sums are order-dependent there).  Uses ctx min_qual.
  */
 int bsc_accumulate(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
@@ -164,10 +165,12 @@ int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
 /*
  * Asynchronous form of bsc_call_block, mirroring how call_genotypes_ML() dispatches a block to the calc threads and
  * returns at once (src/call_genotypes.c:260-272) so that the process thread can prepare the next block meanwhile:
- *   bsc_block_submit  validates, copies the block's inputs into pinned staging (tpl / seq / ref may be recycled when it
+ *   bsc_block_submit  copies the block's inputs into pinned staging (tpl / seq / ref may be recycled when it
  *                     returns, as the reference's align_list is), queues copy + accumulate + call, returns;
  *   bsc_block_fetch   waits for that block and copies its records into out / skip (sizes as submitted); returns
- *                     BSC_WARN_INEXACT like bsc_accumulate.
+ *                     BSC_WARN_INEXACT like bsc_accumulate.  The templates are checked on the device (see
+ *                     bsc_accumulate), so a block that breaks one of the reference's asserts is reported here,
+ *                     BSC_ERR_ARG, with nothing written — not by bsc_block_submit.
  * One block in flight per context, as in the reference (src/call_genotypes.c:161-168).
  */
 int bsc_block_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,

@@ -165,6 +165,51 @@ def test_async_block_submit_fetch(caller, oracle, tables, libm_exact):
         caller.block_fetch()
 
 
+def test_device_side_validation(caller, oracle, tables, libm_exact):
+    """The templates are checked by the kernel that reads them: the first invalid template (lowest index, checks in
+    the reference's order) is named, nothing is written for a bad block, a submitted block reports at fetch, and an
+    unsorted submitted block is sorted and re-run behind the scenes."""
+    tpl, seq, x, y = _block(SEED + 70, 10_000, 30_000, 20)
+    ref = B.synth_ref_host(SEED + 70, x, y - x + 1)
+    bad = tpl.copy()
+    bad["orientation"][900] = 3
+    bad["bs_strand"][900] = 7  # same template: the orientation check comes first
+    bad["off"][400, 0] = len(seq) - 10  # read 0 of an earlier template runs past the buffer
+    bad["bs_strand"][2500] = 3
+    with pytest.raises(B.BscError) as e:
+        caller.accumulate(bad, seq, x, y)
+    assert "read 0 of template 400" in str(e.value)
+    bad["off"][400, 0] = tpl["off"][400, 0]
+    with pytest.raises(B.BscError) as e:
+        caller.accumulate(bad, seq, x, y)
+    assert "template 900 has orientation 3" in str(e.value)
+    bad["orientation"][900] = 1
+    with pytest.raises(B.BscError) as e:
+        caller.accumulate(bad, seq, x, y)
+    assert "template 900 has bs_strand 7" in str(e.value)
+    # nothing is written for a bad block
+    out = np.full(y - x + 1, 0x5A, dtype=np.uint8).repeat(200).view(B.GT_METH)
+    skip = np.full(y - x + 1, 0x5A, dtype=np.uint8)
+    with pytest.raises(B.BscError):
+        caller.call_block(bad, seq, x, y, ref, out=out, skip=skip)
+    assert (out.view(np.uint8) == 0x5A).all() and (skip == 0x5A).all()
+    # asynchronous form: the verdict arrives with the fetch, and the context stays usable
+    caller.block_submit(bad, seq, x, y, ref)
+    with pytest.raises(B.BscError) as e:
+        caller.block_fetch()
+    assert "template 900" in str(e.value)
+    # an unsorted list through submit / fetch
+    flav = oracle.LIBM if libm_exact else oracle.BSM
+    rc, pile = oracle.accumulate(tpl, seq, x, y, 20)
+    exp, eskip = oracle.call_sites(pile, ref, tables, flav, -8)
+    perm = np.random.default_rng(5).permutation(len(tpl))
+    caller.block_submit(tpl[perm], seq, x, y, ref)
+    got, skip = caller.block_fetch()
+    assert (skip == eskip).all() and got.tobytes() == exp.tobytes()
+    got, skip = caller.call_block(tpl[perm], seq, x, y, ref)
+    assert (skip == eskip).all() and got.tobytes() == exp.tobytes()
+
+
 def test_plain_c_host_program():
     """integration/demo_block.c: a gcc-built C program drives the library through the C ABI alone."""
     import os

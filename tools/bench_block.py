@@ -26,13 +26,21 @@ with B.SiteCaller() as c:
     skip = np.zeros(nn, dtype=np.uint8)
     c.accumulate(tpl, seq, x, y, out=pile)  # warm-up: allocations
     c.call_block(tpl, seq, x, y, ref, out=out, skip=skip)
+    # the same with every host buffer page-locked (bsc_alloc_host): DMA straight to/from the caller's memory
+    p_tpl, p_seq, p_ref = B.PinnedBuffer(len(tpl), tpl.dtype), B.PinnedBuffer(len(seq), np.uint8), B.PinnedBuffer(len(ref), np.uint8)
+    p_tpl.array[:], p_seq.array[:], p_ref.array[:] = tpl, seq, ref
+    p_pile, p_out, p_skip = B.PinnedBuffer(nn, B.PILEUP), B.PinnedBuffer(nn, B.GT_METH), B.PinnedBuffer(nn, np.uint8)
     for name, fn in (("accumulate", lambda: c.accumulate(tpl, seq, x, y, out=pile)),
-                     ("call_block", lambda: c.call_block(tpl, seq, x, y, ref, out=out, skip=skip))):
+                     ("call_block", lambda: c.call_block(tpl, seq, x, y, ref, out=out, skip=skip)),
+                     ("accumulate/pinned", lambda: c.accumulate(p_tpl.array, p_seq.array, x, y, out=p_pile.array)),
+                     ("call_block/pinned", lambda: c.call_block(p_tpl.array, p_seq.array, x, y, p_ref.array,
+                                                                out=p_out.array, skip=p_skip.array))):
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
             fn()
             ts.append(time.perf_counter() - t0)
         t = min(ts)
-        print("%-11s %.1f ms  -> %.1f M positions/s, %.1f M bases/s (host buffers, PCIe included)" % (
+        print("%-18s %.1f ms  -> %.1f M positions/s, %.1f M bases/s (host buffers, PCIe included)" % (
             name, t * 1e3, (y - x + 1) / t / 1e6, len(seq) / t / 1e6))
+    assert np.array_equal(p_out.array, out) and np.array_equal(p_skip.array, skip)
