@@ -5,11 +5,10 @@
  *
  *   bsc_order_keys_kernel   one thread per template: the reference's asserts on the template and its sort key (the
  *                           leftmost position); sort.hip orders the block's templates by it on the device.
- *   bsc_prep_reads_kernel   one thread per template, in sorted order: the leading/trailing scan that finds each read's first and
- *                           last countable base (:198-211), the orientation each read is counted with (:187,224,
- *                           including the reference's quirk that a skipped read 0 does not flip it), and a
- *                           compact per-read descriptor; also the template's leftmost position and the largest
- *                           template extent of the block.
+ *   bsc_prep_reads_kernel   one thread per template, in sorted order: the leading/trailing scan that finds each
+ *                           read's first and last countable base (:198-211), the orientation each read is counted
+ *                           with (:187,224, including the reference's quirk that a skipped read 0 does not flip
+ *                           it), and a compact per-read descriptor; also the largest template extent of the block.
  *   bsc_tile_lo_kernel      one thread per 64-position wave-tile: binary search for the first template that can
  *                           reach the tile (the templates are in leftmost-position order by now).
  *   bsc_accumulate_kernel   one wave per wave-tile, lane i OWNS position i of the tile: the wave walks the

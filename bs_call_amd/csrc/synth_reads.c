@@ -18,7 +18,8 @@
 #include "synth.h"
 
 /* Returns the number of templates written (<= max_templates) or -1 if a buffer is too small.
- * seq_used receives the number of bytes written to seq.  Templates come out sorted by leftmost position. */
+ * seq_used receives the number of bytes written to seq.  Templates come out in the order of the pairs' start positions; the 1 % that lost their forward read are
+ * therefore out of leftmost-position order. */
 int64_t bsc_synth_reads_host(uint64_t seed, uint32_t x, uint32_t n_sites, uint32_t coverage, uint32_t flags,
                              bsc_template *tpl, uint64_t max_templates, uint8_t *seq, uint64_t seq_cap,
                              uint64_t *seq_used) {

@@ -141,8 +141,8 @@ int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref
 /*
  * bsc_accumulate: HOT LOOP A of call_genotypes_ML (src/call_genotypes.c:178-226) on the device: scatter the
  * block's reads into the pile-up of positions x..y (inclusive, 1-based genome positions as in the reference).
- *   tpl[nr]   templates, sorted by leftmost position as the reference's align_list is (an unsorted list is
- *             accepted and sorted internally: the sums do not depend on the order)
+ *   tpl[nr]   templates in any order, like the reference's align_list (the sums do not depend on the order; the
+ *             device orders them by leftmost position for its own tiling)
  *   seq       the concatenated read bytes the templates point into (seq_bytes long)
  *   out       y - x + 1 pile-ups (host memory), zero where nothing is covered
  * Returns BSC_ERR_ARG where the reference asserts (y < x; a template starting left of x; orientation > 1) or
@@ -248,8 +248,9 @@ int bsc_reset_stats(bsc_context *ctx);
 int bsc_synth_pileup_device(bsc_context *ctx, uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage,
                             uint32_t flags, void *d_cts, void *d_ref, void *stream);
 /* Host generator of synthetic read pairs over positions x .. x+n_sites-1 ('L-reads'; see
- * bs_call_amd/csrc/synth_reads.c): fills tpl[] (sorted by leftmost position) and seq[]; returns the number of
- * templates, or -1 if a buffer is too small.  Reference bases come from the same synthetic genome as the
+ * bs_call_amd/csrc/synth_reads.c): fills tpl[] (in the order of the pairs' start positions — a template that lost its
+ * forward read is therefore out of leftmost-position order, as in real align_lists) and seq[]; returns the number
+ * of templates, or -1 if a buffer is too small.  Reference bases come from the same synthetic genome as the
  * L-pileup generator (site index = position). */
 int64_t bsc_synth_reads_host(uint64_t seed, uint32_t x, uint32_t n_sites, uint32_t coverage, uint32_t flags,
                              bsc_template *tpl, uint64_t max_templates, uint8_t *seq, uint64_t seq_cap,
