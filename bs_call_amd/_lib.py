@@ -26,6 +26,10 @@ EXPORTS = (
     "bsc_vcf_records",
     "bsc_vcf_records_device",
     "bsc_vcf_format",
+    "bsc_vcf_stats",
+    "bsc_vcf_stats_device",
+    "bsc_get_site_stats",
+    "bsc_reset_site_stats",
     "bsc_set_profiling",
     "bsc_last_kernel_ms",
     "bsc_synchronize",
@@ -147,6 +151,14 @@ def load():
     L.bsc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.bsc_reset_stats.restype = i32
     L.bsc_reset_stats.argtypes = [vp]
+    L.bsc_vcf_stats_device.restype = i32
+    L.bsc_vcf_stats_device.argtypes = [vp, vp, vp, u32, vp, u32, vp]
+    L.bsc_vcf_stats.restype = i32
+    L.bsc_vcf_stats.argtypes = [vp, vp, vp, u32, vp, u32]
+    L.bsc_get_site_stats.restype = i32
+    L.bsc_get_site_stats.argtypes = [vp, vp]
+    L.bsc_reset_site_stats.restype = i32
+    L.bsc_reset_site_stats.argtypes = [vp]
     L.bsc_synth_pileup_device.restype = i32
     L.bsc_synth_pileup_device.argtypes = [vp, u64, u64, u64, u32, u32, vp, vp, vp]
     L.bsc_synth_pileup_host.restype = i32

@@ -61,3 +61,19 @@ VCF_CORE = np.dtype(
         "itemsize": 64,
     }
 )
+
+# bsc_site_stats (include/bscall_amd.h): the sum fields of the reference's bs_stats (src/print_vcf.c:382-526)
+COV_CAP = 4096
+SITE_STATS = np.dtype(
+    [
+        ("snps", "<u8", (2,)), ("indels", "<u8", (2,)), ("multi", "<u8", (2,)), ("dbSNP_sites", "<u8", (2,)),
+        ("dbSNP_var", "<u8", (2,)), ("CpG_ref", "<u8", (2,)), ("CpG_nonref", "<u8", (2,)),
+        ("mut_counts", "<u8", (12, 2)), ("dbSNP_mut_counts", "<u8", (12, 2)),
+        ("qual", "<u8", (4, 256)),
+        ("filter_counts", "<u8", (2, 32)),
+        ("qd_stats", "<u8", (256, 2)), ("fs_stats", "<u8", (256, 2)), ("mq_stats", "<u8", (256, 2)),
+        ("cov", "<u8", (COV_CAP, 6)),
+        ("CpG_ref_meth", "<f8", (2, 101)), ("CpG_nonref_meth", "<f8", (2, 101)),
+    ]
+)
+SITE_STATS_INT_WORDS = (SITE_STATS.itemsize - 4 * 101 * 8) // 8  # the leading u64 part; the rest is 404 doubles

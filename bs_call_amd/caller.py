@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .abi import GT_METH, PILEUP, TEMPLATE, VCF_CORE
+from .abi import GT_METH, PILEUP, SITE_STATS, TEMPLATE, VCF_CORE
 
 SYNTH_NRUNS = 1
 
@@ -156,6 +156,29 @@ class SiteCaller:
                            reg_stop=0xFFFFFFFF, d_dbsnp=None, stream=None):
         p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
         _check(self._L.bsc_vcf_records_device(self._h, d_gtm, stride, d_skip, d_ref, d_dbsnp, n, x, C.byref(p), d_out, stream))
+
+    # -- site statistics (the sums of the reference's bs_stats; the payload of a sharded run's all-reduce) -----
+    def vcf_stats(self, core, gtm, dbsnp=None):
+        """Add the statistics of one block (VCF_CORE[n] from vcf_records + the GT_METH[n] behind them) to the context."""
+        core = np.ascontiguousarray(core, dtype=VCF_CORE)
+        gtm = np.ascontiguousarray(gtm)
+        stride = gtm.dtype.itemsize if gtm.ndim == 1 else gtm.shape[1]
+        if len(gtm) != len(core):
+            raise ValueError("core and gtm differ in length")
+        db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+        _check(self._L.bsc_vcf_stats(self._h, _ptr(core), _ptr(gtm), stride, None if db is None else _ptr(db), len(core)))
+
+    def vcf_stats_device(self, d_core, d_gtm, stride, n, d_dbsnp=None, stream=None):
+        _check(self._L.bsc_vcf_stats_device(self._h, d_core, d_gtm, stride, d_dbsnp, n, stream))
+
+    def site_stats(self):
+        """The accumulated bsc_site_stats as a numpy record (SITE_STATS)."""
+        out = np.zeros(1, dtype=SITE_STATS)
+        _check(self._L.bsc_get_site_stats(self._h, _ptr(out)))
+        return out[0]
+
+    def reset_site_stats(self):
+        _check(self._L.bsc_reset_site_stats(self._h))
 
     # -- device-resident blocks (raw device pointers, e.g. torch tensor .data_ptr()) ---------------
     def call_sites_device(self, d_cts, d_ref, n, d_out, d_skip, out_stride=200, stream=None):

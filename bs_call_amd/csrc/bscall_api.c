@@ -29,6 +29,11 @@ int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uin
                               size_t sort_tmp_bytes, void *rd, void *x1, void *tile_lo, void *cts, void *counters,
                               int num_cus, void *stream);
 int bsc_dev_sort_tmp_bytes(uint32_t nr, size_t *bytes); /* sort.hip */
+int bsc_dev_launch_site_stats(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp, uint32_t n,
+                              const void *tb, const void *logp, const void *carry_in, void *carry_out, void *stats,
+                              void *pairs, int num_cus, void *stream); /* sitestats.hip */
+int bsc_dev_launch_meth_eval(void *pairs, const void *tb, const void *logp, void *stats, int num_cus, void *stream);
+#define BSC_PAIR_BYTES (4u * 64u * 64u * 8u) /* sitestats.hip: [ref / non-ref][all / passed][a < 64][b < 64] u64 */
 int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const void *ref, const void *dbsnp, uint32_t n,
                        uint32_t x, int all_positions, uint32_t reg_start, uint32_t reg_stop, const void *tb, void *g,
                        void *out, int num_cus, void *stream);
@@ -61,6 +66,12 @@ struct bsc_context {
   size_t cap_keys, cap_keys_s, cap_perm, cap_sorttmp;
   void *d_vg, *d_vout, *d_vdb; /* VCF record formation: called genotypes, records, dbSNP flags */
   size_t cap_vg, cap_vout, cap_vdb;
+  /* site statistics (sitestats.hip): the bsc_site_stats block, the printer's CpG carry (two alternating pairs of
+   * words: a launch reads one and writes the other), logp[100] (src/init_param.c:56) */
+  void *d_sstats, *d_pairs; /* d_pairs: CpG cytosines per (a, b), turned into profiles when the statistics are read */
+  uint32_t *d_carry;
+  double *d_logp;
+  unsigned carry_slot;
   void *h_stage;     /* pinned staging of a submitted block's inputs (templates, reads, ref codes) */
   size_t cap_stage;
   uint64_t pending_sz;      /* positions of the submitted, not yet fetched block (0 = none) */
@@ -221,6 +232,10 @@ int bsc_destroy(bsc_context *ctx) {
   if (ctx->s_in) hipStreamDestroy(ctx->s_in);
   if (ctx->s_out) hipStreamDestroy(ctx->s_out);
   hipFree(ctx->d_vg);
+  hipFree(ctx->d_sstats);
+  hipFree(ctx->d_pairs);
+  hipFree(ctx->d_carry);
+  hipFree(ctx->d_logp);
   hipFree(ctx->d_vout);
   hipFree(ctx->d_vdb);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
@@ -662,6 +677,98 @@ int bsc_synchronize(bsc_context *ctx) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_synchronize: ctx is NULL");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return BSC_OK;
+}
+
+/* ---- site statistics -------------------------------------------------------------------------------------- */
+static int bsc_sstats_init(bsc_context *ctx) {
+  if (ctx->d_sstats) return BSC_OK;
+  double logp[100];
+  for (int i = 0; i < 100; i++) logp[i] = log(0.01 * (double)(i + 1)); /* src/init_param.c:56, libm like the reference */
+  if (hipMalloc(&ctx->d_sstats, sizeof(bsc_site_stats)) != hipSuccess ||
+      hipMalloc(&ctx->d_pairs, BSC_PAIR_BYTES) != hipSuccess || hipMemset(ctx->d_pairs, 0, BSC_PAIR_BYTES) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_carry, 4 * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_logp, sizeof logp) != hipSuccess ||
+      hipMemset(ctx->d_sstats, 0, sizeof(bsc_site_stats)) != hipSuccess ||
+      hipMemset(ctx->d_carry, 0, 4 * sizeof(uint32_t)) != hipSuccess ||
+      hipMemcpy(ctx->d_logp, logp, sizeof logp, hipMemcpyHostToDevice) != hipSuccess) {
+    hipFree(ctx->d_sstats);
+  hipFree(ctx->d_pairs);
+    hipFree(ctx->d_carry);
+    hipFree(ctx->d_logp);
+    ctx->d_sstats = NULL;
+    ctx->d_carry = NULL;
+    ctx->d_logp = NULL;
+    return bsc_fail(BSC_ERR_NOMEM, "site statistics: device allocation failed");
+  }
+  ctx->carry_slot = 0;
+  return BSC_OK;
+}
+
+int bsc_vcf_stats_device(bsc_context *ctx, const void *d_core, const void *d_gtm, uint32_t gtm_stride,
+                         const void *d_dbsnp, uint32_t n, void *stream) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_stats_device: ctx is NULL");
+  int rc = bsc_check_stride(gtm_stride);
+  if (rc) return rc;
+  if (n == 0) return BSC_OK;
+  if (!d_core || !d_gtm) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_stats_device: NULL buffer");
+  if (((uintptr_t)d_core & 15u) || ((uintptr_t)d_gtm & 7u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_vcf_stats_device: d_core must be 16-byte and d_gtm 8-byte aligned");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if ((rc = bsc_sstats_init(ctx))) return rc;
+  const unsigned in = ctx->carry_slot, out = in ^ 1u;
+  int e = bsc_dev_launch_site_stats(d_core, d_gtm, gtm_stride, d_dbsnp, n, ctx->d_tables, ctx->d_logp,
+                                    ctx->d_carry + 2 * in, ctx->d_carry + 2 * out, ctx->d_sstats, ctx->d_pairs, ctx->num_cus,
+                                    stream);
+  if (e) return bsc_fail(BSC_ERR_HIP, "site statistics launch failed: %s", hipGetErrorString((hipError_t)e));
+  ctx->carry_slot = out;
+  return BSC_OK;
+}
+
+int bsc_vcf_stats(bsc_context *ctx, const bsc_vcf_core *core, const void *gtm, uint32_t gtm_stride, const uint8_t *dbsnp,
+                  uint32_t n) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_stats: ctx is NULL");
+  int rc = bsc_check_stride(gtm_stride);
+  if (rc) return rc;
+  if (n == 0) return BSC_OK;
+  if (!core || !gtm) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_stats: NULL buffer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)n * gtm_stride))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)n * sizeof(bsc_vcf_core)))) return rc;
+  if (dbsnp && (rc = bsc_reserve(&ctx->d_vdb, &ctx->cap_vdb, (size_t)n))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->d_out, gtm, (size_t)n * gtm_stride, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->d_vout, core, (size_t)n * sizeof(bsc_vcf_core), hipMemcpyHostToDevice, ctx->stream));
+  if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, dbsnp, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = bsc_vcf_stats_device(ctx, ctx->d_vout, ctx->d_out, gtm_stride, dbsnp ? ctx->d_vdb : NULL, n, ctx->stream)))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return BSC_OK;
+}
+
+int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out) {
+  if (!ctx || !out) return bsc_fail(BSC_ERR_ARG, "bsc_get_site_stats: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->d_sstats) {
+    memset(out, 0, sizeof *out);
+    return BSC_OK;
+  }
+  HIP_TRY(hipDeviceSynchronize()); /* the statistics kernels run on whatever stream the caller chose */
+  int e = bsc_dev_launch_meth_eval(ctx->d_pairs, ctx->d_tables, ctx->d_logp, ctx->d_sstats, ctx->num_cus, ctx->stream);
+  if (e) return bsc_fail(BSC_ERR_HIP, "methylation profile launch failed: %s", hipGetErrorString((hipError_t)e));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(out, ctx->d_sstats, sizeof *out, hipMemcpyDeviceToHost));
+  return BSC_OK;
+}
+
+int bsc_reset_site_stats(bsc_context *ctx) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_reset_site_stats: ctx is NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->d_sstats) return BSC_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(ctx->d_sstats, 0, sizeof(bsc_site_stats)));
+  HIP_TRY(hipMemset(ctx->d_pairs, 0, BSC_PAIR_BYTES));
+  HIP_TRY(hipMemset(ctx->d_carry, 0, 4 * sizeof(uint32_t)));
+  ctx->carry_slot = 0;
   return BSC_OK;
 }
 

@@ -91,6 +91,32 @@ def allreduce_stats(local_stats: np.ndarray, device=None) -> np.ndarray:
     return t.cpu().numpy()
 
 
+def allreduce_site_stats(local, device=None):
+    """Sum the per-rank bsc_site_stats blocks (a SITE_STATS record, SiteCaller.site_stats()) over the default process
+    group: every field is a sum over positions, so the shards of a run add.  Two collectives —
+    the u64 counters as one int64 vector, the methylation profiles as one float64 vector (< 250 KB together:
+    latency-bound, the link bandwidth does not matter).  No-op without a process group."""
+    import torch
+    import torch.distributed as dist
+
+    from .abi import SITE_STATS, SITE_STATS_INT_WORDS
+
+    rec = np.array(local, dtype=SITE_STATS).reshape(1).copy()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec[0]
+    raw = rec.view(np.uint8).reshape(-1)
+    ints = raw[: SITE_STATS_INT_WORDS * 8].view(np.int64)
+    flts = raw[SITE_STATS_INT_WORDS * 8 :].view(np.float64)
+    ti, tf = torch.from_numpy(ints.copy()), torch.from_numpy(flts.copy())
+    if device is not None:
+        ti, tf = ti.to(device), tf.to(device)
+    dist.all_reduce(ti, op=dist.ReduceOp.SUM)
+    dist.all_reduce(tf, op=dist.ReduceOp.SUM)
+    ints[:] = ti.cpu().numpy()
+    flts[:] = tf.cpu().numpy()
+    return rec[0]
+
+
 def gather_contig_stats(per_contig: Dict[int, np.ndarray], n_contigs: int, device=None) -> np.ndarray:
     """Per-contig counter blocks -> the full [n_contigs, STATS_WORDS] table on every rank.  Each contig is owned
     by one rank, so a sum-all-reduce of the zero-padded table is a gather."""

@@ -219,6 +219,45 @@ int bsc_vcf_records_device(bsc_context *ctx, const void *d_gtm, uint32_t gtm_str
                            const void *d_ref, const void *d_dbsnp, uint32_t n, uint32_t x,
                            const bsc_vcf_params *params, void *d_out, void *stream);
 
+/*
+ * Site statistics: the sums the reference's printer adds to bs_stats for every position that reaches
+ * _print_vcf_entry (src/print_vcf.c:382-526; types include/bs_call.h:75-95,120-146) — the payload of the one
+ * collective of a sharded run (every field is a sum, so shards add).  Computed on the device
+ * from the bsc_vcf_core records of a block and the gt_meth records they were made from, accumulated in the context.
+ * Faithful to the reference including its quirks: by the time the statistics are taken `alt` has been walked to its
+ * terminator (:177-181), so every written record counts as a SNP (`alt[0] != '.'`, `alt[1] != ','`) and none as
+ * multi-allelic; a CpG is counted when a '-' strand call directly follows a '+' strand call (prev_cpg_x, which
+ * persists from block to block — pass the blocks of a contig in order).  Not covered: the per-coverage GC
+ * histogram (gt_cov_stats.gc_pcent needs the reference's GC bins), indels (the path calls none), the coverage
+ * table beyond BSC_COV_CAP - 1 (deeper positions share the last row), negative FS values (the reference indexes
+ * its fs_stats vector with them: undefined behaviour there, ignored here).
+ * Integer fields are exact; the methylation profiles are sums of doubles whose order differs from the reference's
+ * position order (relative differences ~1e-15).
+ */
+#define BSC_COV_CAP 4096
+typedef struct {
+  uint64_t snps[2], indels[2], multi[2], dbSNP_sites[2], dbSNP_var[2], CpG_ref[2], CpG_nonref[2]; /* [all, passed] */
+  uint64_t mut_counts[12][2], dbSNP_mut_counts[12][2]; /* stats_mut order AC AG AT CA CG CT GA GC GT TA TC TG */
+  uint64_t qual[4][256];          /* qual_cat: all sites, variant sites, CpG ref, CpG non-ref; index = phred */
+  uint64_t filter_counts[2][32];  /* [het genotype][flt & 31] */
+  uint64_t qd_stats[256][2], fs_stats[256][2], mq_stats[256][2]; /* index = QD / FS / MQ value; [hom, het] */
+  uint64_t cov[BSC_COV_CAP][6];   /* gt_cov_stats by coverage: all, var, CpG[2] (index = total depth), CpG_inf[2]
+                                     (index = informative depth) */
+  double CpG_ref_meth[2][101], CpG_nonref_meth[2][101]; /* [all, passed][methylation %] */
+} bsc_site_stats;
+
+/* Adds the statistics of n positions to the context's block: d_core[n] = the bsc_vcf_core records of the block (as
+ * written by bsc_vcf_records_device), d_gtm the gt_meth records they came from, d_dbsnp = rs_found per position or
+ * NULL.  Asynchronous on `stream`. */
+int bsc_vcf_stats_device(bsc_context *ctx, const void *d_core, const void *d_gtm, uint32_t gtm_stride,
+                         const void *d_dbsnp, uint32_t n, void *stream);
+/* Host-buffer form (copies in, runs, returns when done). */
+int bsc_vcf_stats(bsc_context *ctx, const bsc_vcf_core *core, const void *gtm, uint32_t gtm_stride, const uint8_t *dbsnp,
+                  uint32_t n);
+/* Device -> host (synchronises the device first) / back to zero, the CpG carry included. */
+int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out);
+int bsc_reset_site_stats(bsc_context *ctx);
+
 /* Host-side text rendering of one record as a VCF data line ("CHROM POS ID REF ALT QUAL FILTER INFO FORMAT SAMPLE",
  * tab separated, no newline): the field layout of the record the reference hands to htslib (src/print_vcf.c:160-380).
  * Returns the length written, 0 when c->emit == 0, -1 when buf is too small.  `id` NULL/"" prints ".". */

@@ -49,6 +49,10 @@ def lib():
         L.orc_calc_gt_prob_array.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.orc_vcf_block.restype = None
         L.orc_vcf_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_vcf_block_stats.restype = None
+        L.orc_vcf_block_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_sizeof_site_stats.restype = C.c_int
         L.orc_vcf_tables.restype = None
         L.orc_vcf_tables.argtypes = [C.c_void_p] * 4
         assert L.orc_sizeof_vcf_core() == 64
@@ -155,6 +159,32 @@ def vcf_block(gtm, skip, ref, x, all_positions=False, reg_start=1, reg_stop=0xFF
     out = np.zeros(n, dtype=VCF_CORE)
     db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
     lib().orc_vcf_block(_ptr(gtm), _ptr(skip), _ptr(refz), n, x, _ptr(par), None if db is None else _ptr(db), _ptr(out))
+    return out
+
+
+def vcf_block_stats(gtm, skip, ref, x, stats, carry, lfact_store, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF,
+                    dbsnp=None):
+    """vcf_block with the printer's statistics switched on (src/print_vcf.c:382-526): adds the block to `stats`
+    (a SITE_STATS record array of length 1) and updates carry = uint32[2] {prev_cpg_x, prev_cpg_flt}."""
+    from bs_call_amd.abi import GT_METH, SITE_STATS, VCF_CORE
+
+    assert lib().orc_sizeof_site_stats() == SITE_STATS.itemsize
+    gtm = np.ascontiguousarray(gtm, dtype=GT_METH)
+    skip = np.ascontiguousarray(skip, dtype=np.uint8)
+    n = len(gtm)
+    refz = np.zeros(n + 3, dtype=np.uint8)
+    refz[: n + 2] = ref
+    par = np.array([1 if all_positions else 0, reg_start, reg_stop], dtype=np.uint32)
+    out = np.zeros(n, dtype=VCF_CORE)
+    db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+    libm = C.CDLL("libm.so.6")  # src/init_param.c:56 uses libm's log; numpy's may be a vectorised variant
+    libm.log.restype = C.c_double
+    libm.log.argtypes = [C.c_double]
+    logp = np.array([libm.log(0.01 * float(i + 1)) for i in range(100)], dtype=np.float64)
+    lf = np.ascontiguousarray(lfact_store, dtype=np.float64)
+    assert stats.dtype == SITE_STATS and carry.dtype == np.uint32 and len(carry) == 2
+    lib().orc_vcf_block_stats(_ptr(gtm), _ptr(skip), _ptr(refz), n, x, _ptr(par), None if db is None else _ptr(db), _ptr(out),
+                              _ptr(stats), _ptr(lf), _ptr(logp), _ptr(carry))
     return out
 
 

@@ -9,7 +9,8 @@
  *   orc_vcf_entry  <- _print_vcf_entry     src/print_vcf.c:32-381    (everything up to the htslib encoding)
  * and orc_vcf_block drives them like print_thread does for one block (src/process.c:87-104): every position of the
  * block in order, then a flush.  Instead of encoding a BCF record through htslib (absent here), the fields that would
- * be encoded are stored in an orc_vcf_core record.  dbSNP names, the JSON statistics and the header are not restated.
+ * be encoded are stored in an orc_vcf_core record.  The statistics block of _print_vcf_entry (:382-526) is restated in
+ * orc_vcf_stats_update; dbSNP names, the JSON rendering and the header are not restated.
  *
  * The per-genotype lookup tables of the reference (ref_alt, all_idx, gt_int, gt_flag, cs_str, cflag, gflag) are
  * regenerated from their rule (alleles of the genotype vs. the reference base) in orc_vcf_tables_init and
@@ -54,6 +55,26 @@ typedef struct {
 } orc_vcf_core;
 
 int orc_sizeof_vcf_core(void) { return (int)sizeof(orc_vcf_core); }
+
+/* same layout as bsc_site_stats (include/bscall_amd.h): the sum fields of bs_stats (include/bs_call.h:124-146) with its
+ * gt_vectors and its coverage hash made dense */
+#define ORC_COV_CAP 4096
+typedef struct {
+  uint64_t snps[2], indels[2], multi[2], dbSNP_sites[2], dbSNP_var[2], CpG_ref[2], CpG_nonref[2];
+  uint64_t mut_counts[12][2], dbSNP_mut_counts[12][2];
+  uint64_t qual[4][256];
+  uint64_t filter_counts[2][32];
+  uint64_t qd_stats[256][2], fs_stats[256][2], mq_stats[256][2];
+  uint64_t cov[ORC_COV_CAP][6]; /* all, var, CpG[2], CpG_inf[2] */
+  double CpG_ref_meth[2][101], CpG_nonref_meth[2][101];
+} orc_site_stats;
+
+int orc_sizeof_site_stats(void) { return (int)sizeof(orc_site_stats); }
+
+double lgamma(double);
+static double orc_vcf_lfact(uint32_t x, const double *lfact_store) { /* lfact2, include/bs_call.h:335 */
+  return x < 256 ? lfact_store[x] : lgamma((double)x + 1.0);
+}
 
 /* genotype order AA AC AG AT CC CG CT GG GT TT; alleles as base codes 1..4 */
 static const uint8_t G_A[10] = {1, 1, 1, 1, 2, 2, 2, 3, 3, 4};
@@ -111,7 +132,120 @@ typedef struct {
   orc_vcf_core *out;
   uint32_t x0;
   const orc_vcf_params *par;
+  /* statistics (NULL = par->work.stats == NULL) and the printer's static CpG state (src/print_vcf.c:105-106) */
+  orc_site_stats *stats;
+  const double *lfact_store, *logp;
+  uint32_t prev_cpg_x;
+  int prev_cpg_flt;
 } orc_vcf_state;
+
+/* stats_mut (include/bs_call.h:46) of reference base X -> allele Y, base codes 1..4 */
+static int orc_mut_xy(int x, int y) { return 3 * (x - 1) + (y < x ? y - 1 : y - 2); }
+/* mut_type[gt][rfix] (src/print_vcf.c:46-57), regenerated from its rule; 12 = mut_no */
+static int orc_mut_type(int gt, int rfix) {
+  const int a = G_A[gt], b = G_B[gt];
+  if (rfix == 0) return 12;
+  if (a == b) return a == rfix ? 12 : orc_mut_xy(rfix, a);
+  if (a == rfix) return orc_mut_xy(rfix, b);
+  if (b == rfix) return orc_mut_xy(rfix, a);
+  return 12;
+}
+
+/* src/print_vcf.c:382-526.  `skip`, `flt`, `phred`, `qd`, `fs` as _print_vcf_entry has them at that point; by then `alt`
+ * points at the terminator of the ALT string for every written record (the while loop at :177-181 walked it), so the
+ * reference's `alt[0] != '.'` is always true and `alt[1] == ','` reads the byte behind the literal — taken as "not a
+ * comma" here.  The coverage hash is the dense table `cov`, the per-contig copies and the GC histogram are left out. */
+static void orc_vcf_stats_update(orc_vcf_state *st, const orc_gt_meth *gtm, uint32_t x, int gt, int rfix, int skip,
+                                 uint32_t flt, int phred, uint32_t qd, int fs, const char *cpg, const char *prf_ctxt,
+                                 uint32_t dp, uint32_t d_inf, uint8_t rs_found) {
+  orc_site_stats *stats = st->stats;
+  const uint64_t *counts = gtm->counts;
+  uint64_t *gcov = stats->cov[dp < ORC_COV_CAP ? dp : ORC_COV_CAP - 1];
+  gcov[0]++; /* all */
+  if (skip) return;
+  const int het = t_het[gt];
+  const int snp = 1; /* see above */
+  stats->snps[0]++;
+  if (!flt) stats->snps[1]++;
+  stats->qual[1][phred]++; /* variant_sites */
+  gcov[1]++;               /* var */
+  stats->qd_stats[qd > 255 ? 255 : qd][het]++;
+  if (fs >= 0) stats->fs_stats[fs > 255 ? 255 : fs][het]++; /* a negative index is undefined behaviour in the reference */
+  stats->mq_stats[gtm->mq < 0 ? 0 : (gtm->mq > 255 ? 255 : gtm->mq)][het]++;
+  stats->filter_counts[het ? 1 : 0][flt & 31]++;
+  stats->qual[0][phred]++; /* all_sites */
+  if (rs_found) {
+    stats->dbSNP_sites[0]++;
+    if (snp) stats->dbSNP_var[0]++;
+    if (!flt) {
+      stats->dbSNP_sites[1]++;
+      if (snp) stats->dbSNP_var[1]++;
+    }
+  }
+  if (!strcmp(cpg, "CG")) {
+    static const char *cs_str[10] = {"NA", "+", "-", "NA", "+", "+-", "+", "-", "-", "NA"};
+    int ref_cpg = 0, cpg_ok = 0;
+    uint32_t a = 0, b = 0;
+    if (!strcmp(cs_str[gt], "+")) {
+      st->prev_cpg_x = x;
+      st->prev_cpg_flt = (flt != 0);
+      if (!strncmp(prf_ctxt + 2, "CG", 2)) ref_cpg = 1;
+      a = (uint32_t)counts[5];
+      b = (uint32_t)counts[7];
+      cpg_ok = 1;
+    } else if (!strcmp(cs_str[gt], "-")) {
+      if (!strncmp(prf_ctxt + 1, "CG", 2)) ref_cpg = 1;
+      if (x - st->prev_cpg_x == 1) {
+        if (ref_cpg) {
+          stats->CpG_ref[0]++;
+          if (!(st->prev_cpg_flt || flt)) stats->CpG_ref[1]++;
+        } else {
+          stats->CpG_nonref[0]++;
+          if (!(st->prev_cpg_flt || flt)) stats->CpG_nonref[1]++;
+        }
+      }
+      a = (uint32_t)counts[6];
+      b = (uint32_t)counts[4];
+      cpg_ok = 1;
+    }
+    if (cpg_ok) {
+      stats->qual[ref_cpg ? 2 : 3][phred]++;
+      gcov[ref_cpg ? 2 : 3]++;
+      stats->cov[d_inf < ORC_COV_CAP ? d_inf : ORC_COV_CAP - 1][ref_cpg ? 4 : 5]++;
+      if (a + b) {
+        double meth[101];
+        double konst = orc_vcf_lfact(a + b + 1, st->lfact_store) - orc_vcf_lfact(a, st->lfact_store) -
+                       orc_vcf_lfact(b, st->lfact_store);
+        double sum = 0.0;
+        if (a) meth[0] = 0.0;
+        else sum = meth[0] = exp(konst);
+        if (b) meth[100] = 0.0;
+        else sum = (meth[100] = exp(konst));
+        double da = (double)a, db = (double)b;
+        for (int i = 1; i < 100; i++) sum += (meth[i] = exp(konst + st->logp[i - 1] * da + st->logp[99 - i] * db));
+        for (int i = 0; i < 101; i++) {
+          double z = meth[i] / sum;
+          if (ref_cpg) {
+            stats->CpG_ref_meth[0][i] += z;
+            if (!flt) stats->CpG_ref_meth[1][i] += z;
+          } else {
+            stats->CpG_nonref_meth[0][i] += z;
+            if (!flt) stats->CpG_nonref_meth[1][i] += z;
+          }
+        }
+      }
+    }
+  }
+  const int mut = orc_mut_type(gt, rfix);
+  if (mut != 12) {
+    stats->mut_counts[mut][0]++;
+    if (!flt) stats->mut_counts[mut][1]++;
+    if (rs_found) {
+      stats->dbSNP_mut_counts[mut][0]++;
+      if (!flt) stats->dbSNP_mut_counts[mut][1]++;
+    }
+  }
+}
 
 /* src/print_vcf.c:32-381 without the htslib calls */
 static void orc_vcf_entry(orc_vcf_state *st, const orc_gt_meth *gtm, const char *rf_ctxt, uint32_t x, const char *gt_store,
@@ -225,6 +359,7 @@ static void orc_vcf_entry(orc_vcf_state *st, const orc_gt_meth *gtm, const char 
     o->n_gl = (uint8_t)n_gt;
     for (int i = 0; i < n_gt; i++) o->gl[i] = gtl[i];
   }
+  if (st->stats) orc_vcf_stats_update(st, gtm, x, gt, rfix, skip, flt, phred, qd, fs, cpg, prf_ctxt, dp, d_inf, rs_found);
 }
 
 /* src/print_vcf.c:548-594 */
@@ -291,4 +426,30 @@ void orc_vcf_block(const orc_gt_meth *gtm, const uint8_t *skip, const char *ref,
   memset(out, 0, (size_t)n * sizeof *out);
   for (uint32_t i = 0; i < n; i++) orc_vcf_push(&st, gtm + i, ref, x + i, x, skip[i], dbsnp ? dbsnp[i] : 0);
   orc_vcf_flush(&st);
+}
+
+/*
+ * The same with par->work.stats != NULL: the block's contributions are added to *stats.  lfact_store[256] and
+ * logp[100] are the reference's tables (src/stats_utils.c:14-21, src/init_param.c:56); carry[2] = {prev_cpg_x,
+ * prev_cpg_flt}, the printer's static CpG state, read before and written after the block.
+ */
+void orc_vcf_block_stats(const orc_gt_meth *gtm, const uint8_t *skip, const char *ref, uint32_t n, uint32_t x,
+                         const orc_vcf_params *par, const uint8_t *dbsnp, orc_vcf_core *out, orc_site_stats *stats,
+                         const double *lfact_store, const double *logp, uint32_t *carry) {
+  if (!t_init) orc_vcf_tables_init();
+  orc_vcf_state st;
+  memset(&st, 0, sizeof st);
+  st.out = out;
+  st.x0 = x;
+  st.par = par;
+  st.stats = stats;
+  st.lfact_store = lfact_store;
+  st.logp = logp;
+  st.prev_cpg_x = carry[0];
+  st.prev_cpg_flt = (int)carry[1];
+  memset(out, 0, (size_t)n * sizeof *out);
+  for (uint32_t i = 0; i < n; i++) orc_vcf_push(&st, gtm + i, ref, x + i, x, skip[i], dbsnp ? dbsnp[i] : 0);
+  orc_vcf_flush(&st);
+  carry[0] = st.prev_cpg_x;
+  carry[1] = (uint32_t)st.prev_cpg_flt;
 }

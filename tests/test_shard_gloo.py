@@ -58,13 +58,23 @@ def _worker(rank, world, port, q):
         total += v
     allsum = shard.allreduce_stats(total)
     table = shard.gather_contig_stats(per_contig, len(lengths))
+    # the printer's statistics (bsc_site_stats), one contig at a time on the rank that owns it
+    site = np.zeros(1, dtype=B.SITE_STATS)
+    for ci in shard.assign_contigs(lengths, world)[rank]:
+        first = sum(lengths[:ci])
+        pile, ref = B.synth_pileup_host(777, first, lengths[ci] + 2, 10)
+        out, skip = O.call_sites(pile[: lengths[ci]], ref[: lengths[ci]], tb, O.LIBM, 1)
+        O.vcf_block_stats(out, skip, ref, 1, site, np.zeros(2, dtype=np.uint32), tb.lfact_store)
+    site_sum = shard.allreduce_site_stats(site[0])
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, total, allsum, table))
+    q.put((rank, total, allsum, table, site[0].tobytes(), site_sum.tobytes()))
 
 
 def test_world2_gloo_stats_allreduce():
     import torch.multiprocessing as mp
+
+    import bs_call_amd as B
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -78,7 +88,15 @@ def test_world2_gloo_stats_allreduce():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, t0, a0, tab0), (_, t1, a1, tab1) = res
+    (_, t0, a0, tab0, s0, ss0), (_, t1, a1, tab1, s1, ss1) = res
+    s0, s1, ss0, ss1 = (np.frombuffer(b, dtype=B.SITE_STATS)[0] for b in (s0, s1, ss0, ss1))
+    assert ss0.tobytes() == ss1.tobytes()
+    for f in B.SITE_STATS.names:
+        if f.endswith("_meth"):
+            assert np.allclose(ss0[f], s0[f] + s1[f], rtol=1e-15)
+        else:
+            assert (ss0[f] == s0[f] + s1[f]).all(), f
+    assert ss0["snps"][0] > 1000 and ss0["cov"][:, 0].sum() > 100_000
     assert (a0 == a1).all() and (a0 == t0 + t1).all() and (tab0 == tab1).all()
     assert a0[0] == 150_000 and (tab0.sum(axis=0) == a0).all()
     # same numbers as a single-rank run over the whole genome

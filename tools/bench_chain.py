@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Device-resident chain pile-up -> gt_meth -> VCF records on HBM buffers; run under rocprofv3 --kernel-trace --stats to
+"""Device-resident chain pile-up -> gt_meth -> VCF records -> site statistics on HBM buffers; run under rocprofv3 --kernel-trace --stats to
 get the per-kernel times quoted in DESIGN.md.  usage: python tools/bench_chain.py [sites] [coverage]"""
 import os
 import sys
@@ -28,5 +28,11 @@ with B.SiteCaller() as c:
         c.vcf_records_device(d_out.data_ptr(), 200, d_skip.data_ptr(), d_ref.data_ptr(), n, 1000, d_vcf.data_ptr())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        c.vcf_stats_device(d_vcf.data_ptr(), d_out.data_ptr(), 200, n)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
     emit = int(d_vcf.view(n, 64)[:, 4].sum())
     print("chain over %d positions: %.2f ms -> %.2f G positions/s; %d VCF records (%.1f %%)" % (n, dt * 1e3, n / dt / 1e9, emit, 100.0 * emit / n))
+    st = c.site_stats()
+    print("with site statistics: %.2f ms -> %.2f G positions/s; %d CpGs, %d records per launch" % (
+        dt2 * 1e3, n / dt2 / 1e9, int(st["CpG_ref"][0] + st["CpG_nonref"][0]) // 4, int(st["snps"][0]) // 4))
