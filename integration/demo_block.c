@@ -76,6 +76,20 @@ int main(int argc, char **argv) {
       shown++;
     }
   }
+  /* the printer's run statistics (bs_stats): accumulated on the device block by block, read once at the end */
+  CHECK(bsc_vcf_stats(ctx, vcf, gtm, sizeof *gtm, NULL, sz));
+  bsc_site_stats *ss = malloc(sizeof *ss);
+  CHECK(bsc_get_site_stats(ctx, ss));
+  double meth_mean = 0.0, meth_n = 0.0;
+  for (int i = 0; i < 101; i++) {
+    meth_mean += i * (ss->CpG_ref_meth[0][i] + ss->CpG_nonref_meth[0][i]);
+    meth_n += ss->CpG_ref_meth[0][i] + ss->CpG_nonref_meth[0][i];
+  }
+  printf("statistics: %llu records (%llu PASS), %llu reference CpGs, %llu non-reference CpGs, mean CpG methylation %.1f %%\n",
+         (unsigned long long)ss->snps[0], (unsigned long long)ss->snps[1], (unsigned long long)ss->CpG_ref[0],
+         (unsigned long long)ss->CpG_nonref[0], meth_n > 0 ? meth_mean / meth_n : 0.0);
+  if (ss->snps[0] != emitted) { fprintf(stderr, "statistics disagree with the records\n"); return 1; }
+  free(ss);
   bsc_stats st;
   CHECK(bsc_get_stats(ctx, &st));
   printf("block %u..%u: %lld templates, %llu bases -> %llu positions called (%llu covered), %llu VCF records, %llu het\n", x, y,
