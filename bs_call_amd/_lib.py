@@ -22,6 +22,7 @@ EXPORTS = (
     "bsc_call_block",
     "bsc_block_submit",
     "bsc_block_fetch",
+    "bsc_block_submit_to",
     "bsc_synth_reads_host",
     "bsc_vcf_records",
     "bsc_vcf_records_device",
@@ -133,6 +134,8 @@ def load():
     L.bsc_block_submit.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, u32]
     L.bsc_block_fetch.restype = i32
     L.bsc_block_fetch.argtypes = [vp, vp, vp]
+    L.bsc_block_submit_to.restype = i32
+    L.bsc_block_submit_to.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, u32, vp]
     L.bsc_synth_reads_host.restype = C.c_int64
     L.bsc_synth_reads_host.argtypes = [u64, u32, u32, u32, u32, vp, u64, vp, u64, C.POINTER(u64)]
     L.bsc_vcf_records.restype = i32

@@ -127,8 +127,28 @@ class SiteCaller:
         _check(self._L.bsc_block_submit(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref), out_stride))
         self._pending = (int(y) - int(x) + 1, out_stride)
 
+    def block_submit_to(self, templates, seq, x, y, ref, out, skip):
+        """block_submit with the destination named up front (pinned arrays, see PinnedBuffer): the copy-out is queued
+        behind the kernels; block_fetch() then only waits, reports and returns (out, skip)."""
+        templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        n = int(y) - int(x) + 1
+        if len(ref) != n:
+            raise ValueError("ref must have y - x + 1 entries")
+        stride = out.dtype.itemsize if out.ndim == 1 else out.shape[1]
+        if out.nbytes != n * stride or skip.nbytes != n:
+            raise ValueError("out / skip have the wrong size")
+        _check(self._L.bsc_block_submit_to(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref),
+                                           _ptr(out), stride, _ptr(skip)))
+        self._pending = (out, skip)
+
     def block_fetch(self):
         """Wait for the submitted block and return (GT_METH[n] or uint8[n, stride], skip)."""
+        if not isinstance(self._pending[0], int):  # block_submit_to: the records are already on their way
+            out, skip = self._pending
+            _check(self._L.bsc_block_fetch(self._h, None, None))
+            return out, skip
         n, stride = self._pending
         out = np.zeros(n, dtype=GT_METH) if stride == 200 else np.zeros((n, stride), dtype=np.uint8)
         skip = np.zeros(n, dtype=np.uint8)

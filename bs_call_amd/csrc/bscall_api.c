@@ -76,6 +76,7 @@ struct bsc_context {
   size_t cap_stage;
   uint64_t pending_sz;      /* positions of the submitted, not yet fetched block (0 = none) */
   uint32_t pending_stride;
+  int pending_copied;       /* bsc_block_submit_to: the copy-out is already queued behind the kernels */
   /* the block whose accumulate kernels were queued last (bsc_block_check reads their verdict): host copies of its
    * inputs — the caller's buffers, or the staging area for a submitted block */
   const bsc_template *blk_tpl;
@@ -635,15 +636,37 @@ int bsc_block_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, con
   return BSC_OK;
 }
 
+/* bsc_block_submit + the copy-out queued right behind the kernels, into the caller's (pinned) destination: by the time
+ * the producer thread has prepared the next block the records are usually already in host memory. */
+int bsc_block_submit_to(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                        uint32_t x, uint32_t y, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip) {
+  if (!out || !skip) return bsc_fail(BSC_ERR_ARG, "bsc_block_submit_to: NULL destination");
+  int rc = bsc_block_submit(ctx, tpl, nr, seq, seq_bytes, x, y, ref, out_stride);
+  if (rc) return rc;
+  const uint64_t sz = ctx->pending_sz;
+  hipError_t e = hipMemcpyAsync(out, ctx->d_out, (size_t)sz * out_stride, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(skip, ctx->d_skip, (size_t)sz, hipMemcpyDeviceToHost, ctx->stream);
+  if (e != hipSuccess) {
+    ctx->pending_sz = 0;
+    return bsc_fail(BSC_ERR_HIP, "bsc_block_submit_to: copy-out failed: %s", hipGetErrorString(e));
+  }
+  ctx->pending_copied = 1;
+  return BSC_OK;
+}
+
 int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
-  if (!ctx || !out || !skip) return bsc_fail(BSC_ERR_ARG, "bsc_block_fetch: NULL argument");
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_block_fetch: ctx is NULL");
   if (!ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_fetch: no block was submitted");
+  const int copied = ctx->pending_copied;
+  if (!copied && (!out || !skip)) return bsc_fail(BSC_ERR_ARG, "bsc_block_fetch: NULL argument");
   HIP_TRY(hipSetDevice(ctx->device));
   const uint64_t sz = ctx->pending_sz;
   ctx->pending_sz = 0;
+  ctx->pending_copied = 0;
   int inexact = 0;
-  int rc = bsc_block_check(ctx, &inexact); /* the block's templates were checked on the device */
+  int rc = bsc_block_check(ctx, &inexact); /* the block's templates were checked on the device; waits for the stream */
   if (rc) return rc;
+  if (copied) return bsc_inexact_status(inexact); /* the records are where bsc_block_submit_to was told to put them */
   HIP_TRY(hipMemcpyAsync(out, ctx->d_out, (size_t)sz * ctx->pending_stride, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(skip, ctx->d_skip, (size_t)sz, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));

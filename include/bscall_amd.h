@@ -176,6 +176,12 @@ int bsc_call_block(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
 int bsc_block_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                      uint32_t x, uint32_t y, const uint8_t *ref, uint32_t out_stride);
 int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip);
+/* bsc_block_submit with the destination named up front: the copy-out is queued right behind the kernels, so the records
+ * travel to the host while the caller prepares its next block, and bsc_block_fetch(ctx, NULL, NULL) only waits and
+ * reports.  out / skip should come from bsc_alloc_host (with pageable memory the call waits for the block instead of
+ * returning at once); their contents are undefined until the fetch has returned, and after a fetch that failed. */
+int bsc_block_submit_to(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                        uint32_t x, uint32_t y, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip);
 
 /*
  * VCF record formation: what the reference's print thread derives from a block's gt_meth records before it hands a

@@ -163,6 +163,25 @@ def test_async_block_submit_fetch(caller, oracle, tables, libm_exact):
     with pytest.raises(B.BscError):
         caller._pending = (1, 200)
         caller.block_fetch()
+    # destination named at submit (pinned): the copy-out rides behind the kernels, the fetch only waits and reports
+    tpl, seq, x, y, ref, exp, eskip = blocks[0]
+    p_out, p_skip = B.PinnedBuffer(y - x + 1, B.GT_METH), B.PinnedBuffer(y - x + 1, np.uint8)
+    p_out.array.view(np.uint8)[:] = 0xEE
+    caller.block_submit_to(tpl, seq, x, y, ref, p_out.array, p_skip.array)
+    got, skip = caller.block_fetch()
+    assert got is p_out.array and (skip == eskip).all() and got.tobytes() == exp.tobytes()
+    raw = B.PinnedBuffer((y - x + 1, 208), np.uint8)
+    caller.block_submit_to(tpl, seq, x, y, ref, raw.array, p_skip.array)
+    got, skip = caller.block_fetch()
+    assert got[:, :200].tobytes() == exp.tobytes() and (got[:, 201] == eskip).all()
+    bad = tpl.copy()
+    bad["orientation"][3] = 9
+    caller.block_submit_to(bad, seq, x, y, ref, p_out.array, p_skip.array)
+    with pytest.raises(B.BscError):
+        caller.block_fetch()
+    caller.block_submit_to(tpl, seq, x, y, ref, p_out.array, p_skip.array)  # the context is usable afterwards
+    got, skip = caller.block_fetch()
+    assert got.tobytes() == exp.tobytes()
 
 
 def test_device_side_validation(caller, oracle, tables, libm_exact):
