@@ -53,6 +53,23 @@
  * word where the constants' low words are zero. */
 
 /* log(x) for positive, normal, finite x: the table path (x = 2^k z, z in [0x1.6p-1, 0x1.6p0)) */
+/*
+ * a * ks + kv / a * kv + ks with both other operands compile-time constants, one kept in an SGPR pair and one in a
+ * VGPR pair (a VALU instruction reads at most one SGPR operand).  Written as the three-address v_fma_f64 by hand:
+ * for a constant addend the compiler emits "v_mov_b64 tmp, kv; v_fmac_f64 tmp, ks, a", i.e. one more VALU issue per
+ * polynomial step of every log and exp (4 % of the kernel's instructions).
+ */
+__device__ static __forceinline__ double fma_sv(double a, double ks, double kv) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(ks), "v"(kv));
+  return d;
+}
+__device__ static __forceinline__ double fma_vs(double a, double kv, double ks) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(kv), "s"(ks));
+  return d;
+}
+
 __device__ static __forceinline__ double log_main(double x, const double *tab) {
   const uint64_t ix = bsm_bits(x);
   const uint32_t hx = (uint32_t)(ix >> 32);
@@ -69,8 +86,8 @@ __device__ static __forceinline__ double log_main(double x, const double *tab) {
   double lo = BSM_FMA(kd, BSM_LOG_LN2LO, (w - hi) + r);
   const double r2 = r * r;
   const double r3 = r * r2;
-  const double q1 = BSM_FMA(r, BSM_LOG_A2, BSM_LOG_A1);
-  const double q3 = BSM_FMA(r, BSM_LOG_A4, BSM_LOG_A3);
+  const double q1 = fma_sv(r, BSM_LOG_A2, BSM_LOG_A1);
+  const double q3 = fma_sv(r, BSM_LOG_A4, BSM_LOG_A3);
   lo = BSM_FMA(r2, BSM_LOG_A0, lo);
   const double q = BSM_FMA(q3, r2, q1);
   return BSM_FMA(q, r3, lo) + hi;
@@ -120,7 +137,7 @@ __device__ static __forceinline__ double log_dev(double x, const double *tab) {
 
 /* exp(x) where x == 0 or 2^-54 <= |x| < 512 (no over/underflow handling, no tiny-x shortcut) */
 __device__ static __forceinline__ double exp_mid(double x, const uint64_t *tab) {
-  const double kd0 = BSM_FMA(x, BSM_EXP_INVLN2N, BSM_EXP_SHIFT);
+  const double kd0 = fma_vs(x, BSM_EXP_INVLN2N, BSM_EXP_SHIFT);
   const uint32_t ki = (uint32_t)bsm_bits(kd0);
   const double kd = kd0 - BSM_EXP_SHIFT;
   const double r = BSM_FMA(kd, BSM_EXP_NEGLN2LON, BSM_FMA(kd, BSM_EXP_NEGLN2HIN, x));
@@ -128,8 +145,8 @@ __device__ static __forceinline__ double exp_mid(double x, const uint64_t *tab) 
   const double tail = bsm_from_bits(ts.x);
   const uint64_t sbits = ts.y + ((uint64_t)(ki << 13) << 32); /* + (ki << 45): only the high word changes */
   const double r2 = r * r;
-  const double p23 = BSM_FMA(r, BSM_EXP_C3, BSM_EXP_C2);
-  const double p45 = BSM_FMA(r, BSM_EXP_C5, BSM_EXP_C4);
+  const double p23 = fma_sv(r, BSM_EXP_C3, BSM_EXP_C2);
+  const double p45 = fma_sv(r, BSM_EXP_C5, BSM_EXP_C4);
   const double t = BSM_FMA(p23, r2, tail + r);
   const double tmp = BSM_FMA(r2 * r2, p45, t);
   const double scale = bsm_from_bits(sbits);
