@@ -279,3 +279,58 @@ def test_fuzz_parameters_and_blocks(oracle, seed, libm_exact):
         rec = c.vcf_records(got, skip, np.concatenate([ref, [1, 2]]).astype(np.uint8), x)
     if libm_exact:
         assert rec.tobytes() == oracle.vcf_block(exp, eskip, np.concatenate([ref, [1, 2]]).astype(np.uint8), x).tobytes()
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_adversarial_template_lists(caller, oracle, seed):
+    """Hand-rolled template lists that no read simulator produces: arbitrary order, mates far apart or swapped, reads of
+    1..400 bases, reads hanging over the block end or starting beyond it, empty and fully trimmed reads, a pile of
+    identical templates, and blocks from one to a few hundred tiles — the ordering, the tile search (largest template
+    extent) and the window clipping of the device stage against the reference's plain loop."""
+    rng = np.random.default_rng(4242 + seed)
+    n_pos = int(rng.choice([1, 63, 64, 65, 1000, 20_000]))
+    x = int(rng.integers(1, 1_000_000))
+    y = x + n_pos - 1
+    nt = int(rng.choice([0, 1, 7, 300, 5000]))
+    if seed == 4:
+        n_pos, nt = 20_000, 5000
+        y = x + n_pos - 1
+    tpl = np.zeros(nt, dtype=B.TEMPLATE)
+    chunks, off = [], 0
+    for i in range(nt):
+        fwd = x + int(rng.integers(0, n_pos + 50))  # some start right of the block
+        gap = int(rng.choice([0, 1, 50, 300, 3000])) * int(rng.choice([1, -1]))
+        rev = max(x, fwd + gap)
+        tpl["orientation"][i] = rng.integers(0, 2)
+        tpl["bs_strand"][i] = rng.integers(0, 3)
+        for k, pos in ((0, fwd), (1, rev)):
+            kind = rng.integers(0, 10)
+            if kind == 0:
+                continue  # read absent: pos 0, len 0
+            rl = int(rng.choice([1, 2, 30, 100, 400]))
+            q = rng.integers(1, 44, size=rl).astype(np.uint8)
+            b = rng.integers(0, 4, size=rl).astype(np.uint8)
+            if kind == 1:
+                q[:] = 63  # fully trimmed
+            elif kind == 2:
+                q[: rl // 3] = 63
+                q[rl - rl // 4:] = 0
+            tpl["pos"][i, k] = pos
+            tpl["len"][i, k] = rl
+            tpl["off"][i, k] = off
+            tpl["mapq"][i, k] = rng.integers(0, 61)
+            chunks.append(b | (q << 2))
+            off += rl
+        if tpl["len"][i, 0] == 0 and tpl["len"][i, 1] == 0:  # the reference never sees a template without reads
+            tpl["pos"][i, 0], tpl["len"][i, 0], tpl["off"][i, 0] = x, 1, off
+            chunks.append(np.array([1 | (30 << 2)], dtype=np.uint8))
+            off += 1
+    if nt >= 300:  # a pile of identical templates and a hot spot
+        tpl[10:60] = tpl[5]
+    seq = np.concatenate(chunks) if chunks else np.zeros(1, dtype=np.uint8)
+    rc, exp = oracle.accumulate(tpl, seq, x, y, 20)
+    assert rc == 0
+    got = caller.accumulate(tpl, seq, x, y)
+    assert got.tobytes() == exp.tobytes()
+    perm = rng.permutation(nt)
+    assert caller.accumulate(tpl[perm], seq, x, y).tobytes() == exp.tobytes()
