@@ -3,7 +3,7 @@
 The compute lives in bs_call_amd/lib/libbscall_amd.so (gfx950 HIP kernels behind the C ABI of
 include/bscall_amd.h).  This package is the thin Python host mirror used by tests and bench.py.
 """
-from .abi import GENOTYPES, GT_HET, GT_METH, PILEUP, SITE_STATS, SITE_STATS_INT_WORDS, TEMPLATE, VCF_CORE  # noqa: F401
+from .abi import GENOTYPES, GT_HET, GT_METH, PILEUP, SITE_STATS, SITE_STATS_INT_WORDS, TEMPLATE, VCF_CORE, VCF_REC  # noqa: F401
 from .caller import (BscError, BscInexactWarning, PinnedBuffer, SiteCaller, synth_pileup_host, synth_reads_host,  # noqa: F401
                      synth_ref_host)
 

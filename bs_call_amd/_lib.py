@@ -27,6 +27,9 @@ EXPORTS = (
     "bsc_vcf_records",
     "bsc_vcf_records_device",
     "bsc_vcf_format",
+    "bsc_vcf_format_rec",
+    "bsc_vcf_compact_device",
+    "bsc_block_records",
     "bsc_vcf_stats",
     "bsc_vcf_stats_device",
     "bsc_get_site_stats",
@@ -154,6 +157,13 @@ def load():
     L.bsc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.bsc_reset_stats.restype = i32
     L.bsc_reset_stats.argtypes = [vp]
+    L.bsc_vcf_compact_device.restype = i32
+    L.bsc_vcf_compact_device.argtypes = [vp, vp, vp, u32, vp, u32, vp, u64, vp, vp]
+    L.bsc_block_records.restype = i32
+    L.bsc_block_records.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, C.POINTER(VcfParams), i32, vp, u64,
+                                    C.POINTER(C.c_uint64)]
+    L.bsc_vcf_format_rec.restype = i32
+    L.bsc_vcf_format_rec.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
     L.bsc_vcf_stats_device.restype = i32
     L.bsc_vcf_stats_device.argtypes = [vp, vp, vp, u32, vp, u32, vp]
     L.bsc_vcf_stats.restype = i32

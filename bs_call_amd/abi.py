@@ -62,6 +62,16 @@ VCF_CORE = np.dtype(
     }
 )
 
+# bsc_vcf_rec (include/bscall_amd.h): a written record, packed — the core record + the gt_meth fields the encoder reads
+VCF_REC = np.dtype(
+    {
+        "names": ["core", "counts", "qual", "mq", "aq", "max_gt", "rs_found"],
+        "formats": [VCF_CORE, ("<u4", (8,)), ("u1", (8,)), "<i4", "<i4", "u1", "u1"],
+        "offsets": [0, 64, 96, 104, 108, 112, 113],
+        "itemsize": 128,
+    }
+)
+
 # bsc_site_stats (include/bscall_amd.h): the sum fields of the reference's bs_stats (src/print_vcf.c:382-526)
 COV_CAP = 4096
 SITE_STATS = np.dtype(

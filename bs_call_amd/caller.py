@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .abi import GT_METH, PILEUP, SITE_STATS, TEMPLATE, VCF_CORE
+from .abi import GT_METH, PILEUP, SITE_STATS, TEMPLATE, VCF_CORE, VCF_REC
 
 SYNTH_NRUNS = 1
 
@@ -176,6 +176,30 @@ class SiteCaller:
                            reg_stop=0xFFFFFFFF, d_dbsnp=None, stream=None):
         p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
         _check(self._L.bsc_vcf_records_device(self._h, d_gtm, stride, d_skip, d_ref, d_dbsnp, n, x, C.byref(p), d_out, stream))
+
+    # -- reads in, written records out (packed: only what the printer would write crosses PCIe) -----------------
+    def block_records(self, templates, seq, x, y, ref, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None,
+                      with_stats=False, out=None):
+        """One block from reads to packed records (VCF_REC[n_written], position order).  ref: uint8[y - x + 3] codes
+        of x .. y + 2.  `out`: optional preallocated VCF_REC array (capacity); default capacity = every position."""
+        templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        n = int(y) - int(x) + 1
+        if len(ref) != n + 2:
+            raise ValueError("ref must have y - x + 3 entries (x .. y + 2)")
+        db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+        if out is None:
+            out = np.zeros(n, dtype=VCF_REC)
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        cnt = C.c_uint64(0)
+        _check(self._L.bsc_block_records(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref),
+                                         None if db is None else _ptr(db), C.byref(p), 1 if with_stats else 0, _ptr(out),
+                                         len(out), C.byref(cnt)))
+        return out[: cnt.value]
+
+    def vcf_compact_device(self, d_core, d_gtm, stride, n, d_out, out_cap, d_count, d_dbsnp=None, stream=None):
+        _check(self._L.bsc_vcf_compact_device(self._h, d_core, d_gtm, stride, d_dbsnp, n, d_out, out_cap, d_count, stream))
 
     # -- site statistics (the sums of the reference's bs_stats; the payload of a sharded run's all-reduce) -----
     def vcf_stats(self, core, gtm, dbsnp=None):

@@ -33,6 +33,10 @@ int bsc_dev_launch_site_stats(const void *core, const void *gtm, uint32_t gtm_st
                               const void *tb, const void *logp, const void *carry_in, void *carry_out, void *stats,
                               void *pairs, int num_cus, void *stream); /* sitestats.hip */
 int bsc_dev_launch_meth_eval(void *pairs, const void *tb, const void *logp, void *stats, int num_cus, void *stream);
+int bsc_dev_scan_tmp_bytes(uint32_t n, size_t *bytes); /* sort.hip */
+int bsc_dev_launch_compact(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp, uint32_t n,
+                           void *tile_cnt, void *tile_off, void *scan_tmp, size_t scan_tmp_bytes, void *out,
+                           uint64_t out_cap, void *total, int num_cus, void *stream); /* compact.hip */
 #define BSC_PAIR_BYTES (4u * 64u * 64u * 8u) /* sitestats.hip: [ref / non-ref][all / passed][a < 64][b < 64] u64 */
 int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const void *ref, const void *dbsnp, uint32_t n,
                        uint32_t x, int all_positions, uint32_t reg_start, uint32_t reg_stop, const void *tb, void *g,
@@ -66,6 +70,9 @@ struct bsc_context {
   size_t cap_keys, cap_keys_s, cap_perm, cap_sorttmp;
   void *d_vg, *d_vout, *d_vdb; /* VCF record formation: called genotypes, records, dbSNP flags */
   size_t cap_vg, cap_vout, cap_vdb;
+  /* packing of written records (compact.hip): records per tile, their prefix sum, scan scratch, the packed block */
+  void *d_tcnt, *d_toff, *d_scantmp, *d_recs;
+  size_t cap_tcnt, cap_toff, cap_scantmp, cap_recs;
   /* site statistics (sitestats.hip): the bsc_site_stats block, the printer's CpG carry (two alternating pairs of
    * words: a launch reads one and writes the other), logp[100] (src/init_param.c:56) */
   void *d_sstats, *d_pairs; /* d_pairs: CpG cytosines per (a, b), turned into profiles when the statistics are read */
@@ -235,6 +242,10 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_vg);
   hipFree(ctx->d_sstats);
   hipFree(ctx->d_pairs);
+  hipFree(ctx->d_tcnt);
+  hipFree(ctx->d_toff);
+  hipFree(ctx->d_scantmp);
+  hipFree(ctx->d_recs);
   hipFree(ctx->d_carry);
   hipFree(ctx->d_logp);
   hipFree(ctx->d_vout);
@@ -701,6 +712,74 @@ int bsc_synchronize(bsc_context *ctx) {
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return BSC_OK;
+}
+
+/* ---- written records, packed ------------------------------------------------------------------------------ */
+int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_gtm, uint32_t gtm_stride,
+                           const void *d_dbsnp, uint32_t n, void *d_out, uint64_t out_cap, void *d_count, void *stream) {
+  if (!ctx || !d_count) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_compact_device: NULL argument");
+  int rc = bsc_check_stride(gtm_stride);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) {
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), (hipStream_t)stream));
+    return BSC_OK;
+  }
+  if (!d_core || !d_gtm || (!d_out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_compact_device: NULL buffer");
+  if (((uintptr_t)d_core & 15u) || ((uintptr_t)d_gtm & 7u) || ((uintptr_t)d_out & 15u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_vcf_compact_device: d_core / d_out must be 16-byte and d_gtm 8-byte aligned");
+  const uint32_t n_tiles = (n + 63u) / 64u;
+  size_t scan_bytes = 0;
+  if (bsc_dev_scan_tmp_bytes(n_tiles, &scan_bytes)) return bsc_fail(BSC_ERR_HIP, "compact: scan size query failed");
+  if ((rc = bsc_reserve(&ctx->d_tcnt, &ctx->cap_tcnt, (size_t)n_tiles * 4u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_toff, &ctx->cap_toff, (size_t)n_tiles * 4u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_scantmp, &ctx->cap_scantmp, scan_bytes ? scan_bytes : 1))) return rc;
+  int e = bsc_dev_launch_compact(d_core, d_gtm, gtm_stride, d_dbsnp, n, ctx->d_tcnt, ctx->d_toff, ctx->d_scantmp, scan_bytes,
+                                 d_out, out_cap, d_count, ctx->num_cus, stream);
+  if (e) return bsc_fail(BSC_ERR_HIP, "compact launch failed: %s", hipGetErrorString((hipError_t)e));
+  return BSC_OK;
+}
+
+int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                      uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
+                      int with_stats, bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out) {
+  if (!ctx || !ref || !params || !n_out || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records: NULL argument");
+  *n_out = 0;
+  int rc = bsc_accumulate_queue(ctx, tpl, nr, seq, seq_bytes, x, y);
+  if (rc) return rc;
+  const uint64_t sz64 = (uint64_t)y - x + 1;
+  if (sz64 > 0xfffffff0ull) return bsc_fail(BSC_ERR_ARG, "bsc_block_records: block too long");
+  const uint32_t sz = (uint32_t)sz64;
+  if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)sz + 2))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)sz * 200u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)sz))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)sz * sizeof(bsc_vcf_core)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_recs, &ctx->cap_recs, (size_t)(out_cap ? out_cap : 1) * sizeof(bsc_vcf_rec)))) return rc;
+  if (dbsnp && (rc = bsc_reserve(&ctx->d_vdb, &ctx->cap_vdb, (size_t)sz))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz + 2, hipMemcpyHostToDevice, ctx->stream));
+  if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, dbsnp, (size_t)sz, hipMemcpyHostToDevice, ctx->stream));
+  int inexact = 0;
+  if ((rc = bsc_block_check(ctx, &inexact))) return rc; /* nothing is written for a bad block */
+  void *d_db = dbsnp ? ctx->d_vdb : NULL;
+  if ((rc = bsc_call_sites_device(ctx, ctx->d_cts, ctx->d_ref, sz, ctx->d_out, 200, ctx->d_skip, ctx->stream))) return rc;
+  if ((rc = bsc_vcf_records_device(ctx, ctx->d_out, 200, ctx->d_skip, ctx->d_ref, d_db, sz, x, params, ctx->d_vout, ctx->stream)))
+    return rc;
+  if (with_stats && (rc = bsc_vcf_stats_device(ctx, ctx->d_vout, ctx->d_out, 200, d_db, sz, ctx->stream))) return rc;
+  unsigned long long *d_total = ctx->d_counters + BSC_CNT_RECORDS;
+  if ((rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 200, d_db, sz, ctx->d_recs, out_cap, d_total, ctx->stream)))
+    return rc;
+  unsigned long long total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *n_out = total;
+  if (total > out_cap)
+    return bsc_fail(BSC_ERR_ARG, "bsc_block_records: the block has %llu records, out_cap is %llu", total,
+                    (unsigned long long)out_cap);
+  if (total) {
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_recs, (size_t)total * sizeof(bsc_vcf_rec), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return bsc_inexact_status(inexact);
 }
 
 /* ---- site statistics -------------------------------------------------------------------------------------- */

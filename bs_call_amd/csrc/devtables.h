@@ -20,7 +20,8 @@ typedef struct {
 #define BSC_CNT_SPAN 13    /* accumulate: largest template extent of the current block (reset per block) */
 #define BSC_CNT_INEXACT 14 /* accumulate: lanes whose quality / MAPQ^2 sums left the exact-float range */
 #define BSC_CNT_ERR 15     /* accumulate: min over invalid templates of (index << 8 | BSC_TERR_*); all ones = none */
-#define BSC_CNT_WORDS 16
+#define BSC_CNT_RECORDS 16 /* bsc_block_records: written records of the block being packed */
+#define BSC_CNT_WORDS 17
 
 /* what the reference asserts about a block's templates (src/call_genotypes.c:186-188) plus the bounds of the read
  * buffer; checked by bsc_order_keys_kernel, ordered as the checks are made */

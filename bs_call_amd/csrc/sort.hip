@@ -1,5 +1,6 @@
 /*
- * sort.hip — device-side ordering of a block's templates by leftmost position.
+ * sort.hip — the two library primitives of the device path (rocPRIM, ROCm's own primitive library): the ordering of a
+ * block's templates by leftmost position, and (at the end of the file) the prefix sum that packs written records.
  *
  * The reference walks its align_list in whatever order the reads arrived (src/call_genotypes.c:181) — the sums do not
  * depend on it.  The accumulate kernels want the templates ordered by leftmost position so that a 64-position tile
@@ -32,4 +33,17 @@ extern "C" int bsc_dev_sort_templates(const void *keys, void *keys_sorted, void 
   return (int)rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint32_t *)keys, (uint32_t *)keys_sorted,
                                         rocprim::counting_iterator<uint32_t>(0), (uint32_t *)perm, nr, 0, key_bits,
                                         (hipStream_t)stream);
+}
+
+/* exclusive prefix sum of n u32 values (compact.hip: record counts per tile -> first slot of each tile) */
+extern "C" int bsc_dev_scan_tmp_bytes(uint32_t n, size_t *bytes) {
+  *bytes = 0;
+  if (n == 0) return 0;
+  return (int)rocprim::exclusive_scan(nullptr, *bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, n,
+                                      rocprim::plus<uint32_t>(), (hipStream_t)0);
+}
+extern "C" int bsc_dev_scan_u32(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream) {
+  if (n == 0) return 0;
+  return (int)rocprim::exclusive_scan(tmp, tmp_bytes, (const uint32_t *)in, (uint32_t *)out, 0u, n,
+                                      rocprim::plus<uint32_t>(), (hipStream_t)stream);
 }

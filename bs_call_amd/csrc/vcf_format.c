@@ -68,3 +68,16 @@ int bsc_vcf_format(const bsc_vcf_core *c, const bsc_gt_meth *g, const char *cont
   if (het) PUT(":%d", c->fs);
   return (int)len;
 }
+
+int bsc_vcf_format_rec(const bsc_vcf_rec *r, const char *contig, const char *id, char *buf, size_t cap) {
+  bsc_gt_meth g;
+  memset(&g, 0, sizeof g);
+  for (int i = 0; i < 8; i++) {
+    g.counts[i] = r->counts[i];
+    g.qual[i] = r->qual[i];
+  }
+  g.mq = r->mq;
+  g.aq = r->aq;
+  g.max_gt = r->max_gt;
+  return bsc_vcf_format(&r->core, &g, contig, id, buf, cap);
+}

@@ -226,6 +226,41 @@ int bsc_vcf_records_device(bsc_context *ctx, const void *d_gtm, uint32_t gtm_str
                            const bsc_vcf_params *params, void *d_out, void *stream);
 
 /*
+ * Written records only, packed — what a host that renders VCF/BCF needs from a block: for every position with
+ * emit = 1, in position order, its bsc_vcf_core and the gt_meth fields the encoder still reads (MC8 = counts,
+ * AMQ = qual, MQ; src/print_vcf.c:306-359).  64 bytes per position on average on WGBS data instead of the 201 of a
+ * gt_vcf entry, which is what bounds the host-buffer paths (PCIe).
+ */
+typedef struct {
+  bsc_vcf_core core;  /* 64 bytes */
+  uint32_t counts[8]; /* gt_meth.counts (a count beyond 2^32 - 1 saturates) */
+  uint8_t qual[8];    /* gt_meth.qual, 0..43 */
+  int32_t mq, aq;     /* gt_meth.mq, gt_meth.aq */
+  uint8_t max_gt;     /* gt_meth.max_gt */
+  uint8_t rs_found;   /* the dbSNP flag that was passed for the position (0 without dbSNP) */
+  uint8_t _pad[14];
+} bsc_vcf_rec;
+
+/* d_core[n] / d_gtm[n] (device) -> d_out[min(*count, out_cap)] packed records and the number of written records of the
+ * block in *d_count (a device u64; records beyond out_cap are counted, not stored).  Asynchronous on `stream`. */
+int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_gtm, uint32_t gtm_stride,
+                           const void *d_dbsnp, uint32_t n, void *d_out, uint64_t out_cap, void *d_count, void *stream);
+
+/*
+ * One block from reads to written records, nothing else crossing PCIe on the way back: accumulate + call + record
+ * formation (+ site statistics when with_stats != 0) + packing.  ref[y - x + 3] = reference codes of x .. y + 2
+ * (work->ref1 as the reference fills it, src/process_template.c:29-30); dbsnp = rs_found per position or NULL.
+ * out[out_cap]: pinned or pageable; *n_out = records written.  BSC_ERR_ARG if out_cap is too small (*n_out then holds
+ * the number needed), otherwise as bsc_call_block.
+ */
+int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                      uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
+                      int with_stats, bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out);
+
+/* bsc_vcf_format for a packed record. */
+int bsc_vcf_format_rec(const bsc_vcf_rec *r, const char *contig, const char *id, char *buf, size_t cap);
+
+/*
  * Site statistics: the sums the reference's printer adds to bs_stats for every position that reaches
  * _print_vcf_entry (src/print_vcf.c:382-526; types include/bs_call.h:75-95,120-146) — the payload of the one
  * collective of a sharded run (every field is a sum, so shards add).  Computed on the device

@@ -41,6 +41,23 @@ with B.SiteCaller() as c:
             fn()
             ts.append(time.perf_counter() - t0)
         t = min(ts)
-        print("%-18s %.1f ms  -> %.1f M positions/s, %.1f M bases/s (host buffers, PCIe included)" % (
+        print("%-20s %.1f ms  -> %.1f M positions/s, %.1f M bases/s (host buffers, PCIe included)" % (
             name, t * 1e3, (y - x + 1) / t / 1e6, len(seq) / t / 1e6))
     assert np.array_equal(p_out.array, out) and np.array_equal(p_skip.array, skip)
+    # reads in, written records out: only the packed records (128 B per written position) cross PCIe on the way back
+    ref2 = B.synth_ref_host(88172645463325252, x, nn + 2)
+    p_ref2 = B.PinnedBuffer(nn + 2, np.uint8)
+    p_ref2.array[:] = ref2
+    p_rec = B.PinnedBuffer(nn, B.VCF_REC)
+    for name, fn in (("block_records", lambda: c.block_records(tpl, seq, x, y, ref2, out=p_rec.array)),
+                     ("block_records/pinned", lambda: c.block_records(p_tpl.array, p_seq.array, x, y, p_ref2.array, out=p_rec.array)),
+                     ("  ... + statistics", lambda: c.block_records(p_tpl.array, p_seq.array, x, y, p_ref2.array, out=p_rec.array,
+                                                                   with_stats=True))):
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            recs = fn()
+            ts.append(time.perf_counter() - t0)
+        t = min(ts)
+        print("%-20s %.1f ms  -> %.1f M positions/s, %d records (%.1f %% of the positions, %.0f B/position back)" % (
+            name, t * 1e3, nn / t / 1e6, len(recs), 100.0 * len(recs) / nn, 128.0 * len(recs) / nn))
