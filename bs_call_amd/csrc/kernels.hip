@@ -318,10 +318,12 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
       const float qs = __uint_as_float(w[17 + j]);
       const bool has = cnt[j] != 0;
       const float nn = (float)max(cnt[j], 1u);
-      /* f32 divide, promoted to f64 for the +0.5, rounded back to f32 by floorf's parameter.  Evaluated for every
-       * lane (the empty asm keeps the compiler from wrapping each of the eight divisions in its own exec-mask
+      /* The reference promotes the f32 quotient to f64 for the +0.5 and floorf's parameter rounds the sum back to
+       * f32.  The f64 sum is exact whenever it matters (|v| >= 2^-30; below that both forms give 0.5), so the detour
+       * equals ONE correctly rounded f32 addition: (float)(0.5 + (double)v) == v + 0.5f, bit for bit.  Evaluated for
+       * every lane (the empty asm keeps the compiler from wrapping each of the eight divisions in its own exec-mask
        * branch: every class is non-empty somewhere in a 64-site tile, so the branches never skip anything). */
-      int q = (int)floorf((float)(0.5 + (double)(qs / nn)));
+      int q = (int)floorf(qs / nn + 0.5f);
       asm volatile("" : "+v"(q));
       tot_qual += has ? qs : 0.0f;
       const uint32_t qb = has ? ((uint32_t)q & 0xffu) : 0u;
@@ -329,7 +331,7 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
       else qpack1 |= qb << (8 * (j - 4));
     }
     const float nf = covered ? (float)n_reads : 1.0f;
-    const int aq = (int)floorf((float)(0.5 + (double)(tot_qual / nf)));
+    const int aq = (int)floorf(tot_qual / nf + 0.5f);
     const int mq = (int)(0.5 + sqrt((double)(mapq2 / nf)));
 /* table index of class j: its packed quality, clamped to the table (only garbage input exceeds 43) */
 #define QI(j) min((((j) < 4 ? qpack0 : qpack1) >> (8 * ((j)&3))) & 0xffu, 43u)

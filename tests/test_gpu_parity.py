@@ -171,6 +171,37 @@ def test_adversarial_random_pileups(caller, oracle, tables, libm_exact):
     assert ((gp[:, -1] - gp[:, -2] < 1e-12) & (skip == 0)).sum() > 5  # the input does contain near-exact ties
 
 
+def test_summary_rounding_boundaries(caller, oracle, tables, libm_exact):
+    """Mean qualities within a few ulps of k + 0.5 (and of k, and tiny / subnormal ones): the reference rounds them through
+    f32 quotient -> f64 + 0.5 -> f32 -> floorf; the kernel's single f32 addition must agree on every one of them."""
+    rng = np.random.default_rng(17)
+    n = 120_000
+    pile = np.zeros(n, dtype=B.PILEUP)
+    cnt = rng.integers(1, 60, size=(n, 8)).astype(np.uint32) * (rng.random((n, 8)) < 0.7)
+    pile["counts"][:, 0, :] = cnt
+    pile["n"] = cnt.sum(axis=1)
+    k = rng.integers(0, 43, size=(n, 8)).astype(np.float64)
+    frac = rng.choice([0.5, 0.0, 0.25, 0.499999, 0.500001], size=(n, 8))
+    target = ((k + frac) * cnt).astype(np.float32)
+    steps = rng.integers(-3, 4, size=(n, 8))
+    for s in (1, 2, 3):  # walk a few ulps up or down
+        target = np.where(steps >= s, np.nextafter(target, np.float32(np.inf)), target)
+        target = np.where(steps <= -s, np.nextafter(target, np.float32(-np.inf)), target)
+    tiny = rng.random((n, 8)) < 0.02
+    target = np.where(tiny, rng.choice([1e-45, 1e-39, 2.0**-31, 2.0**-26, 2.0**-25 * 1.0000001], size=(n, 8)), target).astype(np.float32)
+    pile["quality"] = np.clip(target, 0, None) * (cnt > 0)
+    pile["quality"] = np.minimum(pile["quality"], (43.4 * cnt).astype(np.float32))
+    pile["mapq2"] = (pile["n"] * rng.choice([1, 399.5, 3600, 3599.9], size=n)).astype(np.float32)
+    cov = pile["n"] > 0
+    ref = rng.integers(0, 5, size=n).astype(np.uint8)
+    got, skip = caller.call_sites(pile, ref)
+    exp, eskip = oracle.call_sites(pile, ref, tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
+    assert (skip == eskip).all()
+    assert (got["qual"] == exp["qual"]).all() and (got["aq"] == exp["aq"]).all() and (got["mq"] == exp["mq"]).all()
+    assert got.tobytes() == exp.tobytes()
+    assert (exp["qual"][cov] <= 43).all()
+
+
 def test_gt_vcf_stride(caller, oracle, tables, libm_exact):
     """out_stride = 208 writes straight into a gt_vcf[] image: gtm at 0, ready(=0) at 200, skip at 201."""
     pile, ref = B.synth_pileup_host(SEED, 0, 10_001, 30)
