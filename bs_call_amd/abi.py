@@ -5,6 +5,8 @@ library (or memcpy'd to the device) without conversion:
   PILEUP   = `pileup`   include/bs_call.h:174-182   (104 B)
   GT_METH  = `gt_meth`  include/bs_call.h:152-160   (200 B)
   TEMPLATE = one read pair flattened out of `align_details` (include/bs_call.h:64-73), 40 B
+Every byte of a record belongs to a named field (`_pad` for the C structs' tail padding): numpy copies records field
+by field and would leave unnamed bytes undefined, which breaks byte-wise comparisons of copies.
 """
 import numpy as np
 
@@ -19,18 +21,18 @@ PILEUP = np.dtype(
 
 GT_METH = np.dtype(
     {
-        "names": ["counts", "qual", "gt_prob", "fisher_strand", "mq", "aq", "max_gt"],
-        "formats": [("<u8", (8,)), ("<i4", (8,)), ("<f8", (10,)), "<f8", "<i4", "<i4", "u1"],
-        "offsets": [0, 64, 96, 176, 184, 188, 192],
+        "names": ["counts", "qual", "gt_prob", "fisher_strand", "mq", "aq", "max_gt", "_pad"],
+        "formats": [("<u8", (8,)), ("<i4", (8,)), ("<f8", (10,)), "<f8", "<i4", "<i4", "u1", ("u1", (7,))],
+        "offsets": [0, 64, 96, 176, 184, 188, 192, 193],
         "itemsize": 200,
     }
 )
 
 TEMPLATE = np.dtype(
     {
-        "names": ["pos", "len", "off", "mapq", "orientation", "bs_strand"],
-        "formats": [("<u4", (2,)), ("<u4", (2,)), ("<u8", (2,)), ("u1", (2,)), "u1", "u1"],
-        "offsets": [0, 8, 16, 32, 34, 35],
+        "names": ["pos", "len", "off", "mapq", "orientation", "bs_strand", "_pad"],
+        "formats": [("<u4", (2,)), ("<u4", (2,)), ("<u8", (2,)), ("u1", (2,)), "u1", "u1", "<u4"],
+        "offsets": [0, 8, 16, 32, 34, 35, 36],
         "itemsize": 40,
     }
 )
@@ -54,10 +56,10 @@ BASE_TAB_ST = np.array([[0, 1, 2, 3], [0, 5, 2, 7], [4, 1, 6, 3]], dtype=np.int8
 VCF_CORE = np.dtype(
     {
         "names": ["pos", "emit", "gt", "ref_code", "gt_enc", "flt", "phred", "n_gl", "cg", "alt", "cx_ref", "cx_gt",
-                  "fs", "qd", "dp", "gl"],
+                  "fs", "qd", "dp", "gl", "_pad"],
         "formats": ["<u4", "u1", "u1", "u1", "u1", "u1", "u1", "u1", "S1", "S2", "S5", "S5", "<i4", "<u4", "<u4",
-                    ("<f4", (6,))],
-        "offsets": [0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 19, 24, 28, 32, 36],
+                    ("<f4", (6,)), "<u4"],
+        "offsets": [0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 19, 24, 28, 32, 36, 60],
         "itemsize": 64,
     }
 )
@@ -65,9 +67,9 @@ VCF_CORE = np.dtype(
 # bsc_vcf_rec (include/bscall_amd.h): a written record, packed — the core record + the gt_meth fields the encoder reads
 VCF_REC = np.dtype(
     {
-        "names": ["core", "counts", "qual", "mq", "aq", "max_gt", "rs_found"],
-        "formats": [VCF_CORE, ("<u4", (8,)), ("u1", (8,)), "<i4", "<i4", "u1", "u1"],
-        "offsets": [0, 64, 96, 104, 108, 112, 113],
+        "names": ["core", "counts", "qual", "mq", "aq", "max_gt", "rs_found", "_pad"],
+        "formats": [VCF_CORE, ("<u4", (8,)), ("u1", (8,)), "<i4", "<i4", "u1", "u1", ("u1", (14,))],
+        "offsets": [0, 64, 96, 104, 108, 112, 113, 114],
         "itemsize": 128,
     }
 )

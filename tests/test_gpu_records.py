@@ -125,3 +125,38 @@ def test_compact_device_chain(oracle, tables, libm_exact):
         assert got["core"].tobytes() == core[sel].tobytes()
         assert (got["counts"] == gtm["counts"][sel]).all() and (got["qual"] == gtm["qual"][sel]).all()
         assert (got["mq"] == gtm["mq"][sel]).all() and (got["max_gt"] == gtm["max_gt"][sel]).all()
+
+
+def test_chain_regression_anchor_on_the_device(caller, libm_exact):
+    """The committed fixture of the whole chain (tests/golden/chain_regression.json), reproduced by the device path
+    alone: reads -> pile-up -> gt_meth -> records -> statistics."""
+    import json
+    import os
+
+    if not libm_exact:
+        pytest.skip("fixture was written on a host whose libm equals the replica")
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chain_regression.json")))
+    g = gold["generator"]
+    tpl, seq = B.synth_reads_host(g["seed"], g["x0"], g["n_sites"], g["coverage"])
+    x, y = gold["block"]["x"], gold["block"]["y"]
+    ref = B.synth_ref_host(g["seed"], x, y - x + 3)
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_golden_chain", os.path.join(root, "tools", "make_golden_chain.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    sha = m.digest  # per field: numpy leaves the padding bytes of copied records undefined
+    assert sha(tpl) == gold["sha256"]["templates"] and sha(seq) == gold["sha256"]["seq"] and sha(ref) == gold["sha256"]["ref"]
+    assert sha(caller.accumulate(tpl, seq, x, y)) == gold["sha256"]["pileup"]
+    gtm, skip = caller.call_block(tpl, seq, x, y, ref[: y - x + 1])
+    assert sha(gtm) == gold["sha256"]["gt_meth"] and sha(skip) == gold["sha256"]["skip"]
+    core = caller.vcf_records(gtm, skip, ref, x)
+    assert sha(core) == gold["sha256"]["vcf_core"]
+    caller.reset_site_stats()
+    caller.vcf_stats(core, gtm)
+    st = caller.site_stats()
+    assert sha(np.frombuffer(st.tobytes()[: B.SITE_STATS_INT_WORDS * 8], dtype=np.uint64)) == gold["sha256"]["site_stats_int"]
+    assert abs(float(st["CpG_ref_meth"][0].sum() + st["CpG_nonref_meth"][0].sum()) - gold["meth_profile_sum"]) < 1e-9
+    recs = caller.block_records(tpl, seq, x, y, ref)
+    assert sha(recs["core"]) == sha(core[core["emit"] == 1])

@@ -66,3 +66,26 @@ def test_q_prob_table(tables):
     import math
 
     assert abs(tables.lfact_store[255] - math.lgamma(256.0)) < 1e-9  # ln(255!)
+
+
+def test_chain_regression_anchor(libm_exact):
+    """tests/golden/chain_regression.json (tools/make_golden_chain.py): the whole oracle chain on one small block gives
+    the digests recorded when the fixture was written — a change to the oracle or to the generators shows up here."""
+    import importlib.util
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_golden_chain", os.path.join(root, "tools", "make_golden_chain.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    gold = json.load(open(os.path.join(root, "tests", "golden", "chain_regression.json")))
+    now = m.summary()
+    for k in ("templates", "seq", "ref", "pileup", "gt_meth", "skip"):
+        assert now["sha256"][k] == gold["sha256"][k], k
+    assert now["block"] == gold["block"]
+    if libm_exact:  # the printer's phred goes through the host's exp / log
+        assert now["sha256"]["vcf_core"] == gold["sha256"]["vcf_core"]
+        assert now["sha256"]["site_stats_int"] == gold["sha256"]["site_stats_int"]
+        assert now["site_stats"] == gold["site_stats"] and now["records"] == gold["records"]
+        assert abs(now["meth_profile_sum"] - gold["meth_profile_sum"]) < 1e-9
