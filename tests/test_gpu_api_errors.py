@@ -1,0 +1,67 @@
+"""Argument checking of the C ABI on a live context: every entry refuses NULL / misaligned / inconsistent arguments with
+BSC_ERR_ARG (-1) and a message, and the context stays usable afterwards."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bs_call_amd as B
+from bs_call_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c_abi_rejects_bad_arguments():
+    import torch
+
+    L = _lib.load()
+    with B.SiteCaller() as c:
+        h = c._h
+        n = 1000
+        pile, ref = B.synth_pileup_host(3, 100, n + 2, 20)
+        out = np.zeros(n, dtype=B.GT_METH)
+        skip = np.zeros(n, dtype=np.uint8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        err = lambda: L.bsc_last_error().decode()
+        # NULL pieces and a bad stride
+        assert L.bsc_call_sites(h, None, p(ref), n, p(out), 200, p(skip)) == -1 and err()
+        assert L.bsc_call_sites(h, p(pile), p(ref), n, p(out), 199, p(skip)) == -1 and "stride" in err()
+        assert L.bsc_call_sites(None, p(pile), p(ref), n, p(out), 200, p(skip)) == -1
+        assert L.bsc_call_sites(h, p(pile), p(ref), 0, p(out), 200, p(skip)) == 0  # an empty block is fine
+        # device entries: misaligned pointers
+        d = torch.zeros(n * 264 + 64, dtype=torch.uint8, device="cuda:0")
+        base = d.data_ptr()
+        assert base % 16 == 0
+        st = None
+        assert L.bsc_call_sites_device(h, base + 4, base, n, base, 200, base, st) == -1 and "align" in err()
+        vp = _lib.VcfParams(0, 1, 0xFFFFFFFF)
+        assert L.bsc_vcf_records_device(h, base + 4, 200, base, base, None, n, 1, C.byref(vp), base, st) == -1
+        assert L.bsc_vcf_stats_device(h, base + 8, base, 200, None, n, st) == -1 and "align" in err()
+        assert L.bsc_vcf_stats_device(h, base, base, 123, None, n, st) == -1
+        assert L.bsc_vcf_compact_device(h, base, base, 200, None, n, base, n, None, st) == -1
+        assert L.bsc_vcf_compact_device(h, base, base + 4, 200, None, n, base, n, base, st) == -1
+        # blocks: y < x, NULL reference, fetch without submit, two submits
+        tpl, seq = B.synth_reads_host(5, 1000, 2000, 10)
+        x, y = 998, int((tpl["pos"] + tpl["len"]).max()) - 1
+        ref2 = B.synth_ref_host(5, x, y - x + 3)
+        cnt = C.c_uint64(0)
+        rec = np.zeros(y - x + 1, dtype=B.VCF_REC)
+        assert L.bsc_block_records(h, p(tpl), len(tpl), p(seq), len(seq), x, y, None, None, C.byref(vp), 0, p(rec), len(rec),
+                                   C.byref(cnt)) == -1
+        assert L.bsc_block_records(h, p(tpl), len(tpl), p(seq), len(seq), y, x, p(ref2), None, C.byref(vp), 0, p(rec), len(rec),
+                                   C.byref(cnt)) == -1
+        assert L.bsc_block_records(h, None, len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec),
+                                   C.byref(cnt)) == -1
+        assert L.bsc_block_fetch(h, p(out), p(skip)) == -1 and "no block" in err()
+        assert L.bsc_block_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), 200) == 0
+        assert L.bsc_block_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), 200) == -1 and "fetched" in err()
+        out2 = np.zeros(y - x + 1, dtype=B.GT_METH)
+        skip2 = np.zeros(y - x + 1, dtype=np.uint8)
+        assert L.bsc_block_fetch(h, None, None) == -1  # this block was submitted without a destination ...
+        assert L.bsc_block_fetch(h, p(out2), p(skip2)) == 0  # ... and is still there for a proper fetch
+        assert out2["counts"].sum() > 0
+        # after all that the context still computes
+        got = c.block_records(tpl, seq, x, y, ref2)
+        assert len(got) > 0 and (got["core"]["emit"] == 1).all()
+        ss = np.zeros(1, dtype=B.SITE_STATS)
+        assert L.bsc_get_site_stats(h, None) == -1 and L.bsc_get_site_stats(h, p(ss)) == 0
