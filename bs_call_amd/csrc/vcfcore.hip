@@ -82,7 +82,7 @@ __device__ static __forceinline__ void vdma16(const void *g, void *lds_wave_base
 /*
  * One wave per 64-position wave-tile, no workgroup barrier after the table set-up.  The tile's 64 records (12 800 or
  * 13 312 contiguous bytes) arrive in the wave's LDS slot by LDS-DMA and each lane works on its own record there (stride
- * 50 / 52 dwords: at most 2-way conflicts); the 64-byte results are collected in a second LDS area and leave with
+ * 50 / 52 dwords: at most 2-way conflicts); the 64-byte results are collected in the slot afterwards and leave with
  * 16-byte-per-lane stores.  The called genotypes of the tile go through 68 LDS bytes (2 halo positions each side, which
  * four lanes fetch from global memory).
  */
@@ -91,13 +91,13 @@ extern "C" __global__ __launch_bounds__(64 * VW) void bsc_vcf_core_kernel(
     const uint8_t *__restrict__ dbsnp, uint32_t n, uint32_t x, int all_positions, uint32_t reg_start, uint32_t reg_stop,
     const bsc_dev_tables *__restrict__ tb, bsc_vcf_core_dev *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint32_t s_slot[VW][VSLOT_DW];
-  __shared__ __attribute__((aligned(16))) uint32_t s_out[VW][64 * 16];
-  __shared__ double s_logtab[256];
-  __shared__ unsigned long long s_exptab[256];
   __shared__ uint8_t s_gw[VW][72];
-  s_logtab[threadIdx.x] = tb->log_tab[threadIdx.x];
-  s_exptab[threadIdx.x] = tb->exp_tab[threadIdx.x];
-  __syncthreads();
+  /* LDS holds nothing but the record slots: 53.5 KB per workgroup, so that three workgroups (12 waves) share a CU —
+   * the kernel waits for memory two thirds of its time and lives on waves in flight.  The exp / log tables of the one
+   * QUAL evaluation per record are read from global memory (4 KB, cache resident), the 64-byte results are staged in
+   * the slot itself once every lane has read its record (a wave executes in lockstep). */
+  const double *const g_logtab = tb->log_tab;
+  const uint64_t *const g_exptab = reinterpret_cast<const uint64_t *>(tb->exp_tab);
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t *slot = s_slot[wid];
@@ -183,11 +183,11 @@ extern "C" __global__ __launch_bounds__(64 * VW) void bsc_vcf_core_kernel(
       const bool het = ga != gb;
       bool skip = !all_positions && !(rs_found & 2) && ((gt == 0 && rfix == 1) || (gt == 9 && rfix == 4));
       /* ---- phred (:140-148) ---- */
-      const double z1 = bsm_exp_t(gp[gt] * BSM_LN10, (const uint64_t *)s_exptab);
+      const double z1 = bsm_exp_t(gp[gt] * BSM_LN10, g_exptab);
       int phred;
       if (z1 >= 1.0) phred = 255;
       else {
-        phred = (int)(-10.0 * bsm_log_t(1.0 - z1, s_logtab) / BSM_LN10);
+        phred = (int)(-10.0 * bsm_log_t(1.0 - z1, g_logtab) / BSM_LN10);
         if (phred > 255) phred = 255;
       }
       const double fisher = *reinterpret_cast<const double *>(rec + 176);
@@ -283,9 +283,9 @@ extern "C" __global__ __launch_bounds__(64 * VW) void bsc_vcf_core_kernel(
         for (int k = 0; k < 6; k++) o.gl[k] = k < ngl ? gl[k] : 0.0f;
       }
     }
-    /* ---- results: own 64-byte record -> LDS, then the tile's 4 KiB leave contiguously ---- */
+    /* ---- results: own 64-byte record -> the slot (all record reads are done), then the tile's 4 KiB leave contiguously ---- */
     {
-      uint4 *so = reinterpret_cast<uint4 *>(s_out[wid]);
+      uint4 *so = reinterpret_cast<uint4 *>(slot);
       const uint4 *s4 = reinterpret_cast<const uint4 *>(&o);
 #pragma unroll
       for (int k = 0; k < 4; k++) so[lane * 4 + k] = s4[k];
@@ -310,7 +310,7 @@ extern "C" int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *
   hipStream_t s = (hipStream_t)stream;
   const unsigned n_wt = (n + 63u) / 64u;
   unsigned grid = (n_wt + VW - 1u) / VW;
-  if (grid > (unsigned)num_cus * 2u * 8u) grid = (unsigned)num_cus * 2u * 8u; /* 2 workgroups (74 KB LDS) per CU */
+  if (grid > (unsigned)num_cus * 3u * 8u) grid = (unsigned)num_cus * 3u * 8u; /* 3 workgroups (53.5 KB LDS) per CU */
   hipLaunchKernelGGL(bsc_vcf_core_kernel, dim3(grid), dim3(64 * VW), 0, s, (const uint8_t *)gtm, stride,
                      (const uint8_t *)skip, (const uint8_t *)ref, (const uint8_t *)dbsnp, n, x, all_positions, reg_start,
                      reg_stop, (const bsc_dev_tables *)tb, (bsc_vcf_core_dev *)out);
