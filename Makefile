@@ -38,6 +38,10 @@ $(LIBDIR)/sitestats.o: $(CSRC)/sitestats.hip $(CSRC)/devtables.h $(CSRC)/bsmath.
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(LIBDIR)/probe.o: $(CSRC)/probe.hip
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(LIBDIR)/compact.o: $(CSRC)/compact.hip include/bscall_amd.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -50,7 +54,7 @@ $(LIBDIR)/synth_reads.o: $(CSRC)/synth_reads.c include/bscall_amd.h $(CSRC)/synt
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o
+$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
 
 oracle:

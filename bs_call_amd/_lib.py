@@ -37,6 +37,7 @@ EXPORTS = (
     "bsc_set_profiling",
     "bsc_last_kernel_ms",
     "bsc_synchronize",
+    "bsc_stream_probe_ms",
     "bsc_get_stats",
     "bsc_reset_stats",
     "bsc_synth_pileup_device",
@@ -157,6 +158,8 @@ def load():
     L.bsc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.bsc_reset_stats.restype = i32
     L.bsc_reset_stats.argtypes = [vp]
+    L.bsc_stream_probe_ms.restype = i32
+    L.bsc_stream_probe_ms.argtypes = [vp, vp, vp, u64, vp, vp, i32, vp, C.POINTER(C.c_float)]
     L.bsc_vcf_compact_device.restype = i32
     L.bsc_vcf_compact_device.argtypes = [vp, vp, vp, u32, vp, u32, vp, u64, vp, vp]
     L.bsc_block_records.restype = i32

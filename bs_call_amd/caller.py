@@ -231,6 +231,12 @@ class SiteCaller:
     def synth_device(self, seed, first_site, n, coverage, d_cts, d_ref, flags=0, stream=None):
         _check(self._L.bsc_synth_pileup_device(self._h, seed, first_site, n, coverage, flags, d_cts, d_ref, stream))
 
+    def stream_probe_ms(self, d_cts, d_ref, n, d_out, d_skip, reps=5, stream=None):
+        """Best-of-reps time of the no-arithmetic copy kernel with call_sites_device's traffic (OVERWRITES d_out / d_skip)."""
+        ms = C.c_float(0)
+        _check(self._L.bsc_stream_probe_ms(self._h, d_cts, d_ref, n, d_out, d_skip, reps, stream, C.byref(ms)))
+        return ms.value
+
     def set_profiling(self, enable=True):
         _check(self._L.bsc_set_profiling(self._h, 1 if enable else 0))
 

@@ -34,6 +34,8 @@ int bsc_dev_launch_site_stats(const void *core, const void *gtm, uint32_t gtm_st
                               void *pairs, int num_cus, void *stream); /* sitestats.hip */
 int bsc_dev_launch_meth_eval(void *pairs, const void *tb, const void *logp, void *stats, int num_cus, void *stream);
 int bsc_dev_scan_tmp_bytes(uint32_t n, size_t *bytes); /* sort.hip */
+int bsc_dev_launch_stream_probe(const void *cts, const void *ref, uint64_t n, void *out, void *skip, int num_cus,
+                                void *stream); /* probe.hip */
 int bsc_dev_launch_compact(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp, uint32_t n,
                            void *tile_cnt, void *tile_off, void *scan_tmp, size_t scan_tmp_bytes, void *out,
                            uint64_t out_cap, void *total, int num_cus, void *stream); /* compact.hip */
@@ -705,6 +707,35 @@ int bsc_last_kernel_ms(bsc_context *ctx, float *call_ms, float *fisher_ms) {
   if (call_ms) *call_ms = a;
   if (fisher_ms) *fisher_ms = b;
   return BSC_OK;
+}
+
+int bsc_stream_probe_ms(bsc_context *ctx, const void *d_cts, const void *d_ref, uint64_t n, void *d_out, void *d_skip,
+                        int reps, void *stream, float *ms) {
+  if (!ctx || !d_cts || !d_ref || !d_out || !d_skip || !ms) return bsc_fail(BSC_ERR_ARG, "bsc_stream_probe_ms: NULL argument");
+  if (((uintptr_t)d_cts & 15u) || ((uintptr_t)d_out & 15u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_stream_probe_ms: d_cts and d_out must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  float best = 0.f;
+  int rc = BSC_OK;
+  for (int r = 0; r < (reps > 0 ? reps : 1); r++) {
+    hipEventRecord(a, (hipStream_t)stream);
+    int e = bsc_dev_launch_stream_probe(d_cts, d_ref, n, d_out, d_skip, ctx->num_cus, stream);
+    hipEventRecord(b, (hipStream_t)stream);
+    if (e || hipEventSynchronize(b) != hipSuccess) {
+      rc = bsc_fail(BSC_ERR_HIP, "stream probe failed: %s", hipGetErrorString(hipGetLastError()));
+      break;
+    }
+    float t = 0.f;
+    hipEventElapsedTime(&t, a, b);
+    if (r == 0 || t < best) best = t;
+  }
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  *ms = best;
+  return rc;
 }
 
 int bsc_synchronize(bsc_context *ctx) {

@@ -312,6 +312,13 @@ int bsc_vcf_format(const bsc_vcf_core *c, const bsc_gt_meth *g, const char *cont
 int bsc_set_profiling(bsc_context *ctx, int enable);
 int bsc_last_kernel_ms(bsc_context *ctx, float *call_ms, float *fisher_ms);
 
+/* Measurement support: the time (ms, HIP events on `stream`, best of `reps` launches) of a kernel that moves exactly
+ * the bytes of bsc_call_sites_device(ctx, d_cts, d_ref, n, d_out, 200, d_skip) — 104 + 1 in, 200 + 1 out per position,
+ * same tile shape, no arithmetic: the practical memory ceiling for that call.  OVERWRITES d_out / d_skip with junk;
+ * n is rounded down to a multiple of 64. */
+int bsc_stream_probe_ms(bsc_context *ctx, const void *d_cts, const void *d_ref, uint64_t n, void *d_out, void *d_skip,
+                        int reps, void *stream, float *ms);
+
 /* Blocks until everything queued on the context's own stream (the host-buffer entries) has finished. */
 int bsc_synchronize(bsc_context *ctx);
 

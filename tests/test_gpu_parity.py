@@ -285,3 +285,26 @@ def test_pipelined_host_path_multi_chunk(caller, oracle, tables, libm_exact):
     finally:
         for b in bufs:
             b.free()
+
+
+def test_stream_probe_runs_and_is_faster_than_the_kernel(oracle, tables):
+    """bsc_stream_probe_ms: the no-arithmetic copy with the calling kernel's traffic (bench.py's roofline.stream_probe)."""
+    import torch
+
+    n = 4_000_000
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    with B.SiteCaller() as c:
+        d_cts = torch.empty(n * 104, dtype=torch.uint8, device=dev)
+        d_ref = torch.empty(n, dtype=torch.uint8, device=dev)
+        d_out = torch.zeros(n * 200, dtype=torch.uint8, device=dev)
+        d_skip = torch.zeros(n, dtype=torch.uint8, device=dev)
+        c.synth_device(SEED, 0, n, 30, d_cts.data_ptr(), d_ref.data_ptr(), 0, st)
+        c.set_profiling(True)
+        for _ in range(3):
+            c.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 200, st)
+        k_ms, _ = c.last_kernel_ms()
+        ms = c.stream_probe_ms(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 5, st)
+        torch.cuda.synchronize()
+        assert 0.0 < ms < k_ms  # moving the bytes alone cannot take longer than moving them and computing
+        assert int(d_out.view(torch.int64).ne(0).sum()) > n  # it really wrote the output buffer
