@@ -172,12 +172,13 @@ def main():
         # Last (it overwrites d_out): the same bytes moved by a kernel that does nothing else — what the memory system
         # delivers for this 1 : 2 read : write mix (HBM3E writes stream slower than reads), measured live on this GPU.
         probe_ms = caller.stream_probe_ms(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 5, stream)
-        res["roofline"]["stream_probe"] = {
-            "what": "copy kernel with the calling kernel's traffic and tile shape, no arithmetic (csrc/probe.hip), best of 5",
-            "ms": probe_ms,
-            "GBps": algo_bytes / (probe_ms * 1e-3) / 1e9,
-            "kernel_frac_of_probe": probe_ms / k_ms,
-        }
+        if probe_ms > 0.0:
+            res["roofline"]["stream_probe"] = {
+                "what": "copy kernel with the calling kernel's traffic and tile shape, no arithmetic (csrc/probe.hip), best of 5",
+                "ms": probe_ms,
+                "GBps": algo_bytes / (probe_ms * 1e-3) / 1e9,
+                "kernel_frac_of_probe": probe_ms / k_ms,
+            }
         print(json.dumps(res), flush=True)
     caller.close()
     if dist is not None:
