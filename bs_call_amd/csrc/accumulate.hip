@@ -3,14 +3,14 @@
  * positions [x, y].  Replaces HOT LOOP A of call_genotypes_ML (reference src/call_genotypes.c:178-226),
  * which the reference runs serially on its process thread.
  *
- *   bsc_order_keys_kernel   one thread per template: the reference's asserts on the template and its sort key (the
- *                           leftmost position); sort.hip orders the block's templates by it on the device.
- *   bsc_prep_reads_kernel   one thread per template, in sorted order: the leading/trailing scan that finds each
- *                           read's first and last countable base (:198-211), the orientation each read is counted
- *                           with (:187,224, including the reference's quirk that a skipped read 0 does not flip
- *                           it), and a compact per-read descriptor; also the largest template extent of the block.
- *   bsc_tile_lo_kernel      one thread per 64-position wave-tile: binary search for the first template that can
- *                           reach the tile (the templates are in leftmost-position order by now).
+ *   bsc_prep_reads_kernel   one thread per template: the reference's asserts on the template; per read the
+ *                           leading/trailing scan that finds its first and last countable base (:198-211), the
+ *                           orientation it is counted with (:187,224, including the reference's quirk that a skipped
+ *                           read 0 does not flip it), a compact descriptor and its sort key (first countable
+ *                           position); also the longest read extent of the block.
+ *   (sort.hip)              the block's reads ordered by that key on the device.
+ *   bsc_tile_lo_kernel      one thread per 64-position wave-tile: binary search for the first read that can reach
+ *                           the tile.
  *   bsc_accumulate_kernel   one wave per wave-tile, lane i OWNS position i of the tile: the wave walks the
  *                           candidate templates (64 descriptors per vector load, ballot-filtered to the reads
  *                           that overlap the tile, broadcast with v_readlane), every lane fetches "its" base of
@@ -75,41 +75,25 @@ __device__ static __forceinline__ uint32_t template_error(const bsc_template_dev
   return 0;
 }
 
-/* One thread per template: sort key = leftmost position relative to the block start (clipped to the block length;
- * invalid templates, which contribute nothing, go to the end), and the verdict on the template — the lowest index of
- * an invalid one with its first failing check reaches the host through counters[BSC_CNT_ERR]. */
-extern "C" __global__ __launch_bounds__(256) void bsc_order_keys_kernel(const bsc_template_dev *__restrict__ tpl,
-                                                                        uint32_t nr, uint64_t seq_bytes, uint32_t x,
-                                                                        uint32_t key_max, uint32_t *__restrict__ keys,
+/* One thread per template (in the caller's order): the reference's asserts (the lowest index of an invalid template with
+ * its first failing check reaches the host through counters[BSC_CNT_ERR]; such a template contributes nothing), then per
+ * read the leading/trailing scan, the orientation it is counted with and its descriptor rd[2t + k], and its sort key:
+ * the first countable position relative to the block start, key_max for a read that contributes nothing.  READS, not
+ * templates, are what the tiles search: a read's extent is bounded by its length, so mates that lie far apart (or a
+ * pathological template) cannot widen every tile's candidate window. */
+extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bsc_template_dev *__restrict__ tpl,
+                                                                        uint32_t nr, const uint8_t *__restrict__ seq,
+                                                                        uint64_t seq_bytes, uint32_t x, uint32_t y,
+                                                                        uint32_t key_max, bsc_read_desc *__restrict__ rd,
+                                                                        uint32_t *__restrict__ keys,
                                                                         unsigned long long *__restrict__ counters) {
+  uint32_t span_max = 0;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nr; t += gridDim.x * blockDim.x) {
     const bsc_template_dev tp = tpl[t];
     const uint32_t left = leftmost(tp.pos[0], tp.pos[1]);
     const uint32_t terr = template_error(tp, left, x, seq_bytes);
-    uint32_t key = key_max;
-    if (terr) atomicMin(&counters[BSC_CNT_ERR], ((unsigned long long)t << 8) | terr);
-    else if (left - x < key_max) key = left - x;
-    keys[t] = key;
-  }
-}
-
-/* One thread per template, in sorted order: thread t prepares the template that comes t-th (perm[t]). */
-extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bsc_template_dev *__restrict__ tpl,
-                                                                        const uint32_t *__restrict__ perm,
-                                                                        const uint32_t *__restrict__ keys_sorted,
-                                                                        uint32_t nr, const uint8_t *__restrict__ seq,
-                                                                        uint64_t seq_bytes, uint32_t x, uint32_t y,
-                                                                        bsc_read_desc *__restrict__ rd,
-                                                                        uint32_t *__restrict__ x1,
-                                                                        unsigned long long *__restrict__ counters) {
-  uint32_t span_max = 0;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nr; t += gridDim.x * blockDim.x) {
-    const bsc_template_dev tp = tpl[perm[t]];
-    const uint32_t left = leftmost(tp.pos[0], tp.pos[1]);
-    /* the ordering the tile search relies on is that of the sort keys: leftmost positions clipped to y + 1 */
-    const uint64_t xs = (uint64_t)x + keys_sorted[t];
-    x1[t] = xs > 0xffffffffull ? 0xffffffffu : (uint32_t)xs;
-    if (template_error(tp, left, x, seq_bytes)) { /* reported by bsc_order_keys_kernel; contributes nothing */
+    if (terr) {
+      atomicMin(&counters[BSC_CNT_ERR], ((unsigned long long)t << 8) | terr);
       bsc_read_desc d;
       d.a = 1;
       d.b = 0;
@@ -118,10 +102,11 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
       d.lut = 0;
       rd[2 * (uint64_t)t] = d;
       rd[2 * (uint64_t)t + 1] = d;
+      keys[2 * (uint64_t)t] = key_max;
+      keys[2 * (uint64_t)t + 1] = key_max;
       continue;
     }
     uint32_t ori = tp.orientation & 1u;
-    uint32_t reach = left;
     /* the end bytes of both reads, fetched together: almost every read starts and ends on a countable base, so
      * the scans below rarely need another load and the thread waits for memory once, not four times */
     uint32_t e_first[2], e_last[2];
@@ -161,16 +146,16 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
           d.base = (int64_t)tp.off[k] - (int64_t)tp.pos[k];
           d.meta = (ori << 5) | (((uint32_t)tp.mapq[k] * tp.mapq[k]) << 8);
           d.lut = tp.bs_strand == 0 ? LUT4(0, 1, 2, 3) : (tp.bs_strand == 1 ? LUT4(0, 5, 2, 7) : LUT4(4, 1, 6, 3));
-          if (d.b >= d.a && d.b > reach) reach = d.b;
           ori ^= 1u; /* :224 — only a read that was walked flips the orientation */
         }
       }
       rd[2 * (uint64_t)t + k] = d;
+      const bool live = d.b >= d.a; /* then x <= a <= b <= y */
+      keys[2 * (uint64_t)t + k] = live ? d.a - x : key_max;
+      if (live && d.b - d.a > span_max) span_max = d.b - d.a;
     }
-    const uint32_t span = reach - left;
-    span_max = span > span_max ? span : span_max;
   }
-  /* largest extent: wave max, one atomic per wave */
+  /* longest read extent: wave max, one atomic per wave */
   for (int o = 32; o > 0; o >>= 1) {
     const uint32_t v = __shfl_xor(span_max, o);
     span_max = v > span_max ? v : span_max;
@@ -183,18 +168,18 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
     atomicMax(&counters[BSC_CNT_SPAN], (unsigned long long)span_max);
 }
 
-extern "C" __global__ __launch_bounds__(256) void bsc_tile_lo_kernel(const uint32_t *__restrict__ x1, uint32_t nr,
-                                                                     uint32_t x, uint32_t n_wt,
+extern "C" __global__ __launch_bounds__(256) void bsc_tile_lo_kernel(const uint32_t *__restrict__ keys_sorted,
+                                                                     uint32_t n_reads, uint32_t n_wt,
                                                                      const unsigned long long *__restrict__ counters,
                                                                      uint32_t *__restrict__ tile_lo) {
-  const uint32_t span = (uint32_t)counters[BSC_CNT_SPAN];
+  const uint32_t span = (uint32_t)counters[BSC_CNT_SPAN]; /* longest read extent, b - a */
   for (uint32_t wt = blockIdx.x * blockDim.x + threadIdx.x; wt < n_wt; wt += gridDim.x * blockDim.x) {
-    const uint64_t p0 = (uint64_t)x + (uint64_t)wt * 64u;
-    const uint32_t key = p0 > span ? (uint32_t)(p0 - span) : 0u; /* first template with x1 >= key */
-    uint32_t lo = 0, hi = nr;
+    const uint32_t r0 = wt * 64u;                       /* the tile's first position, relative to the block start */
+    const uint32_t key = r0 > span ? r0 - span : 0u;    /* first read that can still reach it */
+    uint32_t lo = 0, hi = n_reads;
     while (lo < hi) {
       const uint32_t mid = lo + ((hi - lo) >> 1);
-      if (x1[mid] < key) lo = mid + 1;
+      if (keys_sorted[mid] < key) lo = mid + 1;
       else hi = mid;
     }
     tile_lo[wt] = lo;
@@ -212,9 +197,9 @@ typedef const __attribute__((address_space(1))) uint8_t *global_bytes;
  * clamp, load, range test, quality test, class lookup (v_alignbyte on the strand's table), two LDS adds, one add.
  */
 extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel(
-    const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ x1, uint32_t nr,
-    const uint8_t *__restrict__ seq, uint32_t x, uint32_t y, uint32_t min_qual, const uint32_t *__restrict__ tile_lo,
-    uint32_t *__restrict__ cts, unsigned long long *__restrict__ counters) {
+    const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ keys_sorted, const uint32_t *__restrict__ perm,
+    uint32_t n_reads, const uint8_t *__restrict__ seq, uint32_t x, uint32_t y, uint32_t min_qual,
+    const uint32_t *__restrict__ tile_lo, uint32_t *__restrict__ cts, unsigned long long *__restrict__ counters) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_slot[ACC_WAVES][SLOT_DW];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -225,49 +210,54 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
   /* q counts iff min_qual <= q < 63 (:217)  <=>  (q - min_qual) <u q_span */
   const uint32_t q_span = min_qual < 63u ? 63u - min_qual : 0u;
   unsigned inexact = 0;
-  /* 64 candidate templates per batch: lane i gets the leftmost position and the two read descriptors of template
-   * tb + i.  All three loads are independent of each other (a template right of the tile overlaps nothing). */
-  auto fetch = [&](uint32_t tb, uint32_t &xv, bsc_read_desc &e0, bsc_read_desc &e1) {
+  /* 64 candidate reads per batch: lane i gets the sort key (first countable position relative to x) and the
+   * descriptor of the read that comes (tb + i)-th in position order */
+  auto fetch = [&](uint32_t tb, uint32_t &kv, bsc_read_desc &e) {
     const uint32_t t = tb + lane;
-    xv = 0;
-    e0.a = e1.a = 1;
-    e0.b = e1.b = 0;
-    e0.base = e1.base = 0;
-    e0.meta = e1.meta = 0;
-    e0.lut = e1.lut = 0;
-    if (t < nr) {
-      xv = x1[t];
-      e0 = rd[2 * (uint64_t)t];
-      e1 = rd[2 * (uint64_t)t + 1];
+    kv = 0xffffffffu;
+    e.a = 1;
+    e.b = 0;
+    e.base = 0;
+    e.meta = 0;
+    e.lut = 0;
+    if (t < n_reads) {
+      kv = keys_sorted[t];
+      e = rd[perm[t]];
     }
   };
   /* Software pipeline over the wave's tiles: while tile i is processed, the first batch of tile i+1 and the start
-   * index of tile i+2 are on their way, so the tile_lo -> x1/descriptor chain of dependent loads is off the
+   * index of tile i+2 are on their way, so the tile_lo -> key / index -> descriptor chain of dependent loads is off the
    * critical path. */
   const uint32_t wt_step = gridDim.x * ACC_WAVES;
   uint32_t wt = blockIdx.x * ACC_WAVES + wid;
-  uint32_t t0 = 0, t0_next = 0, xv = 0;
-  bsc_read_desc d0, d1;
+  uint32_t t0 = 0, t0_next = 0, kv = 0xffffffffu;
+  bsc_read_desc d;
+  d.a = 1;
+  d.b = 0;
+  d.base = 0;
+  d.meta = 0;
+  d.lut = 0;
   if (wt < n_wt) {
     t0 = tile_lo[wt];
     if (wt + wt_step < n_wt && wt + wt_step > wt) t0_next = tile_lo[wt + wt_step];
-    fetch(t0, xv, d0, d1);
+    fetch(t0, kv, d);
   }
   for (; wt < n_wt; wt += wt_step) {
     /* x + 64 wt <= y: the tile's first position fits 32 bits; its last one is clipped to y */
     const uint32_t p0 = x + wt * 64u;
     const uint32_t p_last = y - p0 < 63u ? y : p0 + 63u;
+    const uint32_t r_last = p_last - x; /* the tile's last position as a sort key */
     const bool valid = lane <= p_last - p0;
     const uint32_t wt1 = wt + wt_step, wt2 = wt1 + wt_step;
     const bool have1 = wt1 < n_wt && wt1 > wt, have2 = have1 && wt2 < n_wt && wt2 > wt1;
-    uint32_t xv_n = 0, t0_nn = 0;
-    bsc_read_desc n0, n1;
-    n0.a = n1.a = 1;
-    n0.b = n1.b = 0;
-    n0.base = n1.base = 0;
-    n0.meta = n1.meta = 0;
-    n0.lut = n1.lut = 0;
-    if (have1) fetch(t0_next, xv_n, n0, n1);
+    uint32_t kv_n = 0xffffffffu, t0_nn = 0;
+    bsc_read_desc dn;
+    dn.a = 1;
+    dn.b = 0;
+    dn.base = 0;
+    dn.meta = 0;
+    dn.lut = 0;
+    if (have1) fetch(t0_next, kv_n, dn);
     if (have2) t0_nn = tile_lo[wt2];
 #pragma unroll
     for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
@@ -275,12 +265,10 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
 
     bool more = true;
     while (more) {
-      const bool cand = t0 + lane < nr && xv <= p_last;
-      more = __all(cand); /* templates are sorted by x1: the candidates are a prefix of the batch */
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const bsc_read_desc &d = k ? d1 : d0;
-        /* reads that overlap the tile at all */
+      const bool cand = kv <= r_last; /* reads are in key order: the candidates are a prefix of the batch */
+      more = __all(cand);
+      {
+        /* reads that overlap the tile at all (a read past the candidates starts right of the tile: a > p_last) */
         unsigned long long m = __ballot(d.b >= d.a && d.b >= p0 && d.a <= p_last);
         /* per descriptor lane: the read's part of the tile as lane numbers lo .. lo + len (0 <= lo, lo + len <= 63;
          * meaningless where the read does not overlap, never used there), and the address of the byte of lane lo */
@@ -338,7 +326,7 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
 #undef ACC_UPDATE
       }
       t0 += 64u;
-      if (more) fetch(t0, xv, d0, d1); /* a second batch is rare (deep or long-insert data) */
+      if (more) fetch(t0, kv, d); /* further batches: deep data */
     }
     row[25] = m2sum;
 
@@ -373,9 +361,8 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
     }
     t0 = t0_next;
     t0_next = t0_nn;
-    xv = xv_n;
-    d0 = n0;
-    d1 = n1;
+    kv = kv_n;
+    d = dn;
   }
   if (__any(inexact)) {
     const unsigned long long m = __ballot(inexact);
@@ -389,34 +376,31 @@ extern "C" int bsc_dev_sort_templates(const void *keys, void *keys_sorted, void 
 
 extern "C" int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x,
                                          uint32_t y, uint32_t min_qual, void *keys, void *keys_sorted, void *perm,
-                                         void *sort_tmp, size_t sort_tmp_bytes, void *rd, void *x1, void *tile_lo,
-                                         void *cts, void *counters, int num_cus, void *stream) {
+                                         void *sort_tmp, size_t sort_tmp_bytes, void *rd, void *tile_lo, void *cts,
+                                         void *counters, int num_cus, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t n_sites = y - x + 1;
   const uint32_t n_wt = (n_sites + 63u) / 64u;
+  const uint32_t n_reads = 2u * nr; /* nr <= 2^31 - 1 is checked by the caller */
   if (nr) {
     unsigned g = (nr + 255u) / 256u;
     if (g > (unsigned)num_cus * 16u) g = (unsigned)num_cus * 16u;
-    /* keys 0 .. key_max: positions x .. y, and one value for everything right of the block or invalid */
-    const uint32_t key_max = n_sites; /* y - x + 1 <= 2^32 - 1 for any x >= 1 */
+    /* keys 0 .. key_max - 1: positions x .. y; key_max: a read that contributes nothing */
+    const uint32_t key_max = n_sites;
     unsigned key_bits = 1;
     while (key_bits < 32 && (key_max >> key_bits)) key_bits++;
-    hipLaunchKernelGGL(bsc_order_keys_kernel, dim3(g), dim3(256), 0, s, (const bsc_template_dev *)tpl, nr, seq_bytes, x,
-                       key_max, (uint32_t *)keys, (unsigned long long *)counters);
+    hipLaunchKernelGGL(bsc_prep_reads_kernel, dim3(g), dim3(256), 0, s, (const bsc_template_dev *)tpl, nr,
+                       (const uint8_t *)seq, seq_bytes, x, y, key_max, (bsc_read_desc *)rd, (uint32_t *)keys,
+                       (unsigned long long *)counters);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    int rc = bsc_dev_sort_templates(keys, keys_sorted, perm, nr, key_bits, sort_tmp, sort_tmp_bytes, stream);
+    int rc = bsc_dev_sort_templates(keys, keys_sorted, perm, n_reads, key_bits, sort_tmp, sort_tmp_bytes, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(bsc_prep_reads_kernel, dim3(g), dim3(256), 0, s, (const bsc_template_dev *)tpl,
-                       (const uint32_t *)perm, (const uint32_t *)keys_sorted, nr, (const uint8_t *)seq, seq_bytes, x, y,
-                       (bsc_read_desc *)rd, (uint32_t *)x1, (unsigned long long *)counters);
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
   }
   {
     unsigned g = (n_wt + 255u) / 256u;
     if (g > (unsigned)num_cus * 16u) g = (unsigned)num_cus * 16u;
-    hipLaunchKernelGGL(bsc_tile_lo_kernel, dim3(g), dim3(256), 0, s, (const uint32_t *)x1, nr, x, n_wt,
+    hipLaunchKernelGGL(bsc_tile_lo_kernel, dim3(g), dim3(256), 0, s, (const uint32_t *)keys_sorted, n_reads, n_wt,
                        (const unsigned long long *)counters, (uint32_t *)tile_lo);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -426,8 +410,8 @@ extern "C" int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const voi
     const unsigned cap = (unsigned)num_cus * 6u * 8u; /* 6 workgroups of 26 KB LDS fit a CU */
     if (g > cap) g = cap;
     hipLaunchKernelGGL(bsc_accumulate_kernel, dim3(g), dim3(64 * ACC_WAVES), 0, s, (const bsc_read_desc *)rd,
-                       (const uint32_t *)x1, nr, (const uint8_t *)seq, x, y, min_qual, (const uint32_t *)tile_lo,
-                       (uint32_t *)cts, (unsigned long long *)counters);
+                       (const uint32_t *)keys_sorted, (const uint32_t *)perm, n_reads, (const uint8_t *)seq, x, y, min_qual,
+                       (const uint32_t *)tile_lo, (uint32_t *)cts, (unsigned long long *)counters);
   }
   return (int)hipGetLastError();
 }

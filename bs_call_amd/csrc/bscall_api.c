@@ -26,8 +26,8 @@ int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n, void *out,
                         void *ev_mid, void *ev_stop);
 int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
                               uint32_t min_qual, void *keys, void *keys_sorted, void *perm, void *sort_tmp,
-                              size_t sort_tmp_bytes, void *rd, void *x1, void *tile_lo, void *cts, void *counters,
-                              int num_cus, void *stream);
+                              size_t sort_tmp_bytes, void *rd, void *tile_lo, void *cts, void *counters, int num_cus,
+                              void *stream);
 int bsc_dev_sort_tmp_bytes(uint32_t nr, size_t *bytes); /* sort.hip */
 int bsc_dev_launch_site_stats(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp, uint32_t n,
                               const void *tb, const void *logp, const void *carry_in, void *carry_out, void *stats,
@@ -66,8 +66,8 @@ struct bsc_context {
   void *d_het;
   size_t cap_het;
   /* accumulate stage */
-  void *d_tpl, *d_seq, *d_rd, *d_x1, *d_lo;
-  size_t cap_tpl, cap_seq, cap_rd, cap_x1, cap_lo;
+  void *d_tpl, *d_seq, *d_rd, *d_lo;
+  size_t cap_tpl, cap_seq, cap_rd, cap_lo;
   void *d_keys, *d_keys_s, *d_perm, *d_sorttmp; /* ordering of the block's templates (sort.hip) */
   size_t cap_keys, cap_keys_s, cap_perm, cap_sorttmp;
   void *d_vg, *d_vout, *d_vdb; /* VCF record formation: called genotypes, records, dbSNP flags */
@@ -224,7 +224,6 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_tpl);
   hipFree(ctx->d_seq);
   hipFree(ctx->d_rd);
-  hipFree(ctx->d_x1);
   hipFree(ctx->d_lo);
   hipFree(ctx->d_keys);
   hipFree(ctx->d_keys_s);
@@ -444,14 +443,14 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
   if ((rc = bsc_reserve(&ctx->d_lo, &ctx->cap_lo, (size_t)n_wt * 4u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_rd, &ctx->cap_rd, (size_t)(nr ? nr : 1) * 48u))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_x1, &ctx->cap_x1, (size_t)(nr ? nr : 1) * 4u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
   size_t sort_bytes = 0;
-  if (nr) {
-    if (bsc_dev_sort_tmp_bytes(nr, &sort_bytes)) return bsc_fail(BSC_ERR_HIP, "accumulate: sort size query failed");
-    if ((rc = bsc_reserve(&ctx->d_keys, &ctx->cap_keys, (size_t)nr * 4u))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_keys_s, &ctx->cap_keys_s, (size_t)nr * 4u))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_perm, &ctx->cap_perm, (size_t)nr * 4u))) return rc;
+  if (nr) { /* the device orders the block's READS: two entries per template */
+    if (nr > 0x7fffffffu) return bsc_fail(BSC_ERR_ARG, "accumulate: more than 2^31 - 1 templates in one block");
+    if (bsc_dev_sort_tmp_bytes(2u * nr, &sort_bytes)) return bsc_fail(BSC_ERR_HIP, "accumulate: sort size query failed");
+    if ((rc = bsc_reserve(&ctx->d_keys, &ctx->cap_keys, (size_t)nr * 8u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_keys_s, &ctx->cap_keys_s, (size_t)nr * 8u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_perm, &ctx->cap_perm, (size_t)nr * 8u))) return rc;
     if ((rc = bsc_reserve(&ctx->d_sorttmp, &ctx->cap_sorttmp, sort_bytes ? sort_bytes : 1))) return rc;
   }
   if (stage) {
@@ -483,7 +482,7 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
   HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), ctx->stream));
   int e = bsc_dev_launch_accumulate(ctx->d_tpl, nr, ctx->d_seq, seq_bytes, x, y, (uint32_t)ctx->params.min_qual,
                                     ctx->d_keys, ctx->d_keys_s, ctx->d_perm, ctx->d_sorttmp, sort_bytes, ctx->d_rd,
-                                    ctx->d_x1, ctx->d_lo, ctx->d_cts, ctx->d_counters, ctx->num_cus, ctx->stream);
+                                    ctx->d_lo, ctx->d_cts, ctx->d_counters, ctx->num_cus, ctx->stream);
   if (e) return bsc_fail(BSC_ERR_HIP, "accumulate launch failed: %s", hipGetErrorString((hipError_t)e));
   return BSC_OK;
 }

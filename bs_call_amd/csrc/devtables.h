@@ -24,7 +24,7 @@ typedef struct {
 #define BSC_CNT_WORDS 17
 
 /* what the reference asserts about a block's templates (src/call_genotypes.c:186-188) plus the bounds of the read
- * buffer; checked by bsc_order_keys_kernel, ordered as the checks are made */
+ * buffer; checked by bsc_prep_reads_kernel, ordered as the checks are made */
 #define BSC_TERR_LEFT 1   /* leftmost position < block start */
 #define BSC_TERR_ORI 2    /* orientation > 1 */
 #define BSC_TERR_STRAND 3 /* bs_strand > 2 */

@@ -3,12 +3,13 @@
  * block's templates by leftmost position, and (at the end of the file) the prefix sum that packs written records.
  *
  * The reference walks its align_list in whatever order the reads arrived (src/call_genotypes.c:181) — the sums do not
- * depend on it.  The accumulate kernels want the templates ordered by leftmost position so that a 64-position tile
- * only looks at the window of templates that can reach it; align_lists are nearly but not exactly in that order
- * (a template whose forward read is missing or lies right of its mate sorts by the other one), so every block is
- * ordered here: keys = leftmost position relative to the block start (bsc_order_keys_kernel, accumulate.hip),
- * values = template index, rocPRIM's device radix sort over just the bits the block's length needs (ROCm's own
- * primitive library; a million pairs take well under 0.1 ms, the host qsort it replaces took 25 ms).
+ * depend on it.  The accumulate kernels want the block's READS ordered by first countable position so that a
+ * 64-position tile only looks at the window of reads that can reach it (ordering reads rather than templates keeps
+ * that window one read long whatever the distance between mates); align_lists are nearly but not exactly in that
+ * order, so every block is ordered here: keys = first countable position relative to the block start
+ * (bsc_prep_reads_kernel, accumulate.hip), values = read index, rocPRIM's device radix sort over just the bits the
+ * block's length needs (ROCm's own primitive library; 2.4 million pairs take about 0.15 ms, the host qsort of the
+ * templates it replaced took 25 ms).
  */
 #include <cstring>
 #include <hip/hip_runtime.h>

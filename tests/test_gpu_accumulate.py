@@ -334,3 +334,25 @@ def test_adversarial_template_lists(caller, oracle, seed):
     assert got.tobytes() == exp.tobytes()
     perm = rng.permutation(nt)
     assert caller.accumulate(tpl[perm], seq, x, y).tobytes() == exp.tobytes()
+
+
+def test_far_apart_mates_do_not_widen_the_search(caller, oracle):
+    """One template whose mates lie 2.9 Mb apart among 30 000 ordinary ones: the tiles search reads, not templates, so
+    the candidate window stays one read long (ordered by template extent, every tile would walk the whole block)."""
+    import time
+
+    tpl, seq = B.synth_reads_host(SEED + 77, 1000, 3_000_000, 2)
+    x, y = 998, int((tpl["pos"] + tpl["len"]).max()) - 1
+    far = tpl[:1].copy()
+    far["pos"][0] = [1000, y - 150]
+    far["len"][0] = [100, 100]
+    far["off"][0] = [tpl["off"][0, 0], tpl["off"][0, 1]]  # reuse read bytes that exist
+    tpl2 = np.concatenate([tpl, far])
+    rc, exp = oracle.accumulate(tpl2, seq, x, y, 20)
+    assert rc == 0
+    caller.accumulate(tpl2, seq, x, y)  # warm-up (allocations)
+    t0 = time.perf_counter()
+    got = caller.accumulate(tpl2, seq, x, y)
+    dt = time.perf_counter() - t0
+    assert got.tobytes() == exp.tobytes()
+    assert dt < 0.5, "accumulate took %.2f s" % dt
