@@ -70,3 +70,26 @@ def format_block_c(cores, gtms, contig):
         if n:
             out.append(buf.raw[:n].decode())
     return out
+
+
+def format_records_c(recs, contig):
+    """VCF lines of packed records (VCF_REC[], what SiteCaller.block_records returns) through bsc_vcf_format_rec."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+    from .abi import VCF_REC
+
+    L = _lib.load()
+    recs = np.ascontiguousarray(recs, dtype=VCF_REC)
+    buf = C.create_string_buffer(1024)
+    out = []
+    rb = recs.ctypes.data
+    for i in range(len(recs)):
+        n = L.bsc_vcf_format_rec(rb + 128 * i, contig.encode(), None, buf, 1024)
+        if n < 0:
+            raise RuntimeError("bsc_vcf_format_rec: buffer too small")
+        if n:
+            out.append(buf.raw[:n].decode())
+    return out

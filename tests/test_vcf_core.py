@@ -153,3 +153,17 @@ def test_c_formatter_equals_python_formatter(oracle, tables):
     b = vcf.format_block_c(rec, out, "chr7")
     assert len(a) == len(b) == int(rec["emit"].sum())
     assert a == b
+
+
+def test_packed_records_render_the_same_lines(oracle, tables):
+    """bsc_vcf_format_rec on a packed record (core + the gt_meth fields the encoder reads) == bsc_vcf_format on the pair."""
+    from bs_call_amd import vcf
+
+    out, skip, ref = _called_block(oracle, tables, SEED + 44, 1000, 3000, 30)
+    core = oracle.vcf_block(out, skip, ref, 1000)
+    sel = core["emit"] == 1
+    rec = np.zeros(int(sel.sum()), dtype=B.VCF_REC)
+    rec["core"], rec["counts"], rec["qual"] = core[sel], out["counts"][sel], out["qual"][sel]
+    rec["mq"], rec["aq"], rec["max_gt"] = out["mq"][sel], out["aq"][sel], out["max_gt"][sel]
+    a, b = vcf.format_records_c(rec, "chr1"), vcf.format_block_c(core, out, "chr1")
+    assert len(a) == int(sel.sum()) > 100 and a == b
