@@ -703,7 +703,8 @@ extern "C" int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n,
    * a fully persistent grid (1 round) is best for small blocks (the table set-up is paid once per wave slot) but 7 %
    * slower at 50 M positions than 8-16 rounds, whose workgroup turnover keeps the waves of a CU out of phase;
    * beyond 32 rounds the set-up cost shows again. */
-  const uint64_t resident = (uint64_t)num_cus * BSC_WAVES_PER_SIMD * (256 / TILE);
+  uint64_t resident = (uint64_t)num_cus * (BSC_WAVES_PER_SIMD * 4) / (TILE / 64); /* workgroups that fit the chip at once */
+  if (resident < 1) resident = 1;
   const uint64_t n_wt = (n + 63) / 64;
   uint64_t rounds = n_wt / (resident * (TILE / 64) * BSC_TILES_PER_WAVE);
   rounds = rounds < 1 ? 1 : (rounds > 16 ? 16 : rounds);
