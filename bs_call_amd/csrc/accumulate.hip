@@ -68,6 +68,10 @@ __device__ static __forceinline__ uint32_t leftmost(uint32_t p0, uint32_t p1) { 
 __device__ static __forceinline__ uint32_t template_error(const bsc_template_dev &tp, uint32_t left, uint32_t x,
                                                           uint64_t seq_bytes) {
   if (left < x) return BSC_TERR_LEFT;
+  /* The reference checks only the leftmost non-zero position (:183-186) and then indexes counts + pos - x for BOTH reads
+   * (:212): a read with bases whose own position is 0 or left of x is an out-of-bounds walk there.  Here it is the same
+   * error as a template that starts left of the block (its sort key d.a - x would wrap and break the tiles' search). */
+  if ((tp.len[0] && tp.pos[0] < x) || (tp.len[1] && tp.pos[1] < x)) return BSC_TERR_LEFT;
   if (tp.orientation > 1) return BSC_TERR_ORI;
   if (tp.bs_strand > 2) return BSC_TERR_STRAND;
   if (tp.len[0] && (tp.off[0] > seq_bytes || tp.len[0] > seq_bytes - tp.off[0])) return BSC_TERR_RANGE0;
@@ -307,7 +311,8 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
       /* fire-and-forget ds_add_u32: the row has a single writer (this lane), no contention */                   \
       atomicAdd(reinterpret_cast<uint32_t *>(rc + (meta & 32u)), 1u); /* counts[ori][c]++ */                     \
       atomicAdd(reinterpret_cast<uint32_t *>(rc + 68), q); /* quality[c] += q (integer; converted below) */      \
-      m2sum += meta >> 8;                                  /* mapq2 += mapq^2 */                                 \
+      m2sum = __builtin_elementwise_add_sat(m2sum, meta >> 8); /* mapq2 += mapq^2 (v_add_u32 clamp: a sum past   \
+                                                                  2^32 sticks there, so INEXACT cannot be missed) */ \
     }                                                                                                            \
   }
         for (; cnt >= 4u; cnt -= 4u) {

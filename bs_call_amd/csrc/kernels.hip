@@ -236,9 +236,15 @@ __device__ static __forceinline__ void dma16(const void *g, void *lds_wave_base)
  * LDS of one wave is touched only by that wave and a wave's LDS operations execute in order, so the
  * hand-over inside a wave needs no barrier — only the vmcnt wait that retires the DMA.
  */
-extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_kernel(const uint32_t *__restrict__ cts,
+/* FULL = true: the launch's complete 64-position wave-tiles (wt_begin = 0, wt_end = n_sites / 64) — every lane valid,
+ * no guarded paths, and the staging pointers are known to be LDS (ds_write instead of flat stores, which would issue to
+ * the LDS and the vector-memory pipe both: profiles/r01_h counted 26 such stores per tile).  FULL = false: the same
+ * code with the guards, launched for the last, partial wave-tile only. */
+template <bool FULL>
+__global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_kernel_t(const uint32_t *__restrict__ cts,
                                                                       const uint8_t *__restrict__ ref,
-                                                                      uint64_t n_sites, uint32_t *__restrict__ out,
+                                                                      uint64_t n_sites, uint64_t wt_begin,
+                                                                      uint64_t wt_end, uint32_t *__restrict__ out,
                                                                       uint32_t out_dw, uint8_t *__restrict__ skip,
                                                                       const bsc_dev_tables *__restrict__ tb,
                                                                       uint32_t *__restrict__ het_list,
@@ -270,14 +276,13 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
   __syncthreads();
 
   uint32_t *slot = lds_slot[wid];
-  const uint64_t n_wt = (n_sites + 63) / 64;
   const uint64_t wave_stride = (uint64_t)gridDim.x * (TILE / 64);
-  for (uint64_t wt = (uint64_t)blockIdx.x * (TILE / 64) + wid; wt < n_wt; wt += wave_stride) {
+  for (uint64_t wt = wt_begin + (uint64_t)blockIdx.x * (TILE / 64) + wid; wt < wt_end; wt += wave_stride) {
     const uint64_t site0 = wt * 64;
-    const unsigned nvalid = (unsigned)((n_sites - site0) < 64 ? (n_sites - site0) : 64);
-    const bool full = nvalid == 64; /* wave-uniform */
+    const unsigned nvalid = FULL ? 64u : (unsigned)((n_sites - site0) < 64 ? (n_sites - site0) : 64);
+    const bool full = FULL; /* compile-time */
     const uint64_t site = site0 + lane;
-    const bool valid = lane < nvalid;
+    const bool valid = FULL || lane < nvalid;
     const unsigned rf = valid ? ref[site] : 0u;
 
     /* ---- my record ---- */
@@ -506,12 +511,15 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
     }
     if (valid) skip[site] = covered ? 0 : 1;
 
-    /* ---- results: two halves of 32 records through the slot ---- */
+    /* ---- results: two halves of 32 records through the slot ----
+     * A lane's record lands on bytes that other lanes used as their la[] areas, and the second half on bytes the
+     * copy-out of the first half reads: a wave runs in lockstep, so only the COMPILER could reorder these LDS accesses
+     * across lanes' program order; s_wave_barrier (convergent, a scheduling barrier, free at run time) pins them. */
 #pragma unroll 1
     for (unsigned half = 0; half < 2; half++) {
+      __builtin_amdgcn_wave_barrier();
       const bool mine = valid && (lane >> 5) == half;
-      uint2 *rec = reinterpret_cast<uint2 *>(full ? slot + (lane & 31u) * out_dw : out + site * out_dw);
-      if (mine) {
+      auto write_record = [&](auto *rec) {
         if (covered) {
 #pragma unroll
           for (int j = 0; j < 8; j++) rec[j] = make_uint2(cnt[j], 0u); /* counts[j] as u64 */
@@ -533,8 +541,13 @@ extern "C" __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_
         }
         /* out_dw == 52 (gt_vcf): bytes 200.. = {ready = 0, skip, pad} */
         if (out_dw > OUT_DW) rec[25] = make_uint2(covered ? 0u : 0x100u, 0u);
+      };
+      if (mine) {
+        if (full) write_record(reinterpret_cast<uint2 *>(slot + (lane & 31u) * out_dw)); /* LDS */
+        else write_record(reinterpret_cast<uint2 *>(out + site * out_dw));                /* global */
       }
       if (full) { /* copy the 32 records out: 16 bytes per lane, contiguous */
+        __builtin_amdgcn_wave_barrier(); /* the staging stores above must not sink below the cross-lane reads */
         const unsigned nvec = 32u * out_dw / 4u; /* 400 or 416 */
         uint4 *dst = reinterpret_cast<uint4 *>(out + (site0 + half * 32u) * out_dw);
         const uint4 *srcv = reinterpret_cast<const uint4 *>(slot);
@@ -697,7 +710,6 @@ extern "C" int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n,
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, s);
-  const uint64_t n_tiles = (n + TILE - 1) / TILE;
   /* Grid: the workgroups resident at once (BSC_WAVES_PER_SIMD per CU: 33 KB LDS, <= 128 VGPRs each) times a number of
    * rounds chosen so that a wave walks about BSC_TILES_PER_WAVE wave-tiles.  Measured (gpurun_out/ab*.txt):
    * a fully persistent grid (1 round) is best for small blocks (the table set-up is paid once per wave slot) but 7 %
@@ -705,16 +717,27 @@ extern "C" int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n,
    * beyond 32 rounds the set-up cost shows again. */
   uint64_t resident = (uint64_t)num_cus * (BSC_WAVES_PER_SIMD * 4) / (TILE / 64); /* workgroups that fit the chip at once */
   if (resident < 1) resident = 1;
-  const uint64_t n_wt = (n + 63) / 64;
-  uint64_t rounds = n_wt / (resident * (TILE / 64) * BSC_TILES_PER_WAVE);
-  rounds = rounds < 1 ? 1 : (rounds > 16 ? 16 : rounds);
-  uint64_t grid = resident * rounds;
-  if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(bsc_call_kernel, dim3((unsigned)grid), dim3(TILE), 0, s, (const uint32_t *)cts,
-                     (const uint8_t *)ref, n, (uint32_t *)out, out_dw, (uint8_t *)skip, (const bsc_dev_tables *)tb,
-                     (uint32_t *)het_list, (unsigned long long *)counters);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
+  const uint64_t n_full = n / 64; /* complete wave-tiles: the specialised kernel; the ragged rest: the guarded one */
+  hipError_t e = hipSuccess;
+  if (n_full) {
+    const uint64_t n_tiles = (n_full + (TILE / 64) - 1) / (TILE / 64);
+    uint64_t rounds = n_full / (resident * (TILE / 64) * BSC_TILES_PER_WAVE);
+    rounds = rounds < 1 ? 1 : (rounds > 16 ? 16 : rounds);
+    uint64_t grid = resident * rounds;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(bsc_call_kernel_t<true>, dim3((unsigned)grid), dim3(TILE), 0, s, (const uint32_t *)cts,
+                       (const uint8_t *)ref, n, (uint64_t)0, n_full, (uint32_t *)out, out_dw, (uint8_t *)skip,
+                       (const bsc_dev_tables *)tb, (uint32_t *)het_list, (unsigned long long *)counters);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  if (n & 63u) {
+    hipLaunchKernelGGL(bsc_call_kernel_t<false>, dim3(1), dim3(TILE), 0, s, (const uint32_t *)cts, (const uint8_t *)ref, n,
+                       n_full, n_full + 1, (uint32_t *)out, out_dw, (uint8_t *)skip, (const bsc_dev_tables *)tb,
+                       (uint32_t *)het_list, (unsigned long long *)counters);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
   if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
   hipLaunchKernelGGL(bsc_fisher_kernel, dim3((unsigned)(num_cus * 2)), dim3(256), 0, s, (const uint32_t *)cts,
                      (uint32_t *)out, out_dw, (const bsc_dev_tables *)tb, (const uint32_t *)het_list,

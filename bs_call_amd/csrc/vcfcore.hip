@@ -285,10 +285,16 @@ extern "C" __global__ __launch_bounds__(64 * VW) void bsc_vcf_core_kernel(
     }
     /* ---- results: own 64-byte record -> the slot (all record reads are done), then the tile's 4 KiB leave contiguously ---- */
     {
+      /* Lane L's result lands on bytes that still hold other lanes' input records: every lane's record reads must be
+       * issued before any lane's staging store, and the staging stores before the cross-lane copy-out.  A wave runs in
+       * lockstep, so what has to be ruled out is the COMPILER sinking a load or hoisting a store across these points:
+       * s_wave_barrier is convergent and a scheduling barrier, and costs nothing at run time. */
+      __builtin_amdgcn_wave_barrier();
       uint4 *so = reinterpret_cast<uint4 *>(slot);
       const uint4 *s4 = reinterpret_cast<const uint4 *>(&o);
 #pragma unroll
       for (int k = 0; k < 4; k++) so[lane * 4 + k] = s4[k];
+      __builtin_amdgcn_wave_barrier();
       const uint32_t nvec = (n - site0 < 64u ? n - site0 : 64u) * 4u;
       uint4 *d4 = reinterpret_cast<uint4 *>(out + site0);
 #pragma unroll

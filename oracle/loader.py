@@ -146,6 +146,42 @@ def exp_array(x, flavour):
     return y
 
 
+_libm_exact = None
+
+
+def libm_exact():
+    """True when the host's libm log/exp equal the bsmath.h replica bit for bit (glibc >= 2.28 on an x86-64 CPU with
+    FMA, where glibc selects its *_fma variants): then the LIBM flavour — the reference's own arithmetic, independent of
+    the product's bsmath.h — is the one byte equality is asserted against.  Probed, not assumed; cached."""
+    global _libm_exact
+    if _libm_exact is None:
+        rng = np.random.default_rng(5)
+        x = np.concatenate([rng.uniform(1e-5, 10, 200_000), rng.uniform(0.93, 1.07, 50_000)])
+        y = rng.uniform(-745, 30, 250_000)
+        _libm_exact = bool(
+            (log_array(x, LIBM).view(np.int64) == log_array(x, BSM).view(np.int64)).all()
+            and (exp_array(y, LIBM).view(np.int64) == exp_array(y, BSM).view(np.int64)).all()
+        )
+    return _libm_exact
+
+
+def host_description():
+    """What decides libm_exact on this host: machine, libc, whether the CPU has FMA."""
+    import platform
+
+    fma = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fma = " fma " in (line + " ")
+                    break
+    except OSError:
+        pass
+    libc = "-".join(platform.libc_ver())
+    return {"machine": platform.machine(), "libc": libc, "cpu_fma": fma}
+
+
 def vcf_block(gtm, skip, ref, x, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None):
     """print_thread over one block (src/process.c:87-104): gtm GT_METH[n], skip[n], ref codes of x..x+n+1 -> VCF_CORE[n]."""
     from bs_call_amd.abi import GT_METH, VCF_CORE

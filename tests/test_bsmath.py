@@ -7,6 +7,10 @@ import pytest
 
 import bs_call_amd as B
 
+# Every test here runs twice: unmarked in this container, and marked `gpu` so that the driver's GPU box — the host
+# whose libm the GPU parity tests compare against — re-proves bsm == libm for itself.
+BOTH_HOSTS = pytest.mark.parametrize("where", ["here", pytest.param("gpu_box", marks=pytest.mark.gpu)])
+
 
 def _ulps(a, b):
     return np.abs(a.view(np.int64) - b.view(np.int64))
@@ -36,7 +40,8 @@ def _exp_inputs(rng, n):
     ]
 
 
-def test_log_exp_vs_libm(oracle, libm_exact):
+@BOTH_HOSTS
+def test_log_exp_vs_libm(oracle, libm_exact, where):
     rng = np.random.default_rng(2024)
     n = 2_000_000
     for x in _log_inputs(rng, n):
@@ -47,7 +52,8 @@ def test_log_exp_vs_libm(oracle, libm_exact):
         assert u.max() <= (0 if libm_exact else 1), (u.max(), x[np.argmax(u)])
 
 
-def test_special_values(oracle):
+@BOTH_HOSTS
+def test_special_values(oracle, where):
     L = oracle.lib()
     assert L.orc_log(0.0, 1) == -np.inf and L.orc_log(-0.0, 1) == -np.inf
     assert np.isnan(L.orc_log(-1.0, 1)) and np.isnan(L.orc_log(np.nan, 1)) and L.orc_log(np.inf, 1) == np.inf
@@ -56,7 +62,8 @@ def test_special_values(oracle):
     assert L.orc_exp(0.0, 1) == 1.0 and L.orc_exp(-1e4, 1) == 0.0 and L.orc_exp(1e4, 1) == np.inf
 
 
-def test_lfact_vs_libm(oracle, tables, libm_exact):
+@BOTH_HOSTS
+def test_lfact_vs_libm(oracle, tables, libm_exact, where):
     """lfact2 (include/bs_call.h:335): table below 256, lgamma(x + 1) from 256 on."""
     L = oracle.lib()
     rng = np.random.default_rng(1)
@@ -69,7 +76,8 @@ def test_lfact_vs_libm(oracle, tables, libm_exact):
             assert abs(a - b) <= 4e-16 * abs(a), x
 
 
-def test_oracle_flavours_agree_on_records(oracle, tables, libm_exact):
+@BOTH_HOSTS
+def test_oracle_flavours_agree_on_records(oracle, tables, libm_exact, where):
     """Whole gt_meth records: libm flavour (the reference's arithmetic) == bsm flavour (the kernels' arithmetic)."""
     if not libm_exact:
         pytest.skip("host libm is not glibc's FMA variant")
@@ -80,9 +88,27 @@ def test_oracle_flavours_agree_on_records(oracle, tables, libm_exact):
         assert a.tobytes() == b.tobytes() and (sa == sb).all()
 
 
-def test_oracle_threading_modes_agree(oracle, tables):
+@BOTH_HOSTS
+def test_oracle_threading_modes_agree(oracle, tables, where):
     pile, ref = B.synth_pileup_host(5, 0, 50_000, 30)
     a, _ = oracle.call_sites(pile, ref, tables, oracle.LIBM, 1)
     b, _ = oracle.call_sites(pile, ref, tables, oracle.LIBM, 5)  # the reference's interleaved striding
     c, _ = oracle.call_sites(pile, ref, tables, oracle.LIBM, -3)
     assert a.tobytes() == b.tobytes() == c.tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_box_libm_is_exact(oracle, libm_exact):
+    """On the GPU box the LIBM flavour (the reference's arithmetic on the host's libm, no product code in it) must be
+    the asserted one: an x86-64 glibc >= 2.28 host with FMA selects glibc's *_fma log/exp, which bsmath.h replicates
+    bit for bit.  If this fails the parity tests silently fell back to integers-exact + 1e-11 against LIBM."""
+    import platform
+
+    host = oracle.host_description()
+    print("libm_exact=%s host=%s" % (libm_exact, host))
+    name, ver = platform.libc_ver()
+    glibc_ok = name == "glibc" and tuple(int(v) for v in ver.split(".")[:2]) >= (2, 28)
+    if platform.machine() == "x86_64" and glibc_ok and host["cpu_fma"]:
+        assert libm_exact, "x86-64 glibc %s with FMA, yet libm log/exp differ from bsmath.h" % ver
+    else:
+        pytest.skip("not an x86-64 glibc >= 2.28 host with FMA: %s" % host)
