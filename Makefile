@@ -13,7 +13,7 @@ CFLAGS = -O2 -fPIC -Wall -ffp-contract=off -std=gnu11 -I$(ROCM)/include -D__HIP_
 
 all: $(LIBDIR)/libbscall_amd.so oracle demo
 
-$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h $(CSRC)/devtables.h $(CSRC)/synth.h
+$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/callmath.h $(CSRC)/call_body.inc $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h $(CSRC)/devtables.h $(CSRC)/synth.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -34,9 +34,13 @@ $(LIBDIR)/vcfcore.o: $(CSRC)/vcfcore.hip $(CSRC)/devtables.h $(CSRC)/bsmath.h $(
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/sitestats.o: $(CSRC)/sitestats.hip $(CSRC)/devtables.h $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h include/bscall_amd.h
+$(LIBDIR)/sitestats.o: $(CSRC)/sitestats.hip $(CSRC)/sitestats_dev.h $(CSRC)/devtables.h $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h include/bscall_amd.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/fused.o: $(CSRC)/fused.hip $(CSRC)/callmath.h $(CSRC)/call_body.inc $(CSRC)/sitestats_dev.h $(CSRC)/devtables.h $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h include/bscall_amd.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -Wno-unused-variable -c $< -o $@
 
 $(LIBDIR)/probe.o: $(CSRC)/probe.hip
 	@mkdir -p $(LIBDIR)
@@ -54,7 +58,7 @@ $(LIBDIR)/synth_reads.o: $(CSRC)/synth_reads.c include/bscall_amd.h $(CSRC)/synt
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o
+$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
 
 oracle:

@@ -34,6 +34,8 @@ EXPORTS = (
     "bsc_vcf_stats_device",
     "bsc_get_site_stats",
     "bsc_reset_site_stats",
+    "bsc_chain_device",
+    "bsc_last_chain_ms",
     "bsc_set_profiling",
     "bsc_last_kernel_ms",
     "bsc_synchronize",
@@ -57,6 +59,10 @@ class Params(C.Structure):
 
 class VcfParams(C.Structure):
     _fields_ = [("all_positions", C.c_int32), ("reg_start", C.c_uint32), ("reg_stop", C.c_uint32)]
+
+
+class Window(C.Structure):
+    _fields_ = [("x", C.c_uint32), ("n_block", C.c_uint32), ("first", C.c_uint32), ("n", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -148,6 +154,10 @@ def load():
     L.bsc_vcf_records_device.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, C.POINTER(VcfParams), vp, vp]
     L.bsc_vcf_format.restype = i32
     L.bsc_vcf_format.argtypes = [vp, vp, C.c_char_p, C.c_char_p, vp, C.c_size_t]
+    L.bsc_chain_device.restype = i32
+    L.bsc_chain_device.argtypes = [vp, vp, vp, vp, C.POINTER(Window), C.POINTER(VcfParams), i32, vp, vp]
+    L.bsc_last_chain_ms.restype = i32
+    L.bsc_last_chain_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsc_set_profiling.restype = i32
     L.bsc_set_profiling.argtypes = [vp, i32]
     L.bsc_last_kernel_ms.restype = i32

@@ -39,6 +39,15 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _check_dest(name, a, nbytes):
+    """A caller-supplied destination the library writes `nbytes` bytes into: the C ABI takes a bare pointer, so an
+    undersized or strided array would be a host heap overflow."""
+    if not isinstance(a, np.ndarray) or not a.flags["C_CONTIGUOUS"] or not a.flags["WRITEABLE"]:
+        raise ValueError("%s must be a writable C-contiguous numpy array" % name)
+    if a.nbytes != nbytes:
+        raise ValueError("%s has %d bytes, the call writes %d" % (name, a.nbytes, nbytes))
+
+
 class SiteCaller:
     def __init__(self, under_conv=0.01, over_conv=0.05, ref_bias=2.0, min_qual=20, device=-1):
         self._L = _lib.load()
@@ -46,6 +55,7 @@ class SiteCaller:
         h = C.c_void_p()
         _check(self._L.bsc_create(C.byref(p), C.byref(h)))
         self._h = h
+        self._pending = None  # the submitted, not yet fetched block (block_submit / block_submit_to)
 
     # -- lifecycle ------------------------------------------------------------------------------
     def close(self):
@@ -85,8 +95,8 @@ class SiteCaller:
             out = np.zeros(n, dtype=GT_METH) if out_stride == 200 else np.zeros((n, out_stride), dtype=np.uint8)
         if skip is None:
             skip = np.zeros(n, dtype=np.uint8)
-        if out.nbytes != n * out_stride or skip.nbytes != n:
-            raise ValueError("out / skip have the wrong size")
+        _check_dest("out", out, n * out_stride)
+        _check_dest("skip", skip, n)
         _check(self._L.bsc_call_sites(self._h, _ptr(pile), _ptr(ref), n, _ptr(out), out_stride, _ptr(skip)))
         return out, skip
 
@@ -96,8 +106,11 @@ class SiteCaller:
         `out`: optional preallocated PILEUP array (reusing one avoids first-touch page faults in timing loops)."""
         templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        n = max(int(y) - int(x) + 1, 0)
         if out is None:
-            out = np.zeros(max(int(y) - int(x) + 1, 1), dtype=PILEUP)
+            out = np.zeros(max(n, 1), dtype=PILEUP)
+        elif out.dtype != PILEUP or not out.flags["C_CONTIGUOUS"] or len(out) < n:
+            raise ValueError("out must be a C-contiguous PILEUP array of at least y - x + 1 = %d records" % n)
         _check(self._L.bsc_accumulate(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(out)))
         return out[: max(int(y) - int(x) + 1, 0)]
 
@@ -113,6 +126,8 @@ class SiteCaller:
             out = np.zeros(n, dtype=GT_METH) if out_stride == 200 else np.zeros((n, out_stride), dtype=np.uint8)
         if skip is None:
             skip = np.zeros(n, dtype=np.uint8)
+        _check_dest("out", out, n * out_stride)
+        _check_dest("skip", skip, n)
         _check(self._L.bsc_call_block(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref),
                                       _ptr(out), out_stride, _ptr(skip)))
         return out, skip
@@ -137,19 +152,22 @@ class SiteCaller:
         if len(ref) != n:
             raise ValueError("ref must have y - x + 1 entries")
         stride = out.dtype.itemsize if out.ndim == 1 else out.shape[1]
-        if out.nbytes != n * stride or skip.nbytes != n:
-            raise ValueError("out / skip have the wrong size")
+        _check_dest("out", out, n * stride)
+        _check_dest("skip", skip, n)
         _check(self._L.bsc_block_submit_to(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref),
                                            _ptr(out), stride, _ptr(skip)))
         self._pending = (out, skip)
 
     def block_fetch(self):
         """Wait for the submitted block and return (GT_METH[n] or uint8[n, stride], skip)."""
-        if not isinstance(self._pending[0], int):  # block_submit_to: the records are already on their way
-            out, skip = self._pending
+        if self._pending is None:
+            raise BscError(-1, "block_fetch: no block was submitted")
+        pending, self._pending = self._pending, None
+        if not isinstance(pending[0], int):  # block_submit_to: the records are already on their way
+            out, skip = pending
             _check(self._L.bsc_block_fetch(self._h, None, None))
             return out, skip
-        n, stride = self._pending
+        n, stride = pending
         out = np.zeros(n, dtype=GT_METH) if stride == 200 else np.zeros((n, stride), dtype=np.uint8)
         skip = np.zeros(n, dtype=np.uint8)
         _check(self._L.bsc_block_fetch(self._h, _ptr(out), _ptr(skip)))
@@ -177,6 +195,22 @@ class SiteCaller:
         p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
         _check(self._L.bsc_vcf_records_device(self._h, d_gtm, stride, d_skip, d_ref, d_dbsnp, n, x, C.byref(p), d_out, stream))
 
+    # -- the fused chain: pile-ups in, records (+ statistics) out, gt_meth never in HBM -------------------------------
+    def chain_device(self, d_cts, d_ref, x, n_block, first, n, d_core, all_positions=False, reg_start=1,
+                     reg_stop=0xFFFFFFFF, d_dbsnp=None, with_stats=False, stream=None):
+        """One window (block positions first .. first + n - 1) of the block x .. x + n_block - 1.  d_cts points at the
+        pile-up of block position first - min(2, first), d_ref at the reference code of first - min(4, first) (see
+        include/bscall_amd.h); d_core receives n VCF_CORE records."""
+        w = _lib.Window(x, n_block, first, n)
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        _check(self._L.bsc_chain_device(self._h, d_cts, d_ref, d_dbsnp, C.byref(w), C.byref(p), 1 if with_stats else 0,
+                                        d_core, stream))
+
+    def last_chain_ms(self):
+        ms = C.c_float()
+        _check(self._L.bsc_last_chain_ms(self._h, C.byref(ms)))
+        return ms.value
+
     # -- reads in, written records out (packed: only what the printer would write crosses PCIe) -----------------
     def block_records(self, templates, seq, x, y, ref, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None,
                       with_stats=False, out=None):
@@ -189,8 +223,12 @@ class SiteCaller:
         if len(ref) != n + 2:
             raise ValueError("ref must have y - x + 3 entries (x .. y + 2)")
         db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+        if db is not None and len(db) != n:
+            raise ValueError("dbsnp must have y - x + 1 entries")
         if out is None:
             out = np.zeros(n, dtype=VCF_REC)
+        elif out.dtype != VCF_REC or not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]:
+            raise ValueError("out must be a writable C-contiguous VCF_REC array")
         p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
         cnt = C.c_uint64(0)
         _check(self._L.bsc_block_records(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref),

@@ -43,6 +43,7 @@ int bsc_dev_launch_compact(const void *core, const void *gtm, uint32_t gtm_strid
 int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const void *ref, const void *dbsnp, uint32_t n,
                        uint32_t x, int all_positions, uint32_t reg_start, uint32_t reg_stop, const void *tb, void *g,
                        void *out, int num_cus, void *stream);
+int bsc_dev_launch_chain(const bsc_chain_launch *L); /* fused.hip */
 int bsc_dev_launch_synth(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags, void *cts,
                          void *ref, int num_cus, void *stream);
 
@@ -65,6 +66,10 @@ struct bsc_context {
   size_t cap_cts, cap_ref, cap_out, cap_skip;
   void *d_het;
   size_t cap_het;
+  void *d_ovf; /* fused chain: CpG cytosines beyond the methylation pair table (8 bytes each) */
+  size_t cap_ovf;
+  hipEvent_t ev_chain[2]; /* bsc_set_profiling: the fused chain's launches */
+  int ev_chain_valid;
   /* accumulate stage */
   void *d_tpl, *d_seq, *d_rd, *d_lo;
   size_t cap_tpl, cap_seq, cap_rd, cap_lo;
@@ -111,6 +116,27 @@ static int bsc_fail(int code, const char *fmt, ...) {
   va_end(ap);
   return code;
 }
+
+/*
+ * Every entry point makes the context's device current for its HIP calls and puts the caller's device back on EVERY exit
+ * path (a cleanup handler): a process that shares the HIP runtime with other code — PyTorch, in bench.py and the tests —
+ * must not find its current device changed by a call into this library.
+ */
+typedef struct {
+  int prev; /* device to restore, -1 = nothing to do */
+} bsc_devguard;
+static void bsc_devguard_exit(bsc_devguard *g) {
+  if (g->prev >= 0) (void)hipSetDevice(g->prev);
+}
+#define BSC_ENTER(ctx)                                                               \
+  bsc_devguard guard_ __attribute__((cleanup(bsc_devguard_exit), unused)) = {-1};    \
+  do {                                                                               \
+    int cur_ = -1;                                                                   \
+    if (hipGetDevice(&cur_) != hipSuccess || cur_ != (ctx)->device) {                \
+      HIP_TRY(hipSetDevice((ctx)->device));                                          \
+      guard_.prev = cur_;                                                            \
+    }                                                                                \
+  } while (0)
 
 #define HIP_TRY(call)                                                                                        \
   do {                                                                                                       \
@@ -177,10 +203,15 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
   if (e != hipSuccess || ndev <= 0)
     return bsc_fail(BSC_ERR_NO_DEVICE, "bsc_create: no HIP device (%s); this library has no CPU path",
                     e == hipSuccess ? "count = 0" : hipGetErrorString(e));
-  int dev = p.device;
-  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  int dev = p.device, cur = -1;
+  HIP_TRY(hipGetDevice(&cur));
+  if (dev < 0) dev = cur;
   if (dev >= ndev) return bsc_fail(BSC_ERR_ARG, "bsc_create: device %d out of range (%d devices)", dev, ndev);
-  HIP_TRY(hipSetDevice(dev));
+  bsc_devguard guard_ __attribute__((cleanup(bsc_devguard_exit), unused)) = {-1}; /* the caller's device comes back */
+  if (dev != cur) {
+    HIP_TRY(hipSetDevice(dev));
+    guard_.prev = cur;
+  }
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -209,7 +240,14 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
 
 int bsc_destroy(bsc_context *ctx) {
   if (!ctx) return BSC_OK;
-  hipSetDevice(ctx->device);
+  bsc_devguard guard_ __attribute__((cleanup(bsc_devguard_exit), unused)) = {-1};
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) {
+      (void)hipSetDevice(ctx->device);
+      guard_.prev = cur;
+    }
+  }
   if (ctx->stream) {
     hipStreamSynchronize(ctx->stream);
     hipStreamDestroy(ctx->stream);
@@ -221,6 +259,9 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_out);
   hipFree(ctx->d_skip);
   hipFree(ctx->d_het);
+  hipFree(ctx->d_ovf);
+  for (int i = 0; i < 2; i++)
+    if (ctx->ev_chain[i]) hipEventDestroy(ctx->ev_chain[i]);
   hipFree(ctx->d_tpl);
   hipFree(ctx->d_seq);
   hipFree(ctx->d_rd);
@@ -299,7 +340,7 @@ int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref
   if (!d_cts || !d_ref || !d_out || !d_skip) return bsc_fail(BSC_ERR_ARG, "bsc_call_sites_device: NULL buffer");
   if (((uintptr_t)d_cts & 15u) || ((uintptr_t)d_out & 15u))
     return bsc_fail(BSC_ERR_ARG, "bsc_call_sites_device: d_cts and d_out must be 16-byte aligned");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   hipStream_t s = (hipStream_t)stream; /* NULL = HIP's default stream, as everywhere in HIP */
   uint64_t done = 0;
   while (done < n) {
@@ -346,7 +387,7 @@ int bsc_call_sites(bsc_context *ctx, const bsc_pileup *cts, const uint8_t *ref, 
   if (rc) return rc;
   if (n == 0) return BSC_OK;
   if (!cts || !ref || !out || !skip) return bsc_fail(BSC_ERR_ARG, "bsc_call_sites: NULL buffer");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   if ((rc = bsc_pipe_init(ctx))) return rc;
   const uint64_t chunk = n < BSC_PIPE_CHUNK ? n : BSC_PIPE_CHUNK;
   const int nbuf = n > chunk ? 2 : 1;
@@ -435,7 +476,7 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
   /* The templates themselves are checked where they are read anyway — by bsc_prep_reads_kernel, on the device
    * (a host loop over a million 40-byte templates costs more than the whole GPU side of the block); the verdict is
    * collected by bsc_block_check(). */
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   const uint64_t sz = (uint64_t)y - x + 1;
   const uint64_t n_wt = (sz + 63) / 64;
   int rc;
@@ -596,7 +637,7 @@ int bsc_vcf_records_device(bsc_context *ctx, const void *d_gtm, uint32_t gtm_str
   if (!d_gtm || !d_skip || !d_ref || !d_out) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_records_device: NULL buffer");
   if (((uintptr_t)d_gtm & 7u) || ((uintptr_t)d_out & 15u))
     return bsc_fail(BSC_ERR_ARG, "bsc_vcf_records_device: d_gtm must be 8-byte and d_out 16-byte aligned");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   if ((rc = bsc_reserve(&ctx->d_vg, &ctx->cap_vg, (size_t)n))) return rc;
   int e = bsc_dev_launch_vcf(d_gtm, gtm_stride, d_skip, d_ref, d_dbsnp, n, x, params->all_positions != 0,
                              params->reg_start, params->reg_stop, ctx->d_tables, ctx->d_vg, d_out, ctx->num_cus, stream);
@@ -611,7 +652,7 @@ int bsc_vcf_records(bsc_context *ctx, const void *gtm, uint32_t gtm_stride, cons
   if (rc) return rc;
   if (n == 0) return BSC_OK;
   if (!gtm || !skip || !ref || !out) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_records: NULL buffer");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)n * gtm_stride))) return rc;
   if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)n))) return rc;
   if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)n + 2))) return rc;
@@ -659,6 +700,8 @@ int bsc_block_submit_to(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, 
   hipError_t e = hipMemcpyAsync(out, ctx->d_out, (size_t)sz * out_stride, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(skip, ctx->d_skip, (size_t)sz, hipMemcpyDeviceToHost, ctx->stream);
   if (e != hipSuccess) {
+    /* work is still in flight on the staging area: the next submit must not overwrite it under the H2D copies */
+    (void)hipStreamSynchronize(ctx->stream);
     ctx->pending_sz = 0;
     return bsc_fail(BSC_ERR_HIP, "bsc_block_submit_to: copy-out failed: %s", hipGetErrorString(e));
   }
@@ -671,7 +714,7 @@ int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
   if (!ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_fetch: no block was submitted");
   const int copied = ctx->pending_copied;
   if (!copied && (!out || !skip)) return bsc_fail(BSC_ERR_ARG, "bsc_block_fetch: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   const uint64_t sz = ctx->pending_sz;
   ctx->pending_sz = 0;
   ctx->pending_copied = 0;
@@ -687,7 +730,7 @@ int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
 
 int bsc_set_profiling(bsc_context *ctx, int enable) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_set_profiling: ctx is NULL");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   if (enable && !ctx->ev[0])
     for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&ctx->ev[i]));
   ctx->profiling = enable != 0;
@@ -698,7 +741,7 @@ int bsc_set_profiling(bsc_context *ctx, int enable) {
 int bsc_last_kernel_ms(bsc_context *ctx, float *call_ms, float *fisher_ms) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_last_kernel_ms: ctx is NULL");
   if (!ctx->profiling || !ctx->ev_valid) return bsc_fail(BSC_ERR_ARG, "bsc_last_kernel_ms: no profiled launch yet");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   HIP_TRY(hipEventSynchronize(ctx->ev[2]));
   float a = 0.f, b = 0.f;
   HIP_TRY(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
@@ -713,7 +756,7 @@ int bsc_stream_probe_ms(bsc_context *ctx, const void *d_cts, const void *d_ref, 
   if (!ctx || !d_cts || !d_ref || !d_out || !d_skip || !ms) return bsc_fail(BSC_ERR_ARG, "bsc_stream_probe_ms: NULL argument");
   if (((uintptr_t)d_cts & 15u) || ((uintptr_t)d_out & 15u))
     return bsc_fail(BSC_ERR_ARG, "bsc_stream_probe_ms: d_cts and d_out must be 16-byte aligned");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a));
   HIP_TRY(hipEventCreate(&b));
@@ -739,8 +782,89 @@ int bsc_stream_probe_ms(bsc_context *ctx, const void *d_cts, const void *d_ref, 
 
 int bsc_synchronize(bsc_context *ctx) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_synchronize: ctx is NULL");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return BSC_OK;
+}
+
+static int bsc_sstats_init(bsc_context *ctx);
+
+/*
+ * The fused chain: one window of a block, pile-ups in, bsc_vcf_core records (+ statistics) out; gt_meth never exists in
+ * HBM.  Same records and statistics as bsc_call_sites_device -> bsc_vcf_records_device -> bsc_vcf_stats_device over the
+ * whole block.
+ */
+int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, const void *d_dbsnp, const bsc_window *w,
+                     const bsc_vcf_params *params, int with_stats, void *d_core, void *stream) {
+  if (!ctx || !w || !params) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: NULL argument");
+  if (w->n == 0) return BSC_OK;
+  if (!d_cts || !d_ref || !d_core) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: NULL buffer");
+  if ((uint64_t)w->first + w->n > w->n_block)
+    return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: window %u + %u exceeds the block (%u positions)", w->first, w->n, w->n_block);
+  if (w->n > 0x7ffffff0u) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: window too long");
+  if ((uint64_t)w->x + w->n_block > 0xffffffffull) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: positions exceed 32 bits");
+  if (((uintptr_t)d_core & 15u) || ((uintptr_t)d_cts & 7u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: d_core must be 16-byte and d_cts 8-byte aligned");
+  BSC_ENTER(ctx);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, (size_t)w->n * 8u);
+  if (rc) return rc;
+  bsc_chain_launch L;
+  memset(&L, 0, sizeof L);
+  if (with_stats) {
+    if ((rc = bsc_sstats_init(ctx))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_ovf, &ctx->cap_ovf, (size_t)w->n * 8u))) return rc;
+    L.carry_in = ctx->d_carry + 2 * ctx->carry_slot;
+    L.carry_out = ctx->d_carry + 2 * (ctx->carry_slot ^ 1u);
+    L.stats = ctx->d_sstats;
+    L.pairs = ctx->d_pairs;
+    L.ovf_list = ctx->d_ovf;
+    L.ovf_cap = w->n;
+    L.logp = ctx->d_logp;
+  }
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_HET_LIST, 0, sizeof(unsigned long long), s));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_OVF, 0, sizeof(unsigned long long), s));
+  const uint32_t after = w->n_block - w->first - w->n;
+  L.cts = d_cts;
+  L.ref = d_ref;
+  L.dbsnp = d_dbsnp;
+  L.x = w->x;
+  L.n_block = w->n_block;
+  L.first = w->first;
+  L.n = w->n;
+  L.lc = w->first < 2u ? w->first : 2u;
+  L.rc = after < 2u ? after : 2u;
+  L.lr = w->first < 4u ? w->first : 4u;
+  L.all_positions = params->all_positions != 0;
+  L.reg_start = params->reg_start;
+  L.reg_stop = params->reg_stop;
+  L.with_stats = with_stats != 0;
+  L.tb = ctx->d_tables;
+  L.core_out = d_core;
+  L.het_list = ctx->d_het;
+  L.counters = ctx->d_counters;
+  L.num_cus = ctx->num_cus;
+  L.stream = stream;
+  if (ctx->profiling) {
+    if (!ctx->ev_chain[0])
+      for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&ctx->ev_chain[i]));
+    L.ev_start = ctx->ev_chain[0];
+    L.ev_stop = ctx->ev_chain[1];
+    ctx->ev_chain_valid = 1;
+  }
+  int e = bsc_dev_launch_chain(&L);
+  if (e) return bsc_fail(BSC_ERR_HIP, "chain launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (with_stats) ctx->carry_slot ^= 1u;
+  ctx->sites += w->n;
+  return BSC_OK;
+}
+
+int bsc_last_chain_ms(bsc_context *ctx, float *ms) {
+  if (!ctx || !ms) return bsc_fail(BSC_ERR_ARG, "bsc_last_chain_ms: NULL argument");
+  if (!ctx->profiling || !ctx->ev_chain_valid) return bsc_fail(BSC_ERR_ARG, "bsc_last_chain_ms: no profiled launch yet");
+  BSC_ENTER(ctx);
+  HIP_TRY(hipEventSynchronize(ctx->ev_chain[1]));
+  HIP_TRY(hipEventElapsedTime(ms, ctx->ev_chain[0], ctx->ev_chain[1]));
   return BSC_OK;
 }
 
@@ -750,7 +874,7 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
   if (!ctx || !d_count) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_compact_device: NULL argument");
   int rc = bsc_check_stride(gtm_stride);
   if (rc) return rc;
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   if (n == 0) {
     HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), (hipStream_t)stream));
     return BSC_OK;
@@ -846,7 +970,7 @@ int bsc_vcf_stats_device(bsc_context *ctx, const void *d_core, const void *d_gtm
   if (!d_core || !d_gtm) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_stats_device: NULL buffer");
   if (((uintptr_t)d_core & 15u) || ((uintptr_t)d_gtm & 7u))
     return bsc_fail(BSC_ERR_ARG, "bsc_vcf_stats_device: d_core must be 16-byte and d_gtm 8-byte aligned");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   if ((rc = bsc_sstats_init(ctx))) return rc;
   const unsigned in = ctx->carry_slot, out = in ^ 1u;
   int e = bsc_dev_launch_site_stats(d_core, d_gtm, gtm_stride, d_dbsnp, n, ctx->d_tables, ctx->d_logp,
@@ -864,7 +988,7 @@ int bsc_vcf_stats(bsc_context *ctx, const bsc_vcf_core *core, const void *gtm, u
   if (rc) return rc;
   if (n == 0) return BSC_OK;
   if (!core || !gtm) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_stats: NULL buffer");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)n * gtm_stride))) return rc;
   if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)n * sizeof(bsc_vcf_core)))) return rc;
   if (dbsnp && (rc = bsc_reserve(&ctx->d_vdb, &ctx->cap_vdb, (size_t)n))) return rc;
@@ -879,7 +1003,7 @@ int bsc_vcf_stats(bsc_context *ctx, const bsc_vcf_core *core, const void *gtm, u
 
 int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out) {
   if (!ctx || !out) return bsc_fail(BSC_ERR_ARG, "bsc_get_site_stats: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   if (!ctx->d_sstats) {
     memset(out, 0, sizeof *out);
     return BSC_OK;
@@ -894,7 +1018,7 @@ int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out) {
 
 int bsc_reset_site_stats(bsc_context *ctx) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_reset_site_stats: ctx is NULL");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   if (!ctx->d_sstats) return BSC_OK;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(ctx->d_sstats, 0, sizeof(bsc_site_stats)));
@@ -906,7 +1030,7 @@ int bsc_reset_site_stats(bsc_context *ctx) {
 
 int bsc_get_stats(bsc_context *ctx, bsc_stats *out) {
   if (!ctx || !out) return bsc_fail(BSC_ERR_ARG, "bsc_get_stats: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   HIP_TRY(hipDeviceSynchronize());
   unsigned long long c[BSC_CNT_WORDS];
   HIP_TRY(hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
@@ -920,7 +1044,7 @@ int bsc_get_stats(bsc_context *ctx, bsc_stats *out) {
 
 int bsc_reset_stats(bsc_context *ctx) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_reset_stats: ctx is NULL");
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(ctx->d_counters, 0, BSC_CNT_WORDS * sizeof(unsigned long long)));
   ctx->sites = 0;
@@ -932,7 +1056,7 @@ int bsc_synth_pileup_device(bsc_context *ctx, uint64_t seed, uint64_t first_site
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_synth_pileup_device: ctx is NULL");
   if (n && (!d_cts || !d_ref)) return bsc_fail(BSC_ERR_ARG, "bsc_synth_pileup_device: NULL buffer");
   if (coverage > 4000) return bsc_fail(BSC_ERR_ARG, "bsc_synth_pileup_device: coverage %u > 4000", coverage);
-  HIP_TRY(hipSetDevice(ctx->device));
+  BSC_ENTER(ctx);
   int e = bsc_dev_launch_synth(seed, first_site, n, coverage, flags, d_cts, d_ref, ctx->num_cus, stream);
   if (e) return bsc_fail(BSC_ERR_HIP, "synth launch failed: %s", hipGetErrorString((hipError_t)e));
   return BSC_OK;

@@ -2,6 +2,8 @@
 #ifndef BSCALL_AMD_DEVTABLES_H
 #define BSCALL_AMD_DEVTABLES_H
 
+#include <stdint.h>
+
 /* q_prob columns (include/bs_call.h:148-150) as separate arrays, lfact_store (src/stats_utils.c:14-21) and
  * the per-run scalars of calc_gt_prob (src/genotype_model.c:47-48,88-89).  Built on the host with libm,
  * exactly as the reference builds them, and uploaded verbatim. */
@@ -21,7 +23,8 @@ typedef struct {
 #define BSC_CNT_INEXACT 14 /* accumulate: lanes whose quality / MAPQ^2 sums left the exact-float range */
 #define BSC_CNT_ERR 15     /* accumulate: min over invalid templates of (index << 8 | BSC_TERR_*); all ones = none */
 #define BSC_CNT_RECORDS 16 /* bsc_block_records: written records of the block being packed */
-#define BSC_CNT_WORDS 17
+#define BSC_CNT_OVF 17     /* fused chain: CpG cytosines beyond the methylation pair table, listed (reset per launch) */
+#define BSC_CNT_WORDS 18
 
 /* what the reference asserts about a block's templates (src/call_genotypes.c:186-188) plus the bounds of the read
  * buffer; checked by bsc_prep_reads_kernel, ordered as the checks are made */
@@ -30,5 +33,23 @@ typedef struct {
 #define BSC_TERR_STRAND 3 /* bs_strand > 2 */
 #define BSC_TERR_RANGE0 4 /* read 0 outside the read buffer */
 #define BSC_TERR_RANGE1 5 /* read 1 outside the read buffer */
+
+/* arguments of bsc_dev_launch_chain (fused.hip), filled by bsc_chain_device (bscall_api.c) */
+typedef struct bsc_chain_launch {
+  const void *cts, *ref, *dbsnp;
+  uint32_t x, n_block, first, n, lc, rc, lr;
+  int32_t all_positions;
+  uint32_t reg_start, reg_stop;
+  int32_t with_stats;
+  const void *tb;
+  void *core_out, *het_list, *counters;
+  const void *carry_in;
+  void *carry_out, *stats, *pairs, *ovf_list;
+  uint32_t ovf_cap;
+  const void *logp;
+  int num_cus;
+  void *stream;
+  void *ev_start, *ev_stop;
+} bsc_chain_launch;
 
 #endif

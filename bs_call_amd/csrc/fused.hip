@@ -1,0 +1,806 @@
+/*
+ * fused.hip — the print side as ONE pass over the pile-ups: pile-up -> call -> VCF record -> site statistics, the
+ * 200-byte gt_meth records never reaching HBM.  What the unfused chain does in three kernels and 630 bytes of traffic
+ * per position (bsc_call_kernel 105 in + 201 out, bsc_vcf_core_kernel 202 in + 64 out, bsc_site_stats_kernel 136 in) is
+ * done here in 105 + 64.
+ *
+ *   bsc_chain_kernel_t     one wave per tile of 60 positions.  The printer's record of position i needs the called
+ *                          genotypes of i-2 .. i+2 (src/print_vcf.c:548-594), so a wave computes 64 consecutive sites —
+ *                          2 halo sites either side, 60/64 = 94 % of its lanes productive — and every neighbour's
+ *                          genotype is in the wave's own LDS: no exchange between waves, no second pass.  Per lane:
+ *                          the calling kernel's statements (call_body.inc, shared textually with kernels.hip), then
+ *                          the record formation of _print_vcf_entry (:32-381; the restatement is vcfcore.hip's), then
+ *                          the statistics block (:382-526; sitestats.hip's), each lane's 64-byte bsc_vcf_core staged
+ *                          in the wave's slot and written with 16-byte stores.
+ *   bsc_chain_het_kernel   heterozygous calls (0.5 % of WGBS positions) need Fisher's exact test on the strand table
+ *                          (src/call_genotypes.c:61-108), a divergent walk: as in the unfused path they go to a list;
+ *                          this kernel evaluates the test, patches FS / FILTER into the records the main kernel wrote
+ *                          and adds those positions' statistics (nothing about a heterozygous position depends on, or
+ *                          is needed by, its neighbours' statistics: "CG" status needs the homozygous CC / GG pair).
+ *   bsc_meth_ovf_kernel    CpG cytosines whose informative counts exceed the pair table (sitestats.hip) are listed by
+ *                          the main kernel and evaluated here.
+ *
+ * A call handles one WINDOW of a block (the reference's unit: a maximal run of overlapping templates; the printer's
+ * sliding-window state is flushed at its end): the windows of a block give exactly the records of the whole block,
+ * which is what lets a contig be walked in fixed 4 Mi-position windows.  The window's buffers
+ * carry up to 2 positions of pile-ups and up to 4 / 2 reference codes of context either side.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bsmath.h"
+#include "callmath.h"
+#include "devtables.h"
+#include "sitestats_dev.h"
+
+#define FW 16 /* waves per workgroup: one 1024-thread workgroup per CU (the statistics histogram lives in its LDS) */
+#define FT 60 /* positions a wave-tile produces records for (64 computed) */
+#define F_COV_LDS 256 /* coverage rows of the statistics histogram kept in LDS (deeper positions: global atomics) */
+#define F_WORDS (SS_COV + F_COV_LDS * 6)
+#define F_PAIR 32 /* (a, b) < F_PAIR: CpG cytosines counted in the workgroup's LDS pair table; up to SS_PAIR: global */
+
+struct bsc_chain_args {
+  uint32_t x;       /* genome position (1-based) of the block's first position */
+  uint32_t n_block; /* positions in the block */
+  uint32_t first;   /* block-relative index of the window's first position */
+  uint32_t n;       /* positions in the window */
+  uint32_t lc, rc;  /* positions of pile-up context in the buffers left / right of the window (0..2) */
+  uint32_t lr;      /* reference codes in the buffer left of the window (0..4) */
+  uint32_t tile_begin, tile_end;
+  int32_t all_positions;
+  uint32_t reg_start, reg_stop;
+  int32_t with_stats;
+  uint32_t ovf_cap;
+};
+
+struct bsc_vcf_core_f {
+  uint32_t pos;
+  uint8_t emit, gt, ref_code, gt_enc, flt, phred, n_gl;
+  char cg;
+  char alt[2];
+  char cx_ref[5];
+  char cx_gt[5];
+  int32_t fs;
+  uint32_t qd;
+  uint32_t dp;
+  float gl[6];
+  uint32_t _pad;
+};
+static_assert(sizeof(bsc_vcf_core_f) == 64, "bsc_vcf_core is 64 bytes");
+
+/* LDS accesses that hand data from one lane to another inside a wave: the wave runs in lockstep and its LDS operations
+ * execute in order, so only the COMPILER has to be told — a wavefront-scope fence orders the memory operations, the
+ * (free) s_wave_barrier keeps the scheduler from moving anything across. */
+#define WAVE_LDS_SYNC()                                      \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+/* "NACGT"[code] for code 0..4 (v_perm_b32: selector 0..3 picks a byte of the second operand, 4..7 of the first) */
+#define F_BASE_CHAR(code) (__builtin_amdgcn_perm(0x00000054u, 0x4743414Eu, (code)) & 0xffu)
+
+/* genotype -> its two alleles as base codes 1..4 (AA AC AG AT CC CG CT GG GT TT) */
+__device__ static __forceinline__ void f_alleles(int g, int &a, int &b) {
+  a = g < 4 ? 1 : (g < 7 ? 2 : (g < 9 ? 3 : 4));
+  b = g < 4 ? g + 1 : (g < 7 ? g - 2 : (g < 9 ? g - 4 : 4));
+}
+
+/* mac1 (src/print_vcf.c:191-214): either allele of a heterozygous call supported by at most one base */
+__device__ static __forceinline__ bool f_mac1(int gt, const uint32_t c[8]) {
+  const uint64_t sA = (uint64_t)c[0] + c[4], sC = (uint64_t)c[1] + c[5] + c[7], sG = (uint64_t)c[2] + c[6] + c[4],
+                 sT = (uint64_t)c[3] + c[7];
+  switch (gt) {
+    case 1: return sC <= 1 || sA <= 1;                                       /* AC */
+    case 2: return (uint64_t)c[2] + c[6] <= 1 || c[0] <= 1;                  /* AG */
+    case 3: return sT <= 1 || sA <= 1;                                       /* AT */
+    case 5: return sG <= 1 || sC <= 1;                                       /* CG */
+    case 6: return c[3] <= 1 || (uint64_t)c[1] + c[5] <= 1;                  /* CT */
+    case 8: return sT <= 1 || sG <= 1;                                       /* GT */
+    default: return false;
+  }
+}
+
+/* h[idx]++ for the lanes with `on`: the first such lane's bin is bumped once for every lane that shares it (one value
+ * usually dominates), the others go individually.  Whole waves call this (wave-uniform control flow). */
+__device__ static __forceinline__ void f_hist_peel1(uint32_t *h, bool on, uint32_t idx, unsigned lane) {
+  const unsigned long long m = __ballot(on);
+  if (m) {
+    const int src = __builtin_ctzll(m);
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(idx, src);
+    const unsigned long long same = __ballot(on && idx == v);
+    if ((int)lane == src) atomicAdd(&h[v], (uint32_t)__popcll(same));
+    if (on && idx != v) atomicAdd(&h[idx], 1u);
+  }
+}
+
+/* per-lane facts of one position for the statistics (what bsc_site_stats_kernel derives from the records) */
+struct f_facts {
+  bool called, emit, pass, het, rs, cpg_site, ref_cpg, pair, pair_pass, fs_ok, do_meth;
+  uint32_t phred, flt, qd, fsv, mqv, cdp, cinf, m_a, m_b;
+  int mut;
+};
+
+/* the histogram updates of src/print_vcf.c:386-525 for 64 positions at once (wave-uniform control flow), as the
+ * heterozygous positions need them (never a CpG cytosine: the methylation part is in the main kernel only) */
+__device__ static __forceinline__ void f_stats_update(uint32_t *h, const f_facts &F, unsigned long long *stat_words) {
+#define F_COV_ADD(on, row, col)                                                                        \
+  do {                                                                                                 \
+    ss_hist_add<1>(h, (on) && (row) < F_COV_LDS, SS_COV, (row) * 6u + (col));                           \
+    if ((on) && (row) >= F_COV_LDS) atomicAdd(&stat_words[SS_COV + (uint64_t)(row) * 6u + (col)], 1ull); \
+  } while (0)
+  F_COV_ADD(F.called, F.cdp, 0u);
+  F_COV_ADD(F.emit, F.cdp, 1u);
+  ss_hist_add<1>(h, F.emit, SS_MISC + 0, 0u);
+  ss_hist_add<1>(h, F.emit && F.pass, SS_MISC + 1, 0u);
+  ss_hist_add<2>(h, F.emit, SS_QUAL + 0 * 256, F.phred, SS_QUAL + 1 * 256);
+  ss_hist_add<2>(h, F.emit, SS_FST + 0 * 512, F.qd * 2u + F.het);
+  ss_hist_add<2>(h, F.emit && F.fs_ok, SS_FST + 1 * 512, F.fsv * 2u + F.het);
+  ss_hist_add<2>(h, F.emit, SS_FST + 2 * 512, F.mqv * 2u + F.het);
+  ss_hist_add<2>(h, F.emit, SS_FILT, (F.het ? 32u : 0u) + (F.flt & 31u));
+  if (__any(F.rs)) {
+    ss_hist_add<1>(h, F.rs, SS_MISC + 6, 0u, SS_MISC + 8);
+    ss_hist_add<1>(h, F.rs && F.pass, SS_MISC + 7, 0u, SS_MISC + 9);
+  }
+  if (__any(F.cpg_site)) {
+    ss_hist_add<1>(h, F.pair, SS_MISC + 10, F.ref_cpg ? 0u : 2u);
+    ss_hist_add<1>(h, F.pair_pass, SS_MISC + 11, F.ref_cpg ? 0u : 2u);
+    ss_hist_add<1>(h, F.cpg_site, SS_QUAL + 2 * 256, (F.ref_cpg ? 0u : 256u) + F.phred);
+    F_COV_ADD(F.cpg_site, F.cdp, F.ref_cpg ? 2u : 3u);
+    F_COV_ADD(F.cpg_site, F.cinf, F.ref_cpg ? 4u : 5u);
+  }
+  if (__any(F.mut != 12)) {
+    const bool m = F.mut != 12;
+    ss_hist_add<1>(h, m, SS_MUT, (uint32_t)F.mut * 2u);
+    ss_hist_add<1>(h, m && F.pass, SS_MUT + 1, (uint32_t)F.mut * 2u);
+    if (__any(m && F.rs)) {
+      ss_hist_add<1>(h, m && F.rs, SS_DBMUT, (uint32_t)F.mut * 2u);
+      ss_hist_add<1>(h, m && F.rs && F.pass, SS_DBMUT + 1, (uint32_t)F.mut * 2u);
+    }
+  }
+#undef F_COV_ADD
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(64 * FW, 4) void bsc_chain_kernel_t(
+    const uint32_t *__restrict__ cts, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dbsnp,
+    const bsc_chain_args a, const bsc_dev_tables *__restrict__ tb, uint8_t *__restrict__ core_out,
+    unsigned long long *__restrict__ het_list, unsigned long long *__restrict__ counters,
+    const uint32_t *__restrict__ carry_in, uint32_t *__restrict__ carry_out, unsigned long long *__restrict__ stat_words,
+    unsigned long long *__restrict__ pair_cells, unsigned long long *__restrict__ ovf_list) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_slot[FW][SLOT_DW];
+  __shared__ double s_k[44], s_lnk[44], s_half[44], s_one[44];
+  __shared__ double s_logtab[256];
+  __shared__ unsigned long long s_exptab[256];
+  __shared__ unsigned int s_cnt[12];  /* covered, hist[10], het */
+  __shared__ uint8_t s_pairs[FW][256]; /* per wave: the (lane, class) pairs whose logs are needed (call_body.inc) */
+  __shared__ uint32_t s_gw[FW][64];    /* per wave and computed site: the printer's called genotype + 1 (0 = none) | its
+                                          IUPAC letter << 8 | (carries C) << 16 | (carries G) << 17 */
+  __shared__ uint16_t s_rf[FW][72];    /* per wave: reference code | its letter << 8, from 2 before the first computed site */
+  __shared__ uint32_t s_pend[FW][64];  /* per wave: bit 0 = a written '+' strand CG call (the pending cytosine of
+                                          src/print_vcf.c:447-455), bits 8.. = its FILTER bits */
+  __shared__ uint32_t h[F_WORDS];      /* statistics histogram of the workgroup (sitestats_dev.h) */
+  __shared__ uint32_t s_pair[4 * F_PAIR * F_PAIR]; /* CpG cytosines per [ref / non-ref][all / passed][a][b] */
+
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = tid & 63u;
+  const unsigned wid = tid >> 6;
+  if (tid < 44) {
+    s_k[tid] = tb->k[tid];
+    s_lnk[tid] = tb->ln_k[tid];
+    s_half[tid] = tb->ln_k_half[tid];
+    s_one[tid] = tb->ln_k_one[tid];
+  }
+  if (tid < 256) {
+    s_logtab[tid] = tb->log_tab[tid];
+    s_exptab[tid] = tb->exp_tab[tid];
+  }
+  if (tid < 12) s_cnt[tid] = 0;
+  if (a.with_stats) {
+    for (unsigned i = tid; i < F_WORDS; i += 64 * FW) h[i] = 0;
+    for (unsigned i = tid; i < 4 * F_PAIR * F_PAIR; i += 64 * FW) s_pair[i] = 0;
+  }
+  const double l = 1.0 - tb->under_conv;
+  const double t = tb->over_conv;
+  const double lrb = tb->lrb, lrb1 = tb->lrb1;
+  __syncthreads();
+
+  uint32_t *slot = lds_slot[wid];
+  uint32_t *sg = s_gw[wid];
+  uint16_t *srf = s_rf[wid];
+  uint32_t *spd = s_pend[wid];
+  /* the reference codes the buffer holds: block indices [first - lr, min(n_block + 2, first + n + 2)) */
+  const int64_t ref_lo = (int64_t)a.first - a.lr;
+  const int64_t ref_hi = ((int64_t)a.first + a.n + 2 < (int64_t)a.n_block + 2) ? (int64_t)a.first + a.n + 2 : (int64_t)a.n_block + 2;
+
+  for (uint32_t T = a.tile_begin + blockIdx.x * FW + wid; T < a.tile_end; T += gridDim.x * FW) {
+    const int32_t jw0 = (int32_t)(T * FT) - 2;  /* window-relative index of the site lane 0 computes */
+    const int32_t jw = jw0 + (int32_t)lane;
+    const bool valid = FULL || (jw >= -(int32_t)a.lc && jw < (int32_t)(a.n + a.rc)); /* the site is in the buffers */
+    const bool inner = lane >= 2u && lane < 62u && (FULL || (jw >= 0 && jw < (int32_t)a.n));
+    /* Everything per lane is relative to the tile: "lane index" L = block index - b0, b0 = block index of lane 0's
+     * site (wave-uniform, 64-bit, in scalar registers); the block occupies lane indices blk_lo .. blk_hi (clamped far
+     * outside the tile where the block's ends are not near). */
+    const int64_t b0 = (int64_t)a.first + jw0;
+    const int32_t blk_lo = (int32_t)(-b0 < -4096 ? -4096 : (-b0 > 4096 ? 4096 : -b0));
+    const int64_t to_last = (int64_t)a.n_block - 1 - b0;
+    const int32_t blk_hi = (int32_t)(to_last < -4096 ? -4096 : (to_last > 4096 ? 4096 : to_last));
+    const uint32_t pos0 = a.x + (uint32_t)b0; /* genome position of lane index 0 (mod 2^32; only inner lanes use it) */
+
+    /* ---- reference codes of lane indices -2 .. 63 + 2 -> srf[0 .. 67] ---- */
+    {
+      const int64_t r0 = b0 - 2 - ref_lo; /* offset of srf[0]'s code in the buffer */
+      const int64_t avail = ref_hi - ref_lo;
+      const int64_t k0 = r0 + lane;
+      const uint32_t c0 = (k0 >= 0 && k0 < avail) ? ref[k0] : 0u;
+      srf[lane] = (uint16_t)(c0 | (F_BASE_CHAR(c0) << 8));
+      if (lane < 4u) {
+        const int64_t k1 = r0 + 64 + lane;
+        const uint32_t c1 = (k1 >= 0 && k1 < avail) ? ref[k1] : 0u;
+        srf[64u + lane] = (uint16_t)(c1 | (F_BASE_CHAR(c1) << 8));
+      }
+    }
+
+    /* ---- my record ---- */
+    uint32_t w[IN_DW];
+    if (FULL) {
+      const char *src = reinterpret_cast<const char *>(cts + (uint64_t)(jw0 + (int32_t)a.lc) * IN_DW) + lane * 16;
+#pragma unroll
+      for (int j = 0; j < 6; j++) dma16(src + j * 1024, slot + j * 256);
+      if (lane < 32) dma16(src + 6 * 1024, slot + 6 * 256);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint2 *rec = reinterpret_cast<const uint2 *>(slot + lane * IN_DW);
+#pragma unroll
+      for (int i = 0; i < IN_DW / 2; i++) {
+        const uint2 v = rec[i];
+        w[2 * i] = v.x;
+        w[2 * i + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < IN_DW; i++) w[i] = valid ? cts[(uint64_t)(jw + (int32_t)a.lc) * IN_DW + i] : 0u;
+    }
+    WAVE_LDS_SYNC();
+    const unsigned rf = valid ? (unsigned)srf[lane + 2u] & 0xffu : 0u; /* my site's reference code (lane index = lane) */
+#include "call_body.inc"
+
+    /* ---- block counters and the heterozygous list (window positions only, not the halo) ---- */
+    const bool defer = covered && inner && ((0x16Eu >> mxi) & 1u); /* gt_het[max_gt]: Fisher's test (:61) */
+    if (covered && inner) {
+      atomicAdd(&s_cnt[0], 1u);
+      atomicAdd(&s_cnt[1 + mxi], 1u);
+    }
+    {
+      const unsigned long long m = __ballot(defer);
+      if (m) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&counters[BSC_CNT_HET_LIST], (unsigned long long)__popcll(m));
+        base = __shfl(base, 0);
+        if (defer) het_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned long long)(uint32_t)jw | ((unsigned long long)mxi << 32);
+        if (lane == 0) atomicAdd(&s_cnt[11], (unsigned)__popcll(m));
+      }
+    }
+
+    /* ---- the printer's genotype: first-max argmax of gt_prob[], recomputed (src/print_vcf.c:584-591) ----
+     * Published for the neighbours with everything they need from it: its IUPAC letter and whether it carries C / G. */
+    {
+      uint32_t gz = 0;
+      if (covered) {
+        double z = gp[0];
+#pragma unroll
+        for (int k = 1; k < 10; k++)
+          if (gp[k] > z) { z = gp[k]; gz = (uint32_t)k; }
+        gz += 1u;
+      }
+      const uint32_t g0 = gz ? gz - 1u : 0u;
+      /* "NAMRWCSYGKT"[gz] */
+      const uint32_t lo = __builtin_amdgcn_perm(0x59534357u, 0x524D414Eu, gz & 7u);
+      const uint32_t hi = __builtin_amdgcn_perm(0u, 0x00544B47u, gz & 7u);
+      const uint32_t iu = (gz >= 8u ? hi : lo) & 0xffu;
+      const uint32_t fl = gz ? (((0x72u >> g0) & 1u) | (((0x1A4u >> g0) & 1u) << 1)) : 0u; /* AC CC CG CT ; AG CG GG GT */
+      sg[lane] = gz | (iu << 8) | (fl << 16);
+    }
+    WAVE_LDS_SYNC();
+
+    /* ---- record formation (_print_vcf_entry, src/print_vcf.c:32-381; restated as in vcfcore.hip) ----
+     * Lanes 2..61 form their record; lane 1 — the site just left of the tile's first position — runs the same code
+     * for the one thing its right neighbour needs from it: whether it is a written '+' strand CG call, and its FILTER
+     * bits (the pending cytosine of the CpG bookkeeping).  The record is built as its sixteen dwords. */
+    uint32_t od[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) od[k] = 0u;
+    bool pend = false, minus_cg = false, st_called = false, st_emit = false, st_het = false, st_rs = false,
+         st_cpg = false, st_refcpg = false;
+    uint32_t st_phred = 0, st_qd = 0, st_cdp = 0, st_cinf = 0, st_ma = 0, st_mb = 0, st_pos = 0;
+    int st_mut = 12;
+    const bool former = valid && lane >= 1u && lane < 62u && (inner || lane == 1u);
+    const uint32_t me = former ? sg[lane] : 0u;
+    const uint32_t dp1 = cnt[0] + cnt[1] + cnt[2] + cnt[3], d_inf = cnt[4] + cnt[5] + cnt[6] + cnt[7];
+    uint32_t flt = 0;
+    if ((me & 0xffu) != 0 && dp1 + d_inf != 0) {
+      const int gt = (int)(me & 0xffu) - 1;
+      const int L = (int)lane;
+      /* called genotypes of lane indices L-2 .. L+2 (lane 1 clamps at 0: its own record is not kept) */
+      uint32_t ge[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const int j = L - 2 + k;
+        uint32_t v = (j >= blk_lo && j <= blk_hi) ? sg[j < 0 ? 0 : j] : 0x4E00u;
+        if (j > blk_hi && L + 2 > blk_hi) v = sg[blk_hi]; /* flush_vcf_entries repeats the last genotype, :540 */
+        ge[k] = v;
+      }
+      /* reference context through the reference's strncpy of a 7-base window (:570-577); srf[] starts at lane index -2 */
+      uint32_t rr[5];
+      {
+        const int la_ = L + 2 < blk_hi ? L + 2 : blk_hi;    /* look-ahead position that filled the window */
+        const int w0 = la_ >= blk_lo + 4 ? la_ - 4 : blk_lo; /* first base of that copy */
+        bool blank = false;
+        for (int j = w0; j < L - 2; j++) blank |= (srf[j + 2 < 0 ? 0 : j + 2] & 0xffu) == 0; /* an N before the 5 bases */
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          const int j = L - 2 + k;
+          uint32_t v = 0x4E00u; /* code 0, 'N' */
+          if (j >= blk_lo) {
+            v = srf[j + 2 < 0 ? 0 : j + 2];
+            blank |= (v & 0xffu) == 0;
+            if (blank) v = 0x4E00u;
+          }
+          rr[k] = v;
+        }
+      }
+      const int rfix = (int)(rr[2] & 0xffu);
+      const uint32_t rs_found = (dbsnp && inner) ? (uint32_t)dbsnp[jw] : 0u;
+      int ga, gb;
+      f_alleles(gt, ga, gb);
+      const bool het = ga != gb;
+      bool skp = !a.all_positions && !(rs_found & 2u) && ((gt == 0 && rfix == 1) || (gt == 9 && rfix == 4));
+      /* phred (:140-148) */
+      const double z1 = exp_dev(la[gt] * BSM_LN10, (const uint64_t *)s_exptab);
+      int phred;
+      {
+        const double om = 1.0 - z1;
+        const double lg = log_dev(z1 >= 1.0 ? 0.5 : om, s_logtab);
+        phred = (int)(-10.0 * lg / BSM_LN10);
+        if (phred > 255) phred = 255;
+        if (z1 >= 1.0) phred = 255;
+      }
+      /* FS = (int)(-0.0 * 10.0 + 0.5) = 0: fisher_strand is 0 unless gt_het[max_gt]; those go to bsc_chain_het_kernel */
+      const uint32_t qd = dp1 > 0 ? (uint32_t)phred / dp1 : (uint32_t)phred;
+      const uint32_t pos = pos0 + lane;
+      if (!skp) skp = pos < a.reg_start || pos > a.reg_stop;
+      /* CpG status (:227-266) */
+      uint32_t cg = '.';
+      {
+        const uint32_t c = ge[2] & 0xffu, nx = ge[3] & 0xffu, pv = ge[1] & 0xffu;
+        const bool nxG = (ge[3] >> 17) & 1u, pvC = (ge[1] >> 16) & 1u, cC = (ge[2] >> 16) & 1u, cG = (ge[2] >> 17) & 1u;
+        if ((c == 5u && nx == 8u) || (c == 8u && pv == 5u)) cg = 'C'; /* "CG" */
+        else if (cC) cg = nx ? (nxG ? 'H' : 'N') : '?';
+        else if (cG) cg = pv ? (pvC ? 'H' : 'N') : (c == 8u ? '?' : '.');
+      }
+      od[0] = pos;
+      od[2] = ((uint32_t)phred << 8) | (cg << 24);
+      od[3] = ((rr[0] >> 8) << 16) | ((rr[1] >> 8) << 24);
+      od[4] = (rr[2] >> 8) | ((rr[3] >> 8) << 8) | ((rr[4] >> 8) << 16) | (((ge[0] >> 8) & 0xffu) << 24);
+      od[5] = ((ge[1] >> 8) & 0xffu) | (((ge[2] >> 8) & 0xffu) << 8) | (((ge[3] >> 8) & 0xffu) << 16) | (((ge[4] >> 8) & 0xffu) << 24);
+      od[7] = qd;
+      od[8] = dp1;
+      uint32_t d1 = ((uint32_t)gt << 8) | ((uint32_t)rfix << 16);
+      if (!skp) {
+        if (phred < 20) flt |= 1u;
+        if (qd < 2u) flt |= 2u;
+        if (mq < 40) flt |= 8u;
+        if (!flt && het && !defer && f_mac1(gt, cnt)) flt |= 128u; /* deferred sites: after their FS is known */
+        int aix0 = 0, aix1 = 0;
+        if (ga != rfix) aix0 = ga;
+        if (gb != ga && gb != rfix) { if (aix0) aix1 = gb; else aix0 = gb; }
+        /* "\0ACGT"[aix] twice */
+        od[3] |= __builtin_amdgcn_perm(0x00000054u, 0x47434100u, (uint32_t)aix0 | ((uint32_t)aix1 << 8)) & 0xffffu;
+        const uint32_t gt_enc = het ? ((ga == rfix || gb == rfix) ? 0x24u : 0x48u) : (ga == rfix ? 0x22u : 0x44u);
+        d1 |= 1u | (gt_enc << 24);
+        /* GL (:319-347): gt_prob read back from the lane's LDS area (la[], call_body.inc); index of alleles a <= b:
+         * a (9 - a) / 2 + b - 5 */
+#define F_GLIDX(x, y) ((x) * (9 - (x)) / 2 + (y)-5)
+        const bool hr = rfix != 0;
+        const int r1 = hr ? rfix : 1, a0 = aix0 ? aix0 : 1, a1 = aix1 ? aix1 : 1;
+        double zr = hr ? la[F_GLIDX(r1, r1)] : -99.999;
+        double zh0 = la[r1 < a0 ? F_GLIDX(r1, a0) : F_GLIDX(a0, r1)], zm0 = la[F_GLIDX(a0, a0)];
+        double zh1 = la[r1 < a1 ? F_GLIDX(r1, a1) : F_GLIDX(a1, r1)], zm1 = la[F_GLIDX(a1, a1)];
+#undef F_GLIDX
+        zr = zr < -99.999 ? -99.999 : zr;
+        zh0 = zh0 < -99.999 ? -99.999 : zh0;
+        zm0 = zm0 < -99.999 ? -99.999 : zm0;
+        zh1 = zh1 < -99.999 ? -99.999 : zh1;
+        zm1 = zm1 < -99.999 ? -99.999 : zm1;
+        const uint32_t nalt = (aix0 ? 1u : 0u) + (aix1 ? 1u : 0u);
+        const uint32_t ngl = 1u + (hr ? 2u * nalt : nalt);
+        /* with a reference base: ref, het0, hom0, het1, hom1; on an N: ref (-99.999), hom0, hom1 */
+        const float f0 = (float)zr, f1 = (float)(hr ? zh0 : zm0), f2 = (float)(hr ? zm0 : zm1), f3 = (float)zh1, f4 = (float)zm1;
+        od[9] = __float_as_uint(f0);
+        od[10] = ngl > 1u ? __float_as_uint(f1) : 0u;
+        od[11] = ngl > 2u ? __float_as_uint(f2) : 0u;
+        od[12] = ngl > 3u ? __float_as_uint(f3) : 0u;
+        od[13] = ngl > 4u ? __float_as_uint(f4) : 0u;
+        od[2] |= flt | (ngl << 16);
+      }
+      od[1] = d1;
+      /* ---- facts for the statistics and for the right neighbour ---- */
+      const bool emit = !skp;
+      pend = emit && cg == 'C' && gt == 4; /* a written CC call followed by GG: cs_str "+", FORMAT CG "CG" */
+      minus_cg = emit && cg == 'C' && gt == 7;
+      if (inner && !defer) {
+        st_called = true;
+        st_emit = emit;
+        st_phred = (uint32_t)phred;
+        st_qd = qd > 255u ? 255u : qd;
+        st_pos = pos;
+        const uint32_t dpt = dp1 + d_inf;
+        st_cdp = dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u;
+        st_cinf = d_inf < BSC_COV_CAP ? d_inf : BSC_COV_CAP - 1u;
+        if (emit) {
+          st_rs = rs_found != 0;
+          st_het = het;
+          st_mut = ss_mut_type(gt, rfix);
+          if (cg == 'C' && (gt == 4 || gt == 7)) {
+            st_cpg = true;
+            const uint32_t x1 = rr[1] & 0xffu, x2 = rr[2] & 0xffu, x3 = rr[3] & 0xffu;
+            st_refcpg = gt == 4 ? (x2 == 2u && x3 == 3u) : (x1 == 2u && x2 == 3u); /* prf_ctxt + 2 / + 1 == "CG" */
+            st_ma = gt == 4 ? cnt[5] : cnt[6];
+            st_mb = gt == 4 ? cnt[7] : cnt[4];
+          }
+        }
+      }
+    }
+    spd[lane] = (pend ? 1u : 0u) | (flt << 8);
+    WAVE_LDS_SYNC();
+    if (a.with_stats) {
+      /* ---- the statistics block (src/print_vcf.c:386-525; sitestats.hip has the restatement) for the tile ----
+       * Wide histograms take one LDS atomic per lane; where one value dominates (QUAL 255, MQ, FS 0, FILTER 0) the
+       * first lane's value is added once for all lanes that share it. */
+      const bool pass = flt == 0;
+      const uint32_t mqv = (uint32_t)(mq < 0 ? 0 : (mq > 255 ? 255 : mq));
+      if (st_called) { /* cov[depth].all / .var (:393, :419) */
+        if (st_cdp < F_COV_LDS) {
+          atomicAdd(&h[SS_COV + st_cdp * 6u], 1u);
+          if (st_emit) atomicAdd(&h[SS_COV + st_cdp * 6u + 1u], 1u);
+        } else {
+          atomicAdd(&stat_words[SS_COV + (uint64_t)st_cdp * 6u], 1ull);
+          if (st_emit) atomicAdd(&stat_words[SS_COV + (uint64_t)st_cdp * 6u + 1u], 1ull);
+        }
+      }
+      const unsigned long long m_emit = __ballot(st_emit);
+      if (m_emit) {
+        const unsigned long long m_pass = __ballot(st_emit && pass);
+        if (lane == 0) {
+          atomicAdd(&h[SS_MISC + 0], (uint32_t)__popcll(m_emit)); /* snps[all]: every written record, see sitestats.hip */
+          atomicAdd(&h[SS_MISC + 1], (uint32_t)__popcll(m_pass));
+        }
+        const uint32_t hh = st_het ? 1u : 0u;
+        f_hist_peel1(h, st_emit, SS_QUAL + 256u + st_phred, lane); /* qual[variant_sites]; [all_sites] is its copy */
+        if (st_emit) atomicAdd(&h[SS_FST + 0u * 512u + st_qd * 2u + hh], 1u);
+        f_hist_peel1(h, st_emit, SS_FST + 1u * 512u + hh, lane);   /* FS is 0 for every position this kernel finishes */
+        f_hist_peel1(h, st_emit, SS_FST + 2u * 512u + mqv * 2u + hh, lane);
+        f_hist_peel1(h, st_emit, SS_FILT + (hh ? 32u : 0u) + (flt & 31u), lane);
+        if (__any(st_rs)) {
+          if (st_rs) {
+            atomicAdd(&h[SS_MISC + 6], 1u);
+            atomicAdd(&h[SS_MISC + 8], 1u);
+            if (pass) {
+              atomicAdd(&h[SS_MISC + 7], 1u);
+              atomicAdd(&h[SS_MISC + 9], 1u);
+            }
+          }
+        }
+        if (__any(st_cpg)) {
+          bool pair = false, pair_pass = false;
+          if (minus_cg && st_cpg) { /* does the record just before complete a CpG? (:198-205) */
+            bool p_ok;
+            uint32_t p_flt;
+            if (jw == 0 && a.lc == 0) { /* first position of a block: the previous block's pending cytosine, if adjacent */
+              const uint32_t p_pos = carry_in[0];
+              p_ok = p_pos != 0 && st_pos - p_pos == 1u;
+              p_flt = carry_in[1];
+            } else {
+              const uint32_t pw = spd[lane - 1u];
+              p_ok = (pw & 1u) != 0;
+              p_flt = pw >> 8;
+            }
+            pair = p_ok;
+            pair_pass = p_ok && !(p_flt || flt);
+          }
+          if (st_cpg) {
+            const uint32_t rsel = st_refcpg ? 0u : 2u;
+            if (pair) atomicAdd(&h[SS_MISC + 10 + rsel], 1u);
+            if (pair_pass) atomicAdd(&h[SS_MISC + 11 + rsel], 1u);
+            atomicAdd(&h[SS_QUAL + 2u * 256u + (st_refcpg ? 0u : 256u) + st_phred], 1u);
+            if (st_cdp < F_COV_LDS) atomicAdd(&h[SS_COV + st_cdp * 6u + (st_refcpg ? 2u : 3u)], 1u);
+            else atomicAdd(&stat_words[SS_COV + (uint64_t)st_cdp * 6u + (st_refcpg ? 2u : 3u)], 1ull);
+            if (st_cinf < F_COV_LDS) atomicAdd(&h[SS_COV + st_cinf * 6u + (st_refcpg ? 4u : 5u)], 1u);
+            else atomicAdd(&stat_words[SS_COV + (uint64_t)st_cinf * 6u + (st_refcpg ? 4u : 5u)], 1ull);
+            if (st_ma + st_mb != 0) { /* methylation posterior (:492-515): counted per (a, b), evaluated when read */
+              if (st_ma < F_PAIR && st_mb < F_PAIR) {
+                const uint32_t cell = (rsel * F_PAIR + st_ma) * F_PAIR + st_mb;
+                atomicAdd(&s_pair[cell], 1u);
+                if (pass) atomicAdd(&s_pair[cell + F_PAIR * F_PAIR], 1u);
+              } else if (st_ma < SS_PAIR && st_mb < SS_PAIR) {
+                const uint32_t cell = (rsel * SS_PAIR + st_ma) * SS_PAIR + st_mb;
+                atomicAdd(&pair_cells[cell], 1ull);
+                if (pass) atomicAdd(&pair_cells[cell + SS_PAIR * SS_PAIR], 1ull);
+              } else {
+                const unsigned long long k = atomicAdd(&counters[BSC_CNT_OVF], 1ull);
+                if (k < a.ovf_cap)
+                  ovf_list[k] = (unsigned long long)st_ma | ((unsigned long long)st_mb << 24) |
+                                ((unsigned long long)(st_refcpg ? 1u : 0u) << 48) | ((unsigned long long)(pass ? 1u : 0u) << 49);
+              }
+            }
+          }
+        }
+        if (__any(st_mut != 12)) {
+          if (st_mut != 12) {
+            atomicAdd(&h[SS_MUT + (uint32_t)st_mut * 2u], 1u);
+            if (pass) atomicAdd(&h[SS_MUT + (uint32_t)st_mut * 2u + 1u], 1u);
+            if (st_rs) {
+              atomicAdd(&h[SS_DBMUT + (uint32_t)st_mut * 2u], 1u);
+              if (pass) atomicAdd(&h[SS_DBMUT + (uint32_t)st_mut * 2u + 1u], 1u);
+            }
+          }
+        }
+      }
+      /* the window's last position is the pending cytosine, or not, for whatever follows */
+      if (jw == (int32_t)a.n - 1 && lane >= 2u && lane < 62u) {
+        carry_out[0] = pend ? pos0 + lane : 0u;
+        carry_out[1] = pend ? flt : 0u;
+      }
+    }
+
+    /* ---- results: the tile's 60 records, staged in the slot (every la[] read is done), leave contiguously ---- */
+    WAVE_LDS_SYNC();
+    {
+      uint4 *so = reinterpret_cast<uint4 *>(slot);
+      if (lane >= 2u && lane < 62u) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) so[(lane - 2u) * 4u + k] = make_uint4(od[4 * k], od[4 * k + 1], od[4 * k + 2], od[4 * k + 3]);
+      }
+      WAVE_LDS_SYNC();
+      const uint32_t i0 = T * FT;
+      const uint32_t nrec = FULL ? (uint32_t)FT : (a.n - i0 < (uint32_t)FT ? a.n - i0 : (uint32_t)FT);
+      const uint32_t nvec = nrec * 4u;
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 *dst = reinterpret_cast<u32x4 *>(core_out + (uint64_t)i0 * 64u);
+#pragma unroll
+      for (unsigned k = 0; k < 4; k++) {
+        const unsigned idx = k * 64u + lane;
+        if (idx < nvec) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(so)[idx], dst + idx);
+      }
+    }
+    WAVE_LDS_SYNC();
+  }
+
+  __syncthreads();
+  if (tid < 12 && s_cnt[tid]) atomicAdd(&counters[BSC_CNT_COVERED + tid], (unsigned long long)s_cnt[tid]);
+  if (a.with_stats) {
+    for (unsigned i = tid; i < F_WORDS; i += 64 * FW)
+      if (h[i]) {
+        atomicAdd(&stat_words[i], (unsigned long long)h[i]);
+        /* qual[all_sites] receives what qual[variant_sites] receives (every written record counts as a variant) */
+        if (i >= SS_QUAL + 256u && i < SS_QUAL + 512u) atomicAdd(&stat_words[i - 256u], (unsigned long long)h[i]);
+      }
+    for (unsigned i = tid; i < 4 * F_PAIR * F_PAIR; i += 64 * FW)
+      if (s_pair[i]) { /* LDS cell [q][a][b] -> the context's [q][SS_PAIR][SS_PAIR] table */
+        const unsigned q = i / (F_PAIR * F_PAIR), ab = i % (F_PAIR * F_PAIR);
+        atomicAdd(&pair_cells[(q * SS_PAIR + ab / F_PAIR) * SS_PAIR + ab % F_PAIR], (unsigned long long)s_pair[i]);
+      }
+  }
+}
+
+/*
+ * Heterozygous calls: Fisher's exact test on the strand table (src/call_genotypes.c:61-108, src/stats_utils.c:25-91),
+ * FS and the FILTER bits that depend on it patched into the record, the position's statistics.  One lane per listed
+ * position; the histogram updates are made by whole waves.
+ */
+extern "C" __global__ __launch_bounds__(256) void bsc_chain_het_kernel(
+    const uint32_t *__restrict__ cts, const uint8_t *__restrict__ dbsnp, const bsc_chain_args a,
+    const bsc_dev_tables *__restrict__ tb, uint8_t *__restrict__ core_out, const unsigned long long *__restrict__ het_list,
+    unsigned long long *__restrict__ counters, unsigned long long *__restrict__ stat_words) {
+  __shared__ double s_lf[256];
+  __shared__ double s_logtab[256];
+  __shared__ unsigned long long s_exptab[256];
+  __shared__ uint32_t h[F_WORDS];
+  s_lf[threadIdx.x] = tb->lfact[threadIdx.x];
+  s_logtab[threadIdx.x] = tb->log_tab[threadIdx.x];
+  s_exptab[threadIdx.x] = tb->exp_tab[threadIdx.x];
+  if (a.with_stats)
+    for (unsigned i = threadIdx.x; i < F_WORDS; i += 256) h[i] = 0;
+  __syncthreads();
+  const unsigned long long nhet = counters[BSC_CNT_HET_LIST];
+  const unsigned long long n_round = (nhet + 63ull) & ~63ull;
+  for (unsigned long long idx = (unsigned long long)blockIdx.x * 256u + threadIdx.x; idx < n_round;
+       idx += (unsigned long long)gridDim.x * 256u) {
+    f_facts F;
+    F.called = F.emit = F.pass = F.het = F.rs = F.cpg_site = F.ref_cpg = F.pair = F.pair_pass = F.fs_ok = F.do_meth = false;
+    F.phred = F.flt = F.qd = F.fsv = F.mqv = F.cdp = F.cinf = F.m_a = F.m_b = 0;
+    F.mut = 12;
+    if (idx < nhet) {
+      const unsigned long long e = het_list[idx];
+      const uint32_t i = (uint32_t)e;
+      const unsigned mxi = (unsigned)(e >> 32);
+      const uint32_t *p = cts + (uint64_t)(i + a.lc) * IN_DW;
+      uint32_t f[8], r[8], c[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        f[j] = p[j];
+        r[j] = p[8 + j];
+        c[j] = f[j] + r[j];
+      }
+      int t0, t1, t2, t3;
+      strand_table(mxi, f, r, t0, t1, t2, t3);
+      double z = fisher_dev(t0, t1, t2, t3, s_lf, s_logtab, (const uint64_t *)s_exptab);
+      if (z < 1.0e-20) z = 1.0e-20;
+      const double fisher = bsm_log_t(z, s_logtab) / BSM_LN10; /* gt_meth.fisher_strand (:105-107) */
+      const int fs = (int)(-fisher * 10.0 + 0.5);                /* src/print_vcf.c:151 */
+      uint8_t *rec = core_out + (uint64_t)i * 64u;
+      const uint4 c0 = *reinterpret_cast<const uint4 *>(rec);
+      if (c0.x != 0) { /* the position reached _print_vcf_entry with depth > 0 */
+        const bool emit = (c0.y & 0xffu) != 0;
+        const int gt = (int)((c0.y >> 8) & 0xffu), rfix = (int)((c0.y >> 16) & 0xffu);
+        const uint32_t phred = (c0.z >> 8) & 0xffu;
+        const uint32_t qd = *reinterpret_cast<const uint32_t *>(rec + 28);
+        /* mq as the calling statements form it (call_body.inc; src/call_genotypes.c:59) */
+        const uint32_t n_reads = p[16];
+        const float mapq2 = __uint_as_float(p[25]);
+        const int mq = (int)(0.5 + sqrt((double)(mapq2 / (float)n_reads)));
+        int ga, gb;
+        f_alleles(gt, ga, gb);
+        const bool het = ga != gb; /* the printer's genotype; max_gt differs from it only in a rounding tie */
+        uint32_t flt = 0;
+        *reinterpret_cast<int32_t *>(rec + 24) = fs;
+        if (emit) {
+          if (phred < 20) flt |= 1;
+          if (qd < 2) flt |= 2;
+          if (fs > 60) flt |= 4;
+          if (mq < 40) flt |= 8;
+          if (!flt && het && f_mac1(gt, c)) flt |= 128;
+          rec[8] = (uint8_t)flt;
+        }
+        const uint32_t d_inf = c[4] + c[5] + c[6] + c[7], dpt = c[0] + c[1] + c[2] + c[3] + d_inf;
+        F.called = true;
+        F.emit = emit;
+        F.flt = flt;
+        F.phred = phred;
+        F.qd = qd > 255u ? 255u : qd;
+        F.fs_ok = fs >= 0;
+        F.fsv = (uint32_t)(fs > 255 ? 255 : (fs < 0 ? 0 : fs));
+        F.mqv = (uint32_t)(mq < 0 ? 0 : (mq > 255 ? 255 : mq));
+        F.cdp = dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u;
+        if (emit) {
+          F.pass = flt == 0;
+          F.rs = dbsnp ? dbsnp[i] != 0 : false;
+          F.het = het;
+          F.mut = ss_mut_type(gt, rfix);
+        }
+      }
+    }
+    if (a.with_stats) f_stats_update(h, F, stat_words);
+  }
+  __syncthreads();
+  if (a.with_stats)
+    for (unsigned i = threadIdx.x; i < F_WORDS; i += 256)
+      if (h[i]) atomicAdd(&stat_words[i], (unsigned long long)h[i]);
+}
+
+/* CpG cytosines beyond the pair table: one wave per listed cytosine, two bins per lane (src/print_vcf.c:492-515) */
+extern "C" __global__ __launch_bounds__(256) void bsc_meth_ovf_kernel(const unsigned long long *__restrict__ ovf_list,
+                                                                      unsigned long long *__restrict__ counters,
+                                                                      uint32_t ovf_cap, const bsc_dev_tables *__restrict__ tb,
+                                                                      const double *__restrict__ logp,
+                                                                      double *__restrict__ out_meth) {
+  __shared__ double s_meth[4 * 101];
+  __shared__ double s_lf[256], s_logtab[256], s_logp[100];
+  __shared__ unsigned long long s_exptab[256];
+  const unsigned lane = threadIdx.x & 63u;
+  for (unsigned i = threadIdx.x; i < 404; i += 256) s_meth[i] = 0.0;
+  s_lf[threadIdx.x] = tb->lfact[threadIdx.x];
+  s_logtab[threadIdx.x] = tb->log_tab[threadIdx.x];
+  s_exptab[threadIdx.x] = tb->exp_tab[threadIdx.x];
+  if (threadIdx.x < 100) s_logp[threadIdx.x] = logp[threadIdx.x];
+  __syncthreads();
+  unsigned long long n = counters[BSC_CNT_OVF];
+  if (n > ovf_cap) n = ovf_cap;
+  double acc[2][2][2];
+#pragma unroll
+  for (int x = 0; x < 2; x++)
+    for (int y = 0; y < 2; y++) acc[x][y][0] = acc[x][y][1] = 0.0;
+  for (unsigned long long k = (unsigned long long)blockIdx.x * 4u + (threadIdx.x >> 6); k < n; k += (unsigned long long)gridDim.x * 4u) {
+    const unsigned long long e = ovf_list[k];
+    const uint32_t ca = (uint32_t)(e & 0xffffffu), cb = (uint32_t)((e >> 24) & 0xffffffu);
+    const bool is_ref = (e >> 48) & 1u, is_pass = (e >> 49) & 1u;
+    double z2[2];
+    ss_posterior(ca, cb, lane, s_lf, s_logtab, s_logp, s_exptab, z2);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      acc[is_ref ? 0 : 1][0][r] += z2[r];
+      if (is_pass) acc[is_ref ? 0 : 1][1][r] += z2[r];
+    }
+  }
+#pragma unroll
+  for (int rf = 0; rf < 2; rf++)
+    for (int ps = 0; ps < 2; ps++)
+      for (int r = 0; r < 2; r++) {
+        const unsigned bin = lane + 64u * r;
+        if (bin < 101 && acc[rf][ps][r] != 0.0) atomicAdd(&s_meth[(rf * 2 + ps) * 101 + bin], acc[rf][ps][r]);
+      }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < 404; i += 256)
+    if (s_meth[i] != 0.0) atomicAdd(&out_meth[i], s_meth[i]);
+}
+
+/* ---- launcher ------------------------------------------------------------------------------------------------ */
+/* counters[BSC_CNT_HET_LIST] and counters[BSC_CNT_OVF] must be zero on entry (the host queues the memsets) */
+extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
+  if (L->n == 0) return 0;
+  hipStream_t s = (hipStream_t)L->stream;
+  bsc_chain_args a;
+  a.x = L->x;
+  a.n_block = L->n_block;
+  a.first = L->first;
+  a.n = L->n;
+  a.lc = L->lc;
+  a.rc = L->rc;
+  a.lr = L->lr;
+  a.all_positions = L->all_positions;
+  a.reg_start = L->reg_start;
+  a.reg_stop = L->reg_stop;
+  a.with_stats = L->with_stats;
+  a.ovf_cap = L->ovf_cap;
+  const uint32_t n_tiles = (L->n + FT - 1) / FT;
+  /* complete tiles: all 64 computed sites in the buffers, and the first one on a 16-byte boundary for the LDS-DMA
+   * ((60 T - 2 + lc) * 104 bytes: lc even) */
+  uint32_t t_lo = L->lc == 2 ? 0u : 1u;
+  uint32_t t_hi = (L->n + L->rc >= 62u) ? (L->n + L->rc - 62u) / FT + 1u : 0u;
+  if (t_hi > n_tiles) t_hi = n_tiles;
+  if ((L->lc & 1u) || ((uintptr_t)L->cts & 15u) || t_hi <= t_lo) t_lo = t_hi = 0; /* everything through the guarded kernel */
+  unsigned long long *words = (unsigned long long *)L->stats;
+  if (L->ev_start) (void)hipEventRecord((hipEvent_t)L->ev_start, s);
+#define CHAIN_ARGS(A)                                                                                               \
+  (const uint32_t *)L->cts, (const uint8_t *)L->ref, (const uint8_t *)L->dbsnp, A, (const bsc_dev_tables *)L->tb,   \
+      (uint8_t *)L->core_out, (unsigned long long *)L->het_list, (unsigned long long *)L->counters,                 \
+      (const uint32_t *)L->carry_in, (uint32_t *)L->carry_out, words, (unsigned long long *)L->pairs,               \
+      (unsigned long long *)L->ovf_list
+  if (t_hi > t_lo) {
+    a.tile_begin = t_lo;
+    a.tile_end = t_hi;
+    unsigned grid = (t_hi - t_lo + FW - 1) / FW;
+    if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus; /* one 1024-thread workgroup per CU, persistent */
+    hipLaunchKernelGGL(bsc_chain_kernel_t<true>, dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  const uint32_t edge[2][2] = {{0u, t_lo}, {t_hi > t_lo ? t_hi : 0u, n_tiles}};
+  for (int k = 0; k < 2; k++) {
+    if (edge[k][1] <= edge[k][0]) continue;
+    a.tile_begin = edge[k][0];
+    a.tile_end = edge[k][1];
+    unsigned grid = (a.tile_end - a.tile_begin + FW - 1) / FW;
+    if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
+    hipLaunchKernelGGL(bsc_chain_kernel_t<false>, dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+#undef CHAIN_ARGS
+  a.tile_begin = 0;
+  a.tile_end = n_tiles;
+  hipLaunchKernelGGL(bsc_chain_het_kernel, dim3((unsigned)L->num_cus), dim3(256), 0, s, (const uint32_t *)L->cts,
+                     (const uint8_t *)L->dbsnp, a, (const bsc_dev_tables *)L->tb, (uint8_t *)L->core_out,
+                     (const unsigned long long *)L->het_list, (unsigned long long *)L->counters, words);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (L->with_stats) {
+    double *meth = (double *)((char *)L->stats + offsetof(bsc_site_stats, CpG_ref_meth));
+    hipLaunchKernelGGL(bsc_meth_ovf_kernel, dim3(64), dim3(256), 0, s, (const unsigned long long *)L->ovf_list,
+                       (unsigned long long *)L->counters, L->ovf_cap, (const bsc_dev_tables *)L->tb, (const double *)L->logp,
+                       meth);
+    e = hipGetLastError();
+  }
+  if (L->ev_stop) (void)hipEventRecord((hipEvent_t)L->ev_stop, s);
+  return (int)e;
+}

@@ -299,6 +299,36 @@ int bsc_vcf_stats(bsc_context *ctx, const bsc_vcf_core *core, const void *gtm, u
 int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out);
 int bsc_reset_site_stats(bsc_context *ctx);
 
+/*
+ * The fused chain — pile-up -> call -> VCF record -> site statistics in ONE pass, the 200-byte gt_meth records never
+ * reaching HBM: what the print thread consumes from a block (src/process.c:87-104 feeding src/print_vcf.c:32-594),
+ * computed from what the process thread produces (src/call_genotypes.c:178-226).  Same bytes as
+ * bsc_call_sites_device -> bsc_vcf_records_device (-> bsc_vcf_stats_device) over the whole block.
+ *
+ * A call handles one WINDOW of a block (the reference's unit: x .. y of one call_genotypes_ML, whose printer state is
+ * flushed at its end), so that a long block — a whole contig — can be walked in fixed windows with HBM-resident
+ * inputs; the windows of a block, passed in order, give exactly the block's records and statistics.  The printer's
+ * record of a position looks at the called genotypes of 2 positions and the reference bases of up to 4 / 2 positions
+ * either side, so the window's buffers carry that much context where the block has it:
+ *   d_cts    pile-ups of block positions first - lc .. first + n + rc - 1, lc = min(2, first),
+ *            rc = min(2, n_block - first - n)                                   [(lc + n + rc) x 104 bytes]
+ *   d_ref    reference codes of block positions first - lr .. first + n + 1, lr = min(4, first)  (a block's
+ *            reference has n_block + 2 codes: x .. y + 2, src/process_template.c:29-30)
+ *   d_dbsnp  rs_found (0/1/3) of block positions first .. first + n - 1, or NULL
+ *   d_core   n bsc_vcf_core records (16-byte aligned)
+ * Asynchronous on `stream`; counters (bsc_get_stats) and, with_stats != 0, the site statistics accumulate in the context.
+ */
+typedef struct {
+  uint32_t x;       /* genome position (1-based) of the block's first position */
+  uint32_t n_block; /* positions in the block (y - x + 1) */
+  uint32_t first;   /* block-relative index of the window's first position */
+  uint32_t n;       /* positions in the window */
+} bsc_window;
+int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, const void *d_dbsnp, const bsc_window *w,
+                     const bsc_vcf_params *params, int with_stats, void *d_core, void *stream);
+/* with bsc_set_profiling: device time of the most recent bsc_chain_device call (all of its launches) */
+int bsc_last_chain_ms(bsc_context *ctx, float *ms);
+
 /* Host-side text rendering of one record as a VCF data line ("CHROM POS ID REF ALT QUAL FILTER INFO FORMAT SAMPLE",
  * tab separated, no newline): the field layout of the record the reference hands to htslib (src/print_vcf.c:160-380).
  * Returns the length written, 0 when c->emit == 0, -1 when buf is too small.  `id` NULL/"" prints ".". */

@@ -1,0 +1,176 @@
+"""The fused chain (bsc_chain_device: pile-up -> call -> VCF record -> statistics in one pass, csrc/fused.hip) against the
+unfused chain (bsc_call_sites_device -> bsc_vcf_records_device -> bsc_vcf_stats_device) and against the CPU oracle
+(orc_call_sites + orc_vcf_block_stats = the reference's calc threads followed by its print thread): every byte of every
+bsc_vcf_core record, every counter, every integer of the statistics; the methylation profiles to 1e-12 (sum order)."""
+import numpy as np
+import pytest
+import torch
+
+import bs_call_amd as B
+from bs_call_amd.abi import SITE_STATS, SITE_STATS_INT_WORDS, VCF_CORE
+
+pytestmark = pytest.mark.gpu
+SEED = 88172645463325252
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def caller():
+    c = B.SiteCaller()
+    yield c
+    c.close()
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(DEV)
+
+
+def _unfused(c, pile, ref2, x, dbsnp=None, all_positions=False, reg=(1, 0xFFFFFFFF)):
+    """Whole block through the three unfused kernels: (VCF_CORE[n], SITE_STATS, stats dict)."""
+    n = len(pile)
+    d_cts, d_ref = _dev(pile), _dev(ref2)
+    d_out = torch.empty(n * 200, dtype=torch.uint8, device=DEV)
+    d_skip = torch.empty(n, dtype=torch.uint8, device=DEV)
+    d_core = torch.empty(n * 64, dtype=torch.uint8, device=DEV)
+    d_db = None if dbsnp is None else _dev(dbsnp)
+    c.reset_stats()
+    c.reset_site_stats()
+    c.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 200, None)
+    c.vcf_records_device(d_out.data_ptr(), 200, d_skip.data_ptr(), d_ref.data_ptr(), n, x, d_core.data_ptr(), all_positions,
+                         reg[0], reg[1], None if d_db is None else d_db.data_ptr())
+    c.vcf_stats_device(d_core.data_ptr(), d_out.data_ptr(), 200, n, None if d_db is None else d_db.data_ptr())
+    torch.cuda.synchronize()
+    return d_core.cpu().numpy().view(VCF_CORE).copy(), c.site_stats().copy(), c.stats()
+
+
+def _fused(c, pile, ref2, x, windows, dbsnp=None, all_positions=False, reg=(1, 0xFFFFFFFF), with_stats=True):
+    """The block as a sequence of windows [(first, n), ...] through bsc_chain_device, each window from its OWN buffers
+    (only the context the ABI asks for is copied)."""
+    nb = len(pile)
+    core = np.zeros(nb, dtype=VCF_CORE)
+    c.reset_stats()
+    c.reset_site_stats()
+    for first, n in windows:
+        lc, rc, lr = min(2, first), min(2, nb - first - n), min(4, first)
+        d_cts = _dev(pile[first - lc : first + n + rc])
+        d_ref = _dev(ref2[first - lr : first + n + 2])
+        d_db = None if dbsnp is None else _dev(dbsnp[first : first + n])
+        d_core = torch.full((n * 64,), 0xA5, dtype=torch.uint8, device=DEV)
+        c.chain_device(d_cts.data_ptr(), d_ref.data_ptr(), x, nb, first, n, d_core.data_ptr(), all_positions, reg[0], reg[1],
+                       None if d_db is None else d_db.data_ptr(), with_stats, None)
+        torch.cuda.synchronize()
+        core[first : first + n] = d_core.cpu().numpy().view(VCF_CORE)
+    return core, c.site_stats().copy(), c.stats()
+
+
+def _same_stats(a, b):
+    ia = np.frombuffer(a.tobytes(), dtype=np.uint64)[:SITE_STATS_INT_WORDS]
+    ib = np.frombuffer(b.tobytes(), dtype=np.uint64)[:SITE_STATS_INT_WORDS]
+    if not (ia == ib).all():
+        for f in SITE_STATS.names:
+            if a[f].dtype.kind == "u":
+                assert (a[f] == b[f]).all(), "statistics field %s differs: %s" % (f, np.argwhere(a[f] != b[f])[:5].tolist())
+    for f in ("CpG_ref_meth", "CpG_nonref_meth"):
+        np.testing.assert_allclose(a[f], b[f], rtol=1e-12, atol=1e-12)
+
+
+def _same_core(a, b, what):
+    if a.tobytes() != b.tobytes():
+        for f in VCF_CORE.names:
+            x, y = a[f], b[f]
+            same = x.tobytes() == y.tobytes()
+            if not same:
+                idx = [i for i in range(len(a)) if a[i : i + 1][f].tobytes() != b[i : i + 1][f].tobytes()][:5]
+                raise AssertionError("%s: field %s differs at %s: %s vs %s" % (what, f, idx, a[f][idx], b[f][idx]))
+        raise AssertionError(what + ": padding differs")
+
+
+def _block(seed, n, cov, flags=0, x0=4000):
+    pile, ref = B.synth_pileup_host(seed, x0, n + 2, cov, flags)
+    return pile[:n], ref  # ref has n + 2 codes (x .. y + 2)
+
+
+@pytest.mark.parametrize("n,cov", [(50_000, 30), (61, 30), (62, 30), (121, 10), (1, 30), (2, 30), (3, 30), (59, 200), (60, 30)])
+def test_fused_equals_unfused_whole_block(caller, n, cov):
+    pile, ref2 = _block(SEED + n, n, cov)
+    exp, est, ecnt = _unfused(caller, pile, ref2, 4000)
+    got, gst, gcnt = _fused(caller, pile, ref2, 4000, [(0, n)])
+    _same_core(got, exp, "whole block n=%d" % n)
+    _same_stats(gst, est)
+    assert gcnt == ecnt
+
+
+def test_fused_windows_equal_whole_block(caller):
+    """Windows of every alignment (odd starts take the guarded kernel), a 1-position window, windows that end 0, 1, 2
+    positions before the block end: same records and statistics as the block in one piece."""
+    n = 40_000
+    pile, ref2 = _block(SEED + 5, n, 30, flags=1)
+    # make the block end interesting for the flush quirk, and put an N near a window boundary
+    ref2 = ref2.copy()
+    ref2[9_998] = 0
+    exp, est, ecnt = _unfused(caller, pile, ref2, 777)
+    cuts = [0, 1, 2, 3, 64, 4_097, 9_999, 10_000, 10_001, 10_062, 25_000, n - 2, n - 1, n]
+    windows = [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+    got, gst, gcnt = _fused(caller, pile, ref2, 777, windows)
+    _same_core(got, exp, "windowed")
+    _same_stats(gst, est)
+    assert gcnt == ecnt
+
+
+def test_fused_vs_oracle_with_dbsnp_and_region(caller, oracle, tables, libm_exact):
+    """Against the CPU oracle (calc threads + print thread restated), with dbSNP flags (forced hom-ref emission, dbSNP
+    statistics), a region clip and -A."""
+    n = 30_000
+    pile, ref2 = _block(SEED + 9, n, 30)
+    rng = np.random.default_rng(3)
+    db = np.zeros(n, dtype=np.uint8)
+    idx = rng.choice(n, n // 300, replace=False)
+    db[idx] = np.where(rng.random(len(idx)) < 0.1, 3, 1)
+    flav = oracle.LIBM if libm_exact else oracle.BSM
+    gtm, skip = oracle.call_sites(pile, ref2[:n], tables, flav, -8)
+    for allp, reg in ((False, (1, 0xFFFFFFFF)), (True, (1, 0xFFFFFFFF)), (False, (5_000, 20_000))):
+        stats = np.zeros(1, dtype=SITE_STATS)
+        carry = np.zeros(2, dtype=np.uint32)
+        exp = oracle.vcf_block_stats(gtm, skip, ref2, 1000, stats, carry, tables.lfact_store, allp, reg[0], reg[1], db)
+        got, gst, _ = _fused(caller, pile, ref2, 1000, [(0, 12_345), (12_345, n - 12_345)], db, allp, reg)
+        _same_core(got, exp, "oracle all_positions=%s reg=%s" % (allp, reg))
+        _same_stats(gst, stats[0])
+
+
+def test_fused_deep_coverage_overflow_list(caller):
+    """300x: the exp / lgamma fall-backs, and CpG cytosines beyond the 64 x 64 pair table (listed and evaluated)."""
+    n = 20_000
+    pile, ref2 = _block(SEED + 11, n, 300)
+    exp, est, ecnt = _unfused(caller, pile, ref2, 50)
+    got, gst, gcnt = _fused(caller, pile, ref2, 50, [(0, 7_000), (7_000, 13_000)])
+    _same_core(got, exp, "300x")
+    _same_stats(gst, est)
+    assert gcnt == ecnt
+
+
+def test_fused_consecutive_blocks_carry(caller):
+    """Two blocks one after the other (the printer's pending cytosine survives from block to block)."""
+    n = 5_000
+    pile, ref2 = _block(SEED + 13, 2 * n, 30)
+    # unfused: block A then block B
+    caller.reset_site_stats()
+    cores = []
+    for k in range(2):
+        d_cts, d_ref = _dev(pile[k * n : (k + 1) * n]), _dev(ref2[k * n : (k + 1) * n + 2])
+        d_out = torch.empty(n * 200, dtype=torch.uint8, device=DEV)
+        d_skip = torch.empty(n, dtype=torch.uint8, device=DEV)
+        d_core = torch.empty(n * 64, dtype=torch.uint8, device=DEV)
+        caller.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 200, None)
+        caller.vcf_records_device(d_out.data_ptr(), 200, d_skip.data_ptr(), d_ref.data_ptr(), n, 100 + k * n, d_core.data_ptr())
+        caller.vcf_stats_device(d_core.data_ptr(), d_out.data_ptr(), 200, n)
+        torch.cuda.synchronize()
+        cores.append(d_core.cpu().numpy().view(VCF_CORE).copy())
+    est = caller.site_stats().copy()
+    caller.reset_site_stats()
+    for k in range(2):
+        d_cts, d_ref = _dev(pile[k * n : (k + 1) * n]), _dev(ref2[k * n : (k + 1) * n + 2])
+        d_core = torch.empty(n * 64, dtype=torch.uint8, device=DEV)
+        caller.chain_device(d_cts.data_ptr(), d_ref.data_ptr(), 100 + k * n, n, 0, n, d_core.data_ptr(), with_stats=True)
+        torch.cuda.synchronize()
+        _same_core(d_core.cpu().numpy().view(VCF_CORE), cores[k], "block %d" % k)
+    _same_stats(caller.site_stats().copy(), est)
