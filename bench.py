@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py — genome positions called per second by the gfx950 calling path (pile-up -> gt_meth).
+"""bench.py — genome positions called per second by the gfx950 calling path.
 
 Contract (see the task prompt):  python bench.py --gpus N --steps K --warmup W   prints ONE JSON line on rank 0.
-  * a "step" = one pass of the hot path over this rank's synthetic contig (config 2 of BASELINE.json:
-    chr22-sized, 50 Mb at 30x), pile-ups and reference codes already resident in HBM (generated on the
-    device by bsc_synth_pileup_device); the timed region covers the calling kernel, the Fisher pass and,
-    once at the end, the RCCL all-reduce of the per-rank counters.
-  * N > 1: one process per GPU (torch.distributed / RCCL); contigs shard across ranks with no data-path
-    collective (weak scaling: every rank calls its own 50 Mb contig), value = all sites / max-over-ranks time.
-  * roofline: achieved = 305 algorithmic bytes/site (104 B pileup + 1 B ref + 200 B gt_meth)
-    x sites per launch / average device time of the calling kernel, measured with HIP events recorded on
-    the launch stream inside libbscall_amd (bsc_set_profiling / bsc_last_kernel_ms).
-  * cpu_baseline: the CPU oracle (libm flavour = restatement of the reference; "port") timed on this host's
-    cores over the first --cpu-sites positions of the same synthetic contig (rank 0, N = 1 only).
+
+Default workload = BASELINE.json configs[1] (synthetic chr22-sized contig, 50 Mb at 30x WGBS):
+  * a "step" = one pass of the hot path (pile-up -> gt_meth: bsc_call_kernel + the Fisher pass) over this rank's contig,
+    pile-ups and reference codes already resident in HBM (bsc_synth_pileup_device); once at the end the RCCL all-reduce
+    of the per-rank counters.  N > 1: one process per GPU, every rank its own contig, no data-path collective (weak
+    scaling); value = all positions / max-over-ranks time.
+  * roofline: achieved = 305 algorithmic bytes per covered position (104 B pile-up + 1 B reference code + 200 B gt_meth,
+    SURVEY.md 8d; 105 B per uncovered one) x positions per launch / average device time of bsc_call_kernel, HIP events
+    recorded on the launch stream inside libbscall_amd (bsc_set_profiling / bsc_last_kernel_ms).
+  * roofline_chain: the same for the fused print-side chain (bsc_chain_device: pile-up -> call -> VCF record -> site
+    statistics, csrc/fused.hip), 105 B in + 64 B out per position — measured after the timed region.
+  * cpu_baseline (rank 0, N = 1): the CPU oracle's libm flavour (= the reference's arithmetic; "port") on this host's
+    cores over a bounded sample of the same contig: SURVEY.md 8d's three timings, medians of repetitions of >= 1 s.
+
+--config 3 = BASELINE.json configs[2]: a human-scale genome (24 contigs, 3.1 G positions, 30x, 1 % N-runs), contigs
+  assigned to ranks by longest-processing-time (the reference is run one process per contig: README.md:73-76), each
+  contig HBM-resident and walked in 4 Mi-position windows through the fused chain with statistics; at the end the ranks
+  all-reduce the counter block and the statistics block (RCCL).  A step = one pass over the rank's contigs; value =
+  all positions / max-over-ranks time (strong scaling).  --rank-of R [--rank-index I] runs the share rank I of R would
+  own on THIS process alone (what one GPU of an R-GPU run does).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,8 +37,10 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_COVERED = 305
 ALGO_BYTES_UNCOVERED = 105
+CHAIN_BYTES = 105 + 64  # fused chain: pile-up + reference code in, bsc_vcf_core out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 88172645463325252
+KERNEL_SOURCES = ("kernels.hip", "callmath.h", "call_body.inc", "bsmath.h", "bsmath_tables.h", "devtables.h")
 
 
 def main():
@@ -35,16 +48,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="2: configs[1], 50 Mb contig (default); 3: configs[2], human-scale genome")
     ap.add_argument("--sites", type=int, default=50_000_000, help="positions per rank (config 2: 50 Mb)")
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--cpu-sites", type=int, default=32_000_000, help="sample size of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-chain", action="store_true", help="skip the fused-chain measurement (roofline_chain)")
+    ap.add_argument("--rank-of", type=int, default=0, help="config 3: run the share of one rank of this many, on this process alone")
+    ap.add_argument("--rank-index", type=int, default=0)
+    ap.add_argument("--window", type=int, default=0, help="config 3: positions per window (0 = genome.WINDOW: 4 Mi rounded down to whole 60-position wave-tiles)")
+    ap.add_argument("--mem-gb", type=float, default=0.0, help="config 3: HBM budget for resident contigs (0 = 80 %% of free)")
+    ap.add_argument("--genome-scale", type=float, default=1.0, help="config 3: scale every contig length (rehearsals)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
-
-    import bs_call_amd as B
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -67,18 +84,50 @@ def main():
     else:
         torch.cuda.set_device(0)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    env = {"world": world, "rank": rank, "dist": dist, "dev": torch.device("cuda", torch.cuda.current_device())}
+    res = run_config3(args, env) if args.config == 3 else run_config2(args, env)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
+
+def barrier(env):
+    import torch
+
+    if env["dist"] is not None:
+        env["dist"].barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(env, dt):
+    import torch
+
+    if env["dist"] is None:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=env["dev"])
+    env["dist"].all_reduce(t, op=env["dist"].ReduceOp.MAX)
+    return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_config2(args, env):
+    import numpy as np
+    import torch
+
+    import bs_call_amd as B
+
+    world, rank, dist, dev = env["world"], env["rank"], env["dist"], env["dev"]
     n = args.sites
     caller = B.SiteCaller(device=dev.index)
-    d_cts = torch.empty(n * 104, dtype=torch.uint8, device=dev)
-    d_ref = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_cts = torch.empty((n + 2) * 104, dtype=torch.uint8, device=dev)  # two records behind the contig: chain context
+    d_ref = torch.empty(n + 2, dtype=torch.uint8, device=dev)
     d_out = torch.empty(n * 200, dtype=torch.uint8, device=dev)
     d_skip = torch.empty(n, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     # rank r calls contig r of the synthetic genome: same generator, disjoint site range
-    first_site = rank * n
-    caller.synth_device(SEED + 2, first_site, n, args.coverage, d_cts.data_ptr(), d_ref.data_ptr(), 0, stream)
+    first_site = rank * (n + 64)
+    caller.synth_device(SEED + 2, first_site, n + 2, args.coverage, d_cts.data_ptr(), d_ref.data_ptr(), 0, stream)
     torch.cuda.synchronize()
 
     def step():
@@ -90,14 +139,8 @@ def main():
     torch.cuda.synchronize()
     caller.reset_stats()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    kernel_ms = []
-    fisher_ms = []
-    barrier()
+    kernel_ms, fisher_ms = [], []
+    barrier(env)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -109,12 +152,8 @@ def main():
     stats = torch.from_numpy(caller.stats_vector()).to(dev)  # syncs the stream
     if dist is not None:
         dist.all_reduce(stats)  # the only collective: per-rank counters (RCCL)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    barrier(env)
+    dt = max_over_ranks(env, time.perf_counter() - t0)
     if world > 1:
         a, b = caller.last_kernel_ms()
         kernel_ms, fisher_ms = [a], [b]
@@ -124,7 +163,7 @@ def main():
     covered = int(stats[1])
     assert total_sites == n * world * args.steps, (total_sites, n, world, args.steps)
     value = total_sites / dt
-
+    res = None
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         cov_frac = covered / total_sites
@@ -163,44 +202,111 @@ def main():
                 "traffic": profiled_traffic(n, args.coverage),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms_avg": k_ms,
+                "kernel_ms_min": float(np.min(kernel_ms)),
                 "fisher_kernel_ms_avg": float(np.mean(fisher_ms)),
                 "positions_per_s_kernel_only": n / (k_ms * 1e-3),
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args, d_cts, d_ref, d_out, d_skip)
+    if world == 1 and not args.no_chain:
+        res["roofline_chain"] = chain_roofline(args, caller, d_cts, d_ref, n, first_site)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res.update(cpu_baseline(args, d_cts, d_ref, d_out, d_skip))
+    if rank == 0:
         # Last (it overwrites d_out): the same bytes moved by a kernel that does nothing else — what the memory system
         # delivers for this 1 : 2 read : write mix (HBM3E writes stream slower than reads), measured live on this GPU.
         probe_ms = caller.stream_probe_ms(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 5, stream)
         if probe_ms > 0.0:
-            res["roofline"]["stream_probe"] = {
+            r = res["roofline"]
+            r["stream_probe"] = {
                 "what": "copy kernel with the calling kernel's traffic and tile shape, no arithmetic (csrc/probe.hip), best of 5",
                 "ms": probe_ms,
-                "GBps": algo_bytes / (probe_ms * 1e-3) / 1e9,
-                "kernel_frac_of_probe": probe_ms / k_ms,
+                "GBps": r["algorithmic_bytes_per_launch"] / (probe_ms * 1e-3) / 1e9,
+                "kernel_frac_of_probe": probe_ms / r["kernel_ms_avg"],
             }
-        print(json.dumps(res), flush=True)
     caller.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return res
+
+
+def chain_roofline(args, caller, d_cts, d_ref, n, first_site):
+    """The fused print-side chain over the same resident contig (one block, one call), with statistics: device time from
+    HIP events on the launch stream (bsc_last_chain_ms), 105 + 64 algorithmic bytes per position."""
+    import numpy as np
+    import torch
+
+    dev = d_cts.device
+    d_core = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ms, wall = [], []
+    for it in range(2 + min(args.steps, 10)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        caller.chain_device(d_cts.data_ptr(), d_ref.data_ptr(), 1, n, 0, n, d_core.data_ptr(), with_stats=True, stream=stream)
+        torch.cuda.synchronize()
+        if it >= 2:
+            wall.append(time.perf_counter() - t0)
+            ms.append(caller.last_chain_ms())
+    k_ms = float(np.mean(ms))
+    achieved = n * CHAIN_BYTES / (k_ms * 1e-3) / 1e9
+    records = int(d_core.view(n, 64)[:, 4].sum())
+    return {
+        "bound": "hbm",
+        "kernel": "bsc_chain_kernel_t + bsc_chain_het_kernel (bsc_chain_device)",
+        "what": "pile-up -> call -> VCF record -> site statistics in one pass; gt_meth never reaches HBM (the unfused chain "
+        "moves 630 B per position)",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": None,
+        "algorithmic_bytes_per_launch": n * CHAIN_BYTES,
+        "kernel_ms_avg": k_ms,
+        "positions_per_s": n / float(np.median(wall)),
+        "records_written_fraction": records / n,
+        "note": "instruction-issue bound (FP64 model + record formation), not HBM: the roofline fraction is low by construction",
+    }
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "bs_call_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def profiled_traffic(n, coverage):
-    """HBM bytes per bsc_call_kernel launch from the committed PMC passes (profiles/traffic.json, written from
-    `tools/profile_bench.sh`: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
-    doubled per the gfx950 rule).  Counters cannot be read inside this process; None if the workload differs."""
+    """HBM bytes per bsc_call_kernel launch from the committed PMC passes (profiles/traffic.json, written by
+    tools/make_traffic_json.py from `tools/profile_bench.sh`: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command, FETCH_SIZE doubled per the gfx950 rule).  Counters cannot be read inside this process; None when
+    the workload differs or the kernel sources have changed since the passes were taken."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if t.get("positions") == n and t.get("coverage") == coverage:
+        if t.get("positions") == n and t.get("coverage") == coverage and t.get("kernel_source_sha256_16") == kernel_source_hash():
             return t["hbm_bytes_per_launch"]
     except Exception:
         pass
     return None
 
 
+def _median_rate(fn, units, min_s=1.0, reps=5):
+    """Median units/s over `reps` repetitions, each repetition looping fn() until >= min_s seconds have passed."""
+    rates = []
+    for _ in range(reps):
+        k, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            k += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_s:
+                break
+        rates.append(units * k / dt)
+    return sorted(rates)[len(rates) // 2]
+
+
 def cpu_baseline(args, d_cts, d_ref, d_out, d_skip):
-    """Time the CPU oracle (libm flavour) on a bounded sample of the same workload and, while at it,
-    check the GPU output of that sample against the oracle (bsm flavour, bit-exact)."""
+    """The CPU oracle (libm flavour = the reference's arithmetic) on a bounded sample of the same workload — SURVEY.md
+    8d's three timings, single thread and all hardware threads, medians of 5 repetitions of >= 1 s — and, while at it, the
+    GPU output of the sample checked against the oracle byte for byte (LIBM flavour when this host's libm is exact)."""
     import numpy as np
 
     import bs_call_amd as B
@@ -211,33 +317,185 @@ def cpu_baseline(args, d_cts, d_ref, d_out, d_skip):
     ref = d_ref[:m].cpu().numpy()
     tb = O.Tables()
     cores = os.cpu_count() or 1
-    O.call_sites(pile[:100_000], ref[:100_000], tb, O.LIBM, -cores)  # warm-up (page in the library)
+    L = O.lib()
     out = np.zeros(m, dtype=B.GT_METH)
     skip = np.zeros(m, dtype=np.uint8)
-    out[:] = out  # touch the pages so the timing below is compute, not first-touch faults
-    L = O.lib()
-    t0 = time.perf_counter()
-    L.orc_call_sites(pile.ctypes.data, ref.ctypes.data, m, tb.ptr, out.ctypes.data, skip.ctypes.data, O.LIBM, -cores)
-    t_all = time.perf_counter() - t0
+    out[:] = out  # touch the pages so the timings below are compute, not first-touch faults
+    call = lambda k, thr: L.orc_call_sites(pile.ctypes.data, ref.ctypes.data, k, tb.ptr, out.ctypes.data, skip.ctypes.data, O.LIBM, thr)
+    call(m, -cores)  # warm-up: pages in the library, fills out/skip for (i)
+    # (ii) the full per-site path (summary + calc_gt_prob + Fisher + 200-byte record): T threads on contiguous ranges, 1 thread
     m1 = min(m, 4_000_000)
-    t0 = time.perf_counter()
-    L.orc_call_sites(pile.ctypes.data, ref.ctypes.data, m1, tb.ptr, out.ctypes.data, skip.ctypes.data, O.LIBM, 1)
-    t_one = time.perf_counter() - t0
-    # parity of the benchmarked output on a slice of the sample (GPU vs bsm flavour: every byte)
+    full_T = _median_rate(lambda: call(m, -cores), m)
+    full_1 = _median_rate(lambda: call(m1, 1), m1)
+    t_ref = max(1, int(0.4 * (cores - 1)))  # the reference's default split of nproc - 1 extra threads, 4 : 3 : 3 (src/parse_args.c:191-213)
+    mi = min(m, 8_000_000)
+    full_interleaved = _median_rate(lambda: call(mi, t_ref), mi, reps=3)
+    # (i) calc_gt_prob only, on the prepared records of the covered positions
+    cov = skip[:m1] == 0
+    gt, rf = out[:m1][cov].copy(), ref[:m1][cov].copy()
+    model_1 = _median_rate(lambda: L.orc_calc_gt_prob_array(gt.ctypes.data, rf.ctypes.data, len(gt), tb.ptr, O.LIBM), len(gt))
+    covT = skip == 0
+    gtT, rfT = out[covT].copy(), ref[covT].copy()
+    model_T = _median_rate(lambda: L.orc_calc_gt_prob_array_mt(gtT.ctypes.data, rfT.ctypes.data, len(gtT), tb.ptr, O.LIBM, cores), len(gtT))
+    # (iii) HOT LOOP A (reads -> pile-up), which the reference runs serially on its process thread
+    blk = 400_000
+    tpl, seq = B.synth_reads_host(SEED + 2, 1000, blk, args.coverage)
+    x, y = 998, int((tpl["pos"] + tpl["len"]).max()) - 1
+    sz = y - x + 1
+    thr_acc = min(cores, 64)
+    pl = np.zeros(sz * thr_acc, dtype=B.PILEUP)
+    acc = lambda thr: L.orc_accumulate_mt(tpl.ctypes.data, len(tpl), seq.ctypes.data, x, y, 20, pl.ctypes.data, thr, 2)
+    acc_1 = _median_rate(lambda: acc(1), 2 * sz)
+    acc_T = _median_rate(lambda: acc(thr_acc), 2 * sz * thr_acc)
+    # the reference's own shape: block k+1 is accumulated on ONE thread while 1 + T calc threads walk block k with
+    # interleaved striding (src/call_genotypes.c:36-43,180-226,260-272); steady state = the slower of the two
+    pile_blk = np.zeros(sz, dtype=B.PILEUP)
+    L.orc_accumulate(tpl.ctypes.data, len(tpl), seq.ctypes.data, x, y, 20, pile_blk.ctypes.data)
+    ref_blk = B.synth_ref_host(SEED + 2, x, sz)
+    out_blk, skip_blk = np.zeros(sz, dtype=B.GT_METH), np.zeros(sz, dtype=np.uint8)
+
+    def ref_shaped():
+        th = threading.Thread(target=lambda: acc(1))
+        th.start()
+        for _ in range(2):
+            L.orc_call_sites(pile_blk.ctypes.data, ref_blk.ctypes.data, sz, tb.ptr, out_blk.ctypes.data, skip_blk.ctypes.data, O.LIBM, t_ref)
+        th.join()
+
+    ref_rate = _median_rate(ref_shaped, 2 * sz, reps=3)
+    # parity of the benchmarked output on a slice of the sample
+    exact = O.libm_exact()
     mc = min(m, 1_000_000)
-    exp, eskip = O.call_sites(pile[:mc], ref[:mc], tb, O.BSM, -cores)
+    exp, eskip = O.call_sites(pile[:mc], ref[:mc], tb, O.LIBM if exact else O.BSM, -cores)
     got = d_out[: mc * 200].cpu().numpy().view(B.GT_METH)
     ok = got.tobytes() == exp.tobytes() and (d_skip[:mc].cpu().numpy() == eskip).all()
     return {
-        "value": m / t_all,
-        "unit": "positions/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": "first %d positions of the benchmarked contig, oracle libm flavour, %d threads on contiguous ranges; "
-        "single thread on %d positions: %.3g positions/s" % (m, cores, m1, m1 / t_one),
-        "single_thread_value": m1 / t_one,
-        "gpu_output_matches_oracle_on_sample": bool(ok),
+        "cpu_baseline": {
+            "value": full_T,
+            "unit": "positions/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "first %d positions of the benchmarked contig, oracle libm flavour (the reference's arithmetic); medians of 5 "
+            "repetitions of >= 1 s; value = timing (ii), the full per-site path, %d threads on contiguous ranges" % (m, cores),
+            "single_thread_value": full_1,
+            "timings_positions_per_s": {
+                "i_calc_gt_prob_only": {"1_thread": model_1, "%d_threads" % cores: model_T},
+                "ii_full_per_site_path": {"1_thread": full_1, "%d_threads_contiguous" % cores: full_T,
+                                          "%d_threads_interleaved_as_the_reference" % t_ref: full_interleaved},
+                "iii_accumulate_30x": {"1_thread": acc_1, "%d_threads_independent_blocks" % thr_acc: acc_T},
+                "reference_shaped": {"value": ref_rate, "what": "serial accumulate of block k+1 beside %d interleaved calc threads on "
+                                     "block k (src/call_genotypes.c:180-226,260-272): the serial stage caps it whatever -t says" % t_ref},
+            },
+            "gpu_output_matches_oracle_on_sample": bool(ok),
+            "oracle_flavour_compared": "LIBM" if exact else "BSM",
+        },
+        "libm_exact": exact,
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_config3(args, env):
+    """BASELINE.json configs[2]: 24 human-length contigs at 30x, contig-sharded, fused chain with statistics."""
+    import numpy as np
+    import torch
+
+    import bs_call_amd as B
+    from bs_call_amd import genome, shard
+
+    world, rank, dist, dev = env["world"], env["rank"], env["dist"], env["dev"]
+    lengths = [max(1000, int(x * args.genome_scale)) for x in shard.HUMAN_CONTIGS]
+    firsts = genome.contig_first_sites(lengths)
+    if args.rank_of:
+        assert world == 1, "--rank-of emulates one rank of a larger run on a single process"
+        v_rank, v_world = args.rank_index, args.rank_of
+    else:
+        v_rank, v_world = rank, world
+    if args.window <= 0:
+        args.window = genome.WINDOW
+    mine = genome.rank_contigs(lengths, v_rank, v_world)
+    my_positions = sum(lengths[c] for c in mine)
+    free, _total = torch.cuda.mem_get_info()
+    budget = int(args.mem_gb * (1 << 30)) if args.mem_gb > 0 else int(free * 0.8)
+    groups = genome.batches(mine, lengths, budget)
+    caller = B.SiteCaller(device=dev.index)
+    caller.set_profiling(True)
+    stream = torch.cuda.current_stream().cuda_stream
+    dt, n_windows, chain_ms = 0.0, 0, []
+    for gi, group in enumerate(groups):
+        resident = [genome.make_resident(caller, c, lengths[c], firsts[c], args.coverage, dev, stream=stream) for c in group]
+        torch.cuda.synchronize()
+        if gi == 0:
+            for _ in range(args.warmup):
+                for rc in resident:
+                    genome.walk_contig(caller, rc, args.window, True, stream=stream)
+            torch.cuda.synchronize()
+            caller.reset_stats()
+            caller.reset_site_stats()
+        barrier(env)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            for rc in resident:
+                n_windows += genome.walk_contig(caller, rc, args.window, True, stream=stream)
+        if gi == len(groups) - 1:
+            # the only exchange of a sharded run: the counter block and the statistics block (every field a sum)
+            stats = shard.allreduce_stats(caller.stats_vector(), dev if dist is not None else None)
+            site = shard.allreduce_site_stats(caller.site_stats(), dev if dist is not None else None)
+        barrier(env)
+        dt += time.perf_counter() - t0
+        chain_ms.append(caller.last_chain_ms())
+        del resident
+        torch.cuda.empty_cache()
+    dt = max_over_ranks(env, dt)
+    total = int(stats[0])
+    expect = (sum(lengths) if not args.rank_of else my_positions) * args.steps
+    assert total == expect, (total, expect)
+    if rank != 0:
+        caller.close()
+        return None
+    value = total / dt
+    res = {
+        "metric": "genome positions called/sec",
+        "value": value,
+        "unit": "positions/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "gbases_per_hour": value * 3.6e-6,
+        "config": {
+            "workload": "configs[2]: synthetic human-scale genome, 24 contigs, %d positions at %dx WGBS with 1 %% N-runs "
+            "(L-pileup generator), contigs assigned to ranks by longest-processing-time, each contig HBM-resident and walked in "
+            "%d-position windows through the fused chain (pile-up -> call -> VCF record -> site statistics)"
+            % (sum(lengths), args.coverage, args.window),
+            "share": "rank %d of %d%s: contigs %s, %d positions in %d resident group(s)"
+            % (v_rank, v_world, " (emulated on one process)" if args.rank_of else "", mine, my_positions, len(groups)),
+            "windows_per_step": n_windows // max(args.steps, 1),
+            "coverage": args.coverage,
+            "sharding": "whole contigs per rank (LPT), no data-path collective; at the end one all-reduce of the 13-word counter "
+            "block and one of the statistics block (27 k words)",
+            "covered_fraction": float(stats[1]) / total,
+            "records_written": int(site["snps"][0]) // max(args.steps, 1),
+            "CpGs": int(site["CpG_ref"][0] + site["CpG_nonref"][0]) // max(args.steps, 1),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "bsc_chain_kernel_t + bsc_chain_het_kernel (bsc_chain_device), all windows of a step",
+            "achieved": total * CHAIN_BYTES / dt / 1e9 / (1 if args.rank_of else world),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": total * CHAIN_BYTES / dt / 1e9 / (1 if args.rank_of else world) / HBM_PEAK_GBPS,
+            "traffic": None,
+            "algorithmic_bytes_per_position": CHAIN_BYTES,
+            "last_window_device_ms": chain_ms[-1],
+            "note": "per-GPU, from the wall time of the step (windows back to back on one stream); instruction-issue bound, not HBM",
+        },
+    }
+    caller.close()
+    return res
 
 
 if __name__ == "__main__":

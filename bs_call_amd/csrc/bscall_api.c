@@ -66,6 +66,7 @@ struct bsc_context {
   size_t cap_cts, cap_ref, cap_out, cap_skip;
   void *d_het;
   size_t cap_het;
+  int het_dirty; /* bsc_call_sites_device left a heterozygous list behind (the fused chain expects an empty one) */
   void *d_ovf; /* fused chain: CpG cytosines beyond the methylation pair table (8 bytes each) */
   size_t cap_ovf;
   hipEvent_t ev_chain[2]; /* bsc_set_profiling: the fused chain's launches */
@@ -355,6 +356,7 @@ int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref
                                 ctx->profiling ? ctx->ev[0] : NULL, ctx->profiling ? ctx->ev[1] : NULL,
                                 ctx->profiling ? ctx->ev[2] : NULL);
     if (ctx->profiling) ctx->ev_valid = 1;
+    ctx->het_dirty = 1;
     if (e) return bsc_fail(BSC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     done += m;
   }
@@ -822,8 +824,12 @@ int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, con
     L.ovf_cap = w->n;
     L.logp = ctx->d_logp;
   }
-  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_HET_LIST, 0, sizeof(unsigned long long), s));
-  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_OVF, 0, sizeof(unsigned long long), s));
+  /* the het-list / overflow-list lengths are zero here: bsc_chain_het_kernel empties them (no memsets per window) —
+   * unless the unfused calling kernel ran on this context in between */
+  if (ctx->het_dirty) {
+    HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_HET_LIST, 0, sizeof(unsigned long long), s));
+    ctx->het_dirty = 0;
+  }
   const uint32_t after = w->n_block - w->first - w->n;
   L.cts = d_cts;
   L.ref = d_ref;
@@ -853,7 +859,12 @@ int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, con
     ctx->ev_chain_valid = 1;
   }
   int e = bsc_dev_launch_chain(&L);
-  if (e) return bsc_fail(BSC_ERR_HIP, "chain launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (e) { /* a partial launch may leave the list lengths set: put them back before anything else uses them */
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipMemset(ctx->d_counters + BSC_CNT_HET_LIST, 0, sizeof(unsigned long long));
+    (void)hipMemset(ctx->d_counters + BSC_CNT_OVF, 0, 2 * sizeof(unsigned long long));
+    return bsc_fail(BSC_ERR_HIP, "chain launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
   if (with_stats) ctx->carry_slot ^= 1u;
   ctx->sites += w->n;
   return BSC_OK;

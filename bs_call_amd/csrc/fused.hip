@@ -17,8 +17,8 @@
  *                          this kernel evaluates the test, patches FS / FILTER into the records the main kernel wrote
  *                          and adds those positions' statistics (nothing about a heterozygous position depends on, or
  *                          is needed by, its neighbours' statistics: "CG" status needs the homozygous CC / GG pair).
- *   bsc_meth_ovf_kernel    CpG cytosines whose informative counts exceed the pair table (sitestats.hip) are listed by
- *                          the main kernel and evaluated here.
+ *                          It also evaluates the CpG cytosines whose informative counts exceed the pair table
+ *                          (listed by the main kernel) and empties both lists for the next call.
  *
  * A call handles one WINDOW of a block (the reference's unit: a maximal run of overlapping templates; the printer's
  * sliding-window state is flushed at its end): the windows of a block give exactly the records of the whole block,
@@ -601,16 +601,22 @@ __global__ __launch_bounds__(64 * FW, 4) void bsc_chain_kernel_t(
 extern "C" __global__ __launch_bounds__(256) void bsc_chain_het_kernel(
     const uint32_t *__restrict__ cts, const uint8_t *__restrict__ dbsnp, const bsc_chain_args a,
     const bsc_dev_tables *__restrict__ tb, uint8_t *__restrict__ core_out, const unsigned long long *__restrict__ het_list,
-    unsigned long long *__restrict__ counters, unsigned long long *__restrict__ stat_words) {
+    unsigned long long *__restrict__ counters, unsigned long long *__restrict__ stat_words,
+    const unsigned long long *__restrict__ ovf_list, const double *__restrict__ logp) {
   __shared__ double s_lf[256];
   __shared__ double s_logtab[256];
   __shared__ unsigned long long s_exptab[256];
   __shared__ uint32_t h[F_WORDS];
+  __shared__ double s_meth[4 * 101];
+  __shared__ double s_logp[100];
   s_lf[threadIdx.x] = tb->lfact[threadIdx.x];
   s_logtab[threadIdx.x] = tb->log_tab[threadIdx.x];
   s_exptab[threadIdx.x] = tb->exp_tab[threadIdx.x];
-  if (a.with_stats)
+  if (a.with_stats) {
     for (unsigned i = threadIdx.x; i < F_WORDS; i += 256) h[i] = 0;
+    for (unsigned i = threadIdx.x; i < 404; i += 256) s_meth[i] = 0.0;
+    if (threadIdx.x < 100) s_logp[threadIdx.x] = logp[threadIdx.x];
+  }
   __syncthreads();
   const unsigned long long nhet = counters[BSC_CNT_HET_LIST];
   const unsigned long long n_round = (nhet + 63ull) & ~63ull;
@@ -682,60 +688,63 @@ extern "C" __global__ __launch_bounds__(256) void bsc_chain_het_kernel(
     }
     if (a.with_stats) f_stats_update(h, F, stat_words);
   }
-  __syncthreads();
-  if (a.with_stats)
-    for (unsigned i = threadIdx.x; i < F_WORDS; i += 256)
-      if (h[i]) atomicAdd(&stat_words[i], (unsigned long long)h[i]);
-}
-
-/* CpG cytosines beyond the pair table: one wave per listed cytosine, two bins per lane (src/print_vcf.c:492-515) */
-extern "C" __global__ __launch_bounds__(256) void bsc_meth_ovf_kernel(const unsigned long long *__restrict__ ovf_list,
-                                                                      unsigned long long *__restrict__ counters,
-                                                                      uint32_t ovf_cap, const bsc_dev_tables *__restrict__ tb,
-                                                                      const double *__restrict__ logp,
-                                                                      double *__restrict__ out_meth) {
-  __shared__ double s_meth[4 * 101];
-  __shared__ double s_lf[256], s_logtab[256], s_logp[100];
-  __shared__ unsigned long long s_exptab[256];
-  const unsigned lane = threadIdx.x & 63u;
-  for (unsigned i = threadIdx.x; i < 404; i += 256) s_meth[i] = 0.0;
-  s_lf[threadIdx.x] = tb->lfact[threadIdx.x];
-  s_logtab[threadIdx.x] = tb->log_tab[threadIdx.x];
-  s_exptab[threadIdx.x] = tb->exp_tab[threadIdx.x];
-  if (threadIdx.x < 100) s_logp[threadIdx.x] = logp[threadIdx.x];
-  __syncthreads();
-  unsigned long long n = counters[BSC_CNT_OVF];
-  if (n > ovf_cap) n = ovf_cap;
-  double acc[2][2][2];
+  /* CpG cytosines whose informative counts exceed the pair table, listed by the main kernel: one wave per cytosine,
+   * two bins of the posterior per lane (src/print_vcf.c:492-515) */
+  if (a.with_stats) {
+    unsigned long long n_ovf = counters[BSC_CNT_OVF];
+    if (n_ovf > a.ovf_cap) n_ovf = a.ovf_cap;
+    if (n_ovf) { /* grid-uniform */
+      const unsigned lane = threadIdx.x & 63u;
+      double acc[2][2][2];
 #pragma unroll
-  for (int x = 0; x < 2; x++)
-    for (int y = 0; y < 2; y++) acc[x][y][0] = acc[x][y][1] = 0.0;
-  for (unsigned long long k = (unsigned long long)blockIdx.x * 4u + (threadIdx.x >> 6); k < n; k += (unsigned long long)gridDim.x * 4u) {
-    const unsigned long long e = ovf_list[k];
-    const uint32_t ca = (uint32_t)(e & 0xffffffu), cb = (uint32_t)((e >> 24) & 0xffffffu);
-    const bool is_ref = (e >> 48) & 1u, is_pass = (e >> 49) & 1u;
-    double z2[2];
-    ss_posterior(ca, cb, lane, s_lf, s_logtab, s_logp, s_exptab, z2);
+      for (int x = 0; x < 2; x++)
+        for (int y = 0; y < 2; y++) acc[x][y][0] = acc[x][y][1] = 0.0;
+      for (unsigned long long k = (unsigned long long)blockIdx.x * 4u + (threadIdx.x >> 6); k < n_ovf;
+           k += (unsigned long long)gridDim.x * 4u) {
+        const unsigned long long e = ovf_list[k];
+        const uint32_t ca = (uint32_t)(e & 0xffffffu), cb = (uint32_t)((e >> 24) & 0xffffffu);
+        const bool is_ref = (e >> 48) & 1u, is_pass = (e >> 49) & 1u;
+        double z2[2];
+        ss_posterior(ca, cb, lane, s_lf, s_logtab, s_logp, s_exptab, z2);
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      acc[is_ref ? 0 : 1][0][r] += z2[r];
-      if (is_pass) acc[is_ref ? 0 : 1][1][r] += z2[r];
+        for (int r = 0; r < 2; r++) {
+          acc[is_ref ? 0 : 1][0][r] += z2[r];
+          if (is_pass) acc[is_ref ? 0 : 1][1][r] += z2[r];
+        }
+      }
+#pragma unroll
+      for (int rf = 0; rf < 2; rf++)
+        for (int ps = 0; ps < 2; ps++)
+          for (int r = 0; r < 2; r++) {
+            const unsigned bin = lane + 64u * r;
+            if (bin < 101 && acc[rf][ps][r] != 0.0) atomicAdd(&s_meth[(rf * 2 + ps) * 101 + bin], acc[rf][ps][r]);
+          }
     }
   }
-#pragma unroll
-  for (int rf = 0; rf < 2; rf++)
-    for (int ps = 0; ps < 2; ps++)
-      for (int r = 0; r < 2; r++) {
-        const unsigned bin = lane + 64u * r;
-        if (bin < 101 && acc[rf][ps][r] != 0.0) atomicAdd(&s_meth[(rf * 2 + ps) * 101 + bin], acc[rf][ps][r]);
-      }
   __syncthreads();
-  for (unsigned i = threadIdx.x; i < 404; i += 256)
-    if (s_meth[i] != 0.0) atomicAdd(&out_meth[i], s_meth[i]);
+  if (a.with_stats) {
+    for (unsigned i = threadIdx.x; i < F_WORDS; i += 256)
+      if (h[i]) atomicAdd(&stat_words[i], (unsigned long long)h[i]);
+    double *out_meth = reinterpret_cast<double *>(reinterpret_cast<char *>(stat_words) + offsetof(bsc_site_stats, CpG_ref_meth));
+    for (unsigned i = threadIdx.x; i < 404; i += 256)
+      if (s_meth[i] != 0.0) atomicAdd(&out_meth[i], s_meth[i]);
+  }
+  /* the last workgroup to finish empties the two lists for the next call (every workgroup has read their lengths by
+   * then: it took its ticket after its last use) */
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = atomicAdd(&counters[BSC_CNT_TICKET], 1ull);
+    if (t == (unsigned long long)gridDim.x - 1ull) {
+      counters[BSC_CNT_HET_LIST] = 0ull;
+      counters[BSC_CNT_OVF] = 0ull;
+      counters[BSC_CNT_TICKET] = 0ull;
+    }
+  }
 }
 
 /* ---- launcher ------------------------------------------------------------------------------------------------ */
-/* counters[BSC_CNT_HET_LIST] and counters[BSC_CNT_OVF] must be zero on entry (the host queues the memsets) */
+/* counters[BSC_CNT_HET_LIST], [BSC_CNT_OVF] and [BSC_CNT_TICKET] must be zero on entry: they are at context creation,
+ * and bsc_chain_het_kernel leaves them so */
 extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
   if (L->n == 0) return 0;
   hipStream_t s = (hipStream_t)L->stream;
@@ -791,16 +800,9 @@ extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
   a.tile_end = n_tiles;
   hipLaunchKernelGGL(bsc_chain_het_kernel, dim3((unsigned)L->num_cus), dim3(256), 0, s, (const uint32_t *)L->cts,
                      (const uint8_t *)L->dbsnp, a, (const bsc_dev_tables *)L->tb, (uint8_t *)L->core_out,
-                     (const unsigned long long *)L->het_list, (unsigned long long *)L->counters, words);
+                     (const unsigned long long *)L->het_list, (unsigned long long *)L->counters, words,
+                     (const unsigned long long *)L->ovf_list, (const double *)L->logp);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
-  if (L->with_stats) {
-    double *meth = (double *)((char *)L->stats + offsetof(bsc_site_stats, CpG_ref_meth));
-    hipLaunchKernelGGL(bsc_meth_ovf_kernel, dim3(64), dim3(256), 0, s, (const unsigned long long *)L->ovf_list,
-                       (unsigned long long *)L->counters, L->ovf_cap, (const bsc_dev_tables *)L->tb, (const double *)L->logp,
-                       meth);
-    e = hipGetLastError();
-  }
   if (L->ev_stop) (void)hipEventRecord((hipEvent_t)L->ev_stop, s);
   return (int)e;
 }

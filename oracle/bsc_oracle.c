@@ -298,3 +298,81 @@ int orc_call_sites(const orc_pileup *cts, const char *ref, uint64_t n, const orc
   for (int t = 0; t < nthreads; t++) pthread_join(thr[t], NULL);
   return 0;
 }
+
+/* ---- timing helpers for bench.py's cpu_baseline leg (the three CPU timings) ------------------ */
+typedef struct {
+  orc_gt_meth *gt;
+  const char *ref;
+  uint64_t lo, hi;
+  const orc_tables *tb;
+  int flavour;
+} orc_model_job;
+
+static void *orc_model_worker(void *arg) {
+  const orc_model_job *jb = arg;
+  orc_calc_gt_prob_array(jb->gt + jb->lo, jb->ref + jb->lo, jb->hi - jb->lo, jb->tb, jb->flavour);
+  return NULL;
+}
+
+/* (i) calc_gt_prob() only over prepared records, nthreads workers on contiguous ranges */
+int orc_calc_gt_prob_array_mt(orc_gt_meth *gt, const char *ref, uint64_t n, const orc_tables *tb, int flavour, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  orc_model_job jobs[256];
+  pthread_t thr[256];
+  for (int t = 0; t < nthreads; t++) {
+    orc_model_job jb = {gt, ref, n * (uint64_t)t / (uint64_t)nthreads, n * (uint64_t)(t + 1) / (uint64_t)nthreads, tb, flavour};
+    jobs[t] = jb;
+  }
+  if (nthreads == 1) {
+    orc_model_worker(&jobs[0]);
+    return 0;
+  }
+  for (int t = 0; t < nthreads; t++)
+    if (pthread_create(&thr[t], NULL, orc_model_worker, &jobs[t])) return -1;
+  for (int t = 0; t < nthreads; t++) pthread_join(thr[t], NULL);
+  return 0;
+}
+
+typedef struct {
+  const orc_template *tpl;
+  uint32_t nr;
+  const uint8_t *seq;
+  uint32_t x, y;
+  int min_qual, reps, rc;
+  orc_pileup *out;
+} orc_acc_job;
+
+static void *orc_acc_worker(void *arg) {
+  orc_acc_job *jb = arg;
+  for (int r = 0; r < jb->reps; r++) jb->rc |= orc_accumulate(jb->tpl, jb->nr, jb->seq, jb->x, jb->y, jb->min_qual, jb->out);
+  return NULL;
+}
+
+/* (iii) HOT LOOP A: nthreads workers, each accumulating the same block `reps` times into its OWN pile-up array
+ * (out + t * (y - x + 1)): the aggregate rate T independent blocks would reach; the reference runs the loop on one
+ * thread (src/call_genotypes.c:180-226, on the process thread). */
+int orc_accumulate_mt(const orc_template *tpl, uint32_t nr, const uint8_t *seq, uint32_t x, uint32_t y, int min_qual,
+                      orc_pileup *out, int nthreads, int reps) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  orc_acc_job jobs[256];
+  pthread_t thr[256];
+  const uint64_t sz = (uint64_t)y - x + 1;
+  for (int t = 0; t < nthreads; t++) {
+    orc_acc_job jb = {tpl, nr, seq, x, y, min_qual, reps, 0, out + sz * (uint64_t)t};
+    jobs[t] = jb;
+  }
+  if (nthreads == 1) {
+    orc_acc_worker(&jobs[0]);
+    return jobs[0].rc;
+  }
+  for (int t = 0; t < nthreads; t++)
+    if (pthread_create(&thr[t], NULL, orc_acc_worker, &jobs[t])) return -1;
+  int rc = 0;
+  for (int t = 0; t < nthreads; t++) {
+    pthread_join(thr[t], NULL);
+    rc |= jobs[t].rc;
+  }
+  return rc;
+}

@@ -47,6 +47,10 @@ def lib():
         L.orc_accumulate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_calc_gt_prob_array.restype = None
         L.orc_calc_gt_prob_array.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.orc_calc_gt_prob_array_mt.restype = C.c_int
+        L.orc_calc_gt_prob_array_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int]
+        L.orc_accumulate_mt.restype = C.c_int
+        L.orc_accumulate_mt.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_vcf_block.restype = None
         L.orc_vcf_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_vcf_block_stats.restype = None

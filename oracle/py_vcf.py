@@ -1,0 +1,242 @@
+"""py_vcf.py — an independently written, pure-Python restatement of the record formation of bs_call's print thread.
+
+*** TEST INFRASTRUCTURE, NOT PRODUCT *** (same rules as bsc_oracle.c / orc_vcf.c).
+
+Why a second restatement: orc_vcf.c regenerates the printer's per-genotype lookup tables from a rule and is the checker of
+the GPU record kernels; nothing in the image can run the reference's print_vcf.c (it needs htslib), so the C restatement
+is cross-checked here against a restatement that shares NO code with it: the reference's LITERAL tables (as data, from
+tests/golden/print_vcf_tables.json), Python's own bytes / float arithmetic, and the sliding-window state machine written
+out as the reference has it:
+  print_vcf_entry     src/print_vcf.c:548-594   (5-site window; strncpy of a 7-base reference window)
+  flush_vcf_entries   src/print_vcf.c:536-546
+  _print_vcf_entry    src/print_vcf.c:32-381    (everything up to the htslib encoding; the statistics are not restated)
+Records are returned as dicts with the field names of bsc_vcf_core (bs_call_amd/abi.py VCF_CORE).  Pure-Python loops:
+small blocks only.
+"""
+import json
+import math
+import os
+import struct
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_T = json.load(open(os.path.join(os.path.dirname(HERE), "tests", "golden", "print_vcf_tables.json")))
+REF_ALT = _T["ref_alt"]  # [gt][rfix] -> "AC", "", ...
+ALL_IDX = _T["all_idx"]  # [gt][rfix] -> [a0, a1]
+GT_INT = _T["gt_int"]  # [gt][rfix] -> 0x22 / 0x24 / 0x44 / 0x48
+GT_FLAG = [[0] * 5 for _ in range(10)]
+for _g, _r in _T["gt_flag_ones"]:
+    GT_FLAG[_g][_r] = 1
+CFLAG, GFLAG, IUPAC = _T["cflag"], _T["gflag"], _T["iupac"]
+PBASE = "NACGT"
+LOG10 = 2.30258509299404568402  # include/bs_call.h:36
+
+
+def _f32(z):
+    """(float)z as the reference stores GL values."""
+    return struct.unpack("<f", struct.pack("<f", z))[0]
+
+
+def _strncpy(dst, off, src, n):
+    """strncpy(dst + off, src, n): stops copying at a 0 byte and pads the rest of the n bytes with zeros."""
+    ended = False
+    for i in range(n):
+        b = 0
+        if not ended:
+            b = src[i] if i < len(src) else 0
+            if b == 0:
+                ended = True
+        dst[off + i] = b
+
+
+class Printer:
+    """The printer's static state (src/print_vcf.c:529-533) and its three functions, for ONE contig."""
+
+    def __init__(self, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF):
+        self.gt_store = [0] * 5
+        self.store_x = 0
+        self.gtm_store = [None] * 5
+        self.db_store = [0] * 5
+        self.rf_ctxt = [0] * 8
+        self.all_positions = all_positions
+        self.reg = (reg_start, reg_stop)
+        self.records = {}  # position -> record dict
+
+    # src/print_vcf.c:32-381
+    def _entry(self, gtm, rf_ctxt, x, gt_store, rs_found):
+        if x == 0:
+            return
+        counts = gtm["counts"]
+        dp1 = sum(int(c) for c in counts[:4])
+        d_inf = sum(int(c) for c in counts[4:])
+        if dp1 + d_inf == 0:
+            return
+        prf_ctxt = "".join(PBASE[rf_ctxt[i]] for i in range(5))  # :134
+        rfix = rf_ctxt[2]
+        gt = gt_store[2] - 1
+        skip = (not self.all_positions) and not (rs_found & 2) and bool(GT_FLAG[gt][rfix])  # :139
+        z1 = math.exp(float(gtm["gt_prob"][gt]) * LOG10)  # :142
+        if z1 >= 1.0:
+            phred = 255
+        else:
+            phred = int(-10.0 * math.log(1.0 - z1) / LOG10)
+            if phred > 255:
+                phred = 255
+        alt = REF_ALT[gt][rfix]
+        fs = int(-float(gtm["fisher_strand"]) * 10.0 + 0.5)  # :151 (C truncation; int() truncates too)
+        qd = phred // dp1 if dp1 > 0 else phred  # :152
+        flt = 0
+        if not skip:
+            skip = x < self.reg[0] or x > self.reg[1]  # :154-158
+        c = [int(v) for v in counts]
+        if not skip:
+            if phred < 20:
+                flt |= 1
+            if qd < 2:
+                flt |= 2
+            if fs > 60:
+                flt |= 4
+            if int(gtm["mq"]) < 40:
+                flt |= 8
+            if not flt:  # :191-214
+                mac1 = False
+                if gt == 1:
+                    mac1 = c[1] + c[5] + c[7] <= 1 or c[0] + c[4] <= 1
+                elif gt == 2:
+                    mac1 = c[2] + c[6] <= 1 or c[0] <= 1
+                elif gt == 3:
+                    mac1 = c[3] + c[7] <= 1 or c[0] + c[4] <= 1
+                elif gt == 5:
+                    mac1 = c[2] + c[6] + c[4] <= 1 or c[1] + c[5] + c[7] <= 1
+                elif gt == 6:
+                    mac1 = c[3] <= 1 or c[1] + c[5] <= 1
+                elif gt == 8:
+                    mac1 = c[3] + c[7] <= 1 or c[2] + c[6] + c[4] <= 1
+                if mac1:
+                    flt |= 128
+        ctxt = "".join(IUPAC[gt_store[i]] for i in range(5))  # :228-230
+        g2, g3, g1 = gt_store[2], gt_store[3], gt_store[1]
+        cpg = "."
+        if (g2 == 5 and g3 == 8) or (g2 == 8 and g1 == 5):
+            cpg = "CG"
+        elif g2 == 5:
+            cpg = ("H" if GFLAG[g3 - 1] else "N") if g3 else "?"
+        elif g2 == 8:
+            cpg = ("H" if CFLAG[g1 - 1] else "N") if g1 else "?"
+        elif CFLAG[g2 - 1]:
+            cpg = ("H" if GFLAG[g3 - 1] else "N") if g3 else "?"
+        elif GFLAG[g2 - 1]:
+            cpg = ("H" if CFLAG[g1 - 1] else "N") if g1 else "."
+        rec = {
+            "pos": x, "emit": 0, "gt": gt, "ref_code": rfix, "gt_enc": 0, "flt": 0, "phred": phred, "n_gl": 0, "cg": cpg[0],
+            "alt": "", "cx_ref": prf_ctxt, "cx_gt": ctxt, "fs": fs, "qd": qd, "dp": dp1, "gl": [],
+        }
+        if not skip:
+            rec["emit"] = 1
+            rec["flt"] = flt
+            rec["alt"] = alt
+            rec["gt_enc"] = GT_INT[gt][rfix]
+            aix = ALL_IDX[gt][rfix]
+            gp = [float(v) for v in gtm["gt_prob"]]
+            if rfix:  # :322-327
+                z = gp[rfix * (9 - rfix) // 2 + rfix - 5]
+                if z < -99.999:
+                    z = -99.999
+            else:
+                z = -99.999
+            gtl = [_f32(z)]
+            i = 0
+            while i < 2 and aix[i] > 0:  # :330-346
+                if rfix:
+                    if rfix < aix[i]:
+                        j = rfix * (9 - rfix) // 2 + aix[i] - 5
+                    else:
+                        j = aix[i] * (9 - aix[i]) // 2 + rfix - 5
+                    z = gp[j]
+                    if z < -99.999:
+                        z = -99.999
+                    gtl.append(_f32(z))
+                j = aix[i] * (9 - aix[i]) // 2 + aix[i] - 5
+                z = gp[j]
+                if z < -99.999:
+                    z = -99.999
+                gtl.append(_f32(z))
+                i += 1
+            rec["n_gl"] = len(gtl)
+            rec["gl"] = gtl
+        self.records[x] = rec
+
+    # src/print_vcf.c:548-594
+    def push(self, gtm, rf, x, xstart, skip, rs_found=0):
+        """rf: the block's reference codes from xstart on (work->ref, used as a C string), as a list of ints."""
+        l = x - self.store_x
+        if l < 5:
+            self.gt_store = self.gt_store[l:] + [0] * l
+            self.gtm_store = self.gtm_store[l:] + [None] * l  # the vacated slots keep stale data in C; never read
+            self.db_store = self.db_store[l:] + [0] * l
+        else:
+            self.gt_store = [0] * 5
+        assert x > self.store_x
+        self.store_x = x
+        self.gtm_store[4] = gtm
+        self.db_store[4] = rs_found
+        if x - xstart >= 4:
+            _strncpy(self.rf_ctxt, 0, rf[x - xstart - 4 :], 7)
+        else:
+            l2 = x - xstart
+            for i in range(4 - l2):
+                self.rf_ctxt[i] = 0
+            _strncpy(self.rf_ctxt, 4 - l2, rf, 3 + l2)
+        if skip:
+            self.gt_store[4] = 0
+        else:
+            gp = gtm["gt_prob"]
+            z, gt = float(gp[0]), 0
+            for i in range(1, 10):
+                if float(gp[i]) > z:
+                    z, gt = float(gp[i]), i
+            self.gt_store[4] = gt + 1
+        if self.gt_store[2]:
+            self._entry(self.gtm_store[2], self.rf_ctxt, x - 2, self.gt_store, self.db_store[2])
+
+    # src/print_vcf.c:536-546
+    def flush(self):
+        if self.store_x:
+            for i in range(2):
+                # memmove(gt_store, gt_store + 1, 4): the last byte keeps its value
+                self.gt_store = self.gt_store[1:] + [self.gt_store[4]]
+                self.gtm_store = self.gtm_store[1:] + [self.gtm_store[4]]
+                self.db_store = self.db_store[1:] + [self.db_store[4]]
+                self.rf_ctxt = self.rf_ctxt[1:7] + self.rf_ctxt[6:]  # memmove(rf_ctxt, rf_ctxt + 1, 6)
+                if self.gt_store[2]:
+                    self._entry(self.gtm_store[2], self.rf_ctxt, self.store_x - 1 + i, self.gt_store, self.db_store[2])
+            self.store_x = 0
+
+
+def vcf_block(gtm, skip, ref, x, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None):
+    """print_thread over one block (src/process.c:87-104): gtm = sequence of gt_meth-like records (numpy GT_METH rows or
+    dicts) for positions x .. x + n - 1, skip[n], ref = reference codes of x .. x + n + 1 -> {position: record}."""
+    n = len(gtm)
+    rf = [int(v) for v in ref[: n + 2]] + [0]  # C string terminator
+    p = Printer(all_positions, reg_start, reg_stop)
+    for i in range(n):
+        p.push(gtm[i], rf, x + i, x, bool(skip[i]), 0 if dbsnp is None else int(dbsnp[i]))
+    p.flush()
+    return p.records
+
+
+def same_as_core(rec, core):
+    """Compare one record dict with a numpy VCF_CORE row; returns the list of differing field names."""
+    bad = []
+    for f in ("pos", "emit", "gt", "ref_code", "gt_enc", "flt", "phred", "n_gl", "fs", "qd", "dp"):
+        if int(core[f]) != int(rec[f]):
+            bad.append(f)
+    if core["cg"].decode() != rec["cg"]:
+        bad.append("cg")
+    if core["alt"].decode() != rec["alt"]:
+        bad.append("alt")
+    if core["cx_ref"].decode() != rec["cx_ref"] or core["cx_gt"].decode() != rec["cx_gt"]:
+        bad.append("cx")
+    gl = [float(v) for v in core["gl"]]
+    if gl[: rec["n_gl"]] != rec["gl"] or any(v != 0.0 for v in gl[rec["n_gl"] :]):
+        bad.append("gl")
+    return bad

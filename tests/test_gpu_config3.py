@@ -1,0 +1,85 @@
+"""BASELINE.json configs[2] on one GPU: the share rank 0 of 8 owns of the human-scale genome (chr1 and its LPT companions,
+~398 M positions at 30x with 1 % N-runs), every contig HBM-resident and walked in 4 Mi-position windows through the fused
+chain with statistics.  Checked through properties that do not need a 400 M-position CPU run — the counters and the
+statistics are a census of the records; a contig walked in windows gives the bytes of the contig called in one piece —
+and three random 1 M-position windows byte for byte against the CPU oracle (calc threads + print thread restated)."""
+import numpy as np
+import pytest
+
+import bs_call_amd as B
+from bs_call_amd import genome, shard
+from bs_call_amd.abi import VCF_CORE
+
+pytestmark = pytest.mark.gpu
+COV = 30
+
+
+def test_rank0_of_8_share(oracle, tables, libm_exact):
+    import torch
+
+    dev = torch.device("cuda:0")
+    lengths = shard.HUMAN_CONTIGS
+    firsts = genome.contig_first_sites(lengths)
+    mine = genome.rank_contigs(lengths, 0, 8)
+    assert mine[0] == 0 and 3.5e8 < sum(lengths[c] for c in mine) < 4.1e8  # chr1 + companions, one eighth of the genome
+    total = sum(lengths[c] for c in mine)
+    with B.SiteCaller() as c:
+        res = [genome.make_resident(c, k, lengths[k], firsts[k], COV, dev) for k in mine]
+        torch.cuda.synchronize()
+        nwin = sum(genome.walk_contig(c, rc, genome.WINDOW, True) for rc in res)
+        torch.cuda.synchronize()
+        assert nwin == sum((lengths[k] + genome.WINDOW - 1) // genome.WINDOW for k in mine)
+        s = c.stats()
+        st = c.site_stats()
+
+        # (1) counters and statistics = a census of the records
+        assert s["sites"] == total
+        called = emitted = passed = 0
+        hist = torch.zeros(10, dtype=torch.int64, device=dev)
+        for rc in res:
+            rec = rc.d_core.view(rc.length, 64)
+            pos = rc.d_core.view(torch.int32).view(rc.length, 16)[:, 0]
+            is_called = pos != 0
+            called += int(is_called.sum())
+            emit = rec[:, 4] != 0
+            emitted += int(emit.sum())
+            passed += int((emit & (rec[:, 8] == 0)).sum())
+            hist += torch.bincount(rec[:, 5][is_called].long(), minlength=10)
+            # records sit at their own position; uncalled positions are all-zero records
+            idx = torch.nonzero(is_called).view(-1)
+            assert torch.equal(pos[idx].long(), idx + 1)
+            assert int(rec[~is_called].sum()) == 0
+            del rec, pos, is_called, emit, idx
+        assert s["covered"] == called and s["gt_hist"] == hist.cpu().tolist()
+        assert int(st["snps"][0]) == emitted and int(st["snps"][1]) == passed
+        assert int(st["filter_counts"].sum()) == emitted and int(st["cov"][:, 0].sum()) == called and int(st["cov"][:, 1].sum()) == emitted
+        assert int(st["qual"][0].sum()) == emitted and (st["qual"][0] == st["qual"][1]).all()
+        assert int(st["CpG_ref"][0] + st["CpG_nonref"][0]) > 1_000_000  # CpGs were paired across the whole share
+        # every CpG cytosine with informative reads added one posterior (a distribution summing to 1) to a profile
+        n_meth = float(st["CpG_ref_meth"][0].sum() + st["CpG_nonref_meth"][0].sum())
+        assert abs(n_meth - round(n_meth)) < 1e-3 * max(1.0, n_meth ** 0.5) and n_meth > 1e6
+
+        # (2) a contig walked in windows == the contig in one call (records at the window boundaries included)
+        rc = min(res, key=lambda r: r.length)
+        assert rc.length > 10 * genome.WINDOW
+        whole = torch.empty(rc.length * 64, dtype=torch.uint8, device=dev)
+        c.chain_device(rc.d_cts.data_ptr(), rc.d_ref.data_ptr(), 1, rc.length, 0, rc.length, whole.data_ptr(), with_stats=False)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, rc.d_core)
+        del whole
+
+        # (3) three random 1 M-position windows against the oracle, byte for byte
+        rng = np.random.default_rng(20261003)
+        flav = oracle.LIBM if libm_exact else oracle.BSM
+        m, pad = 1_000_000, 8
+        for rc in res:
+            a = int(rng.integers(pad, rc.length - m - pad))
+            lo, hi = a - pad, a + m + pad
+            pile = rc.d_cts[lo * 104 : hi * 104].cpu().numpy().view(B.PILEUP)
+            ref2 = rc.d_ref[lo : hi + 2].cpu().numpy()
+            hp, hr = B.synth_pileup_host(genome.SEED + 3, firsts[rc.index] + lo, hi - lo, COV, 1)
+            assert pile.tobytes() == hp.tobytes() and (ref2[: hi - lo] == hr).all()  # device generator == host twin
+            gtm, skip = oracle.call_sites(pile, ref2[: hi - lo], tables, flav, -16)
+            exp = oracle.vcf_block(gtm, skip, ref2, 1 + lo)
+            got = rc.d_core[a * 64 : (a + m) * 64].cpu().numpy().view(VCF_CORE)
+            assert got.tobytes() == exp[pad : pad + m].tobytes(), "contig %d window at %d" % (rc.index, a)

@@ -22,7 +22,7 @@ for r in range(rounds):
         env = dict(os.environ)
         if n != "main":
             env["BSCALL_AMD_LIB"] = os.path.join(ROOT, "bs_call_amd", "lib", "variants", "lib_%s.so" % n)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "5", "--warmup", "2",
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-chain", "--steps", "5", "--warmup", "2",
                               "--sites", str(sites)], env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the PMC passes of tools/profile_bench.sh: HBM bytes per bsc_call_kernel launch =
+(2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts half of wide coalesced reads, MI355X_MICROARCH.md), tagged
+with the hash of the kernel sources so that bench.py stops quoting it once the kernel has changed.
+usage: python tools/make_traffic_json.py gpurun_out/prof_<tag> [positions] [coverage]"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+d = sys.argv[1]
+positions = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000_000
+coverage = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+
+
+def per_dispatch(sub, name):
+    agg = {}
+    for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == name and "bsc_call_kernel" in r.get("Kernel_Name", "") and "ILb0E" not in r["Kernel_Name"] and "<false>" not in r["Kernel_Name"]:
+                k = r["Dispatch_Id"]
+                agg[k] = agg.get(k, 0.0) + float(r["Counter_Value"])
+    v = list(agg.values())
+    return sum(v) / len(v)
+
+
+fetch, write = per_dispatch("pmc_fetch", "FETCH_SIZE"), per_dispatch("pmc_write", "WRITE_SIZE")
+out = {
+    "_source": "%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python bench.py --steps 2 --warmup 1`, bsc_call_kernel, "
+    "per dispatch; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads)" % d,
+    "positions": positions,
+    "coverage": coverage,
+    "fetch_size_kib": fetch,
+    "write_size_kib": write,
+    "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
+    "kernel_source_sha256_16": bench.kernel_source_hash(),
+}
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(out))

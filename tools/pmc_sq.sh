@@ -7,8 +7,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $ROOT/$OUT/p1 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $ROOT/$OUT/b1.json 2> $ROOT/$OUT/p1.err || { tail -5 $ROOT/$OUT/p1.err; exit 1; }
-rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $ROOT/$OUT/p2 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $ROOT/$OUT/b2.json 2> $ROOT/$OUT/p2.err || { tail -5 $ROOT/$OUT/p2.err; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $ROOT/$OUT/p1 -- python3 $ROOT/bench.py --no-cpu-baseline --no-chain --steps 2 --warmup 1 "$@" > $ROOT/$OUT/b1.json 2> $ROOT/$OUT/p1.err || { tail -5 $ROOT/$OUT/p1.err; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $ROOT/$OUT/p2 -- python3 $ROOT/bench.py --no-cpu-baseline --no-chain --steps 2 --warmup 1 "$@" > $ROOT/$OUT/b2.json 2> $ROOT/$OUT/p2.err || { tail -5 $ROOT/$OUT/p2.err; exit 1; }
 cd $ROOT
 python3 - <<PY
 import csv,glob
