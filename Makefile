@@ -54,12 +54,16 @@ $(LIBDIR)/vcf_format.o: $(CSRC)/vcf_format.c include/bscall_amd.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
+$(LIBDIR)/dbsnp.o: $(CSRC)/dbsnp.c include/bscall_amd.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -c $< -o $@
+
 $(LIBDIR)/synth_reads.o: $(CSRC)/synth_reads.c include/bscall_amd.h $(CSRC)/synth.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
+$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o $(LIBDIR)/dbsnp.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lz
 
 oracle:
 	$(MAKE) -C oracle liboracle.so

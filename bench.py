@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--rank-index", type=int, default=0)
     ap.add_argument("--window", type=int, default=0, help="config 3: positions per window (0 = genome.WINDOW: 4 Mi rounded down to whole 60-position wave-tiles)")
     ap.add_argument("--mem-gb", type=float, default=0.0, help="config 3: HBM budget for resident contigs (0 = 80 %% of free)")
+    ap.add_argument("--dbsnp", action="store_true", help="config 3 -> BASELINE.json configs[4]: a synthetic dbSNP index (1 site / 300 bp, "
+                    "10 %% fq_mask) is written, read back through the library's reader and its flags drive the chain")
     ap.add_argument("--genome-scale", type=float, default=1.0, help="config 3: scale every contig length (rehearsals)")
     args = ap.parse_args()
 
@@ -419,9 +421,19 @@ def run_config3(args, env):
     caller = B.SiteCaller(device=dev.index)
     caller.set_profiling(True)
     stream = torch.cuda.current_stream().cuda_stream
-    dt, n_windows, chain_ms = 0.0, 0, []
+    index = dbsnp_index_for(args, mine, lengths, rank) if args.dbsnp else None
+    dt, n_windows, chain_ms, n_db = 0.0, 0, [], 0
+
+    def flags_of(c):
+        nonlocal n_db
+        if index is None:
+            return None
+        n_db += index.load_contig("ctg%d" % c)
+        return index.flags(1, lengths[c])
+
     for gi, group in enumerate(groups):
-        resident = [genome.make_resident(caller, c, lengths[c], firsts[c], args.coverage, dev, stream=stream) for c in group]
+        resident = [genome.make_resident(caller, c, lengths[c], firsts[c], args.coverage, dev, stream=stream, dbsnp_flags=flags_of(c))
+                    for c in group]
         torch.cuda.synchronize()
         if gi == 0:
             for _ in range(args.warmup):
@@ -467,7 +479,9 @@ def run_config3(args, env):
         "data": "synthetic",
         "gbases_per_hour": value * 3.6e-6,
         "config": {
-            "workload": "configs[2]: synthetic human-scale genome, 24 contigs, %d positions at %dx WGBS with 1 %% N-runs "
+            "workload": ("configs[4]: configs[2] with a dbSNP index loaded (%d sites of this share; synthetic, 1 site / 300 bp, 10 %% "
+                         "flagged fq_mask: forced hom-ref records, dbSNP statistics) — " % n_db if args.dbsnp else "")
+            + "configs[2]: synthetic human-scale genome, 24 contigs, %d positions at %dx WGBS with 1 %% N-runs "
             "(L-pileup generator), contigs assigned to ranks by longest-processing-time, each contig HBM-resident and walked in "
             "%d-position windows through the fused chain (pile-up -> call -> VCF record -> site statistics)"
             % (sum(lengths), args.coverage, args.window),
@@ -480,6 +494,7 @@ def run_config3(args, env):
             "covered_fraction": float(stats[1]) / total,
             "records_written": int(site["snps"][0]) // max(args.steps, 1),
             "CpGs": int(site["CpG_ref"][0] + site["CpG_nonref"][0]) // max(args.steps, 1),
+            "dbSNP_sites_written": int(site["dbSNP_sites"][0]) // max(args.steps, 1),
         },
         "roofline": {
             "bound": "hbm",
@@ -496,6 +511,26 @@ def run_config3(args, env):
     }
     caller.close()
     return res
+
+
+def dbsnp_index_for(args, contigs, lengths, rank):
+    """configs[4]: write the synthetic index of this rank's contigs (tools/make_dbsnp_index.py: the reference's on-disk
+    format) into a temporary file and open it with the library's reader.  Untimed set-up."""
+    import importlib.util
+    import tempfile
+
+    from bs_call_amd.dbsnp import DbSnpIndex
+
+    spec = importlib.util.spec_from_file_location("make_dbsnp_index", os.path.join(ROOT, "tools", "make_dbsnp_index.py"))
+    W = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(W)
+    path = os.path.join(tempfile.mkdtemp(prefix="bsc_dbsnp_"), "rank%d.idx" % rank)
+    first, ctgs = 1000, {}
+    for c in contigs:
+        ctgs["ctg%d" % c] = W.synthetic_sites(lengths[c], 300, first_rs=first)
+        first += 10 * len(ctgs["ctg%d" % c])
+    W.write_index(path, ctgs)
+    return DbSnpIndex(path)
 
 
 if __name__ == "__main__":

@@ -36,6 +36,14 @@ EXPORTS = (
     "bsc_reset_site_stats",
     "bsc_chain_device",
     "bsc_last_chain_ms",
+    "bsc_dbsnp_open",
+    "bsc_dbsnp_close",
+    "bsc_dbsnp_n_contigs",
+    "bsc_dbsnp_contig_name",
+    "bsc_dbsnp_header",
+    "bsc_dbsnp_load_contig",
+    "bsc_dbsnp_flags",
+    "bsc_dbsnp_name",
     "bsc_set_profiling",
     "bsc_last_kernel_ms",
     "bsc_synchronize",
@@ -158,6 +166,22 @@ def load():
     L.bsc_chain_device.argtypes = [vp, vp, vp, vp, C.POINTER(Window), C.POINTER(VcfParams), i32, vp, vp]
     L.bsc_last_chain_ms.restype = i32
     L.bsc_last_chain_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.bsc_dbsnp_open.restype = i32
+    L.bsc_dbsnp_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.bsc_dbsnp_close.restype = None
+    L.bsc_dbsnp_close.argtypes = [vp]
+    L.bsc_dbsnp_n_contigs.restype = i32
+    L.bsc_dbsnp_n_contigs.argtypes = [vp]
+    L.bsc_dbsnp_contig_name.restype = C.c_char_p
+    L.bsc_dbsnp_contig_name.argtypes = [vp, i32]
+    L.bsc_dbsnp_header.restype = C.c_char_p
+    L.bsc_dbsnp_header.argtypes = [vp]
+    L.bsc_dbsnp_load_contig.restype = i32
+    L.bsc_dbsnp_load_contig.argtypes = [vp, C.c_char_p, C.POINTER(u64)]
+    L.bsc_dbsnp_flags.restype = i32
+    L.bsc_dbsnp_flags.argtypes = [vp, u32, u32, vp]
+    L.bsc_dbsnp_name.restype = i32
+    L.bsc_dbsnp_name.argtypes = [vp, u32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.bsc_set_profiling.restype = i32
     L.bsc_set_profiling.argtypes = [vp, i32]
     L.bsc_last_kernel_ms.restype = i32

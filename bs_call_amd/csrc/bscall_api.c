@@ -139,6 +139,15 @@ static void bsc_devguard_exit(bsc_devguard *g) {
     }                                                                                \
   } while (0)
 
+/* the same channel for the other C files of the library (dbsnp.c, prep.c) */
+int bsc_set_error(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(bsc_errbuf, sizeof bsc_errbuf, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
 #define HIP_TRY(call)                                                                                        \
   do {                                                                                                       \
     hipError_t e_ = (call);                                                                                  \

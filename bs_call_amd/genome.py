@@ -68,15 +68,17 @@ class ResidentContig:
 
 
 def make_resident(caller, index: int, length: int, first_site: int, coverage: int, device, flags: int = 1,
-                  seed: int = SEED + 3, stream=None):
-    """Generate contig `index` on the device (the L-pileup generator; flags = 1: 1 % of 10-kb runs are N without reads)."""
+                  seed: int = SEED + 3, stream=None, dbsnp_flags=None):
+    """Generate contig `index` on the device (the L-pileup generator; flags = 1: 1 % of 10-kb runs are N without reads).
+    dbsnp_flags: uint8[length] rs_found per position (DbSnpIndex.flags(1, length)) for BASELINE.json configs[4]."""
     import torch
 
     d_cts = torch.empty((length + 2) * PILEUP_BYTES, dtype=torch.uint8, device=device)
     d_ref = torch.empty(length + 2, dtype=torch.uint8, device=device)
     d_core = torch.empty(length * CORE_BYTES, dtype=torch.uint8, device=device)
     caller.synth_device(seed, first_site, length + 2, coverage, d_cts.data_ptr(), d_ref.data_ptr(), flags, stream)
-    return ResidentContig(index, length, d_cts, d_ref, d_core)
+    d_db = None if dbsnp_flags is None else torch.from_numpy(dbsnp_flags).to(device)
+    return ResidentContig(index, length, d_cts, d_ref, d_core, d_db)
 
 
 def walk_contig(caller, rc: ResidentContig, window: int = WINDOW, with_stats: bool = True, x: int = 1,

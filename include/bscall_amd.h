@@ -329,6 +329,31 @@ int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, con
 /* with bsc_set_profiling: device time of the most recent bsc_chain_device call (all of its launches) */
 int bsc_last_chain_ms(bsc_context *ctx, float *ms);
 
+/*
+ * dbSNP index (host C + zlib; csrc/dbsnp.c): the reader of the compressed index bin/dbSNP_idx writes.  In the reference
+ * the index never touches the likelihoods: an entry names the record (VCF ID), forces the AA / TT homozygous-reference
+ * record of a site flagged in its `fq_mask` to be written (rs_found & 2, src/print_vcf.c:139) and feeds the dbSNP
+ * counters of the statistics (:426-441).
+ *   bsc_dbsnp_open          load_dbSNP_header   src/dbSNP.c:27-141
+ *   bsc_dbsnp_load_contig   load_dbSNP_ctg      src/dbSNP.c:157-304 (the previous contig is dropped, as print_vcf_entry
+ *                                               does at a contig change, src/print_vcf.c:553-562); a contig the index
+ *                                               does not list loads as "nothing flagged"; *n_snps = entries loaded
+ *   bsc_dbsnp_flags         rs_found (0 / 1 / 3) of positions x0 .. x0 + n - 1 (1-based) of the loaded contig: the
+ *                           `dbsnp` array of bsc_chain_device / bsc_block_records / bsc_vcf_records
+ *   bsc_dbsnp_name          dbSNP_lookup_name   src/dbSNP.c:306-350: returns rs_found, the name in rs (NUL-terminated) and
+ *                           in *rs_len the length the reference hands to htslib (an odd number of digits counts its
+ *                           filler byte); negative on error
+ */
+typedef struct bsc_dbsnp bsc_dbsnp;
+int bsc_dbsnp_open(const char *path, bsc_dbsnp **out);
+void bsc_dbsnp_close(bsc_dbsnp *db);
+int bsc_dbsnp_n_contigs(const bsc_dbsnp *db);
+const char *bsc_dbsnp_contig_name(const bsc_dbsnp *db, int i);
+const char *bsc_dbsnp_header(const bsc_dbsnp *db);
+int bsc_dbsnp_load_contig(bsc_dbsnp *db, const char *name, uint64_t *n_snps);
+int bsc_dbsnp_flags(const bsc_dbsnp *db, uint32_t x0, uint32_t n, uint8_t *out);
+int bsc_dbsnp_name(const bsc_dbsnp *db, uint32_t x, char *rs, size_t cap, size_t *rs_len);
+
 /* Host-side text rendering of one record as a VCF data line ("CHROM POS ID REF ALT QUAL FILTER INFO FORMAT SAMPLE",
  * tab separated, no newline): the field layout of the record the reference hands to htslib (src/print_vcf.c:160-380).
  * Returns the length written, 0 when c->emit == 0, -1 when buf is too small.  `id` NULL/"" prints ".". */
