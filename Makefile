@@ -58,11 +58,15 @@ $(LIBDIR)/dbsnp.o: $(CSRC)/dbsnp.c include/bscall_amd.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
+$(LIBDIR)/prep.o: $(CSRC)/prep.c include/bscall_amd.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -c $< -o $@
+
 $(LIBDIR)/synth_reads.o: $(CSRC)/synth_reads.c include/bscall_amd.h $(CSRC)/synth.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o $(LIBDIR)/dbsnp.o
+$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o $(LIBDIR)/dbsnp.o $(LIBDIR)/prep.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lz
 
 oracle:
@@ -71,7 +75,23 @@ oracle:
 # a plain-C host program against the C ABI: gcc only, links the shared library like bs_call would
 demo: $(LIBDIR)/demo_block
 $(LIBDIR)/demo_block: integration/demo_block.c include/bscall_amd.h $(LIBDIR)/libbscall_amd.so
-	$(CC) -O2 -Wall -std=gnu11 -Iinclude $< -o $@ -L$(LIBDIR) -lbscall_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
+	$(CC) -O2 -Wall -std=gnu11 -Iinclude $< -o $@ -L$(LIBDIR) -lbscall_amd -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
+
+# Compile check of the two replacement translation units against the reference's own headers.  Only in a
+# container that has /root/reference; the reference's bs_call.h includes three htslib headers for POINTER TYPES only, so
+# the check gives the compiler opaque typedefs for them (generated under /tmp, never committed).  It checks OUR files'
+# syntax and types against the reference's declarations; it claims nothing about the oracle or about the reference.
+REF ?= /root/reference
+glue-check:
+	@if [ -d $(REF)/include ]; then \
+	  d=$$(mktemp -d /tmp/bsc_glue.XXXXXX); mkdir -p $$d/htslib; \
+	  printf 'typedef struct bam_hdr_t bam_hdr_t; typedef struct htsFile htsFile; typedef struct hts_idx_t hts_idx_t; typedef struct hts_itr_t hts_itr_t; typedef struct bam1_t bam1_t;\n#define FT_UNKN 0\n#define FT_GZ 1\n#define FT_VCF 2\n#define FT_VCF_GZ 3\n#define FT_BCF 4\n#define FT_BCF_GZ 5\n' > $$d/htslib/sam.h; \
+	  printf 'typedef struct bcf_hdr_t bcf_hdr_t; typedef struct bcf1_t bcf1_t;\n' > $$d/htslib/vcf.h; \
+	  printf 'typedef struct faidx_t faidx_t;\n' > $$d/htslib/faidx.h; \
+	  for f in integration/call_genotypes_amd.c integration/call_genotypes_amd_overlap.c; do \
+	    $(CC) -std=gnu11 -Wall -fsyntax-only -D__LINUX__ -I$$d -I$(REF)/include -I$(REF)/gt/include -Iinclude $$f && echo "glue-check: $$f ok" || exit 1; \
+	  done; rm -rf $$d; \
+	else echo "glue-check: $(REF) not present, skipped"; fi
 
 asm: $(CSRC)/kernels.hip
 	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -Rpass-analysis=kernel-resource-usage $< -o $(LIBDIR)/kernels.s
@@ -80,4 +100,4 @@ clean:
 	rm -f $(LIBDIR)/*.o $(LIBDIR)/*.so $(LIBDIR)/*.s $(LIBDIR)/demo_block
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle demo asm clean
+.PHONY: all oracle demo asm clean glue-check

@@ -36,6 +36,9 @@ EXPORTS = (
     "bsc_reset_site_stats",
     "bsc_chain_device",
     "bsc_last_chain_ms",
+    "bsc_prepare_templates",
+    "bsc_block_start",
+    "bsc_template_qual",
     "bsc_dbsnp_open",
     "bsc_dbsnp_close",
     "bsc_dbsnp_n_contigs",
@@ -166,6 +169,12 @@ def load():
     L.bsc_chain_device.argtypes = [vp, vp, vp, vp, C.POINTER(Window), C.POINTER(VcfParams), i32, vp, vp]
     L.bsc_last_chain_ms.restype = i32
     L.bsc_last_chain_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.bsc_prepare_templates.restype = i32
+    L.bsc_prepare_templates.argtypes = [vp, u32, vp, u64, vp, u64, vp, vp, vp, u64, C.POINTER(u64), vp]
+    L.bsc_block_start.restype = u32
+    L.bsc_block_start.argtypes = [vp]
+    L.bsc_template_qual.restype = u32
+    L.bsc_template_qual.argtypes = [vp, vp]
     L.bsc_dbsnp_open.restype = i32
     L.bsc_dbsnp_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.bsc_dbsnp_close.restype = None

@@ -89,3 +89,18 @@ SITE_STATS = np.dtype(
     ]
 )
 SITE_STATS_INT_WORDS = (SITE_STATS.itemsize - 4 * 101 * 8) // 8  # the leading u64 part; the rest is 404 doubles
+
+# bsc_raw_template / bsc_misms / bsc_prep_params / bsc_prep_stats (include/bscall_amd.h): read pre-processing
+RAW_TEMPLATE = np.dtype(
+    {
+        "names": ["pos", "reference_span", "len", "n_misms", "off", "misms_off", "mapq", "orientation", "bs_strand", "_pad"],
+        "formats": [("<u4", (2,)), ("<u4", (2,)), ("<u4", (2,)), ("<u4", (2,)), ("<u8", (2,)), ("<u8", (2,)), ("u1", (2,)), "u1", "u1", "<u4"],
+        "offsets": [0, 8, 16, 24, 32, 48, 64, 66, 67, 68],
+        "itemsize": 72,
+    }
+)
+MISMS = np.dtype([("type", "<u4"), ("position", "<u4"), ("size", "<u4")])
+MISMS_MISMS, MISMS_INS, MISMS_DEL, MISMS_SOFT = 0, 1, 2, 3
+PREP_PARAMS = np.dtype([("left_trim", "<i4", (2,)), ("right_trim", "<i4", (2,)), ("min_qual", "<i4")])
+PREP_STATS = np.dtype([("base_none", "<u8"), ("base_trim", "<u8"), ("base_clip", "<u8"), ("base_overlap", "<u8"), ("base_lowqual", "<u8"),
+                       ("reads", "<u8"), ("read_bases", "<u8")])

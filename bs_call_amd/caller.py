@@ -361,3 +361,24 @@ class PinnedBuffer:
             self.free()
         except Exception:
             pass
+
+
+def prepare_templates(raw, seq, misms, left_trim=(0, 0), right_trim=(0, 0), min_qual=20):
+    """Read pre-processing on the host (bsc_prepare_templates; src/process_template.c:36-111): RAW_TEMPLATE[nr] + read
+    bytes + MISMS[] -> (TEMPLATE[nr], prepared read bytes, PREP_STATS record).  No GPU involved."""
+    from .abi import MISMS, PREP_PARAMS, PREP_STATS, RAW_TEMPLATE
+
+    L = _lib.load()
+    raw = np.ascontiguousarray(raw, dtype=RAW_TEMPLATE)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    misms = np.ascontiguousarray(misms, dtype=MISMS)
+    par = np.zeros(1, dtype=PREP_PARAMS)
+    par["left_trim"][0], par["right_trim"][0], par["min_qual"][0] = left_trim, right_trim, min_qual
+    cap = int(seq.size) + int(misms["size"][misms["type"] == 1].sum()) + 16
+    out_tpl = np.zeros(len(raw), dtype=TEMPLATE)
+    out_seq = np.zeros(cap, dtype=np.uint8)
+    used = C.c_uint64(0)
+    st = np.zeros(1, dtype=PREP_STATS)
+    _check(L.bsc_prepare_templates(_ptr(raw), len(raw), _ptr(seq), seq.size, _ptr(misms), len(misms), _ptr(par), _ptr(out_tpl),
+                                   _ptr(out_seq), cap, C.byref(used), _ptr(st)))
+    return out_tpl, out_seq[: used.value].copy(), st[0]

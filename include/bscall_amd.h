@@ -330,6 +330,57 @@ int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, con
 int bsc_last_chain_ms(bsc_context *ctx, float *ms);
 
 /*
+ * Read pre-processing (host C; csrc/prep.c): from the templates the reader hands over to the templates bsc_accumulate /
+ * bsc_call_block / bsc_block_records consume — what process_template_vector does to every template of a block before it
+ * calls call_genotypes_ML (src/process_template.c:36-111): the fixed trims (trim_read, src/read_utils.c:13-26), the
+ * soft clips (trim_soft_clips, src/al_utils.c:122-162), the overlap of the two mates (handle_overlap, :164-318) and the
+ * normalisation of indels (a deletion from the reference becomes bytes 0, an insertion is removed).
+ *
+ * A raw template is `align_details` (include/bs_call.h:64-73) with its gt_vectors flattened: read k = len[k] bytes
+ * base|qual<<2 at seq + off[k]; its mismatch list = n_misms[k] entries at misms + misms_off[k], as get_bam_misms builds
+ * it from the CIGAR (src/input_sam.c:90-136; note the reference's naming: CIGAR D -> INS, CIGAR I -> DEL).
+ */
+#define BSC_MISMS_MISMS 0u /* gt_misms_t, include/bs_call.h:54 */
+#define BSC_MISMS_INS 1u
+#define BSC_MISMS_DEL 2u
+#define BSC_MISMS_SOFT 3u
+typedef struct {
+  uint32_t type;     /* BSC_MISMS_* */
+  uint32_t position; /* offset in the read */
+  uint32_t size;
+} bsc_misms; /* gt_misms, include/bs_call.h:55-62 */
+typedef struct {
+  uint32_t pos[2];            /* forward_position, reverse_position; 0 = none */
+  uint32_t reference_span[2];
+  uint32_t len[2];            /* 0 = read absent */
+  uint32_t n_misms[2];
+  uint64_t off[2];            /* byte offsets of the reads in seq */
+  uint64_t misms_off[2];      /* index of each read's first entry in misms */
+  uint8_t mapq[2];
+  uint8_t orientation;        /* gt_strand: 0 FORWARD, 1 REVERSE */
+  uint8_t bs_strand;          /* gt_bs_strand */
+  uint32_t _pad;
+} bsc_raw_template;
+typedef struct {
+  int32_t left_trim[2], right_trim[2]; /* sr_param.left_trim / right_trim: [0] read 1, [1] read 2 (-L / -R) */
+  int32_t min_qual;                    /* only for the base counters below */
+} bsc_prep_params;
+typedef struct { /* the base_filter / filter_cts counters of bs_stats this stage feeds (src/process_template.c:50-59) */
+  uint64_t base_none, base_trim, base_clip, base_overlap, base_lowqual; /* base_filter[] */
+  uint64_t reads, read_bases;                                           /* filter_cts / filter_bases[gt_flt_none] */
+} bsc_prep_stats;
+/* tpl_out[nr] and the prepared read bytes in seq_out (capacity seq_out_cap: the input bytes plus the padded deletions
+ * always fit in seq_bytes + sum of INS sizes); *seq_out_used = bytes written.  BSC_ERR_ARG where the reference aborts
+ * (a soft clip that is not at the end of its read or swallows it), naming the template. */
+int bsc_prepare_templates(const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                          const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *par, bsc_template *tpl_out,
+                          uint8_t *seq_out, uint64_t seq_out_cap, uint64_t *seq_out_used, bsc_prep_stats *stats);
+/* x of the block a template list starts: the first template's start - 2, at least 1 (src/process_template.c:22-28) */
+uint32_t bsc_block_start(const bsc_raw_template *first);
+/* get_al_qual (src/al_utils.c:19-35): the score duplicate resolution compares, with the reference's sq[k] indexing */
+uint32_t bsc_template_qual(const bsc_raw_template *t, const uint8_t *seq);
+
+/*
  * dbSNP index (host C + zlib; csrc/dbsnp.c): the reader of the compressed index bin/dbSNP_idx writes.  In the reference
  * the index never touches the likelihoods: an entry names the record (VCF ID), forces the AA / TT homozygous-reference
  * record of a site flagged in its `fq_mask` to be written (rs_found & 2, src/print_vcf.c:139) and feeds the dbSNP

@@ -236,11 +236,46 @@ def test_plain_c_host_program():
 
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bs_call_amd", "lib", "demo_block")
     assert os.path.exists(exe), "run `make demo`"
-    r = subprocess.run([exe, "50000", "30"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stderr
-    last = r.stdout.strip().splitlines()[-1]
+    r = subprocess.run([exe, "50000", "30", "4"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    lines = r.stdout.strip().splitlines()
+    last = lines[-1]
     assert "positions called" in last and "VCF records" in last
-    assert any(ln.startswith("chrS\t") for ln in r.stdout.splitlines())
+    assert any(ln.startswith("chrS\t") for ln in lines)
+    # the overlapped form of the replacement call_genotypes_ML (two pinned gt_vcf arrays, submit / fetch, a consumer thread
+    # draining work->vcf[] on the ready flags like src/process.c:87-104) delivered the synchronous form's bytes
+    ov = [ln for ln in lines if "overlapped" in ln]
+    assert ov and "4 blocks" in ov[0]
+    h = ov[0].split("hash ")[1].split(" / ")
+    assert h[0].strip() == h[1].strip()
+
+
+def test_prepared_templates_on_the_device(caller, oracle):
+    """Reads with soft clips, indels and overlapping mates through bsc_prepare_templates (host C, src/process_template.c:
+    36-111 restated) and then through the device accumulate: same pile-up as the oracle's accumulate over the same
+    prepared templates."""
+    from bs_call_amd.caller import prepare_templates
+    from tests.test_prep import _random_read, to_arrays, tpl
+
+    rng = np.random.default_rng(31)
+    ts = []
+    for i in range(3000):
+        r0, m0, s0 = _random_read(rng, 15)
+        r1, m1, s1 = _random_read(rng, 15)
+        p0 = 1000 + 11 * i
+        ts.append(tpl((p0, p0 + int(rng.integers(0, s0 + 40))), (s0, s1), (r0, r1), (m0, m1), orientation=int(rng.integers(0, 2)),
+                      bs_strand=int(rng.integers(0, 3))))
+    raw, seq, ms = to_arrays(ts)
+    try:
+        out, oseq, st = prepare_templates(raw, seq, ms)
+    except B.BscError:
+        pytest.skip("the random draw hit the reference's undefined indel-beyond-the-read class")
+    x = 998
+    y = int(max((int(o["pos"][k]) + int(o["len"][k])) for o in out for k in range(2) if o["len"][k])) + 1
+    rc, exp = oracle.accumulate(out, oseq, x, y, 20)
+    assert rc == 0 and int(st["base_overlap"]) > 0 and int(st["base_clip"]) > 0
+    got = caller.accumulate(out, oseq, x, y)
+    assert got.tobytes() == exp.tobytes()
 
 
 def test_large_block_multi_chunk_copy_out(caller, oracle, tables, libm_exact):
