@@ -66,6 +66,8 @@ struct bsc_context {
   size_t cap_cts, cap_ref, cap_out, cap_skip;
   void *d_het;
   size_t cap_het;
+  uint64_t max_launch; /* positions per launch of the calling kernel (BSC_MAX_LAUNCH; BSC_MAX_LAUNCH_SITES in the
+                          environment lowers it so that the sub-launch loop of longer calls can be tested) */
   int het_dirty; /* bsc_call_sites_device left a heterozygous list behind (the fused chain expects an empty one) */
   void *d_ovf; /* fused chain: CpG cytosines beyond the methylation pair table (8 bytes each) */
   size_t cap_ovf;
@@ -233,6 +235,14 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
   ctx->params = p;
   ctx->device = dev;
   ctx->num_cus = prop.multiProcessorCount;
+  ctx->max_launch = BSC_MAX_LAUNCH;
+  {
+    const char *ml = getenv("BSC_MAX_LAUNCH_SITES");
+    if (ml && *ml) {
+      const unsigned long long v = strtoull(ml, NULL, 10) & ~63ull; /* whole wave-tiles: keeps both arrays 16-byte aligned */
+      if (v >= 64 && v < BSC_MAX_LAUNCH) ctx->max_launch = v;
+    }
+  }
   bsc_build_tables(ctx);
   int rc = BSC_OK;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -355,7 +365,7 @@ int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref
   uint64_t done = 0;
   while (done < n) {
     uint64_t m = n - done;
-    if (m > BSC_MAX_LAUNCH) m = BSC_MAX_LAUNCH; /* multiple of 2 sites: keeps the 16-byte alignment of both arrays */
+    if (m > ctx->max_launch) m = ctx->max_launch; /* a multiple of 64 sites: keeps the 16-byte alignment of both arrays */
     rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, (size_t)m * 4u);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_HET_LIST, 0, sizeof(unsigned long long), s));

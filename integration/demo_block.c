@@ -57,9 +57,9 @@ typedef struct {
 } work_t;
 
 static void consume(work_t *w, const gt_vcf *v) { /* stands in for print_vcf_entry: every byte the printer would read */
-  const unsigned char *p = (const unsigned char *)&v->gtm;
-  uint64_t h = w->hash;
-  for (size_t i = 0; i < sizeof v->gtm; i++) h = (h ^ p[i]) * 1099511628211ull;
+  uint64_t q[sizeof v->gtm / 8], h = w->hash;
+  memcpy(q, &v->gtm, sizeof q);
+  for (size_t i = 0; i < sizeof q / sizeof q[0]; i++) h = (h ^ q[i]) * 1099511628211ull;
   h = (h ^ (unsigned)v->skip) * 1099511628211ull;
   w->hash = h;
   w->records++;

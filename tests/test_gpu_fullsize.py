@@ -70,3 +70,76 @@ def test_full_contig_properties(oracle, tables, libm_exact):
         exp, eskip = oracle.call_sites(pile, ref, tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
         got = d_out[a * 200 : (a + m) * 200].cpu().numpy().view(B.GT_METH)
         assert got.tobytes() == exp.tobytes() and (d_skip[a : a + m].cpu().numpy() == eskip).all()
+
+
+def test_config4_deep_coverage_window(oracle, tables, libm_exact):
+    """BASELINE.json configs[3]: 10 Mb at 200x (margins >= 256: the lgamma branch of lfact2; |ll - max| >= 512: the exp
+    fall-back; quality sums still exact in f32) — full size through properties (census, idempotence, the fused chain's
+    records == the unfused chain's), and a 200 k window byte for byte against the oracle."""
+    import torch
+
+    n, cov, seed = 10_000_000, 200, SEED + 7
+    dev = torch.device("cuda:0")
+    with B.SiteCaller() as c:
+        d_cts = torch.empty((n + 2) * 104, dtype=torch.uint8, device=dev)
+        d_ref = torch.empty(n + 2, dtype=torch.uint8, device=dev)
+        d_out = torch.empty(n * 200, dtype=torch.uint8, device=dev)
+        d_skip = torch.empty(n, dtype=torch.uint8, device=dev)
+        c.synth_device(seed, 0, n + 2, cov, d_cts.data_ptr(), d_ref.data_ptr(), 0, None)
+        c.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 200, None)
+        torch.cuda.synchronize()
+        s = c.stats()
+        rec = d_out.view(n, 200)
+        skip = d_skip.bool()
+        assert s["sites"] == n and s["covered"] == int((~skip).sum())
+        mx = rec[:, 192][~skip].long()
+        assert s["gt_hist"] == torch.bincount(mx, minlength=10).cpu().tolist()
+        het = torch.tensor(B.GT_HET, device=dev)[rec[:, 192].long()] & ~skip
+        assert s["het_calls"] == int(het.sum()) > 10_000
+        fs = rec[:, 176:184].contiguous().view(torch.float64).view(-1)
+        assert int((fs[~het] != 0).sum()) == 0 and int((fs[het] != 0).sum()) > 0.9 * int(het.sum())
+        # depth really is deep: strand-table margins beyond the 256-entry log-factorial table
+        depth = d_cts.view(torch.int32).view(n + 2, 26)[:n, 16]
+        assert int((depth[het] >= 256).sum()) > 100
+        d_out2 = torch.zeros_like(d_out)
+        c.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out2.data_ptr(), d_skip.data_ptr(), 200, None)
+        torch.cuda.synchronize()
+        assert torch.equal(d_out, d_out2)
+        del d_out2
+        # fused chain == unfused chain on the whole 10 M block (records and statistics)
+        d_core_u = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        d_core_f = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        c.reset_site_stats()
+        c.vcf_records_device(d_out.data_ptr(), 200, d_skip.data_ptr(), d_ref.data_ptr(), n, 1, d_core_u.data_ptr())
+        c.vcf_stats_device(d_core_u.data_ptr(), d_out.data_ptr(), 200, n)
+        torch.cuda.synchronize()
+        st_u = c.site_stats().copy()
+        c.reset_site_stats()
+        c.chain_device(d_cts.data_ptr(), d_ref.data_ptr(), 1, n, 0, n, d_core_f.data_ptr(), with_stats=True)
+        torch.cuda.synchronize()
+        st_f = c.site_stats().copy()
+        assert torch.equal(d_core_u, d_core_f)
+        from tests.test_gpu_chain import _same_stats
+
+        _same_stats(st_f, st_u)
+        # a 200 k window against the oracle, byte for byte
+        a, m = 3_141_592, 200_000
+        pile = d_cts[a * 104 : (a + m) * 104].cpu().numpy().view(B.PILEUP)
+        ref = d_ref[a : a + m].cpu().numpy()
+        exp, eskip = oracle.call_sites(pile, ref, tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
+        got = d_out[a * 200 : (a + m) * 200].cpu().numpy().view(B.GT_METH)
+        assert got.tobytes() == exp.tobytes() and (d_skip[a : a + m].cpu().numpy() == eskip).all()
+
+
+def test_sub_launch_loop(oracle, tables, libm_exact, monkeypatch):
+    """A call longer than one launch's cap (2^31 positions: the heterozygous list holds 32-bit indices) is split into
+    sub-launches; with the cap lowered through BSC_MAX_LAUNCH_SITES the loop runs on a block that fits a test."""
+    monkeypatch.setenv("BSC_MAX_LAUNCH_SITES", "65536")
+    n = 300_001  # 4 full sub-launches and a ragged one
+    pile, ref = B.synth_pileup_host(SEED + 9, 0, n, 30)
+    with B.SiteCaller() as c:
+        got, skip = c.call_sites(pile, ref)
+        s = c.stats()
+    exp, eskip = oracle.call_sites(pile, ref, tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
+    assert got.tobytes() == exp.tobytes() and (skip == eskip).all()
+    assert s["sites"] == n and s["covered"] == int((eskip == 0).sum()) and s["het_calls"] == int(B.GT_HET[exp["max_gt"]][eskip == 0].sum())
