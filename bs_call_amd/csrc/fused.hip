@@ -33,7 +33,12 @@
 #include "devtables.h"
 #include "sitestats_dev.h"
 
+#ifndef FW
 #define FW 16 /* waves per workgroup: one 1024-thread workgroup per CU (the statistics histogram lives in its LDS) */
+#endif
+#ifndef BSC_CHAIN_STAGGER
+#define BSC_CHAIN_STAGGER 0 /* A/B variant: wave w of a workgroup starts w * this many 64-cycle sleeps late */
+#endif
 #define FT 60 /* positions a wave-tile produces records for (64 computed) */
 #define F_COV_LDS 256 /* coverage rows of the statistics histogram kept in LDS (deeper positions: global atomics) */
 #define F_WORDS (SS_COV + F_COV_LDS * 6)
@@ -67,6 +72,18 @@ struct bsc_vcf_core_f {
   uint32_t _pad;
 };
 static_assert(sizeof(bsc_vcf_core_f) == 64, "bsc_vcf_core is 64 bytes");
+
+/*
+ * The same LDS-DMA as callmath.h's dma16(), issued through inline assembly so that the compiler's wait-count insertion
+ * does not see it.  Why: for an LDS-DMA it cannot tell which LDS array is written, so it puts `s_waitcnt vmcnt(0)` in
+ * front of EVERY later LDS operation — the histogram updates that are meant to run while the next tile's pile-ups are in
+ * flight would each wait for them.  Hidden operations can only make compiler-computed waits longer, never too short
+ * (the counter retires in order); the wait that matters is the explicit vmcnt(0) at the top of the next tile.
+ */
+__device__ static __forceinline__ void dma16_hidden(const void *g, void *lds_wave_base) {
+  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(g), "s"(l) : "memory", "m0");
+}
 
 /* LDS accesses that hand data from one lane to another inside a wave: the wave runs in lockstep and its LDS operations
  * execute in order, so only the COMPILER has to be told — a wavefront-scope fence orders the memory operations, the
@@ -163,7 +180,7 @@ __device__ static __forceinline__ void f_stats_update(uint32_t *h, const f_facts
 }
 
 template <bool FULL>
-__global__ __launch_bounds__(64 * FW, 4) void bsc_chain_kernel_t(
+__global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     const uint32_t *__restrict__ cts, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dbsnp,
     const bsc_chain_args a, const bsc_dev_tables *__restrict__ tb, uint8_t *__restrict__ core_out,
     unsigned long long *__restrict__ het_list, unsigned long long *__restrict__ counters,
@@ -184,8 +201,8 @@ __global__ __launch_bounds__(64 * FW, 4) void bsc_chain_kernel_t(
   __shared__ uint32_t s_pair[4 * F_PAIR * F_PAIR]; /* CpG cytosines per [ref / non-ref][all / passed][a][b] */
 
   const unsigned tid = threadIdx.x;
-  const unsigned lane = tid & 63u;
-  const unsigned wid = tid >> 6;
+  const unsigned lane0 = tid & 63u;
+  const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6); /* wave-uniform: the per-wave LDS bases live in scalar registers */
   if (tid < 44) {
     s_k[tid] = tb->k[tid];
     s_lnk[tid] = tb->ln_k[tid];
@@ -205,6 +222,8 @@ __global__ __launch_bounds__(64 * FW, 4) void bsc_chain_kernel_t(
   const double t = tb->over_conv;
   const double lrb = tb->lrb, lrb1 = tb->lrb1;
   __syncthreads();
+  if (BSC_CHAIN_STAGGER)
+    for (unsigned i = 0; i < wid; i++) __builtin_amdgcn_s_sleep(BSC_CHAIN_STAGGER);
 
   uint32_t *slot = lds_slot[wid];
   uint32_t *sg = s_gw[wid];
@@ -214,7 +233,20 @@ __global__ __launch_bounds__(64 * FW, 4) void bsc_chain_kernel_t(
   const int64_t ref_lo = (int64_t)a.first - a.lr;
   const int64_t ref_hi = ((int64_t)a.first + a.n + 2 < (int64_t)a.n_block + 2) ? (int64_t)a.first + a.n + 2 : (int64_t)a.n_block + 2;
 
-  for (uint32_t T = a.tile_begin + blockIdx.x * FW + wid; T < a.tile_end; T += gridDim.x * FW) {
+/* the tile's 64 pile-ups (6 656 contiguous bytes, the first on a 16-byte boundary) -> the wave's slot by LDS-DMA */
+#define F_DMA_TILE(TT, DMA)                                                                                             \
+  do {                                                                                                                  \
+    const char *src_ = reinterpret_cast<const char *>(cts + (uint64_t)((int32_t)((TT)*FT) - 2 + (int32_t)a.lc) * IN_DW) + lane * 16; \
+    _Pragma("unroll") for (int j_ = 0; j_ < 6; j_++) DMA(src_ + j_ * 1024, slot + j_ * 256);                            \
+    if (lane < 32) DMA(src_ + 6 * 1024, slot + 6 * 256);                                                                \
+  } while (0)
+  const uint32_t T_first = a.tile_begin + blockIdx.x * FW + wid;
+  for (uint32_t T = T_first; T < a.tile_end; T += gridDim.x * FW) {
+    /* the lane number, made opaque once per tile: otherwise every lane-dependent address of the loop body is hoisted
+     * out of it, kept alive across the whole kernel and — at 128 VGPRs — spilled to scratch (a vector-memory round trip
+     * per use instead of one VALU instruction) */
+    unsigned lane = lane0;
+    asm volatile("" : "+v"(lane));
     const int32_t jw0 = (int32_t)(T * FT) - 2;  /* window-relative index of the site lane 0 computes */
     const int32_t jw = jw0 + (int32_t)lane;
     const bool valid = FULL || (jw >= -(int32_t)a.lc && jw < (int32_t)(a.n + a.rc)); /* the site is in the buffers */
@@ -245,10 +277,10 @@ __global__ __launch_bounds__(64 * FW, 4) void bsc_chain_kernel_t(
     /* ---- my record ---- */
     uint32_t w[IN_DW];
     if (FULL) {
-      const char *src = reinterpret_cast<const char *>(cts + (uint64_t)(jw0 + (int32_t)a.lc) * IN_DW) + lane * 16;
-#pragma unroll
-      for (int j = 0; j < 6; j++) dma16(src + j * 1024, slot + j * 256);
-      if (lane < 32) dma16(src + 6 * 1024, slot + 6 * 256);
+#ifndef BSC_CHAIN_NO_PREFETCH
+      if (T == T_first) /* the wave's first tile; every later one was requested while its predecessor's statistics ran */
+#endif
+        F_DMA_TILE(T, dma16);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const uint2 *rec = reinterpret_cast<const uint2 *>(slot + lane * IN_DW);
 #pragma unroll
@@ -361,7 +393,7 @@ __global__ __launch_bounds__(64 * FW, 4) void bsc_chain_kernel_t(
       {
         const double om = 1.0 - z1;
         const double lg = log_dev(z1 >= 1.0 ? 0.5 : om, s_logtab);
-        phred = (int)(-10.0 * lg / BSM_LN10);
+        phred = (int)div_ln10_dev(-10.0 * lg); /* x / LOG10, correctly rounded (callmath.h) */
         if (phred > 255) phred = 255;
         if (z1 >= 1.0) phred = 255;
       }
@@ -453,6 +485,37 @@ __global__ __launch_bounds__(64 * FW, 4) void bsc_chain_kernel_t(
     }
     spd[lane] = (pend ? 1u : 0u) | (flt << 8);
     WAVE_LDS_SYNC();
+    /* ---- results: the tile's 60 records, staged in the slot (every la[] read is done: the sync above), leave
+     * contiguously — before the statistics, so that the stores drain while the histograms are updated and the sixteen
+     * record dwords are dead by then ---- */
+    {
+      uint4 *so = reinterpret_cast<uint4 *>(slot);
+      if (lane >= 2u && lane < 62u) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) so[(lane - 2u) * 4u + k] = make_uint4(od[4 * k], od[4 * k + 1], od[4 * k + 2], od[4 * k + 3]);
+      }
+      WAVE_LDS_SYNC();
+      const uint32_t i0 = T * FT;
+      const uint32_t nrec = FULL ? (uint32_t)FT : (a.n - i0 < (uint32_t)FT ? a.n - i0 : (uint32_t)FT);
+      const uint32_t nvec = nrec * 4u;
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 *dst = reinterpret_cast<u32x4 *>(core_out + (uint64_t)i0 * 64u);
+#pragma unroll
+      for (unsigned k = 0; k < 4; k++) {
+        const unsigned idx = k * 64u + lane;
+        if (idx < nvec) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(so)[idx], dst + idx);
+      }
+    }
+#ifndef BSC_CHAIN_NO_PREFETCH
+    /* The slot is free from here to the end of the tile (the statistics below touch other LDS arrays only): request the
+     * wave's NEXT tile now, so that its pile-ups land — and the record stores above drain — while the histograms are
+     * updated, instead of the wave sitting out a full HBM round trip at the top of the next tile. */
+    if (FULL) {
+      WAVE_LDS_SYNC();
+      const uint32_t T_next = T + gridDim.x * FW;
+      if (T_next < a.tile_end) F_DMA_TILE(T_next, dma16_hidden);
+    }
+#endif
     if (a.with_stats) {
       /* ---- the statistics block (src/print_vcf.c:386-525; sitestats.hip has the restatement) for the tile ----
        * Wide histograms take one LDS atomic per lane; where one value dominates (QUAL 255, MQ, FS 0, FILTER 0) the
@@ -553,26 +616,6 @@ __global__ __launch_bounds__(64 * FW, 4) void bsc_chain_kernel_t(
       }
     }
 
-    /* ---- results: the tile's 60 records, staged in the slot (every la[] read is done), leave contiguously ---- */
-    WAVE_LDS_SYNC();
-    {
-      uint4 *so = reinterpret_cast<uint4 *>(slot);
-      if (lane >= 2u && lane < 62u) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) so[(lane - 2u) * 4u + k] = make_uint4(od[4 * k], od[4 * k + 1], od[4 * k + 2], od[4 * k + 3]);
-      }
-      WAVE_LDS_SYNC();
-      const uint32_t i0 = T * FT;
-      const uint32_t nrec = FULL ? (uint32_t)FT : (a.n - i0 < (uint32_t)FT ? a.n - i0 : (uint32_t)FT);
-      const uint32_t nvec = nrec * 4u;
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 *dst = reinterpret_cast<u32x4 *>(core_out + (uint64_t)i0 * 64u);
-#pragma unroll
-      for (unsigned k = 0; k < 4; k++) {
-        const unsigned idx = k * 64u + lane;
-        if (idx < nvec) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(so)[idx], dst + idx);
-      }
-    }
     WAVE_LDS_SYNC();
   }
 

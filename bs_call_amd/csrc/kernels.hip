@@ -68,24 +68,31 @@ __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_kernel_t(co
                                                                       unsigned long long *__restrict__ counters) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_slot[TILE / 64][SLOT_DW];
   __shared__ double s_k[44], s_lnk[44], s_half[44], s_one[44];
+#ifdef BSC_TABLES_GLOBAL /* A/B variant (tools/ab_variants.py): the log / exp tables read through L1 instead of LDS */
+  const double *const s_logtab = tb->log_tab;
+  const unsigned long long *const s_exptab = tb->exp_tab;
+#else
   __shared__ double s_logtab[256];
   __shared__ unsigned long long s_exptab[256];
+#endif
   __shared__ unsigned int s_cnt[12]; /* covered, hist[10], het */
   __shared__ uint8_t s_pairs[TILE / 64][256]; /* per wave: the (lane, class) pairs whose logs are needed */
 
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
-  const unsigned wid = tid >> 6;
+  const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6); /* wave-uniform: the slot base lives in scalar registers */
   if (tid < 44) {
     s_k[tid] = tb->k[tid];
     s_lnk[tid] = tb->ln_k[tid];
     s_half[tid] = tb->ln_k_half[tid];
     s_one[tid] = tb->ln_k_one[tid];
   }
+#ifndef BSC_TABLES_GLOBAL
   for (unsigned i = tid; i < 256; i += TILE) {
     s_logtab[i] = tb->log_tab[i];
     s_exptab[i] = tb->exp_tab[i];
   }
+#endif
   if (tid < 12) s_cnt[tid] = 0;
   const double l = 1.0 - tb->under_conv;
   const double t = tb->over_conv;

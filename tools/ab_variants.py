@@ -9,8 +9,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:]
-sites, rounds = 50_000_000, 3
+sites, rounds, chain = 50_000_000, 3, False
 while args and args[0].startswith("--"):
+    if args[0] == "--chain":  # time the fused chain (tools/bench_chain.py) instead of the calling kernel (bench.py)
+        chain = True
+        args = args[1:]
+        continue
     if args[0] == "--sites":
         sites = int(args[1])
     elif args[0] == "--rounds":
@@ -22,11 +26,15 @@ for r in range(rounds):
         env = dict(os.environ)
         if n != "main":
             env["BSCALL_AMD_LIB"] = os.path.join(ROOT, "bs_call_amd", "lib", "variants", "lib_%s.so" % n)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-chain", "--steps", "5", "--warmup", "2",
-                              "--sites", str(sites)], env=env, capture_output=True, text=True)
+        if chain:
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_chain.py"), "--no-unfused", "--steps", "7", "--sites", str(sites)]
+        else:
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-chain", "--steps", "5", "--warmup", "2",
+                   "--sites", str(sites)]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
-            res[n].append(d["roofline"]["kernel_ms_avg"])
+            res[n].append(d["fused_device_ms_last_window"] if chain else d["roofline"]["kernel_ms_avg"])
         except Exception:
             print(n, "FAILED", out.stderr[-500:])
 for n, v in res.items():
