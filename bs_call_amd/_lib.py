@@ -36,6 +36,7 @@ EXPORTS = (
     "bsc_reset_site_stats",
     "bsc_chain_device",
     "bsc_last_chain_ms",
+    "bsc_chain_window_quantum",
     "bsc_prepare_templates",
     "bsc_block_start",
     "bsc_template_qual",
@@ -167,6 +168,8 @@ def load():
     L.bsc_vcf_format.argtypes = [vp, vp, C.c_char_p, C.c_char_p, vp, C.c_size_t]
     L.bsc_chain_device.restype = i32
     L.bsc_chain_device.argtypes = [vp, vp, vp, vp, C.POINTER(Window), C.POINTER(VcfParams), i32, vp, vp]
+    L.bsc_chain_window_quantum.restype = C.c_uint32
+    L.bsc_chain_window_quantum.argtypes = [vp]
     L.bsc_last_chain_ms.restype = i32
     L.bsc_last_chain_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsc_prepare_templates.restype = i32

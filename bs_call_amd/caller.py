@@ -206,6 +206,10 @@ class SiteCaller:
         _check(self._L.bsc_chain_device(self._h, d_cts, d_ref, d_dbsnp, C.byref(w), C.byref(p), 1 if with_stats else 0,
                                         d_core, stream))
 
+    def window_quantum(self) -> int:
+        """Positions one round of the resident waves covers (`bsc_chain_window_quantum`)."""
+        return int(self._L.bsc_chain_window_quantum(self._h))
+
     def last_chain_ms(self):
         ms = C.c_float()
         _check(self._L.bsc_last_chain_ms(self._h, C.byref(ms)))

@@ -32,18 +32,22 @@ int bsc_dev_sort_tmp_bytes(uint32_t nr, size_t *bytes); /* sort.hip */
 int bsc_dev_launch_site_stats(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp, uint32_t n,
                               const void *tb, const void *logp, const void *carry_in, void *carry_out, void *stats,
                               void *pairs, int num_cus, void *stream); /* sitestats.hip */
-int bsc_dev_launch_meth_eval(void *pairs, const void *tb, const void *logp, void *stats, int num_cus, void *stream);
+int bsc_dev_launch_meth_eval(void *pairs, const void *tb, const void *logp, void *stats, const void *ovf_list,
+                             const void *counters, int num_cus, void *stream);
 int bsc_dev_scan_tmp_bytes(uint32_t n, size_t *bytes); /* sort.hip */
 int bsc_dev_launch_stream_probe(const void *cts, const void *ref, uint64_t n, void *out, void *skip, int num_cus,
                                 void *stream); /* probe.hip */
 int bsc_dev_launch_compact(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp, uint32_t n,
                            void *tile_cnt, void *tile_off, void *scan_tmp, size_t scan_tmp_bytes, void *out,
                            uint64_t out_cap, void *total, int num_cus, void *stream); /* compact.hip */
-#define BSC_PAIR_BYTES (4u * 64u * 64u * 8u) /* sitestats.hip: [ref / non-ref][all / passed][a < 64][b < 64] u64 */
+#define BSC_PAIR_BYTES (4ull * 512u * 512u * 8u) /* sitestats_dev.h SS_PAIR_G: [ref / non-ref][all / passed][a < 512][b < 512] u64 */
+#define BSC_OVF_CAP (1u << 20)                   /* sitestats_dev.h SS_OVF_CAP */
 int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const void *ref, const void *dbsnp, uint32_t n,
                        uint32_t x, int all_positions, uint32_t reg_start, uint32_t reg_stop, const void *tb, void *g,
                        void *out, int num_cus, void *stream);
 int bsc_dev_launch_chain(const bsc_chain_launch *L); /* fused.hip */
+unsigned bsc_dev_chain_quantum(int num_cus);
+size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus);
 int bsc_dev_launch_synth(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags, void *cts,
                          void *ref, int num_cus, void *stream);
 
@@ -68,9 +72,7 @@ struct bsc_context {
   size_t cap_het;
   uint64_t max_launch; /* positions per launch of the calling kernel (BSC_MAX_LAUNCH; BSC_MAX_LAUNCH_SITES in the
                           environment lowers it so that the sub-launch loop of longer calls can be tested) */
-  int het_dirty; /* bsc_call_sites_device left a heterozygous list behind (the fused chain expects an empty one) */
-  void *d_ovf; /* fused chain: CpG cytosines beyond the methylation pair table (8 bytes each) */
-  size_t cap_ovf;
+  void *d_ovf; /* fused chain: CpG cytosines beyond the methylation pair table (BSC_OVF_CAP entries of 8 bytes) */
   hipEvent_t ev_chain[2]; /* bsc_set_profiling: the fused chain's launches */
   int ev_chain_valid;
   /* accumulate stage */
@@ -303,7 +305,7 @@ int bsc_destroy(bsc_context *ctx) {
   if (ctx->s_out) hipStreamDestroy(ctx->s_out);
   hipFree(ctx->d_vg);
   hipFree(ctx->d_sstats);
-  hipFree(ctx->d_pairs);
+    hipFree(ctx->d_pairs);
   hipFree(ctx->d_tcnt);
   hipFree(ctx->d_toff);
   hipFree(ctx->d_scantmp);
@@ -375,7 +377,6 @@ int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref
                                 ctx->profiling ? ctx->ev[0] : NULL, ctx->profiling ? ctx->ev[1] : NULL,
                                 ctx->profiling ? ctx->ev[2] : NULL);
     if (ctx->profiling) ctx->ev_valid = 1;
-    ctx->het_dirty = 1;
     if (e) return bsc_fail(BSC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     done += m;
   }
@@ -822,32 +823,24 @@ int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, con
   if (!d_cts || !d_ref || !d_core) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: NULL buffer");
   if ((uint64_t)w->first + w->n > w->n_block)
     return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: window %u + %u exceeds the block (%u positions)", w->first, w->n, w->n_block);
-  if (w->n > 0x7ffffff0u) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: window too long");
+  if (w->n > 0x0fffffffu) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: window longer than 2^28 - 1 positions");
   if ((uint64_t)w->x + w->n_block > 0xffffffffull) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: positions exceed 32 bits");
   if (((uintptr_t)d_core & 15u) || ((uintptr_t)d_cts & 7u))
     return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: d_core must be 16-byte and d_cts 8-byte aligned");
   BSC_ENTER(ctx);
-  hipStream_t s = (hipStream_t)stream;
-  int rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, (size_t)w->n * 8u);
+  int rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, bsc_dev_chain_het_bytes(w->n, ctx->num_cus));
   if (rc) return rc;
   bsc_chain_launch L;
   memset(&L, 0, sizeof L);
   if (with_stats) {
     if ((rc = bsc_sstats_init(ctx))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_ovf, &ctx->cap_ovf, (size_t)w->n * 8u))) return rc;
     L.carry_in = ctx->d_carry + 2 * ctx->carry_slot;
     L.carry_out = ctx->d_carry + 2 * (ctx->carry_slot ^ 1u);
     L.stats = ctx->d_sstats;
     L.pairs = ctx->d_pairs;
     L.ovf_list = ctx->d_ovf;
-    L.ovf_cap = w->n;
+    L.ovf_cap = BSC_OVF_CAP;
     L.logp = ctx->d_logp;
-  }
-  /* the het-list / overflow-list lengths are zero here: bsc_chain_het_kernel empties them (no memsets per window) —
-   * unless the unfused calling kernel ran on this context in between */
-  if (ctx->het_dirty) {
-    HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_HET_LIST, 0, sizeof(unsigned long long), s));
-    ctx->het_dirty = 0;
   }
   const uint32_t after = w->n_block - w->first - w->n;
   L.cts = d_cts;
@@ -878,16 +871,13 @@ int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, con
     ctx->ev_chain_valid = 1;
   }
   int e = bsc_dev_launch_chain(&L);
-  if (e) { /* a partial launch may leave the list lengths set: put them back before anything else uses them */
-    (void)hipStreamSynchronize((hipStream_t)stream);
-    (void)hipMemset(ctx->d_counters + BSC_CNT_HET_LIST, 0, sizeof(unsigned long long));
-    (void)hipMemset(ctx->d_counters + BSC_CNT_OVF, 0, 2 * sizeof(unsigned long long));
-    return bsc_fail(BSC_ERR_HIP, "chain launch failed: %s", hipGetErrorString((hipError_t)e));
-  }
+  if (e) return bsc_fail(BSC_ERR_HIP, "chain launch failed: %s", hipGetErrorString((hipError_t)e));
   if (with_stats) ctx->carry_slot ^= 1u;
   ctx->sites += w->n;
   return BSC_OK;
 }
+
+uint32_t bsc_chain_window_quantum(const bsc_context *ctx) { return ctx ? bsc_dev_chain_quantum(ctx->num_cus) : 0u; }
 
 int bsc_last_chain_ms(bsc_context *ctx, float *ms) {
   if (!ctx || !ms) return bsc_fail(BSC_ERR_ARG, "bsc_last_chain_ms: NULL argument");
@@ -974,14 +964,17 @@ static int bsc_sstats_init(bsc_context *ctx) {
   if (hipMalloc(&ctx->d_sstats, sizeof(bsc_site_stats)) != hipSuccess ||
       hipMalloc(&ctx->d_pairs, BSC_PAIR_BYTES) != hipSuccess || hipMemset(ctx->d_pairs, 0, BSC_PAIR_BYTES) != hipSuccess ||
       hipMalloc((void **)&ctx->d_carry, 4 * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(&ctx->d_ovf, (size_t)BSC_OVF_CAP * 8u) != hipSuccess ||
       hipMalloc((void **)&ctx->d_logp, sizeof logp) != hipSuccess ||
       hipMemset(ctx->d_sstats, 0, sizeof(bsc_site_stats)) != hipSuccess ||
       hipMemset(ctx->d_carry, 0, 4 * sizeof(uint32_t)) != hipSuccess ||
       hipMemcpy(ctx->d_logp, logp, sizeof logp, hipMemcpyHostToDevice) != hipSuccess) {
     hipFree(ctx->d_sstats);
-  hipFree(ctx->d_pairs);
+    hipFree(ctx->d_pairs);
     hipFree(ctx->d_carry);
     hipFree(ctx->d_logp);
+    hipFree(ctx->d_ovf);
+    ctx->d_ovf = NULL;
     ctx->d_sstats = NULL;
     ctx->d_carry = NULL;
     ctx->d_logp = NULL;
@@ -1039,10 +1032,18 @@ int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out) {
     return BSC_OK;
   }
   HIP_TRY(hipDeviceSynchronize()); /* the statistics kernels run on whatever stream the caller chose */
-  int e = bsc_dev_launch_meth_eval(ctx->d_pairs, ctx->d_tables, ctx->d_logp, ctx->d_sstats, ctx->num_cus, ctx->stream);
+  int e = bsc_dev_launch_meth_eval(ctx->d_pairs, ctx->d_tables, ctx->d_logp, ctx->d_sstats, ctx->d_ovf, ctx->d_counters,
+                                   ctx->num_cus, ctx->stream);
   if (e) return bsc_fail(BSC_ERR_HIP, "methylation profile launch failed: %s", hipGetErrorString((hipError_t)e));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  unsigned long long n_ovf = 0;
+  HIP_TRY(hipMemcpy(&n_ovf, ctx->d_counters + BSC_CNT_OVF, sizeof n_ovf, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(ctx->d_counters + BSC_CNT_OVF, 0, sizeof n_ovf));
   HIP_TRY(hipMemcpy(out, ctx->d_sstats, sizeof *out, hipMemcpyDeviceToHost));
+  if (n_ovf > BSC_OVF_CAP)
+    return bsc_fail(BSC_ERR_RANGE, "bsc_get_site_stats: %llu CpG cytosines with 512 or more informative reads of one kind since the "
+                                   "statistics were last read, %u can be listed: their share of the methylation profiles is missing",
+                    n_ovf, BSC_OVF_CAP);
   return BSC_OK;
 }
 
@@ -1053,6 +1054,7 @@ int bsc_reset_site_stats(bsc_context *ctx) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(ctx->d_sstats, 0, sizeof(bsc_site_stats)));
   HIP_TRY(hipMemset(ctx->d_pairs, 0, BSC_PAIR_BYTES));
+  HIP_TRY(hipMemset(ctx->d_counters + BSC_CNT_OVF, 0, sizeof(unsigned long long)));
   HIP_TRY(hipMemset(ctx->d_carry, 0, 4 * sizeof(uint32_t)));
   ctx->carry_slot = 0;
   return BSC_OK;

@@ -23,8 +23,8 @@ typedef struct {
 #define BSC_CNT_INEXACT 14 /* accumulate: lanes whose quality / MAPQ^2 sums left the exact-float range */
 #define BSC_CNT_ERR 15     /* accumulate: min over invalid templates of (index << 8 | BSC_TERR_*); all ones = none */
 #define BSC_CNT_RECORDS 16 /* bsc_block_records: written records of the block being packed */
-#define BSC_CNT_OVF 17     /* fused chain: CpG cytosines beyond the methylation pair table, listed (reset per launch) */
-#define BSC_CNT_TICKET 18  /* fused chain: workgroups of bsc_chain_het_kernel that have finished (the last one resets the lists) */
+#define BSC_CNT_OVF 17     /* fused chain: CpG cytosines beyond the methylation pair table, listed until the statistics are read */
+#define BSC_CNT_SPARE 18
 #define BSC_CNT_WORDS 19
 
 /* what the reference asserts about a block's templates (src/call_genotypes.c:186-188) plus the bounds of the read

@@ -42,7 +42,7 @@
 #define FT 60 /* positions a wave-tile produces records for (64 computed) */
 #define F_COV_LDS 256 /* coverage rows of the statistics histogram kept in LDS (deeper positions: global atomics) */
 #define F_WORDS (SS_COV + F_COV_LDS * 6)
-#define F_PAIR 32 /* (a, b) < F_PAIR: CpG cytosines counted in the workgroup's LDS pair table; up to SS_PAIR: global */
+#define F_PAIR 32 /* (a, b) < F_PAIR: CpG cytosines counted in the workgroup's LDS pair table; up to SS_PAIR_G: global */
 
 struct bsc_chain_args {
   uint32_t x;       /* genome position (1-based) of the block's first position */
@@ -56,6 +56,7 @@ struct bsc_chain_args {
   uint32_t reg_start, reg_stop;
   int32_t with_stats;
   uint32_t ovf_cap;
+  uint32_t het_cap; /* entries of a wave's heterozygous list */
 };
 
 struct bsc_vcf_core_f {
@@ -151,7 +152,7 @@ __device__ static __forceinline__ void f_stats_update(uint32_t *h, const f_facts
   F_COV_ADD(F.emit, F.cdp, 1u);
   ss_hist_add<1>(h, F.emit, SS_MISC + 0, 0u);
   ss_hist_add<1>(h, F.emit && F.pass, SS_MISC + 1, 0u);
-  ss_hist_add<2>(h, F.emit, SS_QUAL + 0 * 256, F.phred, SS_QUAL + 1 * 256);
+  ss_hist_add<2>(h, F.emit, SS_QUAL + 1 * 256, F.phred); /* qual[variant_sites]; the workgroup copies it to [all_sites] at the end */
   ss_hist_add<2>(h, F.emit, SS_FST + 0 * 512, F.qd * 2u + F.het);
   ss_hist_add<2>(h, F.emit && F.fs_ok, SS_FST + 1 * 512, F.fsv * 2u + F.het);
   ss_hist_add<2>(h, F.emit, SS_FST + 2 * 512, F.mqv * 2u + F.het);
@@ -179,17 +180,95 @@ __device__ static __forceinline__ void f_stats_update(uint32_t *h, const f_facts
 #undef F_COV_ADD
 }
 
+/*
+ * The heterozygous calls a wave has collected (lane k < n_pend holds one): Fisher's exact test on the strand table
+ * (src/call_genotypes.c:61-108, src/stats_utils.c:25-91), FS and the FILTER bits that depend on it patched into the
+ * record the wave stored earlier, the position's statistics.  The whole wave calls this (wave-uniform control flow);
+ * the records are read back from memory, so the caller has waited for its record stores (vmcnt).
+ */
+__device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigned n_pend, unsigned lane, const uint32_t *__restrict__ cts,
+                                                        const uint8_t *__restrict__ dbsnp, const bsc_chain_args &a,
+                                                        uint8_t *__restrict__ core_out, const double *s_lf, const double *s_logtab,
+                                                        const unsigned long long *s_exptab, uint32_t *h,
+                                                        unsigned long long *__restrict__ stat_words) {
+  f_facts F;
+  F.called = F.emit = F.pass = F.het = F.rs = F.cpg_site = F.ref_cpg = F.pair = F.pair_pass = F.fs_ok = F.do_meth = false;
+  F.phred = F.flt = F.qd = F.fsv = F.mqv = F.cdp = F.cinf = F.m_a = F.m_b = 0;
+  F.mut = 12;
+  if (lane < n_pend) {
+    const uint32_t i = pend_e & 0x0fffffffu;
+    const unsigned mxi = pend_e >> 28;
+    const uint32_t *p = cts + (uint64_t)(i + a.lc) * IN_DW;
+    uint32_t f[8], r[8], c[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      f[j] = p[j];
+      r[j] = p[8 + j];
+      c[j] = f[j] + r[j];
+    }
+    int t0, t1, t2, t3;
+    strand_table(mxi, f, r, t0, t1, t2, t3);
+    double z = fisher_dev(t0, t1, t2, t3, s_lf, s_logtab, (const uint64_t *)s_exptab);
+    if (z < 1.0e-20) z = 1.0e-20;
+    const double fisher = bsm_log_t(z, s_logtab) / BSM_LN10; /* gt_meth.fisher_strand (:105-107) */
+    const int fs = (int)(-fisher * 10.0 + 0.5);                /* src/print_vcf.c:151 */
+    uint8_t *rec = core_out + (uint64_t)i * 64u;
+    const uint4 c0 = *reinterpret_cast<const uint4 *>(rec);
+    if (c0.x != 0) { /* the position reached _print_vcf_entry with depth > 0 */
+      const bool emit = (c0.y & 0xffu) != 0;
+      const int gt = (int)((c0.y >> 8) & 0xffu), rfix = (int)((c0.y >> 16) & 0xffu);
+      const uint32_t phred = (c0.z >> 8) & 0xffu;
+      const uint32_t qd = *reinterpret_cast<const uint32_t *>(rec + 28);
+      /* mq as the calling statements form it (call_body.inc; src/call_genotypes.c:59) */
+      const uint32_t n_reads = p[16];
+      const float mapq2 = __uint_as_float(p[25]);
+      const int mq = (int)(0.5 + sqrt((double)(mapq2 / (float)n_reads)));
+      int ga, gb;
+      f_alleles(gt, ga, gb);
+      const bool het = ga != gb; /* the printer's genotype; max_gt differs from it only in a rounding tie */
+      uint32_t flt = 0;
+      *reinterpret_cast<int32_t *>(rec + 24) = fs;
+      if (emit) {
+        if (phred < 20) flt |= 1;
+        if (qd < 2) flt |= 2;
+        if (fs > 60) flt |= 4;
+        if (mq < 40) flt |= 8;
+        if (!flt && het && f_mac1(gt, c)) flt |= 128;
+        rec[8] = (uint8_t)flt;
+      }
+      const uint32_t d_inf = c[4] + c[5] + c[6] + c[7], dpt = c[0] + c[1] + c[2] + c[3] + d_inf;
+      F.called = true;
+      F.emit = emit;
+      F.flt = flt;
+      F.phred = phred;
+      F.qd = qd > 255u ? 255u : qd;
+      F.fs_ok = fs >= 0;
+      F.fsv = (uint32_t)(fs > 255 ? 255 : (fs < 0 ? 0 : fs));
+      F.mqv = (uint32_t)(mq < 0 ? 0 : (mq > 255 ? 255 : mq));
+      F.cdp = dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u;
+      if (emit) {
+        F.pass = flt == 0;
+        F.rs = dbsnp ? dbsnp[i] != 0 : false;
+        F.het = het;
+        F.mut = ss_mut_type(gt, rfix);
+      }
+    }
+  }
+  if (a.with_stats) f_stats_update(h, F, stat_words);
+}
+
 template <bool FULL>
 __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     const uint32_t *__restrict__ cts, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dbsnp,
     const bsc_chain_args a, const bsc_dev_tables *__restrict__ tb, uint8_t *__restrict__ core_out,
-    unsigned long long *__restrict__ het_list, unsigned long long *__restrict__ counters,
+    uint32_t *__restrict__ het_list, unsigned long long *__restrict__ counters,
     const uint32_t *__restrict__ carry_in, uint32_t *__restrict__ carry_out, unsigned long long *__restrict__ stat_words,
     unsigned long long *__restrict__ pair_cells, unsigned long long *__restrict__ ovf_list) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_slot[FW][SLOT_DW];
   __shared__ double s_k[44], s_lnk[44], s_half[44], s_one[44];
   __shared__ double s_logtab[256];
   __shared__ unsigned long long s_exptab[256];
+  __shared__ double s_lf[256];        /* ln x! for x < 256 (Fisher's test of the heterozygous calls) */
   __shared__ unsigned int s_cnt[12];  /* covered, hist[10], het */
   __shared__ uint8_t s_pairs[FW][256]; /* per wave: the (lane, class) pairs whose logs are needed (call_body.inc) */
   __shared__ uint32_t s_gw[FW][64];    /* per wave and computed site: the printer's called genotype + 1 (0 = none) | its
@@ -212,6 +291,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
   if (tid < 256) {
     s_logtab[tid] = tb->log_tab[tid];
     s_exptab[tid] = tb->exp_tab[tid];
+    s_lf[tid] = tb->lfact[tid];
   }
   if (tid < 12) s_cnt[tid] = 0;
   if (a.with_stats) {
@@ -241,6 +321,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     if (lane < 32) DMA(src_ + 6 * 1024, slot + 6 * 256);                                                                \
   } while (0)
   const uint32_t T_first = a.tile_begin + blockIdx.x * FW + wid;
+  /* heterozygous calls waiting for Fisher's test (window index | max_gt << 28): the wave's own list in HBM, one in ~1 000
+   * positions; a.het_cap entries hold every position the wave can meet */
+  uint32_t *wl = het_list + (uint64_t)(blockIdx.x * FW + wid) * a.het_cap;
+  unsigned n_pend = 0; /* wave-uniform */
   for (uint32_t T = T_first; T < a.tile_end; T += gridDim.x * FW) {
     /* the lane number, made opaque once per tile: otherwise every lane-dependent address of the loop body is hoisted
      * out of it, kept alive across the whole kernel and — at 128 VGPRs — spilled to scratch (a vector-memory round trip
@@ -297,21 +381,11 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     const unsigned rf = valid ? (unsigned)srf[lane + 2u] & 0xffu : 0u; /* my site's reference code (lane index = lane) */
 #include "call_body.inc"
 
-    /* ---- block counters and the heterozygous list (window positions only, not the halo) ---- */
-    const bool defer = covered && inner && ((0x16Eu >> mxi) & 1u); /* gt_het[max_gt]: Fisher's test (:61) */
+    /* ---- block counters (window positions only, not the halo) ---- */
+    const bool defer = covered && inner && ((0x16Eu >> mxi) & 1u); /* gt_het[max_gt]: Fisher's test (:61), after the tile */
     if (covered && inner) {
       atomicAdd(&s_cnt[0], 1u);
       atomicAdd(&s_cnt[1 + mxi], 1u);
-    }
-    {
-      const unsigned long long m = __ballot(defer);
-      if (m) {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&counters[BSC_CNT_HET_LIST], (unsigned long long)__popcll(m));
-        base = __shfl(base, 0);
-        if (defer) het_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned long long)(uint32_t)jw | ((unsigned long long)mxi << 32);
-        if (lane == 0) atomicAdd(&s_cnt[11], (unsigned)__popcll(m));
-      }
     }
 
     /* ---- the printer's genotype: first-max argmax of gt_prob[], recomputed (src/print_vcf.c:584-591) ----
@@ -506,6 +580,14 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
         if (idx < nvec) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(so)[idx], dst + idx);
       }
     }
+    /* ---- heterozygous calls: listed, Fisher's test after the wave's last tile ---- */
+    {
+      const unsigned long long m = __ballot(defer);
+      if (m) {
+        if (defer) wl[n_pend + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)jw | ((uint32_t)mxi << 28);
+        n_pend += (unsigned)__popcll(m);
+      }
+    }
 #ifndef BSC_CHAIN_NO_PREFETCH
     /* The slot is free from here to the end of the tile (the statistics below touch other LDS arrays only): request the
      * wave's NEXT tile now, so that its pile-ups land — and the record stores above drain — while the histograms are
@@ -585,10 +667,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
                 const uint32_t cell = (rsel * F_PAIR + st_ma) * F_PAIR + st_mb;
                 atomicAdd(&s_pair[cell], 1u);
                 if (pass) atomicAdd(&s_pair[cell + F_PAIR * F_PAIR], 1u);
-              } else if (st_ma < SS_PAIR && st_mb < SS_PAIR) {
-                const uint32_t cell = (rsel * SS_PAIR + st_ma) * SS_PAIR + st_mb;
+              } else if (st_ma < SS_PAIR_G && st_mb < SS_PAIR_G) {
+                const uint32_t cell = (rsel * SS_PAIR_G + st_ma) * SS_PAIR_G + st_mb;
                 atomicAdd(&pair_cells[cell], 1ull);
-                if (pass) atomicAdd(&pair_cells[cell + SS_PAIR * SS_PAIR], 1ull);
+                if (pass) atomicAdd(&pair_cells[cell + SS_PAIR_G * SS_PAIR_G], 1ull);
               } else {
                 const unsigned long long k = atomicAdd(&counters[BSC_CNT_OVF], 1ull);
                 if (k < a.ovf_cap)
@@ -619,6 +701,19 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     WAVE_LDS_SYNC();
   }
 
+  /* ---- the wave's heterozygous calls: Fisher's exact test, 64 at a time ----
+   * A het is one position in ~1 000: tested inside its tile it would idle 63 lanes for the length of Fisher's loops in
+   * every such tile, tested by a kernel of its own it costs a launch and a drained device per window. */
+  if (n_pend) {
+    if (lane0 == 0) atomicAdd(&s_cnt[11], n_pend);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the wave's records and its list are in memory */
+    for (unsigned k0 = 0; k0 < n_pend; k0 += 64u) {
+      const unsigned nb = n_pend - k0 < 64u ? n_pend - k0 : 64u;
+      const uint32_t e = lane0 < nb ? __hip_atomic_load(&wl[k0 + lane0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      f_fisher_pending(e, nb, lane0, cts, dbsnp, a, core_out, s_lf, s_logtab, s_exptab, h, stat_words);
+    }
+  }
+
   __syncthreads();
   if (tid < 12 && s_cnt[tid]) atomicAdd(&counters[BSC_CNT_COVERED + tid], (unsigned long long)s_cnt[tid]);
   if (a.with_stats) {
@@ -629,165 +724,31 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
         if (i >= SS_QUAL + 256u && i < SS_QUAL + 512u) atomicAdd(&stat_words[i - 256u], (unsigned long long)h[i]);
       }
     for (unsigned i = tid; i < 4 * F_PAIR * F_PAIR; i += 64 * FW)
-      if (s_pair[i]) { /* LDS cell [q][a][b] -> the context's [q][SS_PAIR][SS_PAIR] table */
+      if (s_pair[i]) { /* LDS cell [q][a][b] -> the context's [q][SS_PAIR_G][SS_PAIR_G] table */
         const unsigned q = i / (F_PAIR * F_PAIR), ab = i % (F_PAIR * F_PAIR);
-        atomicAdd(&pair_cells[(q * SS_PAIR + ab / F_PAIR) * SS_PAIR + ab % F_PAIR], (unsigned long long)s_pair[i]);
+        atomicAdd(&pair_cells[(q * SS_PAIR_G + ab / F_PAIR) * SS_PAIR_G + ab % F_PAIR], (unsigned long long)s_pair[i]);
       }
-  }
-}
-
-/*
- * Heterozygous calls: Fisher's exact test on the strand table (src/call_genotypes.c:61-108, src/stats_utils.c:25-91),
- * FS and the FILTER bits that depend on it patched into the record, the position's statistics.  One lane per listed
- * position; the histogram updates are made by whole waves.
- */
-extern "C" __global__ __launch_bounds__(256) void bsc_chain_het_kernel(
-    const uint32_t *__restrict__ cts, const uint8_t *__restrict__ dbsnp, const bsc_chain_args a,
-    const bsc_dev_tables *__restrict__ tb, uint8_t *__restrict__ core_out, const unsigned long long *__restrict__ het_list,
-    unsigned long long *__restrict__ counters, unsigned long long *__restrict__ stat_words,
-    const unsigned long long *__restrict__ ovf_list, const double *__restrict__ logp) {
-  __shared__ double s_lf[256];
-  __shared__ double s_logtab[256];
-  __shared__ unsigned long long s_exptab[256];
-  __shared__ uint32_t h[F_WORDS];
-  __shared__ double s_meth[4 * 101];
-  __shared__ double s_logp[100];
-  s_lf[threadIdx.x] = tb->lfact[threadIdx.x];
-  s_logtab[threadIdx.x] = tb->log_tab[threadIdx.x];
-  s_exptab[threadIdx.x] = tb->exp_tab[threadIdx.x];
-  if (a.with_stats) {
-    for (unsigned i = threadIdx.x; i < F_WORDS; i += 256) h[i] = 0;
-    for (unsigned i = threadIdx.x; i < 404; i += 256) s_meth[i] = 0.0;
-    if (threadIdx.x < 100) s_logp[threadIdx.x] = logp[threadIdx.x];
-  }
-  __syncthreads();
-  const unsigned long long nhet = counters[BSC_CNT_HET_LIST];
-  const unsigned long long n_round = (nhet + 63ull) & ~63ull;
-  for (unsigned long long idx = (unsigned long long)blockIdx.x * 256u + threadIdx.x; idx < n_round;
-       idx += (unsigned long long)gridDim.x * 256u) {
-    f_facts F;
-    F.called = F.emit = F.pass = F.het = F.rs = F.cpg_site = F.ref_cpg = F.pair = F.pair_pass = F.fs_ok = F.do_meth = false;
-    F.phred = F.flt = F.qd = F.fsv = F.mqv = F.cdp = F.cinf = F.m_a = F.m_b = 0;
-    F.mut = 12;
-    if (idx < nhet) {
-      const unsigned long long e = het_list[idx];
-      const uint32_t i = (uint32_t)e;
-      const unsigned mxi = (unsigned)(e >> 32);
-      const uint32_t *p = cts + (uint64_t)(i + a.lc) * IN_DW;
-      uint32_t f[8], r[8], c[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        f[j] = p[j];
-        r[j] = p[8 + j];
-        c[j] = f[j] + r[j];
-      }
-      int t0, t1, t2, t3;
-      strand_table(mxi, f, r, t0, t1, t2, t3);
-      double z = fisher_dev(t0, t1, t2, t3, s_lf, s_logtab, (const uint64_t *)s_exptab);
-      if (z < 1.0e-20) z = 1.0e-20;
-      const double fisher = bsm_log_t(z, s_logtab) / BSM_LN10; /* gt_meth.fisher_strand (:105-107) */
-      const int fs = (int)(-fisher * 10.0 + 0.5);                /* src/print_vcf.c:151 */
-      uint8_t *rec = core_out + (uint64_t)i * 64u;
-      const uint4 c0 = *reinterpret_cast<const uint4 *>(rec);
-      if (c0.x != 0) { /* the position reached _print_vcf_entry with depth > 0 */
-        const bool emit = (c0.y & 0xffu) != 0;
-        const int gt = (int)((c0.y >> 8) & 0xffu), rfix = (int)((c0.y >> 16) & 0xffu);
-        const uint32_t phred = (c0.z >> 8) & 0xffu;
-        const uint32_t qd = *reinterpret_cast<const uint32_t *>(rec + 28);
-        /* mq as the calling statements form it (call_body.inc; src/call_genotypes.c:59) */
-        const uint32_t n_reads = p[16];
-        const float mapq2 = __uint_as_float(p[25]);
-        const int mq = (int)(0.5 + sqrt((double)(mapq2 / (float)n_reads)));
-        int ga, gb;
-        f_alleles(gt, ga, gb);
-        const bool het = ga != gb; /* the printer's genotype; max_gt differs from it only in a rounding tie */
-        uint32_t flt = 0;
-        *reinterpret_cast<int32_t *>(rec + 24) = fs;
-        if (emit) {
-          if (phred < 20) flt |= 1;
-          if (qd < 2) flt |= 2;
-          if (fs > 60) flt |= 4;
-          if (mq < 40) flt |= 8;
-          if (!flt && het && f_mac1(gt, c)) flt |= 128;
-          rec[8] = (uint8_t)flt;
-        }
-        const uint32_t d_inf = c[4] + c[5] + c[6] + c[7], dpt = c[0] + c[1] + c[2] + c[3] + d_inf;
-        F.called = true;
-        F.emit = emit;
-        F.flt = flt;
-        F.phred = phred;
-        F.qd = qd > 255u ? 255u : qd;
-        F.fs_ok = fs >= 0;
-        F.fsv = (uint32_t)(fs > 255 ? 255 : (fs < 0 ? 0 : fs));
-        F.mqv = (uint32_t)(mq < 0 ? 0 : (mq > 255 ? 255 : mq));
-        F.cdp = dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u;
-        if (emit) {
-          F.pass = flt == 0;
-          F.rs = dbsnp ? dbsnp[i] != 0 : false;
-          F.het = het;
-          F.mut = ss_mut_type(gt, rfix);
-        }
-      }
-    }
-    if (a.with_stats) f_stats_update(h, F, stat_words);
-  }
-  /* CpG cytosines whose informative counts exceed the pair table, listed by the main kernel: one wave per cytosine,
-   * two bins of the posterior per lane (src/print_vcf.c:492-515) */
-  if (a.with_stats) {
-    unsigned long long n_ovf = counters[BSC_CNT_OVF];
-    if (n_ovf > a.ovf_cap) n_ovf = a.ovf_cap;
-    if (n_ovf) { /* grid-uniform */
-      const unsigned lane = threadIdx.x & 63u;
-      double acc[2][2][2];
-#pragma unroll
-      for (int x = 0; x < 2; x++)
-        for (int y = 0; y < 2; y++) acc[x][y][0] = acc[x][y][1] = 0.0;
-      for (unsigned long long k = (unsigned long long)blockIdx.x * 4u + (threadIdx.x >> 6); k < n_ovf;
-           k += (unsigned long long)gridDim.x * 4u) {
-        const unsigned long long e = ovf_list[k];
-        const uint32_t ca = (uint32_t)(e & 0xffffffu), cb = (uint32_t)((e >> 24) & 0xffffffu);
-        const bool is_ref = (e >> 48) & 1u, is_pass = (e >> 49) & 1u;
-        double z2[2];
-        ss_posterior(ca, cb, lane, s_lf, s_logtab, s_logp, s_exptab, z2);
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-          acc[is_ref ? 0 : 1][0][r] += z2[r];
-          if (is_pass) acc[is_ref ? 0 : 1][1][r] += z2[r];
-        }
-      }
-#pragma unroll
-      for (int rf = 0; rf < 2; rf++)
-        for (int ps = 0; ps < 2; ps++)
-          for (int r = 0; r < 2; r++) {
-            const unsigned bin = lane + 64u * r;
-            if (bin < 101 && acc[rf][ps][r] != 0.0) atomicAdd(&s_meth[(rf * 2 + ps) * 101 + bin], acc[rf][ps][r]);
-          }
-    }
-  }
-  __syncthreads();
-  if (a.with_stats) {
-    for (unsigned i = threadIdx.x; i < F_WORDS; i += 256)
-      if (h[i]) atomicAdd(&stat_words[i], (unsigned long long)h[i]);
-    double *out_meth = reinterpret_cast<double *>(reinterpret_cast<char *>(stat_words) + offsetof(bsc_site_stats, CpG_ref_meth));
-    for (unsigned i = threadIdx.x; i < 404; i += 256)
-      if (s_meth[i] != 0.0) atomicAdd(&out_meth[i], s_meth[i]);
-  }
-  /* the last workgroup to finish empties the two lists for the next call (every workgroup has read their lengths by
-   * then: it took its ticket after its last use) */
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long t = atomicAdd(&counters[BSC_CNT_TICKET], 1ull);
-    if (t == (unsigned long long)gridDim.x - 1ull) {
-      counters[BSC_CNT_HET_LIST] = 0ull;
-      counters[BSC_CNT_OVF] = 0ull;
-      counters[BSC_CNT_TICKET] = 0ull;
-    }
   }
 }
 
 /* ---- launcher ------------------------------------------------------------------------------------------------ */
-/* counters[BSC_CNT_HET_LIST], [BSC_CNT_OVF] and [BSC_CNT_TICKET] must be zero on entry: they are at context creation,
- * and bsc_chain_het_kernel leaves them so */
+/* positions one round of the resident waves covers: a window that is a whole number of these gives every wave the same
+ * number of tiles (no partly filled last round) */
+extern "C" unsigned bsc_dev_chain_quantum(int num_cus) { return (unsigned)num_cus * FW * FT; }
+
+/* entries of one wave's heterozygous list when `tiles` tiles are spread over `grid` workgroups: every position of its
+ * tiles, rounded to whole 128-byte lines (no line shared between two waves) */
+static uint32_t chain_het_cap(uint32_t tiles, unsigned grid) {
+  const uint32_t rounds = (tiles + grid * FW - 1) / (grid * FW);
+  return (rounds * FT + 31u) & ~31u;
+}
+
+/* bytes the per-wave heterozygous lists of a window of n positions take, at most */
+extern "C" size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus) {
+  const uint64_t tiles = ((uint64_t)n + FT - 1) / FT, waves = (uint64_t)num_cus * FW;
+  return (size_t)((tiles + waves) * FT + waves * 32u) * sizeof(uint32_t);
+}
+
 extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
   if (L->n == 0) return 0;
   hipStream_t s = (hipStream_t)L->stream;
@@ -815,7 +776,7 @@ extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
   if (L->ev_start) (void)hipEventRecord((hipEvent_t)L->ev_start, s);
 #define CHAIN_ARGS(A)                                                                                               \
   (const uint32_t *)L->cts, (const uint8_t *)L->ref, (const uint8_t *)L->dbsnp, A, (const bsc_dev_tables *)L->tb,   \
-      (uint8_t *)L->core_out, (unsigned long long *)L->het_list, (unsigned long long *)L->counters,                 \
+      (uint8_t *)L->core_out, (uint32_t *)L->het_list, (unsigned long long *)L->counters,                           \
       (const uint32_t *)L->carry_in, (uint32_t *)L->carry_out, words, (unsigned long long *)L->pairs,               \
       (unsigned long long *)L->ovf_list
   if (t_hi > t_lo) {
@@ -823,6 +784,7 @@ extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
     a.tile_end = t_hi;
     unsigned grid = (t_hi - t_lo + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus; /* one 1024-thread workgroup per CU, persistent */
+    a.het_cap = chain_het_cap(t_hi - t_lo, grid);
     hipLaunchKernelGGL(bsc_chain_kernel_t<true>, dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -834,17 +796,12 @@ extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
     a.tile_end = edge[k][1];
     unsigned grid = (a.tile_end - a.tile_begin + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
+    a.het_cap = chain_het_cap(a.tile_end - a.tile_begin, grid);
     hipLaunchKernelGGL(bsc_chain_kernel_t<false>, dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
 #undef CHAIN_ARGS
-  a.tile_begin = 0;
-  a.tile_end = n_tiles;
-  hipLaunchKernelGGL(bsc_chain_het_kernel, dim3((unsigned)L->num_cus), dim3(256), 0, s, (const uint32_t *)L->cts,
-                     (const uint8_t *)L->dbsnp, a, (const bsc_dev_tables *)L->tb, (uint8_t *)L->core_out,
-                     (const unsigned long long *)L->het_list, (unsigned long long *)L->counters, words,
-                     (const unsigned long long *)L->ovf_list, (const double *)L->logp);
   hipError_t e = hipGetLastError();
   if (L->ev_stop) (void)hipEventRecord((hipEvent_t)L->ev_stop, s);
   return (int)e;

@@ -214,14 +214,21 @@ extern "C" __global__ __launch_bounds__(SS_THREADS) void bsc_site_stats_kernel(
   for (unsigned i = threadIdx.x; i < 404; i += SS_THREADS)
     if (s_meth[i] != 0.0) atomicAdd(&out_meth[i], s_meth[i]);
   for (unsigned i = threadIdx.x; i < 4 * SS_PAIR * SS_PAIR; i += SS_THREADS)
-    if (s_pair[i]) atomicAdd(&out_pairs[i], (unsigned long long)s_pair[i]);
+    if (s_pair[i]) { /* LDS cell [q][a][b] -> the context's [q][SS_PAIR_G][SS_PAIR_G] table */
+      const unsigned q = i / (SS_PAIR * SS_PAIR), ab = i % (SS_PAIR * SS_PAIR);
+      atomicAdd(&out_pairs[((uint64_t)q * SS_PAIR_G + ab / SS_PAIR) * SS_PAIR_G + ab % SS_PAIR], (unsigned long long)s_pair[i]);
+    }
 }
 
-/* Pair counts -> profiles: one wave per (ref / non-ref, a, b) cell with a count; the cells are consumed (zeroed). */
+/* Pair counts -> profiles: the lanes scan 64 cells at a time, the wave evaluates the posterior of each cell that has a
+ * count (two bins per lane) and adds it times the count; the cells are consumed (zeroed).  Then the fused chain's list of
+ * cytosines beyond the table, one wave per entry. */
 extern "C" __global__ __launch_bounds__(256) void bsc_meth_eval_kernel(unsigned long long *__restrict__ pairs,
                                                                        const bsc_dev_tables *__restrict__ tb,
                                                                        const double *__restrict__ logp,
-                                                                       double *__restrict__ out_meth) {
+                                                                       double *__restrict__ out_meth,
+                                                                       const unsigned long long *__restrict__ ovf_list,
+                                                                       const unsigned long long *__restrict__ counters) {
   __shared__ double s_meth[4 * 101];
   __shared__ double s_lf[256], s_logtab[256], s_logp[100];
   __shared__ unsigned long long s_exptab[256];
@@ -239,23 +246,50 @@ extern "C" __global__ __launch_bounds__(256) void bsc_meth_eval_kernel(unsigned 
 #pragma unroll
   for (int a = 0; a < 2; a++)
     for (int b = 0; b < 2; b++) acc[a][b][0] = acc[a][b][1] = 0.0;
-  const unsigned n_cells = 2u * SS_PAIR * SS_PAIR;
-  for (unsigned c = blockIdx.x * 4u + (threadIdx.x >> 6); c < n_cells; c += gridDim.x * 4u) {
-    const unsigned ref = c / (SS_PAIR * SS_PAIR), ab = c % (SS_PAIR * SS_PAIR);
-    unsigned long long *p_all = pairs + ((uint64_t)ref * 2u) * SS_PAIR * SS_PAIR + ab;
-    unsigned long long *p_pass = p_all + SS_PAIR * SS_PAIR;
-    const unsigned long long n_all = *p_all, n_pass = *p_pass; /* wave-uniform */
-    if (!n_all) continue;
-    double z[2];
-    ss_posterior(ab / SS_PAIR, ab % SS_PAIR, lane, s_lf, s_logtab, s_logp, s_exptab, z);
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-      acc[ref][0][r] += z[r] * (double)n_all;
-      acc[ref][1][r] += z[r] * (double)n_pass;
-    }
-    if (lane == 0) {
+  const unsigned n_cells = 2u * SS_PAIR_G * SS_PAIR_G; /* a multiple of 64 */
+  const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+  for (unsigned c0 = wave * 64u; c0 < n_cells; c0 += n_waves * 64u) {
+    const unsigned c = c0 + lane;
+    const unsigned ref = c / (SS_PAIR_G * SS_PAIR_G), ab = c % (SS_PAIR_G * SS_PAIR_G);
+    unsigned long long *p_all = pairs + ((uint64_t)ref * 2u) * SS_PAIR_G * SS_PAIR_G + ab;
+    unsigned long long *p_pass = p_all + SS_PAIR_G * SS_PAIR_G;
+    const unsigned long long my_all = *p_all;
+    unsigned long long my_pass = 0;
+    if (my_all) {
+      my_pass = *p_pass;
       *p_all = 0;
       *p_pass = 0;
+    }
+    unsigned long long mm = __ballot(my_all != 0);
+    while (mm) {
+      const int src = __builtin_ctzll(mm);
+      mm &= mm - 1;
+      const unsigned cc = c0 + (unsigned)src;
+      const unsigned r2 = cc / (SS_PAIR_G * SS_PAIR_G), ab2 = cc % (SS_PAIR_G * SS_PAIR_G);
+      const double n_all = (double)__shfl(my_all, src), n_pass = (double)__shfl(my_pass, src);
+      double z[2];
+      ss_posterior(ab2 / SS_PAIR_G, ab2 % SS_PAIR_G, lane, s_lf, s_logtab, s_logp, s_exptab, z);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        acc[r2][0][r] += z[r] * n_all;
+        acc[r2][1][r] += z[r] * n_pass;
+      }
+    }
+  }
+  if (ovf_list) {
+    unsigned long long n_ovf = counters[BSC_CNT_OVF]; /* the host zeroes it after this kernel */
+    if (n_ovf > SS_OVF_CAP) n_ovf = SS_OVF_CAP;      /* ... and reports the excess as an error */
+    for (unsigned long long k = wave; k < n_ovf; k += n_waves) {
+      const unsigned long long e = ovf_list[k];
+      const uint32_t ca = (uint32_t)(e & 0xffffffu), cb = (uint32_t)((e >> 24) & 0xffffffu);
+      const bool is_ref = (e >> 48) & 1u, is_pass = (e >> 49) & 1u;
+      double z[2];
+      ss_posterior(ca, cb, lane, s_lf, s_logtab, s_logp, s_exptab, z);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        acc[is_ref ? 0 : 1][0][r] += z[r];
+        if (is_pass) acc[is_ref ? 0 : 1][1][r] += z[r];
+      }
     }
   }
 #pragma unroll
@@ -270,12 +304,12 @@ extern "C" __global__ __launch_bounds__(256) void bsc_meth_eval_kernel(unsigned 
     if (s_meth[i] != 0.0) atomicAdd(&out_meth[i], s_meth[i]);
 }
 
-extern "C" int bsc_dev_launch_meth_eval(void *pairs, const void *tb, const void *logp, void *stats, int num_cus,
-                                        void *stream) {
+extern "C" int bsc_dev_launch_meth_eval(void *pairs, const void *tb, const void *logp, void *stats, const void *ovf_list,
+                                        const void *counters, int num_cus, void *stream) {
   double *meth = (double *)((char *)stats + offsetof(bsc_site_stats, CpG_ref_meth));
-  hipLaunchKernelGGL(bsc_meth_eval_kernel, dim3(2u * SS_PAIR * SS_PAIR / 4u / 8u), dim3(256), 0, (hipStream_t)stream,
-                     (unsigned long long *)pairs, (const bsc_dev_tables *)tb, (const double *)logp, meth);
-  (void)num_cus;
+  hipLaunchKernelGGL(bsc_meth_eval_kernel, dim3((unsigned)num_cus), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned long long *)pairs, (const bsc_dev_tables *)tb, (const double *)logp, meth,
+                     (const unsigned long long *)ovf_list, (const unsigned long long *)counters);
   return (int)hipGetLastError();
 }
 

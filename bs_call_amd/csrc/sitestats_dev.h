@@ -14,7 +14,11 @@
 #include "devtables.h"
 
 #define SS_THREADS 1024 /* one workgroup per CU: its histograms take 110 KB of LDS */
-#define SS_PAIR 64      /* (a, b) < SS_PAIR: the methylation posterior is taken from the pair table */
+#define SS_PAIR 64      /* (a, b) < SS_PAIR: counted in the unfused kernel's LDS pair table */
+#define SS_PAIR_G 512   /* the context's pair table in HBM: u64 [ref / non-ref][all / passed][a < SS_PAIR_G][b < SS_PAIR_G]; a
+                           cell's posterior is evaluated once, when the statistics are read, times its count */
+#define SS_PAIR_G_BYTES (4ull * SS_PAIR_G * SS_PAIR_G * 8ull)
+#define SS_OVF_CAP (1u << 20) /* fused chain: cytosines beyond even that table (>= 512 informative reads of one kind), listed */
 #define SS_COV_LDS 1024 /* coverage rows kept in LDS; deeper positions go to global memory directly */
 
 /* LDS histogram layout (u32 words) */

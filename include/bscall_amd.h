@@ -32,6 +32,7 @@ extern "C" {
 #define BSC_ERR_HIP (-2)       /* a HIP runtime call failed */
 #define BSC_ERR_NOMEM (-3)     /* host or device allocation failed */
 #define BSC_ERR_NO_DEVICE (-4) /* no gfx950 device / kernels not loadable */
+#define BSC_ERR_RANGE (-5)     /* an input beyond what a fixed-size device table holds: the result would be incomplete */
 #define BSC_WARN_INEXACT 1     /* results written, but some pile-up sums left the range where float sums are exact */
 
 /* `pileup`, include/bs_call.h:174-182 — 104 bytes */
@@ -326,6 +327,11 @@ typedef struct {
 } bsc_window;
 int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, const void *d_dbsnp, const bsc_window *w,
                      const bsc_vcf_params *params, int with_stats, void *d_core, void *stream);
+/* Positions that one round of the device's resident waves covers (CUs x waves per workgroup x 60).  A caller that cuts a
+ * resident contig into windows of its own choosing (the reference's blocks are data dependent, src/process_template.c:24-28;
+ * SURVEY.md 8d fixes 4 Mi) should make them a multiple of this: every wave then gets the same number of tiles. 0 if ctx
+ * is NULL. */
+uint32_t bsc_chain_window_quantum(const bsc_context *ctx);
 /* with bsc_set_profiling: device time of the most recent bsc_chain_device call (all of its launches) */
 int bsc_last_chain_ms(bsc_context *ctx, float *ms);
 

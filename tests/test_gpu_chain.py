@@ -100,6 +100,26 @@ def test_fused_equals_unfused_whole_block(caller, n, cov):
     assert gcnt == ecnt
 
 
+@pytest.mark.parametrize("cov", [200, 1400])
+def test_fused_methylation_beyond_the_lds_pair_table(caller, cov):
+    """CpG cytosines with >= 32 informative reads of one kind are counted in the context's 512 x 512 pair table in HBM
+    (200x), those with >= 512 are listed and evaluated one by one when the statistics are read (1400x): same profiles as
+    the unfused statistics kernel, which evaluates each such cytosine where it meets it."""
+    n = 40_000
+    pile, ref2 = _block(SEED + 11 + cov, n, cov)
+    inf = pile["counts"].sum(axis=1)[:, 4:]
+    assert inf.max() >= (512 if cov > 1000 else 64)
+    exp, est, ecnt = _unfused(caller, pile, ref2, 4000)
+    got, gst, gcnt = _fused(caller, pile, ref2, 4000, [(0, 17_000), (17_000, 23_000)])
+    _same_core(got, exp, "deep block")
+    _same_stats(gst, est)
+    assert gcnt == ecnt
+    assert float(gst["CpG_ref_meth"][0].sum() + gst["CpG_nonref_meth"][0].sum()) > 100  # CpGs were profiled
+    # reading the statistics consumed the pair table and the list: a second read adds nothing
+    again = caller.site_stats().copy()
+    _same_stats(again, gst)
+
+
 def test_fused_windows_equal_whole_block(caller):
     """Windows of every alignment (odd starts take the guarded kernel), a 1-position window, windows that end 0, 1, 2
     positions before the block end: same records and statistics as the block in one piece."""

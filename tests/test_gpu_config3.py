@@ -26,9 +26,12 @@ def test_rank0_of_8_share(oracle, tables, libm_exact):
     with B.SiteCaller() as c:
         res = [genome.make_resident(c, k, lengths[k], firsts[k], COV, dev) for k in mine]
         torch.cuda.synchronize()
-        nwin = sum(genome.walk_contig(c, rc, genome.WINDOW, True) for rc in res)
+        # the window bench.py walks with: whole rounds of the resident waves within SURVEY 8(d)'s 4 Mi
+        win = genome.window_for(c)
+        assert win % c.window_quantum() == 0 and win % 60 == 0 and shard.WINDOW - c.window_quantum() < win <= shard.WINDOW
+        nwin = sum(genome.walk_contig(c, rc, win, True) for rc in res)
         torch.cuda.synchronize()
-        assert nwin == sum((lengths[k] + genome.WINDOW - 1) // genome.WINDOW for k in mine)
+        assert nwin == sum((lengths[k] + win - 1) // win for k in mine)
         s = c.stats()
         st = c.site_stats()
 
@@ -61,7 +64,7 @@ def test_rank0_of_8_share(oracle, tables, libm_exact):
 
         # (2) a contig walked in windows == the contig in one call (records at the window boundaries included)
         rc = min(res, key=lambda r: r.length)
-        assert rc.length > 10 * genome.WINDOW
+        assert rc.length > 10 * win
         whole = torch.empty(rc.length * 64, dtype=torch.uint8, device=dev)
         c.chain_device(rc.d_cts.data_ptr(), rc.d_ref.data_ptr(), 1, rc.length, 0, rc.length, whole.data_ptr(), with_stats=False)
         torch.cuda.synchronize()
