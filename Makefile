@@ -8,7 +8,7 @@ LIBDIR = bs_call_amd/lib
 
 # -ffp-contract=off: the reference's arithmetic has no fused operations (x86-64 baseline build); every
 # fused multiply-add in the kernels is an explicit __builtin_fma in bsmath.h.
-HIPFLAGS = -O3 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-function
+HIPFLAGS = -O3 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-function -Wno-inline-asm
 CFLAGS = -O2 -fPIC -Wall -ffp-contract=off -std=gnu11 -I$(ROCM)/include -D__HIP_PLATFORM_AMD__
 
 all: $(LIBDIR)/libbscall_amd.so oracle demo
@@ -62,11 +62,15 @@ $(LIBDIR)/prep.o: $(CSRC)/prep.c include/bscall_amd.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
+$(LIBDIR)/report.o: $(CSRC)/report.c include/bscall_amd.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -c $< -o $@
+
 $(LIBDIR)/synth_reads.o: $(CSRC)/synth_reads.c include/bscall_amd.h $(CSRC)/synth.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o $(LIBDIR)/dbsnp.o $(LIBDIR)/prep.o
+$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o $(LIBDIR)/dbsnp.o $(LIBDIR)/prep.o $(LIBDIR)/report.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lz
 
 oracle:

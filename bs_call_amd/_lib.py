@@ -36,6 +36,8 @@ EXPORTS = (
     "bsc_reset_site_stats",
     "bsc_chain_device",
     "bsc_last_chain_ms",
+    "bsc_get_site_totals",
+    "bsc_report_json",
     "bsc_chain_window_quantum",
     "bsc_prepare_templates",
     "bsc_block_start",
@@ -75,6 +77,33 @@ class VcfParams(C.Structure):
 
 class Window(C.Structure):
     _fields_ = [("x", C.c_uint32), ("n_block", C.c_uint32), ("first", C.c_uint32), ("n", C.c_uint32)]
+
+
+class ContigTotals(C.Structure):
+    _fields_ = [("name", C.c_char_p)] + [(f, C.c_uint64 * 2) for f in
+                                         ("snps", "indels", "multi", "dbSNP_sites", "dbSNP_var", "CpG_ref", "CpG_nonref")]
+
+
+class Report(C.Structure):
+    _fields_ = [
+        ("under_conv", C.c_double),
+        ("over_conv", C.c_double),
+        ("mapq_thresh", C.c_int32),
+        ("min_qual", C.c_int32),
+        ("day", C.c_int32),
+        ("month", C.c_int32),
+        ("year", C.c_int32),
+        ("have_dbsnp", C.c_int32),
+        ("filter_cts", C.c_uint64 * 15),
+        ("filter_bases", C.c_uint64 * 15),
+        ("base_filter", C.c_uint64 * 5),
+        ("total", C.c_void_p),
+        ("gc", C.c_void_p),
+        ("read_profile", C.c_void_p),
+        ("n_read_profile", C.c_uint32),
+        ("n_contigs", C.c_uint32),
+        ("contigs", C.POINTER(ContigTotals)),
+    ]
 
 
 class Stats(C.Structure):
@@ -168,6 +197,10 @@ def load():
     L.bsc_vcf_format.argtypes = [vp, vp, C.c_char_p, C.c_char_p, vp, C.c_size_t]
     L.bsc_chain_device.restype = i32
     L.bsc_chain_device.argtypes = [vp, vp, vp, vp, C.POINTER(Window), C.POINTER(VcfParams), i32, vp, vp]
+    L.bsc_get_site_totals.restype = i32
+    L.bsc_get_site_totals.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.bsc_report_json.restype = C.c_long
+    L.bsc_report_json.argtypes = [C.POINTER(Report), C.c_char_p, C.c_size_t]
     L.bsc_chain_window_quantum.restype = C.c_uint32
     L.bsc_chain_window_quantum.argtypes = [vp]
     L.bsc_last_chain_ms.restype = i32

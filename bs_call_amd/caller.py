@@ -263,6 +263,13 @@ class SiteCaller:
         _check(self._L.bsc_get_site_stats(self._h, _ptr(out)))
         return out[0]
 
+    def site_totals(self):
+        """snps, indels, multi, dbSNP_sites, dbSNP_var, CpG_ref, CpG_nonref as a (7, 2) array [all, passed]: the
+        reference's per-contig copy (gt_ctg_stats) is the difference of two reads."""
+        out = np.zeros(14, dtype=np.uint64)
+        _check(self._L.bsc_get_site_totals(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out.reshape(7, 2)
+
     def reset_site_stats(self):
         _check(self._L.bsc_reset_site_stats(self._h))
 

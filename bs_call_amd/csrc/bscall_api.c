@@ -1047,6 +1047,16 @@ int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out) {
   return BSC_OK;
 }
 
+int bsc_get_site_totals(bsc_context *ctx, uint64_t out[14]) {
+  if (!ctx || !out) return bsc_fail(BSC_ERR_ARG, "bsc_get_site_totals: NULL argument");
+  BSC_ENTER(ctx);
+  memset(out, 0, 14 * sizeof(uint64_t));
+  if (!ctx->d_sstats) return BSC_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, ctx->d_sstats, 14 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return BSC_OK;
+}
+
 int bsc_reset_site_stats(bsc_context *ctx) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_reset_site_stats: ctx is NULL");
   BSC_ENTER(ctx);

@@ -300,6 +300,39 @@ int bsc_vcf_stats(bsc_context *ctx, const bsc_vcf_core *core, const void *gtm, u
 int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out);
 int bsc_reset_site_stats(bsc_context *ctx);
 
+/* The first 14 words of the statistics block — snps, indels, multi, dbSNP_sites, dbSNP_var, CpG_ref, CpG_nonref, each
+ * [all, passed] — as they stand now (synchronises the device).  The reference keeps a copy of these seven pairs per contig
+ * (gt_ctg_stats, include/bs_call.h:124-135): a caller that walks contig after contig takes the difference of two reads. */
+int bsc_get_site_totals(bsc_context *ctx, uint64_t out[14]);
+
+/*
+ * The JSON report of a run (host C; csrc/report.c): the text output_stats() writes at the end of a run
+ * (src/stats.c:19-298), byte for byte, from the statistics this library accumulates and the counters of the stages in
+ * front of it.  bsc_report_json returns the length of the full text (like snprintf: a return >= cap means buf was too
+ * small; call with cap = 0 to size it), -1 on a NULL argument.
+ */
+typedef struct { /* gt_ctg_stats (include/bs_call.h:124-135) without the GC bins */
+  const char *name;
+  uint64_t snps[2], indels[2], multi[2], dbSNP_sites[2], dbSNP_var[2], CpG_ref[2], CpG_nonref[2];
+} bsc_contig_totals;
+typedef struct {
+  double under_conv, over_conv;  /* the "source" line (src/stats.c:29) */
+  int32_t mapq_thresh, min_qual;
+  int32_t day, month, year;      /* the "date" line; year 0 = today (local time, as the reference) */
+  int32_t have_dbsnp;            /* a dbSNP index was loaded: the dbSNP totals are reported */
+  uint64_t filter_cts[15], filter_bases[15]; /* reads / bases by the reader's verdict, gt_filter_reason order
+                                                (include/bs_call.h:50; [14] = "PairNotFound"); [0] = passed */
+  uint64_t base_filter[5];       /* base_filter_types order: passed, trimmed, clipped, overlapping, low quality */
+  const bsc_site_stats *total;
+  const uint64_t *gc;            /* [BSC_COV_CAP][101]: positions by coverage and GC percent of their 100-base bin
+                                    (gt_cov_stats.gc_pcent), or NULL = all zero */
+  const uint64_t *read_profile;  /* [n_read_profile][4]: bs_stats.meth_profile, element 0 included (never reported) */
+  uint32_t n_read_profile;
+  uint32_t n_contigs;
+  const bsc_contig_totals *contigs;
+} bsc_report;
+long bsc_report_json(const bsc_report *r, char *buf, size_t cap);
+
 /*
  * The fused chain — pile-up -> call -> VCF record -> site statistics in ONE pass, the 200-byte gt_meth records never
  * reaching HBM: what the print thread consumes from a block (src/process.c:87-104 feeding src/print_vcf.c:32-594),
