@@ -40,6 +40,7 @@ EXPORTS = (
     "bsc_report_json",
     "bsc_chain_window_quantum",
     "bsc_prepare_templates",
+    "bsc_prepare_templates_profile",
     "bsc_block_start",
     "bsc_template_qual",
     "bsc_dbsnp_open",
@@ -104,6 +105,11 @@ class Report(C.Structure):
         ("n_contigs", C.c_uint32),
         ("contigs", C.POINTER(ContigTotals)),
     ]
+
+
+class ReadProfile(C.Structure):
+    _fields_ = [("ref", C.c_void_p), ("x", C.c_uint32), ("n_ref", C.c_uint32), ("counts", C.c_void_p), ("cap", C.c_uint32),
+                ("used", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -207,6 +213,8 @@ def load():
     L.bsc_last_chain_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsc_prepare_templates.restype = i32
     L.bsc_prepare_templates.argtypes = [vp, u32, vp, u64, vp, u64, vp, vp, vp, u64, C.POINTER(u64), vp]
+    L.bsc_prepare_templates_profile.restype = i32
+    L.bsc_prepare_templates_profile.argtypes = [vp, u32, vp, u64, vp, u64, vp, vp, vp, u64, C.POINTER(u64), vp, C.POINTER(ReadProfile)]
     L.bsc_block_start.restype = u32
     L.bsc_block_start.argtypes = [vp]
     L.bsc_template_qual.restype = u32

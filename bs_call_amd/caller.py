@@ -374,9 +374,24 @@ class PinnedBuffer:
             pass
 
 
-def prepare_templates(raw, seq, misms, left_trim=(0, 0), right_trim=(0, 0), min_qual=20):
+class ReadProfile:
+    """bs_stats.meth_profile: the non-CpG read profile accumulated over blocks by `prepare_templates(..., profile=...)`
+    (src/meth_profile.c).  `counts[i + 1]` = the four counts of read position i; `used` = the reference vector's length."""
+
+    def __init__(self, cap=4096):
+        self.counts = np.zeros((cap, 4), dtype=np.uint64)
+        self.used = 0
+
+    def reported(self):
+        """What the report lists: elements 0 .. used - 1 (the report skips element 0 itself)."""
+        return self.counts[: self.used]
+
+
+def prepare_templates(raw, seq, misms, left_trim=(0, 0), right_trim=(0, 0), min_qual=20, profile=None, x=None, ref=None):
     """Read pre-processing on the host (bsc_prepare_templates; src/process_template.c:36-111): RAW_TEMPLATE[nr] + read
-    bytes + MISMS[] -> (TEMPLATE[nr], prepared read bytes, PREP_STATS record).  No GPU involved."""
+    bytes + MISMS[] -> (TEMPLATE[nr], prepared read bytes, PREP_STATS record).  No GPU involved.  With `profile` (a
+    ReadProfile), the block start `x` and the block's reference codes `ref` (x .. y + 2) the templates also feed the
+    non-CpG read profile."""
     from .abi import MISMS, PREP_PARAMS, PREP_STATS, RAW_TEMPLATE
 
     L = _lib.load()
@@ -390,6 +405,13 @@ def prepare_templates(raw, seq, misms, left_trim=(0, 0), right_trim=(0, 0), min_
     out_seq = np.zeros(cap, dtype=np.uint8)
     used = C.c_uint64(0)
     st = np.zeros(1, dtype=PREP_STATS)
-    _check(L.bsc_prepare_templates(_ptr(raw), len(raw), _ptr(seq), seq.size, _ptr(misms), len(misms), _ptr(par), _ptr(out_tpl),
-                                   _ptr(out_seq), cap, C.byref(used), _ptr(st)))
+    if profile is None:
+        _check(L.bsc_prepare_templates(_ptr(raw), len(raw), _ptr(seq), seq.size, _ptr(misms), len(misms), _ptr(par), _ptr(out_tpl),
+                                       _ptr(out_seq), cap, C.byref(used), _ptr(st)))
+    else:
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        pf = _lib.ReadProfile(ref.ctypes.data, int(x), ref.size, profile.counts.ctypes.data, profile.counts.shape[0], profile.used)
+        _check(L.bsc_prepare_templates_profile(_ptr(raw), len(raw), _ptr(seq), seq.size, _ptr(misms), len(misms), _ptr(par),
+                                               _ptr(out_tpl), _ptr(out_seq), cap, C.byref(used), _ptr(st), C.byref(pf)))
+        profile.used = int(pf.used)
     return out_tpl, out_seq[: used.value].copy(), st[0]

@@ -91,10 +91,64 @@ static uint32_t mean_qual(const prep_read *r) { /* src/al_utils.c:191-203 */
   return n > 0 ? tot / (uint32_t)n : 0;
 }
 
+/*
+ * The non-CpG read profile (src/meth_profile.c:48-77): for every base of a prepared read, by its position in the
+ * ORIGINAL read, whether it is a C / G of the reference outside a CpG and what the read shows there — the four counts
+ * per read position from which the conversion rate along the read is estimated.  The reference's finite-state walk:
+ * `state` = previous and current reference code, 3 bits each.
+ */
+static const uint8_t PROFILE_REF[64] = { /* src/meth_profile.c:14-23: 4 = C not followed by G, 8 = G not preceded by C */
+    0, 0, 0, 0, 0, 0, 0, 0, /* N x */
+    0, 0, 0, 8, 0, 0, 0, 0, /* A x */
+    0, 4, 4, 0, 4, 0, 0, 0, /* C x */
+    0, 0, 0, 8, 0, 0, 0, 0, /* G x */
+    0, 0, 0, 8, 0, 0, 0, 0, /* T x */
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+/* src/init_param.c:57-70: base | quality << 2 -> count index (bits 0-1), "a C / T observation" (4), "a G / A observation" (8);
+ * zero for qualities outside MIN_QUAL .. FLT_QUAL - 1 */
+static uint8_t profile_base(uint32_t bs_strand, uint8_t c) {
+  static const uint8_t tab[3][4] = {{11, 6, 10, 7}, {11, 4, 10, 5}, {9, 6, 8, 7}};
+  const unsigned q = GET_QUAL(c);
+  if (q < 20u /* MIN_QUAL */ || q >= FLT_QUAL || bs_strand > 2) return 0;
+  return tab[bs_strand][c & 3u];
+}
+
+static int profile_read(bsc_read_profile *pf, const uint8_t *sp, const int32_t *orig, uint32_t rl, uint32_t pos, uint32_t bs_strand,
+                        uint32_t ti) {
+  const uint32_t x = pf->x;
+  if (pos < x || (uint64_t)pos - x + rl + 1 > pf->n_ref)
+    return bsc_set_error(BSC_ERR_ARG, "bsc_prepare_templates: template %u lies outside the profile's reference (%u .. %u + %u)", ti, pos, x,
+                         pf->n_ref);
+  const uint8_t *rf = pf->ref + (pos - x);
+  uint8_t state = pos > x ? (uint8_t)((pf->ref[pos - x - 1] << 3) | (*rf++)) : 0;
+  uint8_t mask = PROFILE_REF[state & 63u];
+  for (uint32_t j = 0; j < rl; j++) {
+    const uint8_t xx = profile_base(bs_strand, sp[j]);
+    uint64_t *cts = pf->counts + ((size_t)(orig[j] + 1)) * 4u; /* element 0 collects the padded deletions (orig = -1) */
+    const uint8_t mask1 = (uint8_t)((xx & mask) >> 1);
+    state = (uint8_t)(((state << 3) | (*rf++)) & 63u); /* pos >= x always holds here */
+    mask = PROFILE_REF[state];
+    cts[xx & 3u] += (uint64_t)((((xx & mask) | mask1) >> 2) & 1u);
+  }
+  return BSC_OK;
+}
+
 int bsc_prepare_templates(const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, const bsc_misms *misms_in,
                           uint64_t n_misms_in, const bsc_prep_params *par, bsc_template *tpl_out, uint8_t *seq_out,
                           uint64_t seq_out_cap, uint64_t *seq_out_used, bsc_prep_stats *stats) {
+  return bsc_prepare_templates_profile(raw, nr, seq, seq_bytes, misms_in, n_misms_in, par, tpl_out, seq_out, seq_out_cap, seq_out_used,
+                                       stats, NULL);
+}
+
+int bsc_prepare_templates_profile(const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                                  const bsc_misms *misms_in, uint64_t n_misms_in, const bsc_prep_params *par, bsc_template *tpl_out,
+                                  uint8_t *seq_out, uint64_t seq_out_cap, uint64_t *seq_out_used, bsc_prep_stats *stats,
+                                  bsc_read_profile *pf) {
   if ((nr && (!raw || !tpl_out)) || !seq_out_used || !par) return bsc_set_error(BSC_ERR_ARG, "bsc_prepare_templates: NULL argument");
+  if (pf && (!pf->ref || !pf->counts || pf->used > pf->cap)) return bsc_set_error(BSC_ERR_ARG, "bsc_prepare_templates: bad read profile");
+  int32_t *origs[2] = {NULL, NULL}; /* per read: position of every prepared base in the original read */
+  size_t cap_orig[2] = {0, 0};
   uint64_t used = 0;
   *seq_out_used = 0;
   bsc_prep_stats st;
@@ -154,6 +208,7 @@ int bsc_prepare_templates(const bsc_raw_template *raw, uint32_t nr, const uint8_
     if (par->left_trim[0] || par->right_trim[0]) trim_read(&rd[0 ^ msk], par->left_trim[0], par->right_trim[0]);
     if (par->left_trim[1] || par->right_trim[1]) trim_read(&rd[1 ^ msk], par->left_trim[1], par->right_trim[1]);
     /* 2. soft clips (src/al_utils.c:122-162) */
+    uint32_t trim_l[2] = {0, 0}, trim_r[2] = {0, 0}; /* bases cut from either end (for the read profile's positions) */
     for (int k = 0; k < 2; k++) {
       const uint32_t rl = rd[k].len;
       if (rl == 0) continue;
@@ -169,10 +224,12 @@ int bsc_prepare_templates(const bsc_raw_template *raw, uint32_t nr, const uint8_
             if (m->size >= rl) FAIL("bsc_prepare_templates: template %u read %d: illegal soft clip (%u %u %u %u)", ti, k, z, m->position, m->size, rl);
             adj = m->size;
             st.base_clip += adj;
+            trim_l[k] = adj;
             left_trim(&rd[k], adj);
           } else {
             if (m->position + m->size != rl) FAIL("bsc_prepare_templates: template %u read %d: illegal soft clip (%u %u %u %u)", ti, k, z, m->position, m->size, rl);
             right_trim(&rd[k], m->size);
+            trim_r[k] = m->size;
             st.base_clip += m->size;
           }
         } else if (nclip) {
@@ -288,6 +345,8 @@ int bsc_prepare_templates(const bsc_raw_template *raw, uint32_t nr, const uint8_
         }
         nm[tr] = num;
         st.base_overlap += (rdl[0] - rd[0].len) + (rdl[1] - rd[1].len);
+        if (right) trim_r[tr] += rdl[tr] - rd[tr].len; /* src/al_utils.c:309-313 */
+        else trim_l[tr] += rdl[tr] - rd[tr].len;
       }
     }
     /* 4. indel normalisation (src/process_template.c:62-108) and hand-over */
@@ -299,9 +358,38 @@ int bsc_prepare_templates(const bsc_raw_template *raw, uint32_t nr, const uint8_
     o->mapq[1] = t->mapq[1];
     o->orientation = t->orientation;
     o->bs_strand = t->bs_strand;
+    int32_t max_pos = 0;
+    uint32_t out_len2[2] = {0, 0};
     for (int k = 0; k < 2; k++) {
       const uint32_t rl = rd[k].len;
       uint8_t *sp = rd[k].p;
+      if (pf && t->len[k]) { /* positions in the original read, read 1 counted from its far end (:76-87) */
+        uint64_t pad = 0;
+        for (uint32_t z = 0; z < nm[k]; z++)
+          if (ms[k][z].type == BSC_MISMS_INS) pad += ms[k][z].size;
+        const size_t want = (size_t)rl + (size_t)pad + 1;
+        if (want > cap_orig[k]) {
+          int32_t *nb = realloc(origs[k], want * 2 * sizeof(int32_t));
+          if (!nb) {
+            rc = bsc_set_error(BSC_ERR_NOMEM, "bsc_prepare_templates: out of memory");
+            goto done;
+          }
+          origs[k] = nb;
+          cap_orig[k] = want * 2;
+        }
+        int32_t *orig = origs[k];
+        int32_t mpos;
+        if (k) {
+          const int32_t posx = (int32_t)(rl + trim_r[k]) - 1;
+          for (uint32_t k1 = 0; k1 < rl; k1++) orig[k1] = posx - (int32_t)k1;
+          mpos = posx;
+        } else {
+          const int32_t posx = (int32_t)trim_l[k];
+          for (uint32_t k1 = 0; k1 < rl; k1++) orig[k1] = posx + (int32_t)k1;
+          mpos = posx + (int32_t)rl;
+        }
+        if (mpos > max_pos) max_pos = mpos;
+      }
       for (uint32_t k1 = 0; k1 < rl; k1++) { /* the base counters of the statistics (:50-59) */
         const uint8_t q = (uint8_t)GET_QUAL(sp[k1]);
         if (q == FLT_QUAL) st.base_trim++;
@@ -320,14 +408,21 @@ int bsc_prepare_templates(const bsc_raw_template *raw, uint32_t nr, const uint8_
           if (ix1 > rl + adj) FAIL("bsc_prepare_templates: template %u read %d: indel beyond the read", ti, k);
           memmove(sp + ix1 + m->size, sp + ix1, rl + adj - ix1);
           memset(sp + ix1, 0, m->size);
+          if (pf) {
+            int32_t *orig = origs[k];
+            memmove(orig + ix1 + m->size, orig + ix1, sizeof(int32_t) * (rl + adj - ix1));
+            for (uint32_t k1 = 0; k1 < m->size; k1++) orig[ix1 + k1] = -1;
+          }
           adj += m->size;
         } else if (m->type == BSC_MISMS_DEL) {
           if ((uint64_t)ix1 + m->size > (uint64_t)rl + adj) FAIL("bsc_prepare_templates: template %u read %d: indel beyond the read", ti, k);
           memmove(sp + ix1, sp + ix1 + m->size, rl + adj - ix1 - m->size);
+          if (pf) memmove(origs[k] + ix1, origs[k] + ix1 + m->size, sizeof(int32_t) * (rl + adj - ix1 - m->size));
           adj -= m->size;
         }
       }
       const uint32_t out_len = rl + adj;
+      out_len2[k] = out_len;
       if (used + out_len > seq_out_cap || (out_len && !seq_out)) {
         rc = bsc_set_error(BSC_ERR_ARG, "bsc_prepare_templates: seq_out too small (template %u)", ti);
         goto done;
@@ -337,6 +432,18 @@ int bsc_prepare_templates(const bsc_raw_template *raw, uint32_t nr, const uint8_
       o->off[k] = used;
       used += out_len;
     }
+    if (pf) { /* meth_profile() (src/meth_profile.c:48-77), once both reads of the template are prepared */
+      if ((uint32_t)max_pos + 1u > pf->used) {
+        if ((uint32_t)max_pos + 2u > pf->cap) FAIL("bsc_prepare_templates: template %u: read position %d beyond the profile (%u)", ti, max_pos, pf->cap);
+        /* gt_vector_reserve(.., true) clears everything behind the old end: a count left one past it by a reverse read is lost */
+        memset(pf->counts + (size_t)pf->used * 4u, 0, (size_t)(pf->cap - pf->used) * 4u * sizeof(uint64_t));
+        pf->used = (uint32_t)max_pos + 1u;
+      }
+      for (int k = 0; k < 2; k++) {
+        if (!t->len[k] || !out_len2[k]) continue;
+        if ((rc = profile_read(pf, rd[k].p, origs[k], out_len2[k], k ? pos[1] : pos[0], t->bs_strand, ti))) goto done;
+      }
+    }
   }
   *seq_out_used = used;
   if (stats) *stats = st;
@@ -345,6 +452,8 @@ done:
   free(buf[1]);
   free(ms[0]);
   free(ms[1]);
+  free(origs[0]);
+  free(origs[1]);
   return rc;
 #undef FAIL
 }

@@ -414,6 +414,21 @@ typedef struct { /* the base_filter / filter_cts counters of bs_stats this stage
 int bsc_prepare_templates(const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                           const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *par, bsc_template *tpl_out,
                           uint8_t *seq_out, uint64_t seq_out_cap, uint64_t *seq_out_used, bsc_prep_stats *stats);
+/* The same, and the non-CpG read profile of the templates (meth_profile, src/meth_profile.c:48-77: by position in the
+ * original read, C / G of the reference outside a CpG seen converted or not — bs_stats.meth_profile, the report's
+ * "NonCpGreadProfile").  ref = reference codes 0..4 of genome positions x .. x + n_ref - 1, covering every template
+ * and one base either side (the block's work->ref1: x .. y + 2); counts[cap][4] and used persist from call to call
+ * (used = the reference vector's length: elements 1 .. used - 1 are reported, element i + 1 = read position i). */
+typedef struct {
+  const uint8_t *ref;
+  uint32_t x, n_ref;
+  uint64_t *counts;
+  uint32_t cap, used;
+} bsc_read_profile;
+int bsc_prepare_templates_profile(const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                                  const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *par, bsc_template *tpl_out,
+                                  uint8_t *seq_out, uint64_t seq_out_cap, uint64_t *seq_out_used, bsc_prep_stats *stats,
+                                  bsc_read_profile *profile);
 /* x of the block a template list starts: the first template's start - 2, at least 1 (src/process_template.c:22-28) */
 uint32_t bsc_block_start(const bsc_raw_template *first);
 /* get_al_qual (src/al_utils.c:19-35): the score duplicate resolution compares, with the reference's sq[k] indexing */

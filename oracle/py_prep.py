@@ -6,6 +6,7 @@
   handle_overlap    src/al_utils.c:164-318
   indel normalisation  src/process_template.c:62-108
   get_al_qual       src/al_utils.c:19-35        (incl. the sq[k] indexing)
+  meth_profile      src/meth_profile.c:48-77    (the non-CpG read profile, with the positions process_template.c:76-108 tracks)
 Pinning: like the rest of the oracle, nothing in this image can run the reference's own code for this stage (it needs
 the gt/ containers built against htslib-dependent headers); the restatement is pinned by the hand-worked cases of
 tests/test_prep.py, each derived from the cited lines.
@@ -49,7 +50,7 @@ def _right_trim(rd, l):
             del rd[len(rd) - l :]
 
 
-def trim_soft_clips(al, st):
+def trim_soft_clips(al, st, trim_left=None, trim_right=None):
     for k in range(2):
         rd = al["reads"][k]
         if rd is None:
@@ -71,11 +72,15 @@ def trim_soft_clips(al, st):
                         raise PrepError("Illegal soft clip")
                     adj = m[2]
                     st["base_clip"] += adj
+                    if trim_left is not None:
+                        trim_left[k] = adj  # :143
                     _left_trim(rd, adj)
                 else:
                     if m[1] + m[2] != rl:
                         raise PrepError("Illegal soft clip")
                     _right_trim(rd, m[2])
+                    if trim_right is not None:
+                        trim_right[k] = m[2]  # :149
                     st["base_clip"] += m[2]
             elif nclip:
                 m[1] -= adj
@@ -84,7 +89,7 @@ def trim_soft_clips(al, st):
             del ms[num - nclip :]
 
 
-def handle_overlap(al, st):
+def handle_overlap(al, st, trim_left=None, trim_right=None):
     rdl = [len(r) if r is not None else 0 for r in al["reads"]]
     if not (rdl[0] > 0 and rdl[1] > 0):
         return
@@ -191,13 +196,22 @@ def handle_overlap(al, st):
         del ms[num:]
     rdl1 = [len(r) if r is not None else 0 for r in al["reads"]]
     st["base_overlap"] += rdl[0] - rdl1[0] + rdl[1] - rdl1[1]
+    if trim_left is not None:  # :309-313
+        if right:
+            trim_right[tr] += rdl[tr] - rdl1[tr]
+        else:
+            trim_left[tr] += rdl[tr] - rdl1[tr]
 
 
-def normalise(rd, ms):
-    """src/process_template.c:62-108: returns the read with deletions padded (byte 0) and insertions removed."""
+def normalise(rd, ms, orig=None):
+    """src/process_template.c:62-108: returns the read with deletions padded (byte 0) and insertions removed; `orig` (the
+    position of every base in the original read) is edited alongside (-1 for padding)."""
     sp = list(rd)
     rl = len(sp)
-    sp += [0] * sum(m[2] for m in ms if m[0] == INS)  # gt_vector_reserve_additional
+    npad = sum(m[2] for m in ms if m[0] == INS)
+    sp += [0] * npad  # gt_vector_reserve_additional
+    if orig is not None:
+        orig += [0] * npad
     adj = 0
     for m in ms:
         ix1 = m[1] + adj
@@ -207,18 +221,77 @@ def normalise(rd, ms):
             raise PrepError("indel beyond the read")
         if m[0] == INS:
             sp[ix1 + m[2] : ix1 + m[2] + (rl + adj - ix1)] = sp[ix1 : rl + adj]
+            if orig is not None:
+                orig[ix1 + m[2] : ix1 + m[2] + (rl + adj - ix1)] = orig[ix1 : rl + adj]
             for k1 in range(m[2]):
                 sp[ix1 + k1] = 0
+                if orig is not None:
+                    orig[ix1 + k1] = -1
             adj += m[2]
         elif m[0] == DEL:
             n = rl + adj - ix1 - m[2]
             sp[ix1 : ix1 + n] = sp[ix1 + m[2] : ix1 + m[2] + n]
+            if orig is not None:
+                orig[ix1 : ix1 + n] = orig[ix1 + m[2] : ix1 + m[2] + n]
             adj -= m[2]
+    if orig is not None:
+        del orig[rl + adj :]
     return sp[: rl + adj]
 
 
-def prepare(templates, left_trim=(0, 0), right_trim=(0, 0), min_qual=20):
-    """process_template_vector's per-template loop (src/process_template.c:36-111) -> (prepared templates, stats)."""
+# src/meth_profile.c:14-23 — indexed by (previous reference code << 3 | current): 4 = "CA, CC or CT", 8 = "AG, GG or TG"
+RTAB = [0] * 64
+for _prev, _cur, _v in ((2, 1, 4), (2, 2, 4), (2, 4, 4), (1, 3, 8), (3, 3, 8), (4, 3, 8)):
+    RTAB[_prev << 3 | _cur] = _v
+
+
+def flt_tab(bs_strand, byte, min_q=20):
+    """par->work.flt_tab (src/init_param.c:57-70): entries exist for qualities MIN_QUAL .. FLT_QUAL - 1 only."""
+    q = byte >> 2
+    if q < min_q or q >= FLT_QUAL:
+        return 0
+    return ((11, 6, 10, 7), (11, 4, 10, 5), (9, 6, 8, 7))[bs_strand][byte & 3]
+
+
+class Profile:
+    """bs_stats.meth_profile: a gt_vector of meth_cts, 256 elements allocated and zeroed at the start (src/stats.c:305-309)."""
+
+    def __init__(self, allocated=4096):
+        self.mem = [[0, 0, 0, 0] for _ in range(allocated)]
+        self.used = 0
+
+
+def meth_profile(prof, al, x, ref, orig_pos, max_pos):
+    """src/meth_profile.c:48-77.  `al`: a prepared template (reads normalised), `ref`: codes of x .. (work->ref1)."""
+    if max_pos + 1 > prof.used:  # gt_vector_reserve(.., true): everything from the old end on is cleared (gt_vector.c:34-37)
+        for e in prof.mem[prof.used :]:
+            e[:] = [0, 0, 0, 0]
+        prof.used = max_pos + 1
+    for k in range(2):
+        sp = al["reads"][k]
+        if not sp:
+            continue
+        pos = al["pos"][1] if k else al["pos"][0]
+        r = pos - x
+        if pos > x:
+            state = (ref[r - 1] << 3) | ref[r]
+            r += 1
+        else:
+            state = 0
+        mask = RTAB[state]
+        for j in range(len(sp)):
+            xx = flt_tab(al["bs_strand"], sp[j])
+            cts = prof.mem[1 + orig_pos[k][j]]
+            mask1 = (xx & mask) >> 1
+            state = ((state << 3) | ref[r]) & 63 if pos >= x else 0
+            r += 1
+            mask = RTAB[state]
+            cts[xx & 3] += (((xx & mask) | mask1) >> 2) & 1
+
+
+def prepare(templates, left_trim=(0, 0), right_trim=(0, 0), min_qual=20, profile=None, x=None, ref=None):
+    """process_template_vector's per-template loop (src/process_template.c:36-111) -> (prepared templates, stats); with
+    `profile` (a Profile), block start `x` and the block's reference codes `ref`, also what the mprof thread adds."""
     st = {"base_none": 0, "base_trim": 0, "base_clip": 0, "base_overlap": 0, "base_lowqual": 0, "reads": 0, "read_bases": 0}
     out = []
     for al0 in templates:
@@ -228,14 +301,26 @@ def prepare(templates, left_trim=(0, 0), right_trim=(0, 0), min_qual=20):
             trim_read(al["reads"][0 ^ msk], left_trim[0], right_trim[0])
         if left_trim[1] or right_trim[1]:
             trim_read(al["reads"][1 ^ msk], left_trim[1], right_trim[1])
-        trim_soft_clips(al, st)
-        handle_overlap(al, st)
+        tl, tr_ = [0, 0], [0, 0]
+        trim_soft_clips(al, st, tl, tr_)
+        handle_overlap(al, st, tl, tr_)
         reads = []
+        origs, max_pos = [[], []], 0
         for k in range(2):
             rd = al["reads"][k]
             if rd is None:
                 reads.append([])
                 continue
+            rl = len(rd)
+            if k:  # :76-87
+                posx = rl + tr_[k] - 1
+                origs[k] = [posx - k1 for k1 in range(rl)]
+                mpos = posx
+            else:
+                posx = tl[k]
+                origs[k] = [posx + k1 for k1 in range(rl)]
+                mpos = posx + rl
+            max_pos = max(max_pos, mpos)
             for c in rd:
                 q = c >> 2
                 if q == FLT_QUAL:
@@ -246,8 +331,10 @@ def prepare(templates, left_trim=(0, 0), right_trim=(0, 0), min_qual=20):
                     st["base_none"] += 1
             st["reads"] += 1
             st["read_bases"] += len(rd)
-            reads.append(normalise(rd, al["misms"][k]))
+            reads.append(normalise(rd, al["misms"][k], origs[k]))
         out.append({"pos": list(al["pos"]), "reads": reads, "mapq": al["mapq"], "orientation": al["orientation"], "bs_strand": al["bs_strand"]})
+        if profile is not None:
+            meth_profile(profile, out[-1], x, ref, origs, max_pos)
     return out, st
 
 

@@ -277,3 +277,115 @@ def test_prepared_templates_feed_the_accumulate_stage(oracle):
     # padded deletions (byte 0: q = 0) never count; every other base with q >= 20 counts once
     want = sum(1 for o in out for k in range(2) for c in oseq[int(o["off"][k]) : int(o["off"][k]) + int(o["len"][k])] if (c >> 2) >= 20 and (c >> 2) != 63)
     assert int(pile["n"].sum()) == want
+
+
+# ---- the non-CpG read profile (meth_profile, src/meth_profile.c) -----------------------------------------------------------
+def _profile_both(templates, x, ref, **kw):
+    from bs_call_amd.caller import ReadProfile
+
+    raw, seq, ms = to_arrays(templates)
+    pf = ReadProfile(cap=4096)
+    prepare_templates(raw, seq, ms, profile=pf, x=x, ref=np.array(ref, dtype=np.uint8), **kw)
+    pp = py_prep.Profile(4096)
+    py_prep.prepare(templates, profile=pp, x=x, ref=list(ref), **kw)
+    assert pf.used == pp.used and pf.counts.tolist() == pp.mem
+    return pf
+
+
+def test_read_profile_hand_worked():
+    """Reference (codes 1..4 = ACGT) from x = 10:  A C A C G T G G C T  (positions 10 .. 19) + 2 more.
+    Non-CpG cytosines: 11 (C then A), 18 (C then T); 13 is CpG.  Guanines not after a C: 16 (T G), 17 (G G); 14 is CpG.
+    A C2T forward read at 11 showing  T A C G T G A C T  (quality 30):
+      pos 11 ref C, read T -> flt_tab[C2T][T] = 5: count 1 (b... index 1), a C / T observation at a non-CpG C: counted
+      pos 13 ref C (CpG), read C = 4: index 0, but the reference context is CpG: not counted
+      pos 16 ref G, read G = 10 = 8 | 2: index 2, a G / A observation at a G not preceded by C: counted
+      pos 17 ref G, read A = 11 = 8 | 3: index 3: counted
+      pos 18 ref C, read C = 4: index 0: counted
+    Read position i is element i + 1."""
+    ref = [1, 2, 1, 2, 3, 4, 3, 3, 2, 4, 1, 1]
+    T_, A_, C_, G_ = 3, 0, 1, 2
+    rd = [b(v) for v in (T_, A_, C_, G_, T_, G_, A_, C_, T_)]
+    t = tpl((11, 0), (9, 0), (rd, None), bs_strand=1)
+    pf = _profile_both([t], 10, ref)
+    assert pf.used == 10  # max_pos = trim_left + rl = 9
+    exp = np.zeros((4096, 4), dtype=np.uint64)
+    exp[1 + 0][1] = 1  # pos 11
+    exp[1 + 5][2] = 1  # pos 16
+    exp[1 + 6][3] = 1  # pos 17
+    exp[1 + 7][0] = 1  # pos 18
+    assert (pf.counts == exp).all()
+    # the same bases as the reverse read of a template: positions count from the far end (posx - k1), and a low-quality base
+    # (q < 20) has no table entry
+    rd2 = list(rd)
+    rd2[0] = b(T_, 10)
+    t2 = tpl((0, 11), (0, 9), (None, rd2), bs_strand=1)
+    pf2 = _profile_both([t2], 10, ref)
+    assert pf2.used == 9  # max_pos = rl + trim_right - 1 = 8: one less than for a forward read
+    exp2 = np.zeros((4096, 4), dtype=np.uint64)
+    exp2[1 + 8 - 5][2] = 1
+    exp2[1 + 8 - 6][3] = 1
+    exp2[1 + 8 - 7][0] = 1
+    assert (pf2.counts == exp2).all()
+
+
+def test_read_profile_soft_clip_deletion_and_the_block_start_quirk():
+    """A left soft clip shifts the positions by its length; a deletion's padding lands in element 0; a read starting AT the
+    block start is walked one reference base late (state starts at 0 and the pointer is not advanced, :66-67)."""
+    ref = [2, 1, 2, 4, 3, 1, 2, 1, 4, 4, 1, 1, 1, 1]  # x = 1:  C A C T G A C A T T ...
+    C_, T_ = 1, 3
+    # two clipped bases, then C T | one reference base deleted | T C, aligned at position 3
+    rd = [b(0), b(0), b(C_), b(T_), b(T_), b(C_)]
+    t = tpl((3, 0), (5, 0), (rd, None), (([SOFT, 0, 2], [INS, 4, 1]), ()), bs_strand=1)
+    pf = _profile_both([t], 1, ref)
+    # after the clip: read C T T C at orig 2..5, deletion padded at index 2 -> C T 0 T C over positions 3 4 5 6 7 (ref C T G A C)
+    # pos 3 ref C followed by T: read C (4, index 0) counted at orig 2; pos 7 ref C followed by A: read C counted at orig 5
+    assert pf.used == 2 + 4 + 1 and pf.counts[1 + 2][0] == 1 and pf.counts[1 + 5][0] == 1 and int(pf.counts.sum()) == 2
+    # block start: the read begins at x itself
+    t3 = tpl((1, 0), (4, 0), ([b(C_), b(0), b(C_), b(T_)], None), bs_strand=1)
+    pf3 = _profile_both([t3], 1, ref)
+    # walked one base late: at base j the state is (ref[j-1], ref[j]) instead of (ref[j], ref[j+1]), so the non-CpG C at
+    # position 1 (C then A) is credited to base 1 (an A: a G / A observation, no match) and the C at 3 (C then T) to base 3,
+    # the T (5 = C / T observation, index 1): one count, at read position 3, where a correct walk would give C->C at 0 and 2
+    exp3 = np.zeros((4096, 4), dtype=np.uint64)
+    exp3[1 + 3][1] = 1
+    assert (pf3.counts == exp3).all()
+
+
+def test_read_profile_c_equals_python_on_random_alignments():
+    from bs_call_amd.caller import ReadProfile
+
+    rng = np.random.default_rng(777)
+    ref = [int(v) for v in rng.integers(0, 5, 6000)]
+    pf = ReadProfile(cap=1024)
+    pp = py_prep.Profile(1024)
+    n_done = 0
+    for trial in range(200):
+        ts = []
+        for _ in range(int(rng.integers(1, 8))):
+            r0, m0, s0 = _random_read(rng, qlo=10)
+            r1, m1, s1 = _random_read(rng, qlo=10)
+            p0 = int(rng.integers(5, 5000))
+            kind = rng.random()
+            if kind < 0.2:
+                t = tpl((p0, 0), (s0, 0), (r0, None), (m0, ()))
+            elif kind < 0.4:
+                t = tpl((0, p0), (0, s1), (None, r1), ((), m1))
+            else:
+                t = tpl((p0, max(5, p0 + int(rng.integers(-s1 - 5, s0 + 30)))), (s0, s1), (r0, r1), (m0, m1))
+            t["orientation"] = int(rng.integers(0, 2))
+            t["bs_strand"] = int(rng.integers(0, 3))
+            ts.append(t)
+        x = max(1, min(min(p for p in t["pos"] if p) for t in ts) - 2)
+        raw, seq, ms = to_arrays(ts)
+        import copy
+
+        trial_pp = copy.deepcopy(pp)
+        try:
+            py_prep.prepare(ts, profile=trial_pp, x=x, ref=ref[x - 1 :])
+        except py_prep.PrepError:
+            continue  # the reference-undefined class: the batch is skipped on both sides
+        pp = trial_pp
+        prepare_templates(raw, seq, ms, profile=pf, x=x, ref=np.array(ref[x - 1 :], dtype=np.uint8))
+        assert pf.used == pp.used and pf.counts.tolist() == pp.mem, trial
+        n_done += 1
+    assert n_done > 150 and int(pf.counts.sum()) > 1000 and int(pf.counts[0].sum()) == 0  # padding never counts (byte 0 has no entry)
