@@ -37,6 +37,9 @@ EXPORTS = (
     "bsc_chain_device",
     "bsc_last_chain_ms",
     "bsc_get_site_totals",
+    "bsc_gc_bins",
+    "bsc_set_gc_bins",
+    "bsc_get_gc_stats",
     "bsc_report_json",
     "bsc_chain_window_quantum",
     "bsc_prepare_templates",
@@ -203,6 +206,12 @@ def load():
     L.bsc_vcf_format.argtypes = [vp, vp, C.c_char_p, C.c_char_p, vp, C.c_size_t]
     L.bsc_chain_device.restype = i32
     L.bsc_chain_device.argtypes = [vp, vp, vp, vp, C.POINTER(Window), C.POINTER(VcfParams), i32, vp, vp]
+    L.bsc_gc_bins.restype = i32
+    L.bsc_gc_bins.argtypes = [vp, u64, C.POINTER(u32), vp, u64, C.POINTER(u64)]
+    L.bsc_set_gc_bins.restype = i32
+    L.bsc_set_gc_bins.argtypes = [vp, vp, u32, u32]
+    L.bsc_get_gc_stats.restype = i32
+    L.bsc_get_gc_stats.argtypes = [vp, vp]
     L.bsc_get_site_totals.restype = i32
     L.bsc_get_site_totals.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.bsc_report_json.restype = C.c_long

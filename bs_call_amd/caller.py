@@ -263,6 +263,16 @@ class SiteCaller:
         _check(self._L.bsc_get_site_stats(self._h, _ptr(out)))
         return out[0]
 
+    def set_gc_bins(self, d_gc, n_bins, start_pos):
+        """GC bins of the contig being walked (device pointer, see `gc_bins`); None switches the GC table off."""
+        _check(self._L.bsc_set_gc_bins(self._h, d_gc, n_bins, start_pos))
+
+    def gc_stats(self):
+        """Positions by [total depth][G+C count of their 100-base bin]: the report's "GC" object, (4096, 101) uint64."""
+        out = np.zeros((4096, 101), dtype=np.uint64)
+        _check(self._L.bsc_get_gc_stats(self._h, _ptr(out)))
+        return out
+
     def site_totals(self):
         """snps, indels, multi, dbSNP_sites, dbSNP_var, CpG_ref, CpG_nonref as a (7, 2) array [all, passed]: the
         reference's per-contig copy (gt_ctg_stats) is the difference of two reads."""
@@ -372,6 +382,17 @@ class PinnedBuffer:
             self.free()
         except Exception:
             pass
+
+
+def gc_bins(codes):
+    """ctg_stats->gc of a contig (src/read_reference.c:44-131) from its reference codes 0..4 (position 1 first):
+    (start_pos, uint8 bins)."""
+    L = _lib.load()
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    out = np.zeros(codes.size // 100 + 1, dtype=np.uint8)
+    start, nb = C.c_uint32(0), C.c_uint64(0)
+    _check(L.bsc_gc_bins(_ptr(codes), codes.size, C.byref(start), _ptr(out), out.size, C.byref(nb)))
+    return int(start.value), out[: nb.value].copy()
 
 
 class ReadProfile:

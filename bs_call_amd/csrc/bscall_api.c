@@ -47,7 +47,7 @@ int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const
                        void *out, int num_cus, void *stream);
 int bsc_dev_launch_chain(const bsc_chain_launch *L); /* fused.hip */
 unsigned bsc_dev_chain_quantum(int num_cus);
-size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus);
+size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth);
 int bsc_dev_launch_synth(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags, void *cts,
                          void *ref, int num_cus, void *stream);
 
@@ -73,6 +73,9 @@ struct bsc_context {
   uint64_t max_launch; /* positions per launch of the calling kernel (BSC_MAX_LAUNCH; BSC_MAX_LAUNCH_SITES in the
                           environment lowers it so that the sub-launch loop of longer calls can be tested) */
   void *d_ovf; /* fused chain: CpG cytosines beyond the methylation pair table (BSC_OVF_CAP entries of 8 bytes) */
+  void *d_gc_table;      /* GC content by coverage: u64 [BSC_COV_CAP][101] (bsc_set_gc_bins) */
+  const void *d_gc_bins; /* the current contig's bins (caller's device memory) */
+  uint32_t gc_n_bins, gc_start_pos;
   hipEvent_t ev_chain[2]; /* bsc_set_profiling: the fused chain's launches */
   int ev_chain_valid;
   /* accumulate stage */
@@ -282,6 +285,7 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_skip);
   hipFree(ctx->d_het);
   hipFree(ctx->d_ovf);
+  hipFree(ctx->d_gc_table);
   for (int i = 0; i < 2; i++)
     if (ctx->ev_chain[i]) hipEventDestroy(ctx->ev_chain[i]);
   hipFree(ctx->d_tpl);
@@ -828,7 +832,8 @@ int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, con
   if (((uintptr_t)d_core & 15u) || ((uintptr_t)d_cts & 7u))
     return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: d_core must be 16-byte and d_cts 8-byte aligned");
   BSC_ENTER(ctx);
-  int rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, bsc_dev_chain_het_bytes(w->n, ctx->num_cus));
+  const int gc = with_stats && ctx->d_gc_bins != NULL;
+  int rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, bsc_dev_chain_het_bytes(w->n, ctx->num_cus, gc));
   if (rc) return rc;
   bsc_chain_launch L;
   memset(&L, 0, sizeof L);
@@ -840,6 +845,12 @@ int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, con
     L.pairs = ctx->d_pairs;
     L.ovf_list = ctx->d_ovf;
     L.ovf_cap = BSC_OVF_CAP;
+    if (gc) {
+      L.gc_bins = ctx->d_gc_bins;
+      L.gc_n_bins = ctx->gc_n_bins;
+      L.gc_start_pos = ctx->gc_start_pos;
+      L.gc_table = ctx->d_gc_table;
+    }
     L.logp = ctx->d_logp;
   }
   const uint32_t after = w->n_block - w->first - w->n;
@@ -1047,6 +1058,63 @@ int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out) {
   return BSC_OK;
 }
 
+#define BSC_GC_BYTES ((size_t)BSC_COV_CAP * 101u * sizeof(uint64_t))
+
+int bsc_set_gc_bins(bsc_context *ctx, const void *d_gc, uint32_t n_bins, uint32_t start_pos) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_set_gc_bins: ctx is NULL");
+  BSC_ENTER(ctx);
+  if (d_gc && !ctx->d_gc_table) {
+    if (hipMalloc(&ctx->d_gc_table, BSC_GC_BYTES) != hipSuccess) {
+      ctx->d_gc_table = NULL;
+      return bsc_fail(BSC_ERR_NOMEM, "bsc_set_gc_bins: device allocation failed");
+    }
+    HIP_TRY(hipMemset(ctx->d_gc_table, 0, BSC_GC_BYTES));
+  }
+  ctx->d_gc_bins = d_gc;
+  ctx->gc_n_bins = d_gc ? n_bins : 0;
+  ctx->gc_start_pos = start_pos;
+  return BSC_OK;
+}
+
+int bsc_get_gc_stats(bsc_context *ctx, uint64_t *out) {
+  if (!ctx || !out) return bsc_fail(BSC_ERR_ARG, "bsc_get_gc_stats: NULL argument");
+  BSC_ENTER(ctx);
+  if (!ctx->d_gc_table) {
+    memset(out, 0, BSC_GC_BYTES);
+    return BSC_OK;
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, ctx->d_gc_table, BSC_GC_BYTES, hipMemcpyDeviceToHost));
+  return BSC_OK;
+}
+
+/* ctg_stats->gc of load_sequence (src/read_reference.c:44-131): the contig starts at its first A/C/G/T (*start_pos, 1-based);
+ * from there every 100 bases make a bin = their G+C count, or 255 if one of them is not A/C/G/T; a last, shorter bin is
+ * dropped.  codes[n] = reference codes 0..4 of positions 1 .. n. */
+int bsc_gc_bins(const uint8_t *codes, uint64_t n, uint32_t *start_pos, uint8_t *out, uint64_t out_cap, uint64_t *n_bins) {
+  if ((n && !codes) || !start_pos || !n_bins || (out_cap && !out)) return bsc_fail(BSC_ERR_ARG, "bsc_gc_bins: NULL argument");
+  uint64_t k = 0;
+  while (k < n && (codes[k] < 1 || codes[k] > 4)) k++;
+  *start_pos = (uint32_t)(k + 1);
+  *n_bins = 0;
+  uint64_t nb = 0;
+  unsigned in_bin = 0, valid = 0, gc = 0;
+  for (; k < n; k++) {
+    const uint8_t b = codes[k];
+    if (b >= 1 && b <= 4) {
+      valid++;
+      gc += (b == 2 || b == 3);
+    }
+    if (++in_bin == 100) {
+      if (nb >= out_cap) return bsc_fail(BSC_ERR_ARG, "bsc_gc_bins: out holds %llu bins, more are needed", (unsigned long long)out_cap);
+      out[nb++] = valid == 100 ? (uint8_t)gc : 255;
+      in_bin = valid = gc = 0;
+    }
+  }
+  *n_bins = nb;
+  return BSC_OK;
+}
+
 int bsc_get_site_totals(bsc_context *ctx, uint64_t out[14]) {
   if (!ctx || !out) return bsc_fail(BSC_ERR_ARG, "bsc_get_site_totals: NULL argument");
   BSC_ENTER(ctx);
@@ -1065,6 +1133,7 @@ int bsc_reset_site_stats(bsc_context *ctx) {
   HIP_TRY(hipMemset(ctx->d_sstats, 0, sizeof(bsc_site_stats)));
   HIP_TRY(hipMemset(ctx->d_pairs, 0, BSC_PAIR_BYTES));
   HIP_TRY(hipMemset(ctx->d_counters + BSC_CNT_OVF, 0, sizeof(unsigned long long)));
+  if (ctx->d_gc_table) HIP_TRY(hipMemset(ctx->d_gc_table, 0, BSC_GC_BYTES));
   HIP_TRY(hipMemset(ctx->d_carry, 0, 4 * sizeof(uint32_t)));
   ctx->carry_slot = 0;
   return BSC_OK;

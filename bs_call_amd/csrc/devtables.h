@@ -48,6 +48,9 @@ typedef struct bsc_chain_launch {
   void *carry_out, *stats, *pairs, *ovf_list;
   uint32_t ovf_cap;
   const void *logp;
+  const void *gc_bins; /* the contig's GC bins (device) or NULL */
+  uint32_t gc_n_bins, gc_start_pos;
+  void *gc_table;      /* u64 [BSC_COV_CAP][101] */
   int num_cus;
   void *stream;
   void *ev_start, *ev_stop;

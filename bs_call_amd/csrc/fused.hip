@@ -57,6 +57,8 @@ struct bsc_chain_args {
   int32_t with_stats;
   uint32_t ovf_cap;
   uint32_t het_cap; /* entries of a wave's heterozygous list */
+  uint32_t depth_off; /* != 0: the window's depths (u16 per position, 0 = no record formed) are written at het_list + this
+                         many dwords, for the GC-by-coverage kernel */
 };
 
 struct bsc_vcf_core_f {
@@ -558,6 +560,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
       }
     }
     spd[lane] = (pend ? 1u : 0u) | (flt << 8);
+    if (a.depth_off && inner) { /* total depth of every position that reached the printer (the key of gt_cov_stats) */
+      const uint32_t dpt = dp1 + d_inf;
+      reinterpret_cast<uint16_t *>(het_list + a.depth_off)[jw] = (uint16_t)(od[0] ? (dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u) : 0u);
+    }
     WAVE_LDS_SYNC();
     /* ---- results: the tile's 60 records, staged in the slot (every la[] read is done: the sync above), leave
      * contiguously — before the statistics, so that the stores drain while the histograms are updated and the sixteen
@@ -731,6 +737,34 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
   }
 }
 
+/*
+ * GC content by coverage (gt_cov_stats.gc_pcent, src/print_vcf.c:394-398): every position that reached the printer adds
+ * one to [its total depth][G+C count of its 100-base bin], if the bin holds no N.  Reads the depths the chain kernel left
+ * (2 bytes per position) and the contig's bins (1 byte per 100 positions); the table of a workgroup lives in its LDS
+ * (256 depths x 101), deeper positions go to the table in HBM directly.
+ */
+#define GC_ROWS 256
+extern "C" __global__ __launch_bounds__(1024) void bsc_gc_cov_kernel(const uint16_t *__restrict__ depth, uint32_t n, uint32_t pos0,
+                                                                     const uint8_t *__restrict__ gc_bins, uint32_t n_bins,
+                                                                     uint32_t start_pos, unsigned long long *__restrict__ table) {
+  __shared__ uint32_t t[GC_ROWS * 101];
+  for (unsigned i = threadIdx.x; i < GC_ROWS * 101; i += 1024) t[i] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
+    const uint32_t d = depth[i];
+    if (!d) continue;
+    const uint32_t bn = (pos0 + i - start_pos) / 100u; /* unsigned like the reference's: a position before start_pos is out of range */
+    if (bn >= n_bins) continue;
+    const uint32_t g = gc_bins[bn];
+    if (g > 100u) continue;
+    if (d < GC_ROWS) atomicAdd(&t[d * 101u + g], 1u);
+    else atomicAdd(&table[(uint64_t)d * 101u + g], 1ull);
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < GC_ROWS * 101; i += 1024)
+    if (t[i]) atomicAdd(&table[i], (unsigned long long)t[i]);
+}
+
 /* ---- launcher ------------------------------------------------------------------------------------------------ */
 /* positions one round of the resident waves covers: a window that is a whole number of these gives every wave the same
  * number of tiles (no partly filled last round) */
@@ -743,10 +777,11 @@ static uint32_t chain_het_cap(uint32_t tiles, unsigned grid) {
   return (rounds * FT + 31u) & ~31u;
 }
 
-/* bytes the per-wave heterozygous lists of a window of n positions take, at most */
-extern "C" size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus) {
+/* bytes the per-wave heterozygous lists of a window of n positions take, at most; with_depth: plus the window's depths */
+extern "C" size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth) {
   const uint64_t tiles = ((uint64_t)n + FT - 1) / FT, waves = (uint64_t)num_cus * FW;
-  return (size_t)((tiles + waves) * FT + waves * 32u) * sizeof(uint32_t);
+  const size_t lists = (size_t)((tiles + waves) * FT + waves * 32u) * sizeof(uint32_t);
+  return lists + (with_depth ? (((size_t)n * 2u + 3u) & ~(size_t)3u) : 0u);
 }
 
 extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
@@ -765,6 +800,8 @@ extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
   a.reg_stop = L->reg_stop;
   a.with_stats = L->with_stats;
   a.ovf_cap = L->ovf_cap;
+  const bool gc = L->with_stats && L->gc_bins && L->gc_table;
+  a.depth_off = gc ? (uint32_t)(bsc_dev_chain_het_bytes(L->n, L->num_cus, 0) / sizeof(uint32_t)) : 0u;
   const uint32_t n_tiles = (L->n + FT - 1) / FT;
   /* complete tiles: all 64 computed sites in the buffers, and the first one on a 16-byte boundary for the LDS-DMA
    * ((60 T - 2 + lc) * 104 bytes: lc even) */
@@ -802,6 +839,13 @@ extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
     if (e != hipSuccess) return (int)e;
   }
 #undef CHAIN_ARGS
+  if (gc) { /* the window's positions into the GC-by-coverage table */
+    unsigned grid = (L->n + 1023u) / 1024u;
+    if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
+    hipLaunchKernelGGL(bsc_gc_cov_kernel, dim3(grid), dim3(1024), 0, s,
+                       reinterpret_cast<const uint16_t *>((const uint32_t *)L->het_list + a.depth_off), L->n, L->x + L->first,
+                       (const uint8_t *)L->gc_bins, L->gc_n_bins, L->gc_start_pos, (unsigned long long *)L->gc_table);
+  }
   hipError_t e = hipGetLastError();
   if (L->ev_stop) (void)hipEventRecord((hipEvent_t)L->ev_stop, s);
   return (int)e;

@@ -74,12 +74,16 @@ class ResidentContig:
     d_ref: object  # length + 2 reference codes
     d_core: object  # length x 64 bytes: bsc_vcf_core records
     d_dbsnp: object = None  # length rs_found flags, or None
+    d_gc: object = None  # the contig's GC bins (ctg_stats->gc), or None
+    gc_start: int = 0  # first A/C/G/T position of the contig
 
 
 def make_resident(caller, index: int, length: int, first_site: int, coverage: int, device, flags: int = 1,
-                  seed: int = SEED + 3, stream=None, dbsnp_flags=None):
+                  seed: int = SEED + 3, stream=None, dbsnp_flags=None, with_gc: bool = False):
     """Generate contig `index` on the device (the L-pileup generator; flags = 1: 1 % of 10-kb runs are N without reads).
-    dbsnp_flags: uint8[length] rs_found per position (DbSnpIndex.flags(1, length)) for BASELINE.json configs[4]."""
+    dbsnp_flags: uint8[length] rs_found per position (DbSnpIndex.flags(1, length)) for BASELINE.json configs[4].
+    with_gc: also the contig's GC bins (what load_sequence computes when a report is asked for), for the report's
+    GC-by-coverage table."""
     import torch
 
     d_cts = torch.empty((length + 2) * PILEUP_BYTES, dtype=torch.uint8, device=device)
@@ -87,7 +91,14 @@ def make_resident(caller, index: int, length: int, first_site: int, coverage: in
     d_core = torch.empty(length * CORE_BYTES, dtype=torch.uint8, device=device)
     caller.synth_device(seed, first_site, length + 2, coverage, d_cts.data_ptr(), d_ref.data_ptr(), flags, stream)
     d_db = None if dbsnp_flags is None else torch.from_numpy(dbsnp_flags).to(device)
-    return ResidentContig(index, length, d_cts, d_ref, d_core, d_db)
+    d_gc, gc_start = None, 0
+    if with_gc:
+        from .caller import gc_bins
+
+        torch.cuda.synchronize()
+        gc_start, bins = gc_bins(d_ref[:length].cpu().numpy())
+        d_gc = torch.from_numpy(bins).to(device)
+    return ResidentContig(index, length, d_cts, d_ref, d_core, d_db, d_gc, gc_start)
 
 
 def walk_contig(caller, rc: ResidentContig, window: int = WINDOW, with_stats: bool = True, x: int = 1,
@@ -96,6 +107,8 @@ def walk_contig(caller, rc: ResidentContig, window: int = WINDOW, with_stats: bo
     n_block = rc.length
     core = rc.d_core if d_core is None else d_core
     k = 0
+    if with_stats:  # the GC table follows the contig being walked (None switches it off)
+        caller.set_gc_bins(None if rc.d_gc is None else rc.d_gc.data_ptr(), 0 if rc.d_gc is None else rc.d_gc.numel(), rc.gc_start)
     for first in range(0, n_block, window):
         n = min(window, n_block - first)
         lc, lr = min(2, first), min(4, first)
@@ -105,3 +118,21 @@ def walk_contig(caller, rc: ResidentContig, window: int = WINDOW, with_stats: bo
                             stream=stream)
         k += 1
     return k
+
+
+def walk_with_report(caller, contigs: Sequence[ResidentContig], names: Sequence[str], window: int, stream=None, **report_kw) -> str:
+    """Walk the contigs in order and render the run's JSON report (bsc_report_json: the reference's output_stats): the
+    totals, the per-contig copies of the seven [all, passed] pairs (differences of bsc_get_site_totals around each contig,
+    the reference's gt_ctg_stats) and — for contigs made `with_gc` — the GC-by-coverage table."""
+    from . import report
+
+    per_contig = []
+    before = caller.site_totals()
+    for rc, name in zip(contigs, names):
+        walk_contig(caller, rc, window, True, stream=stream)
+        after = caller.site_totals()
+        per_contig.append((name, after - before))
+        before = after
+    caller.set_gc_bins(None, 0, 0)
+    gc = caller.gc_stats() if any(rc.d_gc is not None for rc in contigs) else None
+    return report.render_json(caller.site_stats(), gc=gc, contigs=per_contig, **report_kw)

@@ -300,6 +300,20 @@ int bsc_vcf_stats(bsc_context *ctx, const bsc_vcf_core *core, const void *gtm, u
 int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out);
 int bsc_reset_site_stats(bsc_context *ctx);
 
+/*
+ * GC content by coverage (gt_cov_stats.gc_pcent, src/print_vcf.c:394-398; the report's "GC" object): with the bins of the
+ * contig being walked set, every bsc_chain_device(with_stats) call also adds its positions that reached the printer to
+ * table[total depth][G+C count of the position's 100-base bin].  The bins are the reference's ctg_stats->gc
+ * (src/read_reference.c:44-131): bsc_gc_bins computes them on the host from the contig's reference codes.
+ *   bsc_set_gc_bins   d_gc[n_bins] in device memory (the caller keeps it alive while set), start_pos = the contig's first
+ *                     A/C/G/T position; d_gc NULL switches the table off.  Call at every contig change.
+ *   bsc_get_gc_stats  out[BSC_COV_CAP][101] (synchronises the device); zeroed by bsc_reset_site_stats.
+ * The unfused bsc_vcf_stats_device does not feed this table.
+ */
+int bsc_gc_bins(const uint8_t *codes, uint64_t n, uint32_t *start_pos, uint8_t *out, uint64_t out_cap, uint64_t *n_bins);
+int bsc_set_gc_bins(bsc_context *ctx, const void *d_gc, uint32_t n_bins, uint32_t start_pos);
+int bsc_get_gc_stats(bsc_context *ctx, uint64_t *out);
+
 /* The first 14 words of the statistics block — snps, indels, multi, dbSNP_sites, dbSNP_var, CpG_ref, CpG_nonref, each
  * [all, passed] — as they stand now (synchronises the device).  The reference keeps a copy of these seven pairs per contig
  * (gt_ctg_stats, include/bs_call.h:124-135): a caller that walks contig after contig takes the difference of two reads. */

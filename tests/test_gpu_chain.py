@@ -194,3 +194,65 @@ def test_fused_consecutive_blocks_carry(caller):
         torch.cuda.synchronize()
         _same_core(d_core.cpu().numpy().view(VCF_CORE), cores[k], "block %d" % k)
     _same_stats(caller.site_stats().copy(), est)
+
+
+def test_gc_by_coverage(caller):
+    """gt_cov_stats.gc_pcent (src/print_vcf.c:394-398): every position that reached the printer counts under [total depth]
+    [G+C of its 100-base bin]; bins with an N (255) and positions outside the bins are not counted.  Checked against a
+    numpy census of the records; the bins themselves against a direct restatement of load_sequence's loop
+    (src/read_reference.c:66-104)."""
+    from bs_call_amd.caller import gc_bins
+
+    n, x0 = 30_000, 4000
+    pile, ref2 = _block(SEED + 77, n, 30, flags=1)
+    ref2 = ref2.copy()
+    ref2[12_345] = 0  # an N inside one bin
+    codes = np.zeros(x0 - 1 + n - 150, dtype=np.uint8)  # the contig ends 150 positions before the block does: no bin there
+    codes[x0 - 1 :] = ref2[: n - 150]
+    codes[x0 - 1 : x0 + 6] = 0  # the contig's first A/C/G/T base is 7 positions into the block
+    start, bins = gc_bins(codes)
+    # restatement: first valid base, then bins of 100
+    k = int(np.argmax((codes >= 1) & (codes <= 4)))
+    assert start == k + 1 == x0 + 7
+    exp_bins = []
+    for b0 in range(k, len(codes) - 99, 100):
+        w = codes[b0 : b0 + 100]
+        exp_bins.append(int(((w == 2) | (w == 3)).sum()) if ((w >= 1) & (w <= 4)).all() else 255)
+    assert bins.tolist() == exp_bins and 255 in exp_bins
+    d_bins = _dev(bins)
+    caller.reset_site_stats()
+    caller.set_gc_bins(d_bins.data_ptr(), len(bins), start)
+    try:
+        got, gst, _ = _fused_keep(caller, pile, ref2, x0, [(0, 11_111), (11_111, 18_889)])
+        tab = caller.gc_stats()
+    finally:
+        caller.set_gc_bins(None, 0, 0)
+    depth = pile["counts"].reshape(n, 16).sum(axis=1)
+    exp = np.zeros((4096, 101), dtype=np.uint64)
+    for i in np.nonzero(got["pos"] != 0)[0]:
+        pos = x0 + int(i)
+        if pos < start:
+            continue
+        bn = (pos - start) // 100
+        if bn < len(bins) and bins[bn] <= 100:
+            exp[min(int(depth[i]), 4095), bins[bn]] += 1
+    assert (tab == exp).all() and int(tab.sum()) > 20_000
+    assert int(tab.sum(axis=1)[: 4096].sum()) <= int(gst["cov"][:, 0].sum())  # a subset of the "All" coverage column
+    # switched off: nothing more is added
+    _fused_keep(caller, pile, ref2, x0, [(0, n)])
+    assert (caller.gc_stats() == tab).all()
+
+
+def _fused_keep(c, pile, ref2, x, windows):
+    """_fused without the statistics reset (the caller set up what it wants accumulated)."""
+    nb = len(pile)
+    core = np.zeros(nb, dtype=VCF_CORE)
+    for first, n in windows:
+        lc, rc, lr = min(2, first), min(2, nb - first - n), min(4, first)
+        d_cts = _dev(pile[first - lc : first + n + rc])
+        d_ref = _dev(ref2[first - lr : first + n + 2])
+        d_core = torch.full((n * 64,), 0xA5, dtype=torch.uint8, device=DEV)
+        c.chain_device(d_cts.data_ptr(), d_ref.data_ptr(), x, nb, first, n, d_core.data_ptr(), False, 1, 0xFFFFFFFF, None, True, None)
+        torch.cuda.synchronize()
+        core[first : first + n] = d_core.cpu().numpy().view(VCF_CORE)
+    return core, c.site_stats().copy(), c.stats()

@@ -86,3 +86,39 @@ def test_rank0_of_8_share(oracle, tables, libm_exact):
             exp = oracle.vcf_block(gtm, skip, ref2, 1 + lo)
             got = rc.d_core[a * 64 : (a + m) * 64].cpu().numpy().view(VCF_CORE)
             assert got.tobytes() == exp[pad : pad + m].tobytes(), "contig %d window at %d" % (rc.index, a)
+
+
+def test_report_of_a_small_genome():
+    """Three small contigs walked in windows with the GC bins set: the JSON report parses, the per-contig copies add up to
+    the totals, the GC table is a census of the "All" coverage column restricted to complete bins."""
+    import json
+
+    import torch
+
+    dev = torch.device("cuda:0")
+    lengths = [700_000, 300_123, 90_000]
+    firsts = genome.contig_first_sites(lengths)
+    with B.SiteCaller() as c:
+        res = [genome.make_resident(c, k, lengths[k], firsts[k], COV, dev, with_gc=True) for k in range(3)]
+        torch.cuda.synchronize()
+        text = genome.walk_with_report(c, res, ["chrA", "chrB", "chrC"], 200_040, date=(3, 10, 2026), filter_cts=[1], filter_bases=[100],
+                                       base_filter=[100])
+        st = c.site_stats()
+        # the reference's writer leaves an object without entries without its opening brace (src/stats.c:113-124: the synthetic
+        # genome has no non-reference CpG): repaired here for the parser, the text itself stays as the reference writes it
+        assert '"NonRefCpG": \n\t\t\t}' in text
+        d = json.loads(text.replace('": \n\t\t\t}', '": {\n\t\t\t}'))
+        assert d["date"] == "03/10/2026" and list(d["contigStats"]) == ["chrA", "chrB", "chrC"]
+        for key, f in (("SNPS", "snps"), ("RefCpG", "CpG_ref"), ("NonRefCpG", "CpG_nonref")):
+            assert sum(v[key]["All"] for v in d["contigStats"].values()) == d["totalStats"][key]["All"] == int(st[f][0])
+            assert sum(v[key]["Passed"] for v in d["contigStats"].values()) == d["totalStats"][key]["Passed"] == int(st[f][1])
+        cov_all = {int(k): v for k, v in d["totalStats"]["coverage"]["All"].items()}
+        gc = {int(k): v for k, v in d["totalStats"]["coverage"]["GC"].items()}
+        assert set(gc) == set(cov_all) and all(len(v) == 101 for v in gc.values())
+        n_gc = sum(sum(v) for v in gc.values())
+        # every called position lies in a bin unless the bin holds an N or is the contig's last, incomplete one
+        assert 0.9 * sum(cov_all.values()) < n_gc <= sum(cov_all.values())
+        assert all(sum(gc[k]) <= cov_all[k] for k in gc)
+        # G+C of a random reference: centred on 50
+        hist = np.array([sum(gc[k][g] for k in gc) for g in range(101)])
+        assert 45 < float((hist * np.arange(101)).sum() / hist.sum()) < 55
