@@ -117,6 +117,23 @@ def allreduce_site_stats(local, device=None):
     return rec[0]
 
 
+def allreduce_counts(local: np.ndarray, device=None) -> np.ndarray:
+    """Sum a table of u64 counts over the default process group: the GC-by-coverage table (SiteCaller.gc_stats()), the
+    non-CpG read profile (ReadProfile.counts, padded to a common length by the caller), the reader's filter counters —
+    everything else the report needs that is a sum.  No-op without a process group."""
+    import torch
+    import torch.distributed as dist
+
+    v = np.ascontiguousarray(local, dtype=np.uint64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return v.copy()
+    t = torch.from_numpy(v.view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy().view(np.uint64).reshape(v.shape)
+
+
 def gather_contig_stats(per_contig: Dict[int, np.ndarray], n_contigs: int, device=None) -> np.ndarray:
     """Per-contig counter blocks -> the full [n_contigs, STATS_WORDS] table on every rank.  Each contig is owned
     by one rank, so a sum-all-reduce of the zero-padded table is a gather."""

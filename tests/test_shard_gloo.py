@@ -66,9 +66,11 @@ def _worker(rank, world, port, q):
         out, skip = O.call_sites(pile[: lengths[ci]], ref[: lengths[ci]], tb, O.LIBM, 1)
         O.vcf_block_stats(out, skip, ref, 1, site, np.zeros(2, dtype=np.uint32), tb.lfact_store)
     site_sum = shard.allreduce_site_stats(site[0])
+    gc = np.random.default_rng(100 + rank).integers(0, 2**40, (4096, 101)).astype(np.uint64)  # a rank's GC-by-coverage table
+    gc_sum = shard.allreduce_counts(gc)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, total, allsum, table, site[0].tobytes(), site_sum.tobytes()))
+    q.put((rank, total, allsum, table, site[0].tobytes(), site_sum.tobytes(), int(gc_sum.sum()), gc_sum[17, 50]))
 
 
 def test_world2_gloo_stats_allreduce():
@@ -88,7 +90,9 @@ def test_world2_gloo_stats_allreduce():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, t0, a0, tab0, s0, ss0), (_, t1, a1, tab1, s1, ss1) = res
+    (_, t0, a0, tab0, s0, ss0, g0, c0), (_, t1, a1, tab1, s1, ss1, g1, c1) = res
+    gcs = [np.random.default_rng(100 + r).integers(0, 2**40, (4096, 101)).astype(np.uint64) for r in range(2)]
+    assert g0 == g1 == int(gcs[0].sum() + gcs[1].sum()) and c0 == c1 == gcs[0][17, 50] + gcs[1][17, 50]
     s0, s1, ss0, ss1 = (np.frombuffer(b, dtype=B.SITE_STATS)[0] for b in (s0, s1, ss0, ss1))
     assert ss0.tobytes() == ss1.tobytes()
     for f in B.SITE_STATS.names:
