@@ -41,6 +41,8 @@ EXPORTS = (
     "bsc_set_gc_bins",
     "bsc_get_gc_stats",
     "bsc_report_json",
+    "bsc_bcf_default_ids",
+    "bsc_bcf_record",
     "bsc_chain_window_quantum",
     "bsc_prepare_templates",
     "bsc_prepare_templates_profile",
@@ -113,6 +115,11 @@ class Report(C.Structure):
 class ReadProfile(C.Structure):
     _fields_ = [("ref", C.c_void_p), ("x", C.c_uint32), ("n_ref", C.c_uint32), ("counts", C.c_void_p), ("cap", C.c_uint32),
                 ("used", C.c_uint32)]
+
+
+class BcfIds(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in ("pass_", "fail", "mac1", "info_cx", "fmt_gt", "fmt_ft", "fmt_gl", "fmt_gq", "fmt_dp",
+                                          "fmt_mq", "fmt_qd", "fmt_mc8", "fmt_amq", "fmt_cs", "fmt_cg", "fmt_cx", "fmt_fs")]
 
 
 class Stats(C.Structure):
@@ -214,6 +221,10 @@ def load():
     L.bsc_get_gc_stats.argtypes = [vp, vp]
     L.bsc_get_site_totals.restype = i32
     L.bsc_get_site_totals.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.bsc_bcf_default_ids.restype = None
+    L.bsc_bcf_default_ids.argtypes = [C.POINTER(BcfIds)]
+    L.bsc_bcf_record.restype = C.c_long
+    L.bsc_bcf_record.argtypes = [vp, i32, C.c_char_p, C.c_size_t, C.POINTER(BcfIds), vp, C.c_size_t]
     L.bsc_report_json.restype = C.c_long
     L.bsc_report_json.argtypes = [C.POINTER(Report), C.c_char_p, C.c_size_t]
     L.bsc_chain_window_quantum.restype = C.c_uint32

@@ -41,11 +41,13 @@ int bsc_vcf_format(const bsc_vcf_core *c, const bsc_gt_meth *g, const char *cont
   PUT("GT:FT:DP:MQ:GQ:QD:GL:MC8%s:CS:CG:CX%s\t", n_amq ? ":AMQ" : "", het ? ":FS" : "");
   PUT("%d/%d:", ((c->gt_enc >> 4) >> 1) - 1, ((c->gt_enc & 15) >> 1) - 1);
   if (c->flt & 15) {
-    int first = 1;
+    /* The reference's copy loop leaves every name's terminator in the buffer (`while((*p++ = *p1++));`,
+     * src/print_vcf.c:289-293): the BCF field is "q20\0;qd2\0" (csrc/bcf.c writes exactly that) and a VCF writer, which
+     * ends a per-sample string at its first NUL, shows the FIRST failed filter only. */
     for (int i = 0; i < 4; i++)
       if (c->flt >> i & 1) {
-        PUT("%s%s", first ? "" : ";", FLT_NAMES[i]);
-        first = 0;
+        PUT("%s", FLT_NAMES[i]);
+        break;
       }
   } else PUT("PASS");
   PUT(":%u:%d:%u:%u:", c->dp, g->mq, c->phred, c->qd);

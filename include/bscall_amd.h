@@ -262,6 +262,24 @@ int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, co
 int bsc_vcf_format_rec(const bsc_vcf_rec *r, const char *contig, const char *id, char *buf, size_t cap);
 
 /*
+ * One written record as a BCF2 record (host C; csrc/bcf.c): the bytes bcf_write() emits for the record the reference
+ * assembles with htslib's typed-value encoders (src/print_vcf.c:160-222, :267-378) — 32 bytes of fixed fields, the shared
+ * block (ID, REF, ALT, FILTER, INFO CX) and the per-sample block (GT FT DP MQ GQ QD GL MC8 [AMQ] CS CG CX [FS]).
+ * `ids` = the header dictionary indices of the keys (bsc_bcf_default_ids: the header print_vcf_header writes,
+ * src/print_vcf.c:712-731); rid = the contig's index among the header's ##contig lines; id / id_len = the dbSNP name as
+ * bsc_dbsnp_name returns it (id_len 0: no ID).  Returns the record's length (> cap: buf too small, nothing usable
+ * written), 0 for a record that is not written (emit == 0), -1 on a bad argument.  The typed-value rules are the BCF2
+ * specification's; byte parity with htslib itself is not pinned in this image.
+ */
+typedef struct {
+  int32_t pass, fail, mac1, info_cx;
+  int32_t fmt_gt, fmt_ft, fmt_gl, fmt_gq, fmt_dp, fmt_mq, fmt_qd, fmt_mc8, fmt_amq, fmt_cs, fmt_cg, fmt_cx, fmt_fs;
+} bsc_bcf_ids;
+void bsc_bcf_default_ids(bsc_bcf_ids *ids);
+long bsc_bcf_record(const bsc_vcf_rec *r, int32_t rid, const char *id, size_t id_len, const bsc_bcf_ids *ids, uint8_t *buf,
+                    size_t cap);
+
+/*
  * Site statistics: the sums the reference's printer adds to bs_stats for every position that reaches
  * _print_vcf_entry (src/print_vcf.c:382-526; types include/bs_call.h:75-95,120-146) — the payload of the one
  * collective of a sharded run (every field is a sum, so shards add).  Computed on the device

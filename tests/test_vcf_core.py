@@ -140,7 +140,8 @@ def _py_format_record(core, gtm, contig, rs_id="."):
             "CX=" + core["cx_ref"].decode()]
     enc = int(core["gt_enc"])
     a, b = (enc >> 4 >> 1) - 1, ((enc & 15) >> 1) - 1
-    ft = ";".join(n for i, n in enumerate(FLT_NAMES) if flt >> i & 1) if flt & 15 else "PASS"
+    # the reference leaves each name's NUL in the FT buffer (src/print_vcf.c:289-293): text shows the first failed filter only
+    ft = next(n for i, n in enumerate(FLT_NAMES) if flt >> i & 1) if flt & 15 else "PASS"
     counts = [int(c) for c in gtm["counts"]]
     amq = [str(int(q)) for c, q in zip(counts, gtm["qual"]) if c > 0]
     keys = ["GT", "FT", "DP", "MQ", "GQ", "QD", "GL", "MC8"]
