@@ -43,6 +43,7 @@ EXPORTS = (
     "bsc_report_json",
     "bsc_bcf_default_ids",
     "bsc_bcf_record",
+    "bsc_bcf_block",
     "bsc_chain_window_quantum",
     "bsc_prepare_templates",
     "bsc_prepare_templates_profile",
@@ -225,6 +226,8 @@ def load():
     L.bsc_bcf_default_ids.argtypes = [C.POINTER(BcfIds)]
     L.bsc_bcf_record.restype = C.c_long
     L.bsc_bcf_record.argtypes = [vp, i32, C.c_char_p, C.c_size_t, C.POINTER(BcfIds), vp, C.c_size_t]
+    L.bsc_bcf_block.restype = C.c_long
+    L.bsc_bcf_block.argtypes = [vp, u64, i32, C.POINTER(BcfIds), vp, vp, C.c_size_t, C.POINTER(u64)]
     L.bsc_report_json.restype = C.c_long
     L.bsc_report_json.argtypes = [C.POINTER(Report), C.c_char_p, C.c_size_t]
     L.bsc_chain_window_quantum.restype = C.c_uint32

@@ -213,3 +213,27 @@ long bsc_bcf_record(const bsc_vcf_rec *r, int32_t rid, const char *id, size_t id
   }
   return total;
 }
+
+/* The written records of a block, one after the other (what the print thread hands bcf_write for a block): recs[n] in
+ * position order; db != NULL names the records whose rs_found flag is set (bsc_dbsnp_name: the loaded contig must be the
+ * block's).  Stops in front of the first record that does not fit; *n_done = records consumed (written or not emitted).
+ * Returns the bytes written, -1 on a bad argument. */
+long bsc_bcf_block(const bsc_vcf_rec *recs, uint64_t n, int32_t rid, const bsc_bcf_ids *ids, const bsc_dbsnp *db, uint8_t *buf,
+                   size_t cap, uint64_t *n_done) {
+  if ((n && !recs) || !ids || !buf || !n_done) return -1;
+  size_t len = 0;
+  uint64_t i = 0;
+  for (; i < n; i++) {
+    char rs[64];
+    size_t rs_len = 0;
+    if (db && recs[i].rs_found) {
+      if (bsc_dbsnp_name(db, recs[i].core.pos, rs, sizeof rs, &rs_len) < 0) return -1;
+    }
+    const long w = bsc_bcf_record(recs + i, rid, rs_len ? rs : NULL, rs_len, ids, buf + len, cap - len);
+    if (w < 0) return -1;
+    if ((size_t)w > cap - len) break;
+    len += (size_t)w;
+  }
+  *n_done = i;
+  return (long)len;
+}

@@ -278,6 +278,11 @@ typedef struct {
 void bsc_bcf_default_ids(bsc_bcf_ids *ids);
 long bsc_bcf_record(const bsc_vcf_rec *r, int32_t rid, const char *id, size_t id_len, const bsc_bcf_ids *ids, uint8_t *buf,
                     size_t cap);
+/* The written records of a block one after the other, named from the dbSNP index where rs_found is set (db may be NULL);
+ * stops in front of the first record that does not fit: *n_done = records consumed.  Returns the bytes written. */
+struct bsc_dbsnp;
+long bsc_bcf_block(const bsc_vcf_rec *recs, uint64_t n, int32_t rid, const bsc_bcf_ids *ids, const struct bsc_dbsnp *db, uint8_t *buf,
+                   size_t cap, uint64_t *n_done);
 
 /*
  * Site statistics: the sums the reference's printer adds to bs_stats for every position that reaches

@@ -118,3 +118,74 @@ def test_not_written_and_bad_arguments():
     assert _c_record(r, 0) == -1
     L = _lib.load()
     assert L.bsc_bcf_record(None, 0, None, 0, None, None, 0) == -1
+
+
+def _read_bgzf(path):
+    """BGZF reader from the SAM specification: concatenated gzip members, each with a 'BC' extra field."""
+    import struct
+    import zlib
+
+    raw = open(path, "rb").read()
+    out, o = bytearray(), 0
+    while o < len(raw):
+        assert raw[o : o + 4] == b"\x1f\x8b\x08\x04"
+        xlen = struct.unpack_from("<H", raw, o + 10)[0]
+        assert raw[o + 12 : o + 16] == b"BC\x02\x00"
+        bsize = struct.unpack_from("<H", raw, o + 16)[0] + 1
+        body = raw[o + 12 + xlen : o + bsize - 8]
+        data = zlib.decompress(body, -15)
+        crc, isize = struct.unpack_from("<II", raw, o + bsize - 8)
+        assert zlib.crc32(data) & 0xFFFFFFFF == crc and isize == len(data)
+        out += data
+        o += bsize
+    assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))  # the EOF marker block
+    return bytes(out)
+
+
+def test_bcf_file_round_trip(tmp_path):
+    """Header + a few thousand records through write_bcf (BGZF) and back through a reader written from the specifications;
+    the same stream uncompressed; gzip's own reader accepts the BGZF file (it is a multi-member gzip file)."""
+    import gzip
+    import struct
+
+    from bs_call_amd import vcf
+
+    rng = np.random.default_rng(5)
+    recs = np.zeros(3000, dtype=VCF_REC)
+    for i in range(len(recs)):
+        recs[i] = _random_rec(rng)
+        recs[i]["core"]["pos"] = 1000 + 3 * i
+    recs[17]["core"]["emit"] = 0  # not written
+    hdr = vcf.header_text([("chr1", 248956422), ("chr2", 242193529, "GRCh38")], "SAMPLE1", date=(3, 10, 2026))
+    assert hdr.startswith("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,") and hdr.endswith("\tFORMAT\tSAMPLE1\n")
+    assert "##contig=<ID=chr2,length=242193529,assembly=GRCh38>\n" in hdr and "##source=bs_call_v2.1,under_conversion=0.01,over_conversion=0.05,mapq_thresh=20,bq_thresh=20\n" in hdr
+    # the keys appear in the order that gives the dictionary indices of bsc_bcf_default_ids
+    keys = []
+    for ln in hdr.splitlines():
+        if ln.startswith(("##FILTER=<ID=", "##INFO=<ID=", "##FORMAT=<ID=")):
+            k = ln.split("<ID=")[1].split(",")[0]
+            if k not in keys:
+                keys.append(k)
+    assert keys == py_bcf.HEADER_KEYS
+    blocks = [vcf.bcf_block(recs[:1000], 0), vcf.bcf_block(recs[1000:], 1)]
+    p1, p2 = tmp_path / "out.bcf", tmp_path / "plain.bcf"
+    vcf.write_bcf(p1, hdr, blocks)
+    vcf.write_bcf(p2, hdr, blocks, compressed=False)
+    stream = _read_bgzf(p1)
+    assert stream == open(p2, "rb").read() == gzip.open(p1, "rb").read()
+    assert stream[:5] == b"BCF\x02\x02"
+    l_text = struct.unpack_from("<I", stream, 5)[0]
+    assert stream[9 : 9 + l_text] == hdr.encode() + b"\0"
+    o, k, n = 9 + l_text, 0, 0
+    while o < len(stream):
+        l_shared, l_indiv = struct.unpack_from("<II", stream, o)
+        rec = stream[o : o + 8 + l_shared + l_indiv]
+        while not recs[k]["core"]["emit"]:
+            k += 1
+        d = py_bcf.decode_record(rec)
+        assert d["pos"] == int(recs[k]["core"]["pos"]) and d["rid"] == (0 if k < 1000 else 1)
+        assert rec == _c_record(recs[k], 0 if k < 1000 else 1)
+        o += len(rec)
+        k += 1
+        n += 1
+    assert n == 2999
