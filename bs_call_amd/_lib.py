@@ -44,6 +44,14 @@ EXPORTS = (
     "bsc_bcf_default_ids",
     "bsc_bcf_record",
     "bsc_bcf_block",
+    "bsc_bam_open",
+    "bsc_bam_close",
+    "bsc_bam_n_refs",
+    "bsc_bam_ref_name",
+    "bsc_bam_ref_len",
+    "bsc_bam_header_text",
+    "bsc_bam_next_block",
+    "bsc_bam_filter_counts",
     "bsc_chain_window_quantum",
     "bsc_prepare_templates",
     "bsc_prepare_templates_profile",
@@ -116,6 +124,16 @@ class Report(C.Structure):
 class ReadProfile(C.Structure):
     _fields_ = [("ref", C.c_void_p), ("x", C.c_uint32), ("n_ref", C.c_uint32), ("counts", C.c_void_p), ("cap", C.c_uint32),
                 ("used", C.c_uint32)]
+
+
+class ReaderParams(C.Structure):
+    _fields_ = [("mapq_thresh", C.c_uint32), ("max_template_len", C.c_uint64), ("keep_unmatched", C.c_int32),
+                ("ignore_duplicates", C.c_int32), ("keep_duplicates", C.c_int32)]
+
+
+class ReadBlock(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("y", C.c_uint32), ("nr", C.c_uint32), ("tpl", C.c_void_p), ("seq", C.c_void_p),
+                ("seq_bytes", C.c_uint64), ("misms", C.c_void_p), ("n_misms", C.c_uint64)]
 
 
 class BcfIds(C.Structure):
@@ -226,6 +244,22 @@ def load():
     L.bsc_bcf_default_ids.argtypes = [C.POINTER(BcfIds)]
     L.bsc_bcf_record.restype = C.c_long
     L.bsc_bcf_record.argtypes = [vp, i32, C.c_char_p, C.c_size_t, C.POINTER(BcfIds), vp, C.c_size_t]
+    L.bsc_bam_open.restype = i32
+    L.bsc_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.bsc_bam_close.restype = None
+    L.bsc_bam_close.argtypes = [vp]
+    L.bsc_bam_n_refs.restype = i32
+    L.bsc_bam_n_refs.argtypes = [vp]
+    L.bsc_bam_ref_name.restype = C.c_char_p
+    L.bsc_bam_ref_name.argtypes = [vp, i32]
+    L.bsc_bam_ref_len.restype = u32
+    L.bsc_bam_ref_len.argtypes = [vp, i32]
+    L.bsc_bam_header_text.restype = C.c_char_p
+    L.bsc_bam_header_text.argtypes = [vp]
+    L.bsc_bam_next_block.restype = i32
+    L.bsc_bam_next_block.argtypes = [vp, C.POINTER(ReaderParams), C.POINTER(ReadBlock)]
+    L.bsc_bam_filter_counts.restype = None
+    L.bsc_bam_filter_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.bsc_bcf_block.restype = C.c_long
     L.bsc_bcf_block.argtypes = [vp, u64, i32, C.POINTER(BcfIds), vp, vp, C.c_size_t, C.POINTER(u64)]
     L.bsc_report_json.restype = C.c_long

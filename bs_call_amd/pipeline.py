@@ -1,0 +1,71 @@
+"""BAM -> BCF through the library, block by block — the reference's four threads in a line (reader: bsc_bam_next_block;
+process: bsc_prepare_templates + the block's reference; calc + print: bsc_block_records on the GPU; output: bsc_bcf_block) —
+and the run's JSON report.  An example of the pieces put together for tests and for INTEGRATION.md, not a command-line
+replacement of bs_call: the reference's argument parsing, region / contig selection and FASTA reader are out of scope
+(SURVEY.md section 8)."""
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import report, vcf
+from .bam import BamReader
+from .caller import ReadProfile, SiteCaller, prepare_templates
+
+
+def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: str = "SAMPLE", report_path: Optional[str] = None,
+        caller: Optional[SiteCaller] = None, dbsnp=None, compressed: bool = True, date=None, left_trim=(0, 0), right_trim=(0, 0),
+        min_qual: int = 20, **reader_kw) -> dict:
+    """reference: contig name -> uint8 reference codes (0 = N, 1..4 = ACGT; position 1 first).  Returns a summary dict."""
+    own = caller is None
+    c = caller or SiteCaller()
+    try:
+        prof = ReadProfile()
+        base_filter = np.zeros(5, dtype=np.uint64)
+        passed = np.zeros(2, dtype=np.uint64)
+        per_contig, blobs = [], []
+        n_blocks = n_records = 0
+        c.reset_site_stats()
+        with BamReader(bam_path, **reader_kw) as rd:
+            refs = rd.refs
+            before, cur_tid = c.site_totals(), -1
+            for tid, y, raw, seq, ms in rd.blocks():
+                name, _ = refs[tid]
+                if tid != cur_tid:
+                    if cur_tid >= 0:
+                        after = c.site_totals()
+                        per_contig.append((refs[cur_tid][0], after - before))
+                        before = after
+                    cur_tid = tid
+                    if dbsnp is not None:
+                        dbsnp.load_contig(name)
+                codes = reference[name]
+                x = int(raw["pos"][0][0]) or int(raw["pos"][0][1])
+                x = x - 2 if x > 2 else 1  # process_template_vector, src/process_template.c:22-28
+                ref = np.zeros(y - x + 3, dtype=np.uint8)
+                have = codes[x - 1 : y + 2]
+                ref[: len(have)] = have
+                tpl, pseq, st = prepare_templates(raw, seq, ms, left_trim, right_trim, min_qual, profile=prof, x=x, ref=ref)
+                base_filter += np.array([st["base_none"], st["base_trim"], st["base_clip"], st["base_overlap"], st["base_lowqual"]], dtype=np.uint64)
+                passed += np.array([st["reads"], st["read_bases"]], dtype=np.uint64)
+                flags = None if dbsnp is None else dbsnp.flags(x, y - x + 1)
+                recs = c.block_records(tpl, pseq, x, y, ref, reg_stop=len(codes), dbsnp=flags, with_stats=True)
+                blobs.append(vcf.bcf_block(recs, tid, dbsnp))
+                n_blocks += 1
+                n_records += len(recs)
+            if cur_tid >= 0:
+                per_contig.append((refs[cur_tid][0], c.site_totals() - before))
+            cts, bases = rd.filter_counts()
+            header = vcf.header_text([(n, l) for n, l in refs], sample, min_qual=min_qual, date=date,
+                                     dbsnp_header=None if dbsnp is None else dbsnp.header)
+        vcf.write_bcf(bcf_path, header, blobs, compressed)
+        cts[0] += int(passed[0])
+        bases[0] += int(passed[1])
+        text = report.render_json(c.site_stats(), min_qual=min_qual, date=date, have_dbsnp=dbsnp is not None, filter_cts=cts, filter_bases=bases,
+                                  base_filter=base_filter.tolist(), read_profile=prof.reported(), contigs=per_contig)
+        if report_path:
+            with open(report_path, "w") as f:
+                f.write(text)
+        return {"blocks": n_blocks, "records": n_records, "report": text, "filter_cts": cts, "contigs": [n for n, _ in per_contig]}
+    finally:
+        if own:
+            c.close()

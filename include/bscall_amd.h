@@ -472,6 +472,44 @@ uint32_t bsc_block_start(const bsc_raw_template *first);
 uint32_t bsc_template_qual(const bsc_raw_template *t, const uint8_t *seq);
 
 /*
+ * BAM in, blocks of templates out (host C + zlib, no htslib; csrc/bamio.c): the reader thread of the reference —
+ * read_input (src/get_template_vector.c:49-389) over get_next_align_details (src/input_sam.c:222-312).  A block is what
+ * read_input queues for process_template_vector: the templates of one stretch of overlapping alignments of one contig
+ * (mates joined, duplicates resolved), ready for bsc_prepare_templates -> bsc_accumulate / bsc_block_records, with
+ * y = the rightmost covered position (x = bsc_block_start of the first template).
+ *   bsc_bam_open        a coordinate-sorted BAM file (BGZF); the header text and the @SQ list are available at once
+ *   bsc_bam_next_block  1 = *blk filled (valid until the next call), 0 = end of input, < 0 = error (bsc_last_error)
+ *   bsc_bam_filter_counts  bs_stats.filter_cts / filter_bases as the reader leaves them: reads and bases by verdict,
+ *                       gt_filter_reason order, [14] = "PairNotFound" ([0], the passed reads, is counted by
+ *                       bsc_prepare_templates: bsc_prep_stats.reads / read_bases)
+ * Not covered: SAM / CRAM input, region queries through an index, contig include / exclude lists.
+ */
+typedef struct bsc_bam bsc_bam;
+typedef struct {
+  uint32_t mapq_thresh;       /* sr_param.mapq_thresh (20) */
+  uint64_t max_template_len;  /* sr_param.max_template_len (1000) */
+  int32_t keep_unmatched, ignore_duplicates, keep_duplicates; /* -u / -d / -k */
+} bsc_reader_params;
+typedef struct {
+  int32_t tid;  /* index of the contig in the BAM header */
+  uint32_t y;   /* rightmost position covered by the block's alignments */
+  uint32_t nr;
+  const bsc_raw_template *tpl;
+  const uint8_t *seq;
+  uint64_t seq_bytes;
+  const bsc_misms *misms;
+  uint64_t n_misms;
+} bsc_read_block;
+int bsc_bam_open(const char *path, bsc_bam **out);
+void bsc_bam_close(bsc_bam *b);
+int bsc_bam_n_refs(const bsc_bam *b);
+const char *bsc_bam_ref_name(const bsc_bam *b, int i);
+uint32_t bsc_bam_ref_len(const bsc_bam *b, int i);
+const char *bsc_bam_header_text(const bsc_bam *b);
+int bsc_bam_next_block(bsc_bam *b, const bsc_reader_params *par, bsc_read_block *blk);
+void bsc_bam_filter_counts(const bsc_bam *b, uint64_t cts[15], uint64_t bases[15]);
+
+/*
  * dbSNP index (host C + zlib; csrc/dbsnp.c): the reader of the compressed index bin/dbSNP_idx writes.  In the reference
  * the index never touches the likelihoods: an entry names the record (VCF ID), forces the AA / TT homozygous-reference
  * record of a site flagged in its `fq_mask` to be written (rs_found & 2, src/print_vcf.c:139) and feeds the dbSNP

@@ -1,0 +1,247 @@
+"""csrc/bamio.c (BAM in, blocks of templates out) against hand-worked scenarios — one per branch of get_next_align_details
+and read_input, each derived from the cited lines — and against the independent Python restatement (oracle/py_bam.py) on
+random coordinate-sorted BAM files written by tools/make_bam.py.  Host code: CPU only."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from bs_call_amd.bam import BamReader
+from bs_call_amd.caller import BscError
+from oracle import py_bam
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("make_bam", os.path.join(ROOT, "tools", "make_bam.py"))
+W = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(W)
+
+REFS = [("chr1", 100_000), ("chr2", 50_000)]
+
+
+def rec(name, flag, pos, mpos, seq="ACGTACGTAC", cigar=None, mapq=60, tid=0, mtid=None, tlen=0, qual=None, aux=b"", **kw):
+    cigar = cigar or [("M", len(seq))]
+    return dict(name=name, flag=flag, tid=tid, pos=pos, mapq=mapq, cigar=cigar, mtid=tid if mtid is None else mtid, mpos=mpos, tlen=tlen,
+                seq=seq, qual=None if qual == "missing" else (qual if qual is not None else [30] * len(seq)), aux=aux, **kw)
+
+
+def c_blocks(path, **kw):
+    out = []
+    with BamReader(path, **kw) as r:
+        for tid, y, tpl, seq, ms in r.blocks():
+            ts = []
+            for t in tpl:
+                reads, misms = [], []
+                for k in range(2):
+                    ln = int(t["len"][k])
+                    reads.append(seq[int(t["off"][k]) : int(t["off"][k]) + ln].tolist() if ln else None)
+                    o, n = int(t["misms_off"][k]), int(t["n_misms"][k])
+                    misms.append([[int(m["type"]), int(m["position"]), int(m["size"])] for m in ms[o : o + n]])
+                ts.append({"pos": [int(v) for v in t["pos"]], "span": [int(t["reference_span"][k]) if t["len"][k] else 0 for k in range(2)],
+                           "reads": reads, "misms": misms, "mapq": [int(v) for v in t["mapq"]], "orientation": int(t["orientation"]),
+                           "bs_strand": int(t["bs_strand"])})
+            out.append((tid, y, ts))
+        cts, bases = r.filter_counts()
+    return out, cts, bases
+
+
+def py_blocks(path, **kw):
+    text, refs, recs = py_bam.parse_bam(path)
+    st = {"cts": [0] * 15, "bases": [0] * 15}
+    out = []
+    for tid, y, als in py_bam.read_input(recs, stats=st, **kw):
+        out.append((tid, y, [{"pos": list(a["pos"]), "span": [a["span"][k] if a["reads"][k] else 0 for k in range(2)], "reads": [a["reads"][0], a["reads"][1]],
+                              "misms": a["misms"], "mapq": list(a["mapq"]), "orientation": a["orientation"], "bs_strand": a["bs_strand"]} for a in als]))
+    return out, st["cts"], st["bases"]
+
+
+def both(tmp_path, records, **kw):
+    p = str(tmp_path / "t.bam")
+    W.write_bam(p, REFS, records)
+    c = c_blocks(p, **kw)
+    py = py_blocks(p, **kw)
+    assert c == py
+    return c
+
+
+def b(base, q=30):
+    return "ACGT".index(base) | (q << 2)
+
+
+# ---- hand-worked scenarios ------------------------------------------------------------------------------------------------
+def test_header_and_a_proper_pair(tmp_path):
+    """Forward read 1 at 1000 (flag 99 = paired, proper, mate reverse, first), reverse read 2 at 1200 (147): one template,
+    FORWARD orientation (read[0] = R1), forward_position 1001, reverse_position 1201, both MAPQs, y = 1201 + 10."""
+    r1 = rec("p", 99, 1000, 1200, "ACGTACGTAC", tlen=210, aux=W.aux_char("XB", "C"), mapq=50)
+    r2 = rec("p", 147, 1200, 1000, "TTTTTGGGGG", tlen=-210, aux=W.aux_char("XB", "C"), mapq=40)
+    (blocks, cts, bases) = both(tmp_path, [r1, r2])
+    assert blocks == [(0, 1211, [{"pos": [1001, 1201], "span": [10, 10], "reads": [[b(c) for c in "ACGTACGTAC"], [b(c) for c in "TTTTTGGGGG"]],
+                                   "misms": [[], []], "mapq": [50, 40], "orientation": 0, "bs_strand": 1}])]
+    assert sum(cts) == 0
+    with BamReader(str(tmp_path / "t.bam")) as r:
+        assert r.refs == REFS and r.header_text.startswith("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:100000\n")
+
+
+def test_orientation_strand_tags_qualities_and_n(tmp_path):
+    """Read 2 forward + read 1 reverse = a REVERSE template; the strand tag of each aligner (src/input_sam.c:144-220); a quality
+    above 43 is clamped, an N (and any ambiguity code) is byte 0 whatever its quality; missing qualities (0xff) clamp to 43."""
+    recs = [rec("a", 163, 100, 300, "ACNTR", tlen=205, qual=[50, 43, 40, 7, 30], aux=W.aux_str("ZS", "-+")),  # BSMAP '-': G2A
+            rec("b", 99, 102, 302, "ACGTA", tlen=205, qual="missing", aux=W.aux_str("XG", "GA")),                 # Bowtie/Bismark: G2A
+            rec("c", 0, 104, -1, "ACGTA", aux=W.aux_int("NM", 3) + W.aux_str("YD", "f")),                     # bwa-meth f: C2T, single
+            rec("d", 16, 106, -1, "ACGTA", aux=W.aux_str("ZB", "CT")),                                        # Novoalign: C2T, reverse single
+            rec("a", 83, 300, 100, "GGGGG", tlen=-205, aux=W.aux_str("ZS", "-+")),
+            rec("b", 147, 302, 102, "CCCCC", tlen=-205, aux=W.aux_str("XG", "GA"))]
+    (blocks, cts, _) = both(tmp_path, recs)
+    ts = blocks[0][2]
+    assert [t["orientation"] for t in ts] == [1, 0, 0, 1] and [t["bs_strand"] for t in ts] == [2, 2, 1, 1]
+    assert ts[0]["reads"][0] == [b("A", 43), b("C", 43), 0, b("T", 7), 0]
+    assert ts[1]["reads"][0] == [b(c, 43) for c in "ACGTA"]
+    assert ts[2]["pos"] == [105, 0] and ts[2]["reads"][1] is None and ts[3]["pos"] == [0, 107] and ts[3]["reads"][0] is None
+    assert ts[3]["mapq"] == [0, 60]  # a reverse single read keeps its MAPQ in slot 1
+
+
+def test_cigar_to_mismatch_list(tmp_path):
+    """3S 4M 2I 3M 5D 2M 1S: soft clips and the insertion are entries with their offset in the read, the deletion an INS entry
+    (the reference's naming) that adds to the reference span only (src/input_sam.c:90-136)."""
+    seq = "A" * 15
+    r = rec("x", 0, 500, -1, seq, cigar=[("S", 3), ("M", 4), ("I", 2), ("M", 3), ("D", 5), ("M", 2), ("S", 1)])
+    (blocks, _, _) = both(tmp_path, [r])
+    t = blocks[0][2][0]
+    assert t["misms"][0] == [[3, 0, 3], [2, 7, 2], [1, 12, 5], [3, 14, 1]] and t["span"][0] == 4 + 3 + 5 + 2
+    assert blocks[0][1] == 501 + 14  # y = position + reference span
+
+
+def test_flag_filters_and_their_reasons(tmp_path):
+    """One record per verdict of get_next_align_details (:234-300), counted with its bases; none reaches a block."""
+    ok1, ok2 = rec("ok", 99, 100, 200, tlen=110), rec("ok", 147, 200, 100, tlen=-110)
+    bad = [rec("sec", 99 | 256, 101, 200), rec("unm", 1 | 4, 102, 200), rec("mun", 1 | 8, 103, 200), rec("qc", 99 | 512, 104, 200),
+           rec("dup", 99 | 1024, 105, 200), rec("npp", 1 | 32 | 64, 106, 200), rec("lowq", 99, 107, 200, mapq=19),
+           rec("chr", 99, 108, 200, mtid=1), rec("long", 99, 109, 2000, tlen=1901), rec("ori", 99, 210, 110, tlen=-100),
+           rec("s_dup", 1024, 111, -1), rec("s_qc", 512, 112, -1)]
+    recs = sorted([ok1, ok2] + bad, key=lambda r: r["pos"])
+    (blocks, cts, bases) = both(tmp_path, recs)
+    assert len(blocks) == 1 and len(blocks[0][2]) == 1
+    exp = [0] * 15
+    for reason, n in ((3, 1), (1, 1), (4, 1), (2, 2), (5, 2), (13, 1), (12, 1), (8, 1), (10, 1), (9, 1)):
+        exp[reason] = n
+    assert cts == exp and bases == [10 * v for v in exp]
+
+
+def test_blocks_split_at_gaps_and_contigs(tmp_path):
+    """A read starting more than one base beyond the rightmost covered position opens a new block (:139-147); adjacency (gap of
+    one) does not; a new contig always does, and the old block keeps the old contig's id (:176-183)."""
+    recs = [rec("a", 0, 100, -1), rec("b", 0, 110, -1),  # 101..110, then 111..120: touching -> same block
+            rec("c", 0, 121, -1),                         # starts at 122 = max_pos(121) + 1: still the same block
+            rec("d", 0, 133, -1),                         # 134 > 131 + 1: new block
+            rec("e", 0, 50, -1, tid=1)]
+    (blocks, _, _) = both(tmp_path, recs)
+    assert [(tid, y, len(ts)) for tid, y, ts in blocks] == [(0, 132, 3), (0, 144, 1), (1, 61, 1)]
+
+
+def test_duplicates_pairs_and_singles(tmp_path):
+    """Templates with the same positions and strand starting at the same place: the better one stays (mean MAPQ, then
+    get_al_qual), the other is counted as a duplicate — two reads if it was a complete pair (:282-321); the dropped
+    template's mate then finds nobody waiting: PairNotFound (:243-246)."""
+    recs = [rec("p1", 99, 100, 300, tlen=210, mapq=30), rec("p2", 99, 100, 300, tlen=210, mapq=50),  # p2 replaces p1
+            rec("p3", 99, 100, 300, tlen=210, mapq=50, qual=[20] * 10),                                # same MAPQ, lower quality: dropped
+            rec("s1", 0, 105, -1, mapq=40), rec("s2", 0, 105, -1, mapq=41),                            # singles: s2 replaces s1
+            rec("p1", 147, 300, 100, tlen=-210, mapq=30), rec("p2", 147, 300, 100, tlen=-210, mapq=50),
+            rec("p3", 147, 300, 100, tlen=-210, mapq=50)]
+    (blocks, cts, bases) = both(tmp_path, recs)
+    ts = blocks[0][2]
+    assert len(ts) == 2 and ts[0]["mapq"] == [50, 50] and ts[0]["reads"][1] is not None and ts[1]["mapq"] == [41, 0]
+    assert cts[5] == 3 and bases[5] == 20 and bases[0] == 10  # p1, p3 (one read each so far), s1 — whose bases land in the PASSED column (:363)
+    assert cts[14] == 2 and bases[14] == 20                   # the mates of p1 and p3
+
+
+def test_keep_duplicates_and_keep_unmatched(tmp_path):
+    recs = [rec("p1", 99, 100, 300, tlen=210), rec("p2", 99, 100, 300, tlen=210), rec("far", 99, 105, 5000, tlen=4905),
+            rec("p1", 147, 300, 100, tlen=-210), rec("p2", 147, 300, 100, tlen=-210)]
+    (blocks, cts, _) = both(tmp_path, recs, keep_duplicates=True)
+    assert len(blocks[0][2]) == 2 and cts[5] == 0 and cts[10] == 1
+    (blocks, cts, _) = both(tmp_path, recs, keep_duplicates=True, keep_unmatched=True)
+    ts = blocks[0][2]
+    assert len(ts) == 3 and ts[2]["pos"] == [106, 0] and cts[10] == 0  # the over-long pair's read is kept as a single
+
+
+def test_unsorted_and_broken_input(tmp_path):
+    p = str(tmp_path / "bad.bam")
+    # a backwards-facing mate whose partner never came is counted (PairNotFound) and dropped, it does not open a block
+    W.write_bam(p, REFS, [rec("a", 0, 100, -1), rec("m", 147, 400, 100, tlen=-310)])
+    blocks, cts, _ = c_blocks(p)
+    assert [(t, y, len(ts)) for t, y, ts in blocks] == [(0, 411, 1)] and cts[14] == 1
+    with open(p, "wb") as f:
+        f.write(b"\x1f\x8b\x08\x00" + b"\0" * 30)
+    with pytest.raises(BscError, match="BGZF"):
+        BamReader(p)
+    W.write_bam(p, REFS, [rec("a", 0, 100, -1)])
+    raw = open(p, "rb").read()
+    open(p, "wb").write(raw[: len(raw) - 40])
+    with pytest.raises(BscError):
+        c_blocks(p)
+    with pytest.raises(BscError, match="cannot open"):
+        BamReader(str(tmp_path / "missing.bam"))
+
+
+# ---- random files: C == Python restatement ---------------------------------------------------------------------------------
+def _random_records(rng, n):
+    recs = []
+    for i in range(n):
+        tid = int(rng.integers(0, 2))
+        pos = int(rng.integers(0, 3000)) if rng.random() < 0.9 else int(rng.integers(10_000, 12_000))
+        L = int(rng.integers(20, 60))
+        seq = "".join(rng.choice(list("ACGTN"), L, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+        qual = [int(v) for v in rng.integers(2, 60, L)]
+        cigar = [("M", L)]
+        if rng.random() < 0.3:
+            a = int(rng.integers(2, L - 6))
+            cigar = [("M", a), (("I", "D")[int(rng.integers(0, 2))], int(rng.integers(1, 4))), ("M", L - a)]
+            if cigar[1][0] == "I":
+                cigar[2] = ("M", L - a - cigar[1][1])
+        if rng.random() < 0.2:
+            cigar = [("S", 2)] + cigar
+            cigar[1] = ("M", cigar[1][1] - 2)
+        tag = [W.aux_char("XB", "C"), W.aux_char("XB", "G"), b"", W.aux_str("XG", "CT")][int(rng.integers(0, 4))]
+        mapq = int(rng.choice([0, 19, 20, 30, 60]))
+        kind = rng.random()
+        name = "r%05d" % (i if rng.random() < 0.97 else max(0, i - 1))
+        if kind < 0.55:  # a proper pair
+            span = sum(n_ for op, n_ in cigar if op in "MD")
+            ins = int(rng.integers(span, 400))
+            r1 = bool(rng.integers(0, 2))
+            dupf = 1024 if rng.random() < 0.03 else 0
+            recs.append(rec(name, 1 | 2 | 32 | (64 if r1 else 128) | dupf, pos, pos + ins - 30, seq, cigar, mapq, tid, tlen=ins, qual=qual, aux=tag))
+            seq2 = "".join(rng.choice(list("ACGT"), 30))
+            recs.append(rec(name, 1 | 2 | 16 | (128 if r1 else 64) | dupf, pos + ins - 30, pos, seq2, None, int(rng.choice([19, 30, 60])), tid, tlen=-ins,
+                            qual=[int(v) for v in rng.integers(2, 60, 30)], aux=tag))
+        elif kind < 0.85:
+            recs.append(rec(name, int(rng.choice([0, 16, 0, 16, 4, 256, 512, 1024])), pos, -1, seq, cigar, mapq, tid, qual=qual, aux=tag))
+        else:  # odd pairs: improper, mate elsewhere, wrong order
+            flag = int(rng.choice([1 | 32 | 64, 1 | 2 | 32 | 64, 1 | 2 | 16 | 128, 1 | 8 | 64]))
+            recs.append(rec(name, flag, pos, pos + int(rng.integers(-200, 2500)), seq, cigar, mapq, tid, mtid=int(rng.integers(0, 2)),
+                            tlen=int(rng.integers(-1500, 1500)), qual=qual, aux=tag))
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    return recs
+
+
+@pytest.mark.parametrize("seed,kw", [(1, {}), (2, {"keep_unmatched": True}), (3, {"keep_duplicates": True}), (4, {"ignore_duplicates": True, "mapq_thresh": 0}),
+                                     (5, {"max_template_len": 200})])
+def test_c_equals_python_on_random_bams(tmp_path, seed, kw):
+    rng = np.random.default_rng(seed)
+    n_blocks = n_tpl = 0
+    for trial in range(6):
+        recs = _random_records(rng, 400)
+        p = str(tmp_path / "r.bam")
+        W.write_bam(p, REFS, recs, block=int(rng.choice([0xFF00, 777, 4096])))
+        try:
+            py = py_blocks(p, **kw)
+        except AssertionError:
+            # the reference asserts (mates that disagree, a mate opening a block, a repeated name): the C reader reports it
+            with pytest.raises(BscError):
+                c_blocks(p, **kw)
+            continue
+        c = c_blocks(p, **kw)
+        assert c == py, (seed, trial)
+        n_blocks += len(c[0])
+        n_tpl += sum(len(ts) for _, _, ts in c[0])
+    assert n_blocks > 10 and n_tpl > 500

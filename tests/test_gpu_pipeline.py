@@ -1,0 +1,99 @@
+"""BAM -> BCF end to end on the GPU (bs_call_amd.pipeline: reader -> read pre-processing -> bsc_block_records -> BCF
+encoder) against the CPU oracle chain over the same file: oracle/py_bam.py (reader) -> oracle/py_prep.py (pre-processing) ->
+the C oracle's accumulate / call / record formation -> oracle/py_bcf.py (encoder).  The BCF streams must be identical."""
+import importlib.util
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import bs_call_amd as B
+from bs_call_amd import pipeline, vcf
+from oracle import py_bam, py_bcf, py_prep
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("make_bam", os.path.join(ROOT, "tools", "make_bam.py"))
+W = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(W)
+
+
+def _oracle_records(oracle, tables, libm_exact, bam, reference):
+    """The written records of every block, as dicts for py_bcf.encode_record, through the CPU oracle chain."""
+    text, refs, recs = py_bam.parse_bam(bam)
+    out = []
+    for tid, y, als in py_bam.read_input(recs):
+        name = refs[tid][0]
+        x = als[0]["pos"][0] or als[0]["pos"][1]
+        x = x - 2 if x > 2 else 1
+        codes = reference[name]
+        ref = np.zeros(y - x + 3, dtype=np.uint8)
+        have = codes[x - 1 : y + 2]
+        ref[: len(have)] = have
+        prepared, _ = py_prep.prepare(als)
+        tpl = np.zeros(len(prepared), dtype=B.TEMPLATE)
+        seq = []
+        for i, t in enumerate(prepared):
+            tpl["pos"][i] = t["pos"]
+            tpl["mapq"][i] = t["mapq"]
+            tpl["orientation"][i] = t["orientation"]
+            tpl["bs_strand"][i] = t["bs_strand"]
+            for k in range(2):
+                tpl["off"][i, k] = len(seq)
+                tpl["len"][i, k] = len(t["reads"][k])
+                seq += t["reads"][k]
+        seq = np.array(seq, dtype=np.uint8)
+        rc, pile = oracle.accumulate(tpl, seq, x, y)
+        assert rc == 0
+        gtm, skip = oracle.call_sites(pile, ref[: y - x + 1], tables, oracle.LIBM if libm_exact else oracle.BSM, 1)
+        core = oracle.vcf_block(gtm, skip, ref, x, reg_stop=len(codes))
+        for c, g in zip(core, gtm):
+            if not c["emit"]:
+                continue
+            out.append((tid, dict(pos=int(c["pos"]), gt=int(c["gt"]), flt=int(c["flt"]), phred=int(c["phred"]), alt=bytes(c["alt"]).rstrip(b"\0"),
+                                  ref=bytes(c["cx_ref"])[2:3], cx_ref=bytes(c["cx_ref"]), cx_gt=bytes(c["cx_gt"]), cg=bytes(c["cg"]),
+                                  gt_enc=int(c["gt_enc"]), dp=int(c["dp"]), mq=int(g["mq"]), qd=int(c["qd"]), fs=int(c["fs"]),
+                                  gl=[float(v) for v in c["gl"][: int(c["n_gl"])]], counts=[int(v) for v in g["counts"]], qual=[int(v) for v in g["qual"]])))
+    return refs, out
+
+
+def test_bam_to_bcf_equals_the_oracle_chain(tmp_path, oracle, tables, libm_exact):
+    rng = np.random.default_rng(31)
+    reference = {"chrA": rng.integers(1, 5, 30_000).astype(np.uint8), "chrB": rng.integers(1, 5, 12_000).astype(np.uint8)}
+    reference["chrA"][5_000:5_400] = 0  # an N run
+    refs = [(k, len(v)) for k, v in reference.items()]
+    recs = W.wgbs_records(rng, reference["chrA"], 0, 1500, het_every=500) + W.wgbs_records(rng, reference["chrB"], 1, 500, strand_tag="XG")
+    # the XG tag is a Z tag for Bowtie / Bismark: rewrite the second contig's tags accordingly
+    for r in recs:
+        if r["tid"] == 1:
+            r["aux"] = W.aux_str("XG", "CT" if r["aux"][3:4] == b"C" else "GA")
+    bam, bcf, rep = str(tmp_path / "in.bam"), str(tmp_path / "out.bcf"), str(tmp_path / "report.json")
+    W.write_bam(bam, refs, recs)
+    res = pipeline.run(bam, reference, bcf, sample="S1", report_path=rep, date=(3, 10, 2026), compressed=False)
+    assert res["blocks"] >= 2 and res["records"] > 5_000 and res["contigs"] == ["chrA", "chrB"]
+    # ---- the oracle chain, encoded by the independent Python encoder ----
+    orefs, orecs = _oracle_records(oracle, tables, libm_exact, bam, reference)
+    assert orefs == refs and len(orecs) == res["records"]
+    stream = open(bcf, "rb").read()
+    hdr = vcf.header_text(refs, "S1", date=(3, 10, 2026)).encode() + b"\0"
+    assert stream[:9] == b"BCF\x02\x02" + struct.pack("<I", len(hdr)) and stream[9 : 9 + len(hdr)] == hdr
+    exp = b"".join(py_bcf.encode_record(d, tid) for tid, d in orecs)
+    assert stream[9 + len(hdr) :] == exp
+    # ---- the report ----
+    text = open(rep).read()
+    d = json.loads(text.replace('": \\n\\t\\t\\t}', '": {\\n\\t\\t\\t}'))
+    rl = d["filterStats"]["ReadLevel"]
+    # every read is accounted for: passed, dropped as the duplicate of a template with the same positions and strand, or the
+    # mate of such a template arriving to find nobody waiting
+    assert rl["Passed"]["Reads"] + rl.get("Duplicate", {"Reads": 0})["Reads"] + rl.get("PairNotFound", {"Reads": 0})["Reads"] == 2 * 2000
+    assert rl["Passed"]["Reads"] > 3800 and d["totalStats"]["SNPS"]["All"] == res["records"]
+    prof = d["totalStats"]["methylation"]["NonCpGreadProfile"]
+    assert len(prof) == 100 and sum(map(sum, prof)) > 10_000  # read positions 0 .. 99
+    # flt_tab (src/init_param.c:57-70) puts the converting strand's observations (C / T on C2T reads, G / A on G2A reads) in
+    # counts 0 / 1 and the other strand's in 2 / 3: the generator converts non-CpG cytosines with p = 120 / 128 and miscalls 0.5 %
+    conv = sum(p[1] for p in prof) / max(1, sum(p[0] + p[1] for p in prof))
+    miss = sum(p[3] for p in prof) / max(1, sum(p[2] + p[3] for p in prof))
+    assert 0.90 < conv < 0.97 and miss < 0.01
+    assert sum(v["SNPS"]["All"] for v in d["contigStats"].values()) == res["records"]
