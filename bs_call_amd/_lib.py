@@ -44,6 +44,8 @@ EXPORTS = (
     "bsc_bcf_default_ids",
     "bsc_bcf_record",
     "bsc_bcf_block",
+    "bsc_fasta_contig",
+    "bsc_block_reference",
     "bsc_bam_open",
     "bsc_bam_close",
     "bsc_bam_n_refs",
@@ -244,6 +246,10 @@ def load():
     L.bsc_bcf_default_ids.argtypes = [C.POINTER(BcfIds)]
     L.bsc_bcf_record.restype = C.c_long
     L.bsc_bcf_record.argtypes = [vp, i32, C.c_char_p, C.c_size_t, C.POINTER(BcfIds), vp, C.c_size_t]
+    L.bsc_fasta_contig.restype = i32
+    L.bsc_fasta_contig.argtypes = [C.c_char_p, C.c_char_p, vp, u64, C.POINTER(u64)]
+    L.bsc_block_reference.restype = i32
+    L.bsc_block_reference.argtypes = [vp, u64, u32, u32, vp]
     L.bsc_bam_open.restype = i32
     L.bsc_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.bsc_bam_close.restype = None

@@ -57,3 +57,28 @@ class BamReader:
         cts, bases = (C.c_uint64 * 15)(), (C.c_uint64 * 15)()
         self._L.bsc_bam_filter_counts(self._h, cts, bases)
         return list(cts), list(bases)
+
+
+def fasta_contig(path, name, length_hint=0):
+    """One contig of a FASTA file (plain / gzip / bgzip) as reference codes 0 = N, 1..4 = ACGT (bsc_fasta_contig)."""
+    L = _lib.load()
+    cap = int(length_hint) or (1 << 20)
+    while True:
+        buf = np.empty(cap, dtype=np.uint8)
+        n = C.c_uint64(0)
+        rc = L.bsc_fasta_contig(str(path).encode(), name.encode(), buf.ctypes.data, cap, C.byref(n))
+        if rc == 0:
+            return buf[: n.value].copy()
+        if n.value > cap:
+            cap = int(n.value)
+            continue
+        _check(rc)
+
+
+def block_reference(codes, x, y):
+    """work->ref1 of the block x .. y: the codes of x .. y + 2 as get_sequence_string hands them over (bsc_block_reference)."""
+    L = _lib.load()
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    out = np.empty(int(y) - int(x) + 3, dtype=np.uint8)
+    _check(L.bsc_block_reference(codes.ctypes.data, codes.size, int(x), out.size, out.ctypes.data))
+    return out

@@ -8,7 +8,7 @@ from typing import Dict, Optional
 import numpy as np
 
 from . import report, vcf
-from .bam import BamReader
+from .bam import BamReader, block_reference
 from .caller import ReadProfile, SiteCaller, prepare_templates
 
 
@@ -41,9 +41,7 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
                 codes = reference[name]
                 x = int(raw["pos"][0][0]) or int(raw["pos"][0][1])
                 x = x - 2 if x > 2 else 1  # process_template_vector, src/process_template.c:22-28
-                ref = np.zeros(y - x + 3, dtype=np.uint8)
-                have = codes[x - 1 : y + 2]
-                ref[: len(have)] = have
+                ref = block_reference(codes, x, y)
                 tpl, pseq, st = prepare_templates(raw, seq, ms, left_trim, right_trim, min_qual, profile=prof, x=x, ref=ref)
                 base_filter += np.array([st["base_none"], st["base_trim"], st["base_clip"], st["base_overlap"], st["base_lowqual"]], dtype=np.uint64)
                 passed += np.array([st["reads"], st["read_bases"]], dtype=np.uint64)

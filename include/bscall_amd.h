@@ -472,6 +472,18 @@ uint32_t bsc_block_start(const bsc_raw_template *first);
 uint32_t bsc_template_qual(const bsc_raw_template *t, const uint8_t *seq);
 
 /*
+ * The reference sequence of a block (host C + zlib; csrc/refseq.c).
+ *   bsc_fasta_contig     one contig of a FASTA file (plain / gzip / bgzip, read sequentially) as reference codes 0 = N,
+ *                        1..4 = ACGT, position 1 first: load_sequence (src/read_reference.c:44-131).  *len = its length
+ *                        (BSC_ERR_ARG with *len set when cap is too small: call again with a larger buffer).
+ *   bsc_block_reference  get_sequence_string (src/get_sequence.c:20-54): out[sz] = codes of positions x .. x + sz - 1
+ *                        (a block's work->ref1: sz = y - x + 3); positions at or beyond the contig's last one read 0, as
+ *                        in the reference (its walk stops in front of end_pos).
+ */
+int bsc_fasta_contig(const char *path, const char *name, uint8_t *codes, uint64_t cap, uint64_t *len);
+int bsc_block_reference(const uint8_t *codes, uint64_t contig_len, uint32_t x, uint32_t sz, uint8_t *out);
+
+/*
  * BAM in, blocks of templates out (host C + zlib, no htslib; csrc/bamio.c): the reader thread of the reference —
  * read_input (src/get_template_vector.c:49-389) over get_next_align_details (src/input_sam.c:222-312).  A block is what
  * read_input queues for process_template_vector: the templates of one stretch of overlapping alignments of one contig

@@ -245,3 +245,25 @@ def test_c_equals_python_on_random_bams(tmp_path, seed, kw):
         n_blocks += len(c[0])
         n_tpl += sum(len(ts) for _, _, ts in c[0])
     assert n_blocks > 10 and n_tpl > 500
+
+
+def test_fasta_contig_and_block_reference(tmp_path):
+    """load_sequence's alphabet (ACGT either case -> 1..4, anything else printable -> 0, white space skipped), a record found by
+    its name up to the first blank, gzip input; get_sequence_string's bounds: the contig's last position reads as N."""
+    import gzip
+
+    from bs_call_amd.bam import block_reference, fasta_contig
+
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">chr1 first\nACGTNacgtn\nRYKM-ACGT\n>chr10\nTTTT\n>chr2\tsecond\nGGGCCC\n")
+    assert fasta_contig(fa, "chr1").tolist() == [1, 2, 3, 4, 0, 1, 2, 3, 4, 0, 0, 0, 0, 0, 0, 1, 2, 3, 4]
+    assert fasta_contig(fa, "chr2").tolist() == [3, 3, 3, 2, 2, 2] and fasta_contig(fa, "chr10").tolist() == [4, 4, 4, 4]
+    gz = tmp_path / "ref.fa.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(fa.read_bytes())
+    assert fasta_contig(gz, "chr2", length_hint=2).tolist() == [3, 3, 3, 2, 2, 2]  # a buffer too small is retried with the length
+    with pytest.raises(BscError, match="no sequence"):
+        fasta_contig(fa, "chr3")
+    codes = np.array([3, 3, 3, 2, 2, 2], dtype=np.uint8)
+    assert block_reference(codes, 1, 4).tolist() == [3, 3, 3, 2, 2, 0]  # positions 1 .. 6: the 6th (= end_pos) reads 0
+    assert block_reference(codes, 4, 8).tolist() == [2, 2, 0, 0, 0, 0, 0]

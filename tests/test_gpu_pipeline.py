@@ -29,9 +29,8 @@ def _oracle_records(oracle, tables, libm_exact, bam, reference):
         x = als[0]["pos"][0] or als[0]["pos"][1]
         x = x - 2 if x > 2 else 1
         codes = reference[name]
-        ref = np.zeros(y - x + 3, dtype=np.uint8)
-        have = codes[x - 1 : y + 2]
-        ref[: len(have)] = have
+        # get_sequence_string (src/get_sequence.c:35-48): positions at or beyond the contig's last one read as N
+        ref = np.array([codes[p - 1] if p < len(codes) else 0 for p in range(x, y + 3)], dtype=np.uint8)
         prepared, _ = py_prep.prepare(als)
         tpl = np.zeros(len(prepared), dtype=B.TEMPLATE)
         seq = []
