@@ -41,6 +41,7 @@ CHAIN_BYTES = 105 + 64  # fused chain: pile-up + reference code in, bsc_vcf_core
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 88172645463325252
 KERNEL_SOURCES = ("kernels.hip", "callmath.h", "call_body.inc", "bsmath.h", "bsmath_tables.h", "devtables.h")
+CHAIN_SOURCES = ("fused.hip", "callmath.h", "call_body.inc", "sitestats_dev.h", "bsmath.h", "bsmath_tables.h", "devtables.h")
 
 
 def main():
@@ -259,7 +260,7 @@ def chain_roofline(args, caller, d_cts, d_ref, n, first_site):
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS,
-        "traffic": None,
+        "traffic": profiled_traffic(n, args.coverage, "chain"),
         "algorithmic_bytes_per_launch": n * CHAIN_BYTES,
         "kernel_ms_avg": k_ms,
         "positions_per_s": n / float(np.median(wall)),
@@ -268,22 +269,25 @@ def chain_roofline(args, caller, d_cts, d_ref, n, first_site):
     }
 
 
-def kernel_source_hash():
+def kernel_source_hash(sources=KERNEL_SOURCES):
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in sources:
         with open(os.path.join(ROOT, "bs_call_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
 
-def profiled_traffic(n, coverage):
+def profiled_traffic(n, coverage, which=None):
     """HBM bytes per bsc_call_kernel launch from the committed PMC passes (profiles/traffic.json, written by
     tools/make_traffic_json.py from `tools/profile_bench.sh`: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
     this same command, FETCH_SIZE doubled per the gfx950 rule).  Counters cannot be read inside this process; None when
     the workload differs or the kernel sources have changed since the passes were taken."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if t.get("positions") == n and t.get("coverage") == coverage and t.get("kernel_source_sha256_16") == kernel_source_hash():
+        want = kernel_source_hash()
+        if which == "chain":  # the fused chain kernel's own passes (tools/bench_chain.py under --pmc), own source hash
+            t, want = t["chain"], kernel_source_hash(CHAIN_SOURCES)
+        if t.get("positions") == n and t.get("coverage") == coverage and t.get("kernel_source_sha256_16") == want:
             return t["hbm_bytes_per_launch"]
     except Exception:
         pass

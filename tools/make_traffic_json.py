@@ -2,6 +2,8 @@
 """profiles/traffic.json from the PMC passes of tools/profile_bench.sh: HBM bytes per bsc_call_kernel launch =
 (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts half of wide coalesced reads, MI355X_MICROARCH.md), tagged
 with the hash of the kernel sources so that bench.py stops quoting it once the kernel has changed.
+With gpurun_out/prof_<tag>/chain_fetch and chain_write (PMC passes of tools/bench_chain.py, see tools/prof_final.sh) the fused
+chain kernel gets an entry of its own ("chain"), tagged with the hash of ITS sources.
 usage: python tools/make_traffic_json.py gpurun_out/prof_<tag> [positions] [coverage]"""
 import csv
 import glob
@@ -18,11 +20,11 @@ positions = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000_000
 coverage = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 
 
-def per_dispatch(sub, name):
+def per_dispatch(sub, name, kernel="bsc_call_kernel"):
     agg = {}
     for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == name and "bsc_call_kernel" in r.get("Kernel_Name", "") and "ILb0E" not in r["Kernel_Name"] and "<false>" not in r["Kernel_Name"]:
+            if r.get("Counter_Name") == name and kernel in r.get("Kernel_Name", "") and "ILb0E" not in r["Kernel_Name"] and "<false>" not in r["Kernel_Name"]:
                 k = r["Dispatch_Id"]
                 agg[k] = agg.get(k, 0.0) + float(r["Counter_Value"])
     v = list(agg.values())
@@ -40,5 +42,17 @@ out = {
     "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
     "kernel_source_sha256_16": bench.kernel_source_hash(),
 }
+if os.path.isdir(os.path.join(d, "chain_fetch")):
+    cf, cw = per_dispatch("chain_fetch", "FETCH_SIZE", "bsc_chain_kernel"), per_dispatch("chain_write", "WRITE_SIZE", "bsc_chain_kernel")
+    out["chain"] = {
+        "_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python tools/bench_chain.py --no-unfused --steps 2`, "
+        "bsc_chain_kernel_t<true>, per dispatch, with statistics",
+        "positions": positions,
+        "coverage": coverage,
+        "fetch_size_kib": cf,
+        "write_size_kib": cw,
+        "hbm_bytes_per_launch": int((2 * cf + cw) * 1024),
+        "kernel_source_sha256_16": bench.kernel_source_hash(bench.CHAIN_SOURCES),
+    }
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out))
