@@ -302,7 +302,7 @@ typedef struct { /* align_details as get_next_align_details fills it for ONE rec
   uint8_t mapq, orientation, bs_strand, reverse;
   const char *name;
   uint32_t l_name;
-  const uint32_t *cigar;
+  const uint8_t *cigar; /* n_cigar little-endian dwords, not necessarily aligned */
   uint32_t n_cigar;
   const uint8_t *seq4, *qual, *aux, *end;
 } bam_rec;
@@ -384,7 +384,7 @@ static int next_record(bsc_bam *b, const bsc_reader_params *par, bam_rec *r, int
   r->tid = tid;
   r->name = (const char *)p + 32;
   r->l_name = l_name; /* the reference keys the pair table on l_qname bytes, the terminator included */
-  r->cigar = (const uint32_t *)(p + 32 + l_name);
+  r->cigar = p + 32 + l_name;
   r->n_cigar = n_cigar;
   r->seq4 = p + 32 + l_name + 4 * n_cigar;
   r->qual = r->seq4 + (l_seq + 1) / 2;
@@ -488,7 +488,7 @@ static int store_read(blk_buf *k, bsc_raw_template *t, int ix, const bam_rec *r)
   uint32_t position = 0, nm = 0;
   for (uint32_t i = 0; i < r->n_cigar; i++) {
     uint32_t c;
-    memcpy(&c, (const uint8_t *)r->cigar + 4 * i, 4);
+    memcpy(&c, r->cigar + 4 * i, 4);
     const uint32_t len = c >> 4;
     bsc_misms m = {0, position, len};
     switch (c & 15u) {
