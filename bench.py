@@ -427,6 +427,7 @@ def run_config3(args, env):
     stream = torch.cuda.current_stream().cuda_stream
     index = dbsnp_index_for(args, mine, lengths, rank) if args.dbsnp else None
     dt, n_windows, chain_ms, n_db = 0.0, 0, [], 0
+    contig_totals = {}
 
     def flags_of(c):
         nonlocal n_db
@@ -448,13 +449,24 @@ def run_config3(args, env):
             caller.reset_site_stats()
         barrier(env)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for it in range(args.steps):
+            last_pass = it == args.steps - 1
+            before = caller.site_totals() if last_pass else None
             for rc in resident:
                 n_windows += genome.walk_contig(caller, rc, args.window, True, stream=stream)
+                if last_pass:  # the reference's per-contig copy of the totals (gt_ctg_stats): one 112-byte read per contig
+                    after = caller.site_totals()
+                    contig_totals[rc.index] = (after - before).astype(np.int64).reshape(-1)
+                    before = after
         if gi == len(groups) - 1:
-            # the only exchange of a sharded run: the counter block and the statistics block (every field a sum)
+            # the only exchange of a sharded run: the counter block and the statistics block (every field a sum), and the
+            # gather of the per-contig totals (each contig is owned by one rank: a sum of zero-padded tables is a gather)
             stats = shard.allreduce_stats(caller.stats_vector(), dev if dist is not None else None)
             site = shard.allreduce_site_stats(caller.site_stats(), dev if dist is not None else None)
+            tab = np.zeros((len(lengths), 14), dtype=np.uint64)
+            for ci, v in contig_totals.items():
+                tab[ci] = v.astype(np.uint64)
+            contig_table = shard.allreduce_counts(tab, dev if dist is not None else None)
         barrier(env)
         dt += time.perf_counter() - t0
         # device time of one window, from HIP events around its launches, outside the timed region
@@ -500,7 +512,9 @@ def run_config3(args, env):
             "windows_per_step": n_windows // max(args.steps, 1),
             "coverage": args.coverage,
             "sharding": "whole contigs per rank (LPT), no data-path collective; at the end one all-reduce of the 13-word counter "
-            "block and one of the statistics block (27 k words)",
+            "block, one of the statistics block (27 k words) and the gather of the per-contig totals (24 x 14 words)",
+            "contigs_with_records_after_gather": int((contig_table[:, 0] > 0).sum()),
+            "per_contig_records_sum_equals_total": bool(int(contig_table[:, 0].sum()) * max(args.steps, 1) == int(site["snps"][0])) if not args.rank_of else None,
             "covered_fraction": float(stats[1]) / total,
             "records_written": int(site["snps"][0]) // max(args.steps, 1),
             "CpGs": int(site["CpG_ref"][0] + site["CpG_nonref"][0]) // max(args.steps, 1),
