@@ -146,20 +146,15 @@ def run_config2(args, env):
     barrier(env)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        if world == 1:
-            # reading the events waits for this launch only; the next launch is queued right after
-            a, b = caller.last_kernel_ms()
-            kernel_ms.append(a)
-            fisher_ms.append(b)
+        step()  # queued back to back: nothing in the loop waits for the device
     stats = torch.from_numpy(caller.stats_vector()).to(dev)  # syncs the stream
     if dist is not None:
         dist.all_reduce(stats)  # the only collective: per-rank counters (RCCL)
     barrier(env)
     dt = max_over_ranks(env, time.perf_counter() - t0)
-    if world > 1:
-        a, b = caller.last_kernel_ms()
-        kernel_ms, fisher_ms = [a], [b]
+    # device times of the timed launches, from the HIP events the library recorded on the launch stream (the last 32 are kept)
+    hist = caller.kernel_ms_history(args.steps)
+    kernel_ms, fisher_ms = [h[0] for h in hist], [h[1] for h in hist]
 
     stats = stats.cpu().numpy()
     total_sites = int(stats[0])

@@ -69,6 +69,7 @@ EXPORTS = (
     "bsc_dbsnp_name",
     "bsc_set_profiling",
     "bsc_last_kernel_ms",
+    "bsc_kernel_ms_history",
     "bsc_synchronize",
     "bsc_stream_probe_ms",
     "bsc_get_stats",
@@ -302,6 +303,8 @@ def load():
     L.bsc_set_profiling.argtypes = [vp, i32]
     L.bsc_last_kernel_ms.restype = i32
     L.bsc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.bsc_kernel_ms_history.restype = i32
+    L.bsc_kernel_ms_history.argtypes = [vp, u32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.bsc_synchronize.restype = i32
     L.bsc_synchronize.argtypes = [vp]
     L.bsc_get_stats.restype = i32

@@ -305,6 +305,16 @@ class SiteCaller:
         _check(self._L.bsc_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def kernel_ms_history(self, n):
+        """[(calling kernel ms, Fisher kernel ms)] of the last n launches, oldest first (the library keeps the last 32):
+        read after a timed loop, so that the loop itself never waits on an event."""
+        out = []
+        for age in range(min(int(n), 32) - 1, -1, -1):
+            a, b = C.c_float(), C.c_float()
+            _check(self._L.bsc_kernel_ms_history(self._h, age, C.byref(a), C.byref(b)))
+            out.append((a.value, b.value))
+        return out
+
     def synchronize(self):
         _check(self._L.bsc_synchronize(self._h))
 

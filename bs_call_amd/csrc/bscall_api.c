@@ -111,8 +111,9 @@ struct bsc_context {
   int pipe_ready;
   /* optional per-launch timing of the calling kernel (bsc_set_profiling) */
   int profiling;
-  hipEvent_t ev[3];
-  int ev_valid;
+#define BSC_EV_RING 32
+  hipEvent_t ev[BSC_EV_RING][3]; /* a ring of event triples: the timings of the last launches can be read after a loop */
+  uint64_t ev_count;             /* profiled launches so far (the next one records into ev[ev_count % BSC_EV_RING]) */
 };
 
 static __thread char bsc_errbuf[512];
@@ -319,8 +320,9 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_vout);
   hipFree(ctx->d_vdb);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
-  for (int i = 0; i < 3; i++)
-    if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+  for (int r = 0; r < BSC_EV_RING; r++)
+    for (int i = 0; i < 3; i++)
+      if (ctx->ev[r][i]) hipEventDestroy(ctx->ev[r][i]);
   free(ctx);
   return BSC_OK;
 }
@@ -378,9 +380,10 @@ int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref
     int e = bsc_dev_launch_call((const char *)d_cts + done * 104u, (const char *)d_ref + done, m,
                                 (char *)d_out + done * out_stride, out_stride / 4u, (char *)d_skip + done,
                                 ctx->d_tables, ctx->d_het, ctx->d_counters, ctx->num_cus, s,
-                                ctx->profiling ? ctx->ev[0] : NULL, ctx->profiling ? ctx->ev[1] : NULL,
-                                ctx->profiling ? ctx->ev[2] : NULL);
-    if (ctx->profiling) ctx->ev_valid = 1;
+                                ctx->profiling ? ctx->ev[ctx->ev_count % BSC_EV_RING][0] : NULL,
+                                ctx->profiling ? ctx->ev[ctx->ev_count % BSC_EV_RING][1] : NULL,
+                                ctx->profiling ? ctx->ev[ctx->ev_count % BSC_EV_RING][2] : NULL);
+    if (ctx->profiling) ctx->ev_count++;
     if (e) return bsc_fail(BSC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     done += m;
   }
@@ -757,25 +760,30 @@ int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
 int bsc_set_profiling(bsc_context *ctx, int enable) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_set_profiling: ctx is NULL");
   BSC_ENTER(ctx);
-  if (enable && !ctx->ev[0])
-    for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&ctx->ev[i]));
+  if (enable && !ctx->ev[0][0])
+    for (int r = 0; r < BSC_EV_RING; r++)
+      for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&ctx->ev[r][i]));
   ctx->profiling = enable != 0;
-  ctx->ev_valid = 0;
+  ctx->ev_count = 0;
   return BSC_OK;
 }
 
-int bsc_last_kernel_ms(bsc_context *ctx, float *call_ms, float *fisher_ms) {
-  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_last_kernel_ms: ctx is NULL");
-  if (!ctx->profiling || !ctx->ev_valid) return bsc_fail(BSC_ERR_ARG, "bsc_last_kernel_ms: no profiled launch yet");
+int bsc_kernel_ms_history(bsc_context *ctx, uint32_t age, float *call_ms, float *fisher_ms) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_kernel_ms_history: ctx is NULL");
+  if (!ctx->profiling || age >= ctx->ev_count || age >= BSC_EV_RING)
+    return bsc_fail(BSC_ERR_ARG, "bsc_kernel_ms_history: no profiled launch %u launches back (the last %d are kept)", age, BSC_EV_RING);
   BSC_ENTER(ctx);
-  HIP_TRY(hipEventSynchronize(ctx->ev[2]));
+  hipEvent_t *ev = ctx->ev[(ctx->ev_count - 1u - age) % BSC_EV_RING];
+  HIP_TRY(hipEventSynchronize(ev[2]));
   float a = 0.f, b = 0.f;
-  HIP_TRY(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-  HIP_TRY(hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+  HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
   if (call_ms) *call_ms = a;
   if (fisher_ms) *fisher_ms = b;
   return BSC_OK;
 }
+
+int bsc_last_kernel_ms(bsc_context *ctx, float *call_ms, float *fisher_ms) { return bsc_kernel_ms_history(ctx, 0, call_ms, fisher_ms); }
 
 int bsc_stream_probe_ms(bsc_context *ctx, const void *d_cts, const void *d_ref, uint64_t n, void *d_out, void *d_skip,
                         int reps, void *stream, float *ms) {

@@ -558,6 +558,9 @@ int bsc_vcf_format(const bsc_vcf_core *c, const bsc_gt_meth *g, const char *cont
  * call only the last sub-launch is reported. */
 int bsc_set_profiling(bsc_context *ctx, int enable);
 int bsc_last_kernel_ms(bsc_context *ctx, float *call_ms, float *fisher_ms);
+/* The same for the launch `age` launches back (0 = the most recent; the last 32 are kept), so that a timed loop can run
+ * without waiting on events and read its launches' device times afterwards. */
+int bsc_kernel_ms_history(bsc_context *ctx, uint32_t age, float *call_ms, float *fisher_ms);
 
 /* Measurement support: the time (ms, HIP events on `stream`, best of `reps` launches) of a kernel that moves exactly
  * the bytes of bsc_call_sites_device(ctx, d_cts, d_ref, n, d_out, 200, d_skip) — 104 + 1 in, 200 + 1 out per position,
