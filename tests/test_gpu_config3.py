@@ -122,3 +122,65 @@ def test_report_of_a_small_genome():
         # G+C of a random reference: centred on 50
         hist = np.array([sum(gc[k][g] for k in gc) for g in range(101)])
         assert 45 < float((hist * np.arange(101)).sum() / hist.sum()) < 55
+
+
+def test_rank0_of_8_share_with_dbsnp_index(tmp_path):
+    """BASELINE.json configs[4] at full size: the rank-0-of-8 share with a dbSNP index (1 site / 300 bp, 10 % fq_mask) written
+    in the reference's on-disk format, read back through csrc/dbsnp.c, its flags resident beside the pile-ups.  Properties
+    (the byte-for-byte check against the oracle is tests/test_gpu_dbsnp.py, 1.2 M positions): the dbSNP counters are a census
+    of the flagged written records, a homozygous-reference AA / TT record exists exactly where fq_mask forces it, and the
+    records elsewhere are those of the run without an index."""
+    import importlib.util
+    import os
+
+    import torch
+
+    from bs_call_amd.dbsnp import DbSnpIndex
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_dbsnp_index", os.path.join(root, "tools", "make_dbsnp_index.py"))
+    W = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(W)
+    dev = torch.device("cuda:0")
+    lengths = shard.HUMAN_CONTIGS
+    firsts = genome.contig_first_sites(lengths)
+    mine = genome.rank_contigs(lengths, 0, 8)
+    path = str(tmp_path / "rank0.idx")
+    sites = {"ctg%d" % k: W.synthetic_sites(lengths[k], 300, first_rs=1000 + 10_000_000 * i) for i, k in enumerate(mine)}
+    W.write_index(path, sites)
+    with DbSnpIndex(path) as db, B.SiteCaller() as c:
+        n_sites = n_forced = n_db_written = 0
+        win = genome.window_for(c)
+        for k in mine:
+            assert db.load_contig("ctg%d" % k) == len(sites["ctg%d" % k])
+            flags = db.flags(1, lengths[k])
+            rc = genome.make_resident(c, k, lengths[k], firsts[k], COV, dev, dbsnp_flags=flags)
+            genome.walk_contig(c, rc, win, True)
+            torch.cuda.synchronize()
+            rec = rc.d_core.view(rc.length, 64)
+            emit = rec[:, 4] != 0
+            gt, rcode = rec[:, 5], rec[:, 6]
+            homref = emit & (((gt == 0) & (rcode == 1)) | ((gt == 9) & (rcode == 4)))
+            fl = rc.d_dbsnp
+            assert bool((fl[homref] == 3).all())  # only fq_mask sites force a hom-ref record
+            n_forced += int(homref.sum())
+            n_db_written += int((emit & (fl != 0)).sum())
+            n_sites += int((fl != 0).sum())
+            # without the index: the same records except the forced ones
+            plain = torch.empty_like(rc.d_core)
+            c2_first = rc.length // 2 // 60 * 60
+            m = min(2_000_040, rc.length - c2_first)
+            with B.SiteCaller() as c2:
+                c2.chain_device(rc.d_cts.data_ptr() + (c2_first - 2) * 104, rc.d_ref.data_ptr() + (c2_first - 4), 1, rc.length, c2_first, m,
+                                plain.data_ptr() + c2_first * 64, with_stats=False)
+                torch.cuda.synchronize()
+            a = rec[c2_first : c2_first + m]
+            b = plain.view(rc.length, 64)[c2_first : c2_first + m]
+            differ = (a != b).any(dim=1)
+            assert bool((differ == homref[c2_first : c2_first + m]).all())
+            del rc, rec, plain, a, b, differ, emit, homref, fl
+            torch.cuda.empty_cache()
+        st = c.site_stats()
+        assert n_sites == sum(len(v) for v in sites.values()) and abs(n_sites - sum(lengths[k] for k in mine) / 300) < 10
+        assert int(st["dbSNP_sites"][0]) == n_db_written > 500_000 and n_forced > 20_000
+        assert int(st["dbSNP_var"][0]) == n_db_written  # every written record counts as a variant (the reference's alt walk)
