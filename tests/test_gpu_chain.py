@@ -256,3 +256,40 @@ def _fused_keep(c, pile, ref2, x, windows):
         torch.cuda.synchronize()
         core[first : first + n] = d_core.cpu().numpy().view(VCF_CORE)
     return core, c.site_stats().copy(), c.stats()
+
+
+def test_fused_equals_unfused_on_adversarial_pileups(caller):
+    """Uniformly random class counts / qualities (not WGBS-like: every class combination, depths from 1 to several thousand
+    — beyond the 4 096-row coverage table —, near-exact likelihood ties, most calls heterozygous), random reference codes
+    with N runs, random dbSNP flags, uncovered stretches: records and statistics of the fused chain, walked in windows of
+    every alignment, equal the three unfused kernels'."""
+    rng = np.random.default_rng(20261004)
+    n = 150_000
+    pile = np.zeros(n, dtype=B.PILEUP)
+    depth_scale = rng.choice([1, 3, 10, 40, 400], size=n)
+    mask = rng.random((n, 2, 8)) < rng.choice([0.1, 0.3, 0.6, 1.0], size=(n, 1, 1))
+    cnt = (rng.integers(0, 8, size=(n, 2, 8)) * depth_scale[:, None, None] * mask).astype(np.uint32)
+    cnt[rng.random(n) < 0.05] = 0  # uncovered positions
+    pile["counts"] = cnt
+    tot = cnt.sum(axis=1)
+    pile["n"] = tot.sum(axis=1)
+    meanq = rng.integers(20, 44, size=(n, 8))
+    pile["quality"] = np.minimum((tot * meanq).astype(np.float32), 43.0 * tot)
+    pile["mapq2"] = (pile["n"] * rng.choice([0, 1, 400, 1521, 3600], size=n)).astype(np.float32)
+    ref2 = rng.integers(1, 5, size=n + 2).astype(np.uint8)
+    for s in rng.integers(0, n - 50, 40):
+        ref2[s : s + int(rng.integers(1, 40))] = 0
+    flags = rng.choice([0, 0, 0, 1, 3], size=n).astype(np.uint8)
+    assert int(pile["n"].max()) > 4096
+    exp, est, ecnt = _unfused(caller, pile, ref2, 777, dbsnp=flags)
+    wins, first = [], 0
+    for w in [1, 59, 60, 61, 3_000, 17_001, 40_020, 2, 33_333]:
+        wins.append((first, w))
+        first += w
+    wins.append((first, n - first))
+    got, gst, gcnt = _fused(caller, pile, ref2, 777, wins, dbsnp=flags)
+    _same_core(got, exp, "adversarial pile-ups")
+    _same_stats(gst, est)
+    assert gcnt == ecnt
+    het = np.array(B.GT_HET)[got["gt"]] & (got["pos"] != 0)
+    assert het.sum() > 0.2 * n and int(gst["cov"][4095, 0]) > 0  # mostly heterozygous calls; the coverage table's last row is in use
