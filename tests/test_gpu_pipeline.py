@@ -96,3 +96,28 @@ def test_bam_to_bcf_equals_the_oracle_chain(tmp_path, oracle, tables, libm_exact
     miss = sum(p[3] for p in prof) / max(1, sum(p[2] + p[3] for p in prof))
     assert 0.90 < conv < 0.97 and miss < 0.01
     assert sum(v["SNPS"]["All"] for v in d["contigStats"].values()) == res["records"]
+
+
+@pytest.mark.parametrize("seed", [3, 5, 7, 4])  # 3, 5, 7 run to the end; 4 holds a pair the reference asserts on
+def test_bam_to_bcf_on_random_alignments(tmp_path, oracle, tables, libm_exact, seed):
+    """The same equality on files full of what the generator above never makes: overlapping mates, soft clips, insertions and
+    deletions, single reads of either strand, duplicates, filtered records, Ns, two contigs."""
+    from tests import test_bam as TB
+
+    rng = np.random.default_rng(seed)
+    reference = {name: rng.integers(1, 5, ln).astype(np.uint8) for name, ln in TB.REFS}
+    recs = TB._random_records(rng, 700)
+    bam, bcf = str(tmp_path / "in.bam"), str(tmp_path / "out.bcf")
+    W.write_bam(bam, TB.REFS, recs)
+    try:
+        orefs, orecs = _oracle_records(oracle, tables, libm_exact, bam, reference)
+    except (AssertionError, py_prep.PrepError):
+        # input the reference asserts on (or walks out of bounds on): the library reports it
+        with pytest.raises(B.BscError):
+            pipeline.run(bam, reference, bcf, compressed=False, date=(3, 10, 2026))
+        return
+    res = pipeline.run(bam, reference, bcf, compressed=False, date=(3, 10, 2026))
+    assert len(orecs) == res["records"] > 1000
+    stream = open(bcf, "rb").read()
+    l_text = struct.unpack_from("<I", stream, 5)[0]
+    assert stream[9 + l_text :] == b"".join(py_bcf.encode_record(d, tid) for tid, d in orecs)
