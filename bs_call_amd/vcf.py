@@ -172,3 +172,28 @@ def write_bcf(path, header: str, record_blocks, compressed=True):
         if pend:
             f.write(_bgzf_block(bytes(pend)))
         f.write(BGZF_EOF)
+
+
+def write_vcf(path, header: str, line_blocks, bgzip=False):
+    """A VCF text file: the header, then the data lines (an iterable of lists of lines, e.g. format_records_c outputs);
+    bgzip=True writes BGZF blocks (the reference's "wz" mode).  The GL floats are printed with %g (see the module text)."""
+    def chunks():
+        yield header.encode()
+        for lines in line_blocks:
+            if lines:
+                yield ("\n".join(lines) + "\n").encode()
+
+    with open(path, "wb") as f:
+        if not bgzip:
+            for c in chunks():
+                f.write(c)
+            return
+        pend = bytearray()
+        for c in chunks():
+            pend += c
+            while len(pend) >= 0xFF00:
+                f.write(_bgzf_block(bytes(pend[:0xFF00])))
+                del pend[:0xFF00]
+        if pend:
+            f.write(_bgzf_block(bytes(pend)))
+        f.write(BGZF_EOF)

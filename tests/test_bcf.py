@@ -189,3 +189,26 @@ def test_bcf_file_round_trip(tmp_path):
         k += 1
         n += 1
     assert n == 2999
+
+
+def test_vcf_text_file(tmp_path):
+    """Header + data lines as plain and as bgzip'ed VCF: the same text either way; the lines are bsc_vcf_format_rec's."""
+    import gzip
+
+    from bs_call_amd import vcf
+
+    rng = np.random.default_rng(9)
+    recs = np.zeros(200, dtype=VCF_REC)
+    for i in range(len(recs)):
+        recs[i] = _random_rec(rng)
+        recs[i]["core"]["pos"] = 10 + i
+    hdr = vcf.header_text([("chr1", 1000)], "S", benchmark_mode=True)
+    assert "fileDate" not in hdr and "##source" not in hdr  # --benchmark-mode leaves the run-dependent lines out
+    lines = vcf.format_records_c(recs, "chr1")
+    assert len(lines) == 200 and all(ln.split("\t")[0] == "chr1" and ln.count("\t") == 9 for ln in lines)
+    p1, p2 = tmp_path / "o.vcf", tmp_path / "o.vcf.gz"
+    vcf.write_vcf(p1, hdr, [lines[:50], [], lines[50:]])
+    vcf.write_vcf(p2, hdr, [lines], bgzip=True)
+    text = open(p1).read()
+    assert text == hdr + "\n".join(lines) + "\n" == gzip.open(p2, "rt").read()
+    assert _read_bgzf(p2).decode() == text
