@@ -426,7 +426,11 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     const uint32_t me = former ? sg[lane] : 0u;
     const uint32_t dp1 = cnt[0] + cnt[1] + cnt[2] + cnt[3], d_inf = cnt[4] + cnt[5] + cnt[6] + cnt[7];
     uint32_t flt = 0;
+#ifdef F_EXPERIMENT_SKIP_RECORD /* timing experiment only (tools/build_variant_fused.sh): the tile's cost without the record formation */
+    if (false) {
+#else
     if ((me & 0xffu) != 0 && dp1 + d_inf != 0) {
+#endif
       const int gt = (int)(me & 0xffu) - 1;
       const int L = (int)lane;
       /* called genotypes of lane indices L-2 .. L+2 (lane 1 clamps at 0: its own record is not kept) */
