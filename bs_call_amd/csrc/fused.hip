@@ -12,13 +12,16 @@
  *                          the record formation of _print_vcf_entry (:32-381; the restatement is vcfcore.hip's), then
  *                          the statistics block (:382-526; sitestats.hip's), each lane's 64-byte bsc_vcf_core staged
  *                          in the wave's slot and written with 16-byte stores.
- *   bsc_chain_het_kernel   heterozygous calls (0.5 % of WGBS positions) need Fisher's exact test on the strand table
- *                          (src/call_genotypes.c:61-108), a divergent walk: as in the unfused path they go to a list;
- *                          this kernel evaluates the test, patches FS / FILTER into the records the main kernel wrote
- *                          and adds those positions' statistics (nothing about a heterozygous position depends on, or
- *                          is needed by, its neighbours' statistics: "CG" status needs the homozygous CC / GG pair).
- *                          It also evaluates the CpG cytosines whose informative counts exceed the pair table
- *                          (listed by the main kernel) and empties both lists for the next call.
+ *                          Heterozygous calls (one position in ~1 000) need Fisher's exact test on the strand table
+ *                          (src/call_genotypes.c:61-108), a divergent walk: each wave lists its own in HBM and, after its
+ *                          last tile, tests them 64 at a time, patches FS / FILTER into the records it wrote and adds
+ *                          those positions' statistics (nothing about a heterozygous position depends on, or is needed
+ *                          by, its neighbours' statistics: "CG" status needs the homozygous CC / GG pair).  CpG
+ *                          cytosines are counted per (informative counts a, b) — LDS table, 512 x 512 table in HBM, a
+ *                          list beyond that — and turned into methylation profiles when the statistics are read
+ *                          (bsc_meth_eval_kernel, sitestats.hip).
+ *   bsc_gc_cov_kernel      GC content by coverage (src/print_vcf.c:394-398) from the per-position depths the main kernel
+ *                          leaves when the contig's GC bins are set (bsc_set_gc_bins).
  *
  * A call handles one WINDOW of a block (the reference's unit: a maximal run of overlapping templates; the printer's
  * sliding-window state is flushed at its end): the windows of a block give exactly the records of the whole block,
