@@ -32,6 +32,8 @@ int bsc_dev_sort_tmp_bytes(uint32_t nr, size_t *bytes); /* sort.hip */
 int bsc_dev_launch_site_stats(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp, uint32_t n,
                               const void *tb, const void *logp, const void *carry_in, void *carry_out, void *stats,
                               void *pairs, int num_cus, void *stream); /* sitestats.hip */
+int bsc_dev_launch_gc_cov_gtm(const void *core, const void *gtm, uint32_t gtm_stride, uint32_t n, const void *gc_bins, uint32_t n_bins,
+                              uint32_t start_pos, void *table, int num_cus, void *stream); /* sitestats.hip */
 int bsc_dev_launch_meth_eval(void *pairs, const void *tb, const void *logp, void *stats, const void *ovf_list,
                              const void *counters, int num_cus, void *stream);
 int bsc_dev_scan_tmp_bytes(uint32_t n, size_t *bytes); /* sort.hip */
@@ -1019,6 +1021,11 @@ int bsc_vcf_stats_device(bsc_context *ctx, const void *d_core, const void *d_gtm
                                     ctx->d_carry + 2 * in, ctx->d_carry + 2 * out, ctx->d_sstats, ctx->d_pairs, ctx->num_cus,
                                     stream);
   if (e) return bsc_fail(BSC_ERR_HIP, "site statistics launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (ctx->d_gc_bins) { /* GC content by coverage, when the contig's bins are set (bsc_set_gc_bins) */
+    e = bsc_dev_launch_gc_cov_gtm(d_core, d_gtm, gtm_stride, n, ctx->d_gc_bins, ctx->gc_n_bins, ctx->gc_start_pos, ctx->d_gc_table,
+                                  ctx->num_cus, stream);
+    if (e) return bsc_fail(BSC_ERR_HIP, "GC statistics launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
   ctx->carry_slot = out;
   return BSC_OK;
 }

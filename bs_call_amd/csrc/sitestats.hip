@@ -313,6 +313,45 @@ extern "C" int bsc_dev_launch_meth_eval(void *pairs, const void *tb, const void 
   return (int)hipGetLastError();
 }
 
+/* GC content by coverage for the unfused path (gt_cov_stats.gc_pcent, src/print_vcf.c:394-398): the depth of a position is
+ * the sum of its gt_meth counts, its genome position the record's; the fused chain has its own form (bsc_gc_cov_kernel). */
+extern "C" __global__ __launch_bounds__(1024) void bsc_gc_cov_gtm_kernel(const uint8_t *__restrict__ core, const uint8_t *__restrict__ gtm,
+                                                                         uint32_t gtm_stride, uint32_t n,
+                                                                         const uint8_t *__restrict__ gc_bins, uint32_t n_bins,
+                                                                         uint32_t start_pos, unsigned long long *__restrict__ table) {
+  __shared__ uint32_t t[256 * 101];
+  for (unsigned i = threadIdx.x; i < 256 * 101; i += 1024) t[i] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
+    const uint32_t pos = *reinterpret_cast<const uint32_t *>(core + (uint64_t)i * 64u);
+    if (!pos) continue; /* the position did not reach the printer */
+    const uint64_t *c = reinterpret_cast<const uint64_t *>(gtm + (uint64_t)i * gtm_stride);
+    uint64_t d = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) d += c[j];
+    const uint32_t dd = d < BSC_COV_CAP ? (uint32_t)d : BSC_COV_CAP - 1u;
+    const uint32_t bn = (pos - start_pos) / 100u;
+    if (bn >= n_bins) continue;
+    const uint32_t g = gc_bins[bn];
+    if (g > 100u) continue;
+    if (dd < 256u) atomicAdd(&t[dd * 101u + g], 1u);
+    else atomicAdd(&table[(uint64_t)dd * 101u + g], 1ull);
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < 256 * 101; i += 1024)
+    if (t[i]) atomicAdd(&table[i], (unsigned long long)t[i]);
+}
+
+extern "C" int bsc_dev_launch_gc_cov_gtm(const void *core, const void *gtm, uint32_t gtm_stride, uint32_t n, const void *gc_bins,
+                                         uint32_t n_bins, uint32_t start_pos, void *table, int num_cus, void *stream) {
+  if (n == 0) return 0;
+  unsigned grid = (n + 1023u) / 1024u;
+  if (grid > (unsigned)num_cus) grid = (unsigned)num_cus;
+  hipLaunchKernelGGL(bsc_gc_cov_gtm_kernel, dim3(grid), dim3(1024), 0, (hipStream_t)stream, (const uint8_t *)core, (const uint8_t *)gtm,
+                     gtm_stride, n, (const uint8_t *)gc_bins, n_bins, start_pos, (unsigned long long *)table);
+  return (int)hipGetLastError();
+}
+
 extern "C" int bsc_dev_launch_site_stats(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp,
                                          uint32_t n, const void *tb, const void *logp, const void *carry_in,
                                          void *carry_out, void *stats, void *pairs, int num_cus, void *stream) {

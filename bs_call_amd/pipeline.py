@@ -9,13 +9,15 @@ import numpy as np
 
 from . import report, vcf
 from .bam import BamReader, block_reference
-from .caller import ReadProfile, SiteCaller, prepare_templates
+from .caller import ReadProfile, SiteCaller, gc_bins, prepare_templates
 
 
 def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: str = "SAMPLE", report_path: Optional[str] = None,
         caller: Optional[SiteCaller] = None, dbsnp=None, compressed: bool = True, date=None, left_trim=(0, 0), right_trim=(0, 0),
         min_qual: int = 20, **reader_kw) -> dict:
     """reference: contig name -> uint8 reference codes (0 = N, 1..4 = ACGT; position 1 first).  Returns a summary dict."""
+    import torch
+
     own = caller is None
     c = caller or SiteCaller()
     try:
@@ -38,6 +40,10 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
                     cur_tid = tid
                     if dbsnp is not None:
                         dbsnp.load_contig(name)
+                    # the contig's GC bins (load_sequence computes them when a report is asked for), resident on the device
+                    gc_start, bins = gc_bins(reference[name])
+                    d_bins = torch.from_numpy(bins).to("cuda") if len(bins) else None
+                    c.set_gc_bins(None if d_bins is None else d_bins.data_ptr(), len(bins), gc_start)
                 codes = reference[name]
                 x = int(raw["pos"][0][0]) or int(raw["pos"][0][1])
                 x = x - 2 if x > 2 else 1  # process_template_vector, src/process_template.c:22-28
@@ -58,7 +64,8 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
         vcf.write_bcf(bcf_path, header, blobs, compressed)
         cts[0] += int(passed[0])
         bases[0] += int(passed[1])
-        text = report.render_json(c.site_stats(), min_qual=min_qual, date=date, have_dbsnp=dbsnp is not None, filter_cts=cts, filter_bases=bases,
+        c.set_gc_bins(None, 0, 0)
+        text = report.render_json(c.site_stats(), gc=c.gc_stats(), min_qual=min_qual, date=date, have_dbsnp=dbsnp is not None, filter_cts=cts, filter_bases=bases,
                                   base_filter=base_filter.tolist(), read_profile=prof.reported(), contigs=per_contig)
         if report_path:
             with open(report_path, "w") as f:

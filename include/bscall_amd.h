@@ -331,7 +331,7 @@ int bsc_reset_site_stats(bsc_context *ctx);
  *   bsc_set_gc_bins   d_gc[n_bins] in device memory (the caller keeps it alive while set), start_pos = the contig's first
  *                     A/C/G/T position; d_gc NULL switches the table off.  Call at every contig change.
  *   bsc_get_gc_stats  out[BSC_COV_CAP][101] (synchronises the device); zeroed by bsc_reset_site_stats.
- * The unfused bsc_vcf_stats_device does not feed this table.
+ * bsc_vcf_stats_device / bsc_vcf_stats / bsc_block_records(with_stats) feed the same table (depth = the sum of the gt_meth counts).
  */
 int bsc_gc_bins(const uint8_t *codes, uint64_t n, uint32_t *start_pos, uint8_t *out, uint64_t out_cap, uint64_t *n_bins);
 int bsc_set_gc_bins(bsc_context *ctx, const void *d_gc, uint32_t n_bins, uint32_t start_pos);

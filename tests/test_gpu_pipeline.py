@@ -20,10 +20,22 @@ W = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(W)
 
 
-def _oracle_records(oracle, tables, libm_exact, bam, reference):
-    """The written records of every block, as dicts for py_bcf.encode_record, through the CPU oracle chain."""
+def _gc_bins(codes):
+    """load_sequence's bins (src/read_reference.c:66-104): from the first A/C/G/T base, 100 at a time, 255 with an N."""
+    k = int(np.argmax((codes >= 1) & (codes <= 4)))
+    bins = []
+    for b0 in range(k, len(codes) - 99, 100):
+        w = codes[b0 : b0 + 100]
+        bins.append(int(((w == 2) | (w == 3)).sum()) if ((w >= 1) & (w <= 4)).all() else 255)
+    return k + 1, bins
+
+
+def _oracle_records(oracle, tables, libm_exact, bam, reference, gc=None):
+    """The written records of every block, as dicts for py_bcf.encode_record, through the CPU oracle chain; gc: a
+    (4096, 101) array that receives the GC-by-coverage census of the positions that reached the printer."""
     text, refs, recs = py_bam.parse_bam(bam)
     out = []
+    bins_of = {name: _gc_bins(codes) for name, codes in reference.items()}
     for tid, y, als in py_bam.read_input(recs):
         name = refs[tid][0]
         x = als[0]["pos"][0] or als[0]["pos"][1]
@@ -48,6 +60,12 @@ def _oracle_records(oracle, tables, libm_exact, bam, reference):
         assert rc == 0
         gtm, skip = oracle.call_sites(pile, ref[: y - x + 1], tables, oracle.LIBM if libm_exact else oracle.BSM, 1)
         core = oracle.vcf_block(gtm, skip, ref, x, reg_stop=len(codes))
+        if gc is not None:
+            start, bins = bins_of[name]
+            for c, g in zip(core, gtm):
+                pos = int(c["pos"])
+                if pos >= start and (pos - start) // 100 < len(bins) and bins[(pos - start) // 100] <= 100:
+                    gc[min(int(g["counts"].sum()), 4095), bins[(pos - start) // 100]] += 1
         for c, g in zip(core, gtm):
             if not c["emit"]:
                 continue
@@ -73,7 +91,8 @@ def test_bam_to_bcf_equals_the_oracle_chain(tmp_path, oracle, tables, libm_exact
     res = pipeline.run(bam, reference, bcf, sample="S1", report_path=rep, date=(3, 10, 2026), compressed=False)
     assert res["blocks"] >= 2 and res["records"] > 5_000 and res["contigs"] == ["chrA", "chrB"]
     # ---- the oracle chain, encoded by the independent Python encoder ----
-    orefs, orecs = _oracle_records(oracle, tables, libm_exact, bam, reference)
+    gc = np.zeros((4096, 101), dtype=np.uint64)
+    orefs, orecs = _oracle_records(oracle, tables, libm_exact, bam, reference, gc)
     assert orefs == refs and len(orecs) == res["records"]
     stream = open(bcf, "rb").read()
     hdr = vcf.header_text(refs, "S1", date=(3, 10, 2026)).encode() + b"\0"
@@ -96,6 +115,9 @@ def test_bam_to_bcf_equals_the_oracle_chain(tmp_path, oracle, tables, libm_exact
     miss = sum(p[3] for p in prof) / max(1, sum(p[2] + p[3] for p in prof))
     assert 0.90 < conv < 0.97 and miss < 0.01
     assert sum(v["SNPS"]["All"] for v in d["contigStats"].values()) == res["records"]
+    got_gc = {int(k): v for k, v in d["totalStats"]["coverage"]["GC"].items()}
+    assert int(gc.sum()) > 30_000 and all(got_gc[cv] == [int(v) for v in gc[cv]] for cv in got_gc)
+    assert sum(sum(v) for v in got_gc.values()) == int(gc.sum())
 
 
 @pytest.mark.parametrize("seed", [3, 5, 7, 4])  # 3, 5, 7 run to the end; 4 holds a pair the reference asserts on
