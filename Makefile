@@ -89,9 +89,13 @@ oracle:
 	$(MAKE) -C oracle liboracle.so
 
 # a plain-C host program against the C ABI: gcc only, links the shared library like bs_call would
-demo: $(LIBDIR)/demo_block
+demo: $(LIBDIR)/demo_block $(LIBDIR)/bam2bcf
 $(LIBDIR)/demo_block: integration/demo_block.c include/bscall_amd.h $(LIBDIR)/libbscall_amd.so
 	$(CC) -O2 -Wall -std=gnu11 -Iinclude $< -o $@ -L$(LIBDIR) -lbscall_amd -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
+# BAM + FASTA -> BCF + JSON report with nothing but the C ABI (the C twin of bs_call_amd/pipeline.py)
+bam2bcf: $(LIBDIR)/bam2bcf
+$(LIBDIR)/bam2bcf: integration/bam2bcf.c include/bscall_amd.h $(LIBDIR)/libbscall_amd.so
+	$(CC) -O2 -Wall -std=gnu11 -Iinclude $< -o $@ -L$(LIBDIR) -lbscall_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
 
 # Compile check of the two replacement translation units against the reference's own headers.  Only in a
 # container that has /root/reference; the reference's bs_call.h includes three htslib headers for POINTER TYPES only, so
@@ -113,7 +117,7 @@ asm: $(CSRC)/kernels.hip
 	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -Rpass-analysis=kernel-resource-usage $< -o $(LIBDIR)/kernels.s
 
 clean:
-	rm -f $(LIBDIR)/*.o $(LIBDIR)/*.so $(LIBDIR)/*.s $(LIBDIR)/demo_block
+	rm -f $(LIBDIR)/*.o $(LIBDIR)/*.so $(LIBDIR)/*.s $(LIBDIR)/demo_block $(LIBDIR)/bam2bcf
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle demo asm clean glue-check

@@ -39,6 +39,7 @@ EXPORTS = (
     "bsc_get_site_totals",
     "bsc_gc_bins",
     "bsc_set_gc_bins",
+    "bsc_set_gc_bins_host",
     "bsc_get_gc_stats",
     "bsc_report_json",
     "bsc_bcf_default_ids",
@@ -239,6 +240,8 @@ def load():
     L.bsc_gc_bins.argtypes = [vp, u64, C.POINTER(u32), vp, u64, C.POINTER(u64)]
     L.bsc_set_gc_bins.restype = i32
     L.bsc_set_gc_bins.argtypes = [vp, vp, u32, u32]
+    L.bsc_set_gc_bins_host.restype = i32
+    L.bsc_set_gc_bins_host.argtypes = [vp, vp, u32, u32]
     L.bsc_get_gc_stats.restype = i32
     L.bsc_get_gc_stats.argtypes = [vp, vp]
     L.bsc_get_site_totals.restype = i32

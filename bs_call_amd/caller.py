@@ -267,6 +267,14 @@ class SiteCaller:
         """GC bins of the contig being walked (device pointer, see `gc_bins`); None switches the GC table off."""
         _check(self._L.bsc_set_gc_bins(self._h, d_gc, n_bins, start_pos))
 
+    def set_gc_bins_host(self, bins, start_pos):
+        """The same from a host array (the context keeps its own device copy); None / empty switches the table off."""
+        if bins is None or len(bins) == 0:
+            _check(self._L.bsc_set_gc_bins_host(self._h, None, 0, 0))
+            return
+        b = np.ascontiguousarray(bins, dtype=np.uint8)
+        _check(self._L.bsc_set_gc_bins_host(self._h, _ptr(b), b.size, start_pos))
+
     def gc_stats(self):
         """Positions by [total depth][G+C count of their 100-base bin]: the report's "GC" object, (4096, 101) uint64."""
         out = np.zeros((4096, 101), dtype=np.uint64)

@@ -76,6 +76,8 @@ struct bsc_context {
                           environment lowers it so that the sub-launch loop of longer calls can be tested) */
   void *d_ovf; /* fused chain: CpG cytosines beyond the methylation pair table (BSC_OVF_CAP entries of 8 bytes) */
   void *d_gc_table;      /* GC content by coverage: u64 [BSC_COV_CAP][101] (bsc_set_gc_bins) */
+  void *d_gc_own;        /* bsc_set_gc_bins_host: the context's own copy of the bins */
+  size_t cap_gc_own;
   const void *d_gc_bins; /* the current contig's bins (caller's device memory) */
   uint32_t gc_n_bins, gc_start_pos;
   hipEvent_t ev_chain[2]; /* bsc_set_profiling: the fused chain's launches */
@@ -289,6 +291,7 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_het);
   hipFree(ctx->d_ovf);
   hipFree(ctx->d_gc_table);
+  hipFree(ctx->d_gc_own);
   for (int i = 0; i < 2; i++)
     if (ctx->ev_chain[i]) hipEventDestroy(ctx->ev_chain[i]);
   hipFree(ctx->d_tpl);
@@ -1089,6 +1092,17 @@ int bsc_set_gc_bins(bsc_context *ctx, const void *d_gc, uint32_t n_bins, uint32_
   ctx->gc_n_bins = d_gc ? n_bins : 0;
   ctx->gc_start_pos = start_pos;
   return BSC_OK;
+}
+
+int bsc_set_gc_bins_host(bsc_context *ctx, const uint8_t *gc, uint32_t n_bins, uint32_t start_pos) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_set_gc_bins_host: ctx is NULL");
+  if (!gc || !n_bins) return bsc_set_gc_bins(ctx, NULL, 0, 0);
+  BSC_ENTER(ctx);
+  HIP_TRY(hipDeviceSynchronize()); /* earlier launches may still read the previous contig's bins */
+  int rc = bsc_reserve(&ctx->d_gc_own, &ctx->cap_gc_own, n_bins);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(ctx->d_gc_own, gc, n_bins, hipMemcpyHostToDevice));
+  return bsc_set_gc_bins(ctx, ctx->d_gc_own, n_bins, start_pos);
 }
 
 int bsc_get_gc_stats(bsc_context *ctx, uint64_t *out) {

@@ -14,10 +14,8 @@ from .caller import ReadProfile, SiteCaller, gc_bins, prepare_templates
 
 def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: str = "SAMPLE", report_path: Optional[str] = None,
         caller: Optional[SiteCaller] = None, dbsnp=None, compressed: bool = True, date=None, left_trim=(0, 0), right_trim=(0, 0),
-        min_qual: int = 20, **reader_kw) -> dict:
+        min_qual: int = 20, benchmark_mode: bool = False, **reader_kw) -> dict:
     """reference: contig name -> uint8 reference codes (0 = N, 1..4 = ACGT; position 1 first).  Returns a summary dict."""
-    import torch
-
     own = caller is None
     c = caller or SiteCaller()
     try:
@@ -42,8 +40,7 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
                         dbsnp.load_contig(name)
                     # the contig's GC bins (load_sequence computes them when a report is asked for), resident on the device
                     gc_start, bins = gc_bins(reference[name])
-                    d_bins = torch.from_numpy(bins).to("cuda") if len(bins) else None
-                    c.set_gc_bins(None if d_bins is None else d_bins.data_ptr(), len(bins), gc_start)
+                    c.set_gc_bins_host(bins, gc_start)
                 codes = reference[name]
                 x = int(raw["pos"][0][0]) or int(raw["pos"][0][1])
                 x = x - 2 if x > 2 else 1  # process_template_vector, src/process_template.c:22-28
@@ -60,11 +57,11 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
                 per_contig.append((refs[cur_tid][0], c.site_totals() - before))
             cts, bases = rd.filter_counts()
             header = vcf.header_text([(n, l) for n, l in refs], sample, min_qual=min_qual, date=date,
-                                     dbsnp_header=None if dbsnp is None else dbsnp.header)
+                                     dbsnp_header=None if dbsnp is None else dbsnp.header, benchmark_mode=benchmark_mode)
         vcf.write_bcf(bcf_path, header, blobs, compressed)
         cts[0] += int(passed[0])
         bases[0] += int(passed[1])
-        c.set_gc_bins(None, 0, 0)
+        c.set_gc_bins_host(None, 0)
         text = report.render_json(c.site_stats(), gc=c.gc_stats(), min_qual=min_qual, date=date, have_dbsnp=dbsnp is not None, filter_cts=cts, filter_bases=bases,
                                   base_filter=base_filter.tolist(), read_profile=prof.reported(), contigs=per_contig)
         if report_path:

@@ -335,6 +335,8 @@ int bsc_reset_site_stats(bsc_context *ctx);
  */
 int bsc_gc_bins(const uint8_t *codes, uint64_t n, uint32_t *start_pos, uint8_t *out, uint64_t out_cap, uint64_t *n_bins);
 int bsc_set_gc_bins(bsc_context *ctx, const void *d_gc, uint32_t n_bins, uint32_t start_pos);
+/* the same from host memory: the context keeps its own device copy (synchronises the device) */
+int bsc_set_gc_bins_host(bsc_context *ctx, const uint8_t *gc, uint32_t n_bins, uint32_t start_pos);
 int bsc_get_gc_stats(bsc_context *ctx, uint64_t *out);
 
 /* The first 14 words of the statistics block — snps, indels, multi, dbSNP_sites, dbSNP_var, CpG_ref, CpG_nonref, each

@@ -1,0 +1,242 @@
+/*
+ * bam2bcf.c — plain-C host program against libbscall_amd.so (gcc only): the reference's data path from a coordinate-sorted
+ * BAM file and a FASTA reference to an uncompressed BCF stream and the JSON report, block by block, with nothing but the
+ * C ABI of include/bscall_amd.h — what bs_call's four threads do between sam_read1() and bcf_write():
+ *
+ *   reader thread     bsc_bam_next_block            read_input / get_next_align_details
+ *   process thread    bsc_block_reference           get_sequence_string
+ *                     bsc_prepare_templates_profile process_template_vector + meth_profile
+ *   calc + print      bsc_block_records             call_genotypes_ML, _print_vcf_entry up to the encoding, the statistics
+ *   output            bsc_bcf_block                 the bcf_enc_* calls + bcf_write
+ *   at the end        bsc_report_json               output_stats
+ *
+ * Not a replacement of the bs_call executable (no option parsing, regions, contig lists, dbSNP, compression): a worked
+ * example of the calls in order, and the C twin of bs_call_amd/pipeline.py — tests/test_gpu_pipeline.py checks that both
+ * write the same bytes.
+ *
+ *   make bam2bcf && bs_call_amd/lib/bam2bcf in.bam ref.fa out.bcf report.json [sample]
+ * The header's date lines are left out (the reference's --benchmark-mode) so that the output is reproducible.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <bscall_amd.h>
+
+#define CHECK(call)                                                          \
+  do {                                                                       \
+    long rc_ = (long)(call);                                                 \
+    if (rc_ < 0) {                                                           \
+      fprintf(stderr, "%s failed (%ld): %s\n", #call, rc_, bsc_last_error()); \
+      exit(1);                                                               \
+    }                                                                        \
+  } while (0)
+
+static void *xrealloc(void *p, size_t n) {
+  void *q = realloc(p, n ? n : 1);
+  if (!q) {
+    fprintf(stderr, "out of memory\n");
+    exit(1);
+  }
+  return q;
+}
+
+/* the header print_vcf_header assembles in --benchmark-mode (src/print_vcf.c:621-745) */
+static void write_header(FILE *f, const bsc_bam *bam, const char *sample) {
+  static const char *const defs[] = {
+      "##INFO=<ID=CX,Number=1,Type=String,Description=\"5 base sequence context (from position -2 to +2 on the positive strand) determined from the reference\">",
+      "##FILTER=<ID=fail,Description=\"No sample passed filters\">",
+      "##FILTER=<ID=q20,Description=\"Genotype Quality below 20\">",
+      "##FILTER=<ID=qd2,Description=\"Quality By Depth below 2\">",
+      "##FILTER=<ID=fs60,Description=\"Fisher Strand above 60\">",
+      "##FILTER=<ID=mq40,Description=\"RMS Mapping Quality below 40\">",
+      "##FILTER=<ID=mac1,Description=\"Minor allele count <= 1\">",
+      "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">",
+      "##FORMAT=<ID=FT,Number=1,Type=String,Description=\"Sample Genotype Filter\">",
+      "##FORMAT=<ID=GL,Number=G,Type=Float,Description=\"Genotype Likelihood\">",
+      "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Phred scaled conditional genotype quality\">",
+      "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Read Depth (non converted reads only)\">",
+      "##FORMAT=<ID=MQ,Number=1,Type=Integer,Description=\"RMS Mapping Quality\">",
+      "##FORMAT=<ID=QD,Number=1,Type=Integer,Description=\"Quality By Depth (Variant quality / read depth (non-converted reads only))\">",
+      "##FORMAT=<ID=MC8,Number=8,Type=Integer,Description=\"Base counts: non-informative for methylation (ACGT) followed by informative for methylation (ACGT)\">",
+      "##FORMAT=<ID=AMQ,Number=.,Type=Integer,Description=\"Average base quailty for where MC8 base count non-zero\">",
+      "##FORMAT=<ID=CS,Number=1,Type=String,Description=\"Strand of Cytosine relative to reference sequence (+/-/+-/NA)\">",
+      "##FORMAT=<ID=CG,Number=1,Type=String,Description=\"CpG Status (from genotype calls: Y/N/H/?)\">",
+      "##FORMAT=<ID=CX,Number=1,Type=String,Description=\"5 base sequence context (from position -2 to +2 on the positive strand) determined from genotype call\">",
+      "##FORMAT=<ID=FS,Number=1,Type=Integer,Description=\"Phred scaled log p-value from Fishers exact test of strand bias\">"};
+  size_t cap = 1 << 16, len = 0;
+  char *t = xrealloc(NULL, cap);
+#define ADD(...)                                                  \
+  do {                                                            \
+    for (;;) {                                                    \
+      const int w_ = snprintf(t + len, cap - len, __VA_ARGS__);   \
+      if ((size_t)w_ < cap - len) {                               \
+        len += (size_t)w_;                                        \
+        break;                                                    \
+      }                                                           \
+      cap *= 2;                                                   \
+      t = xrealloc(t, cap);                                       \
+    }                                                             \
+  } while (0)
+  ADD("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n");
+  for (int i = 0; i < bsc_bam_n_refs(bam); i++) ADD("##contig=<ID=%s,length=%u>\n", bsc_bam_ref_name(bam, i), bsc_bam_ref_len(bam, i));
+  for (size_t i = 0; i < sizeof defs / sizeof defs[0]; i++) ADD("%s\n", defs[i]);
+  ADD("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n", sample);
+#undef ADD
+  const uint32_t l_text = (uint32_t)len + 1; /* the terminator is part of the BCF header text */
+  fwrite("BCF\2\2", 1, 5, f);
+  fwrite(&l_text, 4, 1, f); /* little-endian hosts only, like the rest of this example */
+  fwrite(t, 1, len + 1, f);
+  free(t);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 5) {
+    fprintf(stderr, "usage: %s in.bam ref.fa out.bcf report.json [sample]\n", argv[0]);
+    return 2;
+  }
+  const char *sample = argc > 5 ? argv[5] : "SAMPLE";
+  bsc_bam *bam;
+  CHECK(bsc_bam_open(argv[1], &bam));
+  bsc_params prm = {0.01, 0.05, 2.0, 20, 0};
+  bsc_context *ctx;
+  CHECK(bsc_create(&prm, &ctx));
+  FILE *out = fopen(argv[3], "wb");
+  if (!out) {
+    perror(argv[3]);
+    return 1;
+  }
+  write_header(out, bam, sample);
+  bsc_bcf_ids ids;
+  bsc_bcf_default_ids(&ids);
+  const bsc_reader_params rpar = {20, 1000, 0, 0, 0};
+  const bsc_prep_params ppar = {{0, 0}, {0, 0}, 20};
+
+  const int n_ref = bsc_bam_n_refs(bam);
+  bsc_contig_totals *ctot = calloc((size_t)n_ref + 1, sizeof *ctot);
+  uint64_t prof_counts[4096][4];
+  memset(prof_counts, 0, sizeof prof_counts);
+  bsc_read_profile prof = {NULL, 0, 0, &prof_counts[0][0], 4096, 0};
+  uint64_t base_filter[5] = {0, 0, 0, 0, 0}, passed_reads = 0, passed_bases = 0, before[14], after[14];
+  CHECK(bsc_reset_site_stats(ctx));
+  CHECK(bsc_get_site_totals(ctx, before));
+
+  uint8_t *codes = NULL, *ref = NULL, *pseq = NULL, *bcf = NULL, *gc = NULL;
+  bsc_template *tpl = NULL;
+  bsc_vcf_rec *recs = NULL;
+  uint64_t codes_len = 0;
+  size_t cap_ref = 0, cap_pseq = 0, cap_tpl = 0, cap_recs = 0, cap_bcf = 0;
+  int cur_tid = -1;
+  uint64_t n_blocks = 0, n_records = 0;
+  bsc_read_block blk;
+  int r;
+  while ((r = bsc_bam_next_block(bam, &rpar, &blk)) == 1) {
+    if (blk.tid != cur_tid) { /* contig change: its sequence, and the finished contig's share of the totals */
+      if (cur_tid >= 0) {
+        CHECK(bsc_get_site_totals(ctx, after));
+        uint64_t *d = ctot[cur_tid].snps; /* seven [all, passed] pairs, contiguous */
+        for (int i = 0; i < 14; i++) d[i] += after[i] - before[i];
+        memcpy(before, after, sizeof before);
+      }
+      cur_tid = blk.tid;
+      ctot[cur_tid].name = bsc_bam_ref_name(bam, cur_tid);
+      const uint64_t want = bsc_bam_ref_len(bam, cur_tid);
+      codes = xrealloc(codes, want);
+      CHECK(bsc_fasta_contig(argv[2], bsc_bam_ref_name(bam, cur_tid), codes, want, &codes_len));
+      /* its GC bins, for the report's GC-by-coverage table (load_sequence computes them when a report is asked for) */
+      uint32_t gc_start = 0;
+      uint64_t n_bins = 0;
+      gc = xrealloc(gc, (size_t)(codes_len / 100 + 1));
+      CHECK(bsc_gc_bins(codes, codes_len, &gc_start, gc, codes_len / 100 + 1, &n_bins));
+      CHECK(bsc_set_gc_bins_host(ctx, gc, (uint32_t)n_bins, gc_start));
+    }
+    const uint32_t x = bsc_block_start(&blk.tpl[0]), y = blk.y, n = y - x + 1;
+    if (n + 2 > cap_ref) ref = xrealloc(ref, cap_ref = (size_t)(n + 2) * 2);
+    CHECK(bsc_block_reference(codes, codes_len, x, n + 2, ref));
+    uint64_t pad = 0;
+    for (uint64_t i = 0; i < blk.n_misms; i++)
+      if (blk.misms[i].type == BSC_MISMS_INS) pad += blk.misms[i].size;
+    if (blk.seq_bytes + pad + 16 > cap_pseq) pseq = xrealloc(pseq, cap_pseq = (size_t)(blk.seq_bytes + pad + 16) * 2);
+    if (blk.nr > cap_tpl) tpl = xrealloc(tpl, (cap_tpl = (size_t)blk.nr * 2) * sizeof *tpl);
+    uint64_t used = 0;
+    bsc_prep_stats st;
+    prof.ref = ref;
+    prof.x = x;
+    prof.n_ref = n + 2;
+    CHECK(bsc_prepare_templates_profile(blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, tpl, pseq, cap_pseq, &used, &st,
+                                        &prof));
+    base_filter[0] += st.base_none;
+    base_filter[1] += st.base_trim;
+    base_filter[2] += st.base_clip;
+    base_filter[3] += st.base_overlap;
+    base_filter[4] += st.base_lowqual;
+    passed_reads += st.reads;
+    passed_bases += st.read_bases;
+    if (n > cap_recs) recs = xrealloc(recs, (cap_recs = (size_t)n * 2) * sizeof *recs);
+    const bsc_vcf_params vp = {0, 1, (uint32_t)codes_len};
+    uint64_t n_out = 0;
+    CHECK(bsc_block_records(ctx, tpl, blk.nr, pseq, used, x, y, ref, NULL, &vp, 1, recs, cap_recs, &n_out));
+    if (n_out * 256 + 64 > cap_bcf) bcf = xrealloc(bcf, cap_bcf = (size_t)(n_out * 256 + 64) * 2);
+    uint64_t done = 0;
+    const long nb = bsc_bcf_block(recs, n_out, blk.tid, &ids, NULL, bcf, cap_bcf, &done);
+    CHECK(nb);
+    if (done != n_out) {
+      fprintf(stderr, "BCF buffer too small\n");
+      return 1;
+    }
+    fwrite(bcf, 1, (size_t)nb, out);
+    n_blocks++;
+    n_records += n_out;
+  }
+  CHECK(r);
+  if (cur_tid >= 0) {
+    CHECK(bsc_get_site_totals(ctx, after));
+    uint64_t *d = ctot[cur_tid].snps;
+    for (int i = 0; i < 14; i++) d[i] += after[i] - before[i];
+  }
+  fclose(out);
+
+  /* the report */
+  static bsc_site_stats total;
+  CHECK(bsc_get_site_stats(ctx, &total));
+  bsc_report rep;
+  memset(&rep, 0, sizeof rep);
+  rep.under_conv = prm.under_conv;
+  rep.over_conv = prm.over_conv;
+  rep.mapq_thresh = 20;
+  rep.min_qual = 20;
+  rep.day = 1, rep.month = 1, rep.year = 2000; /* a fixed date: reproducible output */
+  bsc_bam_filter_counts(bam, rep.filter_cts, rep.filter_bases);
+  rep.filter_cts[0] += passed_reads;
+  rep.filter_bases[0] += passed_bases;
+  memcpy(rep.base_filter, base_filter, sizeof base_filter);
+  rep.total = &total;
+  CHECK(bsc_set_gc_bins_host(ctx, NULL, 0, 0));
+  uint64_t *gc_table = xrealloc(NULL, (size_t)BSC_COV_CAP * 101 * sizeof(uint64_t));
+  CHECK(bsc_get_gc_stats(ctx, gc_table));
+  rep.gc = gc_table;
+  rep.read_profile = &prof_counts[0][0];
+  rep.n_read_profile = prof.used;
+  /* contigs in header order, as the reference lists them */
+  bsc_contig_totals *listed = calloc((size_t)n_ref + 1, sizeof *listed);
+  uint32_t nl = 0;
+  for (int i = 0; i < n_ref; i++)
+    if (ctot[i].name) listed[nl++] = ctot[i];
+  rep.contigs = listed;
+  rep.n_contigs = nl;
+  const long need = bsc_report_json(&rep, NULL, 0);
+  CHECK(need);
+  char *text = xrealloc(NULL, (size_t)need + 1);
+  bsc_report_json(&rep, text, (size_t)need + 1);
+  FILE *fr = fopen(argv[4], "w");
+  if (!fr) {
+    perror(argv[4]);
+    return 1;
+  }
+  fwrite(text, 1, (size_t)need, fr);
+  fclose(fr);
+  printf("%llu blocks, %llu records written\n", (unsigned long long)n_blocks, (unsigned long long)n_records);
+  bsc_bam_close(bam);
+  bsc_destroy(ctx);
+  return 0;
+}

@@ -143,3 +143,39 @@ def test_bam_to_bcf_on_random_alignments(tmp_path, oracle, tables, libm_exact, s
     stream = open(bcf, "rb").read()
     l_text = struct.unpack_from("<I", stream, 5)[0]
     assert stream[9 + l_text :] == b"".join(py_bcf.encode_record(d, tid) for tid, d in orecs)
+
+
+def test_plain_c_bam2bcf_equals_the_python_pipeline(tmp_path):
+    """integration/bam2bcf.c — a gcc-built C program that walks BAM + FASTA -> BCF + report with the C ABI alone — writes the
+    bytes bs_call_amd.pipeline.run writes (header in --benchmark-mode, fixed report date)."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "bs_call_amd", "lib", "bam2bcf")
+    assert os.path.exists(exe), "run `make demo`"
+    rng = np.random.default_rng(77)
+    reference = {"chrA": rng.integers(1, 5, 20_000).astype(np.uint8), "chrB": rng.integers(1, 5, 9_000).astype(np.uint8)}
+    reference["chrA"][:37] = 0
+    reference["chrB"][4_000:4_250] = 0
+    refs = [(k, len(v)) for k, v in reference.items()]
+    recs = W.wgbs_records(rng, reference["chrA"], 0, 900, het_every=400) + W.wgbs_records(rng, reference["chrB"], 1, 400)
+    bam, fa = str(tmp_path / "in.bam"), str(tmp_path / "ref.fa")
+    W.write_bam(bam, refs, recs)
+    with open(fa, "w") as f:
+        for name, codes in reference.items():
+            f.write(">%s some description\n" % name)
+            s = "".join("NACGT"[c] for c in codes)
+            for o in range(0, len(s), 60):
+                f.write(s[o : o + 60] + "\n")
+    out_c, rep_c = str(tmp_path / "c.bcf"), str(tmp_path / "c.json")
+    r = subprocess.run([exe, bam, fa, out_c, rep_c, "S9"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    out_p, rep_p = str(tmp_path / "p.bcf"), str(tmp_path / "p.json")
+    # the C program reads the FASTA itself; hand the Python pipeline the same codes through the library's FASTA reader
+    from bs_call_amd.bam import fasta_contig
+
+    ref2 = {name: fasta_contig(fa, name) for name in reference}
+    assert all((ref2[k] == reference[k]).all() for k in reference)
+    res = pipeline.run(bam, ref2, out_p, sample="S9", report_path=rep_p, date=(1, 1, 2000), compressed=False, benchmark_mode=True)
+    assert open(out_c, "rb").read() == open(out_p, "rb").read() and res["records"] > 3_000
+    assert open(rep_c).read() == open(rep_p).read()
+    assert r.stdout.strip() == "%d blocks, %d records written" % (res["blocks"], res["records"])
