@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <bscall_amd.h>
 
@@ -31,6 +32,12 @@
       exit(1);                                                               \
     }                                                                        \
   } while (0)
+
+static double now(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 
 static void *xrealloc(void *p, size_t n) {
   void *q = realloc(p, n ? n : 1);
@@ -130,7 +137,12 @@ int main(int argc, char **argv) {
   uint64_t n_blocks = 0, n_records = 0;
   bsc_read_block blk;
   int r;
-  while ((r = bsc_bam_next_block(bam, &rpar, &blk)) == 1) {
+  double t_read = 0, t_ref = 0, t_prep = 0, t_gpu = 0, t_enc = 0, t0 = now(), t1;
+  for (;;) {
+    r = bsc_bam_next_block(bam, &rpar, &blk);
+    t_read += (t1 = now()) - t0;
+    t0 = t1;
+    if (r != 1) break;
     if (blk.tid != cur_tid) { /* contig change: its sequence, and the finished contig's share of the totals */
       if (cur_tid >= 0) {
         CHECK(bsc_get_site_totals(ctx, after));
@@ -153,6 +165,8 @@ int main(int argc, char **argv) {
     const uint32_t x = bsc_block_start(&blk.tpl[0]), y = blk.y, n = y - x + 1;
     if (n + 2 > cap_ref) ref = xrealloc(ref, cap_ref = (size_t)(n + 2) * 2);
     CHECK(bsc_block_reference(codes, codes_len, x, n + 2, ref));
+    t_ref += (t1 = now()) - t0;
+    t0 = t1;
     uint64_t pad = 0;
     for (uint64_t i = 0; i < blk.n_misms; i++)
       if (blk.misms[i].type == BSC_MISMS_INS) pad += blk.misms[i].size;
@@ -172,10 +186,14 @@ int main(int argc, char **argv) {
     base_filter[4] += st.base_lowqual;
     passed_reads += st.reads;
     passed_bases += st.read_bases;
+    t_prep += (t1 = now()) - t0;
+    t0 = t1;
     if (n > cap_recs) recs = xrealloc(recs, (cap_recs = (size_t)n * 2) * sizeof *recs);
     const bsc_vcf_params vp = {0, 1, (uint32_t)codes_len};
     uint64_t n_out = 0;
     CHECK(bsc_block_records(ctx, tpl, blk.nr, pseq, used, x, y, ref, NULL, &vp, 1, recs, cap_recs, &n_out));
+    t_gpu += (t1 = now()) - t0;
+    t0 = t1;
     if (n_out * 256 + 64 > cap_bcf) bcf = xrealloc(bcf, cap_bcf = (size_t)(n_out * 256 + 64) * 2);
     uint64_t done = 0;
     const long nb = bsc_bcf_block(recs, n_out, blk.tid, &ids, NULL, bcf, cap_bcf, &done);
@@ -187,8 +205,13 @@ int main(int argc, char **argv) {
     fwrite(bcf, 1, (size_t)nb, out);
     n_blocks++;
     n_records += n_out;
+    t_enc += (t1 = now()) - t0;
+    t0 = t1;
   }
   CHECK(r);
+  if (getenv("BAM2BCF_TIMING"))
+    fprintf(stderr, "seconds: reader %.3f  reference (FASTA + block) %.3f  pre-processing %.3f  bsc_block_records %.3f  BCF encode + write %.3f\n", t_read,
+            t_ref, t_prep, t_gpu, t_enc);
   if (cur_tid >= 0) {
     CHECK(bsc_get_site_totals(ctx, after));
     uint64_t *d = ctot[cur_tid].snps;

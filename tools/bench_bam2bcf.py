@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""End-to-end host + device rate of integration/bam2bcf (BAM + FASTA -> BCF + report, plain C over the C ABI) on a synthetic
+WGBS BAM (tools/make_bam.py wgbs_records: paired 2 x 100 bp, 30x).  Prints one JSON line.  usage: python tools/bench_bam2bcf.py [positions]"""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("make_bam", os.path.join(ROOT, "tools", "make_bam.py"))
+W = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(W)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 600_000
+rng = np.random.default_rng(5)
+codes = rng.integers(1, 5, n).astype(np.uint8)
+d = tempfile.mkdtemp(prefix="bam2bcf_")
+t0 = time.time()
+recs = W.wgbs_records(rng, codes, 0, n * 30 // 200)
+bam, fa = os.path.join(d, "in.bam"), os.path.join(d, "ref.fa")
+W.write_bam(bam, [("chrS", n)], recs)
+with open(fa, "w") as f:
+    f.write(">chrS\n")
+    s = "".join("NACGT"[c] for c in codes)
+    for o in range(0, n, 60):
+        f.write(s[o : o + 60] + "\n")
+gen_s = time.time() - t0
+exe = os.path.join(ROOT, "bs_call_amd", "lib", "bam2bcf")
+best = None
+for _ in range(3):
+    t0 = time.time()
+    r = subprocess.run([exe, bam, fa, os.path.join(d, "out.bcf"), os.path.join(d, "rep.json")], capture_output=True, text=True,
+                       env=dict(os.environ, BAM2BCF_TIMING="1"))
+    dt = time.time() - t0
+    assert r.returncode == 0, r.stderr
+    best = dt if best is None else min(best, dt)
+print(json.dumps({"positions": n, "alignments": len(recs), "bam_bytes": os.path.getsize(bam), "bcf_bytes": os.path.getsize(os.path.join(d, "out.bcf")),
+                  "generate_s": round(gen_s, 1), "bam2bcf_wall_s_best_of_3": round(best, 3), "positions_per_s": round(n / best),
+                  "alignments_per_s": round(len(recs) / best), "stdout": r.stdout.strip(), "stages": r.stderr.strip().splitlines()[-1],
+                  "note": "whole process: context creation, BGZF inflate + pairing, pre-processing, GPU calling, BCF encoding, report; one host thread"}))
