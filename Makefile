@@ -83,7 +83,7 @@ $(LIBDIR)/synth_reads.o: $(CSRC)/synth_reads.c include/bscall_amd.h $(CSRC)/synt
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o $(LIBDIR)/dbsnp.o $(LIBDIR)/prep.o $(LIBDIR)/report.o $(LIBDIR)/bcf.o $(LIBDIR)/bamio.o $(LIBDIR)/refseq.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lz
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lz -lpthread
 
 oracle:
 	$(MAKE) -C oracle liboracle.so

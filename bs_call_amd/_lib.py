@@ -48,6 +48,7 @@ EXPORTS = (
     "bsc_fasta_contig",
     "bsc_block_reference",
     "bsc_bam_open",
+    "bsc_bam_open_threads",
     "bsc_bam_close",
     "bsc_bam_n_refs",
     "bsc_bam_ref_name",
@@ -256,6 +257,8 @@ def load():
     L.bsc_block_reference.argtypes = [vp, u64, u32, u32, vp]
     L.bsc_bam_open.restype = i32
     L.bsc_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.bsc_bam_open_threads.restype = i32
+    L.bsc_bam_open_threads.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
     L.bsc_bam_close.restype = None
     L.bsc_bam_close.argtypes = [vp]
     L.bsc_bam_n_refs.restype = i32

@@ -20,6 +20,7 @@
  * restatement (the repository's test oracle) over BAM files written by tools/make_bam.py — not against htslib, which this image lacks.
  */
 #include <errno.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,59 +30,222 @@
 
 int bsc_set_error(int code, const char *fmt, ...);
 
-/* ---- BGZF stream ------------------------------------------------------------------------------------------------- */
+/* ---- BGZF stream ---------------------------------------------------------------------------------------------------
+ * Blocks are independent gzip members: with helper threads (bsc_bam_open_threads) a ring of blocks is read in file order
+ * under one lock, inflated by whichever helper claimed the block, and consumed in order; without, the caller's thread does
+ * both.  Errors found by a helper travel with the block and are raised by the consumer (the error text is per thread). */
+#define BGZF_RING 64
+
+typedef struct {
+  uint8_t raw[65536 + 64]; /* one compressed block */
+  uint8_t out[65536];      /* its inflated bytes */
+  uint32_t clen, isize, crc;
+  int state;               /* SLOT_* */
+  const char *err;
+} bgzf_slot;
+enum { SLOT_FREE, SLOT_BUSY, SLOT_READY, SLOT_EOF, SLOT_ERR };
+
 typedef struct {
   FILE *f;
-  uint8_t *raw;   /* one compressed block */
-  uint8_t *out;   /* its inflated bytes */
-  uint32_t n, o;  /* inflated length, read offset */
+  bgzf_slot *ring;   /* 1 slot without helpers, BGZF_RING with */
+  uint8_t *cur;      /* the block being consumed */
+  uint32_t n, o;     /* its inflated length, read offset */
   int eof;
+  /* helpers */
+  int n_threads, closing, stop_reading;
+  pthread_t th[16];
+  pthread_mutex_t mu;
+  pthread_cond_t cv_ready, cv_free;
+  uint64_t read_idx, cons_idx; /* next block to read from the file / next block the consumer takes */
+  int holding;                 /* the consumer still uses ring[(cons_idx - 1) % BGZF_RING] */
 } bgzf_in;
 
-static int bgzf_fill(bgzf_in *z) { /* 1 = a block with data, 0 = end of file, < 0 error */
+/* one block's header and payload from the file -> slot (raw, clen, crc, isize).  1 = a block, 0 = end of file, < 0 = s->err set */
+static int bgzf_read_raw(FILE *f, bgzf_slot *s) {
+  uint8_t h[18];
+  const size_t got = fread(h, 1, 18, f);
+  if (got == 0) return 0;
+  s->err = NULL;
+  if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) {
+    s->err = "BAM: not a BGZF block (truncated file or plain gzip)";
+    return -1;
+  }
+  const uint32_t xlen = h[10] | (uint32_t)h[11] << 8;
+  /* the BC subfield is the first one in every file written by the usual tools; walk the extra field to be safe (it is
+   * read into the slot's output area, which the payload's inflation overwrites later) */
+  uint32_t bsize = 0;
+  uint8_t *extra = s->out;
+  memcpy(extra, h + 12, 6);
+  if (xlen > 6 && fread(extra + 6, 1, xlen - 6, f) != xlen - 6) {
+    s->err = "BAM: truncated BGZF header";
+    return -1;
+  }
+  for (uint32_t p = 0; p + 4 <= xlen;) {
+    const uint32_t sl = extra[p + 2] | (uint32_t)extra[p + 3] << 8;
+    if (extra[p] == 'B' && extra[p + 1] == 'C' && sl == 2 && p + 6 <= xlen) bsize = (extra[p + 4] | (uint32_t)extra[p + 5] << 8) + 1u;
+    p += 4 + sl;
+  }
+  if (bsize < 12 + xlen + 8) {
+    s->err = "BAM: BGZF block without a valid BC field";
+    return -1;
+  }
+  s->clen = bsize - 12 - xlen - 8;
+  uint8_t tail[8];
+  if (fread(s->raw, 1, s->clen, f) != s->clen || fread(tail, 1, 8, f) != 8) {
+    s->err = "BAM: truncated BGZF block";
+    return -1;
+  }
+  s->crc = tail[0] | (uint32_t)tail[1] << 8 | (uint32_t)tail[2] << 16 | (uint32_t)tail[3] << 24;
+  s->isize = tail[4] | (uint32_t)tail[5] << 8 | (uint32_t)tail[6] << 16 | (uint32_t)tail[7] << 24;
+  if (s->isize > 65536) {
+    s->err = "BAM: BGZF block larger than 64 KiB";
+    return -1;
+  }
+  return 1;
+}
+
+/* raw -> out; 0 or -1 with s->err set.  Touches nothing but the slot: safe on any thread. */
+static int bgzf_inflate(bgzf_slot *s) {
+  z_stream z;
+  memset(&z, 0, sizeof z);
+  if (inflateInit2(&z, -15) != Z_OK) {
+    s->err = "BAM: zlib initialisation failed";
+    return -1;
+  }
+  z.next_in = s->raw;
+  z.avail_in = s->clen;
+  z.next_out = s->out;
+  z.avail_out = 65536;
+  const int r = inflate(&z, Z_FINISH);
+  const uint32_t produced = (uint32_t)z.total_out;
+  inflateEnd(&z);
+  if (r != Z_STREAM_END || produced != s->isize) {
+    s->err = "BAM: corrupt BGZF block";
+    return -1;
+  }
+  if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), s->out, s->isize) != s->crc) {
+    s->err = "BAM: BGZF checksum mismatch";
+    return -1;
+  }
+  return 0;
+}
+
+static void *bgzf_helper(void *arg) {
+  bgzf_in *z = (bgzf_in *)arg;
+  pthread_mutex_lock(&z->mu);
   for (;;) {
-    uint8_t h[18];
-    const size_t got = fread(h, 1, 18, z->f);
-    if (got == 0) {
+    bgzf_slot *s = &z->ring[z->read_idx % BGZF_RING];
+    while (!z->closing && !z->stop_reading && s->state != SLOT_FREE) {
+      pthread_cond_wait(&z->cv_free, &z->mu);
+      s = &z->ring[z->read_idx % BGZF_RING];
+    }
+    if (z->closing || z->stop_reading) break;
+    /* claim the next block: the file is read in order under the lock, the inflation happens outside it */
+    const int r = bgzf_read_raw(z->f, s);
+    z->read_idx++;
+    if (r <= 0) {
+      s->state = r == 0 ? SLOT_EOF : SLOT_ERR;
+      z->stop_reading = 1;
+      pthread_cond_broadcast(&z->cv_ready);
+      pthread_cond_broadcast(&z->cv_free);
+      break;
+    }
+    s->state = SLOT_BUSY;
+    pthread_mutex_unlock(&z->mu);
+    const int e = bgzf_inflate(s);
+    pthread_mutex_lock(&z->mu);
+    s->state = e ? SLOT_ERR : SLOT_READY;
+    pthread_cond_broadcast(&z->cv_ready);
+  }
+  pthread_mutex_unlock(&z->mu);
+  return NULL;
+}
+
+static int bgzf_fill(bgzf_in *z) { /* 1 = a block with data, 0 = end of file, < 0 error */
+  if (z->n_threads == 0) {
+    for (;;) {
+      bgzf_slot *s = &z->ring[0];
+      const int r = bgzf_read_raw(z->f, s);
+      if (r == 0) {
+        z->eof = 1;
+        return 0;
+      }
+      if (r < 0 || bgzf_inflate(s)) return bsc_set_error(BSC_ERR_ARG, "%s", s->err);
+      z->cur = s->out;
+      z->n = s->isize;
+      z->o = 0;
+      if (s->isize) return 1; /* an empty block (the end-of-file marker) is skipped */
+    }
+  }
+  pthread_mutex_lock(&z->mu);
+  for (;;) {
+    if (z->holding) { /* hand the block just consumed back to the helpers */
+      z->ring[(z->cons_idx - 1) % BGZF_RING].state = SLOT_FREE;
+      z->holding = 0;
+      pthread_cond_broadcast(&z->cv_free);
+    }
+    bgzf_slot *s = &z->ring[z->cons_idx % BGZF_RING];
+    /* the slot belongs to block cons_idx once a helper has claimed it: read_idx > cons_idx */
+    while (!(z->read_idx > z->cons_idx && (s->state == SLOT_READY || s->state == SLOT_EOF || s->state == SLOT_ERR))) pthread_cond_wait(&z->cv_ready, &z->mu);
+    if (s->state == SLOT_EOF) {
+      pthread_mutex_unlock(&z->mu);
       z->eof = 1;
       return 0;
     }
-    if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
-      return bsc_set_error(BSC_ERR_ARG, "BAM: not a BGZF block (truncated file or plain gzip)");
-    const uint32_t xlen = h[10] | (uint32_t)h[11] << 8;
-    /* the BC subfield is the first one in every file written by the usual tools; walk the extra field to be safe */
-    uint32_t bsize = 0;
-    uint8_t extra[65536];
-    memcpy(extra, h + 12, 6);
-    if (xlen > 6 && fread(extra + 6, 1, xlen - 6, z->f) != xlen - 6) return bsc_set_error(BSC_ERR_ARG, "BAM: truncated BGZF header");
-    for (uint32_t p = 0; p + 4 <= xlen;) {
-      const uint32_t sl = extra[p + 2] | (uint32_t)extra[p + 3] << 8;
-      if (extra[p] == 'B' && extra[p + 1] == 'C' && sl == 2 && p + 6 <= xlen) bsize = (extra[p + 4] | (uint32_t)extra[p + 5] << 8) + 1u;
-      p += 4 + sl;
+    if (s->state == SLOT_ERR) {
+      const char *msg = s->err;
+      pthread_mutex_unlock(&z->mu);
+      return bsc_set_error(BSC_ERR_ARG, "%s", msg ? msg : "BAM: read error");
     }
-    if (bsize < 12 + xlen + 8) return bsc_set_error(BSC_ERR_ARG, "BAM: BGZF block without a valid BC field");
-    const uint32_t clen = bsize - 12 - xlen - 8;
-    uint8_t tail[8];
-    if (fread(z->raw, 1, clen, z->f) != clen || fread(tail, 1, 8, z->f) != 8) return bsc_set_error(BSC_ERR_ARG, "BAM: truncated BGZF block");
-    const uint32_t isize = tail[4] | (uint32_t)tail[5] << 8 | (uint32_t)tail[6] << 16 | (uint32_t)tail[7] << 24;
-    if (isize > 65536) return bsc_set_error(BSC_ERR_ARG, "BAM: BGZF block larger than 64 KiB");
-    z_stream s;
-    memset(&s, 0, sizeof s);
-    if (inflateInit2(&s, -15) != Z_OK) return bsc_set_error(BSC_ERR_NOMEM, "BAM: zlib initialisation failed");
-    s.next_in = z->raw;
-    s.avail_in = clen;
-    s.next_out = z->out;
-    s.avail_out = 65536;
-    const int r = inflate(&s, Z_FINISH);
-    const uint32_t produced = (uint32_t)s.total_out;
-    inflateEnd(&s);
-    if (r != Z_STREAM_END || produced != isize) return bsc_set_error(BSC_ERR_ARG, "BAM: corrupt BGZF block");
-    const uint32_t crc = tail[0] | (uint32_t)tail[1] << 8 | (uint32_t)tail[2] << 16 | (uint32_t)tail[3] << 24;
-    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), z->out, isize) != crc) return bsc_set_error(BSC_ERR_ARG, "BAM: BGZF checksum mismatch");
-    z->n = isize;
+    z->cons_idx++;
+    z->holding = 1;
+    z->cur = s->out;
+    z->n = s->isize;
     z->o = 0;
-    if (isize) return 1; /* an empty block (the end-of-file marker) is skipped */
+    if (s->isize) break;
   }
+  pthread_mutex_unlock(&z->mu);
+  return 1;
+}
+
+static int bgzf_start(bgzf_in *z, int n_threads) {
+  if (n_threads < 0) n_threads = 0;
+  if (n_threads > 16) n_threads = 16;
+  z->ring = calloc(n_threads ? BGZF_RING : 1, sizeof(bgzf_slot));
+  if (!z->ring) return -1;
+  z->n_threads = 0;
+  if (n_threads) {
+    pthread_mutex_init(&z->mu, NULL);
+    pthread_cond_init(&z->cv_ready, NULL);
+    pthread_cond_init(&z->cv_free, NULL);
+    for (int i = 0; i < n_threads; i++) {
+      if (pthread_create(&z->th[z->n_threads], NULL, bgzf_helper, z)) break;
+      z->n_threads++;
+    }
+    if (z->n_threads == 0) { /* no helper could be started: the caller's thread does the work, on slot 0 */
+      pthread_mutex_destroy(&z->mu);
+      pthread_cond_destroy(&z->cv_ready);
+      pthread_cond_destroy(&z->cv_free);
+    }
+  }
+  return 0;
+}
+
+static void bgzf_stop(bgzf_in *z) {
+  if (z->n_threads) {
+    pthread_mutex_lock(&z->mu);
+    z->closing = 1;
+    pthread_cond_broadcast(&z->cv_free);
+    pthread_cond_broadcast(&z->cv_ready);
+    pthread_mutex_unlock(&z->mu);
+    for (int i = 0; i < z->n_threads; i++) pthread_join(z->th[i], NULL);
+    pthread_mutex_destroy(&z->mu);
+    pthread_cond_destroy(&z->cv_ready);
+    pthread_cond_destroy(&z->cv_free);
+    z->n_threads = 0;
+  }
+  free(z->ring);
+  z->ring = NULL;
 }
 
 /* n bytes into dst; returns 1, 0 at a clean end of file (nothing read), < 0 on error / truncation */
@@ -95,7 +259,7 @@ static int bgzf_read(bgzf_in *z, void *dst, size_t n) {
       if (r == 0) return done ? bsc_set_error(BSC_ERR_ARG, "BAM: input truncated") : 0;
     }
     const size_t take = (n - done < (size_t)(z->n - z->o)) ? n - done : (size_t)(z->n - z->o);
-    memcpy(d + done, z->out + z->o, take);
+    memcpy(d + done, z->cur + z->o, take);
     z->o += (uint32_t)take;
     done += take;
   }
@@ -212,9 +376,8 @@ static int blk_reserve(blk_buf *k, uint32_t more_tpl, uint64_t more_seq, uint64_
 /* ---- open / close -------------------------------------------------------------------------------------------------- */
 void bsc_bam_close(bsc_bam *b) {
   if (!b) return;
+  bgzf_stop(&b->z); /* the helpers read the file: they are joined before it is closed */
   if (b->z.f) fclose(b->z.f);
-  free(b->z.raw);
-  free(b->z.out);
   free(b->text);
   if (b->ref_name)
     for (int32_t i = 0; i < b->n_ref; i++) free(b->ref_name[i]);
@@ -233,18 +396,26 @@ void bsc_bam_close(bsc_bam *b) {
 }
 
 int bsc_bam_open(const char *path, bsc_bam **out) {
+  const char *e = getenv("BSC_BAM_THREADS");
+  return bsc_bam_open_threads(path, e ? atoi(e) : 0, out);
+}
+
+int bsc_bam_open_threads(const char *path, int n_threads, bsc_bam **out) {
   if (!path || !out) return bsc_set_error(BSC_ERR_ARG, "bsc_bam_open: NULL argument");
   *out = NULL;
   bsc_bam *b = calloc(1, sizeof *b);
   if (!b) return bsc_set_error(BSC_ERR_NOMEM, "bsc_bam_open: out of memory");
   b->curr_tid = b->old_tid = -1;
   b->z.f = fopen(path, "rb");
-  b->z.raw = malloc(65536 + 64);
-  b->z.out = malloc(65536);
-  if (!b->z.f || !b->z.raw || !b->z.out) {
+  if (!b->z.f) {
     const int e = errno;
     bsc_bam_close(b);
     return bsc_set_error(BSC_ERR_ARG, "bsc_bam_open: cannot open '%s': %s", path, strerror(e));
+  }
+  setvbuf(b->z.f, NULL, _IOFBF, 1 << 20);
+  if (bgzf_start(&b->z, n_threads)) {
+    bsc_bam_close(b);
+    return bsc_set_error(BSC_ERR_NOMEM, "bsc_bam_open: out of memory");
   }
   uint8_t h[8];
   int rc = bgzf_read(&b->z, h, 8);

@@ -491,7 +491,7 @@ int bsc_block_reference(const uint8_t *codes, uint64_t contig_len, uint32_t x, u
  * read_input queues for process_template_vector: the templates of one stretch of overlapping alignments of one contig
  * (mates joined, duplicates resolved), ready for bsc_prepare_templates -> bsc_accumulate / bsc_block_records, with
  * y = the rightmost covered position (x = bsc_block_start of the first template).
- *   bsc_bam_open        a coordinate-sorted BAM file (BGZF); the header text and the @SQ list are available at once
+ *   bsc_bam_open[_threads]  a coordinate-sorted BAM file (BGZF); the header text and the @SQ list are available at once
  *   bsc_bam_next_block  1 = *blk filled (valid until the next call), 0 = end of input, < 0 = error (bsc_last_error)
  *   bsc_bam_filter_counts  bs_stats.filter_cts / filter_bases as the reader leaves them: reads and bases by verdict,
  *                       gt_filter_reason order, [14] = "PairNotFound" ([0], the passed reads, is counted by
@@ -514,7 +514,9 @@ typedef struct {
   const bsc_misms *misms;
   uint64_t n_misms;
 } bsc_read_block;
-int bsc_bam_open(const char *path, bsc_bam **out);
+int bsc_bam_open(const char *path, bsc_bam **out); /* helper threads from the environment: BSC_BAM_THREADS (default 0) */
+/* n_threads helpers (0 .. 16) inflate the BGZF blocks ahead of the parser: blocks are independent gzip members */
+int bsc_bam_open_threads(const char *path, int n_threads, bsc_bam **out);
 void bsc_bam_close(bsc_bam *b);
 int bsc_bam_n_refs(const bsc_bam *b);
 const char *bsc_bam_ref_name(const bsc_bam *b, int i);

@@ -104,7 +104,7 @@ int main(int argc, char **argv) {
   }
   const char *sample = argc > 5 ? argv[5] : "SAMPLE";
   bsc_bam *bam;
-  CHECK(bsc_bam_open(argv[1], &bam));
+  CHECK(bsc_bam_open_threads(argv[1], getenv("BAM2BCF_THREADS") ? atoi(getenv("BAM2BCF_THREADS")) : 4, &bam)); /* BGZF inflate ahead of the parser */
   bsc_params prm = {0.01, 0.05, 2.0, 20, 0};
   bsc_context *ctx;
   CHECK(bsc_create(&prm, &ctx));

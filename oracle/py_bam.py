@@ -144,11 +144,12 @@ def get_next_align_details(b, mapq_thresh, max_template_len, keep_unmatched, ign
     al = {"pos": [0, 0], "span": [0, 0], "reads": [None, None], "misms": [[], []], "mapq": [0, 0], "bs_strand": 0,
           "orientation": 0 if ((second and reverse) or not (second or reverse)) else 1}
     mult_seg = (flag & (PAIRED | MUNMAP)) == PAIRED
+    u32 = 0xFFFFFFFF  # forward_position / reverse_position are uint32_t: a negative mate position wraps (include/bs_call.h:66-67)
     if reverse:
-        al["pos"] = [b["mpos"] + 1, b["pos"] + 1]
+        al["pos"] = [(b["mpos"] + 1) & u32, (b["pos"] + 1) & u32]
         al["mapq"][1] = b["mapq"]
     else:
-        al["pos"] = [b["pos"] + 1, b["mpos"] + 1]
+        al["pos"] = [(b["pos"] + 1) & u32, (b["mpos"] + 1) & u32]
         al["mapq"][0] = b["mapq"]
     if b["mapq"] < mapq_thresh and not filtered:
         filtered = FLT_MAPQ

@@ -25,9 +25,12 @@ def rec(name, flag, pos, mpos, seq="ACGTACGTAC", cigar=None, mapq=60, tid=0, mti
                 seq=seq, qual=None if qual == "missing" else (qual if qual is not None else [30] * len(seq)), aux=aux, **kw)
 
 
+THREADS = [0]  # test_threaded_reader re-runs the comparisons with helper threads
+
+
 def c_blocks(path, **kw):
     out = []
-    with BamReader(path, **kw) as r:
+    with BamReader(path, threads=THREADS[0], **kw) as r:
         for tid, y, tpl, seq, ms in r.blocks():
             ts = []
             for t in tpl:
@@ -267,3 +270,38 @@ def test_fasta_contig_and_block_reference(tmp_path):
     codes = np.array([3, 3, 3, 2, 2, 2], dtype=np.uint8)
     assert block_reference(codes, 1, 4).tolist() == [3, 3, 3, 2, 2, 0]  # positions 1 .. 6: the 6th (= end_pos) reads 0
     assert block_reference(codes, 4, 8).tolist() == [2, 2, 0, 0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_threaded_reader(tmp_path, threads):
+    """Helper threads that inflate the BGZF blocks ahead of the parser: the same blocks, counts and errors as without, on
+    files of many small BGZF blocks, of one block, truncated files, and readers closed half way."""
+    rng = np.random.default_rng(40 + threads)
+    THREADS[0] = threads
+    try:
+        for trial in range(4):
+            recs = _random_records(rng, 500)
+            p = str(tmp_path / "t.bam")
+            W.write_bam(p, REFS, recs, block=int(rng.choice([300, 5000, 0xFF00])))
+            try:
+                py = py_blocks(p)
+            except AssertionError:
+                with pytest.raises(BscError):
+                    c_blocks(p)
+                continue
+            assert c_blocks(p) == py
+            # closed half way: no hang, no leak of helper threads
+            r = BamReader(p, threads=threads)
+            it = r.blocks()
+            next(it)
+            r.close()
+            # truncated at a random place: an error (or, cut exactly between blocks, a shorter file), never a hang
+            raw = open(p, "rb").read()
+            cut = str(tmp_path / "cut.bam")
+            open(cut, "wb").write(raw[: int(rng.integers(100, len(raw) - 30))])
+            try:
+                c_blocks(cut)
+            except BscError:
+                pass
+    finally:
+        THREADS[0] = 0
