@@ -914,6 +914,12 @@ int bsc_bam_next_block(bsc_bam *b, const bsc_reader_params *par, bsc_read_block 
     if (have_out) goto hand_out;
   }
 hand_out:
+  { /* what the process thread asserts before it touches the block (src/process_template.c:24-26): 0 < x <= y */
+    const uint32_t x0 = b->out.n ? (b->out.tpl[0].pos[0] ? b->out.tpl[0].pos[0] : b->out.tpl[0].pos[1]) : 0;
+    if (b->out.n && (x0 == 0 || x0 > blk->y))
+      return bsc_set_error(BSC_ERR_ARG, "BAM: a block whose first template starts at %u, right of the block's end %u (a mate position that is "
+                                        "negative in the file, or input not sorted by coordinate)", x0, blk->y);
+  }
   blk->nr = b->out.n;
   blk->tpl = b->out.tpl;
   blk->seq = b->out.seq;

@@ -368,3 +368,9 @@ def read_input(recs, mapq_thresh=20, max_template_len=1000, keep_unmatched=False
                 append(al, None)
     if align_list:
         yield curr_tid, max_pos, align_list
+
+
+def check_block(als, y):
+    """What process_template_vector asserts before it touches a block (src/process_template.c:22-26)."""
+    x = als[0]["pos"][0] or als[0]["pos"][1]
+    assert x > 0 and x <= y

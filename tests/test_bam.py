@@ -53,6 +53,7 @@ def py_blocks(path, **kw):
     st = {"cts": [0] * 15, "bases": [0] * 15}
     out = []
     for tid, y, als in py_bam.read_input(recs, stats=st, **kw):
+        py_bam.check_block(als, y)  # the library's reader reports what the process thread would assert on
         out.append((tid, y, [{"pos": list(a["pos"]), "span": [a["span"][k] if a["reads"][k] else 0 for k in range(2)], "reads": [a["reads"][0], a["reads"][1]],
                               "misms": a["misms"], "mapq": list(a["mapq"]), "orientation": a["orientation"], "bs_strand": a["bs_strand"]} for a in als]))
     return out, st["cts"], st["bases"]

@@ -37,6 +37,7 @@ def _oracle_records(oracle, tables, libm_exact, bam, reference, gc=None):
     out = []
     bins_of = {name: _gc_bins(codes) for name, codes in reference.items()}
     for tid, y, als in py_bam.read_input(recs):
+        py_bam.check_block(als, y)
         name = refs[tid][0]
         x = als[0]["pos"][0] or als[0]["pos"][1]
         x = x - 2 if x > 2 else 1
