@@ -464,14 +464,17 @@ def run_config3(args, env):
             contig_table = shard.allreduce_counts(tab, dev if dist is not None else None)
         barrier(env)
         dt += time.perf_counter() - t0
-        # device time of one window, from HIP events around its launches, outside the timed region
-        caller.set_profiling(True)
-        rcl = resident[-1]
-        caller.chain_device(rcl.d_cts.data_ptr(), rcl.d_ref.data_ptr(), 1, rcl.length, 0, min(args.window, rcl.length), rcl.d_core.data_ptr(),
-                            d_dbsnp=None if rcl.d_dbsnp is None else rcl.d_dbsnp.data_ptr(), with_stats=False, stream=stream)
-        chain_ms.append(caller.last_chain_ms())
-        caller.set_profiling(False)
-        del resident, rcl
+        if gi == len(groups) - 1:
+            # device time of one window, from HIP events around its launches, outside the timed region (and after the
+            # counters were read: the extra window is not part of the job)
+            caller.set_profiling(True)
+            rcl = resident[-1]
+            caller.chain_device(rcl.d_cts.data_ptr(), rcl.d_ref.data_ptr(), 1, rcl.length, 0, min(args.window, rcl.length), rcl.d_core.data_ptr(),
+                                d_dbsnp=None if rcl.d_dbsnp is None else rcl.d_dbsnp.data_ptr(), with_stats=False, stream=stream)
+            chain_ms.append(caller.last_chain_ms())
+            caller.set_profiling(False)
+            del rcl
+        del resident
         torch.cuda.empty_cache()
     dt = max_over_ranks(env, dt)
     total = int(stats[0])

@@ -184,3 +184,21 @@ def test_rank0_of_8_share_with_dbsnp_index(tmp_path):
         assert n_sites == sum(len(v) for v in sites.values()) and abs(n_sites - sum(lengths[k] for k in mine) / 300) < 10
         assert int(st["dbSNP_sites"][0]) == n_db_written > 500_000 and n_forced > 20_000
         assert int(st["dbSNP_var"][0]) == n_db_written  # every written record counts as a variant (the reference's alt walk)
+
+
+def test_bench_config3_in_several_resident_groups():
+    """bench.py --config 3 on one GPU when the genome does not fit the HBM budget: the contigs are processed in groups of
+    whole contigs; every position is counted once and the per-contig totals still add up."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "3", "--genome-scale", "0.004", "--mem-gb", "0.9", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "resident group(s)" in d["config"]["share"] and int(d["config"]["share"].split(" positions in ")[1].split()[0]) >= 3
+    assert d["config"]["contigs_with_records_after_gather"] == 24 and d["config"]["per_contig_records_sum_equals_total"] is True
+    assert d["metric"] == "genome positions called/sec" and d["scaling"] == "strong" and d["n_gpus"] == 1
