@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:]
-sites, rounds, chain = 50_000_000, 3, False
+sites, rounds, chain, coverage = 50_000_000, 3, False, 30
 while args and args[0].startswith("--"):
     if args[0] == "--chain":  # time the fused chain (tools/bench_chain.py) instead of the calling kernel (bench.py)
         chain = True
@@ -19,6 +19,8 @@ while args and args[0].startswith("--"):
         sites = int(args[1])
     elif args[0] == "--rounds":
         rounds = int(args[1])
+    elif args[0] == "--coverage":
+        coverage = int(args[1])
     args = args[2:]
 res = {n: [] for n in args}
 for r in range(rounds):
@@ -27,10 +29,10 @@ for r in range(rounds):
         if n != "main":
             env["BSCALL_AMD_LIB"] = os.path.join(ROOT, "bs_call_amd", "lib", "variants", "lib_%s.so" % n)
         if chain:
-            cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_chain.py"), "--no-unfused", "--steps", "7", "--sites", str(sites)]
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_chain.py"), "--no-unfused", "--steps", "7", "--sites", str(sites), "--coverage", str(coverage)]
         else:
             cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-chain", "--steps", "5", "--warmup", "2",
-                   "--sites", str(sites)]
+                   "--sites", str(sites), "--coverage", str(coverage)]
         out = subprocess.run(cmd, env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
