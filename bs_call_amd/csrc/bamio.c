@@ -12,8 +12,11 @@
  *                                     get_bs_strand (:144-220)
  *   bsc_bam_filter_counts             bs_stats.filter_cts / filter_bases as the reader leaves them (the report's ReadLevel)
  *
- * Not covered: SAM text and CRAM input, region queries through a .bai index (the reference's -r), contig include /
- * exclude lists (every @SQ contig is processed).  The block a call returns stays valid until the next call.
+ * SAM text (plain or BGZF-compressed) is read through the same code: every alignment line is re-encoded as a BAM record
+ * (SAM specification sections 1.4 and 4.2) in front of the record decoder.
+ *
+ * Not covered: CRAM input, region queries through a .bai index (the reference's -r), contig include / exclude lists
+ * (every @SQ contig is processed).  The block a call returns stays valid until the next call.
  *
  * htslib is an un-vendored dependency of the reference; what this file needs from it is the BAM / BGZF layout, which the
  * SAM specification fixes.  Parity of the template stream is pinned by hand-worked scenarios and an independent Python
@@ -298,6 +301,13 @@ struct bsc_bam {
   uint32_t *ref_len;
   uint8_t *rec; /* one BAM record */
   uint32_t rec_cap;
+  /* SAM text input: the same reader behind a line parser that re-encodes every alignment line as a BAM record */
+  int is_sam, sam_plain; /* sam_plain: the file is not BGZF-compressed */
+  char *line;
+  size_t line_cap;
+  uint8_t pend[8];       /* bytes already taken from the stream while its kind was being found out */
+  uint32_t n_pend, o_pend;
+  int32_t last_tid;      /* reference-name lookups: consecutive records mostly share it */
   /* read_input's variables (src/get_template_vector.c:53-58) */
   int32_t curr_tid, old_tid;
   uint32_t max_pos, start_pos, curr_pos, start_idx;
@@ -384,6 +394,7 @@ void bsc_bam_close(bsc_bam *b) {
   free(b->ref_name);
   free(b->ref_len);
   free(b->rec);
+  free(b->line);
   name_clear(b);
   blk_buf *ks[2] = {&b->cur, &b->out};
   for (int i = 0; i < 2; i++) {
@@ -394,6 +405,8 @@ void bsc_bam_close(bsc_bam *b) {
   }
   free(b);
 }
+
+static int sam_read_header(bsc_bam *b);
 
 int bsc_bam_open(const char *path, bsc_bam **out) {
   const char *e = getenv("BSC_BAM_THREADS");
@@ -413,16 +426,48 @@ int bsc_bam_open_threads(const char *path, int n_threads, bsc_bam **out) {
     return bsc_set_error(BSC_ERR_ARG, "bsc_bam_open: cannot open '%s': %s", path, strerror(e));
   }
   setvbuf(b->z.f, NULL, _IOFBF, 1 << 20);
-  if (bgzf_start(&b->z, n_threads)) {
+  b->last_tid = -1;
+  { /* what kind of file: gzip magic -> BGZF (BAM, or SAM text inside); anything else is read as plain SAM text */
+    uint8_t m[2];
+    const size_t got = fread(m, 1, 2, b->z.f);
+    b->sam_plain = !(got == 2 && m[0] == 0x1f && m[1] == 0x8b);
+    if (fseek(b->z.f, 0, SEEK_SET)) {
+      bsc_bam_close(b);
+      return bsc_set_error(BSC_ERR_ARG, "bsc_bam_open: '%s' is not seekable", path);
+    }
+  }
+  if (bgzf_start(&b->z, b->sam_plain ? 0 : n_threads)) {
     bsc_bam_close(b);
     return bsc_set_error(BSC_ERR_NOMEM, "bsc_bam_open: out of memory");
   }
   uint8_t h[8];
-  int rc = bgzf_read(&b->z, h, 8);
-  if (rc <= 0 || memcmp(h, "BAM\1", 4)) {
-    bsc_bam_close(b);
-    return rc < 0 ? rc : bsc_set_error(BSC_ERR_ARG, "bsc_bam_open: '%s' is not a BAM file", path);
+  int rc = 1;
+  if (!b->sam_plain) {
+    rc = bgzf_read(&b->z, h, 4);
+    if (rc < 0) {
+      bsc_bam_close(b);
+      return rc;
+    }
   }
+  if (b->sam_plain || rc == 0 || memcmp(h, "BAM\1", 4)) { /* SAM text: hand the bytes already taken back to the line reader */
+    if (!b->sam_plain && rc > 0) {
+      memcpy(b->pend, h, 4);
+      b->n_pend = 4;
+    }
+    b->is_sam = 1;
+    rc = sam_read_header(b);
+    if (rc) {
+      bsc_bam_close(b);
+      return rc;
+    }
+    if (b->l_text == 0 && b->is_sam == 3 && b->line[0] != '@' && strchr(b->line, '\t') == NULL) {
+      bsc_bam_close(b);
+      return bsc_set_error(BSC_ERR_ARG, "bsc_bam_open: '%s' is neither a BAM file nor SAM text", path);
+    }
+    *out = b;
+    return BSC_OK;
+  }
+  if (bgzf_read(&b->z, h + 4, 4) <= 0) goto bad;
   b->l_text = le32(h + 4);
   b->text = malloc((size_t)b->l_text + 1);
   if (!b->text || (b->l_text && bgzf_read(&b->z, b->text, b->l_text) <= 0) || bgzf_read(&b->z, h, 4) <= 0) goto bad;
@@ -456,6 +501,300 @@ void bsc_bam_filter_counts(const bsc_bam *b, uint64_t cts[15], uint64_t bases[15
   if (!b) return;
   if (cts) memcpy(cts, b->filter_cts, sizeof b->filter_cts);
   if (bases) memcpy(bases, b->filter_bases, sizeof b->filter_bases);
+}
+
+/* ---- byte stream under the parsers: BGZF, or the plain file for uncompressed SAM text ------------------------------ */
+static int in_read(bsc_bam *b, void *dst, size_t n) { /* 1, 0 = clean end of input, < 0 = error */
+  uint8_t *d = (uint8_t *)dst;
+  size_t done = 0;
+  while (done < n && b->o_pend < b->n_pend) d[done++] = b->pend[b->o_pend++];
+  if (done == n) return 1;
+  if (b->sam_plain) {
+    const size_t got = fread(d + done, 1, n - done, b->z.f);
+    if (got == n - done) return 1;
+    return (done + got) ? bsc_set_error(BSC_ERR_ARG, "SAM: input truncated") : 0;
+  }
+  const int r = bgzf_read(&b->z, d + done, n - done);
+  if (r == 0 && done) return bsc_set_error(BSC_ERR_ARG, "BAM: input truncated");
+  return r;
+}
+
+/* one text line (without its terminator) into b->line: 1, 0 = end of input, < 0 = error */
+static int in_getline(bsc_bam *b, size_t *len) {
+  size_t n = 0;
+  for (;;) {
+    char c;
+    int r;
+    if (b->o_pend < b->n_pend) {
+      c = (char)b->pend[b->o_pend++];
+      r = 1;
+    } else if (b->sam_plain) {
+      const int ch = getc(b->z.f);
+      r = ch == EOF ? 0 : 1;
+      c = (char)ch;
+    } else {
+      if (b->z.o == b->z.n) {
+        r = bgzf_fill(&b->z);
+        if (r < 0) return r;
+        if (r == 0) c = 0;
+        else c = (char)b->z.cur[b->z.o++];
+      } else {
+        r = 1;
+        c = (char)b->z.cur[b->z.o++];
+      }
+    }
+    if (r == 0) {
+      if (n == 0) return 0;
+      break; /* a last line without a newline */
+    }
+    if (c == '\n') break;
+    if (n + 2 > b->line_cap) {
+      char *nl = realloc(b->line, (n + 2) * 2 + 256);
+      if (!nl) return bsc_set_error(BSC_ERR_NOMEM, "SAM: out of memory");
+      b->line = nl;
+      b->line_cap = (n + 2) * 2 + 256;
+    }
+    b->line[n++] = c;
+  }
+  if (n && b->line[n - 1] == '\r') n--;
+  if (b->line) b->line[n] = 0;
+  *len = n;
+  return 1;
+}
+
+static int32_t sam_tid(bsc_bam *b, const char *name, size_t len) {
+  if (len == 1 && name[0] == '*') return -1;
+  if (b->last_tid >= 0 && strlen(b->ref_name[b->last_tid]) == len && !memcmp(b->ref_name[b->last_tid], name, len)) return b->last_tid;
+  for (int32_t i = 0; i < b->n_ref; i++)
+    if (strlen(b->ref_name[i]) == len && !memcmp(b->ref_name[i], name, len)) return b->last_tid = i;
+  return -2;
+}
+
+/* the header lines of a SAM file: the text as it stands, the @SQ SN / LN pairs as the reference list */
+static int sam_read_header(bsc_bam *b) {
+  size_t cap = 1 << 16, len = 0, ll;
+  b->text = malloc(cap);
+  if (!b->text) return bsc_set_error(BSC_ERR_NOMEM, "SAM: out of memory");
+  int32_t cap_ref = 0;
+  for (;;) {
+    /* peek: header lines start with '@'; the first other line is an alignment and stays in b->line for next_record */
+    const int r = in_getline(b, &ll);
+    if (r < 0) return r;
+    if (r == 0) {
+      b->line_cap = b->line_cap; /* empty file body */
+      if (b->line) b->line[0] = 0;
+      b->is_sam = 2; /* no alignment line is waiting */
+      break;
+    }
+    if (ll == 0 || b->line[0] != '@') {
+      b->is_sam = 3; /* b->line holds the first alignment line */
+      break;
+    }
+    if (len + ll + 2 > cap) {
+      cap = (len + ll + 2) * 2;
+      char *nt = realloc(b->text, cap);
+      if (!nt) return bsc_set_error(BSC_ERR_NOMEM, "SAM: out of memory");
+      b->text = nt;
+    }
+    memcpy(b->text + len, b->line, ll);
+    len += ll;
+    b->text[len++] = '\n';
+    if (!strncmp(b->line, "@SQ\t", 4)) {
+      const char *sn = NULL, *lnp = NULL;
+      size_t sn_len = 0;
+      for (char *f = b->line + 4; f && *f;) {
+        char *e = strchr(f, '\t');
+        const size_t fl = e ? (size_t)(e - f) : strlen(f);
+        if (fl > 3 && f[0] == 'S' && f[1] == 'N' && f[2] == ':') {
+          sn = f + 3;
+          sn_len = fl - 3;
+        } else if (fl > 3 && f[0] == 'L' && f[1] == 'N' && f[2] == ':')
+          lnp = f + 3;
+        f = e ? e + 1 : NULL;
+      }
+      if (!sn || !lnp) return bsc_set_error(BSC_ERR_ARG, "SAM: an @SQ line without SN or LN");
+      if (b->n_ref + 1 > cap_ref) {
+        cap_ref = cap_ref * 2 + 64;
+        char **nn = realloc(b->ref_name, (size_t)cap_ref * sizeof *nn);
+        if (nn) b->ref_name = nn;
+        uint32_t *nl = nn ? realloc(b->ref_len, (size_t)cap_ref * sizeof *nl) : NULL;
+        if (!nn || !nl) return bsc_set_error(BSC_ERR_NOMEM, "SAM: out of memory");
+        b->ref_len = nl;
+      }
+      b->ref_name[b->n_ref] = malloc(sn_len + 1);
+      if (!b->ref_name[b->n_ref]) return bsc_set_error(BSC_ERR_NOMEM, "SAM: out of memory");
+      memcpy(b->ref_name[b->n_ref], sn, sn_len);
+      b->ref_name[b->n_ref][sn_len] = 0;
+      b->ref_len[b->n_ref] = (uint32_t)strtoul(lnp, NULL, 10);
+      b->n_ref++;
+    }
+  }
+  b->text[len] = 0;
+  b->l_text = (uint32_t)len;
+  if (!b->ref_name) { /* a header without @SQ lines: an empty list, not a NULL one */
+    b->ref_name = calloc(1, sizeof *b->ref_name);
+    b->ref_len = calloc(1, sizeof *b->ref_len);
+    if (!b->ref_name || !b->ref_len) return bsc_set_error(BSC_ERR_NOMEM, "SAM: out of memory");
+  }
+  return BSC_OK;
+}
+
+/* the alignment line in b->line -> a BAM record in b->rec (SAM specification section 1.4 -> 4.2); returns its size */
+static long sam_encode_line(bsc_bam *b, size_t ll) {
+  char *f[12];
+  int nf = 0;
+  char *p = b->line;
+  char *aux = NULL;
+  for (; nf < 11; nf++) {
+    f[nf] = p;
+    char *e = strchr(p, '\t');
+    if (!e) {
+      nf++;
+      p = NULL;
+      break;
+    }
+    *e = 0;
+    p = e + 1;
+  }
+  if (nf < 11) return bsc_set_error(BSC_ERR_ARG, "SAM: an alignment line with %d of the 11 mandatory fields", nf);
+  aux = p; /* the optional fields, tab separated, or NULL */
+  const size_t l_name = strlen(f[0]) + 1;
+  if (l_name > 255) return bsc_set_error(BSC_ERR_ARG, "SAM: read name longer than 254 characters");
+  const int32_t tid = sam_tid(b, f[2], strlen(f[2]));
+  int32_t mtid = (f[6][0] == '=' && !f[6][1]) ? tid : sam_tid(b, f[6], strlen(f[6]));
+  if (tid == -2 || mtid == -2) return bsc_set_error(BSC_ERR_ARG, "SAM: reference '%s' is not in the header", tid == -2 ? f[2] : f[6]);
+  /* worst-case size: name + cigar ops + sequence + qualities + optional fields re-encoded (never longer than their text) */
+  const size_t l_seq = (f[9][0] == '*' && !f[9][1]) ? 0 : strlen(f[9]);
+  size_t n_cig = 0;
+  if (!(f[5][0] == '*' && !f[5][1]))
+    for (const char *c = f[5]; *c; c++) n_cig += (*c < '0' || *c > '9');
+  const size_t need = 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq + (aux ? (ll + 16) : 0) + 64;
+  if (need > b->rec_cap) {
+    uint8_t *nr = realloc(b->rec, need * 2);
+    if (!nr) return bsc_set_error(BSC_ERR_NOMEM, "SAM: out of memory");
+    b->rec = nr;
+    b->rec_cap = (uint32_t)(need * 2);
+  }
+  uint8_t *r = b->rec;
+  const uint32_t flag = (uint32_t)strtoul(f[1], NULL, 10), mapq = (uint32_t)strtoul(f[4], NULL, 10);
+  const int32_t pos = (int32_t)strtol(f[3], NULL, 10) - 1, mpos = (int32_t)strtol(f[7], NULL, 10) - 1, tlen = (int32_t)strtol(f[8], NULL, 10);
+#define PUT32(off, v)                        \
+  do {                                       \
+    const uint32_t v_ = (uint32_t)(v);       \
+    r[(off)] = (uint8_t)v_;                  \
+    r[(off) + 1] = (uint8_t)(v_ >> 8);       \
+    r[(off) + 2] = (uint8_t)(v_ >> 16);      \
+    r[(off) + 3] = (uint8_t)(v_ >> 24);      \
+  } while (0)
+  PUT32(0, tid);
+  PUT32(4, pos);
+  r[8] = (uint8_t)l_name;
+  r[9] = (uint8_t)(mapq > 255 ? 255 : mapq);
+  r[10] = r[11] = 0; /* the bin: not used by this reader */
+  r[12] = (uint8_t)n_cig;
+  r[13] = (uint8_t)(n_cig >> 8);
+  r[14] = (uint8_t)flag;
+  r[15] = (uint8_t)(flag >> 8);
+  PUT32(16, l_seq);
+  PUT32(20, mtid);
+  PUT32(24, mpos);
+  PUT32(28, tlen);
+  size_t o = 32;
+  memcpy(r + o, f[0], l_name);
+  o += l_name;
+  if (n_cig) {
+    if (n_cig > 65535) return bsc_set_error(BSC_ERR_ARG, "SAM: more than 65 535 CIGAR operations");
+    for (const char *c = f[5]; *c;) {
+      char *e;
+      const unsigned long len = strtoul(c, &e, 10);
+      static const char ops[] = "MIDNSHP=X";
+      const char *q = (*e && e != c) ? strchr(ops, *e) : NULL;
+      if (!q || len >= (1ul << 28)) return bsc_set_error(BSC_ERR_ARG, "SAM: malformed CIGAR '%s'", f[5]);
+      PUT32(o, (uint32_t)len << 4 | (uint32_t)(q - ops));
+      o += 4;
+      c = e + 1;
+    }
+  }
+  static const char codes[] = "=ACMGRSVTWYHKDBN";
+  memset(r + o, 0, (l_seq + 1) / 2);
+  for (size_t i = 0; i < l_seq; i++) {
+    char ch = f[9][i];
+    if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+    const char *q = strchr(codes, ch);
+    const unsigned v = (q && ch) ? (unsigned)(q - codes) : 15u;
+    r[o + (i >> 1)] |= (uint8_t)(v << ((~i & 1u) << 2));
+  }
+  o += (l_seq + 1) / 2;
+  if (f[10][0] == '*' && !f[10][1]) memset(r + o, 0xff, l_seq);
+  else {
+    if (strlen(f[10]) != l_seq) return bsc_set_error(BSC_ERR_ARG, "SAM: '%s': sequence and quality lengths differ", f[0]);
+    for (size_t i = 0; i < l_seq; i++) r[o + i] = (uint8_t)(f[10][i] - 33);
+  }
+  o += l_seq;
+  /* optional fields TAG:TYPE:VALUE.  Integers are written as 32-bit ('i'): the reader only needs to step over them */
+  for (char *t = aux; t && *t;) {
+    char *e = strchr(t, '\t');
+    if (e) *e = 0;
+    const size_t tl = strlen(t);
+    if (tl >= 5 && t[2] == ':' && t[4] == ':') {
+      const char ty = t[3], *v = t + 5;
+      r[o++] = (uint8_t)t[0];
+      r[o++] = (uint8_t)t[1];
+      switch (ty) {
+        case 'A':
+          r[o++] = 'A';
+          r[o++] = (uint8_t)v[0];
+          break;
+        case 'i':
+          r[o++] = 'i';
+          PUT32(o, (int32_t)strtol(v, NULL, 10));
+          o += 4;
+          break;
+        case 'f': {
+          const float fv = strtof(v, NULL);
+          uint32_t bits;
+          memcpy(&bits, &fv, 4);
+          r[o++] = 'f';
+          PUT32(o, bits);
+          o += 4;
+        } break;
+        case 'Z': case 'H': {
+          const size_t vl = strlen(v);
+          r[o++] = (uint8_t)ty;
+          memcpy(r + o, v, vl + 1);
+          o += vl + 1;
+        } break;
+        case 'B': { /* B:<type>,v,v,... -> type, count, values; only 32-bit element types are written ('i' / 'f') */
+          const char sub = v[0];
+          uint32_t cnt = 0;
+          for (const char *c = v; *c; c++) cnt += *c == ',';
+          r[o++] = 'B';
+          r[o++] = (uint8_t)(sub == 'f' ? 'f' : 'i');
+          PUT32(o, cnt);
+          o += 4;
+          const char *c = strchr(v, ',');
+          while (c) {
+            c++;
+            if (sub == 'f') {
+              const float fv = strtof(c, NULL);
+              uint32_t bits;
+              memcpy(&bits, &fv, 4);
+              PUT32(o, bits);
+            } else
+              PUT32(o, (int32_t)strtol(c, NULL, 10));
+            o += 4;
+            c = strchr(c, ',');
+          }
+        } break;
+        default:
+          o -= 2; /* an unknown type: dropped */
+          break;
+      }
+    }
+    t = e ? e + 1 : NULL;
+  }
+#undef PUT32
+  return (long)o;
 }
 
 /* ---- one alignment record ------------------------------------------------------------------------------------------ */
@@ -533,19 +872,40 @@ static uint8_t bs_strand_of(const uint8_t *s, const uint8_t *end) {
 /* Next record -> *r.  Returns 0 = use it, 1 = filtered (counted), -1 = end of input, < -1 = error.
  * get_next_align_details, src/input_sam.c:222-312. */
 static int next_record(bsc_bam *b, const bsc_reader_params *par, bam_rec *r, int *filtered) {
-  uint8_t h[4];
-  int rc = bgzf_read(&b->z, h, 4);
-  if (rc == 0) return -1;
-  if (rc < 0) return -2;
-  const uint32_t bs = le32(h);
-  if (bs < 32 || bs > (1u << 29)) return bsc_set_error(BSC_ERR_ARG, "BAM: implausible record size %u", bs), -2;
-  if (bs > b->rec_cap) {
-    uint8_t *nr = realloc(b->rec, (size_t)bs * 2);
-    if (!nr) return bsc_set_error(BSC_ERR_NOMEM, "BAM: out of memory"), -2;
-    b->rec = nr;
-    b->rec_cap = bs * 2;
+  uint32_t bs;
+  if (b->is_sam) {
+    size_t ll = 0;
+    if (b->is_sam == 3) { /* the line the header scan stopped at */
+      b->is_sam = 1;
+      ll = strlen(b->line);
+    } else if (b->is_sam == 2)
+      return -1;
+    else {
+      int rl;
+      do {
+        rl = in_getline(b, &ll);
+        if (rl < 0) return -2;
+        if (rl == 0) return -1;
+      } while (ll == 0); /* blank lines are skipped */
+    }
+    const long n = sam_encode_line(b, ll);
+    if (n < 0) return -2;
+    bs = (uint32_t)n;
+  } else {
+    uint8_t h[4];
+    int rc = in_read(b, h, 4);
+    if (rc == 0) return -1;
+    if (rc < 0) return -2;
+    bs = le32(h);
+    if (bs < 32 || bs > (1u << 29)) return bsc_set_error(BSC_ERR_ARG, "BAM: implausible record size %u", bs), -2;
+    if (bs > b->rec_cap) {
+      uint8_t *nr = realloc(b->rec, (size_t)bs * 2);
+      if (!nr) return bsc_set_error(BSC_ERR_NOMEM, "BAM: out of memory"), -2;
+      b->rec = nr;
+      b->rec_cap = bs * 2;
+    }
+    if (in_read(b, b->rec, bs) <= 0) return bsc_set_error(BSC_ERR_ARG, "BAM: input truncated"), -2;
   }
-  if (bgzf_read(&b->z, b->rec, bs) <= 0) return bsc_set_error(BSC_ERR_ARG, "BAM: input truncated"), -2;
   const uint8_t *p = b->rec;
   const int32_t tid = (int32_t)le32(p), pos = (int32_t)le32(p + 4), mtid = (int32_t)le32(p + 20), mpos = (int32_t)le32(p + 24);
   const int32_t isize = (int32_t)le32(p + 28);

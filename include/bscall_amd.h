@@ -491,12 +491,13 @@ int bsc_block_reference(const uint8_t *codes, uint64_t contig_len, uint32_t x, u
  * read_input queues for process_template_vector: the templates of one stretch of overlapping alignments of one contig
  * (mates joined, duplicates resolved), ready for bsc_prepare_templates -> bsc_accumulate / bsc_block_records, with
  * y = the rightmost covered position (x = bsc_block_start of the first template).
- *   bsc_bam_open[_threads]  a coordinate-sorted BAM file (BGZF); the header text and the @SQ list are available at once
+ *   bsc_bam_open[_threads]  a coordinate-sorted BAM or SAM file; the header text and the @SQ list are available at once
  *   bsc_bam_next_block  1 = *blk filled (valid until the next call), 0 = end of input, < 0 = error (bsc_last_error)
  *   bsc_bam_filter_counts  bs_stats.filter_cts / filter_bases as the reader leaves them: reads and bases by verdict,
  *                       gt_filter_reason order, [14] = "PairNotFound" ([0], the passed reads, is counted by
  *                       bsc_prepare_templates: bsc_prep_stats.reads / read_bases)
- * Not covered: SAM / CRAM input, region queries through an index, contig include / exclude lists.
+ * SAM text (plain or BGZF-compressed) is accepted as well: the kind is found out from the first bytes.
+ * Not covered: CRAM input, region queries through an index, contig include / exclude lists.
  */
 typedef struct bsc_bam bsc_bam;
 typedef struct {

@@ -48,6 +48,57 @@ def parse_bam(path):
     return text, refs, recs
 
 
+def parse_sam(path):
+    """SAM text (plain or gzip / BGZF) -> (header text, refs, records) in the shape parse_bam gives (SAM specification 1.3-1.5)."""
+    raw = open(path, "rb").read()
+    if raw[:2] == b"\x1f\x8b":
+        raw = gzip.decompress(raw)
+    text, refs, recs = [], [], []
+    codes = "=ACMGRSVTWYHKDBN"
+    for ln in raw.decode().split("\n"):
+        ln = ln.rstrip("\r")
+        if not ln:
+            continue
+        if ln[0] == "@" and not recs:
+            text.append(ln + "\n")
+            if ln.startswith("@SQ\t"):
+                kv = dict(f.split(":", 1) for f in ln.split("\t")[1:] if ":" in f)
+                refs.append((kv["SN"], int(kv["LN"])))
+            continue
+        f = ln.split("\t")
+        names = [r[0] for r in refs]
+        tid = -1 if f[2] == "*" else names.index(f[2])
+        mtid = tid if f[6] == "=" else (-1 if f[6] == "*" else names.index(f[6]))
+        cigar = []
+        if f[5] != "*":
+            num = ""
+            for ch in f[5]:
+                if ch.isdigit():
+                    num += ch
+                else:
+                    cigar.append(("MIDNSHP=X".index(ch), int(num)))
+                    num = ""
+        seq = "" if f[9] == "*" else f[9].upper()
+        seq4 = bytearray((len(seq) + 1) // 2)
+        for i, ch in enumerate(seq):
+            seq4[i >> 1] |= (codes.index(ch) if ch in codes else 15) << (4 if i % 2 == 0 else 0)
+        qual = bytes([0xFF] * len(seq)) if f[10] == "*" else bytes(ord(c) - 33 for c in f[10])
+        aux = b""
+        for t in f[11:]:
+            tag, ty, v = t[:2], t[3], t[5:]
+            if ty == "A":
+                aux += tag.encode() + b"A" + v[0].encode()
+            elif ty == "i":
+                aux += tag.encode() + b"i" + struct.pack("<i", int(v))
+            elif ty in "ZH":
+                aux += tag.encode() + ty.encode() + v.encode() + b"\0"
+            elif ty == "f":
+                aux += tag.encode() + b"f" + struct.pack("<f", float(v))
+        recs.append(dict(tid=tid, pos=int(f[3]) - 1, name=f[0].encode() + b"\0", mapq=int(f[4]), cigar=cigar, flag=int(f[1]), l_seq=len(seq), mtid=mtid,
+                         mpos=int(f[7]) - 1, tlen=int(f[8]), seq4=bytes(seq4), qual=qual, aux=aux))
+    return "".join(text), refs, recs
+
+
 def get_bs_strand(aux):
     strand, s, end = 0, 0, len(aux)
     sizes = {ord("A"): 1, ord("C"): 1, ord("c"): 1, ord("s"): 2, ord("S"): 2, ord("i"): 4, ord("I"): 4, ord("f"): 4, ord("d"): 8,

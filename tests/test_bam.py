@@ -306,3 +306,45 @@ def test_threaded_reader(tmp_path, threads):
                 pass
     finally:
         THREADS[0] = 0
+
+
+def test_sam_text_input(tmp_path):
+    """The same alignments as SAM text — plain and in BGZF blocks — give the blocks, counts and header of the BAM file
+    (the line parser re-encodes every alignment as a BAM record in front of the same reader), and the independent
+    Python parser of SAM text agrees."""
+    rng = np.random.default_rng(2024)
+    for trial in range(3):
+        recs = _random_records(rng, 400)
+        for r in recs:  # names that are unique per template keep the reference's asserts out of this test
+            pass
+        bam, sam, samz = str(tmp_path / "a.bam"), str(tmp_path / "a.sam"), str(tmp_path / "a.sam.gz")
+        W.write_bam(bam, REFS, recs)
+        W.write_sam(sam, REFS, recs)
+        W.write_sam(samz, REFS, recs, bgzf=True, block=3000)
+        try:
+            want = c_blocks(bam)
+        except BscError:
+            for p in (sam, samz):
+                with pytest.raises(BscError):
+                    c_blocks(p)
+            continue
+        assert c_blocks(sam) == want and c_blocks(samz) == want
+        with BamReader(sam) as r1, BamReader(bam) as r2:
+            assert r1.refs == r2.refs == REFS and r1.header_text == r2.header_text
+        text, refs, precs = py_bam.parse_sam(sam)
+        st = {"cts": [0] * 15, "bases": [0] * 15}
+        pyb = [(tid, y, len(als)) for tid, y, als in py_bam.read_input(precs, stats=st)]
+        assert pyb == [(tid, y, len(ts)) for tid, y, ts in want[0]] and st["cts"] == want[1]
+    # odd but legal text: lower-case bases, '*' qualities, a tag of every kind, no trailing newline, CR LF
+    p = str(tmp_path / "odd.sam")
+    open(p, "w").write("@HD\tVN:1.6\r\n@SQ\tSN:chr1\tLN:100000\r\n@CO\tfree text\r\n"
+                       "r1\t0\tchr1\t101\t60\t2S8M\t*\t0\t0\tacgtnACGTN\t*\tNM:i:3\tXB:A:G\tXX:f:1.5\tYY:Z:hello\tZZ:B:i,1,2,3\tHH:H:1AE3")
+    blocks, cts, _ = c_blocks(p)
+    t = blocks[0][2][0]
+    assert t["bs_strand"] == 2 and t["pos"] == [101, 0] and t["misms"][0] == [[3, 0, 2]]
+    assert t["reads"][0] == [b("A", 43), b("C", 43), b("G", 43), b("T", 43), 0, b("A", 43), b("C", 43), b("G", 43), b("T", 43), 0]
+    with BamReader(p) as r:
+        assert r.refs == [("chr1", 100000)] and r.header_text.count("\n") == 3
+    open(p, "w").write("not a sam file at all")
+    with pytest.raises(BscError):
+        BamReader(p)

@@ -76,6 +76,54 @@ def write_bam(path, refs, records, text=None, block=0xFF00):
         f.write(BGZF_EOF)
 
 
+def aux_text(aux: bytes) -> str:
+    """The optional fields of encode_record's `aux` bytes (A / i / Z tags, as the aux_* helpers make them) as SAM text."""
+    out, o = [], 0
+    while o + 3 <= len(aux):
+        tag, ty = aux[o : o + 2].decode(), chr(aux[o + 2])
+        o += 3
+        if ty == "A":
+            out.append("%s:A:%s" % (tag, chr(aux[o])))
+            o += 1
+        elif ty == "i":
+            out.append("%s:i:%d" % (tag, struct.unpack_from("<i", aux, o)[0]))
+            o += 4
+        elif ty == "Z":
+            e = aux.index(b"\0", o)
+            out.append("%s:Z:%s" % (tag, aux[o:e].decode()))
+            o = e + 1
+        else:
+            raise ValueError("aux_text: type %r not handled" % ty)
+    return "\t".join(out)
+
+
+def write_sam(path, refs, records, text=None, bgzf=False, block=0xFF00):
+    """The same records as SAM text (plain, or in BGZF blocks like `samtools view -h | bgzip`)."""
+    if text is None:
+        text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    lines = [text]
+    for r in records:
+        name = lambda t: "*" if t < 0 else refs[t][0]
+        mt = r.get("mtid", -1)
+        rnext = "=" if (mt >= 0 and mt == r.get("tid", -1)) else name(mt)
+        cig = "".join("%d%s" % (n, op) for op, n in r.get("cigar", [])) or "*"
+        qual = r.get("qual")
+        seq = r.get("seq", "") or "*"
+        q = "*" if (qual is None or not r.get("seq")) else "".join(chr(33 + v) for v in qual)
+        f = [r["name"], str(r["flag"]), name(r.get("tid", -1)), str(r.get("pos", -1) + 1), str(r.get("mapq", 0)), cig, rnext, str(r.get("mpos", -1) + 1),
+             str(r.get("tlen", 0)), seq, q]
+        a = aux_text(r.get("aux", b""))
+        lines.append("\t".join(f) + ("\t" + a if a else "") + "\n")
+    data = "".join(lines).encode()
+    with open(path, "wb") as f:
+        if not bgzf:
+            f.write(data)
+            return
+        for o in range(0, len(data), block):
+            f.write(bgzf_block(data[o : o + block]))
+        f.write(BGZF_EOF)
+
+
 def wgbs_records(rng, ref_codes, tid, n_pairs, read_len=100, insert=300, strand_tag="XB", meth_cpg=0.8, conv=120 / 128, err=0.005, het_every=1000):
     """Paired WGBS alignments over one contig (ref_codes: 1..4 = ACGT, 0 = N; position 1 first), coordinate-sorted: the read
     generator of SURVEY.md 8(d) (level L-reads) as BAM records.  The forward read is read 1 on a FORWARD template."""
