@@ -133,7 +133,8 @@ class ReadProfile(C.Structure):
 
 class ReaderParams(C.Structure):
     _fields_ = [("mapq_thresh", C.c_uint32), ("max_template_len", C.c_uint64), ("keep_unmatched", C.c_int32),
-                ("ignore_duplicates", C.c_int32), ("keep_duplicates", C.c_int32)]
+                ("ignore_duplicates", C.c_int32), ("keep_duplicates", C.c_int32), ("region_tid", C.c_int32), ("region_start", C.c_uint32),
+                ("region_stop", C.c_uint32)]
 
 
 class ReadBlock(C.Structure):

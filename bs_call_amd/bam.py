@@ -11,13 +11,16 @@ from .caller import _check
 
 class BamReader:
     def __init__(self, path, mapq_thresh=20, max_template_len=1000, keep_unmatched=False, ignore_duplicates=False, keep_duplicates=False,
-                 threads=0):
-        """threads: helper threads that inflate the BGZF blocks ahead of the parser (0 = the caller's thread does it)."""
+                 threads=0, region=None):
+        """threads: helper threads that inflate the BGZF blocks ahead of the parser (0 = the caller's thread does it).
+        region: (tid, start, stop), 1-based inclusive: only the alignments overlapping it are read (the reference's -r)."""
         self._L = _lib.load()
         h = C.c_void_p()
         _check(self._L.bsc_bam_open_threads(str(path).encode(), int(threads), C.byref(h)))
         self._h = h
-        self._par = _lib.ReaderParams(mapq_thresh, max_template_len, int(keep_unmatched), int(ignore_duplicates), int(keep_duplicates))
+        reg = region or (0, 0, 0)
+        self._par = _lib.ReaderParams(mapq_thresh, max_template_len, int(keep_unmatched), int(ignore_duplicates), int(keep_duplicates),
+                                      int(reg[0]), int(reg[1]), int(reg[2]))
 
     def close(self):
         if self._h:

@@ -15,8 +15,9 @@
  * SAM text (plain or BGZF-compressed) is read through the same code: every alignment line is re-encoded as a BAM record
  * (SAM specification sections 1.4 and 4.2) in front of the record decoder.
  *
- * Not covered: CRAM input, region queries through a .bai index (the reference's -r), contig include / exclude lists
- * (every @SQ contig is processed).  The block a call returns stays valid until the next call.
+ * A region (the reference's -r) is served by scanning: bsc_reader_params.region_* keeps the alignments an index query would
+ * return.  Not covered: CRAM input, the .bai index itself (no seeking), contig include / exclude lists (every @SQ contig is
+ * processed).  The block a call returns stays valid until the next call.
  *
  * htslib is an un-vendored dependency of the reference; what this file needs from it is the BAM / BGZF layout, which the
  * SAM specification fixes.  Parity of the template stream is pinned by hand-worked scenarios and an independent Python
@@ -922,6 +923,18 @@ static int next_record(bsc_bam *b, const bsc_reader_params *par, bam_rec *r, int
   r->aux = r->qual + l_seq;
   r->end = p + bs;
   r->l_seq = l_seq;
+  if (par->region_stop) { /* an index query hands over the records that overlap the region: the others do not exist for the reader */
+    uint32_t reflen = 0;
+    for (uint32_t i = 0; i < n_cigar; i++) {
+      uint32_t c;
+      memcpy(&c, r->cigar + 4 * i, 4);
+      const uint32_t op = c & 15u;
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += c >> 4; /* M D N = X consume the reference */
+    }
+    const int64_t beg = (int64_t)par->region_start - 1, end = par->region_stop;
+    const int64_t rend = (int64_t)pos + (reflen ? reflen : 1);
+    if (tid != par->region_tid || pos >= end || rend <= beg) return 2;
+  }
   int flt = FLT_NONE;
   if ((flag & F_PAIRED) && !par->keep_unmatched) {
     if ((flag & (F_PROPER | F_UNMAP | F_MUNMAP | F_QCFAIL | F_SECONDARY | F_SUPP | F_DUP)) != F_PROPER) {
@@ -1074,6 +1087,7 @@ int bsc_bam_next_block(bsc_bam *b, const bsc_reader_params *par, bsc_read_block 
       swap_blocks(b);
       goto hand_out;
     }
+    if (ret == 2) continue; /* outside the region */
     if (ret > 0) {
       count_filter(b, filtered, 1, r.l_seq);
       continue;

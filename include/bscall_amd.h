@@ -497,13 +497,19 @@ int bsc_block_reference(const uint8_t *codes, uint64_t contig_len, uint32_t x, u
  *                       gt_filter_reason order, [14] = "PairNotFound" ([0], the passed reads, is counted by
  *                       bsc_prepare_templates: bsc_prep_stats.reads / read_bases)
  * SAM text (plain or BGZF-compressed) is accepted as well: the kind is found out from the first bytes.
- * Not covered: CRAM input, region queries through an index, contig include / exclude lists.
+ * Not covered: CRAM input, seeking through a .bai index (a region is served by scanning), contig include / exclude lists.
  */
 typedef struct bsc_bam bsc_bam;
 typedef struct {
   uint32_t mapq_thresh;       /* sr_param.mapq_thresh (20) */
   uint64_t max_template_len;  /* sr_param.max_template_len (1000) */
   int32_t keep_unmatched, ignore_duplicates, keep_duplicates; /* -u / -d / -k */
+  /* One region (the reference's -r contig:start-stop, region_t): only the alignments that overlap positions
+   * region_start .. region_stop (1-based, inclusive) of contig region_tid reach the reader, as with the reference's index
+   * query sam_itr_queryi(idx, tid, start - 1, stop) (src/get_template_vector.c:69-74) — found here by scanning, no index.
+   * region_stop = 0: no region.  Pass the same bounds to the record formation (bsc_vcf_params.reg_start / reg_stop). */
+  int32_t region_tid;
+  uint32_t region_start, region_stop;
 } bsc_reader_params;
 typedef struct {
   int32_t tid;  /* index of the contig in the BAM header */

@@ -116,7 +116,7 @@ int main(int argc, char **argv) {
   write_header(out, bam, sample);
   bsc_bcf_ids ids;
   bsc_bcf_default_ids(&ids);
-  const bsc_reader_params rpar = {20, 1000, 0, 0, 0};
+  const bsc_reader_params rpar = {20, 1000, 0, 0, 0, 0, 0, 0}; /* defaults of the reference; no region */
   const bsc_prep_params ppar = {{0, 0}, {0, 0}, 20};
 
   const int n_ref = bsc_bam_n_refs(bam);

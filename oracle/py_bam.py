@@ -274,6 +274,17 @@ def get_al_qual(al):
     return py_prep.get_al_qual(al)
 
 
+def region_query(recs, tid, start, stop):
+    """What sam_itr_queryi(idx, tid, start - 1, stop) iterates over (src/get_template_vector.c:69-74): the records of `tid` that
+    overlap [start - 1, stop) — an alignment without reference-consuming operations counts as one base long."""
+    out = []
+    for b in recs:
+        reflen = sum(ln for op, ln in b["cigar"] if op in (0, 2, 3, 7, 8))
+        if b["tid"] == tid and b["pos"] < stop and b["pos"] + (reflen or 1) > start - 1:
+            out.append(b)
+    return out
+
+
 def read_input(recs, mapq_thresh=20, max_template_len=1000, keep_unmatched=False, ignore_duplicates=False, keep_duplicates=False,
                stats=None):
     """Generator of (tid, y, [templates]) — the blocks read_input queues for the process thread."""

@@ -28,9 +28,9 @@ def rec(name, flag, pos, mpos, seq="ACGTACGTAC", cigar=None, mapq=60, tid=0, mti
 THREADS = [0]  # test_threaded_reader re-runs the comparisons with helper threads
 
 
-def c_blocks(path, **kw):
+def c_blocks(path, region=None, **kw):
     out = []
-    with BamReader(path, threads=THREADS[0], **kw) as r:
+    with BamReader(path, threads=THREADS[0], region=region, **kw) as r:
         for tid, y, tpl, seq, ms in r.blocks():
             ts = []
             for t in tpl:
@@ -48,8 +48,10 @@ def c_blocks(path, **kw):
     return out, cts, bases
 
 
-def py_blocks(path, **kw):
+def py_blocks(path, region=None, **kw):
     text, refs, recs = py_bam.parse_bam(path)
+    if region:
+        recs = py_bam.region_query(recs, *region)
     st = {"cts": [0] * 15, "bases": [0] * 15}
     out = []
     for tid, y, als in py_bam.read_input(recs, stats=st, **kw):
@@ -348,3 +350,34 @@ def test_sam_text_input(tmp_path):
     open(p, "w").write("not a sam file at all")
     with pytest.raises(BscError):
         BamReader(p)
+
+
+def test_region(tmp_path):
+    """One region (-r contig:start-stop): the reader sees exactly the alignments an index query would hand it — those of the
+    contig that overlap the interval, a read ending AT start - 1 or starting AT stop + 1 excluded, deletions counted in the
+    extent — and nothing else is counted in the filter statistics."""
+    recs = [rec("a", 0, 89, -1), rec("b", 0, 90, -1), rec("c", 0, 95, -1, cigar=[("M", 3), ("D", 20), ("M", 7)]), rec("d", 0, 200, -1),
+            rec("e", 0, 201, -1), rec("f", 512, 150, -1), rec("g", 0, 150, -1, tid=1)]
+    p = str(tmp_path / "r.bam")
+    W.write_bam(p, REFS, sorted(recs, key=lambda r: (r["tid"], r["pos"])))
+    # region chr1:101-201: a covers 90..99 (out), b covers 91..100 (out: ends at start - 1), c covers 96..125 (in), d 201..210 (in),
+    # e 202.. (out), f is inside and filtered (QC flag): counted
+    blocks, cts, _ = c_blocks(p, region=(0, 101, 201))
+    assert [[t["pos"][0] for t in ts] for _, _, ts in blocks] == [[96], [201]] and cts[2] == 1 and sum(cts) == 1
+    assert (blocks, cts) == py_blocks(p, region=(0, 101, 201))[:2]
+    rng = np.random.default_rng(77)
+    n_cmp = 0
+    for trial in range(6):
+        rr = _random_records(rng, 500)
+        W.write_bam(p, REFS, rr)
+        reg = (int(rng.integers(0, 2)), int(rng.integers(1, 2500)), 0)
+        reg = (reg[0], reg[1], reg[1] + int(rng.integers(1, 1500)))
+        try:
+            want = py_blocks(p, region=reg)
+        except AssertionError:
+            with pytest.raises(BscError):
+                c_blocks(p, region=reg)
+            continue
+        assert c_blocks(p, region=reg) == want
+        n_cmp += 1
+    assert n_cmp >= 3
