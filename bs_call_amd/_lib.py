@@ -19,6 +19,9 @@ EXPORTS = (
     "bsc_free_host",
     "bsc_call_sites_device",
     "bsc_accumulate",
+    "bsc_accumulate_device",
+    "bsc_block_status",
+    "bsc_last_accumulate_ms",
     "bsc_call_block",
     "bsc_block_submit",
     "bsc_block_fetch",
@@ -35,6 +38,8 @@ EXPORTS = (
     "bsc_get_site_stats",
     "bsc_reset_site_stats",
     "bsc_chain_device",
+    "bsc_reads_chain_device",
+    "bsc_last_reads_chain_ms",
     "bsc_last_chain_ms",
     "bsc_get_site_totals",
     "bsc_gc_bins",
@@ -220,6 +225,12 @@ def load():
     L.bsc_call_sites_device.argtypes = [vp, vp, vp, u64, vp, u32, vp, vp]
     L.bsc_accumulate.restype = i32
     L.bsc_accumulate.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp]
+    L.bsc_accumulate_device.restype = i32
+    L.bsc_accumulate_device.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp]
+    L.bsc_block_status.restype = i32
+    L.bsc_block_status.argtypes = [vp, vp]
+    L.bsc_last_accumulate_ms.restype = i32
+    L.bsc_last_accumulate_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsc_call_block.restype = i32
     L.bsc_call_block.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, u32, vp]
     L.bsc_block_submit.restype = i32
@@ -238,6 +249,10 @@ def load():
     L.bsc_vcf_format.argtypes = [vp, vp, C.c_char_p, C.c_char_p, vp, C.c_size_t]
     L.bsc_chain_device.restype = i32
     L.bsc_chain_device.argtypes = [vp, vp, vp, vp, C.POINTER(Window), C.POINTER(VcfParams), i32, vp, vp]
+    L.bsc_reads_chain_device.restype = i32
+    L.bsc_reads_chain_device.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, C.POINTER(VcfParams), i32, vp, vp, vp]
+    L.bsc_last_reads_chain_ms.restype = i32
+    L.bsc_last_reads_chain_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsc_gc_bins.restype = i32
     L.bsc_gc_bins.argtypes = [vp, u64, C.POINTER(u32), vp, u64, C.POINTER(u64)]
     L.bsc_set_gc_bins.restype = i32

@@ -114,6 +114,19 @@ class SiteCaller:
         _check(self._L.bsc_accumulate(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(out)))
         return out[: max(int(y) - int(x) + 1, 0)]
 
+    def accumulate_device(self, d_tpl, nr, d_seq, seq_bytes, x, y, d_cts, stream=None):
+        """HOT LOOP A on device-resident reads (raw device pointers); asynchronous — block_status() collects the verdict."""
+        _check(self._L.bsc_accumulate_device(self._h, d_tpl, nr, d_seq, seq_bytes, x, y, d_cts, stream))
+
+    def block_status(self, stream=None):
+        """Wait for `stream` and raise / warn as the block queued last deserves (invalid template, inexact sums)."""
+        _check(self._L.bsc_block_status(self._h, stream))
+
+    def last_accumulate_ms(self):
+        ms = C.c_float()
+        _check(self._L.bsc_last_accumulate_ms(self._h, C.byref(ms)))
+        return ms.value
+
     def call_block(self, templates, seq, x, y, ref, out_stride=200, out=None, skip=None):
         """One call_genotypes_ML block: accumulate + call.  ref: uint8[y-x+1] codes -> (GT_METH[..], skip)."""
         templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
@@ -205,6 +218,19 @@ class SiteCaller:
         p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
         _check(self._L.bsc_chain_device(self._h, d_cts, d_ref, d_dbsnp, C.byref(w), C.byref(p), 1 if with_stats else 0,
                                         d_core, stream))
+
+    def reads_chain_device(self, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, d_aux=None, all_positions=False, reg_start=1,
+                           reg_stop=0xFFFFFFFF, d_dbsnp=None, with_stats=False, stream=None):
+        """One block, reads in / records out in the chain's single pass (bsc_reads_chain_device): device-resident
+        TEMPLATE[nr] + read bytes, d_ref = codes of x .. y + 2 -> d_core (VCF_CORE per position) [+ d_aux, 64 B per position]."""
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        _check(self._L.bsc_reads_chain_device(self._h, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_dbsnp, C.byref(p),
+                                              1 if with_stats else 0, d_core, d_aux, stream))
+
+    def last_reads_chain_ms(self):
+        ms = C.c_float()
+        _check(self._L.bsc_last_reads_chain_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def window_quantum(self) -> int:
         """Positions one round of the resident waves covers (`bsc_chain_window_quantum`)."""

@@ -28,25 +28,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "accdev.h"
 #include "devtables.h"
 
 #define IN_DW 26
 #define SLOT_DW (64 * IN_DW)
 #define ACC_WAVES 4 /* waves per workgroup */
-
-/* compact read descriptor, 24 bytes; a > b: the read contributes nothing */
-struct __attribute__((aligned(8))) bsc_read_desc {
-  uint32_t a;    /* first countable position (absolute) */
-  uint32_t b;    /* last countable position (absolute, already clipped to y) */
-  int64_t base;  /* seq offset of position 0: byte of position p is seq[base + p] */
-  uint32_t meta; /* bit 5: orientation the read is counted with (= byte offset of counts[ori]), bits 8-23 mapq^2 */
-  uint32_t lut;  /* 4 * class of base codes 0..3 on the read's bisulfite strand, one byte each (LUT4 below) */
-};
-
-/* strand -> 4 * class, one byte per base code (reference base_tab_st, src/call_genotypes.c:17-19):
- * NON_CONVERTED 0 1 2 3 ; C2T 0 5 2 7 ; G2A 4 1 6 3.  Byte-indexed so that one v_perm_b32 turns a base code into
- * the byte offset of its class inside a pile-up row. */
-#define LUT4(c0, c1, c2, c3) ((uint32_t)(4 * (c0)) | ((uint32_t)(4 * (c1)) << 8) | ((uint32_t)(4 * (c2)) << 16) | ((uint32_t)(4 * (c3)) << 24))
 
 /* bsc_template (include/bscall_amd.h) as the kernels read it */
 struct bsc_template_dev {
@@ -172,14 +159,16 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
     atomicMax(&counters[BSC_CNT_SPAN], (unsigned long long)span_max);
 }
 
+/* Tile wt starts at block-relative position base + wt * step (below 0: at the block start): step 64, base 0 for the
+ * stand-alone accumulate kernel; step 60, base = window start - 2 for the reads-in chain (fused.hip). */
 extern "C" __global__ __launch_bounds__(256) void bsc_tile_lo_kernel(const uint32_t *__restrict__ keys_sorted,
-                                                                     uint32_t n_reads, uint32_t n_wt,
+                                                                     uint32_t n_reads, uint32_t n_wt, int64_t base, uint32_t step,
                                                                      const unsigned long long *__restrict__ counters,
                                                                      uint32_t *__restrict__ tile_lo) {
-  const uint32_t span = (uint32_t)counters[BSC_CNT_SPAN]; /* longest read extent, b - a */
+  const int64_t span = (int64_t)(uint32_t)counters[BSC_CNT_SPAN]; /* longest read extent, b - a */
   for (uint32_t wt = blockIdx.x * blockDim.x + threadIdx.x; wt < n_wt; wt += gridDim.x * blockDim.x) {
-    const uint32_t r0 = wt * 64u;                       /* the tile's first position, relative to the block start */
-    const uint32_t key = r0 > span ? r0 - span : 0u;    /* first read that can still reach it */
+    const int64_t r0 = base + (int64_t)wt * step;       /* the tile's first position, relative to the block start */
+    const uint32_t key = r0 > span ? (uint32_t)(r0 - span) : 0u; /* first read that can still reach it */
     uint32_t lo = 0, hi = n_reads;
     while (lo < hi) {
       const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -189,9 +178,6 @@ extern "C" __global__ __launch_bounds__(256) void bsc_tile_lo_kernel(const uint3
     tile_lo[wt] = lo;
   }
 }
-
-/* a pointer the compiler knows to be global memory (a plain pointer rebuilt from two registers would be flat) */
-typedef const __attribute__((address_space(1))) uint8_t *global_bytes;
 
 /*
  * The kernel is instruction-issue bound (profiles/: VALU and scalar units each busy ~2/3 of the time, memory and LDS
@@ -214,21 +200,7 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
   /* q counts iff min_qual <= q < 63 (:217)  <=>  (q - min_qual) <u q_span */
   const uint32_t q_span = min_qual < 63u ? 63u - min_qual : 0u;
   unsigned inexact = 0;
-  /* 64 candidate reads per batch: lane i gets the sort key (first countable position relative to x) and the
-   * descriptor of the read that comes (tb + i)-th in position order */
-  auto fetch = [&](uint32_t tb, uint32_t &kv, bsc_read_desc &e) {
-    const uint32_t t = tb + lane;
-    kv = 0xffffffffu;
-    e.a = 1;
-    e.b = 0;
-    e.base = 0;
-    e.meta = 0;
-    e.lut = 0;
-    if (t < n_reads) {
-      kv = keys_sorted[t];
-      e = rd[perm[t]];
-    }
-  };
+  auto fetch = [&](uint32_t tb, uint32_t &kv, bsc_read_desc &e) { acc_fetch(rd, keys_sorted, perm, n_reads, tb, lane, kv, e); };
   /* Software pipeline over the wave's tiles: while tile i is processed, the first batch of tile i+1 and the start
    * index of tile i+2 are on their way, so the tile_lo -> key / index -> descriptor chain of dependent loads is off the
    * critical path. */
@@ -265,74 +237,7 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
     if (have2) t0_nn = tile_lo[wt2];
 #pragma unroll
     for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
-    uint32_t m2sum = 0; /* mapq2 of this lane's position */
-
-    bool more = true;
-    while (more) {
-      const bool cand = kv <= r_last; /* reads are in key order: the candidates are a prefix of the batch */
-      more = __all(cand);
-      {
-        /* reads that overlap the tile at all (a read past the candidates starts right of the tile: a > p_last) */
-        unsigned long long m = __ballot(d.b >= d.a && d.b >= p0 && d.a <= p_last);
-        /* per descriptor lane: the read's part of the tile as lane numbers lo .. lo + len (0 <= lo, lo + len <= 63;
-         * meaningless where the read does not overlap, never used there), and the address of the byte of lane lo */
-        const uint32_t lo = (d.a > p0 ? d.a : p0) - p0;
-        const uint32_t lolen = lo | (((d.b < p_last ? d.b : p_last) - p0 - lo) << 8);
-        const uint64_t sp = (uint64_t)(uintptr_t)seq + (uint64_t)(d.base + (int64_t)p0 + (int64_t)lo);
-        /* Groups of 4, then 2, then 1 reads: the byte loads of a group are issued back to back and consumed
-         * afterwards, so the wave waits for memory once per group.  Straight-line code per group size: slot
-         * conditions inside a group would be evaluated on the VALU. */
-        uint32_t cnt = (uint32_t)__builtin_popcountll(m);
-        uint32_t g_byte[4], g_t[4], g_len[4], g_meta[4], g_lut[4];
-#define ACC_LOAD(u)                                                                                              \
-  {                                                                                                              \
-    const int src = __builtin_ctzll(m);                                                                          \
-    m &= m - 1;                                                                                                  \
-    const uint32_t ll = (uint32_t)__builtin_amdgcn_readlane(lolen, src);                                         \
-    /* v_readlane returns int: without the casts the low word would be sign-extended into the high one */        \
-    const uint32_t sp_lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)sp, src);                               \
-    const uint32_t sp_hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(sp >> 32), src);                       \
-    const global_bytes p = (global_bytes)(uintptr_t)(((uint64_t)sp_hi << 32) | sp_lo);                           \
-    g_meta[u] = (uint32_t)__builtin_amdgcn_readlane(d.meta, src);                                                \
-    g_lut[u] = (uint32_t)__builtin_amdgcn_readlane(d.lut, src);                                                  \
-    g_len[u] = ll >> 8;                                                                                          \
-    g_t[u] = lane - (ll & 0xffu); /* lanes below the read wrap to huge values */                                 \
-    /* lanes outside the read fetch its last byte in the tile (a valid address, same cache lines) and drop it */ \
-    g_byte[u] = p[g_t[u] < g_len[u] ? g_t[u] : g_len[u]];                                                        \
-  }
-#define ACC_UPDATE(u)                                                                                            \
-  {                                                                                                              \
-    const uint32_t byte = g_byte[u], meta = g_meta[u];                                                           \
-    const uint32_t q = byte >> 2;                                                                                \
-    if (g_t[u] <= g_len[u] && q - min_qual < q_span) {                                                           \
-      /* v_alignbyte_b32 shifts by 8 * (byte & 3): the class offset of this base arrives in the low byte */      \
-      const uint32_t c4 = __builtin_amdgcn_alignbyte(0u, g_lut[u], byte) & 0xffu;                                \
-      char *rc = reinterpret_cast<char *>(row) + c4;                                                             \
-      /* fire-and-forget ds_add_u32: the row has a single writer (this lane), no contention */                   \
-      atomicAdd(reinterpret_cast<uint32_t *>(rc + (meta & 32u)), 1u); /* counts[ori][c]++ */                     \
-      atomicAdd(reinterpret_cast<uint32_t *>(rc + 68), q); /* quality[c] += q (integer; converted below) */      \
-      m2sum = __builtin_elementwise_add_sat(m2sum, meta >> 8); /* mapq2 += mapq^2 (v_add_u32 clamp: a sum past   \
-                                                                  2^32 sticks there, so INEXACT cannot be missed) */ \
-    }                                                                                                            \
-  }
-        for (; cnt >= 4u; cnt -= 4u) {
-          ACC_LOAD(0) ACC_LOAD(1) ACC_LOAD(2) ACC_LOAD(3)
-          ACC_UPDATE(0) ACC_UPDATE(1) ACC_UPDATE(2) ACC_UPDATE(3)
-        }
-        if (cnt & 2u) {
-          ACC_LOAD(0) ACC_LOAD(1)
-          ACC_UPDATE(0) ACC_UPDATE(1)
-        }
-        if (cnt & 1u) {
-          ACC_LOAD(0)
-          ACC_UPDATE(0)
-        }
-#undef ACC_LOAD
-#undef ACC_UPDATE
-      }
-      t0 += 64u;
-      if (more) fetch(t0, kv, d); /* further batches: deep data */
-    }
+    const uint32_t m2sum = acc_walk(rd, keys_sorted, perm, n_reads, seq, lane, lane, row, p0, p_last, r_last, min_qual, q_span, t0, kv, d);
     row[25] = m2sum;
 
     /* n = sum of counts; integer sums -> float */
@@ -375,9 +280,41 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
   }
 }
 
-/* ---- launcher ------------------------------------------------------------------------------------------- */
+/* ---- launchers ------------------------------------------------------------------------------------------ */
 extern "C" int bsc_dev_sort_templates(const void *keys, void *keys_sorted, void *perm, uint32_t nr, unsigned key_bits,
                                       void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
+
+/* template checks, read descriptors and the ordering of the block's reads: rd[2 nr], keys_sorted[2 nr], perm[2 nr] */
+extern "C" int bsc_dev_launch_prep_reads(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                                         void *keys, void *keys_sorted, void *perm, void *sort_tmp, size_t sort_tmp_bytes,
+                                         void *rd, void *counters, int num_cus, void *stream) {
+  if (!nr) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t n_sites = y - x + 1;
+  const uint32_t n_reads = 2u * nr; /* nr <= 2^31 - 1 is checked by the caller */
+  unsigned g = (nr + 255u) / 256u;
+  if (g > (unsigned)num_cus * 16u) g = (unsigned)num_cus * 16u;
+  /* keys 0 .. key_max - 1: positions x .. y; key_max: a read that contributes nothing */
+  const uint32_t key_max = n_sites;
+  unsigned key_bits = 1;
+  while (key_bits < 32 && (key_max >> key_bits)) key_bits++;
+  hipLaunchKernelGGL(bsc_prep_reads_kernel, dim3(g), dim3(256), 0, s, (const bsc_template_dev *)tpl, nr, (const uint8_t *)seq,
+                     seq_bytes, x, y, key_max, (bsc_read_desc *)rd, (uint32_t *)keys, (unsigned long long *)counters);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return bsc_dev_sort_templates(keys, keys_sorted, perm, n_reads, key_bits, sort_tmp, sort_tmp_bytes, stream);
+}
+
+/* first candidate read of every tile (see bsc_tile_lo_kernel) */
+extern "C" int bsc_dev_launch_tile_lo(const void *keys_sorted, uint32_t n_reads, uint32_t n_tiles, int64_t base, uint32_t step,
+                                      const void *counters, void *tile_lo, int num_cus, void *stream) {
+  if (!n_tiles) return 0;
+  unsigned g = (n_tiles + 255u) / 256u;
+  if (g > (unsigned)num_cus * 16u) g = (unsigned)num_cus * 16u;
+  hipLaunchKernelGGL(bsc_tile_lo_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)keys_sorted, n_reads,
+                     n_tiles, base, step, (const unsigned long long *)counters, (uint32_t *)tile_lo);
+  return (int)hipGetLastError();
+}
 
 extern "C" int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x,
                                          uint32_t y, uint32_t min_qual, void *keys, void *keys_sorted, void *perm,
@@ -386,30 +323,11 @@ extern "C" int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const voi
   hipStream_t s = (hipStream_t)stream;
   const uint32_t n_sites = y - x + 1;
   const uint32_t n_wt = (n_sites + 63u) / 64u;
-  const uint32_t n_reads = 2u * nr; /* nr <= 2^31 - 1 is checked by the caller */
-  if (nr) {
-    unsigned g = (nr + 255u) / 256u;
-    if (g > (unsigned)num_cus * 16u) g = (unsigned)num_cus * 16u;
-    /* keys 0 .. key_max - 1: positions x .. y; key_max: a read that contributes nothing */
-    const uint32_t key_max = n_sites;
-    unsigned key_bits = 1;
-    while (key_bits < 32 && (key_max >> key_bits)) key_bits++;
-    hipLaunchKernelGGL(bsc_prep_reads_kernel, dim3(g), dim3(256), 0, s, (const bsc_template_dev *)tpl, nr,
-                       (const uint8_t *)seq, seq_bytes, x, y, key_max, (bsc_read_desc *)rd, (uint32_t *)keys,
-                       (unsigned long long *)counters);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    int rc = bsc_dev_sort_templates(keys, keys_sorted, perm, n_reads, key_bits, sort_tmp, sort_tmp_bytes, stream);
-    if (rc) return rc;
-  }
-  {
-    unsigned g = (n_wt + 255u) / 256u;
-    if (g > (unsigned)num_cus * 16u) g = (unsigned)num_cus * 16u;
-    hipLaunchKernelGGL(bsc_tile_lo_kernel, dim3(g), dim3(256), 0, s, (const uint32_t *)keys_sorted, n_reads, n_wt,
-                       (const unsigned long long *)counters, (uint32_t *)tile_lo);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-  }
+  const uint32_t n_reads = 2u * nr;
+  int rc = bsc_dev_launch_prep_reads(tpl, nr, seq, seq_bytes, x, y, keys, keys_sorted, perm, sort_tmp, sort_tmp_bytes, rd, counters,
+                                     num_cus, stream);
+  if (rc) return rc;
+  if ((rc = bsc_dev_launch_tile_lo(keys_sorted, n_reads, n_wt, 0, 64u, counters, tile_lo, num_cus, stream))) return rc;
   {
     unsigned g = (n_wt + ACC_WAVES - 1) / ACC_WAVES;
     const unsigned cap = (unsigned)num_cus * 6u * 8u; /* 6 workgroups of 26 KB LDS fit a CU */

@@ -523,6 +523,12 @@ static int in_read(bsc_bam *b, void *dst, size_t n) { /* 1, 0 = clean end of inp
 /* one text line (without its terminator) into b->line: 1, 0 = end of input, < 0 = error */
 static int in_getline(bsc_bam *b, size_t *len) {
   size_t n = 0;
+  if (!b->line) { /* an empty first line must still leave a (terminated) buffer behind */
+    b->line = malloc(256);
+    if (!b->line) return bsc_set_error(BSC_ERR_NOMEM, "SAM: out of memory");
+    b->line_cap = 256;
+    b->line[0] = 0;
+  }
   for (;;) {
     char c;
     int r;
@@ -587,7 +593,8 @@ static int sam_read_header(bsc_bam *b) {
       b->is_sam = 2; /* no alignment line is waiting */
       break;
     }
-    if (ll == 0 || b->line[0] != '@') {
+    if (ll == 0) continue; /* a blank line: skipped, like the ones between alignment lines */
+    if (b->line[0] != '@') {
       b->is_sam = 3; /* b->line holds the first alignment line */
       break;
     }
@@ -664,12 +671,16 @@ static long sam_encode_line(bsc_bam *b, size_t ll) {
   const int32_t tid = sam_tid(b, f[2], strlen(f[2]));
   int32_t mtid = (f[6][0] == '=' && !f[6][1]) ? tid : sam_tid(b, f[6], strlen(f[6]));
   if (tid == -2 || mtid == -2) return bsc_set_error(BSC_ERR_ARG, "SAM: reference '%s' is not in the header", tid == -2 ? f[2] : f[6]);
-  /* worst-case size: name + cigar ops + sequence + qualities + optional fields re-encoded (never longer than their text) */
+  /* worst-case size: name + cigar ops + sequence + qualities + the optional fields re-encoded.  A re-encoded field can be
+   * LONGER than its text (every element of a B array, 1-2 text bytes, becomes 4 bytes; an empty "XX:i:" becomes 7), so the
+   * bound is 8 bytes per text byte of the optional part plus slack: tag + type + count (8) per field of >= 5 text bytes
+   * and 4 bytes per remaining text byte at most. */
   const size_t l_seq = (f[9][0] == '*' && !f[9][1]) ? 0 : strlen(f[9]);
   size_t n_cig = 0;
   if (!(f[5][0] == '*' && !f[5][1]))
     for (const char *c = f[5]; *c; c++) n_cig += (*c < '0' || *c > '9');
-  const size_t need = 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq + (aux ? (ll + 16) : 0) + 64;
+  const size_t aux_len = aux ? ll - (size_t)(aux - b->line) : 0;
+  const size_t need = 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq + 8 * aux_len + 128;
   if (need > b->rec_cap) {
     uint8_t *nr = realloc(b->rec, need * 2);
     if (!nr) return bsc_set_error(BSC_ERR_NOMEM, "SAM: out of memory");
@@ -923,6 +934,18 @@ static int next_record(bsc_bam *b, const bsc_reader_params *par, bam_rec *r, int
   r->aux = r->qual + l_seq;
   r->end = p + bs;
   r->l_seq = l_seq;
+  if (l_seq && n_cigar) { /* htslib, which the reference reads through, rejects a CIGAR whose query length is not l_seq */
+    uint64_t qlen = 0;
+    for (uint32_t i = 0; i < n_cigar; i++) {
+      uint32_t c;
+      memcpy(&c, r->cigar + 4 * i, 4);
+      const uint32_t op = c & 15u;
+      if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += c >> 4; /* M I S = X consume the query */
+    }
+    if (qlen != l_seq)
+      return bsc_set_error(BSC_ERR_ARG, "read '%.*s': CIGAR covers %llu query bases, the sequence has %u", (int)l_name, r->name,
+                           (unsigned long long)qlen, l_seq), -2;
+  }
   if (par->region_stop) { /* an index query hands over the records that overlap the region: the others do not exist for the reader */
     uint32_t reflen = 0;
     for (uint32_t i = 0; i < n_cigar; i++) {

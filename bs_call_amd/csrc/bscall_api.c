@@ -49,7 +49,13 @@ int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const
                        void *out, int num_cus, void *stream);
 int bsc_dev_launch_chain(const bsc_chain_launch *L); /* fused.hip */
 unsigned bsc_dev_chain_quantum(int num_cus);
-size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth);
+size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth, int reads);
+size_t bsc_dev_chain_scratch_bytes(int num_cus);
+int bsc_dev_launch_prep_reads(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y, void *keys,
+                              void *keys_sorted, void *perm, void *sort_tmp, size_t sort_tmp_bytes, void *rd, void *counters,
+                              int num_cus, void *stream); /* accumulate.hip */
+int bsc_dev_launch_tile_lo(const void *keys_sorted, uint32_t n_reads, uint32_t n_tiles, int64_t base, uint32_t step,
+                           const void *counters, void *tile_lo, int num_cus, void *stream);
 int bsc_dev_launch_synth(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags, void *cts,
                          void *ref, int num_cus, void *stream);
 
@@ -105,8 +111,15 @@ struct bsc_context {
   int pending_copied;       /* bsc_block_submit_to: the copy-out is already queued behind the kernels */
   /* the block whose accumulate kernels were queued last (bsc_block_check reads their verdict): host copies of its
    * inputs — the caller's buffers, or the staging area for a submitted block */
-  const bsc_template *blk_tpl;
+  const bsc_template *blk_tpl; /* NULL: the templates are only on the device (bsc_accumulate_device), at blk_d_tpl */
+  const void *blk_d_tpl;
   uint32_t blk_x;
+  void *d_fscr; /* reads-in chain: forward-count scratch lines of the resident waves */
+  size_t cap_fscr;
+  hipEvent_t ev_rchain[2]; /* bsc_set_profiling: the reads-in chain's launches (read descriptors, ordering, tile search, chain) */
+  int ev_rchain_valid;
+  hipEvent_t ev_acc[2]; /* bsc_set_profiling: the accumulate stage's launches (prep, ordering, tile search, accumulate) */
+  int ev_acc_valid;
   /* host-buffer pipeline of bsc_call_sites: two chunk buffers, copy streams, events */
   hipStream_t s_in, s_out;
   hipEvent_t ev_in[2], ev_k[2], ev_out[2];
@@ -294,6 +307,11 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_gc_own);
   for (int i = 0; i < 2; i++)
     if (ctx->ev_chain[i]) hipEventDestroy(ctx->ev_chain[i]);
+  for (int i = 0; i < 2; i++)
+    if (ctx->ev_acc[i]) hipEventDestroy(ctx->ev_acc[i]);
+  for (int i = 0; i < 2; i++)
+    if (ctx->ev_rchain[i]) hipEventDestroy(ctx->ev_rchain[i]);
+  hipFree(ctx->d_fscr);
   hipFree(ctx->d_tpl);
   hipFree(ctx->d_seq);
   hipFree(ctx->d_rd);
@@ -503,6 +521,48 @@ static int bsc_accumulate_queue(bsc_context *ctx, const bsc_template *tpl, uint3
   return bsc_accumulate_queue2(ctx, tpl, nr, seq, seq_bytes, x, y, NULL, 0);
 }
 
+/* Workspaces of the accumulate stage for a block of nr templates over positions x .. y (grow-only). */
+static int bsc_accumulate_reserve(bsc_context *ctx, uint32_t nr, uint32_t x, uint32_t y, size_t *sort_bytes) {
+  const uint64_t sz = (uint64_t)y - x + 1;
+  const uint64_t n_wt = (sz + 63) / 64;
+  int rc;
+  *sort_bytes = 0;
+  if ((rc = bsc_reserve(&ctx->d_lo, &ctx->cap_lo, (size_t)n_wt * 4u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_rd, &ctx->cap_rd, (size_t)(nr ? nr : 1) * 48u))) return rc;
+  if (nr) { /* the device orders the block's READS: two entries per template */
+    if (nr > 0x7fffffffu) return bsc_fail(BSC_ERR_ARG, "accumulate: more than 2^31 - 1 templates in one block");
+    if (bsc_dev_sort_tmp_bytes(2u * nr, sort_bytes)) return bsc_fail(BSC_ERR_HIP, "accumulate: sort size query failed");
+    if ((rc = bsc_reserve(&ctx->d_keys, &ctx->cap_keys, (size_t)nr * 8u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_keys_s, &ctx->cap_keys_s, (size_t)nr * 8u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_perm, &ctx->cap_perm, (size_t)nr * 8u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_sorttmp, &ctx->cap_sorttmp, *sort_bytes ? *sort_bytes : 1))) return rc;
+  }
+  return BSC_OK;
+}
+
+/* Queues the accumulate kernels over device-resident templates and read bytes on stream s: pile-up of x .. y -> d_cts
+ * ((y - x + 1 rounded up to whole 64-position tiles) x 104 bytes). */
+static int bsc_accumulate_launch(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes,
+                                 uint32_t x, uint32_t y, void *d_cts, size_t sort_bytes, hipStream_t s) {
+  /* SPAN, INEXACT = 0; ERR = all ones (the kernel takes the minimum) */
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), s));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), s));
+  if (ctx->profiling) {
+    if (!ctx->ev_acc[0])
+      for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&ctx->ev_acc[i]));
+    HIP_TRY(hipEventRecord(ctx->ev_acc[0], s));
+  }
+  int e = bsc_dev_launch_accumulate(d_tpl, nr, d_seq, seq_bytes, x, y, (uint32_t)ctx->params.min_qual, ctx->d_keys,
+                                    ctx->d_keys_s, ctx->d_perm, ctx->d_sorttmp, sort_bytes, ctx->d_rd, ctx->d_lo, d_cts,
+                                    ctx->d_counters, ctx->num_cus, s);
+  if (e) return bsc_fail(BSC_ERR_HIP, "accumulate launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (ctx->profiling) {
+    HIP_TRY(hipEventRecord(ctx->ev_acc[1], s));
+    ctx->ev_acc_valid = 1;
+  }
+  return BSC_OK;
+}
+
 static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq,
                                  uint64_t seq_bytes, uint32_t x, uint32_t y, const uint8_t *ref, int stage) {
   if (y < x) return bsc_fail(BSC_ERR_ARG, "accumulate: y (%u) < x (%u) (reference asserts y >= x)", y, x);
@@ -514,20 +574,11 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
   const uint64_t sz = (uint64_t)y - x + 1;
   const uint64_t n_wt = (sz + 63) / 64;
   int rc;
-  if ((rc = bsc_reserve(&ctx->d_cts, &ctx->cap_cts, (size_t)n_wt * 64u * 104u))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_lo, &ctx->cap_lo, (size_t)n_wt * 4u))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_rd, &ctx->cap_rd, (size_t)(nr ? nr : 1) * 48u))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
   size_t sort_bytes = 0;
-  if (nr) { /* the device orders the block's READS: two entries per template */
-    if (nr > 0x7fffffffu) return bsc_fail(BSC_ERR_ARG, "accumulate: more than 2^31 - 1 templates in one block");
-    if (bsc_dev_sort_tmp_bytes(2u * nr, &sort_bytes)) return bsc_fail(BSC_ERR_HIP, "accumulate: sort size query failed");
-    if ((rc = bsc_reserve(&ctx->d_keys, &ctx->cap_keys, (size_t)nr * 8u))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_keys_s, &ctx->cap_keys_s, (size_t)nr * 8u))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_perm, &ctx->cap_perm, (size_t)nr * 8u))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_sorttmp, &ctx->cap_sorttmp, sort_bytes ? sort_bytes : 1))) return rc;
-  }
+  if ((rc = bsc_reserve(&ctx->d_cts, &ctx->cap_cts, (size_t)n_wt * 64u * 104u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
+  if ((rc = bsc_accumulate_reserve(ctx, nr, x, y, &sort_bytes))) return rc;
   if (stage) {
     /* the previous block's copies out of the staging area have completed: bsc_block_fetch synchronised the stream */
     const size_t b_tpl = (size_t)nr * sizeof(bsc_template), b_seq = (size_t)seq_bytes, b_ref = ref ? (size_t)sz : 0;
@@ -547,19 +598,13 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
     }
   }
   ctx->blk_tpl = tpl;
+  ctx->blk_d_tpl = ctx->d_tpl;
   ctx->blk_x = x;
   if (nr) {
     HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, ctx->stream));
   }
-  /* SPAN, INEXACT = 0; ERR = all ones (the kernel takes the minimum) */
-  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), ctx->stream));
-  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), ctx->stream));
-  int e = bsc_dev_launch_accumulate(ctx->d_tpl, nr, ctx->d_seq, seq_bytes, x, y, (uint32_t)ctx->params.min_qual,
-                                    ctx->d_keys, ctx->d_keys_s, ctx->d_perm, ctx->d_sorttmp, sort_bytes, ctx->d_rd,
-                                    ctx->d_lo, ctx->d_cts, ctx->d_counters, ctx->num_cus, ctx->stream);
-  if (e) return bsc_fail(BSC_ERR_HIP, "accumulate launch failed: %s", hipGetErrorString((hipError_t)e));
-  return BSC_OK;
+  return bsc_accumulate_launch(ctx, ctx->d_tpl, nr, ctx->d_seq, seq_bytes, x, y, ctx->d_cts, sort_bytes, ctx->stream);
 }
 
 /*
@@ -567,13 +612,25 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
  * BSC_ERR_ARG naming the first one and the reference assert it breaks; *inexact -> positions whose float sums left the
  * exact range (BSC_WARN_INEXACT for the caller).
  */
-static int bsc_block_check(bsc_context *ctx, int *inexact) {
+static int bsc_verdict(bsc_context *ctx, const unsigned long long f[2], int *inexact);
+
+static int bsc_block_check_on(bsc_context *ctx, hipStream_t s, int *inexact) {
   unsigned long long f[2]; /* INEXACT, ERR */
-  HIP_TRY(hipMemcpyAsync(f, ctx->d_counters + BSC_CNT_INEXACT, sizeof f, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpyAsync(f, ctx->d_counters + BSC_CNT_INEXACT, sizeof f, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return bsc_verdict(ctx, f, inexact);
+}
+
+static int bsc_block_check(bsc_context *ctx, int *inexact) { return bsc_block_check_on(ctx, ctx->stream, inexact); }
+
+/* f = {INEXACT, ERR} as read from the device counters after the block's prep kernel has run */
+static int bsc_verdict(bsc_context *ctx, const unsigned long long f[2], int *inexact) {
   if (f[1] != ~0ull) {
     const uint32_t i = (uint32_t)(f[1] >> 8);
-    const bsc_template *t = ctx->blk_tpl + i;
+    bsc_template dt;
+    const bsc_template *t = &dt;
+    if (ctx->blk_tpl) t = ctx->blk_tpl + i;
+    else HIP_TRY(hipMemcpy(&dt, (const char *)ctx->blk_d_tpl + (size_t)i * sizeof(bsc_template), sizeof dt, hipMemcpyDeviceToHost));
     switch ((int)(f[1] & 0xffu)) {
       case BSC_TERR_LEFT:
         return bsc_fail(BSC_ERR_ARG, "accumulate: template %u starts at %u, left of the block start %u", i,
@@ -610,6 +667,42 @@ int bsc_accumulate(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
   HIP_TRY(hipMemcpyAsync(out, ctx->d_cts, (size_t)sz * 104u, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return bsc_inexact_status(inexact);
+}
+
+/* HOT LOOP A on device-resident reads: asynchronous on `stream`; bsc_block_status() collects the verdict. */
+int bsc_accumulate_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes, uint32_t x,
+                          uint32_t y, void *d_cts, void *stream) {
+  if (!ctx || !d_cts) return bsc_fail(BSC_ERR_ARG, "bsc_accumulate_device: NULL argument");
+  if (y < x) return bsc_fail(BSC_ERR_ARG, "accumulate: y (%u) < x (%u) (reference asserts y >= x)", y, x);
+  if (nr && (!d_tpl || !d_seq)) return bsc_fail(BSC_ERR_ARG, "accumulate: NULL template or read buffer");
+  if (((uintptr_t)d_cts & 15u) || ((uintptr_t)d_tpl & 7u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_accumulate_device: d_cts must be 16-byte and d_tpl 8-byte aligned");
+  BSC_ENTER(ctx);
+  size_t sort_bytes = 0;
+  int rc = bsc_accumulate_reserve(ctx, nr, x, y, &sort_bytes);
+  if (rc) return rc;
+  ctx->blk_tpl = NULL;
+  ctx->blk_d_tpl = d_tpl;
+  ctx->blk_x = x;
+  return bsc_accumulate_launch(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, d_cts, sort_bytes, (hipStream_t)stream);
+}
+
+int bsc_block_status(bsc_context *ctx, void *stream) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_block_status: ctx is NULL");
+  BSC_ENTER(ctx);
+  int inexact = 0;
+  int rc = bsc_block_check_on(ctx, (hipStream_t)stream, &inexact);
+  if (rc) return rc;
+  return bsc_inexact_status(inexact);
+}
+
+int bsc_last_accumulate_ms(bsc_context *ctx, float *ms) {
+  if (!ctx || !ms) return bsc_fail(BSC_ERR_ARG, "bsc_last_accumulate_ms: NULL argument");
+  if (!ctx->profiling || !ctx->ev_acc_valid) return bsc_fail(BSC_ERR_ARG, "bsc_last_accumulate_ms: no profiled launch yet");
+  BSC_ENTER(ctx);
+  HIP_TRY(hipEventSynchronize(ctx->ev_acc[1]));
+  HIP_TRY(hipEventElapsedTime(ms, ctx->ev_acc[0], ctx->ev_acc[1]));
+  return BSC_OK;
 }
 
 /* Calls n device-resident pile-ups (queued behind whatever is on the context's stream) in chunks and copies each
@@ -833,60 +926,74 @@ static int bsc_sstats_init(bsc_context *ctx);
  * HBM.  Same records and statistics as bsc_call_sites_device -> bsc_vcf_records_device -> bsc_vcf_stats_device over the
  * whole block.
  */
+/* the fields of a chain launch that do not depend on where the pile-ups come from */
+static int bsc_chain_fill(bsc_context *ctx, bsc_chain_launch *L, const bsc_window *w, const bsc_vcf_params *params, int with_stats,
+                          int reads, const void *d_ref, const void *d_dbsnp, void *d_core, void *d_aux, void *stream) {
+  const int gc = with_stats && ctx->d_gc_bins != NULL;
+  int rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, bsc_dev_chain_het_bytes(w->n, ctx->num_cus, gc, reads));
+  if (rc) return rc;
+  memset(L, 0, sizeof *L);
+  if (with_stats) {
+    if ((rc = bsc_sstats_init(ctx))) return rc;
+    L->carry_in = ctx->d_carry + 2 * ctx->carry_slot;
+    L->carry_out = ctx->d_carry + 2 * (ctx->carry_slot ^ 1u);
+    L->stats = ctx->d_sstats;
+    L->pairs = ctx->d_pairs;
+    L->ovf_list = ctx->d_ovf;
+    L->ovf_cap = BSC_OVF_CAP;
+    if (gc) {
+      L->gc_bins = ctx->d_gc_bins;
+      L->gc_n_bins = ctx->gc_n_bins;
+      L->gc_start_pos = ctx->gc_start_pos;
+      L->gc_table = ctx->d_gc_table;
+    }
+    L->logp = ctx->d_logp;
+  }
+  const uint32_t after = w->n_block - w->first - w->n;
+  L->ref = d_ref;
+  L->dbsnp = d_dbsnp;
+  L->x = w->x;
+  L->n_block = w->n_block;
+  L->first = w->first;
+  L->n = w->n;
+  L->lc = w->first < 2u ? w->first : 2u;
+  L->rc = after < 2u ? after : 2u;
+  L->lr = w->first < 4u ? w->first : 4u;
+  L->all_positions = params->all_positions != 0;
+  L->reg_start = params->reg_start;
+  L->reg_stop = params->reg_stop;
+  L->with_stats = with_stats != 0;
+  L->tb = ctx->d_tables;
+  L->core_out = d_core;
+  L->aux_out = d_aux;
+  L->het_list = ctx->d_het;
+  L->counters = ctx->d_counters;
+  L->num_cus = ctx->num_cus;
+  L->stream = stream;
+  return BSC_OK;
+}
+
+static int bsc_window_check(const char *who, const bsc_window *w) {
+  if ((uint64_t)w->first + w->n > w->n_block)
+    return bsc_fail(BSC_ERR_ARG, "%s: window %u + %u exceeds the block (%u positions)", who, w->first, w->n, w->n_block);
+  if (w->n > 0x0fffffffu) return bsc_fail(BSC_ERR_ARG, "%s: window longer than 2^28 - 1 positions", who);
+  if ((uint64_t)w->x + w->n_block > 0xffffffffull) return bsc_fail(BSC_ERR_ARG, "%s: positions exceed 32 bits", who);
+  return BSC_OK;
+}
+
 int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, const void *d_dbsnp, const bsc_window *w,
                      const bsc_vcf_params *params, int with_stats, void *d_core, void *stream) {
   if (!ctx || !w || !params) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: NULL argument");
   if (w->n == 0) return BSC_OK;
   if (!d_cts || !d_ref || !d_core) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: NULL buffer");
-  if ((uint64_t)w->first + w->n > w->n_block)
-    return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: window %u + %u exceeds the block (%u positions)", w->first, w->n, w->n_block);
-  if (w->n > 0x0fffffffu) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: window longer than 2^28 - 1 positions");
-  if ((uint64_t)w->x + w->n_block > 0xffffffffull) return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: positions exceed 32 bits");
+  int rc = bsc_window_check("bsc_chain_device", w);
+  if (rc) return rc;
   if (((uintptr_t)d_core & 15u) || ((uintptr_t)d_cts & 7u))
     return bsc_fail(BSC_ERR_ARG, "bsc_chain_device: d_core must be 16-byte and d_cts 8-byte aligned");
   BSC_ENTER(ctx);
-  const int gc = with_stats && ctx->d_gc_bins != NULL;
-  int rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, bsc_dev_chain_het_bytes(w->n, ctx->num_cus, gc));
-  if (rc) return rc;
   bsc_chain_launch L;
-  memset(&L, 0, sizeof L);
-  if (with_stats) {
-    if ((rc = bsc_sstats_init(ctx))) return rc;
-    L.carry_in = ctx->d_carry + 2 * ctx->carry_slot;
-    L.carry_out = ctx->d_carry + 2 * (ctx->carry_slot ^ 1u);
-    L.stats = ctx->d_sstats;
-    L.pairs = ctx->d_pairs;
-    L.ovf_list = ctx->d_ovf;
-    L.ovf_cap = BSC_OVF_CAP;
-    if (gc) {
-      L.gc_bins = ctx->d_gc_bins;
-      L.gc_n_bins = ctx->gc_n_bins;
-      L.gc_start_pos = ctx->gc_start_pos;
-      L.gc_table = ctx->d_gc_table;
-    }
-    L.logp = ctx->d_logp;
-  }
-  const uint32_t after = w->n_block - w->first - w->n;
+  if ((rc = bsc_chain_fill(ctx, &L, w, params, with_stats, 0, d_ref, d_dbsnp, d_core, NULL, stream))) return rc;
   L.cts = d_cts;
-  L.ref = d_ref;
-  L.dbsnp = d_dbsnp;
-  L.x = w->x;
-  L.n_block = w->n_block;
-  L.first = w->first;
-  L.n = w->n;
-  L.lc = w->first < 2u ? w->first : 2u;
-  L.rc = after < 2u ? after : 2u;
-  L.lr = w->first < 4u ? w->first : 4u;
-  L.all_positions = params->all_positions != 0;
-  L.reg_start = params->reg_start;
-  L.reg_stop = params->reg_stop;
-  L.with_stats = with_stats != 0;
-  L.tb = ctx->d_tables;
-  L.core_out = d_core;
-  L.het_list = ctx->d_het;
-  L.counters = ctx->d_counters;
-  L.num_cus = ctx->num_cus;
-  L.stream = stream;
   if (ctx->profiling) {
     if (!ctx->ev_chain[0])
       for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&ctx->ev_chain[i]));
@@ -898,6 +1005,85 @@ int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, con
   if (e) return bsc_fail(BSC_ERR_HIP, "chain launch failed: %s", hipGetErrorString((hipError_t)e));
   if (with_stats) ctx->carry_slot ^= 1u;
   ctx->sites += w->n;
+  return BSC_OK;
+}
+
+/*
+ * Reads in, records out: the block's reads are checked, described and ordered (accumulate.hip), then ONE kernel piles up,
+ * calls, forms the records and adds the statistics of every 60-position tile (fused.hip, READS = true) — neither the
+ * pile-up nor gt_meth exists in HBM.  d_aux (optional): the second half of a bsc_vcf_rec per position.
+ */
+static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes, uint32_t x,
+                                 uint32_t y, const void *d_ref, const void *d_dbsnp, const bsc_vcf_params *params, int with_stats,
+                                 void *d_core, void *d_aux, hipStream_t s) {
+  const uint64_t sz64 = (uint64_t)y - x + 1;
+  bsc_window w = {x, (uint32_t)sz64, 0u, (uint32_t)sz64};
+  int rc = bsc_window_check("reads chain", &w);
+  if (rc) return rc;
+  const uint32_t n_tiles = (w.n + 59u) / 60u;
+  size_t sort_bytes = 0;
+  if ((rc = bsc_accumulate_reserve(ctx, nr, x, y, &sort_bytes))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_lo, &ctx->cap_lo, (size_t)n_tiles * 4u))) return rc; /* 60-position tiles: more of them than 64-position ones */
+  if ((rc = bsc_reserve(&ctx->d_fscr, &ctx->cap_fscr, bsc_dev_chain_scratch_bytes(ctx->num_cus)))) return rc;
+  bsc_chain_launch L;
+  if ((rc = bsc_chain_fill(ctx, &L, &w, params, with_stats, 1, d_ref, d_dbsnp, d_core, d_aux, s))) return rc;
+  if (!nr) { /* a block without reads: an ordered list of nothing (the kernels never look at rd / perm) */
+    if ((rc = bsc_reserve(&ctx->d_keys_s, &ctx->cap_keys_s, 8u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_perm, &ctx->cap_perm, 8u))) return rc;
+  }
+  /* SPAN, INEXACT = 0; ERR = all ones (the kernel takes the minimum) */
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), s));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), s));
+  if (ctx->profiling) {
+    if (!ctx->ev_rchain[0])
+      for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&ctx->ev_rchain[i]));
+    HIP_TRY(hipEventRecord(ctx->ev_rchain[0], s));
+  }
+  int e = bsc_dev_launch_prep_reads(d_tpl, nr, d_seq, seq_bytes, x, y, ctx->d_keys, ctx->d_keys_s, ctx->d_perm, ctx->d_sorttmp,
+                                    sort_bytes, ctx->d_rd, ctx->d_counters, ctx->num_cus, s);
+  if (!e) e = bsc_dev_launch_tile_lo(ctx->d_keys_s, 2u * nr, n_tiles, -2, 60u, ctx->d_counters, ctx->d_lo, ctx->num_cus, s);
+  if (e) return bsc_fail(BSC_ERR_HIP, "reads chain: launch failed: %s", hipGetErrorString((hipError_t)e));
+  L.rd = ctx->d_rd;
+  L.keys_sorted = ctx->d_keys_s;
+  L.perm = ctx->d_perm;
+  L.seq = d_seq;
+  L.tile_lo = ctx->d_lo;
+  L.f_scratch = ctx->d_fscr;
+  L.n_reads = 2u * nr;
+  L.min_qual = (uint32_t)ctx->params.min_qual;
+  e = bsc_dev_launch_chain(&L);
+  if (e) return bsc_fail(BSC_ERR_HIP, "reads chain launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (ctx->profiling) {
+    HIP_TRY(hipEventRecord(ctx->ev_rchain[1], s));
+    ctx->ev_rchain_valid = 1;
+  }
+  if (with_stats) ctx->carry_slot ^= 1u;
+  ctx->sites += w.n;
+  return BSC_OK;
+}
+
+int bsc_reads_chain_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes, uint32_t x,
+                           uint32_t y, const void *d_ref, const void *d_dbsnp, const bsc_vcf_params *params, int with_stats,
+                           void *d_core, void *d_aux, void *stream) {
+  if (!ctx || !params || !d_ref || !d_core) return bsc_fail(BSC_ERR_ARG, "bsc_reads_chain_device: NULL argument");
+  if (y < x) return bsc_fail(BSC_ERR_ARG, "bsc_reads_chain_device: y (%u) < x (%u) (reference asserts y >= x)", y, x);
+  if (nr && (!d_tpl || !d_seq)) return bsc_fail(BSC_ERR_ARG, "bsc_reads_chain_device: NULL template or read buffer");
+  if (((uintptr_t)d_core & 15u) || ((uintptr_t)d_aux & 15u) || ((uintptr_t)d_tpl & 7u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_reads_chain_device: d_core / d_aux must be 16-byte and d_tpl 8-byte aligned");
+  BSC_ENTER(ctx);
+  ctx->blk_tpl = NULL;
+  ctx->blk_d_tpl = d_tpl;
+  ctx->blk_x = x;
+  return bsc_reads_chain_queue(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_dbsnp, params, with_stats, d_core, d_aux,
+                               (hipStream_t)stream);
+}
+
+int bsc_last_reads_chain_ms(bsc_context *ctx, float *ms) {
+  if (!ctx || !ms) return bsc_fail(BSC_ERR_ARG, "bsc_last_reads_chain_ms: NULL argument");
+  if (!ctx->profiling || !ctx->ev_rchain_valid) return bsc_fail(BSC_ERR_ARG, "bsc_last_reads_chain_ms: no profiled launch yet");
+  BSC_ENTER(ctx);
+  HIP_TRY(hipEventSynchronize(ctx->ev_rchain[1]));
+  HIP_TRY(hipEventElapsedTime(ms, ctx->ev_rchain[0], ctx->ev_rchain[1]));
   return BSC_OK;
 }
 
@@ -999,6 +1185,7 @@ static int bsc_sstats_init(bsc_context *ctx) {
     hipFree(ctx->d_logp);
     hipFree(ctx->d_ovf);
     ctx->d_ovf = NULL;
+    ctx->d_pairs = NULL;
     ctx->d_sstats = NULL;
     ctx->d_carry = NULL;
     ctx->d_logp = NULL;

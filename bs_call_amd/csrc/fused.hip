@@ -30,7 +30,9 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
+#include "accdev.h"
 #include "bsmath.h"
 #include "callmath.h"
 #include "devtables.h"
@@ -62,6 +64,18 @@ struct bsc_chain_args {
   uint32_t het_cap; /* entries of a wave's heterozygous list */
   uint32_t depth_off; /* != 0: the window's depths (u16 per position, 0 = no record formed) are written at het_list + this
                          many dwords, for the GC-by-coverage kernel */
+};
+
+/* the reads-in form (READS = true): the block's ordered reads instead of pile-ups (accdev.h), and where a heterozygous
+ * call's strand counts wait for Fisher's test (the pile-up they come from exists only in the wave's LDS) */
+#define F_HET_DW 20 /* dwords per listed heterozygous call: index | max_gt << 28, counts[0][0..7], counts[0] + counts[1], mq, 2 spare */
+struct bsc_reads_args {
+  const bsc_read_desc *rd;
+  const uint32_t *keys_sorted, *perm;
+  const uint8_t *seq;
+  const uint32_t *tile_lo; /* first candidate read of every tile of the window */
+  uint32_t *f_scratch;     /* per wave 64 x 8 dwords: forward counts of a tile in which some count exceeds a byte */
+  uint32_t n_reads, min_qual;
 };
 
 struct bsc_vcf_core_f {
@@ -191,6 +205,7 @@ __device__ static __forceinline__ void f_stats_update(uint32_t *h, const f_facts
  * record the wave stored earlier, the position's statistics.  The whole wave calls this (wave-uniform control flow);
  * the records are read back from memory, so the caller has waited for its record stores (vmcnt).
  */
+template <bool READS>
 __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigned n_pend, unsigned lane, const uint32_t *__restrict__ cts,
                                                         const uint8_t *__restrict__ dbsnp, const bsc_chain_args &a,
                                                         uint8_t *__restrict__ core_out, const double *s_lf, const double *s_logtab,
@@ -203,13 +218,14 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
   if (lane < n_pend) {
     const uint32_t i = pend_e & 0x0fffffffu;
     const unsigned mxi = pend_e >> 28;
-    const uint32_t *p = cts + (uint64_t)(i + a.lc) * IN_DW;
+    /* READS: cts is the lane's entry of the wave's list (F_HET_DW dwords), else the block's pile-ups in HBM */
+    const uint32_t *p = READS ? cts : cts + (uint64_t)(i + a.lc) * IN_DW;
     uint32_t f[8], r[8], c[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      f[j] = p[j];
-      r[j] = p[8 + j];
-      c[j] = f[j] + r[j];
+    for (int j = 0; j < 8; j++) { /* the list entry was written by this wave: read past the vector L1 */
+      f[j] = READS ? __hip_atomic_load(&p[1 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[j];
+      c[j] = READS ? __hip_atomic_load(&p[9 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : f[j] + p[8 + j];
+      r[j] = c[j] - f[j];
     }
     int t0, t1, t2, t3;
     strand_table(mxi, f, r, t0, t1, t2, t3);
@@ -225,9 +241,13 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
       const uint32_t phred = (c0.z >> 8) & 0xffu;
       const uint32_t qd = *reinterpret_cast<const uint32_t *>(rec + 28);
       /* mq as the calling statements form it (call_body.inc; src/call_genotypes.c:59) */
-      const uint32_t n_reads = p[16];
-      const float mapq2 = __uint_as_float(p[25]);
-      const int mq = (int)(0.5 + sqrt((double)(mapq2 / (float)n_reads)));
+      int mq;
+      if (READS) mq = (int)__hip_atomic_load(&p[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else {
+        const uint32_t n_reads = p[16];
+        const float mapq2 = __uint_as_float(p[25]);
+        mq = (int)(0.5 + sqrt((double)(mapq2 / (float)n_reads)));
+      }
       int ga, gb;
       f_alleles(gt, ga, gb);
       const bool het = ga != gb; /* the printer's genotype; max_gt differs from it only in a rounding tie */
@@ -262,13 +282,14 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
   if (a.with_stats) f_stats_update(h, F, stat_words);
 }
 
-template <bool FULL>
+template <bool FULL, bool READS>
 __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     const uint32_t *__restrict__ cts, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dbsnp,
     const bsc_chain_args a, const bsc_dev_tables *__restrict__ tb, uint8_t *__restrict__ core_out,
     uint32_t *__restrict__ het_list, unsigned long long *__restrict__ counters,
     const uint32_t *__restrict__ carry_in, uint32_t *__restrict__ carry_out, unsigned long long *__restrict__ stat_words,
-    unsigned long long *__restrict__ pair_cells, unsigned long long *__restrict__ ovf_list) {
+    unsigned long long *__restrict__ pair_cells, unsigned long long *__restrict__ ovf_list, uint8_t *__restrict__ aux_out,
+    const bsc_reads_args ra) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_slot[FW][SLOT_DW];
   __shared__ double s_k[44], s_lnk[44], s_half[44], s_one[44];
   __shared__ double s_logtab[256];
@@ -328,8 +349,18 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
   const uint32_t T_first = a.tile_begin + blockIdx.x * FW + wid;
   /* heterozygous calls waiting for Fisher's test (window index | max_gt << 28): the wave's own list in HBM, one in ~1 000
    * positions; a.het_cap entries hold every position the wave can meet */
-  uint32_t *wl = het_list + (uint64_t)(blockIdx.x * FW + wid) * a.het_cap;
+  uint32_t *wl = het_list + (uint64_t)(blockIdx.x * FW + wid) * a.het_cap * (READS ? F_HET_DW : 1u);
   unsigned n_pend = 0; /* wave-uniform */
+  /* READS: the first batch of candidate reads of the wave's next tile (requested a tile ahead) */
+  uint32_t acc_t0 = 0, acc_kv = 0xffffffffu;
+  bsc_read_desc acc_d;
+  acc_dead(acc_d);
+  unsigned inexact = 0;
+  const uint32_t q_span = ra.min_qual < 63u ? 63u - ra.min_qual : 0u; /* q counts iff min_qual <= q < 63 (src/call_genotypes.c:217) */
+  if (READS && T_first < a.tile_end) {
+    acc_t0 = ra.tile_lo[T_first];
+    acc_fetch(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, acc_t0, lane0, acc_kv, acc_d);
+  }
   for (uint32_t T = T_first; T < a.tile_end; T += gridDim.x * FW) {
     /* the lane number, made opaque once per tile: otherwise every lane-dependent address of the loop body is hoisted
      * out of it, kept alive across the whole kernel and — at 128 VGPRs — spilled to scratch (a vector-memory round trip
@@ -338,7 +369,9 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     asm volatile("" : "+v"(lane));
     const int32_t jw0 = (int32_t)(T * FT) - 2;  /* window-relative index of the site lane 0 computes */
     const int32_t jw = jw0 + (int32_t)lane;
-    const bool valid = FULL || (jw >= -(int32_t)a.lc && jw < (int32_t)(a.n + a.rc)); /* the site is in the buffers */
+    /* the site is in the buffers; READS: it is a position of the block (every one can be piled up from the reads) */
+    const bool valid = FULL || (READS ? ((int64_t)a.first + jw >= 0 && (int64_t)a.first + jw < (int64_t)a.n_block)
+                                      : (jw >= -(int32_t)a.lc && jw < (int32_t)(a.n + a.rc)));
     const bool inner = lane >= 2u && lane < 62u && (FULL || (jw >= 0 && jw < (int32_t)a.n));
     /* Everything per lane is relative to the tile: "lane index" L = block index - b0, b0 = block index of lane 0's
      * site (wave-uniform, 64-bit, in scalar registers); the block occupies lane indices blk_lo .. blk_hi (clamped far
@@ -365,7 +398,52 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
 
     /* ---- my record ---- */
     uint32_t w[IN_DW];
-    if (FULL) {
+    bool bigf_any = false; /* READS, wave-uniform: some forward count of the tile exceeds a byte */
+    uint32_t acc_t0n = 0;
+    if (READS) {
+      /* ---- HOT LOOP A for the tile's 64 sites (src/call_genotypes.c:180-226; accdev.h): the pile-up the calling
+       * statements read is built in the wave's slot and never leaves it ---- */
+      const uint32_t T_next = T + gridDim.x * FW;
+      if (T_next < a.tile_end) acc_t0n = ra.tile_lo[T_next];
+      const uint32_t loff = b0 < 0 ? (uint32_t)(-b0) : 0u; /* lanes in front of the block's first position (0 .. 2) */
+      const int64_t bl = b0 + 63 < (int64_t)a.n_block - 1 ? b0 + 63 : (int64_t)a.n_block - 1; /* last block index of the tile */
+      const uint32_t pa = a.x + (uint32_t)(b0 + (int64_t)loff), p_last = a.x + (uint32_t)bl;
+      uint32_t *row = slot + lane * IN_DW;
+#pragma unroll
+      for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
+      const uint32_t m2 = acc_walk(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, ra.seq, lane, lane - loff, row, pa, p_last, (uint32_t)bl,
+                                   ra.min_qual, q_span, acc_t0, acc_kv, acc_d);
+      uint32_t nsum = 0, fmax = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint2 v = reinterpret_cast<const uint2 *>(row)[i];
+        w[2 * i] = v.x;
+        w[2 * i + 1] = v.y;
+        nsum += v.x + v.y;
+      }
+      w[16] = nsum;
+      bool inx = m2 >= (1u << 24);
+#pragma unroll
+      for (int j = 0; j < 8; j++) { /* integer sums -> the reference's float sums (exact below 2^24) */
+        const uint32_t qs = row[17 + j];
+        inx |= qs >= (1u << 24);
+        w[17 + j] = __float_as_uint((float)qs);
+        fmax |= w[j];
+      }
+      w[25] = __float_as_uint((float)m2);
+      inexact |= (inx && lane >= 2u && lane < 62u) ? 1u : 0u;
+      /* the forward-strand counts, which only Fisher's test of a heterozygous call needs again, wait in the two dwords of
+       * the lane's slot area that the calling statements leave alone (la[12]), a byte each; a tile with a larger count
+       * parks them in the wave's scratch lines in HBM instead */
+      reinterpret_cast<uint2 *>(row)[12] = make_uint2(w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24),
+                                                      w[4] | (w[5] << 8) | (w[6] << 16) | (w[7] << 24));
+      bigf_any = __any(fmax > 255u);
+      if (__builtin_expect(bigf_any, 0)) {
+        uint4 *fs = reinterpret_cast<uint4 *>(ra.f_scratch + ((uint64_t)(blockIdx.x * FW + wid) * 64u + lane) * 8u);
+        fs[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        fs[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      }
+    } else if (FULL) {
 #ifndef BSC_CHAIN_NO_PREFETCH
       if (T == T_first) /* the wave's first tile; every later one was requested while its predecessor's statistics ran */
 #endif
@@ -391,6 +469,35 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     if (covered && inner) {
       atomicAdd(&s_cnt[0], 1u);
       atomicAdd(&s_cnt[1 + mxi], 1u);
+    }
+    if (READS) { /* heterozygous calls: listed now, with what Fisher's test and the FILTER bits after it need — the counts
+                  * are in registers and the forward-strand stash is still intact */
+      const unsigned long long m = __ballot(defer);
+      if (m) {
+        if (defer) {
+          uint32_t f[8];
+          if (__builtin_expect(bigf_any, 0)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the lane's own stores to the scratch lines */
+            const uint32_t *fs = ra.f_scratch + ((uint64_t)(blockIdx.x * FW + wid) * 64u + lane) * 8u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) f[j] = __hip_atomic_load(&fs[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            const uint2 st = reinterpret_cast<const uint2 *>(slot + lane * IN_DW)[12];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              f[j] = (st.x >> (8 * j)) & 0xffu;
+              f[4 + j] = (st.y >> (8 * j)) & 0xffu;
+            }
+          }
+          uint4 *e = reinterpret_cast<uint4 *>(wl + (uint64_t)(n_pend + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) * F_HET_DW);
+          e[0] = make_uint4((uint32_t)jw | ((uint32_t)mxi << 28), f[0], f[1], f[2]);
+          e[1] = make_uint4(f[3], f[4], f[5], f[6]);
+          e[2] = make_uint4(f[7], cnt[0], cnt[1], cnt[2]);
+          e[3] = make_uint4(cnt[3], cnt[4], cnt[5], cnt[6]);
+          e[4] = make_uint4(cnt[7], (uint32_t)mq, 0u, 0u);
+        }
+        n_pend += (unsigned)__popcll(m);
+      }
     }
 
     /* ---- the printer's genotype: first-max argmax of gt_prob[], recomputed (src/print_vcf.c:584-591) ----
@@ -592,9 +699,28 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
         const unsigned idx = k * 64u + lane;
         if (idx < nvec) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(so)[idx], dst + idx);
       }
+      if (aux_out) { /* what the encoder of a written record reads besides the core record (src/print_vcf.c:306-359): MC8 counts,
+                      * AMQ qualities, MQ, mean quality, max_gt, the dbSNP flag — the second half of a bsc_vcf_rec */
+        WAVE_LDS_SYNC();
+        if (lane >= 2u && lane < 62u) {
+          const uint32_t rsf = (dbsnp && inner) ? (uint32_t)dbsnp[jw] : 0u;
+          const bool hasrec = od[0] != 0u;
+          so[(lane - 2u) * 4u + 0] = hasrec ? make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]) : make_uint4(0u, 0u, 0u, 0u);
+          so[(lane - 2u) * 4u + 1] = hasrec ? make_uint4(cnt[4], cnt[5], cnt[6], cnt[7]) : make_uint4(0u, 0u, 0u, 0u);
+          so[(lane - 2u) * 4u + 2] = hasrec ? make_uint4(qpack0, qpack1, (uint32_t)mq, (uint32_t)aq) : make_uint4(0u, 0u, 0u, 0u);
+          so[(lane - 2u) * 4u + 3] = hasrec ? make_uint4((uint32_t)mxi | (rsf << 8), 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        WAVE_LDS_SYNC();
+        u32x4 *dsta = reinterpret_cast<u32x4 *>(aux_out + (uint64_t)i0 * 64u);
+#pragma unroll
+        for (unsigned k = 0; k < 4; k++) {
+          const unsigned idx = k * 64u + lane;
+          if (idx < nvec) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(so)[idx], dsta + idx);
+        }
+      }
     }
     /* ---- heterozygous calls: listed, Fisher's test after the wave's last tile ---- */
-    {
+    if (!READS) {
       const unsigned long long m = __ballot(defer);
       if (m) {
         if (defer) wl[n_pend + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)jw | ((uint32_t)mxi << 28);
@@ -605,12 +731,16 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     /* The slot is free from here to the end of the tile (the statistics below touch other LDS arrays only): request the
      * wave's NEXT tile now, so that its pile-ups land — and the record stores above drain — while the histograms are
      * updated, instead of the wave sitting out a full HBM round trip at the top of the next tile. */
-    if (FULL) {
+    if (FULL && !READS) {
       WAVE_LDS_SYNC();
       const uint32_t T_next = T + gridDim.x * FW;
       if (T_next < a.tile_end) F_DMA_TILE(T_next, dma16_hidden);
     }
 #endif
+    if (READS) { /* the first batch of the wave's next tile: on its way while the histograms are updated */
+      acc_t0 = acc_t0n;
+      if (T + gridDim.x * FW < a.tile_end) acc_fetch(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, acc_t0, lane, acc_kv, acc_d);
+    }
     if (a.with_stats) {
       /* ---- the statistics block (src/print_vcf.c:386-525; sitestats.hip has the restatement) for the tile ----
        * Wide histograms take one LDS atomic per lane; where one value dominates (QUAL 255, MQ, FS 0, FILTER 0) the
@@ -722,9 +852,14 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the wave's records and its list are in memory */
     for (unsigned k0 = 0; k0 < n_pend; k0 += 64u) {
       const unsigned nb = n_pend - k0 < 64u ? n_pend - k0 : 64u;
-      const uint32_t e = lane0 < nb ? __hip_atomic_load(&wl[k0 + lane0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      f_fisher_pending(e, nb, lane0, cts, dbsnp, a, core_out, s_lf, s_logtab, s_exptab, h, stat_words);
+      const uint32_t *ent = wl + (uint64_t)(k0 + lane0) * (READS ? F_HET_DW : 1u);
+      const uint32_t e = lane0 < nb ? __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      f_fisher_pending<READS>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_out, s_lf, s_logtab, s_exptab, h, stat_words);
     }
+  }
+  if (READS && __any(inexact)) { /* positions whose quality / MAPQ^2 sums left the exact-float range (accumulate.hip) */
+    const unsigned long long m = __ballot(inexact != 0);
+    if (lane0 == 0) atomicAdd(&counters[BSC_CNT_INEXACT], (unsigned long long)__popcll(m));
   }
 
   __syncthreads();
@@ -784,15 +919,19 @@ static uint32_t chain_het_cap(uint32_t tiles, unsigned grid) {
   return (rounds * FT + 31u) & ~31u;
 }
 
-/* bytes the per-wave heterozygous lists of a window of n positions take, at most; with_depth: plus the window's depths */
-extern "C" size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth) {
+/* bytes the per-wave heterozygous lists of a window of n positions take, at most; with_depth: plus the window's depths;
+ * reads: the reads-in form, whose entries carry the call's strand counts (F_HET_DW dwords) */
+extern "C" size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth, int reads) {
   const uint64_t tiles = ((uint64_t)n + FT - 1) / FT, waves = (uint64_t)num_cus * FW;
-  const size_t lists = (size_t)((tiles + waves) * FT + waves * 32u) * sizeof(uint32_t);
+  const size_t lists = (size_t)((tiles + waves) * FT + waves * 32u) * sizeof(uint32_t) * (reads ? F_HET_DW : 1u);
   return lists + (with_depth ? (((size_t)n * 2u + 3u) & ~(size_t)3u) : 0u);
 }
 
-extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
-  if (L->n == 0) return 0;
+/* bytes of the reads-in form's forward-count scratch lines (64 x 8 dwords per resident wave) */
+extern "C" size_t bsc_dev_chain_scratch_bytes(int num_cus) { return (size_t)num_cus * FW * 64u * 8u * sizeof(uint32_t); }
+
+template <bool READS>
+static int chain_launch_t(const bsc_chain_launch *L) {
   hipStream_t s = (hipStream_t)L->stream;
   bsc_chain_args a;
   a.x = L->x;
@@ -808,28 +947,49 @@ extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
   a.with_stats = L->with_stats;
   a.ovf_cap = L->ovf_cap;
   const bool gc = L->with_stats && L->gc_bins && L->gc_table;
-  a.depth_off = gc ? (uint32_t)(bsc_dev_chain_het_bytes(L->n, L->num_cus, 0) / sizeof(uint32_t)) : 0u;
+  a.depth_off = gc ? (uint32_t)(bsc_dev_chain_het_bytes(L->n, L->num_cus, 0, READS) / sizeof(uint32_t)) : 0u;
   const uint32_t n_tiles = (L->n + FT - 1) / FT;
-  /* complete tiles: all 64 computed sites in the buffers, and the first one on a 16-byte boundary for the LDS-DMA
-   * ((60 T - 2 + lc) * 104 bytes: lc even) */
-  uint32_t t_lo = L->lc == 2 ? 0u : 1u;
-  uint32_t t_hi = (L->n + L->rc >= 62u) ? (L->n + L->rc - 62u) / FT + 1u : 0u;
-  if (t_hi > n_tiles) t_hi = n_tiles;
-  if ((L->lc & 1u) || ((uintptr_t)L->cts & 15u) || t_hi <= t_lo) t_lo = t_hi = 0; /* everything through the guarded kernel */
+  bsc_reads_args ra;
+  memset(&ra, 0, sizeof ra);
+  uint32_t t_lo, t_hi;
+  if (READS) {
+    ra.rd = (const bsc_read_desc *)L->rd;
+    ra.keys_sorted = (const uint32_t *)L->keys_sorted;
+    ra.perm = (const uint32_t *)L->perm;
+    ra.seq = (const uint8_t *)L->seq;
+    ra.tile_lo = (const uint32_t *)L->tile_lo;
+    ra.f_scratch = (uint32_t *)L->f_scratch;
+    ra.n_reads = L->n_reads;
+    ra.min_qual = L->min_qual;
+    /* complete tiles: all 64 computed sites are positions of the block, all 60 records positions of the window */
+    t_lo = L->first >= 2u ? 0u : 1u;
+    const uint64_t after = (uint64_t)L->n_block - L->first; /* block positions from the window start on */
+    const uint64_t t_blk = after >= 62u ? (after - 62u) / FT + 1u : 0u; /* 60 T + 61 <= after - 1 */
+    const uint64_t t_win = L->n / FT;                                    /* 60 T + 59 <= n - 1 */
+    t_hi = (uint32_t)(t_blk < t_win ? t_blk : t_win);
+    if (t_hi <= t_lo) t_lo = t_hi = 0;
+  } else {
+    /* complete tiles: all 64 computed sites in the buffers, and the first one on a 16-byte boundary for the LDS-DMA
+     * ((60 T - 2 + lc) * 104 bytes: lc even) */
+    t_lo = L->lc == 2 ? 0u : 1u;
+    t_hi = (L->n + L->rc >= 62u) ? (L->n + L->rc - 62u) / FT + 1u : 0u;
+    if (t_hi > n_tiles) t_hi = n_tiles;
+    if ((L->lc & 1u) || ((uintptr_t)L->cts & 15u) || t_hi <= t_lo) t_lo = t_hi = 0; /* everything through the guarded kernel */
+  }
   unsigned long long *words = (unsigned long long *)L->stats;
   if (L->ev_start) (void)hipEventRecord((hipEvent_t)L->ev_start, s);
 #define CHAIN_ARGS(A)                                                                                               \
   (const uint32_t *)L->cts, (const uint8_t *)L->ref, (const uint8_t *)L->dbsnp, A, (const bsc_dev_tables *)L->tb,   \
       (uint8_t *)L->core_out, (uint32_t *)L->het_list, (unsigned long long *)L->counters,                           \
       (const uint32_t *)L->carry_in, (uint32_t *)L->carry_out, words, (unsigned long long *)L->pairs,               \
-      (unsigned long long *)L->ovf_list
+      (unsigned long long *)L->ovf_list, (uint8_t *)L->aux_out, ra
   if (t_hi > t_lo) {
     a.tile_begin = t_lo;
     a.tile_end = t_hi;
     unsigned grid = (t_hi - t_lo + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus; /* one 1024-thread workgroup per CU, persistent */
     a.het_cap = chain_het_cap(t_hi - t_lo, grid);
-    hipLaunchKernelGGL(bsc_chain_kernel_t<true>, dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
+    hipLaunchKernelGGL((bsc_chain_kernel_t<true, READS>), dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
@@ -841,7 +1001,7 @@ extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
     unsigned grid = (a.tile_end - a.tile_begin + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
     a.het_cap = chain_het_cap(a.tile_end - a.tile_begin, grid);
-    hipLaunchKernelGGL(bsc_chain_kernel_t<false>, dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
+    hipLaunchKernelGGL((bsc_chain_kernel_t<false, READS>), dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
@@ -856,4 +1016,9 @@ extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
   hipError_t e = hipGetLastError();
   if (L->ev_stop) (void)hipEventRecord((hipEvent_t)L->ev_stop, s);
   return (int)e;
+}
+
+extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
+  if (L->n == 0) return 0;
+  return L->rd ? chain_launch_t<true>(L) : chain_launch_t<false>(L);
 }

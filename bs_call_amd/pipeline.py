@@ -14,7 +14,7 @@ from .caller import ReadProfile, SiteCaller, gc_bins, prepare_templates
 
 def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: str = "SAMPLE", report_path: Optional[str] = None,
         caller: Optional[SiteCaller] = None, dbsnp=None, compressed: bool = True, date=None, left_trim=(0, 0), right_trim=(0, 0),
-        min_qual: int = 20, benchmark_mode: bool = False, **reader_kw) -> dict:
+        min_qual: int = 20, benchmark_mode: bool = False, under_conv: float = 0.01, over_conv: float = 0.05, **reader_kw) -> dict:
     """reference: contig name -> uint8 reference codes (0 = N, 1..4 = ACGT; position 1 first).  Returns a summary dict."""
     own = caller is None
     c = caller or SiteCaller()
@@ -22,43 +22,49 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
         prof = ReadProfile()
         base_filter = np.zeros(5, dtype=np.uint64)
         passed = np.zeros(2, dtype=np.uint64)
-        per_contig, blobs = [], []
+        per_contig = []
         n_blocks = n_records = 0
         c.reset_site_stats()
         with BamReader(bam_path, **reader_kw) as rd:
             refs = rd.refs
-            before, cur_tid = c.site_totals(), -1
-            for tid, y, raw, seq, ms in rd.blocks():
-                name, _ = refs[tid]
-                if tid != cur_tid:
-                    if cur_tid >= 0:
-                        after = c.site_totals()
-                        per_contig.append((refs[cur_tid][0], after - before))
-                        before = after
-                    cur_tid = tid
-                    if dbsnp is not None:
-                        dbsnp.load_contig(name)
-                    # the contig's GC bins (load_sequence computes them when a report is asked for), resident on the device
-                    gc_start, bins = gc_bins(reference[name])
-                    c.set_gc_bins_host(bins, gc_start)
-                codes = reference[name]
-                x = int(raw["pos"][0][0]) or int(raw["pos"][0][1])
-                x = x - 2 if x > 2 else 1  # process_template_vector, src/process_template.c:22-28
-                ref = block_reference(codes, x, y)
-                tpl, pseq, st = prepare_templates(raw, seq, ms, left_trim, right_trim, min_qual, profile=prof, x=x, ref=ref)
-                base_filter += np.array([st["base_none"], st["base_trim"], st["base_clip"], st["base_overlap"], st["base_lowqual"]], dtype=np.uint64)
-                passed += np.array([st["reads"], st["read_bases"]], dtype=np.uint64)
-                flags = None if dbsnp is None else dbsnp.flags(x, y - x + 1)
-                recs = c.block_records(tpl, pseq, x, y, ref, reg_stop=len(codes), dbsnp=flags, with_stats=True)
-                blobs.append(vcf.bcf_block(recs, tid, dbsnp))
-                n_blocks += 1
-                n_records += len(recs)
-            if cur_tid >= 0:
-                per_contig.append((refs[cur_tid][0], c.site_totals() - before))
-            cts, bases = rd.filter_counts()
-            header = vcf.header_text([(n, l) for n, l in refs], sample, min_qual=min_qual, date=date,
+            # the header names the run's own thresholds (print_vcf_header, src/print_vcf.c:647-692)
+            header = vcf.header_text([(n, l) for n, l in refs], sample, under_conv=under_conv, over_conv=over_conv,
+                                     mapq_thresh=reader_kw.get("mapq_thresh", 20), min_qual=min_qual, date=date,
                                      dbsnp_header=None if dbsnp is None else dbsnp.header, benchmark_mode=benchmark_mode)
-        vcf.write_bcf(bcf_path, header, blobs, compressed)
+
+            def block_blobs():
+                nonlocal n_blocks, n_records, base_filter, passed
+                before, cur_tid = c.site_totals(), -1
+                for tid, y, raw, seq, ms in rd.blocks():
+                    name, _ = refs[tid]
+                    if tid != cur_tid:
+                        if cur_tid >= 0:
+                            after = c.site_totals()
+                            per_contig.append((refs[cur_tid][0], after - before))
+                            before = after
+                        cur_tid = tid
+                        if dbsnp is not None:
+                            dbsnp.load_contig(name)
+                        # the contig's GC bins (load_sequence computes them when a report is asked for), resident on the device
+                        gc_start, bins = gc_bins(reference[name])
+                        c.set_gc_bins_host(bins, gc_start)
+                    codes = reference[name]
+                    x = int(raw["pos"][0][0]) or int(raw["pos"][0][1])
+                    x = x - 2 if x > 2 else 1  # process_template_vector, src/process_template.c:22-28
+                    ref = block_reference(codes, x, y)
+                    tpl, pseq, st = prepare_templates(raw, seq, ms, left_trim, right_trim, min_qual, profile=prof, x=x, ref=ref)
+                    base_filter += np.array([st["base_none"], st["base_trim"], st["base_clip"], st["base_overlap"], st["base_lowqual"]], dtype=np.uint64)
+                    passed += np.array([st["reads"], st["read_bases"]], dtype=np.uint64)
+                    flags = None if dbsnp is None else dbsnp.flags(x, y - x + 1)
+                    recs = c.block_records(tpl, pseq, x, y, ref, reg_stop=len(codes), dbsnp=flags, with_stats=True)
+                    yield vcf.bcf_block(recs, tid, dbsnp)
+                    n_blocks += 1
+                    n_records += len(recs)
+                if cur_tid >= 0:
+                    per_contig.append((refs[cur_tid][0], c.site_totals() - before))
+
+            vcf.write_bcf(bcf_path, header, block_blobs(), compressed)  # blocks go to the writer as they are formed
+            cts, bases = rd.filter_counts()
         cts[0] += int(passed[0])
         bases[0] += int(passed[1])
         c.set_gc_bins_host(None, 0)

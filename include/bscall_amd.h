@@ -155,6 +155,21 @@ int bsc_accumulate(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const
                    uint32_t x, uint32_t y, bsc_pileup *out);
 
 /*
+ * bsc_accumulate_device: the same stage on device-resident inputs — d_tpl[nr] (bsc_template, 8-byte aligned), d_seq
+ * (seq_bytes read bytes) -> d_cts, the pile-ups of x .. y (16-byte aligned; room for y - x + 1 rounded up to a whole
+ * number of 64-position tiles, x 104 bytes: the last tile is written whole).  Asynchronous on `stream`.  The templates
+ * are validated by the kernel that reads them; bsc_block_status() waits for `stream` and returns the verdict of the
+ * block queued last: BSC_OK, BSC_WARN_INEXACT or BSC_ERR_ARG naming the first template that breaks one of the
+ * reference's asserts (src/call_genotypes.c:186-188) — such a template contributes nothing to the pile-up.
+ * bsc_last_accumulate_ms (with bsc_set_profiling): device time of the stage's launches (template checks + read
+ * descriptors, ordering, tile search, accumulate) of the most recent call, from HIP events on its stream.
+ */
+int bsc_accumulate_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes, uint32_t x,
+                          uint32_t y, void *d_cts, void *stream);
+int bsc_block_status(bsc_context *ctx, void *stream);
+int bsc_last_accumulate_ms(bsc_context *ctx, float *ms);
+
+/*
  * bsc_call_block: the compute of one call_genotypes_ML() invocation (src/call_genotypes.c:155-273) without its
  * thread hand-offs: accumulate (above) followed by the per-site calling of bsc_call_sites(), the pile-up never
  * leaving the device.  ref[i] is the reference code of position x + i; out / out_stride / skip as in
@@ -399,6 +414,25 @@ typedef struct {
 } bsc_window;
 int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, const void *d_dbsnp, const bsc_window *w,
                      const bsc_vcf_params *params, int with_stats, void *d_core, void *stream);
+/*
+ * bsc_reads_chain_device: one whole block from reads to records in the chain's single pass — the block's templates are
+ * checked, described and ordered like bsc_accumulate_device's, then every 60-position tile is piled up in the LDS of the
+ * wave that calls it: HOT LOOP A (src/call_genotypes.c:180-226), the calc threads (:43-115) and what the print thread
+ * derives from their output (src/process.c:87-104 -> src/print_vcf.c:32-594) with neither the pile-up nor gt_meth in HBM.
+ *   d_tpl[nr], d_seq   device-resident templates (8-byte aligned) and read bytes of the block x .. y
+ *   d_ref              reference codes of x .. y + 2 (y - x + 3 bytes: work->ref1, src/process_template.c:29-30)
+ *   d_dbsnp            rs_found per position or NULL
+ *   d_core             y - x + 1 bsc_vcf_core records (16-byte aligned): the bytes bsc_accumulate_device + bsc_chain_device give
+ *   d_aux              NULL, or 64 bytes per position (16-byte aligned): the second half of a bsc_vcf_rec — counts[8], qual[8],
+ *                      mq, aq, max_gt, rs_found — of every position with a record, zero elsewhere
+ * Asynchronous on `stream`; bsc_block_status() returns the templates' verdict (an invalid template contributes nothing);
+ * counters and, with_stats != 0, the site statistics accumulate in the context.  bsc_last_reads_chain_ms (with
+ * bsc_set_profiling): device time of all of its launches.
+ */
+int bsc_reads_chain_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes, uint32_t x,
+                           uint32_t y, const void *d_ref, const void *d_dbsnp, const bsc_vcf_params *params, int with_stats,
+                           void *d_core, void *d_aux, void *stream);
+int bsc_last_reads_chain_ms(bsc_context *ctx, float *ms);
 /* Positions that one round of the device's resident waves covers (CUs x waves per workgroup x 60).  A caller that cuts a
  * resident contig into windows of its own choosing (the reference's blocks are data dependent, src/process_template.c:24-28;
  * SURVEY.md 8d fixes 4 Mi) should make them a multiple of this: every wave then gets the same number of tiles. 0 if ctx

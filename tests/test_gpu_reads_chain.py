@@ -1,0 +1,128 @@
+"""bsc_reads_chain_device (reads in, records out: HOT LOOP A fused into the chain kernel, csrc/fused.hip READS = true)
+against the CPU oracle — orc_accumulate -> orc_call_sites -> orc_vcf_block_stats = the reference's process, calc and print
+threads (src/call_genotypes.c:180-226 -> :43-115 -> src/print_vcf.c:32-594) — every byte of every bsc_vcf_core record and of
+the packed half records (MC8 / AMQ / MQ), every counter, every integer of the statistics."""
+import numpy as np
+import pytest
+import torch
+
+import bs_call_amd as B
+from bs_call_amd.abi import SITE_STATS, VCF_CORE
+
+from test_gpu_chain import _dev, _same_core, _same_stats
+
+pytestmark = pytest.mark.gpu
+SEED = 88172645463325252
+DEV = "cuda:0"
+AUX = np.dtype([("counts", "<u4", (8,)), ("qual", "u1", (8,)), ("mq", "<i4"), ("aq", "<i4"), ("max_gt", "u1"), ("rs_found", "u1"),
+                ("_pad", "u1", (14,))])
+
+
+@pytest.fixture(scope="module")
+def caller():
+    c = B.SiteCaller()
+    yield c
+    c.close()
+
+
+def _block(seed, x0, n, cov):
+    tpl, seq = B.synth_reads_host(seed, x0, n, cov)
+    x = max(1, x0 - 2)
+    y = int(max((tpl["pos"] + tpl["len"]).max(), x0)) - 1 if len(tpl) else x0
+    return tpl, seq, x, y
+
+
+def _reads_chain(c, tpl, seq, x, y, ref2, dbsnp=None, all_positions=False, reg=(1, 0xFFFFFFFF), with_stats=True, aux=True):
+    n = y - x + 1
+    d_tpl = _dev(tpl) if len(tpl) else torch.zeros(64, dtype=torch.uint8, device=DEV)
+    d_seq = _dev(seq) if len(seq) else torch.zeros(64, dtype=torch.uint8, device=DEV)
+    d_ref = _dev(ref2)
+    d_db = None if dbsnp is None else _dev(dbsnp)
+    d_core = torch.full((n * 64,), 0xA5, dtype=torch.uint8, device=DEV)
+    d_aux = torch.full((n * 64,), 0x5A, dtype=torch.uint8, device=DEV) if aux else None
+    c.reset_stats()
+    c.reset_site_stats()
+    c.reads_chain_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), len(seq), x, y, d_ref.data_ptr(), d_core.data_ptr(),
+                         None if d_aux is None else d_aux.data_ptr(), all_positions, reg[0], reg[1],
+                         None if d_db is None else d_db.data_ptr(), with_stats, None)
+    c.block_status(None)
+    torch.cuda.synchronize()
+    core = d_core.cpu().numpy().view(VCF_CORE).copy()
+    a = None if d_aux is None else d_aux.cpu().numpy().view(AUX).copy()
+    return core, a, c.site_stats().copy(), c.stats()
+
+
+def _oracle_chain(oracle, tables, libm_exact, tpl, seq, x, y, ref2, dbsnp=None, all_positions=False, reg=(1, 0xFFFFFFFF)):
+    n = y - x + 1
+    rc, pile = oracle.accumulate(tpl, seq, x, y, 20)
+    assert rc == 0
+    gtm, skip = oracle.call_sites(pile, ref2[:n], tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
+    stats = np.zeros(1, dtype=SITE_STATS)
+    carry = np.zeros(2, dtype=np.uint32)
+    core = oracle.vcf_block_stats(gtm, skip, ref2, x, stats, carry, tables.lfact_store, all_positions, reg[0], reg[1], dbsnp)
+    aux = np.zeros(n, dtype=AUX)
+    has = core["pos"] != 0
+    aux["counts"][has] = gtm["counts"][has]
+    aux["qual"][has] = gtm["qual"][has]
+    aux["mq"][has], aux["aq"][has], aux["max_gt"][has] = gtm["mq"][has], gtm["aq"][has], gtm["max_gt"][has]
+    if dbsnp is not None:
+        aux["rs_found"][has] = dbsnp[has]
+    return core, aux, stats[0], gtm, skip
+
+
+@pytest.mark.parametrize("cov,n,x0", [(30, 120_000, 9_000), (10, 30_000, 5), (200, 6_000, 777_777), (30, 64, 100), (30, 1, 50),
+                                      (30, 59, 3), (30, 121, 1), (300, 3_000, 40)])
+def test_reads_chain_vs_oracle(caller, oracle, tables, libm_exact, cov, n, x0):
+    if not libm_exact:
+        pytest.skip("host libm differs from the replica: the record bytes go through exp/log")
+    rng = np.random.default_rng(cov * 1000 + n)
+    tpl, seq, x, y = _block(SEED + 700 + cov + n, x0, n, cov)
+    sz = y - x + 1
+    ref2 = B.synth_ref_host(SEED + 700 + cov + n, x, sz + 2)
+    db = rng.choice([0, 1, 3], size=sz, p=[0.9, 0.05, 0.05]).astype(np.uint8)
+    for kw in (dict(), dict(all_positions=True), dict(reg=(x + sz // 4, x + sz // 2)), dict(dbsnp=db)):
+        ecore, eaux, est, gtm, skip = _oracle_chain(oracle, tables, libm_exact, tpl, seq, x, y, ref2, **kw)
+        core, aux, gst, cnt = _reads_chain(caller, tpl, seq, x, y, ref2, **kw)
+        _same_core(core, ecore, "reads chain %s" % (kw.keys(),))
+        assert aux.tobytes() == eaux.tobytes(), [f for f in AUX.names if aux[f].tobytes() != eaux[f].tobytes()]
+        _same_stats(gst, est)
+        assert cnt["sites"] == sz and cnt["covered"] == int((skip == 0).sum())
+        assert cnt["gt_hist"] == np.bincount(gtm["max_gt"][skip == 0], minlength=10).tolist()
+
+
+def test_reads_chain_equals_accumulate_then_chain(caller):
+    """The same block through the unfused route on the device (bsc_accumulate_device -> bsc_chain_device): same bytes, and
+    the counts of a block whose forward counts exceed a byte (the scratch-line path of the heterozygous calls)."""
+    for cov, n in ((30, 400_000), (1400, 4_000)):
+        tpl, seq, x, y = _block(SEED + 800 + cov, 5_000, n, cov)
+        sz = y - x + 1
+        ref2 = B.synth_ref_host(SEED + 800 + cov, x, sz + 2)
+        core, aux, gst, cnt = _reads_chain(caller, tpl, seq, x, y, ref2)
+        d_tpl, d_seq, d_ref = _dev(tpl), _dev(seq), _dev(ref2)
+        pad = (sz + 63) // 64 * 64
+        d_cts = torch.zeros(pad * 104 + 256, dtype=torch.uint8, device=DEV)
+        d_core = torch.empty(sz * 64, dtype=torch.uint8, device=DEV)
+        caller.reset_stats()
+        caller.reset_site_stats()
+        caller.accumulate_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), len(seq), x, y, d_cts.data_ptr(), None)
+        caller.block_status(None)
+        caller.chain_device(d_cts.data_ptr(), d_ref.data_ptr(), x, sz, 0, sz, d_core.data_ptr(), with_stats=True)
+        torch.cuda.synchronize()
+        _same_core(core, d_core.cpu().numpy().view(VCF_CORE), "unfused route %dx" % cov)
+        _same_stats(gst, caller.site_stats())
+        assert cnt == caller.stats()
+        if cov == 1400:
+            assert int(aux["counts"].max()) > 600  # deep enough for forward counts beyond a byte
+
+
+def test_reads_chain_bad_template_and_empty_block(caller):
+    tpl, seq, x, y = _block(SEED + 900, 20_000, 5_000, 30)
+    sz = y - x + 1
+    ref2 = B.synth_ref_host(SEED + 900, x, sz + 2)
+    bad = tpl.copy()
+    bad["orientation"][7] = 3
+    with pytest.raises(B.BscError) as e:
+        _reads_chain(caller, bad, seq, x, y, ref2)
+    assert "template 7" in str(e.value)
+    core, aux, st, cnt = _reads_chain(caller, tpl[:0], seq[:0], x, x + 199, ref2[:202])
+    assert not core.view(np.uint8).any() and not aux.view(np.uint8).any() and cnt["covered"] == 0
