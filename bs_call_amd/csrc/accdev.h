@@ -9,22 +9,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef ACC_GROUP
+#define ACC_GROUP 8 /* reads whose byte loads are issued back to back before the first is consumed (4 or 8) */
+#endif
+
 /* compact read descriptor, 24 bytes; a > b: the read contributes nothing */
 struct __attribute__((aligned(8))) bsc_read_desc {
-  uint32_t a;    /* first countable position (absolute) */
-  uint32_t b;    /* last countable position (absolute, already clipped to y) */
+  uint32_t a;    /* position of the read's first base (absolute) */
+  uint32_t b;    /* position of its last base (absolute, already clipped to y) */
   int64_t base;  /* seq offset of position 0: byte of position p is seq[base + p] */
-  uint32_t meta; /* bit 5: orientation the read is counted with (= byte offset of counts[ori]), bits 8-23 mapq^2 */
+  uint32_t meta; /* ACC_META: bit 12 = the orientation the read is counted with, bits 16-31 = mapq^2 */
   uint32_t lut;  /* 4 * class of base codes 0..3 on the read's bisulfite strand, one byte each (LUT4 below) */
 };
+#define ACC_META(ori, mapq) ((((uint32_t)(ori)&1u) << 12) | (((uint32_t)(mapq) * (uint32_t)(mapq)) << 16))
 
 /* strand -> 4 * class, one byte per base code (reference base_tab_st, src/call_genotypes.c:17-19):
- * NON_CONVERTED 0 1 2 3 ; C2T 0 5 2 7 ; G2A 4 1 6 3.  Byte-indexed so that one v_perm_b32 turns a base code into
+ * NON_CONVERTED 0 1 2 3 ; C2T 0 5 2 7 ; G2A 4 1 6 3.  Byte-indexed so that one v_alignbyte_b32 turns a base code into
  * the byte offset of its class inside a pile-up row. */
 #define LUT4(c0, c1, c2, c3) ((uint32_t)(4 * (c0)) | ((uint32_t)(4 * (c1)) << 8) | ((uint32_t)(4 * (c2)) << 16) | ((uint32_t)(4 * (c3)) << 24))
-
-/* a pointer the compiler knows to be global memory (a plain pointer rebuilt from two registers would be flat) */
-typedef const __attribute__((address_space(1))) uint8_t *acc_global_bytes;
 
 __device__ static __forceinline__ void acc_dead(bsc_read_desc &e) {
   e.a = 1;
@@ -34,7 +36,7 @@ __device__ static __forceinline__ void acc_dead(bsc_read_desc &e) {
   e.lut = 0;
 }
 
-/* 64 candidate reads per batch: lane i gets the sort key (first countable position relative to the block start) and the
+/* 64 candidate reads per batch: lane i gets the sort key (first position relative to the block start) and the
  * descriptor of the read that comes (tb + i)-th in position order */
 __device__ static __forceinline__ void acc_fetch(const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ keys_sorted,
                                                  const uint32_t *__restrict__ perm, uint32_t n_reads, uint32_t tb, unsigned lane,
@@ -50,15 +52,20 @@ __device__ static __forceinline__ void acc_fetch(const bsc_read_desc *__restrict
 
 /*
  * One tile: lane L owns genome position pa + (L - loff) for L - loff in 0 .. p_last - pa (lane_p = L - loff as an unsigned
- * number: the lanes in front of the tile's first position wrap to huge values and fall out of every range test) and bumps
- * its own pile-up row (`row`, 26 dwords in LDS, zeroed by the caller; counts and INTEGER quality sums, the caller converts).
- * The wave walks the candidate reads from the t0-th in key order — the first batch (kv, d) fetched by the caller — until a
- * read starts right of the tile.  Returns the lane's MAPQ^2 sum (saturating).
+ * number: the lanes in front of the tile's first position wrap to huge values and fall out of the range of every read) and
+ * bumps its own pile-up row (`row`, 26 dwords in LDS, zeroed by the caller; counts and INTEGER quality sums, the caller
+ * converts).  The wave walks the candidate reads from the t0-th in key order — the first batch (kv, d) fetched by the
+ * caller — until a read starts right of the tile.  Returns the lane's MAPQ^2 sum (saturating).
  *
- * Instruction-issue and latency bound, so the work per (read, tile) pair is kept to a minimum: what depends on the read
- * and the tile but not on the lane — the read's lane range, the address of its first byte in the tile — is computed once
- * per descriptor lane, 64 reads at a time, and reaches the scalar registers with v_readlane; per lane that leaves clamp,
- * load, range test, quality test, class lookup (v_alignbyte on the strand's table), two LDS adds, one add.
+ * The VALU is what this loop (and the kernels around it) run out of, so the work per (read, tile) pair is kept off it where
+ * possible.  What depends on the read and the tile but not on the lane — the read's lane range, its orientation, its
+ * MAPQ^2, the address of its first byte in the tile — is computed once per descriptor lane, 64 reads at a time, packed into
+ * one dword and reaches the scalar registers with four v_readlane (packed word, class table, address); the scalar unit
+ * unpacks it.  The bytes are fetched through a buffer descriptor built per read (base = the read's first byte in the tile,
+ * num_records = its length there): a lane outside the read gets 0 from the range check of the load itself — quality 0,
+ * which never counts (min_qual >= 1, src/parse_args.c:170-171) — so no lane clamps an index or tests a range.  Per lane
+ * that leaves: offset, load, quality, window test, class lookup (v_alignbyte on the strand's table), two address adds, two
+ * LDS adds, one add.
  */
 __device__ static __forceinline__ uint32_t acc_walk(const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ keys_sorted,
                                                     const uint32_t *__restrict__ perm, uint32_t n_reads,
@@ -74,50 +81,61 @@ __device__ static __forceinline__ uint32_t acc_walk(const bsc_read_desc *__restr
       /* reads that overlap the tile at all (a read past the candidates starts right of the tile: a > p_last) */
       unsigned long long m = __ballot(d.b >= d.a && d.b >= pa && d.a <= p_last);
       /* per descriptor lane: the read's part of the tile as position offsets lo .. lo + len from pa (meaningless where the
-       * read does not overlap, never used there), and the address of the byte at offset lo */
+       * read does not overlap, never used there) packed with its orientation and MAPQ^2, and the address of the byte at lo */
       const uint32_t lo = (d.a > pa ? d.a : pa) - pa;
-      const uint32_t lolen = lo | (((d.b < p_last ? d.b : p_last) - pa - lo) << 8);
+      const uint32_t pk = lo | (((d.b < p_last ? d.b : p_last) - pa - lo) << 6) | d.meta;
       const uint64_t sp = (uint64_t)(uintptr_t)seq + (uint64_t)(d.base + (int64_t)pa + (int64_t)lo);
-      /* Groups of 4, then 2, then 1 reads: the byte loads of a group are issued back to back and consumed
+      /* Groups of ACC_GROUP, then smaller ones: the byte loads of a group are issued back to back and consumed
        * afterwards, so the wave waits for memory once per group.  Straight-line code per group size: slot
        * conditions inside a group would be evaluated on the VALU. */
       uint32_t cnt = (uint32_t)__builtin_popcountll(m);
-      uint32_t g_byte[4], g_t[4], g_len[4], g_meta[4], g_lut[4];
+      uint32_t g_byte[ACC_GROUP], g_pk[ACC_GROUP], g_lut[ACC_GROUP];
 #define ACC_LOAD(u)                                                                                              \
   {                                                                                                              \
     const int src = __builtin_ctzll(m);                                                                          \
-    m &= m - 1;                                                                                                  \
-    const uint32_t ll = (uint32_t)__builtin_amdgcn_readlane(lolen, src);                                         \
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(src)); /* m &= m - 1 in one scalar instruction */                 \
+    const uint32_t pks = (uint32_t)__builtin_amdgcn_readlane(pk, src);                                           \
     /* v_readlane returns int: without the casts the low word would be sign-extended into the high one */        \
     const uint32_t sp_lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)sp, src);                               \
     const uint32_t sp_hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(sp >> 32), src);                       \
-    const acc_global_bytes p = (acc_global_bytes)(uintptr_t)(((uint64_t)sp_hi << 32) | sp_lo);                   \
-    g_meta[u] = (uint32_t)__builtin_amdgcn_readlane(d.meta, src);                                                \
     g_lut[u] = (uint32_t)__builtin_amdgcn_readlane(d.lut, src);                                                  \
-    g_len[u] = ll >> 8;                                                                                          \
-    g_t[u] = lane_p - (ll & 0xffu); /* lanes below the read wrap to huge values */                               \
-    /* lanes outside the read fetch its last byte in the tile (a valid address, same cache lines) and drop it */ \
-    g_byte[u] = p[g_t[u] < g_len[u] ? g_t[u] : g_len[u]];                                                        \
+    g_pk[u] = pks;                                                                                               \
+    /* raw buffer over the read's bytes in the tile, lo .. lo + len: offsets beyond it (the lanes in front of the   \
+     * read wrap to huge offsets) read as 0 */                                                                   \
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(                                         \
+        (void *)(uintptr_t)(((uint64_t)sp_hi << 32) | sp_lo), 0, (int)(((pks >> 6) & 63u) + 1u), 0x00020000);    \
+    g_byte[u] = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane_p - (pks & 63u)), 0, 0);                      \
   }
 #define ACC_UPDATE(u)                                                                                            \
   {                                                                                                              \
-    const uint32_t byte = g_byte[u], meta = g_meta[u];                                                           \
+    const uint32_t byte = g_byte[u], pks = g_pk[u];                                                              \
     const uint32_t q = byte >> 2;                                                                                \
-    if (g_t[u] <= g_len[u] && q - min_qual < q_span) {                                                           \
+    if (q - min_qual < q_span) { /* q counts iff min_qual <= q < 63 */                                           \
       /* v_alignbyte_b32 shifts by 8 * (byte & 3): the class offset of this base arrives in the low byte */      \
       const uint32_t c4 = __builtin_amdgcn_alignbyte(0u, g_lut[u], byte) & 0xffu;                                \
       char *rc = reinterpret_cast<char *>(row) + c4;                                                             \
       /* fire-and-forget ds_add_u32: the row has a single writer (this lane), no contention */                   \
-      atomicAdd(reinterpret_cast<uint32_t *>(rc + (meta & 32u)), 1u); /* counts[ori][c]++ */                     \
+      atomicAdd(reinterpret_cast<uint32_t *>(rc + ((pks >> 7) & 32u)), 1u); /* counts[ori][c]++ */               \
       atomicAdd(reinterpret_cast<uint32_t *>(rc + 68), q); /* quality[c] += q (integer; converted below) */      \
-      m2sum = __builtin_elementwise_add_sat(m2sum, meta >> 8); /* mapq2 += mapq^2 (v_add_u32 clamp: a sum past   \
+      m2sum = __builtin_elementwise_add_sat(m2sum, pks >> 16); /* mapq2 += mapq^2 (v_add_u32 clamp: a sum past   \
                                                                   2^32 sticks there, so INEXACT cannot be missed) */ \
     }                                                                                                            \
   }
+#if ACC_GROUP == 8
+      for (; cnt >= 8u; cnt -= 8u) {
+        ACC_LOAD(0) ACC_LOAD(1) ACC_LOAD(2) ACC_LOAD(3) ACC_LOAD(4) ACC_LOAD(5) ACC_LOAD(6) ACC_LOAD(7)
+        ACC_UPDATE(0) ACC_UPDATE(1) ACC_UPDATE(2) ACC_UPDATE(3) ACC_UPDATE(4) ACC_UPDATE(5) ACC_UPDATE(6) ACC_UPDATE(7)
+      }
+      if (cnt & 4u) {
+        ACC_LOAD(0) ACC_LOAD(1) ACC_LOAD(2) ACC_LOAD(3)
+        ACC_UPDATE(0) ACC_UPDATE(1) ACC_UPDATE(2) ACC_UPDATE(3)
+      }
+#else
       for (; cnt >= 4u; cnt -= 4u) {
         ACC_LOAD(0) ACC_LOAD(1) ACC_LOAD(2) ACC_LOAD(3)
         ACC_UPDATE(0) ACC_UPDATE(1) ACC_UPDATE(2) ACC_UPDATE(3)
       }
+#endif
       if (cnt & 2u) {
         ACC_LOAD(0) ACC_LOAD(1)
         ACC_UPDATE(0) ACC_UPDATE(1)

@@ -4,10 +4,9 @@
  * which the reference runs serially on its process thread.
  *
  *   bsc_prep_reads_kernel   one thread per template: the reference's asserts on the template; per read the
- *                           leading/trailing scan that finds its first and last countable base (:198-211), the
- *                           orientation it is counted with (:187,224, including the reference's quirk that a skipped
- *                           read 0 does not flip it), a compact descriptor and its sort key (first countable
- *                           position); also the longest read extent of the block.
+ *                           orientation it is counted with (:187,224, including the reference's quirk that a read 0
+ *                           without a countable base does not flip it), a compact descriptor and its sort key (the
+ *                           position of its first base); also the longest read extent of the block.
  *   (sort.hip)              the block's reads ordered by that key on the device.
  *   bsc_tile_lo_kernel      one thread per 64-position wave-tile: binary search for the first read that can reach
  *                           the tile.
@@ -86,11 +85,7 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
     if (terr) {
       atomicMin(&counters[BSC_CNT_ERR], ((unsigned long long)t << 8) | terr);
       bsc_read_desc d;
-      d.a = 1;
-      d.b = 0;
-      d.base = 0;
-      d.meta = 0;
-      d.lut = 0;
+      acc_dead(d);
       rd[2 * (uint64_t)t] = d;
       rd[2 * (uint64_t)t + 1] = d;
       keys[2 * (uint64_t)t] = key_max;
@@ -98,48 +93,42 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
       continue;
     }
     uint32_t ori = tp.orientation & 1u;
-    /* the end bytes of both reads, fetched together: almost every read starts and ends on a countable base, so
-     * the scans below rarely need another load and the thread waits for memory once, not four times */
-    uint32_t e_first[2], e_last[2];
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const uint32_t rl = tp.len[k];
-      e_first[k] = rl ? seq[tp.off[k]] : 0u;
-      e_last[k] = rl ? seq[tp.off[k] + rl - 1] : 0u;
+    /*
+     * The reference walks a read from its first to its last base with a quality other than 0 / 63 (:198-211) and tests every
+     * base in between against min_qual (:217).  The bases it trims off the ends fail that test anyway (0 < min_qual, 63 is
+     * excluded by name), so the device walks the whole read and this kernel does not look for the ends.  What the scan does
+     * decide is whether a read counts as walked at all: only then is the orientation flipped for its mate (:224, and the
+     * `continue`s of :203,:210 in front of it).  That needs the first countable base of read 0 — almost always its first
+     * byte, so one byte per template is fetched here instead of four.
+     */
+    bool walked0 = false;
+    {
+      const uint32_t rl = tp.len[0];
+      const uint8_t *sp = seq + tp.off[0];
+      for (uint32_t j = 0; j < rl; j++) {
+        const uint32_t q = (uint32_t)sp[j] >> 2;
+        if (q > 0 && q != 63u) {
+          walked0 = true;
+          break;
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       bsc_read_desc d;
-      d.a = 1;
-      d.b = 0;
-      d.base = 0;
-      d.meta = 0;
-      d.lut = 0;
+      acc_dead(d);
       const uint32_t rl = tp.len[k];
-      if (rl != 0) {
-        const uint8_t *sp = seq + tp.off[k];
-        uint32_t j = 0;
-        for (; j < rl; j++) { /* :198-201 */
-          const uint32_t q = (j == 0 ? e_first[k] : (uint32_t)sp[j]) >> 2;
-          if (q > 0 && q != 63u) break;
-        }
-        if (j < rl) {
-          const uint32_t first = j;
-          for (j = rl; j > 0; j--) { /* :205-208 */
-            const uint32_t q = (j == rl ? e_last[k] : (uint32_t)sp[j - 1]) >> 2;
-            if (q > 0 && q != 63u) break;
-          }
-          const uint32_t last = j - 1;
-          const uint64_t pa = (uint64_t)tp.pos[k] + first, pb = (uint64_t)tp.pos[k] + last;
-          d.a = pa > 0xffffffffull ? 0xffffffffu : (uint32_t)pa;
+      if (rl != 0 && (k == 1 || walked0)) {
+        const uint64_t pa = (uint64_t)tp.pos[k], pb = (uint64_t)tp.pos[k] + rl - 1u;
+        if (pa <= y) {
+          d.a = (uint32_t)pa;
           d.b = pb > y ? y : (uint32_t)pb; /* pos <= y, :214 */
-          if (pa > y) { d.a = 1; d.b = 0; }
           d.base = (int64_t)tp.off[k] - (int64_t)tp.pos[k];
-          d.meta = (ori << 5) | (((uint32_t)tp.mapq[k] * tp.mapq[k]) << 8);
+          d.meta = ACC_META(ori, tp.mapq[k]);
           d.lut = tp.bs_strand == 0 ? LUT4(0, 1, 2, 3) : (tp.bs_strand == 1 ? LUT4(0, 5, 2, 7) : LUT4(4, 1, 6, 3));
-          ori ^= 1u; /* :224 — only a read that was walked flips the orientation */
         }
       }
+      if (k == 0 && walked0) ori ^= 1u; /* :224 — only a read that was walked flips the orientation */
       rd[2 * (uint64_t)t + k] = d;
       const bool live = d.b >= d.a; /* then x <= a <= b <= y */
       keys[2 * (uint64_t)t + k] = live ? d.a - x : key_max;

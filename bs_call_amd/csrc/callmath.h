@@ -134,6 +134,56 @@ __device__ static __forceinline__ double exp_dev(double x, const uint64_t *tab) 
 }
 
 /*
+ * One term exp(x), x <= 0, of the normalising sum of calc_gt_prob (src/genotype_model.c:240-243: sum += exp(ll[i] - max),
+ * index order, one of the terms being exp(0) = 1 exactly).  Deep coverage puts most arguments below -512, where glibc's
+ * exp leaves its main path; running the whole function for the wave whenever one lane is there doubled the cost of the
+ * loop at 200x (profiles/r03_cfg4_*).  Instead:
+ *   -700 <= x <= -512   glibc's `specialcase` for k < 0 with a result that stays normal (>= 2^-1022, i.e. x > -708.39):
+ *                       scale' = scale * 2^1022, y = scale' + RN(scale' * tmp), result 2^-1022 * y — two roundings where
+ *                       the main path has one fma, so it is evaluated as glibc does, for the wave, only when some lane needs it;
+ *   x < -700            the term is replaced by exp(-700) (the argument is clamped: one v_max_f64): below 2^-1000 either way,
+ *                       and no term below 2^-1000 can change the sum.  Proof: before the term 1.0 is added a partial sum
+ *                       below 2^-53 is absorbed by it (RN(1 + q) = 1), and a partial sum that is not below 2^-53 contains a
+ *                       term >= 2^-57, on whose arrival everything that came before it below 2^-1000 was absorbed
+ *                       (q < ulp / 2); from the 1.0 on the partial sum is >= 1 and absorbs every term below 2^-53.  So the
+ *                       sum has the same bits whatever stands in for the tiny terms (tests/test_gpu_parity.py at 200x /
+ *                       300x / 1400x against the oracle, which evaluates every term with libm).
+ * Anything else that is not in exp_mid's range (never: |x| >= 2^-54 or x == 0 for differences of sums of logs, and a
+ * difference to the maximum is never positive) takes the full function.  tools/check_exp_far.c: the far form equals libm on
+ * 2e8 arguments in [-700, -512].
+ */
+__device__ static __forceinline__ double exp_term_dev(double x, const uint64_t *tab) {
+  double xc; /* max(x, -700) as the one instruction it is (fmax() comes with a canonicalising v_max_f64 x, x in front) */
+  asm("v_max_f64 %0, %1, %2" : "=v"(xc) : "v"(x), "s"(-700.0));
+  const uint32_t hx = (uint32_t)(bsm_bits(xc) >> 32);
+  const bool far = hx >= 0xC0800000u; /* xc <= -512 (a negative double's high word grows with its magnitude) */
+  const bool ok = ((hx & 0x7fffffffu) - 0x3c900000u < 0x40900000u - 0x3c900000u) || x == 0.0; /* 2^-54 <= |xc| < 1024, or 0 */
+  const double kd0 = fma_vs(xc, BSM_EXP_INVLN2N, BSM_EXP_SHIFT);
+  const uint32_t ki = (uint32_t)bsm_bits(kd0);
+  const double kd = kd0 - BSM_EXP_SHIFT;
+  const double r = BSM_FMA(kd, BSM_EXP_NEGLN2LON, BSM_FMA(kd, BSM_EXP_NEGLN2HIN, xc));
+  const ulonglong2 ts = *reinterpret_cast<const ulonglong2 *>(tab + 2u * (ki & 127u));
+  const double tail = bsm_from_bits(ts.x);
+  const uint64_t sbits = ts.y + ((uint64_t)(ki << 13) << 32);
+  const double r2 = r * r;
+  const double p23 = fma_sv(r, BSM_EXP_C3, BSM_EXP_C2);
+  const double p45 = fma_sv(r, BSM_EXP_C5, BSM_EXP_C4);
+  const double t = BSM_FMA(p23, r2, tail + r);
+  const double tmp = BSM_FMA(r2 * r2, p45, t);
+  const double scale = bsm_from_bits(sbits);
+  double y = BSM_FMA(scale, tmp, scale);
+  if (__any(far)) {
+    asm volatile(""); /* keeps this a branch: the block is cheap enough for the compiler to run it for every wave otherwise */
+    const double sc2 = bsm_from_bits(sbits + (1022ull << 52));
+    const double st = sc2 * tmp;
+    const double yf = 0x1p-1022 * (sc2 + st);
+    y = far ? yf : y;
+  }
+  if (__builtin_expect(__any(!ok), 0)) y = ok ? y : bsm_exp_t(x, tab);
+  return y;
+}
+
+/*
  * x / ln(10), correctly rounded (the reference divides by its LOG10 macro, src/genotype_model.c:244).
  * Markstein's theorem: with rc = RN(1/c), q0 = RN(x*rc), r = x - c*q0 (exact in an fma) the value
  * RN(q0 + r*rc) is the correctly rounded quotient, barring underflow in r.  tools/check_div.c compares this

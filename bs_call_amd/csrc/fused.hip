@@ -78,6 +78,54 @@ struct bsc_reads_args {
   uint32_t n_reads, min_qual;
 };
 
+/*
+ * The kernel's one parameter.  The first members are read where the kernel starts and stay in scalar registers; the ones
+ * after `a` are wanted once per tile or less (a pointer for a rare statistics row, the region, the reads-in arguments during
+ * the pile-up phase only), and kept live across the tile loop they were what the register allocator parked in VGPR lanes —
+ * a v_readlane per use, on the VALU, which is this kernel's bottleneck (profiles/r02_e_chain_sq_counters.txt: 108 spilled
+ * SGPRs).  K_COLD reads such a member from the kernel-argument segment where it is used, through a pointer the compiler
+ * cannot see through (so it cannot hoist the load out of the loop either): one s_load on the otherwise idle scalar
+ * memory path.
+ */
+struct bsc_chain_kargs {
+  const uint32_t *cts;
+  const uint8_t *ref;
+  uint8_t *core_out;
+  const bsc_dev_tables *tb;
+  bsc_chain_args a;
+  const uint8_t *dbsnp;
+  uint32_t *het_list;
+  unsigned long long *counters;
+  const uint32_t *carry_in;
+  uint32_t *carry_out;
+  unsigned long long *stat_words, *pair_cells, *ovf_list;
+  uint8_t *aux_out;
+  bsc_reads_args ra;
+};
+typedef const __attribute__((address_space(4))) bsc_chain_kargs *bsc_kargs_p;
+#define K_COLD(f)                                                                    \
+  ({                                                                                 \
+    bsc_kargs_p p_ = (bsc_kargs_p)__builtin_amdgcn_kernarg_segment_ptr();            \
+    asm volatile("" : "+s"(p_));                                                     \
+    p_->f;                                                                           \
+  })
+
+/* the reads-in arguments, member by member (a struct cannot be copied out of the constant address space as a whole) */
+#define K_LOAD_RA(ra)                                                                \
+  bsc_reads_args ra;                                                                 \
+  {                                                                                  \
+    bsc_kargs_p p_ = (bsc_kargs_p)__builtin_amdgcn_kernarg_segment_ptr();            \
+    asm volatile("" : "+s"(p_));                                                     \
+    ra.rd = p_->ra.rd;                                                               \
+    ra.keys_sorted = p_->ra.keys_sorted;                                             \
+    ra.perm = p_->ra.perm;                                                           \
+    ra.seq = p_->ra.seq;                                                             \
+    ra.tile_lo = p_->ra.tile_lo;                                                     \
+    ra.f_scratch = p_->ra.f_scratch;                                                 \
+    ra.n_reads = p_->ra.n_reads;                                                     \
+    ra.min_qual = p_->ra.min_qual;                                                   \
+  }
+
 struct bsc_vcf_core_f {
   uint32_t pos;
   uint8_t emit, gt, ref_code, gt_enc, flt, phred, n_gl;
@@ -283,13 +331,12 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
 }
 
 template <bool FULL, bool READS>
-__global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
-    const uint32_t *__restrict__ cts, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dbsnp,
-    const bsc_chain_args a, const bsc_dev_tables *__restrict__ tb, uint8_t *__restrict__ core_out,
-    uint32_t *__restrict__ het_list, unsigned long long *__restrict__ counters,
-    const uint32_t *__restrict__ carry_in, uint32_t *__restrict__ carry_out, unsigned long long *__restrict__ stat_words,
-    unsigned long long *__restrict__ pair_cells, unsigned long long *__restrict__ ovf_list, uint8_t *__restrict__ aux_out,
-    const bsc_reads_args ra) {
+__global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_chain_kargs K) {
+  const uint32_t *__restrict__ const cts = K.cts;
+  const uint8_t *__restrict__ const ref = K.ref;
+  uint8_t *__restrict__ const core_out = K.core_out;
+  const bsc_dev_tables *__restrict__ const tb = K.tb;
+  const bsc_chain_args &a = K.a;
   __shared__ __attribute__((aligned(16))) uint32_t lds_slot[FW][SLOT_DW];
   __shared__ double s_k[44], s_lnk[44], s_half[44], s_one[44];
   __shared__ double s_logtab[256];
@@ -349,15 +396,15 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
   const uint32_t T_first = a.tile_begin + blockIdx.x * FW + wid;
   /* heterozygous calls waiting for Fisher's test (window index | max_gt << 28): the wave's own list in HBM, one in ~1 000
    * positions; a.het_cap entries hold every position the wave can meet */
-  uint32_t *wl = het_list + (uint64_t)(blockIdx.x * FW + wid) * a.het_cap * (READS ? F_HET_DW : 1u);
+#define F_WL() (K_COLD(het_list) + (uint64_t)(blockIdx.x * FW + wid) * K_COLD(a.het_cap) * (READS ? F_HET_DW : 1u))
   unsigned n_pend = 0; /* wave-uniform */
   /* READS: the first batch of candidate reads of the wave's next tile (requested a tile ahead) */
   uint32_t acc_t0 = 0, acc_kv = 0xffffffffu;
   bsc_read_desc acc_d;
   acc_dead(acc_d);
   unsigned inexact = 0;
-  const uint32_t q_span = ra.min_qual < 63u ? 63u - ra.min_qual : 0u; /* q counts iff min_qual <= q < 63 (src/call_genotypes.c:217) */
   if (READS && T_first < a.tile_end) {
+    K_LOAD_RA(ra);
     acc_t0 = ra.tile_lo[T_first];
     acc_fetch(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, acc_t0, lane0, acc_kv, acc_d);
   }
@@ -403,6 +450,8 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     if (READS) {
       /* ---- HOT LOOP A for the tile's 64 sites (src/call_genotypes.c:180-226; accdev.h): the pile-up the calling
        * statements read is built in the wave's slot and never leaves it ---- */
+      K_LOAD_RA(ra);
+      const uint32_t q_span = ra.min_qual < 63u ? 63u - ra.min_qual : 0u; /* q counts iff min_qual <= q < 63 (src/call_genotypes.c:217) */
       const uint32_t T_next = T + gridDim.x * FW;
       if (T_next < a.tile_end) acc_t0n = ra.tile_lo[T_next];
       const uint32_t loff = b0 < 0 ? (uint32_t)(-b0) : 0u; /* lanes in front of the block's first position (0 .. 2) */
@@ -478,7 +527,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
           uint32_t f[8];
           if (__builtin_expect(bigf_any, 0)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the lane's own stores to the scratch lines */
-            const uint32_t *fs = ra.f_scratch + ((uint64_t)(blockIdx.x * FW + wid) * 64u + lane) * 8u;
+            const uint32_t *fs = K_COLD(ra.f_scratch) + ((uint64_t)(blockIdx.x * FW + wid) * 64u + lane) * 8u;
 #pragma unroll
             for (int j = 0; j < 8; j++) f[j] = __hip_atomic_load(&fs[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           } else {
@@ -489,7 +538,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
               f[4 + j] = (st.y >> (8 * j)) & 0xffu;
             }
           }
-          uint4 *e = reinterpret_cast<uint4 *>(wl + (uint64_t)(n_pend + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) * F_HET_DW);
+          uint4 *e = reinterpret_cast<uint4 *>(F_WL() + (uint64_t)(n_pend + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) * F_HET_DW);
           e[0] = make_uint4((uint32_t)jw | ((uint32_t)mxi << 28), f[0], f[1], f[2]);
           e[1] = make_uint4(f[3], f[4], f[5], f[6]);
           e[2] = make_uint4(f[7], cnt[0], cnt[1], cnt[2]);
@@ -572,11 +621,12 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
         }
       }
       const int rfix = (int)(rr[2] & 0xffu);
+      const uint8_t *const dbsnp = K_COLD(dbsnp);
       const uint32_t rs_found = (dbsnp && inner) ? (uint32_t)dbsnp[jw] : 0u;
       int ga, gb;
       f_alleles(gt, ga, gb);
       const bool het = ga != gb;
-      bool skp = !a.all_positions && !(rs_found & 2u) && ((gt == 0 && rfix == 1) || (gt == 9 && rfix == 4));
+      bool skp = !K_COLD(a.all_positions) && !(rs_found & 2u) && ((gt == 0 && rfix == 1) || (gt == 9 && rfix == 4));
       /* phred (:140-148) */
       const double z1 = exp_dev(la[gt] * BSM_LN10, (const uint64_t *)s_exptab);
       int phred;
@@ -590,7 +640,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
       /* FS = (int)(-0.0 * 10.0 + 0.5) = 0: fisher_strand is 0 unless gt_het[max_gt]; those go to bsc_chain_het_kernel */
       const uint32_t qd = dp1 > 0 ? (uint32_t)phred / dp1 : (uint32_t)phred;
       const uint32_t pos = pos0 + lane;
-      if (!skp) skp = pos < a.reg_start || pos > a.reg_stop;
+      if (!skp) skp = pos < K_COLD(a.reg_start) || pos > K_COLD(a.reg_stop);
       /* CpG status (:227-266) */
       uint32_t cg = '.';
       {
@@ -674,9 +724,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
       }
     }
     spd[lane] = (pend ? 1u : 0u) | (flt << 8);
-    if (a.depth_off && inner) { /* total depth of every position that reached the printer (the key of gt_cov_stats) */
+    const uint32_t depth_off = K_COLD(a.depth_off);
+    if (depth_off && inner) { /* total depth of every position that reached the printer (the key of gt_cov_stats) */
       const uint32_t dpt = dp1 + d_inf;
-      reinterpret_cast<uint16_t *>(het_list + a.depth_off)[jw] = (uint16_t)(od[0] ? (dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u) : 0u);
+      reinterpret_cast<uint16_t *>(K_COLD(het_list) + depth_off)[jw] = (uint16_t)(od[0] ? (dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u) : 0u);
     }
     WAVE_LDS_SYNC();
     /* ---- results: the tile's 60 records, staged in the slot (every la[] read is done: the sync above), leave
@@ -699,11 +750,13 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
         const unsigned idx = k * 64u + lane;
         if (idx < nvec) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(so)[idx], dst + idx);
       }
+      uint8_t *const aux_out = K_COLD(aux_out);
       if (aux_out) { /* what the encoder of a written record reads besides the core record (src/print_vcf.c:306-359): MC8 counts,
                       * AMQ qualities, MQ, mean quality, max_gt, the dbSNP flag — the second half of a bsc_vcf_rec */
         WAVE_LDS_SYNC();
         if (lane >= 2u && lane < 62u) {
-          const uint32_t rsf = (dbsnp && inner) ? (uint32_t)dbsnp[jw] : 0u;
+          const uint8_t *const dbs = K_COLD(dbsnp);
+          const uint32_t rsf = (dbs && inner) ? (uint32_t)dbs[jw] : 0u;
           const bool hasrec = od[0] != 0u;
           so[(lane - 2u) * 4u + 0] = hasrec ? make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]) : make_uint4(0u, 0u, 0u, 0u);
           so[(lane - 2u) * 4u + 1] = hasrec ? make_uint4(cnt[4], cnt[5], cnt[6], cnt[7]) : make_uint4(0u, 0u, 0u, 0u);
@@ -723,7 +776,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     if (!READS) {
       const unsigned long long m = __ballot(defer);
       if (m) {
-        if (defer) wl[n_pend + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)jw | ((uint32_t)mxi << 28);
+        if (defer) F_WL()[n_pend + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)jw | ((uint32_t)mxi << 28);
         n_pend += (unsigned)__popcll(m);
       }
     }
@@ -739,7 +792,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
 #endif
     if (READS) { /* the first batch of the wave's next tile: on its way while the histograms are updated */
       acc_t0 = acc_t0n;
-      if (T + gridDim.x * FW < a.tile_end) acc_fetch(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, acc_t0, lane, acc_kv, acc_d);
+      if (T + gridDim.x * FW < a.tile_end) {
+        K_LOAD_RA(ra);
+        acc_fetch(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, acc_t0, lane, acc_kv, acc_d);
+      }
     }
     if (a.with_stats) {
       /* ---- the statistics block (src/print_vcf.c:386-525; sitestats.hip has the restatement) for the tile ----
@@ -752,6 +808,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
           atomicAdd(&h[SS_COV + st_cdp * 6u], 1u);
           if (st_emit) atomicAdd(&h[SS_COV + st_cdp * 6u + 1u], 1u);
         } else {
+          unsigned long long *const stat_words = K_COLD(stat_words);
           atomicAdd(&stat_words[SS_COV + (uint64_t)st_cdp * 6u], 1ull);
           if (st_emit) atomicAdd(&stat_words[SS_COV + (uint64_t)st_cdp * 6u + 1u], 1ull);
         }
@@ -785,6 +842,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
             bool p_ok;
             uint32_t p_flt;
             if (jw == 0 && a.lc == 0) { /* first position of a block: the previous block's pending cytosine, if adjacent */
+              const uint32_t *const carry_in = K_COLD(carry_in);
               const uint32_t p_pos = carry_in[0];
               p_ok = p_pos != 0 && st_pos - p_pos == 1u;
               p_flt = carry_in[1];
@@ -802,9 +860,9 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
             if (pair_pass) atomicAdd(&h[SS_MISC + 11 + rsel], 1u);
             atomicAdd(&h[SS_QUAL + 2u * 256u + (st_refcpg ? 0u : 256u) + st_phred], 1u);
             if (st_cdp < F_COV_LDS) atomicAdd(&h[SS_COV + st_cdp * 6u + (st_refcpg ? 2u : 3u)], 1u);
-            else atomicAdd(&stat_words[SS_COV + (uint64_t)st_cdp * 6u + (st_refcpg ? 2u : 3u)], 1ull);
+            else atomicAdd(&K_COLD(stat_words)[SS_COV + (uint64_t)st_cdp * 6u + (st_refcpg ? 2u : 3u)], 1ull);
             if (st_cinf < F_COV_LDS) atomicAdd(&h[SS_COV + st_cinf * 6u + (st_refcpg ? 4u : 5u)], 1u);
-            else atomicAdd(&stat_words[SS_COV + (uint64_t)st_cinf * 6u + (st_refcpg ? 4u : 5u)], 1ull);
+            else atomicAdd(&K_COLD(stat_words)[SS_COV + (uint64_t)st_cinf * 6u + (st_refcpg ? 4u : 5u)], 1ull);
             if (st_ma + st_mb != 0) { /* methylation posterior (:492-515): counted per (a, b), evaluated when read */
               if (st_ma < F_PAIR && st_mb < F_PAIR) {
                 const uint32_t cell = (rsel * F_PAIR + st_ma) * F_PAIR + st_mb;
@@ -812,12 +870,13 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
                 if (pass) atomicAdd(&s_pair[cell + F_PAIR * F_PAIR], 1u);
               } else if (st_ma < SS_PAIR_G && st_mb < SS_PAIR_G) {
                 const uint32_t cell = (rsel * SS_PAIR_G + st_ma) * SS_PAIR_G + st_mb;
+                unsigned long long *const pair_cells = K_COLD(pair_cells);
                 atomicAdd(&pair_cells[cell], 1ull);
                 if (pass) atomicAdd(&pair_cells[cell + SS_PAIR_G * SS_PAIR_G], 1ull);
               } else {
-                const unsigned long long k = atomicAdd(&counters[BSC_CNT_OVF], 1ull);
-                if (k < a.ovf_cap)
-                  ovf_list[k] = (unsigned long long)st_ma | ((unsigned long long)st_mb << 24) |
+                const unsigned long long k = atomicAdd(&K_COLD(counters)[BSC_CNT_OVF], 1ull);
+                if (k < K_COLD(a.ovf_cap))
+                  K_COLD(ovf_list)[k] = (unsigned long long)st_ma | ((unsigned long long)st_mb << 24) |
                                 ((unsigned long long)(st_refcpg ? 1u : 0u) << 48) | ((unsigned long long)(pass ? 1u : 0u) << 49);
               }
             }
@@ -836,6 +895,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
       }
       /* the window's last position is the pending cytosine, or not, for whatever follows */
       if (jw == (int32_t)a.n - 1 && lane >= 2u && lane < 62u) {
+        uint32_t *const carry_out = K_COLD(carry_out);
         carry_out[0] = pend ? pos0 + lane : 0u;
         carry_out[1] = pend ? flt : 0u;
       }
@@ -847,7 +907,11 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
   /* ---- the wave's heterozygous calls: Fisher's exact test, 64 at a time ----
    * A het is one position in ~1 000: tested inside its tile it would idle 63 lanes for the length of Fisher's loops in
    * every such tile, tested by a kernel of its own it costs a launch and a drained device per window. */
+  unsigned long long *const counters = K_COLD(counters);
+  unsigned long long *const stat_words = K_COLD(stat_words);
   if (n_pend) {
+    uint32_t *const wl = F_WL();
+    const uint8_t *const dbsnp = K_COLD(dbsnp);
     if (lane0 == 0) atomicAdd(&s_cnt[11], n_pend);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the wave's records and its list are in memory */
     for (unsigned k0 = 0; k0 < n_pend; k0 += 64u) {
@@ -874,7 +938,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(
     for (unsigned i = tid; i < 4 * F_PAIR * F_PAIR; i += 64 * FW)
       if (s_pair[i]) { /* LDS cell [q][a][b] -> the context's [q][SS_PAIR_G][SS_PAIR_G] table */
         const unsigned q = i / (F_PAIR * F_PAIR), ab = i % (F_PAIR * F_PAIR);
-        atomicAdd(&pair_cells[(q * SS_PAIR_G + ab / F_PAIR) * SS_PAIR_G + ab % F_PAIR], (unsigned long long)s_pair[i]);
+        atomicAdd(&K_COLD(pair_cells)[(q * SS_PAIR_G + ab / F_PAIR) * SS_PAIR_G + ab % F_PAIR], (unsigned long long)s_pair[i]);
       }
   }
 }
@@ -978,11 +1042,23 @@ static int chain_launch_t(const bsc_chain_launch *L) {
   }
   unsigned long long *words = (unsigned long long *)L->stats;
   if (L->ev_start) (void)hipEventRecord((hipEvent_t)L->ev_start, s);
-#define CHAIN_ARGS(A)                                                                                               \
-  (const uint32_t *)L->cts, (const uint8_t *)L->ref, (const uint8_t *)L->dbsnp, A, (const bsc_dev_tables *)L->tb,   \
-      (uint8_t *)L->core_out, (uint32_t *)L->het_list, (unsigned long long *)L->counters,                           \
-      (const uint32_t *)L->carry_in, (uint32_t *)L->carry_out, words, (unsigned long long *)L->pairs,               \
-      (unsigned long long *)L->ovf_list, (uint8_t *)L->aux_out, ra
+  bsc_chain_kargs K;
+  memset(&K, 0, sizeof K);
+  K.cts = (const uint32_t *)L->cts;
+  K.ref = (const uint8_t *)L->ref;
+  K.core_out = (uint8_t *)L->core_out;
+  K.tb = (const bsc_dev_tables *)L->tb;
+  K.dbsnp = (const uint8_t *)L->dbsnp;
+  K.het_list = (uint32_t *)L->het_list;
+  K.counters = (unsigned long long *)L->counters;
+  K.carry_in = (const uint32_t *)L->carry_in;
+  K.carry_out = (uint32_t *)L->carry_out;
+  K.stat_words = words;
+  K.pair_cells = (unsigned long long *)L->pairs;
+  K.ovf_list = (unsigned long long *)L->ovf_list;
+  K.aux_out = (uint8_t *)L->aux_out;
+  K.ra = ra;
+#define CHAIN_ARGS(A) (K.a = (A), K)
   if (t_hi > t_lo) {
     a.tile_begin = t_lo;
     a.tile_end = t_hi;

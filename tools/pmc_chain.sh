@@ -15,7 +15,7 @@ import csv,glob
 agg={}
 for f in glob.glob('$OUT/p*/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'bsc_chain_kernel_t<true>' not in r['Kernel_Name'] and 'chain_kernel_tILb1' not in r['Kernel_Name']: continue
+        if 'bsc_chain_kernel_t<true' not in r['Kernel_Name'] and 'chain_kernel_tILb1' not in r['Kernel_Name']: continue
         k=(r['Counter_Name'],r['Dispatch_Id'])
         agg[k]=agg.get(k,0)+float(r['Counter_Value'])
 per={}
