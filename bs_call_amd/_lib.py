@@ -33,6 +33,8 @@ EXPORTS = (
     "bsc_vcf_format_rec",
     "bsc_vcf_compact_device",
     "bsc_block_records",
+    "bsc_block_records_submit",
+    "bsc_block_records_fetch",
     "bsc_vcf_stats",
     "bsc_vcf_stats_device",
     "bsc_get_site_stats",
@@ -340,6 +342,10 @@ def load():
     L.bsc_block_records.restype = i32
     L.bsc_block_records.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, C.POINTER(VcfParams), i32, vp, u64,
                                     C.POINTER(C.c_uint64)]
+    L.bsc_block_records_submit.restype = i32
+    L.bsc_block_records_submit.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, C.POINTER(VcfParams), i32, vp, u64]
+    L.bsc_block_records_fetch.restype = i32
+    L.bsc_block_records_fetch.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.bsc_vcf_format_rec.restype = i32
     L.bsc_vcf_format_rec.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
     L.bsc_vcf_stats_device.restype = i32

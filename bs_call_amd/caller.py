@@ -266,6 +266,36 @@ class SiteCaller:
                                          len(out), C.byref(cnt)))
         return out[: cnt.value]
 
+    def block_records_submit(self, templates, seq, x, y, ref, out, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None,
+                             with_stats=False):
+        """Queue one block (reads -> packed records into `out`, a VCF_REC array that must stay alive until the fetch) and
+        return at once; the inputs may be reused immediately.  block_records_fetch() completes it."""
+        templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        n = int(y) - int(x) + 1
+        if len(ref) != n + 2:
+            raise ValueError("ref must have y - x + 3 entries (x .. y + 2)")
+        db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+        if db is not None and len(db) != n:
+            raise ValueError("dbsnp must have y - x + 1 entries")
+        if out.dtype != VCF_REC or not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]:
+            raise ValueError("out must be a writable C-contiguous VCF_REC array")
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        _check(self._L.bsc_block_records_submit(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref),
+                                                None if db is None else _ptr(db), C.byref(p), 1 if with_stats else 0, _ptr(out), len(out)))
+        self._pending_rec = out
+
+    def block_records_fetch(self):
+        """Wait for the submitted block: VCF_REC[n_written] (a view of the array named at submit)."""
+        out = getattr(self, "_pending_rec", None)
+        if out is None:
+            raise BscError(-1, "block_records_fetch: no block was submitted")
+        self._pending_rec = None
+        cnt = C.c_uint64(0)
+        _check(self._L.bsc_block_records_fetch(self._h, C.byref(cnt)))
+        return out[: cnt.value]
+
     def vcf_compact_device(self, d_core, d_gtm, stride, n, d_out, out_cap, d_count, d_dbsnp=None, stream=None):
         _check(self._L.bsc_vcf_compact_device(self._h, d_core, d_gtm, stride, d_dbsnp, n, d_out, out_cap, d_count, stream))
 

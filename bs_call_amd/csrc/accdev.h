@@ -121,7 +121,22 @@ __device__ static __forceinline__ uint32_t acc_walk(const bsc_read_desc *__restr
                                                                   2^32 sticks there, so INEXACT cannot be missed) */ \
     }                                                                                                            \
   }
-#if ACC_GROUP == 8
+#if ACC_GROUP == 16
+      for (; cnt >= 16u; cnt -= 16u) {
+        ACC_LOAD(0) ACC_LOAD(1) ACC_LOAD(2) ACC_LOAD(3) ACC_LOAD(4) ACC_LOAD(5) ACC_LOAD(6) ACC_LOAD(7)
+        ACC_LOAD(8) ACC_LOAD(9) ACC_LOAD(10) ACC_LOAD(11) ACC_LOAD(12) ACC_LOAD(13) ACC_LOAD(14) ACC_LOAD(15)
+        ACC_UPDATE(0) ACC_UPDATE(1) ACC_UPDATE(2) ACC_UPDATE(3) ACC_UPDATE(4) ACC_UPDATE(5) ACC_UPDATE(6) ACC_UPDATE(7)
+        ACC_UPDATE(8) ACC_UPDATE(9) ACC_UPDATE(10) ACC_UPDATE(11) ACC_UPDATE(12) ACC_UPDATE(13) ACC_UPDATE(14) ACC_UPDATE(15)
+      }
+      if (cnt & 8u) {
+        ACC_LOAD(0) ACC_LOAD(1) ACC_LOAD(2) ACC_LOAD(3) ACC_LOAD(4) ACC_LOAD(5) ACC_LOAD(6) ACC_LOAD(7)
+        ACC_UPDATE(0) ACC_UPDATE(1) ACC_UPDATE(2) ACC_UPDATE(3) ACC_UPDATE(4) ACC_UPDATE(5) ACC_UPDATE(6) ACC_UPDATE(7)
+      }
+      if (cnt & 4u) {
+        ACC_LOAD(0) ACC_LOAD(1) ACC_LOAD(2) ACC_LOAD(3)
+        ACC_UPDATE(0) ACC_UPDATE(1) ACC_UPDATE(2) ACC_UPDATE(3)
+      }
+#elif ACC_GROUP == 8
       for (; cnt >= 8u; cnt -= 8u) {
         ACC_LOAD(0) ACC_LOAD(1) ACC_LOAD(2) ACC_LOAD(3) ACC_LOAD(4) ACC_LOAD(5) ACC_LOAD(6) ACC_LOAD(7)
         ACC_UPDATE(0) ACC_UPDATE(1) ACC_UPDATE(2) ACC_UPDATE(3) ACC_UPDATE(4) ACC_UPDATE(5) ACC_UPDATE(6) ACC_UPDATE(7)

@@ -114,6 +114,14 @@ struct bsc_context {
   const bsc_template *blk_tpl; /* NULL: the templates are only on the device (bsc_accumulate_device), at blk_d_tpl */
   const void *blk_d_tpl;
   uint32_t blk_x;
+  /* bsc_block_records / _submit / _fetch: the pinned {INEXACT, ERR, RECORDS} block, the destination of the block in flight,
+   * how many records were copied ahead of the count, the share of positions with a record the next copy is sized from */
+  unsigned long long *h_cnt;
+  bsc_vcf_rec *rec_out;
+  uint64_t rec_cap, rec_copied;
+  uint32_t rec_sz;
+  int rec_pending;
+  double rec_share;
   void *d_fscr; /* reads-in chain: forward-count scratch lines of the resident waves */
   size_t cap_fscr;
   hipEvent_t ev_rchain[2]; /* bsc_set_profiling: the reads-in chain's launches (read descriptors, ordering, tile search, chain) */
@@ -259,6 +267,7 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
   ctx->device = dev;
   ctx->num_cus = prop.multiProcessorCount;
   ctx->max_launch = BSC_MAX_LAUNCH;
+  ctx->rec_share = 0.55; /* WGBS: a record for every C and G and little else */
   {
     const char *ml = getenv("BSC_MAX_LAUNCH_SITES");
     if (ml && *ml) {
@@ -343,6 +352,7 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_vout);
   hipFree(ctx->d_vdb);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
+  if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
   for (int r = 0; r < BSC_EV_RING; r++)
     for (int i = 0; i < 3; i++)
       if (ctx->ev[r][i]) hipEventDestroy(ctx->ev[r][i]);
@@ -1102,7 +1112,7 @@ int bsc_last_chain_ms(bsc_context *ctx, float *ms) {
 int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_gtm, uint32_t gtm_stride,
                            const void *d_dbsnp, uint32_t n, void *d_out, uint64_t out_cap, void *d_count, void *stream) {
   if (!ctx || !d_count) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_compact_device: NULL argument");
-  int rc = bsc_check_stride(gtm_stride);
+  int rc = gtm_stride ? bsc_check_stride(gtm_stride) : BSC_OK; /* 0: d_gtm is the chain's aux array (bsc_reads_chain_device) */
   if (rc) return rc;
   BSC_ENTER(ctx);
   if (n == 0) {
@@ -1124,46 +1134,139 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
   return BSC_OK;
 }
 
+/*
+ * One block, reads in -> packed written records out, on the reads-in chain (bsc_reads_chain_queue): H2D of the block,
+ * template checks + ordering, ONE kernel from reads to records (+ the second half of every bsc_vcf_rec), packing, and
+ * the copy-out — all queued back to back; the host waits ONCE, for the verdict on the templates, the record count and the
+ * records together.  The copy-out is sized before the count is known, from the share of positions the previous blocks
+ * wrote a record for (WGBS: every C and G, about half); only a block that writes more than that pays a second copy.
+ */
+static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
+                             uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                             bsc_vcf_rec *out, uint64_t out_cap, int stage) {
+  if (y < x) return bsc_fail(BSC_ERR_ARG, "accumulate: y (%u) < x (%u) (reference asserts y >= x)", y, x);
+  if (nr && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "accumulate: NULL template or read buffer");
+  const uint64_t sz64 = (uint64_t)y - x + 1;
+  if (sz64 > 0x0fffffffull) return bsc_fail(BSC_ERR_ARG, "bsc_block_records: block longer than 2^28 - 1 positions");
+  const uint32_t sz = (uint32_t)sz64;
+  BSC_ENTER(ctx);
+  int rc;
+  if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)sz + 2))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)sz * 64u))) return rc; /* the chain's aux array */
+  if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)sz * sizeof(bsc_vcf_core)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_recs, &ctx->cap_recs, (size_t)(out_cap ? out_cap : 1) * sizeof(bsc_vcf_rec)))) return rc;
+  if (dbsnp && (rc = bsc_reserve(&ctx->d_vdb, &ctx->cap_vdb, (size_t)sz))) return rc;
+  if (!ctx->h_cnt && hipHostMalloc((void **)&ctx->h_cnt, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
+    return bsc_fail(BSC_ERR_NOMEM, "bsc_block_records: pinned counter block");
+  if (stage) { /* the caller may recycle its buffers as soon as the call returns: inputs go through the pinned staging area */
+    const size_t b_tpl = (size_t)nr * sizeof(bsc_template), b_seq = (size_t)seq_bytes, b_ref = (size_t)sz + 2, b_db = dbsnp ? (size_t)sz : 0;
+    const size_t o_seq = (b_tpl + 63u) & ~(size_t)63u, o_ref = (o_seq + b_seq + 63u) & ~(size_t)63u, o_db = (o_ref + b_ref + 63u) & ~(size_t)63u;
+    if ((rc = bsc_stage_reserve(ctx, o_db + b_db + 64u))) return rc;
+    char *st = ctx->h_stage;
+    if (nr) {
+      memcpy(st, tpl, b_tpl);
+      memcpy(st + o_seq, seq, b_seq);
+      tpl = (const bsc_template *)st;
+      seq = (const uint8_t *)(st + o_seq);
+    }
+    memcpy(st + o_ref, ref, b_ref);
+    ref = (const uint8_t *)(st + o_ref);
+    if (dbsnp) {
+      memcpy(st + o_db, dbsnp, b_db);
+      dbsnp = (const uint8_t *)(st + o_db);
+    }
+  }
+  hipStream_t s = ctx->stream;
+  ctx->blk_tpl = tpl;
+  ctx->blk_d_tpl = ctx->d_tpl;
+  ctx->blk_x = x;
+  if (nr) {
+    HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz + 2, hipMemcpyHostToDevice, s));
+  if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, dbsnp, (size_t)sz, hipMemcpyHostToDevice, s));
+  void *d_db = dbsnp ? ctx->d_vdb : NULL;
+  if ((rc = bsc_reads_chain_queue(ctx, ctx->d_tpl, nr, ctx->d_seq, seq_bytes, x, y, ctx->d_ref, d_db, params, with_stats, ctx->d_vout,
+                                  ctx->d_out, s)))
+    return rc;
+  unsigned long long *d_total = ctx->d_counters + BSC_CNT_RECORDS;
+  if ((rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 0, d_db, sz, ctx->d_recs, out_cap, d_total, s))) return rc;
+  /* INEXACT, ERR, RECORDS are consecutive counter words: the verdict and the count in one small copy */
+  HIP_TRY(hipMemcpyAsync(ctx->h_cnt, ctx->d_counters + BSC_CNT_INEXACT, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  uint64_t guess = (uint64_t)((double)sz * ctx->rec_share) + 4096u;
+  if (guess > out_cap) guess = out_cap;
+  if (guess > sz) guess = sz;
+  if (guess) HIP_TRY(hipMemcpyAsync(out, ctx->d_recs, (size_t)guess * sizeof(bsc_vcf_rec), hipMemcpyDeviceToHost, s));
+  ctx->rec_out = out;
+  ctx->rec_cap = out_cap;
+  ctx->rec_copied = guess;
+  ctx->rec_sz = sz;
+  return BSC_OK;
+}
+
+/* the one wait of a block queued by bsc_records_queue, and what is left to do after it */
+static int bsc_records_finish(bsc_context *ctx, uint64_t *n_out) {
+  *n_out = 0;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  int inexact = 0;
+  int rc = bsc_verdict(ctx, ctx->h_cnt, &inexact); /* h_cnt = {INEXACT, ERR, RECORDS} */
+  if (rc) return rc; /* an invalid template: the contents of `out` are unspecified */
+  const unsigned long long total = ctx->h_cnt[2];
+  *n_out = total;
+  if (total > ctx->rec_cap)
+    return bsc_fail(BSC_ERR_ARG, "bsc_block_records: the block has %llu records, out_cap is %llu", total,
+                    (unsigned long long)ctx->rec_cap);
+  if (total > ctx->rec_copied) { /* more records than the share so far suggested: the rest in a second copy */
+    HIP_TRY(hipMemcpyAsync((char *)ctx->rec_out + (size_t)ctx->rec_copied * sizeof(bsc_vcf_rec),
+                           (const char *)ctx->d_recs + (size_t)ctx->rec_copied * sizeof(bsc_vcf_rec),
+                           (size_t)(total - ctx->rec_copied) * sizeof(bsc_vcf_rec), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  if (ctx->rec_sz >= 4096u) { /* the share the next block's copy-out is sized from: this block's, plus 2 % */
+    const double share = (double)total / (double)ctx->rec_sz * 1.02;
+    ctx->rec_share = share > 1.0 ? 1.0 : share;
+  }
+  return bsc_inexact_status(inexact);
+}
+
 int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                       uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
                       int with_stats, bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out) {
   if (!ctx || !ref || !params || !n_out || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records: NULL argument");
   *n_out = 0;
-  int rc = bsc_accumulate_queue(ctx, tpl, nr, seq, seq_bytes, x, y);
+  if (ctx->rec_pending) return bsc_fail(BSC_ERR_ARG, "bsc_block_records: a submitted block has not been fetched");
+  int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 0);
   if (rc) return rc;
-  const uint64_t sz64 = (uint64_t)y - x + 1;
-  if (sz64 > 0xfffffff0ull) return bsc_fail(BSC_ERR_ARG, "bsc_block_records: block too long");
-  const uint32_t sz = (uint32_t)sz64;
-  if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)sz + 2))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)sz * 200u))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)sz))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)sz * sizeof(bsc_vcf_core)))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_recs, &ctx->cap_recs, (size_t)(out_cap ? out_cap : 1) * sizeof(bsc_vcf_rec)))) return rc;
-  if (dbsnp && (rc = bsc_reserve(&ctx->d_vdb, &ctx->cap_vdb, (size_t)sz))) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz + 2, hipMemcpyHostToDevice, ctx->stream));
-  if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, dbsnp, (size_t)sz, hipMemcpyHostToDevice, ctx->stream));
-  int inexact = 0;
-  if ((rc = bsc_block_check(ctx, &inexact))) return rc; /* nothing is written for a bad block */
-  void *d_db = dbsnp ? ctx->d_vdb : NULL;
-  if ((rc = bsc_call_sites_device(ctx, ctx->d_cts, ctx->d_ref, sz, ctx->d_out, 200, ctx->d_skip, ctx->stream))) return rc;
-  if ((rc = bsc_vcf_records_device(ctx, ctx->d_out, 200, ctx->d_skip, ctx->d_ref, d_db, sz, x, params, ctx->d_vout, ctx->stream)))
+  BSC_ENTER(ctx);
+  return bsc_records_finish(ctx, n_out);
+}
+
+/* The split form: queue the block and return (the inputs are staged, so the caller's buffers are free at once; `out` must
+ * stay valid until the fetch); bsc_block_records_fetch waits and completes it. */
+int bsc_block_records_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
+                             uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                             bsc_vcf_rec *out, uint64_t out_cap) {
+  if (!ctx || !ref || !params || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_submit: NULL argument");
+  if (ctx->rec_pending || ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_submit: the previous block has not been fetched");
+  int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 1);
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream); /* nothing may still read the staging area when the next block is staged */
     return rc;
-  if (with_stats && (rc = bsc_vcf_stats_device(ctx, ctx->d_vout, ctx->d_out, 200, d_db, sz, ctx->stream))) return rc;
-  unsigned long long *d_total = ctx->d_counters + BSC_CNT_RECORDS;
-  if ((rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 200, d_db, sz, ctx->d_recs, out_cap, d_total, ctx->stream)))
-    return rc;
-  unsigned long long total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  *n_out = total;
-  if (total > out_cap)
-    return bsc_fail(BSC_ERR_ARG, "bsc_block_records: the block has %llu records, out_cap is %llu", total,
-                    (unsigned long long)out_cap);
-  if (total) {
-    HIP_TRY(hipMemcpyAsync(out, ctx->d_recs, (size_t)total * sizeof(bsc_vcf_rec), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
-  return bsc_inexact_status(inexact);
+  ctx->rec_pending = 1;
+  return BSC_OK;
+}
+
+int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out) {
+  if (!ctx || !n_out) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_fetch: NULL argument");
+  *n_out = 0;
+  if (!ctx->rec_pending) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_fetch: no block was submitted");
+  ctx->rec_pending = 0;
+  BSC_ENTER(ctx);
+  return bsc_records_finish(ctx, n_out);
 }
 
 /* ---- site statistics -------------------------------------------------------------------------------------- */

@@ -78,9 +78,42 @@ extern "C" __global__ __launch_bounds__(256) void bsc_compact_kernel(const uint8
   }
 }
 
+/* The same packing when the encoder's fields come from the chain kernel itself (fused.hip, aux_out): aux[i] is already the
+ * second half of position i's bsc_vcf_rec (counts, qualities, MQ, mean quality, max_gt, rs_found) — the chain formed it from
+ * the pile-up in its registers, there is no gt_meth to read. */
+extern "C" __global__ __launch_bounds__(256) void bsc_compact_aux_kernel(const uint8_t *__restrict__ core,
+                                                                         const uint8_t *__restrict__ aux, uint32_t n,
+                                                                         const uint32_t *__restrict__ tile_off,
+                                                                         const uint32_t *__restrict__ tile_cnt,
+                                                                         uint8_t *__restrict__ out, uint64_t out_cap,
+                                                                         unsigned long long *__restrict__ total) {
+  const unsigned lane = threadIdx.x & 63u;
+  const uint32_t n_tiles = (n + 63u) / 64u;
+  for (uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * 4u) {
+    const uint32_t i = tile * 64u + lane;
+    const uint32_t off = tile_off[tile];
+    if (tile == n_tiles - 1u && lane == 0) *total = (unsigned long long)off + tile_cnt[tile];
+    uint4 c0 = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n) c0 = *reinterpret_cast<const uint4 *>(core + (uint64_t)i * 64u);
+    const bool emit = (c0.y & 0xffu) != 0;
+    const unsigned long long m = __ballot(emit);
+    if (!emit) continue;
+    const uint64_t slot = (uint64_t)off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (slot >= out_cap) continue; /* the host reports the overflow from *total */
+    const uint4 *cs = reinterpret_cast<const uint4 *>(core + (uint64_t)i * 64u);
+    const uint4 *as = reinterpret_cast<const uint4 *>(aux + (uint64_t)i * 64u);
+    uint4 *o = reinterpret_cast<uint4 *>(out + slot * 128u);
+    o[0] = c0;
+#pragma unroll
+    for (int k = 1; k < 4; k++) o[k] = cs[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[4 + k] = as[k];
+  }
+}
+
 extern "C" int bsc_dev_scan_u32(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
 
-/* tile_cnt / tile_off: (n + 63) / 64 words each; total: one u64 */
+/* tile_cnt / tile_off: (n + 63) / 64 words each; total: one u64; gtm_stride = 0: gtm is the chain's aux array (64 bytes per position) */
 extern "C" int bsc_dev_launch_compact(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp, uint32_t n,
                                       void *tile_cnt, void *tile_off, void *scan_tmp, size_t scan_tmp_bytes, void *out,
                                       uint64_t out_cap, void *total, int num_cus, void *stream) {
@@ -94,8 +127,12 @@ extern "C" int bsc_dev_launch_compact(const void *core, const void *gtm, uint32_
   if (e != hipSuccess) return (int)e;
   int rc = bsc_dev_scan_u32(tile_cnt, tile_off, n_tiles, scan_tmp, scan_tmp_bytes, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(bsc_compact_kernel, dim3(grid), dim3(256), 0, s, (const uint8_t *)core, (const uint8_t *)gtm, gtm_stride,
-                     (const uint8_t *)dbsnp, n, (const uint32_t *)tile_off, (const uint32_t *)tile_cnt, (uint8_t *)out,
-                     out_cap, (unsigned long long *)total);
+  if (gtm_stride == 0) /* gtm = the chain's aux array */
+    hipLaunchKernelGGL(bsc_compact_aux_kernel, dim3(grid), dim3(256), 0, s, (const uint8_t *)core, (const uint8_t *)gtm, n,
+                       (const uint32_t *)tile_off, (const uint32_t *)tile_cnt, (uint8_t *)out, out_cap, (unsigned long long *)total);
+  else
+    hipLaunchKernelGGL(bsc_compact_kernel, dim3(grid), dim3(256), 0, s, (const uint8_t *)core, (const uint8_t *)gtm, gtm_stride,
+                       (const uint8_t *)dbsnp, n, (const uint32_t *)tile_off, (const uint32_t *)tile_cnt, (uint8_t *)out,
+                       out_cap, (unsigned long long *)total);
   return (int)hipGetLastError();
 }

@@ -258,20 +258,36 @@ typedef struct {
 } bsc_vcf_rec;
 
 /* d_core[n] / d_gtm[n] (device) -> d_out[min(*count, out_cap)] packed records and the number of written records of the
- * block in *d_count (a device u64; records beyond out_cap are counted, not stored).  Asynchronous on `stream`. */
+ * block in *d_count (a device u64; records beyond out_cap are counted, not stored).  Asynchronous on `stream`.
+ * gtm_stride = 0: d_gtm is the d_aux array of bsc_reads_chain_device (64 bytes per position, already the second half of
+ * the packed record; d_dbsnp is then unused: the flag is in it). */
 int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_gtm, uint32_t gtm_stride,
                            const void *d_dbsnp, uint32_t n, void *d_out, uint64_t out_cap, void *d_count, void *stream);
 
 /*
- * One block from reads to written records, nothing else crossing PCIe on the way back: accumulate + call + record
- * formation (+ site statistics when with_stats != 0) + packing.  ref[y - x + 3] = reference codes of x .. y + 2
- * (work->ref1 as the reference fills it, src/process_template.c:29-30); dbsnp = rs_found per position or NULL.
+ * One block from reads to written records, nothing else crossing PCIe on the way back: what call_genotypes_ML hands to
+ * the calc threads (src/call_genotypes.c:180-226 -> :260-272) and the print thread makes of their output
+ * (src/process.c:87-104 -> src/print_vcf.c:32-594), on the reads-in chain (bsc_reads_chain_device: neither the pile-up nor
+ * gt_meth in HBM), then the packing — every launch and copy queued back to back, ONE wait for the templates' verdict, the
+ * record count and the records together.  ref[y - x + 3] = reference codes of x .. y + 2 (work->ref1 as the reference fills
+ * it, src/process_template.c:29-30); dbsnp = rs_found per position or NULL; with_stats != 0: the site statistics too.
  * out[out_cap]: pinned or pageable; *n_out = records written.  BSC_ERR_ARG if out_cap is too small (*n_out then holds
- * the number needed), otherwise as bsc_call_block.
+ * the number needed) or a template breaks one of the reference's asserts (the contents of out are then unspecified);
+ * BSC_WARN_INEXACT as bsc_accumulate.
+ *
+ * bsc_block_records_submit / _fetch: the same split where the reference splits it — submit returns once the block is queued,
+ * as call_genotypes_ML returns once its calc threads are dispatched (src/call_genotypes.c:260-272), its inputs copied to a
+ * pinned staging area (the caller's buffers are free at once); fetch is the wait at the top of the next call (:161-168) and
+ * completes the block into the `out` named at submit (which must stay valid until then).  One block in flight per context.
  */
 int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                       uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
                       int with_stats, bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out);
+
+int bsc_block_records_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
+                             uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                             bsc_vcf_rec *out, uint64_t out_cap);
+int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out);
 
 /* bsc_vcf_format for a packed record. */
 int bsc_vcf_format_rec(const bsc_vcf_rec *r, const char *contig, const char *id, char *buf, size_t cap);

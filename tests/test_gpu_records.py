@@ -160,3 +160,43 @@ def test_chain_regression_anchor_on_the_device(caller, libm_exact):
     assert abs(float(st["CpG_ref_meth"][0].sum() + st["CpG_nonref_meth"][0].sum()) - gold["meth_profile_sum"]) < 1e-9
     recs = caller.block_records(tpl, seq, x, y, ref)
     assert sha(recs["core"]) == sha(core[core["emit"] == 1])
+
+
+def test_block_records_submit_fetch(caller, oracle, tables, libm_exact):
+    """The split form (bsc_block_records_submit / _fetch): blocks queued one after the other, inputs recycled right after
+    the submit, records = the synchronous call's = the oracle chain's; a block that writes a record for every position
+    (-A) after blocks that write half exercises the second copy of the copy-out."""
+    blocks = []
+    for k, (cov, n, x0, kw) in enumerate(((30, 60_000, 9_000, dict()), (30, 40_000, 200_000, dict(all_positions=True)),
+                                          (10, 30_000, 400_000, dict()), (30, 5_000, 500_000, dict(all_positions=True)))):
+        tpl, seq, x, y = _block(SEED + 900 + k, x0, n, cov)
+        ref = B.synth_ref_host(SEED + 900 + k, x, y - x + 3)
+        blocks.append((tpl, seq, x, y, ref, kw))
+    sync = [caller.block_records(t, s, x, y, r, **kw).copy() for t, s, x, y, r, kw in blocks]
+    if libm_exact:
+        for (t, s, x, y, r, kw), got in zip(blocks, sync):
+            exp = _expected(oracle, tables, libm_exact, t, s, x, y, r, **kw)[0]
+            assert got.tobytes() == exp.tobytes()
+    outs = [B.PinnedBuffer(y - x + 1, B.VCF_REC) for _, _, x, y, _, _ in blocks]
+    got = []
+    for k, (t, s, x, y, r, kw) in enumerate(blocks):
+        t2, s2, r2 = t.copy(), s.copy(), r.copy()
+        caller.block_records_submit(t2, s2, x, y, r2, outs[k].array, **kw)
+        t2[:], s2[:], r2[:] = 0, 0, 0  # the inputs were staged: the caller may recycle them at once
+        with pytest.raises(B.BscError):
+            caller.block_records_submit(t, s, x, y, r, outs[k].array, **kw)  # one block in flight per context
+        got.append(caller.block_records_fetch().copy())
+    for a, b in zip(got, sync):
+        assert a.tobytes() == b.tobytes()
+    with pytest.raises(B.BscError):
+        caller.block_records_fetch()
+    # a bad template surfaces at the fetch, and the context goes on working
+    t, s, x, y, r, kw = blocks[0]
+    bad = t.copy()
+    bad["bs_strand"][3] = 7
+    caller.block_records_submit(bad, s, x, y, r, outs[0].array)
+    with pytest.raises(B.BscError) as e:
+        caller.block_records_fetch()
+    assert "template 3" in str(e.value)
+    caller.block_records_submit(t, s, x, y, r, outs[0].array)
+    assert caller.block_records_fetch().tobytes() == sync[0].tobytes()
