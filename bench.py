@@ -13,6 +13,10 @@ Default workload = BASELINE.json configs[1] (synthetic chr22-sized contig, 50 Mb
     recorded on the launch stream inside libbscall_amd (bsc_set_profiling / bsc_last_kernel_ms).
   * roofline_chain: the same for the fused print-side chain (bsc_chain_device: pile-up -> call -> VCF record -> site
     statistics, csrc/fused.hip), 105 B in + 64 B out per position — measured after the timed region.
+  * roofline_accumulate / roofline_reads (N = 1): HOT LOOP A (reference src/call_genotypes.c:180-226) and the reads-in chain
+    (reads -> records in one kernel, neither pile-up nor gt_meth in HBM) over device-resident L-reads of the same contig
+    (1 B per base + 16 B per template in; 104 B pile-up, or 1 B reference code in + 64 B record out, per
+    position), device time from HIP events around all launches of the stage — measured after the timed region.
   * cpu_baseline (rank 0, N = 1): the CPU oracle's libm flavour (= the reference's arithmetic; "port") on this host's
     cores over a bounded sample of the same contig: SURVEY.md 8d's three timings, medians of repetitions of >= 1 s.
 
@@ -55,6 +59,7 @@ def main():
     ap.add_argument("--cpu-sites", type=int, default=32_000_000, help="sample size of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="skip the fused-chain measurement (roofline_chain)")
+    ap.add_argument("--no-reads", action="store_true", help="skip the reads-in measurements (roofline_accumulate, roofline_reads)")
     ap.add_argument("--rank-of", type=int, default=0, help="config 3: run the share of one rank of this many, on this process alone")
     ap.add_argument("--rank-index", type=int, default=0)
     ap.add_argument("--window", type=int, default=0, help="config 3: positions per window (0 = genome.window_for: the largest whole number of resident-wave rounds within 4 Mi)")
@@ -207,8 +212,13 @@ def run_config2(args, env):
         }
     if world == 1 and not args.no_chain:
         res["roofline_chain"] = chain_roofline(args, caller, d_cts, d_ref, n, first_site)
+    if world == 1 and not args.no_reads:
+        res.update(reads_rooflines(args, caller))
+    reads_sample = res.pop("_reads_sample", None) if res else None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res.update(cpu_baseline(args, d_cts, d_ref, d_out, d_skip))
+        if reads_sample is not None:
+            check_reads_sample(args, res, reads_sample)
     if rank == 0:
         # Last (it overwrites d_out): the same bytes moved by a kernel that does nothing else — what the memory system
         # delivers for this 1 : 2 read : write mix (HBM3E writes stream slower than reads), measured live on this GPU.
@@ -261,6 +271,90 @@ def chain_roofline(args, caller, d_cts, d_ref, n, first_site):
         "positions_per_s": n / float(np.median(wall)),
         "records_written_fraction": records / n,
         "note": "instruction-issue bound (FP64 model + record formation), not HBM: the roofline fraction is low by construction",
+    }
+
+
+def reads_rooflines(args, caller):
+    """HOT LOOP A alone (bsc_accumulate_device) and the reads-in chain (bsc_reads_chain_device, with statistics) over one block
+    of device-resident L-reads the size of the benchmarked contig; a sample of both outputs checked against the CPU oracle."""
+    import numpy as np
+    import torch
+
+    import bs_call_amd as B
+    from bs_call_amd import reads as R
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream().cuda_stream
+    x, chunk = 1000, 1_000_000
+    tpl, seq, y = R.synth_block(SEED + 2, x, args.sites, args.coverage, chunk=chunk)
+    n = y - x + 1
+    n_pad = (n + 63) // 64 * 64
+    ref = B.synth_ref_host(SEED + 2, x, n + 2)
+    d_tpl = torch.from_numpy(tpl.view(np.uint8).reshape(-1)).to(dev)
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_ref = torch.from_numpy(ref).to(dev)
+    d_pile = torch.empty(n_pad * 104, dtype=torch.uint8, device=dev)
+    d_core = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    reps = 2 + min(args.steps, 10)
+    acc_ms, rc_ms = [], []
+    for it in range(reps):
+        caller.accumulate_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), seq.size, x, y, d_pile.data_ptr(), stream)
+        caller.block_status(stream)
+        if it >= 2:
+            acc_ms.append(caller.last_accumulate_ms())
+    for it in range(reps):
+        caller.reads_chain_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), seq.size, x, y, d_ref.data_ptr(), d_core.data_ptr(),
+                                  with_stats=True, stream=stream)
+        caller.block_status(stream)
+        if it >= 2:
+            rc_ms.append(caller.last_reads_chain_ms())
+    # a sample for the checker (cpu_baseline): positions well inside the first chunk are covered by that chunk's templates only
+    m = min(chunk, args.sites)
+    keep = (m - 400) if args.sites > m else n
+    sample = {"x": x, "m": m, "chunk": chunk, "keep": keep, "pile": d_pile[: keep * 104].cpu().numpy(), "core": d_core[: (keep - 8) * 64].cpu().numpy()}
+    bytes_in = R.algorithmic_bytes_in(tpl, seq)
+    a_ms, r_ms = float(np.mean(acc_ms)), float(np.mean(rc_ms))
+    a_bytes, r_bytes = bytes_in + n * 104, bytes_in + n + n * 64
+    block = "one block of %d positions at %dx: %d templates, %d bases, resident in HBM" % (n, args.coverage, len(tpl), seq.size)
+    return {
+        "roofline_accumulate": {
+            "bound": "hbm",
+            "kernel": "bsc_prep_reads_kernel + rocPRIM radix sort of the reads + bsc_tile_lo_kernel + bsc_accumulate_kernel (bsc_accumulate_device)",
+            "what": "HOT LOOP A, reads -> pile-up (reference src/call_genotypes.c:180-226, serial on its process thread); " + block,
+            "achieved": a_bytes / (a_ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": a_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": a_bytes,
+            "algorithmic_bytes_per_position": a_bytes / n,
+            "stage_ms_avg": a_ms,
+            "stage_ms_min": float(np.min(acc_ms)),
+            "positions_per_s": n / (a_ms * 1e-3),
+            "bases_per_s": seq.size / (a_ms * 1e-3),
+            "first_chunk_equals_oracle": None,
+            "note": "latency / instruction-issue bound (one byte load per read and 64-position tile), not HBM",
+        },
+        "roofline_reads": {
+            "bound": "hbm",
+            "kernel": "bsc_prep_reads_kernel + sort + bsc_tile_lo_kernel + bsc_chain_kernel_t<.., READS> (bsc_reads_chain_device), with statistics",
+            "what": "reads -> pile-up -> call -> VCF record -> site statistics; the pile-up lives in the LDS of the wave that calls it, "
+            "gt_meth in its registers; " + block,
+            "achieved": r_bytes / (r_ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": r_bytes,
+            "algorithmic_bytes_per_position": r_bytes / n,
+            "stage_ms_avg": r_ms,
+            "stage_ms_min": float(np.min(rc_ms)),
+            "positions_per_s": n / (r_ms * 1e-3),
+            "records_written_fraction": int(d_core.view(n, 64)[:, 4].sum()) / n,
+            "first_chunk_records_equal_oracle": None,
+            "note": "instruction-issue bound (FP64 model + record formation + the pile-up walk), not HBM",
+        },
+        "_reads_sample": sample,
     }
 
 
@@ -391,6 +485,25 @@ def cpu_baseline(args, d_cts, d_ref, d_out, d_skip):
         },
         "libm_exact": exact,
     }
+
+
+def check_reads_sample(args, res, sample):
+    """Part of the CPU leg: the first chunk of the reads-in measurements' outputs against the oracle chain
+    (orc_accumulate -> orc_call_sites -> orc_vcf_block = the reference's process, calc and print threads)."""
+    import bs_call_amd as B
+    from bs_call_amd import reads as R
+    from oracle import loader as O
+
+    x, keep = sample["x"], sample["keep"]
+    t1, s1, y1 = R.synth_block(SEED + 2, x, sample["m"], args.coverage, chunk=sample["chunk"])
+    _rc, pile = O.accumulate(t1, s1, x, y1, 20)
+    ref = B.synth_ref_host(SEED + 2, x, len(pile) + 2)
+    exact = O.libm_exact()
+    gtm, skip = O.call_sites(pile, ref[: len(pile)], O.Tables(), O.LIBM if exact else O.BSM, -(os.cpu_count() or 1))
+    core = O.vcf_block(gtm, skip, ref, x)
+    res["roofline_accumulate"]["first_chunk_equals_oracle"] = bool(sample["pile"].tobytes() == pile[:keep].tobytes())
+    res["roofline_reads"]["first_chunk_records_equal_oracle"] = bool(sample["core"].tobytes() == core[: keep - 8].tobytes())
+    res["roofline_reads"]["oracle_flavour_compared"] = "LIBM" if exact else "BSM"
 
 
 # ---------------------------------------------------------------------------------------------------------------------

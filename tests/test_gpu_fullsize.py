@@ -144,3 +144,56 @@ def test_sub_launch_loop(oracle, tables, libm_exact, monkeypatch):
     exp, eskip = oracle.call_sites(pile, ref, tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
     assert got.tobytes() == exp.tobytes() and (skip == eskip).all()
     assert s["sites"] == n and s["covered"] == int((eskip == 0).sum()) and s["het_calls"] == int(B.GT_HET[exp["max_gt"]][eskip == 0].sum())
+
+
+@pytest.mark.parametrize("sites,cov", [(10_000_000, 200), (50_000_000, 30)])
+def test_reads_in_full_size(oracle, tables, libm_exact, sites, cov):
+    """HOT LOOP A and the reads-in chain at config sizes (BASELINE.json configs[3]: 10 Mb at 200x, the deep read-stack path;
+    configs[1]: 50 Mb at 30x) on device-resident L-reads: the pile-up's n summed over the block = a census of the countable
+    bases of the reads; a 200 k-position window of the pile-up and of the records = the oracle chain
+    (orc_accumulate -> orc_call_sites -> orc_vcf_block); the records of bsc_reads_chain_device = those of
+    bsc_accumulate_device -> bsc_chain_device over the whole block, and its counters a census of them."""
+    import torch
+
+    from bs_call_amd import reads as R
+    from bs_call_amd.abi import VCF_CORE
+
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    x, chunk, win = 1000, 1_000_000, 200_000
+    tpl, seq, y = R.synth_block(SEED, x, sites, cov, chunk=chunk)
+    n = y - x + 1
+    n_pad = (n + 63) // 64 * 64
+    ref = B.synth_ref_host(SEED, x, n + 2)
+    q = seq >> 2
+    census = int(((q >= 20) & (q < 63)).sum())  # every byte of seq belongs to one read; every read lies inside the block
+    with B.SiteCaller() as c:
+        d_tpl = torch.from_numpy(tpl.view(np.uint8).reshape(-1)).to(dev)
+        d_seq = torch.from_numpy(seq).to(dev)
+        d_ref = torch.from_numpy(ref).to(dev)
+        d_pile = torch.zeros((n_pad + 2) * 104, dtype=torch.uint8, device=dev)
+        c.accumulate_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), seq.size, x, y, d_pile.data_ptr(), st)
+        c.block_status(st)
+        rows = d_pile[: n * 104].view(n, 104).view(torch.int32).view(n, 26)
+        assert int(rows[:, 16].sum(dtype=torch.int64)) == census
+        assert int(rows[:, :16].sum(dtype=torch.int64)) == census
+        # the first chunk's templates alone cover its positions: compare a window with the oracle
+        t1, s1, y1 = R.synth_block(SEED, x, min(chunk, sites), cov, chunk=chunk)
+        rc, pile = oracle.accumulate(t1, s1, x, y1, 20)
+        assert rc == 0 and d_pile[: win * 104].cpu().numpy().tobytes() == pile[:win].tobytes()
+        # the reads-in chain against the unfused route on the device, whole block
+        d_core = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        d_core2 = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        c.reset_stats()
+        c.reads_chain_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), seq.size, x, y, d_ref.data_ptr(), d_core.data_ptr(), stream=st)
+        c.block_status(st)
+        cnt = c.stats()
+        c.chain_device(d_pile.data_ptr(), d_ref.data_ptr(), x, n, 0, n, d_core2.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        assert torch.equal(d_core, d_core2)
+        covered = int((rows[:, 16] != 0).sum())
+        assert cnt["sites"] == n and cnt["covered"] == covered
+        if libm_exact:
+            gtm, skip = oracle.call_sites(pile[: win + 8], ref[: win + 8], tables, oracle.LIBM, -8)
+            core = oracle.vcf_block(gtm, skip, ref[: win + 10], x)
+            assert d_core[: win * 64].cpu().numpy().tobytes() == core[:win].tobytes()
