@@ -90,8 +90,8 @@ oracle:
 
 # a plain-C host program against the C ABI: gcc only, links the shared library like bs_call would
 demo: $(LIBDIR)/demo_block $(LIBDIR)/bam2bcf
-$(LIBDIR)/demo_block: integration/demo_block.c include/bscall_amd.h $(LIBDIR)/libbscall_amd.so
-	$(CC) -O2 -Wall -std=gnu11 -Iinclude $< -o $@ -L$(LIBDIR) -lbscall_amd -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
+$(LIBDIR)/demo_block: integration/demo_block.c integration/mock_work.h integration/amd_overlap_protocol.h include/bscall_amd.h $(LIBDIR)/libbscall_amd.so
+	$(CC) -O2 -Wall -std=gnu11 -Iinclude -Iintegration $< -o $@ -L$(LIBDIR) -lbscall_amd -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
 # BAM + FASTA -> BCF + JSON report with nothing but the C ABI (the C twin of bs_call_amd/pipeline.py)
 bam2bcf: $(LIBDIR)/bam2bcf
 $(LIBDIR)/bam2bcf: integration/bam2bcf.c include/bscall_amd.h $(LIBDIR)/libbscall_amd.so

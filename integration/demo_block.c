@@ -4,11 +4,14 @@
  *
  *   synchronous   per block: bsc_prepare_templates (the process thread's read pre-processing) -> bsc_call_block into a
  *                 gt_vcf[] array -> the records are consumed                      (integration/call_genotypes_amd.c)
- *   overlapped    block k is submitted (bsc_block_submit_to, into one of two pinned gt_vcf[] arrays) and the call
- *                 returns; at the start of the next call (and at the end of the run) block k is fetched and PUBLISHED
- *                 to a consumer thread that drains work->vcf[] in index order on the `ready` flags exactly as the
- *                 reference's print thread does (src/process.c:87-104) — so block k's copy-out and consumption overlap
- *                 block k+1's preparation and submission               (integration/call_genotypes_amd_overlap.c)
+ *   overlapped    the protocol of integration/call_genotypes_amd_overlap.c itself (integration/amd_overlap_protocol.h, the
+ *                 same code) against a mock of the reference's work_t (integration/mock_work.h): block k is submitted
+ *                 (bsc_block_submit_to, into one of two pinned gt_vcf[] arrays) and the call returns once the meth
+ *                 profiling thread has let go of work->ref1; at the start of the next call (and at the end of the run)
+ *                 block k is fetched and PUBLISHED to a print thread that drains work->vcf[] in index order on the
+ *                 `ready` flags exactly as the reference's does (src/process.c:87-104), reading work->ref beside it; a
+ *                 profiling thread reads work->ref1 for every queued template while this thread, like the reference's
+ *                 process thread, overwrites ref1 for the next block the moment the call returns
  *
  * Both forms must deliver the same bytes: the program compares a running hash of every gt_vcf record in consumption
  * order and fails if they differ.  Then it forms VCF records of the last block and the run statistics, as round 1's
@@ -36,80 +39,8 @@
 
 static const char *GT_NAME[10] = {"AA", "AC", "AG", "AT", "CC", "CG", "CT", "GG", "GT", "TT"};
 
-/* `gt_vcf`, include/bs_call.h:162-166: what the calc side publishes per position (208 bytes) */
-typedef struct {
-  bsc_gt_meth gtm;
-  bool ready;
-  bool skip;
-} gt_vcf;
-_Static_assert(sizeof(gt_vcf) == 208, "gt_vcf is 208 bytes: the out_stride of the gt_vcf[] form");
-
-/* the fields of the reference's work_t the publish protocol uses (include/bs_call.h:230-282) */
-typedef struct {
-  gt_vcf *vcf;
-  int vcf_n;
-  uint32_t vcf_x;
-  bool print_end;
-  pthread_mutex_t print_mutex, vcf_mutex;
-  pthread_cond_t print_cond1, print_cond2, vcf_cond;
-  /* what this demo's "printer" keeps */
-  uint64_t hash, records, covered;
-} work_t;
-
-static void consume(work_t *w, const gt_vcf *v) { /* stands in for print_vcf_entry: every byte the printer would read */
-  uint64_t q[sizeof v->gtm / 8], h = w->hash;
-  memcpy(q, &v->gtm, sizeof q);
-  for (size_t i = 0; i < sizeof q / sizeof q[0]; i++) h = (h ^ q[i]) * 1099511628211ull;
-  h = (h ^ (unsigned)v->skip) * 1099511628211ull;
-  w->hash = h;
-  w->records++;
-  w->covered += !v->skip;
-}
-
-/* print_thread, src/process.c:74-110: wait for a block (vcf_n > 0), take its positions in index order as their `ready`
- * flags appear, then declare the block drained (vcf_n = 0, print_cond2) */
-static void *print_thread(void *arg) {
-  work_t *w = arg;
-  for (;;) {
-    pthread_mutex_lock(&w->print_mutex);
-    while (!w->vcf_n && !w->print_end) pthread_cond_wait(&w->print_cond1, &w->print_mutex);
-    const int n = w->vcf_n;
-    pthread_mutex_unlock(&w->print_mutex);
-    if (!n) break;
-    for (int i = 0; i < n; i++) {
-      gt_vcf *v = w->vcf + i;
-      if (!__atomic_load_n(&v->ready, __ATOMIC_ACQUIRE)) {
-        pthread_mutex_lock(&w->vcf_mutex);
-        while (!__atomic_load_n(&v->ready, __ATOMIC_ACQUIRE)) pthread_cond_wait(&w->vcf_cond, &w->vcf_mutex);
-        pthread_mutex_unlock(&w->vcf_mutex);
-      }
-      consume(w, v);
-    }
-    pthread_mutex_lock(&w->print_mutex);
-    w->vcf_n = 0;
-    pthread_cond_signal(&w->print_cond2);
-    pthread_mutex_unlock(&w->print_mutex);
-  }
-  return NULL;
-}
-
-/* the publish protocol of call_genotypes_ML (src/call_genotypes.c:228-258 and :110-114): wait until the printer has
- * drained the previous block, hand it the array, set the flags, wake it */
-static void publish(work_t *w, gt_vcf *arr, uint32_t sz, uint32_t x) {
-  pthread_mutex_lock(&w->print_mutex);
-  while (w->vcf_n) pthread_cond_wait(&w->print_cond2, &w->print_mutex);
-  w->vcf = arr;
-  w->vcf_x = x;
-  pthread_mutex_unlock(&w->print_mutex);
-  for (uint32_t i = 0; i < sz; i++) __atomic_store_n(&arr[i].ready, true, __ATOMIC_RELEASE);
-  pthread_mutex_lock(&w->print_mutex);
-  w->vcf_n = (int)sz;
-  pthread_cond_signal(&w->print_cond1);
-  pthread_mutex_unlock(&w->print_mutex);
-  pthread_mutex_lock(&w->vcf_mutex);
-  pthread_cond_signal(&w->vcf_cond);
-  pthread_mutex_unlock(&w->vcf_mutex);
-}
+#include "mock_work.h"
+#include "amd_overlap_protocol.h"
 
 /* one block of the run: raw templates as the reader delivers them, prepared templates, extent, reference codes */
 typedef struct {
@@ -189,53 +120,50 @@ int main(int argc, char **argv) {
 
   /* ---- synchronous form: call, then consume ---- */
   work_t ws;
-  memset(&ws, 0, sizeof ws);
-  ws.hash = 1469598103934665603ull;
+  mock_work_init(&ws);
   double t0 = now();
   for (int k = 0; k < nblk; k++) {
     const block_t *b = &blk[k];
     CHECK(bsc_call_block(ctx, b->tpl, b->nt, b->seq, b->seq_used, b->x, b->y, b->ref, arr[0], sizeof(gt_vcf), skp[0]));
-    for (uint32_t i = 0; i < b->sz; i++) consume(&ws, arr[0] + i);
+    for (uint32_t i = 0; i < b->sz; i++) mock_consume(&ws, arr[0] + i);
+    ws.ref_hash = mock_fnv(ws.ref_hash, b->ref, (size_t)b->sz + 2);
   }
   const double t_sync = now() - t0;
 
-  /* ---- overlapped form: submit block k, publish block k-1 to the consumer thread meanwhile ---- */
+  /* ---- overlapped form: the glue's own protocol (amd_overlap_protocol.h) between this thread (the process thread), a
+   * print thread and a meth profiling thread ---- */
   work_t wo;
-  memset(&wo, 0, sizeof wo);
-  wo.hash = 1469598103934665603ull;
-  pthread_mutex_init(&wo.print_mutex, NULL);
-  pthread_mutex_init(&wo.vcf_mutex, NULL);
-  pthread_cond_init(&wo.print_cond1, NULL);
-  pthread_cond_init(&wo.print_cond2, NULL);
-  pthread_cond_init(&wo.vcf_cond, NULL);
-  pthread_t pt;
-  pthread_create(&pt, NULL, print_thread, &wo);
+  mock_work_init(&wo);
+  amd_ctx = ctx;
+  pthread_t pt, mt;
+  pthread_create(&pt, NULL, mock_print_thread, &wo);
+  pthread_create(&mt, NULL, mock_mprof_thread, &wo);
   t0 = now();
-  int in_flight = -1; /* block whose records are on their way into arr[in_flight & 1] */
-  for (int k = 0; k <= nblk; k++) {
-    if (in_flight >= 0) { /* start of call k (or join_calc_threads): block k-1 has to be complete before it is published */
-      CHECK(bsc_block_fetch(ctx, NULL, NULL));
-      publish(&wo, arr[in_flight & 1], blk[in_flight].sz, blk[in_flight].x);
-      in_flight = -1;
-    }
-    if (k == nblk) break;
+  for (int k = 0; k < nblk; k++) {
     const block_t *b = &blk[k];
-    /* arr[k & 1] was published two calls ago: the printer has drained it before the previous publish returned */
-    for (uint32_t i = 0; i < b->sz; i++) arr[k & 1][i].ready = false;
-    CHECK(bsc_block_submit_to(ctx, b->tpl, b->nt, b->seq, b->seq_used, b->x, b->y, b->ref, arr[k & 1], sizeof(gt_vcf), skp[k & 1]));
-    in_flight = k; /* returns at once: the process thread goes on to prepare block k+1 */
+    /* process_template_vector: the block's reference codes into work->ref1 (over the previous block's), one profiling job
+     * per template (capped: the ring has 256 slots and the jobs are cheap here) */
+    mock_prepare_block(&wo, b->ref, b->sz, b->nt < 2000 ? (int)b->nt : 2000);
+    amd_overlap_call(&wo, NULL, b->tpl, b->nt, b->seq, b->seq_used, b->x, b->y); /* call_genotypes_ML: returns with the block in flight */
   }
+  amd_overlap_join(&wo); /* join_calc_threads */
   pthread_mutex_lock(&wo.print_mutex);
-  while (wo.vcf_n) pthread_cond_wait(&wo.print_cond2, &wo.print_mutex);
   wo.print_end = true;
   pthread_cond_signal(&wo.print_cond1);
   pthread_mutex_unlock(&wo.print_mutex);
+  pthread_mutex_lock(&wo.mprof_mutex);
+  wo.mprof_end = true;
+  pthread_cond_signal(&wo.mprof_cond1);
+  pthread_mutex_unlock(&wo.mprof_mutex);
   pthread_join(pt, NULL);
+  pthread_join(mt, NULL);
   const double t_over = now() - t0;
   printf("%d blocks, %llu positions: synchronous %.1f ms, overlapped %.1f ms; consumer saw %llu / %llu records, hash %016llx / %016llx\n",
          nblk, (unsigned long long)ws.records, t_sync * 1e3, t_over * 1e3, (unsigned long long)ws.records,
          (unsigned long long)wo.records, (unsigned long long)ws.hash, (unsigned long long)wo.hash);
-  if (ws.hash != wo.hash || ws.records != wo.records || ws.covered != wo.covered) {
+  printf("overlapped form: %llu profiling jobs read work->ref1, %llu found it changed under them; reference codes beside the blocks %s\n",
+         (unsigned long long)wo.mprof_jobs, (unsigned long long)wo.mprof_bad, ws.ref_hash == wo.ref_hash ? "as handed over" : "DIFFERENT");
+  if (ws.hash != wo.hash || ws.records != wo.records || ws.covered != wo.covered || ws.ref_hash != wo.ref_hash || wo.mprof_bad) {
     fprintf(stderr, "the overlapped form delivered different records\n");
     return 1;
   }

@@ -248,6 +248,10 @@ def test_plain_c_host_program():
     assert ov and "4 blocks" in ov[0]
     h = ov[0].split("hash ")[1].split(" / ")
     assert h[0].strip() == h[1].strip()
+    # ... through the protocol code of integration/call_genotypes_amd_overlap.c itself, with a meth profiling thread reading
+    # work->ref1 while the process thread overwrites it for the next block the moment each call returns
+    mp = [ln for ln in lines if "profiling jobs" in ln]
+    assert mp and " 0 found it changed" in mp[0] and "as handed over" in mp[0]
 
 
 def test_prepared_templates_on_the_device(caller, oracle):
