@@ -27,8 +27,8 @@ _Static_assert(sizeof(gt_vcf) == 208, "gt_vcf is 208 bytes: the out_stride of th
 
 #define N_MPROF_BUFFERS 256 /* include/bs_call.h:228 */
 typedef struct {
-  uint32_t sz;     /* reference codes of the job's block: sz + 2 */
-  uint64_t expect; /* their checksum as the process thread wrote them */
+  uint32_t off, len; /* the stretch of the block's reference codes this job looks at (a template's span) */
+  uint64_t expect;   /* its checksum as the process thread wrote the codes */
 } mprof_job_t;
 
 typedef struct mock_ctg mock_ctg; /* opaque, like ctg_t for the protocol */
@@ -106,7 +106,7 @@ static void *mock_mprof_thread(void *arg) {
     pthread_mutex_unlock(&w->mprof_mutex);
     if (end) break;
     const mprof_job_t *j = &w->mprof_thread[ix];
-    const uint64_t h = mock_fnv(1469598103934665603ull, w->ref1, (size_t)j->sz + 2);
+    const uint64_t h = mock_fnv(1469598103934665603ull, w->ref1 + j->off, j->len);
     w->mprof_jobs++;
     w->mprof_bad += h != j->expect;
     pthread_mutex_lock(&w->mprof_mutex);
@@ -139,11 +139,11 @@ static void mock_prepare_block(work_t *w, const uint8_t *ref, uint32_t sz, int j
   }
   memcpy(w->ref1, ref, (size_t)sz + 2);
   w->ref1[sz + 2] = 0;
-  const uint64_t expect = mock_fnv(1469598103934665603ull, ref, (size_t)sz + 2);
   for (int k = 0; k < jobs; k++) {
     mprof_job_t *mp = &w->mprof_thread[w->mprof_write_idx];
-    mp->sz = sz;
-    mp->expect = expect;
+    mp->len = sz + 2 < 400u ? sz + 2 : 400u;
+    mp->off = (uint32_t)(((uint64_t)k * 7919u) % (sz + 3 - mp->len));
+    mp->expect = mock_fnv(1469598103934665603ull, ref + mp->off, mp->len);
     const int ix = (w->mprof_write_idx + 1) % N_MPROF_BUFFERS;
     pthread_mutex_lock(&w->mprof_mutex);
     while (ix == w->mprof_read_idx) pthread_cond_wait(&w->mprof_cond2, &w->mprof_mutex);
