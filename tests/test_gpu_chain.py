@@ -258,13 +258,8 @@ def _fused_keep(c, pile, ref2, x, windows):
     return core, c.site_stats().copy(), c.stats()
 
 
-def test_fused_equals_unfused_on_adversarial_pileups(caller):
-    """Uniformly random class counts / qualities (not WGBS-like: every class combination, depths from 1 to several thousand
-    — beyond the 4 096-row coverage table —, near-exact likelihood ties, most calls heterozygous), random reference codes
-    with N runs, random dbSNP flags, uncovered stretches: records and statistics of the fused chain, walked in windows of
-    every alignment, equal the three unfused kernels'."""
-    rng = np.random.default_rng(20261004)
-    n = 150_000
+def _adversarial(rng, n):
+    """Uniformly random class counts / qualities, depths from 1 to several thousand, N runs, dbSNP flags, uncovered stretches."""
     pile = np.zeros(n, dtype=B.PILEUP)
     depth_scale = rng.choice([1, 3, 10, 40, 400], size=n)
     mask = rng.random((n, 2, 8)) < rng.choice([0.1, 0.3, 0.6, 1.0], size=(n, 1, 1))
@@ -280,6 +275,123 @@ def test_fused_equals_unfused_on_adversarial_pileups(caller):
     for s in rng.integers(0, n - 50, 40):
         ref2[s : s + int(rng.integers(1, 40))] = 0
     flags = rng.choice([0, 0, 0, 1, 3], size=n).astype(np.uint8)
+    return pile, ref2, flags
+
+
+def _oracle_chain(oracle, tables, libm_exact, pile, ref2, x, dbsnp=None, all_positions=False, reg=(1, 0xFFFFFFFF)):
+    """The reference's calc threads followed by its print thread, restated: (VCF_CORE[n], SITE_STATS record, counters)."""
+    n = len(pile)
+    gtm, skip = oracle.call_sites(pile, ref2[:n], tables, oracle.LIBM if libm_exact else oracle.BSM, -8)
+    stats = np.zeros(1, dtype=SITE_STATS)
+    core = oracle.vcf_block_stats(gtm, skip, ref2, x, stats, np.zeros(2, dtype=np.uint32), tables.lfact_store, all_positions, reg[0],
+                                  reg[1], dbsnp)
+    cov = skip == 0
+    cnt = {"sites": n, "covered": int(cov.sum()), "gt_hist": np.bincount(gtm["max_gt"][cov], minlength=10).tolist(),
+           "het_calls": int(np.array(B.GT_HET)[gtm["max_gt"][cov]].sum())}
+    return core, stats[0], cnt
+
+
+def test_fused_vs_oracle_on_adversarial_pileups(caller, oracle, tables, libm_exact):
+    """The adversarial pile-ups of the test below — ties, depths beyond the 4 096-row coverage table, N runs, dbSNP flags,
+    mostly heterozygous calls — through the FUSED chain in windows of every alignment, against the CPU oracle directly
+    (orc_call_sites + orc_vcf_block_stats): records, statistics, counters."""
+    if not libm_exact:
+        pytest.skip("host libm differs from the replica: the record bytes go through exp/log")
+    pile, ref2, flags = _adversarial(np.random.default_rng(20261004), 150_000)
+    n = len(pile)
+    wins, first = [], 0
+    for w in [1, 59, 60, 61, 3_000, 17_001, 40_020, 2, 33_333]:
+        wins.append((first, w))
+        first += w
+    wins.append((first, n - first))
+    for kw in (dict(dbsnp=flags), dict(all_positions=True), dict(reg=(777 + 20_000, 777 + 90_000), dbsnp=flags)):
+        ecore, est, ecnt = _oracle_chain(oracle, tables, libm_exact, pile, ref2, 777, **kw)
+        got, gst, gcnt = _fused(caller, pile, ref2, 777, wins, **kw)
+        _same_core(got, ecore, "fused vs oracle, adversarial %s" % (list(kw),))
+        _same_stats(gst, est)
+        assert gcnt == ecnt
+
+
+@pytest.mark.parametrize("cov,n", [(200, 60_000), (1400, 6_000)])
+def test_fused_vs_oracle_deep_coverage(caller, oracle, tables, libm_exact, cov, n):
+    """200x (BASELINE.json configs[3]) and 1 400x blocks — the exp range beyond -512, lgamma in Fisher's test, CpG cytosines
+    beyond the LDS and HBM pair tables — through the fused chain against the oracle directly."""
+    if not libm_exact:
+        pytest.skip("host libm differs from the replica: the record bytes go through exp/log")
+    pile, ref2 = _block(SEED + 40 + cov, n, cov)
+    ecore, est, ecnt = _oracle_chain(oracle, tables, libm_exact, pile, ref2, 50)
+    got, gst, gcnt = _fused(caller, pile, ref2, 50, [(0, n // 3), (n // 3, n - n // 3)])
+    _same_core(got, ecore, "fused vs oracle %dx" % cov)
+    _same_stats(gst, est)
+    assert gcnt == ecnt
+
+
+def fuzz_round(c, oracle, tables, flav, seed, rnd, always_oracle=False):
+    """One round of tools/fuzz_chain.py: a random block (WGBS-like from the generator, or adversarial class counts), random
+    window cuts, random printing parameters — fused against the three unfused kernels and (every fourth round, or always)
+    against the CPU oracle.  Raises AssertionError on a difference."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 59, 60, 61, 119, 500, 5_000, 60_000, 200_000]))
+    if always_oracle and n > 60_000:
+        n = 60_000
+    x0 = int(rng.choice([1, 2, 3, 1000, 4_000_000_000 - 300_000]))
+    kind = rng.random()
+    if kind < 0.5:
+        pile, ref2 = B.synth_pileup_host(seed, x0 + 7, n + 2, int(rng.choice([1, 5, 30, 200, 600])), int(rng.integers(0, 2)))
+        pile = pile[:n]
+    else:
+        pile = np.zeros(n, dtype=B.PILEUP)
+        scale = rng.choice([1, 1, 3, 10, 40, 400], size=n)
+        mask = rng.random((n, 2, 8)) < rng.choice([0.1, 0.3, 0.6, 1.0], size=(n, 1, 1))
+        cnt = (rng.integers(0, 8, size=(n, 2, 8)) * scale[:, None, None] * mask).astype(np.uint32)
+        cnt[rng.random(n) < rng.choice([0.0, 0.05, 0.5])] = 0
+        pile["counts"] = cnt
+        tot = cnt.sum(axis=1)
+        pile["n"] = tot.sum(axis=1)
+        pile["quality"] = np.minimum((tot * rng.integers(20, 44, size=(n, 8))).astype(np.float32), 43.0 * tot)
+        pile["mapq2"] = (pile["n"] * rng.choice([0, 1, 400, 1521, 3600], size=n)).astype(np.float32)
+        ref2 = rng.integers(0 if rng.random() < 0.3 else 1, 5, size=n + 2).astype(np.uint8)
+    flags = rng.choice([0, 0, 0, 1, 3], size=n).astype(np.uint8) if rng.random() < 0.5 else None
+    allp = bool(rng.integers(0, 2)) if rng.random() < 0.3 else False
+    reg = (1, 0xFFFFFFFF) if rng.random() < 0.7 else (x0 + n // 4, x0 + 3 * n // 4)
+    cuts = sorted(set(int(v) for v in rng.integers(0, n + 1, int(rng.integers(0, 6)))) | {0, n})
+    wins = [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    what = "seed=%d n=%d x0=%d kind=%.2f wins=%s" % (seed, n, x0, kind, wins)
+    got, gst, gcnt = _fused(c, pile, ref2, x0, wins, dbsnp=flags, all_positions=allp, reg=reg)
+    if not always_oracle:
+        exp, est, ecnt = _unfused(c, pile, ref2, x0, dbsnp=flags, all_positions=allp, reg=reg)
+        _same_core(got, exp, "fused vs unfused " + what)
+        _same_stats(gst, est)
+        assert gcnt == ecnt, what
+    if always_oracle or (rnd % 4 == 0 and n <= 60_000):
+        gtm, skip = oracle.call_sites(pile, ref2[:n], tables, flav, -4)
+        st = np.zeros(1, dtype=SITE_STATS)
+        ocore = oracle.vcf_block_stats(gtm, skip, ref2, x0, st, np.zeros(2, dtype=np.uint32), tables.lfact_store, allp, reg[0], reg[1], flags)
+        _same_core(got, ocore, "fused vs oracle " + what)
+        _same_stats(gst, st[0])
+    return n, len(wins)
+
+
+def test_fuzz_slice_vs_oracle(caller, oracle, tables, libm_exact):
+    """A seeded, time-bounded slice of tools/fuzz_chain.py with EVERY round compared with the CPU oracle directly."""
+    import time
+
+    if not libm_exact:
+        pytest.skip("host libm differs from the replica: the record bytes go through exp/log")
+    t_end, rnd = time.time() + 45.0, 0
+    while time.time() < t_end or rnd < 20:
+        fuzz_round(caller, oracle, tables, oracle.LIBM, 3_000_017 + rnd, rnd, always_oracle=True)
+        rnd += 1
+    assert rnd >= 20
+
+
+def test_fused_equals_unfused_on_adversarial_pileups(caller):
+    """Uniformly random class counts / qualities (not WGBS-like: every class combination, depths from 1 to several thousand
+    — beyond the 4 096-row coverage table —, near-exact likelihood ties, most calls heterozygous), random reference codes
+    with N runs, random dbSNP flags, uncovered stretches: records and statistics of the fused chain, walked in windows of
+    every alignment, equal the three unfused kernels'."""
+    pile, ref2, flags = _adversarial(np.random.default_rng(20261004), 150_000)
+    n = len(pile)
     assert int(pile["n"].max()) > 4096
     exp, est, ecnt = _unfused(caller, pile, ref2, 777, dbsnp=flags)
     wins, first = [], 0

@@ -1,0 +1,44 @@
+"""The N > 1 code path of bench.py on the one-GPU box: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
+--config 3 --genome-scale 0.004` as a fresh child process with BENCH_REHEARSAL=1 (both ranks on cuda:0, gloo instead of RCCL,
+which refuses two ranks on one device) — contig partition (the reference's unit: one process per contig, README.md:73-76),
+the all-reduce of the counter and statistics blocks and the gather of the per-contig totals, against the N = 1 run of the
+same genome.  The numbers of a rehearsal mean nothing; the sums must be the same."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, env=None):
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines, p.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_two_rank_rehearsal_equals_single_process():
+    common = ["bench.py", "--config", "3", "--genome-scale", "0.004", "--steps", "2", "--warmup", "1"]
+    one = _run([sys.executable] + common + ["--gpus", "1"])
+    env = dict(os.environ, BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())] + common + ["--gpus", "2"], env)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    c1, c2 = one["config"], two["config"]
+    assert c2["per_contig_records_sum_equals_total"] is True and c1["per_contig_records_sum_equals_total"] is True
+    assert c2["contigs_with_records_after_gather"] == 24 == c1["contigs_with_records_after_gather"]
+    for k in ("records_written", "CpGs", "dbSNP_sites_written", "covered_fraction"):
+        assert c1[k] == c2[k], (k, c1[k], c2[k])
+    assert "rank 0 of 2" in c2["share"]
