@@ -204,6 +204,28 @@ def load():
         )
     _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
+    if os.environ.get("BSCALL_AMD_LIB"):
+        # a developer's A/B build of an older revision may lack newer entries: bind what it has (tools/ab_*.py)
+        class _Tolerant:
+            def __init__(self, lib):
+                object.__setattr__(self, "_lib", lib)
+
+            def __getattr__(self, name):
+                try:
+                    return getattr(self._lib, name)
+                except AttributeError:
+                    class _Missing:
+                        restype = None
+                        argtypes = None
+
+                        def __call__(self, *a):
+                            raise ImportError("%s is not in %s" % (name, LIB_PATH))
+
+                    m = _Missing()
+                    object.__setattr__(self, name, m)
+                    return m
+
+        L = _Tolerant(L)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     L.bsc_abi_version.restype = i32
     L.bsc_abi_version.argtypes = []

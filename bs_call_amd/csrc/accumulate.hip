@@ -131,7 +131,7 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
       if (k == 0 && walked0) ori ^= 1u; /* :224 — only a read that was walked flips the orientation */
       rd[2 * (uint64_t)t + k] = d;
       const bool live = d.b >= d.a; /* then x <= a <= b <= y */
-      keys[2 * (uint64_t)t + k] = live ? d.a - x : key_max;
+      keys[2 * (uint64_t)t + k] = live ? (d.a - x) >> ACC_BIN_SHIFT : key_max;
       if (live && d.b - d.a > span_max) span_max = d.b - d.a;
     }
   }
@@ -157,7 +157,7 @@ extern "C" __global__ __launch_bounds__(256) void bsc_tile_lo_kernel(const uint3
   const int64_t span = (int64_t)(uint32_t)counters[BSC_CNT_SPAN]; /* longest read extent, b - a */
   for (uint32_t wt = blockIdx.x * blockDim.x + threadIdx.x; wt < n_wt; wt += gridDim.x * blockDim.x) {
     const int64_t r0 = base + (int64_t)wt * step;       /* the tile's first position, relative to the block start */
-    const uint32_t key = r0 > span ? (uint32_t)(r0 - span) : 0u; /* first read that can still reach it */
+    const uint32_t key = r0 > span ? (uint32_t)(r0 - span) >> ACC_BIN_SHIFT : 0u; /* bin of the first read that can still reach it */
     uint32_t lo = 0, hi = n_reads;
     while (lo < hi) {
       const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -283,8 +283,8 @@ extern "C" int bsc_dev_launch_prep_reads(const void *tpl, uint32_t nr, const voi
   const uint32_t n_reads = 2u * nr; /* nr <= 2^31 - 1 is checked by the caller */
   unsigned g = (nr + 255u) / 256u;
   if (g > (unsigned)num_cus * 16u) g = (unsigned)num_cus * 16u;
-  /* keys 0 .. key_max - 1: positions x .. y; key_max: a read that contributes nothing */
-  const uint32_t key_max = n_sites;
+  /* keys 0 .. key_max - 1: the 64-position bins of x .. y; key_max: a read that contributes nothing */
+  const uint32_t key_max = ((n_sites - 1u) >> ACC_BIN_SHIFT) + 1u;
   unsigned key_bits = 1;
   while (key_bits < 32 && (key_max >> key_bits)) key_bits++;
   hipLaunchKernelGGL(bsc_prep_reads_kernel, dim3(g), dim3(256), 0, s, (const bsc_template_dev *)tpl, nr, (const uint8_t *)seq,

@@ -974,6 +974,10 @@ static int bsc_chain_fill(bsc_context *ctx, bsc_chain_launch *L, const bsc_windo
   L->reg_stop = params->reg_stop;
   L->with_stats = with_stats != 0;
   L->tb = ctx->d_tables;
+  L->par_l = 1.0 - ctx->host_tables.under_conv;
+  L->par_t = ctx->host_tables.over_conv;
+  L->par_lrb = ctx->host_tables.lrb;
+  L->par_lrb1 = ctx->host_tables.lrb1;
   L->core_out = d_core;
   L->aux_out = d_aux;
   L->het_list = ctx->d_het;

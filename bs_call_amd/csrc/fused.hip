@@ -93,6 +93,7 @@ struct bsc_chain_kargs {
   uint8_t *core_out;
   const bsc_dev_tables *tb;
   bsc_chain_args a;
+  double l, t, lrb, lrb1; /* 1 - under_conv, over_conv, log(ref_bias), log(0.5 (1 + ref_bias)): calc_gt_prob's scalars (host-computed) */
   const uint8_t *dbsnp;
   uint32_t *het_list;
   unsigned long long *counters;
@@ -332,11 +333,12 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
 
 template <bool FULL, bool READS>
 __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_chain_kargs K) {
-  const uint32_t *__restrict__ const cts = K.cts;
-  const uint8_t *__restrict__ const ref = K.ref;
-  uint8_t *__restrict__ const core_out = K.core_out;
-  const bsc_dev_tables *__restrict__ const tb = K.tb;
+  const bsc_dev_tables *__restrict__ const tb = K.tb; /* the set-up below only */
   const bsc_chain_args &a = K.a;
+/* the three arrays every tile touches: read from the argument segment where used, like the cold members */
+#define cts K_COLD(cts)
+#define ref K_COLD(ref)
+#define core_out K_COLD(core_out)
   __shared__ __attribute__((aligned(16))) uint32_t lds_slot[FW][SLOT_DW];
   __shared__ double s_k[44], s_lnk[44], s_half[44], s_one[44];
   __shared__ double s_logtab[256];
@@ -371,9 +373,6 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     for (unsigned i = tid; i < F_WORDS; i += 64 * FW) h[i] = 0;
     for (unsigned i = tid; i < 4 * F_PAIR * F_PAIR; i += 64 * FW) s_pair[i] = 0;
   }
-  const double l = 1.0 - tb->under_conv;
-  const double t = tb->over_conv;
-  const double lrb = tb->lrb, lrb1 = tb->lrb1;
   __syncthreads();
   if (BSC_CHAIN_STAGGER)
     for (unsigned i = 0; i < wid; i++) __builtin_amdgcn_s_sleep(BSC_CHAIN_STAGGER);
@@ -389,7 +388,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
 /* the tile's 64 pile-ups (6 656 contiguous bytes, the first on a 16-byte boundary) -> the wave's slot by LDS-DMA */
 #define F_DMA_TILE(TT, DMA)                                                                                             \
   do {                                                                                                                  \
-    const char *src_ = reinterpret_cast<const char *>(cts + (uint64_t)((int32_t)((TT)*FT) - 2 + (int32_t)a.lc) * IN_DW) + lane * 16; \
+    const char *src_ = reinterpret_cast<const char *>(cts + (uint64_t)((int32_t)((TT)*FT) - 2 + (int32_t)K_COLD(a.lc)) * IN_DW) + lane * 16; \
     _Pragma("unroll") for (int j_ = 0; j_ < 6; j_++) DMA(src_ + j_ * 1024, slot + j_ * 256);                            \
     if (lane < 32) DMA(src_ + 6 * 1024, slot + 6 * 256);                                                                \
   } while (0)
@@ -433,12 +432,13 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     {
       const int64_t r0 = b0 - 2 - ref_lo; /* offset of srf[0]'s code in the buffer */
       const int64_t avail = ref_hi - ref_lo;
+      const uint8_t *const refp = ref;
       const int64_t k0 = r0 + lane;
-      const uint32_t c0 = (k0 >= 0 && k0 < avail) ? ref[k0] : 0u;
+      const uint32_t c0 = (k0 >= 0 && k0 < avail) ? refp[k0] : 0u;
       srf[lane] = (uint16_t)(c0 | (F_BASE_CHAR(c0) << 8));
       if (lane < 4u) {
         const int64_t k1 = r0 + 64 + lane;
-        const uint32_t c1 = (k1 >= 0 && k1 < avail) ? ref[k1] : 0u;
+        const uint32_t c1 = (k1 >= 0 && k1 < avail) ? refp[k1] : 0u;
         srf[64u + lane] = (uint16_t)(c1 | (F_BASE_CHAR(c1) << 8));
       }
     }
@@ -506,11 +506,13 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         w[2 * i + 1] = v.y;
       }
     } else {
+      const uint32_t *const ctsp = cts;
 #pragma unroll
-      for (int i = 0; i < IN_DW; i++) w[i] = valid ? cts[(uint64_t)(jw + (int32_t)a.lc) * IN_DW + i] : 0u;
+      for (int i = 0; i < IN_DW; i++) w[i] = valid ? ctsp[(uint64_t)(jw + (int32_t)a.lc) * IN_DW + i] : 0u;
     }
     WAVE_LDS_SYNC();
     const unsigned rf = valid ? (unsigned)srf[lane + 2u] & 0xffu : 0u; /* my site's reference code (lane index = lane) */
+    const double l = K_COLD(l), t = K_COLD(t), lrb = K_COLD(lrb), lrb1 = K_COLD(lrb1);
 #include "call_body.inc"
 
     /* ---- block counters (window positions only, not the halo) ---- */
@@ -741,7 +743,8 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       }
       WAVE_LDS_SYNC();
       const uint32_t i0 = T * FT;
-      const uint32_t nrec = FULL ? (uint32_t)FT : (a.n - i0 < (uint32_t)FT ? a.n - i0 : (uint32_t)FT);
+      const uint32_t an_ = FULL ? 0u : K_COLD(a.n);
+      const uint32_t nrec = FULL ? (uint32_t)FT : (an_ - i0 < (uint32_t)FT ? an_ - i0 : (uint32_t)FT);
       const uint32_t nvec = nrec * 4u;
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       u32x4 *dst = reinterpret_cast<u32x4 *>(core_out + (uint64_t)i0 * 64u);
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         acc_fetch(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, acc_t0, lane, acc_kv, acc_d);
       }
     }
-    if (a.with_stats) {
+    if (K_COLD(a.with_stats)) {
       /* ---- the statistics block (src/print_vcf.c:386-525; sitestats.hip has the restatement) for the tile ----
        * Wide histograms take one LDS atomic per lane; where one value dominates (QUAL 255, MQ, FS 0, FILTER 0) the
        * first lane's value is added once for all lanes that share it. */
@@ -841,7 +844,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
           if (minus_cg && st_cpg) { /* does the record just before complete a CpG? (:198-205) */
             bool p_ok;
             uint32_t p_flt;
-            if (jw == 0 && a.lc == 0) { /* first position of a block: the previous block's pending cytosine, if adjacent */
+            if (jw == 0 && K_COLD(a.lc) == 0) { /* first position of a block: the previous block's pending cytosine, if adjacent */
               const uint32_t *const carry_in = K_COLD(carry_in);
               const uint32_t p_pos = carry_in[0];
               p_ok = p_pos != 0 && st_pos - p_pos == 1u;
@@ -894,7 +897,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         }
       }
       /* the window's last position is the pending cytosine, or not, for whatever follows */
-      if (jw == (int32_t)a.n - 1 && lane >= 2u && lane < 62u) {
+      if (jw == (int32_t)K_COLD(a.n) - 1 && lane >= 2u && lane < 62u) {
         uint32_t *const carry_out = K_COLD(carry_out);
         carry_out[0] = pend ? pos0 + lane : 0u;
         carry_out[1] = pend ? flt : 0u;
@@ -919,6 +922,9 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       const uint32_t *ent = wl + (uint64_t)(k0 + lane0) * (READS ? F_HET_DW : 1u);
       const uint32_t e = lane0 < nb ? __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       f_fisher_pending<READS>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_out, s_lf, s_logtab, s_exptab, h, stat_words);
+#undef cts
+#undef ref
+#undef core_out
     }
   }
   if (READS && __any(inexact)) { /* positions whose quality / MAPQ^2 sums left the exact-float range (accumulate.hip) */
@@ -1048,6 +1054,10 @@ static int chain_launch_t(const bsc_chain_launch *L) {
   K.ref = (const uint8_t *)L->ref;
   K.core_out = (uint8_t *)L->core_out;
   K.tb = (const bsc_dev_tables *)L->tb;
+  K.l = L->par_l;
+  K.t = L->par_t;
+  K.lrb = L->par_lrb;
+  K.lrb1 = L->par_lrb1;
   K.dbsnp = (const uint8_t *)L->dbsnp;
   K.het_list = (uint32_t *)L->het_list;
   K.counters = (unsigned long long *)L->counters;

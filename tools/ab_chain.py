@@ -17,7 +17,7 @@ for f in sorted(glob.glob(os.path.join(ROOT, "bs_call_amd", "lib", "variants", "
 for rep in range(2):
     for n, f in libs:
         env = dict(os.environ, BSCALL_AMD_LIB=f)
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--sites", sites, "--coverage", cov, "--steps", "10"],
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--sites", sites, "--coverage", cov, "--steps", "10", "--no-reads"],
                            env=env, capture_output=True, text=True)
         try:
             d = json.loads(p.stdout.strip().splitlines()[-1])
