@@ -14,6 +14,18 @@
  * radix sort of a 50 Mb block handles 20 key bits instead of 26 — three passes instead of four. */
 #define ACC_BIN_SHIFT 6
 
+/* timing experiments only (tools/build_variant_fused.sh): the walk without its loads / without its updates */
+#if defined(ACC_EXPERIMENT_NOLOAD)
+#define ACC_EXP_LOAD(u, rs, pks) g_byte[u] = (unsigned char)(((lane_p - ((pks)&63u)) <= (((pks) >> 6) & 63u)) ? (100u + ((lane_p + (pks)) & 3u)) : 0u);
+#else
+#define ACC_EXP_LOAD(u, rs, pks) g_byte[u] = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane_p - ((pks)&63u)), 0, 0);
+#endif
+#if defined(ACC_EXPERIMENT_NOUPDATE)
+#define ACC_EXP_UPD(u) m2sum ^= (uint32_t)g_byte[u]; if (false)
+#else
+#define ACC_EXP_UPD(u)
+#endif
+
 #ifndef ACC_GROUP
 #define ACC_GROUP 8 /* reads whose byte loads are issued back to back before the first is consumed (4 or 8) */
 #endif
@@ -69,15 +81,26 @@ __device__ static __forceinline__ void acc_fetch(const bsc_read_desc *__restrict
  * unpacks it.  The bytes are fetched through a buffer descriptor built per read (base = the read's first byte in the tile,
  * num_records = its length there): a lane outside the read gets 0 from the range check of the load itself — quality 0,
  * which never counts (min_qual >= 1, src/parse_args.c:170-171) — so no lane clamps an index or tests a range.  Per lane
- * that leaves: offset, load, quality, window test, class lookup (v_alignbyte on the strand's table), two address adds, two
- * LDS adds, one add.
+ * that leaves: offset, load, window test, class lookup (v_alignbyte on the strand's table), two address adds, the LDS
+ * add(s), one add.
+ *
+ * The LDS is the other thing the loop runs out of (sixteen waves of a chain workgroup share one): PACKED = true keeps count
+ * and quality of a (strand, class) cell in ONE dword — count in bits 0-11, the sum of the counted read BYTES (quality << 2 |
+ * base) in bits 12-31 — so a counted base costs one ds_add_u32 instead of two; acc_unpack() takes the cell apart (a class's
+ * base is class & 3, so its quality sum is (byte sum - base * count) >> 2).  A cell holds 4 095 bases (255 * 4 095 < 2^20):
+ * the walk counts the reads it has applied and gives up (returns false, rows to be zeroed and walked again unpacked) before
+ * their number could reach that.  PACKED = false is the plain layout: counts[2][8] at dwords 0-15, quality sums at 17-24.
  */
-__device__ static __forceinline__ uint32_t acc_walk(const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ keys_sorted,
-                                                    const uint32_t *__restrict__ perm, uint32_t n_reads,
-                                                    const uint8_t *__restrict__ seq, unsigned lane, uint32_t lane_p, uint32_t *row,
-                                                    uint32_t pa, uint32_t p_last, uint32_t r_last, uint32_t min_qual,
-                                                    uint32_t q_span, uint32_t t0, uint32_t kv, bsc_read_desc d) {
-  uint32_t m2sum = 0; /* mapq2 of this lane's position */
+#define ACC_PACK_MAX 4095u
+template <bool PACKED>
+__device__ static __forceinline__ bool acc_walk(const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ keys_sorted,
+                                                const uint32_t *__restrict__ perm, uint32_t n_reads, const uint8_t *__restrict__ seq,
+                                                unsigned lane, uint32_t lane_p, uint32_t *row, uint32_t pa, uint32_t p_last,
+                                                uint32_t r_last, uint32_t min_qual, uint32_t q_span, uint32_t t0, uint32_t kv,
+                                                bsc_read_desc d, uint32_t &m2sum) {
+  m2sum = 0; /* mapq2 of this lane's position */
+  uint32_t applied = 0; /* reads applied to the tile so far: no cell can hold more bases than that */
+  const uint32_t b_lo = min_qual << 2, b_span = q_span << 2; /* the window test on the byte: quality in [min_qual, 63) */
   bool more = true;
   while (more) {
     const bool cand = kv <= (r_last >> ACC_BIN_SHIFT); /* reads are in key (bin) order: the candidates are a prefix of the batch */
@@ -85,16 +108,24 @@ __device__ static __forceinline__ uint32_t acc_walk(const bsc_read_desc *__restr
     {
       /* reads that overlap the tile at all (a read past the candidates starts right of the tile: a > p_last) */
       unsigned long long m = __ballot(d.b >= d.a && d.b >= pa && d.a <= p_last);
+      if (PACKED) {
+        applied += (uint32_t)__builtin_popcountll(m);
+        if (__builtin_expect(applied > ACC_PACK_MAX, 0)) return false;
+      }
       /* per descriptor lane: the read's part of the tile as position offsets lo .. lo + len from pa (meaningless where the
        * read does not overlap, never used there) packed with its orientation and MAPQ^2, and the address of the byte at lo */
       const uint32_t lo = (d.a > pa ? d.a : pa) - pa;
       const uint32_t pk = lo | (((d.b < p_last ? d.b : p_last) - pa - lo) << 6) | d.meta;
+      /* PACKED: a counted base touches one cell, counts[ori][c] — the strand's table with the orientation's 32 bytes folded
+       * into every entry gives its offset in one lookup */
+      const uint32_t lutv = PACKED ? d.lut + ((d.meta >> 12) & 1u) * 0x20202020u : d.lut;
       const uint64_t sp = (uint64_t)(uintptr_t)seq + (uint64_t)(d.base + (int64_t)pa + (int64_t)lo);
       /* Groups of ACC_GROUP, then smaller ones: the byte loads of a group are issued back to back and consumed
        * afterwards, so the wave waits for memory once per group.  Straight-line code per group size: slot
        * conditions inside a group would be evaluated on the VALU. */
       uint32_t cnt = (uint32_t)__builtin_popcountll(m);
-      uint32_t g_byte[ACC_GROUP], g_pk[ACC_GROUP], g_lut[ACC_GROUP];
+      unsigned char g_byte[ACC_GROUP];
+      uint32_t g_pk[ACC_GROUP], g_lut[ACC_GROUP];
 #define ACC_LOAD(u)                                                                                              \
   {                                                                                                              \
     const int src = __builtin_ctzll(m);                                                                          \
@@ -103,25 +134,27 @@ __device__ static __forceinline__ uint32_t acc_walk(const bsc_read_desc *__restr
     /* v_readlane returns int: without the casts the low word would be sign-extended into the high one */        \
     const uint32_t sp_lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)sp, src);                               \
     const uint32_t sp_hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(sp >> 32), src);                       \
-    g_lut[u] = (uint32_t)__builtin_amdgcn_readlane(d.lut, src);                                                  \
+    g_lut[u] = (uint32_t)__builtin_amdgcn_readlane(lutv, src);                                                   \
     g_pk[u] = pks;                                                                                               \
     /* raw buffer over the read's bytes in the tile, lo .. lo + len: offsets beyond it (the lanes in front of the   \
      * read wrap to huge offsets) read as 0 */                                                                   \
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(                                         \
         (void *)(uintptr_t)(((uint64_t)sp_hi << 32) | sp_lo), 0, (int)(((pks >> 6) & 63u) + 1u), 0x00020000);    \
-    g_byte[u] = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane_p - (pks & 63u)), 0, 0);                      \
+    ACC_EXP_LOAD(u, rs, pks)                                                                                     \
   }
 #define ACC_UPDATE(u)                                                                                            \
-  {                                                                                                              \
+  ACC_EXP_UPD(u) {                                                                                               \
     const uint32_t byte = g_byte[u], pks = g_pk[u];                                                              \
-    const uint32_t q = byte >> 2;                                                                                \
-    if (q - min_qual < q_span) { /* q counts iff min_qual <= q < 63 */                                           \
+    if (byte - b_lo < b_span) { /* the base counts iff min_qual <= quality < 63 (quality = byte >> 2) */         \
       /* v_alignbyte_b32 shifts by 8 * (byte & 3): the class offset of this base arrives in the low byte */      \
       const uint32_t c4 = __builtin_amdgcn_alignbyte(0u, g_lut[u], byte) & 0xffu;                                \
-      char *rc = reinterpret_cast<char *>(row) + c4;                                                             \
+      char *rc = reinterpret_cast<char *>(row) + c4 + (PACKED ? 0u : ((pks >> 7) & 32u)); /* the cell of counts[ori][c] */ \
       /* fire-and-forget ds_add_u32: the row has a single writer (this lane), no contention */                   \
-      atomicAdd(reinterpret_cast<uint32_t *>(rc + ((pks >> 7) & 32u)), 1u); /* counts[ori][c]++ */               \
-      atomicAdd(reinterpret_cast<uint32_t *>(rc + 68), q); /* quality[c] += q (integer; converted below) */      \
+      if (PACKED) atomicAdd(reinterpret_cast<uint32_t *>(rc), (byte << 12) | 1u); /* count++, byte sum += byte */ \
+      else {                                                                                                     \
+        atomicAdd(reinterpret_cast<uint32_t *>(rc), 1u);                                  /* counts[ori][c]++ */ \
+        atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(row) + c4 + 68), byte >> 2); /* quality[c] += q */ \
+      }                                                                                                          \
       m2sum = __builtin_elementwise_add_sat(m2sum, pks >> 16); /* mapq2 += mapq^2 (v_add_u32 clamp: a sum past   \
                                                                   2^32 sticks there, so INEXACT cannot be missed) */ \
     }                                                                                                            \
@@ -170,7 +203,57 @@ __device__ static __forceinline__ uint32_t acc_walk(const bsc_read_desc *__restr
     t0 += 64u;
     if (more) acc_fetch(rd, keys_sorted, perm, n_reads, t0, lane, kv, d); /* further batches: deep data */
   }
-  return m2sum;
+  return true;
+}
+
+/* The lane's row after the walk -> the 26 dwords of its `pileup` record (include/bs_call.h:174-182) in w[]: counts[2][8], n,
+ * the eight quality sums and the MAPQ^2 sum as the floats the reference accumulates (integer sums convert exactly below
+ * 2^24: DESIGN.md section 2).  Returns whether a sum left that range (BSC_WARN_INEXACT). */
+__device__ static __forceinline__ bool acc_unpack(const uint32_t *row, bool packed, uint32_t m2, uint32_t w[26]) {
+  uint32_t qs[8], n = 0;
+  if (packed) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint2 a = make_uint2(row[j], row[8 + j]);
+      w[j] = a.x & 0xfffu;
+      w[8 + j] = a.y & 0xfffu;
+      qs[j] = ((a.x >> 12) + (a.y >> 12) - (uint32_t)(j & 3) * (w[j] + w[8 + j])) >> 2;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; j++) w[j] = row[j];
+#pragma unroll
+    for (int j = 0; j < 8; j++) qs[j] = row[17 + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j++) n += w[j];
+  w[16] = n;
+  bool inexact = m2 >= (1u << 24);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    inexact |= qs[j] >= (1u << 24);
+    w[17 + j] = __float_as_uint((float)qs[j]);
+  }
+  w[25] = __float_as_uint((float)m2);
+  return inexact;
+}
+
+/* the whole tile: rows zeroed, walked packed, and — a tile more than ACC_PACK_MAX reads deep — once more unpacked */
+__device__ static __forceinline__ bool acc_tile(const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ keys_sorted,
+                                                const uint32_t *__restrict__ perm, uint32_t n_reads, const uint8_t *__restrict__ seq,
+                                                unsigned lane, uint32_t lane_p, uint32_t *row, uint32_t pa, uint32_t p_last,
+                                                uint32_t r_last, uint32_t min_qual, uint32_t q_span, uint32_t t0, uint32_t kv,
+                                                const bsc_read_desc &d, uint32_t w[26]) {
+  uint32_t m2;
+#pragma unroll
+  for (int i = 0; i < 8; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
+  bool packed = acc_walk<true>(rd, keys_sorted, perm, n_reads, seq, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2);
+  if (__builtin_expect(!packed, 0)) {
+#pragma unroll
+    for (int i = 0; i < 13; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
+    (void)acc_walk<false>(rd, keys_sorted, perm, n_reads, seq, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2);
+  }
+  return acc_unpack(row, packed, m2, w);
 }
 
 #endif /* BSCALL_AMD_ACCDEV_H */

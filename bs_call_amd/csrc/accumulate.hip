@@ -224,26 +224,11 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
     dn.lut = 0;
     if (have1) fetch(t0_next, kv_n, dn);
     if (have2) t0_nn = tile_lo[wt2];
-#pragma unroll
-    for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
-    const uint32_t m2sum = acc_walk(rd, keys_sorted, perm, n_reads, seq, lane, lane, row, p0, p_last, r_last, min_qual, q_span, t0, kv, d);
-    row[25] = m2sum;
-
-    /* n = sum of counts; integer sums -> float */
     {
-      uint32_t n = 0;
+      uint32_t w[IN_DW];
+      inexact |= acc_tile(rd, keys_sorted, perm, n_reads, seq, lane, lane, row, p0, p_last, r_last, min_qual, q_span, t0, kv, d, w) ? 1u : 0u;
 #pragma unroll
-      for (int j = 0; j < 16; j++) n += row[j];
-      row[16] = n;
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const uint32_t qs = row[17 + j];
-        inexact |= qs >= (1u << 24);
-        row[17 + j] = __float_as_uint((float)qs);
-      }
-      const uint32_t m2 = row[25];
-      inexact |= m2 >= (1u << 24);
-      row[25] = __float_as_uint((float)m2);
+      for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(w[2 * i], w[2 * i + 1]);
     }
     /* the slot is the tile's pileup[] image: copy it out */
     const uint32_t nvalid = p_last - p0 + 1u;

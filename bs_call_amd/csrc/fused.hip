@@ -458,28 +458,11 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       const int64_t bl = b0 + 63 < (int64_t)a.n_block - 1 ? b0 + 63 : (int64_t)a.n_block - 1; /* last block index of the tile */
       const uint32_t pa = a.x + (uint32_t)(b0 + (int64_t)loff), p_last = a.x + (uint32_t)bl;
       uint32_t *row = slot + lane * IN_DW;
+      const bool inx = acc_tile(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, ra.seq, lane, lane - loff, row, pa, p_last, (uint32_t)bl,
+                                ra.min_qual, q_span, acc_t0, acc_kv, acc_d, w);
+      uint32_t fmax = 0;
 #pragma unroll
-      for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
-      const uint32_t m2 = acc_walk(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, ra.seq, lane, lane - loff, row, pa, p_last, (uint32_t)bl,
-                                   ra.min_qual, q_span, acc_t0, acc_kv, acc_d);
-      uint32_t nsum = 0, fmax = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const uint2 v = reinterpret_cast<const uint2 *>(row)[i];
-        w[2 * i] = v.x;
-        w[2 * i + 1] = v.y;
-        nsum += v.x + v.y;
-      }
-      w[16] = nsum;
-      bool inx = m2 >= (1u << 24);
-#pragma unroll
-      for (int j = 0; j < 8; j++) { /* integer sums -> the reference's float sums (exact below 2^24) */
-        const uint32_t qs = row[17 + j];
-        inx |= qs >= (1u << 24);
-        w[17 + j] = __float_as_uint((float)qs);
-        fmax |= w[j];
-      }
-      w[25] = __float_as_uint((float)m2);
+      for (int j = 0; j < 8; j++) fmax |= w[j];
       inexact |= (inx && lane >= 2u && lane < 62u) ? 1u : 0u;
       /* the forward-strand counts, which only Fisher's test of a heterozygous call needs again, wait in the two dwords of
        * the lane's slot area that the calling statements leave alone (la[12]), a byte each; a tile with a larger count

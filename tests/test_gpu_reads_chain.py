@@ -71,7 +71,7 @@ def _oracle_chain(oracle, tables, libm_exact, tpl, seq, x, y, ref2, dbsnp=None, 
 
 
 @pytest.mark.parametrize("cov,n,x0", [(30, 120_000, 9_000), (10, 30_000, 5), (200, 6_000, 777_777), (30, 64, 100), (30, 1, 50),
-                                      (30, 59, 3), (30, 121, 1), (300, 3_000, 40)])
+                                      (30, 59, 3), (30, 121, 1), (300, 3_000, 40), (3000, 700, 40)])
 def test_reads_chain_vs_oracle(caller, oracle, tables, libm_exact, cov, n, x0):
     if not libm_exact:
         pytest.skip("host libm differs from the replica: the record bytes go through exp/log")
@@ -92,8 +92,9 @@ def test_reads_chain_vs_oracle(caller, oracle, tables, libm_exact, cov, n, x0):
 
 def test_reads_chain_equals_accumulate_then_chain(caller):
     """The same block through the unfused route on the device (bsc_accumulate_device -> bsc_chain_device): same bytes, and
-    the counts of a block whose forward counts exceed a byte (the scratch-line path of the heterozygous calls)."""
-    for cov, n in ((30, 400_000), (1400, 4_000)):
+    the counts of a block whose forward counts exceed a byte (the scratch-line path of the heterozygous calls); at 3 000x a
+    tile sees more reads than a packed pile-up cell can count (accdev.h ACC_PACK_MAX): both kernels take the unpacked walk."""
+    for cov, n in ((30, 400_000), (1400, 4_000), (3000, 1_500)):
         tpl, seq, x, y = _block(SEED + 800 + cov, 5_000, n, cov)
         sz = y - x + 1
         ref2 = B.synth_ref_host(SEED + 800 + cov, x, sz + 2)
