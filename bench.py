@@ -45,7 +45,8 @@ CHAIN_BYTES = 105 + 64  # fused chain: pile-up + reference code in, bsc_vcf_core
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 88172645463325252
 KERNEL_SOURCES = ("kernels.hip", "callmath.h", "call_body.inc", "bsmath.h", "bsmath_tables.h", "devtables.h")
-CHAIN_SOURCES = ("fused.hip", "callmath.h", "call_body.inc", "sitestats_dev.h", "bsmath.h", "bsmath_tables.h", "devtables.h")
+READS_SOURCES = ("fused.hip", "accdev.h", "accumulate.hip", "callmath.h", "call_body.inc", "sitestats_dev.h", "bsmath.h", "bsmath_tables.h", "devtables.h")
+CHAIN_SOURCES = ("fused.hip", "accdev.h", "callmath.h", "call_body.inc", "sitestats_dev.h", "bsmath.h", "bsmath_tables.h", "devtables.h")
 
 
 def main():
@@ -325,7 +326,7 @@ def reads_rooflines(args, caller):
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": a_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": profiled_traffic(args.sites, args.coverage, "accumulate"),
             "algorithmic_bytes_per_launch": a_bytes,
             "algorithmic_bytes_per_position": a_bytes / n,
             "stage_ms_avg": a_ms,
@@ -344,7 +345,7 @@ def reads_rooflines(args, caller):
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": profiled_traffic(args.sites, args.coverage, "reads"),
             "algorithmic_bytes_per_launch": r_bytes,
             "algorithmic_bytes_per_position": r_bytes / n,
             "stage_ms_avg": r_ms,
@@ -376,6 +377,8 @@ def profiled_traffic(n, coverage, which=None):
         want = kernel_source_hash()
         if which == "chain":  # the fused chain kernel's own passes (tools/bench_chain.py under --pmc), own source hash
             t, want = t["chain"], kernel_source_hash(CHAIN_SOURCES)
+        elif which in ("reads", "accumulate"):  # tools/bench_reads.py under --pmc
+            t, want = t[which], kernel_source_hash(READS_SOURCES)
         if t.get("positions") == n and t.get("coverage") == coverage and t.get("kernel_source_sha256_16") == want:
             return t["hbm_bytes_per_launch"]
     except Exception:

@@ -24,7 +24,7 @@ def per_dispatch(sub, name, kernel="bsc_call_kernel"):
     agg = {}
     for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == name and kernel in r.get("Kernel_Name", "") and "ILb0E" not in r["Kernel_Name"] and "<false>" not in r["Kernel_Name"]:
+            if r.get("Counter_Name") == name and kernel in r.get("Kernel_Name", "") and "ILb0E" not in r["Kernel_Name"] and "<false" not in r["Kernel_Name"]:
                 k = r["Dispatch_Id"]
                 agg[k] = agg.get(k, 0.0) + float(r["Counter_Value"])
     v = list(agg.values())
@@ -54,5 +54,17 @@ if os.path.isdir(os.path.join(d, "chain_fetch")):
         "hbm_bytes_per_launch": int((2 * cf + cw) * 1024),
         "kernel_source_sha256_16": bench.kernel_source_hash(bench.CHAIN_SOURCES),
     }
+if os.path.isdir(os.path.join(d, "reads_fetch")):
+    # the reads-in chain's kernel (READS = true) and the stand-alone accumulate kernel, from tools/bench_reads.py under --pmc
+    rf, rw = per_dispatch("reads_fetch", "FETCH_SIZE", "bsc_chain_kernel_t<true, true>"), per_dispatch("reads_write", "WRITE_SIZE", "bsc_chain_kernel_t<true, true>")
+    af, aw = per_dispatch("reads_fetch", "FETCH_SIZE", "bsc_accumulate_kernel"), per_dispatch("reads_write", "WRITE_SIZE", "bsc_accumulate_kernel")
+    src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python tools/bench_reads.py --steps 2 --no-check`, per dispatch"
+    h = bench.kernel_source_hash(bench.READS_SOURCES)
+    out["reads"] = {"_source": src + ", bsc_chain_kernel_t<true, true> (the dominant kernel of bsc_reads_chain_device)", "positions": positions,
+                    "coverage": coverage, "fetch_size_kib": rf, "write_size_kib": rw, "hbm_bytes_per_launch": int((2 * rf + rw) * 1024),
+                    "kernel_source_sha256_16": h}
+    out["accumulate"] = {"_source": src + ", bsc_accumulate_kernel (the dominant kernel of bsc_accumulate_device)", "positions": positions,
+                         "coverage": coverage, "fetch_size_kib": af, "write_size_kib": aw, "hbm_bytes_per_launch": int((2 * af + aw) * 1024),
+                         "kernel_source_sha256_16": h}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out))
