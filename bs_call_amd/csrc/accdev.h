@@ -9,10 +9,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-/* Reads are ordered by the 64-position bin of their first base, not by the position itself: the sums do not depend on the
- * order inside a bin, a tile's candidates are still a contiguous range of the ordered list (a few reads longer), and the
- * radix sort of a 50 Mb block handles 20 key bits instead of 26 — three passes instead of four. */
+/* Reads are grouped by the 64-position bin of their first base (accumulate.hip: count, scan, scatter — the sums do not
+ * depend on the order inside a bin, so a full sort is not needed): rd[] holds the live reads bin after bin, bin_off[b] the
+ * index of bin b's first read, bin_off[n_bins] their number.  A tile's candidates are the contiguous range from the bin of
+ * (tile start - longest read extent) on. */
 #define ACC_BIN_SHIFT 6
+
+/* what the walk needs of the grouped reads */
+struct acc_reads {
+  const struct bsc_read_desc *rd; /* live reads, grouped by bin */
+  const uint32_t *bin_off;        /* n_bins + 1 entries */
+  const uint8_t *seq;
+  uint32_t n_bins, x;             /* x: the block's first position (bin 0 starts there) */
+};
 
 /* timing experiments only (tools/build_variant_fused.sh): the walk without its loads / without its updates */
 #if defined(ACC_EXPERIMENT_NOLOAD)
@@ -53,18 +62,23 @@ __device__ static __forceinline__ void acc_dead(bsc_read_desc &e) {
   e.lut = 0;
 }
 
-/* 64 candidate reads per batch: lane i gets the sort key (bin of the first position relative to the block start) and the
- * descriptor of the read that comes (tb + i)-th in position order */
-__device__ static __forceinline__ void acc_fetch(const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ keys_sorted,
-                                                 const uint32_t *__restrict__ perm, uint32_t n_reads, uint32_t tb, unsigned lane,
-                                                 uint32_t &kv, bsc_read_desc &e) {
+/* 64 candidate reads per batch: lane i gets the descriptor of the read that comes (tb + i)-th in bin order and its bin */
+__device__ static __forceinline__ void acc_fetch(const acc_reads &R, uint32_t n_live, uint32_t tb, unsigned lane, uint32_t &kv,
+                                                 bsc_read_desc &e) {
   const uint32_t t = tb + lane;
   kv = 0xffffffffu;
   acc_dead(e);
-  if (t < n_reads) {
-    kv = keys_sorted[t];
-    e = rd[perm[t]];
+  if (t < n_live) {
+    e = R.rd[t];
+    kv = (e.a - R.x) >> ACC_BIN_SHIFT;
   }
+}
+
+/* index of the first candidate read of a tile whose first position is r0 (relative to the block start; below 0: the block
+ * start), given the longest read extent of the block */
+__device__ static __forceinline__ uint32_t acc_tile_start(const acc_reads &R, int64_t r0, uint32_t span) {
+  const int64_t k = r0 - (int64_t)span;
+  return R.bin_off[k > 0 ? (uint32_t)k >> ACC_BIN_SHIFT : 0u];
 }
 
 /*
@@ -93,11 +107,10 @@ __device__ static __forceinline__ void acc_fetch(const bsc_read_desc *__restrict
  */
 #define ACC_PACK_MAX 4095u
 template <bool PACKED>
-__device__ static __forceinline__ bool acc_walk(const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ keys_sorted,
-                                                const uint32_t *__restrict__ perm, uint32_t n_reads, const uint8_t *__restrict__ seq,
-                                                unsigned lane, uint32_t lane_p, uint32_t *row, uint32_t pa, uint32_t p_last,
-                                                uint32_t r_last, uint32_t min_qual, uint32_t q_span, uint32_t t0, uint32_t kv,
-                                                bsc_read_desc d, uint32_t &m2sum) {
+__device__ static __forceinline__ bool acc_walk(const acc_reads &R, uint32_t n_live, unsigned lane, uint32_t lane_p, uint32_t *row,
+                                                uint32_t pa, uint32_t p_last, uint32_t r_last, uint32_t min_qual, uint32_t q_span,
+                                                uint32_t t0, uint32_t kv, bsc_read_desc d, uint32_t &m2sum) {
+  const uint8_t *__restrict__ const seq = R.seq;
   m2sum = 0; /* mapq2 of this lane's position */
   uint32_t applied = 0; /* reads applied to the tile so far: no cell can hold more bases than that */
   const uint32_t b_lo = min_qual << 2, b_span = q_span << 2; /* the window test on the byte: quality in [min_qual, 63) */
@@ -201,7 +214,7 @@ __device__ static __forceinline__ bool acc_walk(const bsc_read_desc *__restrict_
 #undef ACC_UPDATE
     }
     t0 += 64u;
-    if (more) acc_fetch(rd, keys_sorted, perm, n_reads, t0, lane, kv, d); /* further batches: deep data */
+    if (more) acc_fetch(R, n_live, t0, lane, kv, d); /* further batches: deep data */
   }
   return true;
 }
@@ -239,19 +252,17 @@ __device__ static __forceinline__ bool acc_unpack(const uint32_t *row, bool pack
 }
 
 /* the whole tile: rows zeroed, walked packed, and — a tile more than ACC_PACK_MAX reads deep — once more unpacked */
-__device__ static __forceinline__ bool acc_tile(const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ keys_sorted,
-                                                const uint32_t *__restrict__ perm, uint32_t n_reads, const uint8_t *__restrict__ seq,
-                                                unsigned lane, uint32_t lane_p, uint32_t *row, uint32_t pa, uint32_t p_last,
-                                                uint32_t r_last, uint32_t min_qual, uint32_t q_span, uint32_t t0, uint32_t kv,
-                                                const bsc_read_desc &d, uint32_t w[26]) {
+__device__ static __forceinline__ bool acc_tile(const acc_reads &R, uint32_t n_live, unsigned lane, uint32_t lane_p, uint32_t *row,
+                                                uint32_t pa, uint32_t p_last, uint32_t r_last, uint32_t min_qual, uint32_t q_span,
+                                                uint32_t t0, uint32_t kv, const bsc_read_desc &d, uint32_t w[26]) {
   uint32_t m2;
 #pragma unroll
   for (int i = 0; i < 8; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
-  bool packed = acc_walk<true>(rd, keys_sorted, perm, n_reads, seq, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2);
+  bool packed = acc_walk<true>(R, n_live, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2);
   if (__builtin_expect(!packed, 0)) {
 #pragma unroll
     for (int i = 0; i < 13; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
-    (void)acc_walk<false>(rd, keys_sorted, perm, n_reads, seq, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2);
+    (void)acc_walk<false>(R, n_live, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2);
   }
   return acc_unpack(row, packed, m2, w);
 }

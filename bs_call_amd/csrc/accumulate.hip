@@ -3,20 +3,16 @@
  * positions [x, y].  Replaces HOT LOOP A of call_genotypes_ML (reference src/call_genotypes.c:178-226),
  * which the reference runs serially on its process thread.
  *
- *   bsc_prep_reads_kernel   one thread per template: the reference's asserts on the template; per read the
- *                           orientation it is counted with (:187,224, including the reference's quirk that a read 0
- *                           without a countable base does not flip it), a compact descriptor and its sort key (the
- *                           position of its first base); also the longest read extent of the block.
- *   (sort.hip)              the block's reads ordered by that key on the device.
- *   bsc_tile_lo_kernel      one thread per 64-position wave-tile: binary search for the first read that can reach
- *                           the tile.
- *   bsc_accumulate_kernel   one wave per wave-tile, lane i OWNS position i of the tile: the wave walks the
- *                           candidate templates (64 descriptors per vector load, ballot-filtered to the reads
- *                           that overlap the tile, broadcast with v_readlane), every lane fetches "its" base of
- *                           the read (consecutive lanes = consecutive bytes: coalesced) and bumps its own
- *                           pile-up row in the wave's LDS slot.  A row has one writer, so there is no atomic
- *                           contention and the result does not depend on any ordering; the slot is the
- *                           reference's pileup[] layout and leaves with 16-byte-per-lane stores.
+ *   bsc_bin_count_kernel    one thread per template: the reference's asserts on the template; per read the
+ *   bsc_bin_scatter_kernel  orientation it is counted with (:187,224, including the reference's quirk that a read 0
+ *                           without a countable base does not flip it) and a compact descriptor; the reads grouped by the
+ *                           64-position bin of their first base in two passes around a prefix sum (count in an LDS window
+ *                           per workgroup, scatter by rank) — no sort: the sums do not depend on the order inside a bin.
+ *   bsc_accumulate_kernel   one wave per 64-position wave-tile, lane i OWNS position i of the tile: the wave walks the
+ *                           candidate reads (accdev.h: 64 descriptors per vector load, ballot-filtered to the reads that
+ *                           overlap the tile, broadcast with v_readlane), every lane fetches "its" base of the read
+ *                           (consecutive lanes = consecutive bytes: coalesced) and bumps its own pile-up row in the wave's
+ *                           LDS slot.
  *
  * Exactness: the reference sums base qualities and MAPQ^2 in float.  Sums of integers are exact in float
  * below 2^24, and then order-independent, so integer accumulation + one conversion gives the same bits.
@@ -65,44 +61,80 @@ __device__ static __forceinline__ uint32_t template_error(const bsc_template_dev
   return 0;
 }
 
-/* One thread per template (in the caller's order): the reference's asserts (the lowest index of an invalid template with
- * its first failing check reaches the host through counters[BSC_CNT_ERR]; such a template contributes nothing), then per
- * read the leading/trailing scan, the orientation it is counted with and its descriptor rd[2t + k], and its sort key:
- * the first countable position relative to the block start, key_max for a read that contributes nothing.  READS, not
- * templates, are what the tiles search: a read's extent is bounded by its length, so mates that lie far apart (or a
- * pathological template) cannot widen every tile's candidate window. */
-extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bsc_template_dev *__restrict__ tpl,
-                                                                        uint32_t nr, const uint8_t *__restrict__ seq,
-                                                                        uint64_t seq_bytes, uint32_t x, uint32_t y,
-                                                                        uint32_t key_max, bsc_read_desc *__restrict__ rd,
-                                                                        uint32_t *__restrict__ keys,
-                                                                        unsigned long long *__restrict__ counters) {
-  uint32_t span_max = 0;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nr; t += gridDim.x * blockDim.x) {
-    const bsc_template_dev tp = tpl[t];
-    const uint32_t left = leftmost(tp.pos[0], tp.pos[1]);
-    const uint32_t terr = template_error(tp, left, x, seq_bytes);
-    if (terr) {
-      atomicMin(&counters[BSC_CNT_ERR], ((unsigned long long)t << 8) | terr);
-      bsc_read_desc d;
-      acc_dead(d);
-      rd[2 * (uint64_t)t] = d;
-      rd[2 * (uint64_t)t + 1] = d;
-      keys[2 * (uint64_t)t] = key_max;
-      keys[2 * (uint64_t)t + 1] = key_max;
-      continue;
+/*
+ * What one template contributes: its two read descriptors (dead ones for a read that contributes nothing), and its error code.
+ * `walked0`: read 0 has a base with a quality other than 0 / 63.  The reference walks a read from its first to its last such
+ * base (:198-211) and tests every base in between against min_qual (:217); the bases it trims off the ends fail that test
+ * anyway (0 < min_qual, 63 is excluded by name), so the device walks the whole read.  What the scan does decide is whether a
+ * read counts as walked at all: only then is the orientation flipped for its mate (:224, and the `continue`s of :203,:210 in
+ * front of it).
+ */
+__device__ static __forceinline__ uint32_t template_reads(const bsc_template_dev &tp, uint32_t x, uint32_t y, uint64_t seq_bytes,
+                                                          bool walked0, bsc_read_desc d[2]) {
+  acc_dead(d[0]);
+  acc_dead(d[1]);
+  const uint32_t terr = template_error(tp, leftmost(tp.pos[0], tp.pos[1]), x, seq_bytes);
+  if (terr) return terr;
+  uint32_t ori = tp.orientation & 1u;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint32_t rl = tp.len[k];
+    if (rl != 0 && (k == 1 || walked0)) {
+      const uint64_t pa = (uint64_t)tp.pos[k], pb = (uint64_t)tp.pos[k] + rl - 1u;
+      if (pa <= y) {
+        d[k].a = (uint32_t)pa;
+        d[k].b = pb > y ? y : (uint32_t)pb; /* pos <= y, :214 */
+        d[k].base = (int64_t)tp.off[k] - (int64_t)tp.pos[k];
+        d[k].meta = ACC_META(ori, tp.mapq[k]);
+        d[k].lut = tp.bs_strand == 0 ? LUT4(0, 1, 2, 3) : (tp.bs_strand == 1 ? LUT4(0, 5, 2, 7) : LUT4(4, 1, 6, 3));
+      }
     }
-    uint32_t ori = tp.orientation & 1u;
-    /*
-     * The reference walks a read from its first to its last base with a quality other than 0 / 63 (:198-211) and tests every
-     * base in between against min_qual (:217).  The bases it trims off the ends fail that test anyway (0 < min_qual, 63 is
-     * excluded by name), so the device walks the whole read and this kernel does not look for the ends.  What the scan does
-     * decide is whether a read counts as walked at all: only then is the orientation flipped for its mate (:224, and the
-     * `continue`s of :203,:210 in front of it).  That needs the first countable base of read 0 — almost always its first
-     * byte, so one byte per template is fetched here instead of four.
-     */
+    if (k == 0 && walked0) ori ^= 1u; /* :224 — only a read that was walked flips the orientation */
+  }
+  return 0;
+}
+
+#define BIN_WG 256   /* templates per workgroup */
+#define BIN_WIN 1024 /* bins of the workgroup's LDS window: a coordinate-ordered align_list keeps a workgroup's 512 reads
+                        within a few dozen bins; reads outside the window take a global atomic each */
+
+/* the workgroup's window starts at the lowest bin among its live reads */
+__device__ static __forceinline__ uint32_t wg_min_bin(uint32_t b0, uint32_t b1, uint32_t *s_min) {
+  if (threadIdx.x == 0) *s_min = 0xffffffffu;
+  __syncthreads();
+  uint32_t m = b0 < b1 ? b0 : b1;
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t v = __shfl_xor(m, o);
+    m = v < m ? v : m;
+  }
+  if ((threadIdx.x & 63u) == 0 && m != 0xffffffffu) atomicMin(s_min, m);
+  __syncthreads();
+  return *s_min;
+}
+
+/*
+ * Grouping the block's reads by the 64-position bin of their first base, pass 1 of 2 — one thread per template, in the
+ * caller's order: the reference's asserts (the lowest index of an invalid template with its first failing check reaches the
+ * host through counters[BSC_CNT_ERR]; such a template contributes nothing), whether read 0 was walked (one byte of it,
+ * almost always; kept in tflag[] for pass 2), the bins of its two reads counted — in an LDS window of the workgroup, one
+ * global atomic per non-empty bin and workgroup — and the longest read extent of the block.
+ * READS, not templates, are what the tiles search: a read's extent is bounded by its length, so mates that lie far apart
+ * (or a pathological template) cannot widen every tile's candidate window.
+ */
+extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_count_kernel(const bsc_template_dev *__restrict__ tpl, uint32_t nr,
+                                                                          const uint8_t *__restrict__ seq, uint64_t seq_bytes,
+                                                                          uint32_t x, uint32_t y, uint8_t *__restrict__ tflag,
+                                                                          uint32_t *__restrict__ bin_cnt,
+                                                                          unsigned long long *__restrict__ counters) {
+  __shared__ uint32_t s_cnt[BIN_WIN];
+  __shared__ uint32_t s_min;
+  for (unsigned i = threadIdx.x; i < BIN_WIN; i += BIN_WG) s_cnt[i] = 0;
+  const uint32_t t = blockIdx.x * BIN_WG + threadIdx.x;
+  uint32_t bin[2] = {0xffffffffu, 0xffffffffu}, span_max = 0;
+  if (t < nr) {
+    const bsc_template_dev tp = tpl[t];
     bool walked0 = false;
-    {
+    if (template_error(tp, leftmost(tp.pos[0], tp.pos[1]), x, seq_bytes) == 0) {
       const uint32_t rl = tp.len[0];
       const uint8_t *sp = seq + tp.off[0];
       for (uint32_t j = 0; j < rl; j++) {
@@ -113,28 +145,27 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
         }
       }
     }
+    tflag[t] = walked0 ? 1 : 0;
+    bsc_read_desc d[2];
+    const uint32_t terr = template_reads(tp, x, y, seq_bytes, walked0, d);
+    if (terr) atomicMin(&counters[BSC_CNT_ERR], ((unsigned long long)t << 8) | terr);
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-      bsc_read_desc d;
-      acc_dead(d);
-      const uint32_t rl = tp.len[k];
-      if (rl != 0 && (k == 1 || walked0)) {
-        const uint64_t pa = (uint64_t)tp.pos[k], pb = (uint64_t)tp.pos[k] + rl - 1u;
-        if (pa <= y) {
-          d.a = (uint32_t)pa;
-          d.b = pb > y ? y : (uint32_t)pb; /* pos <= y, :214 */
-          d.base = (int64_t)tp.off[k] - (int64_t)tp.pos[k];
-          d.meta = ACC_META(ori, tp.mapq[k]);
-          d.lut = tp.bs_strand == 0 ? LUT4(0, 1, 2, 3) : (tp.bs_strand == 1 ? LUT4(0, 5, 2, 7) : LUT4(4, 1, 6, 3));
-        }
+    for (int k = 0; k < 2; k++)
+      if (d[k].b >= d[k].a) { /* live: x <= a <= b <= y */
+        bin[k] = (d[k].a - x) >> ACC_BIN_SHIFT;
+        if (d[k].b - d[k].a > span_max) span_max = d[k].b - d[k].a;
       }
-      if (k == 0 && walked0) ori ^= 1u; /* :224 — only a read that was walked flips the orientation */
-      rd[2 * (uint64_t)t + k] = d;
-      const bool live = d.b >= d.a; /* then x <= a <= b <= y */
-      keys[2 * (uint64_t)t + k] = live ? (d.a - x) >> ACC_BIN_SHIFT : key_max;
-      if (live && d.b - d.a > span_max) span_max = d.b - d.a;
-    }
   }
+  const uint32_t base = wg_min_bin(bin[0], bin[1], &s_min); /* also orders the zeroing of s_cnt before its use */
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (bin[k] != 0xffffffffu) {
+      if (bin[k] - base < BIN_WIN) atomicAdd(&s_cnt[bin[k] - base], 1u);
+      else atomicAdd(&bin_cnt[bin[k]], 1u);
+    }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < BIN_WIN; i += BIN_WG)
+    if (s_cnt[i]) atomicAdd(&bin_cnt[base + i], s_cnt[i]);
   /* longest read extent: wave max, one atomic per wave */
   for (int o = 32; o > 0; o >>= 1) {
     const uint32_t v = __shfl_xor(span_max, o);
@@ -148,37 +179,56 @@ extern "C" __global__ __launch_bounds__(256) void bsc_prep_reads_kernel(const bs
     atomicMax(&counters[BSC_CNT_SPAN], (unsigned long long)span_max);
 }
 
-/* Tile wt starts at block-relative position base + wt * step (below 0: at the block start): step 64, base 0 for the
- * stand-alone accumulate kernel; step 60, base = window start - 2 for the reads-in chain (fused.hip). */
-extern "C" __global__ __launch_bounds__(256) void bsc_tile_lo_kernel(const uint32_t *__restrict__ keys_sorted,
-                                                                     uint32_t n_reads, uint32_t n_wt, int64_t base, uint32_t step,
-                                                                     const unsigned long long *__restrict__ counters,
-                                                                     uint32_t *__restrict__ tile_lo) {
-  const int64_t span = (int64_t)(uint32_t)counters[BSC_CNT_SPAN]; /* longest read extent, b - a */
-  for (uint32_t wt = blockIdx.x * blockDim.x + threadIdx.x; wt < n_wt; wt += gridDim.x * blockDim.x) {
-    const int64_t r0 = base + (int64_t)wt * step;       /* the tile's first position, relative to the block start */
-    const uint32_t key = r0 > span ? (uint32_t)(r0 - span) >> ACC_BIN_SHIFT : 0u; /* bin of the first read that can still reach it */
-    uint32_t lo = 0, hi = n_reads;
-    while (lo < hi) {
-      const uint32_t mid = lo + ((hi - lo) >> 1);
-      if (keys_sorted[mid] < key) lo = mid + 1;
-      else hi = mid;
-    }
-    tile_lo[wt] = lo;
+/*
+ * Pass 2: bin_cur[] starts as the exclusive prefix sum of the bin counts (= bin_off[]).  Every workgroup takes, per bin of
+ * its window, as many consecutive slots of that bin as it has reads for it (one global atomic per non-empty bin) and its
+ * reads take theirs by their rank inside the workgroup (LDS atomic); the descriptors land in rd[] bin after bin.  The order
+ * inside a bin depends on the order the atomics were served in — the pile-up sums do not.
+ */
+extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_scatter_kernel(const bsc_template_dev *__restrict__ tpl, uint32_t nr,
+                                                                            uint64_t seq_bytes, uint32_t x, uint32_t y,
+                                                                            const uint8_t *__restrict__ tflag,
+                                                                            uint32_t *__restrict__ bin_cur,
+                                                                            bsc_read_desc *__restrict__ rd) {
+  __shared__ uint32_t s_cnt[BIN_WIN]; /* reads of the workgroup per bin of its window, then: the first slot they got */
+  __shared__ uint32_t s_min;
+  for (unsigned i = threadIdx.x; i < BIN_WIN; i += BIN_WG) s_cnt[i] = 0;
+  const uint32_t t = blockIdx.x * BIN_WG + threadIdx.x;
+  uint32_t bin[2] = {0xffffffffu, 0xffffffffu}, rank[2] = {0, 0};
+  bsc_read_desc d[2];
+  acc_dead(d[0]);
+  acc_dead(d[1]);
+  if (t < nr) {
+    (void)template_reads(tpl[t], x, y, seq_bytes, tflag[t] != 0, d);
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (d[k].b >= d[k].a) bin[k] = (d[k].a - x) >> ACC_BIN_SHIFT;
   }
+  const uint32_t base = wg_min_bin(bin[0], bin[1], &s_min);
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (bin[k] != 0xffffffffu && bin[k] - base < BIN_WIN) rank[k] = atomicAdd(&s_cnt[bin[k] - base], 1u);
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < BIN_WIN; i += BIN_WG)
+    if (s_cnt[i]) s_cnt[i] = atomicAdd(&bin_cur[base + i], s_cnt[i]);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (bin[k] != 0xffffffffu) {
+      const uint32_t slot = bin[k] - base < BIN_WIN ? s_cnt[bin[k] - base] + rank[k] : atomicAdd(&bin_cur[bin[k]], 1u);
+      rd[slot] = d[k];
+    }
 }
 
 /*
- * The kernel is instruction-issue bound (profiles/: VALU and scalar units each busy ~2/3 of the time, memory and LDS
- * far from their limits), so the work per (read, tile) pair is kept to a minimum: what depends on the read and the
- * tile but not on the lane — the read's lane range, the address of its first byte in the tile — is computed once per
- * descriptor lane, 64 reads at a time, and reaches the scalar registers with v_readlane; per lane that leaves
- * clamp, load, range test, quality test, class lookup (v_alignbyte on the strand's table), two LDS adds, one add.
+ * The stand-alone accumulate kernel: one wave per 64-position tile; lane i owns position i of the tile and bumps its own
+ * pile-up row in the wave's LDS slot (accdev.h: the walk).  A row has one writer, so there is no atomic contention and the
+ * result does not depend on any ordering; the slot becomes the reference's pileup[] layout and leaves with 16-byte-per-lane
+ * stores.
  */
 extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel(
-    const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ keys_sorted, const uint32_t *__restrict__ perm,
-    uint32_t n_reads, const uint8_t *__restrict__ seq, uint32_t x, uint32_t y, uint32_t min_qual,
-    const uint32_t *__restrict__ tile_lo, uint32_t *__restrict__ cts, unsigned long long *__restrict__ counters) {
+    const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ bin_off, uint32_t n_bins, const uint8_t *__restrict__ seq,
+    uint32_t x, uint32_t y, uint32_t min_qual, uint32_t *__restrict__ cts, unsigned long long *__restrict__ counters) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_slot[ACC_WAVES][SLOT_DW];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -189,44 +239,42 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
   /* q counts iff min_qual <= q < 63 (:217)  <=>  (q - min_qual) <u q_span */
   const uint32_t q_span = min_qual < 63u ? 63u - min_qual : 0u;
   unsigned inexact = 0;
-  auto fetch = [&](uint32_t tb, uint32_t &kv, bsc_read_desc &e) { acc_fetch(rd, keys_sorted, perm, n_reads, tb, lane, kv, e); };
-  /* Software pipeline over the wave's tiles: while tile i is processed, the first batch of tile i+1 and the start
-   * index of tile i+2 are on their way, so the tile_lo -> key / index -> descriptor chain of dependent loads is off the
-   * critical path. */
+  acc_reads R;
+  R.rd = rd;
+  R.bin_off = bin_off;
+  R.seq = seq;
+  R.n_bins = n_bins;
+  R.x = x;
+  const uint32_t n_live = bin_off[n_bins];
+  const uint32_t span = (uint32_t)counters[BSC_CNT_SPAN]; /* longest read extent, b - a */
+  /* Software pipeline over the wave's tiles: while tile i is processed, the first batch of tile i+1 is on its way */
   const uint32_t wt_step = gridDim.x * ACC_WAVES;
   uint32_t wt = blockIdx.x * ACC_WAVES + wid;
-  uint32_t t0 = 0, t0_next = 0, kv = 0xffffffffu;
+  uint32_t t0 = 0, kv = 0xffffffffu;
   bsc_read_desc d;
-  d.a = 1;
-  d.b = 0;
-  d.base = 0;
-  d.meta = 0;
-  d.lut = 0;
+  acc_dead(d);
   if (wt < n_wt) {
-    t0 = tile_lo[wt];
-    if (wt + wt_step < n_wt && wt + wt_step > wt) t0_next = tile_lo[wt + wt_step];
-    fetch(t0, kv, d);
+    t0 = acc_tile_start(R, (int64_t)wt * 64, span);
+    acc_fetch(R, n_live, t0, lane, kv, d);
   }
   for (; wt < n_wt; wt += wt_step) {
     /* x + 64 wt <= y: the tile's first position fits 32 bits; its last one is clipped to y */
     const uint32_t p0 = x + wt * 64u;
     const uint32_t p_last = y - p0 < 63u ? y : p0 + 63u;
-    const uint32_t r_last = p_last - x; /* the tile's last position as a sort key */
+    const uint32_t r_last = p_last - x; /* the tile's last position relative to the block start */
     const bool valid = lane <= p_last - p0;
-    const uint32_t wt1 = wt + wt_step, wt2 = wt1 + wt_step;
-    const bool have1 = wt1 < n_wt && wt1 > wt, have2 = have1 && wt2 < n_wt && wt2 > wt1;
-    uint32_t kv_n = 0xffffffffu, t0_nn = 0;
+    const uint32_t wt1 = wt + wt_step;
+    const bool have1 = wt1 < n_wt && wt1 > wt;
+    uint32_t kv_n = 0xffffffffu, t0_n = 0;
     bsc_read_desc dn;
-    dn.a = 1;
-    dn.b = 0;
-    dn.base = 0;
-    dn.meta = 0;
-    dn.lut = 0;
-    if (have1) fetch(t0_next, kv_n, dn);
-    if (have2) t0_nn = tile_lo[wt2];
+    acc_dead(dn);
+    if (have1) {
+      t0_n = acc_tile_start(R, (int64_t)wt1 * 64, span);
+      acc_fetch(R, n_live, t0_n, lane, kv_n, dn);
+    }
     {
       uint32_t w[IN_DW];
-      inexact |= acc_tile(rd, keys_sorted, perm, n_reads, seq, lane, lane, row, p0, p_last, r_last, min_qual, q_span, t0, kv, d, w) ? 1u : 0u;
+      inexact |= acc_tile(R, n_live, lane, lane, row, p0, p_last, r_last, min_qual, q_span, t0, kv, d, w) ? 1u : 0u;
 #pragma unroll
       for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(w[2 * i], w[2 * i + 1]);
     }
@@ -243,8 +291,7 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
 #pragma unroll
       for (int i = 0; i < IN_DW; i++) dst[lane * IN_DW + i] = row[i];
     }
-    t0 = t0_next;
-    t0_next = t0_nn;
+    t0 = t0_n;
     kv = kv_n;
     d = dn;
   }
@@ -255,60 +302,43 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
 }
 
 /* ---- launchers ------------------------------------------------------------------------------------------ */
-extern "C" int bsc_dev_sort_templates(const void *keys, void *keys_sorted, void *perm, uint32_t nr, unsigned key_bits,
-                                      void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
+extern "C" int bsc_dev_scan_u32(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
 
-/* template checks, read descriptors and the ordering of the block's reads: rd[2 nr], keys_sorted[2 nr], perm[2 nr] */
-extern "C" int bsc_dev_launch_prep_reads(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
-                                         void *keys, void *keys_sorted, void *perm, void *sort_tmp, size_t sort_tmp_bytes,
-                                         void *rd, void *counters, int num_cus, void *stream) {
-  if (!nr) return 0;
+/* bins of a block of n_sites positions */
+extern "C" uint32_t bsc_dev_n_bins(uint32_t n_sites) { return ((n_sites - 1u) >> ACC_BIN_SHIFT) + 1u; }
+
+/* template checks, read descriptors and their grouping by bin: rd[<= 2 nr] (live reads, bin after bin), bin_off[n_bins + 1].
+ * bin_cnt / bin_off / bin_cur: n_bins + 1 words each; tflag: nr bytes. */
+extern "C" int bsc_dev_launch_bin_reads(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                                        void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
+                                        size_t scan_tmp_bytes, void *rd, void *counters, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  const uint32_t n_sites = y - x + 1;
-  const uint32_t n_reads = 2u * nr; /* nr <= 2^31 - 1 is checked by the caller */
-  unsigned g = (nr + 255u) / 256u;
-  if (g > (unsigned)num_cus * 16u) g = (unsigned)num_cus * 16u;
-  /* keys 0 .. key_max - 1: the 64-position bins of x .. y; key_max: a read that contributes nothing */
-  const uint32_t key_max = ((n_sites - 1u) >> ACC_BIN_SHIFT) + 1u;
-  unsigned key_bits = 1;
-  while (key_bits < 32 && (key_max >> key_bits)) key_bits++;
-  hipLaunchKernelGGL(bsc_prep_reads_kernel, dim3(g), dim3(256), 0, s, (const bsc_template_dev *)tpl, nr, (const uint8_t *)seq,
-                     seq_bytes, x, y, key_max, (bsc_read_desc *)rd, (uint32_t *)keys, (unsigned long long *)counters);
-  hipError_t e = hipGetLastError();
+  const uint32_t nb = bsc_dev_n_bins(y - x + 1);
+  const size_t bytes = ((size_t)nb + 1u) * sizeof(uint32_t);
+  if (!nr) return (int)hipMemsetAsync(bin_off, 0, bytes, s); /* no reads: every bin empty */
+  hipError_t e = hipMemsetAsync(bin_cnt, 0, bytes, s);
   if (e != hipSuccess) return (int)e;
-  return bsc_dev_sort_templates(keys, keys_sorted, perm, n_reads, key_bits, sort_tmp, sort_tmp_bytes, stream);
-}
-
-/* first candidate read of every tile (see bsc_tile_lo_kernel) */
-extern "C" int bsc_dev_launch_tile_lo(const void *keys_sorted, uint32_t n_reads, uint32_t n_tiles, int64_t base, uint32_t step,
-                                      const void *counters, void *tile_lo, int num_cus, void *stream) {
-  if (!n_tiles) return 0;
-  unsigned g = (n_tiles + 255u) / 256u;
-  if (g > (unsigned)num_cus * 16u) g = (unsigned)num_cus * 16u;
-  hipLaunchKernelGGL(bsc_tile_lo_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)keys_sorted, n_reads,
-                     n_tiles, base, step, (const unsigned long long *)counters, (uint32_t *)tile_lo);
+  const unsigned g = (nr + BIN_WG - 1u) / BIN_WG; /* nr <= 2^31 - 1 is checked by the caller */
+  hipLaunchKernelGGL(bsc_bin_count_kernel, dim3(g), dim3(BIN_WG), 0, s, (const bsc_template_dev *)tpl, nr, (const uint8_t *)seq,
+                     seq_bytes, x, y, (uint8_t *)tflag, (uint32_t *)bin_cnt, (unsigned long long *)counters);
+  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  int rc = bsc_dev_scan_u32(bin_cnt, bin_off, nb + 1u, scan_tmp, scan_tmp_bytes, stream);
+  if (rc) return rc;
+  if ((e = hipMemcpyAsync(bin_cur, bin_off, bytes, hipMemcpyDeviceToDevice, s)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(bsc_bin_scatter_kernel, dim3(g), dim3(BIN_WG), 0, s, (const bsc_template_dev *)tpl, nr, seq_bytes, x, y,
+                     (const uint8_t *)tflag, (uint32_t *)bin_cur, (bsc_read_desc *)rd);
   return (int)hipGetLastError();
 }
 
-extern "C" int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x,
-                                         uint32_t y, uint32_t min_qual, void *keys, void *keys_sorted, void *perm,
-                                         void *sort_tmp, size_t sort_tmp_bytes, void *rd, void *tile_lo, void *cts,
-                                         void *counters, int num_cus, void *stream) {
-  hipStream_t s = (hipStream_t)stream;
+extern "C" int bsc_dev_launch_accumulate(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y, uint32_t min_qual,
+                                         void *cts, void *counters, int num_cus, void *stream) {
   const uint32_t n_sites = y - x + 1;
   const uint32_t n_wt = (n_sites + 63u) / 64u;
-  const uint32_t n_reads = 2u * nr;
-  int rc = bsc_dev_launch_prep_reads(tpl, nr, seq, seq_bytes, x, y, keys, keys_sorted, perm, sort_tmp, sort_tmp_bytes, rd, counters,
-                                     num_cus, stream);
-  if (rc) return rc;
-  if ((rc = bsc_dev_launch_tile_lo(keys_sorted, n_reads, n_wt, 0, 64u, counters, tile_lo, num_cus, stream))) return rc;
-  {
-    unsigned g = (n_wt + ACC_WAVES - 1) / ACC_WAVES;
-    const unsigned cap = (unsigned)num_cus * 6u * 8u; /* 6 workgroups of 26 KB LDS fit a CU */
-    if (g > cap) g = cap;
-    hipLaunchKernelGGL(bsc_accumulate_kernel, dim3(g), dim3(64 * ACC_WAVES), 0, s, (const bsc_read_desc *)rd,
-                       (const uint32_t *)keys_sorted, (const uint32_t *)perm, n_reads, (const uint8_t *)seq, x, y, min_qual,
-                       (const uint32_t *)tile_lo, (uint32_t *)cts, (unsigned long long *)counters);
-  }
+  unsigned g = (n_wt + ACC_WAVES - 1) / ACC_WAVES;
+  const unsigned cap = (unsigned)num_cus * 6u * 8u; /* 6 workgroups of 26 KB LDS fit a CU */
+  if (g > cap) g = cap;
+  hipLaunchKernelGGL(bsc_accumulate_kernel, dim3(g), dim3(64 * ACC_WAVES), 0, (hipStream_t)stream, (const bsc_read_desc *)rd,
+                     (const uint32_t *)bin_off, bsc_dev_n_bins(n_sites), (const uint8_t *)seq, x, y, min_qual, (uint32_t *)cts,
+                     (unsigned long long *)counters);
   return (int)hipGetLastError();
 }

@@ -24,11 +24,12 @@
 int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n, void *out, uint32_t out_dw, void *skip,
                         const void *tb, void *het_list, void *counters, int num_cus, void *stream, void *ev_start,
                         void *ev_mid, void *ev_stop);
-int bsc_dev_launch_accumulate(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
-                              uint32_t min_qual, void *keys, void *keys_sorted, void *perm, void *sort_tmp,
-                              size_t sort_tmp_bytes, void *rd, void *tile_lo, void *cts, void *counters, int num_cus,
-                              void *stream);
-int bsc_dev_sort_tmp_bytes(uint32_t nr, size_t *bytes); /* sort.hip */
+int bsc_dev_launch_accumulate(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y, uint32_t min_qual, void *cts,
+                              void *counters, int num_cus, void *stream);
+int bsc_dev_launch_bin_reads(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y, void *tflag,
+                             void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp, size_t scan_tmp_bytes, void *rd,
+                             void *counters, void *stream); /* accumulate.hip */
+uint32_t bsc_dev_n_bins(uint32_t n_sites);
 int bsc_dev_launch_site_stats(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp, uint32_t n,
                               const void *tb, const void *logp, const void *carry_in, void *carry_out, void *stats,
                               void *pairs, int num_cus, void *stream); /* sitestats.hip */
@@ -49,16 +50,10 @@ int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const
                        void *out, int num_cus, void *stream);
 int bsc_dev_launch_chain(const bsc_chain_launch *L); /* fused.hip */
 unsigned bsc_dev_chain_quantum(int num_cus);
-size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth, int reads);
-size_t bsc_dev_chain_scratch_bytes(int num_cus);
-int bsc_dev_launch_prep_reads(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y, void *keys,
-                              void *keys_sorted, void *perm, void *sort_tmp, size_t sort_tmp_bytes, void *rd, void *counters,
-                              int num_cus, void *stream); /* accumulate.hip */
-int bsc_dev_launch_tile_lo(const void *keys_sorted, uint32_t n_reads, uint32_t n_tiles, int64_t base, uint32_t step,
-                           const void *counters, void *tile_lo, int num_cus, void *stream);
 int bsc_dev_launch_synth(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags, void *cts,
                          void *ref, int num_cus, void *stream);
-
+size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth, int reads);
+size_t bsc_dev_chain_scratch_bytes(int num_cus);
 #define BSC_LN10 (2.30258509299404568402) /* the reference's LOG10 literal (include/bs_call.h:36) */
 #define BSC_HOST_CHUNK (4u << 20)         /* sites per host->device round trip (4 Mi sites = 1.2 GiB of records) */
 #define BSC_MAX_LAUNCH (1ull << 31)       /* sites per launch: site indices in the het list are 32-bit */
@@ -89,10 +84,11 @@ struct bsc_context {
   hipEvent_t ev_chain[2]; /* bsc_set_profiling: the fused chain's launches */
   int ev_chain_valid;
   /* accumulate stage */
-  void *d_tpl, *d_seq, *d_rd, *d_lo;
-  size_t cap_tpl, cap_seq, cap_rd, cap_lo;
-  void *d_keys, *d_keys_s, *d_perm, *d_sorttmp; /* ordering of the block's templates (sort.hip) */
-  size_t cap_keys, cap_keys_s, cap_perm, cap_sorttmp;
+  void *d_tpl, *d_seq, *d_rd;
+  size_t cap_tpl, cap_seq, cap_rd;
+  /* grouping of the block's reads by bin (accumulate.hip): walked flags per template, bin counts / offsets / cursors, scan scratch */
+  void *d_tflag, *d_bcnt, *d_boff, *d_bcur, *d_bscan;
+  size_t cap_tflag, cap_bcnt, cap_boff, cap_bcur, cap_bscan;
   void *d_vg, *d_vout, *d_vdb; /* VCF record formation: called genotypes, records, dbSNP flags */
   size_t cap_vg, cap_vout, cap_vdb;
   /* packing of written records (compact.hip): records per tile, their prefix sum, scan scratch, the packed block */
@@ -324,11 +320,11 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_tpl);
   hipFree(ctx->d_seq);
   hipFree(ctx->d_rd);
-  hipFree(ctx->d_lo);
-  hipFree(ctx->d_keys);
-  hipFree(ctx->d_keys_s);
-  hipFree(ctx->d_perm);
-  hipFree(ctx->d_sorttmp);
+  hipFree(ctx->d_tflag);
+  hipFree(ctx->d_bcnt);
+  hipFree(ctx->d_boff);
+  hipFree(ctx->d_bcur);
+  hipFree(ctx->d_bscan);
   for (int b = 0; b < 2; b++) {
     hipFree(ctx->p_cts[b]);
     hipFree(ctx->p_ref[b]);
@@ -532,39 +528,48 @@ static int bsc_accumulate_queue(bsc_context *ctx, const bsc_template *tpl, uint3
 }
 
 /* Workspaces of the accumulate stage for a block of nr templates over positions x .. y (grow-only). */
-static int bsc_accumulate_reserve(bsc_context *ctx, uint32_t nr, uint32_t x, uint32_t y, size_t *sort_bytes) {
+static int bsc_accumulate_reserve(bsc_context *ctx, uint32_t nr, uint32_t x, uint32_t y, size_t *scan_bytes) {
   const uint64_t sz = (uint64_t)y - x + 1;
-  const uint64_t n_wt = (sz + 63) / 64;
+  if (sz > 0xffffffffull) return bsc_fail(BSC_ERR_ARG, "accumulate: block longer than 2^32 - 1 positions");
+  const size_t nb1 = (size_t)bsc_dev_n_bins((uint32_t)sz) + 1u;
   int rc;
-  *sort_bytes = 0;
-  if ((rc = bsc_reserve(&ctx->d_lo, &ctx->cap_lo, (size_t)n_wt * 4u))) return rc;
+  *scan_bytes = 0;
+  if (nr > 0x7fffffffu) return bsc_fail(BSC_ERR_ARG, "accumulate: more than 2^31 - 1 templates in one block");
+  if (bsc_dev_scan_tmp_bytes((uint32_t)nb1, scan_bytes)) return bsc_fail(BSC_ERR_HIP, "accumulate: scan size query failed");
   if ((rc = bsc_reserve(&ctx->d_rd, &ctx->cap_rd, (size_t)(nr ? nr : 1) * 48u))) return rc;
-  if (nr) { /* the device orders the block's READS: two entries per template */
-    if (nr > 0x7fffffffu) return bsc_fail(BSC_ERR_ARG, "accumulate: more than 2^31 - 1 templates in one block");
-    if (bsc_dev_sort_tmp_bytes(2u * nr, sort_bytes)) return bsc_fail(BSC_ERR_HIP, "accumulate: sort size query failed");
-    if ((rc = bsc_reserve(&ctx->d_keys, &ctx->cap_keys, (size_t)nr * 8u))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_keys_s, &ctx->cap_keys_s, (size_t)nr * 8u))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_perm, &ctx->cap_perm, (size_t)nr * 8u))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_sorttmp, &ctx->cap_sorttmp, *sort_bytes ? *sort_bytes : 1))) return rc;
-  }
+  if ((rc = bsc_reserve(&ctx->d_tflag, &ctx->cap_tflag, (size_t)(nr ? nr : 1)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_bcnt, &ctx->cap_bcnt, nb1 * 4u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_boff, &ctx->cap_boff, nb1 * 4u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_bcur, &ctx->cap_bcur, nb1 * 4u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_bscan, &ctx->cap_bscan, *scan_bytes ? *scan_bytes : 1))) return rc;
+  return BSC_OK;
+}
+
+/* template checks, read descriptors and their grouping by bin on stream s; SPAN, INEXACT = 0 and ERR = all ones first (the
+ * kernels take maxima / the minimum) */
+static int bsc_reads_prepare(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes, uint32_t x,
+                             uint32_t y, size_t scan_bytes, hipStream_t s) {
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), s));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), s));
+  int e = bsc_dev_launch_bin_reads(d_tpl, nr, d_seq, seq_bytes, x, y, ctx->d_tflag, ctx->d_bcnt, ctx->d_boff, ctx->d_bcur,
+                                   ctx->d_bscan, scan_bytes, ctx->d_rd, ctx->d_counters, s);
+  if (e) return bsc_fail(BSC_ERR_HIP, "read grouping launch failed: %s", hipGetErrorString((hipError_t)e));
   return BSC_OK;
 }
 
 /* Queues the accumulate kernels over device-resident templates and read bytes on stream s: pile-up of x .. y -> d_cts
  * ((y - x + 1 rounded up to whole 64-position tiles) x 104 bytes). */
 static int bsc_accumulate_launch(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes,
-                                 uint32_t x, uint32_t y, void *d_cts, size_t sort_bytes, hipStream_t s) {
-  /* SPAN, INEXACT = 0; ERR = all ones (the kernel takes the minimum) */
-  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), s));
-  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), s));
+                                 uint32_t x, uint32_t y, void *d_cts, size_t scan_bytes, hipStream_t s) {
   if (ctx->profiling) {
     if (!ctx->ev_acc[0])
       for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&ctx->ev_acc[i]));
     HIP_TRY(hipEventRecord(ctx->ev_acc[0], s));
   }
-  int e = bsc_dev_launch_accumulate(d_tpl, nr, d_seq, seq_bytes, x, y, (uint32_t)ctx->params.min_qual, ctx->d_keys,
-                                    ctx->d_keys_s, ctx->d_perm, ctx->d_sorttmp, sort_bytes, ctx->d_rd, ctx->d_lo, d_cts,
-                                    ctx->d_counters, ctx->num_cus, s);
+  int rc = bsc_reads_prepare(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, scan_bytes, s);
+  if (rc) return rc;
+  int e = bsc_dev_launch_accumulate(ctx->d_rd, ctx->d_boff, d_seq, x, y, (uint32_t)ctx->params.min_qual, d_cts, ctx->d_counters,
+                                    ctx->num_cus, s);
   if (e) return bsc_fail(BSC_ERR_HIP, "accumulate launch failed: %s", hipGetErrorString((hipError_t)e));
   if (ctx->profiling) {
     HIP_TRY(hipEventRecord(ctx->ev_acc[1], s));
@@ -584,11 +589,11 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
   const uint64_t sz = (uint64_t)y - x + 1;
   const uint64_t n_wt = (sz + 63) / 64;
   int rc;
-  size_t sort_bytes = 0;
+  size_t scan_bytes = 0;
   if ((rc = bsc_reserve(&ctx->d_cts, &ctx->cap_cts, (size_t)n_wt * 64u * 104u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
-  if ((rc = bsc_accumulate_reserve(ctx, nr, x, y, &sort_bytes))) return rc;
+  if ((rc = bsc_accumulate_reserve(ctx, nr, x, y, &scan_bytes))) return rc;
   if (stage) {
     /* the previous block's copies out of the staging area have completed: bsc_block_fetch synchronised the stream */
     const size_t b_tpl = (size_t)nr * sizeof(bsc_template), b_seq = (size_t)seq_bytes, b_ref = ref ? (size_t)sz : 0;
@@ -614,7 +619,7 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
     HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, ctx->stream));
   }
-  return bsc_accumulate_launch(ctx, ctx->d_tpl, nr, ctx->d_seq, seq_bytes, x, y, ctx->d_cts, sort_bytes, ctx->stream);
+  return bsc_accumulate_launch(ctx, ctx->d_tpl, nr, ctx->d_seq, seq_bytes, x, y, ctx->d_cts, scan_bytes, ctx->stream);
 }
 
 /*
@@ -688,13 +693,13 @@ int bsc_accumulate_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, cons
   if (((uintptr_t)d_cts & 15u) || ((uintptr_t)d_tpl & 7u))
     return bsc_fail(BSC_ERR_ARG, "bsc_accumulate_device: d_cts must be 16-byte and d_tpl 8-byte aligned");
   BSC_ENTER(ctx);
-  size_t sort_bytes = 0;
-  int rc = bsc_accumulate_reserve(ctx, nr, x, y, &sort_bytes);
+  size_t scan_bytes = 0;
+  int rc = bsc_accumulate_reserve(ctx, nr, x, y, &scan_bytes);
   if (rc) return rc;
   ctx->blk_tpl = NULL;
   ctx->blk_d_tpl = d_tpl;
   ctx->blk_x = x;
-  return bsc_accumulate_launch(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, d_cts, sort_bytes, (hipStream_t)stream);
+  return bsc_accumulate_launch(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, d_cts, scan_bytes, (hipStream_t)stream);
 }
 
 int bsc_block_status(bsc_context *ctx, void *stream) {
@@ -1034,36 +1039,23 @@ static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t n
   bsc_window w = {x, (uint32_t)sz64, 0u, (uint32_t)sz64};
   int rc = bsc_window_check("reads chain", &w);
   if (rc) return rc;
-  const uint32_t n_tiles = (w.n + 59u) / 60u;
-  size_t sort_bytes = 0;
-  if ((rc = bsc_accumulate_reserve(ctx, nr, x, y, &sort_bytes))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_lo, &ctx->cap_lo, (size_t)n_tiles * 4u))) return rc; /* 60-position tiles: more of them than 64-position ones */
+  size_t scan_bytes = 0;
+  if ((rc = bsc_accumulate_reserve(ctx, nr, x, y, &scan_bytes))) return rc;
   if ((rc = bsc_reserve(&ctx->d_fscr, &ctx->cap_fscr, bsc_dev_chain_scratch_bytes(ctx->num_cus)))) return rc;
   bsc_chain_launch L;
   if ((rc = bsc_chain_fill(ctx, &L, &w, params, with_stats, 1, d_ref, d_dbsnp, d_core, d_aux, s))) return rc;
-  if (!nr) { /* a block without reads: an ordered list of nothing (the kernels never look at rd / perm) */
-    if ((rc = bsc_reserve(&ctx->d_keys_s, &ctx->cap_keys_s, 8u))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_perm, &ctx->cap_perm, 8u))) return rc;
-  }
-  /* SPAN, INEXACT = 0; ERR = all ones (the kernel takes the minimum) */
-  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), s));
-  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), s));
   if (ctx->profiling) {
     if (!ctx->ev_rchain[0])
       for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&ctx->ev_rchain[i]));
     HIP_TRY(hipEventRecord(ctx->ev_rchain[0], s));
   }
-  int e = bsc_dev_launch_prep_reads(d_tpl, nr, d_seq, seq_bytes, x, y, ctx->d_keys, ctx->d_keys_s, ctx->d_perm, ctx->d_sorttmp,
-                                    sort_bytes, ctx->d_rd, ctx->d_counters, ctx->num_cus, s);
-  if (!e) e = bsc_dev_launch_tile_lo(ctx->d_keys_s, 2u * nr, n_tiles, -2, 60u, ctx->d_counters, ctx->d_lo, ctx->num_cus, s);
-  if (e) return bsc_fail(BSC_ERR_HIP, "reads chain: launch failed: %s", hipGetErrorString((hipError_t)e));
+  if ((rc = bsc_reads_prepare(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, scan_bytes, s))) return rc;
+  int e;
   L.rd = ctx->d_rd;
-  L.keys_sorted = ctx->d_keys_s;
-  L.perm = ctx->d_perm;
+  L.bin_off = ctx->d_boff;
   L.seq = d_seq;
-  L.tile_lo = ctx->d_lo;
   L.f_scratch = ctx->d_fscr;
-  L.n_reads = 2u * nr;
+  L.n_bins = bsc_dev_n_bins(w.n);
   L.min_qual = (uint32_t)ctx->params.min_qual;
   e = bsc_dev_launch_chain(&L);
   if (e) return bsc_fail(BSC_ERR_HIP, "reads chain launch failed: %s", hipGetErrorString((hipError_t)e));

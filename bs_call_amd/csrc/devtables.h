@@ -56,11 +56,11 @@ typedef struct bsc_chain_launch {
   void *ev_start, *ev_stop;
   double par_l, par_t, par_lrb, par_lrb1; /* 1 - under_conv, over_conv, lrb, lrb1 of the context's tables */
   void *aux_out; /* NULL, or 64 bytes per position: the second half of a bsc_vcf_rec (MC8 counts, AMQ, MQ, aq, max_gt, rs_found) */
-  /* the reads-in form (rd != NULL): the block's ordered reads instead of cts (accumulate.hip: bsc_dev_launch_prep_reads,
-   * bsc_dev_launch_tile_lo with base = first - 2, step = 60); first / n may be any window of the block, lc / rc are unused */
-  const void *rd, *keys_sorted, *perm, *seq, *tile_lo;
+  /* the reads-in form (rd != NULL): the block's reads grouped by bin instead of cts (accumulate.hip:
+   * bsc_dev_launch_bin_reads); first / n may be any window of the block, lc / rc are unused */
+  const void *rd, *bin_off, *seq;
   void *f_scratch;
-  uint32_t n_reads, min_qual;
+  uint32_t n_bins, min_qual;
 } bsc_chain_launch;
 
 #endif

@@ -70,12 +70,11 @@ struct bsc_chain_args {
  * call's strand counts wait for Fisher's test (the pile-up they come from exists only in the wave's LDS) */
 #define F_HET_DW 20 /* dwords per listed heterozygous call: index | max_gt << 28, counts[0][0..7], counts[0] + counts[1], mq, 2 spare */
 struct bsc_reads_args {
-  const bsc_read_desc *rd;
-  const uint32_t *keys_sorted, *perm;
+  const bsc_read_desc *rd;   /* the block's live reads, grouped by the 64-position bin of their first base (accumulate.hip) */
+  const uint32_t *bin_off;   /* n_bins + 1: index of each bin's first read; [n_bins] = number of live reads */
   const uint8_t *seq;
-  const uint32_t *tile_lo; /* first candidate read of every tile of the window */
-  uint32_t *f_scratch;     /* per wave 64 x 8 dwords: forward counts of a tile in which some count exceeds a byte */
-  uint32_t n_reads, min_qual;
+  uint32_t *f_scratch;       /* per wave 64 x 8 dwords: forward counts of a tile in which some count exceeds a byte */
+  uint32_t n_bins, min_qual;
 };
 
 /*
@@ -118,14 +117,18 @@ typedef const __attribute__((address_space(4))) bsc_chain_kargs *bsc_kargs_p;
     bsc_kargs_p p_ = (bsc_kargs_p)__builtin_amdgcn_kernarg_segment_ptr();            \
     asm volatile("" : "+s"(p_));                                                     \
     ra.rd = p_->ra.rd;                                                               \
-    ra.keys_sorted = p_->ra.keys_sorted;                                             \
-    ra.perm = p_->ra.perm;                                                           \
+    ra.bin_off = p_->ra.bin_off;                                                     \
     ra.seq = p_->ra.seq;                                                             \
-    ra.tile_lo = p_->ra.tile_lo;                                                     \
     ra.f_scratch = p_->ra.f_scratch;                                                 \
-    ra.n_reads = p_->ra.n_reads;                                                     \
+    ra.n_bins = p_->ra.n_bins;                                                       \
     ra.min_qual = p_->ra.min_qual;                                                   \
-  }
+  }                                                                                  \
+  acc_reads R_;                                                                      \
+  R_.rd = ra.rd;                                                                     \
+  R_.bin_off = ra.bin_off;                                                           \
+  R_.seq = ra.seq;                                                                   \
+  R_.n_bins = ra.n_bins;                                                             \
+  R_.x = K.a.x;
 
 struct bsc_vcf_core_f {
   uint32_t pos;
@@ -402,10 +405,15 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   bsc_read_desc acc_d;
   acc_dead(acc_d);
   unsigned inexact = 0;
-  if (READS && T_first < a.tile_end) {
+  uint32_t acc_span = 0, acc_live = 0; /* READS: the block's longest read extent and its number of live reads */
+  if (READS) {
     K_LOAD_RA(ra);
-    acc_t0 = ra.tile_lo[T_first];
-    acc_fetch(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, acc_t0, lane0, acc_kv, acc_d);
+    acc_span = (uint32_t)K_COLD(counters)[BSC_CNT_SPAN];
+    acc_live = ra.bin_off[ra.n_bins];
+    if (T_first < a.tile_end) {
+      acc_t0 = acc_tile_start(R_, (int64_t)a.first + (int64_t)T_first * FT - 2, acc_span);
+      acc_fetch(R_, acc_live, acc_t0, lane0, acc_kv, acc_d);
+    }
   }
   for (uint32_t T = T_first; T < a.tile_end; T += gridDim.x * FW) {
     /* the lane number, made opaque once per tile: otherwise every lane-dependent address of the loop body is hoisted
@@ -453,13 +461,13 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       K_LOAD_RA(ra);
       const uint32_t q_span = ra.min_qual < 63u ? 63u - ra.min_qual : 0u; /* q counts iff min_qual <= q < 63 (src/call_genotypes.c:217) */
       const uint32_t T_next = T + gridDim.x * FW;
-      if (T_next < a.tile_end) acc_t0n = ra.tile_lo[T_next];
+      if (T_next < a.tile_end) acc_t0n = acc_tile_start(R_, (int64_t)a.first + (int64_t)T_next * FT - 2, acc_span);
       const uint32_t loff = b0 < 0 ? (uint32_t)(-b0) : 0u; /* lanes in front of the block's first position (0 .. 2) */
       const int64_t bl = b0 + 63 < (int64_t)a.n_block - 1 ? b0 + 63 : (int64_t)a.n_block - 1; /* last block index of the tile */
       const uint32_t pa = a.x + (uint32_t)(b0 + (int64_t)loff), p_last = a.x + (uint32_t)bl;
       uint32_t *row = slot + lane * IN_DW;
-      const bool inx = acc_tile(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, ra.seq, lane, lane - loff, row, pa, p_last, (uint32_t)bl,
-                                ra.min_qual, q_span, acc_t0, acc_kv, acc_d, w);
+      const bool inx = acc_tile(R_, acc_live, lane, lane - loff, row, pa, p_last, (uint32_t)bl, ra.min_qual, q_span, acc_t0, acc_kv,
+                                acc_d, w);
       uint32_t fmax = 0;
 #pragma unroll
       for (int j = 0; j < 8; j++) fmax |= w[j];
@@ -780,7 +788,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       acc_t0 = acc_t0n;
       if (T + gridDim.x * FW < a.tile_end) {
         K_LOAD_RA(ra);
-        acc_fetch(ra.rd, ra.keys_sorted, ra.perm, ra.n_reads, acc_t0, lane, acc_kv, acc_d);
+        acc_fetch(R_, acc_live, acc_t0, lane, acc_kv, acc_d);
       }
     }
     if (K_COLD(a.with_stats)) {
@@ -1007,12 +1015,10 @@ static int chain_launch_t(const bsc_chain_launch *L) {
   uint32_t t_lo, t_hi;
   if (READS) {
     ra.rd = (const bsc_read_desc *)L->rd;
-    ra.keys_sorted = (const uint32_t *)L->keys_sorted;
-    ra.perm = (const uint32_t *)L->perm;
+    ra.bin_off = (const uint32_t *)L->bin_off;
     ra.seq = (const uint8_t *)L->seq;
-    ra.tile_lo = (const uint32_t *)L->tile_lo;
     ra.f_scratch = (uint32_t *)L->f_scratch;
-    ra.n_reads = L->n_reads;
+    ra.n_bins = L->n_bins;
     ra.min_qual = L->min_qual;
     /* complete tiles: all 64 computed sites are positions of the block, all 60 records positions of the window */
     t_lo = L->first >= 2u ? 0u : 1u;
