@@ -1235,7 +1235,10 @@ int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, co
   *n_out = 0;
   if (ctx->rec_pending) return bsc_fail(BSC_ERR_ARG, "bsc_block_records: a submitted block has not been fetched");
   int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 0);
-  if (rc) return rc;
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream); /* copies already queued read the caller's buffers: none may outlive the call */
+    return rc;
+  }
   BSC_ENTER(ctx);
   return bsc_records_finish(ctx, n_out);
 }
