@@ -60,6 +60,38 @@ def test_c_abi_rejects_bad_arguments():
         assert L.bsc_block_fetch(h, None, None) == -1  # this block was submitted without a destination ...
         assert L.bsc_block_fetch(h, p(out2), p(skip2)) == 0  # ... and is still there for a proper fetch
         assert out2["counts"].sum() > 0
+        # round 3's entries: device-resident reads, the reads-in chain, the split records form
+        nrec = y - x + 1
+        d_tpl = torch.from_numpy(tpl.view(np.uint8).reshape(-1)).to("cuda:0")
+        d_seq = torch.from_numpy(seq).to("cuda:0")
+        d_ref = torch.from_numpy(ref2).to("cuda:0")
+        d_cts = torch.zeros(((nrec + 63) // 64 * 64) * 104, dtype=torch.uint8, device="cuda:0")
+        d_core = torch.zeros(nrec * 64, dtype=torch.uint8, device="cuda:0")
+        A = (h, d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), len(seq))
+        assert L.bsc_accumulate_device(*A, x, y, None, st) == -1
+        assert L.bsc_accumulate_device(*A, y, x, d_cts.data_ptr(), st) == -1 and "y (" in err()
+        assert L.bsc_accumulate_device(*A, x, y, d_cts.data_ptr() + 4, st) == -1 and "align" in err()
+        assert L.bsc_accumulate_device(h, None, len(tpl), d_seq.data_ptr(), len(seq), x, y, d_cts.data_ptr(), st) == -1
+        assert L.bsc_reads_chain_device(*A, x, y, None, None, C.byref(vp), 0, d_core.data_ptr(), None, st) == -1
+        assert L.bsc_reads_chain_device(*A, x, y, d_ref.data_ptr(), None, None, 0, d_core.data_ptr(), None, st) == -1
+        assert L.bsc_reads_chain_device(*A, x, y, d_ref.data_ptr(), None, C.byref(vp), 0, d_core.data_ptr() + 8, None, st) == -1 and "align" in err()
+        assert L.bsc_reads_chain_device(*A, y, x, d_ref.data_ptr(), None, C.byref(vp), 0, d_core.data_ptr(), None, st) == -1
+        ms = C.c_float()
+        assert L.bsc_last_reads_chain_ms(h, C.byref(ms)) == -1 and L.bsc_last_accumulate_ms(h, C.byref(ms)) == -1  # profiling is off
+        assert L.bsc_accumulate_device(*A, x, y, d_cts.data_ptr(), st) == 0 and L.bsc_block_status(h, st) == 0
+        assert L.bsc_reads_chain_device(*A, x, y, d_ref.data_ptr(), None, C.byref(vp), 0, d_core.data_ptr(), None, st) == 0
+        assert L.bsc_block_status(h, st) == 0 and int(d_core.view(nrec, 64)[:, 4].sum()) > 0
+        assert L.bsc_block_records_fetch(h, C.byref(cnt)) == -1 and "no block" in err()
+        assert L.bsc_block_records_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, None, None, C.byref(vp), 0, p(rec), len(rec)) == -1
+        assert L.bsc_block_records_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec)) == 0
+        assert L.bsc_block_records(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec),
+                                   C.byref(cnt)) == -1 and "fetched" in err()  # one block in flight per context
+        assert L.bsc_block_records_fetch(h, None) == -1  # NULL count: the block stays pending ...
+        assert L.bsc_block_records_fetch(h, C.byref(cnt)) == 0 and cnt.value > 0  # ... for a proper fetch
+        small = np.zeros(8, dtype=B.VCF_REC)
+        assert L.bsc_block_records_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(small), len(small)) == 0
+        need = C.c_uint64(0)
+        assert L.bsc_block_records_fetch(h, C.byref(need)) == -1 and need.value == cnt.value and "out_cap" in err()
         # after all that the context still computes
         got = c.block_records(tpl, seq, x, y, ref2)
         assert len(got) > 0 and (got["core"]["emit"] == 1).all()
