@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   } while (0)
   const uint32_t T_first = a.tile_begin + blockIdx.x * FW + wid;
   /* heterozygous calls waiting for Fisher's test (window index | max_gt << 28): the wave's own list in HBM, one in ~1 000
-   * positions; a.het_cap entries hold every position the wave can meet */
+   * positions; a.het_cap entries (F_HET_CAP), tested whenever fewer than 64 are free (the epochs below) */
 #define F_WL() (K_COLD(het_list) + (uint64_t)(blockIdx.x * FW + wid) * K_COLD(a.het_cap) * (READS ? F_HET_DW : 1u))
   unsigned n_pend = 0; /* wave-uniform */
   /* READS: the first batch of candidate reads of the wave's next tile (requested a tile ahead) */
@@ -415,7 +415,16 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       acc_fetch(R_, acc_live, acc_t0, lane0, acc_kv, acc_d);
     }
   }
-  for (uint32_t T = T_first; T < a.tile_end; T += gridDim.x * FW) {
+  /* The tile loop runs in epochs: a wave goes on to its next tile as long as its list of heterozygous calls has room for a
+   * whole tile's worth (60), then — and after its last tile — tests what it has listed.  A list of F_HET_CAP entries is
+   * filled once in ~8 000 tiles on WGBS data, so an epoch is normally the whole launch; on input where most calls are
+   * heterozygous the test simply runs more often.  (Sized for the worst case instead, the reads-in form's 80-byte entries
+   * took 80 bytes of address space per position.) */
+  uint32_t T = T_first;
+  const uint32_t het_room = K_COLD(a.het_cap) - 64u;
+  for (;;) {
+  n_pend = 0;
+  for (; T < a.tile_end && n_pend <= het_room; T += gridDim.x * FW) {
     /* the lane number, made opaque once per tile: otherwise every lane-dependent address of the loop body is hoisted
      * out of it, kept alive across the whole kernel and — at 128 VGPRs — spilled to scratch (a vector-memory round trip
      * per use instead of one VALU instruction) */
@@ -901,9 +910,8 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   /* ---- the wave's heterozygous calls: Fisher's exact test, 64 at a time ----
    * A het is one position in ~1 000: tested inside its tile it would idle 63 lanes for the length of Fisher's loops in
    * every such tile, tested by a kernel of its own it costs a launch and a drained device per window. */
-  unsigned long long *const counters = K_COLD(counters);
-  unsigned long long *const stat_words = K_COLD(stat_words);
   if (n_pend) {
+    unsigned long long *const stat_words = K_COLD(stat_words);
     uint32_t *const wl = F_WL();
     const uint8_t *const dbsnp = K_COLD(dbsnp);
     if (lane0 == 0) atomicAdd(&s_cnt[11], n_pend);
@@ -913,11 +921,15 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       const uint32_t *ent = wl + (uint64_t)(k0 + lane0) * (READS ? F_HET_DW : 1u);
       const uint32_t e = lane0 < nb ? __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       f_fisher_pending<READS>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_out, s_lf, s_logtab, s_exptab, h, stat_words);
+    }
+  }
+  if (T >= a.tile_end) break; /* wave-uniform */
+  } /* epochs */
 #undef cts
 #undef ref
 #undef core_out
-    }
-  }
+  unsigned long long *const counters = K_COLD(counters);
+  unsigned long long *const stat_words = K_COLD(stat_words);
   if (READS && __any(inexact)) { /* positions whose quality / MAPQ^2 sums left the exact-float range (accumulate.hip) */
     const unsigned long long m = __ballot(inexact != 0);
     if (lane0 == 0) atomicAdd(&counters[BSC_CNT_INEXACT], (unsigned long long)__popcll(m));
@@ -973,18 +985,18 @@ extern "C" __global__ __launch_bounds__(1024) void bsc_gc_cov_kernel(const uint1
  * number of tiles (no partly filled last round) */
 extern "C" unsigned bsc_dev_chain_quantum(int num_cus) { return (unsigned)num_cus * FW * FT; }
 
-/* entries of one wave's heterozygous list when `tiles` tiles are spread over `grid` workgroups: every position of its
- * tiles, rounded to whole 128-byte lines (no line shared between two waves) */
+/* entries of one wave's heterozygous list: the kernel tests the listed calls whenever fewer than 64 entries are free */
+#define F_HET_CAP 512u
 static uint32_t chain_het_cap(uint32_t tiles, unsigned grid) {
-  const uint32_t rounds = (tiles + grid * FW - 1) / (grid * FW);
-  return (rounds * FT + 31u) & ~31u;
+  (void)tiles;
+  (void)grid;
+  return F_HET_CAP;
 }
 
-/* bytes the per-wave heterozygous lists of a window of n positions take, at most; with_depth: plus the window's depths;
+/* bytes of the per-wave heterozygous lists (one per resident wave, F_HET_CAP entries); with_depth: plus the window's depths;
  * reads: the reads-in form, whose entries carry the call's strand counts (F_HET_DW dwords) */
 extern "C" size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth, int reads) {
-  const uint64_t tiles = ((uint64_t)n + FT - 1) / FT, waves = (uint64_t)num_cus * FW;
-  const size_t lists = (size_t)((tiles + waves) * FT + waves * 32u) * sizeof(uint32_t) * (reads ? F_HET_DW : 1u);
+  const size_t lists = (size_t)num_cus * FW * F_HET_CAP * sizeof(uint32_t) * (reads ? F_HET_DW : 1u);
   return lists + (with_depth ? (((size_t)n * 2u + 3u) & ~(size_t)3u) : 0u);
 }
 
