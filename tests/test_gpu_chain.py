@@ -405,3 +405,18 @@ def test_fused_equals_unfused_on_adversarial_pileups(caller):
     assert gcnt == ecnt
     het = np.array(B.GT_HET)[got["gt"]] & (got["pos"] != 0)
     assert het.sum() > 0.2 * n and int(gst["cov"][4095, 0]) > 0  # mostly heterozygous calls; the coverage table's last row is in use
+
+
+def test_fused_many_heterozygous_calls_per_wave(caller, oracle, tables, libm_exact):
+    """4 M adversarial positions, 85 % of the calls heterozygous: every resident wave lists ~700 of them, more than its list
+    holds (csrc/fused.hip F_HET_CAP 512) — the tile loop's epochs (Fisher pass, list reused, tiles resumed) against the oracle."""
+    if not libm_exact:
+        pytest.skip("host libm differs from the replica: the record bytes go through exp/log")
+    pile, ref2, flags = _adversarial(np.random.default_rng(77), 4_000_000)
+    n = len(pile)
+    ecore, est, ecnt = _oracle_chain(oracle, tables, libm_exact, pile, ref2, 777, dbsnp=flags)
+    assert ecnt["het_calls"] > 0.7 * n
+    got, gst, gcnt = _fused(caller, pile, ref2, 777, [(0, n)], dbsnp=flags)
+    _same_core(got, ecore, "fused vs oracle, 4 M mostly heterozygous")
+    _same_stats(gst, est)
+    assert gcnt == ecnt

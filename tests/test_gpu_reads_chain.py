@@ -127,3 +127,24 @@ def test_reads_chain_bad_template_and_empty_block(caller):
     assert "template 7" in str(e.value)
     core, aux, st, cnt = _reads_chain(caller, tpl[:0], seq[:0], x, x + 199, ref2[:202])
     assert not core.view(np.uint8).any() and not aux.view(np.uint8).any() and cnt["covered"] == 0
+
+
+def test_reads_chain_many_heterozygous_calls_per_wave(caller, oracle, tables, libm_exact):
+    """Reads whose bases are random (qualities kept): most positions are called heterozygous, ~700 per resident wave on 4 M
+    positions — more than a wave's list of 80-byte entries holds (csrc/fused.hip F_HET_CAP 512), so the tile loop runs in
+    several epochs: Fisher pass, list reused, accumulate resumed.  Against the oracle, every byte."""
+    if not libm_exact:
+        pytest.skip("host libm differs from the replica: the record bytes go through exp/log")
+    tpl, seq, x, y = _block(SEED + 1000, 3_000, 4_000_000, 30)
+    rng = np.random.default_rng(31)
+    seq = seq ^ rng.integers(0, 4, size=len(seq), dtype=np.uint8)
+    sz = y - x + 1
+    ref2 = B.synth_ref_host(SEED + 1000, x, sz + 2)
+    ecore, eaux, est, gtm, skip = _oracle_chain(oracle, tables, libm_exact, tpl, seq, x, y, ref2)
+    het = np.array(B.GT_HET)[gtm["max_gt"][skip == 0]].sum()
+    assert het > 0.6 * sz, het
+    core, aux, gst, cnt = _reads_chain(caller, tpl, seq, x, y, ref2)
+    _same_core(core, ecore, "reads chain, mostly heterozygous")
+    assert aux.tobytes() == eaux.tobytes(), [f for f in AUX.names if aux[f].tobytes() != eaux[f].tobytes()]
+    _same_stats(gst, est)
+    assert cnt["het_calls"] == int(het)
