@@ -34,6 +34,7 @@ EXPORTS = (
     "bsc_vcf_compact_device",
     "bsc_block_records",
     "bsc_block_records_submit",
+    "bsc_block_records_submit_inplace",
     "bsc_block_records_fetch",
     "bsc_vcf_stats",
     "bsc_vcf_stats_device",
@@ -366,6 +367,8 @@ def load():
                                     C.POINTER(C.c_uint64)]
     L.bsc_block_records_submit.restype = i32
     L.bsc_block_records_submit.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, C.POINTER(VcfParams), i32, vp, u64]
+    L.bsc_block_records_submit_inplace.restype = i32
+    L.bsc_block_records_submit_inplace.argtypes = L.bsc_block_records_submit.argtypes
     L.bsc_block_records_fetch.restype = i32
     L.bsc_block_records_fetch.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.bsc_vcf_format_rec.restype = i32

@@ -267,9 +267,10 @@ class SiteCaller:
         return out[: cnt.value]
 
     def block_records_submit(self, templates, seq, x, y, ref, out, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None,
-                             with_stats=False):
+                             with_stats=False, inplace=False):
         """Queue one block (reads -> packed records into `out`, a VCF_REC array that must stay alive until the fetch) and
-        return at once; the inputs may be reused immediately.  block_records_fetch() completes it."""
+        return at once; the inputs may be reused immediately — unless inplace (bsc_block_records_submit_inplace): then they
+        are read where they lie, no staging copy, and must stay unchanged until the fetch.  block_records_fetch() completes it."""
         templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         ref = np.ascontiguousarray(ref, dtype=np.uint8)
@@ -282,9 +283,11 @@ class SiteCaller:
         if out.dtype != VCF_REC or not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]:
             raise ValueError("out must be a writable C-contiguous VCF_REC array")
         p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
-        _check(self._L.bsc_block_records_submit(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref),
-                                                None if db is None else _ptr(db), C.byref(p), 1 if with_stats else 0, _ptr(out), len(out)))
+        fn = self._L.bsc_block_records_submit_inplace if inplace else self._L.bsc_block_records_submit
+        _check(fn(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref), None if db is None else _ptr(db),
+                  C.byref(p), 1 if with_stats else 0, _ptr(out), len(out)))
         self._pending_rec = out
+        self._pending_in = (templates, seq, ref, db) if inplace else None  # kept alive until the fetch
 
     def block_records_fetch(self):
         """Wait for the submitted block: VCF_REC[n_written] (a view of the array named at submit)."""
@@ -293,7 +296,10 @@ class SiteCaller:
             raise BscError(-1, "block_records_fetch: no block was submitted")
         self._pending_rec = None
         cnt = C.c_uint64(0)
-        _check(self._L.bsc_block_records_fetch(self._h, C.byref(cnt)))
+        try:
+            _check(self._L.bsc_block_records_fetch(self._h, C.byref(cnt)))
+        finally:
+            self._pending_in = None
         return out[: cnt.value]
 
     def vcf_compact_device(self, d_core, d_gtm, stride, n, d_out, out_cap, d_count, d_dbsnp=None, stream=None):

@@ -1243,20 +1243,33 @@ int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, co
   return bsc_records_finish(ctx, n_out);
 }
 
-/* The split form: queue the block and return (the inputs are staged, so the caller's buffers are free at once; `out` must
- * stay valid until the fetch); bsc_block_records_fetch waits and completes it. */
-int bsc_block_records_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
-                             uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
-                             bsc_vcf_rec *out, uint64_t out_cap) {
+/* The split form: queue the block and return; bsc_block_records_fetch waits and completes it.  stage != 0: the inputs go
+ * through the pinned staging area, so the caller's buffers are free at once; 0: they are read where they lie and must stay
+ * unchanged until the fetch (`out` must stay valid until then either way). */
+static int bsc_records_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
+                              uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                              bsc_vcf_rec *out, uint64_t out_cap, int stage) {
   if (!ctx || !ref || !params || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_submit: NULL argument");
   if (ctx->rec_pending || ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_submit: the previous block has not been fetched");
-  int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 1);
+  int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, stage);
   if (rc) {
-    (void)hipStreamSynchronize(ctx->stream); /* nothing may still read the staging area when the next block is staged */
+    (void)hipStreamSynchronize(ctx->stream); /* nothing may still read the inputs / the staging area after a failed submit */
     return rc;
   }
   ctx->rec_pending = 1;
   return BSC_OK;
+}
+
+int bsc_block_records_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
+                             uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                             bsc_vcf_rec *out, uint64_t out_cap) {
+  return bsc_records_submit(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 1);
+}
+
+int bsc_block_records_submit_inplace(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                                     uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
+                                     int with_stats, bsc_vcf_rec *out, uint64_t out_cap) {
+  return bsc_records_submit(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 0);
 }
 
 int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out) {

@@ -279,6 +279,10 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
  * as call_genotypes_ML returns once its calc threads are dispatched (src/call_genotypes.c:260-272), its inputs copied to a
  * pinned staging area (the caller's buffers are free at once); fetch is the wait at the top of the next call (:161-168) and
  * completes the block into the `out` named at submit (which must stay valid until then).  One block in flight per context.
+ * bsc_block_records_submit_inplace: no staging copy — the inputs are read where they lie (page-locked buffers from
+ * bsc_alloc_host make the upload a true DMA) and must stay unchanged until the fetch, as the reference's align_list stays
+ * untouched until the next hand-off (src/process.c:61,68).  A host that flattens block k + 1 into a second set of buffers
+ * while block k is in flight on another context keeps both PCIe directions busy (tools/bench_two_contexts.py).
  */
 int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                       uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
@@ -287,6 +291,9 @@ int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, co
 int bsc_block_records_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
                              uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
                              bsc_vcf_rec *out, uint64_t out_cap);
+int bsc_block_records_submit_inplace(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                                     uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
+                                     int with_stats, bsc_vcf_rec *out, uint64_t out_cap);
 int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out);
 
 /* bsc_vcf_format for a packed record. */

@@ -200,3 +200,21 @@ def test_block_records_submit_fetch(caller, oracle, tables, libm_exact):
     assert "template 3" in str(e.value)
     caller.block_records_submit(t, s, x, y, r, outs[0].array)
     assert caller.block_records_fetch().tobytes() == sync[0].tobytes()
+    # the in-place form: no staging copy, the (page-locked) inputs read where they lie; two contexts alternating, block k + 1
+    # submitted before block k is fetched — the pipeline of tools/bench_two_contexts.py
+    with B.SiteCaller() as c2:
+        ctx = (caller, c2)
+        pins = []
+        for t, s, x, y, r, kw in blocks:
+            pt, ps, pr = B.PinnedBuffer(len(t), t.dtype), B.PinnedBuffer(len(s), np.uint8), B.PinnedBuffer(len(r), np.uint8)
+            pt.array[:], ps.array[:], pr.array[:] = t, s, r
+            pins.append((pt, ps, pr))
+        got = []
+        for k, (t, s, x, y, r, kw) in enumerate(blocks):
+            pt, ps, pr = pins[k]
+            ctx[k & 1].block_records_submit(pt.array, ps.array, x, y, pr.array, outs[k].array, inplace=True, **kw)
+            if k:
+                got.append(ctx[(k - 1) & 1].block_records_fetch().copy())
+        got.append(ctx[(len(blocks) - 1) & 1].block_records_fetch().copy())
+        for a, b in zip(got, sync):
+            assert a.tobytes() == b.tobytes()
