@@ -236,6 +236,25 @@ def run_config2(args, env):
     return res
 
 
+WARM_MS = 40.0  # device time of untimed launches in front of the legs below: after an idle stretch (host-side set-up) the first
+# ~20 ms of launches run below the steady clock (tools/warm_hist.py) — it matters for launches shorter than a few ms
+
+
+def timed_launches(launch, last_ms, reps):
+    """`launch()` queues one launch and waits for it; `last_ms()` is its device time (HIP events inside the library).  Untimed
+    launches until WARM_MS of device time have run (2 .. 200 of them), then `reps` timed ones: their device times."""
+    warm, k = 0.0, 0
+    while k < 2 or (warm < WARM_MS and k < 200):
+        launch()
+        warm += last_ms()
+        k += 1
+    ms = []
+    for _ in range(reps):
+        launch()
+        ms.append(last_ms())
+    return ms
+
+
 def chain_roofline(args, caller, d_cts, d_ref, n, first_site):
     """The fused print-side chain over the same resident contig (one block, one call), with statistics: device time from
     HIP events on the launch stream (bsc_last_chain_ms), 105 + 64 algorithmic bytes per position."""
@@ -245,15 +264,11 @@ def chain_roofline(args, caller, d_cts, d_ref, n, first_site):
     dev = d_cts.device
     d_core = torch.empty(n * 64, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    ms, wall = [], []
-    for it in range(2 + min(args.steps, 10)):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+    def launch():
         caller.chain_device(d_cts.data_ptr(), d_ref.data_ptr(), 1, n, 0, n, d_core.data_ptr(), with_stats=True, stream=stream)
         torch.cuda.synchronize()
-        if it >= 2:
-            wall.append(time.perf_counter() - t0)
-            ms.append(caller.last_chain_ms())
+
+    ms = timed_launches(launch, caller.last_chain_ms, min(args.steps, 10))
     k_ms = float(np.mean(ms))
     achieved = n * CHAIN_BYTES / (k_ms * 1e-3) / 1e9
     records = int(d_core.view(n, 64)[:, 4].sum())
@@ -269,7 +284,7 @@ def chain_roofline(args, caller, d_cts, d_ref, n, first_site):
         "traffic": profiled_traffic(n, args.coverage, "chain"),
         "algorithmic_bytes_per_launch": n * CHAIN_BYTES,
         "kernel_ms_avg": k_ms,
-        "positions_per_s": n / float(np.median(wall)),
+        "positions_per_s": n / (k_ms * 1e-3),
         "records_written_fraction": records / n,
         "note": "instruction-issue bound (FP64 model + record formation), not HBM: the roofline fraction is low by construction",
     }
@@ -296,19 +311,18 @@ def reads_rooflines(args, caller):
     d_ref = torch.from_numpy(ref).to(dev)
     d_pile = torch.empty(n_pad * 104, dtype=torch.uint8, device=dev)
     d_core = torch.empty(n * 64, dtype=torch.uint8, device=dev)
-    reps = 2 + min(args.steps, 10)
-    acc_ms, rc_ms = [], []
-    for it in range(reps):
+    def launch_acc():
         caller.accumulate_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), seq.size, x, y, d_pile.data_ptr(), stream)
         caller.block_status(stream)
-        if it >= 2:
-            acc_ms.append(caller.last_accumulate_ms())
-    for it in range(reps):
+
+    def launch_rc():
         caller.reads_chain_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), seq.size, x, y, d_ref.data_ptr(), d_core.data_ptr(),
                                   with_stats=True, stream=stream)
         caller.block_status(stream)
-        if it >= 2:
-            rc_ms.append(caller.last_reads_chain_ms())
+
+    reps = min(args.steps, 10)
+    acc_ms = timed_launches(launch_acc, caller.last_accumulate_ms, reps)
+    rc_ms = timed_launches(launch_rc, caller.last_reads_chain_ms, reps)
     # a sample for the checker (cpu_baseline): positions well inside the first chunk are covered by that chunk's templates only
     m = min(chunk, args.sites)
     keep = (m - 400) if args.sites > m else n
@@ -320,7 +334,7 @@ def reads_rooflines(args, caller):
     return {
         "roofline_accumulate": {
             "bound": "hbm",
-            "kernel": "bsc_prep_reads_kernel + rocPRIM radix sort of the reads + bsc_tile_lo_kernel + bsc_accumulate_kernel (bsc_accumulate_device)",
+            "kernel": "bsc_bin_count_kernel + rocPRIM prefix sum + bsc_bin_scatter_kernel + bsc_accumulate_kernel (bsc_accumulate_device)",
             "what": "HOT LOOP A, reads -> pile-up (reference src/call_genotypes.c:180-226, serial on its process thread); " + block,
             "achieved": a_bytes / (a_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBPS,
@@ -338,7 +352,7 @@ def reads_rooflines(args, caller):
         },
         "roofline_reads": {
             "bound": "hbm",
-            "kernel": "bsc_prep_reads_kernel + sort + bsc_tile_lo_kernel + bsc_chain_kernel_t<.., READS> (bsc_reads_chain_device), with statistics",
+            "kernel": "bsc_bin_count_kernel + prefix sum + bsc_bin_scatter_kernel + bsc_chain_kernel_t<.., READS> (bsc_reads_chain_device), with statistics",
             "what": "reads -> pile-up -> call -> VCF record -> site statistics; the pile-up lives in the LDS of the wave that calls it, "
             "gt_meth in its registers; " + block,
             "achieved": r_bytes / (r_ms * 1e-3) / 1e9,

@@ -403,9 +403,8 @@ int bsc_call_sites_device(bsc_context *ctx, const void *d_cts, const void *d_ref
   while (done < n) {
     uint64_t m = n - done;
     if (m > ctx->max_launch) m = ctx->max_launch; /* a multiple of 64 sites: keeps the 16-byte alignment of both arrays */
-    rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, (size_t)m * 4u);
+    rc = bsc_reserve(&ctx->d_het, &ctx->cap_het, (size_t)((m + 63u) / 64u) * 8u); /* one 64-bit mask per wave-tile */
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_HET_LIST, 0, sizeof(unsigned long long), s));
     int e = bsc_dev_launch_call((const char *)d_cts + done * 104u, (const char *)d_ref + done, m,
                                 (char *)d_out + done * out_stride, out_stride / 4u, (char *)d_skip + done,
                                 ctx->d_tables, ctx->d_het, ctx->d_counters, ctx->num_cus, s,

@@ -34,7 +34,7 @@
 #define TILE 256 /* threads per workgroup of bsc_call_kernel (a multiple of 64) */
 #endif
 #ifndef BSC_TILES_PER_WAVE
-#define BSC_TILES_PER_WAVE 8 /* launch heuristic: wave-tiles per wave (8 measured best over 1 M .. 50 M positions) */
+#define BSC_TILES_PER_WAVE 16 /* launch heuristic: wave-tiles per wave (round 3, tools/ab_call.py: 16 is 1 % ahead of 8 at 50 M positions, 2.5 % at 25 M, level below; 2-4 lose 4-18 % at 10 M, 64 loses 4 % at 50 M) */
 #endif
 #ifndef BSC_WAVES_PER_SIMD
 #define BSC_WAVES_PER_SIMD 4 /* occupancy target of bsc_call_kernel: bounds its VGPR budget (512 / waves) */
@@ -137,14 +137,14 @@ __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_kernel_t(co
       atomicAdd(&s_cnt[0], 1u);
       atomicAdd(&s_cnt[1 + mxi], 1u);
     }
-    {
+    { /* one 64-bit mask per wave-tile, written whether or not it has a bit set (nothing to clear between launches).  Rounds
+       * 1-2 appended to ONE compact list through an atomic on its length: at 10x, where four tiles in five hold a
+       * heterozygous call, the 1.3e5 returning atomics on that one address serialised to 1 ms per 10 M positions — 2.5x the
+       * kernel's own time (tools/ab_call.py). */
       const unsigned long long m = __ballot(het);
-      if (m) {
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd((unsigned int *)&counters[BSC_CNT_HET_LIST], (unsigned)__popcll(m));
-        base = __shfl(base, 0);
-        if (het) het_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)site;
-        if (lane == 0) atomicAdd(&s_cnt[11], (unsigned)__popcll(m));
+      if (lane == 0) {
+        reinterpret_cast<unsigned long long *>(het_list)[wt] = m;
+        if (m) atomicAdd(&s_cnt[11], (unsigned)__popcll(m));
       }
     }
     if (valid) skip[site] = covered ? 0 : 1;
@@ -206,38 +206,92 @@ __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_kernel_t(co
   if (tid < 12 && s_cnt[tid]) atomicAdd(&counters[BSC_CNT_COVERED + tid], (unsigned long long)s_cnt[tid]);
 }
 
-/* One thread per heterozygous site of the compact list. */
-extern "C" __global__ __launch_bounds__(256) void bsc_fisher_kernel(const uint32_t *__restrict__ cts,
-                                                                    uint32_t *__restrict__ out, uint32_t out_dw,
-                                                                    const bsc_dev_tables *__restrict__ tb,
-                                                                    const uint32_t *__restrict__ het_list,
-                                                                    const unsigned long long *__restrict__ counters) {
+/*
+ * Fisher's test for the heterozygous calls of a launch, found through the per-tile masks the calling kernel left.  A
+ * workgroup takes a chunk of consecutive wave-tiles at a time: its threads count the set bits of their share of the masks,
+ * a prefix sum over the 256 shares orders them, every thread writes the positions of its own calls into one compact list in
+ * LDS (FI_LIST at a time when a chunk holds more), and the threads then take the listed calls one each — all lanes busy
+ * whatever the density.  The launcher sizes the chunk so that every workgroup has about one (dense input: several rounds
+ * of 256 per chunk; WGBS at 30x: ~100 calls per chunk, one round).
+ */
+#define FI_THREADS 256
+#define FI_LIST 2048
+extern "C" __global__ __launch_bounds__(FI_THREADS) void bsc_fisher_kernel(const uint32_t *__restrict__ cts,
+                                                                           uint32_t *__restrict__ out, uint32_t out_dw,
+                                                                           const bsc_dev_tables *__restrict__ tb,
+                                                                           const unsigned long long *__restrict__ masks,
+                                                                           uint32_t n_tiles, uint32_t chunk_tiles) {
   __shared__ double s_lf[256];
   __shared__ double s_logtab[256];
   __shared__ unsigned long long s_exptab[256];
-  s_lf[threadIdx.x] = tb->lfact[threadIdx.x];
-  s_logtab[threadIdx.x] = tb->log_tab[threadIdx.x];
-  s_exptab[threadIdx.x] = tb->exp_tab[threadIdx.x];
-  __syncthreads();
-  const unsigned nhet = (unsigned)counters[BSC_CNT_HET_LIST];
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nhet; i += gridDim.x * blockDim.x) {
-    const uint64_t site = het_list[i];
-    const uint32_t *p = cts + site * IN_DW;
-    uint32_t f[8], r[8]; /* counts[0][*] forward, counts[1][*] reverse */
+  __shared__ uint32_t s_scan[FI_THREADS + 1];
+  __shared__ uint32_t s_list[FI_LIST];
+  const unsigned tid = threadIdx.x;
+  s_lf[tid] = tb->lfact[tid];
+  s_logtab[tid] = tb->log_tab[tid];
+  s_exptab[tid] = tb->exp_tab[tid];
+  const uint32_t per = (chunk_tiles + FI_THREADS - 1) / FI_THREADS; /* masks per thread */
+  for (uint32_t c0 = blockIdx.x * chunk_tiles; c0 < n_tiles; c0 += gridDim.x * chunk_tiles) {
+    const uint32_t c1 = min(c0 + chunk_tiles, n_tiles);
+    const uint32_t t0 = min(c0 + tid * per, c1), t1 = min(t0 + per, c1); /* this thread's masks */
+    uint32_t mine = 0;
+    for (uint32_t t = t0; t < t1; t++) mine += (uint32_t)__popcll(masks[t]);
+    __syncthreads(); /* the previous chunk's list and scan are done with (first pass: the tables are in place) */
+    s_scan[tid + 1] = mine;
+    if (tid == 0) s_scan[0] = 0;
+    __syncthreads();
+    if (tid < 64) { /* inclusive scan of 256 counts by one wave: four per lane, then across lanes */
+      uint32_t a = s_scan[4 * tid + 1], b = a + s_scan[4 * tid + 2], c = b + s_scan[4 * tid + 3], d = c + s_scan[4 * tid + 4];
+      uint32_t run = d;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      f[j] = p[j];
-      r[j] = p[8 + j];
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(run, off);
+        if ((int)tid >= off) run += v;
+      }
+      const uint32_t base = run - d;
+      s_scan[4 * tid + 1] = base + a;
+      s_scan[4 * tid + 2] = base + b;
+      s_scan[4 * tid + 3] = base + c;
+      s_scan[4 * tid + 4] = base + d;
     }
-    uint32_t *rec = out + site * out_dw;
-    const unsigned mxi = rec[48] & 0xffu; /* max_gt at byte 192 */
-    int t0, t1, t2, t3;
-    strand_table(mxi, f, r, t0, t1, t2, t3);
-    double z = fisher_dev(t0, t1, t2, t3, s_lf, s_logtab, (const uint64_t *)s_exptab);
-    if (z < 1.0e-20) z = 1.0e-20;
-    const double fs = bsm_log_t(z, s_logtab) / BSM_LN10;
-    const uint64_t b = bsm_bits(fs);
-    reinterpret_cast<uint2 *>(rec)[22] = make_uint2((uint32_t)b, (uint32_t)(b >> 32));
+    __syncthreads();
+    const uint32_t total = s_scan[FI_THREADS], first = s_scan[tid];
+    for (uint32_t w0 = 0; w0 < total; w0 += FI_LIST) { /* the chunk's calls, FI_LIST at a time */
+      if (w0) __syncthreads();
+      if (first < w0 + FI_LIST && first + mine > w0) {
+        uint32_t k = first;
+        for (uint32_t t = t0; t < t1; t++) {
+          unsigned long long m = masks[t];
+          while (m) {
+            const unsigned bit = (unsigned)__builtin_ctzll(m);
+            m &= m - 1ull;
+            if (k >= w0 && k < w0 + FI_LIST) s_list[k - w0] = t * 64u + bit;
+            k++;
+          }
+        }
+      }
+      __syncthreads();
+      const uint32_t cnt = min((uint32_t)FI_LIST, total - w0);
+      for (uint32_t i = tid; i < cnt; i += FI_THREADS) {
+        const uint64_t site = s_list[i];
+        const uint32_t *p = cts + site * IN_DW;
+        uint32_t f[8], r[8]; /* counts[0][*] forward, counts[1][*] reverse */
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          f[j] = p[j];
+          r[j] = p[8 + j];
+        }
+        uint32_t *rec = out + site * out_dw;
+        const unsigned mxi = rec[48] & 0xffu; /* max_gt at byte 192 */
+        int t0_, t1_, t2_, t3_;
+        strand_table(mxi, f, r, t0_, t1_, t2_, t3_);
+        double z = fisher_dev(t0_, t1_, t2_, t3_, s_lf, s_logtab, (const uint64_t *)s_exptab);
+        if (z < 1.0e-20) z = 1.0e-20;
+        const double fs = bsm_log_t(z, s_logtab) / BSM_LN10;
+        const uint64_t b = bsm_bits(fs);
+        reinterpret_cast<uint2 *>(rec)[22] = make_uint2((uint32_t)b, (uint32_t)(b >> 32));
+      }
+    }
   }
 }
 
@@ -264,7 +318,7 @@ extern "C" __global__ __launch_bounds__(256) void bsc_synth_kernel(uint64_t seed
 /* ---- launchers (called from the C host code in bscall_api.c) ---------------------------------------- */
 
 /* pile-up -> gt_meth for n sites (n < 2^32), then the Fisher pass over the heterozygous list.
- * counters[BSC_CNT_HET_LIST] must be zero on entry (the host queues a memset in front). */
+ * het_list: room for one 64-bit mask per wave-tile, (n + 63) / 64 of them. */
 extern "C" int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n, void *out, uint32_t out_dw, void *skip,
                                    const void *tb, void *het_list, void *counters, int num_cus, void *stream,
                                    void *ev_start, void *ev_mid, void *ev_stop) {
@@ -300,9 +354,15 @@ extern "C" int bsc_dev_launch_call(const void *cts, const void *ref, uint64_t n,
     if (e != hipSuccess) return (int)e;
   }
   if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
-  hipLaunchKernelGGL(bsc_fisher_kernel, dim3((unsigned)(num_cus * 2)), dim3(256), 0, s, (const uint32_t *)cts,
-                     (uint32_t *)out, out_dw, (const bsc_dev_tables *)tb, (const uint32_t *)het_list,
-                     (const unsigned long long *)counters);
+  {
+    const uint32_t n_tiles = (uint32_t)((n + 63) / 64);
+    const uint32_t grid = (uint32_t)num_cus * 2u;
+    uint32_t chunk = (n_tiles + grid - 1) / grid; /* about one chunk per workgroup ... */
+    chunk = chunk < 64u ? 64u : (chunk > 4096u ? 4096u : chunk); /* ... of 4 K .. 256 K positions */
+    const uint32_t n_chunks = (n_tiles + chunk - 1) / chunk;
+    hipLaunchKernelGGL(bsc_fisher_kernel, dim3(n_chunks < grid ? n_chunks : grid), dim3(FI_THREADS), 0, s, (const uint32_t *)cts,
+                       (uint32_t *)out, out_dw, (const bsc_dev_tables *)tb, (const unsigned long long *)het_list, n_tiles, chunk);
+  }
   e = hipGetLastError();
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, s);
   return (int)e;

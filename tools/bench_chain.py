@@ -23,6 +23,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--window", type=int, default=0, help="walk the block in windows of this many positions (0 = one call)")
 ap.add_argument("--no-unfused", action="store_true")
 ap.add_argument("--no-stats", action="store_true")
+ap.add_argument("--warm", type=int, default=1, help="untimed launches in front (the first ~20 ms after an idle stretch run below the steady clock)")
 args = ap.parse_args()
 n, cov, x0 = args.sites, args.coverage, 1000
 dev = torch.device("cuda:0")
@@ -30,7 +31,8 @@ stats = not args.no_stats
 
 
 def timed(fn, steps):
-    fn()
+    for _ in range(max(1, args.warm)):
+        fn()
     torch.cuda.synchronize()
     ts = []
     for _ in range(steps):

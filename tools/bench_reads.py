@@ -26,6 +26,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--chunk", type=int, default=1_000_000)
 ap.add_argument("--no-chain", action="store_true")
 ap.add_argument("--no-check", action="store_true")
+ap.add_argument("--warm", type=int, default=2, help="untimed launches in front of each timed loop (the first ~20 ms after an idle stretch run below the steady clock)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 x = 1000
@@ -42,12 +43,12 @@ with B.SiteCaller() as c:
     stream = torch.cuda.current_stream().cuda_stream
     c.set_profiling(True)
     ms, wall = [], []
-    for it in range(2 + args.steps):
+    for it in range(args.warm + args.steps):
         torch.cuda.synchronize()
         w0 = time.perf_counter()
         c.accumulate_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), seq.size, x, y, d_cts.data_ptr(), stream)
         c.block_status(stream)
-        if it >= 2:
+        if it >= args.warm:
             wall.append(time.perf_counter() - w0)
             ms.append(c.last_accumulate_ms())
     k = float(np.mean(ms))
@@ -77,13 +78,13 @@ with B.SiteCaller() as c:
         d_ref = torch.from_numpy(ref).to(dev)
         d_core = torch.empty(n * 64, dtype=torch.uint8, device=dev)
         ms, wall = [], []
-        for it in range(2 + args.steps):
+        for it in range(args.warm + args.steps):
             torch.cuda.synchronize()
             w0 = time.perf_counter()
             c.reads_chain_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), seq.size, x, y, d_ref.data_ptr(), d_core.data_ptr(),
                                  with_stats=True, stream=stream)
             c.block_status(stream)
-            if it >= 2:
+            if it >= args.warm:
                 wall.append(time.perf_counter() - w0)
                 ms.append(c.last_reads_chain_ms())
         k = float(np.mean(ms))
