@@ -227,7 +227,7 @@ def run_config2(args, env):
         if probe_ms > 0.0:
             r = res["roofline"]
             r["stream_probe"] = {
-                "what": "copy kernel with the calling kernel's traffic and tile shape, no arithmetic (csrc/probe.hip), best of 5",
+                "what": "copy kernel with the calling kernel's traffic and tile shape, no arithmetic (csrc/probe.hip); average of 5 launches queued back to back behind 3 untimed ones",
                 "ms": probe_ms,
                 "GBps": r["algorithmic_bytes_per_launch"] / (probe_ms * 1e-3) / 1e9,
                 "kernel_frac_of_probe": probe_ms / r["kernel_ms_avg"],

@@ -630,7 +630,7 @@ int bsc_last_kernel_ms(bsc_context *ctx, float *call_ms, float *fisher_ms);
  * without waiting on events and read its launches' device times afterwards. */
 int bsc_kernel_ms_history(bsc_context *ctx, uint32_t age, float *call_ms, float *fisher_ms);
 
-/* Measurement support: the time (ms, HIP events on `stream`, best of `reps` launches) of a kernel that moves exactly
+/* Measurement support: the time (ms, HIP events on `stream`, average of `reps` launches queued back to back behind three untimed ones) of a kernel that moves exactly
  * the bytes of bsc_call_sites_device(ctx, d_cts, d_ref, n, d_out, 200, d_skip) — 104 + 1 in, 200 + 1 out per position,
  * same tile shape, no arithmetic: the practical memory ceiling for that call.  OVERWRITES d_out / d_skip with junk;
  * n is rounded down to a multiple of 64. */
