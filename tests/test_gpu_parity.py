@@ -308,3 +308,27 @@ def test_stream_probe_runs_and_is_faster_than_the_kernel(oracle, tables):
         torch.cuda.synchronize()
         assert 0.0 < ms < k_ms  # moving the bytes alone cannot take longer than moving them and computing
         assert int(d_out.view(torch.int64).ne(0).sum()) > n  # it really wrote the output buffer
+
+
+def test_dense_heterozygous_calls_device_resident(caller, oracle, tables, libm_exact):
+    """3 000 001 adversarial positions (85 % heterozygous calls, a ragged last wave-tile) through bsc_call_sites_device: the
+    Fisher kernel finds the calls through the per-tile masks in chunks of ~90 wave-tiles, each holding more calls than its
+    LDS list takes at once (csrc/kernels.hip FI_LIST) — fisher_strand of every call against the oracle, every byte."""
+    import torch
+
+    from test_gpu_chain import _adversarial
+
+    pile, ref2, _ = _adversarial(np.random.default_rng(99), 3_000_001)
+    n = len(pile)
+    ref = ref2[:n].copy()
+    dev = torch.device("cuda:0")
+    d_cts = torch.from_numpy(pile.view(np.uint8).reshape(-1)).to(dev)
+    d_ref = torch.from_numpy(ref).to(dev)
+    d_out = torch.full((n * 200,), 0xEE, dtype=torch.uint8, device=dev)
+    d_skip = torch.empty(n, dtype=torch.uint8, device=dev)
+    caller.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 200, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got, skip = d_out.cpu().numpy().view(B.GT_METH), d_skip.cpu().numpy()
+    exp = _check(oracle, tables, libm_exact, pile, ref, got, skip)
+    het = B.GT_HET[exp["max_gt"]] & (skip == 0)
+    assert het.sum() > 0.7 * n and (exp["fisher_strand"][het] != 0).sum() > 0.5 * n
