@@ -17,7 +17,7 @@ typedef struct {
 } bsc_dev_tables;
 
 /* unsigned long long counters[BSC_CNT_WORDS] in device memory */
-#define BSC_CNT_HET_LIST 0 /* length of the heterozygous-site list of the current launch (reset per launch) */
+#define BSC_CNT_HET_LIST 0 /* unused since round 3 (was: length of the calling kernel's heterozygous-site list) */
 #define BSC_CNT_COVERED 1  /* then gt_hist[10] at 2..11, het_calls at 12 */
 #define BSC_CNT_SPAN 13    /* accumulate: largest template extent of the current block (reset per block) */
 #define BSC_CNT_INEXACT 14 /* accumulate: lanes whose quality / MAPQ^2 sums left the exact-float range */

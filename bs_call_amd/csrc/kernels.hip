@@ -3,10 +3,10 @@
  *
  *   bsc_call_kernel    pile-up -> gt_meth for a batch of genome positions: the body of the reference's
  *                      calc-thread loop (src/call_genotypes.c:44-60,109-113) and calc_gt_prob()
- *                      (src/genotype_model.c:44-246, get_Z :23-42).  Heterozygous calls are appended to a
- *                      compact list instead of running the divergent Fisher walk in this kernel.
+ *                      (src/genotype_model.c:44-246, get_Z :23-42).  Heterozygous calls are marked in a 64-bit
+ *                      mask per wave-tile instead of running the divergent Fisher walk in this kernel.
  *   bsc_fisher_kernel  strand table + fisher() (src/call_genotypes.c:61-108, src/stats_utils.c:25-91) over
- *                      the compacted heterozygous sites.
+ *                      the marked sites, compacted chunk by chunk in LDS.
  *   bsc_synth_kernel   synthetic L-pileup generator (synth.h) — bench/test support.
  *
  * Design (DESIGN.md has the numbers): the kernel is a streaming scan, 104 B + 1 B in and 200 B out per
