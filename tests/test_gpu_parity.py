@@ -287,8 +287,10 @@ def test_pipelined_host_path_multi_chunk(caller, oracle, tables, libm_exact):
             b.free()
 
 
-def test_stream_probe_runs_and_is_faster_than_the_kernel(oracle, tables):
-    """bsc_stream_probe_ms: the no-arithmetic copy with the calling kernel's traffic (bench.py's roofline.stream_probe)."""
+def test_stream_probe_runs_and_is_no_slower_than_the_kernel(oracle, tables):
+    """bsc_stream_probe_ms: the no-arithmetic copy with the calling kernel's traffic (bench.py's roofline.stream_probe).  Since
+    round 3 the calling kernel runs at the copy's speed (within a few per cent either way, launch to launch), so the check is
+    a band, not an order."""
     import torch
 
     n = 4_000_000
@@ -306,7 +308,7 @@ def test_stream_probe_runs_and_is_faster_than_the_kernel(oracle, tables):
         k_ms, _ = c.last_kernel_ms()
         ms = c.stream_probe_ms(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 5, st)
         torch.cuda.synchronize()
-        assert 0.0 < ms < k_ms  # moving the bytes alone cannot take longer than moving them and computing
+        assert 0.25 * k_ms < ms < 1.25 * k_ms  # the copy alone is in the kernel's range: neither broken nor doing less than it says
         assert int(d_out.view(torch.int64).ne(0).sum()) > n  # it really wrote the output buffer
 
 
