@@ -92,6 +92,14 @@ def test_c_abi_rejects_bad_arguments():
         assert L.bsc_block_records_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(small), len(small)) == 0
         need = C.c_uint64(0)
         assert L.bsc_block_records_fetch(h, C.byref(need)) == -1 and need.value == cnt.value and "out_cap" in err()
+        # the in-place form: same argument checks, same one-block-in-flight rule, same fetch
+        SI = L.bsc_block_records_submit_inplace
+        assert SI(h, p(tpl), len(tpl), p(seq), len(seq), x, y, None, None, C.byref(vp), 0, p(rec), len(rec)) == -1
+        assert SI(h, p(tpl), len(tpl), p(seq), len(seq), y, x, p(ref2), None, C.byref(vp), 0, p(rec), len(rec)) == -1
+        assert SI(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec)) == 0
+        assert SI(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec)) == -1 and "fetched" in err()
+        n_in = C.c_uint64(0)
+        assert L.bsc_block_records_fetch(h, C.byref(n_in)) == 0 and n_in.value == cnt.value
         # after all that the context still computes
         got = c.block_records(tpl, seq, x, y, ref2)
         assert len(got) > 0 and (got["core"]["emit"] == 1).all()
