@@ -239,6 +239,44 @@ __device__ static __forceinline__ void get_Z(double x1, double x2, double k1, do
   Z2 = 0.5 * (lmt * s2 + 2.0 - lpt);
 }
 
+/*
+ * Logs that need no evaluation per site.  When one class of a strand's pair is empty — no C among the C2T reads of a T site,
+ * every C of a site converted, a G2A strand seen only as A — get_Z's three quotients are beyond +-1 by a wide margin
+ * ((3 - l - t) / (l - t) >= 2 and the like, whatever the counts), the clamp makes them exactly -1 or +1, the three Z equal
+ *   Zc = 0.5 * (lmt * -1.0 + 2.0 - lpt)   (the pair's first class empty)   or   Zd = 0.5 * (lmt * 1.0 + 2.0 - lpt)   (its second),
+ * and the class's three log arguments depend on nothing but its quality index q (through k = q_prob[q].k):
+ *   PT_A  log(1.0 - Zc + k)        class 7: CC        class 4: GG
+ *   PT_B  log(1.0 - 0.5 * Zc + k)  class 7: CT        class 4: AG
+ *   PT_C  log(0.5 * (1.0 - Zc) + k)  class 7: AC, CG  class 4: CG, GT
+ *   PT_D  log(Zd + k)              class 5: CC        class 6: GG
+ *   PT_E  log(0.5 * Zd + k)        class 5: CT, AC, CG  class 6: AG, CG, GT
+ * 5 x 44 doubles, filled once per workgroup by the same expressions and the same log as the per-site path (pure_log_entry),
+ * so a tabulated value is the value the site would have computed.  Such classes are half of all (site, class) pairs of WGBS
+ * data at 30x; leaving them out of the log rounds halves those rounds (call_body.inc).
+ */
+#define PT_Q 44
+#define PT_A 0
+#define PT_B 1
+#define PT_C 2
+#define PT_D 3
+#define PT_E 4
+#define PT_WORDS (5 * PT_Q)
+__device__ static __forceinline__ double pure_log_entry(unsigned idx, double l, double t, const double *s_k, const double *logtab) {
+  const unsigned id = idx / PT_Q, q = idx - id * PT_Q;
+  const double lpt = l + t, lmt = l - t; /* as get_Z forms them */
+  const double Zc = 0.5 * (lmt * -1.0 + 2.0 - lpt), Zd = 0.5 * (lmt * 1.0 + 2.0 - lpt);
+  const double k = s_k[q];
+  double x;
+  switch (id) {
+    case PT_A: x = 1.0 - Zc + k; break;
+    case PT_B: x = 1.0 - 0.5 * Zc + k; break;
+    case PT_C: x = 0.5 * (1.0 - Zc) + k; break;
+    case PT_D: x = Zd + k; break;
+    default: x = 0.5 * Zd + k; break;
+  }
+  return bsm_log_t(x, logtab);
+}
+
 /* LDS-DMA: 16 bytes per lane, global (per-lane address) -> LDS (wave-uniform base + lane * 16). */
 __device__ static __forceinline__ void dma16(const void *g, void *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,

@@ -347,6 +347,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   __shared__ double s_logtab[256];
   __shared__ unsigned long long s_exptab[256];
   __shared__ double s_lf[256];        /* ln x! for x < 256 (Fisher's test of the heterozygous calls) */
+  __shared__ double s_ptab[PT_WORDS]; /* logs of the methylation arguments of a class whose partner class is empty (callmath.h) */
   __shared__ unsigned int s_cnt[12];  /* covered, hist[10], het */
   __shared__ uint8_t s_pairs[FW][256]; /* per wave: the (lane, class) pairs whose logs are needed (call_body.inc) */
   __shared__ uint32_t s_gw[FW][64];    /* per wave and computed site: the printer's called genotype + 1 (0 = none) | its
@@ -376,6 +377,8 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     for (unsigned i = tid; i < F_WORDS; i += 64 * FW) h[i] = 0;
     for (unsigned i = tid; i < 4 * F_PAIR * F_PAIR; i += 64 * FW) s_pair[i] = 0;
   }
+  __syncthreads();
+  if (tid < PT_WORDS) s_ptab[tid] = pure_log_entry(tid, K_COLD(l), K_COLD(t), s_k, s_logtab); /* callmath.h PT_* */
   __syncthreads();
   if (BSC_CHAIN_STAGGER)
     for (unsigned i = 0; i < wid; i++) __builtin_amdgcn_s_sleep(BSC_CHAIN_STAGGER);

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_kernel_t(co
   __shared__ unsigned long long s_exptab[256];
 #endif
   __shared__ unsigned int s_cnt[12]; /* covered, hist[10], het */
+  __shared__ double s_ptab[PT_WORDS]; /* logs of the methylation arguments of a class whose partner class is empty (callmath.h) */
   __shared__ uint8_t s_pairs[TILE / 64][256]; /* per wave: the (lane, class) pairs whose logs are needed */
 
   const unsigned tid = threadIdx.x;
@@ -97,6 +98,8 @@ __global__ __launch_bounds__(TILE, BSC_WAVES_PER_SIMD) void bsc_call_kernel_t(co
   const double l = 1.0 - tb->under_conv;
   const double t = tb->over_conv;
   const double lrb = tb->lrb, lrb1 = tb->lrb1;
+  __syncthreads();
+  for (unsigned i = tid; i < PT_WORDS; i += TILE) s_ptab[i] = pure_log_entry(i, l, t, s_k, s_logtab); /* callmath.h PT_* */
   __syncthreads();
 
   uint32_t *slot = lds_slot[wid];
