@@ -373,11 +373,21 @@ def reads_rooflines(args, caller):
     }
 
 
+def _code_only(text):
+    """C / HIP source without comments and with white space collapsed: what the compiler sees, as far as a traffic figure cares."""
+    import re
+
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return " ".join(text.split())
+
+
 def kernel_source_hash(sources=KERNEL_SOURCES):
+    """Tag of the kernel sources a PMC traffic figure belongs to: comments and white space do not enter it."""
     h = hashlib.sha256()
     for f in sources:
-        with open(os.path.join(ROOT, "bs_call_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "bs_call_amd", "csrc", f), "r", encoding="utf-8") as fh:
+            h.update(_code_only(fh.read()).encode("utf-8"))
     return h.hexdigest()[:16]
 
 
