@@ -334,3 +334,19 @@ def test_dense_heterozygous_calls_device_resident(caller, oracle, tables, libm_e
     exp = _check(oracle, tables, libm_exact, pile, ref, got, skip)
     het = B.GT_HET[exp["max_gt"]] & (skip == 0)
     assert het.sum() > 0.7 * n and (exp["fisher_strand"][het] != 0).sum() > 0.5 * n
+
+
+@pytest.mark.parametrize("under,over", [(0.0, 0.0), (0.5, 0.4999), (0.9, 0.05), (0.3, 0.69999), (0.999, 0.0)])
+def test_adversarial_pileups_with_extreme_parameters(oracle, libm_exact, under, over):
+    """Random class counts (every combination of empty and non-empty partner classes, deep and shallow) under conversion
+    rates from one end of the accepted range to the other — l - t from 1 down to 1e-5: the tabulated logs of a class whose
+    partner is empty (csrc/callmath.h PT_*) are functions of these two parameters, and get_Z's clamp has to hold for all of
+    them (tests/test_pure_logs.py has the premise; here: the bytes against the oracle)."""
+    from test_gpu_chain import _adversarial
+
+    pile, ref2, _ = _adversarial(np.random.default_rng(int(1e6 * under + 1e3 * over) + 5), 120_001)
+    ref = ref2[: len(pile)].copy()
+    tb = oracle.Tables(under, over, 2.0, 20)
+    with B.SiteCaller(under, over, 2.0, 20) as c:
+        got, skip = c.call_sites(pile, ref)
+    _check(oracle, tb, libm_exact, pile, ref, got, skip)
