@@ -70,6 +70,11 @@ def main():
     ap.add_argument("--genome-scale", type=float, default=1.0, help="config 3: scale every contig length (rehearsals)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process never touches a GPU; it starts one rank per GPU as a fresh
+        # child (torch.distributed.run), relays the child's output (rank 0's JSON line) and exits with its code.
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,6 +104,23 @@ def main():
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """One process per GPU (the reference's unit of parallelism is one process per contig, README.md:73-76): the same
+    command line under torch.distributed.run on 127.0.0.1 and a free port.  Called before anything initialises the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def barrier(env):

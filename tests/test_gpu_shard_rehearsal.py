@@ -1,5 +1,5 @@
-"""The N > 1 code path of bench.py on the one-GPU box: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
---config 3 --genome-scale 0.004` as a fresh child process with BENCH_REHEARSAL=1 (both ranks on cuda:0, gloo instead of RCCL,
+"""The N > 1 code path of bench.py on the one-GPU box: the bare `python bench.py --gpus 2 --config 3 --genome-scale 0.004`
+(bench.py starts its own ranks: launch_ranks -> torch.distributed.run, the parent never touches the GPU) with BENCH_REHEARSAL=1 (both ranks on cuda:0, gloo instead of RCCL,
 which refuses two ranks on one device) — contig partition (the reference's unit: one process per contig, README.md:73-76),
 the all-reduce of the counter and statistics blocks and the gather of the per-contig totals, against the N = 1 run of the
 same genome.  The numbers of a rehearsal mean nothing; the sums must be the same."""
@@ -32,9 +32,11 @@ def _run(cmd, env=None):
 def test_two_rank_rehearsal_equals_single_process():
     common = ["bench.py", "--config", "3", "--genome-scale", "0.004", "--steps", "2", "--warmup", "1"]
     one = _run([sys.executable] + common + ["--gpus", "1"])
-    env = dict(os.environ, BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", str(_free_port())] + common + ["--gpus", "2"], env)
+    env = dict(os.environ, BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # exactly what the driver types for N = 2, no external launcher
+    two = _run([sys.executable] + common + ["--gpus", "2"], env)
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
     c1, c2 = one["config"], two["config"]
     assert c2["per_contig_records_sum_equals_total"] is True and c1["per_contig_records_sum_equals_total"] is True
@@ -42,3 +44,12 @@ def test_two_rank_rehearsal_equals_single_process():
     for k in ("records_written", "CpGs", "dbSNP_sites_written", "covered_fraction"):
         assert c1[k] == c2[k], (k, c1[k], c2[k])
     assert "rank 0 of 2" in c2["share"]
+
+
+def test_external_launcher_still_works():
+    """The driver's other form: torch.distributed.run around bench.py (WORLD_SIZE set => bench.py does not launch again)."""
+    common = ["bench.py", "--config", "3", "--genome-scale", "0.002", "--steps", "1", "--warmup", "1"]
+    env = dict(os.environ, BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())] + common + ["--gpus", "2"], env)
+    assert two["n_gpus"] == 2 and two["config"]["per_contig_records_sum_equals_total"] is True
