@@ -52,6 +52,7 @@ class SiteCaller:
     def __init__(self, under_conv=0.01, over_conv=0.05, ref_bias=2.0, min_qual=20, device=-1):
         self._L = _lib.load()
         p = _lib.Params(under_conv, over_conv, ref_bias, min_qual, device)
+        self.params = {"under_conv": float(under_conv), "over_conv": float(over_conv), "ref_bias": float(ref_bias), "min_qual": int(min_qual)}
         h = C.c_void_p()
         _check(self._L.bsc_create(C.byref(p), C.byref(h)))
         self._h = h

@@ -4,10 +4,15 @@
  * per position (bsc_call_kernel 105 in + 201 out, bsc_vcf_core_kernel 202 in + 64 out, bsc_site_stats_kernel 136 in) is
  * done here in 105 + 64.
  *
- *   bsc_chain_kernel_t     one wave per tile of 60 positions.  The printer's record of position i needs the called
- *                          genotypes of i-2 .. i+2 (src/print_vcf.c:548-594), so a wave computes 64 consecutive sites —
- *                          2 halo sites either side, 60/64 = 94 % of its lanes productive — and every neighbour's
- *                          genotype is in the wave's own LDS: no exchange between waves, no second pass.  Per lane:
+ *   bsc_chain_kernel_t     one wave per RUN of consecutive tiles.  The printer's record of position i needs the called
+ *                          genotypes of i-2 .. i+2 (src/print_vcf.c:548-594): a tile computes 64 consecutive sites and
+ *                          forms the records of all but the last two (their right neighbours are the next tile's);
+ *                          the genotypes of the two sites before a tile are the previous tile's (two words carried in
+ *                          the wave's LDS), so a tile advances by 62 — 97 % of the lanes productive — except the
+ *                          first tile of a run, which has nobody to inherit from and spends its first two lanes on
+ *                          the left halo (60 records).  Every neighbour's genotype is in the wave's own LDS: no
+ *                          exchange between waves, no second pass; and the reads-in form meets the reads of one tile
+ *                          again in the next, a few microseconds later in the same CU's caches.  Per lane:
  *                          the calling kernel's statements (call_body.inc, shared textually with kernels.hip), then
  *                          the record formation of _print_vcf_entry (:32-381; the restatement is vcfcore.hip's), then
  *                          the statistics block (:382-526; sitestats.hip's), each lane's 64-byte bsc_vcf_core staged
@@ -30,6 +35,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "accdev.h"
@@ -44,7 +50,11 @@
 #ifndef BSC_CHAIN_STAGGER
 #define BSC_CHAIN_STAGGER 0 /* A/B variant: wave w of a workgroup starts w * this many 64-cycle sleeps late */
 #endif
-#define FT 60 /* positions a wave-tile produces records for (64 computed) */
+#define FT 60  /* records of the first tile of a run (64 sites computed, two of halo either side) */
+#define FT2 62 /* records of every further tile of a run: the left halo is the previous tile's (carried) */
+#ifndef BSC_RUN_CAP
+#define BSC_RUN_CAP 32 /* longest run of tiles the launcher gives a wave at a time (BSC_CHAIN_RUN_CAP overrides: experiments) */
+#endif
 #define F_COV_LDS 256 /* coverage rows of the statistics histogram kept in LDS (deeper positions: global atomics) */
 #define F_WORDS (SS_COV + F_COV_LDS * 6)
 #define F_PAIR 32 /* (a, b) < F_PAIR: CpG cytosines counted in the workgroup's LDS pair table; up to SS_PAIR_G: global */
@@ -56,7 +66,10 @@ struct bsc_chain_args {
   uint32_t n;       /* positions in the window */
   uint32_t lc, rc;  /* positions of pile-up context in the buffers left / right of the window (0..2) */
   uint32_t lr;      /* reference codes in the buffer left of the window (0..4) */
-  uint32_t tile_begin, tile_end;
+  /* the launch's records are cut into n_runs runs, run k for wave k mod (number of waves): the first run_extra runs have
+   * run_tiles + 1 tiles, the others run_tiles; a run of t tiles forms FT + (t - 1) FT2 consecutive records, run 0 from window
+   * index `origin` on */
+  uint32_t origin, n_runs, run_tiles, run_extra;
   int32_t all_positions;
   uint32_t reg_start, reg_stop;
   int32_t with_stats;
@@ -350,11 +363,12 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   __shared__ double s_ptab[PT_WORDS]; /* logs of the methylation arguments of a class whose partner class is empty (callmath.h) */
   __shared__ unsigned int s_cnt[12];  /* covered, hist[10], het */
   __shared__ uint8_t s_pairs[FW][256]; /* per wave: the (lane, class) pairs whose logs are needed (call_body.inc) */
-  __shared__ uint32_t s_gw[FW][64];    /* per wave and computed site: the printer's called genotype + 1 (0 = none) | its
-                                          IUPAC letter << 8 | (carries C) << 16 | (carries G) << 17 */
-  __shared__ uint16_t s_rf[FW][72];    /* per wave: reference code | its letter << 8, from 2 before the first computed site */
-  __shared__ uint32_t s_pend[FW][64];  /* per wave: bit 0 = a written '+' strand CG call (the pending cytosine of
-                                          src/print_vcf.c:447-455), bits 8.. = its FILTER bits */
+  __shared__ uint32_t s_gw[FW][66];    /* per wave, entry 2 + lane: the printer's called genotype + 1 (0 = none) of the lane's
+                                          site | its IUPAC letter << 8 | (carries C) << 16 | (carries G) << 17; entries 0, 1:
+                                          the two sites before the tile, carried over from the run's previous tile */
+  __shared__ uint16_t s_rf[FW][68];    /* per wave: reference code | its letter << 8, from 2 before the first computed site */
+  __shared__ uint16_t s_pend[FW][66];  /* per wave, entry 2 + lane (entry 1: carried like s_gw's): bit 0 = a written '+' strand
+                                          CG call (the pending cytosine of src/print_vcf.c:447-455), bits 8.. = its FILTER bits */
   __shared__ uint32_t h[F_WORDS];      /* statistics histogram of the workgroup (sitestats_dev.h) */
   __shared__ uint32_t s_pair[4 * F_PAIR * F_PAIR]; /* CpG cytosines per [ref / non-ref][all / passed][a][b] */
 
@@ -386,59 +400,77 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   uint32_t *slot = lds_slot[wid];
   uint32_t *sg = s_gw[wid];
   uint16_t *srf = s_rf[wid];
-  uint32_t *spd = s_pend[wid];
+  uint16_t *spd = s_pend[wid];
   /* the reference codes the buffer holds: block indices [first - lr, min(n_block + 2, first + n + 2)) */
   const int64_t ref_lo = (int64_t)a.first - a.lr;
   const int64_t ref_hi = ((int64_t)a.first + a.n + 2 < (int64_t)a.n_block + 2) ? (int64_t)a.first + a.n + 2 : (int64_t)a.n_block + 2;
 
 /* the tile's 64 pile-ups (6 656 contiguous bytes, the first on a 16-byte boundary) -> the wave's slot by LDS-DMA */
-#define F_DMA_TILE(TT, DMA)                                                                                             \
+#define F_DMA_TILE(JW0, DMA)                                                                                            \
   do {                                                                                                                  \
-    const char *src_ = reinterpret_cast<const char *>(cts + (uint64_t)((int32_t)((TT)*FT) - 2 + (int32_t)K_COLD(a.lc)) * IN_DW) + lane * 16; \
+    const char *src_ = reinterpret_cast<const char *>(cts + (uint64_t)((int32_t)(JW0) + (int32_t)K_COLD(a.lc)) * IN_DW) + lane * 16; \
     _Pragma("unroll") for (int j_ = 0; j_ < 6; j_++) DMA(src_ + j_ * 1024, slot + j_ * 256);                            \
     if (lane < 32) DMA(src_ + 6 * 1024, slot + 6 * 256);                                                                \
   } while (0)
-  const uint32_t T_first = a.tile_begin + blockIdx.x * FW + wid;
+  /* ---- the wave's runs: run k = wave index + a multiple of the number of waves; tile tj of a run starts 62 tj sites
+   * after the run's first computed site (all wave-uniform, scalar registers) ---- */
+  const uint32_t n_waves = gridDim.x * FW;
+  const uint32_t run_p = FT + (a.run_tiles - 1u) * FT2; /* records of a short run */
+  uint32_t run = blockIdx.x * FW + wid, tj = 0, run_n = 0;
+  int32_t run_s = 0; /* window index of the run's first record */
+#define F_RUN_SETUP(k)                                                                                          \
+  do {                                                                                                          \
+    const uint32_t k_ = (k), ex_ = a.run_extra;                                                         \
+    run_n = a.run_tiles + (k_ < ex_ ? 1u : 0u);                                                                 \
+    run_s = (int32_t)(a.origin + k_ * run_p + FT2 * (k_ < ex_ ? k_ : ex_));                              \
+  } while (0)
+  if (run < a.n_runs) F_RUN_SETUP(run);
   /* heterozygous calls waiting for Fisher's test (window index | max_gt << 28): the wave's own list in HBM, one in ~1 000
    * positions; a.het_cap entries (F_HET_CAP), tested whenever fewer than 64 are free (the epochs below) */
 #define F_WL() (K_COLD(het_list) + (uint64_t)(blockIdx.x * FW + wid) * K_COLD(a.het_cap) * (READS ? F_HET_DW : 1u))
   unsigned n_pend = 0; /* wave-uniform */
-  /* READS: the first batch of candidate reads of the wave's next tile (requested a tile ahead) */
-  uint32_t acc_t0 = 0, acc_kv = 0xffffffffu;
-  bsc_read_desc acc_d;
-  acc_dead(acc_d);
   unsigned inexact = 0;
   uint32_t acc_span = 0, acc_live = 0; /* READS: the block's longest read extent and its number of live reads */
   if (READS) {
     K_LOAD_RA(ra);
     acc_span = (uint32_t)K_COLD(counters)[BSC_CNT_SPAN];
     acc_live = ra.bin_off[ra.n_bins];
-    if (T_first < a.tile_end) {
-      acc_t0 = acc_tile_start(R_, (int64_t)a.first + (int64_t)T_first * FT - 2, acc_span);
-      acc_fetch(R_, acc_live, acc_t0, lane0, acc_kv, acc_d);
-    }
   }
+#ifndef BSC_CHAIN_NO_PREFETCH
+  if (FULL && !READS && run < a.n_runs) { /* the wave's first tile; every later one is requested while its predecessor's statistics run */
+    const unsigned lane = lane0;
+    F_DMA_TILE(run_s - 2, dma16);
+  }
+#endif
   /* The tile loop runs in epochs: a wave goes on to its next tile as long as its list of heterozygous calls has room for a
-   * whole tile's worth (60), then — and after its last tile — tests what it has listed.  A list of F_HET_CAP entries is
+   * whole tile's worth, then — and after its last tile — tests what it has listed.  A list of F_HET_CAP entries is
    * filled once in ~8 000 tiles on WGBS data, so an epoch is normally the whole launch; on input where most calls are
    * heterozygous the test simply runs more often.  (Sized for the worst case instead, the reads-in form's 80-byte entries
    * took 80 bytes of address space per position.) */
-  uint32_t T = T_first;
   const uint32_t het_room = K_COLD(a.het_cap) - 64u;
   for (;;) {
   n_pend = 0;
-  for (; T < a.tile_end && n_pend <= het_room; T += gridDim.x * FW) {
+  while (run < a.n_runs && n_pend <= het_room) {
     /* the lane number, made opaque once per tile: otherwise every lane-dependent address of the loop body is hoisted
      * out of it, kept alive across the whole kernel and — at 128 VGPRs — spilled to scratch (a vector-memory round trip
      * per use instead of one VALU instruction) */
     unsigned lane = lane0;
     asm volatile("" : "+v"(lane));
-    const int32_t jw0 = (int32_t)(T * FT) - 2;  /* window-relative index of the site lane 0 computes */
+    const uint32_t f0 = tj ? 0u : 2u;                     /* first lane that forms a record: the first tile of a run has two of left halo */
+    const int32_t jw0 = run_s + (int32_t)(tj * FT2) - 2;  /* window-relative index of the site lane 0 computes */
+    /* the wave's next tile (the next of the run, or the first of its next run), if any */
+    const bool last_of_run = tj + 1u == run_n;
+    const bool have_next = !last_of_run || run + n_waves < a.n_runs;
+    int32_t jw0_next = jw0 + (int32_t)FT2;
+    if (last_of_run && have_next) {
+      const uint32_t k_ = run + n_waves, ex_ = a.run_extra;
+      jw0_next = (int32_t)(a.origin + k_ * run_p + FT2 * (k_ < ex_ ? k_ : ex_)) - 2;
+    }
     const int32_t jw = jw0 + (int32_t)lane;
     /* the site is in the buffers; READS: it is a position of the block (every one can be piled up from the reads) */
     const bool valid = FULL || (READS ? ((int64_t)a.first + jw >= 0 && (int64_t)a.first + jw < (int64_t)a.n_block)
                                       : (jw >= -(int32_t)a.lc && jw < (int32_t)(a.n + a.rc)));
-    const bool inner = lane >= 2u && lane < 62u && (FULL || (jw >= 0 && jw < (int32_t)a.n));
+    const bool inner = lane >= f0 && lane < 62u && (FULL || (jw >= 0 && jw < (int32_t)a.n));
     /* Everything per lane is relative to the tile: "lane index" L = block index - b0, b0 = block index of lane 0's
      * site (wave-uniform, 64-bit, in scalar registers); the block occupies lane indices blk_lo .. blk_hi (clamped far
      * outside the tile where the block's ends are not near). */
@@ -466,14 +498,18 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     /* ---- my record ---- */
     uint32_t w[IN_DW];
     bool bigf_any = false; /* READS, wave-uniform: some forward count of the tile exceeds a byte */
-    uint32_t acc_t0n = 0;
     if (READS) {
       /* ---- HOT LOOP A for the tile's 64 sites (src/call_genotypes.c:180-226; accdev.h): the pile-up the calling
        * statements read is built in the wave's slot and never leaves it ---- */
       K_LOAD_RA(ra);
       const uint32_t q_span = ra.min_qual < 63u ? 63u - ra.min_qual : 0u; /* q counts iff min_qual <= q < 63 (src/call_genotypes.c:217) */
-      const uint32_t T_next = T + gridDim.x * FW;
-      if (T_next < a.tile_end) acc_t0n = acc_tile_start(R_, (int64_t)a.first + (int64_t)T_next * FT - 2, acc_span);
+      /* the tile's first batch of candidate reads: in a run they are mostly the previous tile's (read a moment ago by this
+       * very wave: cache hits), so nothing is requested a tile ahead — the descriptors kept live across the calling
+       * statements for that were what the register allocator sent to scratch */
+      const uint32_t acc_t0 = acc_tile_start(R_, b0, acc_span);
+      uint32_t acc_kv;
+      bsc_read_desc acc_d;
+      acc_fetch(R_, acc_live, acc_t0, lane, acc_kv, acc_d);
       const uint32_t loff = b0 < 0 ? (uint32_t)(-b0) : 0u; /* lanes in front of the block's first position (0 .. 2) */
       const int64_t bl = b0 + 63 < (int64_t)a.n_block - 1 ? b0 + 63 : (int64_t)a.n_block - 1; /* last block index of the tile */
       const uint32_t pa = a.x + (uint32_t)(b0 + (int64_t)loff), p_last = a.x + (uint32_t)bl;
@@ -483,7 +519,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       uint32_t fmax = 0;
 #pragma unroll
       for (int j = 0; j < 8; j++) fmax |= w[j];
-      inexact |= (inx && lane >= 2u && lane < 62u) ? 1u : 0u;
+      inexact |= (inx && lane >= f0 && lane < 62u) ? 1u : 0u;
       /* the forward-strand counts, which only Fisher's test of a heterozygous call needs again, wait in the two dwords of
        * the lane's slot area that the calling statements leave alone (la[12]), a byte each; a tile with a larger count
        * parks them in the wave's scratch lines in HBM instead */
@@ -496,11 +532,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         fs[1] = make_uint4(w[4], w[5], w[6], w[7]);
       }
     } else if (FULL) {
-#ifndef BSC_CHAIN_NO_PREFETCH
-      if (T == T_first) /* the wave's first tile; every later one was requested while its predecessor's statistics ran */
+#ifdef BSC_CHAIN_NO_PREFETCH
+      F_DMA_TILE(jw0, dma16);
 #endif
-        F_DMA_TILE(T, dma16);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the tile was requested before the loop / by the previous tile */
       const uint2 *rec = reinterpret_cast<const uint2 *>(slot + lane * IN_DW);
 #pragma unroll
       for (int i = 0; i < IN_DW / 2; i++) {
@@ -571,7 +606,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       const uint32_t hi = __builtin_amdgcn_perm(0u, 0x00544B47u, gz & 7u);
       const uint32_t iu = (gz >= 8u ? hi : lo) & 0xffu;
       const uint32_t fl = gz ? (((0x72u >> g0) & 1u) | (((0x1A4u >> g0) & 1u) << 1)) : 0u; /* AC CC CG CT ; AG CG GG GT */
-      sg[lane] = gz | (iu << 8) | (fl << 16);
+      sg[2u + lane] = gz | (iu << 8) | (fl << 16);
     }
     WAVE_LDS_SYNC();
 
@@ -586,8 +621,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
          st_cpg = false, st_refcpg = false;
     uint32_t st_phred = 0, st_qd = 0, st_cdp = 0, st_cinf = 0, st_ma = 0, st_mb = 0, st_pos = 0;
     int st_mut = 12;
-    const bool former = valid && lane >= 1u && lane < 62u && (inner || lane == 1u);
-    const uint32_t me = former ? sg[lane] : 0u;
+    /* a run's first tile: lane 1 — the site just left of its first record — forms just enough of its record for its right
+     * neighbour (below); in the other tiles that site's facts are the carried ones */
+    const bool former = valid && lane < 62u && (inner || (f0 == 2u && lane == 1u));
+    const uint32_t me = former ? sg[2u + lane] : 0u;
     const uint32_t dp1 = cnt[0] + cnt[1] + cnt[2] + cnt[3], d_inf = cnt[4] + cnt[5] + cnt[6] + cnt[7];
     uint32_t flt = 0;
 #ifdef F_EXPERIMENT_SKIP_RECORD /* timing experiment only (tools/build_variant_fused.sh): the tile's cost without the record formation */
@@ -597,13 +634,14 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
 #endif
       const int gt = (int)(me & 0xffu) - 1;
       const int L = (int)lane;
-      /* called genotypes of lane indices L-2 .. L+2 (lane 1 clamps at 0: its own record is not kept) */
+      /* called genotypes of lane indices L-2 .. L+2: entries L .. L+4 of sg[], whose first two are the carried sites (a run's
+       * first tile has none: its lane 1 clamps at lane 0, its own record is not kept) */
       uint32_t ge[5];
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         const int j = L - 2 + k;
-        uint32_t v = (j >= blk_lo && j <= blk_hi) ? sg[j < 0 ? 0 : j] : 0x4E00u;
-        if (j > blk_hi && L + 2 > blk_hi) v = sg[blk_hi]; /* flush_vcf_entries repeats the last genotype, :540 */
+        uint32_t v = (j >= blk_lo && j <= blk_hi) ? sg[j + 2 < (int)f0 ? (int)f0 : j + 2] : 0x4E00u;
+        if (j > blk_hi && L + 2 > blk_hi) v = sg[blk_hi + 2]; /* flush_vcf_entries repeats the last genotype, :540 */
         ge[k] = v;
       }
       /* reference context through the reference's strncpy of a 7-base window (:570-577); srf[] starts at lane index -2 */
@@ -728,7 +766,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         }
       }
     }
-    spd[lane] = (pend ? 1u : 0u) | (flt << 8);
+    spd[2u + lane] = (uint16_t)((pend ? 1u : 0u) | (flt << 8));
     const uint32_t depth_off = K_COLD(a.depth_off);
     if (depth_off && inner) { /* total depth of every position that reached the printer (the key of gt_cov_stats) */
       const uint32_t dpt = dp1 + d_inf;
@@ -740,14 +778,14 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
      * record dwords are dead by then ---- */
     {
       uint4 *so = reinterpret_cast<uint4 *>(slot);
-      if (lane >= 2u && lane < 62u) {
+      if (lane >= f0 && lane < 62u) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) so[(lane - 2u) * 4u + k] = make_uint4(od[4 * k], od[4 * k + 1], od[4 * k + 2], od[4 * k + 3]);
+        for (int k = 0; k < 4; k++) so[(lane - f0) * 4u + k] = make_uint4(od[4 * k], od[4 * k + 1], od[4 * k + 2], od[4 * k + 3]);
       }
       WAVE_LDS_SYNC();
-      const uint32_t i0 = T * FT;
+      const uint32_t i0 = (uint32_t)(jw0 + (int32_t)f0); /* window index of the tile's first record */
       const uint32_t an_ = FULL ? 0u : K_COLD(a.n);
-      const uint32_t nrec = FULL ? (uint32_t)FT : (an_ - i0 < (uint32_t)FT ? an_ - i0 : (uint32_t)FT);
+      const uint32_t nrec = FULL ? 62u - f0 : (i0 < an_ ? (an_ - i0 < 62u - f0 ? an_ - i0 : 62u - f0) : 0u);
       const uint32_t nvec = nrec * 4u;
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       u32x4 *dst = reinterpret_cast<u32x4 *>(core_out + (uint64_t)i0 * 64u);
@@ -760,14 +798,14 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       if (aux_out) { /* what the encoder of a written record reads besides the core record (src/print_vcf.c:306-359): MC8 counts,
                       * AMQ qualities, MQ, mean quality, max_gt, the dbSNP flag — the second half of a bsc_vcf_rec */
         WAVE_LDS_SYNC();
-        if (lane >= 2u && lane < 62u) {
+        if (lane >= f0 && lane < 62u) {
           const uint8_t *const dbs = K_COLD(dbsnp);
           const uint32_t rsf = (dbs && inner) ? (uint32_t)dbs[jw] : 0u;
           const bool hasrec = od[0] != 0u;
-          so[(lane - 2u) * 4u + 0] = hasrec ? make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]) : make_uint4(0u, 0u, 0u, 0u);
-          so[(lane - 2u) * 4u + 1] = hasrec ? make_uint4(cnt[4], cnt[5], cnt[6], cnt[7]) : make_uint4(0u, 0u, 0u, 0u);
-          so[(lane - 2u) * 4u + 2] = hasrec ? make_uint4(qpack0, qpack1, (uint32_t)mq, (uint32_t)aq) : make_uint4(0u, 0u, 0u, 0u);
-          so[(lane - 2u) * 4u + 3] = hasrec ? make_uint4((uint32_t)mxi | (rsf << 8), 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+          so[(lane - f0) * 4u + 0] = hasrec ? make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]) : make_uint4(0u, 0u, 0u, 0u);
+          so[(lane - f0) * 4u + 1] = hasrec ? make_uint4(cnt[4], cnt[5], cnt[6], cnt[7]) : make_uint4(0u, 0u, 0u, 0u);
+          so[(lane - f0) * 4u + 2] = hasrec ? make_uint4(qpack0, qpack1, (uint32_t)mq, (uint32_t)aq) : make_uint4(0u, 0u, 0u, 0u);
+          so[(lane - f0) * 4u + 3] = hasrec ? make_uint4((uint32_t)mxi | (rsf << 8), 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
         }
         WAVE_LDS_SYNC();
         u32x4 *dsta = reinterpret_cast<u32x4 *>(aux_out + (uint64_t)i0 * 64u);
@@ -792,17 +830,9 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
      * updated, instead of the wave sitting out a full HBM round trip at the top of the next tile. */
     if (FULL && !READS) {
       WAVE_LDS_SYNC();
-      const uint32_t T_next = T + gridDim.x * FW;
-      if (T_next < a.tile_end) F_DMA_TILE(T_next, dma16_hidden);
+      if (have_next) F_DMA_TILE(jw0_next, dma16_hidden);
     }
 #endif
-    if (READS) { /* the first batch of the wave's next tile: on its way while the histograms are updated */
-      acc_t0 = acc_t0n;
-      if (T + gridDim.x * FW < a.tile_end) {
-        K_LOAD_RA(ra);
-        acc_fetch(R_, acc_live, acc_t0, lane, acc_kv, acc_d);
-      }
-    }
     if (K_COLD(a.with_stats)) {
       /* ---- the statistics block (src/print_vcf.c:386-525; sitestats.hip has the restatement) for the tile ----
        * Wide histograms take one LDS atomic per lane; where one value dominates (QUAL 255, MQ, FS 0, FILTER 0) the
@@ -853,7 +883,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
               p_ok = p_pos != 0 && st_pos - p_pos == 1u;
               p_flt = carry_in[1];
             } else {
-              const uint32_t pw = spd[lane - 1u];
+              const uint32_t pw = spd[1u + lane]; /* the site to the left: the previous lane's, or (lane 0) the carried one */
               p_ok = (pw & 1u) != 0;
               p_flt = pw >> 8;
             }
@@ -900,14 +930,25 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         }
       }
       /* the window's last position is the pending cytosine, or not, for whatever follows */
-      if (jw == (int32_t)K_COLD(a.n) - 1 && lane >= 2u && lane < 62u) {
+      if (jw == (int32_t)K_COLD(a.n) - 1 && lane >= f0 && lane < 62u) {
         uint32_t *const carry_out = K_COLD(carry_out);
         carry_out[0] = pend ? pos0 + lane : 0u;
         carry_out[1] = pend ? flt : 0u;
       }
     }
 
+    /* ---- what the run's next tile inherits: genotype words and pending-cytosine facts of this tile's last two record
+     * sites (lanes 60, 61) become entries 0, 1 ---- */
+    if (lane < 2u) {
+      sg[lane] = sg[62u + lane];
+      spd[lane] = spd[62u + lane];
+    }
     WAVE_LDS_SYNC();
+    if (++tj == run_n) {
+      tj = 0;
+      run += n_waves;
+      if (run < a.n_runs) F_RUN_SETUP(run);
+    }
   }
 
   /* ---- the wave's heterozygous calls: Fisher's exact test, 64 at a time ----
@@ -926,7 +967,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       f_fisher_pending<READS>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_out, s_lf, s_logtab, s_exptab, h, stat_words);
     }
   }
-  if (T >= a.tile_end) break; /* wave-uniform */
+  if (run >= a.n_runs) break; /* wave-uniform */
   } /* epochs */
 #undef cts
 #undef ref
@@ -1024,10 +1065,8 @@ static int chain_launch_t(const bsc_chain_launch *L) {
   a.ovf_cap = L->ovf_cap;
   const bool gc = L->with_stats && L->gc_bins && L->gc_table;
   a.depth_off = gc ? (uint32_t)(bsc_dev_chain_het_bytes(L->n, L->num_cus, 0, READS) / sizeof(uint32_t)) : 0u;
-  const uint32_t n_tiles = (L->n + FT - 1) / FT;
   bsc_reads_args ra;
   memset(&ra, 0, sizeof ra);
-  uint32_t t_lo, t_hi;
   if (READS) {
     ra.rd = (const bsc_read_desc *)L->rd;
     ra.bin_off = (const uint32_t *)L->bin_off;
@@ -1035,20 +1074,39 @@ static int chain_launch_t(const bsc_chain_launch *L) {
     ra.f_scratch = (uint32_t *)L->f_scratch;
     ra.n_bins = L->n_bins;
     ra.min_qual = L->min_qual;
-    /* complete tiles: all 64 computed sites are positions of the block, all 60 records positions of the window */
-    t_lo = L->first >= 2u ? 0u : 1u;
-    const uint64_t after = (uint64_t)L->n_block - L->first; /* block positions from the window start on */
-    const uint64_t t_blk = after >= 62u ? (after - 62u) / FT + 1u : 0u; /* 60 T + 61 <= after - 1 */
-    const uint64_t t_win = L->n / FT;                                    /* 60 T + 59 <= n - 1 */
-    t_hi = (uint32_t)(t_blk < t_win ? t_blk : t_win);
-    if (t_hi <= t_lo) t_lo = t_hi = 0;
+  }
+  /*
+   * The window's records [0, n) in three parts.  HEAD: without two sites of context in front (lc < 2: the block starts here)
+   * the first tile's left halo lies outside the buffers / the block — one guarded tile, records [0, 60).  MAIN: runs of
+   * complete tiles (all 64 computed sites exist, so the kernel instance without bounds checks runs them); its last computed
+   * site is the one after its last record's right neighbour: main_end + 1 <= n + rc - 1.  TAIL: what is left, under 64 + 62
+   * records, guarded tiles.  The pile-up-in form also needs each tile's first pile-up on a 16-byte boundary for the LDS-DMA
+   * ((window index + lc) * 104 bytes: lc even, every run and tile start even); failing that everything is guarded.
+   */
+  const unsigned waves = (unsigned)L->num_cus * FW;
+  uint32_t head = L->lc == 2u ? 0u : (L->n < (uint32_t)FT ? L->n : (uint32_t)FT);
+  const int64_t avail = (int64_t)L->n + L->rc - 2 - head;
+  uint32_t m_runs = 0, m_tiles = 1, m_extra = 0, m_len = 0;
+  const bool main_ok = (head == 0u || head == (uint32_t)FT) && avail >= FT &&
+                       (READS || (!(L->lc & 1u) && !((uintptr_t)L->cts & 15u)));
+  if (main_ok) {
+    static int run_cap = 0;
+    if (!run_cap) {
+      const char *e = getenv("BSC_CHAIN_RUN_CAP");
+      run_cap = e && atoi(e) > 0 ? atoi(e) : BSC_RUN_CAP;
+    }
+    const uint64_t tiles_all = ((uint64_t)avail + FT2 - 1) / FT2;           /* about what the window needs */
+    const uint64_t per_wave = (tiles_all + waves - 1) / waves;              /* tiles a wave gets */
+    const uint64_t rounds = (per_wave + (uint64_t)run_cap - 1) / (uint64_t)run_cap; /* runs a wave gets */
+    uint64_t nr = rounds * waves;
+    if (nr > (uint64_t)avail / FT) nr = (uint64_t)avail / FT;               /* every run has a first tile of 60 records */
+    const uint64_t more = ((uint64_t)avail - nr * FT) / FT2;                /* further tiles, 62 records each */
+    m_runs = (uint32_t)nr;
+    m_tiles = 1u + (uint32_t)(more / nr);
+    m_extra = (uint32_t)(more % nr);
+    m_len = (uint32_t)(nr * FT + more * FT2);
   } else {
-    /* complete tiles: all 64 computed sites in the buffers, and the first one on a 16-byte boundary for the LDS-DMA
-     * ((60 T - 2 + lc) * 104 bytes: lc even) */
-    t_lo = L->lc == 2 ? 0u : 1u;
-    t_hi = (L->n + L->rc >= 62u) ? (L->n + L->rc - 62u) / FT + 1u : 0u;
-    if (t_hi > n_tiles) t_hi = n_tiles;
-    if ((L->lc & 1u) || ((uintptr_t)L->cts & 15u) || t_hi <= t_lo) t_lo = t_hi = 0; /* everything through the guarded kernel */
+    head = 0;
   }
   unsigned long long *words = (unsigned long long *)L->stats;
   if (L->ev_start) (void)hipEventRecord((hipEvent_t)L->ev_start, s);
@@ -1073,24 +1131,29 @@ static int chain_launch_t(const bsc_chain_launch *L) {
   K.aux_out = (uint8_t *)L->aux_out;
   K.ra = ra;
 #define CHAIN_ARGS(A) (K.a = (A), K)
-  if (t_hi > t_lo) {
-    a.tile_begin = t_lo;
-    a.tile_end = t_hi;
-    unsigned grid = (t_hi - t_lo + FW - 1) / FW;
+  if (m_runs) {
+    a.origin = head;
+    a.n_runs = m_runs;
+    a.run_tiles = m_tiles;
+    a.run_extra = m_extra;
+    unsigned grid = (m_runs + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus; /* one 1024-thread workgroup per CU, persistent */
-    a.het_cap = chain_het_cap(t_hi - t_lo, grid);
+    a.het_cap = chain_het_cap(m_runs, grid);
     hipLaunchKernelGGL((bsc_chain_kernel_t<true, READS>), dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
-  const uint32_t edge[2][2] = {{0u, t_lo}, {t_hi > t_lo ? t_hi : 0u, n_tiles}};
+  /* guarded tiles, one per run: the head, then everything behind the main part */
+  const uint32_t edge[2][2] = {{0u, head}, {head + m_len, L->n}};
   for (int k = 0; k < 2; k++) {
     if (edge[k][1] <= edge[k][0]) continue;
-    a.tile_begin = edge[k][0];
-    a.tile_end = edge[k][1];
-    unsigned grid = (a.tile_end - a.tile_begin + FW - 1) / FW;
+    a.origin = edge[k][0];
+    a.n_runs = (edge[k][1] - edge[k][0] + FT - 1) / FT;
+    a.run_tiles = 1;
+    a.run_extra = 0;
+    unsigned grid = (a.n_runs + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
-    a.het_cap = chain_het_cap(a.tile_end - a.tile_begin, grid);
+    a.het_cap = chain_het_cap(a.n_runs, grid);
     hipLaunchKernelGGL((bsc_chain_kernel_t<false, READS>), dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -14,10 +14,24 @@ from .caller import ReadProfile, SiteCaller, gc_bins, prepare_templates
 
 def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: str = "SAMPLE", report_path: Optional[str] = None,
         caller: Optional[SiteCaller] = None, dbsnp=None, compressed: bool = True, date=None, left_trim=(0, 0), right_trim=(0, 0),
-        min_qual: int = 20, benchmark_mode: bool = False, under_conv: float = 0.01, over_conv: float = 0.05, **reader_kw) -> dict:
-    """reference: contig name -> uint8 reference codes (0 = N, 1..4 = ACGT; position 1 first).  Returns a summary dict."""
+        min_qual: Optional[int] = None, benchmark_mode: bool = False, under_conv: Optional[float] = None, over_conv: Optional[float] = None,
+        **reader_kw) -> dict:
+    """reference: contig name -> uint8 reference codes (0 = N, 1..4 = ACGT; position 1 first).  Returns a summary dict.
+    under_conv / over_conv / min_qual (defaults 0.01 / 0.05 / 20, src/init_param.c:26-31) are the MODEL's parameters: without
+    `caller` the run builds its SiteCaller from them; with one, they are taken from it and a differing explicit value is an error
+    (the header must name the thresholds the genotypes were computed with, src/print_vcf.c:647-692)."""
     own = caller is None
-    c = caller or SiteCaller()
+    if own:
+        under_conv = 0.01 if under_conv is None else under_conv
+        over_conv = 0.05 if over_conv is None else over_conv
+        min_qual = 20 if min_qual is None else min_qual
+        c = SiteCaller(under_conv=under_conv, over_conv=over_conv, min_qual=min_qual)
+    else:
+        c = caller
+        for name, given in (("under_conv", under_conv), ("over_conv", over_conv), ("min_qual", min_qual)):
+            if given is not None and given != c.params[name]:
+                raise ValueError("%s=%r disagrees with the supplied caller's %r" % (name, given, c.params[name]))
+        under_conv, over_conv, min_qual = c.params["under_conv"], c.params["over_conv"], c.params["min_qual"]
     try:
         prof = ReadProfile()
         base_filter = np.zeros(5, dtype=np.uint64)

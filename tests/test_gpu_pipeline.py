@@ -30,7 +30,7 @@ def _gc_bins(codes):
     return k + 1, bins
 
 
-def _oracle_records(oracle, tables, libm_exact, bam, reference, gc=None):
+def _oracle_records(oracle, tables, libm_exact, bam, reference, gc=None, min_qual=20):
     """The written records of every block, as dicts for py_bcf.encode_record, through the CPU oracle chain; gc: a
     (4096, 101) array that receives the GC-by-coverage census of the positions that reached the printer."""
     text, refs, recs = py_bam.parse_bam(bam)
@@ -44,7 +44,7 @@ def _oracle_records(oracle, tables, libm_exact, bam, reference, gc=None):
         codes = reference[name]
         # get_sequence_string (src/get_sequence.c:35-48): positions at or beyond the contig's last one read as N
         ref = np.array([codes[p - 1] if p < len(codes) else 0 for p in range(x, y + 3)], dtype=np.uint8)
-        prepared, _ = py_prep.prepare(als)
+        prepared, _ = py_prep.prepare(als, min_qual=min_qual)
         tpl = np.zeros(len(prepared), dtype=B.TEMPLATE)
         seq = []
         for i, t in enumerate(prepared):
@@ -57,7 +57,7 @@ def _oracle_records(oracle, tables, libm_exact, bam, reference, gc=None):
                 tpl["len"][i, k] = len(t["reads"][k])
                 seq += t["reads"][k]
         seq = np.array(seq, dtype=np.uint8)
-        rc, pile = oracle.accumulate(tpl, seq, x, y)
+        rc, pile = oracle.accumulate(tpl, seq, x, y, min_qual)
         assert rc == 0
         gtm, skip = oracle.call_sites(pile, ref[: y - x + 1], tables, oracle.LIBM if libm_exact else oracle.BSM, 1)
         core = oracle.vcf_block(gtm, skip, ref, x, reg_stop=len(codes))
@@ -119,6 +119,37 @@ def test_bam_to_bcf_equals_the_oracle_chain(tmp_path, oracle, tables, libm_exact
     got_gc = {int(k): v for k, v in d["totalStats"]["coverage"]["GC"].items()}
     assert int(gc.sum()) > 30_000 and all(got_gc[cv] == [int(v) for v in gc[cv]] for cv in got_gc)
     assert sum(sum(v) for v in got_gc.values()) == int(gc.sum())
+
+
+def test_bam_to_bcf_with_other_model_parameters(tmp_path, oracle, libm_exact):
+    """run(..., under_conv=, over_conv=, min_qual=) builds the caller from THOSE values (src/init_param.c:26-31,
+    src/parse_args.c:126-136): records = the oracle chain with the same parameters, not with the defaults, and the header
+    names them; a supplied caller's own parameters win and a contradicting explicit value is refused."""
+    rng = np.random.default_rng(77)
+    reference = {"chrA": rng.integers(1, 5, 20_000).astype(np.uint8)}
+    refs = [("chrA", 20_000)]
+    recs = W.wgbs_records(rng, reference["chrA"], 0, 1200, het_every=300)
+    bam, bcf = str(tmp_path / "in.bam"), str(tmp_path / "out.bcf")
+    W.write_bam(bam, refs, recs)
+    uc, oc, mq = 0.03, 0.11, 27
+    res = pipeline.run(bam, reference, bcf, sample="S2", date=(4, 10, 2026), compressed=False, under_conv=uc, over_conv=oc, min_qual=mq)
+    tb = oracle.Tables(uc, oc, 2.0, mq)
+    _, orecs = _oracle_records(oracle, tb, libm_exact, bam, reference, min_qual=mq)
+    _, drecs = _oracle_records(oracle, oracle.Tables(), libm_exact, bam, reference)
+    assert len(orecs) == res["records"]
+    stream = open(bcf, "rb").read()
+    hdr = vcf.header_text(refs, "S2", date=(4, 10, 2026), under_conv=uc, over_conv=oc, min_qual=mq).encode() + b"\0"
+    assert stream[9 : 9 + len(hdr)] == hdr
+    exp = b"".join(py_bcf.encode_record(d, tid) for tid, d in orecs)
+    assert stream[9 + len(hdr) :] == exp
+    assert exp != b"".join(py_bcf.encode_record(d, tid) for tid, d in drecs)  # the parameters matter on this input
+    # a supplied caller: its parameters go into the header; a contradicting explicit value is an error
+    with B.SiteCaller(under_conv=uc, over_conv=oc, min_qual=mq) as c:
+        bcf2 = str(tmp_path / "out2.bcf")
+        pipeline.run(bam, reference, bcf2, sample="S2", date=(4, 10, 2026), compressed=False, caller=c)
+        assert open(bcf2, "rb").read() == stream
+        with pytest.raises(ValueError):
+            pipeline.run(bam, reference, bcf2, compressed=False, caller=c, under_conv=0.01)
 
 
 @pytest.mark.parametrize("seed", [3, 5, 7, 4])  # 3, 5, 7 run to the end; 4 holds a pair the reference asserts on
