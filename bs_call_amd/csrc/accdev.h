@@ -36,7 +36,7 @@ struct acc_reads {
 #endif
 
 #ifndef ACC_GROUP
-#define ACC_GROUP 8 /* reads whose byte loads are issued back to back before the first is consumed (4 or 8) */
+#define ACC_GROUP 16 /* reads whose byte loads are issued back to back before the first is consumed (4, 8 or 16) */
 #endif
 
 /* compact read descriptor, 24 bytes; a > b: the read contributes nothing */
