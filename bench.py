@@ -17,6 +17,9 @@ Default workload = BASELINE.json configs[1] (synthetic chr22-sized contig, 50 Mb
     (reads -> records in one kernel, neither pile-up nor gt_meth in HBM) over device-resident L-reads of the same contig
     (1 B per base + 16 B per template in; 104 B pile-up, or 1 B reference code in + 64 B record out, per
     position), device time from HIP events around all launches of the stage — measured after the timed region.
+  * every leg also carries `valu`: the fraction of the VALU issue capacity (1 024 SIMDs, one wave-instruction per 4 cycles) its
+    kernels use — SQ_INSTS_VALU and the clock from the committed counter passes (profiles/valu.json), the time from this run.
+    SURVEY.md 8d names FP64 VALU as the close second bound; for every kernel but bsc_call_kernel it is the one that binds.
   * cpu_baseline (rank 0, N = 1): the CPU oracle's libm flavour (= the reference's arithmetic; "port") on this host's
     cores over a bounded sample of the same contig: SURVEY.md 8d's three timings, medians of repetitions of >= 1 s.
 
@@ -43,6 +46,8 @@ ALGO_BYTES_COVERED = 305
 ALGO_BYTES_UNCOVERED = 105
 CHAIN_BYTES = 105 + 64  # fused chain: pile-up + reference code in, bsc_vcf_core out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_SIMDS = 1024  # 256 CUs x 4 SIMDs
+VALU_CYCLES_PER_INST = 4  # a wave64 instruction occupies its SIMD's VALU for 4 cycles, FP64 included (78.6 TFLOP/s vector FP64)
 SEED = 88172645463325252
 KERNEL_SOURCES = ("kernels.hip", "callmath.h", "call_body.inc", "bsmath.h", "bsmath_tables.h", "devtables.h")
 READS_SOURCES = ("fused.hip", "accdev.h", "accumulate.hip", "callmath.h", "call_body.inc", "sitestats_dev.h", "bsmath.h", "bsmath_tables.h", "devtables.h")
@@ -226,6 +231,7 @@ def run_config2(args, env):
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": profiled_traffic(n, args.coverage),
+                "valu": valu_block(n, args.coverage, "call", k_ms + float(np.mean(fisher_ms))),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms_avg": k_ms,
                 "kernel_ms_min": float(np.min(kernel_ms)),
@@ -286,16 +292,22 @@ def chain_roofline(args, caller, d_cts, d_ref, n, first_site):
     dev = d_cts.device
     d_core = torch.empty(n * 64, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    wall = []
+
     def launch():
+        t0 = time.perf_counter()
         caller.chain_device(d_cts.data_ptr(), d_ref.data_ptr(), 1, n, 0, n, d_core.data_ptr(), with_stats=True, stream=stream)
         torch.cuda.synchronize()
+        wall.append(time.perf_counter() - t0)
 
-    ms = timed_launches(launch, caller.last_chain_ms, min(args.steps, 10))
+    reps = min(args.steps, 10)
+    ms = timed_launches(launch, caller.last_chain_ms, reps)
     k_ms = float(np.mean(ms))
+    wall_s = float(np.median(wall[-reps:]))
     achieved = n * CHAIN_BYTES / (k_ms * 1e-3) / 1e9
     records = int(d_core.view(n, 64)[:, 4].sum())
     return {
-        "bound": "hbm",
+        "bound": "valu_issue",
         "kernel": "bsc_chain_kernel_t (bsc_chain_device)",
         "what": "pile-up -> call -> VCF record -> site statistics in one pass; gt_meth never reaches HBM (the unfused chain "
         "moves 630 B per position)",
@@ -304,11 +316,14 @@ def chain_roofline(args, caller, d_cts, d_ref, n, first_site):
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS,
         "traffic": profiled_traffic(n, args.coverage, "chain"),
+        "valu": valu_block(n, args.coverage, "chain", k_ms),
         "algorithmic_bytes_per_launch": n * CHAIN_BYTES,
         "kernel_ms_avg": k_ms,
-        "positions_per_s": n / (k_ms * 1e-3),
+        "positions_per_s": n / wall_s,  # per call as the host sees it (launch + one wait), median: round 2's definition of this key
+        "positions_per_s_device": n / (k_ms * 1e-3),  # HIP events around the launches (round 3 reported this one under the key above)
         "records_written_fraction": records / n,
-        "note": "instruction-issue bound (FP64 model + record formation), not HBM: the roofline fraction is low by construction",
+        "note": "bound by VALU instruction issue (FP64 model + record formation), not by HBM: `frac` (of 8 TB/s) is low by "
+        "construction, `valu.frac` is the fraction of the bound that binds",
     }
 
 
@@ -355,7 +370,7 @@ def reads_rooflines(args, caller):
     block = "one block of %d positions at %dx: %d templates, %d bases, resident in HBM" % (n, args.coverage, len(tpl), seq.size)
     return {
         "roofline_accumulate": {
-            "bound": "hbm",
+            "bound": "valu_issue",
             "kernel": "bsc_bin_count_kernel + rocPRIM prefix sum + bsc_bin_scatter_kernel + bsc_accumulate_kernel (bsc_accumulate_device)",
             "what": "HOT LOOP A, reads -> pile-up (reference src/call_genotypes.c:180-226, serial on its process thread); " + block,
             "achieved": a_bytes / (a_ms * 1e-3) / 1e9,
@@ -363,6 +378,7 @@ def reads_rooflines(args, caller):
             "unit": "GB/s",
             "frac": a_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "traffic": profiled_traffic(args.sites, args.coverage, "accumulate"),
+            "valu": valu_block(args.sites, args.coverage, "accumulate", a_ms),
             "algorithmic_bytes_per_launch": a_bytes,
             "algorithmic_bytes_per_position": a_bytes / n,
             "stage_ms_avg": a_ms,
@@ -370,10 +386,11 @@ def reads_rooflines(args, caller):
             "positions_per_s": n / (a_ms * 1e-3),
             "bases_per_s": seq.size / (a_ms * 1e-3),
             "first_chunk_equals_oracle": None,
-            "note": "latency / instruction-issue bound (one byte load per read and 64-position tile), not HBM",
+            "note": "latency and instruction issue (one byte load per read and 64-position tile) share this stage with the HBM writes "
+            "of the 104-byte pile-ups; neither bound is reached: both fractions are reported",
         },
         "roofline_reads": {
-            "bound": "hbm",
+            "bound": "valu_issue",
             "kernel": "bsc_bin_count_kernel + prefix sum + bsc_bin_scatter_kernel + bsc_chain_kernel_t<.., READS> (bsc_reads_chain_device), with statistics",
             "what": "reads -> pile-up -> call -> VCF record -> site statistics; the pile-up lives in the LDS of the wave that calls it, "
             "gt_meth in its registers; " + block,
@@ -382,6 +399,7 @@ def reads_rooflines(args, caller):
             "unit": "GB/s",
             "frac": r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "traffic": profiled_traffic(args.sites, args.coverage, "reads"),
+            "valu": valu_block(args.sites, args.coverage, "reads", r_ms),
             "algorithmic_bytes_per_launch": r_bytes,
             "algorithmic_bytes_per_position": r_bytes / n,
             "stage_ms_avg": r_ms,
@@ -389,7 +407,8 @@ def reads_rooflines(args, caller):
             "positions_per_s": n / (r_ms * 1e-3),
             "records_written_fraction": int(d_core.view(n, 64)[:, 4].sum()) / n,
             "first_chunk_records_equal_oracle": None,
-            "note": "instruction-issue bound (FP64 model + record formation + the pile-up walk), not HBM",
+            "note": "bound by VALU instruction issue (FP64 model + record formation + the pile-up walk), not by HBM: `valu.frac` is the "
+            "fraction of the bound that binds",
         },
         "_reads_sample": sample,
     }
@@ -430,6 +449,25 @@ def profiled_traffic(n, coverage, which=None):
     except Exception:
         pass
     return None
+
+
+def valu_block(n, coverage, which, ms):
+    """The VALU-issue side of a leg: wave-instructions per launch of all its kernels and the clock its dominant kernel ran at,
+    from the committed SQ counter passes (profiles/valu.json, tools/make_valu_json.py — counters cannot be read inside this
+    process); frac = instructions x 4 cycles / (1 024 SIMDs x clock x the leg's device time measured HERE).  None when the
+    workload differs or the kernel sources have changed since the passes were taken."""
+    try:
+        v = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))[which]
+        want = kernel_source_hash({"call": KERNEL_SOURCES, "chain": CHAIN_SOURCES}.get(which, READS_SOURCES))
+        if v.get("positions") != n or v.get("coverage") != coverage or v.get("kernel_source_sha256_16") != want or not v.get("clock_ghz"):
+            return None
+        insts, clk = v["insts_valu_per_launch"], v["clock_ghz"]
+        return {"insts_per_launch": insts, "cycles_per_inst": VALU_CYCLES_PER_INST, "simds": VALU_SIMDS, "clock_ghz": clk,
+                "frac": insts * VALU_CYCLES_PER_INST / (VALU_SIMDS * clk * 1e9 * ms * 1e-3),
+                "what": "SQ_INSTS_VALU of the leg's kernels x 4 cycles / (1 024 SIMDs x clock x this run's device time); clock = "
+                "SQ_BUSY_CYCLES / 32 shader engines / duration of the dominant kernel in the counter pass (profiles/valu.json)"}
+    except Exception:
+        return None
 
 
 def _median_rate(fn, units, min_s=1.0, reps=5):
