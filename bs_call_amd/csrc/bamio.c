@@ -934,7 +934,11 @@ static int next_record(bsc_bam *b, const bsc_reader_params *par, bam_rec *r, int
   r->aux = r->qual + l_seq;
   r->end = p + bs;
   r->l_seq = l_seq;
-  if (l_seq && n_cigar) { /* htslib, which the reference reads through, rejects a CIGAR whose query length is not l_seq */
+  if (l_seq && n_cigar) {
+    /* A CIGAR whose query length is not l_seq.  htslib, which the reference reads through, refuses it where it parses SAM
+     * text (sam_parse1) — an error here too; a binary BAM record is handed over as it is (bam_read1 does not look), and what
+     * the reference then does with it is a walk outside the read's bases: here the record is dropped before anything walks it,
+     * and the file is read on. */
     uint64_t qlen = 0;
     for (uint32_t i = 0; i < n_cigar; i++) {
       uint32_t c;
@@ -942,9 +946,12 @@ static int next_record(bsc_bam *b, const bsc_reader_params *par, bam_rec *r, int
       const uint32_t op = c & 15u;
       if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += c >> 4; /* M I S = X consume the query */
     }
-    if (qlen != l_seq)
-      return bsc_set_error(BSC_ERR_ARG, "read '%.*s': CIGAR covers %llu query bases, the sequence has %u", (int)l_name, r->name,
-                           (unsigned long long)qlen, l_seq), -2;
+    if (qlen != l_seq) {
+      if (b->is_sam)
+        return bsc_set_error(BSC_ERR_ARG, "read '%.*s': CIGAR covers %llu query bases, the sequence has %u", (int)l_name, r->name,
+                             (unsigned long long)qlen, l_seq), -2;
+      return 2; /* like a record outside the region: it does not exist for the reader */
+    }
   }
   if (par->region_stop) { /* an index query hands over the records that overlap the region: the others do not exist for the reader */
     uint32_t reflen = 0;

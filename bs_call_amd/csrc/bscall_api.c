@@ -581,6 +581,10 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
                                  uint64_t seq_bytes, uint32_t x, uint32_t y, const uint8_t *ref, int stage) {
   if (y < x) return bsc_fail(BSC_ERR_ARG, "accumulate: y (%u) < x (%u) (reference asserts y >= x)", y, x);
   if (nr && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "accumulate: NULL template or read buffer");
+  /* one block in flight per context, whichever pair of calls submitted it: the host-buffer paths share the staging area, the
+   * device workspaces (templates, reads, reference, results) and the verdict counters */
+  if (ctx->pending_sz || ctx->rec_pending)
+    return bsc_fail(BSC_ERR_ARG, "a submitted block has not been fetched (bsc_block_fetch / bsc_block_records_fetch first)");
   /* The templates themselves are checked where they are read anyway — by bsc_prep_reads_kernel, on the device
    * (a host loop over a million 40-byte templates costs more than the whole GPU side of the block); the verdict is
    * collected by bsc_block_check(). */
@@ -1145,6 +1149,8 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
                              bsc_vcf_rec *out, uint64_t out_cap, int stage) {
   if (y < x) return bsc_fail(BSC_ERR_ARG, "accumulate: y (%u) < x (%u) (reference asserts y >= x)", y, x);
   if (nr && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "accumulate: NULL template or read buffer");
+  if (ctx->pending_sz || ctx->rec_pending)
+    return bsc_fail(BSC_ERR_ARG, "a submitted block has not been fetched (bsc_block_fetch / bsc_block_records_fetch first)");
   const uint64_t sz64 = (uint64_t)y - x + 1;
   if (sz64 > 0x0fffffffull) return bsc_fail(BSC_ERR_ARG, "bsc_block_records: block longer than 2^28 - 1 positions");
   const uint32_t sz = (uint32_t)sz64;

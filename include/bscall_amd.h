@@ -274,6 +274,13 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
  * out[out_cap]: pinned or pageable; *n_out = records written.  BSC_ERR_ARG if out_cap is too small (*n_out then holds
  * the number needed) or a template breaks one of the reference's asserts (the contents of out are then unspecified);
  * BSC_WARN_INEXACT as bsc_accumulate.
+ * The reference aborts on such a template (asserts enabled in release builds, src/call_genotypes.c:186-188); here the block is
+ * queued before its verdict is known (one wait per block), so when BSC_ERR_ARG names a template the context's site statistics,
+ * CpG carry and position counters already hold what the block's other reads gave: they are undefined from there on — a
+ * caller that goes on after the error calls bsc_reset_site_stats() (and bsc_reset_stats()) first.
+ * One block in flight per context across ALL host-buffer block entries (bsc_accumulate, bsc_call_block, bsc_block_submit[_to],
+ * bsc_block_records[_submit[_inplace]]): they share the staging area, the device workspaces and the verdict counters, and
+ * each refuses with BSC_ERR_ARG while a submitted block has not been fetched.
  *
  * bsc_block_records_submit / _fetch: the same split where the reference splits it — submit returns once the block is queued,
  * as call_genotypes_ML returns once its calc threads are dispatched (src/call_genotypes.c:260-272), its inputs copied to a

@@ -189,6 +189,23 @@ def test_unsorted_and_broken_input(tmp_path):
         BamReader(str(tmp_path / "missing.bam"))
 
 
+def test_cigar_that_disagrees_with_the_sequence_length(tmp_path):
+    """A CIGAR whose query length is not l_seq: htslib (un-vendored; the reference reads through it) refuses it where it
+    parses SAM text (sam_parse1) and hands a binary BAM record over unchecked — the reader errors on the text and, for BAM,
+    drops the record before anything walks outside its bases and reads the file on."""
+    good = [rec("a", 0, 100, -1), rec("c", 0, 300, -1)]
+    bad = rec("b", 0, 200, -1, seq="ACGTACGTAC", cigar=[("M", 14)])
+    p = str(tmp_path / "x.bam")
+    W.write_bam(p, REFS, [good[0], bad, good[1]])
+    blocks, cts, _ = c_blocks(p)
+    W.write_bam(p, REFS, good)
+    assert (blocks, cts) == c_blocks(p)[:2]  # as if the record were not there
+    sam = str(tmp_path / "x.sam")
+    W.write_sam(sam, REFS, [good[0], bad, good[1]])
+    with pytest.raises(BscError, match="CIGAR covers 14 query bases"):
+        c_blocks(sam)
+
+
 # ---- random files: C == Python restatement ---------------------------------------------------------------------------------
 def _random_records(rng, n):
     recs = []

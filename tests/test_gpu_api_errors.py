@@ -100,6 +100,22 @@ def test_c_abi_rejects_bad_arguments():
         assert SI(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec)) == -1 and "fetched" in err()
         n_in = C.c_uint64(0)
         assert L.bsc_block_records_fetch(h, C.byref(n_in)) == 0 and n_in.value == cnt.value
+        # the two asynchronous block forms share the staging area, the device workspaces and the verdict counters: a block
+        # submitted through either keeps every other host-buffer block entry out until it has been fetched
+        pile_h = np.zeros(y - x + 1, dtype=B.PILEUP)
+        assert L.bsc_block_records_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec)) == 0
+        assert L.bsc_block_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), 200) == -1 and "fetched" in err()
+        assert L.bsc_accumulate(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(pile_h)) == -1 and "fetched" in err()
+        assert L.bsc_call_block(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), p(out2), 200, p(skip2)) == -1 and "fetched" in err()
+        assert L.bsc_block_records_fetch(h, C.byref(n_in)) == 0 and n_in.value == cnt.value  # untouched by the refused calls
+        assert rec[: cnt.value]["core"]["emit"].all()
+        assert L.bsc_block_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), 200) == 0
+        assert L.bsc_block_records(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec),
+                                   C.byref(cnt)) == -1 and "fetched" in err()
+        assert L.bsc_block_records_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec)) == -1
+        assert L.bsc_accumulate(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(pile_h)) == -1 and "fetched" in err()
+        out3 = np.zeros(y - x + 1, dtype=B.GT_METH)
+        assert L.bsc_block_fetch(h, p(out3), p(skip2)) == 0 and out3.tobytes() == out2.tobytes()  # ... and neither was this one
         # after all that the context still computes
         got = c.block_records(tpl, seq, x, y, ref2)
         assert len(got) > 0 and (got["core"]["emit"] == 1).all()
