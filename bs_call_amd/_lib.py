@@ -36,6 +36,9 @@ EXPORTS = (
     "bsc_block_records_submit",
     "bsc_block_records_submit_inplace",
     "bsc_block_records_fetch",
+    "bsc_blocks_records_submit",
+    "bsc_blocks_records_fetch",
+    "bsc_blocks_records",
     "bsc_vcf_stats",
     "bsc_vcf_stats_device",
     "bsc_get_site_stats",
@@ -371,6 +374,12 @@ def load():
     L.bsc_block_records_submit_inplace.argtypes = L.bsc_block_records_submit.argtypes
     L.bsc_block_records_fetch.restype = i32
     L.bsc_block_records_fetch.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.bsc_blocks_records_submit.restype = i32
+    L.bsc_blocks_records_submit.argtypes = [vp, vp, u32, vp, vp, u64, vp, vp, vp, i32, vp, u64]
+    L.bsc_blocks_records_fetch.restype = i32
+    L.bsc_blocks_records_fetch.argtypes = [vp, C.POINTER(C.c_uint64), vp]
+    L.bsc_blocks_records.restype = i32
+    L.bsc_blocks_records.argtypes = [vp, vp, u32, vp, vp, u64, vp, vp, vp, i32, vp, u64, C.POINTER(C.c_uint64), vp]
     L.bsc_vcf_format_rec.restype = i32
     L.bsc_vcf_format_rec.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
     L.bsc_vcf_stats_device.restype = i32

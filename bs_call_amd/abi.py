@@ -91,6 +91,8 @@ SITE_STATS = np.dtype(
 SITE_STATS_INT_WORDS = (SITE_STATS.itemsize - 4 * 101 * 8) // 8  # the leading u64 part; the rest is 404 doubles
 
 # bsc_raw_template / bsc_misms / bsc_prep_params / bsc_prep_stats (include/bscall_amd.h): read pre-processing
+BLOCK_DESC = np.dtype([("x", "<u4"), ("y", "<u4"), ("nr", "<u4"), ("_pad", "<u4")])  # bsc_block_desc (bsc_blocks_records)
+
 RAW_TEMPLATE = np.dtype(
     {
         "names": ["pos", "reference_span", "len", "n_misms", "off", "misms_off", "mapq", "orientation", "bs_strand", "_pad"],

@@ -267,6 +267,54 @@ class SiteCaller:
                                          len(out), C.byref(cnt)))
         return out[: cnt.value]
 
+    def blocks_records(self, blocks, ref, out=None, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False,
+                       submit_only=False):
+        """Several blocks in one launch sequence (bsc_blocks_records): blocks = [(templates, seq, x, y), ...] in genome order;
+        ref = their reference codes, a list of uint8[y - x + 3] arrays (or one array, block after block); dbsnp likewise
+        (y - x + 1 each) or None.  Returns (VCF_REC[n_written] of all blocks, block after block; records written per block) —
+        the records of block_records() called on the blocks one after another.  submit_only: queue and return; then
+        blocks_records_fetch()."""
+        from .abi import BLOCK_DESC
+
+        tpls, seqs, desc, off = [], [], np.zeros(len(blocks), dtype=BLOCK_DESC), 0
+        for i, (t, sq, x, y) in enumerate(blocks):
+            t = np.array(t, dtype=TEMPLATE)  # a copy: the read offsets become offsets into the joined read buffer
+            sq = np.ascontiguousarray(sq, dtype=np.uint8)
+            t["off"] += np.uint64(off)
+            off += sq.size
+            tpls.append(t)
+            seqs.append(sq)
+            desc[i] = (x, y, len(t), 0)
+        tpl = np.concatenate(tpls) if tpls else np.zeros(0, dtype=TEMPLATE)
+        seq = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
+        sizes = [int(y) - int(x) + 1 for _, _, x, y in blocks]
+        refs = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint8) for r in ref]) if isinstance(ref, (list, tuple)) else ref, dtype=np.uint8)
+        if min(sizes) > 0 and len(refs) != sum(sizes) + 2 * len(sizes):  # (a block with y < x is the library's to refuse)
+            raise ValueError("ref must hold y - x + 3 codes per block")
+        db = None
+        if dbsnp is not None:
+            db = np.ascontiguousarray(np.concatenate([np.asarray(d, dtype=np.uint8) for d in dbsnp]) if isinstance(dbsnp, (list, tuple)) else dbsnp, dtype=np.uint8)
+            if min(sizes) > 0 and len(db) != sum(sizes):
+                raise ValueError("dbsnp must hold y - x + 1 flags per block")
+        if out is None:
+            out = np.zeros(sum(sizes), dtype=VCF_REC)
+        elif out.dtype != VCF_REC or not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]:
+            raise ValueError("out must be a writable C-contiguous VCF_REC array")
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        _check(self._L.bsc_blocks_records_submit(self._h, _ptr(desc), len(desc), _ptr(tpl), _ptr(seq), seq.size, _ptr(refs),
+                                                 None if db is None else _ptr(db), C.byref(p), 1 if with_stats else 0, _ptr(out), len(out)))
+        self._pending_blocks = (out, len(desc))
+        return None if submit_only else self.blocks_records_fetch()
+
+    def blocks_records_fetch(self):
+        out, nb = getattr(self, "_pending_blocks", None) or (None, 0)
+        if out is None:
+            raise BscError(-1, "blocks_records_fetch: no blocks were submitted")
+        self._pending_blocks = None
+        cnt, per = C.c_uint64(0), np.zeros(nb, dtype=np.uint64)
+        _check(self._L.bsc_blocks_records_fetch(self._h, C.byref(cnt), _ptr(per)))
+        return out[: cnt.value], per
+
     def block_records_submit(self, templates, seq, x, y, ref, out, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None,
                              with_stats=False, inplace=False):
         """Queue one block (reads -> packed records into `out`, a VCF_REC array that must stay alive until the fetch) and

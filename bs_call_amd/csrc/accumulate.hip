@@ -94,6 +94,23 @@ __device__ static __forceinline__ uint32_t template_reads(const bsc_template_dev
   return 0;
 }
 
+/* Several blocks in one pass (bsc_blocks_records): template t belongs to the block whose tpl_end is the first one above t; its
+ * positions and bins are that block's (devtables.h).  blk == NULL: one block, x .. y, bins from 0. */
+__device__ static __forceinline__ void template_block(const bsc_chain_mblock *__restrict__ blk, uint32_t n_blk, uint32_t t, uint32_t &x,
+                                                      uint32_t &y, uint32_t &bin0) {
+  bin0 = 0;
+  if (!blk) return;
+  uint32_t lo = 0, hi = n_blk - 1u; /* t < blk[n_blk - 1].tpl_end */
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (t < blk[mid].tpl_end) hi = mid;
+    else lo = mid + 1u;
+  }
+  x = blk[lo].x;
+  y = blk[lo].x + (blk[lo].n - 1u);
+  bin0 = blk[lo].bin0;
+}
+
 #define BIN_WG 256   /* templates per workgroup */
 #define BIN_WIN 1024 /* bins of the workgroup's LDS window: a coordinate-ordered align_list keeps a workgroup's 512 reads
                         within a few dozen bins; reads outside the window take a global atomic each */
@@ -125,7 +142,8 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_count_kernel(const 
                                                                           const uint8_t *__restrict__ seq, uint64_t seq_bytes,
                                                                           uint32_t x, uint32_t y, uint8_t *__restrict__ tflag,
                                                                           uint32_t *__restrict__ bin_cnt,
-                                                                          unsigned long long *__restrict__ counters) {
+                                                                          unsigned long long *__restrict__ counters,
+                                                                          const bsc_chain_mblock *__restrict__ blk, uint32_t n_blk) {
   __shared__ uint32_t s_cnt[BIN_WIN];
   __shared__ uint32_t s_min;
   for (unsigned i = threadIdx.x; i < BIN_WIN; i += BIN_WG) s_cnt[i] = 0;
@@ -133,6 +151,8 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_count_kernel(const 
   uint32_t bin[2] = {0xffffffffu, 0xffffffffu}, span_max = 0;
   if (t < nr) {
     const bsc_template_dev tp = tpl[t];
+    uint32_t bin0;
+    template_block(blk, n_blk, t, x, y, bin0);
     bool walked0 = false;
     if (template_error(tp, leftmost(tp.pos[0], tp.pos[1]), x, seq_bytes) == 0) {
       const uint32_t rl = tp.len[0];
@@ -152,7 +172,7 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_count_kernel(const 
 #pragma unroll
     for (int k = 0; k < 2; k++)
       if (d[k].b >= d[k].a) { /* live: x <= a <= b <= y */
-        bin[k] = (d[k].a - x) >> ACC_BIN_SHIFT;
+        bin[k] = bin0 + ((d[k].a - x) >> ACC_BIN_SHIFT);
         if (d[k].b - d[k].a > span_max) span_max = d[k].b - d[k].a;
       }
   }
@@ -189,7 +209,8 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_scatter_kernel(cons
                                                                             uint64_t seq_bytes, uint32_t x, uint32_t y,
                                                                             const uint8_t *__restrict__ tflag,
                                                                             uint32_t *__restrict__ bin_cur,
-                                                                            bsc_read_desc *__restrict__ rd) {
+                                                                            bsc_read_desc *__restrict__ rd,
+                                                                            const bsc_chain_mblock *__restrict__ blk, uint32_t n_blk) {
   __shared__ uint32_t s_cnt[BIN_WIN]; /* reads of the workgroup per bin of its window, then: the first slot they got */
   __shared__ uint32_t s_min;
   for (unsigned i = threadIdx.x; i < BIN_WIN; i += BIN_WG) s_cnt[i] = 0;
@@ -199,10 +220,12 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_scatter_kernel(cons
   acc_dead(d[0]);
   acc_dead(d[1]);
   if (t < nr) {
+    uint32_t bin0;
+    template_block(blk, n_blk, t, x, y, bin0);
     (void)template_reads(tpl[t], x, y, seq_bytes, tflag[t] != 0, d);
 #pragma unroll
     for (int k = 0; k < 2; k++)
-      if (d[k].b >= d[k].a) bin[k] = (d[k].a - x) >> ACC_BIN_SHIFT;
+      if (d[k].b >= d[k].a) bin[k] = bin0 + ((d[k].a - x) >> ACC_BIN_SHIFT);
   }
   const uint32_t base = wg_min_bin(bin[0], bin[1], &s_min);
 #pragma unroll
@@ -309,25 +332,42 @@ extern "C" uint32_t bsc_dev_n_bins(uint32_t n_sites) { return ((n_sites - 1u) >>
 
 /* template checks, read descriptors and their grouping by bin: rd[<= 2 nr] (live reads, bin after bin), bin_off[n_bins + 1].
  * bin_cnt / bin_off / bin_cur: n_bins + 1 words each; tflag: nr bytes. */
-extern "C" int bsc_dev_launch_bin_reads(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
-                                        void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
-                                        size_t scan_tmp_bytes, void *rd, void *counters, void *stream) {
+static int launch_bin_reads(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y, uint32_t nb,
+                            const bsc_chain_mblock *blk, uint32_t n_blk, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur,
+                            void *scan_tmp, size_t scan_tmp_bytes, void *rd, void *counters, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  const uint32_t nb = bsc_dev_n_bins(y - x + 1);
   const size_t bytes = ((size_t)nb + 1u) * sizeof(uint32_t);
   if (!nr) return (int)hipMemsetAsync(bin_off, 0, bytes, s); /* no reads: every bin empty */
   hipError_t e = hipMemsetAsync(bin_cnt, 0, bytes, s);
   if (e != hipSuccess) return (int)e;
   const unsigned g = (nr + BIN_WG - 1u) / BIN_WG; /* nr <= 2^31 - 1 is checked by the caller */
   hipLaunchKernelGGL(bsc_bin_count_kernel, dim3(g), dim3(BIN_WG), 0, s, (const bsc_template_dev *)tpl, nr, (const uint8_t *)seq,
-                     seq_bytes, x, y, (uint8_t *)tflag, (uint32_t *)bin_cnt, (unsigned long long *)counters);
+                     seq_bytes, x, y, (uint8_t *)tflag, (uint32_t *)bin_cnt, (unsigned long long *)counters, blk, n_blk);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   int rc = bsc_dev_scan_u32(bin_cnt, bin_off, nb + 1u, scan_tmp, scan_tmp_bytes, stream);
   if (rc) return rc;
   if ((e = hipMemcpyAsync(bin_cur, bin_off, bytes, hipMemcpyDeviceToDevice, s)) != hipSuccess) return (int)e;
   hipLaunchKernelGGL(bsc_bin_scatter_kernel, dim3(g), dim3(BIN_WG), 0, s, (const bsc_template_dev *)tpl, nr, seq_bytes, x, y,
-                     (const uint8_t *)tflag, (uint32_t *)bin_cur, (bsc_read_desc *)rd);
+                     (const uint8_t *)tflag, (uint32_t *)bin_cur, (bsc_read_desc *)rd, blk, n_blk);
   return (int)hipGetLastError();
+}
+
+/* template checks, read descriptors and their grouping by bin: rd[<= 2 nr] (live reads, bin after bin), bin_off[n_bins + 1].
+ * bin_cnt / bin_off / bin_cur: n_bins + 1 words each; tflag: nr bytes. */
+extern "C" int bsc_dev_launch_bin_reads(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                                        void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
+                                        size_t scan_tmp_bytes, void *rd, void *counters, void *stream) {
+  return launch_bin_reads(tpl, nr, seq, seq_bytes, x, y, bsc_dev_n_bins(y - x + 1), NULL, 0, tflag, bin_cnt, bin_off, bin_cur, scan_tmp,
+                          scan_tmp_bytes, rd, counters, stream);
+}
+
+/* the same over the templates of several blocks at once: d_blk[n_blk] (device) says which templates, positions and bins are
+ * whose; n_bins = the bins of all blocks together */
+extern "C" int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk,
+                                              uint32_t n_blk, uint32_t n_bins, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur,
+                                              void *scan_tmp, size_t scan_tmp_bytes, void *rd, void *counters, void *stream) {
+  return launch_bin_reads(tpl, nr, seq, seq_bytes, 0, 0, n_bins, (const bsc_chain_mblock *)d_blk, n_blk, tflag, bin_cnt, bin_off, bin_cur,
+                          scan_tmp, scan_tmp_bytes, rd, counters, stream);
 }
 
 extern "C" int bsc_dev_launch_accumulate(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y, uint32_t min_qual,

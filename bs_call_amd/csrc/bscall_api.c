@@ -54,6 +54,12 @@ int bsc_dev_launch_synth(uint64_t seed, uint64_t first_site, uint64_t n, uint32_
                          void *ref, int num_cus, void *stream);
 size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth, int reads);
 size_t bsc_dev_chain_scratch_bytes(int num_cus);
+size_t bsc_dev_chain_multi_table_bytes(uint32_t n_blocks);
+int bsc_dev_launch_chain_multi(const bsc_chain_launch *L, const bsc_chain_mblock *blk, uint32_t b_first, uint32_t b_last, void *tab_h,
+                               void *tab_d, size_t *cursor);
+int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk, uint32_t n_blk,
+                                   uint32_t n_bins, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
+                                   size_t scan_tmp_bytes, void *rd, void *counters, void *stream);
 #define BSC_LN10 (2.30258509299404568402) /* the reference's LOG10 literal (include/bs_call.h:36) */
 #define BSC_HOST_CHUNK (4u << 20)         /* sites per host->device round trip (4 Mi sites = 1.2 GiB of records) */
 #define BSC_MAX_LAUNCH (1ull << 31)       /* sites per launch: site indices in the het list are 32-bit */
@@ -118,6 +124,13 @@ struct bsc_context {
   uint32_t rec_sz;
   int rec_pending;
   double rec_share;
+  /* bsc_blocks_records_submit / _fetch: the blocks of the launch in flight (their table lives in the staging area), the device
+   * copies of that table and of the chain's segment tables, where the per-tile record offsets come back to */
+  const bsc_chain_mblock *mb_tab;
+  uint32_t mb_n;
+  void *d_mblk, *d_mtab;
+  size_t cap_mblk, cap_mtab;
+  const uint32_t *mb_toff;
   void *d_fscr; /* reads-in chain: forward-count scratch lines of the resident waves */
   size_t cap_fscr;
   hipEvent_t ev_rchain[2]; /* bsc_set_profiling: the reads-in chain's launches (read descriptors, ordering, tile search, chain) */
@@ -343,6 +356,8 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_toff);
   hipFree(ctx->d_scantmp);
   hipFree(ctx->d_recs);
+  hipFree(ctx->d_mblk);
+  hipFree(ctx->d_mtab);
   hipFree(ctx->d_carry);
   hipFree(ctx->d_logp);
   hipFree(ctx->d_vout);
@@ -1284,10 +1299,203 @@ int bsc_block_records_submit_inplace(bsc_context *ctx, const bsc_template *tpl, 
 int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out) {
   if (!ctx || !n_out) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_fetch: NULL argument");
   *n_out = 0;
-  if (!ctx->rec_pending) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_fetch: no block was submitted");
+  if (ctx->rec_pending != 1) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_fetch: no block was submitted");
   ctx->rec_pending = 0;
   BSC_ENTER(ctx);
   return bsc_records_finish(ctx, n_out);
+}
+
+/*
+ * Several blocks, one launch sequence (bsc_blocks_records_submit): what bsc_records_queue does for one block — H2D, template
+ * checks + grouping, the reads-in chain, packing, copy-out, one wait — for n_blocks of them at once.  The blocks' positions lie
+ * one block after another in the per-position arrays, each block from a multiple of 64 on (so a block's first packed record is
+ * where the packing pass's offset of its first 64-position tile says); their reads are grouped in one pass, bins numbered
+ * through; the chain runs one pair of launches (unguarded + guarded kernel) over the segments of all blocks — two pairs where a
+ * block begins right behind its predecessor's last position, because only there can the printer's pending cytosine
+ * (src/print_vcf.c:447-455) pair across blocks, and the second launch reads what the first left.
+ */
+static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                            uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                            bsc_vcf_rec *out, uint64_t out_cap) {
+  if (ctx->pending_sz || ctx->rec_pending)
+    return bsc_fail(BSC_ERR_ARG, "a submitted block has not been fetched (bsc_block_fetch / bsc_block_records_fetch first)");
+  if (n_blocks == 0 || n_blocks > 65536u) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records: n_blocks must be 1 .. 65536, got %u", n_blocks);
+  uint64_t nr64 = 0, pos64 = 0, ref64 = 0, sites = 0;
+  for (uint32_t b = 0; b < n_blocks; b++) {
+    if (blocks[b].y < blocks[b].x)
+      return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records: block %u has y (%u) < x (%u) (reference asserts y >= x)", b, blocks[b].y, blocks[b].x);
+    const uint64_t sz = (uint64_t)blocks[b].y - blocks[b].x + 1;
+    if (blocks[b].y == 0xffffffffu) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records: positions exceed 32 bits");
+    nr64 += blocks[b].nr;
+    pos64 += (sz + 63u) & ~(uint64_t)63u;
+    ref64 += sz + 2;
+    sites += sz;
+  }
+  if (pos64 > 0x0fffffffull) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records: more than 2^28 - 1 positions in one call");
+  if (nr64 > 0x7fffffffull) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records: more than 2^31 - 1 templates in one call");
+  const uint32_t nr = (uint32_t)nr64, P = (uint32_t)pos64;
+  if (nr && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records: NULL template or read buffer");
+  BSC_ENTER(ctx);
+  int rc;
+  size_t scan_bytes = 0;
+  if ((rc = bsc_accumulate_reserve(ctx, nr, 1u, P, &scan_bytes))) return rc; /* P positions = P / 64 bins */
+  if ((rc = bsc_reserve(&ctx->d_fscr, &ctx->cap_fscr, bsc_dev_chain_scratch_bytes(ctx->num_cus)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)ref64))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)P * 64u))) return rc; /* the chain's aux array */
+  if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)P * sizeof(bsc_vcf_core)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_recs, &ctx->cap_recs, (size_t)(out_cap ? out_cap : 1) * sizeof(bsc_vcf_rec)))) return rc;
+  if (dbsnp && (rc = bsc_reserve(&ctx->d_vdb, &ctx->cap_vdb, (size_t)P))) return rc;
+  const size_t tab_bytes = bsc_dev_chain_multi_table_bytes(n_blocks);
+  if ((rc = bsc_reserve(&ctx->d_mblk, &ctx->cap_mblk, (size_t)n_blocks * sizeof(bsc_chain_mblock)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_mtab, &ctx->cap_mtab, tab_bytes))) return rc;
+  if (!ctx->h_cnt && hipHostMalloc((void **)&ctx->h_cnt, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
+    return bsc_fail(BSC_ERR_NOMEM, "bsc_blocks_records: pinned counter block");
+  /* the pinned staging area: inputs (the caller's buffers are free when the call returns), the tables, and the per-tile record
+   * offsets on their way back */
+  const size_t b_tpl = (size_t)nr * sizeof(bsc_template), b_seq = (size_t)seq_bytes, b_db = dbsnp ? (size_t)P : 0;
+  const size_t b_blk = (size_t)n_blocks * sizeof(bsc_chain_mblock), b_toff = ((size_t)(P >> 6) + 1u) * 4u;
+#define AL64(v) (((v) + 63u) & ~(size_t)63u)
+  const size_t o_seq = AL64(b_tpl), o_ref = AL64(o_seq + b_seq), o_db = AL64(o_ref + (size_t)ref64), o_blk = AL64(o_db + b_db),
+               o_tab = AL64(o_blk + b_blk), o_toff = AL64(o_tab + tab_bytes);
+#undef AL64
+  if ((rc = bsc_stage_reserve(ctx, o_toff + b_toff + 64u))) return rc;
+  char *st = ctx->h_stage;
+  if (nr) {
+    memcpy(st, tpl, b_tpl);
+    memcpy(st + o_seq, seq, b_seq);
+  }
+  memcpy(st + o_ref, ref, (size_t)ref64);
+  bsc_chain_mblock *mb = (bsc_chain_mblock *)(st + o_blk);
+  {
+    uint32_t t_end = 0, r_off = 0, p_off = 0;
+    uint64_t d_in = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+      const uint32_t sz = blocks[b].y - blocks[b].x + 1u;
+      t_end += blocks[b].nr;
+      mb[b].x = blocks[b].x;
+      mb[b].n = sz;
+      mb[b].tpl_end = t_end;
+      mb[b].ref_off = r_off;
+      mb[b].pos_off = p_off;
+      mb[b].bin0 = p_off >> 6;
+      mb[b].bin_end = (p_off >> 6) + bsc_dev_n_bins(sz);
+      mb[b]._pad = 0;
+      if (dbsnp) { /* the caller's flags are packed block after block; on the device every block starts on a multiple of 64 */
+        memcpy(st + o_db + p_off, dbsnp + d_in, sz);
+        memset(st + o_db + p_off + sz, 0, ((sz + 63u) & ~63u) - sz);
+        d_in += sz;
+      }
+      r_off += sz + 2u;
+      p_off += (sz + 63u) & ~63u;
+    }
+  }
+  hipStream_t s = ctx->stream;
+  ctx->blk_tpl = (const bsc_template *)st;
+  ctx->blk_d_tpl = ctx->d_tpl;
+  ctx->blk_x = blocks[0].x;
+  ctx->mb_tab = mb;
+  ctx->mb_n = n_blocks;
+  if (nr) {
+    HIP_TRY(hipMemcpyAsync(ctx->d_tpl, st, b_tpl, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_seq, st + o_seq, b_seq, hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->d_ref, st + o_ref, (size_t)ref64, hipMemcpyHostToDevice, s));
+  if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, st + o_db, b_db, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->d_mblk, mb, b_blk, hipMemcpyHostToDevice, s));
+  void *d_db = dbsnp ? ctx->d_vdb : NULL;
+  /* template checks + grouping of all blocks' reads (SPAN, INEXACT = 0 and ERR = all ones first, as bsc_reads_prepare) */
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), s));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), s));
+  int e = bsc_dev_launch_bin_reads_multi(ctx->d_tpl, nr, ctx->d_seq, seq_bytes, ctx->d_mblk, n_blocks, P >> 6, ctx->d_tflag, ctx->d_bcnt,
+                                         ctx->d_boff, ctx->d_bcur, ctx->d_bscan, scan_bytes, ctx->d_rd, ctx->d_counters, s);
+  if (e) return bsc_fail(BSC_ERR_HIP, "read grouping launch failed: %s", hipGetErrorString((hipError_t)e));
+  /* the chain: one launch group per stretch of blocks none of which begins right behind its predecessor */
+  bsc_window w = {1u, P, 0u, P};
+  size_t cursor = 0;
+  for (uint32_t b0 = 0; b0 < n_blocks;) {
+    uint32_t b1 = b0;
+    while (b1 + 1u < n_blocks && blocks[b1 + 1u].x != blocks[b1].y + 1u) b1++;
+    bsc_chain_launch L;
+    if ((rc = bsc_chain_fill(ctx, &L, &w, params, with_stats, 1, ctx->d_ref, d_db, ctx->d_vout, ctx->d_out, s))) return rc;
+    L.rd = ctx->d_rd;
+    L.bin_off = ctx->d_boff;
+    L.seq = ctx->d_seq;
+    L.f_scratch = ctx->d_fscr;
+    L.n_bins = P >> 6;
+    L.min_qual = (uint32_t)ctx->params.min_qual;
+    e = bsc_dev_launch_chain_multi(&L, mb, b0, b1, st + o_tab, ctx->d_mtab, &cursor);
+    if (e) return bsc_fail(BSC_ERR_HIP, "reads chain launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (with_stats) ctx->carry_slot ^= 1u;
+    b0 = b1 + 1u;
+  }
+  ctx->sites += sites;
+  unsigned long long *d_total = ctx->d_counters + BSC_CNT_RECORDS;
+  if ((rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 0, d_db, P, ctx->d_recs, out_cap, d_total, s))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->h_cnt, ctx->d_counters + BSC_CNT_INEXACT, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(st + o_toff, ctx->d_toff, (size_t)(P >> 6) * 4u, hipMemcpyDeviceToHost, s));
+  ctx->mb_toff = (const uint32_t *)(st + o_toff);
+  uint64_t guess = (uint64_t)((double)sites * ctx->rec_share) + 4096u;
+  if (guess > out_cap) guess = out_cap;
+  if (guess > sites) guess = sites;
+  if (guess) HIP_TRY(hipMemcpyAsync(out, ctx->d_recs, (size_t)guess * sizeof(bsc_vcf_rec), hipMemcpyDeviceToHost, s));
+  ctx->rec_out = out;
+  ctx->rec_cap = out_cap;
+  ctx->rec_copied = guess;
+  ctx->rec_sz = sites > 0xffffffffull ? 0xffffffffu : (uint32_t)sites;
+  return BSC_OK;
+}
+
+int bsc_blocks_records_submit(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                              uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                              bsc_vcf_rec *out, uint64_t out_cap) {
+  if (!ctx || !blocks || !ref || !params || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records_submit: NULL argument");
+  int rc = bsc_blocks_queue(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap);
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream); /* nothing may still read the staging area after a failed submit */
+    return rc;
+  }
+  ctx->rec_pending = 2;
+  return BSC_OK;
+}
+
+int bsc_blocks_records_fetch(bsc_context *ctx, uint64_t *n_out, uint64_t *block_counts) {
+  if (!ctx || !n_out) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records_fetch: NULL argument");
+  *n_out = 0;
+  if (ctx->rec_pending != 2) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records_fetch: no blocks were submitted");
+  ctx->rec_pending = 0;
+  BSC_ENTER(ctx);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_cnt[1] != ~0ull) { /* an invalid template: name it with its own block's start */
+    const uint32_t t = (uint32_t)(ctx->h_cnt[1] >> 8);
+    for (uint32_t b = 0; b < ctx->mb_n; b++)
+      if (t < ctx->mb_tab[b].tpl_end) {
+        ctx->blk_x = ctx->mb_tab[b].x;
+        break;
+      }
+  }
+  int rc = bsc_records_finish(ctx, n_out);
+  if (rc < 0) return rc;
+  if (block_counts) { /* a block's records start where the packing pass put its first 64-position tile */
+    const uint64_t total = *n_out;
+    for (uint32_t b = 0; b < ctx->mb_n; b++) {
+      const uint64_t lo = ctx->mb_toff[ctx->mb_tab[b].pos_off >> 6];
+      const uint64_t hi = b + 1u < ctx->mb_n ? ctx->mb_toff[ctx->mb_tab[b + 1u].pos_off >> 6] : total;
+      block_counts[b] = hi - lo;
+    }
+  }
+  return rc;
+}
+
+int bsc_blocks_records(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                       uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                       bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out, uint64_t *block_counts) {
+  if (!n_out) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records: NULL argument");
+  *n_out = 0;
+  int rc = bsc_blocks_records_submit(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap);
+  if (rc) return rc;
+  return bsc_blocks_records_fetch(ctx, n_out, block_counts);
 }
 
 /* ---- site statistics -------------------------------------------------------------------------------------- */

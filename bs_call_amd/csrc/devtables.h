@@ -63,4 +63,14 @@ typedef struct bsc_chain_launch {
   uint32_t n_bins, min_qual;
 } bsc_chain_launch;
 
+/* one block of a launch of several (bsc_dev_launch_chain_multi, bsc_dev_launch_bin_reads_multi) */
+typedef struct bsc_chain_mblock {
+  uint32_t x, n;     /* first position, positions */
+  uint32_t tpl_end;  /* index behind the block's last template among the call's templates */
+  uint32_t ref_off;  /* its n + 2 reference codes start here in the reference buffer */
+  uint32_t pos_off;  /* its positions start here in the per-position arrays: a multiple of 64 */
+  uint32_t bin0, bin_end; /* its bins in bin_off[]: pos_off / 64 .. */
+  uint32_t _pad;
+} bsc_chain_mblock;
+
 #endif

@@ -70,6 +70,14 @@ struct bsc_chain_args {
    * run_tiles + 1 tiles, the others run_tiles; a run of t tiles forms FT + (t - 1) FT2 consecutive records, run 0 from window
    * index `origin` on */
   uint32_t origin, n_runs, run_tiles, run_extra;
+  /* MULTI (several blocks in one launch, bsc_blocks_records): this struct describes ONE SEGMENT — a block's head, main part or
+   * tail, always with first = 0, n = n_block, no context — and the launch runs the segments' runs one after another: */
+  uint32_t run0;    /* the segment's first run among the launch's */
+  uint32_t ref_off; /* where the block's reference codes start in the reference buffer */
+  uint32_t pos_off; /* index of the block's first position in the per-position arrays (records, second halves, dbSNP flags,
+                       depths): a multiple of 64 */
+  uint32_t bin0, bin_end; /* the block's bins in bin_off[]: [bin0, bin_end) */
+  uint32_t first_block, last_block; /* the launch's first block takes the context's CpG carry, its last one leaves it */
   int32_t all_positions;
   uint32_t reg_start, reg_stop;
   int32_t with_stats;
@@ -102,7 +110,7 @@ struct bsc_reads_args {
 struct bsc_chain_kargs {
   const uint32_t *cts;
   const uint8_t *ref;
-  uint8_t *core_out;
+  uint8_t *core_p; /* the records (the kernel's `core_out`) */
   const bsc_dev_tables *tb;
   bsc_chain_args a;
   double l, t, lrb, lrb1; /* 1 - under_conv, over_conv, log(ref_bias), log(0.5 (1 + ref_bias)): calc_gt_prob's scalars (host-computed) */
@@ -114,6 +122,10 @@ struct bsc_chain_kargs {
   unsigned long long *stat_words, *pair_cells, *ovf_list;
   uint8_t *aux_out;
   bsc_reads_args ra;
+  /* MULTI: the launch's segments and, segment by segment, their first runs (n_segs + 1 entries: the last = all runs) */
+  const bsc_chain_args *segs;
+  const uint32_t *seg_run0;
+  uint32_t n_segs;
 };
 typedef const __attribute__((address_space(4))) bsc_chain_kargs *bsc_kargs_p;
 #define K_COLD(f)                                                                    \
@@ -138,10 +150,10 @@ typedef const __attribute__((address_space(4))) bsc_chain_kargs *bsc_kargs_p;
   }                                                                                  \
   acc_reads R_;                                                                      \
   R_.rd = ra.rd;                                                                     \
-  R_.bin_off = ra.bin_off;                                                           \
+  R_.bin_off = ra.bin_off + (MULTI ? a.bin0 : 0u);                                   \
   R_.seq = ra.seq;                                                                   \
   R_.n_bins = ra.n_bins;                                                             \
-  R_.x = K.a.x;
+  R_.x = a.x;
 
 struct bsc_vcf_core_f {
   uint32_t pos;
@@ -347,14 +359,22 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
   if (a.with_stats) f_stats_update(h, F, stat_words);
 }
 
-template <bool FULL, bool READS>
+typedef const __attribute__((address_space(4))) uint32_t *f_cptr;
+
+template <bool FULL, bool READS, bool MULTI>
 __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_chain_kargs K) {
   const bsc_dev_tables *__restrict__ const tb = K.tb; /* the set-up below only */
-  const bsc_chain_args &a = K.a;
+  /* MULTI: the segment the wave's current run belongs to, in scalar registers (F_RUN_SETUP); until the first run the launch-wide
+   * members of the kernel's own copy (with_stats ...) */
+  bsc_chain_args a_m = K.a;
+  const bsc_chain_args &a = MULTI ? a_m : K.a;
+/* a member that differs from segment to segment (the others are the same in every segment and in K.a) */
+#define A_COLD(f) (MULTI ? a.f : K_COLD(a.f))
 /* the three arrays every tile touches: read from the argument segment where used, like the cold members */
 #define cts K_COLD(cts)
-#define ref K_COLD(ref)
-#define core_out K_COLD(core_out)
+#define ref (K_COLD(ref) + (MULTI ? a.ref_off : 0u))
+#define core_base K_COLD(core_p)
+#define core_out (K_COLD(core_p) + (MULTI ? (uint64_t)a.pos_off * 64u : 0ull))
   __shared__ __attribute__((aligned(16))) uint32_t lds_slot[FW][SLOT_DW];
   __shared__ double s_k[44], s_lnk[44], s_half[44], s_one[44];
   __shared__ double s_logtab[256];
@@ -402,42 +422,68 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   uint16_t *srf = s_rf[wid];
   uint16_t *spd = s_pend[wid];
   /* the reference codes the buffer holds: block indices [first - lr, min(n_block + 2, first + n + 2)) */
-  const int64_t ref_lo = (int64_t)a.first - a.lr;
-  const int64_t ref_hi = ((int64_t)a.first + a.n + 2 < (int64_t)a.n_block + 2) ? (int64_t)a.first + a.n + 2 : (int64_t)a.n_block + 2;
+  int64_t ref_lo, ref_hi;
+#define F_SEG_CONSTS()                                                                                                   \
+  do {                                                                                                                   \
+    ref_lo = (int64_t)a.first - a.lr;                                                                                    \
+    ref_hi = ((int64_t)a.first + a.n + 2 < (int64_t)a.n_block + 2) ? (int64_t)a.first + a.n + 2 : (int64_t)a.n_block + 2; \
+  } while (0)
+  F_SEG_CONSTS();
 
 /* the tile's 64 pile-ups (6 656 contiguous bytes, the first on a 16-byte boundary) -> the wave's slot by LDS-DMA */
 #define F_DMA_TILE(JW0, DMA)                                                                                            \
   do {                                                                                                                  \
-    const char *src_ = reinterpret_cast<const char *>(cts + (uint64_t)((int32_t)(JW0) + (int32_t)K_COLD(a.lc)) * IN_DW) + lane * 16; \
+    const char *src_ = reinterpret_cast<const char *>(cts + (uint64_t)((int32_t)(JW0) + (int32_t)A_COLD(lc)) * IN_DW) + lane * 16; \
     _Pragma("unroll") for (int j_ = 0; j_ < 6; j_++) DMA(src_ + j_ * 1024, slot + j_ * 256);                            \
     if (lane < 32) DMA(src_ + 6 * 1024, slot + 6 * 256);                                                                \
   } while (0)
   /* ---- the wave's runs: run k = wave index + a multiple of the number of waves; tile tj of a run starts 62 tj sites
    * after the run's first computed site (all wave-uniform, scalar registers) ---- */
   const uint32_t n_waves = gridDim.x * FW;
-  const uint32_t run_p = FT + (a.run_tiles - 1u) * FT2; /* records of a short run */
+  uint32_t run_p = FT + (a.run_tiles - 1u) * FT2; /* records of a short run */
+  const uint32_t n_runs_all = MULTI ? (uint32_t)((f_cptr)(uintptr_t)K_COLD(seg_run0))[K_COLD(n_segs)] : a.n_runs;
   uint32_t run = blockIdx.x * FW + wid, tj = 0, run_n = 0;
   int32_t run_s = 0; /* window index of the run's first record */
+  uint32_t acc_live = 0; /* READS: the reads from here on belong to other blocks (MULTI) / do not exist */
+  /* MULTI: the segment of run k — the last one whose first run is not behind k (binary search in the launch's table) — member by
+   * member into the scalar registers (a struct cannot be copied out of the constant address space as a whole) */
+#define F_SEG_LOAD(k)                                                                                           \
+  do {                                                                                                          \
+    const f_cptr r0_ = (f_cptr)(uintptr_t)K_COLD(seg_run0);                                                     \
+    uint32_t lo_ = 0, hi_ = K_COLD(n_segs);                                                                     \
+    while (hi_ - lo_ > 1u) {                                                                                    \
+      const uint32_t mid_ = (lo_ + hi_) >> 1;                                                                   \
+      if (r0_[mid_] <= (k)) lo_ = mid_;                                                                         \
+      else hi_ = mid_;                                                                                          \
+    }                                                                                                           \
+    const f_cptr g_ = (f_cptr)(uintptr_t)(K_COLD(segs) + lo_);                                                  \
+    uint32_t *d_ = reinterpret_cast<uint32_t *>(&a_m);                                                          \
+    _Pragma("unroll") for (unsigned i_ = 0; i_ < sizeof(bsc_chain_args) / 4u; i_++) d_[i_] = g_[i_];             \
+    F_SEG_CONSTS();                                                                                             \
+    run_p = FT + (a.run_tiles - 1u) * FT2;                                                                      \
+    if (READS) acc_live = ((f_cptr)(uintptr_t)K_COLD(ra.bin_off))[a.bin_end];                                   \
+  } while (0)
 #define F_RUN_SETUP(k)                                                                                          \
   do {                                                                                                          \
-    const uint32_t k_ = (k), ex_ = a.run_extra;                                                         \
+    if (MULTI) F_SEG_LOAD(k);                                                                                   \
+    const uint32_t k_ = (k) - (MULTI ? a.run0 : 0u), ex_ = a.run_extra;                                         \
     run_n = a.run_tiles + (k_ < ex_ ? 1u : 0u);                                                                 \
-    run_s = (int32_t)(a.origin + k_ * run_p + FT2 * (k_ < ex_ ? k_ : ex_));                              \
+    run_s = (int32_t)(a.origin + k_ * run_p + FT2 * (k_ < ex_ ? k_ : ex_));                                     \
   } while (0)
-  if (run < a.n_runs) F_RUN_SETUP(run);
+  if (run < n_runs_all) F_RUN_SETUP(run);
   /* heterozygous calls waiting for Fisher's test (window index | max_gt << 28): the wave's own list in HBM, one in ~1 000
    * positions; a.het_cap entries (F_HET_CAP), tested whenever fewer than 64 are free (the epochs below) */
 #define F_WL() (K_COLD(het_list) + (uint64_t)(blockIdx.x * FW + wid) * K_COLD(a.het_cap) * (READS ? F_HET_DW : 1u))
   unsigned n_pend = 0; /* wave-uniform */
   unsigned inexact = 0;
-  uint32_t acc_span = 0, acc_live = 0; /* READS: the block's longest read extent and its number of live reads */
+  uint32_t acc_span = 0; /* READS: the longest read extent of the launch's blocks */
   if (READS) {
     K_LOAD_RA(ra);
     acc_span = (uint32_t)K_COLD(counters)[BSC_CNT_SPAN];
-    acc_live = ra.bin_off[ra.n_bins];
+    if (!MULTI) acc_live = ra.bin_off[ra.n_bins];
   }
 #ifndef BSC_CHAIN_NO_PREFETCH
-  if (FULL && !READS && run < a.n_runs) { /* the wave's first tile; every later one is requested while its predecessor's statistics run */
+  if (FULL && !READS && run < n_runs_all) { /* the wave's first tile; every later one is requested while its predecessor's statistics run */
     const unsigned lane = lane0;
     F_DMA_TILE(run_s - 2, dma16);
   }
@@ -450,7 +496,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   const uint32_t het_room = K_COLD(a.het_cap) - 64u;
   for (;;) {
   n_pend = 0;
-  while (run < a.n_runs && n_pend <= het_room) {
+  while (run < n_runs_all && n_pend <= het_room) {
     /* the lane number, made opaque once per tile: otherwise every lane-dependent address of the loop body is hoisted
      * out of it, kept alive across the whole kernel and — at 128 VGPRs — spilled to scratch (a vector-memory round trip
      * per use instead of one VALU instruction) */
@@ -460,9 +506,9 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     const int32_t jw0 = run_s + (int32_t)(tj * FT2) - 2;  /* window-relative index of the site lane 0 computes */
     /* the wave's next tile (the next of the run, or the first of its next run), if any */
     const bool last_of_run = tj + 1u == run_n;
-    const bool have_next = !last_of_run || run + n_waves < a.n_runs;
+    const bool have_next = !last_of_run || run + n_waves < n_runs_all;
     int32_t jw0_next = jw0 + (int32_t)FT2;
-    if (last_of_run && have_next) {
+    if (!MULTI && last_of_run && have_next) { /* (only the pile-up-in form looks a tile ahead, and that one is never MULTI) */
       const uint32_t k_ = run + n_waves, ex_ = a.run_extra;
       jw0_next = (int32_t)(a.origin + k_ * run_p + FT2 * (k_ < ex_ ? k_ : ex_)) - 2;
     }
@@ -579,7 +625,8 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
             }
           }
           uint4 *e = reinterpret_cast<uint4 *>(F_WL() + (uint64_t)(n_pend + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) * F_HET_DW);
-          e[0] = make_uint4((uint32_t)jw | ((uint32_t)mxi << 28), f[0], f[1], f[2]);
+          /* MULTI: the index among the launch's positions (the pass after the loop knows nothing of blocks) */
+          e[0] = make_uint4((uint32_t)(jw + (int32_t)(MULTI ? a.pos_off : 0u)) | ((uint32_t)mxi << 28), f[0], f[1], f[2]);
           e[1] = make_uint4(f[3], f[4], f[5], f[6]);
           e[2] = make_uint4(f[7], cnt[0], cnt[1], cnt[2]);
           e[3] = make_uint4(cnt[3], cnt[4], cnt[5], cnt[6]);
@@ -665,7 +712,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       }
       const int rfix = (int)(rr[2] & 0xffu);
       const uint8_t *const dbsnp = K_COLD(dbsnp);
-      const uint32_t rs_found = (dbsnp && inner) ? (uint32_t)dbsnp[jw] : 0u;
+      const uint32_t rs_found = (dbsnp && inner) ? (uint32_t)dbsnp[jw + (int32_t)(MULTI ? a.pos_off : 0u)] : 0u;
       int ga, gb;
       f_alleles(gt, ga, gb);
       const bool het = ga != gb;
@@ -770,7 +817,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     const uint32_t depth_off = K_COLD(a.depth_off);
     if (depth_off && inner) { /* total depth of every position that reached the printer (the key of gt_cov_stats) */
       const uint32_t dpt = dp1 + d_inf;
-      reinterpret_cast<uint16_t *>(K_COLD(het_list) + depth_off)[jw] = (uint16_t)(od[0] ? (dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u) : 0u);
+      reinterpret_cast<uint16_t *>(K_COLD(het_list) + depth_off)[jw + (int32_t)(MULTI ? a.pos_off : 0u)] = (uint16_t)(od[0] ? (dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u) : 0u);
     }
     WAVE_LDS_SYNC();
     /* ---- results: the tile's 60 records, staged in the slot (every la[] read is done: the sync above), leave
@@ -784,7 +831,9 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       }
       WAVE_LDS_SYNC();
       const uint32_t i0 = (uint32_t)(jw0 + (int32_t)f0); /* window index of the tile's first record */
-      const uint32_t an_ = FULL ? 0u : K_COLD(a.n);
+      /* MULTI: a block's records end where the next block's begin, on a multiple of 64 — the positions between are written as
+       * what they are, no record (the packing pass reads every position of the launch) */
+      const uint32_t an_ = FULL ? 0u : (MULTI ? (a.n + 63u) & ~63u : K_COLD(a.n));
       const uint32_t nrec = FULL ? 62u - f0 : (i0 < an_ ? (an_ - i0 < 62u - f0 ? an_ - i0 : 62u - f0) : 0u);
       const uint32_t nvec = nrec * 4u;
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -800,7 +849,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         WAVE_LDS_SYNC();
         if (lane >= f0 && lane < 62u) {
           const uint8_t *const dbs = K_COLD(dbsnp);
-          const uint32_t rsf = (dbs && inner) ? (uint32_t)dbs[jw] : 0u;
+          const uint32_t rsf = (dbs && inner) ? (uint32_t)dbs[jw + (int32_t)(MULTI ? a.pos_off : 0u)] : 0u;
           const bool hasrec = od[0] != 0u;
           so[(lane - f0) * 4u + 0] = hasrec ? make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]) : make_uint4(0u, 0u, 0u, 0u);
           so[(lane - f0) * 4u + 1] = hasrec ? make_uint4(cnt[4], cnt[5], cnt[6], cnt[7]) : make_uint4(0u, 0u, 0u, 0u);
@@ -808,7 +857,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
           so[(lane - f0) * 4u + 3] = hasrec ? make_uint4((uint32_t)mxi | (rsf << 8), 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
         }
         WAVE_LDS_SYNC();
-        u32x4 *dsta = reinterpret_cast<u32x4 *>(aux_out + (uint64_t)i0 * 64u);
+        u32x4 *dsta = reinterpret_cast<u32x4 *>(aux_out + ((uint64_t)i0 + (MULTI ? a.pos_off : 0u)) * 64u);
 #pragma unroll
         for (unsigned k = 0; k < 4; k++) {
           const unsigned idx = k * 64u + lane;
@@ -877,10 +926,12 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
           if (minus_cg && st_cpg) { /* does the record just before complete a CpG? (:198-205) */
             bool p_ok;
             uint32_t p_flt;
-            if (jw == 0 && K_COLD(a.lc) == 0) { /* first position of a block: the previous block's pending cytosine, if adjacent */
+            if (jw == 0 && A_COLD(lc) == 0) { /* first position of a block: the previous block's pending cytosine, if adjacent */
               const uint32_t *const carry_in = K_COLD(carry_in);
               const uint32_t p_pos = carry_in[0];
-              p_ok = p_pos != 0 && st_pos - p_pos == 1u;
+              /* MULTI: only the launch's first block follows something — the host starts a new launch at a block that begins
+               * right behind its predecessor's last position */
+              p_ok = p_pos != 0 && st_pos - p_pos == 1u && (!MULTI || a.first_block);
               p_flt = carry_in[1];
             } else {
               const uint32_t pw = spd[1u + lane]; /* the site to the left: the previous lane's, or (lane 0) the carried one */
@@ -930,7 +981,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         }
       }
       /* the window's last position is the pending cytosine, or not, for whatever follows */
-      if (jw == (int32_t)K_COLD(a.n) - 1 && lane >= f0 && lane < 62u) {
+      if (jw == (int32_t)A_COLD(n) - 1 && lane >= f0 && lane < 62u && (!MULTI || a.last_block)) {
         uint32_t *const carry_out = K_COLD(carry_out);
         carry_out[0] = pend ? pos0 + lane : 0u;
         carry_out[1] = pend ? flt : 0u;
@@ -947,7 +998,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     if (++tj == run_n) {
       tj = 0;
       run += n_waves;
-      if (run < a.n_runs) F_RUN_SETUP(run);
+      if (run < n_runs_all) F_RUN_SETUP(run);
     }
   }
 
@@ -964,14 +1015,15 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       const unsigned nb = n_pend - k0 < 64u ? n_pend - k0 : 64u;
       const uint32_t *ent = wl + (uint64_t)(k0 + lane0) * (READS ? F_HET_DW : 1u);
       const uint32_t e = lane0 < nb ? __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      f_fisher_pending<READS>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_out, s_lf, s_logtab, s_exptab, h, stat_words);
+      f_fisher_pending<READS>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_base, s_lf, s_logtab, s_exptab, h, stat_words);
     }
   }
-  if (run >= a.n_runs) break; /* wave-uniform */
+  if (run >= n_runs_all) break; /* wave-uniform */
   } /* epochs */
 #undef cts
 #undef ref
 #undef core_out
+#undef core_base
   unsigned long long *const counters = K_COLD(counters);
   unsigned long long *const stat_words = K_COLD(stat_words);
   if (READS && __any(inexact)) { /* positions whose quality / MAPQ^2 sums left the exact-float range (accumulate.hip) */
@@ -1047,74 +1099,69 @@ extern "C" size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_dept
 /* bytes of the reads-in form's forward-count scratch lines (64 x 8 dwords per resident wave) */
 extern "C" size_t bsc_dev_chain_scratch_bytes(int num_cus) { return (size_t)num_cus * FW * 64u * 8u * sizeof(uint32_t); }
 
+/*
+ * A block's (or window's) records [0, n) in three parts.  HEAD: without two sites of context in front (lc < 2: the block starts
+ * here) the first tile's left halo lies outside the buffers / the block — one guarded tile, records [0, 60).  MAIN: runs of
+ * complete tiles (all 64 computed sites exist, so the kernel instance without bounds checks runs them); its last computed site
+ * is the one after its last record's right neighbour: main_end + 1 <= n + rc - 1.  TAIL: what is left, under 64 + 62 records,
+ * guarded tiles.  The pile-up-in form also needs each tile's first pile-up on a 16-byte boundary for the LDS-DMA ((window
+ * index + lc) * 104 bytes: lc even, every run and tile start even); failing that (`aligned` = false) everything is guarded.
+ * `waves`: the waves this block may count on (all resident ones, or its share of them in a launch of several blocks).
+ */
+struct chain_plan {
+  uint32_t head, m_runs, m_tiles, m_extra, m_len;
+};
+static chain_plan chain_plan_block(uint32_t n, uint32_t lc, uint32_t rc, bool aligned, uint64_t waves) {
+  chain_plan p = {0u, 0u, 1u, 0u, 0u};
+  p.head = lc == 2u ? 0u : (n < (uint32_t)FT ? n : (uint32_t)FT);
+  const int64_t avail = (int64_t)n + rc - 2 - p.head;
+  if (!((p.head == 0u || p.head == (uint32_t)FT) && avail >= FT && aligned)) {
+    p.head = 0;
+    return p;
+  }
+  static int run_cap = 0;
+  if (!run_cap) {
+    const char *e = getenv("BSC_CHAIN_RUN_CAP");
+    run_cap = e && atoi(e) > 0 ? atoi(e) : BSC_RUN_CAP;
+  }
+  if (waves < 1) waves = 1;
+  const uint64_t tiles_all = ((uint64_t)avail + FT2 - 1) / FT2;                   /* about what the block needs */
+  const uint64_t per_wave = (tiles_all + waves - 1) / waves;                      /* tiles a wave gets */
+  const uint64_t rounds = (per_wave + (uint64_t)run_cap - 1) / (uint64_t)run_cap; /* runs a wave gets */
+  uint64_t nr = rounds * waves;
+  if (nr > (uint64_t)avail / FT) nr = (uint64_t)avail / FT;                       /* every run has a first tile of 60 records */
+  const uint64_t more = ((uint64_t)avail - nr * FT) / FT2;                        /* further tiles, 62 records each */
+  p.m_runs = (uint32_t)nr;
+  p.m_tiles = 1u + (uint32_t)(more / nr);
+  p.m_extra = (uint32_t)(more % nr);
+  p.m_len = (uint32_t)(nr * FT + more * FT2);
+  return p;
+}
+
+/* the members of the kernel's argument that do not depend on the block */
 template <bool READS>
-static int chain_launch_t(const bsc_chain_launch *L) {
-  hipStream_t s = (hipStream_t)L->stream;
-  bsc_chain_args a;
-  a.x = L->x;
-  a.n_block = L->n_block;
-  a.first = L->first;
-  a.n = L->n;
-  a.lc = L->lc;
-  a.rc = L->rc;
-  a.lr = L->lr;
+static void chain_common(const bsc_chain_launch *L, uint32_t n_all, bsc_chain_kargs &K, bool &gc) {
+  bsc_chain_args &a = K.a;
+  memset(&K, 0, sizeof K);
   a.all_positions = L->all_positions;
   a.reg_start = L->reg_start;
   a.reg_stop = L->reg_stop;
   a.with_stats = L->with_stats;
   a.ovf_cap = L->ovf_cap;
-  const bool gc = L->with_stats && L->gc_bins && L->gc_table;
-  a.depth_off = gc ? (uint32_t)(bsc_dev_chain_het_bytes(L->n, L->num_cus, 0, READS) / sizeof(uint32_t)) : 0u;
-  bsc_reads_args ra;
-  memset(&ra, 0, sizeof ra);
+  a.het_cap = F_HET_CAP;
+  gc = L->with_stats && L->gc_bins && L->gc_table;
+  a.depth_off = gc ? (uint32_t)(bsc_dev_chain_het_bytes(n_all, L->num_cus, 0, READS) / sizeof(uint32_t)) : 0u;
   if (READS) {
-    ra.rd = (const bsc_read_desc *)L->rd;
-    ra.bin_off = (const uint32_t *)L->bin_off;
-    ra.seq = (const uint8_t *)L->seq;
-    ra.f_scratch = (uint32_t *)L->f_scratch;
-    ra.n_bins = L->n_bins;
-    ra.min_qual = L->min_qual;
+    K.ra.rd = (const bsc_read_desc *)L->rd;
+    K.ra.bin_off = (const uint32_t *)L->bin_off;
+    K.ra.seq = (const uint8_t *)L->seq;
+    K.ra.f_scratch = (uint32_t *)L->f_scratch;
+    K.ra.n_bins = L->n_bins;
+    K.ra.min_qual = L->min_qual;
   }
-  /*
-   * The window's records [0, n) in three parts.  HEAD: without two sites of context in front (lc < 2: the block starts here)
-   * the first tile's left halo lies outside the buffers / the block — one guarded tile, records [0, 60).  MAIN: runs of
-   * complete tiles (all 64 computed sites exist, so the kernel instance without bounds checks runs them); its last computed
-   * site is the one after its last record's right neighbour: main_end + 1 <= n + rc - 1.  TAIL: what is left, under 64 + 62
-   * records, guarded tiles.  The pile-up-in form also needs each tile's first pile-up on a 16-byte boundary for the LDS-DMA
-   * ((window index + lc) * 104 bytes: lc even, every run and tile start even); failing that everything is guarded.
-   */
-  const unsigned waves = (unsigned)L->num_cus * FW;
-  uint32_t head = L->lc == 2u ? 0u : (L->n < (uint32_t)FT ? L->n : (uint32_t)FT);
-  const int64_t avail = (int64_t)L->n + L->rc - 2 - head;
-  uint32_t m_runs = 0, m_tiles = 1, m_extra = 0, m_len = 0;
-  const bool main_ok = (head == 0u || head == (uint32_t)FT) && avail >= FT &&
-                       (READS || (!(L->lc & 1u) && !((uintptr_t)L->cts & 15u)));
-  if (main_ok) {
-    static int run_cap = 0;
-    if (!run_cap) {
-      const char *e = getenv("BSC_CHAIN_RUN_CAP");
-      run_cap = e && atoi(e) > 0 ? atoi(e) : BSC_RUN_CAP;
-    }
-    const uint64_t tiles_all = ((uint64_t)avail + FT2 - 1) / FT2;           /* about what the window needs */
-    const uint64_t per_wave = (tiles_all + waves - 1) / waves;              /* tiles a wave gets */
-    const uint64_t rounds = (per_wave + (uint64_t)run_cap - 1) / (uint64_t)run_cap; /* runs a wave gets */
-    uint64_t nr = rounds * waves;
-    if (nr > (uint64_t)avail / FT) nr = (uint64_t)avail / FT;               /* every run has a first tile of 60 records */
-    const uint64_t more = ((uint64_t)avail - nr * FT) / FT2;                /* further tiles, 62 records each */
-    m_runs = (uint32_t)nr;
-    m_tiles = 1u + (uint32_t)(more / nr);
-    m_extra = (uint32_t)(more % nr);
-    m_len = (uint32_t)(nr * FT + more * FT2);
-  } else {
-    head = 0;
-  }
-  unsigned long long *words = (unsigned long long *)L->stats;
-  if (L->ev_start) (void)hipEventRecord((hipEvent_t)L->ev_start, s);
-  bsc_chain_kargs K;
-  memset(&K, 0, sizeof K);
   K.cts = (const uint32_t *)L->cts;
   K.ref = (const uint8_t *)L->ref;
-  K.core_out = (uint8_t *)L->core_out;
+  K.core_p = (uint8_t *)L->core_out;
   K.tb = (const bsc_dev_tables *)L->tb;
   K.l = L->par_l;
   K.t = L->par_t;
@@ -1125,26 +1172,42 @@ static int chain_launch_t(const bsc_chain_launch *L) {
   K.counters = (unsigned long long *)L->counters;
   K.carry_in = (const uint32_t *)L->carry_in;
   K.carry_out = (uint32_t *)L->carry_out;
-  K.stat_words = words;
+  K.stat_words = (unsigned long long *)L->stats;
   K.pair_cells = (unsigned long long *)L->pairs;
   K.ovf_list = (unsigned long long *)L->ovf_list;
   K.aux_out = (uint8_t *)L->aux_out;
-  K.ra = ra;
-#define CHAIN_ARGS(A) (K.a = (A), K)
-  if (m_runs) {
-    a.origin = head;
-    a.n_runs = m_runs;
-    a.run_tiles = m_tiles;
-    a.run_extra = m_extra;
-    unsigned grid = (m_runs + FW - 1) / FW;
+}
+
+template <bool READS>
+static int chain_launch_t(const bsc_chain_launch *L) {
+  hipStream_t s = (hipStream_t)L->stream;
+  bsc_chain_kargs K;
+  bool gc;
+  chain_common<READS>(L, L->n, K, gc);
+  bsc_chain_args &a = K.a;
+  a.x = L->x;
+  a.n_block = L->n_block;
+  a.first = L->first;
+  a.n = L->n;
+  a.lc = L->lc;
+  a.rc = L->rc;
+  a.lr = L->lr;
+  const chain_plan p = chain_plan_block(L->n, L->lc, L->rc, READS || (!(L->lc & 1u) && !((uintptr_t)L->cts & 15u)),
+                                        (uint64_t)L->num_cus * FW);
+  if (L->ev_start) (void)hipEventRecord((hipEvent_t)L->ev_start, s);
+  if (p.m_runs) {
+    a.origin = p.head;
+    a.n_runs = p.m_runs;
+    a.run_tiles = p.m_tiles;
+    a.run_extra = p.m_extra;
+    unsigned grid = (p.m_runs + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus; /* one 1024-thread workgroup per CU, persistent */
-    a.het_cap = chain_het_cap(m_runs, grid);
-    hipLaunchKernelGGL((bsc_chain_kernel_t<true, READS>), dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
+    hipLaunchKernelGGL((bsc_chain_kernel_t<true, READS, false>), dim3(grid), dim3(64 * FW), 0, s, K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
   /* guarded tiles, one per run: the head, then everything behind the main part */
-  const uint32_t edge[2][2] = {{0u, head}, {head + m_len, L->n}};
+  const uint32_t edge[2][2] = {{0u, p.head}, {p.head + p.m_len, L->n}};
   for (int k = 0; k < 2; k++) {
     if (edge[k][1] <= edge[k][0]) continue;
     a.origin = edge[k][0];
@@ -1153,12 +1216,10 @@ static int chain_launch_t(const bsc_chain_launch *L) {
     a.run_extra = 0;
     unsigned grid = (a.n_runs + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
-    a.het_cap = chain_het_cap(a.n_runs, grid);
-    hipLaunchKernelGGL((bsc_chain_kernel_t<false, READS>), dim3(grid), dim3(64 * FW), 0, s, CHAIN_ARGS(a));
+    hipLaunchKernelGGL((bsc_chain_kernel_t<false, READS, false>), dim3(grid), dim3(64 * FW), 0, s, K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
-#undef CHAIN_ARGS
   if (gc) { /* the window's positions into the GC-by-coverage table */
     unsigned grid = (L->n + 1023u) / 1024u;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
@@ -1169,6 +1230,110 @@ static int chain_launch_t(const bsc_chain_launch *L) {
   hipError_t e = hipGetLastError();
   if (L->ev_stop) (void)hipEventRecord((hipEvent_t)L->ev_stop, s);
   return (int)e;
+}
+
+/*
+ * Several whole blocks in one launch sequence (bsc_blocks_records): blk[b_first .. b_last] — reads-in form only.  Every block
+ * is cut as above, its share of the waves in proportion to its size; the main parts of all blocks become the segments of ONE
+ * launch of the unguarded kernel, their heads and tails the segments of ONE launch of the guarded one.  The segment tables are
+ * put together in tab_h (pinned, from byte *cursor on; 8-byte aligned), copied to the same offset of tab_d and read by the
+ * kernels through the scalar cache.  L->n = the positions of ALL the call's blocks (what the depth array is sized for).
+ */
+extern "C" size_t bsc_dev_chain_multi_table_bytes(uint32_t n_blocks) {
+  /* per block at most 1 main + 2 edge segments and as many run0 entries, + 2 closing run0 entries per launch group (<= n_blocks) */
+  return (size_t)n_blocks * (3u * sizeof(bsc_chain_args) + 5u * sizeof(uint32_t) + 16u) + 64u;
+}
+
+extern "C" int bsc_dev_launch_chain_multi(const bsc_chain_launch *L, const bsc_chain_mblock *blk, uint32_t b_first, uint32_t b_last,
+                                          void *tab_h, void *tab_d, size_t *cursor) {
+  hipStream_t s = (hipStream_t)L->stream;
+  bsc_chain_kargs K;
+  bool gc;
+  chain_common<true>(L, L->n, K, gc);
+  const uint32_t nb = b_last - b_first + 1u;
+  const uint64_t waves = (uint64_t)L->num_cus * FW;
+  uint64_t tiles_all = 0;
+  for (uint32_t b = b_first; b <= b_last; b++) tiles_all += (blk[b].n + FT2 - 1) / FT2;
+  /* table space: [main segments][edge segments][main run0 (+1)][edge run0 (+1)] */
+  char *const base = (char *)tab_h + *cursor;
+  bsc_chain_args *const seg_m = (bsc_chain_args *)base, *const seg_e = seg_m + nb;
+  uint32_t *const run_m = (uint32_t *)(seg_e + 2u * nb), *const run_e = run_m + (nb + 1u);
+  const size_t bytes = (((size_t)((char *)(run_e + 2u * nb + 1u) - base)) + 7u) & ~(size_t)7u;
+  uint32_t n_m = 0, n_e = 0, runs_m = 0, runs_e = 0;
+  for (uint32_t b = b_first; b <= b_last; b++) {
+    const bsc_chain_mblock &B = blk[b];
+    bsc_chain_args a = K.a; /* the launch-wide members */
+    a.x = B.x;
+    a.n_block = a.n = B.n;
+    a.first = a.lc = a.rc = a.lr = 0;
+    a.ref_off = B.ref_off;
+    a.pos_off = B.pos_off;
+    a.bin0 = B.bin0;
+    a.bin_end = B.bin_end;
+    a.first_block = b == b_first;
+    a.last_block = b == b_last;
+    /* the block's share of the waves, in proportion to its tiles */
+    const uint64_t share = tiles_all ? (waves * ((B.n + FT2 - 1) / FT2) + tiles_all - 1) / tiles_all : waves;
+    const chain_plan p = chain_plan_block(B.n, 0u, 0u, true, share);
+    if (p.m_runs) {
+      a.origin = p.head;
+      a.n_runs = p.m_runs;
+      a.run_tiles = p.m_tiles;
+      a.run_extra = p.m_extra;
+      a.run0 = runs_m;
+      run_m[n_m] = runs_m;
+      seg_m[n_m++] = a;
+      runs_m += p.m_runs;
+    }
+    /* guarded: the head, and everything behind the main part up to the next multiple of 64 positions (where the next block's
+     * records begin: the positions between get records that say "none") */
+    const uint32_t n_pad = (B.n + 63u) & ~63u;
+    const uint32_t edge[2][2] = {{0u, p.head}, {p.head + p.m_len, n_pad}};
+    for (int k = 0; k < 2; k++) {
+      if (edge[k][1] <= edge[k][0]) continue;
+      a.origin = edge[k][0];
+      a.n_runs = (edge[k][1] - edge[k][0] + FT - 1) / FT;
+      a.run_tiles = 1;
+      a.run_extra = 0;
+      a.run0 = runs_e;
+      run_e[n_e] = runs_e;
+      seg_e[n_e++] = a;
+      runs_e += a.n_runs;
+    }
+  }
+  run_m[n_m] = runs_m;
+  run_e[n_e] = runs_e;
+  hipError_t e = hipMemcpyAsync((char *)tab_d + *cursor, base, bytes, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return (int)e;
+  const char *const dbase = (const char *)tab_d + *cursor;
+  *cursor += bytes;
+  if (n_m) {
+    K.segs = (const bsc_chain_args *)dbase;
+    K.seg_run0 = (const uint32_t *)(dbase + ((const char *)run_m - base));
+    K.n_segs = n_m;
+    unsigned grid = (runs_m + FW - 1) / FW;
+    if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
+    hipLaunchKernelGGL((bsc_chain_kernel_t<true, true, true>), dim3(grid), dim3(64 * FW), 0, s, K);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  }
+  if (n_e) {
+    K.segs = (const bsc_chain_args *)(dbase + ((const char *)seg_e - base));
+    K.seg_run0 = (const uint32_t *)(dbase + ((const char *)run_e - base));
+    K.n_segs = n_e;
+    unsigned grid = (runs_e + FW - 1) / FW;
+    if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
+    hipLaunchKernelGGL((bsc_chain_kernel_t<false, true, true>), dim3(grid), dim3(64 * FW), 0, s, K);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  }
+  if (gc) /* block by block: the table is keyed by genome position */
+    for (uint32_t b = b_first; b <= b_last; b++) {
+      unsigned grid = (blk[b].n + 1023u) / 1024u;
+      if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
+      hipLaunchKernelGGL(bsc_gc_cov_kernel, dim3(grid), dim3(1024), 0, s,
+                         reinterpret_cast<const uint16_t *>((const uint32_t *)L->het_list + K.a.depth_off) + blk[b].pos_off, blk[b].n,
+                         blk[b].x, (const uint8_t *)L->gc_bins, L->gc_n_bins, L->gc_start_pos, (unsigned long long *)L->gc_table);
+    }
+  return (int)hipGetLastError();
 }
 
 extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {

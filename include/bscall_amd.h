@@ -303,6 +303,40 @@ int bsc_block_records_submit_inplace(bsc_context *ctx, const bsc_template *tpl, 
                                      int with_stats, bsc_vcf_rec *out, uint64_t out_cap);
 int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out);
 
+/*
+ * Several blocks in ONE launch sequence.  The reference calls call_genotypes_ML once per maximal run of overlapping templates
+ * (src/get_template_vector.c:141-147: 10^2 .. 10^7 positions a call) and its calc threads cost nothing to start; a GPU block
+ * costs a dozen launches, four copies and a wait whatever its size, which a 10 000-position block does not repay.  A host that
+ * holds blocks back (integration/call_genotypes_amd_overlap.c: until 1 M positions are pending, a contig ends or the run does)
+ * hands them over together: one upload, one grouping pass over all their reads, the reads-in chain over all their tiles, one
+ * packing pass, one copy-out, one wait.  Every block is still a block of its own — its printer state flushed at its end
+ * (src/print_vcf.c:529-546), its first two and last two positions without the neighbours' context — so the records and the
+ * statistics are those of bsc_block_records called on the blocks one after another, in order.
+ *   blocks[n_blocks]  x .. y and the number of templates of every block, in the order their records are wanted (genome order
+ *                     on one contig: the CpG pairing across blocks, src/print_vcf.c:447-455, follows this order)
+ *   tpl, seq          the templates of all blocks, block after block (off[] index the one read buffer `seq`)
+ *   ref               the blocks' reference codes one block after another: y - x + 3 codes each (x .. y + 2)
+ *   dbsnp             NULL, or rs_found per position, block after block (y - x + 1 each)
+ *   out[out_cap]      the written records of all blocks, block after block; block_counts[n_blocks] (optional) = how many each
+ *                     block wrote
+ * At most 2^28 - 1 positions (each block rounded up to a multiple of 64) and 65 536 blocks a call.  Errors as
+ * bsc_block_records (a bad template is named by its index among the call's templates); one call in flight per context,
+ * shared with the single-block entries.  The inputs are copied to the pinned staging area: the caller's buffers are free when
+ * submit returns; `out` must stay valid until the fetch.
+ */
+typedef struct {
+  uint32_t x, y; /* first and last position of the block */
+  uint32_t nr;   /* its templates: the next nr of tpl[] */
+  uint32_t _pad;
+} bsc_block_desc;
+int bsc_blocks_records_submit(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl,
+                              const uint8_t *seq, uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp,
+                              const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap);
+int bsc_blocks_records_fetch(bsc_context *ctx, uint64_t *n_out, uint64_t *block_counts);
+int bsc_blocks_records(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                       uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                       bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out, uint64_t *block_counts);
+
 /* bsc_vcf_format for a packed record. */
 int bsc_vcf_format_rec(const bsc_vcf_rec *r, const char *contig, const char *id, char *buf, size_t cap);
 
