@@ -37,6 +37,7 @@ EXPORTS = (
     "bsc_block_records_submit_inplace",
     "bsc_block_records_fetch",
     "bsc_blocks_records_submit",
+    "bsc_blocks_records_submit_inplace",
     "bsc_blocks_records_fetch",
     "bsc_blocks_records",
     "bsc_vcf_stats",
@@ -376,6 +377,8 @@ def load():
     L.bsc_block_records_fetch.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.bsc_blocks_records_submit.restype = i32
     L.bsc_blocks_records_submit.argtypes = [vp, vp, u32, vp, vp, u64, vp, vp, vp, i32, vp, u64]
+    L.bsc_blocks_records_submit_inplace.restype = i32
+    L.bsc_blocks_records_submit_inplace.argtypes = [vp, vp, u32, vp, vp, u64, vp, vp, vp, i32, vp, u64]
     L.bsc_blocks_records_fetch.restype = i32
     L.bsc_blocks_records_fetch.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.bsc_blocks_records.restype = i32

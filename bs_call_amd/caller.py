@@ -306,6 +306,20 @@ class SiteCaller:
         self._pending_blocks = (out, len(desc))
         return None if submit_only else self.blocks_records_fetch()
 
+    def blocks_records_joined(self, desc, tpl, seq, ref, out, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None,
+                              with_stats=False, inplace=False, submit_only=False):
+        """bsc_blocks_records_submit[_inplace] on arrays that are already joined as the C ABI wants them (what a C host that
+        flattens its blocks into one set of buffers holds): desc BLOCK_DESC[n_blocks], tpl TEMPLATE[sum nr] with off[] into `seq`,
+        ref = the blocks' y - x + 3 codes one block after another.  inplace: no staging copy (the arrays — page-locked ones from
+        PinnedBuffer make the upload a DMA — must stay unchanged until the fetch)."""
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        fn = self._L.bsc_blocks_records_submit_inplace if inplace else self._L.bsc_blocks_records_submit
+        _check(fn(self._h, _ptr(desc), len(desc), _ptr(tpl), _ptr(seq), seq.size, _ptr(ref), None if dbsnp is None else _ptr(dbsnp),
+                  C.byref(p), 1 if with_stats else 0, _ptr(out), len(out)))
+        self._pending_blocks = (out, len(desc))
+        self._pending_in = (desc, tpl, seq, ref, dbsnp)
+        return None if submit_only else self.blocks_records_fetch()
+
     def blocks_records_fetch(self):
         out, nb = getattr(self, "_pending_blocks", None) or (None, 0)
         if out is None:

@@ -1316,7 +1316,7 @@ int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out) {
  */
 static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
                             uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
-                            bsc_vcf_rec *out, uint64_t out_cap) {
+                            bsc_vcf_rec *out, uint64_t out_cap, int stage) {
   if (ctx->pending_sz || ctx->rec_pending)
     return bsc_fail(BSC_ERR_ARG, "a submitted block has not been fetched (bsc_block_fetch / bsc_block_records_fetch first)");
   if (n_blocks == 0 || n_blocks > 65536u) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records: n_blocks must be 1 .. 65536, got %u", n_blocks);
@@ -1352,21 +1352,28 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
   if ((rc = bsc_reserve(&ctx->d_mtab, &ctx->cap_mtab, tab_bytes))) return rc;
   if (!ctx->h_cnt && hipHostMalloc((void **)&ctx->h_cnt, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
     return bsc_fail(BSC_ERR_NOMEM, "bsc_blocks_records: pinned counter block");
-  /* the pinned staging area: inputs (the caller's buffers are free when the call returns), the tables, and the per-tile record
+  /* the pinned staging area: inputs (stage != 0: the caller's buffers are free when the call returns; 0: templates, reads and
+   * reference codes are read where they lie), the dbSNP flags in the device's padded layout, the tables, and the per-tile record
    * offsets on their way back */
-  const size_t b_tpl = (size_t)nr * sizeof(bsc_template), b_seq = (size_t)seq_bytes, b_db = dbsnp ? (size_t)P : 0;
+  const size_t b_tpl = stage ? (size_t)nr * sizeof(bsc_template) : 0, b_seq = stage ? (size_t)seq_bytes : 0, b_ref = stage ? (size_t)ref64 : 0,
+               b_db = dbsnp ? (size_t)P : 0;
   const size_t b_blk = (size_t)n_blocks * sizeof(bsc_chain_mblock), b_toff = ((size_t)(P >> 6) + 1u) * 4u;
 #define AL64(v) (((v) + 63u) & ~(size_t)63u)
-  const size_t o_seq = AL64(b_tpl), o_ref = AL64(o_seq + b_seq), o_db = AL64(o_ref + (size_t)ref64), o_blk = AL64(o_db + b_db),
+  const size_t o_seq = AL64(b_tpl), o_ref = AL64(o_seq + b_seq), o_db = AL64(o_ref + b_ref), o_blk = AL64(o_db + b_db),
                o_tab = AL64(o_blk + b_blk), o_toff = AL64(o_tab + tab_bytes);
 #undef AL64
   if ((rc = bsc_stage_reserve(ctx, o_toff + b_toff + 64u))) return rc;
   char *st = ctx->h_stage;
-  if (nr) {
-    memcpy(st, tpl, b_tpl);
-    memcpy(st + o_seq, seq, b_seq);
+  if (stage) {
+    if (nr) {
+      memcpy(st, tpl, b_tpl);
+      memcpy(st + o_seq, seq, b_seq);
+      tpl = (const bsc_template *)st;
+      seq = (const uint8_t *)(st + o_seq);
+    }
+    memcpy(st + o_ref, ref, b_ref);
+    ref = (const uint8_t *)(st + o_ref);
   }
-  memcpy(st + o_ref, ref, (size_t)ref64);
   bsc_chain_mblock *mb = (bsc_chain_mblock *)(st + o_blk);
   {
     uint32_t t_end = 0, r_off = 0, p_off = 0;
@@ -1392,16 +1399,16 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
     }
   }
   hipStream_t s = ctx->stream;
-  ctx->blk_tpl = (const bsc_template *)st;
+  ctx->blk_tpl = tpl;
   ctx->blk_d_tpl = ctx->d_tpl;
   ctx->blk_x = blocks[0].x;
   ctx->mb_tab = mb;
   ctx->mb_n = n_blocks;
   if (nr) {
-    HIP_TRY(hipMemcpyAsync(ctx->d_tpl, st, b_tpl, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ctx->d_seq, st + o_seq, b_seq, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
   }
-  HIP_TRY(hipMemcpyAsync(ctx->d_ref, st + o_ref, (size_t)ref64, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)ref64, hipMemcpyHostToDevice, s));
   if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, st + o_db, b_db, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->d_mblk, mb, b_blk, hipMemcpyHostToDevice, s));
   void *d_db = dbsnp ? ctx->d_vdb : NULL;
@@ -1447,17 +1454,29 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
   return BSC_OK;
 }
 
-int bsc_blocks_records_submit(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
-                              uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
-                              bsc_vcf_rec *out, uint64_t out_cap) {
+static int bsc_blocks_submit(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                             uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                             bsc_vcf_rec *out, uint64_t out_cap, int stage) {
   if (!ctx || !blocks || !ref || !params || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records_submit: NULL argument");
-  int rc = bsc_blocks_queue(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap);
+  int rc = bsc_blocks_queue(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap, stage);
   if (rc) {
-    (void)hipStreamSynchronize(ctx->stream); /* nothing may still read the staging area after a failed submit */
+    (void)hipStreamSynchronize(ctx->stream); /* nothing may still read the inputs / the staging area after a failed submit */
     return rc;
   }
   ctx->rec_pending = 2;
   return BSC_OK;
+}
+
+int bsc_blocks_records_submit(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                              uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                              bsc_vcf_rec *out, uint64_t out_cap) {
+  return bsc_blocks_submit(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap, 1);
+}
+
+int bsc_blocks_records_submit_inplace(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl,
+                                      const uint8_t *seq, uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp,
+                                      const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap) {
+  return bsc_blocks_submit(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap, 0);
 }
 
 int bsc_blocks_records_fetch(bsc_context *ctx, uint64_t *n_out, uint64_t *block_counts) {

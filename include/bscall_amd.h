@@ -321,8 +321,8 @@ int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out);
  *                     block wrote
  * At most 2^28 - 1 positions (each block rounded up to a multiple of 64) and 65 536 blocks a call.  Errors as
  * bsc_block_records (a bad template is named by its index among the call's templates); one call in flight per context,
- * shared with the single-block entries.  The inputs are copied to the pinned staging area: the caller's buffers are free when
- * submit returns; `out` must stay valid until the fetch.
+ * shared with the single-block entries.  bsc_blocks_records_submit copies the inputs to the pinned staging area: the caller's
+ * buffers are free when it returns; `out` must stay valid until the fetch.
  */
 typedef struct {
   uint32_t x, y; /* first and last position of the block */
@@ -332,6 +332,11 @@ typedef struct {
 int bsc_blocks_records_submit(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl,
                               const uint8_t *seq, uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp,
                               const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap);
+/* no staging copy of templates, reads and reference codes: read where they lie (page-locked buffers from bsc_alloc_host make the
+ * upload a true DMA), unchanged until the fetch — the form for a host that flattens its blocks straight into such buffers */
+int bsc_blocks_records_submit_inplace(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl,
+                                      const uint8_t *seq, uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp,
+                                      const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap);
 int bsc_blocks_records_fetch(bsc_context *ctx, uint64_t *n_out, uint64_t *block_counts);
 int bsc_blocks_records(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
                        uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,

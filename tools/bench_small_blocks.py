@@ -1,17 +1,94 @@
-import sys, time
-sys.path.insert(0, '.')
+#!/usr/bin/env python3
+"""Small blocks — the reference's real unit (one call_genotypes_ML per maximal run of overlapping templates,
+src/get_template_vector.c:141-147: 10^2 .. 10^7 positions): host buffers in, packed records out, wall time per position.
+  one by one   bsc_block_records per block (a dozen launches, four copies and one wait each)
+  batched      bsc_blocks_records over batches of >= --batch positions (one launch sequence per batch)
+usage: python tools/bench_small_blocks.py [--batch 1000000] [--total 4000000] [--coverage 30] [--sizes 1000,10000,100000]"""
+import argparse
+import json
+import sys
+import time
+
+sys.path.insert(0, ".")
 import numpy as np
+
 import bs_call_amd as B
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1_000_000)
+ap.add_argument("--total", type=int, default=4_000_000)
+ap.add_argument("--coverage", type=int, default=30)
+ap.add_argument("--sizes", default="1000,10000,100000")
+args = ap.parse_args()
+res = {"coverage": args.coverage, "batch_positions": args.batch, "what": "wall time, host buffers in (pageable), packed records out; best of 5 passes", "sizes": {}}
 with B.SiteCaller() as c:
-    for n in (1_000, 10_000, 100_000, 1_000_000):
-        tpl, seq = B.synth_reads_host(5, 1000, n, 30)
-        x, y = 998, int((tpl["pos"] + tpl["len"]).max()) - 1
-        nn = y - x + 1
-        ref = B.synth_ref_host(5, x, nn + 2)
-        out = np.zeros(nn, dtype=B.GT_METH); skip = np.zeros(nn, dtype=np.uint8); rec = np.zeros(nn, dtype=B.VCF_REC)
-        c.call_block(tpl, seq, x, y, ref[:nn], out=out, skip=skip); c.block_records(tpl, seq, x, y, ref, out=rec)
-        ts = []; tr = []
-        for _ in range(20):
-            t0 = time.perf_counter(); c.call_block(tpl, seq, x, y, ref[:nn], out=out, skip=skip); ts.append(time.perf_counter() - t0)
-            t0 = time.perf_counter(); c.block_records(tpl, seq, x, y, ref, out=rec); tr.append(time.perf_counter() - t0)
-        print("%8d positions: call_block %.0f us (%.1f M/s), block_records %.0f us (%.1f M/s)" % (nn, min(ts) * 1e6, nn / min(ts) / 1e6, min(tr) * 1e6, nn / min(tr) / 1e6))
+    for n in [int(v) for v in args.sizes.split(",")]:
+        k = max(2, args.total // n)
+        blocks, refs, pos = [], [], 1000
+        for i in range(k):
+            tpl, seq = B.synth_reads_host(5 + i, pos + 200, n, args.coverage)
+            x, y = pos + 198, int((tpl["pos"] + tpl["len"]).max()) - 1
+            blocks.append((tpl, seq, x, y))
+            refs.append(B.synth_ref_host(5 + i, x, y - x + 3))
+            pos = y
+        total = sum(y - x + 1 for _, _, x, y in blocks)
+        out = np.zeros(total, dtype=B.VCF_REC)
+        per_batch = max(1, args.batch // n)
+        groups = [(blocks[i : i + per_batch], refs[i : i + per_batch]) for i in range(0, k, per_batch)]
+        t_one, t_bat, n1, n2 = [], [], 0, 0
+        for rep in range(6):
+            t0 = time.perf_counter()
+            n1 = sum(len(c.block_records(t, s, x, y, refs[i], out=out)) for i, (t, s, x, y) in enumerate(blocks))
+            t1 = time.perf_counter()
+            n2 = sum(len(c.blocks_records(g, r, out=out)[0]) for g, r in groups)
+            t2 = time.perf_counter()
+            if rep:  # the first pass sizes the workspaces
+                t_one.append(t1 - t0)
+                t_bat.append(t2 - t1)
+        assert n1 == n2
+        # what a C host does: it flattens its blocks straight into ONE set of page-locked buffers per batch (here: built once,
+        # outside the timed passes) and submits them in place; records come back into a page-locked array
+        from bs_call_amd.abi import BLOCK_DESC
+        from bs_call_amd.caller import PinnedBuffer
+        keep, joined = [], []
+        for g, r in groups:
+            nt, ns, nr_ = sum(len(b[0]) for b in g), sum(b[1].size for b in g), sum(len(v) for v in r)
+            pt, ps, pr = PinnedBuffer(nt, B.TEMPLATE), PinnedBuffer(ns, np.uint8), PinnedBuffer(nr_, np.uint8)
+            po = PinnedBuffer(sum(b[3] - b[2] + 1 for b in g), B.VCF_REC)
+            desc = np.zeros(len(g), dtype=BLOCK_DESC)
+            ot = os_ = orf = 0
+            for i, (t, sq, x, y) in enumerate(g):
+                pt.array[ot : ot + len(t)] = t
+                pt.array["off"][ot : ot + len(t)] += np.uint64(os_)
+                ps.array[os_ : os_ + sq.size] = sq
+                pr.array[orf : orf + len(r[i])] = r[i]
+                desc[i] = (x, y, len(t), 0)
+                ot, os_, orf = ot + len(t), os_ + sq.size, orf + len(r[i])
+            keep.append((pt, ps, pr, po))
+            joined.append((desc, pt.array, ps.array, pr.array, po.array))
+        t_pin, n3 = [], 0
+        for rep in range(6):
+            t0 = time.perf_counter()
+            n3 = sum(len(c.blocks_records_joined(*j, inplace=True)[0]) for j in joined)
+            if rep:
+                t_pin.append(time.perf_counter() - t0)
+        assert n3 == n1
+        # the Python wrapper joins the blocks' arrays for the batched call (np.concatenate): timed apart, it is not the library's
+        t0 = time.perf_counter()
+        for g, r in groups:
+            np.concatenate([b[0] for b in g]), np.concatenate([b[1] for b in g]), np.concatenate(r)
+        join_s = time.perf_counter() - t0
+        res["sizes"][str(n)] = {"blocks": k, "positions": total, "records": n1,
+                                "one_by_one_M_positions_per_s": total / min(t_one) / 1e6, "one_by_one_us_per_block": min(t_one) / k * 1e6,
+                                "batched_M_positions_per_s": total / min(t_bat) / 1e6, "batched_us_per_block": min(t_bat) / k * 1e6,
+                                "batched_minus_python_join_M_positions_per_s": total / max(min(t_bat) - join_s, 1e-9) / 1e6,
+                                "batched_inplace_pinned_M_positions_per_s": total / min(t_pin) / 1e6,
+                                "batched_inplace_pinned_us_per_block": min(t_pin) / k * 1e6, "blocks_per_batch": per_batch}
+        print("%7d-position blocks x %4d: one by one %8.1f M positions/s (%6.0f us per block)   batched %8.1f M positions/s (%6.0f us per block; "
+              "%.1f without the wrapper's array joins)   batched, in place from page-locked buffers %8.1f M positions/s (%6.0f us per block)"
+              % (n, k, total / min(t_one) / 1e6, min(t_one) / k * 1e6, total / min(t_bat) / 1e6, min(t_bat) / k * 1e6,
+                 total / max(min(t_bat) - join_s, 1e-9) / 1e6, total / min(t_pin) / 1e6, min(t_pin) / k * 1e6), file=sys.stderr)
+        for pb in keep:
+            for q in pb:
+                q.free()
+print(json.dumps(res))
