@@ -305,11 +305,20 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
     const uint32_t nvalid = p_last - p0 + 1u;
     uint32_t *dst = cts + (uint64_t)wt * SLOT_DW;
     if (nvalid == 64u) {
-      const uint4 *s4 = reinterpret_cast<const uint4 *>(slot);
-      uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+      /* written once, read by another kernel much later: non-temporal, like the calling kernel's records (ACC_PLAIN_STORES:
+       * the A/B build) */
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 *s4 = reinterpret_cast<const u32x4 *>(slot);
+      u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+#ifdef ACC_PLAIN_STORES
+#define ACC_ST(p, v) *(p) = (v)
+#else
+#define ACC_ST(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 #pragma unroll
-      for (int v = 0; v < 6; v++) d4[v * 64 + lane] = s4[v * 64 + lane];
-      if (lane < 32) d4[6 * 64 + lane] = s4[6 * 64 + lane];
+      for (int v = 0; v < 6; v++) ACC_ST(d4 + v * 64 + lane, s4[v * 64 + lane]);
+      if (lane < 32) ACC_ST(d4 + 6 * 64 + lane, s4[6 * 64 + lane]);
+#undef ACC_ST
     } else if (valid) {
 #pragma unroll
       for (int i = 0; i < IN_DW; i++) dst[lane * IN_DW + i] = row[i];
