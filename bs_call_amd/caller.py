@@ -172,6 +172,33 @@ class SiteCaller:
                                            _ptr(out), stride, _ptr(skip)))
         self._pending = (out, skip)
 
+    def blocks_submit_to(self, blocks, ref, out_stride=200):
+        """bsc_blocks_submit_to: blocks = [(templates, seq, x, y), ...], ref = their y - x + 3 codes each (list of arrays); the
+        images of all blocks land in ONE page-locked array (block b from position offset off[b] on, a multiple of 64).  Returns
+        (off, out, skip) after the fetch: out = GT_METH[P] (stride 200) or uint8[P, 208]."""
+        from .abi import BLOCK_DESC
+
+        tpls, seqs, desc, o = [], [], np.zeros(len(blocks), dtype=BLOCK_DESC), 0
+        for i, (t, sq, x, y) in enumerate(blocks):
+            t = np.array(t, dtype=TEMPLATE)
+            sq = np.ascontiguousarray(sq, dtype=np.uint8)
+            t["off"] += np.uint64(o)
+            o += sq.size
+            tpls.append(t)
+            seqs.append(sq)
+            desc[i] = (x, y, len(t), 0)
+        tpl, seq = np.concatenate(tpls), np.concatenate(seqs)
+        refs = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint8) for r in ref]))
+        P = sum(((int(y) - int(x) + 1 + 63) // 64) * 64 for _, _, x, y in blocks)
+        self._pin = (PinnedBuffer(P, GT_METH) if out_stride == 200 else PinnedBuffer((P, out_stride), np.uint8), PinnedBuffer(P, np.uint8))
+        out, skip = self._pin[0].array, self._pin[1].array
+        off = np.zeros(len(blocks), dtype=np.uint64)
+        _check(self._L.bsc_blocks_submit_to(self._h, _ptr(desc), len(desc), _ptr(tpl), _ptr(seq), seq.size, _ptr(refs), _ptr(out), out_stride,
+                                            _ptr(skip), _ptr(off)))
+        self._pending = (out, skip)
+        o2, s2 = self.block_fetch()
+        return off, o2.copy(), s2.copy()
+
     def block_fetch(self):
         """Wait for the submitted block and return (GT_METH[n] or uint8[n, stride], skip)."""
         if self._pending is None:

@@ -251,14 +251,17 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_scatter_kernel(cons
  */
 extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel(
     const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ bin_off, uint32_t n_bins, const uint8_t *__restrict__ seq,
-    uint32_t x, uint32_t y, uint32_t min_qual, uint32_t *__restrict__ cts, unsigned long long *__restrict__ counters) {
+    uint32_t x, uint32_t y, uint32_t min_qual, uint32_t *__restrict__ cts, unsigned long long *__restrict__ counters,
+    const bsc_chain_mblock *__restrict__ blk, uint32_t n_blk) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_slot[ACC_WAVES][SLOT_DW];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t *slot = lds_slot[wid];
   uint32_t *row = slot + lane * IN_DW;
+  /* blk != NULL (bsc_blocks_submit_to): several blocks, each from a multiple of 64 positions on in the pile-up array — tile wt
+   * is bin wt of the grouped reads and belongs to the block whose [bin0, bin_end) holds it; n_bins = the tiles of all blocks */
   const uint32_t n_sites = y - x + 1;
-  const uint32_t n_wt = (n_sites + 63u) / 64u;
+  const uint32_t n_wt = blk ? n_bins : (n_sites + 63u) / 64u;
   /* q counts iff min_qual <= q < 63 (:217)  <=>  (q - min_qual) <u q_span */
   const uint32_t q_span = min_qual < 63u ? 63u - min_qual : 0u;
   unsigned inexact = 0;
@@ -268,7 +271,7 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
   R.seq = seq;
   R.n_bins = n_bins;
   R.x = x;
-  const uint32_t n_live = bin_off[n_bins];
+  uint32_t n_live = bin_off[n_bins];
   const uint32_t span = (uint32_t)counters[BSC_CNT_SPAN]; /* longest read extent, b - a */
   /* Software pipeline over the wave's tiles: while tile i is processed, the first batch of tile i+1 is on its way */
   const uint32_t wt_step = gridDim.x * ACC_WAVES;
@@ -276,28 +279,50 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
   uint32_t t0 = 0, kv = 0xffffffffu;
   bsc_read_desc d;
   acc_dead(d);
+  uint32_t wl = wt, wl_n = 0; /* the tile's index inside its block (blk: set by ACC_BLOCK_OF) */
+  /* the block of tile w (wave-uniform: scalar loads): positions, bins, and where its reads end */
+#define ACC_BLOCK_OF(w, wlocal)                                    \
+  do {                                                             \
+    uint32_t lo_ = 0, hi_ = n_blk - 1u;                            \
+    while (lo_ < hi_) {                                            \
+      const uint32_t mid_ = (lo_ + hi_) >> 1;                      \
+      if ((w) < blk[mid_].bin_end) hi_ = mid_;                     \
+      else lo_ = mid_ + 1u;                                        \
+    }                                                              \
+    x = blk[lo_].x;                                                \
+    y = blk[lo_].x + (blk[lo_].n - 1u);                            \
+    R.x = x;                                                       \
+    R.bin_off = bin_off + blk[lo_].bin0;                           \
+    n_live = bin_off[blk[lo_].bin_end];                            \
+    (wlocal) = (w)-blk[lo_].bin0;                                  \
+  } while (0)
   if (wt < n_wt) {
-    t0 = acc_tile_start(R, (int64_t)wt * 64, span);
+    if (blk) ACC_BLOCK_OF(wt, wl);
+    t0 = acc_tile_start(R, (int64_t)wl * 64, span);
     acc_fetch(R, n_live, t0, lane, kv, d);
   }
   for (; wt < n_wt; wt += wt_step) {
-    /* x + 64 wt <= y: the tile's first position fits 32 bits; its last one is clipped to y */
-    const uint32_t p0 = x + wt * 64u;
+    /* x + 64 wl <= y: the tile's first position fits 32 bits; its last one is clipped to y */
+    const uint32_t p0 = x + wl * 64u;
     const uint32_t p_last = y - p0 < 63u ? y : p0 + 63u;
     const uint32_t r_last = p_last - x; /* the tile's last position relative to the block start */
     const bool valid = lane <= p_last - p0;
+    const acc_reads Rc = R; /* this tile's block; the request below may move R on to the next tile's */
+    const uint32_t n_live_c = n_live;
     const uint32_t wt1 = wt + wt_step;
     const bool have1 = wt1 < n_wt && wt1 > wt;
     uint32_t kv_n = 0xffffffffu, t0_n = 0;
     bsc_read_desc dn;
     acc_dead(dn);
+    wl_n = wt1;
     if (have1) {
-      t0_n = acc_tile_start(R, (int64_t)wt1 * 64, span);
+      if (blk) ACC_BLOCK_OF(wt1, wl_n);
+      t0_n = acc_tile_start(R, (int64_t)wl_n * 64, span);
       acc_fetch(R, n_live, t0_n, lane, kv_n, dn);
     }
     {
       uint32_t w[IN_DW];
-      inexact |= acc_tile(R, n_live, lane, lane, row, p0, p_last, r_last, min_qual, q_span, t0, kv, d, w) ? 1u : 0u;
+      inexact |= acc_tile(Rc, n_live_c, lane, lane, row, p0, p_last, r_last, min_qual, q_span, t0, kv, d, w) ? 1u : 0u;
 #pragma unroll
       for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(w[2 * i], w[2 * i + 1]);
     }
@@ -319,13 +344,14 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
       for (int v = 0; v < 6; v++) ACC_ST(d4 + v * 64 + lane, s4[v * 64 + lane]);
       if (lane < 32) ACC_ST(d4 + 6 * 64 + lane, s4[6 * 64 + lane]);
 #undef ACC_ST
-    } else if (valid) {
+    } else if (valid || blk) { /* blk: the positions between a block's end and the next multiple of 64 are called too: nothing piled up */
 #pragma unroll
-      for (int i = 0; i < IN_DW; i++) dst[lane * IN_DW + i] = row[i];
+      for (int i = 0; i < IN_DW; i++) dst[lane * IN_DW + i] = valid ? row[i] : 0u;
     }
     t0 = t0_n;
     kv = kv_n;
     d = dn;
+    wl = wl_n;
   }
   if (__any(inexact)) {
     const unsigned long long m = __ballot(inexact);
@@ -379,15 +405,24 @@ extern "C" int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, cons
                           scan_tmp, scan_tmp_bytes, rd, counters, stream);
 }
 
-extern "C" int bsc_dev_launch_accumulate(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y, uint32_t min_qual,
-                                         void *cts, void *counters, int num_cus, void *stream) {
-  const uint32_t n_sites = y - x + 1;
-  const uint32_t n_wt = (n_sites + 63u) / 64u;
+static int launch_accumulate(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y, uint32_t n_wt, uint32_t min_qual,
+                             void *cts, void *counters, const bsc_chain_mblock *blk, uint32_t n_blk, int num_cus, void *stream) {
   unsigned g = (n_wt + ACC_WAVES - 1) / ACC_WAVES;
   const unsigned cap = (unsigned)num_cus * 6u * 8u; /* 6 workgroups of 26 KB LDS fit a CU */
   if (g > cap) g = cap;
   hipLaunchKernelGGL(bsc_accumulate_kernel, dim3(g), dim3(64 * ACC_WAVES), 0, (hipStream_t)stream, (const bsc_read_desc *)rd,
-                     (const uint32_t *)bin_off, bsc_dev_n_bins(n_sites), (const uint8_t *)seq, x, y, min_qual, (uint32_t *)cts,
-                     (unsigned long long *)counters);
+                     (const uint32_t *)bin_off, n_wt, (const uint8_t *)seq, x, y, min_qual, (uint32_t *)cts,
+                     (unsigned long long *)counters, blk, n_blk);
   return (int)hipGetLastError();
+}
+
+extern "C" int bsc_dev_launch_accumulate(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y, uint32_t min_qual,
+                                         void *cts, void *counters, int num_cus, void *stream) {
+  return launch_accumulate(rd, bin_off, seq, x, y, bsc_dev_n_bins(y - x + 1), min_qual, cts, counters, NULL, 0, num_cus, stream);
+}
+
+/* several blocks (d_blk[n_blk], device): n_bins = the 64-position tiles of all of them = the bins of their grouped reads */
+extern "C" int bsc_dev_launch_accumulate_multi(const void *rd, const void *bin_off, const void *seq, const void *d_blk, uint32_t n_blk,
+                                               uint32_t n_bins, uint32_t min_qual, void *cts, void *counters, int num_cus, void *stream) {
+  return launch_accumulate(rd, bin_off, seq, 0, 0, n_bins, min_qual, cts, counters, (const bsc_chain_mblock *)d_blk, n_blk, num_cus, stream);
 }

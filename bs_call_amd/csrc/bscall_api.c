@@ -57,6 +57,8 @@ size_t bsc_dev_chain_scratch_bytes(int num_cus);
 size_t bsc_dev_chain_multi_table_bytes(uint32_t n_blocks);
 int bsc_dev_launch_chain_multi(const bsc_chain_launch *L, const bsc_chain_mblock *blk, uint32_t b_first, uint32_t b_last, void *tab_h,
                                void *tab_d, size_t *cursor);
+int bsc_dev_launch_accumulate_multi(const void *rd, const void *bin_off, const void *seq, const void *d_blk, uint32_t n_blk, uint32_t n_bins,
+                                    uint32_t min_qual, void *cts, void *counters, int num_cus, void *stream);
 int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk, uint32_t n_blk,
                                    uint32_t n_bins, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
                                    size_t scan_tmp_bytes, void *rd, void *counters, void *stream);
@@ -633,6 +635,7 @@ static int bsc_accumulate_queue2(bsc_context *ctx, const bsc_template *tpl, uint
   ctx->blk_tpl = tpl;
   ctx->blk_d_tpl = ctx->d_tpl;
   ctx->blk_x = x;
+  ctx->mb_n = 0;
   if (nr) {
     HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -664,10 +667,16 @@ static int bsc_verdict(bsc_context *ctx, const unsigned long long f[2], int *ine
     const bsc_template *t = &dt;
     if (ctx->blk_tpl) t = ctx->blk_tpl + i;
     else HIP_TRY(hipMemcpy(&dt, (const char *)ctx->blk_d_tpl + (size_t)i * sizeof(bsc_template), sizeof dt, hipMemcpyDeviceToHost));
+    uint32_t blk_x = ctx->blk_x;
+    for (uint32_t b = 0; b < ctx->mb_n; b++) /* several blocks in flight: the template is named with its own block's start */
+      if (i < ctx->mb_tab[b].tpl_end) {
+        blk_x = ctx->mb_tab[b].x;
+        break;
+      }
     switch ((int)(f[1] & 0xffu)) {
       case BSC_TERR_LEFT:
         return bsc_fail(BSC_ERR_ARG, "accumulate: template %u starts at %u, left of the block start %u", i,
-                        bsc_leftmost(t), ctx->blk_x);
+                        bsc_leftmost(t), blk_x);
       case BSC_TERR_ORI:
         return bsc_fail(BSC_ERR_ARG, "accumulate: template %u has orientation %u (reference asserts ori < 2)", i,
                         t->orientation);
@@ -717,6 +726,7 @@ int bsc_accumulate_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, cons
   ctx->blk_tpl = NULL;
   ctx->blk_d_tpl = d_tpl;
   ctx->blk_x = x;
+  ctx->mb_n = 0;
   return bsc_accumulate_launch(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, d_cts, scan_bytes, (hipStream_t)stream);
 }
 
@@ -865,6 +875,120 @@ int bsc_block_submit_to(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, 
     ctx->pending_sz = 0;
     return bsc_fail(BSC_ERR_HIP, "bsc_block_submit_to: copy-out failed: %s", hipGetErrorString(e));
   }
+  ctx->pending_copied = 1;
+  return BSC_OK;
+}
+
+/*
+ * bsc_block_submit_to for several blocks at once (the drop-in glue holds small blocks back, integration/amd_overlap_protocol.h):
+ * one upload, one grouping pass over all the blocks' reads, ONE accumulate launch and ONE launch of the calling kernel over the
+ * positions of all blocks, one copy-out.  In the pile-up / result arrays every block starts on a multiple of 64 positions
+ * (block_off[b], returned): out holds (block_off[n_blocks - 1] + that block's positions rounded up to 64) images of out_stride
+ * bytes, block b's from image block_off[b] on — the positions between a block's end and the next multiple of 64 are images of
+ * nothing (skip = 1).  bsc_block_fetch(ctx, NULL, NULL) completes it.
+ */
+int bsc_blocks_submit_to(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                         uint64_t seq_bytes, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip, uint64_t *block_off) {
+  if (!ctx || !blocks || !ref || !out || !skip || !block_off) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_submit_to: NULL argument");
+  if (ctx->pending_sz || ctx->rec_pending)
+    return bsc_fail(BSC_ERR_ARG, "a submitted block has not been fetched (bsc_block_fetch / bsc_block_records_fetch first)");
+  int rc = bsc_check_stride(out_stride);
+  if (rc) return rc;
+  if (n_blocks == 0 || n_blocks > 65536u) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_submit_to: n_blocks must be 1 .. 65536, got %u", n_blocks);
+  uint64_t nr64 = 0, pos64 = 0, ref64 = 0;
+  for (uint32_t b = 0; b < n_blocks; b++) {
+    if (blocks[b].y < blocks[b].x)
+      return bsc_fail(BSC_ERR_ARG, "bsc_blocks_submit_to: block %u has y (%u) < x (%u) (reference asserts y >= x)", b, blocks[b].y, blocks[b].x);
+    if (blocks[b].y == 0xffffffffu) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_submit_to: positions exceed 32 bits");
+    const uint64_t sz = (uint64_t)blocks[b].y - blocks[b].x + 1;
+    block_off[b] = pos64;
+    nr64 += blocks[b].nr;
+    pos64 += (sz + 63u) & ~(uint64_t)63u;
+    ref64 += sz + 2;
+  }
+  if (pos64 > 0x0fffffffull) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_submit_to: more than 2^28 - 1 positions in one call");
+  if (nr64 > 0x7fffffffull) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_submit_to: more than 2^31 - 1 templates in one call");
+  const uint32_t nr = (uint32_t)nr64, P = (uint32_t)pos64;
+  if (nr && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_submit_to: NULL template or read buffer");
+  BSC_ENTER(ctx);
+  size_t scan_bytes = 0;
+  if ((rc = bsc_accumulate_reserve(ctx, nr, 1u, P, &scan_bytes))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_cts, &ctx->cap_cts, (size_t)P * 104u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)P))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)P * out_stride))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)P))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_mblk, &ctx->cap_mblk, (size_t)n_blocks * sizeof(bsc_chain_mblock)))) return rc;
+  /* staging: templates, reads, the reference codes in the device's layout (a block's y - x + 1 codes from its multiple of 64
+   * on; its two look-ahead codes are the printer's, not the caller's), the block table */
+  const size_t b_tpl = (size_t)nr * sizeof(bsc_template), b_seq = (size_t)seq_bytes, b_blk = (size_t)n_blocks * sizeof(bsc_chain_mblock);
+#define AL64(v) (((v) + 63u) & ~(size_t)63u)
+  const size_t o_seq = AL64(b_tpl), o_ref = AL64(o_seq + b_seq), o_blk = AL64(o_ref + (size_t)P);
+#undef AL64
+  if ((rc = bsc_stage_reserve(ctx, o_blk + b_blk + 64u))) return rc;
+  char *st = ctx->h_stage;
+  if (nr) {
+    memcpy(st, tpl, b_tpl);
+    memcpy(st + o_seq, seq, b_seq);
+  }
+  bsc_chain_mblock *mb = (bsc_chain_mblock *)(st + o_blk);
+  {
+    uint32_t t_end = 0, p_off = 0;
+    uint64_t r_in = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+      const uint32_t sz = blocks[b].y - blocks[b].x + 1u;
+      t_end += blocks[b].nr;
+      mb[b].x = blocks[b].x;
+      mb[b].n = sz;
+      mb[b].tpl_end = t_end;
+      mb[b].ref_off = p_off;
+      mb[b].pos_off = p_off;
+      mb[b].bin0 = p_off >> 6;
+      mb[b].bin_end = (p_off >> 6) + bsc_dev_n_bins(sz);
+      mb[b]._pad = 0;
+      memcpy(st + o_ref + p_off, ref + r_in, sz);
+      memset(st + o_ref + p_off + sz, 0, ((sz + 63u) & ~63u) - sz);
+      r_in += (uint64_t)sz + 2u;
+      p_off += (sz + 63u) & ~63u;
+    }
+  }
+  hipStream_t s = ctx->stream;
+  ctx->blk_tpl = (const bsc_template *)st;
+  ctx->blk_d_tpl = ctx->d_tpl;
+  ctx->blk_x = blocks[0].x;
+  ctx->mb_tab = mb;
+  ctx->mb_n = n_blocks;
+  if (nr) {
+    HIP_TRY(hipMemcpyAsync(ctx->d_tpl, st, b_tpl, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_seq, st + o_seq, b_seq, hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->d_ref, st + o_ref, (size_t)P, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->d_mblk, mb, b_blk, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), s));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), s));
+  int e = bsc_dev_launch_bin_reads_multi(ctx->d_tpl, nr, ctx->d_seq, seq_bytes, ctx->d_mblk, n_blocks, P >> 6, ctx->d_tflag, ctx->d_bcnt,
+                                         ctx->d_boff, ctx->d_bcur, ctx->d_bscan, scan_bytes, ctx->d_rd, ctx->d_counters, s);
+  if (!e)
+    e = bsc_dev_launch_accumulate_multi(ctx->d_rd, ctx->d_boff, ctx->d_seq, ctx->d_mblk, n_blocks, P >> 6, (uint32_t)ctx->params.min_qual,
+                                        ctx->d_cts, ctx->d_counters, ctx->num_cus, s);
+  if (e) {
+    (void)hipStreamSynchronize(s);
+    return bsc_fail(BSC_ERR_HIP, "accumulate launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
+  if ((rc = bsc_call_sites_device(ctx, ctx->d_cts, ctx->d_ref, P, ctx->d_out, out_stride, ctx->d_skip, s))) {
+    (void)hipStreamSynchronize(s);
+    return rc;
+  }
+  hipError_t he = hipMemcpyAsync(out, ctx->d_out, (size_t)P * out_stride, hipMemcpyDeviceToHost, s);
+  if (he == hipSuccess) he = hipMemcpyAsync(skip, ctx->d_skip, (size_t)P, hipMemcpyDeviceToHost, s);
+  if (he != hipSuccess) {
+    (void)hipStreamSynchronize(s);
+    return bsc_fail(BSC_ERR_HIP, "bsc_blocks_submit_to: copy-out failed: %s", hipGetErrorString(he));
+  }
+  ctx->sites -= P - (ref64 - 2ull * n_blocks); /* the positions between the blocks were launched, not processed */
+  ctx->pending_sz = P;
+  ctx->pending_stride = out_stride;
   ctx->pending_copied = 1;
   return BSC_OK;
 }
@@ -1102,6 +1226,7 @@ int bsc_reads_chain_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, con
   ctx->blk_tpl = NULL;
   ctx->blk_d_tpl = d_tpl;
   ctx->blk_x = x;
+  ctx->mb_n = 0;
   return bsc_reads_chain_queue(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_dbsnp, params, with_stats, d_core, d_aux,
                                (hipStream_t)stream);
 }
@@ -1202,6 +1327,7 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   ctx->blk_tpl = tpl;
   ctx->blk_d_tpl = ctx->d_tpl;
   ctx->blk_x = x;
+  ctx->mb_n = 0;
   if (nr) {
     HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
@@ -1486,14 +1612,6 @@ int bsc_blocks_records_fetch(bsc_context *ctx, uint64_t *n_out, uint64_t *block_
   ctx->rec_pending = 0;
   BSC_ENTER(ctx);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (ctx->h_cnt[1] != ~0ull) { /* an invalid template: name it with its own block's start */
-    const uint32_t t = (uint32_t)(ctx->h_cnt[1] >> 8);
-    for (uint32_t b = 0; b < ctx->mb_n; b++)
-      if (t < ctx->mb_tab[b].tpl_end) {
-        ctx->blk_x = ctx->mb_tab[b].x;
-        break;
-      }
-  }
   int rc = bsc_records_finish(ctx, n_out);
   if (rc < 0) return rc;
   if (block_counts) { /* a block's records start where the packing pass put its first 64-position tile */

@@ -342,6 +342,19 @@ int bsc_blocks_records(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t 
                        uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
                        bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out, uint64_t *block_counts);
 
+/*
+ * The gt_meth / gt_vcf form: bsc_block_submit_to for several blocks in ONE launch sequence — same block list, same joined
+ * template / read / reference arrays (ref: y - x + 3 codes per block, of which the first y - x + 1 are used).  One upload, one
+ * grouping pass over all the blocks' reads, one accumulate launch and one launch of the calling kernel over all positions, one
+ * copy-out.  In `out` (page-locked; out_stride = 200 or 208) and `skip` every block starts on a multiple of 64 positions:
+ * block b's images from image block_off[b] on (returned; each block takes its positions rounded up to 64, and out / skip
+ * must hold the sum); the positions in between are images of nothing (skip = 1).  bsc_block_fetch(ctx, NULL, NULL) completes it;
+ * counters and errors as for one block (a bad template is named by its index among the call's templates).  The drop-in glue
+ * (integration/amd_overlap_protocol.h) holds small blocks back and hands them over through this entry.
+ */
+int bsc_blocks_submit_to(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                         uint64_t seq_bytes, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip, uint64_t *block_off);
+
 /* bsc_vcf_format for a packed record. */
 int bsc_vcf_format_rec(const bsc_vcf_rec *r, const char *contig, const char *id, char *buf, size_t cap);
 

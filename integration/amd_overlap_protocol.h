@@ -29,17 +29,43 @@
 #include <bscall_amd.h>
 
 static bsc_context *amd_ctx;
-/* the two blocks that can be alive at once: one being printed, one being computed */
-static struct amd_slot {
-  AMD_GT_VCF_T *vcf; /* page-locked (bsc_alloc_host): the copy-out is a true DMA behind the kernels */
-  uint8_t *skip;     /* bsc_block_submit_to's skip array (the gt_vcf images carry the flag too) */
-  char *ref;         /* private copy of the block's reference codes, x .. y + 2, NUL-terminated */
-  size_t cap, ref_cap;
-  uint32_t x, sz;
-  AMD_CTG_T *ctg;
-} amd_slot[2];
-static int amd_cur = -1; /* slot of the block in flight, -1 = none */
-static int amd_next;     /* slot the next block goes into */
+/*
+ * Round 4: small blocks are HELD BACK.  The reference calls call_genotypes_ML once per maximal run of overlapping templates
+ * (src/get_template_vector.c:141-147: 10^2 .. 10^7 positions), and its calc threads cost nothing to start; a GPU block costs a
+ * dozen launches, four copies and a wait whatever its size (a 10 000-position block: 43 M positions/s, under the host's own
+ * cores).  So a call appends its block to the BATCH being filled and returns; when the batch holds AMD_BATCH_POSITIONS positions
+ * (or at join) it is submitted as one launch sequence (bsc_blocks_submit_to) and the batch submitted before it — complete by
+ * then — is handed to the print thread block by block, in order, exactly as single blocks were.  Two batches are alive at once:
+ * one being filled / in flight, one being printed.
+ */
+#ifndef AMD_BATCH_POSITIONS
+#define AMD_BATCH_POSITIONS 1000000u
+#endif
+static struct amd_batch {
+  /* inputs, joined as bsc_blocks_submit_to wants them (plain memory: the library copies them to its pinned staging area) */
+  bsc_template *tpl;
+  uint8_t *seq;
+  char *ref;            /* the blocks' reference codes, x .. y + 2 each, one block after another */
+  bsc_block_desc *desc;
+  AMD_CTG_T **ctg;
+  uint64_t *off;        /* where each block's images start in vcf[] (bsc_blocks_submit_to) */
+  size_t n_tpl, cap_tpl, n_seq, cap_seq, n_ref, cap_ref, n_blk, cap_blk;
+  uint64_t positions, padded; /* positions of the blocks; the same with every block rounded up to 64 (the images needed) */
+  /* outputs: page-locked (bsc_alloc_host), the copy-out is a true DMA behind the kernels */
+  AMD_GT_VCF_T *vcf;
+  uint8_t *skip;
+  size_t cap_out;
+} amd_batch[2];
+static int amd_flight = -1; /* batch in flight, -1 = none */
+static int amd_fill;        /* batch being filled */
+static uint64_t amd_threshold = AMD_BATCH_POSITIONS;
+
+/* BSCALL_AMD_BATCH_POSITIONS in the environment overrides the threshold (0: every block is submitted by its own call, as in
+ * round 3); called once, before the first block */
+static void amd_overlap_init(void) {
+  const char *e = getenv("BSCALL_AMD_BATCH_POSITIONS");
+  if (e && *e) amd_threshold = strtoull(e, NULL, 10);
+}
 
 static void amd_die(const char *what) {
   fprintf(stderr, "bscall_amd: %s: %s\n", what, bsc_last_error());
@@ -63,94 +89,152 @@ static void amd_wait_mprof(AMD_WORK_T *const work) {
   pthread_mutex_unlock(&work->mprof_mutex);
 }
 
-/* block in flight -> complete -> handed to the print thread */
-static void amd_publish_pending(AMD_WORK_T *const work) {
-  if (amd_cur < 0) return;
-  struct amd_slot *s = &amd_slot[amd_cur];
+static void *amd_grow_to(void *p, size_t *cap, size_t need, size_t elem) {
+  if (need > *cap) {
+    const size_t n = need + need / 2 + 64;
+    p = realloc(p, n * elem);
+    if (!p) { fprintf(stderr, "bscall_amd: out of memory\n"); exit(1); }
+    *cap = n;
+  }
+  return p;
+}
+
+/* batch in flight -> complete -> its blocks handed to the print thread, one after another */
+static void amd_publish_flight(AMD_WORK_T *const work) {
+  if (amd_flight < 0) return;
+  struct amd_batch *q = &amd_batch[amd_flight];
   const int rc = bsc_block_fetch(amd_ctx, NULL, NULL); /* waits for the kernels and the copy-out */
-  if (rc < 0) amd_die("bsc_block_fetch"); /* BSC_ERR_ARG here = one of the original's asserts (:186,188) on that block */
+  if (rc < 0) amd_die("bsc_block_fetch"); /* BSC_ERR_ARG here = one of the original's asserts (:186,188) on a block of the batch */
   if (rc == BSC_WARN_INEXACT) fprintf(stderr, "bscall_amd: %s\n", bsc_last_error());
-  /* the print thread must have drained the block before (original :228-235) */
-  pthread_mutex_lock(&work->print_mutex);
-  while (work->vcf_n) amd_timed_wait(&work->print_cond2, &work->print_mutex);
-  pthread_mutex_unlock(&work->print_mutex);
-  work->vcf = s->vcf;
-  work->vcf_size = (int)s->cap;
-  work->vcf_x = s->x;
-  work->vcf_ctg = s->ctg;
-  AMD_SET_REF(work, s->ref, s->sz); /* the print thread is idle (vcf_n == 0): nobody reads work->ref now */
-  /* records are complete: flags, then wake the print thread (original :110-114, :255-258) */
-  pthread_mutex_lock(&work->vcf_mutex);
-  for (uint32_t i = 0; i < s->sz; i++) __atomic_store_n(&s->vcf[i].ready, true, __ATOMIC_RELEASE);
-  pthread_mutex_unlock(&work->vcf_mutex);
-  pthread_mutex_lock(&work->print_mutex);
-  work->vcf_n = (int)s->sz;
-  pthread_cond_signal(&work->print_cond1);
-  pthread_mutex_unlock(&work->print_mutex);
-  pthread_mutex_lock(&work->vcf_mutex);
-  pthread_cond_signal(&work->vcf_cond);
-  pthread_mutex_unlock(&work->vcf_mutex);
-  amd_cur = -1;
+  size_t ref_at = 0;
+  for (size_t b = 0; b < q->n_blk; b++) {
+    const uint32_t sz = q->desc[b].y - q->desc[b].x + 1u;
+    AMD_GT_VCF_T *const v = q->vcf + q->off[b];
+    /* the print thread must have drained the block before (original :228-235) */
+    pthread_mutex_lock(&work->print_mutex);
+    while (work->vcf_n) amd_timed_wait(&work->print_cond2, &work->print_mutex);
+    pthread_mutex_unlock(&work->print_mutex);
+    work->vcf = v;
+    work->vcf_size = (int)(q->cap_out - q->off[b]);
+    work->vcf_x = q->desc[b].x;
+    work->vcf_ctg = q->ctg[b];
+    AMD_SET_REF(work, q->ref + ref_at, sz); /* the print thread is idle (vcf_n == 0): nobody reads work->ref now */
+    ref_at += (size_t)sz + 2;
+    /* records are complete: flags, then wake the print thread (original :110-114, :255-258) */
+    pthread_mutex_lock(&work->vcf_mutex);
+    for (uint32_t i = 0; i < sz; i++) __atomic_store_n(&v[i].ready, true, __ATOMIC_RELEASE);
+    pthread_mutex_unlock(&work->vcf_mutex);
+    pthread_mutex_lock(&work->print_mutex);
+    work->vcf_n = (int)sz;
+    pthread_cond_signal(&work->print_cond1);
+    pthread_mutex_unlock(&work->print_mutex);
+    pthread_mutex_lock(&work->vcf_mutex);
+    pthread_cond_signal(&work->vcf_cond);
+    pthread_mutex_unlock(&work->vcf_mutex);
+  }
+  amd_flight = -1;
+}
+
+/* the batch being filled goes to the GPU; the one submitted before it is published first (its images are complete by now, and
+ * only then is the print thread done with the arrays of the batch before that — the ones about to be written again) */
+static void amd_flush(AMD_WORK_T *const work) {
+  amd_publish_flight(work);
+  struct amd_batch *q = &amd_batch[amd_fill];
+  if (q->n_blk == 0) return;
+  if (q->padded > q->cap_out) { /* this batch's arrays were published two flushes ago and the print thread waited for since */
+    bsc_free_host(q->vcf);
+    bsc_free_host(q->skip);
+    q->cap_out = (size_t)(q->padded + q->padded / 4);
+    q->vcf = bsc_alloc_host((uint64_t)q->cap_out * sizeof(AMD_GT_VCF_T));
+    q->skip = bsc_alloc_host((uint64_t)q->cap_out);
+    if (!q->vcf || !q->skip) amd_die("bsc_alloc_host");
+  }
+  /* records land as gt_vcf images (stride 208: gtm, ready = 0, skip) right behind the kernels */
+  if (bsc_blocks_submit_to(amd_ctx, q->desc, (uint32_t)q->n_blk, q->tpl, q->seq, q->n_seq, (const uint8_t *)q->ref, q->vcf,
+                           (uint32_t)sizeof(AMD_GT_VCF_T), q->skip, q->off) < 0)
+    amd_die("bsc_blocks_submit_to");
+  amd_flight = amd_fill;
+  amd_fill ^= 1;
+  q = &amd_batch[amd_fill]; /* published in this very flush: its inputs are free to be overwritten, its images are the print thread's */
+  q->n_tpl = q->n_seq = q->n_ref = q->n_blk = 0;
+  q->positions = q->padded = 0;
 }
 
 /*
- * One call_genotypes_ML: (1) the previous block is completed and handed to the print thread (the original waits for its
- * calc threads here, :161-168); (2) this block — already flattened into tpl / seq by the caller — is submitted into the
- * other gt_vcf[] array with a private copy of its reference codes; (3) the meth profiling thread is waited for, so that
- * the caller may overwrite work->ref1.  Returns with the block in flight, like the original after its dispatch (:260-272).
+ * One call_genotypes_ML: the block — already flattened into tpl / seq by the caller — joins the batch being filled, with a
+ * private copy of its reference codes; the meth profiling thread is waited for, so that the caller may overwrite work->ref1;
+ * a full batch is submitted (and the batch before it published).  Returns with the block pending or in flight, like the
+ * original after its dispatch (:260-272).
  */
 static void amd_overlap_call(AMD_WORK_T *const work, AMD_CTG_T *const ctg, const bsc_template *tpl, uint32_t nr, const uint8_t *seq,
                              uint64_t nbytes, uint32_t x, uint32_t y) {
   const uint32_t sz = y - x + 1;
 #ifdef AMD_TEST_ROUND2_BUG
-  const int had_pending = amd_cur >= 0;
+  const int had_pending = amd_flight >= 0 || amd_batch[amd_fill].n_blk != 0;
 #endif
-  amd_publish_pending(work);
-  struct amd_slot *s = &amd_slot[amd_next];
-  if (sz > s->cap) { /* the slot was published two calls ago and the print thread waited for since: free to regrow */
-    bsc_free_host(s->vcf);
-    bsc_free_host(s->skip);
-    s->cap = (size_t)sz + sz / 4;
-    s->vcf = bsc_alloc_host((uint64_t)s->cap * sizeof(AMD_GT_VCF_T));
-    s->skip = bsc_alloc_host((uint64_t)s->cap);
-    if (!s->vcf || !s->skip) amd_die("bsc_alloc_host");
+  /* a batch may hold 2^28 - 1 image slots and 2^31 - 1 templates (bsc_blocks_submit_to): one that this block would push past
+   * either goes first */
+  if (amd_batch[amd_fill].n_blk && (amd_batch[amd_fill].padded + sz + 64u > 0x0fffffffull || amd_batch[amd_fill].n_tpl + nr > 0x7fffffffull))
+    amd_flush(work);
+  struct amd_batch *q = &amd_batch[amd_fill];
+  q->tpl = amd_grow_to(q->tpl, &q->cap_tpl, q->n_tpl + nr, sizeof *q->tpl);
+  q->seq = amd_grow_to(q->seq, &q->cap_seq, q->n_seq + (size_t)nbytes, 1);
+  q->ref = amd_grow_to(q->ref, &q->cap_ref, q->n_ref + (size_t)sz + 3, 1);
+  {
+    size_t cap = q->cap_blk;
+    q->desc = amd_grow_to(q->desc, &cap, q->n_blk + 1, sizeof *q->desc);
+    cap = q->cap_blk;
+    q->ctg = amd_grow_to(q->ctg, &cap, q->n_blk + 1, sizeof *q->ctg);
+    q->off = amd_grow_to(q->off, &q->cap_blk, q->n_blk + 1, sizeof *q->off);
   }
-  if ((size_t)sz + 3 > s->ref_cap) {
-    s->ref = realloc(s->ref, (size_t)sz + 3);
-    if (!s->ref) { fprintf(stderr, "bscall_amd: out of memory\n"); exit(1); }
-    s->ref_cap = (size_t)sz + 3;
+  for (uint32_t i = 0; i < nr; i++) { /* the read offsets become offsets into the batch's read buffer */
+    bsc_template t = tpl[i];
+    t.off[0] += q->n_seq;
+    t.off[1] += q->n_seq;
+    q->tpl[q->n_tpl + i] = t;
   }
-  memcpy(s->ref, AMD_REF1(work), (size_t)sz + 2); /* work->ref1: codes of x .. y + 2 */
-  s->ref[sz + 2] = 0;
-  s->x = x;
-  s->sz = sz;
-  s->ctg = ctg;
-  /* records land as gt_vcf images (stride 208: gtm, ready = 0, skip) right behind the kernels */
-  if (bsc_block_submit_to(amd_ctx, tpl, nr, seq, nbytes, x, y, (const uint8_t *)s->ref, s->vcf, (uint32_t)sizeof(AMD_GT_VCF_T),
-                          s->skip) < 0)
-    amd_die("bsc_block_submit_to");
-  amd_cur = amd_next;
-  amd_next ^= 1;
-#ifdef AMD_TEST_ROUND2_BUG /* tests only: round 2's behaviour, no wait in a call that found no block pending — the harness must catch it */
+  memcpy(q->seq + q->n_seq, seq, (size_t)nbytes);
+  memcpy(q->ref + q->n_ref, AMD_REF1(work), (size_t)sz + 2); /* work->ref1: codes of x .. y + 2 */
+  q->ref[q->n_ref + sz + 2] = 0;
+  q->desc[q->n_blk].x = x;
+  q->desc[q->n_blk].y = y;
+  q->desc[q->n_blk].nr = nr;
+  q->desc[q->n_blk]._pad = 0;
+  q->ctg[q->n_blk] = ctg;
+  q->n_tpl += nr;
+  q->n_seq += (size_t)nbytes;
+  q->n_ref += (size_t)sz + 2;
+  q->n_blk++;
+  q->positions += sz;
+  q->padded += ((uint64_t)sz + 63u) & ~(uint64_t)63u;
+  if (q->positions >= amd_threshold) amd_flush(work);
+#ifdef AMD_TEST_ROUND2_BUG /* tests only: round 2's behaviour, no wait in a call that found nothing pending — the harness must catch it */
   if (had_pending)
 #endif
-    amd_wait_mprof(work); /* in EVERY call, block pending or not (original :244-251) */
+    amd_wait_mprof(work); /* in EVERY call, whatever is pending (original :244-251): the reference codes were copied above */
 }
 
-/* join_calc_threads: the last block is published, the print thread drains it, the arrays go */
+/* join_calc_threads: what is still held back is submitted, everything is published, the print thread drains it, the arrays go */
 static void amd_overlap_join(AMD_WORK_T *const work) {
-  amd_publish_pending(work);
+  amd_flush(work);         /* publishes the batch in flight, submits the one being filled */
+  amd_publish_flight(work); /* ... and publishes that one */
   pthread_mutex_lock(&work->print_mutex);
   while (work->vcf_n) amd_timed_wait(&work->print_cond2, &work->print_mutex);
   pthread_mutex_unlock(&work->print_mutex);
   for (int k = 0; k < 2; k++) {
-    bsc_free_host(amd_slot[k].vcf);
-    bsc_free_host(amd_slot[k].skip);
-    free(amd_slot[k].ref);
-    memset(&amd_slot[k], 0, sizeof amd_slot[k]);
+    struct amd_batch *q = &amd_batch[k];
+    bsc_free_host(q->vcf);
+    bsc_free_host(q->skip);
+    free(q->tpl);
+    free(q->seq);
+    free(q->ref);
+    free(q->desc);
+    free(q->ctg);
+    free(q->off);
+    memset(q, 0, sizeof *q);
   }
-  amd_cur = -1;
-  amd_next = 0;
+  amd_flight = -1;
+  amd_fill = 0;
 }
 
 #endif /* AMD_OVERLAP_PROTOCOL_H */

@@ -4,18 +4,22 @@
  * call_genotypes_amd.c, but the call returns as soon as the block is queued on the GPU, as the original returns as soon
  * as its calc threads are dispatched (src/call_genotypes.c:260-272):
  *
- *   call k     1. block k-1 (if any) is fetched — bsc_block_fetch waits for its kernels and for its records, which
- *                 bsc_block_submit_to had queued straight into a page-locked gt_vcf[] array — and PUBLISHED: the print
- *                 thread is waited for (vcf_n == 0, print_cond2), work->vcf / vcf_x / vcf_ctg are pointed at block k-1,
- *                 the mprof thread is waited for, work->ref receives block k-1's reference codes, the `ready` flags are
- *                 set, the print thread is woken (original :228-258 and :110-114);
- *              2. block k is flattened, its reference codes are copied (the caller overwrites work->ref1 for the next
- *                 block, src/process_template.c:29-30), and it is submitted into the OTHER gt_vcf[] array.
- *   join       the last block is fetched and published, then the context is destroyed.
- * So the GPU computes block k and copies it out while the process thread prepares block k+1 and the print thread
- * writes block k-1 — the overlap the original has between its calc threads and its process thread,
- * which the synchronous glue gives up.  work->vcf alternates between the two arrays; a block's array is reused two
- * calls later, after the print thread has been waited for twice.
+ *   call k     the block is flattened and appended, with a private copy of its reference codes (the caller overwrites
+ *              work->ref1 for the next block, src/process_template.c:29-30), to the BATCH being filled; the meth profiling
+ *              thread is waited for; if the batch now holds AMD_BATCH_POSITIONS positions (1 M) it is FLUSHED:
+ *   flush      the batch submitted before (complete by now) is fetched — bsc_block_fetch waits for its kernels and for its
+ *              images, which bsc_blocks_submit_to had queued straight into a page-locked gt_vcf[] array — and PUBLISHED
+ *              block by block, in order: the print thread is waited for (vcf_n == 0, print_cond2), work->vcf / vcf_x /
+ *              vcf_ctg are pointed at the block's images, work->ref receives its reference codes, the `ready` flags are
+ *              set, the print thread is woken (original :228-258 and :110-114); then the batch being filled is submitted
+ *              as ONE launch sequence into the OTHER gt_vcf[] array.
+ *   join       what is still held back is submitted, everything published, then the context is destroyed.
+ * So the GPU computes batch k and copies it out while the process thread prepares batch k+1 and the print thread writes
+ * batch k-1 — the overlap the original has between its calc threads and its process thread — and a block
+ * of a few thousand positions (the reference's common case, src/get_template_vector.c:141-147) no longer pays a launch
+ * sequence of its own: held back, 10 000-position blocks go through the library at over 400 M positions/s instead of 43 M
+ * (profiles/r04_small_blocks.txt).  work->vcf alternates between the two arrays; an array is written again two flushes
+ * after it was published, after the print thread has been waited for in between.
  *
  * The thread protocol itself lives in integration/amd_overlap_protocol.h, shared with integration/demo_block.c, which runs
  * the very same code against a mock of the work_t fields it touches — on the GPU, and as a CPU-only build with stub
@@ -70,6 +74,7 @@ void init_calc_threads(sr_param *const param) {
   p.ref_bias = param->ref_bias;
   p.min_qual = param->min_qual;
   if (bsc_create(&p, &amd_ctx) != BSC_OK) amd_die("bsc_create");
+  amd_overlap_init();
   work->calc_end = false;
   work->n_calc_threads = 1;
   work->calc_threads_complete = 1; /* the next call never waits on calc_cond2: it fetches instead */

@@ -135,6 +135,7 @@ int main(int argc, char **argv) {
   work_t wo;
   mock_work_init(&wo);
   amd_ctx = ctx;
+  amd_overlap_init(); /* BSCALL_AMD_BATCH_POSITIONS: how many positions are held back before a launch sequence */
   pthread_t pt, mt;
   pthread_create(&pt, NULL, mock_print_thread, &wo);
   pthread_create(&mt, NULL, mock_mprof_thread, &wo);

@@ -1,8 +1,9 @@
 /*
  * overlap_tsan.c — the overlapped glue's thread protocol (integration/amd_overlap_protocol.h) on the CPU alone, for
  * ThreadSanitizer: the same protocol code as integration/call_genotypes_amd_overlap.c, the mock work_t and the three
- * reference-shaped threads of integration/mock_work.h, and STUB bsc_* entries in this file — bsc_block_submit_to starts a
- * thread that fills the gt_vcf[] array a little later (the GPU's kernels and copy-out), bsc_block_fetch joins it.
+ * reference-shaped threads of integration/mock_work.h, and STUB bsc_* entries in this file — bsc_blocks_submit_to starts a
+ * thread that fills the gt_vcf[] images of the batch's blocks a little later (the GPU's kernels and copy-out), bsc_block_fetch
+ * joins it.  Blocks are held back until a batch holds argv[2] positions (default 9 000: a handful of blocks; 0: none held).
  *
  *   gcc -O1 -g -fsanitize=thread -Iinclude integration/overlap_tsan.c -o /tmp/overlap_tsan -lpthread && /tmp/overlap_tsan
  *
@@ -26,10 +27,12 @@
 struct bsc_context {
   pthread_t th;
   int busy;
+  const bsc_block_desc *desc; /* the glue's batch: stays valid until the fetch */
+  uint32_t n_blocks;
   const uint8_t *ref;
   gt_vcf *out;
   uint8_t *skip;
-  uint32_t x, sz;
+  uint64_t *off;
 };
 static struct bsc_context stub_ctx;
 const char *bsc_last_error(void) { return "stub"; }
@@ -47,21 +50,34 @@ static void stub_record(gt_vcf *v, uint32_t pos, uint8_t code) { /* deterministi
 
 static void *stub_worker(void *arg) {
   struct bsc_context *c = arg;
-  usleep(2000); /* the kernels run while the caller prepares the next block */
-  for (uint32_t i = 0; i < c->sz; i++) stub_record(c->out + i, c->x + i, c->ref[i]);
-  for (uint32_t i = 0; i < c->sz; i++) c->skip[i] = c->out[i].skip;
+  usleep(2000); /* the kernels run while the caller prepares the next blocks */
+  size_t ref_at = 0;
+  for (uint32_t b = 0; b < c->n_blocks; b++) {
+    const uint32_t x = c->desc[b].x, sz = c->desc[b].y - x + 1u;
+    gt_vcf *v = c->out + c->off[b];
+    for (uint32_t i = 0; i < sz; i++) stub_record(v + i, x + i, c->ref[ref_at + i]);
+    for (uint32_t i = 0; i < sz; i++) c->skip[c->off[b] + i] = v[i].skip;
+    ref_at += (size_t)sz + 2;
+  }
   return NULL;
 }
 
-int bsc_block_submit_to(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
-                        uint32_t y, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip) {
-  (void)tpl; (void)nr; (void)seq; (void)seq_bytes;
-  if (ctx->busy || out_stride != sizeof(gt_vcf)) return BSC_ERR_ARG;
-  ctx->ref = ref; /* the glue's private copy: stays valid until the fetch */
+/* bsc_blocks_submit_to: every block's images from a multiple of 64 on, the offsets returned */
+int bsc_blocks_submit_to(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                         uint64_t seq_bytes, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip, uint64_t *block_off) {
+  (void)tpl; (void)seq; (void)seq_bytes;
+  if (ctx->busy || out_stride != sizeof(gt_vcf) || n_blocks == 0) return BSC_ERR_ARG;
+  uint64_t p = 0;
+  for (uint32_t b = 0; b < n_blocks; b++) {
+    block_off[b] = p;
+    p += ((uint64_t)(blocks[b].y - blocks[b].x + 1u) + 63u) & ~(uint64_t)63u;
+  }
+  ctx->desc = blocks;
+  ctx->n_blocks = n_blocks;
+  ctx->ref = ref;
   ctx->out = out;
   ctx->skip = skip;
-  ctx->x = x;
-  ctx->sz = y - x + 1;
+  ctx->off = block_off;
   ctx->busy = 1;
   return pthread_create(&ctx->th, NULL, stub_worker, ctx) ? BSC_ERR_HIP : BSC_OK;
 }
@@ -77,6 +93,8 @@ int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
 int main(int argc, char **argv) {
   const int nblk = argc > 1 ? atoi(argv[1]) : 40;
   const uint32_t max_sz = 5000;
+  amd_overlap_init();
+  amd_threshold = argc > 2 ? (uint64_t)atoll(argv[2]) : 9000u; /* a handful of blocks per batch; 0: every block its own batch */
   work_t w;
   mock_work_init(&w);
   amd_ctx = &stub_ctx;

@@ -236,8 +236,18 @@ def test_plain_c_host_program():
 
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bs_call_amd", "lib", "demo_block")
     assert os.path.exists(exe), "run `make demo`"
-    r = subprocess.run([exe, "50000", "30", "4"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stderr + r.stdout
+    first = None
+    # the glue's protocol holds blocks back until a batch is worth a launch sequence (integration/amd_overlap_protocol.h): all
+    # four blocks in one batch (default threshold, 1 M positions), two per batch, every block its own batch — same bytes
+    for batch in (None, "90000", "0"):
+        env = dict(os.environ)
+        if batch is not None:
+            env["BSCALL_AMD_BATCH_POSITIONS"] = batch
+        r = subprocess.run([exe, "50000", "30", "4"], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stderr + r.stdout
+        ov = [ln for ln in r.stdout.strip().splitlines() if "overlapped" in ln][0].split("hash ")[1]
+        first = first or ov
+        assert ov == first
     lines = r.stdout.strip().splitlines()
     last = lines[-1]
     assert "positions called" in last and "VCF records" in last

@@ -168,3 +168,35 @@ def test_blocks_errors_and_the_one_in_flight_rule(caller):
     got, per2 = caller.blocks_records_fetch()
     assert got.tobytes() == good.tobytes() and (per2 == per).all()
     assert len(caller.block_records(tpl, seq, x, y, refs[0])) == int(per[0])  # the context goes on
+
+
+def test_blocks_submit_to_equals_block_by_block(caller):
+    """bsc_blocks_submit_to (the gt_meth / gt_vcf form the drop-in glue batches small blocks through): every block's images are
+    the bytes of bsc_call_block on that block alone, the positions between blocks are images of nothing, counters add up."""
+    rng = np.random.default_rng(77)
+    blocks = [b[:4] + (b[4],) for b in _random_blocks(rng, 60, 1, 9_000, split_every=4)]
+    refs = [b[4] for b in blocks]
+    blocks = [b[:4] for b in blocks]
+    caller.reset_stats()
+    single = [caller.call_block(t, s, x, y, refs[i][: y - x + 1]) for i, (t, s, x, y) in enumerate(blocks)]
+    st1 = caller.stats()
+    caller.reset_stats()
+    for stride in (200, 208):
+        off, out, skip = caller.blocks_submit_to(blocks, refs, out_stride=stride)
+        for i, (t, s, x, y) in enumerate(blocks):
+            n, o = y - x + 1, int(off[i])
+            assert o % 64 == 0
+            img = out[o : o + n]
+            if stride == 208:
+                assert img[:, :200].tobytes() == single[i][0].tobytes() and (img[:, 201] == single[i][1]).all() and not img[:, 200].any()
+            else:
+                assert img.tobytes() == single[i][0].tobytes(), i
+            assert (skip[o : o + n] == single[i][1]).all()
+            pad = ((n + 63) // 64) * 64 - n
+            assert (skip[o + n : o + n + pad] == 1).all()
+    st2 = caller.stats()
+    assert st2["sites"] == 2 * st1["sites"] and st2["covered"] == 2 * st1["covered"] and st2["het_calls"] == 2 * st1["het_calls"]
+    bad = blocks[3][0].copy()
+    bad["bs_strand"][0] = 9
+    with pytest.raises(B.BscError, match="bs_strand 9"):
+        caller.blocks_submit_to(blocks[:3] + [(bad,) + blocks[3][1:]] + blocks[4:], refs)
