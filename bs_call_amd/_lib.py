@@ -83,6 +83,7 @@ EXPORTS = (
     "bsc_dbsnp_flags",
     "bsc_dbsnp_name",
     "bsc_set_profiling",
+    "bsc_set_reads_fused",
     "bsc_last_kernel_ms",
     "bsc_kernel_ms_history",
     "bsc_synchronize",
@@ -351,6 +352,8 @@ def load():
     L.bsc_dbsnp_flags.argtypes = [vp, u32, u32, vp]
     L.bsc_dbsnp_name.restype = i32
     L.bsc_dbsnp_name.argtypes = [vp, u32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.bsc_set_reads_fused.restype = i32
+    L.bsc_set_reads_fused.argtypes = [vp, i32]
     L.bsc_set_profiling.restype = i32
     L.bsc_set_profiling.argtypes = [vp, i32]
     L.bsc_last_kernel_ms.restype = i32

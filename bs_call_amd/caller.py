@@ -456,6 +456,10 @@ class SiteCaller:
         _check(self._L.bsc_stream_probe_ms(self._h, d_cts, d_ref, n, d_out, d_skip, reps, stream, C.byref(ms)))
         return ms.value
 
+    def set_reads_fused(self, fused=True):
+        """reads -> records in ONE kernel (True) or through a pile-up in HBM (False, the default: faster)."""
+        _check(self._L.bsc_set_reads_fused(self._h, 1 if fused else 0))
+
     def set_profiling(self, enable=True):
         _check(self._L.bsc_set_profiling(self._h, 1 if enable else 0))
 

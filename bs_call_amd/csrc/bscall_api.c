@@ -133,6 +133,7 @@ struct bsc_context {
   void *d_mblk, *d_mtab;
   size_t cap_mblk, cap_mtab;
   const uint32_t *mb_toff;
+  int reads_fused; /* bsc_set_reads_fused: 1 = the one-kernel form always; 0 = the pile-up through HBM when it can be allocated */
   void *d_fscr; /* reads-in chain: forward-count scratch lines of the resident waves */
   size_t cap_fscr;
   hipEvent_t ev_rchain[2]; /* bsc_set_profiling: the reads-in chain's launches (read descriptors, ordering, tile search, chain) */
@@ -1012,6 +1013,12 @@ int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
   return bsc_inexact_status(inexact);
 }
 
+int bsc_set_reads_fused(bsc_context *ctx, int fused) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_set_reads_fused: ctx is NULL");
+  ctx->reads_fused = fused != 0;
+  return BSC_OK;
+}
+
 int bsc_set_profiling(bsc_context *ctx, int enable) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_set_profiling: ctx is NULL");
   BSC_ENTER(ctx);
@@ -1197,12 +1204,29 @@ static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t n
   }
   if ((rc = bsc_reads_prepare(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, scan_bytes, s))) return rc;
   int e;
-  L.rd = ctx->d_rd;
-  L.bin_off = ctx->d_boff;
-  L.seq = d_seq;
-  L.f_scratch = ctx->d_fscr;
-  L.n_bins = bsc_dev_n_bins(w.n);
-  L.min_qual = (uint32_t)ctx->params.min_qual;
+  /* Two forms, same records (tests/test_gpu_reads_chain.py runs both).  TWO KERNELS: bsc_accumulate_kernel leaves the block's
+   * pile-up in HBM and the pile-up-in chain reads it — 104 bytes per position written and read again, and the faster form
+   * (round 4: 5.77 against 6.14 ms per 50 M positions at 30x): alone, the walk runs 24 waves to a CU and hides its byte loads;
+   * inside the chain kernel (128 registers, 16 waves to a CU) it waits for them.  ONE KERNEL (READS = true): neither the pile-up
+   * nor gt_meth in HBM — taken when the context is told to (bsc_set_reads_fused) or the pile-up cannot be allocated. */
+  int two_kernels = !ctx->reads_fused;
+  if (two_kernels) {
+    const size_t n_pad = ((size_t)w.n + 63u) / 64u * 64u;
+    if (bsc_reserve(&ctx->d_cts, &ctx->cap_cts, n_pad * 104u) != BSC_OK) two_kernels = 0; /* no room: the lean form */
+  }
+  if (two_kernels) {
+    e = bsc_dev_launch_accumulate(ctx->d_rd, ctx->d_boff, d_seq, x, y, (uint32_t)ctx->params.min_qual, ctx->d_cts, ctx->d_counters,
+                                  ctx->num_cus, s);
+    if (e) return bsc_fail(BSC_ERR_HIP, "accumulate launch failed: %s", hipGetErrorString((hipError_t)e));
+    L.cts = ctx->d_cts;
+  } else {
+    L.rd = ctx->d_rd;
+    L.bin_off = ctx->d_boff;
+    L.seq = d_seq;
+    L.f_scratch = ctx->d_fscr;
+    L.n_bins = bsc_dev_n_bins(w.n);
+    L.min_qual = (uint32_t)ctx->params.min_qual;
+  }
   e = bsc_dev_launch_chain(&L);
   if (e) return bsc_fail(BSC_ERR_HIP, "reads chain launch failed: %s", hipGetErrorString((hipError_t)e));
   if (ctx->profiling) {

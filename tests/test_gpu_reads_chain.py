@@ -18,9 +18,12 @@ AUX = np.dtype([("counts", "<u4", (8,)), ("qual", "u1", (8,)), ("mq", "<i4"), ("
                 ("_pad", "u1", (14,))])
 
 
-@pytest.fixture(scope="module")
-def caller():
+@pytest.fixture(scope="module", params=["two_kernels", "one_kernel"])
+def caller(request):
+    """Every test of this module in both forms of the reads -> records path (bsc_set_reads_fused): the pile-up through HBM
+    (accumulate kernel, then the pile-up-in chain: the default) and the reads-in chain kernel."""
     c = B.SiteCaller()
+    c.set_reads_fused(request.param == "one_kernel")
     yield c
     c.close()
 
