@@ -13,7 +13,7 @@ CFLAGS = -O2 -fPIC -Wall -ffp-contract=off -std=gnu11 -I$(ROCM)/include -D__HIP_
 
 all: $(LIBDIR)/libbscall_amd.so oracle demo
 
-$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/callmath.h $(CSRC)/call_body.inc $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h $(CSRC)/devtables.h $(CSRC)/synth.h
+$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/callmath.h $(CSRC)/call_body.inc $(CSRC)/call_summary.inc $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h $(CSRC)/devtables.h $(CSRC)/synth.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -21,7 +21,7 @@ $(LIBDIR)/bscall_api.o: $(CSRC)/bscall_api.c include/bscall_amd.h $(CSRC)/bsmath
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/accumulate.o: $(CSRC)/accumulate.hip $(CSRC)/accdev.h $(CSRC)/devtables.h
+$(LIBDIR)/accumulate.o: $(CSRC)/accumulate.hip $(CSRC)/accdev.h $(CSRC)/devtables.h $(CSRC)/call_summary.inc
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -38,7 +38,7 @@ $(LIBDIR)/sitestats.o: $(CSRC)/sitestats.hip $(CSRC)/sitestats_dev.h $(CSRC)/dev
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/fused.o: $(CSRC)/fused.hip $(CSRC)/accdev.h $(CSRC)/callmath.h $(CSRC)/call_body.inc $(CSRC)/sitestats_dev.h $(CSRC)/devtables.h $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h include/bscall_amd.h
+$(LIBDIR)/fused.o: $(CSRC)/fused.hip $(CSRC)/accdev.h $(CSRC)/callmath.h $(CSRC)/call_body.inc $(CSRC)/call_summary.inc $(CSRC)/sitestats_dev.h $(CSRC)/devtables.h $(CSRC)/bsmath.h $(CSRC)/bsmath_tables.h include/bscall_amd.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Wno-unused-variable -c $< -o $@
 

@@ -29,6 +29,7 @@
 #define IN_DW 26
 #define SLOT_DW (64 * IN_DW)
 #define ACC_WAVES 4 /* waves per workgroup */
+#define SUM_DW 22   /* dwords of a site summary (the kernel's summary form; read by fused.hip, which explains the size) */
 
 /* bsc_template (include/bscall_amd.h) as the kernels read it */
 struct bsc_template_dev {
@@ -249,7 +250,13 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_scatter_kernel(cons
  * result does not depend on any ordering; the slot becomes the reference's pileup[] layout and leaves with 16-byte-per-lane
  * stores.
  */
-extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel(
+/* SUMM: instead of the 104-byte pile-up the tile leaves 88-byte SITE SUMMARIES — counts[2][8] and the per-site summary of
+ * call_thread (src/call_genotypes.c:44-59: rounded mean quality per class, mean quality, MQ; call_summary.inc, the statements
+ * the calling kernels run) — which is what the chain kernel's summary-in form starts from: 15 % fewer bytes through HBM, and
+ * the summary's arithmetic (a ninth of the chain kernel's vector instructions) moves to the kernel that has issue slots to
+ * spare. */
+template <bool SUMM>
+__global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel_t(
     const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ bin_off, uint32_t n_bins, const uint8_t *__restrict__ seq,
     uint32_t x, uint32_t y, uint32_t min_qual, uint32_t *__restrict__ cts, unsigned long long *__restrict__ counters,
     const bsc_chain_mblock *__restrict__ blk, uint32_t n_blk) {
@@ -323,12 +330,32 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
     {
       uint32_t w[IN_DW];
       inexact |= acc_tile(Rc, n_live_c, lane, lane, row, p0, p_last, r_last, min_qual, q_span, t0, kv, d, w) ? 1u : 0u;
+      if (SUMM) {
+        uint32_t o[SUM_DW];
+        {
+#include "call_summary.inc"
 #pragma unroll
-      for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(w[2 * i], w[2 * i + 1]);
+          for (int j = 0; j < 16; j++) o[j] = w[j];
+          o[16] = qpack0;
+          o[17] = qpack1;
+          o[18] = ((uint32_t)aq & 0xffffu) | ((uint32_t)mq << 16);
+          o[19] = covered ? n_reads : 0u;
+          o[20] = o[21] = 0u;
+        }
+        /* the rows are re-laid at the summary's stride: every lane has read its own row (acc_tile) — but lane L's new row
+         * overlaps old rows of lower lanes only (22 L < 26 L), all read by now: the wave's LDS operations execute in order */
+        uint32_t *srow = slot + lane * SUM_DW;
+#pragma unroll
+        for (int i = 0; i < SUM_DW / 2; i++) reinterpret_cast<uint2 *>(srow)[i] = make_uint2(o[2 * i], o[2 * i + 1]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < IN_DW / 2; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(w[2 * i], w[2 * i + 1]);
+      }
     }
     /* the slot is the tile's pileup[] image: copy it out */
     const uint32_t nvalid = p_last - p0 + 1u;
-    uint32_t *dst = cts + (uint64_t)wt * SLOT_DW;
+    constexpr unsigned ROW = SUMM ? SUM_DW : IN_DW;
+    uint32_t *dst = cts + (uint64_t)wt * (64u * ROW);
     if (nvalid == 64u) {
       /* written once, read by another kernel much later: non-temporal, like the calling kernel's records (ACC_PLAIN_STORES:
        * the A/B build) */
@@ -340,13 +367,15 @@ extern "C" __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kern
 #else
 #define ACC_ST(p, v) __builtin_nontemporal_store((v), (p))
 #endif
+      constexpr int full = (int)(64u * ROW * 4u / 1024u); /* 6.5 KB of pile-ups, 5.5 KB of summaries */
 #pragma unroll
-      for (int v = 0; v < 6; v++) ACC_ST(d4 + v * 64 + lane, s4[v * 64 + lane]);
-      if (lane < 32) ACC_ST(d4 + 6 * 64 + lane, s4[6 * 64 + lane]);
+      for (int v = 0; v < full; v++) ACC_ST(d4 + v * 64 + lane, s4[v * 64 + lane]);
+      if (lane < 32) ACC_ST(d4 + full * 64 + lane, s4[full * 64 + lane]);
 #undef ACC_ST
     } else if (valid || blk) { /* blk: the positions between a block's end and the next multiple of 64 are called too: nothing piled up */
+      const uint32_t *orow = slot + lane * ROW;
 #pragma unroll
-      for (int i = 0; i < IN_DW; i++) dst[lane * IN_DW + i] = valid ? row[i] : 0u;
+      for (int i = 0; i < (int)ROW; i++) dst[lane * ROW + i] = valid ? orow[i] : 0u;
     }
     t0 = t0_n;
     kv = kv_n;
@@ -406,15 +435,28 @@ extern "C" int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, cons
 }
 
 static int launch_accumulate(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y, uint32_t n_wt, uint32_t min_qual,
-                             void *cts, void *counters, const bsc_chain_mblock *blk, uint32_t n_blk, int num_cus, void *stream) {
+                             void *cts, void *counters, const bsc_chain_mblock *blk, uint32_t n_blk, int num_cus, void *stream,
+                             bool summary = false) {
   unsigned g = (n_wt + ACC_WAVES - 1) / ACC_WAVES;
   const unsigned cap = (unsigned)num_cus * 6u * 8u; /* 6 workgroups of 26 KB LDS fit a CU */
   if (g > cap) g = cap;
-  hipLaunchKernelGGL(bsc_accumulate_kernel, dim3(g), dim3(64 * ACC_WAVES), 0, (hipStream_t)stream, (const bsc_read_desc *)rd,
-                     (const uint32_t *)bin_off, n_wt, (const uint8_t *)seq, x, y, min_qual, (uint32_t *)cts,
-                     (unsigned long long *)counters, blk, n_blk);
+  if (summary)
+    hipLaunchKernelGGL(bsc_accumulate_kernel_t<true>, dim3(g), dim3(64 * ACC_WAVES), 0, (hipStream_t)stream, (const bsc_read_desc *)rd,
+                       (const uint32_t *)bin_off, n_wt, (const uint8_t *)seq, x, y, min_qual, (uint32_t *)cts,
+                       (unsigned long long *)counters, blk, n_blk);
+  else
+    hipLaunchKernelGGL(bsc_accumulate_kernel_t<false>, dim3(g), dim3(64 * ACC_WAVES), 0, (hipStream_t)stream, (const bsc_read_desc *)rd,
+                       (const uint32_t *)bin_off, n_wt, (const uint8_t *)seq, x, y, min_qual, (uint32_t *)cts,
+                       (unsigned long long *)counters, blk, n_blk);
   return (int)hipGetLastError();
 }
+
+/* the summary form (one block): cts receives (positions rounded up to 64) x 88 bytes */
+extern "C" int bsc_dev_launch_accumulate_summary(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y,
+                                                 uint32_t min_qual, void *cts, void *counters, int num_cus, void *stream) {
+  return launch_accumulate(rd, bin_off, seq, x, y, bsc_dev_n_bins(y - x + 1), min_qual, cts, counters, NULL, 0, num_cus, stream, true);
+}
+extern "C" size_t bsc_dev_summary_bytes(void) { return SUM_DW * 4u; }
 
 extern "C" int bsc_dev_launch_accumulate(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y, uint32_t min_qual,
                                          void *cts, void *counters, int num_cus, void *stream) {

@@ -57,6 +57,9 @@ size_t bsc_dev_chain_scratch_bytes(int num_cus);
 size_t bsc_dev_chain_multi_table_bytes(uint32_t n_blocks);
 int bsc_dev_launch_chain_multi(const bsc_chain_launch *L, const bsc_chain_mblock *blk, uint32_t b_first, uint32_t b_last, void *tab_h,
                                void *tab_d, size_t *cursor);
+int bsc_dev_launch_accumulate_summary(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y, uint32_t min_qual, void *cts,
+                                      void *counters, int num_cus, void *stream);
+size_t bsc_dev_summary_bytes(void);
 int bsc_dev_launch_accumulate_multi(const void *rd, const void *bin_off, const void *seq, const void *d_blk, uint32_t n_blk, uint32_t n_bins,
                                     uint32_t min_qual, void *cts, void *counters, int num_cus, void *stream);
 int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk, uint32_t n_blk,
@@ -1204,21 +1207,24 @@ static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t n
   }
   if ((rc = bsc_reads_prepare(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, scan_bytes, s))) return rc;
   int e;
-  /* Two forms, same records (tests/test_gpu_reads_chain.py runs both).  TWO KERNELS: bsc_accumulate_kernel leaves the block's
-   * pile-up in HBM and the pile-up-in chain reads it — 104 bytes per position written and read again, and the faster form
-   * (round 4: 5.77 against 6.14 ms per 50 M positions at 30x): alone, the walk runs 24 waves to a CU and hides its byte loads;
-   * inside the chain kernel (128 registers, 16 waves to a CU) it waits for them.  ONE KERNEL (READS = true): neither the pile-up
-   * nor gt_meth in HBM — taken when the context is told to (bsc_set_reads_fused) or the pile-up cannot be allocated. */
+  /* Two forms, same records (tests/test_gpu_reads_chain.py runs both).  TWO KERNELS: the accumulate kernel's summary form
+   * leaves 88 bytes per position in HBM — the counts and the per-site summary of src/call_genotypes.c:44-59 — and the chain
+   * kernel's summary-in form starts from them: the faster form (round 4, per 50 M positions at 30x: 6.14 ms in one kernel, 5.77
+   * through a 104-byte pile-up, less through the summaries): alone, the walk runs 24 waves to a CU and hides its byte loads —
+   * inside the chain kernel (128 registers, 16 waves to a CU) it waits for them — and the summary's arithmetic runs where there
+   * are issue slots to spare.  ONE KERNEL (READS = true): nothing per position in HBM but the records — taken when the context
+   * is told to (bsc_set_reads_fused) or the summaries cannot be allocated. */
   int two_kernels = !ctx->reads_fused;
   if (two_kernels) {
     const size_t n_pad = ((size_t)w.n + 63u) / 64u * 64u;
-    if (bsc_reserve(&ctx->d_cts, &ctx->cap_cts, n_pad * 104u) != BSC_OK) two_kernels = 0; /* no room: the lean form */
+    if (bsc_reserve(&ctx->d_cts, &ctx->cap_cts, n_pad * bsc_dev_summary_bytes()) != BSC_OK) two_kernels = 0; /* no room: the lean form */
   }
   if (two_kernels) {
-    e = bsc_dev_launch_accumulate(ctx->d_rd, ctx->d_boff, d_seq, x, y, (uint32_t)ctx->params.min_qual, ctx->d_cts, ctx->d_counters,
-                                  ctx->num_cus, s);
+    e = bsc_dev_launch_accumulate_summary(ctx->d_rd, ctx->d_boff, d_seq, x, y, (uint32_t)ctx->params.min_qual, ctx->d_cts,
+                                          ctx->d_counters, ctx->num_cus, s);
     if (e) return bsc_fail(BSC_ERR_HIP, "accumulate launch failed: %s", hipGetErrorString((hipError_t)e));
     L.cts = ctx->d_cts;
+    L.cts_summary = 1;
   } else {
     L.rd = ctx->d_rd;
     L.bin_off = ctx->d_boff;

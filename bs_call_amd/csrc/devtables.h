@@ -61,6 +61,8 @@ typedef struct bsc_chain_launch {
   const void *rd, *bin_off, *seq;
   void *f_scratch;
   uint32_t n_bins, min_qual;
+  /* != 0: cts holds site summaries, 88 bytes per position (bsc_dev_launch_accumulate_summary), not pile-ups; whole blocks only */
+  int32_t cts_summary;
 } bsc_chain_launch;
 
 /* one block of a launch of several (bsc_dev_launch_chain_multi, bsc_dev_launch_bin_reads_multi) */

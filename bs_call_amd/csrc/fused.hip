@@ -55,6 +55,9 @@
 #ifndef BSC_RUN_CAP
 #define BSC_RUN_CAP 32 /* longest run of tiles the launcher gives a wave at a time (BSC_CHAIN_RUN_CAP overrides: experiments) */
 #endif
+#define SUM_DW 22 /* dwords of a site summary (accumulate.hip, summary form): counts[2][8], the packed mean qualities (2), aq | mq << 16,
+                     n, 2 spare — 88 bytes: a tile's 64 rows keep every tile's first row on a 16-byte boundary and read without
+                     bank conflicts like the 26-dword pile-up rows */
 #define F_COV_LDS 256 /* coverage rows of the statistics histogram kept in LDS (deeper positions: global atomics) */
 #define F_WORDS (SS_COV + F_COV_LDS * 6)
 #define F_PAIR 32 /* (a, b) < F_PAIR: CpG cytosines counted in the workgroup's LDS pair table; up to SS_PAIR_G: global */
@@ -282,7 +285,7 @@ __device__ static __forceinline__ void f_stats_update(uint32_t *h, const f_facts
  * record the wave stored earlier, the position's statistics.  The whole wave calls this (wave-uniform control flow);
  * the records are read back from memory, so the caller has waited for its record stores (vmcnt).
  */
-template <bool READS>
+template <bool READS, bool SUMM>
 __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigned n_pend, unsigned lane, const uint32_t *__restrict__ cts,
                                                         const uint8_t *__restrict__ dbsnp, const bsc_chain_args &a,
                                                         uint8_t *__restrict__ core_out, const double *s_lf, const double *s_logtab,
@@ -296,7 +299,7 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
     const uint32_t i = pend_e & 0x0fffffffu;
     const unsigned mxi = pend_e >> 28;
     /* READS: cts is the lane's entry of the wave's list (F_HET_DW dwords), else the block's pile-ups in HBM */
-    const uint32_t *p = READS ? cts : cts + (uint64_t)(i + a.lc) * IN_DW;
+    const uint32_t *p = READS ? cts : cts + (uint64_t)(i + a.lc) * (SUMM ? SUM_DW : IN_DW);
     uint32_t f[8], r[8], c[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { /* the list entry was written by this wave: read past the vector L1 */
@@ -320,6 +323,7 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
       /* mq as the calling statements form it (call_body.inc; src/call_genotypes.c:59) */
       int mq;
       if (READS) mq = (int)__hip_atomic_load(&p[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (SUMM) mq = (int)(p[18] >> 16);
       else {
         const uint32_t n_reads = p[16];
         const float mapq2 = __uint_as_float(p[25]);
@@ -361,8 +365,12 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
 
 typedef const __attribute__((address_space(4))) uint32_t *f_cptr;
 
-template <bool FULL, bool READS, bool MULTI>
+/* FULL: the launch's tiles are complete (no bounds checks).  What a tile starts from: READS — the block's reads (the wave piles
+ * them up itself); SUMM — site summaries, 88 bytes per position (the accumulate kernel's summary form: counts and the per-site
+ * summary of src/call_genotypes.c:44-59 already made); neither — pile-ups, 104 bytes per position.  MULTI: several blocks. */
+template <bool FULL, bool READS, bool MULTI, bool SUMM>
 __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_chain_kargs K) {
+  constexpr unsigned ROW_DW = SUMM ? SUM_DW : IN_DW; /* dwords per position of the input array */
   const bsc_dev_tables *__restrict__ const tb = K.tb; /* the set-up below only */
   /* MULTI: the segment the wave's current run belongs to, in scalar registers (F_RUN_SETUP); until the first run the launch-wide
    * members of the kernel's own copy (with_stats ...) */
@@ -433,9 +441,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
 /* the tile's 64 pile-ups (6 656 contiguous bytes, the first on a 16-byte boundary) -> the wave's slot by LDS-DMA */
 #define F_DMA_TILE(JW0, DMA)                                                                                            \
   do {                                                                                                                  \
-    const char *src_ = reinterpret_cast<const char *>(cts + (uint64_t)((int32_t)(JW0) + (int32_t)A_COLD(lc)) * IN_DW) + lane * 16; \
-    _Pragma("unroll") for (int j_ = 0; j_ < 6; j_++) DMA(src_ + j_ * 1024, slot + j_ * 256);                            \
-    if (lane < 32) DMA(src_ + 6 * 1024, slot + 6 * 256);                                                                \
+    const char *src_ = reinterpret_cast<const char *>(cts + (uint64_t)((int32_t)(JW0) + (int32_t)A_COLD(lc)) * ROW_DW) + lane * 16; \
+    constexpr int full_ = (int)(64u * ROW_DW * 4u / 1024u); /* 6 656 bytes = 6.5 KB of pile-ups, 5 632 = 5.5 KB of summaries */ \
+    _Pragma("unroll") for (int j_ = 0; j_ < full_; j_++) DMA(src_ + j_ * 1024, slot + j_ * 256);                        \
+    if (lane < 32) DMA(src_ + full_ * 1024, slot + full_ * 256);                                                        \
   } while (0)
   /* ---- the wave's runs: run k = wave index + a multiple of the number of waves; tile tj of a run starts 62 tj sites
    * after the run's first computed site (all wave-uniform, scalar registers) ---- */
@@ -582,9 +591,9 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       F_DMA_TILE(jw0, dma16);
 #endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the tile was requested before the loop / by the previous tile */
-      const uint2 *rec = reinterpret_cast<const uint2 *>(slot + lane * IN_DW);
+      const uint2 *rec = reinterpret_cast<const uint2 *>(slot + lane * ROW_DW);
 #pragma unroll
-      for (int i = 0; i < IN_DW / 2; i++) {
+      for (int i = 0; i < (int)ROW_DW / 2; i++) {
         const uint2 v = rec[i];
         w[2 * i] = v.x;
         w[2 * i + 1] = v.y;
@@ -592,12 +601,52 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     } else {
       const uint32_t *const ctsp = cts;
 #pragma unroll
-      for (int i = 0; i < IN_DW; i++) w[i] = valid ? ctsp[(uint64_t)(jw + (int32_t)a.lc) * IN_DW + i] : 0u;
+      for (int i = 0; i < (int)ROW_DW; i++) w[i] = valid ? ctsp[(uint64_t)(jw + (int32_t)a.lc) * ROW_DW + i] : 0u;
     }
     WAVE_LDS_SYNC();
+    /* ---- the per-site summary (src/call_genotypes.c:44-59): made here from the pile-up, or taken as the accumulate kernel
+     * made it (the same statements there: call_summary.inc) ---- */
+    uint32_t n_reads, cnt[8], qpack0, qpack1;
+    bool covered;
+    int aq, mq;
+    if (SUMM) {
+      n_reads = w[19];
+      covered = valid && n_reads != 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) cnt[j] = w[j] + w[8 + j];
+      qpack0 = w[16];
+      qpack1 = w[17];
+      aq = (int)(w[18] & 0xffffu);
+      mq = (int)(w[18] >> 16);
+    } else {
+      uint32_t n_o, c_o[8], q0_o, q1_o;
+      bool cov_o;
+      int aq_o, mq_o;
+      {
+#include "call_summary.inc"
+        n_o = n_reads;
+        cov_o = covered;
+#pragma unroll
+        for (int j = 0; j < 8; j++) c_o[j] = cnt[j];
+        q0_o = qpack0;
+        q1_o = qpack1;
+        aq_o = aq;
+        mq_o = mq;
+      }
+      n_reads = n_o;
+      covered = cov_o;
+#pragma unroll
+      for (int j = 0; j < 8; j++) cnt[j] = c_o[j];
+      qpack0 = q0_o;
+      qpack1 = q1_o;
+      aq = aq_o;
+      mq = mq_o;
+    }
     const unsigned rf = valid ? (unsigned)srf[lane + 2u] & 0xffu : 0u; /* my site's reference code (lane index = lane) */
     const double l = K_COLD(l), t = K_COLD(t), lrb = K_COLD(lrb), lrb1 = K_COLD(lrb1);
+#define CALL_SUMMARY_GIVEN
 #include "call_body.inc"
+#undef CALL_SUMMARY_GIVEN
 
     /* ---- block counters (window positions only, not the halo) ---- */
     const bool defer = covered && inner && ((0x16Eu >> mxi) & 1u); /* gt_het[max_gt]: Fisher's test (:61), after the tile */
@@ -1015,7 +1064,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       const unsigned nb = n_pend - k0 < 64u ? n_pend - k0 : 64u;
       const uint32_t *ent = wl + (uint64_t)(k0 + lane0) * (READS ? F_HET_DW : 1u);
       const uint32_t e = lane0 < nb ? __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      f_fisher_pending<READS>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_base, s_lf, s_logtab, s_exptab, h, stat_words);
+      f_fisher_pending<READS, SUMM>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_base, s_lf, s_logtab, s_exptab, h, stat_words);
     }
   }
   if (run >= n_runs_all) break; /* wave-uniform */
@@ -1178,7 +1227,7 @@ static void chain_common(const bsc_chain_launch *L, uint32_t n_all, bsc_chain_ka
   K.aux_out = (uint8_t *)L->aux_out;
 }
 
-template <bool READS>
+template <bool READS, bool SUMM>
 static int chain_launch_t(const bsc_chain_launch *L) {
   hipStream_t s = (hipStream_t)L->stream;
   bsc_chain_kargs K;
@@ -1202,7 +1251,7 @@ static int chain_launch_t(const bsc_chain_launch *L) {
     a.run_extra = p.m_extra;
     unsigned grid = (p.m_runs + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus; /* one 1024-thread workgroup per CU, persistent */
-    hipLaunchKernelGGL((bsc_chain_kernel_t<true, READS, false>), dim3(grid), dim3(64 * FW), 0, s, K);
+    hipLaunchKernelGGL((bsc_chain_kernel_t<true, READS, false, SUMM>), dim3(grid), dim3(64 * FW), 0, s, K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
@@ -1216,7 +1265,7 @@ static int chain_launch_t(const bsc_chain_launch *L) {
     a.run_extra = 0;
     unsigned grid = (a.n_runs + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
-    hipLaunchKernelGGL((bsc_chain_kernel_t<false, READS, false>), dim3(grid), dim3(64 * FW), 0, s, K);
+    hipLaunchKernelGGL((bsc_chain_kernel_t<false, READS, false, SUMM>), dim3(grid), dim3(64 * FW), 0, s, K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
@@ -1313,7 +1362,7 @@ extern "C" int bsc_dev_launch_chain_multi(const bsc_chain_launch *L, const bsc_c
     K.n_segs = n_m;
     unsigned grid = (runs_m + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
-    hipLaunchKernelGGL((bsc_chain_kernel_t<true, true, true>), dim3(grid), dim3(64 * FW), 0, s, K);
+    hipLaunchKernelGGL((bsc_chain_kernel_t<true, true, true, false>), dim3(grid), dim3(64 * FW), 0, s, K);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   }
   if (n_e) {
@@ -1322,7 +1371,7 @@ extern "C" int bsc_dev_launch_chain_multi(const bsc_chain_launch *L, const bsc_c
     K.n_segs = n_e;
     unsigned grid = (runs_e + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
-    hipLaunchKernelGGL((bsc_chain_kernel_t<false, true, true>), dim3(grid), dim3(64 * FW), 0, s, K);
+    hipLaunchKernelGGL((bsc_chain_kernel_t<false, true, true, false>), dim3(grid), dim3(64 * FW), 0, s, K);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   }
   if (gc) /* block by block: the table is keyed by genome position */
@@ -1338,5 +1387,6 @@ extern "C" int bsc_dev_launch_chain_multi(const bsc_chain_launch *L, const bsc_c
 
 extern "C" int bsc_dev_launch_chain(const bsc_chain_launch *L) {
   if (L->n == 0) return 0;
-  return L->rd ? chain_launch_t<true>(L) : chain_launch_t<false>(L);
+  if (L->rd) return chain_launch_t<true, false>(L);
+  return L->cts_summary ? chain_launch_t<false, true>(L) : chain_launch_t<false, false>(L);
 }
