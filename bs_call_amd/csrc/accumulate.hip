@@ -282,7 +282,24 @@ __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel_t(
   const uint32_t span = (uint32_t)counters[BSC_CNT_SPAN]; /* longest read extent, b - a */
   /* Software pipeline over the wave's tiles: while tile i is processed, the first batch of tile i+1 is on its way */
   const uint32_t wt_step = gridDim.x * ACC_WAVES;
-  uint32_t wt = blockIdx.x * ACC_WAVES + wid;
+  /* Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own, and a read is wanted by every tile it
+   * overlaps (2.6 of them at 100 bases): with consecutive workgroups on consecutive tile groups, every XCD fetches nearly
+   * every read (FETCH_SIZE 3.8 GB per 50 M positions at 30x for 1.6 GB of reads).  So the workgroups that share an XCD
+   * (blockIdx % 8: a label, not the XCD's id) take ACC_XCD_CHUNK CONSECUTIVE tile groups at a time — neighbours in the genome
+   * are neighbours in one L2 — while the 8 XCDs work side by side in the same stretch of the genome (one contiguous stretch
+   * per XCD and round halves the fetched bytes too, but was 3 % slower).  Whole chunks only: the ragged end of the grid stays
+   * where it is; a wrong guess about the placement costs speed, nothing else.  ACC_NO_XCD_SWIZZLE: the A/B build. */
+#ifndef ACC_XCD_CHUNK
+#define ACC_XCD_CHUNK 16
+#endif
+#ifndef ACC_NO_XCD_SWIZZLE
+  const uint32_t per8 = 8u * ACC_XCD_CHUNK, full8 = gridDim.x / per8 * per8;
+  const uint32_t lb = blockIdx.x >> 3;
+  const uint32_t vb = blockIdx.x < full8 ? (lb / ACC_XCD_CHUNK) * per8 + (blockIdx.x & 7u) * ACC_XCD_CHUNK + lb % ACC_XCD_CHUNK : blockIdx.x;
+#else
+  const uint32_t vb = blockIdx.x;
+#endif
+  uint32_t wt = vb * ACC_WAVES + wid;
   uint32_t t0 = 0, kv = 0xffffffffu;
   bsc_read_desc d;
   acc_dead(d);
