@@ -49,9 +49,11 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_SIMDS = 1024  # 256 CUs x 4 SIMDs
 VALU_CYCLES_PER_INST = 4  # a wave64 instruction occupies its SIMD's VALU for 4 cycles, FP64 included (78.6 TFLOP/s vector FP64)
 SEED = 88172645463325252
-KERNEL_SOURCES = ("kernels.hip", "callmath.h", "call_body.inc", "bsmath.h", "bsmath_tables.h", "devtables.h")
-READS_SOURCES = ("fused.hip", "accdev.h", "accumulate.hip", "callmath.h", "call_body.inc", "sitestats_dev.h", "bsmath.h", "bsmath_tables.h", "devtables.h")
-CHAIN_SOURCES = ("fused.hip", "accdev.h", "callmath.h", "call_body.inc", "sitestats_dev.h", "bsmath.h", "bsmath_tables.h", "devtables.h")
+KERNEL_SOURCES = ("kernels.hip", "callmath.h", "call_body.inc", "call_summary.inc", "bsmath.h", "bsmath_tables.h", "devtables.h")
+READS_SOURCES = ("fused.hip", "accdev.h", "accumulate.hip", "callmath.h", "call_body.inc", "call_summary.inc", "sitestats_dev.h", "bsmath.h",
+                 "bsmath_tables.h", "devtables.h")
+CHAIN_SOURCES = ("fused.hip", "accdev.h", "callmath.h", "call_body.inc", "call_summary.inc", "sitestats_dev.h", "bsmath.h", "bsmath_tables.h",
+                 "devtables.h")
 
 
 def main():
@@ -391,9 +393,10 @@ def reads_rooflines(args, caller):
         },
         "roofline_reads": {
             "bound": "valu_issue",
-            "kernel": "bsc_bin_count_kernel + prefix sum + bsc_bin_scatter_kernel + bsc_chain_kernel_t<.., READS> (bsc_reads_chain_device), with statistics",
-            "what": "reads -> pile-up -> call -> VCF record -> site statistics; the pile-up lives in the LDS of the wave that calls it, "
-            "gt_meth in its registers; " + block,
+            "kernel": "bsc_bin_count_kernel + prefix sum + bsc_bin_scatter_kernel + bsc_accumulate_kernel_t<summary> + bsc_chain_kernel_t<.., summary-in> "
+            "(bsc_reads_chain_device, its default two-kernel form), with statistics",
+            "what": "reads -> site summaries (counts + the per-site summary of src/call_genotypes.c:44-59, 88 B per position through HBM) -> call -> "
+            "VCF record -> site statistics; gt_meth never leaves the registers; " + block,
             "achieved": r_bytes / (r_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

@@ -136,7 +136,7 @@ struct bsc_context {
   void *d_mblk, *d_mtab;
   size_t cap_mblk, cap_mtab;
   const uint32_t *mb_toff;
-  int reads_fused; /* bsc_set_reads_fused: 1 = the one-kernel form always; 0 = the pile-up through HBM when it can be allocated */
+  int reads_fused; /* bsc_set_reads_fused: 1 = the one-kernel form always; 0 = site summaries through HBM when they can be allocated */
   void *d_fscr; /* reads-in chain: forward-count scratch lines of the resident waves */
   size_t cap_fscr;
   hipEvent_t ev_rchain[2]; /* bsc_set_profiling: the reads-in chain's launches (read descriptors, ordering, tile search, chain) */

@@ -515,12 +515,13 @@ int bsc_reads_chain_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, con
                            uint32_t y, const void *d_ref, const void *d_dbsnp, const bsc_vcf_params *params, int with_stats,
                            void *d_core, void *d_aux, void *stream);
 int bsc_last_reads_chain_ms(bsc_context *ctx, float *ms);
-/* How bsc_reads_chain_device / bsc_block_records get from reads to records.  0 (default): two kernels — the stand-alone
- * accumulate kernel leaves the block's pile-up in HBM (104 bytes per position, the context's own workspace) and the pile-up-in
- * chain reads it: the faster form (the walk alone runs at 24 waves to a CU and hides its byte loads; inside the 128-register
- * chain kernel it waits for them), taken whenever that workspace can be allocated.  1: always the ONE-kernel form (READS-in
- * chain: neither the pile-up nor gt_meth in HBM).  Same records and statistics either way.  (bsc_blocks_records always runs the
- * one-kernel form: small blocks are bound by launches and PCIe, not by the walk.) */
+/* How bsc_reads_chain_device / bsc_block_records get from reads to records.  0 (default): TWO kernels — the accumulate kernel's
+ * summary form leaves 88 bytes per position in HBM (counts[2][8] and the per-site summary of src/call_genotypes.c:44-59; the
+ * context's own workspace) and the chain kernel's summary-in form starts from them: the faster form (the walk alone runs at 24
+ * waves to a CU and hides its byte loads — inside the 128-register chain kernel it waits for them — and the summary's arithmetic
+ * runs where there are issue slots to spare), taken whenever that workspace can be allocated.  1: always the ONE-kernel form
+ * (reads-in chain: nothing per position in HBM but the records).  Same records and statistics either way.  (bsc_blocks_records
+ * always runs the one-kernel form: small blocks are bound by launches and PCIe, not by the walk.) */
 int bsc_set_reads_fused(bsc_context *ctx, int fused);
 /* Positions that one round of the device's resident waves covers (CUs x waves per workgroup x 60).  A caller that cuts a
  * resident contig into windows of its own choosing (the reference's blocks are data dependent, src/process_template.c:24-28;

@@ -26,6 +26,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--chunk", type=int, default=1_000_000)
 ap.add_argument("--no-chain", action="store_true")
 ap.add_argument("--no-check", action="store_true")
+ap.add_argument("--one-kernel", action="store_true", help="the reads-in chain kernel (bsc_set_reads_fused) instead of the default two-kernel form")
 ap.add_argument("--warm", type=int, default=2, help="untimed launches in front of each timed loop (the first ~20 ms after an idle stretch run below the steady clock)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -42,6 +43,8 @@ with B.SiteCaller() as c:
     d_cts = torch.empty(n_pad * 104, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     c.set_profiling(True)
+    c.set_reads_fused(args.one_kernel)
+    res["reads_path"] = "one kernel (reads-in chain)" if args.one_kernel else "two kernels (site summaries through HBM)"
     ms, wall = [], []
     for it in range(args.warm + args.steps):
         torch.cuda.synchronize()

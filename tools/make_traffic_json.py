@@ -24,7 +24,9 @@ def per_dispatch(sub, name, kernel="bsc_call_kernel"):
     agg = {}
     for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == name and kernel in r.get("Kernel_Name", "") and "ILb0E" not in r["Kernel_Name"] and "<false" not in r["Kernel_Name"]:
+            kn = r.get("Kernel_Name", "")
+            # the launch's complete tiles only (bsc_call_kernel_t<true>, bsc_chain_kernel_t<true, ...>), unless a full name was asked for
+            if r.get("Counter_Name") == name and kernel in kn and ("<" in kernel or ("ILb0E" not in kn and "_t<false" not in kn)):
                 k = r["Dispatch_Id"]
                 agg[k] = agg.get(k, 0.0) + float(r["Counter_Value"])
     v = list(agg.values())
@@ -43,7 +45,7 @@ out = {
     "kernel_source_sha256_16": bench.kernel_source_hash(),
 }
 if os.path.isdir(os.path.join(d, "chain_fetch")):
-    cf, cw = per_dispatch("chain_fetch", "FETCH_SIZE", "bsc_chain_kernel"), per_dispatch("chain_write", "WRITE_SIZE", "bsc_chain_kernel")
+    cf, cw = per_dispatch("chain_fetch", "FETCH_SIZE", "bsc_chain_kernel_t<true, false, false, false>"), per_dispatch("chain_write", "WRITE_SIZE", "bsc_chain_kernel_t<true, false, false, false>")
     out["chain"] = {
         "_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python tools/bench_chain.py --no-unfused --steps 2`, "
         "bsc_chain_kernel_t<true>, per dispatch, with statistics",
@@ -55,15 +57,24 @@ if os.path.isdir(os.path.join(d, "chain_fetch")):
         "kernel_source_sha256_16": bench.kernel_source_hash(bench.CHAIN_SOURCES),
     }
 if os.path.isdir(os.path.join(d, "reads_fetch")):
-    # the reads-in chain's kernel (READS = true) and the stand-alone accumulate kernel, from tools/bench_reads.py under --pmc
-    rf, rw = per_dispatch("reads_fetch", "FETCH_SIZE", "bsc_chain_kernel_t<true, true>"), per_dispatch("reads_write", "WRITE_SIZE", "bsc_chain_kernel_t<true, true>")
-    af, aw = per_dispatch("reads_fetch", "FETCH_SIZE", "bsc_accumulate_kernel"), per_dispatch("reads_write", "WRITE_SIZE", "bsc_accumulate_kernel")
+    # tools/bench_reads.py under --pmc: the stand-alone accumulate kernel (bsc_accumulate_device) and the two kernels of
+    # bsc_reads_chain_device's default form — the accumulate kernel's summary form and the chain kernel's summary-in form
+    def two(kernel):
+        return per_dispatch("reads_fetch", "FETCH_SIZE", kernel), per_dispatch("reads_write", "WRITE_SIZE", kernel)
+
+    af, aw = two("bsc_accumulate_kernel_t<false>")
+    sf, sw = two("bsc_accumulate_kernel_t<true>")
+    cf, cw = two("bsc_chain_kernel_t<true, false, false, true>")
     src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python tools/bench_reads.py --steps 2 --no-check`, per dispatch"
     h = bench.kernel_source_hash(bench.READS_SOURCES)
-    out["reads"] = {"_source": src + ", bsc_chain_kernel_t<true, true> (the dominant kernel of bsc_reads_chain_device)", "positions": positions,
-                    "coverage": coverage, "fetch_size_kib": rf, "write_size_kib": rw, "hbm_bytes_per_launch": int((2 * rf + rw) * 1024),
+    out["reads"] = {"_source": src + ", bsc_accumulate_kernel_t<true> + bsc_chain_kernel_t<true, false, false, true> (the two kernels of "
+                    "bsc_reads_chain_device; the 88-byte summaries are written by the first and read by the second: HBM bytes the "
+                    "algorithmic count does not have)", "positions": positions, "coverage": coverage,
+                    "fetch_size_kib": sf + cf, "write_size_kib": sw + cw, "hbm_bytes_per_launch": int((2 * (sf + cf) + sw + cw) * 1024),
+                    "kernels": {"bsc_accumulate_kernel_t<true>": {"fetch_size_kib": sf, "write_size_kib": sw},
+                                "bsc_chain_kernel_t<true, false, false, true>": {"fetch_size_kib": cf, "write_size_kib": cw}},
                     "kernel_source_sha256_16": h}
-    out["accumulate"] = {"_source": src + ", bsc_accumulate_kernel (the dominant kernel of bsc_accumulate_device)", "positions": positions,
+    out["accumulate"] = {"_source": src + ", bsc_accumulate_kernel_t<false> (the dominant kernel of bsc_accumulate_device)", "positions": positions,
                          "coverage": coverage, "fetch_size_kib": af, "write_size_kib": aw, "hbm_bytes_per_launch": int((2 * af + aw) * 1024),
                          "kernel_source_sha256_16": h}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)

@@ -67,12 +67,16 @@ path = os.path.join(ROOT, "profiles", "valu.json")
 out = json.load(open(path)) if os.path.exists(path) else {}
 if "call" in opt:
     out["call"] = leg(opt["call"], [("bsc_call_kernel", 1), ("bsc_fisher_kernel", 1)], bench.KERNEL_SOURCES)
+# kernel-name substrings as rocprofv3 prints them: bsc_chain_kernel_t<FULL, READS, MULTI, SUMM>, bsc_accumulate_kernel_t<SUMM>
 if "chain" in opt:
-    out["chain"] = leg(opt["chain"], [("bsc_chain_kernel_t<true, false>", 1), ("bsc_chain_kernel_t<false, false>", 2)], bench.CHAIN_SOURCES)
-if "reads" in opt:
-    out["reads"] = leg(opt["reads"], [("bsc_chain_kernel_t<true, true>", 1), ("bsc_chain_kernel_t<false, true>", 2), ("bsc_bin_count_kernel", 1),
-                                      ("bsc_bin_scatter_kernel", 1)], bench.READS_SOURCES)
+    out["chain"] = leg(opt["chain"], [("bsc_chain_kernel_t<true, false, false, false>", 1), ("bsc_chain_kernel_t<false, false, false, false>", 2)],
+                       bench.CHAIN_SOURCES)
+if "reads" in opt:  # bsc_reads_chain_device's default form: summaries through HBM
+    out["reads"] = leg(opt["reads"], [("bsc_chain_kernel_t<true, false, false, true>", 1), ("bsc_chain_kernel_t<false, false, false, true>", 2),
+                                      ("bsc_accumulate_kernel_t<true>", 1), ("bsc_bin_count_kernel", 1), ("bsc_bin_scatter_kernel", 1)],
+                       bench.READS_SOURCES)
 if "acc" in opt:
-    out["accumulate"] = leg(opt["acc"], [("bsc_accumulate_kernel", 1), ("bsc_bin_count_kernel", 1), ("bsc_bin_scatter_kernel", 1)], bench.READS_SOURCES)
+    out["accumulate"] = leg(opt["acc"], [("bsc_accumulate_kernel_t<false>", 1), ("bsc_bin_count_kernel", 1), ("bsc_bin_scatter_kernel", 1)],
+                            bench.READS_SOURCES)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
