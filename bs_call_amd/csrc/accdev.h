@@ -86,7 +86,7 @@ __device__ static __forceinline__ uint32_t acc_tile_start(const acc_reads &R, in
  * number: the lanes in front of the tile's first position wrap to huge values and fall out of the range of every read) and
  * bumps its own pile-up row (`row`, 26 dwords in LDS, zeroed by the caller; counts and INTEGER quality sums, the caller
  * converts).  The wave walks the candidate reads from the t0-th in key order — the first batch (kv, d) fetched by the
- * caller — until a read starts right of the tile.  Returns the lane's MAPQ^2 sum (saturating).
+ * caller — until a read starts right of the tile.  The lane's MAPQ^2 sum comes back in two parts (m2sum, m2cnt; see acc_unpack).
  *
  * The VALU is what this loop (and the kernels around it) run out of, so the work per (read, tile) pair is kept off it where
  * possible.  What depends on the read and the tile but not on the lane — the read's lane range, its orientation, its
@@ -109,9 +109,11 @@ __device__ static __forceinline__ uint32_t acc_tile_start(const acc_reads &R, in
 template <bool PACKED>
 __device__ static __forceinline__ bool acc_walk(const acc_reads &R, uint32_t n_live, unsigned lane, uint32_t lane_p, uint32_t *row,
                                                 uint32_t pa, uint32_t p_last, uint32_t r_last, uint32_t min_qual, uint32_t q_span,
-                                                uint32_t t0, uint32_t kv, bsc_read_desc d, uint32_t &m2sum) {
+                                                uint32_t t0, uint32_t kv, bsc_read_desc d, uint32_t m2_ref, uint32_t &m2sum,
+                                                uint32_t &m2cnt) {
   const uint8_t *__restrict__ const seq = R.seq;
-  m2sum = 0; /* mapq2 of this lane's position */
+  m2sum = 0; /* MAPQ^2 of this lane's counted bases from reads whose MAPQ^2 is not m2_ref ... */
+  m2cnt = 0; /* ... and their number (acc_unpack puts the lane's sum together) */
   uint32_t applied = 0; /* reads applied to the tile so far: no cell can hold more bases than that */
   const uint32_t b_lo = min_qual << 2, b_span = q_span << 2; /* the window test on the byte: quality in [min_qual, 63) */
   bool more = true;
@@ -168,8 +170,15 @@ __device__ static __forceinline__ bool acc_walk(const acc_reads &R, uint32_t n_l
         atomicAdd(reinterpret_cast<uint32_t *>(rc), 1u);                                  /* counts[ori][c]++ */ \
         atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(row) + c4 + 68), byte >> 2); /* quality[c] += q */ \
       }                                                                                                          \
-      m2sum = __builtin_elementwise_add_sat(m2sum, pks >> 16); /* mapq2 += mapq^2 (v_add_u32 clamp: a sum past   \
-                                                                  2^32 sticks there, so INEXACT cannot be missed) */ \
+      /* mapq2 += mapq^2: a read with the tile's reference MAPQ^2 (nearly every read) costs nothing here — its bases \
+       * are counted in the row anyway and acc_unpack multiplies; the others add theirs (v_add_u32 clamp: a sum   \
+       * past 2^32 sticks there, so INEXACT cannot be missed) and are counted.  The test is on scalar registers;  \
+       * the empty assembly keeps it a branch (if-converted it is three vector instructions for every read) */   \
+      if ((pks >> 16) != m2_ref) {                                                                               \
+        asm volatile("; a read off the reference MAPQ^2");                                                       \
+        m2sum = __builtin_elementwise_add_sat(m2sum, pks >> 16);                                                 \
+        m2cnt++;                                                                                                 \
+      }                                                                                                          \
     }                                                                                                            \
   }
 #if ACC_GROUP == 16
@@ -222,7 +231,8 @@ __device__ static __forceinline__ bool acc_walk(const acc_reads &R, uint32_t n_l
 /* The lane's row after the walk -> the 26 dwords of its `pileup` record (include/bs_call.h:174-182) in w[]: counts[2][8], n,
  * the eight quality sums and the MAPQ^2 sum as the floats the reference accumulates (integer sums convert exactly below
  * 2^24: DESIGN.md section 2).  Returns whether a sum left that range (BSC_WARN_INEXACT). */
-__device__ static __forceinline__ bool acc_unpack(const uint32_t *row, bool packed, uint32_t m2, uint32_t w[26]) {
+__device__ static __forceinline__ bool acc_unpack(const uint32_t *row, bool packed, uint32_t m2_ref, uint32_t m2sum, uint32_t m2cnt,
+                                                  uint32_t w[26]) {
   uint32_t qs[8], n = 0;
   if (packed) {
 #pragma unroll
@@ -241,6 +251,11 @@ __device__ static __forceinline__ bool acc_unpack(const uint32_t *row, bool pack
 #pragma unroll
   for (int j = 0; j < 16; j++) n += w[j];
   w[16] = n;
+  /* the position's MAPQ^2 sum: its n - m2cnt bases from reads with the reference value, and the others' own sum; what the
+   * reference's sequence of float additions gives is this integer as a float while it stays below 2^24, and a sum past 2^32
+   * (where a chain of saturating additions would stick) is as inexact as one past 2^24 */
+  const uint64_t m2w = (uint64_t)m2_ref * (uint64_t)(n - m2cnt) + (uint64_t)m2sum;
+  const uint32_t m2 = (m2sum == 0xffffffffu || m2w > 0xffffffffull) ? 0xffffffffu : (uint32_t)m2w;
   bool inexact = m2 >= (1u << 24);
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -255,16 +270,18 @@ __device__ static __forceinline__ bool acc_unpack(const uint32_t *row, bool pack
 __device__ static __forceinline__ bool acc_tile(const acc_reads &R, uint32_t n_live, unsigned lane, uint32_t lane_p, uint32_t *row,
                                                 uint32_t pa, uint32_t p_last, uint32_t r_last, uint32_t min_qual, uint32_t q_span,
                                                 uint32_t t0, uint32_t kv, const bsc_read_desc &d, uint32_t w[26]) {
-  uint32_t m2;
+  uint32_t m2sum, m2cnt;
+  /* the tile's reference MAPQ^2: its first candidate's (any value gives the same sums; the common one gives them cheaply) */
+  const uint32_t m2_ref = (uint32_t)__builtin_amdgcn_readfirstlane(d.meta) >> 16;
 #pragma unroll
   for (int i = 0; i < 8; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
-  bool packed = acc_walk<true>(R, n_live, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2);
+  bool packed = acc_walk<true>(R, n_live, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2_ref, m2sum, m2cnt);
   if (__builtin_expect(!packed, 0)) {
 #pragma unroll
     for (int i = 0; i < 13; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
-    (void)acc_walk<false>(R, n_live, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2);
+    (void)acc_walk<false>(R, n_live, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2_ref, m2sum, m2cnt);
   }
-  return acc_unpack(row, packed, m2, w);
+  return acc_unpack(row, packed, m2_ref, m2sum, m2cnt, w);
 }
 
 #endif /* BSCALL_AMD_ACCDEV_H */
