@@ -70,6 +70,7 @@ EXPORTS = (
     "bsc_bam_next_block",
     "bsc_bam_filter_counts",
     "bsc_chain_window_quantum",
+    "bsc_chain_window_size",
     "bsc_prepare_templates",
     "bsc_prepare_templates_profile",
     "bsc_block_start",
@@ -324,6 +325,8 @@ def load():
     L.bsc_bcf_block.argtypes = [vp, u64, i32, C.POINTER(BcfIds), vp, vp, C.c_size_t, C.POINTER(u64)]
     L.bsc_report_json.restype = C.c_long
     L.bsc_report_json.argtypes = [C.POINTER(Report), C.c_char_p, C.c_size_t]
+    L.bsc_chain_window_size.restype = C.c_uint32
+    L.bsc_chain_window_size.argtypes = [vp, C.c_uint32]
     L.bsc_chain_window_quantum.restype = C.c_uint32
     L.bsc_chain_window_quantum.argtypes = [vp]
     L.bsc_last_chain_ms.restype = i32

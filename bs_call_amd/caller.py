@@ -260,6 +260,10 @@ class SiteCaller:
         _check(self._L.bsc_last_reads_chain_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def window_size(self, limit: int) -> int:
+        """The largest window <= limit positions in which every resident wave runs the same number of tiles (`bsc_chain_window_size`)."""
+        return int(self._L.bsc_chain_window_size(self._h, int(limit)))
+
     def window_quantum(self) -> int:
         """Positions one round of the resident waves covers (`bsc_chain_window_quantum`)."""
         return int(self._L.bsc_chain_window_quantum(self._h))

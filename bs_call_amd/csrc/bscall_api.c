@@ -50,6 +50,7 @@ int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const
                        void *out, int num_cus, void *stream);
 int bsc_dev_launch_chain(const bsc_chain_launch *L); /* fused.hip */
 unsigned bsc_dev_chain_quantum(int num_cus);
+unsigned bsc_dev_chain_window(int num_cus, unsigned limit);
 int bsc_dev_launch_synth(uint64_t seed, uint64_t first_site, uint64_t n, uint32_t coverage, uint32_t flags, void *cts,
                          void *ref, int num_cus, void *stream);
 size_t bsc_dev_chain_het_bytes(uint32_t n, int num_cus, int with_depth, int reads);
@@ -1271,6 +1272,7 @@ int bsc_last_reads_chain_ms(bsc_context *ctx, float *ms) {
 }
 
 uint32_t bsc_chain_window_quantum(const bsc_context *ctx) { return ctx ? bsc_dev_chain_quantum(ctx->num_cus) : 0u; }
+uint32_t bsc_chain_window_size(const bsc_context *ctx, uint32_t limit) { return ctx ? bsc_dev_chain_window(ctx->num_cus, limit) : 0u; }
 
 int bsc_last_chain_ms(bsc_context *ctx, float *ms) {
   if (!ctx || !ms) return bsc_fail(BSC_ERR_ARG, "bsc_last_chain_ms: NULL argument");

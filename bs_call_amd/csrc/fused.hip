@@ -1130,6 +1130,14 @@ extern "C" __global__ __launch_bounds__(1024) void bsc_gc_cov_kernel(const uint1
  * number of tiles (no partly filled last round) */
 extern "C" unsigned bsc_dev_chain_quantum(int num_cus) { return (unsigned)num_cus * FW * FT; }
 
+/* the largest window <= limit in which every resident wave gets ONE run of the same number of tiles: waves x (60 + 62 k) */
+extern "C" unsigned bsc_dev_chain_window(int num_cus, unsigned limit) {
+  const unsigned waves = (unsigned)num_cus * FW;
+  if (limit < waves * FT) return limit / FT * FT;
+  const unsigned k = (limit / waves - FT) / FT2;
+  return waves * (FT + FT2 * k);
+}
+
 /* entries of one wave's heterozygous list: the kernel tests the listed calls whenever fewer than 64 entries are free */
 #define F_HET_CAP 512u
 static uint32_t chain_het_cap(uint32_t tiles, unsigned grid) {
@@ -1179,6 +1187,14 @@ static chain_plan chain_plan_block(uint32_t n, uint32_t lc, uint32_t rc, bool al
   const uint64_t rounds = (per_wave + (uint64_t)run_cap - 1) / (uint64_t)run_cap; /* runs a wave gets */
   uint64_t nr = rounds * waves;
   if (nr > (uint64_t)avail / FT) nr = (uint64_t)avail / FT;                       /* every run has a first tile of 60 records */
+  /* 60 nr + 62 more = avail exactly for some nr among any 31 consecutive values when avail is even (60 nr = -2 nr mod 62): a
+   * few runs fewer, and nothing is left behind the main part for a guarded launch of its own — which a 4 Mi-position window of
+   * a resident contig, with its context either side, would otherwise pay (20 us + a launch gap on 350 us) */
+  for (uint64_t k = 0; k <= 30 && k < nr; k++)
+    if (((uint64_t)avail - (nr - k) * FT) % FT2 == 0) {
+      nr -= k;
+      break;
+    }
   const uint64_t more = ((uint64_t)avail - nr * FT) / FT2;                        /* further tiles, 62 records each */
   p.m_runs = (uint32_t)nr;
   p.m_tiles = 1u + (uint32_t)(more / nr);

@@ -24,12 +24,10 @@ BYTES_PER_POSITION = PILEUP_BYTES + 1 + CORE_BYTES  # resident: pile-up + refere
 
 
 def window_for(caller, limit: int = shard.WINDOW) -> int:
-    """The largest window <= `limit` positions (4 Mi) that gives every resident wave of the fused kernel
-    the same number of 60-position tiles: a multiple of `bsc_chain_window_quantum` (256 CUs x 16 waves x 60 = 245 760 on
-    an MI355X -> 17 rounds = 4 177 920 positions).  With WINDOW (69 905 tiles over 4 096 waves) a few waves run an 18th
-    tile while the others idle: 5 % of every window."""
-    q = caller.window_quantum()
-    return (limit // q) * q if limit >= q else (limit // 60) * 60
+    """The largest window <= `limit` positions (4 Mi) in which every resident wave of the fused kernel runs the
+    same number of tiles and nothing is left for a guarded launch (`bsc_chain_window_size`: 256 CUs x 16 waves x (60 + 62 k) on
+    an MI355X -> k = 15, 4 055 040 positions: the first tile of a wave's run forms 60 records, every further one 62)."""
+    return caller.window_size(limit)
 
 
 def contig_first_sites(lengths: Sequence[int], pad: int = 64) -> List[int]:

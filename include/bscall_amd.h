@@ -523,10 +523,12 @@ int bsc_last_reads_chain_ms(bsc_context *ctx, float *ms);
  * (reads-in chain: nothing per position in HBM but the records).  Same records and statistics either way.  (bsc_blocks_records
  * always runs the one-kernel form: small blocks are bound by launches and PCIe, not by the walk.) */
 int bsc_set_reads_fused(bsc_context *ctx, int fused);
-/* Positions that one round of the device's resident waves covers (CUs x waves per workgroup x 60).  A caller that cuts a
- * resident contig into windows of its own choosing (the reference's blocks are data dependent, src/process_template.c:24-28;
- * SURVEY.md 8d fixes 4 Mi) should make them a multiple of this: every wave then gets the same number of tiles. 0 if ctx
- * is NULL. */
+/* Window sizes for a caller that cuts a resident contig into windows of its own choosing (the reference's blocks are data
+ * dependent, src/process_template.c:24-28; SURVEY.md 8d fixes 4 Mi).  bsc_chain_window_size: the largest window <= limit in
+ * which every resident wave runs the same number of tiles and the main launch covers the window exactly — CUs x waves per
+ * workgroup x (60 + 62 k): the first tile of a wave's run forms 60 records, every further one 62.  bsc_chain_window_quantum:
+ * the smallest such window (k = 0).  0 if ctx is NULL. */
+uint32_t bsc_chain_window_size(const bsc_context *ctx, uint32_t limit);
 uint32_t bsc_chain_window_quantum(const bsc_context *ctx);
 /* with bsc_set_profiling: device time of the most recent bsc_chain_device call (all of its launches) */
 int bsc_last_chain_ms(bsc_context *ctx, float *ms);

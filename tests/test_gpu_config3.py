@@ -28,7 +28,8 @@ def test_rank0_of_8_share(oracle, tables, libm_exact):
         torch.cuda.synchronize()
         # the window bench.py walks with: whole rounds of the resident waves within SURVEY 8(d)'s 4 Mi
         win = genome.window_for(c)
-        assert win % c.window_quantum() == 0 and win % 60 == 0 and shard.WINDOW - c.window_quantum() < win <= shard.WINDOW
+        waves = c.window_quantum() // 60
+        assert win % waves == 0 and (win // waves - 60) % 62 == 0 and shard.WINDOW - waves * 62 < win <= shard.WINDOW
         nwin = sum(genome.walk_contig(c, rc, win, True) for rc in res)
         torch.cuda.synchronize()
         assert nwin == sum((lengths[k] + win - 1) // win for k in mine)
