@@ -88,6 +88,16 @@ $(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accu
 oracle:
 	$(MAKE) -C oracle liboracle.so
 
+# The library with its HOST C files under AddressSanitizer + UndefinedBehaviorSanitizer (gcc's runtimes; the device objects
+# are the ordinary ones): what tests/test_host_sanitizers.py and tools/fuzz_host_inputs.py run the readers and the host
+# logic under, on the CPU.  Load it with LD_PRELOAD=<libasan.so>:<libubsan.so> BSCALL_AMD_LIB=$(LIBDIR)/san/libbscall_amd_san.so.
+SANFLAGS = -O1 -g -fPIC -Wall -ffp-contract=off -std=gnu11 -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer
+HOST_C = bscall_api synth_reads vcf_format dbsnp prep report bcf bamio refseq
+san: $(LIBDIR)/libbscall_amd.so
+	@mkdir -p $(LIBDIR)/san
+	for f in $(HOST_C); do $(CC) $(SANFLAGS) -c $(CSRC)/$$f.c -o $(LIBDIR)/san/$$f.o || exit 1; done
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/san/libbscall_amd_san.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(addprefix $(LIBDIR)/san/,$(addsuffix .o,$(HOST_C))) -L$(dir $(shell $(CC) -print-file-name=libasan.so)) -lasan -lubsan -lm -lz -lpthread
+
 # a plain-C host program against the C ABI: gcc only, links the shared library like bs_call would
 demo: $(LIBDIR)/demo_block $(LIBDIR)/bam2bcf
 $(LIBDIR)/demo_block: integration/demo_block.c integration/mock_work.h integration/amd_overlap_protocol.h include/bscall_amd.h $(LIBDIR)/libbscall_amd.so
@@ -117,7 +127,7 @@ asm: $(CSRC)/kernels.hip
 	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -Rpass-analysis=kernel-resource-usage $< -o $(LIBDIR)/kernels.s
 
 clean:
-	rm -f $(LIBDIR)/*.o $(LIBDIR)/*.so $(LIBDIR)/*.s $(LIBDIR)/demo_block $(LIBDIR)/bam2bcf
+	rm -rf $(LIBDIR)/san; rm -f $(LIBDIR)/*.o $(LIBDIR)/*.so $(LIBDIR)/*.s $(LIBDIR)/demo_block $(LIBDIR)/bam2bcf
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle demo asm clean glue-check
+.PHONY: all oracle demo asm clean glue-check san

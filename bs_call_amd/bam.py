@@ -37,11 +37,11 @@ class BamReader:
     def refs(self):
         """[(name, length)] of the @SQ list, in header order (a block's tid indexes it)."""
         n = self._L.bsc_bam_n_refs(self._h)
-        return [(self._L.bsc_bam_ref_name(self._h, i).decode(), int(self._L.bsc_bam_ref_len(self._h, i))) for i in range(n)]
+        return [(self._L.bsc_bam_ref_name(self._h, i).decode("utf-8", "replace"), int(self._L.bsc_bam_ref_len(self._h, i))) for i in range(n)]
 
     @property
     def header_text(self):
-        return self._L.bsc_bam_header_text(self._h).decode()
+        return self._L.bsc_bam_header_text(self._h).decode("utf-8", "replace")
 
     def blocks(self):
         """Yields (tid, y, RAW_TEMPLATE[nr], read bytes, MISMS[]) per block, copies (the library's block lives until the

@@ -599,7 +599,9 @@ def prepare_templates(raw, seq, misms, left_trim=(0, 0), right_trim=(0, 0), min_
     misms = np.ascontiguousarray(misms, dtype=MISMS)
     par = np.zeros(1, dtype=PREP_PARAMS)
     par["left_trim"][0], par["right_trim"][0], par["min_qual"][0] = left_trim, right_trim, min_qual
-    cap = int(seq.size) + int(misms["size"][misms["type"] == 1].sum()) + 16
+    # room for the prepared bytes: the reads plus what their listed insertions can add; a size field larger than the block's
+    # bytes is damage (the entry refuses it), not a reason to reserve gigabytes
+    cap = int(seq.size) + int(np.minimum(misms["size"][misms["type"] == 1].astype(np.uint64), np.uint64(seq.size)).sum()) + 16
     out_tpl = np.zeros(len(raw), dtype=TEMPLATE)
     out_seq = np.zeros(cap, dtype=np.uint8)
     used = C.c_uint64(0)

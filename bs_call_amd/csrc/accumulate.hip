@@ -112,9 +112,13 @@ __device__ static __forceinline__ void template_block(const bsc_chain_mblock *__
   bin0 = blk[lo].bin0;
 }
 
+#ifndef BIN_WG
 #define BIN_WG 256   /* templates per workgroup */
+#endif
+#ifndef BIN_WIN
 #define BIN_WIN 1024 /* bins of the workgroup's LDS window: a coordinate-ordered align_list keeps a workgroup's 512 reads
                         within a few dozen bins; reads outside the window take a global atomic each */
+#endif
 
 /* the workgroup's window starts at the lowest bin among its live reads */
 __device__ static __forceinline__ uint32_t wg_min_bin(uint32_t b0, uint32_t b1, uint32_t *s_min) {

@@ -469,22 +469,51 @@ int bsc_bam_open_threads(const char *path, int n_threads, bsc_bam **out) {
     return BSC_OK;
   }
   if (bgzf_read(&b->z, h + 4, 4) <= 0) goto bad;
-  b->l_text = le32(h + 4);
-  b->text = malloc((size_t)b->l_text + 1);
-  if (!b->text || (b->l_text && bgzf_read(&b->z, b->text, b->l_text) <= 0) || bgzf_read(&b->z, h, 4) <= 0) goto bad;
-  b->text[b->l_text] = 0;
-  b->n_ref = (int32_t)le32(h);
-  if (b->n_ref < 0) goto bad;
-  b->ref_name = calloc((size_t)b->n_ref + 1, sizeof *b->ref_name);
-  b->ref_len = calloc((size_t)b->n_ref + 1, sizeof *b->ref_len);
+  /* l_text and n_ref come from the file, and neither is believed before the bytes behind it have arrived: the text grows
+   * with what the stream delivers, the reference list by doubling, so a damaged count costs an error and not gigabytes */
+  {
+    const uint32_t l_text = le32(h + 4);
+    size_t cap = 0;
+    while (b->l_text < l_text) {
+      const uint32_t step = l_text - b->l_text < (1u << 20) ? l_text - b->l_text : (1u << 20);
+      if ((size_t)b->l_text + step + 1 > cap) {
+        cap = ((size_t)b->l_text + step) * 2 + 1;
+        if (cap > (size_t)l_text + 1) cap = (size_t)l_text + 1;
+        char *nt = realloc(b->text, cap);
+        if (!nt) goto bad;
+        b->text = nt;
+      }
+      if (bgzf_read(&b->z, b->text + b->l_text, step) <= 0) goto bad;
+      b->l_text += step;
+    }
+    if (!b->text && !(b->text = malloc(1))) goto bad;
+    b->text[b->l_text] = 0;
+  }
+  if (bgzf_read(&b->z, h, 4) <= 0) goto bad;
+  const int32_t n_ref = (int32_t)le32(h);
+  if (n_ref < 0) goto bad;
+  size_t ref_cap = (size_t)(n_ref < 1024 ? n_ref : 1024) + 1;
+  b->ref_name = calloc(ref_cap, sizeof *b->ref_name);
+  b->ref_len = calloc(ref_cap, sizeof *b->ref_len);
   if (!b->ref_name || !b->ref_len) goto bad;
-  for (int32_t i = 0; i < b->n_ref; i++) {
+  for (int32_t i = 0; i < n_ref; i++) { /* b->n_ref counts the entries filled so far: what bsc_bam_close() frees */
+    if ((size_t)i + 1 >= ref_cap) {
+      ref_cap *= 2;
+      char **nn = realloc(b->ref_name, ref_cap * sizeof *b->ref_name);
+      if (nn) b->ref_name = nn;
+      uint32_t *nl = realloc(b->ref_len, ref_cap * sizeof *b->ref_len);
+      if (nl) b->ref_len = nl;
+      if (!nn || !nl) goto bad;
+    }
     if (bgzf_read(&b->z, h, 4) <= 0) goto bad;
     const uint32_t ln = le32(h);
     if (ln == 0 || ln > 65536) goto bad;
-    b->ref_name[i] = malloc(ln);
-    if (!b->ref_name[i] || bgzf_read(&b->z, b->ref_name[i], ln) <= 0 || bgzf_read(&b->z, h, 4) <= 0) goto bad;
-    b->ref_name[i][ln - 1] = 0;
+    char *nm = malloc(ln);
+    if (!nm) goto bad;
+    b->ref_name[i] = nm;
+    b->n_ref = i + 1;
+    if (bgzf_read(&b->z, nm, ln) <= 0 || bgzf_read(&b->z, h, 4) <= 0) goto bad;
+    nm[ln - 1] = 0;
     b->ref_len[i] = le32(h);
   }
   *out = b;
@@ -689,7 +718,12 @@ static long sam_encode_line(bsc_bam *b, size_t ll) {
   }
   uint8_t *r = b->rec;
   const uint32_t flag = (uint32_t)strtoul(f[1], NULL, 10), mapq = (uint32_t)strtoul(f[4], NULL, 10);
-  const int32_t pos = (int32_t)strtol(f[3], NULL, 10) - 1, mpos = (int32_t)strtol(f[7], NULL, 10) - 1, tlen = (int32_t)strtol(f[8], NULL, 10);
+  /* POS / PNEXT: 0 .. 2^31 - 1 (section 1.4; a BAM record holds them minus one as int32), TLEN: -2^31 + 1 .. 2^31 - 1; a value
+   * outside is an error as in sam_parse1, not a wrapped number */
+  const long long pos1 = strtoll(f[3], NULL, 10), mpos1 = strtoll(f[7], NULL, 10), tlen1 = strtoll(f[8], NULL, 10);
+  if (pos1 < 0 || pos1 > 0x7fffffffLL || mpos1 < 0 || mpos1 > 0x7fffffffLL || tlen1 < -0x7fffffffLL || tlen1 > 0x7fffffffLL)
+    return bsc_set_error(BSC_ERR_ARG, "SAM: position or template length out of range in the line of read '%s'", f[0]);
+  const int32_t pos = (int32_t)(pos1 - 1), mpos = (int32_t)(mpos1 - 1), tlen = (int32_t)tlen1;
 #define PUT32(off, v)                        \
   do {                                       \
     const uint32_t v_ = (uint32_t)(v);       \
@@ -988,11 +1022,11 @@ static int next_record(bsc_bam *b, const bsc_reader_params *par, bam_rec *r, int
   r->orientation = ((second && reverse) || !(second || reverse)) ? 0 : 1;
   const int mult_seg = (flag & (F_PAIRED | F_MUNMAP)) == F_PAIRED;
   if (reverse) {
-    r->fwd = (uint32_t)(mpos + 1);
-    r->rev = (uint32_t)(pos + 1);
+    r->fwd = (uint32_t)mpos + 1u;
+    r->rev = (uint32_t)pos + 1u;
   } else {
-    r->fwd = (uint32_t)(pos + 1);
-    r->rev = (uint32_t)(mpos + 1);
+    r->fwd = (uint32_t)pos + 1u;
+    r->rev = (uint32_t)mpos + 1u;
   }
   r->mapq = (uint8_t)mapq;
   if (mapq < par->mapq_thresh && !flt) flt = FLT_MAPQ;

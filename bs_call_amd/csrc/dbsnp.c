@@ -57,6 +57,7 @@ struct bsc_dbsnp {
   dbsnp_ctg *ctgs;
   int loaded; /* index of the loaded contig, -1 = none */
   dbsnp_bin *bins;
+  uint64_t bins_used; /* 1 + the highest bin of the loaded contig that holds entries */
   uint64_t n_snps;
 };
 
@@ -66,13 +67,16 @@ int bsc_set_error(int code, const char *fmt, ...);
 static void dbsnp_unload(bsc_dbsnp *db) {
   if (db->bins && db->loaded >= 0) {
     const dbsnp_ctg *c = db->ctgs + db->loaded;
-    for (uint64_t i = 0; i <= (uint64_t)c->max_bin - c->min_bin; i++) {
+    uint64_t n = (uint64_t)c->max_bin - c->min_bin + 1;
+    if (n > db->bins_used) n = db->bins_used; /* the bins past it were never written (and their pages never touched) */
+    for (uint64_t i = 0; i < n; i++) {
       free(db->bins[i].entries);
       free(db->bins[i].name_buf);
     }
   }
   free(db->bins);
   db->bins = NULL;
+  db->bins_used = 0;
   db->loaded = -1;
   db->n_snps = 0;
 }
@@ -142,6 +146,9 @@ int bsc_dbsnp_open(const char *path, bsc_dbsnp **out) {
   uint32_t nctg;
   memcpy(&npre, ubuf + 2, 2);
   memcpy(&nctg, ubuf + 4, 4);
+  /* a prefix takes at least 1 byte of the directory, a contig at least 17: counts beyond that are damage, not a reason to
+   * reserve memory for them */
+  if ((uint64_t)npre > size || (uint64_t)nctg > size / 17u) FAIL("bsc_dbsnp_open: directory lists more entries than it holds");
   const char *p = (const char *)ubuf + 8, *p1 = (const char *)ubuf + size;
   size_t l = strnlen(p, (size_t)(p1 - p));
   if (p + 8 >= p1 || strncmp(p, "track ", 6) || p + l >= p1) FAIL("bsc_dbsnp_open: no \"track\" header line");
@@ -168,6 +175,7 @@ int bsc_dbsnp_open(const char *path, bsc_dbsnp **out) {
     memcpy(&c->max_bin, p + 4, 4);
     memcpy(&c->file_offset, p + 8, 8);
     if (c->max_bin < c->min_bin) FAIL("bsc_dbsnp_open: contig %u has max_bin < min_bin", i);
+    if (c->max_bin >= (1u << 26)) FAIL("bsc_dbsnp_open: contig %u has a bin beyond position 2^32", i);
     p += 16;
     l = strnlen(p, (size_t)(p1 - p));
     if (p + l >= p1) FAIL("bsc_dbsnp_open: unterminated contig name");
@@ -304,6 +312,7 @@ int bsc_dbsnp_load_contig(bsc_dbsnp *db, const char *name, uint64_t *n_snps) {
       entries[n_entries++] = (uint16_t)((k << 8) | x);
       if (tm & 1u) { /* last entry of the bin */
         if (bins->n_entries) FAIL("bsc_dbsnp_load_contig: %s: bin listed twice", name);
+        if ((uint64_t)(bins - db->bins) + 1 > db->bins_used) db->bins_used = (uint64_t)(bins - db->bins) + 1;
         bins->entries = malloc(sizeof(uint16_t) * (size_t)n_entries);
         bins->name_buf = malloc((size_t)(name_ptr ? name_ptr : 1));
         if (!bins->entries || !bins->name_buf) {

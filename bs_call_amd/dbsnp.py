@@ -40,11 +40,11 @@ class DbSnpIndex:
 
     @property
     def contigs(self):
-        return [self._L.bsc_dbsnp_contig_name(self._h, i).decode() for i in range(self._L.bsc_dbsnp_n_contigs(self._h))]
+        return [self._L.bsc_dbsnp_contig_name(self._h, i).decode("utf-8", "replace") for i in range(self._L.bsc_dbsnp_n_contigs(self._h))]
 
     @property
     def header(self):
-        return self._L.bsc_dbsnp_header(self._h).decode()
+        return self._L.bsc_dbsnp_header(self._h).decode("utf-8", "replace")
 
     def load_contig(self, name):
         """Make `name` the loaded contig (the previous one is dropped); returns the number of entries (0 for a contig the
@@ -64,4 +64,4 @@ class DbSnpIndex:
         buf = C.create_string_buffer(600)
         ln = C.c_size_t(0)
         r = _check(self._L.bsc_dbsnp_name(self._h, x, buf, 600, C.byref(ln)))
-        return r, buf.value.decode(), ln.value
+        return r, buf.value.decode("utf-8", "replace"), ln.value

@@ -189,6 +189,41 @@ def test_unsorted_and_broken_input(tmp_path):
         BamReader(str(tmp_path / "missing.bam"))
 
 
+def test_counts_and_positions_of_a_damaged_file(tmp_path):
+    """Found by tools/fuzz_host_inputs.py under the sanitized build (tests/test_host_sanitizers.py): (1) l_text / n_ref of a BAM
+    header sized allocations before the bytes behind them were read — n_ref = 2^31 - 1 reserved 16 GB and the clean-up walked
+    all of it; (2) POS / PNEXT outside 0 .. 2^31 - 1 in SAM text wrapped (signed overflow) instead of failing like sam_parse1;
+    (3) a BAM record with pos = 2^31 - 1 overflowed the 1-based position."""
+    import struct
+    import time
+
+    p = str(tmp_path / "h.bam")
+    for l_text, n_ref in ((0x7FFFFFFF, 1), (4, 0x7FFFFFFF)):
+        data = b"BAM\1" + struct.pack("<I", l_text) + b"@HD\n" + struct.pack("<i", n_ref) + struct.pack("<I", 5) + b"chr1\0" + struct.pack("<I", 1000)
+        with open(p, "wb") as f:
+            f.write(W.bgzf_block(data) + W.BGZF_EOF)
+        t0 = time.time()
+        with pytest.raises(BscError, match="header"):
+            BamReader(p)
+        assert time.time() - t0 < 2.0
+    sam = str(tmp_path / "p.sam")
+    head = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:100000\n"
+    for pos, pnext, tlen in (("2147483648", "0", "0"), ("100", "4294967296", "0"), ("-5", "0", "0"), ("100", "0", "-2147483648"), ("99999999999999999999", "0", "0")):
+        open(sam, "w").write(head + "r1\t0\tchr1\t%s\t60\t10M\t*\t%s\t%s\tACGTACGTAC\t*\n" % (pos, pnext, tlen))
+        with pytest.raises(BscError, match="out of range"):
+            c_blocks(sam)
+    open(sam, "w").write(head + "r1\t0\tchr1\t2147483647\t60\t10M\t*\t0\t0\tACGTACGTAC\t*\n")  # the largest POS there is: no wrap
+    try:
+        c_blocks(sam)
+    except BscError:
+        pass
+    W.write_bam(p, REFS, [rec("a", 99, 0x7FFFFFFF, 0x7FFFFFFF, tlen=10)])  # a record at pos 2^31 - 1: read or refused, not undefined
+    try:
+        c_blocks(p)
+    except BscError:
+        pass
+
+
 def test_cigar_that_disagrees_with_the_sequence_length(tmp_path):
     """A CIGAR whose query length is not l_seq: htslib (un-vendored; the reference reads through it) refuses it where it
     parses SAM text (sam_parse1) and hands a binary BAM record over unchecked — the reader errors on the text and, for BAM,

@@ -134,6 +134,33 @@ def test_malformed_files(tmp_path, index_file):
         assert db.load_contig("chrE") == 1
 
 
+def test_counts_in_a_damaged_directory_are_not_believed(tmp_path):
+    """Found by tools/fuzz_host_inputs.py under the sanitized build: the directory's contig / prefix counts and a contig's bin
+    range sized allocations before anything was checked (100 GB for a count of 2^32 - 1).  A count the directory cannot hold
+    and a bin beyond position 2^32 are errors."""
+    import zlib
+
+    for field, value, msg in ((4, 0xFFFFFFFF, "more entries than it holds"), (2, 0xFFFF, "more entries than it holds"), (None, 1 << 27, "beyond position")):
+        path = str(tmp_path / "d.idx")
+        W.write_index(path, {"chr1": [(5, "42", True, 0)]})
+        raw = bytearray(open(path, "rb").read())
+        _, _, off, max_buf, zlen = struct.unpack_from("<IIQQQ", raw, 0)
+        d = bytearray(zlib.decompress(bytes(raw[off : off + zlen])))
+        if field == 4:
+            struct.pack_into("<I", d, 4, value)
+        elif field == 2:
+            struct.pack_into("<H", d, 2, value)
+        else:  # max_bin of the only contig: it follows the header line and the prefix
+            o = d.index(b"rs\0", 8) + 3
+            struct.pack_into("<I", d, o + 4, value)
+        z = zlib.compress(bytes(d))
+        out = bytes(raw[:off]) + z + struct.pack("<I", W.MAGIC)
+        out = struct.pack("<IIQQQ", W.MAGIC, 0, off, max(max_buf, len(d)), len(z)) + out[32:]
+        open(path, "wb").write(out)
+        with pytest.raises(BscError, match=msg):
+            DbSnpIndex(path)
+
+
 def test_bcf_records_carry_the_dbsnp_names(index_file):
     """bsc_bcf_block names the records whose rs_found flag is set: the ID field is the name with the length the reference
     hands to htslib (an odd digit count keeps its filler NUL, src/dbSNP.c:306-350)."""
