@@ -14,6 +14,7 @@ EXPORTS = (
     "bsc_create",
     "bsc_destroy",
     "bsc_get_tables",
+    "bsc_phred_table",
     "bsc_call_sites",
     "bsc_alloc_host",
     "bsc_free_host",
@@ -247,6 +248,8 @@ def load():
     L.bsc_destroy.argtypes = [vp]
     L.bsc_get_tables.restype = i32
     L.bsc_get_tables.argtypes = [vp, vp, vp]
+    L.bsc_phred_table.restype = i32
+    L.bsc_phred_table.argtypes = [vp, vp]
     L.bsc_call_sites.restype = i32
     L.bsc_call_sites.argtypes = [vp, vp, vp, u64, vp, u32, vp]
     L.bsc_alloc_host.restype = vp

@@ -17,6 +17,7 @@
 
 #include "../../include/bscall_amd.h"
 #include "devtables.h"
+#include "bsmath.h"
 #include "bsmath_tables.h"
 #include "synth.h"
 
@@ -217,6 +218,60 @@ void bsc_params_default(bsc_params *p) {
 
 /* fill_base_prob_table (src/genotype_model.c:10-21) + lfact_store_init (src/stats_utils.c:14-21) + the two
  * prior logs (src/genotype_model.c:88-89), with libm as in the reference. */
+/*
+ * QUAL (src/print_vcf.c:140-148): phred = (int)(-10 * log(1 - z) / LOG10), capped at 255, z = exp(LOG10 * gt_prob[max_gt]).
+ * Only the INTEGER leaves the printer, and as a function of om = 1 - z it is a staircase: phred(om) >= k exactly for
+ * om <= T[k].  The chain kernel therefore does not evaluate the log (a sixth of its record formation) but looks om up
+ * between the steps: T[k] is found here by bisection over the doubles with the very operations the kernel's log path ran
+ * (bsm_log_t = glibc's log, the product, the division by LOG10, the truncation), so the lookup returns what those
+ * operations return wherever phred() is monotone — and log's error (< 1 ulp) keeps it monotone except within a few hundred
+ * ulps of om around a step, where the test suite checks every double (tests/test_gpu_records.py).  A binade of om spans
+ * 10 log10(2) = 3.01 units of phred, i.e. at most four steps: per binade the value at its upper end and the four steps
+ * above it.  om is a multiple of 2^-53 (z < 1 is a double), so binades 0 .. 53 occur; the table has 64.
+ */
+static int bsc_phred_of_om(double om) {
+  const double lg = bsm_log_t(om, bsm_log_tab);
+  const double v = (-10.0 * lg) / BSC_LN10;
+  const int p = (int)v;
+  return p > 255 ? 255 : p;
+}
+static int bsc_build_phred_table(bsc_dev_tables *t) {
+  double T[260]; /* T[k], k = 1 .. 255: the largest om with phred(om) >= k; beyond 255: never */
+  for (int k = 1; k <= 255; k++) {
+    uint64_t lo = bsm_bits(0x1p-1000), hi = bsm_bits(1.0); /* phred(lo) = 255 >= k > phred(hi) = 0 */
+    if (bsc_phred_of_om(bsm_from_bits(lo)) < k || bsc_phred_of_om(bsm_from_bits(hi)) >= k) return -1;
+    while (hi - lo > 1) {
+      const uint64_t mid = lo + (hi - lo) / 2;
+      if (bsc_phred_of_om(bsm_from_bits(mid)) >= k) lo = mid;
+      else hi = mid;
+    }
+    T[k] = bsm_from_bits(lo);
+    if (k > 1 && !(T[k] < T[k - 1])) return -1;
+  }
+  for (int k = 256; k < 260; k++) T[k] = -1.0;
+  for (int e = 0; e < 64; e++) {
+    const double top = e == 0 ? 1.0 : bsm_from_bits(bsm_bits(ldexp(1.0, 1 - e)) - 1); /* the largest om of the binade */
+    const int b = bsc_phred_of_om(top);
+    if (bsc_phred_of_om(ldexp(1.0, -e)) - b > 4) return -1;
+    t->phred_base[e] = (unsigned char)b;
+    for (int j = 0; j < 4; j++) t->phred_thr[e][j] = T[b + 1 + j];
+  }
+  return 0;
+}
+
+int bsc_phred_table(double *thr_64x4, unsigned char *base_64) {
+  if (!thr_64x4 || !base_64) return bsc_fail(BSC_ERR_ARG, "bsc_phred_table: NULL argument");
+  bsc_dev_tables *t = malloc(sizeof *t);
+  if (!t) return bsc_fail(BSC_ERR_NOMEM, "bsc_phred_table: out of memory");
+  const int rc = bsc_build_phred_table(t);
+  if (!rc) {
+    memcpy(thr_64x4, t->phred_thr, sizeof t->phred_thr);
+    memcpy(base_64, t->phred_base, sizeof t->phred_base);
+  }
+  free(t);
+  return rc ? bsc_fail(BSC_ERR_ARG, "bsc_phred_table: the QUAL staircase of this build's log is not monotone") : BSC_OK;
+}
+
 static void bsc_build_tables(bsc_context *ctx) {
   bsc_dev_tables *t = &ctx->host_tables;
   for (int q = 0; q <= 43; q++) {
@@ -293,6 +348,11 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
   }
   bsc_build_tables(ctx);
   int rc = BSC_OK;
+  if (bsc_build_phred_table(&ctx->host_tables)) { /* cannot happen with a monotone log; never a silently wrong QUAL */
+    rc = bsc_fail(BSC_ERR_ARG, "bsc_create: the QUAL staircase of this build's log is not monotone");
+    bsc_destroy(ctx);
+    return rc;
+  }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc(&ctx->d_tables, sizeof(bsc_dev_tables)) != hipSuccess ||
       hipMalloc((void **)&ctx->d_counters, BSC_CNT_WORDS * sizeof(unsigned long long)) != hipSuccess ||

@@ -42,6 +42,13 @@ __device__ static __forceinline__ double fma_vs(double a, double kv, double ks) 
   return d;
 }
 
+/* a * ks + a */
+__device__ static __forceinline__ double fma_s_self(double a, double ks) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %1" : "=v"(d) : "v"(a), "s"(ks));
+  return d;
+}
+
 __device__ static __forceinline__ double log_main(double x, const double *tab) {
   const uint64_t ix = bsm_bits(x);
   const uint32_t hx = (uint32_t)(ix >> 32);
@@ -70,15 +77,15 @@ __device__ static __forceinline__ double log_near1(double x) {
   const double s = x - 1.0;
   const double s2 = s * s;
   const double s3 = s * s2;
-  double t7 = BSM_FMA(s, BSM_LOG_B8, BSM_LOG_B7);
+  double t7 = fma_sv(s, BSM_LOG_B8, BSM_LOG_B7); /* the heads of the three chains and the splitter: three-address, see above */
   t7 = BSM_FMA(s2, BSM_LOG_B9, t7);
   t7 = BSM_FMA(s3, BSM_LOG_B10, t7);
-  double t4 = BSM_FMA(s, BSM_LOG_B5, BSM_LOG_B4);
+  double t4 = fma_sv(s, BSM_LOG_B5, BSM_LOG_B4);
   t4 = BSM_FMA(s2, BSM_LOG_B6, t4);
-  double t1 = BSM_FMA(s, BSM_LOG_B2, BSM_LOG_B1);
+  double t1 = fma_sv(s, BSM_LOG_B2, BSM_LOG_B1);
   t1 = BSM_FMA(s2, BSM_LOG_B3, t1);
   const double p = BSM_FMA(BSM_FMA(t7, s3, t4), s3, t1);
-  const double a = BSM_FMA(s, 0x1p27, s);
+  const double a = fma_s_self(s, 0x1p27);
   const double shi = BSM_FMA(-0x1p27, s, a);
   const double slo = s - shi;
   const double shi2 = shi * shi;

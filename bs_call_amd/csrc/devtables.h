@@ -14,6 +14,11 @@ typedef struct {
   unsigned long long exp_tab[256]; /* bsm_exp_tab: {tail, scale} x 128 */
   double under_conv, over_conv;
   double lrb, lrb1; /* log(ref_bias), log(0.5 * (1 + ref_bias)) */
+  /* QUAL of a record as a function of om = 1 - exp(LOG10 gt_prob[max_gt]) (src/print_vcf.c:140-148) without the log: for
+   * the binade e = 1023 - exponent(om) of om, phred = phred_base[e] + the number of phred_thr[e][0..3] that om does not
+   * exceed (bscall_api.c builds and checks the table; fused.hip reads it) */
+  double phred_thr[64][4];
+  unsigned char phred_base[64];
 } bsc_dev_tables;
 
 /* unsigned long long counters[BSC_CNT_WORDS] in device memory */

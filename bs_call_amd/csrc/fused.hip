@@ -288,7 +288,7 @@ __device__ static __forceinline__ void f_stats_update(uint32_t *h, const f_facts
 template <bool READS, bool SUMM>
 __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigned n_pend, unsigned lane, const uint32_t *__restrict__ cts,
                                                         const uint8_t *__restrict__ dbsnp, const bsc_chain_args &a,
-                                                        uint8_t *__restrict__ core_out, const double *s_lf, const double *s_logtab,
+                                                        uint8_t *__restrict__ core_out, const double *__restrict__ s_lf, const double *s_logtab,
                                                         const unsigned long long *s_exptab, uint32_t *h,
                                                         unsigned long long *__restrict__ stat_words) {
   f_facts F;
@@ -387,7 +387,8 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   __shared__ double s_k[44], s_lnk[44], s_half[44], s_one[44];
   __shared__ double s_logtab[256];
   __shared__ unsigned long long s_exptab[256];
-  __shared__ double s_lf[256];        /* ln x! for x < 256 (Fisher's test of the heterozygous calls) */
+  __shared__ double s_pthr[64 * 4];   /* QUAL without the log: per binade of om = 1 - z its four steps ... */
+  __shared__ uint8_t s_pbase[64];     /* ... and the value below them (devtables.h; ln x! of Fisher's test is read from memory) */
   __shared__ double s_ptab[PT_WORDS]; /* logs of the methylation arguments of a class whose partner class is empty (callmath.h) */
   __shared__ unsigned int s_cnt[12];  /* covered, hist[10], het */
   __shared__ uint8_t s_pairs[FW][256]; /* per wave: the (lane, class) pairs whose logs are needed (call_body.inc) */
@@ -412,8 +413,9 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   if (tid < 256) {
     s_logtab[tid] = tb->log_tab[tid];
     s_exptab[tid] = tb->exp_tab[tid];
-    s_lf[tid] = tb->lfact[tid];
+    s_pthr[tid] = (&tb->phred_thr[0][0])[tid];
   }
+  if (tid < 64) s_pbase[tid] = tb->phred_base[tid];
   if (tid < 12) s_cnt[tid] = 0;
   if (a.with_stats) {
     for (unsigned i = tid; i < F_WORDS; i += 64 * FW) h[i] = 0;
@@ -710,12 +712,15 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
      * Lanes 2..61 form their record; lane 1 — the site just left of the tile's first position — runs the same code
      * for the one thing its right neighbour needs from it: whether it is a written '+' strand CG call, and its FILTER
      * bits (the pending cytosine of the CpG bookkeeping).  The record is built as its sixteen dwords. */
-    uint32_t od[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) od[k] = 0u;
+    uint32_t od0 = 0u; /* the lane's record position, 0 = it has none: all that is read of the record after the branch */
     bool pend = false, minus_cg = false, st_called = false, st_emit = false, st_het = false, st_rs = false,
          st_cpg = false, st_refcpg = false;
-    uint32_t st_phred = 0, st_qd = 0, st_cdp = 0, st_cinf = 0, st_ma = 0, st_mb = 0, st_pos = 0;
+    /* operands of the statistics, each read only under one of the flags above: "some register" (an empty asm defines the
+     * value without an instruction) instead of a default that would cost a v_mov per value wherever a branch skips them */
+    uint32_t st_phred, st_qd, st_cdp, st_cinf, st_ma, st_mb, st_pos;
+#define F_ANY(v) asm volatile("" : "=v"(v)) /* volatile: seven separate registers, not one shared and copied */
+    F_ANY(st_phred); F_ANY(st_qd); F_ANY(st_cdp); F_ANY(st_cinf); F_ANY(st_ma); F_ANY(st_mb); F_ANY(st_pos);
+#undef F_ANY
     int st_mut = 12;
     /* a run's first tile: lane 1 — the site just left of its first record — forms just enough of its record for its right
      * neighbour (below); in the other tiles that site's facts are the carried ones */
@@ -726,8 +731,12 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
 #ifdef F_EXPERIMENT_SKIP_RECORD /* timing experiment only (tools/build_variant_fused.sh): the tile's cost without the record formation */
     if (false) {
 #else
-    if ((me & 0xffu) != 0 && dp1 + d_inf != 0) {
+    if (((me & 0xffu) != 0) & (dp1 + d_inf != 0)) { /* one branch, not two nested ones */
 #endif
+      /* The record is built AND staged inside the branch: sixteen dwords that leave it would each need a default for the
+       * lanes that skip it — a v_mov per dword at every level of the branch, ~40 vector instructions a tile. */
+      uint32_t od[16];
+      od[6] = od[9] = od[10] = od[11] = od[12] = od[13] = od[14] = od[15] = 0u; /* 9-13: the GLs of a WRITTEN record, below */
       const int gt = (int)(me & 0xffu) - 1;
       const int L = (int)lane;
       /* called genotypes of lane indices L-2 .. L+2: entries L .. L+4 of sg[], whose first two are the carried sites (a run's
@@ -769,12 +778,14 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       /* phred (:140-148) */
       const double z1 = exp_dev(la[gt] * BSM_LN10, (const uint64_t *)s_exptab);
       int phred;
-      {
+      { /* (int)(-10 log(1 - z1) / LOG10) capped at 255, as a staircase in om = 1 - z1 (bscall_api.c: bsc_build_phred_table):
+         * the value below the four steps a binade of om can hold, plus the steps om does not exceed */
         const double om = 1.0 - z1;
-        const double lg = log_dev(z1 >= 1.0 ? 0.5 : om, s_logtab);
-        phred = (int)div_ln10_dev(-10.0 * lg); /* x / LOG10, correctly rounded (callmath.h) */
-        if (phred > 255) phred = 255;
-        if (z1 >= 1.0) phred = 255;
+        uint32_t e = 1023u - ((uint32_t)(bsm_bits(om) >> 32) >> 20); /* 0 < om <= 1: binades 0 .. 53 */
+        e = e > 63u ? 63u : e;
+        const double2 ta = *reinterpret_cast<const double2 *>(s_pthr + 4u * e), tb2 = *reinterpret_cast<const double2 *>(s_pthr + 4u * e + 2u);
+        phred = (int)s_pbase[e] + (om <= ta.x ? 1 : 0) + (om <= ta.y ? 1 : 0) + (om <= tb2.x ? 1 : 0) + (om <= tb2.y ? 1 : 0);
+        if (z1 >= 1.0) phred = 255; /* om = 0 (src/print_vcf.c:142-145) */
       }
       /* FS = (int)(-0.0 * 10.0 + 0.5) = 0: fisher_strand is 0 unless gt_het[max_gt]; those go to bsc_chain_het_kernel */
       const uint32_t qd = dp1 > 0 ? (uint32_t)phred / dp1 : (uint32_t)phred;
@@ -789,7 +800,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         else if (cC) cg = nx ? (nxG ? 'H' : 'N') : '?';
         else if (cG) cg = pv ? (pvC ? 'H' : 'N') : (c == 8u ? '?' : '.');
       }
-      od[0] = pos;
+      od[0] = od0 = pos;
       od[2] = ((uint32_t)phred << 8) | (cg << 24);
       od[3] = ((rr[0] >> 8) << 16) | ((rr[1] >> 8) << 24);
       od[4] = (rr[2] >> 8) | ((rr[3] >> 8) << 8) | ((rr[4] >> 8) << 16) | (((ge[0] >> 8) & 0xffu) << 24);
@@ -861,12 +872,20 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
           }
         }
       }
+      /* the record goes to the tile's staging area, which lies over la[]: every read of la[] is above, and a wave's LDS
+       * operations execute in order (lane 1 of a run's first tile forms a record for its neighbour's sake only) */
+      WAVE_LDS_SYNC();
+      if (lane >= f0) {
+        uint4 *so = reinterpret_cast<uint4 *>(slot);
+#pragma unroll
+        for (int k = 0; k < 4; k++) so[(lane - f0) * 4u + k] = make_uint4(od[4 * k], od[4 * k + 1], od[4 * k + 2], od[4 * k + 3]);
+      }
     }
     spd[2u + lane] = (uint16_t)((pend ? 1u : 0u) | (flt << 8));
     const uint32_t depth_off = K_COLD(a.depth_off);
     if (depth_off && inner) { /* total depth of every position that reached the printer (the key of gt_cov_stats) */
       const uint32_t dpt = dp1 + d_inf;
-      reinterpret_cast<uint16_t *>(K_COLD(het_list) + depth_off)[jw + (int32_t)(MULTI ? a.pos_off : 0u)] = (uint16_t)(od[0] ? (dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u) : 0u);
+      reinterpret_cast<uint16_t *>(K_COLD(het_list) + depth_off)[jw + (int32_t)(MULTI ? a.pos_off : 0u)] = (uint16_t)(od0 ? (dpt < BSC_COV_CAP ? dpt : BSC_COV_CAP - 1u) : 0u);
     }
     WAVE_LDS_SYNC();
     /* ---- results: the tile's 60 records, staged in the slot (every la[] read is done: the sync above), leave
@@ -874,9 +893,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
      * record dwords are dead by then ---- */
     {
       uint4 *so = reinterpret_cast<uint4 *>(slot);
-      if (lane >= f0 && lane < 62u) {
+      if (od0 == 0u && lane >= f0 && lane < 62u) { /* no record (an uncovered position, one in ~1 000): sixty-four zero bytes;
+                                                    * after the branch above, i.e. after the last read of la[] */
 #pragma unroll
-        for (int k = 0; k < 4; k++) so[(lane - f0) * 4u + k] = make_uint4(od[4 * k], od[4 * k + 1], od[4 * k + 2], od[4 * k + 3]);
+        for (int k = 0; k < 4; k++) so[(lane - f0) * 4u + k] = make_uint4(0u, 0u, 0u, 0u);
       }
       WAVE_LDS_SYNC();
       const uint32_t i0 = (uint32_t)(jw0 + (int32_t)f0); /* window index of the tile's first record */
@@ -899,7 +919,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         if (lane >= f0 && lane < 62u) {
           const uint8_t *const dbs = K_COLD(dbsnp);
           const uint32_t rsf = (dbs && inner) ? (uint32_t)dbs[jw + (int32_t)(MULTI ? a.pos_off : 0u)] : 0u;
-          const bool hasrec = od[0] != 0u;
+          const bool hasrec = od0 != 0u;
           so[(lane - f0) * 4u + 0] = hasrec ? make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]) : make_uint4(0u, 0u, 0u, 0u);
           so[(lane - f0) * 4u + 1] = hasrec ? make_uint4(cnt[4], cnt[5], cnt[6], cnt[7]) : make_uint4(0u, 0u, 0u, 0u);
           so[(lane - f0) * 4u + 2] = hasrec ? make_uint4(qpack0, qpack1, (uint32_t)mq, (uint32_t)aq) : make_uint4(0u, 0u, 0u, 0u);
@@ -1064,7 +1084,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       const unsigned nb = n_pend - k0 < 64u ? n_pend - k0 : 64u;
       const uint32_t *ent = wl + (uint64_t)(k0 + lane0) * (READS ? F_HET_DW : 1u);
       const uint32_t e = lane0 < nb ? __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      f_fisher_pending<READS, SUMM>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_base, s_lf, s_logtab, s_exptab, h, stat_words);
+      f_fisher_pending<READS, SUMM>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_base, K_COLD(tb)->lfact, s_logtab, s_exptab, h, stat_words);
     }
   }
   if (run >= n_runs_all) break; /* wave-uniform */

@@ -111,6 +111,16 @@ int bsc_destroy(bsc_context *ctx);
 int bsc_get_tables(const bsc_context *ctx, double *q_prob_44x5, double *lfact_256);
 
 /*
+ * The QUAL staircase the fused chain reads instead of evaluating src/print_vcf.c:140-148's log: phred = (int)(-10 *
+ * log(om) / LOG10) capped at 255 is, as a function of om = 1 - exp(LOG10 * gt_prob[max_gt]), a staircase; for the binade
+ * e = 1023 - exponent(om) (0 .. 63) of om, phred = base_64[e] + the number of thr_64x4[e][0..3] that om does not exceed.
+ * Built on the host by bisection with the operations the kernels' log path runs (a context builds the same table and fails
+ * if the staircase is not monotone).  No GPU involved: what tests/test_phred_table.py checks against libm double by double
+ * around every step.  Returns BSC_OK or BSC_ERR_ARG.
+ */
+int bsc_phred_table(double *thr_64x4, unsigned char *base_64);
+
+/*
  * bsc_call_sites: the call_thread() loop over one block (src/call_genotypes.c:43-115): per site the
  * quality/MAPQ summary, calc_gt_prob(), the strand table + fisher() for heterozygous calls.
  *   cts[n]  pile-ups (host memory)
