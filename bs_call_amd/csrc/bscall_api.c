@@ -225,7 +225,7 @@ void bsc_params_default(bsc_params *p) {
  * between the steps: T[k] is found here by bisection over the doubles with the very operations the kernel's log path ran
  * (bsm_log_t = glibc's log, the product, the division by LOG10, the truncation), so the lookup returns what those
  * operations return wherever phred() is monotone — and log's error (< 1 ulp) keeps it monotone except within a few hundred
- * ulps of om around a step, where the test suite checks every double (tests/test_gpu_records.py).  A binade of om spans
+ * ulps of om around a step, where the test suite checks every double (tests/test_phred_table.py).  A binade of om spans
  * 10 log10(2) = 3.01 units of phred, i.e. at most four steps: per binade the value at its upper end and the four steps
  * above it.  om is a multiple of 2^-53 (z < 1 is a double), so binades 0 .. 53 occur; the table has 64.
  */
