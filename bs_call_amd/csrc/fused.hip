@@ -88,6 +88,8 @@ struct bsc_chain_args {
   uint32_t het_cap; /* entries of a wave's heterozygous list */
   uint32_t depth_off; /* != 0: the window's depths (u16 per position, 0 = no record formed) are written at het_list + this
                          many dwords, for the GC-by-coverage kernel */
+  uint32_t edge_gap;  /* guarded single-block launches: records between run 0 and run 1 that belong to another launch — a
+                         block's head tile and the tiles behind its main part as ONE launch (chain_launch_t) */
 };
 
 /* the reads-in form (READS = true): the block's ordered reads instead of pile-ups (accdev.h), and where a heterozygous
@@ -480,6 +482,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     const uint32_t k_ = (k) - (MULTI ? a.run0 : 0u), ex_ = a.run_extra;                                         \
     run_n = a.run_tiles + (k_ < ex_ ? 1u : 0u);                                                                 \
     run_s = (int32_t)(a.origin + k_ * run_p + FT2 * (k_ < ex_ ? k_ : ex_));                                     \
+    if (!FULL && !MULTI && k_ >= 1u) run_s += (int32_t)a.edge_gap;                                              \
   } while (0)
   if (run < n_runs_all) F_RUN_SETUP(run);
   /* heterozygous calls waiting for Fisher's test (window index | max_gt << 28): the wave's own list in HBM, one in ~1 000
@@ -1291,14 +1294,23 @@ static int chain_launch_t(const bsc_chain_launch *L) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
-  /* guarded tiles, one per run: the head, then everything behind the main part */
-  const uint32_t edge[2][2] = {{0u, p.head}, {p.head + p.m_len, L->n}};
+  /* guarded tiles, one per run: the head, then everything behind the main part — as ONE launch where both exist (each is a
+   * wave or three in one workgroup, 18 us of a single wave's latency with the device otherwise idle): run 0 is the head tile,
+   * the runs from 1 on lie edge_gap records further on, behind the main part */
+  uint32_t edge[2][2] = {{0u, p.head}, {p.head + p.m_len, L->n}};
+  const bool merged = p.m_runs && p.head == (uint32_t)FT && edge[1][1] > edge[1][0];
   for (int k = 0; k < 2; k++) {
     if (edge[k][1] <= edge[k][0]) continue;
     a.origin = edge[k][0];
     a.n_runs = (edge[k][1] - edge[k][0] + FT - 1) / FT;
     a.run_tiles = 1;
     a.run_extra = 0;
+    a.edge_gap = 0;
+    if (merged) {
+      if (k == 1) break;
+      a.n_runs = 1u + (edge[1][1] - edge[1][0] + FT - 1) / FT;
+      a.edge_gap = edge[1][0] - (uint32_t)FT;
+    }
     unsigned grid = (a.n_runs + FW - 1) / FW;
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
     hipLaunchKernelGGL((bsc_chain_kernel_t<false, READS, false, SUMM>), dim3(grid), dim3(64 * FW), 0, s, K);
