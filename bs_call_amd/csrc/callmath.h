@@ -18,6 +18,22 @@
 #define MAX_OUT_DW 52 /* gt_vcf stride (208 B) */
 #define SLOT_DW (64 * IN_DW) /* per-wave LDS slot: 64 pile-ups = 6 656 B >= 32 results (6 400 / 6 656 B) */
 
+/* LDS accesses that hand data from one lane to another inside a wave: the wave runs in lockstep and its LDS operations
+ * execute in order, so only the COMPILER has to be told — a wavefront-scope fence orders the memory operations, the
+ * (free) s_wave_barrier keeps the scheduler from moving anything across. */
+#define WAVE_LDS_ORDER()                                     \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+/* number of set bits of a wave-wide mask below the calling lane (v_mbcnt_lo / _hi: two instructions, against the seven of
+ * popcount(m & ((1 << lane) - 1)) in 64-bit arithmetic) */
+__device__ static __forceinline__ unsigned lane_rank(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 /* ---- device forms of bsmath.h with wave-uniform branches only -------------------------------------------
  * Same operations in the same order as bsm_log_t / bsm_exp_t, hence the same bits, but without per-lane
  * branches: the table path of log() runs for every lane, its near-1 polynomial only when some lane of the wave

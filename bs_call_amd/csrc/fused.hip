@@ -187,15 +187,7 @@ __device__ static __forceinline__ void dma16_hidden(const void *g, void *lds_wav
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(g), "s"(l) : "memory", "m0");
 }
 
-/* LDS accesses that hand data from one lane to another inside a wave: the wave runs in lockstep and its LDS operations
- * execute in order, so only the COMPILER has to be told — a wavefront-scope fence orders the memory operations, the
- * (free) s_wave_barrier keeps the scheduler from moving anything across. */
-#define WAVE_LDS_SYNC()                                      \
-  do {                                                       \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
-    __builtin_amdgcn_wave_barrier();                         \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
-  } while (0)
+#define WAVE_LDS_SYNC() WAVE_LDS_ORDER() /* callmath.h */
 
 /* "NACGT"[code] for code 0..4 (v_perm_b32: selector 0..3 picks a byte of the second operand, 4..7 of the first) */
 #define F_BASE_CHAR(code) (__builtin_amdgcn_perm(0x00000054u, 0x4743414Eu, (code)) & 0xffu)
@@ -541,6 +533,8 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     const uint32_t pos0 = a.x + (uint32_t)b0; /* genome position of lane index 0 (mod 2^32; only inner lanes use it) */
 
     /* ---- reference codes of lane indices -2 .. 63 + 2 -> srf[0 .. 67] ---- */
+    bool tile_n; /* wave-uniform: an N (or the end of the buffer) among them — the printer's context blanking (:570-577) may then
+                  * turn a lane's own reference base into N */
     {
       const int64_t r0 = b0 - 2 - ref_lo; /* offset of srf[0]'s code in the buffer */
       const int64_t avail = ref_hi - ref_lo;
@@ -548,11 +542,13 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       const int64_t k0 = r0 + lane;
       const uint32_t c0 = (k0 >= 0 && k0 < avail) ? refp[k0] : 0u;
       srf[lane] = (uint16_t)(c0 | (F_BASE_CHAR(c0) << 8));
+      uint32_t c1 = 1u;
       if (lane < 4u) {
         const int64_t k1 = r0 + 64 + lane;
-        const uint32_t c1 = (k1 >= 0 && k1 < avail) ? refp[k1] : 0u;
+        c1 = (k1 >= 0 && k1 < avail) ? refp[k1] : 0u;
         srf[64u + lane] = (uint16_t)(c1 | (F_BASE_CHAR(c1) << 8));
       }
+      tile_n = __any(c0 == 0u || c1 == 0u);
     }
 
     /* ---- my record ---- */
@@ -649,9 +645,24 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     }
     const unsigned rf = valid ? (unsigned)srf[lane + 2u] & 0xffu : 0u; /* my site's reference code (lane index = lane) */
     const double l = K_COLD(l), t = K_COLD(t), lrb = K_COLD(lrb), lrb1 = K_COLD(lrb1);
+    /* a run's first tile: lane 1 — the site just left of its first record — forms just enough of its record for its right
+     * neighbour (below); in the other tiles that site's facts are the carried ones */
+    const bool former = valid && lane < 62u && (inner || (f0 == 2u && lane == 1u));
+    const uint8_t *const dbsnp_p = K_COLD(dbsnp);
+    const uint32_t rs_found = (dbsnp_p && inner) ? (uint32_t)dbsnp_p[jw + (int32_t)(MULTI ? a.pos_off : 0u)] : 0u;
+    /* May the lane's record be written?  The hom-ref skip rule (src/print_vcf.c:85-96,139) on max_gt and the lane's own reference
+     * base: exactly the printer's decision unless gt_prob[] ties (call_body.inc looks after those) or the context blanking replaces
+     * the base (tile_n: then every lane counts as written).  The region clip (:154-158) is not looked at: such lanes are
+     * normalised for nothing. */
+    const bool want_all = tile_n || K_COLD(a.all_positions) != 0;
+#define CALL_WANT_GP(g_) (former && (want_all || (rs_found & 2u) || !(((g_) == 0 && rf == 1u) || ((g_) == 9 && rf == 4u))))
+#define CALL_PRINTER_GT
+#define CALL_COMPACT (!READS) /* READS: the forward counts wait in the lanes' slot areas (la[12]) until the heterozygous calls are listed */
+#define CALL_COMPACT_CAP 39u
 #define CALL_SUMMARY_GIVEN
 #include "call_body.inc"
 #undef CALL_SUMMARY_GIVEN
+#undef CALL_WANT_GP
 
     /* ---- block counters (window positions only, not the halo) ---- */
     const bool defer = covered && inner && ((0x16Eu >> mxi) & 1u); /* gt_het[max_gt]: Fisher's test (:61), after the tile */
@@ -693,14 +704,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     /* ---- the printer's genotype: first-max argmax of gt_prob[], recomputed (src/print_vcf.c:584-591) ----
      * Published for the neighbours with everything they need from it: its IUPAC letter and whether it carries C / G. */
     {
-      uint32_t gz = 0;
-      if (covered) {
-        double z = gp[0];
-#pragma unroll
-        for (int k = 1; k < 10; k++)
-          if (gp[k] > z) { z = gp[k]; gz = (uint32_t)k; }
-        gz += 1u;
-      }
+      const uint32_t gz = covered ? (uint32_t)pgi + 1u : 0u; /* call_body.inc: max_gt, or the argmax itself where gt_prob[] may tie */
       const uint32_t g0 = gz ? gz - 1u : 0u;
       /* "NAMRWCSYGKT"[gz] */
       const uint32_t lo = __builtin_amdgcn_perm(0x59534357u, 0x524D414Eu, gz & 7u);
@@ -725,9 +729,6 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     F_ANY(st_phred); F_ANY(st_qd); F_ANY(st_cdp); F_ANY(st_cinf); F_ANY(st_ma); F_ANY(st_mb); F_ANY(st_pos);
 #undef F_ANY
     int st_mut = 12;
-    /* a run's first tile: lane 1 — the site just left of its first record — forms just enough of its record for its right
-     * neighbour (below); in the other tiles that site's facts are the carried ones */
-    const bool former = valid && lane < 62u && (inner || (f0 == 2u && lane == 1u));
     const uint32_t me = former ? sg[2u + lane] : 0u;
     const uint32_t dp1 = cnt[0] + cnt[1] + cnt[2] + cnt[3], d_inf = cnt[4] + cnt[5] + cnt[6] + cnt[7];
     uint32_t flt = 0;
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       /* The record is built AND staged inside the branch: sixteen dwords that leave it would each need a default for the
        * lanes that skip it — a v_mov per dword at every level of the branch, ~40 vector instructions a tile. */
       uint32_t od[16];
-      od[6] = od[9] = od[10] = od[11] = od[12] = od[13] = od[14] = od[15] = 0u; /* 9-13: the GLs of a WRITTEN record, below */
+      od[6] = od[7] = od[9] = od[10] = od[11] = od[12] = od[13] = od[14] = od[15] = 0u; /* 9-13: the GLs of a WRITTEN record, below */
       const int gt = (int)(me & 0xffu) - 1;
       const int L = (int)lane;
       /* called genotypes of lane indices L-2 .. L+2: entries L .. L+4 of sg[], whose first two are the carried sites (a run's
@@ -772,26 +773,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         }
       }
       const int rfix = (int)(rr[2] & 0xffu);
-      const uint8_t *const dbsnp = K_COLD(dbsnp);
-      const uint32_t rs_found = (dbsnp && inner) ? (uint32_t)dbsnp[jw + (int32_t)(MULTI ? a.pos_off : 0u)] : 0u;
       int ga, gb;
       f_alleles(gt, ga, gb);
       const bool het = ga != gb;
       bool skp = !K_COLD(a.all_positions) && !(rs_found & 2u) && ((gt == 0 && rfix == 1) || (gt == 9 && rfix == 4));
-      /* phred (:140-148) */
-      const double z1 = exp_dev(la[gt] * BSM_LN10, (const uint64_t *)s_exptab);
-      int phred;
-      { /* (int)(-10 log(1 - z1) / LOG10) capped at 255, as a staircase in om = 1 - z1 (bscall_api.c: bsc_build_phred_table):
-         * the value below the four steps a binade of om can hold, plus the steps om does not exceed */
-        const double om = 1.0 - z1;
-        uint32_t e = 1023u - ((uint32_t)(bsm_bits(om) >> 32) >> 20); /* 0 < om <= 1: binades 0 .. 53 */
-        e = e > 63u ? 63u : e;
-        const double2 ta = *reinterpret_cast<const double2 *>(s_pthr + 4u * e), tb2 = *reinterpret_cast<const double2 *>(s_pthr + 4u * e + 2u);
-        phred = (int)s_pbase[e] + (om <= ta.x ? 1 : 0) + (om <= ta.y ? 1 : 0) + (om <= tb2.x ? 1 : 0) + (om <= tb2.y ? 1 : 0);
-        if (z1 >= 1.0) phred = 255; /* om = 0 (src/print_vcf.c:142-145) */
-      }
-      /* FS = (int)(-0.0 * 10.0 + 0.5) = 0: fisher_strand is 0 unless gt_het[max_gt]; those go to bsc_chain_het_kernel */
-      const uint32_t qd = dp1 > 0 ? (uint32_t)phred / dp1 : (uint32_t)phred;
       const uint32_t pos = pos0 + lane;
       if (!skp) skp = pos < K_COLD(a.reg_start) || pos > K_COLD(a.reg_stop);
       /* CpG status (:227-266) */
@@ -804,14 +789,30 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         else if (cG) cg = pv ? (pvC ? 'H' : 'N') : (c == 8u ? '?' : '.');
       }
       od[0] = od0 = pos;
-      od[2] = ((uint32_t)phred << 8) | (cg << 24);
+      od[2] = cg << 24;
       od[3] = ((rr[0] >> 8) << 16) | ((rr[1] >> 8) << 24);
       od[4] = (rr[2] >> 8) | ((rr[3] >> 8) << 8) | ((rr[4] >> 8) << 16) | (((ge[0] >> 8) & 0xffu) << 24);
       od[5] = ((ge[1] >> 8) & 0xffu) | (((ge[2] >> 8) & 0xffu) << 8) | (((ge[3] >> 8) & 0xffu) << 16) | (((ge[4] >> 8) & 0xffu) << 24);
-      od[7] = qd;
       od[8] = dp1;
       uint32_t d1 = ((uint32_t)gt << 8) | ((uint32_t)rfix << 16);
+      /* QUAL and QD of a position whose record is not written stay 0: the printer computes them (:140-152) and never looks at them
+       * (the record's flags and the statistics, :185-217,382-398, are behind `skip`), and such a lane's gt_prob[] is not made */
+      int phred = 0;
+      uint32_t qd = 0;
       if (!skp) {
+        /* phred (:140-148) */
+        const double z1 = exp_dev(lg[gt] * BSM_LN10, (const uint64_t *)s_exptab);
+        { /* (int)(-10 log(1 - z1) / LOG10) capped at 255, as a staircase in om = 1 - z1 (bscall_api.c: bsc_build_phred_table):
+           * the value below the four steps a binade of om can hold, plus the steps om does not exceed */
+          const double om = 1.0 - z1;
+          uint32_t e = 1023u - ((uint32_t)(bsm_bits(om) >> 32) >> 20); /* 0 < om <= 1: binades 0 .. 53 */
+          e = e > 63u ? 63u : e;
+          const double2 ta = *reinterpret_cast<const double2 *>(s_pthr + 4u * e), tb2 = *reinterpret_cast<const double2 *>(s_pthr + 4u * e + 2u);
+          phred = (int)s_pbase[e] + (om <= ta.x ? 1 : 0) + (om <= ta.y ? 1 : 0) + (om <= tb2.x ? 1 : 0) + (om <= tb2.y ? 1 : 0);
+          if (z1 >= 1.0) phred = 255; /* om = 0 (src/print_vcf.c:142-145) */
+        }
+        /* FS = (int)(-0.0 * 10.0 + 0.5) = 0: fisher_strand is 0 unless gt_het[max_gt]; those are tested after the wave's last tile */
+        qd = dp1 > 0 ? (uint32_t)phred / dp1 : (uint32_t)phred;
         if (phred < 20) flt |= 1u;
         if (qd < 2u) flt |= 2u;
         if (mq < 40) flt |= 8u;
@@ -828,9 +829,9 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
 #define F_GLIDX(x, y) ((x) * (9 - (x)) / 2 + (y)-5)
         const bool hr = rfix != 0;
         const int r1 = hr ? rfix : 1, a0 = aix0 ? aix0 : 1, a1 = aix1 ? aix1 : 1;
-        double zr = hr ? la[F_GLIDX(r1, r1)] : -99.999;
-        double zh0 = la[r1 < a0 ? F_GLIDX(r1, a0) : F_GLIDX(a0, r1)], zm0 = la[F_GLIDX(a0, a0)];
-        double zh1 = la[r1 < a1 ? F_GLIDX(r1, a1) : F_GLIDX(a1, r1)], zm1 = la[F_GLIDX(a1, a1)];
+        double zr = hr ? lg[F_GLIDX(r1, r1)] : -99.999;
+        double zh0 = lg[r1 < a0 ? F_GLIDX(r1, a0) : F_GLIDX(a0, r1)], zm0 = lg[F_GLIDX(a0, a0)];
+        double zh1 = lg[r1 < a1 ? F_GLIDX(r1, a1) : F_GLIDX(a1, r1)], zm1 = lg[F_GLIDX(a1, a1)];
 #undef F_GLIDX
         zr = zr < -99.999 ? -99.999 : zr;
         zh0 = zh0 < -99.999 ? -99.999 : zh0;
@@ -846,7 +847,8 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         od[11] = ngl > 2u ? __float_as_uint(f2) : 0u;
         od[12] = ngl > 3u ? __float_as_uint(f3) : 0u;
         od[13] = ngl > 4u ? __float_as_uint(f4) : 0u;
-        od[2] |= flt | (ngl << 16);
+        od[2] |= flt | ((uint32_t)phred << 8) | (ngl << 16);
+        od[7] = qd;
       }
       od[1] = d1;
       /* ---- facts for the statistics and for the right neighbour ---- */
@@ -920,8 +922,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
                       * AMQ qualities, MQ, mean quality, max_gt, the dbSNP flag — the second half of a bsc_vcf_rec */
         WAVE_LDS_SYNC();
         if (lane >= f0 && lane < 62u) {
-          const uint8_t *const dbs = K_COLD(dbsnp);
-          const uint32_t rsf = (dbs && inner) ? (uint32_t)dbs[jw + (int32_t)(MULTI ? a.pos_off : 0u)] : 0u;
+          const uint32_t rsf = rs_found;
           const bool hasrec = od0 != 0u;
           so[(lane - f0) * 4u + 0] = hasrec ? make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]) : make_uint4(0u, 0u, 0u, 0u);
           so[(lane - f0) * 4u + 1] = hasrec ? make_uint4(cnt[4], cnt[5], cnt[6], cnt[7]) : make_uint4(0u, 0u, 0u, 0u);

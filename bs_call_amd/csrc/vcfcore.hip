@@ -211,9 +211,12 @@ extern "C" __global__ __launch_bounds__(64 * VW) void bsc_vcf_core_kernel(
       o.pos = pos;
       o.gt = (uint8_t)gt;
       o.ref_code = (uint8_t)rfix;
-      o.phred = (uint8_t)phred;
+      /* QUAL / QD of a position whose record is not written: the printer computes them (:140-152) and never reads them again
+       * (flags and statistics are behind `skip`, :185-217,382-398) — left 0, so that the fused chain (fused.hip) need not make the
+       * gt_prob[] of such a position */
+      o.phred = skip ? (uint8_t)0 : (uint8_t)phred;
       o.fs = fs;
-      o.qd = qd;
+      o.qd = skip ? 0u : qd;
       o.dp = dp1;
       o.cg = cg;
 #pragma unroll

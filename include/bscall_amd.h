@@ -223,14 +223,15 @@ typedef struct {
   uint8_t ref_code; /* REF base code 0..4 as the printer sees it (an N up to two positions before blanks it, :570-577) */
   uint8_t gt_enc;   /* FORMAT GT: two BCF allele codes ((allele+1)<<1), high and low nibble (reference gt_int table) */
   uint8_t flt;      /* 1 q20, 2 qd2, 4 fs60, 8 mq40 (FILTER fail / FT names), 128 mac1; 0 = PASS */
-  uint8_t phred;    /* QUAL and FORMAT GQ */
+  uint8_t phred;    /* QUAL and FORMAT GQ; 0 in a record with emit = 0 (the printer computes it for every position,
+                       src/print_vcf.c:140-148, and reads it behind `skip` only, :185-217,382-398; round 5) */
   uint8_t n_gl;     /* number of FORMAT GL values */
   char cg;          /* FORMAT CG: 'C' (= "CG"), 'H', 'N', '?', '.' */
   char alt[2];      /* ALT alleles, 0-padded */
   char cx_ref[5];   /* INFO CX: reference context */
   char cx_gt[5];    /* FORMAT CX: IUPAC context of the called genotypes */
   int32_t fs;       /* FORMAT FS (the reference writes it for heterozygous genotypes only) */
-  uint32_t qd;      /* FORMAT QD */
+  uint32_t qd;      /* FORMAT QD; 0 where emit = 0, like phred */
   uint32_t dp;      /* FORMAT DP (non-informative depth) */
   float gl[6];      /* FORMAT GL */
   uint32_t _pad;

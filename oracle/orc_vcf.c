@@ -318,9 +318,11 @@ static void orc_vcf_entry(orc_vcf_state *st, const orc_gt_meth *gtm, const char 
   o->pos = x;
   o->gt = (uint8_t)gt;
   o->ref_code = (uint8_t)rfix;
-  o->phred = (uint8_t)phred;
+  /* the record of a position that is not written keeps no QUAL / QD (include/bscall_amd.h: bsc_vcf_core): the reference computes
+   * them for every position (:140-152) but reads them behind `skip` only (:185-217,382-398) */
+  o->phred = skip ? 0 : (uint8_t)phred;
   o->fs = fs;
-  o->qd = qd;
+  o->qd = skip ? 0 : qd;
   o->dp = dp1;
   o->cg = *cpg;
   memcpy(o->cx_ref, prf_ctxt, 5);

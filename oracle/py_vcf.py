@@ -126,9 +126,10 @@ class Printer:
             cpg = ("H" if GFLAG[g3 - 1] else "N") if g3 else "?"
         elif GFLAG[g2 - 1]:
             cpg = ("H" if CFLAG[g1 - 1] else "N") if g1 else "."
+        # a record that is not written keeps no QUAL / QD (bsc_vcf_core): the reference reads them behind `skip` only
         rec = {
-            "pos": x, "emit": 0, "gt": gt, "ref_code": rfix, "gt_enc": 0, "flt": 0, "phred": phred, "n_gl": 0, "cg": cpg[0],
-            "alt": "", "cx_ref": prf_ctxt, "cx_gt": ctxt, "fs": fs, "qd": qd, "dp": dp1, "gl": [],
+            "pos": x, "emit": 0, "gt": gt, "ref_code": rfix, "gt_enc": 0, "flt": 0, "phred": 0 if skip else phred, "n_gl": 0, "cg": cpg[0],
+            "alt": "", "cx_ref": prf_ctxt, "cx_gt": ctxt, "fs": fs, "qd": 0 if skip else qd, "dp": dp1, "gl": [],
         }
         if not skip:
             rec["emit"] = 1

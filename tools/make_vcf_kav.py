@@ -119,8 +119,8 @@ case("GL floor at -99.999", "325,337,344", "TTATTTT",
      flank([site("AC", gp=[-250.0, 0.0, -3.0, -4.0, -1e9, -6.0, -7.0, -8.0, -9.0, -10.0], counts=(15, 15, 0, 0, 0, 0, 0, 0))]),
      {102: {"emit": 1, "n_gl": 3, "gl": [-99.999, 0.0, -99.999], "phred": 255}})
 # ---- hom-ref skip rule, dbSNP, -A, region (:85-96, :139, :154-158) ------------------------------------------------------
-case("AA on reference A is not written (but is formed: position, QUAL, context)", "139", "TTATTTT",
-     flank([site("AA", 0.0, A30)]), {102: {"emit": 0, "pos": 102, "gt": 0, "phred": 255, "flt": 0, "n_gl": 0, "alt": "", "cx_ref": "TTATT"}})
+case("AA on reference A is not written (but is formed: position, genotype, context; QUAL and QD are not kept)", "139", "TTATTTT",
+     flank([site("AA", 0.0, A30)]), {102: {"emit": 0, "pos": 102, "gt": 0, "phred": 0, "qd": 0, "flt": 0, "n_gl": 0, "alt": "", "cx_ref": "TTATT"}})  # unwritten: no QUAL / QD kept
 case("AA on reference A with a dbSNP fq_mask site (rs_found = 3) is written", "139", "TTATTTT", flank([site("AA", 0.0, A30)]),
      {102: {"emit": 1, "gt": 0, "alt": "", "gt_enc": 0x22}}, dbsnp=[0, 0, 3, 0, 0])
 case("rs_found = 1 does not force it", "139", "TTATTTT", flank([site("AA", 0.0, A30)]), {102: {"emit": 0}}, dbsnp=[0, 0, 1, 0, 0])
