@@ -121,10 +121,15 @@ __device__ static __forceinline__ double log_dev(double x, const double *tab) {
   const uint32_t hx = (uint32_t)(bsm_bits(x) >> 32);
   const bool near = hx - 0x3fee0000u < 0x3ff10900u - 0x3fee0000u;
   const bool ok = hx - 0x00100000u < 0x7fe00000u;
-  double y = log_main(x, tab);
-  if (__any(near)) {
-    const double yn = log_near1(x);
-    y = near ? yn : y;
+  double y;
+  if (__all(near)) { /* e.g. the log of the normalising sum of a tile of confident calls: the table path is not wanted at all */
+    y = log_near1(x);
+  } else {
+    y = log_main(x, tab);
+    if (__any(near)) {
+      const double yn = log_near1(x);
+      y = near ? yn : y;
+    }
   }
   if (__builtin_expect(__any(!ok), 0)) y = ok ? y : bsm_log_t(x, tab);
   return y;

@@ -655,6 +655,9 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
      * the base (tile_n: then every lane counts as written).  The region clip (:154-158) is not looked at: such lanes are
      * normalised for nothing. */
     const bool want_all = tile_n || K_COLD(a.all_positions) != 0;
+    /* wave-uniform: the block's ends and every N are out of reach of the tile's records (lane indices -1 .. 63 in the block, no
+     * blanked base): their neighbours and reference context need no case distinction */
+    const bool plain = !tile_n && blk_lo <= -1 && blk_hi >= 63;
 #define CALL_WANT_GP(g_) (former && (want_all || (rs_found & 2u) || !(((g_) == 0 && rf == 1u) || ((g_) == 9 && rf == 4u))))
 #define CALL_PRINTER_GT
 #define CALL_COMPACT (!READS) /* READS: the forward counts wait in the lanes' slot areas (la[12]) until the heterozygous calls are listed */
@@ -744,18 +747,24 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       const int gt = (int)(me & 0xffu) - 1;
       const int L = (int)lane;
       /* called genotypes of lane indices L-2 .. L+2: entries L .. L+4 of sg[], whose first two are the carried sites (a run's
-       * first tile has none: its lane 1 clamps at lane 0, its own record is not kept) */
-      uint32_t ge[5];
+       * first tile has none: its lane 1 clamps at lane 0, its own record is not kept); reference context through the reference's
+       * strncpy of a 7-base window (:570-577); srf[] starts at lane index -2 */
+      uint32_t ge[5], rr[5];
+      if (plain) { /* no block end and no N anywhere near the tile: the five neighbours and the five bases as they stand */
 #pragma unroll
-      for (int k = 0; k < 5; k++) {
-        const int j = L - 2 + k;
-        uint32_t v = (j >= blk_lo && j <= blk_hi) ? sg[j + 2 < (int)f0 ? (int)f0 : j + 2] : 0x4E00u;
-        if (j > blk_hi && L + 2 > blk_hi) v = sg[blk_hi + 2]; /* flush_vcf_entries repeats the last genotype, :540 */
-        ge[k] = v;
-      }
-      /* reference context through the reference's strncpy of a 7-base window (:570-577); srf[] starts at lane index -2 */
-      uint32_t rr[5];
-      {
+        for (int k = 0; k < 5; k++) {
+          const uint32_t j2 = lane + (uint32_t)k;
+          ge[k] = sg[j2 < f0 ? f0 : j2];
+          rr[k] = srf[j2];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          const int j = L - 2 + k;
+          uint32_t v = (j >= blk_lo && j <= blk_hi) ? sg[j + 2 < (int)f0 ? (int)f0 : j + 2] : 0x4E00u;
+          if (j > blk_hi && L + 2 > blk_hi) v = sg[blk_hi + 2]; /* flush_vcf_entries repeats the last genotype, :540 */
+          ge[k] = v;
+        }
         const int la_ = L + 2 < blk_hi ? L + 2 : blk_hi;    /* look-ahead position that filled the window */
         const int w0 = la_ >= blk_lo + 4 ? la_ - 4 : blk_lo; /* first base of that copy */
         bool blank = false;
