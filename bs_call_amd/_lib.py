@@ -76,6 +76,7 @@ EXPORTS = (
     "bsc_prepare_templates_profile",
     "bsc_block_start",
     "bsc_template_qual",
+    "bsc_template_walk_flags",
     "bsc_dbsnp_open",
     "bsc_dbsnp_close",
     "bsc_dbsnp_n_contigs",
@@ -342,6 +343,8 @@ def load():
     L.bsc_block_start.argtypes = [vp]
     L.bsc_template_qual.restype = u32
     L.bsc_template_qual.argtypes = [vp, vp]
+    L.bsc_template_walk_flags.restype = u32
+    L.bsc_template_walk_flags.argtypes = [vp, u32]
     L.bsc_dbsnp_open.restype = i32
     L.bsc_dbsnp_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.bsc_dbsnp_close.restype = None

@@ -30,7 +30,7 @@ GT_METH = np.dtype(
 
 TEMPLATE = np.dtype(
     {
-        "names": ["pos", "len", "off", "mapq", "orientation", "bs_strand", "_pad"],
+        "names": ["pos", "len", "off", "mapq", "orientation", "bs_strand", "flags"],
         "formats": [("<u4", (2,)), ("<u4", (2,)), ("<u8", (2,)), ("u1", (2,)), "u1", "u1", "<u4"],
         "offsets": [0, 8, 16, 32, 34, 35, 36],
         "itemsize": 40,

@@ -39,8 +39,10 @@ struct bsc_template_dev {
   uint8_t mapq[2];
   uint8_t orientation;
   uint8_t bs_strand;
-  uint32_t _pad;
+  uint32_t flags; /* BSC_TPL_* (include/bscall_amd.h) */
 };
+#define TPL_WALK_KNOWN 1u
+#define TPL_WALKED0 2u
 
 __device__ static __forceinline__ uint32_t leftmost(uint32_t p0, uint32_t p1) { /* src/call_genotypes.c:183-185 */
   return p0 == 0 ? p1 : (p1 > 0 && p1 < p0 ? p1 : p0);
@@ -137,8 +139,8 @@ __device__ static __forceinline__ uint32_t wg_min_bin(uint32_t b0, uint32_t b1, 
 /*
  * Grouping the block's reads by the 64-position bin of their first base, pass 1 of 2 — one thread per template, in the
  * caller's order: the reference's asserts (the lowest index of an invalid template with its first failing check reaches the
- * host through counters[BSC_CNT_ERR]; such a template contributes nothing), whether read 0 was walked (one byte of it,
- * almost always; kept in tflag[] for pass 2), the bins of its two reads counted — in an LDS window of the workgroup, one
+ * host through counters[BSC_CNT_ERR]; such a template contributes nothing), whether read 0 was walked (as the host says,
+ * bsc_template.flags, or else found out here: one byte of it, almost always; kept in tflag[] for pass 2), the bins of its two reads counted — in an LDS window of the workgroup, one
  * global atomic per non-empty bin and workgroup — and the longest read extent of the block.
  * READS, not templates, are what the tiles search: a read's extent is bounded by its length, so mates that lie far apart
  * (or a pathological template) cannot widen every tile's candidate window.
@@ -159,7 +161,8 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_count_kernel(const 
     uint32_t bin0;
     template_block(blk, n_blk, t, x, y, bin0);
     bool walked0 = false;
-    if (template_error(tp, leftmost(tp.pos[0], tp.pos[1]), x, seq_bytes) == 0) {
+    if (tp.flags & TPL_WALK_KNOWN) walked0 = (tp.flags & TPL_WALKED0) != 0; /* the host says (include/bscall_amd.h) */
+    else if (template_error(tp, leftmost(tp.pos[0], tp.pos[1]), x, seq_bytes) == 0) { /* read 0's first countable base */
       const uint32_t rl = tp.len[0];
       const uint8_t *sp = seq + tp.off[0];
       for (uint32_t j = 0; j < rl; j++) {

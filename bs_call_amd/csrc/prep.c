@@ -428,6 +428,7 @@ int bsc_prepare_templates_profile(const bsc_raw_template *raw, uint32_t nr, cons
         goto done;
       }
       if (out_len) memcpy(seq_out + used, sp, out_len);
+      if (k == 0) o->flags = bsc_template_walk_flags(sp, out_len); /* every base was touched above: HOT LOOP A's scan comes for free */
       o->len[k] = out_len;
       o->off[k] = used;
       used += out_len;
@@ -456,6 +457,16 @@ done:
   free(origs[1]);
   return rc;
 #undef FAIL
+}
+
+/* bsc_template.flags of a template whose read 0 is read0[0 .. len0): has it a base the scan of src/call_genotypes.c:198-211
+ * stops at (quality neither 0 nor 63)? */
+uint32_t bsc_template_walk_flags(const uint8_t *read0, uint32_t len0) {
+  for (uint32_t j = 0; j < len0; j++) {
+    const uint32_t q = (uint32_t)read0[j] >> 2;
+    if (q != 0 && q != 63u) return BSC_TPL_WALK_KNOWN | BSC_TPL_WALKED0;
+  }
+  return BSC_TPL_WALK_KNOWN;
 }
 
 /* The block a list of prepared templates spans, as process_template_vector derives it before it calls

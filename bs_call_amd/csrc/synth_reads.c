@@ -94,13 +94,17 @@ int64_t bsc_synth_reads_host(uint64_t seed, uint32_t x, uint32_t n_sites, uint32
         if (j < ltrim || j + rtrim >= rl) byte = (uint8_t)(b | (63u << 2)); /* trimmed: q = FLT_QUAL */
         sp[j] = byte;
       }
+      if (k == 0) t.flags = bsc_template_walk_flags(sp, rl); /* as a host that writes the bytes would (bsc_prepare_templates, the glue) */
       t.pos[k] = rpos;
       t.len[k] = rl;
       t.off[k] = used;
       used += rl;
     }
     if (t.len[0] == 0 && t.len[1] == 0) continue; /* nothing aligned */
-    if (t.len[0] == 0) t.pos[0] = 0;              /* forward_position 0 = none (src/call_genotypes.c:183-185) */
+    if (t.len[0] == 0) {
+      t.pos[0] = 0;                                /* forward_position 0 = none (src/call_genotypes.c:183-185) */
+      t.flags = BSC_TPL_WALK_KNOWN;                /* no read 0: nothing walked */
+    }
     if (t.len[1] == 0) t.pos[1] = 0;
     tpl[nt++] = t;
   }

@@ -53,3 +53,19 @@ def synth_block(seed, x, n_sites, coverage, flags=0, chunk=1_000_000, threads=No
 def algorithmic_bytes_in(tpl, seq):
     """1 byte per base + 16 bytes per template."""
     return int(seq.size) + 16 * int(len(tpl))
+
+
+TPL_WALK_KNOWN, TPL_WALKED0 = 1, 2  # bsc_template.flags (include/bscall_amd.h: BSC_TPL_*)
+
+
+def walk_flags(tpl, seq):
+    """bsc_template_walk_flags() of every template (include/bscall_amd.h): BSC_TPL_WALK_KNOWN, and BSC_TPL_WALKED0 where read 0
+    holds a base whose quality is neither 0 nor 63 (what decides whether HOT LOOP A flips the orientation for read 1,
+    src/call_genotypes.c:198-211,224).  Plain numpy over the read bytes: for tests and for callers that build templates in
+    Python."""
+    q = np.asarray(seq, dtype=np.uint8) >> 2
+    ok = np.concatenate(([0], np.cumsum((q != 0) & (q != 63), dtype=np.int64)))
+    a = tpl["off"][:, 0].astype(np.int64)
+    b = a + tpl["len"][:, 0].astype(np.int64)
+    walked = (tpl["len"][:, 0] > 0) & (ok[np.minimum(b, len(q))] - ok[np.minimum(a, len(q))] > 0)
+    return (TPL_WALK_KNOWN | np.where(walked, TPL_WALKED0, 0)).astype(np.uint32)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BSC_ABI_VERSION 1
+#define BSC_ABI_VERSION 2
 
 #define BSC_OK 0
 #define BSC_ERR_ARG (-1)       /* bad argument (the reference would assert: src/call_genotypes.c:158,186,188) */
@@ -64,8 +64,19 @@ typedef struct {
   uint8_t mapq[2];
   uint8_t orientation; /* gt_strand: 0 FORWARD, 1 REVERSE */
   uint8_t bs_strand;   /* gt_bs_strand: 0 NON_CONVERTED, 1 STRAND_C2T, 2 STRAND_G2A */
-  uint32_t _pad;
+  uint32_t flags;      /* 0, or BSC_TPL_* (ABI 2; the field was padding, required to be 0, before) */
 } bsc_template;
+
+/*
+ * bsc_template.flags.  HOT LOOP A flips the orientation for read 1 only if read 0 "was walked": if it holds a base whose
+ * quality is neither 0 nor 63 (the scan of src/call_genotypes.c:198-211 and the `continue`s in front of :224).  A host that
+ * writes the read bytes knows that bit and can hand it over; otherwise (flags = 0) the device finds it out itself, which costs
+ * it a 128-byte memory line per template for the one byte that usually decides.  BSC_TPL_WALK_KNOWN without a correct
+ * BSC_TPL_WALKED0 gives a pile-up the reference would not: use bsc_template_walk_flags().
+ */
+#define BSC_TPL_WALK_KNOWN 1u /* BSC_TPL_WALKED0 is valid */
+#define BSC_TPL_WALKED0 2u    /* read 0 has a base with 0 < quality < 63 */
+uint32_t bsc_template_walk_flags(const uint8_t *read0, uint32_t len0); /* host C (csrc/prep.c): stops at the first countable base */
 
 /* Model parameters: sr_param.under_conv/over_conv/ref_bias/min_qual (include/bs_call.h:320-324;
  * defaults src/init_param.c:26-31 = 0.01, 0.05, 2, 20; min_qual is clamped to [1,43] as in

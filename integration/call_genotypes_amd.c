@@ -100,6 +100,8 @@ void call_genotypes_ML(ctg_t *const ctg, gt_vector *const align_list, const uint
       memcpy(amd_seq + off, gt_vector_get_mem(al->read[k], uint8_t), rl);
       off += rl;
     }
+    /* was read 0 "walked" (:198-211 of the original)?  Its first bytes are in the cache right now */
+    t->flags = bsc_template_walk_flags(amd_seq + t->off[0], t->len[0]);
   }
 
   /* wait for the print thread to have drained the previous block, then own work->vcf (original :228-242) */

@@ -128,6 +128,8 @@ void call_genotypes_ML(ctg_t *const ctg, gt_vector *const align_list, const uint
       memcpy(amd_seq + off, gt_vector_get_mem(al->read[k], uint8_t), rl);
       off += rl;
     }
+    /* was read 0 "walked" (:198-211 of the original)?  Its first bytes are in the cache right now */
+    t->flags = bsc_template_walk_flags(amd_seq + t->off[0], t->len[0]);
   }
   /* previous block published, this one submitted, the meth profiling thread waited for (amd_overlap_protocol.h) */
   amd_overlap_call(work, ctg, amd_tpl, nr, amd_seq, nbytes, x, y);

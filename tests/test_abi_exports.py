@@ -27,7 +27,7 @@ def test_header_symbols_all_exported():
     for s in syms:
         assert hasattr(L, s), "libbscall_amd.so does not export %s" % s
     assert sorted(_lib.EXPORTS) == syms  # the binding knows exactly the declared set
-    assert L.bsc_abi_version() == 1
+    assert L.bsc_abi_version() == 2
 
 
 def test_record_layouts():

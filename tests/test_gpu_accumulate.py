@@ -31,6 +31,12 @@ def test_accumulate_parity(caller, oracle, cov, n, x0):
     got = caller.accumulate(tpl, seq, x, y)
     assert got.tobytes() == exp.tobytes()
     assert abs(got["n"][100:-400].mean() - cov * 0.935) < cov * 0.05  # 3 % low quality, 1 % N, trimmed ends
+    # the generator hands over whether read 0 "was walked" (bsc_template.flags); without the flags the device finds out itself
+    from bs_call_amd.reads import walk_flags
+    assert (tpl["flags"] == walk_flags(tpl, seq)).all() and (tpl["flags"] & 2 == 0).any()
+    bare = tpl.copy()
+    bare["flags"] = 0
+    assert caller.accumulate(bare, seq, x, y).tobytes() == exp.tobytes()
 
 
 @pytest.mark.parametrize("y_cut", [0, 1, 63, 64, 65, 150, 1000])
@@ -71,8 +77,13 @@ def test_empty_single_end_and_unsorted(caller, oracle):
             seq2[o : o + l] = (seq2[o : o + l] & 3) | (63 << 2)
     rc, exp2 = oracle.accumulate(t2, seq2, x, y, 20)
     assert rc == 0
+    # the reads were edited after the generator flagged them: without the host's word (flags = 0), and with it made again
+    from bs_call_amd.reads import walk_flags
+    t2["flags"] = 0
     got2 = caller.accumulate(t2, seq2, x, y)
     assert got2.tobytes() == exp2.tobytes()
+    t2["flags"] = walk_flags(t2, seq2)
+    assert (t2["flags"] == 1).sum() > 100 and caller.accumulate(t2, seq2, x, y).tobytes() == exp2.tobytes()
     assert got2.tobytes() != exp.tobytes()
 
 
@@ -383,6 +394,11 @@ def test_adversarial_template_lists(caller, oracle, seed):
     assert got.tobytes() == exp.tobytes()
     perm = rng.permutation(nt)
     assert caller.accumulate(tpl[perm], seq, x, y).tobytes() == exp.tobytes()
+    # the same list with the host's word on read 0 (fully trimmed / quality-0 read 0s are among them: :203,:210,:224)
+    from bs_call_amd.reads import walk_flags
+    told = tpl.copy()
+    told["flags"] = walk_flags(tpl, seq)
+    assert caller.accumulate(told, seq, x, y).tobytes() == exp.tobytes()
 
 
 def test_far_apart_mates_do_not_widen_the_search(caller, oracle):
@@ -396,6 +412,7 @@ def test_far_apart_mates_do_not_widen_the_search(caller, oracle):
     far["pos"][0] = [1000, y - 150]
     far["len"][0] = [100, 100]
     far["off"][0] = [tpl["off"][0, 0], tpl["off"][0, 1]]  # reuse read bytes that exist
+    far["flags"] = 0  # not the generator's template any more: let the device look at read 0
     tpl2 = np.concatenate([tpl, far])
     rc, exp = oracle.accumulate(tpl2, seq, x, y, 20)
     assert rc == 0

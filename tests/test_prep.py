@@ -279,6 +279,32 @@ def test_prepared_templates_feed_the_accumulate_stage(oracle):
     assert int(pile["n"].sum()) == want
 
 
+def test_prepared_templates_say_whether_read0_was_walked():
+    """bsc_template.flags (round 5): bsc_prepare_templates and the L-reads generator hand over whether read 0 holds a base whose
+    quality is neither 0 nor 63 — what the scan of src/call_genotypes.c:198-211 decides for the orientation flip of :224 — so
+    that the device stage need not fetch it.  Against a plain numpy scan, on inputs that have fully trimmed read 0s."""
+    from bs_call_amd.reads import TPL_WALK_KNOWN, TPL_WALKED0, walk_flags
+
+    rng = np.random.default_rng(77)
+    ts = []
+    for i in range(400):
+        r0, m0, s0 = _random_read(rng, 30)
+        r1, m1, s1 = _random_read(rng, 30)
+        p0 = 2000 + 5 * i
+        kind = i % 4
+        if kind == 0:
+            r0 = [b(c & 3, 63 if j % 2 else 0) for j, c in enumerate(r0)]  # nothing countable in read 0
+        ts.append(tpl((p0, p0 + int(rng.integers(0, s0 + 40))) if kind != 1 else (0, p0), (s0, s1) if kind != 1 else (0, s1),
+                      (r0, r1) if kind != 1 else (None, r1), (m0, m1) if kind != 1 else ((), m1)))
+    raw, seq, ms = to_arrays(ts)
+    out, oseq, _ = prepare_templates(raw, seq, ms, left_trim=(3, 0), right_trim=(0, 2))
+    want = walk_flags(out, oseq)
+    assert (out["flags"] == want).all()
+    assert (out["flags"] == TPL_WALK_KNOWN).sum() >= 100 and (out["flags"] == (TPL_WALK_KNOWN | TPL_WALKED0)).sum() >= 100
+    gt, gs = B.synth_reads_host(88172645463325252, 1000, 200_000, 30)
+    assert (gt["flags"] == walk_flags(gt, gs)).all() and (gt["flags"] == TPL_WALK_KNOWN).any()
+
+
 # ---- the non-CpG read profile (meth_profile, src/meth_profile.c) -----------------------------------------------------------
 def _profile_both(templates, x, ref, **kw):
     from bs_call_amd.caller import ReadProfile
