@@ -42,6 +42,7 @@ EXPORTS = (
     "bsc_blocks_records_fetch",
     "bsc_blocks_records",
     "bsc_blocks_submit_to",
+    "bsc_blocks_submit_to_inplace",
     "bsc_vcf_stats",
     "bsc_vcf_stats_device",
     "bsc_get_site_stats",
@@ -396,6 +397,8 @@ def load():
     L.bsc_blocks_records_fetch.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.bsc_blocks_submit_to.restype = i32
     L.bsc_blocks_submit_to.argtypes = [vp, vp, u32, vp, vp, u64, vp, vp, u32, vp, vp]
+    L.bsc_blocks_submit_to_inplace.restype = i32
+    L.bsc_blocks_submit_to_inplace.argtypes = [vp, vp, u32, vp, vp, u64, vp, vp, u32, vp, vp]
     L.bsc_blocks_records.restype = i32
     L.bsc_blocks_records.argtypes = [vp, vp, u32, vp, vp, u64, vp, vp, vp, i32, vp, u64, C.POINTER(C.c_uint64), vp]
     L.bsc_vcf_format_rec.restype = i32

@@ -172,10 +172,11 @@ class SiteCaller:
                                            _ptr(out), stride, _ptr(skip)))
         self._pending = (out, skip)
 
-    def blocks_submit_to(self, blocks, ref, out_stride=200):
+    def blocks_submit_to(self, blocks, ref, out_stride=200, inplace=False):
         """bsc_blocks_submit_to: blocks = [(templates, seq, x, y), ...], ref = their y - x + 3 codes each (list of arrays); the
         images of all blocks land in ONE page-locked array (block b from position offset off[b] on, a multiple of 64).  Returns
-        (off, out, skip) after the fetch: out = GT_METH[P] (stride 200) or uint8[P, 208]."""
+        (off, out, skip) after the fetch: out = GT_METH[P] (stride 200) or uint8[P, 208].  inplace: bsc_blocks_submit_to_inplace
+        from page-locked copies of the joined inputs (no staging copy inside the library)."""
         from .abi import BLOCK_DESC
 
         tpls, seqs, desc, o = [], [], np.zeros(len(blocks), dtype=BLOCK_DESC), 0
@@ -193,10 +194,22 @@ class SiteCaller:
         self._pin = (PinnedBuffer(P, GT_METH) if out_stride == 200 else PinnedBuffer((P, out_stride), np.uint8), PinnedBuffer(P, np.uint8))
         out, skip = self._pin[0].array, self._pin[1].array
         off = np.zeros(len(blocks), dtype=np.uint64)
-        _check(self._L.bsc_blocks_submit_to(self._h, _ptr(desc), len(desc), _ptr(tpl), _ptr(seq), seq.size, _ptr(refs), _ptr(out), out_stride,
-                                            _ptr(skip), _ptr(off)))
+        fn = self._L.bsc_blocks_submit_to
+        if inplace:
+            fn = self._L.bsc_blocks_submit_to_inplace
+            pins = (PinnedBuffer(len(tpl), TEMPLATE), PinnedBuffer(max(seq.size, 1), np.uint8), PinnedBuffer(max(refs.size, 1), np.uint8))
+            pins[0].array[:] = tpl
+            pins[1].array[: seq.size] = seq
+            pins[2].array[: refs.size] = refs
+            tpl, seq_a, refs = pins[0].array, pins[1].array, pins[2].array
+            _check(fn(self._h, _ptr(desc), len(desc), _ptr(tpl), _ptr(seq_a), seq.size, _ptr(refs), _ptr(out), out_stride, _ptr(skip), _ptr(off)))
+        else:
+            _check(fn(self._h, _ptr(desc), len(desc), _ptr(tpl), _ptr(seq), seq.size, _ptr(refs), _ptr(out), out_stride, _ptr(skip), _ptr(off)))
         self._pending = (out, skip)
         o2, s2 = self.block_fetch()
+        if inplace:
+            for b in pins:
+                b.free()
         return off, o2.copy(), s2.copy()
 
     def block_fetch(self):

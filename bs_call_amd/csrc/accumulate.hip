@@ -412,6 +412,34 @@ __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel_t(
   }
 }
 
+/*
+ * bsc_blocks_submit_to_inplace: the caller's reference codes — y - x + 3 per block, one block after another — into the layout the
+ * calling kernel reads beside the pile-ups: a block's y - x + 1 codes from its multiple of 64 on, 0 up to the next block.
+ */
+extern "C" __global__ __launch_bounds__(256) void bsc_ref_pad_kernel(const uint8_t *__restrict__ packed, const bsc_chain_mblock *__restrict__ blk,
+                                                                     uint32_t n_blk, uint8_t *__restrict__ padded, uint32_t n_pos) {
+  for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n_pos; p += gridDim.x * 256u) {
+    uint32_t lo = 0, hi = n_blk; /* the last block whose pos_off is not behind p */
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (blk[mid].pos_off <= p) lo = mid;
+      else hi = mid;
+    }
+    const uint32_t i = p - blk[lo].pos_off;
+    padded[p] = i < blk[lo].n ? packed[(uint64_t)blk[lo].ref_in + i] : (uint8_t)0;
+  }
+}
+
+extern "C" int bsc_dev_launch_ref_pad(const void *packed, const void *d_blk, uint32_t n_blk, void *padded, uint32_t n_pos, int num_cus,
+                                      void *stream) {
+  if (!n_pos) return 0;
+  unsigned g = (n_pos + 255u) / 256u;
+  if (g > (unsigned)num_cus * 8u) g = (unsigned)num_cus * 8u;
+  hipLaunchKernelGGL(bsc_ref_pad_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)packed, (const bsc_chain_mblock *)d_blk,
+                     n_blk, (uint8_t *)padded, n_pos);
+  return (int)hipGetLastError();
+}
+
 /* ---- launchers ------------------------------------------------------------------------------------------ */
 extern "C" int bsc_dev_scan_u32(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
 

@@ -64,6 +64,7 @@ int bsc_dev_launch_accumulate_summary(const void *rd, const void *bin_off, const
 size_t bsc_dev_summary_bytes(void);
 int bsc_dev_launch_accumulate_multi(const void *rd, const void *bin_off, const void *seq, const void *d_blk, uint32_t n_blk, uint32_t n_bins,
                                     uint32_t min_qual, void *cts, void *counters, int num_cus, void *stream);
+int bsc_dev_launch_ref_pad(const void *packed, const void *d_blk, uint32_t n_blk, void *padded, uint32_t n_pos, int num_cus, void *stream);
 int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk, uint32_t n_blk,
                                    uint32_t n_bins, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
                                    size_t scan_tmp_bytes, void *rd, void *counters, void *stream);
@@ -137,6 +138,8 @@ struct bsc_context {
   uint32_t mb_n;
   void *d_mblk, *d_mtab;
   size_t cap_mblk, cap_mtab;
+  void *d_refp; /* bsc_blocks_submit_to_inplace: the caller's packed reference codes, before bsc_ref_pad_kernel lays them out */
+  size_t cap_refp;
   const uint32_t *mb_toff;
   int reads_fused; /* bsc_set_reads_fused: 1 = the one-kernel form always; 0 = site summaries through HBM when they can be allocated */
   void *d_fscr; /* reads-in chain: forward-count scratch lines of the resident waves */
@@ -425,6 +428,7 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_recs);
   hipFree(ctx->d_mblk);
   hipFree(ctx->d_mtab);
+  hipFree(ctx->d_refp);
   hipFree(ctx->d_carry);
   hipFree(ctx->d_logp);
   hipFree(ctx->d_vout);
@@ -456,12 +460,30 @@ static int bsc_reserve(void **p, size_t *cap, size_t need) {
   size_t sz = need + need / 4; /* grow-only with slack */
   hipError_t e = hipMalloc(p, sz);
   if (e != hipSuccess) {
+    (void)hipGetLastError(); /* a failed allocation stays behind as the runtime's "last error": the next launch check would report it */
     sz = need;
     e = hipMalloc(p, sz);
   }
-  if (e != hipSuccess) return bsc_fail(BSC_ERR_NOMEM, "hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *p = NULL;
+    return bsc_fail(BSC_ERR_NOMEM, "hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e));
+  }
   *cap = sz;
   return BSC_OK;
+}
+
+/* bsc_reserve for a workspace the caller can do without: a failure leaves neither an error message nor the runtime's sticky error */
+static int bsc_try_reserve(void **p, size_t *cap, size_t need) {
+  if (need <= *cap) return 1;
+  char keep[sizeof bsc_errbuf];
+  memcpy(keep, bsc_errbuf, sizeof keep);
+  const int ok = bsc_reserve(p, cap, need) == BSC_OK;
+  if (!ok) {
+    (void)hipGetLastError();
+    memcpy(bsc_errbuf, keep, sizeof keep);
+  }
+  return ok;
 }
 
 static int bsc_check_stride(uint32_t out_stride) {
@@ -952,8 +974,9 @@ int bsc_block_submit_to(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, 
  * bytes, block b's from image block_off[b] on — the positions between a block's end and the next multiple of 64 are images of
  * nothing (skip = 1).  bsc_block_fetch(ctx, NULL, NULL) completes it.
  */
-int bsc_blocks_submit_to(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
-                         uint64_t seq_bytes, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip, uint64_t *block_off) {
+static int bsc_blocks_submit_to_(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                                 uint64_t seq_bytes, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip, uint64_t *block_off,
+                                 int inplace) {
   if (!ctx || !blocks || !ref || !out || !skip || !block_off) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_submit_to: NULL argument");
   if (ctx->pending_sz || ctx->rec_pending)
     return bsc_fail(BSC_ERR_ARG, "a submitted block has not been fetched (bsc_block_fetch / bsc_block_records_fetch first)");
@@ -986,14 +1009,16 @@ int bsc_blocks_submit_to(bsc_context *ctx, const bsc_block_desc *blocks, uint32_
   if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)P))) return rc;
   if ((rc = bsc_reserve(&ctx->d_mblk, &ctx->cap_mblk, (size_t)n_blocks * sizeof(bsc_chain_mblock)))) return rc;
   /* staging: templates, reads, the reference codes in the device's layout (a block's y - x + 1 codes from its multiple of 64
-   * on; its two look-ahead codes are the printer's, not the caller's), the block table */
+   * on; its two look-ahead codes are the printer's, not the caller's), the block table.  inplace: the block table alone — templates,
+   * reads and the packed reference codes are uploaded from where they lie, and the device lays the codes out (bsc_ref_pad_kernel) */
   const size_t b_tpl = (size_t)nr * sizeof(bsc_template), b_seq = (size_t)seq_bytes, b_blk = (size_t)n_blocks * sizeof(bsc_chain_mblock);
 #define AL64(v) (((v) + 63u) & ~(size_t)63u)
-  const size_t o_seq = AL64(b_tpl), o_ref = AL64(o_seq + b_seq), o_blk = AL64(o_ref + (size_t)P);
+  const size_t o_seq = inplace ? 0 : AL64(b_tpl), o_ref = inplace ? 0 : AL64(o_seq + b_seq), o_blk = inplace ? 0 : AL64(o_ref + (size_t)P);
 #undef AL64
   if ((rc = bsc_stage_reserve(ctx, o_blk + b_blk + 64u))) return rc;
+  if (inplace && (rc = bsc_reserve(&ctx->d_refp, &ctx->cap_refp, (size_t)ref64))) return rc;
   char *st = ctx->h_stage;
-  if (nr) {
+  if (nr && !inplace) {
     memcpy(st, tpl, b_tpl);
     memcpy(st + o_seq, seq, b_seq);
   }
@@ -1011,25 +1036,34 @@ int bsc_blocks_submit_to(bsc_context *ctx, const bsc_block_desc *blocks, uint32_
       mb[b].pos_off = p_off;
       mb[b].bin0 = p_off >> 6;
       mb[b].bin_end = (p_off >> 6) + bsc_dev_n_bins(sz);
-      mb[b]._pad = 0;
-      memcpy(st + o_ref + p_off, ref + r_in, sz);
-      memset(st + o_ref + p_off + sz, 0, ((sz + 63u) & ~63u) - sz);
+      mb[b].ref_in = (uint32_t)r_in;
+      if (!inplace) {
+        memcpy(st + o_ref + p_off, ref + r_in, sz);
+        memset(st + o_ref + p_off + sz, 0, ((sz + 63u) & ~63u) - sz);
+      }
       r_in += (uint64_t)sz + 2u;
       p_off += (sz + 63u) & ~63u;
     }
   }
   hipStream_t s = ctx->stream;
-  ctx->blk_tpl = (const bsc_template *)st;
+  ctx->blk_tpl = inplace ? tpl : (const bsc_template *)st;
   ctx->blk_d_tpl = ctx->d_tpl;
   ctx->blk_x = blocks[0].x;
   ctx->mb_tab = mb;
   ctx->mb_n = n_blocks;
   if (nr) {
-    HIP_TRY(hipMemcpyAsync(ctx->d_tpl, st, b_tpl, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ctx->d_seq, st + o_seq, b_seq, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_tpl, inplace ? (const void *)tpl : (const void *)st, b_tpl, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_seq, inplace ? (const void *)seq : (const void *)(st + o_seq), b_seq, hipMemcpyHostToDevice, s));
   }
-  HIP_TRY(hipMemcpyAsync(ctx->d_ref, st + o_ref, (size_t)P, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->d_mblk, mb, b_blk, hipMemcpyHostToDevice, s));
+  if (inplace) {
+    HIP_TRY(hipMemcpyAsync(ctx->d_refp, ref, (size_t)ref64, hipMemcpyHostToDevice, s));
+    int pe = bsc_dev_launch_ref_pad(ctx->d_refp, ctx->d_mblk, n_blocks, ctx->d_ref, P, ctx->num_cus, s);
+    if (pe) {
+      (void)hipStreamSynchronize(s);
+      return bsc_fail(BSC_ERR_HIP, "reference layout launch failed: %s", hipGetErrorString((hipError_t)pe));
+    }
+  } else HIP_TRY(hipMemcpyAsync(ctx->d_ref, st + o_ref, (size_t)P, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), s));
   HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), s));
   int e = bsc_dev_launch_bin_reads_multi(ctx->d_tpl, nr, ctx->d_seq, seq_bytes, ctx->d_mblk, n_blocks, P >> 6, ctx->d_tflag, ctx->d_bcnt,
@@ -1056,6 +1090,19 @@ int bsc_blocks_submit_to(bsc_context *ctx, const bsc_block_desc *blocks, uint32_
   ctx->pending_stride = out_stride;
   ctx->pending_copied = 1;
   return BSC_OK;
+}
+
+int bsc_blocks_submit_to(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                         uint64_t seq_bytes, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip, uint64_t *block_off) {
+  return bsc_blocks_submit_to_(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, out, out_stride, skip, block_off, 0);
+}
+
+/* no staging copy: templates, reads and reference codes are uploaded from where they lie (page-locked buffers from bsc_alloc_host
+ * make that a true DMA behind which the call returns) and must stay unchanged until bsc_block_fetch */
+int bsc_blocks_submit_to_inplace(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl,
+                                 const uint8_t *seq, uint64_t seq_bytes, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip,
+                                 uint64_t *block_off) {
+  return bsc_blocks_submit_to_(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, out, out_stride, skip, block_off, 1);
 }
 
 int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
@@ -1277,8 +1324,19 @@ static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t n
    * is told to (bsc_set_reads_fused) or the summaries cannot be allocated. */
   int two_kernels = !ctx->reads_fused;
   if (two_kernels) {
+    /* 88 bytes per position of HBM the one-kernel form does not need (a maximal block of 2^28 positions: 23 GB); kept, grow-only,
+     * in the context.  No room: the lean form — silently, and with the runtime's error state cleared (ROCm keeps a failed
+     * hipMalloc as its last error, which the launch check below would otherwise report as its own).
+     * BSC_TEST_FAIL_SUMMARY_ALLOC in the environment makes this allocation fail for real (tests/test_gpu_reads_chain.py). */
     const size_t n_pad = ((size_t)w.n + 63u) / 64u * 64u;
-    if (bsc_reserve(&ctx->d_cts, &ctx->cap_cts, n_pad * bsc_dev_summary_bytes()) != BSC_OK) two_kernels = 0; /* no room: the lean form */
+    size_t need = n_pad * bsc_dev_summary_bytes();
+    if (getenv("BSC_TEST_FAIL_SUMMARY_ALLOC")) {
+      void *never = NULL;
+      size_t cap0 = 0;
+      if (!bsc_try_reserve(&never, &cap0, (size_t)1 << 60)) need = 0;
+      else hipFree(never);
+    }
+    if (!need || !bsc_try_reserve(&ctx->d_cts, &ctx->cap_cts, need)) two_kernels = 0;
   }
   if (two_kernels) {
     e = bsc_dev_launch_accumulate_summary(ctx->d_rd, ctx->d_boff, d_seq, x, y, (uint32_t)ctx->params.min_qual, ctx->d_cts,
@@ -1606,7 +1664,7 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
       mb[b].pos_off = p_off;
       mb[b].bin0 = p_off >> 6;
       mb[b].bin_end = (p_off >> 6) + bsc_dev_n_bins(sz);
-      mb[b]._pad = 0;
+      mb[b].ref_in = 0;
       if (dbsnp) { /* the caller's flags are packed block after block; on the device every block starts on a multiple of 64 */
         memcpy(st + o_db + p_off, dbsnp + d_in, sz);
         memset(st + o_db + p_off + sz, 0, ((sz + 63u) & ~63u) - sz);

@@ -77,7 +77,7 @@ typedef struct bsc_chain_mblock {
   uint32_t ref_off;  /* its n + 2 reference codes start here in the reference buffer */
   uint32_t pos_off;  /* its positions start here in the per-position arrays: a multiple of 64 */
   uint32_t bin0, bin_end; /* its bins in bin_off[]: pos_off / 64 .. */
-  uint32_t _pad;
+  uint32_t ref_in;   /* bsc_blocks_submit_to_inplace: where its n + 2 codes lie in the packed reference the caller handed over */
 } bsc_chain_mblock;
 
 #endif

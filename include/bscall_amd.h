@@ -329,7 +329,8 @@ int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out);
  * Several blocks in ONE launch sequence.  The reference calls call_genotypes_ML once per maximal run of overlapping templates
  * (src/get_template_vector.c:141-147: 10^2 .. 10^7 positions a call) and its calc threads cost nothing to start; a GPU block
  * costs a dozen launches, four copies and a wait whatever its size, which a 10 000-position block does not repay.  A host that
- * holds blocks back (integration/call_genotypes_amd_overlap.c: until 1 M positions are pending, a contig ends or the run does)
+ * holds blocks back (integration/call_genotypes_amd_overlap.c: until 1 M positions or 65 536 blocks are pending, or the run ends;
+ * a batch may mix contigs — every block carries its own)
  * hands them over together: one upload, one grouping pass over all their reads, the reads-in chain over all their tiles, one
  * packing pass, one copy-out, one wait.  Every block is still a block of its own — its printer state flushed at its end
  * (src/print_vcf.c:529-546), its first two and last two positions without the neighbours' context — so the records and the
@@ -376,6 +377,14 @@ int bsc_blocks_records(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t 
  */
 int bsc_blocks_submit_to(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
                          uint64_t seq_bytes, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip, uint64_t *block_off);
+/* The same without the staging copy (round 5): templates, reads and reference codes are uploaded from where they lie — page-locked
+ * buffers from bsc_alloc_host make that a true DMA — and must stay unchanged until bsc_block_fetch, as the reference's align_list
+ * stays untouched until the next hand-off (src/process.c:61,68).  The form for a host that builds its batch straight in such
+ * buffers (integration/amd_overlap_protocol.h since round 5): the staged form from ordinary memory runs at a third of its rate
+ * (profiles/r05_small_blocks.txt). */
+int bsc_blocks_submit_to_inplace(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl,
+                                 const uint8_t *seq, uint64_t seq_bytes, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip,
+                                 uint64_t *block_off);
 
 /* bsc_vcf_format for a packed record. */
 int bsc_vcf_format_rec(const bsc_vcf_rec *r, const char *contig, const char *id, char *buf, size_t cap);
@@ -543,7 +552,9 @@ int bsc_last_reads_chain_ms(bsc_context *ctx, float *ms);
  * waves to a CU and hides its byte loads — inside the 128-register chain kernel it waits for them — and the summary's arithmetic
  * runs where there are issue slots to spare), taken whenever that workspace can be allocated.  1: always the ONE-kernel form
  * (reads-in chain: nothing per position in HBM but the records).  Same records and statistics either way.  (bsc_blocks_records
- * always runs the one-kernel form: small blocks are bound by launches and PCIe, not by the walk.) */
+ * always runs the one-kernel form: small blocks are bound by launches and PCIe, not by the walk.)  Memory: the two-kernel form
+ * keeps 88 bytes per position of the largest block seen so far in the context (grow-only; 4.4 GB for a 50 M-position block, 23 GB
+ * for a maximal one of 2^28) — a context that must stay lean sets 1. */
 int bsc_set_reads_fused(bsc_context *ctx, int fused);
 /* Window sizes for a caller that cuts a resident contig into windows of its own choosing (the reference's blocks are data
  * dependent, src/process_template.c:24-28; SURVEY.md 8d fixes 4 Mi).  bsc_chain_window_size: the largest window <= limit in

@@ -5,13 +5,14 @@
  *   synchronous   per block: bsc_prepare_templates (the process thread's read pre-processing) -> bsc_call_block into a
  *                 gt_vcf[] array -> the records are consumed                      (integration/call_genotypes_amd.c)
  *   overlapped    the protocol of integration/call_genotypes_amd_overlap.c itself (integration/amd_overlap_protocol.h, the
- *                 same code) against a mock of the reference's work_t (integration/mock_work.h): block k is submitted
- *                 (bsc_block_submit_to, into one of two pinned gt_vcf[] arrays) and the call returns once the meth
- *                 profiling thread has let go of work->ref1; at the start of the next call (and at the end of the run)
- *                 block k is fetched and PUBLISHED to a print thread that drains work->vcf[] in index order on the
- *                 `ready` flags exactly as the reference's does (src/process.c:87-104), reading work->ref beside it; a
- *                 profiling thread reads work->ref1 for every queued template while this thread, like the reference's
- *                 process thread, overwrites ref1 for the next block the moment the call returns
+ *                 same code) against a mock of the reference's work_t (integration/mock_work.h): a call appends its block
+ *                 to a batch in page-locked buffers and returns once the meth profiling thread has let go of work->ref1; a
+ *                 full batch is submitted (bsc_blocks_submit_to_inplace) while the batch before it is HANDED OVER block by
+ *                 block to a print thread that drains work->vcf[] in index order on the `ready` flags exactly as the
+ *                 reference's does (src/process.c:87-104), reading work->ref beside it; a profiling thread reads work->ref1
+ *                 for every queued template while this thread, like the reference's process thread, overwrites ref1 for the
+ *                 next block the moment the call returns.  BSC_DEMO_PRINT_NS in the environment makes the mock printer as
+ *                 slow as a real one (nanoseconds per position) for end-to-end timings.
  *
  * Both forms must deliver the same bytes: the program compares a running hash of every gt_vcf record in consumption
  * order and fails if they differ.  Then it forms VCF records of the last block and the run statistics, as round 1's
@@ -139,12 +140,15 @@ int main(int argc, char **argv) {
   pthread_t pt, mt;
   pthread_create(&pt, NULL, mock_print_thread, &wo);
   pthread_create(&mt, NULL, mock_mprof_thread, &wo);
+  /* BSC_DEMO_MPROF_JOBS: profiling jobs queued per block (default: one per template up to 2 000, each a mutex round trip with
+   * the mock profiling thread — which then dominates a timing of many small blocks) */
+  const int mprof_cap = getenv("BSC_DEMO_MPROF_JOBS") ? atoi(getenv("BSC_DEMO_MPROF_JOBS")) : 2000;
   t0 = now();
   for (int k = 0; k < nblk; k++) {
     const block_t *b = &blk[k];
     /* process_template_vector: the block's reference codes into work->ref1 (over the previous block's), one profiling job
      * per template (capped: the ring has 256 slots and the jobs are cheap here) */
-    mock_prepare_block(&wo, b->ref, b->sz, b->nt < 2000 ? (int)b->nt : 2000);
+    mock_prepare_block(&wo, b->ref, b->sz, (int)b->nt < mprof_cap ? (int)b->nt : mprof_cap);
     amd_overlap_call(&wo, NULL, b->tpl, b->nt, b->seq, b->seq_used, b->x, b->y); /* call_genotypes_ML: returns with the block in flight */
   }
   amd_overlap_join(&wo); /* join_calc_threads */
@@ -159,6 +163,8 @@ int main(int argc, char **argv) {
   pthread_join(pt, NULL);
   pthread_join(mt, NULL);
   const double t_over = now() - t0;
+  printf("glue protocol end to end: %.1f M positions/s (threshold %llu positions, mock printer %ld ns per position)\n",
+         (double)wo.records / t_over * 1e-6, (unsigned long long)amd_threshold, wo.print_ns);
   printf("%d blocks, %llu positions: synchronous %.1f ms, overlapped %.1f ms; consumer saw %llu / %llu records, hash %016llx / %016llx\n",
          nblk, (unsigned long long)ws.records, t_sync * 1e3, t_over * 1e3, (unsigned long long)ws.records,
          (unsigned long long)wo.records, (unsigned long long)ws.hash, (unsigned long long)wo.hash);

@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <bscall_amd.h>
 
@@ -49,6 +50,8 @@ typedef struct {
   uint64_t hash, records, covered; /* print thread: every byte it would read */
   uint64_t ref_hash;               /* print thread: the reference codes it saw beside each block */
   uint64_t mprof_jobs, mprof_bad;  /* profiling thread: jobs done, jobs that found ref1 changed under them */
+  long print_ns;                   /* BSC_DEMO_PRINT_NS: what the mock printer spends per position on top of hashing it (the
+                                      reference's prints a record in about a microsecond) — to time the hand-over under a slow consumer */
 } work_t;
 
 static uint64_t mock_fnv(uint64_t h, const void *p, size_t n) {
@@ -87,6 +90,11 @@ static void *mock_print_thread(void *arg) {
       }
       mock_consume(w, v);
     }
+    if (w->print_ns > 0) {
+      const long long ns = (long long)w->print_ns * n;
+      struct timespec ts = {(time_t)(ns / 1000000000ll), (long)(ns % 1000000000ll)};
+      nanosleep(&ts, NULL);
+    }
     pthread_mutex_lock(&w->print_mutex);
     w->vcf_n = 0;
     pthread_cond_signal(&w->print_cond2);
@@ -119,6 +127,10 @@ static void *mock_mprof_thread(void *arg) {
 static void mock_work_init(work_t *w) {
   memset(w, 0, sizeof *w);
   w->hash = w->ref_hash = 1469598103934665603ull;
+  {
+    const char *e = getenv("BSC_DEMO_PRINT_NS");
+    w->print_ns = e && *e ? atol(e) : 0;
+  }
   pthread_mutex_init(&w->print_mutex, NULL);
   pthread_mutex_init(&w->vcf_mutex, NULL);
   pthread_mutex_init(&w->mprof_mutex, NULL);

@@ -1,9 +1,11 @@
 /*
  * overlap_tsan.c — the overlapped glue's thread protocol (integration/amd_overlap_protocol.h) on the CPU alone, for
  * ThreadSanitizer: the same protocol code as integration/call_genotypes_amd_overlap.c, the mock work_t and the three
- * reference-shaped threads of integration/mock_work.h, and STUB bsc_* entries in this file — bsc_blocks_submit_to starts a
- * thread that fills the gt_vcf[] images of the batch's blocks a little later (the GPU's kernels and copy-out), bsc_block_fetch
- * joins it.  Blocks are held back until a batch holds argv[2] positions (default 9 000: a handful of blocks; 0: none held).
+ * reference-shaped threads of integration/mock_work.h, and STUB bsc_* entries in this file — bsc_blocks_submit_to_inplace starts a
+ * thread that fills the gt_vcf[] images of the batch's blocks a little later (the GPU's kernels and copy-out), reading the batch's
+ * inputs where they lie as the real entry does, bsc_block_fetch joins it.  Blocks are held back until a batch holds argv[2]
+ * positions (default 9 000: a handful of blocks; 0: none held); argv[3] = the largest block (default 5 000 positions; with 6 and
+ * 70 000 blocks under a huge threshold a batch reaches the library's 65 536-block limit and must be flushed by the glue itself).
  *
  *   gcc -O1 -g -fsanitize=thread -Iinclude integration/overlap_tsan.c -o /tmp/overlap_tsan -lpthread && /tmp/overlap_tsan
  *
@@ -62,11 +64,11 @@ static void *stub_worker(void *arg) {
   return NULL;
 }
 
-/* bsc_blocks_submit_to: every block's images from a multiple of 64 on, the offsets returned */
-int bsc_blocks_submit_to(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+/* bsc_blocks_submit_to_inplace: every block's images from a multiple of 64 on, the offsets returned */
+int bsc_blocks_submit_to_inplace(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
                          uint64_t seq_bytes, const uint8_t *ref, void *out, uint32_t out_stride, uint8_t *skip, uint64_t *block_off) {
   (void)tpl; (void)seq; (void)seq_bytes;
-  if (ctx->busy || out_stride != sizeof(gt_vcf) || n_blocks == 0) return BSC_ERR_ARG;
+  if (ctx->busy || out_stride != sizeof(gt_vcf) || n_blocks == 0 || n_blocks > 65536u) return BSC_ERR_ARG; /* the real entry's limits */
   uint64_t p = 0;
   for (uint32_t b = 0; b < n_blocks; b++) {
     block_off[b] = p;
@@ -92,7 +94,7 @@ int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
 
 int main(int argc, char **argv) {
   const int nblk = argc > 1 ? atoi(argv[1]) : 40;
-  const uint32_t max_sz = 5000;
+  const uint32_t max_sz = argc > 3 ? (uint32_t)atoi(argv[3]) : 5000, min_sz = max_sz > 400 ? 200 : 2;
   amd_overlap_init();
   amd_threshold = argc > 2 ? (uint64_t)atoll(argv[2]) : 9000u; /* a handful of blocks per batch; 0: every block its own batch */
   work_t w;
@@ -113,10 +115,10 @@ int main(int argc, char **argv) {
   uint64_t s = 88172645463325252ull;
   for (int k = 0; k < nblk; k++) {
     s ^= s << 13; s ^= s >> 7; s ^= s << 17;
-    const uint32_t sz = 200 + (uint32_t)(s % (max_sz - 200));
+    const uint32_t sz = min_sz + (uint32_t)(s % (max_sz - min_sz));
     for (uint32_t i = 0; i < sz + 2; i++) ref[i] = (uint8_t)(1 + ((s >> (i % 40)) + i * 7 + (uint32_t)k) % 4);
     /* the process thread: reference codes of the block into work->ref1, one profiling job per template */
-    mock_prepare_block(&w, ref, sz, 30 + (int)(s % 300));
+    mock_prepare_block(&w, ref, sz, max_sz > 400 ? 30 + (int)(s % 300) : 1 + (int)(s % 3));
     amd_overlap_call(&w, NULL, tpl, 4, seq, sizeof seq, x, x + sz - 1);
     /* ... and straight on to the next block: ref1 is overwritten at the top of the next iteration */
     expect.ref_hash = mock_fnv(expect.ref_hash, ref, (size_t)sz + 2);

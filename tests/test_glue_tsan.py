@@ -31,6 +31,12 @@ def test_overlap_protocol_is_tsan_clean(tmp_path):
         assert p.returncode == 0, p.stdout + p.stderr
         assert "ThreadSanitizer" not in p.stderr, p.stderr[-2000:]
         assert "record hash ok, reference hash ok" in p.stdout and " 0 saw ref1 change" in p.stdout
+    # more tiny blocks than one bsc_blocks_submit_to call takes (65 536), under a threshold that never triggers: the glue must
+    # flush by itself (the stub refuses a longer list, as the library does)
+    p = subprocess.run([exe, "70000", "1000000000", "6"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "ThreadSanitizer" not in p.stderr, p.stderr[-2000:]
+    assert "70000 blocks" in p.stdout and "record hash ok, reference hash ok" in p.stdout
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not found")

@@ -170,9 +170,10 @@ def test_blocks_errors_and_the_one_in_flight_rule(caller):
     assert len(caller.block_records(tpl, seq, x, y, refs[0])) == int(per[0])  # the context goes on
 
 
-def test_blocks_submit_to_equals_block_by_block(caller):
-    """bsc_blocks_submit_to (the gt_meth / gt_vcf form the drop-in glue batches small blocks through): every block's images are
-    the bytes of bsc_call_block on that block alone, the positions between blocks are images of nothing, counters add up."""
+def test_blocks_submit_to_equals_block_by_block(caller, oracle, tables, libm_exact):
+    """bsc_blocks_submit_to / bsc_blocks_submit_to_inplace (the gt_meth / gt_vcf form the drop-in glue batches small blocks through):
+    every block's images are the bytes of bsc_call_block on that block alone AND of the CPU oracle (HOT LOOP A, then the calc
+    threads' loop: oracle.accumulate + oracle.call_sites), the positions between blocks are images of nothing, counters add up."""
     rng = np.random.default_rng(77)
     blocks = [b[:4] + (b[4],) for b in _random_blocks(rng, 60, 1, 9_000, split_every=4)]
     refs = [b[4] for b in blocks]
@@ -180,9 +181,17 @@ def test_blocks_submit_to_equals_block_by_block(caller):
     caller.reset_stats()
     single = [caller.call_block(t, s, x, y, refs[i][: y - x + 1]) for i, (t, s, x, y) in enumerate(blocks)]
     st1 = caller.stats()
+    # the path the drop-in runs, against the oracle itself (not only against another HIP path): every third block
+    flav = oracle.LIBM if libm_exact else oracle.BSM
+    for i in range(0, len(blocks), 3):
+        t, s, x, y = blocks[i]
+        rc, pile = oracle.accumulate(t, s, x, y, 20)
+        assert rc == 0
+        exp, eskip = oracle.call_sites(pile, refs[i][: y - x + 1], tables, flav, -8)
+        assert single[i][0].tobytes() == exp.tobytes() and (single[i][1] == eskip).all(), i
     caller.reset_stats()
-    for stride in (200, 208):
-        off, out, skip = caller.blocks_submit_to(blocks, refs, out_stride=stride)
+    for stride, inplace in ((200, False), (208, False), (208, True), (200, True)):
+        off, out, skip = caller.blocks_submit_to(blocks, refs, out_stride=stride, inplace=inplace)
         for i, (t, s, x, y) in enumerate(blocks):
             n, o = y - x + 1, int(off[i])
             assert o % 64 == 0
@@ -195,8 +204,11 @@ def test_blocks_submit_to_equals_block_by_block(caller):
             pad = ((n + 63) // 64) * 64 - n
             assert (skip[o + n : o + n + pad] == 1).all()
     st2 = caller.stats()
-    assert st2["sites"] == 2 * st1["sites"] and st2["covered"] == 2 * st1["covered"] and st2["het_calls"] == 2 * st1["het_calls"]
+    assert st2["sites"] == 4 * st1["sites"] and st2["covered"] == 4 * st1["covered"] and st2["het_calls"] == 4 * st1["het_calls"]
     bad = blocks[3][0].copy()
     bad["bs_strand"][0] = 9
     with pytest.raises(B.BscError, match="bs_strand 9"):
         caller.blocks_submit_to(blocks[:3] + [(bad,) + blocks[3][1:]] + blocks[4:], refs)
+    with pytest.raises(B.BscError, match="bs_strand 9"):
+        caller.blocks_submit_to(blocks[:3] + [(bad,) + blocks[3][1:]] + blocks[4:], refs, inplace=True)
+    assert caller.blocks_submit_to(blocks[:2], refs[:2], inplace=True)[1][: blocks[0][3] - blocks[0][2] + 1].tobytes() == single[0][0].tobytes()

@@ -3,6 +3,8 @@
 src/get_template_vector.c:141-147: 10^2 .. 10^7 positions): host buffers in, packed records out, wall time per position.
   one by one   bsc_block_records per block (a dozen launches, four copies and one wait each)
   batched      bsc_blocks_records over batches of >= --batch positions (one launch sequence per batch)
+  gt_vcf form  bsc_blocks_submit_to (staged, from ordinary memory) and bsc_blocks_submit_to_inplace (page-locked buffers) + bsc_block_fetch:
+               208-byte images of every position, the form the drop-in glue runs (integration/amd_overlap_protocol.h)
 usage: python tools/bench_small_blocks.py [--batch 1000000] [--total 4000000] [--coverage 30] [--sizes 1000,10000,100000]"""
 import argparse
 import json
@@ -73,6 +75,29 @@ with B.SiteCaller() as c:
             if rep:
                 t_pin.append(time.perf_counter() - t0)
         assert n3 == n1
+        # ---- the gt_vcf form the drop-in glue runs (integration/amd_overlap_protocol.h): bsc_blocks_submit_to[_inplace] + bsc_block_fetch,
+        # 208-byte images of every position back into a page-locked array; straight through the C ABI on arrays joined beforehand
+        # (a) staged: inputs in ordinary memory, the library copies them to its pinned staging area (round 4's glue);
+        # (b) in place: the batch built in page-locked buffers (round 5's glue)
+        from bs_call_amd.caller import _ptr
+        L, h = c._L, c._h
+        P_max = max(sum(((b[3] - b[2] + 1 + 63) // 64) * 64 for b in g) for g, _ in groups)
+        img, skp = PinnedBuffer((P_max, 208), np.uint8), PinnedBuffer(P_max, np.uint8)
+        t_stage, t_inpl = [], []
+        pageable = [(d, np.array(t), np.array(sq), np.array(rf)) for d, t, sq, rf, _ in joined]
+        for rep in range(4):
+            for fn, lst, acc in ((L.bsc_blocks_submit_to, pageable, t_stage), (L.bsc_blocks_submit_to_inplace, [j[:4] for j in joined], t_inpl)):
+                t0 = time.perf_counter()
+                for d, t, sq, rf in lst:
+                    off = np.zeros(len(d), dtype=np.uint64)
+                    rc = fn(h, _ptr(d), len(d), _ptr(t), _ptr(sq), sq.size, _ptr(rf), _ptr(img.array), 208, _ptr(skp.array), _ptr(off))
+                    assert rc >= 0, rc
+                    rc = L.bsc_block_fetch(h, None, None)
+                    assert rc >= 0, rc
+                if rep:
+                    acc.append(time.perf_counter() - t0)
+        img.free()
+        skp.free()
         # the Python wrapper joins the blocks' arrays for the batched call (np.concatenate): timed apart, it is not the library's
         t0 = time.perf_counter()
         for g, r in groups:
@@ -83,11 +108,16 @@ with B.SiteCaller() as c:
                                 "batched_M_positions_per_s": total / min(t_bat) / 1e6, "batched_us_per_block": min(t_bat) / k * 1e6,
                                 "batched_minus_python_join_M_positions_per_s": total / max(min(t_bat) - join_s, 1e-9) / 1e6,
                                 "batched_inplace_pinned_M_positions_per_s": total / min(t_pin) / 1e6,
-                                "batched_inplace_pinned_us_per_block": min(t_pin) / k * 1e6, "blocks_per_batch": per_batch}
+                                "batched_inplace_pinned_us_per_block": min(t_pin) / k * 1e6, "blocks_per_batch": per_batch,
+                                "gt_vcf_images_staged_M_positions_per_s": total / min(t_stage) / 1e6,
+                                "gt_vcf_images_inplace_pinned_M_positions_per_s": total / min(t_inpl) / 1e6}
         print("%7d-position blocks x %4d: one by one %8.1f M positions/s (%6.0f us per block)   batched %8.1f M positions/s (%6.0f us per block; "
               "%.1f without the wrapper's array joins)   batched, in place from page-locked buffers %8.1f M positions/s (%6.0f us per block)"
               % (n, k, total / min(t_one) / 1e6, min(t_one) / k * 1e6, total / min(t_bat) / 1e6, min(t_bat) / k * 1e6,
                  total / max(min(t_bat) - join_s, 1e-9) / 1e6, total / min(t_pin) / 1e6, min(t_pin) / k * 1e6), file=sys.stderr)
+        print("%7s gt_vcf images (208 B per position back; what the drop-in glue runs): bsc_blocks_submit_to from ordinary memory %8.1f M positions/s"
+              "   bsc_blocks_submit_to_inplace from page-locked buffers %8.1f M positions/s" % ("", total / min(t_stage) / 1e6, total / min(t_inpl) / 1e6),
+              file=sys.stderr)
         for pb in keep:
             for q in pb:
                 q.free()
