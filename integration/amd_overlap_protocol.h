@@ -117,10 +117,14 @@ static void *amd_grow_to(void *p, size_t *cap, size_t need, size_t elem) {
   return p;
 }
 
-/* the same for a page-locked array holding `used` elements */
-static void *amd_grow_pinned(void *p, size_t *cap, size_t used, size_t need, size_t elem) {
+/* the same for a page-locked array holding `used` elements.  Page-locking memory is slow (milliseconds per call), and batches
+ * resemble each other: an array grows to at least what the largest array of its kind has needed so far (*hint), so that after the
+ * first batch the three slots are sized in one step each */
+static void *amd_grow_pinned(void *p, size_t *cap, size_t used, size_t need, size_t elem, size_t *hint) {
+  if (need > *hint) *hint = need;
   if (need > *cap) {
-    const size_t n = need + need / 2 + 4096;
+    size_t n = need + need / 2 + 4096;
+    if (n < *hint + *hint / 8) n = *hint + *hint / 8;
     void *q = bsc_alloc_host((uint64_t)n * elem);
     if (!q) amd_die("bsc_alloc_host");
     if (used) memcpy(q, p, used * elem);
@@ -245,9 +249,10 @@ static void amd_overlap_call(AMD_WORK_T *const work, AMD_CTG_T *const ctg, const
        amd_batch[amd_fill].n_blk >= AMD_BATCH_BLOCKS))
     amd_flush(work);
   struct amd_batch *q = &amd_batch[amd_fill];
-  q->tpl = amd_grow_pinned(q->tpl, &q->cap_tpl, q->n_tpl, q->n_tpl + nr, sizeof *q->tpl);
-  q->seq = amd_grow_pinned(q->seq, &q->cap_seq, q->n_seq, q->n_seq + (size_t)nbytes, 1);
-  q->ref = amd_grow_pinned(q->ref, &q->cap_ref, q->n_ref, q->n_ref + (size_t)sz + 3, 1);
+  static size_t hint_tpl, hint_seq, hint_ref;
+  q->tpl = amd_grow_pinned(q->tpl, &q->cap_tpl, q->n_tpl, q->n_tpl + nr, sizeof *q->tpl, &hint_tpl);
+  q->seq = amd_grow_pinned(q->seq, &q->cap_seq, q->n_seq, q->n_seq + (size_t)nbytes, 1, &hint_seq);
+  q->ref = amd_grow_pinned(q->ref, &q->cap_ref, q->n_ref, q->n_ref + (size_t)sz + 3, 1, &hint_ref);
   {
     size_t cap = q->cap_blk;
     q->desc = amd_grow_to(q->desc, &cap, q->n_blk + 1, sizeof *q->desc);

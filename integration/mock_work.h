@@ -61,6 +61,11 @@ static uint64_t mock_fnv(uint64_t h, const void *p, size_t n) {
 }
 
 static void mock_consume(work_t *w, const gt_vcf *v) { /* stands in for print_vcf_entry: every byte the printer would read */
+  if (w->print_ns < 0) { /* BSC_DEMO_PRINT_NS < 0: a consumer that only counts (timings of the hand-over itself; no hash to compare) */
+    w->records++;
+    w->covered += !v->skip;
+    return;
+  }
   uint64_t q[sizeof v->gtm / 8], h = w->hash;
   memcpy(q, &v->gtm, sizeof q);
   for (size_t i = 0; i < sizeof q / sizeof q[0]; i++) h = (h ^ q[i]) * 1099511628211ull;

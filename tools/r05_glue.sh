@@ -16,7 +16,7 @@ cat $O/small_blocks.txt
 : > $O/demo.txt
 # BSC_DEMO_MPROF_JOBS=4: the mock profiling thread costs a mutex round trip per job; with one job per template it, not the glue, is
 # what a run of small blocks waits for.  1 200 blocks of 10 000 positions: the page-locked arrays are allocated during the first batches.
-for ns in 0 10 40 100; do
+for ns in -1 0 40; do
   for exe in bs_call_amd/lib/demo_block bs_call_amd/lib/variants/demo_block_r4; do
     [ -x $exe ] || continue
     for rep in 1 2; do
