@@ -212,6 +212,38 @@ class SiteCaller:
                 b.free()
         return off, o2.copy(), s2.copy()
 
+    def prepare_templates_device(self, raw, seq, misms, left_trim=(0, 0), right_trim=(0, 0), min_qual=20, keep_on_device=False):
+        """bsc_prepare_templates_device: the read pre-processing on the GPU.  Host arrays in (uploaded with torch), the prepared
+        templates / read bytes / PREP_STATS back — or, keep_on_device, the two device tensors (uint8 views) and the byte count, for
+        a caller that goes on with accumulate_device / reads_chain_device."""
+        import torch
+
+        from .abi import MISMS, PREP_PARAMS, PREP_STATS, RAW_TEMPLATE
+
+        raw = np.ascontiguousarray(raw, dtype=RAW_TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        misms = np.ascontiguousarray(misms, dtype=MISMS)
+        par = np.zeros(1, dtype=PREP_PARAMS)
+        par["left_trim"][0], par["right_trim"][0], par["min_qual"][0] = left_trim, right_trim, min_qual
+        cap = int(seq.size) + int(np.minimum(misms["size"][misms["type"] == 1].astype(np.uint64), np.uint64(seq.size)).sum()) + 16
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def up(a):
+            b = a.view(np.uint8).reshape(-1)
+            return torch.from_numpy(b.copy()).to(dev) if b.size else torch.zeros(64, dtype=torch.uint8, device=dev)
+
+        d_raw, d_seq, d_ms = up(raw), up(seq), up(misms)
+        d_tpl = torch.zeros(max(len(raw), 1) * TEMPLATE.itemsize, dtype=torch.uint8, device=dev)
+        d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        used = C.c_uint64(0)
+        st = np.zeros(1, dtype=PREP_STATS)
+        _check(self._L.bsc_prepare_templates_device(self._h, d_raw.data_ptr(), len(raw), d_seq.data_ptr(), seq.size, d_ms.data_ptr(), len(misms),
+                                                    _ptr(par), d_tpl.data_ptr(), d_out.data_ptr(), cap, C.byref(used), _ptr(st), None))
+        if keep_on_device:
+            return d_tpl, d_out, int(used.value), st[0]
+        tpl = d_tpl.cpu().numpy()[: len(raw) * TEMPLATE.itemsize].view(TEMPLATE).copy()
+        return tpl, d_out.cpu().numpy()[: used.value].copy(), st[0]
+
     def block_fetch(self):
         """Wait for the submitted block and return (GT_METH[n] or uint8[n, stride], skip)."""
         if self._pending is None:
@@ -310,6 +342,32 @@ class SiteCaller:
                                          None if db is None else _ptr(db), C.byref(p), 1 if with_stats else 0, _ptr(out),
                                          len(out), C.byref(cnt)))
         return out[: cnt.value]
+
+    def block_records_raw(self, raw, seq, misms, x, y, ref, left_trim=(0, 0), right_trim=(0, 0), min_qual=20, all_positions=False,
+                          reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False, out=None):
+        """bsc_block_records_raw: one block from what the reader delivers (RAW_TEMPLATE[nr], read bytes, MISMS[]) to packed records;
+        the read pre-processing runs on the GPU.  Returns (VCF_REC[n_written], PREP_STATS record)."""
+        from .abi import MISMS, PREP_PARAMS, PREP_STATS, RAW_TEMPLATE
+
+        raw = np.ascontiguousarray(raw, dtype=RAW_TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        misms = np.ascontiguousarray(misms, dtype=MISMS)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        n = int(y) - int(x) + 1
+        if len(ref) != n + 2:
+            raise ValueError("ref must have y - x + 3 entries (x .. y + 2)")
+        db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+        if out is None:
+            out = np.zeros(n, dtype=VCF_REC)
+        par = np.zeros(1, dtype=PREP_PARAMS)
+        par["left_trim"][0], par["right_trim"][0], par["min_qual"][0] = left_trim, right_trim, min_qual
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        cnt = C.c_uint64(0)
+        st = np.zeros(1, dtype=PREP_STATS)
+        _check(self._L.bsc_block_records_raw(self._h, _ptr(raw), len(raw), _ptr(seq), seq.size, _ptr(misms), len(misms), _ptr(par), x, y,
+                                             _ptr(ref), None if db is None else _ptr(db), C.byref(p), 1 if with_stats else 0, _ptr(out),
+                                             len(out), C.byref(cnt), _ptr(st)))
+        return out[: cnt.value], st[0]
 
     def blocks_records(self, blocks, ref, out=None, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False,
                        submit_only=False):

@@ -64,6 +64,11 @@ int bsc_dev_launch_accumulate_summary(const void *rd, const void *bin_off, const
 size_t bsc_dev_summary_bytes(void);
 int bsc_dev_launch_accumulate_multi(const void *rd, const void *bin_off, const void *seq, const void *d_blk, uint32_t n_blk, uint32_t n_bins,
                                     uint32_t min_qual, void *cts, void *counters, int num_cus, void *stream);
+int bsc_dev_scan_tmp_bytes_u64(uint32_t n, size_t *bytes); /* sort.hip */
+size_t bsc_dev_prep_plan_bytes(void);                     /* prepdev.hip */
+int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *misms, uint64_t n_misms,
+                        const bsc_prep_params *par, void *ms_work, void *plan, void *out_len, void *out_off, void *scan_tmp,
+                        size_t scan_tmp_bytes, void *tpl_out, void *seq_out, uint64_t seq_out_cap, void *cnt, int num_cus, void *stream);
 int bsc_dev_launch_ref_pad(const void *packed, const void *d_blk, uint32_t n_blk, void *padded, uint32_t n_pos, int num_cus, void *stream);
 int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk, uint32_t n_blk,
                                    uint32_t n_bins, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
@@ -138,6 +143,10 @@ struct bsc_context {
   uint32_t mb_n;
   void *d_mblk, *d_mtab;
   size_t cap_mblk, cap_mtab;
+  /* bsc_prepare_templates_device: plans, output lengths / offsets, the edited mismatch lists, scan scratch, counters; and, for the
+   * host-buffer entry bsc_block_records_raw, the raw templates / reads / lists on the device */
+  void *d_pplan, *d_plen, *d_poff, *d_pms, *d_pscan, *d_pcnt, *d_raw, *d_rseq, *d_rms;
+  size_t cap_pplan, cap_plen, cap_poff, cap_pms, cap_pscan, cap_pcnt, cap_raw, cap_rseq, cap_rms;
   void *d_refp; /* bsc_blocks_submit_to_inplace: the caller's packed reference codes, before bsc_ref_pad_kernel lays them out */
   size_t cap_refp;
   const uint32_t *mb_toff;
@@ -429,6 +438,15 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_mblk);
   hipFree(ctx->d_mtab);
   hipFree(ctx->d_refp);
+  hipFree(ctx->d_pplan);
+  hipFree(ctx->d_plen);
+  hipFree(ctx->d_poff);
+  hipFree(ctx->d_pms);
+  hipFree(ctx->d_pscan);
+  hipFree(ctx->d_pcnt);
+  hipFree(ctx->d_raw);
+  hipFree(ctx->d_rseq);
+  hipFree(ctx->d_rms);
   hipFree(ctx->d_carry);
   hipFree(ctx->d_logp);
   hipFree(ctx->d_vout);
@@ -1401,6 +1419,120 @@ int bsc_last_chain_ms(bsc_context *ctx, float *ms) {
   return BSC_OK;
 }
 
+/* ---- read pre-processing on the device (prepdev.hip) ------------------------------------------------------------- */
+/* The device names a template and the check it fails; the words are csrc/prep.c's: that one template is fetched and run through
+ * the host form, whose message (and code) stand. */
+static int bsc_prep_device_error(bsc_context *ctx, unsigned long long word, const void *d_raw, const void *d_seq, const void *d_misms,
+                                 const bsc_prep_params *par) {
+  (void)ctx;
+  const uint32_t ti = (uint32_t)(word >> 8), code = (uint32_t)(word & 0xffu);
+  if (code == 9u) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates: seq_out too small (template %u)", ti);
+  bsc_raw_template t;
+  HIP_TRY(hipMemcpy(&t, (const char *)d_raw + (size_t)ti * sizeof t, sizeof t, hipMemcpyDeviceToHost));
+  if (code == 1u) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates: template %u has orientation %u", ti, t.orientation);
+  if (code == 2u || code == 3u) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates: read %d of template %u lies outside the read buffer", (int)code - 2, ti);
+  if (code == 4u || code == 5u)
+    return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates: mismatch list %d of template %u lies outside the list buffer", (int)code - 4, ti);
+  /* a soft clip or an indel the reference would abort on: the template's reads and lists (inside the buffers: the device checked)
+   * go through csrc/prep.c, numbered 0 there */
+  const size_t nb = (size_t)t.len[0] + t.len[1], nmm = (size_t)t.n_misms[0] + t.n_misms[1];
+  uint8_t *rb = malloc(nb + 1);
+  bsc_misms *mb = malloc((nmm + 1) * sizeof *mb);
+  uint8_t *so = NULL;
+  size_t so_cap = nb + 16;
+  if (!rb || !mb) {
+    free(rb);
+    free(mb);
+    return bsc_fail(BSC_ERR_NOMEM, "bsc_prepare_templates_device: out of memory");
+  }
+  bsc_raw_template l = t;
+  size_t ob = 0, om = 0;
+  for (int k = 0; k < 2; k++) {
+    if (t.len[k]) (void)hipMemcpy(rb + ob, (const char *)d_seq + t.off[k], t.len[k], hipMemcpyDeviceToHost);
+    if (t.n_misms[k])
+      (void)hipMemcpy(mb + om, (const char *)d_misms + (size_t)t.misms_off[k] * sizeof *mb, (size_t)t.n_misms[k] * sizeof *mb, hipMemcpyDeviceToHost);
+    l.off[k] = ob;
+    l.misms_off[k] = om;
+    ob += t.len[k];
+    om += t.n_misms[k];
+  }
+  for (size_t z = 0; z < nmm; z++) /* room for what the host form writes before it reaches the failing check */
+    if (mb[z].type == BSC_MISMS_INS && mb[z].size <= nb) so_cap += mb[z].size;
+  so = malloc(so_cap);
+  if (!so) {
+    free(rb);
+    free(mb);
+    return bsc_fail(BSC_ERR_NOMEM, "bsc_prepare_templates_device: out of memory");
+  }
+  bsc_template o;
+  uint64_t used = 0;
+  const int rc = bsc_prepare_templates(&l, 1, rb, nb, mb, nmm, par, &o, so, so_cap, &used, NULL); /* only its checks are wanted */
+  free(rb);
+  free(mb);
+  free(so);
+  if (rc >= 0 || strstr(bsc_errbuf, "seq_out too small"))
+    return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: template %u fails check %u on the device, none on the host", ti, code);
+  char msg[sizeof bsc_errbuf];
+  snprintf(msg, sizeof msg, "%s", bsc_errbuf);
+  char *at = strstr(msg, "template 0 ");
+  if (at) { /* "template 0 read k: ..." -> the template's index in the call */
+    char tail[sizeof bsc_errbuf];
+    snprintf(tail, sizeof tail, "%s", at + 11);
+    *at = 0;
+    return bsc_fail(rc, "%stemplate %u %s", msg, ti, tail);
+  }
+  return bsc_fail(rc, "%s (template %u)", msg, ti);
+}
+
+int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms,
+                                 uint64_t n_misms, const bsc_prep_params *par, void *d_tpl_out, void *d_seq_out, uint64_t seq_out_cap,
+                                 uint64_t *seq_out_used, bsc_prep_stats *stats, void *stream) {
+  if (!ctx || !par || !seq_out_used || (nr && (!d_raw || !d_tpl_out))) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: NULL argument");
+  if ((seq_bytes && !d_seq) || (n_misms && !d_misms) || (seq_out_cap && !d_seq_out))
+    return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: NULL buffer");
+  if (nr > 0x7fffffffu) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: more than 2^31 - 1 templates in one call");
+  if (((uintptr_t)d_raw & 7u) || ((uintptr_t)d_tpl_out & 7u) || ((uintptr_t)d_misms & 3u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: d_raw / d_tpl_out must be 8-byte, d_misms 4-byte aligned");
+  *seq_out_used = 0;
+  if (stats) memset(stats, 0, sizeof *stats);
+  BSC_ENTER(ctx);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  size_t scan_bytes = 0;
+  const uint32_t n2 = 2u * nr + 1u;
+  if (bsc_dev_scan_tmp_bytes_u64(n2, &scan_bytes)) return bsc_fail(BSC_ERR_HIP, "bsc_prepare_templates_device: scan size query failed");
+  if ((rc = bsc_reserve(&ctx->d_pplan, &ctx->cap_pplan, (size_t)(nr ? nr : 1) * 2u * bsc_dev_prep_plan_bytes()))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_plen, &ctx->cap_plen, (size_t)n2 * 8u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_poff, &ctx->cap_poff, (size_t)n2 * 8u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_pms, &ctx->cap_pms, (size_t)(n_misms ? n_misms : 1) * sizeof(bsc_misms)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_pscan, &ctx->cap_pscan, scan_bytes ? scan_bytes : 1))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_pcnt, &ctx->cap_pcnt, 8 * sizeof(unsigned long long)))) return rc;
+  HIP_TRY(hipMemsetAsync(ctx->d_pcnt, 0, 8 * sizeof(unsigned long long), s));
+  HIP_TRY(hipMemsetAsync(ctx->d_pcnt, 0xff, sizeof(unsigned long long), s));
+  int e = bsc_dev_launch_prep(d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, par, ctx->d_pms, ctx->d_pplan, ctx->d_plen, ctx->d_poff,
+                              ctx->d_pscan, scan_bytes, d_tpl_out, d_seq_out, seq_out_cap, ctx->d_pcnt, ctx->num_cus, s);
+  if (e) {
+    (void)hipStreamSynchronize(s);
+    return bsc_fail(BSC_ERR_HIP, "read pre-processing launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
+  unsigned long long h[9];
+  HIP_TRY(hipMemcpyAsync(h, ctx->d_pcnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h + 8, (const char *)ctx->d_poff + (size_t)(nr ? 2u * nr : 0u) * 8u, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h[0] != ~0ull) return bsc_prep_device_error(ctx, h[0], d_raw, d_seq, d_misms, par);
+  *seq_out_used = h[8];
+  if (stats) {
+    stats->base_clip = h[1];
+    stats->base_overlap = h[2];
+    stats->base_none = h[3];
+    stats->base_trim = h[4];
+    stats->base_lowqual = h[5];
+    stats->reads = h[6];
+    stats->read_bases = h[7];
+  }
+  return BSC_OK;
+}
+
 /* ---- written records, packed ------------------------------------------------------------------------------ */
 int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_gtm, uint32_t gtm_stride,
                            const void *d_dbsnp, uint32_t n, void *d_out, uint64_t out_cap, void *d_count, void *stream) {
@@ -1434,11 +1566,14 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
  * records together.  The copy-out is sized before the count is known, from the share of positions the previous blocks
  * wrote a record for (WGBS: every C and G, about half); only a block that writes more than that pays a second copy.
  */
+/* tpl == NULL with nr != 0: the templates and their reads are already in ctx->d_tpl / ctx->d_seq (bsc_block_records_raw: the device
+ * prepared them) */
 static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
                              uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
                              bsc_vcf_rec *out, uint64_t out_cap, int stage) {
+  const int resident = nr && !tpl;
   if (y < x) return bsc_fail(BSC_ERR_ARG, "accumulate: y (%u) < x (%u) (reference asserts y >= x)", y, x);
-  if (nr && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "accumulate: NULL template or read buffer");
+  if (nr && !resident && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "accumulate: NULL template or read buffer");
   if (ctx->pending_sz || ctx->rec_pending)
     return bsc_fail(BSC_ERR_ARG, "a submitted block has not been fetched (bsc_block_fetch / bsc_block_records_fetch first)");
   const uint64_t sz64 = (uint64_t)y - x + 1;
@@ -1446,8 +1581,10 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   const uint32_t sz = (uint32_t)sz64;
   BSC_ENTER(ctx);
   int rc;
-  if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
+  if (!resident) {
+    if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
+  }
   if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)sz + 2))) return rc;
   if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)sz * 64u))) return rc; /* the chain's aux array */
   if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)sz * sizeof(bsc_vcf_core)))) return rc;
@@ -1456,11 +1593,12 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   if (!ctx->h_cnt && hipHostMalloc((void **)&ctx->h_cnt, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
     return bsc_fail(BSC_ERR_NOMEM, "bsc_block_records: pinned counter block");
   if (stage) { /* the caller may recycle its buffers as soon as the call returns: inputs go through the pinned staging area */
-    const size_t b_tpl = (size_t)nr * sizeof(bsc_template), b_seq = (size_t)seq_bytes, b_ref = (size_t)sz + 2, b_db = dbsnp ? (size_t)sz : 0;
+    const size_t b_tpl = resident ? 0 : (size_t)nr * sizeof(bsc_template), b_seq = resident ? 0 : (size_t)seq_bytes, b_ref = (size_t)sz + 2,
+                 b_db = dbsnp ? (size_t)sz : 0;
     const size_t o_seq = (b_tpl + 63u) & ~(size_t)63u, o_ref = (o_seq + b_seq + 63u) & ~(size_t)63u, o_db = (o_ref + b_ref + 63u) & ~(size_t)63u;
     if ((rc = bsc_stage_reserve(ctx, o_db + b_db + 64u))) return rc;
     char *st = ctx->h_stage;
-    if (nr) {
+    if (nr && !resident) {
       memcpy(st, tpl, b_tpl);
       memcpy(st + o_seq, seq, b_seq);
       tpl = (const bsc_template *)st;
@@ -1474,11 +1612,11 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
     }
   }
   hipStream_t s = ctx->stream;
-  ctx->blk_tpl = tpl;
+  ctx->blk_tpl = tpl; /* resident: NULL — a bad template is fetched from the device for the message */
   ctx->blk_d_tpl = ctx->d_tpl;
   ctx->blk_x = x;
   ctx->mb_n = 0;
-  if (nr) {
+  if (nr && !resident) {
     HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
   }
@@ -1540,6 +1678,50 @@ int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, co
     return rc;
   }
   BSC_ENTER(ctx);
+  return bsc_records_finish(ctx, n_out);
+}
+
+/*
+ * bsc_block_records from what the READER delivers: raw templates with their mismatch lists (bsc_read_block) — uploaded as they are,
+ * prepared on the device (bsc_prepare_templates_device: trims, soft clips, mate overlap, indel normalisation), and straight on to
+ * the grouping, the walk and the chain; the process thread's per-template work (src/process_template.c:36-111) never touches a
+ * host core.  x .. y: the block as the reader found it (src/get_template_vector.c:141-147; x = bsc_block_start).
+ */
+int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                          const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref,
+                          const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap,
+                          uint64_t *n_out, bsc_prep_stats *prep_stats) {
+  if (!ctx || !ref || !params || !prep || !n_out || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: NULL argument");
+  *n_out = 0;
+  if (prep_stats) memset(prep_stats, 0, sizeof *prep_stats);
+  if (ctx->rec_pending || ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: a submitted block has not been fetched");
+  if (nr && (!raw || (seq_bytes && !seq) || (n_misms && !misms))) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: NULL input buffer");
+  if (!nr) return bsc_block_records(ctx, NULL, 0, NULL, 0, x, y, ref, dbsnp, params, with_stats, out, out_cap, n_out);
+  BSC_ENTER(ctx);
+  /* room for the prepared reads: the bytes handed over plus every padded deletion (a size no read could hold is damage: the
+   * device refuses that list) */
+  uint64_t cap = seq_bytes + 16;
+  for (uint64_t z = 0; z < n_misms; z++)
+    if (misms[z].type == BSC_MISMS_INS && misms[z].size <= seq_bytes) cap += misms[z].size;
+  int rc;
+  if ((rc = bsc_reserve(&ctx->d_raw, &ctx->cap_raw, (size_t)nr * sizeof *raw))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_rseq, &ctx->cap_rseq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_rms, &ctx->cap_rms, (size_t)(n_misms ? n_misms : 1) * sizeof *misms))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)nr * sizeof(bsc_template)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)cap))) return rc;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->d_raw, raw, (size_t)nr * sizeof *raw, hipMemcpyHostToDevice, s));
+  if (seq_bytes) HIP_TRY(hipMemcpyAsync(ctx->d_rseq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
+  if (n_misms) HIP_TRY(hipMemcpyAsync(ctx->d_rms, misms, (size_t)n_misms * sizeof *misms, hipMemcpyHostToDevice, s));
+  uint64_t used = 0;
+  if ((rc = bsc_prepare_templates_device(ctx, ctx->d_raw, nr, ctx->d_rseq, seq_bytes, ctx->d_rms, n_misms, prep, ctx->d_tpl, ctx->d_seq, cap, &used,
+                                         prep_stats, s)))
+    return rc; /* (it has waited for the stream: nothing reads the caller's buffers any more) */
+  rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 0);
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
   return bsc_records_finish(ctx, n_out);
 }
 

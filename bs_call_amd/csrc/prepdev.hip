@@ -1,0 +1,454 @@
+/*
+ * prepdev.hip — read pre-processing ON THE DEVICE: from the templates the reader hands over (reads as
+ * base | qual << 2 bytes with their CIGAR-derived mismatch lists) to the templates the pile-up accumulate stage consumes — what the
+ * reference's process thread does to every template of a block before it calls call_genotypes_ML
+ * (src/process_template.c:36-111): trim_read (src/read_utils.c:13-26), trim_soft_clips (src/al_utils.c:122-162), handle_overlap
+ * (src/al_utils.c:164-318), the indel normalisation (src/process_template.c:62-108).  The host form is csrc/prep.c; the bar is
+ * byte equality with it (and with the tests' pure-Python restatement), quirks included (tests/test_gpu_prep.py).
+ *
+ * The host form edits every read in place (memmove).  Here nothing moves until the end:
+ *   bsc_prep_plan_kernel   one thread per template.  The reads' bytes are not touched except for the mean qualities that break a
+ *                          tie between mates of equal span.  What the trims, clips and the overlap do to a read is a WINDOW of it
+ *                          (first byte, length) and an edited copy of its mismatch list; what the normalisation does is, per list
+ *                          entry, where it cuts or pads (ix1, src/process_template.c:93).  Out: the plan of both reads, the output
+ *                          lengths (for the prefix sum that places the reads in the output buffer), the template's positions.
+ *   bsc_prep_copy_kernel   one wave per template.  Output byte j of a read comes from the inverse of the list's edits — walked
+ *                          backwards, a padded deletion gives 0, everything else an index into the window — through the fixed
+ *                          trims' marks (quality 63; the right trim takes the BASE of the byte mirrored at the read's other end,
+ *                          as the reference's loop does).  Consecutive lanes = consecutive output bytes.  Also here, because every
+ *                          byte passes by: the base counters of the statistics (:50-59) and bsc_template.flags (was read 0
+ *                          walked, src/call_genotypes.c:198-211).
+ * Where the reference aborts (an illegal soft clip ...) the lowest offending template and its first failing check come back
+ * through one atomicMin; the host entry runs csrc/prep.c on that one template for the message.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bscall_amd.h"
+
+#define FLT_QUAL 63u
+
+/* what the plan kernel leaves per read (48 bytes) */
+struct bsc_prep_plan {
+  uint64_t src;     /* offset of the ORIGINAL read's first byte in seq */
+  uint64_t ms;      /* index of its edited mismatch list in ms_work */
+  uint32_t rl0;     /* the original read's length */
+  uint32_t w0, wl;  /* the window of it that is left: first byte, length */
+  uint32_t nm;      /* entries of the edited list; their `position` is ix1 (src/process_template.c:93) */
+  uint32_t mark_l, mark_r; /* fixed trims: this many bytes from either end of the original read carry quality 63 */
+  uint32_t out_len;
+  uint32_t present; /* the reader delivered a vector for this read (t->len[k] != 0): it counts in filter_cts (:57-58) */
+};
+
+/* error codes, in the order csrc/prep.c makes its checks; the low byte of the word the kernels atomicMin */
+#define PE_ORI 1u
+#define PE_READ 2u  /* + k */
+#define PE_LIST 4u  /* + k */
+#define PE_SOFT_POS 6u
+#define PE_SOFT_ILL 7u
+#define PE_INDEL 8u
+#define PE_CAP 9u   /* the output buffer is too small */
+
+struct prep_rd {
+  uint32_t w0, wl;
+};
+__device__ static __forceinline__ void d_left_trim(prep_rd &r, uint32_t l) { /* src/al_utils.c:103-113 */
+  if (l > 0) {
+    if (l >= r.wl) r.wl = 0;
+    else {
+      r.w0 += l;
+      r.wl -= l;
+    }
+  }
+}
+__device__ static __forceinline__ void d_right_trim(prep_rd &r, uint32_t l) { /* src/al_utils.c:115-120 */
+  if (l > 0) {
+    if (l >= r.wl) r.wl = 0;
+    else r.wl -= l;
+  }
+}
+
+/* quality of byte i of the original read after the fixed trims */
+__device__ static __forceinline__ uint32_t d_qual(const uint8_t *sp, uint32_t i, uint32_t rl0, uint32_t mark_l, uint32_t mark_r) {
+  return (i < mark_l || i >= rl0 - mark_r) ? FLT_QUAL : (uint32_t)sp[i] >> 2;
+}
+
+/* src/al_utils.c:191-203 over the read's window */
+__device__ static uint32_t d_mean_qual(const uint8_t *sp, const prep_rd &r, uint32_t rl0, uint32_t mark_l, uint32_t mark_r) {
+  uint32_t tot = 0;
+  int n = 0;
+  for (uint32_t i = 0; i < r.wl; i++) {
+    const uint32_t q = d_qual(sp, r.w0 + i, rl0, mark_l, mark_r);
+    if (q != FLT_QUAL) {
+      tot += q;
+      n++;
+    }
+  }
+  return n > 0 ? tot / (uint32_t)n : 0;
+}
+
+__global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_template *__restrict__ raw, uint32_t nr, const uint8_t *__restrict__ seq,
+                                                            uint64_t seq_bytes, const bsc_misms *__restrict__ misms_in, uint64_t n_misms_in,
+                                                            bsc_prep_params par, bsc_misms *__restrict__ ms_work,
+                                                            bsc_prep_plan *__restrict__ plan, unsigned long long *__restrict__ out_len,
+                                                            bsc_template *__restrict__ tpl_out, unsigned long long *__restrict__ cnt) {
+  const uint32_t ti = blockIdx.x * 256u + threadIdx.x;
+  unsigned long long n_clip = 0, n_overlap = 0;
+  uint32_t err = 0;
+  if (ti < nr) {
+    const bsc_raw_template t = raw[ti];
+    bsc_prep_plan P[2];
+    prep_rd rd[2];
+    uint32_t nm[2];
+    bsc_misms *ms[2];
+    uint32_t pos[2] = {t.pos[0], t.pos[1]};
+    if (t.orientation > 1) err = PE_ORI;
+    for (int k = 0; k < 2 && !err; k++) {
+      if (t.len[k] && (t.off[k] > seq_bytes || t.len[k] > seq_bytes - t.off[k])) err = PE_READ + (uint32_t)k;
+      else if (t.n_misms[k] && (t.misms_off[k] > n_misms_in || t.n_misms[k] > n_misms_in - t.misms_off[k])) err = PE_LIST + (uint32_t)k;
+    }
+    if (!err) {
+      /* 1. fixed trims (src/process_template.c:39-41): read[0] is R1 on a FORWARD template, R2 on a REVERSE one — as marks */
+      const int msk = t.orientation == 0 ? 0 : 1;
+      for (int k = 0; k < 2; k++) {
+        const int side = k ^ msk; /* rd[k] is trimmed with left_trim[side], right_trim[side] */
+        const uint32_t rl = t.len[k];
+        const int32_t lt = par.left_trim[side], rt = par.right_trim[side];
+        P[k].src = t.off[k];
+        P[k].ms = t.misms_off[k];
+        P[k].rl0 = rl;
+        P[k].mark_l = lt > 0 ? ((uint32_t)lt < rl ? (uint32_t)lt : rl) : 0u;
+        P[k].mark_r = rt > 0 ? ((uint32_t)rt < rl ? (uint32_t)rt : rl) : 0u;
+        P[k].present = rl != 0;
+        rd[k].w0 = 0;
+        rd[k].wl = rl;
+        nm[k] = t.n_misms[k];
+        ms[k] = ms_work + t.misms_off[k];
+        for (uint32_t z = 0; z < nm[k]; z++) ms[k][z] = misms_in[t.misms_off[k] + z];
+      }
+      /* 2. soft clips (src/al_utils.c:122-162) */
+      for (int k = 0; k < 2 && !err; k++) {
+        const uint32_t rl = rd[k].wl;
+        if (rl == 0) continue;
+        int nclip = 0;
+        uint32_t adj = 0;
+        const uint32_t n0 = nm[k];
+        for (uint32_t z = 0; z < n0; z++) {
+          bsc_misms *m = ms[k] + z;
+          if (m->type == BSC_MISMS_SOFT) {
+            if (z && z != n0 - 1) { err = PE_SOFT_POS; break; }
+            nclip++;
+            if (!m->position) {
+              if (m->size >= rl) { err = PE_SOFT_ILL; break; }
+              adj = m->size;
+              n_clip += adj;
+              d_left_trim(rd[k], adj);
+            } else {
+              if (m->position + m->size != rl) { err = PE_SOFT_ILL; break; }
+              d_right_trim(rd[k], m->size);
+              n_clip += m->size;
+            }
+          } else if (nclip) {
+            m->position -= adj;
+            ms[k][z - (uint32_t)nclip] = *m;
+          }
+        }
+        if (nclip) nm[k] -= (uint32_t)nclip;
+      }
+    }
+    if (!err) {
+      /* 3. mate overlap (src/al_utils.c:164-318) */
+      const uint32_t rdl[2] = {rd[0].wl, rd[1].wl};
+      if (rdl[0] > 0 && rdl[1] > 0) {
+        int rev;
+        int32_t overlap;
+        if (pos[0] <= pos[1]) {
+          overlap = (int32_t)(t.reference_span[0] - pos[1] + pos[0]);
+          rev = 0;
+        } else {
+          overlap = (int32_t)(t.reference_span[1] + pos[1] - pos[0]);
+          rev = 1;
+        }
+        if (pos[0] + t.reference_span[0] >= pos[1]) {
+          const uint32_t *rspan = t.reference_span;
+          int tr; /* the read that is trimmed */
+          if (rspan[0] > rspan[1]) tr = 1;
+          else if (rspan[0] < rspan[1]) tr = 0;
+          else
+            tr = d_mean_qual(seq + P[0].src, rd[0], P[0].rl0, P[0].mark_l, P[0].mark_r) <=
+                         d_mean_qual(seq + P[1].src, rd[1], P[1].rl0, P[1].mark_l, P[1].mark_r)
+                     ? 0
+                     : 1;
+          const int right = (rev && tr) || !(rev || tr); /* trim the right end of read tr; else its left end */
+          if (!right) { /* a left trim moves the read's start */
+            if (tr) pos[1] += (uint32_t)overlap;
+            else pos[0] += (uint32_t)overlap;
+          }
+          bsc_misms *mm = ms[tr];
+          uint32_t num = nm[tr];
+          if (!num) {
+            if (right) d_right_trim(rd[tr], (uint32_t)overlap);
+            else d_left_trim(rd[tr], (uint32_t)overlap);
+          } else {
+            int trimmed = 0;
+            if (right) {
+              const uint32_t xx = t.reference_span[tr] - (uint32_t)overlap;
+              int64_t adj = 0;
+              for (uint32_t z = 0; z < num; z++) {
+                bsc_misms *m = mm + z;
+                if ((int64_t)m->position + adj >= (int64_t)xx) {
+                  const int64_t trim = (int64_t)rdl[tr] - xx + adj;
+                  d_right_trim(rd[tr], (uint32_t)trim);
+                  num = z;
+                  trimmed = 1;
+                  break;
+                }
+                if (m->type == BSC_MISMS_INS) {
+                  if ((int64_t)m->position + adj + m->size >= (int64_t)xx) {
+                    const int64_t trim = (int64_t)rdl[tr] - m->position;
+                    m->size = (uint32_t)((int64_t)xx - ((int64_t)m->position + adj));
+                    d_right_trim(rd[tr], (uint32_t)trim);
+                    num = z + 1;
+                    trimmed = 1; /* (no break in the reference: the walk goes on over the shortened list) */
+                  }
+                  adj += m->size;
+                } else if (m->type == BSC_MISMS_DEL) adj -= m->size;
+              }
+              if (!trimmed) d_right_trim(rd[tr], (uint32_t)overlap);
+            } else {
+              const uint32_t xx = (uint32_t)overlap;
+              int64_t adj = 0;
+              uint32_t z;
+              for (z = 0; z < num; z++) {
+                bsc_misms *m = mm + z;
+                if ((int64_t)m->position + adj >= (int64_t)xx) {
+                  const uint32_t trim = (uint32_t)((int64_t)overlap - adj);
+                  d_left_trim(rd[tr], trim);
+                  trimmed = 1;
+                  if (z) {
+                    for (uint32_t z1 = z; z1 < num; z1++) {
+                      mm[z1].position -= trim;
+                      const bsc_misms a = mm[z1], b = mm[z1 - z];
+                      mm[z1 - z] = a;
+                      mm[z1] = b;
+                    }
+                    num -= z;
+                  } else {
+                    for (uint32_t z1 = 0; z1 < num; z1++) mm[z1].position -= trim;
+                  }
+                  break;
+                }
+                if (m->type == BSC_MISMS_INS) {
+                  if ((int64_t)m->position + adj + m->size >= (int64_t)xx) {
+                    m->size = (uint32_t)((int64_t)m->position + m->size + adj - xx);
+                    const uint32_t trim = m->position;
+                    d_left_trim(rd[tr], trim);
+                    trimmed = 1;
+                    const uint32_t z2 = m->size ? z : z + 1;
+                    for (uint32_t z1 = z2; z1 < num; z1++) {
+                      mm[z1].position -= trim;
+                      if (z2) {
+                        const bsc_misms a = mm[z1], b = mm[z1 - z2];
+                        mm[z1 - z2] = a;
+                        mm[z1] = b;
+                      }
+                    }
+                    num -= z2;
+                    break;
+                  }
+                  adj += m->size;
+                } else if (m->type == BSC_MISMS_DEL) adj -= m->size;
+              }
+              if (!trimmed) {
+                d_left_trim(rd[tr], (uint32_t)((int64_t)overlap - adj));
+                num = 0;
+              }
+            }
+          }
+          nm[tr] = num;
+          n_overlap += (rdl[0] - rd[0].wl) + (rdl[1] - rd[1].wl);
+        }
+      }
+      /* 4. indel normalisation (src/process_template.c:62-108): where every entry cuts or pads — ix1 — and the length that results */
+      for (int k = 0; k < 2 && !err; k++) {
+        const uint32_t rl = rd[k].wl;
+        uint32_t adj = 0;
+        for (uint32_t z = 0; z < nm[k]; z++) {
+          bsc_misms *m = ms[k] + z;
+          const uint32_t ix1 = m->position + adj;
+          if (m->type == BSC_MISMS_INS) {
+            if (ix1 > rl + adj) { err = PE_INDEL; break; }
+            adj += m->size;
+          } else if (m->type == BSC_MISMS_DEL) {
+            if ((uint64_t)ix1 + m->size > (uint64_t)rl + adj) { err = PE_INDEL; break; }
+            adj -= m->size;
+          }
+          m->position = ix1;
+        }
+        P[k].w0 = rd[k].w0;
+        P[k].wl = rl;
+        P[k].nm = nm[k];
+        P[k].out_len = rl + adj;
+      }
+    }
+    if (err) {
+      for (int k = 0; k < 2; k++) {
+        P[k].src = P[k].ms = 0;
+        P[k].rl0 = P[k].w0 = P[k].wl = P[k].nm = P[k].mark_l = P[k].mark_r = P[k].out_len = P[k].present = 0;
+      }
+      atomicMin(&cnt[0], ((unsigned long long)ti << 8) | err);
+      n_clip = n_overlap = 0;
+    }
+    plan[2u * ti] = P[0];
+    plan[2u * ti + 1u] = P[1];
+    out_len[2u * ti] = P[0].out_len;
+    out_len[2u * ti + 1u] = P[1].out_len;
+    bsc_template o;
+    o.pos[0] = pos[0];
+    o.pos[1] = pos[1];
+    o.len[0] = P[0].out_len;
+    o.len[1] = P[1].out_len;
+    o.off[0] = o.off[1] = 0; /* the copy kernel knows where the reads land */
+    o.mapq[0] = t.mapq[0];
+    o.mapq[1] = t.mapq[1];
+    o.orientation = t.orientation;
+    o.bs_strand = t.bs_strand;
+    o.flags = 0;
+    tpl_out[ti] = o;
+  }
+  /* base_clip, base_overlap: wave sums, one atomic each */
+  for (int o = 32; o > 0; o >>= 1) {
+    n_clip += __shfl_xor(n_clip, o);
+    n_overlap += __shfl_xor(n_overlap, o);
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    if (n_clip) atomicAdd(&cnt[1], n_clip);
+    if (n_overlap) atomicAdd(&cnt[2], n_overlap);
+  }
+}
+
+/* byte i (0 <= i < rl0) of the original read after the fixed trims (src/read_utils.c:13-26): the left trim keeps the base; the
+ * right trim's loop writes sp[rl - 1 - k1] = base of sp[k1] — the mirrored byte, unless that one was itself overwritten earlier
+ * in the loop (the trim reaches past the middle), in which case the byte gets its own base back */
+__device__ static __forceinline__ uint32_t d_marked(const uint8_t *sp, uint32_t i, uint32_t rl0, uint32_t mark_l, uint32_t mark_r) {
+  const bool in_r = i >= rl0 - mark_r;
+  const uint32_t b = sp[(in_r && 2u * i > rl0 - 1u) ? rl0 - 1u - i : i];
+  return (i < mark_l || in_r) ? (b & 3u) | (FLT_QUAL << 2) : (uint32_t)sp[i];
+}
+
+#define PREP_WAVES 4
+__global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bsc_prep_plan *__restrict__ plan, uint32_t nr,
+                                                                        const uint8_t *__restrict__ seq, const bsc_misms *__restrict__ ms_work,
+                                                                        const unsigned long long *__restrict__ out_off, int32_t min_qual,
+                                                                        bsc_template *__restrict__ tpl_out, uint8_t *__restrict__ seq_out,
+                                                                        uint64_t seq_out_cap, unsigned long long *__restrict__ cnt) {
+  const unsigned lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * PREP_WAVES + (threadIdx.x >> 6), n_waves = gridDim.x * PREP_WAVES;
+  uint32_t c_trim = 0, c_low = 0, c_none = 0, c_reads = 0; /* per lane; summed over the wave at the end */
+  unsigned long long c_bases = 0;
+  for (uint32_t ti = wave; ti < nr; ti += n_waves) {
+    uint32_t flags = BSC_TPL_WALK_KNOWN;
+    for (int k = 0; k < 2; k++) {
+      const bsc_prep_plan P = plan[2u * ti + (uint32_t)k];
+      const unsigned long long off = out_off[2u * ti + (uint32_t)k];
+      const uint8_t *const sp = seq + P.src;
+      if (lane == 0) {
+        tpl_out[ti].off[k] = off;
+        if (P.present) {
+          c_reads++;
+          c_bases += P.wl;
+        }
+      }
+      /* the base counters of the statistics (:50-59) run over the window, before the normalisation */
+      if (P.nm) {
+        for (uint32_t s = lane; s < P.wl; s += 64u) {
+          const uint32_t q = d_marked(sp, P.w0 + s, P.rl0, P.mark_l, P.mark_r) >> 2;
+          if (q == FLT_QUAL) c_trim++;
+          else if ((int)q < min_qual) c_low++;
+          else c_none++;
+        }
+      }
+      const bsc_misms *const ms = ms_work + P.ms;
+      bool walked = false;
+      for (uint32_t j0 = 0; j0 < P.out_len; j0 += 64u) {
+        const uint32_t j = j0 + lane;
+        if (j < P.out_len) {
+          /* the list's edits undone, last first: INS (a deletion from the reference) padded `size` zeros in at ix1, DEL (an
+           * insertion) cut `size` bytes out at ix1 */
+          uint32_t s = j;
+          bool pad = false;
+          for (uint32_t z = P.nm; z-- > 0;) {
+            const bsc_misms m = ms[z];
+            if (m.type == BSC_MISMS_INS) {
+              if (s >= m.position) {
+                if (s - m.position < m.size) {
+                  pad = true;
+                  break;
+                }
+                s -= m.size;
+              }
+            } else if (m.type == BSC_MISMS_DEL) {
+              if (s >= m.position) s += m.size;
+            }
+          }
+          const uint32_t byte = pad ? 0u : d_marked(sp, P.w0 + s, P.rl0, P.mark_l, P.mark_r);
+          if (!P.nm) { /* nothing cut or padded: the output IS the window, counted here */
+            const uint32_t q = byte >> 2;
+            if (q == FLT_QUAL) c_trim++;
+            else if ((int)q < min_qual) c_low++;
+            else c_none++;
+          }
+          const uint32_t q = byte >> 2;
+          walked |= q != 0 && q != FLT_QUAL;
+          if (off + j < seq_out_cap) seq_out[off + j] = (uint8_t)byte;
+        }
+      }
+      if (k == 0 && __any(walked)) flags |= BSC_TPL_WALKED0;
+      if (lane == 0 && off + P.out_len > seq_out_cap) atomicMin(&cnt[0], ((unsigned long long)ti << 8) | PE_CAP);
+    }
+    if (lane == 0) tpl_out[ti].flags = flags;
+  }
+  unsigned long long v[5] = {c_none, c_trim, c_low, c_reads, c_bases};
+  for (int i = 0; i < 5; i++)
+    for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+  if (lane == 0) {
+    if (v[0]) atomicAdd(&cnt[3], v[0]);
+    if (v[1]) atomicAdd(&cnt[4], v[1]);
+    if (v[2]) atomicAdd(&cnt[5], v[2]);
+    if (v[3]) atomicAdd(&cnt[6], v[3]);
+    if (v[4]) atomicAdd(&cnt[7], v[4]);
+  }
+}
+
+/* ---- launcher ------------------------------------------------------------------------------------------------------------------ */
+extern "C" int bsc_dev_scan_u64(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
+
+extern "C" size_t bsc_dev_prep_plan_bytes(void) { return sizeof(bsc_prep_plan); }
+
+/*
+ * cnt[8] (device, unsigned long long): [0] the error word (all ones = none: set by the caller), [1] base_clip, [2] base_overlap,
+ * [3] base_none, [4] base_trim, [5] base_lowqual, [6] reads, [7] read_bases — zeroed by the caller.  out_len / out_off: 2 nr + 1
+ * words each; ms_work: n_misms entries; plan: 2 nr entries.  After the launch out_off[2 nr] = the bytes written.
+ */
+extern "C" int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *misms, uint64_t n_misms,
+                                   const bsc_prep_params *par, void *ms_work, void *plan, void *out_len, void *out_off, void *scan_tmp,
+                                   size_t scan_tmp_bytes, void *tpl_out, void *seq_out, uint64_t seq_out_cap, void *cnt, int num_cus,
+                                   void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!nr) return (int)hipMemsetAsync(out_off, 0, sizeof(unsigned long long), s);
+  hipError_t e = hipMemsetAsync((unsigned long long *)out_len + 2ull * nr, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(bsc_prep_plan_kernel, dim3((nr + 255u) / 256u), dim3(256), 0, s, (const bsc_raw_template *)raw, nr, (const uint8_t *)seq,
+                     seq_bytes, (const bsc_misms *)misms, n_misms, *par, (bsc_misms *)ms_work, (bsc_prep_plan *)plan,
+                     (unsigned long long *)out_len, (bsc_template *)tpl_out, (unsigned long long *)cnt);
+  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  int rc = bsc_dev_scan_u64(out_len, out_off, 2u * nr + 1u, scan_tmp, scan_tmp_bytes, stream);
+  if (rc) return rc;
+  unsigned g = (nr + PREP_WAVES - 1u) / PREP_WAVES;
+  const unsigned cap = (unsigned)num_cus * 8u * 2u; /* 16 waves to a SIMD are plenty to hide a read's latency */
+  if (g > cap) g = cap;
+  hipLaunchKernelGGL(bsc_prep_copy_kernel, dim3(g), dim3(64 * PREP_WAVES), 0, s, (const bsc_prep_plan *)plan, nr, (const uint8_t *)seq,
+                     (const bsc_misms *)ms_work, (const unsigned long long *)out_off, par->min_qual, (bsc_template *)tpl_out,
+                     (uint8_t *)seq_out, seq_out_cap, (unsigned long long *)cnt);
+  return (int)hipGetLastError();
+}

@@ -21,3 +21,16 @@ extern "C" int bsc_dev_scan_u32(const void *in, void *out, uint32_t n, void *tmp
   return (int)rocprim::exclusive_scan(tmp, tmp_bytes, (const uint32_t *)in, (uint32_t *)out, 0u, n,
                                       rocprim::plus<uint32_t>(), (hipStream_t)stream);
 }
+
+/* the same over n u64 values (bsc_prepare_templates_device: where every prepared read lands in the output buffer) */
+extern "C" int bsc_dev_scan_tmp_bytes_u64(uint32_t n, size_t *bytes) {
+  *bytes = 0;
+  if (n == 0) return 0;
+  return (int)rocprim::exclusive_scan(nullptr, *bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, 0ull, n,
+                                      rocprim::plus<unsigned long long>(), (hipStream_t)0);
+}
+extern "C" int bsc_dev_scan_u64(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream) {
+  if (n == 0) return 0;
+  return (int)rocprim::exclusive_scan(tmp, tmp_bytes, (const unsigned long long *)in, (unsigned long long *)out, 0ull, n,
+                                      rocprim::plus<unsigned long long>(), (hipStream_t)stream);
+}

@@ -1,0 +1,188 @@
+"""Read pre-processing on the device (csrc/prepdev.hip, bsc_prepare_templates_device) against the host form
+(csrc/prep.c) and the pure-Python restatement (oracle/py_prep.py): the hand-worked cases of tests/test_prep.py — one per branch of
+trim_read / trim_soft_clips / handle_overlap / the indel normalisation, each derived by hand from the cited lines of the reference —
+and random valid alignments, incl. the quirks (read_utils.c:22: the right trim copies the base of sp[k1]; al_utils.c: the overlap
+walk over a shortened list).  Byte equality of everything that comes out: templates (positions, lengths, offsets, flags), read
+bytes, statistics."""
+import numpy as np
+import pytest
+
+import bs_call_amd as B
+from bs_call_amd.caller import prepare_templates
+from oracle import py_prep
+
+import test_prep as T  # the hand-worked cases and the generators live with the host form's tests
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def caller():
+    c = B.SiteCaller()
+    yield c
+    c.close()
+
+
+def _both(caller, templates, **kw):
+    """device == host C == Python on one template list; returns the host result"""
+    raw, seq, ms = T.to_arrays(templates)
+    try:
+        h_tpl, h_seq, h_st = prepare_templates(raw, seq, ms, **kw)
+    except B.BscError as e:
+        with pytest.raises(B.BscError) as d:  # the same refusal, in the host form's words (it is run on the offending template)
+            caller.prepare_templates_device(raw, seq, ms, **kw)
+        for key in ("soft clip", "indel beyond the read", "orientation", "outside the"):
+            assert (key in str(e)) == (key in str(d.value)), (str(e), str(d.value))
+        return None
+    d_tpl, d_seq, d_st = caller.prepare_templates_device(raw, seq, ms, **kw)
+    assert d_seq.tobytes() == h_seq.tobytes()
+    for f in h_tpl.dtype.names:
+        assert (d_tpl[f] == h_tpl[f]).all(), f
+    assert d_tpl.tobytes() == h_tpl.tobytes() and d_st.tobytes() == h_st.tobytes()
+    return h_tpl, h_seq, h_st
+
+
+def test_hand_worked_cases_on_the_device(caller, monkeypatch):
+    """Every hand-worked case of tests/test_prep.py once more, with the device form checked inside its `both` / `run_c`."""
+    seen = []
+    real_run_c = T.run_c
+
+    def run_c(templates, **kw):
+        got = real_run_c(templates, **kw)
+        _both(caller, templates, **kw)
+        seen.append(len(templates))
+        return got
+
+    monkeypatch.setattr(T, "run_c", run_c)
+    for name in ("test_fixed_trims_and_the_right_trim_quirk", "test_soft_clips", "test_overlap_equal_spans_quality_decides_right_trim_of_read0",
+                 "test_overlap_longer_span_wins_left_trim_moves_the_start", "test_overlap_reverse_read_first",
+                 "test_no_overlap_and_single_reads_are_left_alone", "test_overlap_right_trim_walks_the_indels",
+                 "test_overlap_left_trim_walks_the_indels", "test_indel_normalisation_alone"):
+        getattr(T, name)()
+    assert len(seen) >= 9
+
+
+def test_random_alignments_device_equals_host(caller):
+    rng = np.random.default_rng(20250505)
+    n_err = 0
+    for trial in range(250):
+        ts = []
+        for _ in range(int(rng.integers(1, 40))):
+            r0, m0, s0 = T._random_read(rng)
+            r1, m1, s1 = T._random_read(rng)
+            kind = rng.random()
+            p0 = int(rng.integers(50, 5000))
+            if kind < 0.15:
+                t = T.tpl((p0, 0), (s0, 0), (r0, None), (m0, ()))
+            elif kind < 0.3:
+                t = T.tpl((0, p0), (0, s1), (None, r1), ((), m1))
+            else:
+                p1 = p0 + int(rng.integers(-s1 - 5, s0 + 30))
+                t = T.tpl((p0, max(1, p1)), (s0, s1), (r0, r1), (m0, m1))
+            t["orientation"] = int(rng.integers(0, 2))
+            t["bs_strand"] = int(rng.integers(0, 3))
+            ts.append(t)
+        # fixed trims up to beyond the middle of a read: the right trim's mirrored bases
+        lt = tuple(int(v) for v in rng.integers(0, 90, 2)) if rng.random() < 0.4 else (0, 0)
+        rt = tuple(int(v) for v in rng.integers(0, 90, 2)) if rng.random() < 0.4 else (0, 0)
+        n_err += _both(caller, ts, left_trim=lt, right_trim=rt, min_qual=int(rng.integers(1, 44))) is None
+    assert n_err < 125  # most lists are valid
+
+
+def test_device_equals_python_restatement(caller):
+    rng = np.random.default_rng(99)
+    done = 0
+    while done < 40:
+        ts = []
+        for _ in range(int(rng.integers(1, 10))):
+            r0, m0, s0 = T._random_read(rng)
+            r1, m1, s1 = T._random_read(rng)
+            p0 = int(rng.integers(50, 5000))
+            ts.append(T.tpl((p0, max(1, p0 + int(rng.integers(-s1 - 5, s0 + 30)))), (s0, s1), (r0, r1), (m0, m1), orientation=int(rng.integers(0, 2))))
+        kw = dict(left_trim=(int(rng.integers(0, 5)), 0), right_trim=(0, int(rng.integers(0, 5))), min_qual=20)
+        try:
+            p, pst = py_prep.prepare(ts, **kw)
+        except py_prep.PrepError:
+            continue
+        raw, seq, ms = T.to_arrays(ts)
+        d_tpl, d_seq, d_st = caller.prepare_templates_device(raw, seq, ms, **kw)
+        got = [{"pos": [int(v) for v in o["pos"]], "reads": [d_seq[int(o["off"][k]) : int(o["off"][k]) + int(o["len"][k])].tolist() for k in range(2)],
+                "mapq": [int(v) for v in o["mapq"]], "orientation": int(o["orientation"]), "bs_strand": int(o["bs_strand"])} for o in d_tpl]
+        assert got == p and {f: int(d_st[f]) for f in d_st.dtype.names} == pst
+        done += 1
+
+
+def test_block_of_generated_reads_through_the_device_prep_feeds_the_accumulate_stage(caller, oracle):
+    """A 200 000-position block of generated pairs handed over RAW (no indels: the span is the length; trimmed stretches, empty reads, single ends): prepared on
+    the device, the pile-up of the prepared reads — still on the device — equals the oracle's over the host-prepared ones."""
+    import torch
+
+    from bs_call_amd.abi import RAW_TEMPLATE
+
+    tpl, seq = B.synth_reads_host(88172645463325252 + 5, 3000, 200_000, 30)
+    raw = np.zeros(len(tpl), dtype=RAW_TEMPLATE)
+    for f in ("pos", "len", "off", "mapq", "orientation", "bs_strand"):
+        raw[f] = tpl[f]
+    raw["reference_span"] = tpl["len"]
+    ms = np.zeros(0, dtype=B.abi.MISMS)
+    h_tpl, h_seq, h_st = prepare_templates(raw, seq, ms)
+    d_tpl, d_seq, used, d_st = caller.prepare_templates_device(raw, seq, ms, keep_on_device=True)
+    assert used == h_seq.size and d_st.tobytes() == h_st.tobytes() and int(h_st["base_trim"]) > 0
+    assert d_seq.cpu().numpy()[:used].tobytes() == h_seq.tobytes()
+    assert d_tpl.cpu().numpy()[: len(raw) * 40].tobytes() == h_tpl.tobytes()
+    x = max(1, int(min(p for p in h_tpl["pos"].ravel() if p)) - 2)
+    y = int((h_tpl["pos"].astype(np.int64) + h_tpl["len"]).max()) - 1
+    rc, exp = oracle.accumulate(h_tpl, h_seq, x, y, 20)
+    assert rc == 0
+    n_pad = (y - x + 1 + 63) // 64 * 64
+    d_cts = torch.zeros(n_pad * 104, dtype=torch.uint8, device=d_seq.device)
+    caller.accumulate_device(d_tpl.data_ptr(), len(raw), d_seq.data_ptr(), used, x, y, d_cts.data_ptr(), None)
+    caller.block_status(None)
+    torch.cuda.synchronize()
+    assert d_cts.cpu().numpy()[: (y - x + 1) * 104].tobytes() == exp.tobytes()
+
+
+def test_block_records_from_raw_templates(caller):
+    """bsc_block_records_raw: raw templates with indels, soft clips and overlapping mates in, packed records out — the records (and
+    the statistics) of bsc_prepare_templates on the host followed by bsc_block_records."""
+    rng = np.random.default_rng(4711)
+    ts, p0 = [], 2000
+    for i in range(3000):
+        r0, m0, s0 = T._random_read(rng, 20)
+        r1, m1, s1 = T._random_read(rng, 20)
+        p0 += int(rng.integers(0, 6))
+        kind = rng.random()
+        if kind < 0.1:
+            t = T.tpl((p0, 0), (s0, 0), (r0, None), (m0, ()))
+        else:
+            t = T.tpl((p0, p0 + int(rng.integers(0, s0 + 40))), (s0, s1), (r0, r1), (m0, m1))
+        t["orientation"] = int(rng.integers(0, 2))
+        t["bs_strand"] = int(rng.integers(1, 3))
+        ts.append(t)
+    ok = []
+    for t in ts:  # keep the templates the reference would not abort on
+        try:
+            py_prep.prepare([t])
+            ok.append(t)
+        except py_prep.PrepError:
+            pass
+    raw, seq, ms = T.to_arrays(ok)
+    kw = dict(left_trim=(2, 0), right_trim=(0, 3), min_qual=20)
+    h_tpl, h_seq, h_st = prepare_templates(raw, seq, ms, **kw)
+    x = max(1, int(min(p for p in raw["pos"].ravel() if p)) - 2)
+    y = int(max((raw["pos"].astype(np.int64) + raw["reference_span"]).max(), (h_tpl["pos"].astype(np.int64) + h_tpl["len"]).max())) + 5
+    ref = B.synth_ref_host(7, x, y - x + 3)
+    caller.reset_site_stats()
+    want = caller.block_records(h_tpl, h_seq, x, y, ref, with_stats=True).copy()
+    st_want = caller.site_stats().copy()
+    caller.reset_site_stats()
+    got, st = caller.block_records_raw(raw, seq, ms, x, y, ref, with_stats=True, **kw)
+    assert len(want) > 1000 and got.tobytes() == want.tobytes() and st.tobytes() == h_st.tobytes()
+    assert caller.site_stats().tobytes() == st_want.tobytes()
+    # a template the reference aborts on: refused with the host form's words, and the context goes on
+    bad = list(ok[:50]) + [T.tpl((3000, 0), (30, 0), (T.read(30), None), (((3, 5, 4),), ()))] + list(ok[50:60])
+    raw2, seq2, ms2 = T.to_arrays(bad)
+    with pytest.raises(B.BscError, match="template 50 read 0: illegal soft clip"):
+        caller.block_records_raw(raw2, seq2, ms2, x, y, ref, **kw)
+    again, _ = caller.block_records_raw(raw, seq, ms, x, y, ref, **kw)
+    assert again.tobytes() == want.tobytes()
