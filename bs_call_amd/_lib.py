@@ -347,9 +347,9 @@ def load():
     L.bsc_template_qual.restype = u32
     L.bsc_template_qual.argtypes = [vp, vp]
     L.bsc_prepare_templates_device.restype = i32
-    L.bsc_prepare_templates_device.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, vp, vp, u64, vp, vp, vp]
+    L.bsc_prepare_templates_device.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, vp, vp, u64, vp, vp, vp, vp]
     L.bsc_block_records_raw.restype = i32
-    L.bsc_block_records_raw.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, u32, u32, vp, vp, vp, i32, vp, u64, vp, vp]
+    L.bsc_block_records_raw.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, u32, u32, vp, vp, vp, i32, vp, u64, vp, vp, vp]
     L.bsc_template_walk_flags.restype = u32
     L.bsc_template_walk_flags.argtypes = [vp, u32]
     L.bsc_dbsnp_open.restype = i32

@@ -212,7 +212,8 @@ class SiteCaller:
                 b.free()
         return off, o2.copy(), s2.copy()
 
-    def prepare_templates_device(self, raw, seq, misms, left_trim=(0, 0), right_trim=(0, 0), min_qual=20, keep_on_device=False):
+    def prepare_templates_device(self, raw, seq, misms, left_trim=(0, 0), right_trim=(0, 0), min_qual=20, keep_on_device=False,
+                                 profile=None, x=None, ref=None):
         """bsc_prepare_templates_device: the read pre-processing on the GPU.  Host arrays in (uploaded with torch), the prepared
         templates / read bytes / PREP_STATS back — or, keep_on_device, the two device tensors (uint8 views) and the byte count, for
         a caller that goes on with accumulate_device / reads_chain_device."""
@@ -237,8 +238,15 @@ class SiteCaller:
         d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
         used = C.c_uint64(0)
         st = np.zeros(1, dtype=PREP_STATS)
+        pf = None
+        if profile is not None:  # the read profile: the block's codes (x .. y + 2) on the device, the counts on the host
+            d_ref = up(np.ascontiguousarray(ref, dtype=np.uint8))
+            pf = _lib.ReadProfile(d_ref.data_ptr(), int(x), len(ref), profile.counts.ctypes.data, profile.counts.shape[0], profile.used)
         _check(self._L.bsc_prepare_templates_device(self._h, d_raw.data_ptr(), len(raw), d_seq.data_ptr(), seq.size, d_ms.data_ptr(), len(misms),
-                                                    _ptr(par), d_tpl.data_ptr(), d_out.data_ptr(), cap, C.byref(used), _ptr(st), None))
+                                                    _ptr(par), d_tpl.data_ptr(), d_out.data_ptr(), cap, C.byref(used), _ptr(st),
+                                                    None if pf is None else C.byref(pf), None))
+        if pf is not None:
+            profile.used = int(pf.used)
         if keep_on_device:
             return d_tpl, d_out, int(used.value), st[0]
         tpl = d_tpl.cpu().numpy()[: len(raw) * TEMPLATE.itemsize].view(TEMPLATE).copy()
@@ -344,7 +352,7 @@ class SiteCaller:
         return out[: cnt.value]
 
     def block_records_raw(self, raw, seq, misms, x, y, ref, left_trim=(0, 0), right_trim=(0, 0), min_qual=20, all_positions=False,
-                          reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False, out=None):
+                          reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False, out=None, profile=None):
         """bsc_block_records_raw: one block from what the reader delivers (RAW_TEMPLATE[nr], read bytes, MISMS[]) to packed records;
         the read pre-processing runs on the GPU.  Returns (VCF_REC[n_written], PREP_STATS record)."""
         from .abi import MISMS, PREP_PARAMS, PREP_STATS, RAW_TEMPLATE
@@ -364,9 +372,12 @@ class SiteCaller:
         p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
         cnt = C.c_uint64(0)
         st = np.zeros(1, dtype=PREP_STATS)
+        pf = None if profile is None else _lib.ReadProfile(None, 0, 0, profile.counts.ctypes.data, profile.counts.shape[0], profile.used)
         _check(self._L.bsc_block_records_raw(self._h, _ptr(raw), len(raw), _ptr(seq), seq.size, _ptr(misms), len(misms), _ptr(par), x, y,
                                              _ptr(ref), None if db is None else _ptr(db), C.byref(p), 1 if with_stats else 0, _ptr(out),
-                                             len(out), C.byref(cnt), _ptr(st)))
+                                             len(out), C.byref(cnt), _ptr(st), None if pf is None else C.byref(pf)))
+        if pf is not None:
+            profile.used = int(pf.used)
         return out[: cnt.value], st[0]
 
     def blocks_records(self, blocks, ref, out=None, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False,

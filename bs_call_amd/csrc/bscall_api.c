@@ -68,7 +68,9 @@ int bsc_dev_scan_tmp_bytes_u64(uint32_t n, size_t *bytes); /* sort.hip */
 size_t bsc_dev_prep_plan_bytes(void);                     /* prepdev.hip */
 int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *misms, uint64_t n_misms,
                         const bsc_prep_params *par, void *ms_work, void *plan, void *out_len, void *out_off, void *scan_tmp,
-                        size_t scan_tmp_bytes, void *tpl_out, void *seq_out, uint64_t seq_out_cap, void *cnt, int num_cus, void *stream);
+                        size_t scan_tmp_bytes, void *tpl_out, void *seq_out, uint64_t seq_out_cap, void *cnt, int num_cus, void *stream,
+                        const void *prof_ref, uint32_t prof_x, uint32_t prof_n_ref, uint32_t prof_cap, uint32_t prof_used0, void *prof_table,
+                        void *max_pos1, void *used_scan);
 int bsc_dev_launch_ref_pad(const void *packed, const void *d_blk, uint32_t n_blk, void *padded, uint32_t n_pos, int num_cus, void *stream);
 int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk, uint32_t n_blk,
                                    uint32_t n_bins, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
@@ -147,6 +149,8 @@ struct bsc_context {
    * host-buffer entry bsc_block_records_raw, the raw templates / reads / lists on the device */
   void *d_pplan, *d_plen, *d_poff, *d_pms, *d_pscan, *d_pcnt, *d_raw, *d_rseq, *d_rms;
   size_t cap_pplan, cap_plen, cap_poff, cap_pms, cap_pscan, cap_pcnt, cap_raw, cap_rseq, cap_rms;
+  void *d_pprof, *d_pmax, *d_pused; /* the read profile's counts of one call, the templates' last read positions, their running maximum */
+  size_t cap_pprof, cap_pmax, cap_pused;
   void *d_refp; /* bsc_blocks_submit_to_inplace: the caller's packed reference codes, before bsc_ref_pad_kernel lays them out */
   size_t cap_refp;
   const uint32_t *mb_toff;
@@ -447,6 +451,9 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_raw);
   hipFree(ctx->d_rseq);
   hipFree(ctx->d_rms);
+  hipFree(ctx->d_pprof);
+  hipFree(ctx->d_pmax);
+  hipFree(ctx->d_pused);
   hipFree(ctx->d_carry);
   hipFree(ctx->d_logp);
   hipFree(ctx->d_vout);
@@ -1427,6 +1434,8 @@ static int bsc_prep_device_error(bsc_context *ctx, unsigned long long word, cons
   (void)ctx;
   const uint32_t ti = (uint32_t)(word >> 8), code = (uint32_t)(word & 0xffu);
   if (code == 9u) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates: seq_out too small (template %u)", ti);
+  if (code == 10u) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates: template %u: read position beyond the profile", ti);
+  if (code == 11u) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates: template %u lies outside the profile's reference", ti);
   bsc_raw_template t;
   HIP_TRY(hipMemcpy(&t, (const char *)d_raw + (size_t)ti * sizeof t, sizeof t, hipMemcpyDeviceToHost));
   if (code == 1u) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates: template %u has orientation %u", ti, t.orientation);
@@ -1486,7 +1495,8 @@ static int bsc_prep_device_error(bsc_context *ctx, unsigned long long word, cons
 
 int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms,
                                  uint64_t n_misms, const bsc_prep_params *par, void *d_tpl_out, void *d_seq_out, uint64_t seq_out_cap,
-                                 uint64_t *seq_out_used, bsc_prep_stats *stats, void *stream) {
+                                 uint64_t *seq_out_used, bsc_prep_stats *stats, bsc_read_profile *pf, void *stream) {
+  if (pf && (!pf->ref || !pf->counts || pf->used > pf->cap || !pf->cap)) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: bad read profile");
   if (!ctx || !par || !seq_out_used || (nr && (!d_raw || !d_tpl_out))) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: NULL argument");
   if ((seq_bytes && !d_seq) || (n_misms && !d_misms) || (seq_out_cap && !d_seq_out))
     return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: NULL buffer");
@@ -1507,10 +1517,19 @@ int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t n
   if ((rc = bsc_reserve(&ctx->d_pms, &ctx->cap_pms, (size_t)(n_misms ? n_misms : 1) * sizeof(bsc_misms)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_pscan, &ctx->cap_pscan, scan_bytes ? scan_bytes : 1))) return rc;
   if ((rc = bsc_reserve(&ctx->d_pcnt, &ctx->cap_pcnt, 8 * sizeof(unsigned long long)))) return rc;
+  const size_t prof_bytes = pf ? (size_t)pf->cap * 4u * sizeof(unsigned long long) : 0;
+  if (pf && nr) {
+    if ((rc = bsc_reserve(&ctx->d_pprof, &ctx->cap_pprof, prof_bytes))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_pmax, &ctx->cap_pmax, (size_t)nr * 4u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_pused, &ctx->cap_pused, (size_t)nr * 4u))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_pprof, 0, prof_bytes, s));
+  }
   HIP_TRY(hipMemsetAsync(ctx->d_pcnt, 0, 8 * sizeof(unsigned long long), s));
   HIP_TRY(hipMemsetAsync(ctx->d_pcnt, 0xff, sizeof(unsigned long long), s));
   int e = bsc_dev_launch_prep(d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, par, ctx->d_pms, ctx->d_pplan, ctx->d_plen, ctx->d_poff,
-                              ctx->d_pscan, scan_bytes, d_tpl_out, d_seq_out, seq_out_cap, ctx->d_pcnt, ctx->num_cus, s);
+                              ctx->d_pscan, scan_bytes, d_tpl_out, d_seq_out, seq_out_cap, ctx->d_pcnt, ctx->num_cus, s,
+                              pf && nr ? pf->ref : NULL, pf ? pf->x : 0u, pf ? pf->n_ref : 0u, pf ? pf->cap : 0u, pf ? pf->used : 0u,
+                              ctx->d_pprof, ctx->d_pmax, ctx->d_pused);
   if (e) {
     (void)hipStreamSynchronize(s);
     return bsc_fail(BSC_ERR_HIP, "read pre-processing launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -1518,8 +1537,34 @@ int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t n
   unsigned long long h[9];
   HIP_TRY(hipMemcpyAsync(h, ctx->d_pcnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(h + 8, (const char *)ctx->d_poff + (size_t)(nr ? 2u * nr : 0u) * 8u, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (h[0] != ~0ull) return bsc_prep_device_error(ctx, h[0], d_raw, d_seq, d_misms, par);
+  uint32_t used_last = 0;
+  uint64_t *delta = NULL;
+  if (pf && nr) { /* this call's counts and the vector's new length */
+    delta = malloc(prof_bytes);
+    if (!delta) {
+      (void)hipStreamSynchronize(s);
+      return bsc_fail(BSC_ERR_NOMEM, "bsc_prepare_templates_device: out of memory");
+    }
+    (void)hipMemcpyAsync(delta, ctx->d_pprof, prof_bytes, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(&used_last, (const char *)ctx->d_pused + (size_t)(nr - 1u) * 4u, 4, hipMemcpyDeviceToHost, s);
+  }
+  hipError_t se = hipStreamSynchronize(s);
+  if (se != hipSuccess) {
+    free(delta);
+    return bsc_fail(BSC_ERR_HIP, "bsc_prepare_templates_device: %s", hipGetErrorString(se));
+  }
+  if (h[0] != ~0ull) {
+    free(delta);
+    return bsc_prep_device_error(ctx, h[0], d_raw, d_seq, d_misms, par);
+  }
+  if (delta) {
+    if (used_last > pf->used) { /* growing the vector clears everything behind its old end (csrc/prep.c) */
+      memset(pf->counts + (size_t)pf->used * 4u, 0, (size_t)(pf->cap - pf->used) * 4u * sizeof(uint64_t));
+      pf->used = used_last;
+    }
+    for (size_t i = 0; i < (size_t)pf->cap * 4u; i++) pf->counts[i] += delta[i];
+    free(delta);
+  }
   *seq_out_used = h[8];
   if (stats) {
     stats->base_clip = h[1];
@@ -1690,13 +1735,15 @@ int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, co
 int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                           const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref,
                           const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap,
-                          uint64_t *n_out, bsc_prep_stats *prep_stats) {
+                          uint64_t *n_out, bsc_prep_stats *prep_stats, bsc_read_profile *profile) {
   if (!ctx || !ref || !params || !prep || !n_out || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: NULL argument");
+  if (y < x) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: y (%u) < x (%u)", y, x);
   *n_out = 0;
   if (prep_stats) memset(prep_stats, 0, sizeof *prep_stats);
   if (ctx->rec_pending || ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: a submitted block has not been fetched");
   if (nr && (!raw || (seq_bytes && !seq) || (n_misms && !misms))) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: NULL input buffer");
   if (!nr) return bsc_block_records(ctx, NULL, 0, NULL, 0, x, y, ref, dbsnp, params, with_stats, out, out_cap, n_out);
+  if (y - x > 0x0ffffffeu) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: block longer than 2^28 - 1 positions");
   BSC_ENTER(ctx);
   /* room for the prepared reads: the bytes handed over plus every padded deletion (a size no read could hold is damage: the
    * device refuses that list) */
@@ -1714,9 +1761,20 @@ int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_
   if (seq_bytes) HIP_TRY(hipMemcpyAsync(ctx->d_rseq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
   if (n_misms) HIP_TRY(hipMemcpyAsync(ctx->d_rms, misms, (size_t)n_misms * sizeof *misms, hipMemcpyHostToDevice, s));
   uint64_t used = 0;
-  if ((rc = bsc_prepare_templates_device(ctx, ctx->d_raw, nr, ctx->d_rseq, seq_bytes, ctx->d_rms, n_misms, prep, ctx->d_tpl, ctx->d_seq, cap, &used,
-                                         prep_stats, s)))
-    return rc; /* (it has waited for the stream: nothing reads the caller's buffers any more) */
+  bsc_read_profile dp;
+  if (profile) { /* the block's reference codes (x .. y + 2) are what the profile reads: up they go first */
+    const uint64_t n_ref = (uint64_t)y - x + 3;
+    if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)n_ref))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)n_ref, hipMemcpyHostToDevice, s));
+    dp = *profile;
+    dp.ref = ctx->d_ref;
+    dp.x = x;
+    dp.n_ref = (uint32_t)n_ref;
+  }
+  rc = bsc_prepare_templates_device(ctx, ctx->d_raw, nr, ctx->d_rseq, seq_bytes, ctx->d_rms, n_misms, prep, ctx->d_tpl, ctx->d_seq, cap, &used,
+                                    prep_stats, profile ? &dp : NULL, s);
+  if (profile) profile->used = dp.used;
+  if (rc) return rc; /* (it has waited for the stream: nothing reads the caller's buffers any more) */
   rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 0);
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream);

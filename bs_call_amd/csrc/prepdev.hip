@@ -28,7 +28,7 @@
 
 #define FLT_QUAL 63u
 
-/* what the plan kernel leaves per read (48 bytes) */
+/* what the plan kernel leaves per read (56 bytes) */
 struct bsc_prep_plan {
   uint64_t src;     /* offset of the ORIGINAL read's first byte in seq */
   uint64_t ms;      /* index of its edited mismatch list in ms_work */
@@ -38,6 +38,8 @@ struct bsc_prep_plan {
   uint32_t mark_l, mark_r; /* fixed trims: this many bytes from either end of the original read carry quality 63 */
   uint32_t out_len;
   uint32_t present; /* the reader delivered a vector for this read (t->len[k] != 0): it counts in filter_cts (:57-58) */
+  uint32_t trim_l, trim_r; /* bases cut from either end by the soft clips and the overlap (src/al_utils.c:309-313): the read profile's
+                              positions in the ORIGINAL read (src/process_template.c:76-87) */
 };
 
 /* error codes, in the order csrc/prep.c makes its checks; the low byte of the word the kernels atomicMin */
@@ -48,6 +50,8 @@ struct bsc_prep_plan {
 #define PE_SOFT_ILL 7u
 #define PE_INDEL 8u
 #define PE_CAP 9u   /* the output buffer is too small */
+#define PE_PROF_CAP 10u   /* a read position beyond the profile (the host form checks this first) */
+#define PE_PROF_RANGE 11u /* a read outside the profile's reference */
 
 struct prep_rd {
   uint32_t w0, wl;
@@ -91,7 +95,8 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
                                                             uint64_t seq_bytes, const bsc_misms *__restrict__ misms_in, uint64_t n_misms_in,
                                                             bsc_prep_params par, bsc_misms *__restrict__ ms_work,
                                                             bsc_prep_plan *__restrict__ plan, unsigned long long *__restrict__ out_len,
-                                                            bsc_template *__restrict__ tpl_out, unsigned long long *__restrict__ cnt) {
+                                                            bsc_template *__restrict__ tpl_out, unsigned long long *__restrict__ cnt,
+                                                            uint32_t *__restrict__ max_pos1) {
   const uint32_t ti = blockIdx.x * 256u + threadIdx.x;
   unsigned long long n_clip = 0, n_overlap = 0;
   uint32_t err = 0;
@@ -120,6 +125,7 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
         P[k].mark_l = lt > 0 ? ((uint32_t)lt < rl ? (uint32_t)lt : rl) : 0u;
         P[k].mark_r = rt > 0 ? ((uint32_t)rt < rl ? (uint32_t)rt : rl) : 0u;
         P[k].present = rl != 0;
+        P[k].trim_l = P[k].trim_r = 0;
         rd[k].w0 = 0;
         rd[k].wl = rl;
         nm[k] = t.n_misms[k];
@@ -142,10 +148,12 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
               if (m->size >= rl) { err = PE_SOFT_ILL; break; }
               adj = m->size;
               n_clip += adj;
+              P[k].trim_l = adj;
               d_left_trim(rd[k], adj);
             } else {
               if (m->position + m->size != rl) { err = PE_SOFT_ILL; break; }
               d_right_trim(rd[k], m->size);
+              P[k].trim_r = m->size;
               n_clip += m->size;
             }
           } else if (nclip) {
@@ -267,6 +275,8 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
           }
           nm[tr] = num;
           n_overlap += (rdl[0] - rd[0].wl) + (rdl[1] - rd[1].wl);
+          if (right) P[tr].trim_r += rdl[tr] - rd[tr].wl; /* src/al_utils.c:309-313 */
+          else P[tr].trim_l += rdl[tr] - rd[tr].wl;
         }
       }
       /* 4. indel normalisation (src/process_template.c:62-108): where every entry cuts or pads — ix1 — and the length that results */
@@ -294,13 +304,22 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
     if (err) {
       for (int k = 0; k < 2; k++) {
         P[k].src = P[k].ms = 0;
-        P[k].rl0 = P[k].w0 = P[k].wl = P[k].nm = P[k].mark_l = P[k].mark_r = P[k].out_len = P[k].present = 0;
+        P[k].rl0 = P[k].w0 = P[k].wl = P[k].nm = P[k].mark_l = P[k].mark_r = P[k].out_len = P[k].present = P[k].trim_l = P[k].trim_r = 0;
       }
       atomicMin(&cnt[0], ((unsigned long long)ti << 8) | err);
       n_clip = n_overlap = 0;
     }
     plan[2u * ti] = P[0];
     plan[2u * ti + 1u] = P[1];
+    if (max_pos1) { /* the read profile's vector must reach the template's last read position (src/process_template.c:76-89) */
+      int32_t max_pos = 0;
+      for (int k = 0; k < 2; k++)
+        if (P[k].present) {
+          const int32_t mpos = k ? (int32_t)(P[k].wl + P[k].trim_r) - 1 : (int32_t)(P[k].trim_l + P[k].wl);
+          if (mpos > max_pos) max_pos = mpos;
+        }
+      max_pos1[ti] = err ? 0u : (uint32_t)max_pos + 1u;
+    }
     out_len[2u * ti] = P[0].out_len;
     out_len[2u * ti + 1u] = P[1].out_len;
     bsc_template o;
@@ -336,22 +355,74 @@ __device__ static __forceinline__ uint32_t d_marked(const uint8_t *sp, uint32_t 
   return (i < mark_l || in_r) ? (b & 3u) | (FLT_QUAL << 2) : (uint32_t)sp[i];
 }
 
+/*
+ * The non-CpG read profile (meth_profile, src/meth_profile.c:48-77; host form: csrc/prep.c profile_read): for every prepared base,
+ * by its position in the ORIGINAL read, whether it is a C / G of the reference outside a CpG and what the read shows there.  The
+ * reference walks a read with a state of two reference codes; per base that is a function of the three codes around it —
+ * mask(before) from (ref[v - 1], ref[v]), mask(after) from (ref[v], ref[v + 1]) — with v = the base's index in the block's codes,
+ * except for a read that starts at the block's first position, whose walk starts one code late (v one lower, codes in front of
+ * the block reading 0).  The vector of counts grows to the largest read position seen so far, and growing clears everything behind
+ * its old end: a count is kept iff its index is inside the vector as the template's own growth left it (used_scan: the running
+ * maximum over the templates in order).
+ */
+struct bsc_prep_prof {
+  const uint8_t *ref;            /* codes of x .. x + n_ref - 1 (device) */
+  uint32_t x, n_ref, cap, used0; /* the profile's capacity and its length before this call */
+  const uint32_t *used_scan;     /* per template: max over the templates up to it of (last read position + 1) */
+  unsigned long long *table;     /* [cap][4], zeroed by the caller: this call's counts */
+};
+#define PROF_LDS 1024u /* read positions whose counts a workgroup keeps in LDS */
+__device__ static const uint8_t PROF_REF[64] = { /* src/meth_profile.c:14-23: 4 = C not followed by G, 8 = G not preceded by C */
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0, 0, 0, 0, 0, 4, 4, 0, 4, 0, 0, 0, 0, 0, 0, 8, 0, 0, 0, 0,
+    0, 0, 0, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ static __forceinline__ uint32_t d_profile_base(uint32_t bs_strand, uint32_t c) { /* src/init_param.c:57-70 */
+  const uint32_t q = c >> 2;
+  if (q < 20u /* MIN_QUAL */ || q >= FLT_QUAL || bs_strand > 2u) return 0u;
+  /* {11, 6, 10, 7}, {11, 4, 10, 5}, {9, 6, 8, 7}: a nibble each */
+  return ((bs_strand == 0 ? 0x7A6Bu : (bs_strand == 1 ? 0x5A4Bu : 0x7869u)) >> (4u * (c & 3u))) & 15u;
+}
+
 #define PREP_WAVES 4
 __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bsc_prep_plan *__restrict__ plan, uint32_t nr,
                                                                         const uint8_t *__restrict__ seq, const bsc_misms *__restrict__ ms_work,
                                                                         const unsigned long long *__restrict__ out_off, int32_t min_qual,
                                                                         bsc_template *__restrict__ tpl_out, uint8_t *__restrict__ seq_out,
-                                                                        uint64_t seq_out_cap, unsigned long long *__restrict__ cnt) {
+                                                                        uint64_t seq_out_cap, unsigned long long *__restrict__ cnt,
+                                                                        const bsc_prep_prof F) {
+  __shared__ uint32_t s_prof[PROF_LDS * 4u];
+  const bool prof = F.table != nullptr;
+  if (prof) {
+    for (unsigned i = threadIdx.x; i < PROF_LDS * 4u; i += 64 * PREP_WAVES) s_prof[i] = 0;
+    __syncthreads();
+  }
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t wave = blockIdx.x * PREP_WAVES + (threadIdx.x >> 6), n_waves = gridDim.x * PREP_WAVES;
   uint32_t c_trim = 0, c_low = 0, c_none = 0, c_reads = 0; /* per lane; summed over the wave at the end */
   unsigned long long c_bases = 0;
   for (uint32_t ti = wave; ti < nr; ti += n_waves) {
     uint32_t flags = BSC_TPL_WALK_KNOWN;
+    uint32_t used_t = 0, strand = 0;
+    if (prof) {
+      const uint32_t before = ti ? (F.used_scan[ti - 1u] > F.used0 ? F.used_scan[ti - 1u] : F.used0) : F.used0;
+      used_t = F.used_scan[ti] > before ? F.used_scan[ti] : before;
+      /* growing the vector past its capacity is where the host form gives up (csrc/prep.c) */
+      if (lane == 0 && used_t > before && (unsigned long long)used_t + 1ull > F.cap) atomicMin(&cnt[0], ((unsigned long long)ti << 8) | PE_PROF_CAP);
+      strand = tpl_out[ti].bs_strand;
+    }
     for (int k = 0; k < 2; k++) {
       const bsc_prep_plan P = plan[2u * ti + (uint32_t)k];
       const unsigned long long off = out_off[2u * ti + (uint32_t)k];
       const uint8_t *const sp = seq + P.src;
+      /* the read's place in the block's reference codes */
+      const bool prof_k = prof && P.present && P.out_len != 0;
+      int64_t v0 = 0; /* index of output byte 0 in F.ref, one lower for a read at the block's first position */
+      if (prof_k) {
+        const uint32_t pos = tpl_out[ti].pos[k];
+        if (pos < F.x || (uint64_t)pos - F.x + P.out_len + 1u > F.n_ref) {
+          if (lane == 0) atomicMin(&cnt[0], ((unsigned long long)ti << 8) | PE_PROF_RANGE);
+        }
+        v0 = pos > F.x ? (int64_t)(pos - F.x) : -1;
+      }
       if (lane == 0) {
         tpl_out[ti].off[k] = off;
         if (P.present) {
@@ -401,12 +472,34 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
           const uint32_t q = byte >> 2;
           walked |= q != 0 && q != FLT_QUAL;
           if (off + j < seq_out_cap) seq_out[off + j] = (uint8_t)byte;
+          if (prof_k && !pad) {
+            const uint32_t xx = d_profile_base(strand, byte);
+            const int64_t v = v0 + j;
+            if (xx && v + 1 < (int64_t)F.n_ref) {
+              const uint32_t ra = v >= 1 ? F.ref[v - 1] : 0u, rb = v >= 0 ? F.ref[v] : 0u, rc = F.ref[v + 1];
+              const uint32_t m_before = PROF_REF[((ra << 3) | rb) & 63u], m_after = PROF_REF[((rb << 3) | rc) & 63u];
+              if ((((xx & m_after) | ((xx & m_before) >> 1)) >> 2) & 1u) {
+                /* position in the original read: read 1 is counted from its far end (src/process_template.c:76-87) */
+                const int32_t orig = k ? (int32_t)(P.wl + P.trim_r) - 1 - (int32_t)s : (int32_t)(P.trim_l + s);
+                const uint32_t ix = (uint32_t)(orig + 1);
+                if (ix < used_t && ix < F.cap) {
+                  if (ix < PROF_LDS) atomicAdd(&s_prof[ix * 4u + (xx & 3u)], 1u);
+                  else atomicAdd(&F.table[(uint64_t)ix * 4u + (xx & 3u)], 1ull);
+                }
+              }
+            }
+          }
         }
       }
       if (k == 0 && __any(walked)) flags |= BSC_TPL_WALKED0;
       if (lane == 0 && off + P.out_len > seq_out_cap) atomicMin(&cnt[0], ((unsigned long long)ti << 8) | PE_CAP);
     }
     if (lane == 0) tpl_out[ti].flags = flags;
+  }
+  if (prof) {
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < PROF_LDS * 4u; i += 64 * PREP_WAVES)
+      if (s_prof[i] && i / 4u < F.cap) atomicAdd(&F.table[i], (unsigned long long)s_prof[i]);
   }
   unsigned long long v[5] = {c_none, c_trim, c_low, c_reads, c_bases};
   for (int i = 0; i < 5; i++)
@@ -430,25 +523,41 @@ extern "C" size_t bsc_dev_prep_plan_bytes(void) { return sizeof(bsc_prep_plan); 
  * [3] base_none, [4] base_trim, [5] base_lowqual, [6] reads, [7] read_bases — zeroed by the caller.  out_len / out_off: 2 nr + 1
  * words each; ms_work: n_misms entries; plan: 2 nr entries.  After the launch out_off[2 nr] = the bytes written.
  */
+extern "C" int bsc_dev_scan_max_u32(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
+
+/* prof_ref != NULL: the read profile too — prof_ref = the codes of prof_x .. prof_x + prof_n_ref - 1 (device), prof_table = u64 [prof_cap][4]
+ * zeroed by the caller (this call's counts), prof_used0 = the vector's length before the call, max_pos1 / used_scan: nr words each */
 extern "C" int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *misms, uint64_t n_misms,
                                    const bsc_prep_params *par, void *ms_work, void *plan, void *out_len, void *out_off, void *scan_tmp,
                                    size_t scan_tmp_bytes, void *tpl_out, void *seq_out, uint64_t seq_out_cap, void *cnt, int num_cus,
-                                   void *stream) {
+                                   void *stream, const void *prof_ref, uint32_t prof_x, uint32_t prof_n_ref, uint32_t prof_cap,
+                                   uint32_t prof_used0, void *prof_table, void *max_pos1, void *used_scan) {
   hipStream_t s = (hipStream_t)stream;
   if (!nr) return (int)hipMemsetAsync(out_off, 0, sizeof(unsigned long long), s);
   hipError_t e = hipMemsetAsync((unsigned long long *)out_len + 2ull * nr, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(bsc_prep_plan_kernel, dim3((nr + 255u) / 256u), dim3(256), 0, s, (const bsc_raw_template *)raw, nr, (const uint8_t *)seq,
                      seq_bytes, (const bsc_misms *)misms, n_misms, *par, (bsc_misms *)ms_work, (bsc_prep_plan *)plan,
-                     (unsigned long long *)out_len, (bsc_template *)tpl_out, (unsigned long long *)cnt);
+                     (unsigned long long *)out_len, (bsc_template *)tpl_out, (unsigned long long *)cnt, prof_ref ? (uint32_t *)max_pos1 : nullptr);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   int rc = bsc_dev_scan_u64(out_len, out_off, 2u * nr + 1u, scan_tmp, scan_tmp_bytes, stream);
   if (rc) return rc;
+  bsc_prep_prof F = {nullptr, 0u, 0u, 0u, 0u, nullptr, nullptr};
+  if (prof_ref) {
+    if ((rc = bsc_dev_scan_max_u32(max_pos1, used_scan, nr, scan_tmp, scan_tmp_bytes, stream))) return rc;
+    F.ref = (const uint8_t *)prof_ref;
+    F.x = prof_x;
+    F.n_ref = prof_n_ref;
+    F.cap = prof_cap;
+    F.used0 = prof_used0;
+    F.used_scan = (const uint32_t *)used_scan;
+    F.table = (unsigned long long *)prof_table;
+  }
   unsigned g = (nr + PREP_WAVES - 1u) / PREP_WAVES;
   const unsigned cap = (unsigned)num_cus * 8u * 2u; /* 16 waves to a SIMD are plenty to hide a read's latency */
   if (g > cap) g = cap;
   hipLaunchKernelGGL(bsc_prep_copy_kernel, dim3(g), dim3(64 * PREP_WAVES), 0, s, (const bsc_prep_plan *)plan, nr, (const uint8_t *)seq,
                      (const bsc_misms *)ms_work, (const unsigned long long *)out_off, par->min_qual, (bsc_template *)tpl_out,
-                     (uint8_t *)seq_out, seq_out_cap, (unsigned long long *)cnt);
+                     (uint8_t *)seq_out, seq_out_cap, (unsigned long long *)cnt, F);
   return (int)hipGetLastError();
 }

@@ -34,3 +34,14 @@ extern "C" int bsc_dev_scan_u64(const void *in, void *out, uint32_t n, void *tmp
   return (int)rocprim::exclusive_scan(tmp, tmp_bytes, (const unsigned long long *)in, (unsigned long long *)out, 0ull, n,
                                       rocprim::plus<unsigned long long>(), (hipStream_t)stream);
 }
+
+/* inclusive running maximum of n u32 values (the read profile's vector length after every template); the scratch of the u64 scan
+ * over 2 n + 1 values is more than this one needs */
+extern "C" int bsc_dev_scan_max_u32(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream) {
+  if (n == 0) return 0;
+  size_t need = 0;
+  hipError_t e = rocprim::inclusive_scan(nullptr, need, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, rocprim::maximum<uint32_t>(), (hipStream_t)0);
+  if (e != hipSuccess) return (int)e;
+  if (need > tmp_bytes) return (int)hipErrorInvalidValue;
+  return (int)rocprim::inclusive_scan(tmp, need, (const uint32_t *)in, (uint32_t *)out, n, rocprim::maximum<uint32_t>(), (hipStream_t)stream);
+}

@@ -15,11 +15,12 @@ from .caller import ReadProfile, SiteCaller, gc_bins, prepare_templates
 def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: str = "SAMPLE", report_path: Optional[str] = None,
         caller: Optional[SiteCaller] = None, dbsnp=None, compressed: bool = True, date=None, left_trim=(0, 0), right_trim=(0, 0),
         min_qual: Optional[int] = None, benchmark_mode: bool = False, under_conv: Optional[float] = None, over_conv: Optional[float] = None,
-        **reader_kw) -> dict:
+        host_prep: bool = False, **reader_kw) -> dict:
     """reference: contig name -> uint8 reference codes (0 = N, 1..4 = ACGT; position 1 first).  Returns a summary dict.
     under_conv / over_conv / min_qual (defaults 0.01 / 0.05 / 20, src/init_param.c:26-31) are the MODEL's parameters: without
     `caller` the run builds its SiteCaller from them; with one, they are taken from it and a differing explicit value is an error
-    (the header must name the thresholds the genotypes were computed with, src/print_vcf.c:647-692)."""
+    (the header must name the thresholds the genotypes were computed with, src/print_vcf.c:647-692).  host_prep: the read
+    pre-processing on the host (bsc_prepare_templates_profile) instead of the device (round 5's default) — same bytes."""
     own = caller is None
     if own:
         under_conv = 0.01 if under_conv is None else under_conv
@@ -66,11 +67,15 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
                     x = int(raw["pos"][0][0]) or int(raw["pos"][0][1])
                     x = x - 2 if x > 2 else 1  # process_template_vector, src/process_template.c:22-28
                     ref = block_reference(codes, x, y)
-                    tpl, pseq, st = prepare_templates(raw, seq, ms, left_trim, right_trim, min_qual, profile=prof, x=x, ref=ref)
+                    flags = None if dbsnp is None else dbsnp.flags(x, y - x + 1)
+                    if host_prep:  # round 4's split: the process thread's per-template work here, then the block
+                        tpl, pseq, st = prepare_templates(raw, seq, ms, left_trim, right_trim, min_qual, profile=prof, x=x, ref=ref)
+                        recs = c.block_records(tpl, pseq, x, y, ref, reg_stop=len(codes), dbsnp=flags, with_stats=True)
+                    else:  # raw templates up, pre-processing and the read profile on the device (bsc_block_records_raw)
+                        recs, st = c.block_records_raw(raw, seq, ms, x, y, ref, left_trim, right_trim, min_qual, reg_stop=len(codes), dbsnp=flags,
+                                                       with_stats=True, profile=prof)
                     base_filter += np.array([st["base_none"], st["base_trim"], st["base_clip"], st["base_overlap"], st["base_lowqual"]], dtype=np.uint64)
                     passed += np.array([st["reads"], st["read_bases"]], dtype=np.uint64)
-                    flags = None if dbsnp is None else dbsnp.flags(x, y - x + 1)
-                    recs = c.block_records(tpl, pseq, x, y, ref, reg_stop=len(codes), dbsnp=flags, with_stats=True)
                     yield vcf.bcf_block(recs, tid, dbsnp)
                     n_blocks += 1
                     n_records += len(recs)

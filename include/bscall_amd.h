@@ -636,23 +636,27 @@ int bsc_prepare_templates_profile(const bsc_raw_template *raw, uint32_t nr, cons
  * d_seq_out (seq_out_cap bytes: seq_bytes + the sizes of all BSC_MISMS_INS entries always suffice).  Queued on `stream`, then
  * waited for: *seq_out_used, *stats (may be NULL) and the verdict come back with the call — BSC_ERR_ARG where the host form
  * fails, naming the lowest offending template with the host form's own message.  Workspaces (48 bytes per read + the lists)
- * stay with the context.  The read profile (bsc_prepare_templates_profile) is not made here.
+ * stay with the context.  profile (may be NULL): the non-CpG read profile as bsc_prepare_templates_profile makes it — here
+ * profile->ref is a DEVICE pointer to the codes of x .. x + n_ref - 1, counts / cap / used are the host's (counts[cap][4] receives
+ * this call's counts, used grows, with the host form's clearing of what lies behind the old end).
  */
 int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes,
                                  const void *d_misms, uint64_t n_misms, const bsc_prep_params *par, void *d_tpl_out, void *d_seq_out,
-                                 uint64_t seq_out_cap, uint64_t *seq_out_used, bsc_prep_stats *stats, void *stream);
+                                 uint64_t seq_out_cap, uint64_t *seq_out_used, bsc_prep_stats *stats, bsc_read_profile *profile,
+                                 void *stream);
 /*
  * bsc_block_records from what the READER delivers (bsc_read_block: raw templates, their reads and mismatch lists, host buffers):
  * uploaded as they are, prepared on the device, then grouped, walked and called like bsc_block_records — the process thread's
  * per-template work (src/process_template.c:36-111) on no host core.  x .. y = the block as the reader found it (x =
  * bsc_block_start(raw), y = bsc_read_block.y); ref = the codes of x .. y + 2.  prep_stats (may be NULL) = the base counters the
- * pre-processing feeds.  Same records as bsc_prepare_templates + bsc_block_records; two host waits (the prepared size, the
- * records) instead of one.
+ * pre-processing feeds; profile (may be NULL) = the read profile, counts / cap / used as in bsc_read_profile (ref, x, n_ref are
+ * taken from the block).  Same records as bsc_prepare_templates[_profile] + bsc_block_records; two host waits (the prepared
+ * size, the records) instead of one.
  */
 int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                           const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref,
                           const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap,
-                          uint64_t *n_out, bsc_prep_stats *prep_stats);
+                          uint64_t *n_out, bsc_prep_stats *prep_stats, bsc_read_profile *profile);
 /* x of the block a template list starts: the first template's start - 2, at least 1 (src/process_template.c:22-28) */
 uint32_t bsc_block_start(const bsc_raw_template *first);
 /* get_al_qual (src/al_utils.c:19-35): the score duplicate resolution compares, with the reference's sq[k] indexing */

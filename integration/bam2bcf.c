@@ -5,8 +5,10 @@
  *
  *   reader thread     bsc_bam_next_block            read_input / get_next_align_details
  *   process thread    bsc_block_reference           get_sequence_string
- *                     bsc_prepare_templates_profile process_template_vector + meth_profile
- *   calc + print      bsc_block_records             call_genotypes_ML, _print_vcf_entry up to the encoding, the statistics
+ *   process + calc    bsc_block_records_raw         process_template_vector + meth_profile (on the device since round 5:
+ *     + print                                       bsc_prepare_templates_device), call_genotypes_ML, _print_vcf_entry up to the
+ *                                                   encoding, the statistics   (BAM2BCF_HOST_PREP: the pre-processing on this thread,
+ *                                                   bsc_prepare_templates_profile + bsc_block_records, as in round 4)
  *   output            bsc_bcf_block                 the bcf_enc_* calls + bcf_write
  *   at the end        bsc_report_json               output_stats
  *
@@ -138,6 +140,7 @@ int main(int argc, char **argv) {
   bsc_read_block blk;
   int r;
   double t_read = 0, t_ref = 0, t_prep = 0, t_gpu = 0, t_enc = 0, t0 = now(), t1;
+  const int host_prep = getenv("BAM2BCF_HOST_PREP") != NULL;
   for (;;) {
     r = bsc_bam_next_block(bam, &rpar, &blk);
     t_read += (t1 = now()) - t0;
@@ -167,18 +170,32 @@ int main(int argc, char **argv) {
     CHECK(bsc_block_reference(codes, codes_len, x, n + 2, ref));
     t_ref += (t1 = now()) - t0;
     t0 = t1;
-    uint64_t pad = 0;
-    for (uint64_t i = 0; i < blk.n_misms; i++)
-      if (blk.misms[i].type == BSC_MISMS_INS) pad += blk.misms[i].size;
-    if (blk.seq_bytes + pad + 16 > cap_pseq) pseq = xrealloc(pseq, cap_pseq = (size_t)(blk.seq_bytes + pad + 16) * 2);
-    if (blk.nr > cap_tpl) tpl = xrealloc(tpl, (cap_tpl = (size_t)blk.nr * 2) * sizeof *tpl);
-    uint64_t used = 0;
+    /* the process thread's per-template work and call_genotypes_ML in one call: the raw templates go up as the reader left them,
+     * the device prepares them (trims, clips, mate overlap, indels; the read profile) and calls the block.  BAM2BCF_HOST_PREP in the
+     * environment keeps round 4's split (bsc_prepare_templates_profile on this thread, then bsc_block_records) for comparison. */
     bsc_prep_stats st;
-    prof.ref = ref;
-    prof.x = x;
-    prof.n_ref = n + 2;
-    CHECK(bsc_prepare_templates_profile(blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, tpl, pseq, cap_pseq, &used, &st,
-                                        &prof));
+    if (n > cap_recs) recs = xrealloc(recs, (cap_recs = (size_t)n * 2) * sizeof *recs);
+    const bsc_vcf_params vp = {0, 1, (uint32_t)codes_len};
+    uint64_t n_out = 0;
+    if (!host_prep) {
+      CHECK(bsc_block_records_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 1, recs,
+                                  cap_recs, &n_out, &st, &prof));
+    } else {
+      uint64_t pad = 0;
+      for (uint64_t i = 0; i < blk.n_misms; i++)
+        if (blk.misms[i].type == BSC_MISMS_INS) pad += blk.misms[i].size;
+      if (blk.seq_bytes + pad + 16 > cap_pseq) pseq = xrealloc(pseq, cap_pseq = (size_t)(blk.seq_bytes + pad + 16) * 2);
+      if (blk.nr > cap_tpl) tpl = xrealloc(tpl, (cap_tpl = (size_t)blk.nr * 2) * sizeof *tpl);
+      uint64_t used = 0;
+      prof.ref = ref;
+      prof.x = x;
+      prof.n_ref = n + 2;
+      CHECK(bsc_prepare_templates_profile(blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, tpl, pseq, cap_pseq, &used, &st,
+                                          &prof));
+      t_prep += (t1 = now()) - t0;
+      t0 = t1;
+      CHECK(bsc_block_records(ctx, tpl, blk.nr, pseq, used, x, y, ref, NULL, &vp, 1, recs, cap_recs, &n_out));
+    }
     base_filter[0] += st.base_none;
     base_filter[1] += st.base_trim;
     base_filter[2] += st.base_clip;
@@ -186,12 +203,6 @@ int main(int argc, char **argv) {
     base_filter[4] += st.base_lowqual;
     passed_reads += st.reads;
     passed_bases += st.read_bases;
-    t_prep += (t1 = now()) - t0;
-    t0 = t1;
-    if (n > cap_recs) recs = xrealloc(recs, (cap_recs = (size_t)n * 2) * sizeof *recs);
-    const bsc_vcf_params vp = {0, 1, (uint32_t)codes_len};
-    uint64_t n_out = 0;
-    CHECK(bsc_block_records(ctx, tpl, blk.nr, pseq, used, x, y, ref, NULL, &vp, 1, recs, cap_recs, &n_out));
     t_gpu += (t1 = now()) - t0;
     t0 = t1;
     if (n_out * 256 + 64 > cap_bcf) bcf = xrealloc(bcf, cap_bcf = (size_t)(n_out * 256 + 64) * 2);
@@ -210,8 +221,8 @@ int main(int argc, char **argv) {
   }
   CHECK(r);
   if (getenv("BAM2BCF_TIMING"))
-    fprintf(stderr, "seconds: reader %.3f  reference (FASTA + block) %.3f  pre-processing %.3f  bsc_block_records %.3f  BCF encode + write %.3f\n", t_read,
-            t_ref, t_prep, t_gpu, t_enc);
+    fprintf(stderr, "seconds: reader %.3f  reference (FASTA + block) %.3f  pre-processing on the host %.3f  %s %.3f  BCF encode + write %.3f\n",
+            t_read, t_ref, t_prep, host_prep ? "bsc_block_records" : "bsc_block_records_raw (pre-processing on the device)", t_gpu, t_enc);
   if (cur_tid >= 0) {
     CHECK(bsc_get_site_totals(ctx, after));
     uint64_t *d = ctot[cur_tid].snps;

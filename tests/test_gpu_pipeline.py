@@ -90,6 +90,10 @@ def test_bam_to_bcf_equals_the_oracle_chain(tmp_path, oracle, tables, libm_exact
     bam, bcf, rep = str(tmp_path / "in.bam"), str(tmp_path / "out.bcf"), str(tmp_path / "report.json")
     W.write_bam(bam, refs, recs)
     res = pipeline.run(bam, reference, bcf, sample="S1", report_path=rep, date=(3, 10, 2026), compressed=False)
+    # the read pre-processing ran on the device (bsc_block_records_raw); on the host (round 4's split) the same bytes come out
+    bcf_h, rep_h = str(tmp_path / "host_prep.bcf"), str(tmp_path / "host_prep.json")
+    pipeline.run(bam, reference, bcf_h, sample="S1", report_path=rep_h, date=(3, 10, 2026), compressed=False, host_prep=True)
+    assert open(bcf_h, "rb").read() == open(bcf, "rb").read() and open(rep_h).read() == open(rep).read()
     assert res["blocks"] >= 2 and res["records"] > 5_000 and res["contigs"] == ["chrA", "chrB"]
     # ---- the oracle chain, encoded by the independent Python encoder ----
     gc = np.zeros((4096, 101), dtype=np.uint64)

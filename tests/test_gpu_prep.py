@@ -186,3 +186,51 @@ def test_block_records_from_raw_templates(caller):
         caller.block_records_raw(raw2, seq2, ms2, x, y, ref, **kw)
     again, _ = caller.block_records_raw(raw, seq, ms, x, y, ref, **kw)
     assert again.tobytes() == want.tobytes()
+
+
+def test_read_profile_on_the_device(caller):
+    """The non-CpG read profile (meth_profile, src/meth_profile.c:48-77) made by the device form: the host form's counts and vector
+    length, over several calls that grow the vector (incl. the clearing of what lies one past its old end), on random alignments with
+    indels, clips and overlapping mates, reads at the block's first position (the walk that starts one code late) among them."""
+    from bs_call_amd.caller import ReadProfile
+
+    rng = np.random.default_rng(31337)
+    pf_h, pf_d = ReadProfile(cap=4096), ReadProfile(cap=4096)
+    for call in range(12):
+        ts, p0 = [], 500
+        for i in range(int(rng.integers(5, 400))):
+            qlo = 20
+            r0, m0, s0 = T._random_read(rng, qlo)
+            r1, m1, s1 = T._random_read(rng, qlo)
+            if call < 4:  # short reads first: later calls make the vector grow
+                r0, m0, s0 = T.read(20 + call * 5, q=30), (), 20 + call * 5
+                r1, m1, s1 = T.read(22 + call * 5, start=1, q=33), (), 22 + call * 5
+            p0 += int(rng.integers(0, 9))
+            kind = rng.random()
+            if kind < 0.12:
+                t = T.tpl((p0, 0), (s0, 0), (r0, None), (m0, ()))
+            elif kind < 0.2:
+                t = T.tpl((0, p0), (0, s1), (None, r1), ((), m1))
+            else:
+                t = T.tpl((p0, p0 + int(rng.integers(0, s0 + 30))), (s0, s1), (r0, r1), (m0, m1))
+            t["orientation"] = int(rng.integers(0, 2))
+            t["bs_strand"] = int(rng.integers(0, 3))
+            try:
+                py_prep.prepare([t])
+                ts.append(t)
+            except py_prep.PrepError:
+                pass
+        raw, seq, ms = T.to_arrays(ts)
+        h_tpl, h_seq, _ = prepare_templates(raw, seq, ms)
+        x = int(min(p for p in h_tpl["pos"].ravel() if p)) - (0 if call % 3 == 0 else 2)  # every third block starts AT its first read
+        x = max(1, x)
+        y = int((h_tpl["pos"].astype(np.int64) + h_tpl["len"]).max()) + 3
+        ref = rng.integers(0, 5, size=y - x + 3).astype(np.uint8)
+        kw = dict(left_trim=(int(rng.integers(0, 4)), 0), right_trim=(0, int(rng.integers(0, 4))))
+        prepare_templates(raw, seq, ms, profile=pf_h, x=x, ref=ref, **kw)
+        caller.prepare_templates_device(raw, seq, ms, profile=pf_d, x=x, ref=ref, **kw)
+        # (what the host form leaves ONE PAST the vector's end — a reverse read's first base — is not part of the profile: the next
+        # growth clears it, csrc/prep.c; the device form never writes it)
+        assert pf_d.used == pf_h.used and pf_d.counts[: pf_d.used].tobytes() == pf_h.counts[: pf_h.used].tobytes(), call
+        assert not pf_d.counts[pf_d.used :].any()
+    assert pf_h.used > 60 and int(pf_h.counts[1 : pf_h.used].sum()) > 1000
