@@ -139,13 +139,26 @@ def barrier(env):
 
 
 def max_over_ranks(env, dt):
+    """The job's time = the slowest rank's.  Also leaves every rank's own time in env["rank_s"] (one all-reduce of a world-sized
+    vector, each rank filling its own slot) for the line's max / mean — a strong-scaling run is as fast as its largest share."""
     import torch
 
     if env["dist"] is None:
+        env["rank_s"] = [dt]
         return dt
-    t = torch.tensor([dt], dtype=torch.float64, device=env["dev"])
-    env["dist"].all_reduce(t, op=env["dist"].ReduceOp.MAX)
-    return float(t.item())
+    t = torch.zeros(env["world"], dtype=torch.float64, device=env["dev"])
+    t[env["rank"]] = dt
+    env["dist"].all_reduce(t)
+    env["rank_s"] = [float(v) for v in t.cpu()]
+    return max(env["rank_s"])
+
+
+def rank_time_summary(env):
+    rs = env.get("rank_s") or []
+    if not rs:
+        return None
+    mean = sum(rs) / len(rs)
+    return {"max_s": max(rs), "mean_s": mean, "max_over_mean": max(rs) / mean if mean > 0 else None, "per_rank_s": [round(v, 6) for v in rs]}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -216,6 +229,7 @@ def run_config2(args, env):
             "dtype": "f64",
             "data": "synthetic",
             "gbases_per_hour": value * 3.6e-6,
+            "rank_time": rank_time_summary(env),  # max / mean over the ranks of the timed region (the value is positions / max)
             "config": {
                 "workload": "configs[1]: synthetic chr22-sized contig, %d positions at %dx WGBS (L-pileup generator), "
                 "pile-ups resident in HBM, one contig per GPU" % (n, args.coverage),
@@ -680,6 +694,12 @@ def run_config3(args, env):
         del resident
         torch.cuda.empty_cache()
     dt = max_over_ranks(env, dt)
+    # who owned what: the longest-processing-time assignment of whole contigs (shard.assign_contigs), the same on every rank
+    share_table = [{"rank": r, "contigs": genome.rank_contigs(lengths, r, v_world), "positions": sum(lengths[c] for c in genome.rank_contigs(lengths, r, v_world))}
+                   for r in range(v_world)]
+    largest = max(sh["positions"] for sh in share_table)
+    for sh in share_table:
+        sh["of_largest"] = round(sh["positions"] / largest, 4)
     total = int(stats[0])
     expect = (sum(lengths) if not args.rank_of else my_positions) * args.steps
     assert total == expect, (total, expect)
@@ -701,7 +721,9 @@ def run_config3(args, env):
         "dtype": "f64",
         "data": "synthetic",
         "gbases_per_hour": value * 3.6e-6,
+        "rank_time": rank_time_summary(env),  # max / mean over the ranks: the job is as fast as its largest share
         "config": {
+            "shares": share_table,
             "workload": ("configs[4]: configs[2] with a dbSNP index loaded (%d sites of this share; synthetic, 1 site / 300 bp, 10 %% "
                          "flagged fq_mask: forced hom-ref records, dbSNP statistics) — " % n_db if args.dbsnp else "")
             + "configs[2]: synthetic human-scale genome, 24 contigs, %d positions at %dx WGBS with 1 %% N-runs "

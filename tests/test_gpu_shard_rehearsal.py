@@ -44,6 +44,18 @@ def test_two_rank_rehearsal_equals_single_process():
     for k in ("records_written", "CpGs", "dbSNP_sites_written", "covered_fraction"):
         assert c1[k] == c2[k], (k, c1[k], c2[k])
     assert "rank 0 of 2" in c2["share"]
+    # the N > 1 line explains itself: strong scaling, who owned what (whole contigs, longest-processing-time), max / mean rank time
+    shares = c2["shares"]
+    assert [sh["rank"] for sh in shares] == [0, 1] and sorted(c for sh in shares for c in sh["contigs"]) == list(range(24))
+    assert sum(sh["positions"] for sh in shares) == c1["shares"][0]["positions"] and max(sh["of_largest"] for sh in shares) == 1.0
+    assert min(sh["of_largest"] for sh in shares) > 0.9  # LPT over 24 human-length contigs balances two ranks within a few percent
+    rt = two["rank_time"]
+    assert len(rt["per_rank_s"]) == 2 and abs(rt["max_s"] - max(rt["per_rank_s"])) < 1e-5 and rt["max_over_mean"] >= 1.0
+    assert abs(two["ms_per_step"] * two["steps"] / 1e3 - rt["max_s"]) < 1e-3  # the value is positions / the slowest rank's time
+    assert one["rank_time"]["max_over_mean"] == 1.0 and len(c1["shares"]) == 1
+    # configs[1] (the default line): weak scaling, one contig per rank, the same summary
+    w2 = _run([sys.executable, "bench.py", "--gpus", "2", "--sites", "2000000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-chain", "--no-reads"], env)
+    assert w2["n_gpus"] == 2 and w2["scaling"] == "weak" and len(w2["rank_time"]["per_rank_s"]) == 2 and w2["rank_time"]["max_over_mean"] >= 1.0
 
 
 def test_external_launcher_still_works():
