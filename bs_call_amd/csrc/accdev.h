@@ -228,106 +228,6 @@ __device__ static __forceinline__ bool acc_walk(const acc_reads &R, uint32_t n_l
   return true;
 }
 
-/*
- * The packed walk over a tile of 128 positions (round 5): lane L owns positions pa + L (row0) and pa + 64 + L (row1).  What a read
- * costs per tile and not per lane — finding it among the candidates, the four v_readlane that bring its packed word, class table
- * and address to the scalar registers — is paid once for both halves: a 100-base read lies in 2.6 tiles of 64 positions but in 1.8
- * of 128.  Per half the read still gets its own buffer descriptor (its bytes in that half) and its own update.  Rows are 16 dwords
- * (the packed layout's cells: count in bits 0-11, byte sum above; see acc_walk): 8 KB for the tile.  Returns false (rows to be
- * walked again, half by half, by acc_walk) when a cell could overflow.  Stand-alone accumulate kernel only: no lanes in front of
- * the block, one block.
- */
-#define ACC128_GROUP 8 /* reads per group: up to 16 byte loads in flight */
-__device__ static __forceinline__ bool acc_walk128(const acc_reads &R, uint32_t n_live, unsigned lane, uint32_t *row0, uint32_t *row1,
-                                                   uint32_t pa, uint32_t p_last, uint32_t r_last, uint32_t min_qual, uint32_t q_span, uint32_t t0,
-                                                   uint32_t kv, bsc_read_desc d, uint32_t m2_ref, uint32_t m2sum[2], uint32_t m2cnt[2]) {
-  const uint8_t *__restrict__ const seq = R.seq;
-  m2sum[0] = m2sum[1] = m2cnt[0] = m2cnt[1] = 0;
-  uint32_t applied = 0;
-  const uint32_t b_lo = min_qual << 2, b_span = q_span << 2;
-  bool more = true;
-  while (more) {
-    const bool cand = kv <= (r_last >> ACC_BIN_SHIFT);
-    more = __all(cand);
-    {
-      unsigned long long m = __ballot(d.b >= d.a && d.b >= pa && d.a <= p_last);
-      applied += (uint32_t)__builtin_popcountll(m);
-      if (__builtin_expect(applied > ACC_PACK_MAX, 0)) return false;
-      /* the read's part of the tile: offsets lo .. lo + len from pa, 7 bits each; orientation at bit 14, MAPQ^2 above */
-      const uint32_t lo = (d.a > pa ? d.a : pa) - pa;
-      const uint32_t pk = lo | (((d.b < p_last ? d.b : p_last) - pa - lo) << 7) | (((d.meta >> 12) & 1u) << 14) | (d.meta & 0xffff0000u);
-      const uint32_t lutv = d.lut + ((d.meta >> 12) & 1u) * 0x20202020u;
-      const uint64_t sp = (uint64_t)(uintptr_t)seq + (uint64_t)(d.base + (int64_t)pa + (int64_t)lo);
-      uint32_t cnt = (uint32_t)__builtin_popcountll(m);
-      unsigned char g_b0[ACC128_GROUP], g_b1[ACC128_GROUP];
-      uint32_t g_pk[ACC128_GROUP], g_lut[ACC128_GROUP];
-#define ACC2_LOAD(u)                                                                                                  \
-  {                                                                                                                   \
-    const int src = __builtin_ctzll(m);                                                                               \
-    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(src));                                                                 \
-    const uint32_t pks = (uint32_t)__builtin_amdgcn_readlane(pk, src);                                                \
-    const uint32_t sp_lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)sp, src);                                    \
-    const uint32_t sp_hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(sp >> 32), src);                            \
-    g_lut[u] = (uint32_t)__builtin_amdgcn_readlane(lutv, src);                                                        \
-    g_pk[u] = pks;                                                                                                    \
-    const uint32_t lo_s = pks & 127u, end_s = lo_s + ((pks >> 7) & 127u);                                             \
-    const uint64_t a0 = ((uint64_t)sp_hi << 32) | sp_lo;                                                              \
-    /* first half: bytes lo .. min(end, 63), none if lo > 63 (num_records 0: every lane reads 0) */                   \
-    const uint32_t n0 = lo_s <= 63u ? (end_s < 63u ? end_s : 63u) - lo_s + 1u : 0u;                                   \
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)a0, 0, (int)n0, 0x00020000); \
-    g_b0[u] = __builtin_amdgcn_raw_buffer_load_b8(rs0, (int)(lane - lo_s), 0, 0);                                     \
-    /* second half: bytes max(lo, 64) .. end, none if end < 64 */                                                     \
-    const uint32_t st1 = lo_s > 64u ? lo_s : 64u;                                                                     \
-    const uint32_t n1 = end_s >= 64u ? end_s - st1 + 1u : 0u;                                                         \
-    const __amdgpu_buffer_rsrc_t rs1 =                                                                                \
-        __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(a0 + (st1 - lo_s)), 0, (int)n1, 0x00020000);            \
-    g_b1[u] = __builtin_amdgcn_raw_buffer_load_b8(rs1, (int)(lane + 64u - st1), 0, 0);                                \
-  }
-#define ACC2_UPDATE_H(u, gb, rowp, H)                                                                                 \
-  {                                                                                                                   \
-    const uint32_t byte = gb[u], pks = g_pk[u];                                                                       \
-    if (byte - b_lo < b_span) {                                                                                       \
-      const uint32_t c4 = __builtin_amdgcn_alignbyte(0u, g_lut[u], byte) & 0xffu;                                     \
-      atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(rowp) + c4), (byte << 12) | 1u);                \
-      if ((pks >> 16) != m2_ref) {                                                                                    \
-        asm volatile("; a read off the reference MAPQ^2");                                                            \
-        m2sum[H] = __builtin_elementwise_add_sat(m2sum[H], pks >> 16);                                                \
-        m2cnt[H]++;                                                                                                   \
-      }                                                                                                               \
-    }                                                                                                                 \
-  }
-#define ACC2_UPDATE(u)                                                                                                \
-  {                                                                                                                   \
-    const uint32_t pks_ = g_pk[u];                                                                                    \
-    if ((pks_ & 127u) <= 63u) ACC2_UPDATE_H(u, g_b0, row0, 0)      /* scalar tests: a half the read does not reach is skipped */ \
-    if ((pks_ & 127u) + ((pks_ >> 7) & 127u) >= 64u) ACC2_UPDATE_H(u, g_b1, row1, 1)                                   \
-  }
-      for (; cnt >= 8u; cnt -= 8u) {
-        ACC2_LOAD(0) ACC2_LOAD(1) ACC2_LOAD(2) ACC2_LOAD(3) ACC2_LOAD(4) ACC2_LOAD(5) ACC2_LOAD(6) ACC2_LOAD(7)
-        ACC2_UPDATE(0) ACC2_UPDATE(1) ACC2_UPDATE(2) ACC2_UPDATE(3) ACC2_UPDATE(4) ACC2_UPDATE(5) ACC2_UPDATE(6) ACC2_UPDATE(7)
-      }
-      if (cnt & 4u) {
-        ACC2_LOAD(0) ACC2_LOAD(1) ACC2_LOAD(2) ACC2_LOAD(3)
-        ACC2_UPDATE(0) ACC2_UPDATE(1) ACC2_UPDATE(2) ACC2_UPDATE(3)
-      }
-      if (cnt & 2u) {
-        ACC2_LOAD(0) ACC2_LOAD(1)
-        ACC2_UPDATE(0) ACC2_UPDATE(1)
-      }
-      if (cnt & 1u) {
-        ACC2_LOAD(0)
-        ACC2_UPDATE(0)
-      }
-#undef ACC2_LOAD
-#undef ACC2_UPDATE
-#undef ACC2_UPDATE_H
-    }
-    t0 += 64u;
-    if (more) acc_fetch(R, n_live, t0, lane, kv, d);
-  }
-  return true;
-}
-
 /* The lane's row after the walk -> the 26 dwords of its `pileup` record (include/bs_call.h:174-182) in w[]: counts[2][8], n,
  * the eight quality sums and the MAPQ^2 sum as the floats the reference accumulates (integer sums convert exactly below
  * 2^24: DESIGN.md section 2).  Returns whether a sum left that range (BSC_WARN_INEXACT). */

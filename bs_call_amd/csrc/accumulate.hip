@@ -22,7 +22,6 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "accdev.h"
 #include "devtables.h"
@@ -414,143 +413,6 @@ __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel_t(
 }
 
 /*
- * The same stage over tiles of 128 positions (round 5; accdev.h: acc_walk128): one wave per tile, lane i owns positions i and
- * 64 + i.  A read's descriptor work is shared by the two halves.  LDS: 128 packed rows of 16 dwords = 8 KB per wave (20 waves to a
- * CU against the 64-position kernel's 24); the tile leaves half by half through the same staging area.  A tile too deep for the
- * packed cells is walked again half by half by the 64-position walk.  One block only (several blocks start on multiples of 64).
- */
-#define SLOT128_DW (128 * 16)
-template <bool SUMM>
-__global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate128_kernel_t(
-    const bsc_read_desc *__restrict__ rd, const uint32_t *__restrict__ bin_off, uint32_t n_bins, const uint8_t *__restrict__ seq,
-    uint32_t x, uint32_t y, uint32_t min_qual, uint32_t *__restrict__ cts, unsigned long long *__restrict__ counters) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_slot[ACC_WAVES][SLOT128_DW];
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint32_t *slot = lds_slot[wid];
-  uint32_t *row0 = slot + lane * 16u, *row1 = slot + (64u + lane) * 16u;
-  const uint32_t n_sites = y - x + 1;
-  const uint32_t n_wt = (n_sites + 127u) / 128u;
-  const uint32_t q_span = min_qual < 63u ? 63u - min_qual : 0u;
-  unsigned inexact = 0;
-  acc_reads R;
-  R.rd = rd;
-  R.bin_off = bin_off;
-  R.seq = seq;
-  R.n_bins = n_bins;
-  R.x = x;
-  const uint32_t n_live = bin_off[n_bins];
-  const uint32_t span = (uint32_t)counters[BSC_CNT_SPAN];
-  const uint32_t wt_step = gridDim.x * ACC_WAVES;
-  /* XCD-aware tile order, as in the 64-position kernel: the workgroups of one XCD take ACC_XCD_CHUNK / 2 consecutive tile groups */
-  const uint32_t chunk = ACC_XCD_CHUNK / 2u, per8 = 8u * chunk, full8 = gridDim.x / per8 * per8;
-  const uint32_t lb = blockIdx.x >> 3;
-  const uint32_t vb = blockIdx.x < full8 ? (lb / chunk) * per8 + (blockIdx.x & 7u) * chunk + lb % chunk : blockIdx.x;
-  uint32_t wt = vb * ACC_WAVES + wid;
-  uint32_t t0 = 0, kv = 0xffffffffu;
-  bsc_read_desc d;
-  acc_dead(d);
-  if (wt < n_wt) {
-    t0 = acc_tile_start(R, (int64_t)wt * 128, span);
-    acc_fetch(R, n_live, t0, lane, kv, d);
-  }
-  for (; wt < n_wt; wt += wt_step) {
-    const uint32_t p0 = x + wt * 128u;
-    const uint32_t p_last = y - p0 < 127u ? y : p0 + 127u;
-    const uint32_t wt1 = wt + wt_step;
-    const bool have1 = wt1 < n_wt && wt1 > wt;
-    uint32_t kv_n = 0xffffffffu, t0_n = 0;
-    bsc_read_desc dn;
-    acc_dead(dn);
-    if (have1) { /* the next tile's first batch of candidates is on its way while this one is walked */
-      t0_n = acc_tile_start(R, (int64_t)wt1 * 128, span);
-      acc_fetch(R, n_live, t0_n, lane, kv_n, dn);
-    }
-    const uint32_t m2_ref = (uint32_t)__builtin_amdgcn_readfirstlane(d.meta) >> 16;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      reinterpret_cast<uint4 *>(row0)[i] = make_uint4(0u, 0u, 0u, 0u);
-      reinterpret_cast<uint4 *>(row1)[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    uint32_t m2sum[2], m2cnt[2];
-    const bool packed = acc_walk128(R, n_live, lane, row0, row1, p0, p_last, p_last - x, min_qual, q_span, t0, kv, d, m2_ref, m2sum, m2cnt);
-    constexpr unsigned ROW = SUMM ? SUM_DW : IN_DW;
-#define ACC128_SYNC()                                        \
-  do {                                                       \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
-    __builtin_amdgcn_wave_barrier();                         \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
-  } while (0)
-    /* The tile leaves half by half through a staging area that lies over the rows (64 output rows: 6 656 bytes of the slot's
-     * 8 192): the second half's PACKED row (16 dwords) waits in registers meanwhile. */
-    uint32_t r1[16];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const uint4 v = reinterpret_cast<const uint4 *>(row1)[i];
-      r1[4 * i] = v.x; r1[4 * i + 1] = v.y; r1[4 * i + 2] = v.z; r1[4 * i + 3] = v.w;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const uint32_t ph = p0 + 64u * (uint32_t)h;
-      if (ph > p_last) break; /* wave-uniform */
-      const uint32_t pl = y - ph < 63u ? y : ph + 63u;
-      const bool valid = lane <= pl - ph;
-      uint32_t w[IN_DW];
-      if (__builtin_expect(packed, 1)) inexact |= acc_unpack(h ? r1 : row0, true, m2_ref, m2sum[h], m2cnt[h], w) ? 1u : 0u;
-      else { /* a tile more than ACC_PACK_MAX reads deep: this half once more, by the 64-position walk */
-        ACC128_SYNC();
-        const uint32_t th = acc_tile_start(R, (int64_t)(ph - x), span);
-        uint32_t kvh;
-        bsc_read_desc dh;
-        acc_fetch(R, n_live, th, lane, kvh, dh);
-        inexact |= acc_tile(R, n_live, lane, lane, slot + lane * IN_DW, ph, pl, pl - x, min_qual, q_span, th, kvh, dh, w) ? 1u : 0u;
-      }
-      uint32_t o[ROW];
-      if (SUMM) {
-#include "call_summary.inc"
-#pragma unroll
-        for (int j = 0; j < 16; j++) o[j] = w[j];
-        o[16] = qpack0;
-        o[17] = qpack1;
-        o[18] = ((uint32_t)aq & 0xffffu) | ((uint32_t)mq << 16);
-        o[19] = covered ? n_reads : 0u;
-        if (SUM_DW > 20) o[20] = o[SUM_DW - 1] = 0u;
-      } else {
-#pragma unroll
-        for (int i = 0; i < IN_DW; i++) o[i] = w[i];
-      }
-      ACC128_SYNC(); /* every lane has read its row */
-      uint32_t *orow = slot + lane * ROW;
-#pragma unroll
-      for (int i = 0; i < (int)ROW / 2; i++) reinterpret_cast<uint2 *>(orow)[i] = make_uint2(o[2 * i], o[2 * i + 1]);
-      ACC128_SYNC();
-      uint32_t *dst = cts + ((uint64_t)wt * 128u + 64u * (uint32_t)h) * ROW;
-      if (pl - ph == 63u) {
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 *s4 = reinterpret_cast<const u32x4 *>(slot);
-        u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
-        constexpr int full = (int)(64u * ROW * 4u / 1024u);
-#pragma unroll
-        for (int v = 0; v < full; v++) __builtin_nontemporal_store(s4[v * 64 + lane], d4 + v * 64 + lane);
-        if (lane < 32) __builtin_nontemporal_store(s4[full * 64 + lane], d4 + full * 64 + lane);
-      } else if (valid) {
-#pragma unroll
-        for (int i = 0; i < (int)ROW; i++) dst[lane * ROW + i] = orow[i];
-      }
-      ACC128_SYNC();
-    }
-#undef ACC128_SYNC
-    t0 = t0_n;
-    kv = kv_n;
-    d = dn;
-  }
-  if (__any(inexact)) {
-    const unsigned long long m = __ballot(inexact);
-    if (lane == 0) atomicAdd(&counters[BSC_CNT_INEXACT], (unsigned long long)__popcll(m));
-  }
-}
-
-/*
  * bsc_blocks_submit_to_inplace: the caller's reference codes — y - x + 3 per block, one block after another — into the layout the
  * calling kernel reads beside the pile-ups: a block's y - x + 1 codes from its multiple of 64 on, 0 up to the next block.
  */
@@ -627,22 +489,6 @@ extern "C" int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, cons
 static int launch_accumulate(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y, uint32_t n_wt, uint32_t min_qual,
                              void *cts, void *counters, const bsc_chain_mblock *blk, uint32_t n_blk, int num_cus, void *stream,
                              bool summary = false) {
-  /* one block: tiles of 128 positions (acc_walk128) unless BSC_ACC_TILE64 is set (the A/B and fallback build) */
-  static int tile128 = -1;
-  if (tile128 < 0) tile128 = getenv("BSC_ACC_TILE64") ? 0 : 1;
-  if (!blk && tile128) {
-    const uint32_t n128 = (y - x + 1u + 127u) / 128u;
-    unsigned g = (n128 + ACC_WAVES - 1) / ACC_WAVES;
-    const unsigned cap = (unsigned)num_cus * 5u * 8u; /* 5 workgroups of 32 KB LDS fit a CU */
-    if (g > cap) g = cap;
-    if (summary)
-      hipLaunchKernelGGL(bsc_accumulate128_kernel_t<true>, dim3(g), dim3(64 * ACC_WAVES), 0, (hipStream_t)stream, (const bsc_read_desc *)rd,
-                         (const uint32_t *)bin_off, n_wt, (const uint8_t *)seq, x, y, min_qual, (uint32_t *)cts, (unsigned long long *)counters);
-    else
-      hipLaunchKernelGGL(bsc_accumulate128_kernel_t<false>, dim3(g), dim3(64 * ACC_WAVES), 0, (hipStream_t)stream, (const bsc_read_desc *)rd,
-                         (const uint32_t *)bin_off, n_wt, (const uint8_t *)seq, x, y, min_qual, (uint32_t *)cts, (unsigned long long *)counters);
-    return (int)hipGetLastError();
-  }
   unsigned g = (n_wt + ACC_WAVES - 1) / ACC_WAVES;
   const unsigned cap = (unsigned)num_cus * 6u * 8u; /* 6 workgroups of 26 KB LDS fit a CU */
   if (g > cap) g = cap;
