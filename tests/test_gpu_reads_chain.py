@@ -170,3 +170,42 @@ def test_summary_workspace_that_cannot_be_allocated_falls_back_quietly(oracle, t
         _same_stats(a[2], want[2])  # (the methylation profiles are float sums: equal up to the order of the additions)
     exp = _oracle_chain(oracle, tables, libm_exact, tpl, seq, x, y, ref2)
     assert got[0].tobytes() == exp[0].tobytes()
+
+
+def test_class_mean_qualities_at_their_rounding_boundaries(caller, oracle, tables, libm_exact):
+    """Rounded mean qualities of a class (src/call_genotypes.c:49-53) where the mean sits on, or as close as its depth allows to,
+    k + 1/2: n single-base reads of qualities k and k + 1, n / 2 (or (n +- 1) / 2) of them the higher one — through the accumulate
+    kernel's summary form (or the one-kernel form) against the oracle's f32 quotient -> f64 + 0.5 -> f32 -> floorf, and against the
+    mean rounded half up in exact arithmetic; every AMQ byte, at depths from 1 to 600."""
+    if not libm_exact:
+        pytest.skip("host libm differs from the replica: the record bytes go through exp/log")
+    rng = np.random.default_rng(606)
+    n_pos, x = 4000, 5000
+    depth = rng.integers(1, 601, size=n_pos)
+    depth[:64] = np.arange(1, 65)
+    k = rng.integers(20, 43, size=n_pos)
+    m = np.clip(depth // 2 + rng.integers(-1, 2, size=n_pos), 0, depth)  # reads with quality k + 1
+    strand = rng.integers(0, 3, size=n_pos)
+    base = rng.integers(0, 4, size=n_pos)
+    nt = int(depth.sum())
+    tpl = np.zeros(nt, dtype=B.TEMPLATE)
+    pos = np.repeat(np.arange(n_pos), depth)
+    first = np.concatenate(([0], np.cumsum(depth)[:-1]))
+    rank = np.arange(nt) - np.repeat(first, depth)
+    q = np.repeat(k, depth) + (rank < np.repeat(m, depth))
+    seq = (np.repeat(base, depth) | (q << 2)).astype(np.uint8)
+    tpl["pos"][:, 0] = x + 2 + pos
+    tpl["len"][:, 0] = 1
+    tpl["off"][:, 0] = np.arange(nt)
+    tpl["mapq"][:, 0] = 60
+    tpl["bs_strand"] = np.repeat(strand, depth)
+    tpl["orientation"] = rank & 1
+    y = x + 2 + n_pos - 1
+    ref2 = rng.integers(1, 5, size=y - x + 3).astype(np.uint8)
+    ecore, eaux, est, gtm, skip = _oracle_chain(oracle, tables, libm_exact, tpl, seq, x, y, ref2, all_positions=True)
+    core, aux, gst, cnt = _reads_chain(caller, tpl, seq, x, y, ref2, all_positions=True)
+    want = np.floor((2 * (k * depth + m) + depth) / (2 * depth)).astype(int)  # the mean, rounded half up, in exact arithmetic
+    cls = np.array([[0, 1, 2, 3], [0, 5, 2, 7], [4, 1, 6, 3]])[strand, base]
+    assert (gtm["qual"][2 + np.arange(n_pos), cls] == want).all()
+    assert (aux["qual"] == eaux["qual"]).all() and aux.tobytes() == eaux.tobytes()
+    _same_core(core, ecore, "records")
