@@ -269,7 +269,7 @@ __device__ static __forceinline__ bool acc_unpack(const uint32_t *row, bool pack
 /* the whole tile: rows zeroed, walked packed, and — a tile more than ACC_PACK_MAX reads deep — once more unpacked */
 __device__ static __forceinline__ bool acc_tile(const acc_reads &R, uint32_t n_live, unsigned lane, uint32_t lane_p, uint32_t *row,
                                                 uint32_t pa, uint32_t p_last, uint32_t r_last, uint32_t min_qual, uint32_t q_span,
-                                                uint32_t t0, uint32_t kv, const bsc_read_desc &d, uint32_t w[26]) {
+                                                uint32_t t0, uint32_t kv, const bsc_read_desc &d, uint32_t w[26], bool *was_packed = nullptr) {
   uint32_t m2sum, m2cnt;
   /* the tile's reference MAPQ^2: its first candidate's (any value gives the same sums; the common one gives them cheaply) */
   const uint32_t m2_ref = (uint32_t)__builtin_amdgcn_readfirstlane(d.meta) >> 16;
@@ -281,6 +281,7 @@ __device__ static __forceinline__ bool acc_tile(const acc_reads &R, uint32_t n_l
     for (int i = 0; i < 13; i++) reinterpret_cast<uint2 *>(row)[i] = make_uint2(0u, 0u);
     (void)acc_walk<false>(R, n_live, lane, lane_p, row, pa, p_last, r_last, min_qual, q_span, t0, kv, d, m2_ref, m2sum, m2cnt);
   }
+  if (was_packed) *was_packed = packed;
   return acc_unpack(row, packed, m2_ref, m2sum, m2cnt, w);
 }
 

@@ -29,7 +29,7 @@
 #define IN_DW 26
 #define SLOT_DW (64 * IN_DW)
 #define ACC_WAVES 4 /* waves per workgroup */
-#define SUM_DW 22   /* dwords of a site summary (the kernel's summary form; read by fused.hip, which explains the size) */
+#define SUM_DW 12   /*  dwords of a site summary (the kernel's summary form; read by fused.hip, which explains the size) */
 
 /* bsc_template (include/bscall_amd.h) as the kernels read it */
 struct bsc_template_dev {
@@ -257,9 +257,9 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_scatter_kernel(cons
  * result does not depend on any ordering; the slot becomes the reference's pileup[] layout and leaves with 16-byte-per-lane
  * stores.
  */
-/* SUMM: instead of the 104-byte pile-up the tile leaves 88-byte SITE SUMMARIES — counts[2][8] and the per-site summary of
+/* SUMM: instead of the 104-byte pile-up the tile leaves 48-byte SITE SUMMARIES — per class its count | its forward-strand part << 16, and the per-site summary of
  * call_thread (src/call_genotypes.c:44-59: rounded mean quality per class, mean quality, MQ; call_summary.inc, the statements
- * the calling kernels run) — which is what the chain kernel's summary-in form starts from: 15 % fewer bytes through HBM, and
+ * the calling kernels run) — which is what the chain kernel's summary-in form starts from: under half the bytes through HBM, and
  * the summary's arithmetic (a ninth of the chain kernel's vector instructions) moves to the kernel that has issue slots to
  * spare. */
 template <bool SUMM>
@@ -353,18 +353,24 @@ __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel_t(
     }
     {
       uint32_t w[IN_DW];
-      inexact |= acc_tile(Rc, n_live_c, lane, lane, row, p0, p_last, r_last, min_qual, q_span, t0, kv, d, w) ? 1u : 0u;
+      bool packed;
+      inexact |= acc_tile(Rc, n_live_c, lane, lane, row, p0, p_last, r_last, min_qual, q_span, t0, kv, d, w, &packed) ? 1u : 0u;
       if (SUMM) {
+        if (__builtin_expect(!packed, 0)) { /* a tile more than 4 095 reads deep: do its counts still fit the summary's 16 bits? */
+          uint32_t cmax = 0;
+#pragma unroll
+          for (int j = 0; j < 8; j++) cmax = max(cmax, w[j] + w[8 + j]);
+          if (__any(cmax > 0xffffu) && lane == 0) atomicMax(&counters[BSC_CNT_DEEP], 1ull);
+        }
         uint32_t o[SUM_DW];
         {
 #include "call_summary.inc"
 #pragma unroll
-          for (int j = 0; j < 16; j++) o[j] = w[j];
-          o[16] = qpack0;
-          o[17] = qpack1;
-          o[18] = ((uint32_t)aq & 0xffffu) | ((uint32_t)mq << 16);
-          o[19] = covered ? n_reads : 0u;
-          o[20] = o[21] = 0u;
+          for (int j = 0; j < 8; j++) o[j] = ((w[j] + w[8 + j]) & 0xffffu) | (w[j] << 16); /* class count | its forward-strand part */
+          o[8] = qpack0;
+          o[9] = qpack1;
+          o[10] = ((uint32_t)aq & 0xffffu) | ((uint32_t)mq << 16);
+          o[11] = covered ? n_reads : 0u;
         }
         /* the rows are re-laid at the summary's stride: every lane has read its own row (acc_tile) — but lane L's new row
          * overlaps old rows of lower lanes only (22 L < 26 L), all read by now: the wave's LDS operations execute in order */
@@ -394,7 +400,8 @@ __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel_t(
       constexpr int full = (int)(64u * ROW * 4u / 1024u); /* 6.5 KB of pile-ups, 5.5 KB of summaries */
 #pragma unroll
       for (int v = 0; v < full; v++) ACC_ST(d4 + v * 64 + lane, s4[v * 64 + lane]);
-      if (lane < 32) ACC_ST(d4 + full * 64 + lane, s4[full * 64 + lane]);
+      constexpr unsigned rem = (64u * ROW * 4u % 1024u) / 16u; /* lanes of the last, partial kilobyte */
+      if (rem && lane < rem) ACC_ST(d4 + full * 64 + lane, s4[full * 64 + lane]);
 #undef ACC_ST
     } else if (valid || blk) { /* blk: the positions between a block's end and the next multiple of 64 are called too: nothing piled up */
       const uint32_t *orow = slot + lane * ROW;
@@ -503,7 +510,7 @@ static int launch_accumulate(const void *rd, const void *bin_off, const void *se
   return (int)hipGetLastError();
 }
 
-/* the summary form (one block): cts receives (positions rounded up to 64) x 88 bytes */
+/* the summary form (one block): cts receives (positions rounded up to 64) x 48 bytes */
 extern "C" int bsc_dev_launch_accumulate_summary(const void *rd, const void *bin_off, const void *seq, uint32_t x, uint32_t y,
                                                  uint32_t min_qual, void *cts, void *counters, int num_cus, void *stream) {
   return launch_accumulate(rd, bin_off, seq, x, y, bsc_dev_n_bins(y - x + 1), min_qual, cts, counters, NULL, 0, num_cus, stream, true);

@@ -679,6 +679,7 @@ static int bsc_reads_prepare(bsc_context *ctx, const void *d_tpl, uint32_t nr, c
                              uint32_t y, size_t scan_bytes, hipStream_t s) {
   HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), s));
   HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_ERR, 0xff, sizeof(unsigned long long), s));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_DEEP, 0, sizeof(unsigned long long), s));
   int e = bsc_dev_launch_bin_reads(d_tpl, nr, d_seq, seq_bytes, x, y, ctx->d_tflag, ctx->d_bcnt, ctx->d_boff, ctx->d_bcur,
                                    ctx->d_bscan, scan_bytes, ctx->d_rd, ctx->d_counters, s);
   if (e) return bsc_fail(BSC_ERR_HIP, "read grouping launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -1341,7 +1342,7 @@ static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t n
   if ((rc = bsc_reads_prepare(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, scan_bytes, s))) return rc;
   int e;
   /* Two forms, same records (tests/test_gpu_reads_chain.py runs both).  TWO KERNELS: the accumulate kernel's summary form
-   * leaves 88 bytes per position in HBM — the counts and the per-site summary of src/call_genotypes.c:44-59 — and the chain
+   * leaves 48 bytes per position in HBM — the counts and the per-site summary of src/call_genotypes.c:44-59 — and the chain
    * kernel's summary-in form starts from them: the faster form (round 4, per 50 M positions at 30x: 6.14 ms in one kernel, 5.77
    * through a 104-byte pile-up, less through the summaries): alone, the walk runs 24 waves to a CU and hides its byte loads —
    * inside the chain kernel (128 registers, 16 waves to a CU) it waits for them — and the summary's arithmetic runs where there
@@ -1349,7 +1350,7 @@ static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t n
    * is told to (bsc_set_reads_fused) or the summaries cannot be allocated. */
   int two_kernels = !ctx->reads_fused;
   if (two_kernels) {
-    /* 88 bytes per position of HBM the one-kernel form does not need (a maximal block of 2^28 positions: 23 GB); kept, grow-only,
+    /* 48 bytes per position of HBM the one-kernel form does not need (a maximal block of 2^28 positions: 13 GB); kept, grow-only,
      * in the context.  No room: the lean form — silently, and with the runtime's error state cleared (ROCm keeps a failed
      * hipMalloc as its last error, which the launch check below would otherwise report as its own).
      * BSC_TEST_FAIL_SUMMARY_ALLOC in the environment makes this allocation fail for real (tests/test_gpu_reads_chain.py). */
@@ -1367,9 +1368,20 @@ static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t n
     e = bsc_dev_launch_accumulate_summary(ctx->d_rd, ctx->d_boff, d_seq, x, y, (uint32_t)ctx->params.min_qual, ctx->d_cts,
                                           ctx->d_counters, ctx->num_cus, s);
     if (e) return bsc_fail(BSC_ERR_HIP, "accumulate launch failed: %s", hipGetErrorString((hipError_t)e));
+    /* The summaries carry 16-bit counts.  A block with a position deeper than 65 535 reads of one class (the accumulate kernel
+     * says so in counters[BSC_CNT_DEEP]) is the reads-in twin's: both launches are queued, each looks at the flag where it starts
+     * and exactly one does the work — no host round trip, and the statistics are added once. */
+    bsc_chain_launch L2 = L;
     L.cts = ctx->d_cts;
     L.cts_summary = 1;
-  } else {
+    L.run_if = 2;
+    e = bsc_dev_launch_chain(&L);
+    if (e) return bsc_fail(BSC_ERR_HIP, "reads chain launch failed: %s", hipGetErrorString((hipError_t)e));
+    L = L2;
+    L.run_if = 1;
+    L.ev_start = NULL; /* the timed pair of events brackets both launches */
+  }
+  if (!two_kernels || L.run_if) {
     L.rd = ctx->d_rd;
     L.bin_off = ctx->d_boff;
     L.seq = d_seq;

@@ -29,7 +29,8 @@ typedef struct {
 #define BSC_CNT_ERR 15     /* accumulate: min over invalid templates of (index << 8 | BSC_TERR_*); all ones = none */
 #define BSC_CNT_RECORDS 16 /* bsc_block_records: written records of the block being packed */
 #define BSC_CNT_OVF 17     /* fused chain: CpG cytosines beyond the methylation pair table, listed until the statistics are read */
-#define BSC_CNT_SPARE 18
+#define BSC_CNT_DEEP 18    /* accumulate, summary form: != 0 = some position holds more than 65 535 reads of one class — more than the 16-bit
+                              counts of a site summary carry: the summary-in chain stands back, the reads-in chain runs (bscall_api.c) */
 #define BSC_CNT_WORDS 19
 
 /* what the reference asserts about a block's templates (src/call_genotypes.c:186-188) plus the bounds of the read
@@ -66,8 +67,11 @@ typedef struct bsc_chain_launch {
   const void *rd, *bin_off, *seq;
   void *f_scratch;
   uint32_t n_bins, min_qual;
-  /* != 0: cts holds site summaries, 88 bytes per position (bsc_dev_launch_accumulate_summary), not pile-ups; whole blocks only */
+  /* != 0: cts holds site summaries, 48 bytes per position (bsc_dev_launch_accumulate_summary), not pile-ups; whole blocks only */
   int32_t cts_summary;
+  /* 0: the launch runs; 1: only if counters[BSC_CNT_DEEP] is set; 2: only if it is not — the summary-in chain and its reads-in
+   * twin are queued behind the accumulate kernel's summary form, and exactly one of them does the work */
+  uint32_t run_if;
 } bsc_chain_launch;
 
 /* one block of a launch of several (bsc_dev_launch_chain_multi, bsc_dev_launch_bin_reads_multi) */

@@ -55,9 +55,9 @@
 #ifndef BSC_RUN_CAP
 #define BSC_RUN_CAP 32 /* longest run of tiles the launcher gives a wave at a time (BSC_CHAIN_RUN_CAP overrides: experiments) */
 #endif
-#define SUM_DW 22 /* dwords of a site summary (accumulate.hip, summary form): counts[2][8], the packed mean qualities (2), aq | mq << 16,
-                     n, 2 spare — 88 bytes: a tile's 64 rows keep every tile's first row on a 16-byte boundary and read without
-                     bank conflicts like the 26-dword pile-up rows */
+#define SUM_DW 12 /* dwords of a site summary (accumulate.hip, summary form): per class its count | the forward-strand part of it << 16
+                     (8), the packed mean qualities (2), aq | mq << 16, n — 48 bytes: a tile's 64 rows are 3 KB, every tile's first
+                     row on a 16-byte boundary.  Counts beyond 16 bits: counters[BSC_CNT_DEEP], and the reads-in twin runs instead */
 #define F_COV_LDS 256 /* coverage rows of the statistics histogram kept in LDS (deeper positions: global atomics) */
 #define F_WORDS (SS_COV + F_COV_LDS * 6)
 #define F_PAIR 32 /* (a, b) < F_PAIR: CpG cytosines counted in the workgroup's LDS pair table; up to SS_PAIR_G: global */
@@ -90,6 +90,7 @@ struct bsc_chain_args {
                          many dwords, for the GC-by-coverage kernel */
   uint32_t edge_gap;  /* guarded single-block launches: records between run 0 and run 1 that belong to another launch — a
                          block's head tile and the tiles behind its main part as ONE launch (chain_launch_t) */
+  uint32_t run_if;    /* 0: run; 1: only if counters[BSC_CNT_DEEP] != 0; 2: only if it is 0 (devtables.h: bsc_chain_launch.run_if) */
 };
 
 /* the reads-in form (READS = true): the block's ordered reads instead of pile-ups (accdev.h), and where a heterozygous
@@ -297,8 +298,8 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
     uint32_t f[8], r[8], c[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { /* the list entry was written by this wave: read past the vector L1 */
-      f[j] = READS ? __hip_atomic_load(&p[1 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[j];
-      c[j] = READS ? __hip_atomic_load(&p[9 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : f[j] + p[8 + j];
+      f[j] = READS ? __hip_atomic_load(&p[1 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (SUMM ? p[j] >> 16 : p[j]);
+      c[j] = READS ? __hip_atomic_load(&p[9 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (SUMM ? p[j] & 0xffffu : f[j] + p[8 + j]);
       r[j] = c[j] - f[j];
     }
     int t0, t1, t2, t3;
@@ -317,7 +318,7 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
       /* mq as the calling statements form it (call_body.inc; src/call_genotypes.c:59) */
       int mq;
       if (READS) mq = (int)__hip_atomic_load(&p[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if (SUMM) mq = (int)(p[18] >> 16);
+      else if (SUMM) mq = (int)(p[10] >> 16);
       else {
         const uint32_t n_reads = p[16];
         const float mapq2 = __uint_as_float(p[25]);
@@ -360,7 +361,7 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
 typedef const __attribute__((address_space(4))) uint32_t *f_cptr;
 
 /* FULL: the launch's tiles are complete (no bounds checks).  What a tile starts from: READS — the block's reads (the wave piles
- * them up itself); SUMM — site summaries, 88 bytes per position (the accumulate kernel's summary form: counts and the per-site
+ * them up itself); SUMM — site summaries, 48 bytes per position (the accumulate kernel's summary form: counts and the per-site
  * summary of src/call_genotypes.c:44-59 already made); neither — pile-ups, 104 bytes per position.  MULTI: several blocks. */
 template <bool FULL, bool READS, bool MULTI, bool SUMM>
 __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_chain_kargs K) {
@@ -395,6 +396,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   __shared__ uint32_t h[F_WORDS];      /* statistics histogram of the workgroup (sitestats_dev.h) */
   __shared__ uint32_t s_pair[4 * F_PAIR * F_PAIR]; /* CpG cytosines per [ref / non-ref][all / passed][a][b] */
 
+  if (K.a.run_if) { /* one of a pair of launches behind the accumulate kernel's summary form: does this one do the work? */
+    const bool deep = K_COLD(counters)[BSC_CNT_DEEP] != 0;
+    if ((K.a.run_if == 1u) != deep) return;
+  }
   const unsigned tid = threadIdx.x;
   const unsigned lane0 = tid & 63u;
   const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6); /* wave-uniform: the per-wave LDS bases live in scalar registers */
@@ -440,7 +445,8 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     const char *src_ = reinterpret_cast<const char *>(cts + (uint64_t)((int32_t)(JW0) + (int32_t)A_COLD(lc)) * ROW_DW) + lane * 16; \
     constexpr int full_ = (int)(64u * ROW_DW * 4u / 1024u); /* 6 656 bytes = 6.5 KB of pile-ups, 5 632 = 5.5 KB of summaries */ \
     _Pragma("unroll") for (int j_ = 0; j_ < full_; j_++) DMA(src_ + j_ * 1024, slot + j_ * 256);                        \
-    if (lane < 32) DMA(src_ + full_ * 1024, slot + full_ * 256);                                                        \
+    constexpr unsigned rem_ = (64u * ROW_DW * 4u % 1024u) / 16u; /* lanes of the last, partial kilobyte */             \
+    if (rem_ && lane < rem_) DMA(src_ + full_ * 1024, slot + full_ * 256);                                               \
   } while (0)
   /* ---- the wave's runs: run k = wave index + a multiple of the number of waves; tile tj of a run starts 62 tj sites
    * after the run's first computed site (all wave-uniform, scalar registers) ---- */
@@ -611,14 +617,14 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     bool covered;
     int aq, mq;
     if (SUMM) {
-      n_reads = w[19];
+      n_reads = w[11];
       covered = valid && n_reads != 0;
 #pragma unroll
-      for (int j = 0; j < 8; j++) cnt[j] = w[j] + w[8 + j];
-      qpack0 = w[16];
-      qpack1 = w[17];
-      aq = (int)(w[18] & 0xffffu);
-      mq = (int)(w[18] >> 16);
+      for (int j = 0; j < 8; j++) cnt[j] = w[j] & 0xffffu;
+      qpack0 = w[8];
+      qpack1 = w[9];
+      aq = (int)(w[10] & 0xffffu);
+      mq = (int)(w[10] >> 16);
     } else {
       uint32_t n_o, c_o[8], q0_o, q1_o;
       bool cov_o;
@@ -1139,8 +1145,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
 #define GC_ROWS 256
 extern "C" __global__ __launch_bounds__(1024) void bsc_gc_cov_kernel(const uint16_t *__restrict__ depth, uint32_t n, uint32_t pos0,
                                                                      const uint8_t *__restrict__ gc_bins, uint32_t n_bins,
-                                                                     uint32_t start_pos, unsigned long long *__restrict__ table) {
+                                                                     uint32_t start_pos, unsigned long long *__restrict__ table,
+                                                                     const unsigned long long *__restrict__ counters, uint32_t run_if) {
   __shared__ uint32_t t[GC_ROWS * 101];
+  if (run_if && (run_if == 1u) != (counters[BSC_CNT_DEEP] != 0)) return; /* the chain launch this one follows stood back (bsc_chain_args.run_if) */
   for (unsigned i = threadIdx.x; i < GC_ROWS * 101; i += 1024) t[i] = 0;
   __syncthreads();
   for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
@@ -1247,6 +1255,7 @@ static void chain_common(const bsc_chain_launch *L, uint32_t n_all, bsc_chain_ka
   a.with_stats = L->with_stats;
   a.ovf_cap = L->ovf_cap;
   a.het_cap = F_HET_CAP;
+  a.run_if = L->run_if;
   gc = L->with_stats && L->gc_bins && L->gc_table;
   a.depth_off = gc ? (uint32_t)(bsc_dev_chain_het_bytes(n_all, L->num_cus, 0, READS) / sizeof(uint32_t)) : 0u;
   if (READS) {
@@ -1332,7 +1341,8 @@ static int chain_launch_t(const bsc_chain_launch *L) {
     if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
     hipLaunchKernelGGL(bsc_gc_cov_kernel, dim3(grid), dim3(1024), 0, s,
                        reinterpret_cast<const uint16_t *>((const uint32_t *)L->het_list + a.depth_off), L->n, L->x + L->first,
-                       (const uint8_t *)L->gc_bins, L->gc_n_bins, L->gc_start_pos, (unsigned long long *)L->gc_table);
+                       (const uint8_t *)L->gc_bins, L->gc_n_bins, L->gc_start_pos, (unsigned long long *)L->gc_table,
+                       (const unsigned long long *)L->counters, L->run_if);
   }
   hipError_t e = hipGetLastError();
   if (L->ev_stop) (void)hipEventRecord((hipEvent_t)L->ev_stop, s);
@@ -1438,7 +1448,8 @@ extern "C" int bsc_dev_launch_chain_multi(const bsc_chain_launch *L, const bsc_c
       if (grid > (unsigned)L->num_cus) grid = (unsigned)L->num_cus;
       hipLaunchKernelGGL(bsc_gc_cov_kernel, dim3(grid), dim3(1024), 0, s,
                          reinterpret_cast<const uint16_t *>((const uint32_t *)L->het_list + K.a.depth_off) + blk[b].pos_off, blk[b].n,
-                         blk[b].x, (const uint8_t *)L->gc_bins, L->gc_n_bins, L->gc_start_pos, (unsigned long long *)L->gc_table);
+                         blk[b].x, (const uint8_t *)L->gc_bins, L->gc_n_bins, L->gc_start_pos, (unsigned long long *)L->gc_table,
+                         (const unsigned long long *)L->counters, 0u);
     }
   return (int)hipGetLastError();
 }

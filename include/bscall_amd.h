@@ -547,13 +547,14 @@ int bsc_reads_chain_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, con
                            void *d_core, void *d_aux, void *stream);
 int bsc_last_reads_chain_ms(bsc_context *ctx, float *ms);
 /* How bsc_reads_chain_device / bsc_block_records get from reads to records.  0 (default): TWO kernels — the accumulate kernel's
- * summary form leaves 88 bytes per position in HBM (counts[2][8] and the per-site summary of src/call_genotypes.c:44-59; the
- * context's own workspace) and the chain kernel's summary-in form starts from them: the faster form (the walk alone runs at 24
+ * summary form leaves 48 bytes per position in HBM (per class its count and the forward-strand part of it, 16 bits each, and the
+ * per-site summary of src/call_genotypes.c:44-59; the context's own workspace; a block with a position deeper than 65 535 reads
+ * of one class is flagged on the device and done by the reads-in kernel queued behind as a stand-in) and the chain kernel's summary-in form starts from them: the faster form (the walk alone runs at 24
  * waves to a CU and hides its byte loads — inside the 128-register chain kernel it waits for them — and the summary's arithmetic
  * runs where there are issue slots to spare), taken whenever that workspace can be allocated.  1: always the ONE-kernel form
  * (reads-in chain: nothing per position in HBM but the records).  Same records and statistics either way.  (bsc_blocks_records
  * always runs the one-kernel form: small blocks are bound by launches and PCIe, not by the walk.)  Memory: the two-kernel form
- * keeps 88 bytes per position of the largest block seen so far in the context (grow-only; 4.4 GB for a 50 M-position block, 23 GB
+ * keeps 48 bytes per position of the largest block seen so far in the context (grow-only; 2.4 GB for a 50 M-position block, 13 GB
  * for a maximal one of 2^28) — a context that must stay lean sets 1. */
 int bsc_set_reads_fused(bsc_context *ctx, int fused);
 /* Window sizes for a caller that cuts a resident contig into windows of its own choosing (the reference's blocks are data

@@ -209,3 +209,35 @@ def test_class_mean_qualities_at_their_rounding_boundaries(caller, oracle, table
     assert (gtm["qual"][2 + np.arange(n_pos), cls] == want).all()
     assert (aux["qual"] == eaux["qual"]).all() and aux.tobytes() == eaux.tobytes()
     _same_core(core, ecore, "records")
+
+
+def test_position_deeper_than_the_summaries_carry(caller, oracle, tables, libm_exact):
+    """70 000 reads of one class on one position: more than the 16-bit counts of a site summary hold.  The accumulate kernel flags
+    the block (counters[BSC_CNT_DEEP]); of the two chain launches queued behind it the summary-in one stands back and the reads-in
+    twin does the work — same records as the oracle, statistics added once, and the next (ordinary) block goes the usual way."""
+    if not libm_exact:
+        pytest.skip("host libm differs from the replica: the record bytes go through exp/log")
+    x, n_pos = 9000, 700
+    tpl0, seq0 = B.synth_reads_host(SEED + 4, x + 2, n_pos - 110, 20)
+    deep = np.zeros(70_000, dtype=B.TEMPLATE)
+    deep["pos"][:, 0] = x + 300
+    deep["len"][:, 0] = 1
+    deep["off"][:, 0] = len(seq0) + np.arange(len(deep))
+    deep["mapq"][:, 0] = 10
+    deep["bs_strand"] = 1
+    deep["orientation"] = np.arange(len(deep)) & 1
+    tpl = np.concatenate([tpl0, deep])
+    seq = np.concatenate([seq0, np.full(len(deep), 3 | (30 << 2), dtype=np.uint8)])  # T on C2T reads: class 7
+    y = x + n_pos - 1
+    ref2 = B.synth_ref_host(SEED + 4, x, n_pos + 2)
+    ecore, eaux, est, gtm, skip = _oracle_chain(oracle, tables, libm_exact, tpl, seq, x, y, ref2)
+    assert int(gtm["counts"][300, 7]) >= 70_000
+    core, aux, gst, cnt = _reads_chain(caller, tpl, seq, x, y, ref2)
+    _same_core(core, ecore, "deep block")
+    assert aux.tobytes() == eaux.tobytes()
+    _same_stats(gst, est)
+    # an ordinary block afterwards: the flag is per block
+    ecore, eaux, est, gtm, skip = _oracle_chain(oracle, tables, libm_exact, tpl0, seq0, x, y, ref2)
+    core, aux, gst, cnt = _reads_chain(caller, tpl0, seq0, x, y, ref2)
+    _same_core(core, ecore, "ordinary block")
+    _same_stats(gst, est)
