@@ -58,6 +58,13 @@ __device__ static __forceinline__ double fma_vs(double a, double kv, double ks) 
   return d;
 }
 
+/* max(a, b) as the one v_max_f64 it is (fmax() puts a canonicalising v_max_f64 x, x in front of every operand) */
+__device__ static __forceinline__ double max_raw(double a, double b) {
+  double d;
+  asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 /* a * ks + a */
 __device__ static __forceinline__ double fma_s_self(double a, double ks) {
   double d;

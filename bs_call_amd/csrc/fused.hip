@@ -385,6 +385,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   __shared__ double s_pthr[64 * 4];   /* QUAL without the log: per binade of om = 1 - z its four steps ... */
   __shared__ uint8_t s_pbase[64];     /* ... and the value below them (devtables.h; ln x! of Fisher's test is read from memory) */
   __shared__ double s_ptab[PT_WORDS]; /* logs of the methylation arguments of a class whose partner class is empty (callmath.h) */
+  __shared__ __attribute__((aligned(16))) double s_prior[5 * 10]; /* the priors of the ten genotypes by reference code (src/genotype_model.c:87-108) */
   __shared__ unsigned int s_cnt[12];  /* covered, hist[10], het */
   __shared__ uint8_t s_pairs[FW][256]; /* per wave: the (lane, class) pairs whose logs are needed (call_body.inc) */
   __shared__ uint32_t s_gw[FW][66];    /* per wave, entry 2 + lane: the printer's called genotype + 1 (0 = none) of the lane's
@@ -422,6 +423,12 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
   }
   __syncthreads();
   if (tid < PT_WORDS) s_ptab[tid] = pure_log_entry(tid, K_COLD(l), K_COLD(t), s_k, s_logtab); /* callmath.h PT_* */
+  if (tid >= 256 && tid < 306) { /* log(ref_bias) on the reference's homozygote, log(0.5 (1 + ref_bias)) on the heterozygotes that carry it; N: none */
+    const unsigned r = (tid - 256u) / 10u, g = (tid - 256u) % 10u;
+    int ga, gb;
+    f_alleles((int)g, ga, gb);
+    s_prior[tid - 256u] = r == 0 ? 0.0 : (ga == (int)r && gb == (int)r ? K_COLD(lrb) : ((ga == (int)r || gb == (int)r) ? K_COLD(lrb1) : 0.0));
+  }
   __syncthreads();
   if (BSC_CHAIN_STAGGER)
     for (unsigned i = 0; i < wid; i++) __builtin_amdgcn_s_sleep(BSC_CHAIN_STAGGER);
@@ -666,6 +673,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     const bool plain = !tile_n && blk_lo <= -1 && blk_hi >= 63;
 #define CALL_WANT_GP(g_) (former && (want_all || (rs_found & 2u) || !(((g_) == 0 && rf == 1u) || ((g_) == 9 && rf == 4u))))
 #define CALL_PRINTER_GT
+#define CALL_PRIOR_TABLE s_prior
 #define CALL_COMPACT (!READS) /* READS: the forward counts wait in the lanes' slot areas (la[12]) until the heterozygous calls are listed */
 #define CALL_COMPACT_CAP 39u
 #define CALL_SUMMARY_GIVEN
