@@ -403,13 +403,15 @@ def reads_rooflines(args, caller):
             "bases_per_s": seq.size / (a_ms * 1e-3),
             "first_chunk_equals_oracle": None,
             "note": "latency and instruction issue (one byte load per read and 64-position tile) share this stage with the HBM writes "
-            "of the 104-byte pile-ups; neither bound is reached: both fractions are reported",
+            "of the 104-byte pile-ups; neither bound is reached: both fractions are reported.  The generator hands over whether read 0 "
+            "was walked (bsc_template.flags, as bsc_prepare_templates and the glue do); without the flag the grouping fetches one byte of "
+            "every read 0 itself (+ 0.18 ms)",
         },
         "roofline_reads": {
             "bound": "valu_issue",
             "kernel": "bsc_bin_count_kernel + prefix sum + bsc_bin_scatter_kernel + bsc_accumulate_kernel_t<summary> + bsc_chain_kernel_t<.., summary-in> "
             "(bsc_reads_chain_device, its default two-kernel form), with statistics",
-            "what": "reads -> site summaries (counts + the per-site summary of src/call_genotypes.c:44-59, 88 B per position through HBM) -> call -> "
+            "what": "reads -> site summaries (16-bit class counts + the per-site summary of src/call_genotypes.c:44-59, 48 B per position through HBM) -> call -> "
             "VCF record -> site statistics; gt_meth never leaves the registers; " + block,
             "achieved": r_bytes / (r_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBPS,
@@ -425,7 +427,8 @@ def reads_rooflines(args, caller):
             "records_written_fraction": int(d_core.view(n, 64)[:, 4].sum()) / n,
             "first_chunk_records_equal_oracle": None,
             "note": "bound by VALU instruction issue (FP64 model + record formation + the pile-up walk), not by HBM: `valu.frac` is the "
-            "fraction of the bound that binds",
+            "fraction of the bound that binds.  traffic / algorithmic bytes: the 48-byte summaries are written by one kernel and read by "
+            "the next (round 4: 88 bytes, 2.96 x)",
         },
         "_reads_sample": sample,
     }

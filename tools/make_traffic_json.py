@@ -68,7 +68,7 @@ if os.path.isdir(os.path.join(d, "reads_fetch")):
     src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python tools/bench_reads.py --steps 2 --no-check`, per dispatch"
     h = bench.kernel_source_hash(bench.READS_SOURCES)
     out["reads"] = {"_source": src + ", bsc_accumulate_kernel_t<true> + bsc_chain_kernel_t<true, false, false, true> (the two kernels of "
-                    "bsc_reads_chain_device; the 88-byte summaries are written by the first and read by the second: HBM bytes the "
+                    "bsc_reads_chain_device; the 48-byte summaries are written by the first and read by the second: HBM bytes the "
                     "algorithmic count does not have)", "positions": positions, "coverage": coverage,
                     "fetch_size_kib": sf + cf, "write_size_kib": sw + cw, "hbm_bytes_per_launch": int((2 * (sf + cf) + sw + cw) * 1024),
                     "kernels": {"bsc_accumulate_kernel_t<true>": {"fetch_size_kib": sf, "write_size_kib": sw},
