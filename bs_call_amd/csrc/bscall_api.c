@@ -1623,12 +1623,16 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
  * records together.  The copy-out is sized before the count is known, from the share of positions the previous blocks
  * wrote a record for (WGBS: every C and G, about half); only a block that writes more than that pays a second copy.
  */
-/* tpl == NULL with nr != 0: the templates and their reads are already in ctx->d_tpl / ctx->d_seq (bsc_block_records_raw: the device
- * prepared them) */
+/* stage == 2 ("resident"): the templates and their reads are already in ctx->d_tpl / ctx->d_seq (bsc_block_records_raw: the device
+ * prepared them); tpl and seq are not looked at */
 static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
                              uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
                              bsc_vcf_rec *out, uint64_t out_cap, int stage) {
-  const int resident = nr && !tpl;
+  const int resident = stage == 2;
+  if (resident) {
+    stage = 0;
+    tpl = NULL;
+  }
   if (y < x) return bsc_fail(BSC_ERR_ARG, "accumulate: y (%u) < x (%u) (reference asserts y >= x)", y, x);
   if (nr && !resident && (!tpl || !seq)) return bsc_fail(BSC_ERR_ARG, "accumulate: NULL template or read buffer");
   if (ctx->pending_sz || ctx->rec_pending)
@@ -1787,7 +1791,7 @@ int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_
                                     prep_stats, profile ? &dp : NULL, s);
   if (profile) profile->used = dp.used;
   if (rc) return rc; /* (it has waited for the stream: nothing reads the caller's buffers any more) */
-  rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 0);
+  rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 2);
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream);
     return rc;
