@@ -116,6 +116,52 @@ def test_c_abi_rejects_bad_arguments():
         assert L.bsc_accumulate(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(pile_h)) == -1 and "fetched" in err()
         out3 = np.zeros(y - x + 1, dtype=B.GT_METH)
         assert L.bsc_block_fetch(h, p(out3), p(skip2)) == 0 and out3.tobytes() == out2.tobytes()  # ... and neither was this one
+        # round 5's entries: the device pre-processing, the raw-template block, the in-place gt_vcf form of several blocks
+        from bs_call_amd.abi import BLOCK_DESC, MISMS, PREP_PARAMS, PREP_STATS, RAW_TEMPLATE
+
+        raw = np.zeros(len(tpl), dtype=RAW_TEMPLATE)
+        for f in ("pos", "len", "off", "mapq", "orientation", "bs_strand"):
+            raw[f] = tpl[f]
+        raw["reference_span"] = tpl["len"]
+        par = np.zeros(1, dtype=PREP_PARAMS)
+        par["min_qual"] = 20
+        no_ms = np.zeros(1, dtype=MISMS)
+        d_raw = torch.from_numpy(raw.view(np.uint8).reshape(-1)).to("cuda:0")
+        d_po = torch.zeros(len(seq) + 64, dtype=torch.uint8, device="cuda:0")
+        d_pt = torch.zeros(len(raw) * 40, dtype=torch.uint8, device="cuda:0")
+        used, pst = C.c_uint64(0), np.zeros(1, dtype=PREP_STATS)
+        PD = L.bsc_prepare_templates_device
+        args_ok = (h, d_raw.data_ptr(), len(raw), d_seq.data_ptr(), len(seq), None, 0, p(par), d_pt.data_ptr(), d_po.data_ptr(), len(seq) + 64,
+                   C.byref(used), p(pst), None, st)
+        assert PD(*args_ok) == 0 and used.value == len(seq) and int(pst["reads"][0]) > 0
+        assert PD(h, None, len(raw), *args_ok[3:]) == -1 and PD(h, d_raw.data_ptr() + 4, *args_ok[2:]) == -1 and "align" in err()
+        assert PD(*args_ok[:7], None, *args_ok[8:]) == -1 and PD(*args_ok[:11], None, *args_ok[12:]) == -1
+        assert PD(*args_ok[:10], 100, *args_ok[11:]) == -1 and "seq_out too small" in err()  # the output buffer cannot hold the reads
+        bad = raw.copy()
+        bad["orientation"][5] = 3
+        d_bad = torch.from_numpy(bad.view(np.uint8).reshape(-1)).to("cuda:0")
+        assert PD(h, d_bad.data_ptr(), *args_ok[2:]) == -1 and "template 5 has orientation 3" in err()
+        bad = raw.copy()
+        bad["off"][7, 1] = len(seq)
+        d_bad = torch.from_numpy(bad.view(np.uint8).reshape(-1)).to("cuda:0")
+        assert PD(h, d_bad.data_ptr(), *args_ok[2:]) == -1 and "read 1 of template 7 lies outside" in err()
+        RAWF = L.bsc_block_records_raw
+        r_ok = (h, p(raw), len(raw), p(seq), len(seq), p(no_ms), 0, p(par), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec), C.byref(cnt), p(pst), None)
+        assert RAWF(*r_ok) == 0 and cnt.value == n_in.value
+        assert RAWF(h, None, *r_ok[2:]) == -1 and RAWF(*r_ok[:7], None, *r_ok[8:]) == -1 and RAWF(*r_ok[:10], None, *r_ok[11:]) == -1
+        assert RAWF(*r_ok[:8], y, x, *r_ok[10:]) == -1 and "y (" in err()
+        desc = np.zeros(1, dtype=BLOCK_DESC)
+        desc[0] = (x, y, len(tpl), 0)
+        img, sk, off = B.PinnedBuffer((y - x + 64, 208), np.uint8), B.PinnedBuffer(y - x + 64, np.uint8), np.zeros(1, dtype=np.uint64)
+        INP = L.bsc_blocks_submit_to_inplace
+        assert INP(h, p(desc), 1, p(tpl), p(seq), len(seq), None, p(img.array), 208, p(sk.array), p(off)) == -1
+        assert INP(h, p(desc), 0, p(tpl), p(seq), len(seq), p(ref2), p(img.array), 208, p(sk.array), p(off)) == -1 and "n_blocks" in err()
+        assert INP(h, p(desc), 1, p(tpl), p(seq), len(seq), p(ref2), p(img.array), 123, p(sk.array), p(off)) == -1 and "stride" in err()
+        assert INP(h, p(desc), 1, p(tpl), p(seq), len(seq), p(ref2), p(img.array), 208, p(sk.array), p(off)) == 0
+        assert INP(h, p(desc), 1, p(tpl), p(seq), len(seq), p(ref2), p(img.array), 208, p(sk.array), p(off)) == -1 and "fetched" in err()
+        assert L.bsc_block_fetch(h, None, None) == 0 and img.array[: y - x + 1, :200].tobytes() == out2.tobytes()
+        img.free()
+        sk.free()
         # after all that the context still computes
         got = c.block_records(tpl, seq, x, y, ref2)
         assert len(got) > 0 and (got["core"]["emit"] == 1).all()
