@@ -42,6 +42,22 @@ struct bsc_prep_plan {
                               positions in the ORIGINAL read (src/process_template.c:76-87) */
 };
 
+/* what the copy kernel needs of a read whose bytes are its window as it stands (32 bytes, fetched with scalar loads): almost
+ * every read.  The full plan is written — and read — only for the others (PD_FULL). */
+struct bsc_prep_desc {
+  uint64_t srcw;    /* offset in seq of output byte 0: src + w0 (an edited read: unused) */
+  uint32_t out_len;
+  uint32_t ml;      /* output bytes below ml carry the left trim's mark */
+  uint32_t hr;      /* output bytes from hr on lie in the right trim (mirrored bases: done the long way, from the full plan) */
+  uint32_t flags;   /* PD_* */
+  uint32_t wl;      /* the window's length (= out_len unless the list cuts or pads) */
+  int32_t pc;       /* the read profile: window byte s lies at pc + s (read 0), pc - s (read 1, counted from its far end:
+                       src/process_template.c:76-87) of the ORIGINAL read */
+};
+#define PD_PRESENT 1u
+#define PD_EDITED 2u /* the edited list holds an INS or a DEL: the inverse mapping runs */
+#define PD_FULL 4u   /* plan[] holds this read's full plan */
+
 /* error codes, in the order csrc/prep.c makes its checks; the low byte of the word the kernels atomicMin */
 #define PE_ORI 1u
 #define PE_READ 2u  /* + k */
@@ -94,7 +110,8 @@ __device__ static uint32_t d_mean_qual(const uint8_t *sp, const prep_rd &r, uint
 __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_template *__restrict__ raw, uint32_t nr, const uint8_t *__restrict__ seq,
                                                             uint64_t seq_bytes, const bsc_misms *__restrict__ misms_in, uint64_t n_misms_in,
                                                             bsc_prep_params par, bsc_misms *__restrict__ ms_work,
-                                                            bsc_prep_plan *__restrict__ plan, unsigned long long *__restrict__ out_len,
+                                                            bsc_prep_plan *__restrict__ plan, bsc_prep_desc *__restrict__ desc,
+                                                            unsigned long long *__restrict__ out_len,
                                                             bsc_template *__restrict__ tpl_out, unsigned long long *__restrict__ cnt,
                                                             uint32_t *__restrict__ max_pos1) {
   const uint32_t ti = blockIdx.x * 256u + threadIdx.x;
@@ -106,6 +123,7 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
     prep_rd rd[2];
     uint32_t nm[2];
     bsc_misms *ms[2];
+    bool edited[2] = {false, false};
     uint32_t pos[2] = {t.pos[0], t.pos[1]};
     if (t.orientation > 1) err = PE_ORI;
     for (int k = 0; k < 2 && !err; k++) {
@@ -286,6 +304,7 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
         for (uint32_t z = 0; z < nm[k]; z++) {
           bsc_misms *m = ms[k] + z;
           const uint32_t ix1 = m->position + adj;
+          edited[k] |= m->type == BSC_MISMS_INS || m->type == BSC_MISMS_DEL;
           if (m->type == BSC_MISMS_INS) {
             if (ix1 > rl + adj) { err = PE_INDEL; break; }
             adj += m->size;
@@ -309,8 +328,21 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
       atomicMin(&cnt[0], ((unsigned long long)ti << 8) | err);
       n_clip = n_overlap = 0;
     }
-    plan[2u * ti] = P[0];
-    plan[2u * ti + 1u] = P[1];
+    for (int k = 0; k < 2; k++) {
+      bsc_prep_desc d;
+      d.srcw = P[k].src + P[k].w0;
+      d.out_len = P[k].out_len;
+      d.ml = P[k].mark_l > P[k].w0 ? (P[k].mark_l - P[k].w0 < P[k].out_len ? P[k].mark_l - P[k].w0 : P[k].out_len) : 0u;
+      const uint32_t keep = P[k].rl0 - P[k].mark_r; /* original bytes from here on are the right trim's */
+      d.hr = keep > P[k].w0 ? (keep - P[k].w0 < P[k].out_len ? keep - P[k].w0 : P[k].out_len) : 0u;
+      const bool ed = edited[k] && !err;
+      const bool full = ed || d.hr < d.out_len;
+      d.flags = (P[k].present ? PD_PRESENT : 0u) | (ed ? PD_EDITED : 0u) | (full ? PD_FULL : 0u);
+      d.wl = P[k].wl;
+      d.pc = k ? (int32_t)(P[k].wl + P[k].trim_r) - 1 : (int32_t)P[k].trim_l;
+      desc[2u * ti + (uint32_t)k] = d;
+      if (full) plan[2u * ti + (uint32_t)k] = P[k];
+    }
     if (max_pos1) { /* the read profile's vector must reach the template's last read position (src/process_template.c:76-89) */
       int32_t max_pos = 0;
       for (int k = 0; k < 2; k++)
@@ -371,7 +403,6 @@ struct bsc_prep_prof {
   const uint32_t *used_scan;     /* per template: max over the templates up to it of (last read position + 1) */
   unsigned long long *table;     /* [cap][4], zeroed by the caller: this call's counts */
 };
-#define PROF_LDS 1024u /* read positions whose counts a workgroup keeps in LDS */
 __device__ static const uint8_t PROF_REF[64] = { /* src/meth_profile.c:14-23: 4 = C not followed by G, 8 = G not preceded by C */
     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0, 0, 0, 0, 0, 4, 4, 0, 4, 0, 0, 0, 0, 0, 0, 8, 0, 0, 0, 0,
     0, 0, 0, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -383,140 +414,295 @@ __device__ static __forceinline__ uint32_t d_profile_base(uint32_t bs_strand, ui
 }
 
 #define PREP_WAVES 4
-__global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bsc_prep_plan *__restrict__ plan, uint32_t nr,
+#define PREP_BATCH 2u  /* templates a wave places at a time: the loads of their four reads are in flight together */
+#define PREP_CHUNKS 3u /* 64-byte pieces of a read fetched ahead (192 bases); longer reads go on in a loop */
+#define PROF_LDS 512u  /* read positions whose counts a workgroup keeps in LDS */
+
+/* one prepared base for the read profile; s = its index in the window, v = its index in F.ref (see above) */
+__device__ static __forceinline__ void d_prof_base(const bsc_prep_prof &F, uint32_t *s_prof, uint32_t strand, uint32_t used_t, int64_t v,
+                                                   int32_t orig, uint32_t byte) {
+  const uint32_t xx = d_profile_base(strand, byte);
+  if (xx && v + 1 < (int64_t)F.n_ref) {
+    const uint32_t ra = v >= 1 ? F.ref[v - 1] : 0u, rb = v >= 0 ? F.ref[v] : 0u, rc = F.ref[v + 1];
+    const uint32_t m_before = PROF_REF[((ra << 3) | rb) & 63u], m_after = PROF_REF[((rb << 3) | rc) & 63u];
+    if ((((xx & m_after) | ((xx & m_before) >> 1)) >> 2) & 1u) {
+      const uint32_t ix = (uint32_t)(orig + 1);
+      if (ix < used_t && ix < F.cap) {
+        if (ix < PROF_LDS) atomicAdd(&s_prof[ix * 4u + (xx & 3u)], 1u);
+        else atomicAdd(&F.table[(uint64_t)ix * 4u + (xx & 3u)], 1ull);
+      }
+    }
+  }
+}
+
+/*
+ * One wave per 64 reads (32 templates) at a time.  Lane r fetches read r's descriptor and place (coalesced; streaming them through
+ * the scalar cache instead holds the whole kernel to 0.5 TB/s) and does the per-read bookkeeping.  The wave then walks the reads
+ * four at a time, their descriptors broadcast lane by lane, so everything about a read is wave-uniform: lane l moves bytes
+ * 4l .. 4l + 3 of the read with ONE unaligned dword load and one dword store — the last lane of a length that is no multiple of
+ * four moves the read's last four bytes, overlapping its neighbour (same values twice) — so a read of up to 256 bases is one load
+ * and one store instruction; the loads of the four reads are in flight together.  The base counters are byte-parallel arithmetic
+ * on the dword (qualities are 6 bits: bit 6 / bit 7 of every byte are free for the carries) and per-lane population counts.
+ * Reads the list cuts or pads, reads with a right trim (mirrored bases), reads shorter than four bytes and reads that do not fit
+ * the output go the long way, byte by byte (prep_slow_read).
+ */
+#define PD_SLOW 8u /* (set here, not by the plan kernel) */
+__device__ static __forceinline__ uint32_t d_bcast(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ static __forceinline__ unsigned long long d_bcast64(unsigned long long v, uint32_t l) {
+  return (unsigned long long)d_bcast((uint32_t)v, l) | ((unsigned long long)d_bcast((uint32_t)(v >> 32), l) << 32);
+}
+__device__ static __forceinline__ uint32_t d_ld32(const uint8_t *p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+__device__ static __forceinline__ void d_st32(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+struct prep_prof_rd { /* the read profile's view of one read (wave-uniform) */
+  uint32_t used_t, strand;
+  int64_t v0; /* index of output byte 0 in F.ref, one lower for a read at the block's first position */
+  int32_t pc;
+  bool on;
+};
+struct prep_slow_ret {
+  uint32_t c63, cge; /* this lane's bytes of quality 63 / of quality >= mq among those that count */
+  uint32_t walked;
+};
+
+template <bool PROF>
+__device__ __noinline__ static prep_slow_ret prep_slow_read(const bsc_prep_plan *__restrict__ plan_r, const bsc_prep_desc d, unsigned long long o,
+                                                            const uint8_t *__restrict__ seq, const bsc_misms *__restrict__ ms_work,
+                                                            uint8_t *__restrict__ seq_out, uint64_t seq_out_cap, uint32_t mq, uint32_t k,
+                                                            const bsc_prep_prof F, uint32_t *s_prof, const prep_prof_rd pr) {
+  const unsigned lane = threadIdx.x & 63u;
+  prep_slow_ret r = {0u, 0u, 0u};
+  uint8_t *const dp = seq_out + o;
+  const uint32_t room = o < seq_out_cap ? (seq_out_cap - o < d.out_len ? (uint32_t)(seq_out_cap - o) : d.out_len) : 0u;
+  bsc_prep_plan P;
+  if (d.flags & PD_FULL) P = *plan_r;
+  else { /* a plain read that is short or does not fit: its plan from the descriptor (no right trim: hr = out_len) */
+    P.src = d.srcw;
+    P.ms = 0;
+    P.rl0 = d.out_len;
+    P.w0 = 0;
+    P.wl = d.out_len;
+    P.nm = 0;
+    P.mark_l = d.ml;
+    P.mark_r = 0;
+    P.out_len = d.out_len;
+  }
+  const uint8_t *const sp = seq + P.src;
+  const bool edited = (d.flags & PD_EDITED) != 0;
+  if (edited) { /* the base counters run over the window, before the normalisation (src/process_template.c:50-59) */
+    for (uint32_t s0 = 0; s0 < P.wl; s0 += 64u) {
+      const uint32_t s = s0 + lane;
+      if (s < P.wl) {
+        const uint32_t q = d_marked(sp, P.w0 + s, P.rl0, P.mark_l, P.mark_r) >> 2;
+        r.c63 += q == FLT_QUAL;
+        r.cge += q >= mq;
+      }
+    }
+  }
+  const bsc_misms *const ms = ms_work + P.ms;
+  bool walked = false;
+  for (uint32_t j0 = 0; j0 < d.out_len; j0 += 64u) {
+    const uint32_t j = j0 + lane;
+    if (j < d.out_len) {
+      /* the list's edits undone, last first: INS (a deletion from the reference) padded `size` zeros in at ix1, DEL (an
+       * insertion) cut `size` bytes out at ix1 */
+      uint32_t s = j;
+      bool pad = false;
+      if (edited) {
+        for (uint32_t z = P.nm; z-- > 0;) {
+          const bsc_misms m = ms[z];
+          if (m.type == BSC_MISMS_INS) {
+            if (s >= m.position) {
+              if (s - m.position < m.size) {
+                pad = true;
+                break;
+              }
+              s -= m.size;
+            }
+          } else if (m.type == BSC_MISMS_DEL) {
+            if (s >= m.position) s += m.size;
+          }
+        }
+      }
+      const uint32_t byte = pad ? 0u : d_marked(sp, P.w0 + s, P.rl0, P.mark_l, P.mark_r);
+      const uint32_t q = byte >> 2;
+      if (!edited) { /* nothing cut or padded: the output IS the window, counted as it passes */
+        r.c63 += q == FLT_QUAL;
+        r.cge += q >= mq;
+      }
+      walked |= q != 0 && q != FLT_QUAL;
+      if (j < room) dp[j] = (uint8_t)byte;
+      if (PROF && pr.on && !pad) d_prof_base(F, s_prof, pr.strand, pr.used_t, pr.v0 + j, k ? pr.pc - (int32_t)s : pr.pc + (int32_t)s, byte);
+    }
+  }
+  r.walked = __any(walked) ? 1u : 0u;
+  return r;
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bsc_prep_plan *__restrict__ plan,
+                                                                        const bsc_prep_desc *__restrict__ desc, uint32_t nr,
                                                                         const uint8_t *__restrict__ seq, const bsc_misms *__restrict__ ms_work,
                                                                         const unsigned long long *__restrict__ out_off, int32_t min_qual,
                                                                         bsc_template *__restrict__ tpl_out, uint8_t *__restrict__ seq_out,
                                                                         uint64_t seq_out_cap, unsigned long long *__restrict__ cnt,
                                                                         const bsc_prep_prof F) {
-  __shared__ uint32_t s_prof[PROF_LDS * 4u];
-  const bool prof = F.table != nullptr;
-  if (prof) {
+  __shared__ uint32_t s_prof[PROF ? PROF_LDS * 4u : 4u];
+  if (PROF) {
     for (unsigned i = threadIdx.x; i < PROF_LDS * 4u; i += 64 * PREP_WAVES) s_prof[i] = 0;
     __syncthreads();
   }
-  const unsigned lane = threadIdx.x & 63u;
-  const uint32_t wave = blockIdx.x * PREP_WAVES + (threadIdx.x >> 6), n_waves = gridDim.x * PREP_WAVES;
-  uint32_t c_trim = 0, c_low = 0, c_none = 0, c_reads = 0; /* per lane; summed over the wave at the end */
-  unsigned long long c_bases = 0;
-  for (uint32_t ti = wave; ti < nr; ti += n_waves) {
-    uint32_t flags = BSC_TPL_WALK_KNOWN;
-    uint32_t used_t = 0, strand = 0;
-    if (prof) {
-      const uint32_t before = ti ? (F.used_scan[ti - 1u] > F.used0 ? F.used_scan[ti - 1u] : F.used0) : F.used0;
-      used_t = F.used_scan[ti] > before ? F.used_scan[ti] : before;
-      /* growing the vector past its capacity is where the host form gives up (csrc/prep.c) */
-      if (lane == 0 && used_t > before && (unsigned long long)used_t + 1ull > F.cap) atomicMin(&cnt[0], ((unsigned long long)ti << 8) | PE_PROF_CAP);
-      strand = tpl_out[ti].bs_strand;
+  const unsigned lane = threadIdx.x & 63u, lane4 = lane * 4u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * PREP_WAVES + (threadIdx.x >> 6)));
+  const uint32_t n_waves = gridDim.x * PREP_WAVES;
+  const uint32_t mq = min_qual < 0 ? 0u : (min_qual > 64 ? 64u : (uint32_t)min_qual), mq4 = mq * 0x01010101u;
+  /* per lane: bytes that count, those of quality 63, those of quality >= mq; reads, their bases */
+  unsigned long long l_total = 0, l_bases = 0;
+  uint32_t c63 = 0, cge = 0, l_reads = 0;
+  constexpr uint32_t R = 2u * PREP_BATCH;
+  const uint32_t n_reads2 = 2u * nr, n_groups = (n_reads2 + 63u) / 64u;
+  for (uint32_t g = wave; g < n_groups; g += n_waves) {
+    const uint32_t g0 = g * 64u, n = n_reads2 - g0 < 64u ? n_reads2 - g0 : 64u;
+    /* ---- lane r: read g0 + r ---- */
+    const uint32_t ri = g0 + (lane < n ? lane : 0u), my_ti = ri >> 1, my_k = ri & 1u;
+    bsc_prep_desc L = desc[ri];
+    const unsigned long long l_off = out_off[ri];
+    uint32_t l_used = 0, l_pos = 0, l_strand = 0;
+    if (lane >= n) L.out_len = L.flags = 0;
+    if (lane < n) {
+      tpl_out[my_ti].off[my_k] = l_off;
+      const bool fits = l_off <= seq_out_cap && seq_out_cap - l_off >= L.out_len;
+      if (!fits) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_CAP);
+      if ((L.flags & PD_EDITED) || L.hr < L.out_len || L.out_len < 4u || !fits) L.flags |= PD_SLOW;
+      l_total += (L.flags & PD_EDITED) ? L.wl : L.out_len;
+      if (L.flags & PD_PRESENT) {
+        l_reads++;
+        l_bases += L.wl;
+      }
+      if (PROF && (L.flags & PD_PRESENT) && L.out_len != 0) { /* this read's place in the block's codes, its template's share of the vector */
+        const uint32_t before = my_ti ? (F.used_scan[my_ti - 1u] > F.used0 ? F.used_scan[my_ti - 1u] : F.used0) : F.used0;
+        l_used = F.used_scan[my_ti] > before ? F.used_scan[my_ti] : before;
+        /* growing the vector past its capacity is where the host form gives up (csrc/prep.c) */
+        if (l_used > before && (unsigned long long)l_used + 1ull > F.cap) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_CAP);
+        l_strand = tpl_out[my_ti].bs_strand;
+        l_pos = tpl_out[my_ti].pos[my_k];
+        if (l_pos < F.x || (uint64_t)l_pos - F.x + L.out_len + 1u > F.n_ref) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_RANGE);
+        l_strand |= 0x100u; /* "this read is profiled" */
+      }
     }
-    for (int k = 0; k < 2; k++) {
-      const bsc_prep_plan P = plan[2u * ti + (uint32_t)k];
-      const unsigned long long off = out_off[2u * ti + (uint32_t)k];
-      const uint8_t *const sp = seq + P.src;
-      /* the read's place in the block's reference codes */
-      const bool prof_k = prof && P.present && P.out_len != 0;
-      int64_t v0 = 0; /* index of output byte 0 in F.ref, one lower for a read at the block's first position */
-      if (prof_k) {
-        const uint32_t pos = tpl_out[ti].pos[k];
-        if (pos < F.x || (uint64_t)pos - F.x + P.out_len + 1u > F.n_ref) {
-          if (lane == 0) atomicMin(&cnt[0], ((unsigned long long)ti << 8) | PE_PROF_RANGE);
-        }
-        v0 = pos > F.x ? (int64_t)(pos - F.x) : -1;
+    unsigned long long walked_mask = 0; /* bit r: read r (an even one: a template's read 0) was walked */
+    for (uint32_t i0 = 0; i0 < n; i0 += R) { /* (n is even and so is R: reads past n have length 0) */
+      unsigned long long srcw[R], off[R];
+      uint32_t len[R], ml[R], fg[R], v[R];
+#pragma unroll
+      for (uint32_t i = 0; i < R; i++) {
+        const uint32_t l = i0 + i;
+        srcw[i] = d_bcast64(L.srcw, l);
+        off[i] = d_bcast64(l_off, l);
+        len[i] = d_bcast(L.out_len, l);
+        ml[i] = d_bcast(L.ml, l);
+        fg[i] = d_bcast(L.flags, l);
       }
-      if (lane == 0) {
-        tpl_out[ti].off[k] = off;
-        if (P.present) {
-          c_reads++;
-          c_bases += P.wl;
-        }
+      /* the first 256 bytes of all four reads, asked for before any is used */
+#pragma unroll
+      for (uint32_t i = 0; i < R; i++) {
+        v[i] = 0;
+        if (len[i] != 0 && !(fg[i] & PD_SLOW) && lane4 < len[i]) v[i] = d_ld32(seq + srcw[i] + (lane4 < len[i] - 4u ? lane4 : len[i] - 4u));
       }
-      /* the base counters of the statistics (:50-59) run over the window, before the normalisation */
-      if (P.nm) {
-        for (uint32_t s = lane; s < P.wl; s += 64u) {
-          const uint32_t q = d_marked(sp, P.w0 + s, P.rl0, P.mark_l, P.mark_r) >> 2;
-          if (q == FLT_QUAL) c_trim++;
-          else if ((int)q < min_qual) c_low++;
-          else c_none++;
+#pragma unroll
+      for (uint32_t i = 0; i < R; i++) {
+        if (len[i] == 0) continue;
+        const uint32_t l = i0 + i, k = i & 1u; /* (g0 and i0 are even) */
+        prep_prof_rd pr = {0u, 0u, 0, 0, false};
+        if (PROF) {
+          const uint32_t st = d_bcast(l_strand, l), pos = d_bcast(l_pos, l);
+          pr.on = (st & 0x100u) != 0;
+          pr.strand = st & 0xffu;
+          pr.used_t = d_bcast(l_used, l);
+          pr.v0 = pos > F.x ? (int64_t)(pos - F.x) : -1;
+          pr.pc = (int32_t)d_bcast((uint32_t)L.pc, l);
         }
-      }
-      const bsc_misms *const ms = ms_work + P.ms;
-      bool walked = false;
-      for (uint32_t j0 = 0; j0 < P.out_len; j0 += 64u) {
-        const uint32_t j = j0 + lane;
-        if (j < P.out_len) {
-          /* the list's edits undone, last first: INS (a deletion from the reference) padded `size` zeros in at ix1, DEL (an
-           * insertion) cut `size` bytes out at ix1 */
-          uint32_t s = j;
-          bool pad = false;
-          for (uint32_t z = P.nm; z-- > 0;) {
-            const bsc_misms m = ms[z];
-            if (m.type == BSC_MISMS_INS) {
-              if (s >= m.position) {
-                if (s - m.position < m.size) {
-                  pad = true;
-                  break;
-                }
-                s -= m.size;
+        if (fg[i] & PD_SLOW) {
+          bsc_prep_desc d;
+          d.srcw = srcw[i];
+          d.out_len = len[i];
+          d.ml = ml[i];
+          d.hr = d_bcast(L.hr, l);
+          d.flags = fg[i];
+          d.wl = 0;
+          d.pc = 0;
+          const prep_slow_ret r = prep_slow_read<PROF>(plan + g0 + l, d, off[i], seq, ms_work, seq_out, seq_out_cap, mq, k, F, s_prof, pr);
+          c63 += r.c63;
+          cge += r.cge;
+          if (k == 0 && r.walked) walked_mask |= 1ull << l;
+          continue;
+        }
+        const uint8_t *const sp = seq + srcw[i];
+        uint8_t *const dp = seq_out + off[i];
+        bool walked = false;
+        for (uint32_t base = 0; base < len[i]; base += 256u) {
+          const uint32_t nominal = base + lane4;
+          const bool act = nominal < len[i];
+          const uint32_t o = nominal < len[i] - 4u ? nominal : len[i] - 4u;
+          uint32_t w = base == 0 ? v[i] : (act ? d_ld32(sp + o) : 0u);
+          /* bytes this lane shares with its neighbour (the low ones of a last, overlapping dword) do not count twice */
+          const uint32_t vm = act ? 0xffffffffu << (8u * (nominal - o)) : 0u;
+          if (ml[i] > base) { /* the left trim's mark: quality 63 on bytes below ml */
+            const uint32_t nmk = ml[i] > o ? (ml[i] - o < 4u ? ml[i] - o : 4u) : 0u;
+            const uint32_t mm = nmk >= 4u ? 0xffffffffu : (1u << (8u * nmk)) - 1u;
+            w = (w & ~mm) | (((w & 0x03030303u) | 0xfcfcfcfcu) & mm);
+          }
+          const uint32_t qh = ((w >> 2) & 0x3f3f3f3fu) | 0x80808080u;       /* 0x80 + quality, byte by byte */
+          const uint32_t t63 = (qh + 0x01010101u) & 0x40404040u & vm;       /* bit 6: quality 63 */
+          const uint32_t ge = (qh - mq4) & 0x80808080u & vm;                /* bit 7: quality >= mq */
+          c63 += (uint32_t)__popc(t63);
+          cge += (uint32_t)__popc(ge);
+          if (k == 0) { /* was read 0 walked: a quality that is neither 0 nor 63 (src/call_genotypes.c:198-211) */
+            const uint32_t nz = (qh - 0x01010101u) & 0x80808080u & vm;
+            walked |= __any((nz & ~(t63 << 1)) != 0u) != 0;
+          }
+          if (act) d_st32(dp + o, w);
+          if (PROF && pr.on) {
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; t++)
+              if ((vm >> (8u * t)) & 1u) {
+                const uint32_t j = o + t;
+                d_prof_base(F, s_prof, pr.strand, pr.used_t, pr.v0 + j, k ? pr.pc - (int32_t)j : pr.pc + (int32_t)j, (w >> (8u * t)) & 0xffu);
               }
-            } else if (m.type == BSC_MISMS_DEL) {
-              if (s >= m.position) s += m.size;
-            }
-          }
-          const uint32_t byte = pad ? 0u : d_marked(sp, P.w0 + s, P.rl0, P.mark_l, P.mark_r);
-          if (!P.nm) { /* nothing cut or padded: the output IS the window, counted here */
-            const uint32_t q = byte >> 2;
-            if (q == FLT_QUAL) c_trim++;
-            else if ((int)q < min_qual) c_low++;
-            else c_none++;
-          }
-          const uint32_t q = byte >> 2;
-          walked |= q != 0 && q != FLT_QUAL;
-          if (off + j < seq_out_cap) seq_out[off + j] = (uint8_t)byte;
-          if (prof_k && !pad) {
-            const uint32_t xx = d_profile_base(strand, byte);
-            const int64_t v = v0 + j;
-            if (xx && v + 1 < (int64_t)F.n_ref) {
-              const uint32_t ra = v >= 1 ? F.ref[v - 1] : 0u, rb = v >= 0 ? F.ref[v] : 0u, rc = F.ref[v + 1];
-              const uint32_t m_before = PROF_REF[((ra << 3) | rb) & 63u], m_after = PROF_REF[((rb << 3) | rc) & 63u];
-              if ((((xx & m_after) | ((xx & m_before) >> 1)) >> 2) & 1u) {
-                /* position in the original read: read 1 is counted from its far end (src/process_template.c:76-87) */
-                const int32_t orig = k ? (int32_t)(P.wl + P.trim_r) - 1 - (int32_t)s : (int32_t)(P.trim_l + s);
-                const uint32_t ix = (uint32_t)(orig + 1);
-                if (ix < used_t && ix < F.cap) {
-                  if (ix < PROF_LDS) atomicAdd(&s_prof[ix * 4u + (xx & 3u)], 1u);
-                  else atomicAdd(&F.table[(uint64_t)ix * 4u + (xx & 3u)], 1ull);
-                }
-              }
-            }
           }
         }
+        if (k == 0 && walked) walked_mask |= 1ull << l;
       }
-      if (k == 0 && __any(walked)) flags |= BSC_TPL_WALKED0;
-      if (lane == 0 && off + P.out_len > seq_out_cap) atomicMin(&cnt[0], ((unsigned long long)ti << 8) | PE_CAP);
     }
-    if (lane == 0) tpl_out[ti].flags = flags;
+    if (lane < n && my_k == 0) tpl_out[my_ti].flags = BSC_TPL_WALK_KNOWN | (((walked_mask >> lane) & 1ull) ? BSC_TPL_WALKED0 : 0u);
   }
-  if (prof) {
+  if (PROF) {
     __syncthreads();
     for (unsigned i = threadIdx.x; i < PROF_LDS * 4u; i += 64 * PREP_WAVES)
       if (s_prof[i] && i / 4u < F.cap) atomicAdd(&F.table[i], (unsigned long long)s_prof[i]);
   }
-  unsigned long long v[5] = {c_none, c_trim, c_low, c_reads, c_bases};
+  unsigned long long w[5] = {l_total, c63, cge, l_reads, l_bases};
   for (int i = 0; i < 5; i++)
-    for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+    for (int o = 32; o > 0; o >>= 1) w[i] += __shfl_xor(w[i], o);
   if (lane == 0) {
-    if (v[0]) atomicAdd(&cnt[3], v[0]);
-    if (v[1]) atomicAdd(&cnt[4], v[1]);
-    if (v[2]) atomicAdd(&cnt[5], v[2]);
-    if (v[3]) atomicAdd(&cnt[6], v[3]);
-    if (v[4]) atomicAdd(&cnt[7], v[4]);
+    /* base_trim = quality 63; base_lowqual = below min_qual and not 63; base_none = the rest */
+    const unsigned long long low = w[0] - w[2] - (mq > FLT_QUAL ? w[1] : 0ull), none = w[0] - w[1] - low;
+    if (none) atomicAdd(&cnt[3], none);
+    if (w[1]) atomicAdd(&cnt[4], w[1]);
+    if (low) atomicAdd(&cnt[5], low);
+    if (w[3]) atomicAdd(&cnt[6], w[3]);
+    if (w[4]) atomicAdd(&cnt[7], w[4]);
   }
 }
 
 /* ---- launcher ------------------------------------------------------------------------------------------------------------------ */
 extern "C" int bsc_dev_scan_u64(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
 
-extern "C" size_t bsc_dev_prep_plan_bytes(void) { return sizeof(bsc_prep_plan); }
+extern "C" size_t bsc_dev_prep_plan_bytes(void) { return sizeof(bsc_prep_plan) + sizeof(bsc_prep_desc); } /* per read */
 
 /*
  * cnt[8] (device, unsigned long long): [0] the error word (all ones = none: set by the caller), [1] base_clip, [2] base_overlap,
@@ -533,11 +719,12 @@ extern "C" int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq
                                    void *stream, const void *prof_ref, uint32_t prof_x, uint32_t prof_n_ref, uint32_t prof_cap,
                                    uint32_t prof_used0, void *prof_table, void *max_pos1, void *used_scan) {
   hipStream_t s = (hipStream_t)stream;
+  bsc_prep_desc *const desc = (bsc_prep_desc *)((bsc_prep_plan *)plan + 2ull * nr); /* the descriptors lie behind the plans */
   if (!nr) return (int)hipMemsetAsync(out_off, 0, sizeof(unsigned long long), s);
   hipError_t e = hipMemsetAsync((unsigned long long *)out_len + 2ull * nr, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(bsc_prep_plan_kernel, dim3((nr + 255u) / 256u), dim3(256), 0, s, (const bsc_raw_template *)raw, nr, (const uint8_t *)seq,
-                     seq_bytes, (const bsc_misms *)misms, n_misms, *par, (bsc_misms *)ms_work, (bsc_prep_plan *)plan,
+                     seq_bytes, (const bsc_misms *)misms, n_misms, *par, (bsc_misms *)ms_work, (bsc_prep_plan *)plan, desc,
                      (unsigned long long *)out_len, (bsc_template *)tpl_out, (unsigned long long *)cnt, prof_ref ? (uint32_t *)max_pos1 : nullptr);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   int rc = bsc_dev_scan_u64(out_len, out_off, 2u * nr + 1u, scan_tmp, scan_tmp_bytes, stream);
@@ -553,10 +740,11 @@ extern "C" int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq
     F.used_scan = (const uint32_t *)used_scan;
     F.table = (unsigned long long *)prof_table;
   }
-  unsigned g = (nr + PREP_WAVES - 1u) / PREP_WAVES;
-  const unsigned cap = (unsigned)num_cus * 8u * 2u; /* 16 waves to a SIMD are plenty to hide a read's latency */
+  unsigned g = ((nr + 31u) / 32u + PREP_WAVES - 1u) / PREP_WAVES;
+  const unsigned cap = (unsigned)num_cus * 8u; /* 8 waves to a SIMD: all that fit */
   if (g > cap) g = cap;
-  hipLaunchKernelGGL(bsc_prep_copy_kernel, dim3(g), dim3(64 * PREP_WAVES), 0, s, (const bsc_prep_plan *)plan, nr, (const uint8_t *)seq,
+  hipLaunchKernelGGL(prof_ref ? bsc_prep_copy_kernel<true> : bsc_prep_copy_kernel<false>, dim3(g), dim3(64 * PREP_WAVES), 0, s,
+                     (const bsc_prep_plan *)plan, (const bsc_prep_desc *)desc, nr, (const uint8_t *)seq,
                      (const bsc_misms *)ms_work, (const unsigned long long *)out_off, par->min_qual, (bsc_template *)tpl_out,
                      (uint8_t *)seq_out, seq_out_cap, (unsigned long long *)cnt, F);
   return (int)hipGetLastError();
