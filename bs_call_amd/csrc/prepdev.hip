@@ -414,8 +414,7 @@ __device__ static __forceinline__ uint32_t d_profile_base(uint32_t bs_strand, ui
 }
 
 #define PREP_WAVES 4
-#define PREP_BATCH 2u  /* templates a wave places at a time: the loads of their four reads are in flight together */
-#define PREP_CHUNKS 3u /* 64-byte pieces of a read fetched ahead (192 bases); longer reads go on in a loop */
+#define PREP_BATCH 4u  /* templates a wave places at a time: the loads of their eight reads are in flight together */
 #define PROF_LDS 512u  /* read positions whose counts a workgroup keeps in LDS */
 
 /* one prepared base for the read profile; s = its index in the window, v = its index in F.ref (see above) */
@@ -594,28 +593,37 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
         l_strand |= 0x100u; /* "this read is profiled" */
       }
     }
+    /* what the walk needs of a read in one word: length (20 bits), left mark (8 bits), flags (4 bits); a read too long or
+     * marked too far for that goes the long way */
+    if (L.out_len >= (1u << 20) || L.ml >= 256u) L.flags |= PD_SLOW;
+    const uint32_t l_pk = (L.out_len & 0xfffffu) | ((L.ml & 0xffu) << 20) | (L.flags << 28);
     unsigned long long walked_mask = 0; /* bit r: read r (an even one: a template's read 0) was walked */
+    /* the first 256 bytes of R reads at a time, asked for one round ahead: a round's loads are in flight while the round
+     * before it is counted and stored (and do not queue behind its stores) */
+    auto fetch = [&](uint32_t i0, uint32_t(&vv)[R]) {
+#pragma unroll
+      for (uint32_t i = 0; i < R; i++) {
+        const uint32_t l = i0 + i, pk = d_bcast(l_pk, l), ln = pk & 0xfffffu;
+        const unsigned long long sw = d_bcast64(L.srcw, l);
+        vv[i] = 0;
+        if (ln != 0 && !(pk >> 31) && lane4 < ln) vv[i] = d_ld32(seq + sw + (lane4 < ln - 4u ? lane4 : ln - 4u));
+      }
+    };
+    uint32_t v[R], vn[R];
+    fetch(0, v);
     for (uint32_t i0 = 0; i0 < n; i0 += R) { /* (n is even and so is R: reads past n have length 0) */
-      unsigned long long srcw[R], off[R];
-      uint32_t len[R], ml[R], fg[R], v[R];
+      if (i0 + R < n) fetch(i0 + R, vn);
+      unsigned long long off[R];
+      uint32_t pk[R];
 #pragma unroll
       for (uint32_t i = 0; i < R; i++) {
-        const uint32_t l = i0 + i;
-        srcw[i] = d_bcast64(L.srcw, l);
-        off[i] = d_bcast64(l_off, l);
-        len[i] = d_bcast(L.out_len, l);
-        ml[i] = d_bcast(L.ml, l);
-        fg[i] = d_bcast(L.flags, l);
-      }
-      /* the first 256 bytes of all four reads, asked for before any is used */
-#pragma unroll
-      for (uint32_t i = 0; i < R; i++) {
-        v[i] = 0;
-        if (len[i] != 0 && !(fg[i] & PD_SLOW) && lane4 < len[i]) v[i] = d_ld32(seq + srcw[i] + (lane4 < len[i] - 4u ? lane4 : len[i] - 4u));
+        off[i] = d_bcast64(l_off, i0 + i);
+        pk[i] = d_bcast(l_pk, i0 + i);
       }
 #pragma unroll
       for (uint32_t i = 0; i < R; i++) {
-        if (len[i] == 0) continue;
+        const uint32_t len = pk[i] & 0xfffffu, ml = (pk[i] >> 20) & 0xffu;
+        if (len == 0) continue;
         const uint32_t l = i0 + i, k = i & 1u; /* (g0 and i0 are even) */
         prep_prof_rd pr = {0u, 0u, 0, 0, false};
         if (PROF) {
@@ -626,13 +634,13 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
           pr.v0 = pos > F.x ? (int64_t)(pos - F.x) : -1;
           pr.pc = (int32_t)d_bcast((uint32_t)L.pc, l);
         }
-        if (fg[i] & PD_SLOW) {
+        if (pk[i] >> 31) { /* PD_SLOW */
           bsc_prep_desc d;
-          d.srcw = srcw[i];
-          d.out_len = len[i];
-          d.ml = ml[i];
+          d.srcw = d_bcast64(L.srcw, l);
+          d.out_len = d_bcast(L.out_len, l);
+          d.ml = d_bcast(L.ml, l);
           d.hr = d_bcast(L.hr, l);
-          d.flags = fg[i];
+          d.flags = pk[i] >> 28;
           d.wl = 0;
           d.pc = 0;
           const prep_slow_ret r = prep_slow_read<PROF>(plan + g0 + l, d, off[i], seq, ms_work, seq_out, seq_out_cap, mq, k, F, s_prof, pr);
@@ -641,35 +649,33 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
           if (k == 0 && r.walked) walked_mask |= 1ull << l;
           continue;
         }
-        const uint8_t *const sp = seq + srcw[i];
         uint8_t *const dp = seq_out + off[i];
         bool walked = false;
-        for (uint32_t base = 0; base < len[i]; base += 256u) {
+        for (uint32_t base = 0; base < len; base += 256u) {
           const uint32_t nominal = base + lane4;
-          const bool act = nominal < len[i];
-          const uint32_t o = nominal < len[i] - 4u ? nominal : len[i] - 4u;
-          uint32_t w = base == 0 ? v[i] : (act ? d_ld32(sp + o) : 0u);
-          /* bytes this lane shares with its neighbour (the low ones of a last, overlapping dword) do not count twice */
-          const uint32_t vm = act ? 0xffffffffu << (8u * (nominal - o)) : 0u;
-          if (ml[i] > base) { /* the left trim's mark: quality 63 on bytes below ml */
-            const uint32_t nmk = ml[i] > o ? (ml[i] - o < 4u ? ml[i] - o : 4u) : 0u;
+          const bool act = nominal < len;
+          const uint32_t o = nominal < len - 4u ? nominal : len - 4u;
+          uint32_t w = v[i];
+          if (base) w = act ? d_ld32(seq + d_bcast64(L.srcw, l) + o) : 0u;
+          if (ml > base) { /* the left trim's mark: quality 63 on bytes below ml */
+            const uint32_t nmk = act && ml > o ? (ml - o < 4u ? ml - o : 4u) : 0u;
             const uint32_t mm = nmk >= 4u ? 0xffffffffu : (1u << (8u * nmk)) - 1u;
             w = (w & ~mm) | (((w & 0x03030303u) | 0xfcfcfcfcu) & mm);
           }
-          const uint32_t qh = ((w >> 2) & 0x3f3f3f3fu) | 0x80808080u;       /* 0x80 + quality, byte by byte */
-          const uint32_t t63 = (qh + 0x01010101u) & 0x40404040u & vm;       /* bit 6: quality 63 */
-          const uint32_t ge = (qh - mq4) & 0x80808080u & vm;                /* bit 7: quality >= mq */
-          c63 += (uint32_t)__popc(t63);
-          cge += (uint32_t)__popc(ge);
-          if (k == 0) { /* was read 0 walked: a quality that is neither 0 nor 63 (src/call_genotypes.c:198-211) */
-            const uint32_t nz = (qh - 0x01010101u) & 0x80808080u & vm;
-            walked |= __any((nz & ~(t63 << 1)) != 0u) != 0;
-          }
+          /* bytes this lane shares with its neighbour (the low ones of a last, overlapping dword) do not count twice: shifted
+           * out; what comes in is quality 0, base 0 — neither 63 nor walked nor (mq > 0) >= mq — like an idle lane's zero */
+          const uint32_t wc = act ? w >> (8u * (nominal - o)) : 0u;
+          const uint32_t qh = ((wc >> 2) & 0x3f3f3f3fu) | 0x80808080u; /* 0x80 + quality, byte by byte */
+          const uint32_t q1 = qh + 0x01010101u;                        /* bit 6: quality 63; bits 1..5 clear: quality 0 or 63 */
+          c63 += (uint32_t)__popc(q1 & 0x40404040u);
+          cge += (uint32_t)__popc((qh - mq4) & 0x80808080u);           /* bit 7: quality >= mq */
+          /* was read 0 walked: a quality that is neither 0 nor 63 (src/call_genotypes.c:198-211) */
+          if (k == 0) walked |= __any((q1 & 0x3e3e3e3eu) != 0u) != 0;
           if (act) d_st32(dp + o, w);
-          if (PROF && pr.on) {
+          if (PROF && pr.on && act) {
 #pragma unroll
             for (uint32_t t = 0; t < 4u; t++)
-              if ((vm >> (8u * t)) & 1u) {
+              if (t >= nominal - o) {
                 const uint32_t j = o + t;
                 d_prof_base(F, s_prof, pr.strand, pr.used_t, pr.v0 + j, k ? pr.pc - (int32_t)j : pr.pc + (int32_t)j, (w >> (8u * t)) & 0xffu);
               }
@@ -677,6 +683,8 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
         }
         if (k == 0 && walked) walked_mask |= 1ull << l;
       }
+#pragma unroll
+      for (uint32_t i = 0; i < R; i++) v[i] = vn[i];
     }
     if (lane < n && my_k == 0) tpl_out[my_ti].flags = BSC_TPL_WALK_KNOWN | (((walked_mask >> lane) & 1ull) ? BSC_TPL_WALKED0 : 0u);
   }
@@ -688,6 +696,7 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
   unsigned long long w[5] = {l_total, c63, cge, l_reads, l_bases};
   for (int i = 0; i < 5; i++)
     for (int o = 32; o > 0; o >>= 1) w[i] += __shfl_xor(w[i], o);
+  if (mq == 0) w[2] = w[0]; /* (idle lanes and shifted-in bytes read quality 0: with mq = 0 they were counted; every byte is >= 0) */
   if (lane == 0) {
     /* base_trim = quality 63; base_lowqual = below min_qual and not 63; base_none = the rest */
     const unsigned long long low = w[0] - w[2] - (mq > FLT_QUAL ? w[1] : 0ull), none = w[0] - w[1] - low;
@@ -741,7 +750,18 @@ extern "C" int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq
     F.table = (unsigned long long *)prof_table;
   }
   unsigned g = ((nr + 31u) / 32u + PREP_WAVES - 1u) / PREP_WAVES;
-  const unsigned cap = (unsigned)num_cus * 8u; /* 8 waves to a SIMD: all that fit */
+  /* as many workgroups as are resident at once: every wave strides over the groups of reads, one that starts late would do its
+   * whole share after the others have finished */
+  static int per_cu[2] = {0, 0};
+  const int pv = prof_ref ? 1 : 0;
+  if (!per_cu[pv]) {
+    int nb = 0;
+    const hipError_t eo = pv ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bsc_prep_copy_kernel<true>, 64 * PREP_WAVES, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bsc_prep_copy_kernel<false>, 64 * PREP_WAVES, 0);
+    per_cu[pv] = (eo == hipSuccess && nb > 0) ? nb : 4;
+    (void)hipGetLastError();
+  }
+  const unsigned cap = (unsigned)num_cus * (unsigned)per_cu[pv];
   if (g > cap) g = cap;
   hipLaunchKernelGGL(prof_ref ? bsc_prep_copy_kernel<true> : bsc_prep_copy_kernel<false>, dim3(g), dim3(64 * PREP_WAVES), 0, s,
                      (const bsc_prep_plan *)plan, (const bsc_prep_desc *)desc, nr, (const uint8_t *)seq,
