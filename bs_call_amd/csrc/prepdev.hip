@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
     bool edited[2] = {false, false};
     uint32_t pos[2] = {t.pos[0], t.pos[1]};
     if (t.orientation > 1) err = PE_ORI;
+#pragma unroll
     for (int k = 0; k < 2 && !err; k++) {
       if (t.len[k] && (t.off[k] > seq_bytes || t.len[k] > seq_bytes - t.off[k])) err = PE_READ + (uint32_t)k;
       else if (t.n_misms[k] && (t.misms_off[k] > n_misms_in || t.n_misms[k] > n_misms_in - t.misms_off[k])) err = PE_LIST + (uint32_t)k;
@@ -133,10 +134,11 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
     if (!err) {
       /* 1. fixed trims (src/process_template.c:39-41): read[0] is R1 on a FORWARD template, R2 on a REVERSE one — as marks */
       const int msk = t.orientation == 0 ? 0 : 1;
+#pragma unroll
       for (int k = 0; k < 2; k++) {
         const int side = k ^ msk; /* rd[k] is trimmed with left_trim[side], right_trim[side] */
         const uint32_t rl = t.len[k];
-        const int32_t lt = par.left_trim[side], rt = par.right_trim[side];
+        const int32_t lt = side ? par.left_trim[1] : par.left_trim[0], rt = side ? par.right_trim[1] : par.right_trim[0];
         P[k].src = t.off[k];
         P[k].ms = t.misms_off[k];
         P[k].rl0 = rl;
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
         for (uint32_t z = 0; z < nm[k]; z++) ms[k][z] = misms_in[t.misms_off[k] + z];
       }
       /* 2. soft clips (src/al_utils.c:122-162) */
+#pragma unroll
       for (int k = 0; k < 2 && !err; k++) {
         const uint32_t rl = rd[k].wl;
         if (rl == 0) continue;
@@ -196,10 +199,9 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
           rev = 1;
         }
         if (pos[0] + t.reference_span[0] >= pos[1]) {
-          const uint32_t *rspan = t.reference_span;
           int tr; /* the read that is trimmed */
-          if (rspan[0] > rspan[1]) tr = 1;
-          else if (rspan[0] < rspan[1]) tr = 0;
+          if (t.reference_span[0] > t.reference_span[1]) tr = 1;
+          else if (t.reference_span[0] < t.reference_span[1]) tr = 0;
           else
             tr = d_mean_qual(seq + P[0].src, rd[0], P[0].rl0, P[0].mark_l, P[0].mark_r) <=
                          d_mean_qual(seq + P[1].src, rd[1], P[1].rl0, P[1].mark_l, P[1].mark_r)
@@ -210,37 +212,40 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
             if (tr) pos[1] += (uint32_t)overlap;
             else pos[0] += (uint32_t)overlap;
           }
-          bsc_misms *mm = ms[tr];
-          uint32_t num = nm[tr];
+          /* (the trimmed read's state in scalars: arrays indexed by `tr` would live in scratch memory) */
+          bsc_misms *mm = tr ? ms[1] : ms[0];
+          prep_rd rdt = tr ? rd[1] : rd[0];
+          const uint32_t rdl_t = tr ? rdl[1] : rdl[0], span_t = tr ? t.reference_span[1] : t.reference_span[0];
+          uint32_t num = tr ? nm[1] : nm[0];
           if (!num) {
-            if (right) d_right_trim(rd[tr], (uint32_t)overlap);
-            else d_left_trim(rd[tr], (uint32_t)overlap);
+            if (right) d_right_trim(rdt, (uint32_t)overlap);
+            else d_left_trim(rdt, (uint32_t)overlap);
           } else {
             int trimmed = 0;
             if (right) {
-              const uint32_t xx = t.reference_span[tr] - (uint32_t)overlap;
+              const uint32_t xx = span_t - (uint32_t)overlap;
               int64_t adj = 0;
               for (uint32_t z = 0; z < num; z++) {
                 bsc_misms *m = mm + z;
                 if ((int64_t)m->position + adj >= (int64_t)xx) {
-                  const int64_t trim = (int64_t)rdl[tr] - xx + adj;
-                  d_right_trim(rd[tr], (uint32_t)trim);
+                  const int64_t trim = (int64_t)rdl_t - xx + adj;
+                  d_right_trim(rdt, (uint32_t)trim);
                   num = z;
                   trimmed = 1;
                   break;
                 }
                 if (m->type == BSC_MISMS_INS) {
                   if ((int64_t)m->position + adj + m->size >= (int64_t)xx) {
-                    const int64_t trim = (int64_t)rdl[tr] - m->position;
+                    const int64_t trim = (int64_t)rdl_t - m->position;
                     m->size = (uint32_t)((int64_t)xx - ((int64_t)m->position + adj));
-                    d_right_trim(rd[tr], (uint32_t)trim);
+                    d_right_trim(rdt, (uint32_t)trim);
                     num = z + 1;
                     trimmed = 1; /* (no break in the reference: the walk goes on over the shortened list) */
                   }
                   adj += m->size;
                 } else if (m->type == BSC_MISMS_DEL) adj -= m->size;
               }
-              if (!trimmed) d_right_trim(rd[tr], (uint32_t)overlap);
+              if (!trimmed) d_right_trim(rdt, (uint32_t)overlap);
             } else {
               const uint32_t xx = (uint32_t)overlap;
               int64_t adj = 0;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
                 bsc_misms *m = mm + z;
                 if ((int64_t)m->position + adj >= (int64_t)xx) {
                   const uint32_t trim = (uint32_t)((int64_t)overlap - adj);
-                  d_left_trim(rd[tr], trim);
+                  d_left_trim(rdt, trim);
                   trimmed = 1;
                   if (z) {
                     for (uint32_t z1 = z; z1 < num; z1++) {
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
                   if ((int64_t)m->position + adj + m->size >= (int64_t)xx) {
                     m->size = (uint32_t)((int64_t)m->position + m->size + adj - xx);
                     const uint32_t trim = m->position;
-                    d_left_trim(rd[tr], trim);
+                    d_left_trim(rdt, trim);
                     trimmed = 1;
                     const uint32_t z2 = m->size ? z : z + 1;
                     for (uint32_t z1 = z2; z1 < num; z1++) {
@@ -286,18 +291,31 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
                 } else if (m->type == BSC_MISMS_DEL) adj -= m->size;
               }
               if (!trimmed) {
-                d_left_trim(rd[tr], (uint32_t)((int64_t)overlap - adj));
+                d_left_trim(rdt, (uint32_t)((int64_t)overlap - adj));
                 num = 0;
               }
             }
           }
-          nm[tr] = num;
+          if (tr) {
+            nm[1] = num;
+            rd[1] = rdt;
+          } else {
+            nm[0] = num;
+            rd[0] = rdt;
+          }
           n_overlap += (rdl[0] - rd[0].wl) + (rdl[1] - rd[1].wl);
-          if (right) P[tr].trim_r += rdl[tr] - rd[tr].wl; /* src/al_utils.c:309-313 */
-          else P[tr].trim_l += rdl[tr] - rd[tr].wl;
+          const uint32_t cut = tr ? rdl[1] - rd[1].wl : rdl[0] - rd[0].wl; /* src/al_utils.c:309-313 */
+          if (right) {
+            if (tr) P[1].trim_r += cut;
+            else P[0].trim_r += cut;
+          } else {
+            if (tr) P[1].trim_l += cut;
+            else P[0].trim_l += cut;
+          }
         }
       }
       /* 4. indel normalisation (src/process_template.c:62-108): where every entry cuts or pads — ix1 — and the length that results */
+#pragma unroll
       for (int k = 0; k < 2 && !err; k++) {
         const uint32_t rl = rd[k].wl;
         uint32_t adj = 0;
@@ -321,6 +339,7 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
       }
     }
     if (err) {
+#pragma unroll
       for (int k = 0; k < 2; k++) {
         P[k].src = P[k].ms = 0;
         P[k].rl0 = P[k].w0 = P[k].wl = P[k].nm = P[k].mark_l = P[k].mark_r = P[k].out_len = P[k].present = P[k].trim_l = P[k].trim_r = 0;
@@ -328,6 +347,7 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
       atomicMin(&cnt[0], ((unsigned long long)ti << 8) | err);
       n_clip = n_overlap = 0;
     }
+#pragma unroll
     for (int k = 0; k < 2; k++) {
       bsc_prep_desc d;
       d.srcw = P[k].src + P[k].w0;
@@ -345,6 +365,7 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
     }
     if (max_pos1) { /* the read profile's vector must reach the template's last read position (src/process_template.c:76-89) */
       int32_t max_pos = 0;
+#pragma unroll
       for (int k = 0; k < 2; k++)
         if (P[k].present) {
           const int32_t mpos = k ? (int32_t)(P[k].wl + P[k].trim_r) - 1 : (int32_t)(P[k].trim_l + P[k].wl);
