@@ -12,12 +12,21 @@
  *                          (first byte, length) and an edited copy of its mismatch list; what the normalisation does is, per list
  *                          entry, where it cuts or pads (ix1, src/process_template.c:93).  Out: the plan of both reads, the output
  *                          lengths (for the prefix sum that places the reads in the output buffer), the template's positions.
- *   bsc_prep_copy_kernel   one wave per template.  Output byte j of a read comes from the inverse of the list's edits — walked
- *                          backwards, a padded deletion gives 0, everything else an index into the window — through the fixed
- *                          trims' marks (quality 63; the right trim takes the BASE of the byte mirrored at the read's other end,
- *                          as the reference's loop does).  Consecutive lanes = consecutive output bytes.  Also here, because every
- *                          byte passes by: the base counters of the statistics (:50-59) and bsc_template.flags (was read 0
- *                          walked, src/call_genotypes.c:198-211).
+ *                          Per read a 16-byte descriptor (where its bytes start, length, left mark, flags); the full 56-byte plan
+ *                          only for the reads that need it (the list cuts or pads, a right trim, very short / very long).
+ *   bsc_prep_copy_kernel   one wave per 64 reads at a time: lane r fetches read r's descriptor and place and does the per-read
+ *                          bookkeeping, then the wave walks the reads, descriptors broadcast lane by lane.  A read whose output is
+ *                          its window moves as dwords — lane l one unaligned 4-byte load and store, eight reads' loads in flight a
+ *                          round ahead of the round being stored; the left trim's mark (quality 63) and the base counters of the
+ *                          statistics (:50-59) are byte-parallel arithmetic on the dword, bsc_template.flags (was read 0 walked,
+ *                          src/call_genotypes.c:198-211) one lane vote.  The other reads go byte by byte: output byte j from the
+ *                          inverse of the list's edits — walked backwards, a padded deletion gives 0, everything else an index
+ *                          into the window — through the fixed trims' marks (the right trim takes the BASE of the byte mirrored at
+ *                          the read's other end, as the reference's loop does).
+ * Measured (tools/bench_prep.py, 50 Mb at 30x, 7.5 M templates, 1.48 G bases, every 50th read with an indel pair): plan 0.36 ms,
+ * prefix sum 0.1 ms, copy 1.5 ms (2 x 1.5 GB of read bytes + 0.5 GB of descriptors and places at 2.8 TB/s; VALU issue 57 %).
+ * The round-5 form it replaces — one wave per template, its plan through the scalar cache, a byte per lane — took 0.9 + 6.4 ms:
+ * profiles/r05_prep.json.
  * Where the reference aborts (an illegal soft clip ...) the lowest offending template and its first failing check come back
  * through one atomicMin; the host entry runs csrc/prep.c on that one template for the message.
  */
@@ -42,21 +51,19 @@ struct bsc_prep_plan {
                               positions in the ORIGINAL read (src/process_template.c:76-87) */
 };
 
-/* what the copy kernel needs of a read whose bytes are its window as it stands (32 bytes, fetched with scalar loads): almost
- * every read.  The full plan is written — and read — only for the others (PD_FULL). */
+/* what the copy kernel needs of a read whose bytes are its window as it stands (16 bytes): almost every read.  The full plan
+ * is written — and read — only for the others (PD_SLOW). */
 struct bsc_prep_desc {
-  uint64_t srcw;    /* offset in seq of output byte 0: src + w0 (an edited read: unused) */
-  uint32_t out_len;
-  uint32_t ml;      /* output bytes below ml carry the left trim's mark */
-  uint32_t hr;      /* output bytes from hr on lie in the right trim (mirrored bases: done the long way, from the full plan) */
-  uint32_t flags;   /* PD_* */
-  uint32_t wl;      /* the window's length (= out_len unless the list cuts or pads) */
-  int32_t pc;       /* the read profile: window byte s lies at pc + s (read 0), pc - s (read 1, counted from its far end:
-                       src/process_template.c:76-87) of the ORIGINAL read */
+  uint64_t srcw; /* offset in seq of output byte 0: src + w0 (a read that goes the long way: unused) */
+  uint32_t pk;   /* out_len (20 bits; a longer read: 0xfffff and PD_SLOW) | left mark << 20 (8 bits: output bytes below it carry the
+                    left trim's quality 63) | PD_* << 28 */
+  int32_t pc;    /* the read profile: window byte s lies at pc + s (read 0), pc - s (read 1, counted from its far end:
+                    src/process_template.c:76-87) of the ORIGINAL read */
 };
 #define PD_PRESENT 1u
 #define PD_EDITED 2u /* the edited list holds an INS or a DEL: the inverse mapping runs */
-#define PD_FULL 4u   /* plan[] holds this read's full plan */
+#define PD_SLOW 8u   /* byte by byte from the full plan in plan[]: an edited read, one with a right trim (mirrored bases), one
+                        shorter than 4 or longer than 2^20 - 2 bytes, one marked further than 255 bytes in */
 
 /* error codes, in the order csrc/prep.c makes its checks; the low byte of the word the kernels atomicMin */
 #define PE_ORI 1u
@@ -350,18 +357,18 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       bsc_prep_desc d;
+      const uint32_t ol = P[k].out_len;
       d.srcw = P[k].src + P[k].w0;
-      d.out_len = P[k].out_len;
-      d.ml = P[k].mark_l > P[k].w0 ? (P[k].mark_l - P[k].w0 < P[k].out_len ? P[k].mark_l - P[k].w0 : P[k].out_len) : 0u;
+      const uint32_t ml = P[k].mark_l > P[k].w0 ? (P[k].mark_l - P[k].w0 < ol ? P[k].mark_l - P[k].w0 : ol) : 0u;
       const uint32_t keep = P[k].rl0 - P[k].mark_r; /* original bytes from here on are the right trim's */
-      d.hr = keep > P[k].w0 ? (keep - P[k].w0 < P[k].out_len ? keep - P[k].w0 : P[k].out_len) : 0u;
+      const uint32_t hr = keep > P[k].w0 ? (keep - P[k].w0 < ol ? keep - P[k].w0 : ol) : 0u;
       const bool ed = edited[k] && !err;
-      const bool full = ed || d.hr < d.out_len;
-      d.flags = (P[k].present ? PD_PRESENT : 0u) | (ed ? PD_EDITED : 0u) | (full ? PD_FULL : 0u);
-      d.wl = P[k].wl;
+      const bool slow = ol != 0 && (ed || hr < ol || ol < 4u || ol >= 0xfffffu || ml >= 256u);
+      d.pk = (ol < 0xfffffu ? ol : 0xfffffu) | ((ml & 0xffu) << 20) |
+             (((P[k].present ? PD_PRESENT : 0u) | (ed ? PD_EDITED : 0u) | (slow ? PD_SLOW : 0u)) << 28);
       d.pc = k ? (int32_t)(P[k].wl + P[k].trim_r) - 1 : (int32_t)P[k].trim_l;
       desc[2u * ti + (uint32_t)k] = d;
-      if (full) plan[2u * ti + (uint32_t)k] = P[k];
+      if (slow) plan[2u * ti + (uint32_t)k] = P[k];
     }
     if (max_pos1) { /* the read profile's vector must reach the template's last read position (src/process_template.c:76-89) */
       int32_t max_pos = 0;
@@ -466,7 +473,6 @@ __device__ static __forceinline__ void d_prof_base(const bsc_prep_prof &F, uint3
  * Reads the list cuts or pads, reads with a right trim (mirrored bases), reads shorter than four bytes and reads that do not fit
  * the output go the long way, byte by byte (prep_slow_read).
  */
-#define PD_SLOW 8u /* (set here, not by the plan kernel) */
 __device__ static __forceinline__ uint32_t d_bcast(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ static __forceinline__ unsigned long long d_bcast64(unsigned long long v, uint32_t l) {
   return (unsigned long long)d_bcast((uint32_t)v, l) | ((unsigned long long)d_bcast((uint32_t)(v >> 32), l) << 32);
@@ -490,29 +496,17 @@ struct prep_slow_ret {
 };
 
 template <bool PROF>
-__device__ __noinline__ static prep_slow_ret prep_slow_read(const bsc_prep_plan *__restrict__ plan_r, const bsc_prep_desc d, unsigned long long o,
-                                                            const uint8_t *__restrict__ seq, const bsc_misms *__restrict__ ms_work,
-                                                            uint8_t *__restrict__ seq_out, uint64_t seq_out_cap, uint32_t mq, uint32_t k,
-                                                            const bsc_prep_prof F, uint32_t *s_prof, const prep_prof_rd pr) {
+__device__ __noinline__ static prep_slow_ret prep_slow_read(const bsc_prep_plan *__restrict__ plan_r, uint32_t flags, uint8_t *__restrict__ dp,
+                                                            const uint8_t *__restrict__ seq, const bsc_misms *__restrict__ ms_work, uint32_t mq,
+                                                            uint32_t k, const bsc_prep_prof F, uint32_t *s_prof, const prep_prof_rd pr) {
   const unsigned lane = threadIdx.x & 63u;
   prep_slow_ret r = {0u, 0u, 0u};
-  uint8_t *const dp = seq_out + o;
-  const uint32_t room = o < seq_out_cap ? (seq_out_cap - o < d.out_len ? (uint32_t)(seq_out_cap - o) : d.out_len) : 0u;
-  bsc_prep_plan P;
-  if (d.flags & PD_FULL) P = *plan_r;
-  else { /* a plain read that is short or does not fit: its plan from the descriptor (no right trim: hr = out_len) */
-    P.src = d.srcw;
-    P.ms = 0;
-    P.rl0 = d.out_len;
-    P.w0 = 0;
-    P.wl = d.out_len;
-    P.nm = 0;
-    P.mark_l = d.ml;
-    P.mark_r = 0;
-    P.out_len = d.out_len;
-  }
+  const bsc_prep_plan P = *plan_r;
+  struct {
+    uint32_t out_len;
+  } d = {P.out_len};
   const uint8_t *const sp = seq + P.src;
-  const bool edited = (d.flags & PD_EDITED) != 0;
+  const bool edited = (flags & PD_EDITED) != 0;
   if (edited) { /* the base counters run over the window, before the normalisation (src/process_template.c:50-59) */
     for (uint32_t s0 = 0; s0 < P.wl; s0 += 64u) {
       const uint32_t s = s0 + lane;
@@ -555,7 +549,7 @@ __device__ __noinline__ static prep_slow_ret prep_slow_read(const bsc_prep_plan 
         r.cge += q >= mq;
       }
       walked |= q != 0 && q != FLT_QUAL;
-      if (j < room) dp[j] = (uint8_t)byte;
+      dp[j] = (uint8_t)byte; /* (a read that does not fit the output never gets here) */
       if (PROF && pr.on && !pad) d_prof_base(F, s_prof, pr.strand, pr.used_t, pr.v0 + j, k ? pr.pc - (int32_t)s : pr.pc + (int32_t)s, byte);
     }
   }
@@ -592,60 +586,85 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
     bsc_prep_desc L = desc[ri];
     const unsigned long long l_off = out_off[ri];
     uint32_t l_used = 0, l_pos = 0, l_strand = 0;
-    if (lane >= n) L.out_len = L.flags = 0;
+    if (lane >= n) L.pk = 0;
     if (lane < n) {
-      tpl_out[my_ti].off[my_k] = l_off;
-      const bool fits = l_off <= seq_out_cap && seq_out_cap - l_off >= L.out_len;
-      if (!fits) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_CAP);
-      if ((L.flags & PD_EDITED) || L.hr < L.out_len || L.out_len < 4u || !fits) L.flags |= PD_SLOW;
-      l_total += (L.flags & PD_EDITED) ? L.wl : L.out_len;
-      if (L.flags & PD_PRESENT) {
-        l_reads++;
-        l_bases += L.wl;
+      const uint32_t fl = L.pk >> 28;
+      uint32_t ol = L.pk & 0xfffffu, wl = ol; /* the read's length as it goes out, its window's */
+      if (fl & PD_SLOW) {
+        ol = plan[ri].out_len;
+        wl = plan[ri].wl;
       }
-      if (PROF && (L.flags & PD_PRESENT) && L.out_len != 0) { /* this read's place in the block's codes, its template's share of the vector */
+      tpl_out[my_ti].off[my_k] = l_off;
+      if (l_off > seq_out_cap || seq_out_cap - l_off < ol) { /* does not fit: refused, and not written at all */
+        atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_CAP);
+        L.pk &= 0xf0000000u;
+      }
+      l_total += (fl & PD_EDITED) ? wl : ol;
+      if (fl & PD_PRESENT) {
+        l_reads++;
+        l_bases += wl;
+      }
+      if (PROF && (fl & PD_PRESENT) && ol != 0) { /* this read's place in the block's codes, its template's share of the vector */
         const uint32_t before = my_ti ? (F.used_scan[my_ti - 1u] > F.used0 ? F.used_scan[my_ti - 1u] : F.used0) : F.used0;
         l_used = F.used_scan[my_ti] > before ? F.used_scan[my_ti] : before;
         /* growing the vector past its capacity is where the host form gives up (csrc/prep.c) */
         if (l_used > before && (unsigned long long)l_used + 1ull > F.cap) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_CAP);
         l_strand = tpl_out[my_ti].bs_strand;
         l_pos = tpl_out[my_ti].pos[my_k];
-        if (l_pos < F.x || (uint64_t)l_pos - F.x + L.out_len + 1u > F.n_ref) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_RANGE);
+        if (l_pos < F.x || (uint64_t)l_pos - F.x + ol + 1u > F.n_ref) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_RANGE);
         l_strand |= 0x100u; /* "this read is profiled" */
       }
     }
-    /* what the walk needs of a read in one word: length (20 bits), left mark (8 bits), flags (4 bits); a read too long or
-     * marked too far for that goes the long way */
-    if (L.out_len >= (1u << 20) || L.ml >= 256u) L.flags |= PD_SLOW;
-    const uint32_t l_pk = (L.out_len & 0xfffffu) | ((L.ml & 0xffu) << 20) | (L.flags << 28);
+    /* ---- what the walk needs of a read, made here once per lane so that the walk itself is short: every instruction of the
+     * walk — vector or scalar — is an issue slot of the wave, and the issue slots are what this kernel runs out of ----
+     * l_ctl: length (20 bits) | left mark << 20 (8 bits) | kind << 28 | edited << 30;  kind 0: nothing to do,
+     * KIND_LEAN: the window as it stands, at most 256 bytes, no mark (without the read profile), KIND_FAST: the window, any
+     * length, marked below ml, KIND_SLOW: byte by byte from the full plan */
+    enum : uint32_t { KIND_LEAN = 1u, KIND_FAST = 2u, KIND_SLOW = 3u };
+    const uint32_t my_len = L.pk & 0xfffffu, my_ml = (L.pk >> 20) & 0xffu;
+    const uint32_t my_kind =
+        my_len == 0 ? 0u : ((L.pk >> 28) & PD_SLOW ? KIND_SLOW : ((!PROF && my_len <= 256u && my_ml == 0) ? KIND_LEAN : KIND_FAST));
+    const uint32_t l_ctl = (L.pk & 0x0fffffffu) | (my_kind << 28) | (((L.pk >> 28) & PD_EDITED) ? 1u << 30 : 0u);
+    const bool my_fetch = my_kind == KIND_LEAN || my_kind == KIND_FAST; /* (then my_len >= 4) */
+    /* where the read's bytes start, as an offset from desc[] (a pointer the compiler knows to be global memory; a broadcast
+     * pointer would be a generic one); a read that is not fetched: desc[] itself, four bytes that exist */
+    const unsigned long long l_src = my_fetch ? (unsigned long long)(seq + L.srcw) - (unsigned long long)desc : 0ull;
+    const uint32_t l_last = my_fetch ? my_len - 4u : 0u;
     unsigned long long walked_mask = 0; /* bit r: read r (an even one: a template's read 0) was walked */
     /* the first 256 bytes of R reads at a time, asked for one round ahead: a round's loads are in flight while the round
-     * before it is counted and stored (and do not queue behind its stores) */
+     * before it is counted and stored (and do not queue behind its stores).  No branch around a load: the wait for a round's
+     * loads can then leave the next round's in flight.  (A round past the group's last wraps round to its first lanes: loads
+     * of bytes that exist, unused.) */
     auto fetch = [&](uint32_t i0, uint32_t(&vv)[R]) {
 #pragma unroll
       for (uint32_t i = 0; i < R; i++) {
-        const uint32_t l = i0 + i, pk = d_bcast(l_pk, l), ln = pk & 0xfffffu;
-        const unsigned long long sw = d_bcast64(L.srcw, l);
-        vv[i] = 0;
-        if (ln != 0 && !(pk >> 31) && lane4 < ln) vv[i] = d_ld32(seq + sw + (lane4 < ln - 4u ? lane4 : ln - 4u));
+        const uint32_t l = i0 + i, last = d_bcast(l_last, l);
+        vv[i] = d_ld32((const uint8_t *)desc + d_bcast64(l_src, l) + (lane4 < last ? lane4 : last)); /* (idle lanes fetch the read's last dword) */
       }
     };
-    uint32_t v[R], vn[R];
-    fetch(0, v);
-    for (uint32_t i0 = 0; i0 < n; i0 += R) { /* (n is even and so is R: reads past n have length 0) */
-      if (i0 + R < n) fetch(i0 + R, vn);
-      unsigned long long off[R];
-      uint32_t pk[R];
+    auto process = [&](const uint32_t i0, const uint32_t(&v)[R]) {
 #pragma unroll
       for (uint32_t i = 0; i < R; i++) {
-        off[i] = d_bcast64(l_off, i0 + i);
-        pk[i] = d_bcast(l_pk, i0 + i);
-      }
-#pragma unroll
-      for (uint32_t i = 0; i < R; i++) {
-        const uint32_t len = pk[i] & 0xfffffu, ml = (pk[i] >> 20) & 0xffu;
-        if (len == 0) continue;
         const uint32_t l = i0 + i, k = i & 1u; /* (g0 and i0 are even) */
+        const uint32_t ctl = d_bcast(l_ctl, l), kind = (ctl >> 28) & 3u, len = ctl & 0xfffffu;
+        if (kind == 0) continue;
+        uint8_t *const dp = seq_out + d_bcast64(l_off, l);
+        if (!PROF && kind == KIND_LEAN) {
+          const bool act = lane4 < len;
+          const uint32_t o = lane4 < len - 4u ? lane4 : len - 4u, w = v[i];
+          /* bytes this lane shares with its neighbour (the low ones of a last, overlapping dword) do not count twice: shifted
+           * out; what comes in is quality 0, base 0 — neither 63 nor walked nor (mq > 0) >= mq — like an idle lane's zero */
+          const uint32_t wc = act ? w >> (8u * (lane4 - o)) : 0u;
+          const uint32_t qh = ((wc >> 2) & 0x3f3f3f3fu) | 0x80808080u; /* 0x80 + quality, byte by byte */
+          const uint32_t q1 = qh + 0x01010101u;                        /* bit 6: quality 63; bits 1..5 clear: quality 0 or 63 */
+          c63 += (uint32_t)__popc(q1 & 0x40404040u);
+          cge += (uint32_t)__popc((qh - mq4) & 0x80808080u);           /* bit 7: quality >= mq */
+          /* was read 0 walked: a quality that is neither 0 nor 63 (src/call_genotypes.c:198-211) */
+          const bool walked = k == 0 && __any((q1 & 0x3e3e3e3eu) != 0u) != 0;
+          if (act) d_st32(dp + o, w);
+          if (k == 0 && walked) walked_mask |= 1ull << l;
+          continue;
+        }
         prep_prof_rd pr = {0u, 0u, 0, 0, false};
         if (PROF) {
           const uint32_t st = d_bcast(l_strand, l), pos = d_bcast(l_pos, l);
@@ -655,42 +674,31 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
           pr.v0 = pos > F.x ? (int64_t)(pos - F.x) : -1;
           pr.pc = (int32_t)d_bcast((uint32_t)L.pc, l);
         }
-        if (pk[i] >> 31) { /* PD_SLOW */
-          bsc_prep_desc d;
-          d.srcw = d_bcast64(L.srcw, l);
-          d.out_len = d_bcast(L.out_len, l);
-          d.ml = d_bcast(L.ml, l);
-          d.hr = d_bcast(L.hr, l);
-          d.flags = pk[i] >> 28;
-          d.wl = 0;
-          d.pc = 0;
-          const prep_slow_ret r = prep_slow_read<PROF>(plan + g0 + l, d, off[i], seq, ms_work, seq_out, seq_out_cap, mq, k, F, s_prof, pr);
+        if (kind == KIND_SLOW) {
+          const prep_slow_ret r = prep_slow_read<PROF>(plan + g0 + l, (ctl >> 30) & 1u ? PD_EDITED : 0u, dp, seq, ms_work, mq, k, F, s_prof, pr);
           c63 += r.c63;
           cge += r.cge;
           if (k == 0 && r.walked) walked_mask |= 1ull << l;
           continue;
         }
-        uint8_t *const dp = seq_out + off[i];
+        const uint32_t ml = (ctl >> 20) & 0xffu;
         bool walked = false;
         for (uint32_t base = 0; base < len; base += 256u) {
           const uint32_t nominal = base + lane4;
           const bool act = nominal < len;
           const uint32_t o = nominal < len - 4u ? nominal : len - 4u;
           uint32_t w = v[i];
-          if (base) w = act ? d_ld32(seq + d_bcast64(L.srcw, l) + o) : 0u;
+          if (base) w = act ? d_ld32((const uint8_t *)desc + d_bcast64(l_src, l) + o) : 0u;
           if (ml > base) { /* the left trim's mark: quality 63 on bytes below ml */
             const uint32_t nmk = act && ml > o ? (ml - o < 4u ? ml - o : 4u) : 0u;
             const uint32_t mm = nmk >= 4u ? 0xffffffffu : (1u << (8u * nmk)) - 1u;
             w = (w & ~mm) | (((w & 0x03030303u) | 0xfcfcfcfcu) & mm);
           }
-          /* bytes this lane shares with its neighbour (the low ones of a last, overlapping dword) do not count twice: shifted
-           * out; what comes in is quality 0, base 0 — neither 63 nor walked nor (mq > 0) >= mq — like an idle lane's zero */
-          const uint32_t wc = act ? w >> (8u * (nominal - o)) : 0u;
-          const uint32_t qh = ((wc >> 2) & 0x3f3f3f3fu) | 0x80808080u; /* 0x80 + quality, byte by byte */
-          const uint32_t q1 = qh + 0x01010101u;                        /* bit 6: quality 63; bits 1..5 clear: quality 0 or 63 */
+          const uint32_t wc = act ? w >> (8u * (nominal - o)) : 0u; /* (as above; an idle lane counts like a zero) */
+          const uint32_t qh = ((wc >> 2) & 0x3f3f3f3fu) | 0x80808080u;
+          const uint32_t q1 = qh + 0x01010101u;
           c63 += (uint32_t)__popc(q1 & 0x40404040u);
-          cge += (uint32_t)__popc((qh - mq4) & 0x80808080u);           /* bit 7: quality >= mq */
-          /* was read 0 walked: a quality that is neither 0 nor 63 (src/call_genotypes.c:198-211) */
+          cge += (uint32_t)__popc((qh - mq4) & 0x80808080u);
           if (k == 0) walked |= __any((q1 & 0x3e3e3e3eu) != 0u) != 0;
           if (act) d_st32(dp + o, w);
           if (PROF && pr.on && act) {
@@ -704,8 +712,15 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
         }
         if (k == 0 && walked) walked_mask |= 1ull << l;
       }
-#pragma unroll
-      for (uint32_t i = 0; i < R; i++) v[i] = vn[i];
+    };
+    /* two buffers in turn: no register is copied, so nothing waits for a round's loads before that round's turn */
+    uint32_t va[R], vb[R];
+    fetch(0, va);
+    for (uint32_t i0 = 0; i0 < n; i0 += 2u * R) { /* (n is even and so is R: reads past n are of kind 0) */
+      fetch(i0 + R, vb);
+      process(i0, va);
+      fetch(i0 + 2u * R, va);
+      if (i0 + R < n) process(i0 + R, vb);
     }
     if (lane < n && my_k == 0) tpl_out[my_ti].flags = BSC_TPL_WALK_KNOWN | (((walked_mask >> lane) & 1ull) ? BSC_TPL_WALKED0 : 0u);
   }

@@ -632,11 +632,11 @@ int bsc_prepare_templates_profile(const bsc_raw_template *raw, uint32_t nr, cons
  * bsc_prepare_templates ON THE DEVICE (round 5; csrc/prepdev.hip): the same bytes — prepared templates incl. their flags, prepared
  * reads in template order, the statistics — from device-resident inputs into device-resident outputs, ready for
  * bsc_accumulate_device / bsc_reads_chain_device without a host pass: one thread per template plans the trims, clips, the mate
- * overlap and the indel normalisation on the mismatch lists alone, a prefix sum places the reads, one wave per template writes
- * them.  d_raw (bsc_raw_template[nr], 8-byte aligned), d_seq, d_misms (bsc_misms[n_misms]); d_tpl_out (bsc_template[nr]) and
+ * overlap and the indel normalisation on the mismatch lists alone, a prefix sum places the reads, a wave per 64 reads writes
+ * them (a dword per lane).  d_raw (bsc_raw_template[nr], 8-byte aligned), d_seq, d_misms (bsc_misms[n_misms]); d_tpl_out (bsc_template[nr]) and
  * d_seq_out (seq_out_cap bytes: seq_bytes + the sizes of all BSC_MISMS_INS entries always suffice).  Queued on `stream`, then
  * waited for: *seq_out_used, *stats (may be NULL) and the verdict come back with the call — BSC_ERR_ARG where the host form
- * fails, naming the lowest offending template with the host form's own message.  Workspaces (48 bytes per read + the lists)
+ * fails, naming the lowest offending template with the host form's own message.  Workspaces (88 bytes per read + the lists)
  * stay with the context.  profile (may be NULL): the non-CpG read profile as bsc_prepare_templates_profile makes it — here
  * profile->ref is a DEVICE pointer to the codes of x .. x + n_ref - 1, counts / cap / used are the host's (counts[cap][4] receives
  * this call's counts, used grows, with the host form's clearing of what lies behind the old end).
