@@ -386,6 +386,9 @@ __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel_t(
     const uint32_t nvalid = p_last - p0 + 1u;
     constexpr unsigned ROW = SUMM ? SUM_DW : IN_DW;
     uint32_t *dst = cts + (uint64_t)wt * (64u * ROW);
+#ifdef ACC_EXPERIMENT_NOSTORE /* timing experiment: the walk without the tile image's way out */
+    if (wt == 0xffffffffu)
+#endif
     if (nvalid == 64u) {
       /* written once, read by another kernel much later: non-temporal, like the calling kernel's records (ACC_PLAIN_STORES:
        * the A/B build) */
