@@ -455,7 +455,7 @@ __device__ static __forceinline__ void d_prof_base(const bsc_prep_prof &F, uint3
     if ((((xx & m_after) | ((xx & m_before) >> 1)) >> 2) & 1u) {
       const uint32_t ix = (uint32_t)(orig + 1);
       if (ix < used_t && ix < F.cap) {
-        if (ix < PROF_LDS) atomicAdd(&s_prof[ix * 4u + (xx & 3u)], 1u);
+        if (ix < PROF_LDS) atomicAdd(&s_prof[(xx & 3u) * PROF_LDS + ix], 1u); /* [column][position]: neighbours in a read, neighbours in the banks */
         else atomicAdd(&F.table[(uint64_t)ix * 4u + (xx & 3u)], 1ull);
       }
     }
@@ -611,8 +611,11 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
         if (l_used > before && (unsigned long long)l_used + 1ull > F.cap) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_CAP);
         l_strand = tpl_out[my_ti].bs_strand;
         l_pos = tpl_out[my_ti].pos[my_k];
-        if (l_pos < F.x || (uint64_t)l_pos - F.x + ol + 1u > F.n_ref) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_RANGE);
-        l_strand |= 0x100u; /* "this read is profiled" */
+        const bool in_ref = l_pos >= F.x && (uint64_t)l_pos - F.x + ol + 1u <= F.n_ref;
+        if (!in_ref) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_RANGE);
+        /* "this read is profiled": inside the block's codes (else the call fails anyway), on a strand that has a profile
+         * (src/init_param.c:57-70: bs_strand 0 .. 2) */
+        if (in_ref && l_strand <= 2u) l_strand |= 0x100u;
       }
     }
     /* ---- what the walk needs of a read, made here once per lane so that the walk itself is short: every instruction of the
@@ -702,12 +705,44 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
           if (k == 0) walked |= __any((q1 & 0x3e3e3e3eu) != 0u) != 0;
           if (act) d_st32(dp + o, w);
           if (PROF && pr.on && act) {
+            /* the read profile (see d_prof_base): a base counts iff its quality is in [20, 63) and either it reads C / T (base
+             * code odd) over a reference C followed by A, C or T, or it reads A / G over a reference G preceded by A, G or T.  Four
+             * bases at a time: the reference codes before, at and behind them are three byte-shifted views of 8 code bytes */
+            const int64_t bq = pr.v0 + (int64_t)o - 1; /* index in F.ref of the code BEFORE this dword's first base */
+            if (bq >= 0 && bq + 8 <= (int64_t)F.n_ref) {
+              const uint32_t lo = d_ld32(F.ref + bq) & 0x07070707u, hi = d_ld32(F.ref + bq + 4) & 0x07070707u;
+              const uint32_t r_at = __builtin_amdgcn_alignbyte(hi, lo, 1u), r_next = __builtin_amdgcn_alignbyte(hi, lo, 2u);
+#define PROF_NE(x, c) ((((x) ^ ((c) * 0x01010101u)) + 0x7f7f7f7fu) & 0x80808080u) /* bit 7 of every byte: the code (< 8) is not c */
+              const uint32_t over_c = ~PROF_NE(r_at, 2u) & PROF_NE(r_next, 0u) & PROF_NE(r_next, 3u); /* C, then A / C / T */
+              const uint32_t over_g = ~PROF_NE(r_at, 3u) & PROF_NE(lo, 0u) & PROF_NE(lo, 2u);         /* G, after A / G / T */
+#undef PROF_NE
+              const uint32_t odd = (w & 0x01010101u) << 7;
+              const uint32_t qf = ((w >> 2) & 0x3f3f3f3fu) | 0x80808080u; /* 0x80 + quality (of ALL four bytes: w, not wc) */
+              const uint32_t q_ok = (qf - 20u * 0x01010101u) & ~((qf + 0x01010101u) << 1) & 0x80808080u; /* >= 20 and not 63 */
+              /* the bytes that are this lane's own (an overlapping last dword: not the low ones) */
+              uint32_t hits = ((odd & over_c) | (~odd & over_g)) & q_ok & (0x80808080u << (8u * (nominal - o)));
+              const uint32_t coltab = pr.strand == 0 ? 0xebu : (pr.strand == 1 ? 0x63u : 0xc9u); /* xx & 3 by base code, two bits each */
+              const uint32_t lim = pr.used_t < F.cap ? pr.used_t : F.cap; /* positions that are kept (wave-uniform) */
+              const int32_t ix0 = (k ? pr.pc - (int32_t)o : pr.pc + (int32_t)o) + 1, step = k ? -1 : 1;
+              if (__any(hits != 0u)) {
 #pragma unroll
-            for (uint32_t t = 0; t < 4u; t++)
-              if (t >= nominal - o) {
-                const uint32_t j = o + t;
-                d_prof_base(F, s_prof, pr.strand, pr.used_t, pr.v0 + j, k ? pr.pc - (int32_t)j : pr.pc + (int32_t)j, (w >> (8u * t)) & 0xffu);
+                for (uint32_t t = 0; t < 4u; t++) {
+                  const uint32_t ix = (uint32_t)(ix0 + step * (int32_t)t);
+                  if (((hits >> (8u * t + 7u)) & 1u) && ix < lim) {
+                    const uint32_t col = (coltab >> (2u * ((w >> (8u * t)) & 3u))) & 3u;
+                    if (ix < PROF_LDS) atomicAdd(&s_prof[col * PROF_LDS + ix], 1u);
+                    else atomicAdd(&F.table[(uint64_t)ix * 4u + col], 1ull);
+                  }
+                }
               }
+            } else { /* at the block's first position or its last few: base by base */
+#pragma unroll
+              for (uint32_t t = 0; t < 4u; t++)
+                if (t >= nominal - o) {
+                  const uint32_t j = o + t;
+                  d_prof_base(F, s_prof, pr.strand, pr.used_t, pr.v0 + j, k ? pr.pc - (int32_t)j : pr.pc + (int32_t)j, (w >> (8u * t)) & 0xffu);
+                }
+            }
           }
         }
         if (k == 0 && walked) walked_mask |= 1ull << l;
@@ -727,7 +762,7 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
   if (PROF) {
     __syncthreads();
     for (unsigned i = threadIdx.x; i < PROF_LDS * 4u; i += 64 * PREP_WAVES)
-      if (s_prof[i] && i / 4u < F.cap) atomicAdd(&F.table[i], (unsigned long long)s_prof[i]);
+      if (s_prof[i] && i % PROF_LDS < F.cap) atomicAdd(&F.table[(uint64_t)(i % PROF_LDS) * 4u + i / PROF_LDS], (unsigned long long)s_prof[i]);
   }
   unsigned long long w[5] = {l_total, c63, cge, l_reads, l_bases};
   for (int i = 0; i < 5; i++)

@@ -27,6 +27,7 @@ ap.add_argument("--sites", type=int, default=50_000_000)
 ap.add_argument("--coverage", type=int, default=30)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--indel-every", type=int, default=50)
+ap.add_argument("--profile", action="store_true", help="with the non-CpG read profile (the form the pipeline runs)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 tpl, seq, y = R.synth_block(88172645463325252 + 2, 1000, args.sites, args.coverage)
@@ -52,16 +53,27 @@ with B.SiteCaller() as c:
     d_tpl = torch.empty(len(raw) * TEMPLATE.itemsize, dtype=torch.uint8, device=dev)
     d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
     used, st = C.c_uint64(0), np.zeros(1, dtype=PREP_STATS)
+    pf = None
+    if args.profile:  # the block's reference codes (x .. y + 2) on the device, the counts on the host
+        from bs_call_amd import _lib
+        from bs_call_amd.caller import ReadProfile
+
+        x = max(1, int(min(int(raw["pos"][0, 0]) or 1 << 30, int(raw["pos"][0, 1]) or 1 << 30)) - 2)
+        y = int((raw["pos"].astype(np.int64) + raw["reference_span"]).max()) + 2
+        d_ref = up(B.synth_ref_host(7, x, y - x + 3))
+        prof = ReadProfile(cap=4096)
+        pf = _lib.ReadProfile(d_ref.data_ptr(), x, y - x + 3, prof.counts.ctypes.data, prof.counts.shape[0], 0)
     wall = []
     for it in range(2 + args.steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         rc = c._L.bsc_prepare_templates_device(c._h, d_raw.data_ptr(), len(raw), d_seq.data_ptr(), seq.size, d_ms.data_ptr(), len(ms), _ptr(par),
-                                               d_tpl.data_ptr(), d_out.data_ptr(), cap, C.byref(used), _ptr(st), None, None)
+                                               d_tpl.data_ptr(), d_out.data_ptr(), cap, C.byref(used), _ptr(st), None if pf is None else C.byref(pf), None)
         assert rc == 0, c._L.bsc_last_error()
         if it >= 2:
             wall.append(time.perf_counter() - t0)
     w = float(np.median(wall))
+    res["read_profile"] = bool(args.profile)
     res.update(wall_ms=w * 1e3, templates_per_s=len(raw) / w, bases_per_s=seq.size / w, positions_per_s=args.sites / w,
                bytes_in_plus_out=int(seq.size + used.value + len(raw) * (72 + 40) + len(ms) * 12),
                GBps=(seq.size + used.value + len(raw) * 112 + len(ms) * 12) / w / 1e9, prepared_bytes=int(used.value))
