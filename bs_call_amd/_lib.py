@@ -71,6 +71,7 @@ EXPORTS = (
     "bsc_bam_header_text",
     "bsc_bam_next_block",
     "bsc_bam_filter_counts",
+    "bsc_bam_malformed",
     "bsc_chain_window_quantum",
     "bsc_chain_window_size",
     "bsc_prepare_templates",
@@ -328,6 +329,8 @@ def load():
     L.bsc_bam_next_block.argtypes = [vp, C.POINTER(ReaderParams), C.POINTER(ReadBlock)]
     L.bsc_bam_filter_counts.restype = None
     L.bsc_bam_filter_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.bsc_bam_malformed.restype = C.c_uint64
+    L.bsc_bam_malformed.argtypes = [vp]
     L.bsc_bcf_block.restype = C.c_long
     L.bsc_bcf_block.argtypes = [vp, u64, i32, C.POINTER(BcfIds), vp, vp, C.c_size_t, C.POINTER(u64)]
     L.bsc_report_json.restype = C.c_long

@@ -63,6 +63,10 @@ class BamReader:
         self._L.bsc_bam_filter_counts(self._h, cts, bases)
         return list(cts), list(bases)
 
+    def malformed(self):
+        """BAM records dropped because their CIGAR does not cover l_seq query bases (bsc_bam_malformed)."""
+        return int(self._L.bsc_bam_malformed(self._h))
+
 
 def fasta_contig(path, name, length_hint=0):
     """One contig of a FASTA file (plain / gzip / bgzip) as reference codes 0 = N, 1..4 = ACGT (bsc_fasta_contig)."""

@@ -316,6 +316,7 @@ struct bsc_bam {
   name_node *bucket[NAME_BUCKETS];
   int finished;
   uint64_t filter_cts[15], filter_bases[15];
+  uint64_t malformed; /* BAM records dropped because their CIGAR does not cover l_seq query bases */
 };
 
 static uint32_t name_hash(const char *s, uint32_t n) {
@@ -532,6 +533,8 @@ void bsc_bam_filter_counts(const bsc_bam *b, uint64_t cts[15], uint64_t bases[15
   if (cts) memcpy(cts, b->filter_cts, sizeof b->filter_cts);
   if (bases) memcpy(bases, b->filter_bases, sizeof b->filter_bases);
 }
+
+uint64_t bsc_bam_malformed(const bsc_bam *b) { return b ? b->malformed : 0; }
 
 /* ---- byte stream under the parsers: BGZF, or the plain file for uncompressed SAM text ------------------------------ */
 static int in_read(bsc_bam *b, void *dst, size_t n) { /* 1, 0 = clean end of input, < 0 = error */
@@ -984,7 +987,8 @@ static int next_record(bsc_bam *b, const bsc_reader_params *par, bam_rec *r, int
       if (b->is_sam)
         return bsc_set_error(BSC_ERR_ARG, "read '%.*s': CIGAR covers %llu query bases, the sequence has %u", (int)l_name, r->name,
                              (unsigned long long)qlen, l_seq), -2;
-      return 2; /* like a record outside the region: it does not exist for the reader */
+      b->malformed++; /* counted apart (bsc_bam_malformed): damaged input must not change the coverage unseen */
+      return 2;       /* like a record outside the region: it does not exist for the reader */
     }
   }
   if (par->region_stop) { /* an index query hands over the records that overlap the region: the others do not exist for the reader */

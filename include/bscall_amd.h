@@ -721,6 +721,10 @@ uint32_t bsc_bam_ref_len(const bsc_bam *b, int i);
 const char *bsc_bam_header_text(const bsc_bam *b);
 int bsc_bam_next_block(bsc_bam *b, const bsc_reader_params *par, bsc_read_block *blk);
 void bsc_bam_filter_counts(const bsc_bam *b, uint64_t cts[15], uint64_t bases[15]);
+/* BAM records the reader dropped because their CIGAR does not cover l_seq query bases (htslib hands such a record over as it
+ * is and the reference walks outside the read; SAM text with the same defect is an error, as in htslib's parser): not part of
+ * the reference's counters — a caller should tell its user when this is not 0 (integration/bam2bcf.c does) */
+uint64_t bsc_bam_malformed(const bsc_bam *b);
 
 /*
  * dbSNP index (host C + zlib; csrc/dbsnp.c): the reader of the compressed index bin/dbSNP_idx writes.  In the reference

@@ -241,6 +241,9 @@ int main(int argc, char **argv) {
   rep.min_qual = 20;
   rep.day = 1, rep.month = 1, rep.year = 2000; /* a fixed date: reproducible output */
   bsc_bam_filter_counts(bam, rep.filter_cts, rep.filter_bases);
+  if (bsc_bam_malformed(bam))
+    fprintf(stderr, "bam2bcf: warning: %llu BAM records dropped, their CIGAR does not cover the sequence (damaged input?)\n",
+            (unsigned long long)bsc_bam_malformed(bam));
   rep.filter_cts[0] += passed_reads;
   rep.filter_bases[0] += passed_bases;
   memcpy(rep.base_filter, base_filter, sizeof base_filter);

@@ -233,8 +233,15 @@ def test_cigar_that_disagrees_with_the_sequence_length(tmp_path):
     p = str(tmp_path / "x.bam")
     W.write_bam(p, REFS, [good[0], bad, good[1]])
     blocks, cts, _ = c_blocks(p)
+    with BamReader(p, threads=THREADS[0]) as r:  # ... but not unseen: the reader counts what it dropped
+        assert r.malformed() == 0
+        list(r.blocks())
+        assert r.malformed() == 1
     W.write_bam(p, REFS, good)
     assert (blocks, cts) == c_blocks(p)[:2]  # as if the record were not there
+    with BamReader(p, threads=THREADS[0]) as r:
+        list(r.blocks())
+        assert r.malformed() == 0
     sam = str(tmp_path / "x.sam")
     W.write_sam(sam, REFS, [good[0], bad, good[1]])
     with pytest.raises(BscError, match="CIGAR covers 14 query bases"):
