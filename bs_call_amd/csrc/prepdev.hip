@@ -692,7 +692,8 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
           const uint32_t o = nominal < len - 4u ? nominal : len - 4u;
           uint32_t w = v[i];
           if (base) w = act ? d_ld32((const uint8_t *)desc + d_bcast64(l_src, l) + o) : 0u;
-          if (ml > base) { /* the left trim's mark: quality 63 on bytes below ml */
+          if (ml + 3u > base) { /* the left trim's mark: quality 63 on bytes below ml (a last, overlapping dword reaches up to
+                                   three bytes back into the round before: they must be stored as that round marked them) */
             const uint32_t nmk = act && ml > o ? (ml - o < 4u ? ml - o : 4u) : 0u;
             const uint32_t mm = nmk >= 4u ? 0xffffffffu : (1u << (8u * nmk)) - 1u;
             w = (w & ~mm) | (((w & 0x03030303u) | 0xfcfcfcfcu) & mm);

@@ -89,6 +89,55 @@ def test_random_alignments_device_equals_host(caller):
     assert n_err < 125  # most lists are valid
 
 
+def test_tiny_long_and_oddly_placed_reads(caller):
+    """The copy kernel moves a plain read as dwords — lane l bytes 4l .. 4l + 3, the last lane the read's last four bytes over its
+    neighbour's, 256 bytes a round — and sends what does not fit that (shorter than four bytes, a right trim, a mark more than 255
+    bytes in) the long way: lengths around every one of those limits, every quality incl. 0 and 63, fixed trims short and long
+    (beyond the read's middle, beyond the read), single ends, empty reads, overlapping mates of equal span (the mean-quality tie),
+    output offsets of every alignment; with the read profile too."""
+    from bs_call_amd.caller import ReadProfile
+
+    rng = np.random.default_rng(777)
+    lens = [1, 2, 3, 4, 5, 6, 7, 8, 9, 31, 63, 64, 65, 127, 128, 129, 252, 253, 254, 255, 256, 257, 258, 259, 260, 300, 511, 512, 513, 514, 700, 1023, 1025]
+    for trial in range(24):
+        ts, p0 = [], 400
+        for i in range(int(rng.integers(20, 140))):
+            n0, n1 = int(rng.choice(lens)), int(rng.choice(lens))
+            qmode = rng.random()
+            mk = lambda n: [int(rng.integers(0, 4)) | ((63 if qmode < 0.1 else (0 if qmode < 0.2 else int(rng.integers(0, 64)))) << 2) for _ in range(n)]
+            p0 += int(rng.integers(0, 40))
+            kind = rng.random()
+            if kind < 0.2:
+                t = T.tpl((p0, 0), (n0, 0), (mk(n0), None))
+            elif kind < 0.3:
+                t = T.tpl((0, p0), (0, n1), (None, mk(n1)))
+            elif kind < 0.5:  # overlapping mates, often of equal span
+                n1 = n0 if rng.random() < 0.6 else n1
+                t = T.tpl((p0, p0 + int(rng.integers(0, n0 + 1))), (n0, n1), (mk(n0), mk(n1)))
+            else:
+                t = T.tpl((p0, p0 + n0 + int(rng.integers(1, 50))), (n0, n1), (mk(n0), mk(n1)))
+            t["orientation"] = int(rng.integers(0, 2))
+            t["bs_strand"] = int(rng.integers(0, 3))
+            ts.append(t)
+        lt = tuple(int(v) for v in rng.choice([0, 1, 3, 5, 100, 254, 255, 256, 257, 300, 2000], 2))
+        rt = tuple(int(v) for v in rng.choice([0, 0, 0, 1, 4, 130, 600], 2))
+        kw = dict(left_trim=lt, right_trim=rt, min_qual=int(rng.choice([0, 1, 20, 63, 64, 70])))
+        got = _both(caller, ts, **kw)
+        assert got is not None
+        # the read profile over the same templates (reads at the block's first position in every third trial)
+        raw, seq, ms = T.to_arrays(ts)
+        h_tpl = got[0]
+        pos = [int(p) for p in h_tpl["pos"].ravel() if p]
+        x = max(1, min(pos) - (0 if trial % 3 == 0 else 2))
+        y = int((h_tpl["pos"].astype(np.int64) + h_tpl["len"]).max()) + 3
+        ref = rng.integers(0, 5, size=y - x + 3).astype(np.uint8)
+        pf_h, pf_d = ReadProfile(cap=4096), ReadProfile(cap=4096)
+        prepare_templates(raw, seq, ms, profile=pf_h, x=x, ref=ref, **kw)
+        d_tpl, d_seq, d_st = caller.prepare_templates_device(raw, seq, ms, profile=pf_d, x=x, ref=ref, **kw)
+        assert d_seq.tobytes() == got[1].tobytes() and d_tpl.tobytes() == got[0].tobytes() and d_st.tobytes() == got[2].tobytes()
+        assert pf_d.used == pf_h.used and pf_d.counts[: pf_d.used].tobytes() == pf_h.counts[: pf_h.used].tobytes(), trial
+
+
 def test_device_equals_python_restatement(caller):
     rng = np.random.default_rng(99)
     done = 0
