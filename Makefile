@@ -46,6 +46,10 @@ $(LIBDIR)/prepdev.o: $(CSRC)/prepdev.hip include/bscall_amd.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(LIBDIR)/bcfdev.o: $(CSRC)/bcfdev.hip include/bscall_amd.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(LIBDIR)/probe.o: $(CSRC)/probe.hip
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -86,7 +90,7 @@ $(LIBDIR)/synth_reads.o: $(CSRC)/synth_reads.c include/bscall_amd.h $(CSRC)/synt
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/prepdev.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o $(LIBDIR)/dbsnp.o $(LIBDIR)/prep.o $(LIBDIR)/report.o $(LIBDIR)/bcf.o $(LIBDIR)/bamio.o $(LIBDIR)/refseq.o
+$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/prepdev.o $(LIBDIR)/bcfdev.o $(LIBDIR)/bscall_api.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o $(LIBDIR)/dbsnp.o $(LIBDIR)/prep.o $(LIBDIR)/report.o $(LIBDIR)/bcf.o $(LIBDIR)/bamio.o $(LIBDIR)/refseq.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lz -lpthread
 
 oracle:
@@ -100,7 +104,7 @@ HOST_C = bscall_api synth_reads vcf_format dbsnp prep report bcf bamio refseq
 san: $(LIBDIR)/libbscall_amd.so
 	@mkdir -p $(LIBDIR)/san
 	for f in $(HOST_C); do $(CC) $(SANFLAGS) -c $(CSRC)/$$f.c -o $(LIBDIR)/san/$$f.o || exit 1; done
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/san/libbscall_amd_san.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/prepdev.o $(addprefix $(LIBDIR)/san/,$(addsuffix .o,$(HOST_C))) -L$(dir $(shell $(CC) -print-file-name=libasan.so)) -lasan -lubsan -lm -lz -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/san/libbscall_amd_san.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/prepdev.o $(LIBDIR)/bcfdev.o $(addprefix $(LIBDIR)/san/,$(addsuffix .o,$(HOST_C))) -L$(dir $(shell $(CC) -print-file-name=libasan.so)) -lasan -lubsan -lm -lz -lpthread
 
 # a plain-C host program against the C ABI: gcc only, links the shared library like bs_call would
 demo: $(LIBDIR)/demo_block $(LIBDIR)/bam2bcf

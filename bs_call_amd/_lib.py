@@ -60,6 +60,10 @@ EXPORTS = (
     "bsc_bcf_default_ids",
     "bsc_bcf_record",
     "bsc_bcf_block",
+    "bsc_bcf_block_device",
+    "bsc_block_bcf",
+    "bsc_block_bcf_raw",
+    "bsc_dbsnp_names",
     "bsc_fasta_contig",
     "bsc_block_reference",
     "bsc_bam_open",
@@ -166,6 +170,12 @@ class ReadBlock(C.Structure):
 class BcfIds(C.Structure):
     _fields_ = [(f, C.c_int32) for f in ("pass_", "fail", "mac1", "info_cx", "fmt_gt", "fmt_ft", "fmt_gl", "fmt_gq", "fmt_dp",
                                           "fmt_mq", "fmt_qd", "fmt_mc8", "fmt_amq", "fmt_cs", "fmt_cg", "fmt_cx", "fmt_fs")]
+
+
+class BcfNames(C.Structure):
+    """bsc_bcf_names: the dbSNP names of a block's flagged positions (host arrays)."""
+
+    _fields_ = [("pos", C.c_void_p), ("off", C.c_void_p), ("bytes", C.c_void_p), ("n", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -353,6 +363,15 @@ def load():
     L.bsc_prepare_templates_device.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, vp, vp, u64, vp, vp, vp, vp]
     L.bsc_block_records_raw.restype = i32
     L.bsc_block_records_raw.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, u32, u32, vp, vp, vp, i32, vp, u64, vp, vp, vp]
+    L.bsc_block_bcf.restype = i32
+    L.bsc_block_bcf.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, vp, i32, i32, C.POINTER(BcfIds), vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.bsc_block_bcf_raw.restype = i32
+    L.bsc_block_bcf_raw.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, u32, u32, vp, vp, vp, i32, i32, C.POINTER(BcfIds), vp, vp, u64,
+                                    C.POINTER(u64), C.POINTER(u64), vp, vp]
+    L.bsc_bcf_block_device.restype = i32
+    L.bsc_bcf_block_device.argtypes = [vp, vp, vp, u64, i32, C.POINTER(BcfIds), vp, vp, u64, vp, vp]
+    L.bsc_dbsnp_names.restype = i32
+    L.bsc_dbsnp_names.argtypes = [vp, u32, u32, vp, vp, vp, u32, u64, C.POINTER(u32), C.POINTER(u64)]
     L.bsc_template_walk_flags.restype = u32
     L.bsc_template_walk_flags.argtypes = [vp, u32]
     L.bsc_dbsnp_open.restype = i32

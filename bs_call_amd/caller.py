@@ -380,6 +380,111 @@ class SiteCaller:
             profile.used = int(pf.used)
         return out[: cnt.value], st[0]
 
+    # -- reads in, the block's BCF stream out (encoded on the device, csrc/bcfdev.hip) ---------------------------------------
+    @staticmethod
+    def _bcf_names(names):
+        """names: None, or (pos uint32[n] ascending, off uint32[n + 1], bytes) as DbSnpIndex.names gives them -> (struct, keep-alive)."""
+        if names is None:
+            return None, None
+        pos = np.ascontiguousarray(names[0], dtype=np.uint32)
+        off = np.ascontiguousarray(names[1], dtype=np.uint32)
+        by = np.frombuffer(bytes(names[2]) + b"\0", dtype=np.uint8)
+        if len(off) != len(pos) + 1:
+            raise ValueError("names: off must have one entry more than pos")
+        st = _lib.BcfNames(pos.ctypes.data, off.ctypes.data, by.ctypes.data, len(pos))
+        return st, (pos, off, by)
+
+    def block_bcf(self, templates, seq, x, y, ref, rid, names=None, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None,
+                  with_stats=False, cap=None, ids=None):
+        """bsc_block_bcf: block_records with the BCF encoder behind the packing, on the device.  Returns (bytes, n_records)."""
+        templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        n = int(y) - int(x) + 1
+        if len(ref) != n + 2:
+            raise ValueError("ref must have y - x + 3 entries (x .. y + 2)")
+        db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+        if db is not None and len(db) != n:
+            raise ValueError("dbsnp must have y - x + 1 entries")
+        if ids is None:
+            ids = _lib.BcfIds()
+            self._L.bsc_bcf_default_ids(C.byref(ids))
+        nm, keep = self._bcf_names(names)
+        cap_given = cap
+        cap = 64 + 192 * n if cap is None else int(cap)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        nb, nr = C.c_uint64(0), C.c_uint64(0)
+
+        def go(stats):
+            return self._L.bsc_block_bcf(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref), None if db is None else _ptr(db),
+                                         C.byref(p), stats, rid, C.byref(ids), None if nm is None else C.addressof(nm), _ptr(out), cap, C.byref(nb),
+                                         C.byref(nr))
+
+        rc = go(1 if with_stats else 0)
+        if rc == -1 and nb.value > cap and cap_given is None:  # longer records than the default room: once more, the statistics are in already
+            cap = int(nb.value)
+            out = np.empty(cap, dtype=np.uint8)
+            rc = go(0)
+        _check(rc)
+        del keep
+        return out[: nb.value].tobytes(), nr.value
+
+    def block_bcf_raw(self, raw, seq, misms, x, y, ref, rid, names=None, left_trim=(0, 0), right_trim=(0, 0), min_qual=20, all_positions=False,
+                      reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False, cap=None, profile=None, ids=None):
+        """bsc_block_bcf_raw: what the reader delivers in, the block's BCF bytes out; pre-processing, calling, record formation and the
+        encoding all on the device.  Returns (bytes, n_records, PREP_STATS record)."""
+        from .abi import MISMS, PREP_PARAMS, PREP_STATS, RAW_TEMPLATE
+
+        raw = np.ascontiguousarray(raw, dtype=RAW_TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        misms = np.ascontiguousarray(misms, dtype=MISMS)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        n = int(y) - int(x) + 1
+        if len(ref) != n + 2:
+            raise ValueError("ref must have y - x + 3 entries (x .. y + 2)")
+        db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+        if ids is None:
+            ids = _lib.BcfIds()
+            self._L.bsc_bcf_default_ids(C.byref(ids))
+        nm, keep = self._bcf_names(names)
+        cap_given = cap
+        cap = 64 + 192 * n if cap is None else int(cap)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        par = np.zeros(1, dtype=PREP_PARAMS)
+        par["left_trim"][0], par["right_trim"][0], par["min_qual"][0] = left_trim, right_trim, min_qual
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        nb, nr = C.c_uint64(0), C.c_uint64(0)
+        st = np.zeros(1, dtype=PREP_STATS)
+        pf = None if profile is None else _lib.ReadProfile(None, 0, 0, profile.counts.ctypes.data, profile.counts.shape[0], profile.used)
+
+        def go(stats, st_, pf_):
+            return self._L.bsc_block_bcf_raw(self._h, _ptr(raw), len(raw), _ptr(seq), seq.size, _ptr(misms), len(misms), _ptr(par), x, y, _ptr(ref),
+                                             None if db is None else _ptr(db), C.byref(p), stats, rid, C.byref(ids),
+                                             None if nm is None else C.addressof(nm), _ptr(out), cap, C.byref(nb), C.byref(nr), _ptr(st_),
+                                             None if pf_ is None else C.byref(pf_))
+
+        rc = go(1 if with_stats else 0, st, pf)
+        if rc == -1 and nb.value > cap and cap_given is None:  # as block_bcf; the first pass has counted the bases and the profile too
+            cap = int(nb.value)
+            out = np.empty(cap, dtype=np.uint8)
+            rc = go(0, np.zeros(1, dtype=PREP_STATS), None)
+        _check(rc)
+        del keep
+        if pf is not None:
+            profile.used = int(pf.used)
+        return out[: nb.value].tobytes(), nr.value, st[0]
+
+    def bcf_block_device(self, d_recs, d_n_recs, max_recs, rid, d_out, out_cap, d_totals, names=None, ids=None, stream=None):
+        """bsc_bcf_block_device: packed records in HBM -> their BCF stream in HBM (asynchronous on `stream`)."""
+        if ids is None:
+            ids = _lib.BcfIds()
+            self._L.bsc_bcf_default_ids(C.byref(ids))
+        nm, keep = self._bcf_names(names)
+        _check(self._L.bsc_bcf_block_device(self._h, d_recs, d_n_recs, max_recs, rid, C.byref(ids), None if nm is None else C.addressof(nm), d_out,
+                                            out_cap, d_totals, stream))
+        del keep
+
     def blocks_records(self, blocks, ref, out=None, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False,
                        submit_only=False):
         """Several blocks in one launch sequence (bsc_blocks_records): blocks = [(templates, seq, x, y), ...] in genome order;

@@ -1,0 +1,407 @@
+/*
+ * bcfdev.hip — the tail of row f-1 on the device: a block's packed written records (bsc_vcf_rec, compact.hip) as the BCF2
+ * records bcf_write() emits for them — the typed values _print_vcf_entry encodes with htslib's bcf_enc_* (src/print_vcf.c:160-222
+ * the shared block, :267-378 the per-sample block) behind bcf_write's 32 bytes of fixed fields.  The host form is csrc/bcf.c
+ * (bsc_bcf_record / bsc_bcf_block: the checker of this file, statement for statement the same rules — see its header for the
+ * BCF2 typed-value rules and the dictionary indices); what crosses PCIe is the stream the output thread writes, ~113 bytes per
+ * written record instead of 128, and no host core touches a record.
+ *
+ *   bsc_bcf_size_kernel    one wave per tile of 64 records: every lane the length of its record (the emitter below over a sink
+ *                          that only counts), the tile's sum -> tile_bytes[tile] (u64); records beyond *n_recs count 0
+ *   (exclusive scan of the tile sums, rocPRIM u64: sort.hip; one more entry behind the last tile = the stream's length)
+ *   bsc_bcf_write_kernel   one wave per tile: lane offsets from a wave prefix sum, every lane writes its record into the wave's LDS
+ *                          image of the tile's span of the stream (byte stores; the image starts at the span's phase within 16
+ *                          bytes), then the wave copies the image out — whole 16-byte chunks as one dwordx4 store per lane, the ragged
+ *                          head and tail byte by byte (the neighbouring tiles own the other bytes of those chunks).  A tile whose
+ *                          span does not fit the image (> 64 x 160 bytes: long IDs, wide dictionary indices) goes out in two halves.
+ *
+ * Names: the dbSNP name of a record whose rs_found flag is set comes from a table of the block's flagged positions (sorted
+ * positions, offsets, bytes: bsc_dbsnp_names on the host, uploaded with the block) by binary search; a flagged record the table
+ * does not list has no ID, as in bsc_bcf_block when bsc_dbsnp_name finds nothing.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bscall_amd.h"
+
+static_assert(sizeof(bsc_vcf_rec) == 128, "bsc_vcf_rec is 128 bytes");
+
+enum { BT_INT8 = 1, BT_INT16 = 2, BT_INT32 = 3, BT_FLOAT = 5, BT_CHAR = 7 };
+#define BCF_ID_MAX 63u        /* bsc_bcf_block's rs[64] */
+#define BCF_REC_MAX 336u      /* 32 + shared (3 + 63 + 2 + 4 + 5 + 5 + 6) + per-sample (13 keys x 5 + 136): an upper bound of one record */
+#define BCF_IMG_BYTES 10752u  /* the wave's image: 32 records of the longest kind (10 752 = 32 x 336), or 64 ordinary ones */
+#define BCF_WAVES 4u
+
+struct bcf_args {
+  const uint8_t *recs;                /* bsc_vcf_rec[] */
+  const unsigned long long *n_recs;   /* device: how many of them */
+  uint64_t max_recs;                  /* never more than this (the array's size) */
+  int32_t rid;
+  bsc_bcf_ids ids;
+  const uint32_t *name_pos;           /* n_names sorted 1-based positions, or NULL */
+  const uint32_t *name_off;           /* n_names + 1 offsets into name_bytes */
+  const uint8_t *name_bytes;
+  uint32_t n_names;
+};
+
+/* ---- sinks: the emitter runs over one that counts and one that writes ---- */
+struct count_sink {
+  unsigned len;
+  __device__ __forceinline__ void u8(unsigned) { len++; }
+  __device__ __forceinline__ void le(uint32_t, unsigned bytes) { len += bytes; }
+  __device__ __forceinline__ void skip(unsigned bytes) { len += bytes; }
+};
+struct lds_sink {
+  uint8_t *p;
+  unsigned len;
+  __device__ __forceinline__ void u8(unsigned v) { p[len++] = (uint8_t)v; }
+  __device__ __forceinline__ void le(uint32_t v, unsigned bytes) {
+    for (unsigned k = 0; k < bytes; k++) p[len++] = (uint8_t)(v >> (8u * k));
+  }
+  __device__ __forceinline__ void skip(unsigned bytes) { len += bytes; }
+};
+
+__device__ __forceinline__ int int_type(int32_t lo, int32_t hi) {
+  if (hi <= 127 && lo >= -120) return BT_INT8;
+  if (hi <= 32767 && lo >= -32760) return BT_INT16;
+  return BT_INT32;
+}
+__device__ __forceinline__ unsigned type_bytes(int t) { return t == BT_INT8 ? 1u : (t == BT_INT16 ? 2u : 4u); }
+
+template <class S>
+__device__ __forceinline__ void put_int(S &s, int32_t v) { /* a typed single integer */
+  const int t = int_type(v, v);
+  s.u8(1u << 4 | (unsigned)t);
+  s.le((uint32_t)v, type_bytes(t));
+}
+template <class S>
+__device__ __forceinline__ void put_descriptor(S &s, uint32_t n, int type) {
+  if (n >= 15u) {
+    s.u8(15u << 4 | (unsigned)type);
+    put_int(s, (int32_t)n);
+  } else
+    s.u8(n << 4 | (unsigned)type);
+}
+
+/* the record's fields as the emitter reads them: one 128-byte record in eight 16-byte loads */
+struct rec_regs {
+  uint32_t w[32];
+  __device__ __forceinline__ uint8_t byte(unsigned o) const { return (uint8_t)(w[o >> 2] >> (8u * (o & 3u))); }
+};
+
+/* Everything behind the 32 fixed bytes, in the reference's order; returns l_shared (the per-sample block follows it in the sink).
+ * id / id_len: the record's name (global memory).  bad: set for a record bsc_bcf_record refuses (gt > 9, n_gl > 6). */
+template <class S>
+__device__ __forceinline__ unsigned bcf_emit_body(S &s, const rec_regs &r, const bcf_args &a, const uint8_t *id, unsigned id_len, bool &bad) {
+  const unsigned gt_raw = r.byte(5), n_gl_raw = r.byte(10);
+  bad = gt_raw > 9u || n_gl_raw > 6u;
+  const unsigned gt = gt_raw > 9u ? 9u : gt_raw, n_gl = n_gl_raw > 6u ? 6u : n_gl_raw;
+  const unsigned flt = r.byte(8), phred = r.byte(9), gt_enc = r.byte(7);
+  const unsigned alt0 = r.byte(12), alt1 = r.byte(13);
+  const bool het = (0x16Eu >> gt) & 1u; /* gt_het {0,1,1,1,0,1,1,0,1,0} (src/init_param.c:16) */
+  const unsigned s0 = s.len;
+  /* ---- shared: ID, REF, ALT, FILTER, INFO CX (:165-221) ---- */
+  put_descriptor(s, id_len, BT_CHAR);
+  for (unsigned k = 0; k < id_len; k++) s.u8(id[k]);
+  s.u8(1u << 4 | BT_CHAR);
+  s.u8(r.byte(16)); /* REF = cx_ref[2] */
+  if (alt0) {
+    s.u8(1u << 4 | BT_CHAR);
+    s.u8(alt0);
+    if (alt1) {
+      s.u8(1u << 4 | BT_CHAR);
+      s.u8(alt1);
+    }
+  }
+  put_int(s, flt == 0u ? a.ids.pass : ((flt & 128u) ? a.ids.mac1 : a.ids.fail));
+  put_int(s, a.ids.info_cx);
+  s.u8(5u << 4 | BT_CHAR);
+#pragma unroll
+  for (unsigned k = 0; k < 5u; k++) s.u8(r.byte(14u + k));
+  const unsigned l_shared = s.len - s0;
+  /* ---- per sample: GT FT DP MQ GQ QD GL MC8 [AMQ] CS CG CX [FS] (:267-378) ---- */
+  put_int(s, a.ids.fmt_gt);
+  s.u8(2u << 4 | BT_INT8); /* two allele codes below 16 */
+  s.u8(gt_enc >> 4);
+  s.u8(gt_enc & 15u);
+  put_int(s, a.ids.fmt_ft);
+  if (flt & 15u) { /* each name WITH its terminator, ';' between (:283-296): "q20\0;qd2\0" */
+    const unsigned nf = (unsigned)__popc(flt & 15u);
+    const unsigned ft_len = ((flt & 1u) ? 4u : 0u) + ((flt & 2u) ? 4u : 0u) + ((flt & 4u) ? 5u : 0u) + ((flt & 8u) ? 5u : 0u) + nf - 1u;
+    put_descriptor(s, ft_len, BT_CHAR);
+    bool first = true;
+#define FT_NAME(bit, c0, c1, c2, c3, n) \
+  if (flt & (bit)) {                    \
+    if (!first) s.u8(';');              \
+    first = false;                      \
+    s.u8(c0); s.u8(c1); s.u8(c2);       \
+    if ((n) == 4) s.u8(c3);             \
+    s.u8(0);                            \
+  }
+    FT_NAME(1u, 'q', '2', '0', 0, 3)
+    FT_NAME(2u, 'q', 'd', '2', 0, 3)
+    FT_NAME(4u, 'f', 's', '6', '0', 4)
+    FT_NAME(8u, 'm', 'q', '4', '0', 4)
+#undef FT_NAME
+  } else {
+    s.u8(4u << 4 | BT_CHAR);
+    s.u8('P'); s.u8('A'); s.u8('S'); s.u8('S');
+  }
+  put_int(s, a.ids.fmt_dp);
+  put_int(s, (int32_t)r.w[8]);  /* dp */
+  put_int(s, a.ids.fmt_mq);
+  put_int(s, (int32_t)r.w[26]); /* mq */
+  put_int(s, a.ids.fmt_gq);
+  put_int(s, (int32_t)phred);
+  put_int(s, a.ids.fmt_qd);
+  put_int(s, (int32_t)r.w[7]);  /* qd */
+  put_int(s, a.ids.fmt_gl);
+  s.u8(n_gl << 4 | BT_FLOAT);
+#pragma unroll
+  for (unsigned k = 0; k < 6u; k++)
+    if (k < n_gl) s.le(r.w[9u + k], 4u);
+  put_int(s, a.ids.fmt_mc8);
+  {
+    int32_t lo = (int32_t)r.w[16], hi = lo;
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+      const int32_t v = (int32_t)r.w[16 + k];
+      lo = v < lo ? v : lo;
+      hi = v > hi ? v : hi;
+    }
+    const int t = int_type(lo, hi);
+    s.u8(8u << 4 | (unsigned)t);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s.le(r.w[16 + k], type_bytes(t));
+  }
+  {
+    unsigned n_amq = 0;
+    int32_t lo = 255, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (r.w[16 + k] > 0u) {
+        const int32_t q = (int32_t)r.byte(96u + (unsigned)k);
+        n_amq++;
+        lo = q < lo ? q : lo;
+        hi = q > hi ? q : hi;
+      }
+    if (n_amq) {
+      put_int(s, a.ids.fmt_amq);
+      const int t = int_type(lo, hi);
+      s.u8(n_amq << 4 | (unsigned)t); /* one element: put_int's descriptor is the same byte */
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (r.w[16 + k] > 0u) s.le(r.byte(96u + (unsigned)k), type_bytes(t));
+    }
+  }
+  put_int(s, a.ids.fmt_cs);
+  { /* cs_str {"NA","+","-","NA","+","+-","+","-","-","NA"} (src/print_vcf.c:58-59) */
+    const bool na = (0x209u >> gt) & 1u, plus = (0x72u >> gt) & 1u, minus = (0x1A4u >> gt) & 1u;
+    if (na) {
+      s.u8(2u << 4 | BT_CHAR);
+      s.u8('N'); s.u8('A');
+    } else {
+      s.u8(((plus ? 1u : 0u) + (minus ? 1u : 0u)) << 4 | BT_CHAR);
+      if (plus) s.u8('+');
+      if (minus) s.u8('-');
+    }
+  }
+  put_int(s, a.ids.fmt_cg);
+  s.u8(1u << 4 | BT_CHAR);
+  s.u8(r.byte(11));
+  put_int(s, a.ids.fmt_cx);
+  s.u8(5u << 4 | BT_CHAR);
+#pragma unroll
+  for (unsigned k = 0; k < 5u; k++) s.u8(r.byte(19u + k));
+  if (het) {
+    put_int(s, a.ids.fmt_fs);
+    put_int(s, (int32_t)r.w[6]);
+  }
+  return l_shared;
+}
+
+/* the 32 fixed bytes bcf_write puts in front */
+__device__ __forceinline__ void bcf_emit_fixed(uint8_t *p, const rec_regs &r, const bcf_args &a, unsigned l_shared, unsigned l_indiv) {
+  const unsigned gt = r.byte(5) > 9u ? 9u : r.byte(5);
+  const unsigned alt0 = r.byte(12), alt1 = r.byte(13);
+  const uint32_t n_allele = 1u + (alt0 ? 1u : 0u) + (alt0 && alt1 ? 1u : 0u);
+  bool amq = false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) amq |= r.w[16 + k] > 0u;
+  const uint32_t n_fmt = 11u + (amq ? 1u : 0u) + (((0x16Eu >> gt) & 1u) ? 1u : 0u);
+  const float qual = (float)r.byte(9);
+  lds_sink f = {p, 0u};
+  f.le(l_shared + 24u, 4u);
+  f.le(l_indiv, 4u);
+  f.le((uint32_t)a.rid, 4u);
+  f.le(r.w[0] - 1u, 4u);
+  f.le(1u, 4u); /* rlen */
+  f.le(__float_as_uint(qual), 4u);
+  f.le(n_allele << 16 | 1u, 4u); /* one INFO field */
+  f.le(n_fmt << 24 | 1u, 4u);    /* one sample */
+}
+
+__device__ __forceinline__ void load_rec(rec_regs &r, const uint8_t *recs, uint64_t i) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(recs + i * 128u);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint4 v = src[k];
+    r.w[4 * k] = v.x;
+    r.w[4 * k + 1] = v.y;
+    r.w[4 * k + 2] = v.z;
+    r.w[4 * k + 3] = v.w;
+  }
+}
+
+/* the name of a flagged record: binary search of its position in the block's table */
+__device__ __forceinline__ unsigned find_name(const bcf_args &a, const rec_regs &r, const uint8_t *&id) {
+  id = nullptr;
+  if (!a.n_names || !r.byte(113)) return 0u;
+  const uint32_t pos = r.w[0];
+  uint32_t lo = 0, hi = a.n_names;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a.name_pos[mid] < pos) lo = mid + 1u; else hi = mid;
+  }
+  if (lo >= a.n_names || a.name_pos[lo] != pos) return 0u;
+  const uint32_t o0 = a.name_off[lo], o1 = a.name_off[lo + 1u];
+  id = a.name_bytes + o0;
+  const uint32_t l = o1 - o0;
+  return l > BCF_ID_MAX ? BCF_ID_MAX : l;
+}
+
+__device__ __forceinline__ uint64_t clamp_n(const bcf_args &a) {
+  const unsigned long long n = *a.n_recs;
+  return n < a.max_recs ? n : a.max_recs;
+}
+
+/* length of record i (0 beyond n, 0 for a record that is not written) */
+__device__ __forceinline__ unsigned rec_len(const bcf_args &a, uint64_t i, uint64_t n, rec_regs &r, const uint8_t *&id, unsigned &id_len, bool &bad) {
+  bad = false;
+  id_len = 0;
+  id = nullptr;
+  if (i >= n) return 0u;
+  load_rec(r, a.recs, i);
+  if (!r.byte(4)) return 0u; /* emit */
+  id_len = find_name(a, r, id);
+  count_sink c = {0u};
+  (void)bcf_emit_body(c, r, a, id, id_len, bad);
+  return 32u + c.len;
+}
+
+/* n_tiles = tiles of max_recs; tile_bytes[n_tiles] = 0 (so that the scan's last output is the stream's length) */
+extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_kernel(bcf_args a, uint32_t n_tiles, unsigned long long *__restrict__ tile_bytes,
+                                                                      unsigned long long *__restrict__ err) {
+  const unsigned lane = threadIdx.x & 63u;
+  const uint64_t n = clamp_n(a);
+  if (blockIdx.x == 0 && threadIdx.x == 0) tile_bytes[n_tiles] = 0ull;
+  for (uint32_t tile = blockIdx.x * BCF_WAVES + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * BCF_WAVES) {
+    rec_regs r;
+    const uint8_t *id;
+    unsigned id_len;
+    bool bad;
+    unsigned len = rec_len(a, (uint64_t)tile * 64u + lane, n, r, id, id_len, bad);
+    if (bad) atomicAdd(err, 1ull);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) len += __shfl_xor(len, d);
+    if (lane == 0) tile_bytes[tile] = len;
+  }
+}
+
+extern "C" __global__ __launch_bounds__(256) void bsc_bcf_write_kernel(bcf_args a, uint32_t n_tiles, const unsigned long long *__restrict__ tile_off,
+                                                                       uint8_t *__restrict__ out, uint64_t out_cap,
+                                                                       unsigned long long *__restrict__ total) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[BCF_WAVES][BCF_IMG_BYTES + 16u];
+  const unsigned lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  uint8_t *const img = s_img[wid];
+  const uint64_t n = clamp_n(a);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *total = tile_off[n_tiles];
+  for (uint32_t tile = blockIdx.x * BCF_WAVES + wid; tile < n_tiles; tile += gridDim.x * BCF_WAVES) {
+    if ((uint64_t)tile * 64u >= n) break; /* wave-uniform; later tiles of this wave lie further out still */
+    rec_regs r;
+    const uint8_t *id;
+    unsigned id_len;
+    bool bad;
+    const unsigned len = rec_len(a, (uint64_t)tile * 64u + lane, n, r, id, id_len, bad);
+    /* exclusive prefix of the lengths over the wave */
+    unsigned inc = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned v = __shfl_up(inc, d);
+      if (lane >= (unsigned)d) inc += v;
+    }
+    const unsigned excl = inc - len;
+    const unsigned t_all = __shfl(inc, 63);
+    const uint64_t g_tile = tile_off[tile];
+    if (g_tile + t_all > out_cap) continue; /* the host reports the overflow from *total */
+    /* one pass when the tile's span fits the image, else lanes 0..31 and 32..63 apart (32 records always fit) */
+    const unsigned t_half = __shfl(inc, 31);
+    const unsigned passes = t_all <= BCF_IMG_BYTES ? 1u : 2u;
+    for (unsigned ps = 0; ps < passes; ps++) {
+      const unsigned b0 = ps ? t_half : 0u;                                  /* the pass's first byte within the tile */
+      const unsigned b1 = passes == 1u ? t_all : (ps ? t_all : t_half);      /* one past its last */
+      const bool mine = len && excl >= b0 && excl < b1;
+      const uint64_t g0 = g_tile + b0;
+      const unsigned ph = (unsigned)(g0 & 15u);
+      if (mine) {
+        uint8_t *p = img + ph + (excl - b0);
+        lds_sink w = {p + 32u, 0u};
+        bool bad2;
+        const unsigned l_shared = bcf_emit_body(w, r, a, id, id_len, bad2);
+        bcf_emit_fixed(p, r, a, l_shared, w.len - l_shared);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      /* the image [ph, ph + t) -> out[g0, g0 + t) */
+      const unsigned t = b1 - b0, end = ph + t;
+      uint8_t *const dst = out + (g0 - ph);
+      const unsigned head_end = ph ? (end < 16u ? end : 16u) : 0u; /* bytes [ph, head_end) singly */
+      if (lane >= ph && lane < head_end) dst[lane] = img[lane];
+      const unsigned body0 = ph ? 16u : 0u, body1 = end & ~15u;
+      for (unsigned o = body0 + 16u * lane; o < body1; o += 1024u) *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(img + o);
+      const unsigned tail0 = body1 > head_end ? body1 : head_end;
+      if (tail0 + lane < end) dst[tail0 + lane] = img[tail0 + lane];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
+extern "C" int bsc_dev_scan_u64(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
+
+/*
+ * recs[<= max_recs] packed records, *n_recs of them (device u64) -> out[<= out_cap] BCF bytes; totals[0] = the stream's length
+ * (also when it exceeds out_cap: then only the tiles that fit whole are written), totals[1] += records bsc_bcf_record refuses.
+ * tile_bytes / tile_off: max_recs / 64 (rounded up) + 1 u64 each; scan_tmp: bsc_dev_scan_tmp_bytes_u64 of that many.
+ */
+extern "C" int bsc_dev_launch_bcf(const void *recs, const void *n_recs, uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids, const void *name_pos,
+                                  const void *name_off, const void *name_bytes, uint32_t n_names, void *tile_bytes, void *tile_off, void *scan_tmp,
+                                  size_t scan_tmp_bytes, void *out, uint64_t out_cap, void *totals, int num_cus, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  bcf_args a;
+  a.recs = (const uint8_t *)recs;
+  a.n_recs = (const unsigned long long *)n_recs;
+  a.max_recs = max_recs;
+  a.rid = rid;
+  a.ids = *ids;
+  a.name_pos = (const uint32_t *)name_pos;
+  a.name_off = (const uint32_t *)name_off;
+  a.name_bytes = (const uint8_t *)name_bytes;
+  a.n_names = name_pos ? n_names : 0u;
+  const uint64_t nt64 = (max_recs + 63u) / 64u;
+  if (nt64 > 0x7fffffffull) return (int)hipErrorInvalidValue;
+  const uint32_t n_tiles = (uint32_t)nt64;
+  unsigned grid = (n_tiles + BCF_WAVES - 1u) / BCF_WAVES;
+  if (grid > (unsigned)num_cus * 12u) grid = (unsigned)num_cus * 12u;
+  if (grid == 0) grid = 1;
+  hipLaunchKernelGGL(bsc_bcf_size_kernel, dim3(grid), dim3(256), 0, s, a, n_tiles, (unsigned long long *)tile_bytes, (unsigned long long *)totals + 1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  const int rc = bsc_dev_scan_u64(tile_bytes, tile_off, n_tiles + 1u, scan_tmp, scan_tmp_bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bsc_bcf_write_kernel, dim3(grid), dim3(256), 0, s, a, n_tiles, (const unsigned long long *)tile_off, (uint8_t *)out, out_cap,
+                     (unsigned long long *)totals);
+  return (int)hipGetLastError();
+}

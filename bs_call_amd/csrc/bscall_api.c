@@ -71,6 +71,9 @@ int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq, uint64_t 
                         size_t scan_tmp_bytes, void *tpl_out, void *seq_out, uint64_t seq_out_cap, void *cnt, int num_cus, void *stream,
                         const void *prof_ref, uint32_t prof_x, uint32_t prof_n_ref, uint32_t prof_cap, uint32_t prof_used0, void *prof_table,
                         void *max_pos1, void *used_scan);
+int bsc_dev_launch_bcf(const void *recs, const void *n_recs, uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids, const void *name_pos,
+                       const void *name_off, const void *name_bytes, uint32_t n_names, void *tile_bytes, void *tile_off, void *scan_tmp,
+                       size_t scan_tmp_bytes, void *out, uint64_t out_cap, void *totals, int num_cus, void *stream); /* bcfdev.hip */
 int bsc_dev_launch_ref_pad(const void *packed, const void *d_blk, uint32_t n_blk, void *padded, uint32_t n_pos, int num_cus, void *stream);
 int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk, uint32_t n_blk,
                                    uint32_t n_bins, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
@@ -139,6 +142,14 @@ struct bsc_context {
   uint32_t rec_sz;
   int rec_pending;
   double rec_share;
+  /* the BCF encoder on the device (bcfdev.hip): bytes per tile of 64 records, their prefix sum, scan scratch, the names' table, the
+   * block's stream, {length, refused records}; bsc_block_bcf: the destination of the block in flight (NULL: a records block), how
+   * many bytes went ahead of the length, the bytes per position the next copy is sized from */
+  void *d_btb, *d_bto, *d_bscn, *d_bnm, *d_bcf, *d_btot;
+  size_t cap_btb, cap_bto, cap_bscn, cap_bnm, cap_bcf, cap_btot;
+  uint8_t *bcf_out;
+  uint64_t bcf_cap, bcf_copied, bcf_bytes; /* bcf_bytes: the length of the last block's stream (also when it did not fit) */
+  double bcf_share;
   /* bsc_blocks_records_submit / _fetch: the blocks of the launch in flight (their table lives in the staging area), the device
    * copies of that table and of the chain's segment tables, where the per-tile record offsets come back to */
   const bsc_chain_mblock *mb_tab;
@@ -439,6 +450,12 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_toff);
   hipFree(ctx->d_scantmp);
   hipFree(ctx->d_recs);
+  hipFree(ctx->d_btb);
+  hipFree(ctx->d_bto);
+  hipFree(ctx->d_bscn);
+  hipFree(ctx->d_bnm);
+  hipFree(ctx->d_bcf);
+  hipFree(ctx->d_btot);
   hipFree(ctx->d_mblk);
   hipFree(ctx->d_mtab);
   hipFree(ctx->d_refp);
@@ -1616,6 +1633,62 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
   return BSC_OK;
 }
 
+/* ---- the BCF stream of packed records, encoded on the device (bcfdev.hip) ----------------------------------- */
+int bsc_bcf_block_device(bsc_context *ctx, const void *d_recs, const void *d_n_recs, uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids,
+                         const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream) {
+  if (!ctx || !d_n_recs || !ids || !d_totals || (max_recs && !d_recs) || (out_cap && !d_out))
+    return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: NULL argument");
+  if (((uintptr_t)d_recs & 15u) || ((uintptr_t)d_n_recs & 7u) || ((uintptr_t)d_totals & 7u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: d_recs must be 16-byte, d_n_recs / d_totals 8-byte aligned");
+  if (max_recs > 0x1fffffffc0ull) return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: more than 2^37 records");
+  uint32_t n_names = 0;
+  uint64_t name_bytes = 0;
+  if (names && names->n) {
+    if (!names->pos || !names->off || (!names->bytes && names->off[names->n]))
+      return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: a names table with NULL arrays");
+    n_names = names->n;
+    name_bytes = names->off[n_names];
+    for (uint32_t i = 0; i < n_names; i++) {
+      if (names->off[i] > names->off[i + 1] || (i && names->pos[i] <= names->pos[i - 1]))
+        return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: names table entry %u: positions must ascend, offsets must not descend", i);
+    }
+  }
+  BSC_ENTER(ctx);
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t n_tiles = (uint32_t)((max_recs + 63u) / 64u);
+  size_t scan_bytes = 0;
+  if (bsc_dev_scan_tmp_bytes_u64(n_tiles + 1u, &scan_bytes)) return bsc_fail(BSC_ERR_HIP, "bsc_bcf_block_device: scan size query failed");
+  int rc;
+  if ((rc = bsc_reserve(&ctx->d_btb, &ctx->cap_btb, ((size_t)n_tiles + 1u) * 8u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_bto, &ctx->cap_bto, ((size_t)n_tiles + 1u) * 8u))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_bscn, &ctx->cap_bscn, scan_bytes ? scan_bytes : 1))) return rc;
+  const void *d_pos = NULL, *d_off = NULL, *d_nb = NULL;
+  if (n_names) { /* positions | offsets | bytes in one workspace */
+    const size_t o_off = (size_t)n_names * 4u, o_by = o_off + ((size_t)n_names + 1u) * 4u;
+    if ((rc = bsc_reserve(&ctx->d_bnm, &ctx->cap_bnm, o_by + (size_t)name_bytes + 1u))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->d_bnm, names->pos, (size_t)n_names * 4u, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync((char *)ctx->d_bnm + o_off, names->off, ((size_t)n_names + 1u) * 4u, hipMemcpyHostToDevice, s));
+    if (name_bytes) HIP_TRY(hipMemcpyAsync((char *)ctx->d_bnm + o_by, names->bytes, (size_t)name_bytes, hipMemcpyHostToDevice, s));
+    d_pos = ctx->d_bnm;
+    d_off = (char *)ctx->d_bnm + o_off;
+    d_nb = (char *)ctx->d_bnm + o_by;
+  }
+  HIP_TRY(hipMemsetAsync(d_totals, 0, 2 * sizeof(unsigned long long), s));
+  const int e = bsc_dev_launch_bcf(d_recs, d_n_recs, max_recs, rid, ids, d_pos, d_off, d_nb, n_names, ctx->d_btb, ctx->d_bto, ctx->d_bscn, scan_bytes,
+                                   d_out, out_cap, d_totals, ctx->num_cus, stream);
+  if (e) return bsc_fail(BSC_ERR_HIP, "BCF encoder launch failed: %s", hipGetErrorString((hipError_t)e));
+  return BSC_OK;
+}
+
+/* what bsc_block_bcf asks of bsc_records_queue: the encoder behind the packing, its stream instead of the records on the way back */
+typedef struct {
+  int32_t rid;
+  const bsc_bcf_ids *ids;
+  const bsc_bcf_names *names;
+  uint8_t *out;
+  uint64_t out_cap;
+} bsc_bcf_req;
+
 /*
  * One block, reads in -> packed written records out, on the reads-in chain (bsc_reads_chain_queue): H2D of the block,
  * template checks + ordering, ONE kernel from reads to records (+ the second half of every bsc_vcf_rec), packing, and
@@ -1627,7 +1700,7 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
  * prepared them); tpl and seq are not looked at */
 static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
                              uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
-                             bsc_vcf_rec *out, uint64_t out_cap, int stage) {
+                             bsc_vcf_rec *out, uint64_t out_cap, int stage, const bsc_bcf_req *bcf) {
   const int resident = stage == 2;
   if (resident) {
     stage = 0;
@@ -1642,6 +1715,12 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   const uint32_t sz = (uint32_t)sz64;
   BSC_ENTER(ctx);
   int rc;
+  if (bcf) { /* the records stay in HBM (room for one per position); their stream goes back */
+    out = NULL;
+    out_cap = sz;
+    if ((rc = bsc_reserve(&ctx->d_bcf, &ctx->cap_bcf, (size_t)(bcf->out_cap ? bcf->out_cap : 1)))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_btot, &ctx->cap_btot, 2 * sizeof(unsigned long long)))) return rc;
+  }
   if (!resident) {
     if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
     if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
@@ -1691,26 +1770,60 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   if ((rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 0, d_db, sz, ctx->d_recs, out_cap, d_total, s))) return rc;
   /* INEXACT, ERR, RECORDS are consecutive counter words: the verdict and the count in one small copy */
   HIP_TRY(hipMemcpyAsync(ctx->h_cnt, ctx->d_counters + BSC_CNT_INEXACT, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  ctx->rec_out = out;
+  ctx->rec_cap = out_cap;
+  ctx->rec_sz = sz;
+  ctx->bcf_out = NULL;
+  if (bcf) { /* the encoder reads the count where the packing left it; {length, refused} come back behind the verdict */
+    if ((rc = bsc_bcf_block_device(ctx, ctx->d_recs, d_total, sz, bcf->rid, bcf->ids, bcf->names, ctx->d_bcf, bcf->out_cap, ctx->d_btot, s))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_cnt + 4, ctx->d_btot, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    uint64_t guess = ctx->bcf_share > 0.0 ? (uint64_t)((double)sz * ctx->bcf_share) + 65536u : 0u;
+    if (guess > bcf->out_cap) guess = bcf->out_cap;
+    if (guess) HIP_TRY(hipMemcpyAsync(bcf->out, ctx->d_bcf, (size_t)guess, hipMemcpyDeviceToHost, s));
+    ctx->bcf_out = bcf->out;
+    ctx->bcf_cap = bcf->out_cap;
+    ctx->bcf_copied = guess;
+    ctx->rec_copied = 0;
+    return BSC_OK;
+  }
   uint64_t guess = (uint64_t)((double)sz * ctx->rec_share) + 4096u;
   if (guess > out_cap) guess = out_cap;
   if (guess > sz) guess = sz;
   if (guess) HIP_TRY(hipMemcpyAsync(out, ctx->d_recs, (size_t)guess * sizeof(bsc_vcf_rec), hipMemcpyDeviceToHost, s));
-  ctx->rec_out = out;
-  ctx->rec_cap = out_cap;
   ctx->rec_copied = guess;
-  ctx->rec_sz = sz;
   return BSC_OK;
+}
+
+/* bsc_records_finish for a block whose stream comes back (bsc_block_bcf): h_cnt[4] = its length, h_cnt[5] = records refused */
+static int bsc_bcf_finish(bsc_context *ctx, uint8_t *out, int inexact) {
+  const unsigned long long bytes = ctx->h_cnt[4], bad = ctx->h_cnt[5];
+  ctx->bcf_bytes = bytes;
+  ctx->bcf_copied = ctx->bcf_copied < bytes ? ctx->bcf_copied : bytes;
+  if (bad) return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf: %llu records with a genotype beyond 9 or more than 6 likelihoods", bad);
+  if (bytes > ctx->bcf_cap) {
+    return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf: the block's stream has %llu bytes, out_cap is %llu", bytes, (unsigned long long)ctx->bcf_cap);
+  }
+  if (bytes > ctx->bcf_copied) { /* first block, or more bytes than the share so far suggested: the rest in a second copy */
+    HIP_TRY(hipMemcpyAsync(out + ctx->bcf_copied, (const char *)ctx->d_bcf + ctx->bcf_copied, (size_t)(bytes - ctx->bcf_copied), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  if (ctx->rec_sz >= 4096u) ctx->bcf_share = (double)bytes / (double)ctx->rec_sz * 1.02;
+  return bsc_inexact_status(inexact);
 }
 
 /* the one wait of a block queued by bsc_records_queue, and what is left to do after it */
 static int bsc_records_finish(bsc_context *ctx, uint64_t *n_out) {
   *n_out = 0;
+  uint8_t *const bcf_out = ctx->bcf_out;
+  ctx->bcf_out = NULL;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   int inexact = 0;
   int rc = bsc_verdict(ctx, ctx->h_cnt, &inexact); /* h_cnt = {INEXACT, ERR, RECORDS} */
   if (rc) return rc; /* an invalid template: the contents of `out` are unspecified */
   const unsigned long long total = ctx->h_cnt[2];
   *n_out = total;
+  if (bcf_out) return bsc_bcf_finish(ctx, bcf_out, inexact);
   if (total > ctx->rec_cap)
     return bsc_fail(BSC_ERR_ARG, "bsc_block_records: the block has %llu records, out_cap is %llu", total,
                     (unsigned long long)ctx->rec_cap);
@@ -1727,13 +1840,13 @@ static int bsc_records_finish(bsc_context *ctx, uint64_t *n_out) {
   return bsc_inexact_status(inexact);
 }
 
-int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
-                      uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
-                      int with_stats, bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out) {
+static int bsc_block_records_(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                              uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
+                              int with_stats, bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out, const bsc_bcf_req *bcf) {
   if (!ctx || !ref || !params || !n_out || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records: NULL argument");
   *n_out = 0;
   if (ctx->rec_pending) return bsc_fail(BSC_ERR_ARG, "bsc_block_records: a submitted block has not been fetched");
-  int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 0);
+  int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 0, bcf);
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream); /* copies already queued read the caller's buffers: none may outlive the call */
     return rc;
@@ -1742,23 +1855,49 @@ int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, co
   return bsc_records_finish(ctx, n_out);
 }
 
+int bsc_block_records(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                      uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
+                      int with_stats, bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out) {
+  return bsc_block_records_(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, n_out, NULL);
+}
+
+static int bsc_bcf_req_check(const char *who, const bsc_bcf_ids *ids, uint8_t *out, uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records) {
+  if (!ids || !n_bytes || !n_records || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "%s: NULL argument", who);
+  *n_bytes = 0;
+  *n_records = 0;
+  return BSC_OK;
+}
+
+/* bsc_block_records with the encoder behind the packing (bcfdev.hip): the block's BCF bytes come back instead of its records */
+int bsc_block_bcf(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                  const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids,
+                  const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records) {
+  int rc = bsc_bcf_req_check("bsc_block_bcf", ids, out, out_cap, n_bytes, n_records);
+  if (rc) return rc;
+  const bsc_bcf_req req = {rid, ids, names, out, out_cap};
+  if (ctx) ctx->bcf_bytes = 0;
+  rc = bsc_block_records_(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, NULL, 0, n_records, &req);
+  if (ctx) *n_bytes = ctx->bcf_bytes;
+  return rc;
+}
+
 /*
  * bsc_block_records from what the READER delivers: raw templates with their mismatch lists (bsc_read_block) — uploaded as they are,
  * prepared on the device (bsc_prepare_templates_device: trims, soft clips, mate overlap, indel normalisation), and straight on to
  * the grouping, the walk and the chain; the process thread's per-template work (src/process_template.c:36-111) never touches a
  * host core.  x .. y: the block as the reader found it (src/get_template_vector.c:141-147; x = bsc_block_start).
  */
-int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
-                          const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref,
-                          const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap,
-                          uint64_t *n_out, bsc_prep_stats *prep_stats, bsc_read_profile *profile) {
+static int bsc_block_records_raw_(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                                  const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref,
+                                  const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap,
+                                  uint64_t *n_out, bsc_prep_stats *prep_stats, bsc_read_profile *profile, const bsc_bcf_req *bcf) {
   if (!ctx || !ref || !params || !prep || !n_out || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: NULL argument");
   if (y < x) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: y (%u) < x (%u)", y, x);
   *n_out = 0;
   if (prep_stats) memset(prep_stats, 0, sizeof *prep_stats);
   if (ctx->rec_pending || ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: a submitted block has not been fetched");
   if (nr && (!raw || (seq_bytes && !seq) || (n_misms && !misms))) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: NULL input buffer");
-  if (!nr) return bsc_block_records(ctx, NULL, 0, NULL, 0, x, y, ref, dbsnp, params, with_stats, out, out_cap, n_out);
+  if (!nr) return bsc_block_records_(ctx, NULL, 0, NULL, 0, x, y, ref, dbsnp, params, with_stats, out, out_cap, n_out, bcf);
   if (y - x > 0x0ffffffeu) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_raw: block longer than 2^28 - 1 positions");
   BSC_ENTER(ctx);
   /* room for the prepared reads: the bytes handed over plus every padded deletion (a size no read could hold is damage: the
@@ -1791,12 +1930,34 @@ int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_
                                     prep_stats, profile ? &dp : NULL, s);
   if (profile) profile->used = dp.used;
   if (rc) return rc; /* (it has waited for the stream: nothing reads the caller's buffers any more) */
-  rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 2);
+  rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 2, bcf);
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream);
     return rc;
   }
   return bsc_records_finish(ctx, n_out);
+}
+
+int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
+                          const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref,
+                          const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap,
+                          uint64_t *n_out, bsc_prep_stats *prep_stats, bsc_read_profile *profile) {
+  return bsc_block_records_raw_(ctx, raw, nr, seq, seq_bytes, misms, n_misms, prep, x, y, ref, dbsnp, params, with_stats, out, out_cap, n_out, prep_stats,
+                                profile, NULL);
+}
+
+int bsc_block_bcf_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, const bsc_misms *misms,
+                      uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
+                      const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out,
+                      uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records, bsc_prep_stats *prep_stats, bsc_read_profile *profile) {
+  int rc = bsc_bcf_req_check("bsc_block_bcf_raw", ids, out, out_cap, n_bytes, n_records);
+  if (rc) return rc;
+  const bsc_bcf_req req = {rid, ids, names, out, out_cap};
+  if (ctx) ctx->bcf_bytes = 0;
+  rc = bsc_block_records_raw_(ctx, raw, nr, seq, seq_bytes, misms, n_misms, prep, x, y, ref, dbsnp, params, with_stats, NULL, 0, n_records, prep_stats,
+                              profile, &req);
+  if (ctx) *n_bytes = ctx->bcf_bytes;
+  return rc;
 }
 
 /* The split form: queue the block and return; bsc_block_records_fetch waits and completes it.  stage != 0: the inputs go
@@ -1807,7 +1968,7 @@ static int bsc_records_submit(bsc_context *ctx, const bsc_template *tpl, uint32_
                               bsc_vcf_rec *out, uint64_t out_cap, int stage) {
   if (!ctx || !ref || !params || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_submit: NULL argument");
   if (ctx->rec_pending || ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_submit: the previous block has not been fetched");
-  int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, stage);
+  int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, stage, NULL);
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream); /* nothing may still read the inputs / the staging area after a failed submit */
     return rc;

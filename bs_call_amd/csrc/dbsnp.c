@@ -422,3 +422,50 @@ int bsc_dbsnp_name(const bsc_dbsnp *db, uint32_t x, char *rs, size_t cap, size_t
   if (rs_len) *rs_len = (size_t)(tp - rs);
   return res;
 }
+
+/* The names of every flagged position of x0 .. x0 + n - 1 (the table the device encoder of csrc/bcfdev.hip looks a record's ID up
+ * in): ascending positions, offsets, the bytes bsc_dbsnp_name returns for each (*rs_len of them, the filler of an odd digit count
+ * included).  NULL arrays: the sizes only. */
+int bsc_dbsnp_names(const bsc_dbsnp *db, uint32_t x0, uint32_t n, uint32_t *pos, uint32_t *off, char *bytes, uint32_t cap_names,
+                    uint64_t cap_bytes, uint32_t *n_names, uint64_t *n_bytes) {
+  if (!db || !n_names || !n_bytes) return bsc_set_error(BSC_ERR_ARG, "bsc_dbsnp_names: NULL argument");
+  const int fill = pos && off && bytes;
+  uint32_t k = 0;
+  uint64_t nb = 0;
+  *n_names = 0;
+  *n_bytes = 0;
+  if (db->loaded >= 0 && db->bins && n) {
+    const dbsnp_ctg *c = db->ctgs + db->loaded;
+    const uint64_t last = (uint64_t)x0 + n - 1;
+    uint64_t bn0 = (uint64_t)x0 >> 6, bn1 = last >> 6;
+    if (bn0 < c->min_bin) bn0 = c->min_bin;
+    if (bn1 > c->max_bin) bn1 = c->max_bin;
+    for (uint64_t bn = bn0; bn <= bn1 && bn >= c->min_bin; bn++) {
+      if (bn - c->min_bin >= db->bins_used) break;
+      uint64_t m = db->bins[bn - c->min_bin].mask;
+      while (m) {
+        const unsigned bit = (unsigned)__builtin_ctzll(m);
+        m &= m - 1;
+        const uint64_t x = bn * 64u + bit;
+        if (x < x0 || x > last) continue;
+        char rs[256];
+        size_t l = 0;
+        const int r = bsc_dbsnp_name(db, (uint32_t)x, rs, sizeof rs, &l);
+        if (r < 0) return r;
+        if (fill) {
+          if (k >= cap_names || nb + l > cap_bytes || nb + l > 0xffffffffull)
+            return bsc_set_error(BSC_ERR_ARG, "bsc_dbsnp_names: more than %u names / %llu bytes", cap_names, (unsigned long long)cap_bytes);
+          pos[k] = (uint32_t)x;
+          off[k] = (uint32_t)nb;
+          memcpy(bytes + nb, rs, l);
+        }
+        k++;
+        nb += l;
+      }
+    }
+  }
+  if (fill) off[k] = (uint32_t)nb;
+  *n_names = k;
+  *n_bytes = nb;
+  return BSC_OK;
+}

@@ -59,6 +59,18 @@ class DbSnpIndex:
         _check(self._L.bsc_dbsnp_flags(self._h, x0, n, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def names(self, x0, n):
+        """The names of the flagged positions of x0 .. x0 + n - 1 of the loaded contig (bsc_dbsnp_names): (pos uint32[k] ascending,
+        off uint32[k + 1], bytes) — the table SiteCaller.block_bcf* hands to the device encoder."""
+        k, nb = C.c_uint32(0), C.c_uint64(0)
+        _check(self._L.bsc_dbsnp_names(self._h, x0, n, None, None, None, 0, 0, C.byref(k), C.byref(nb)))
+        pos = np.zeros(k.value, dtype=np.uint32)
+        off = np.zeros(k.value + 1, dtype=np.uint32)
+        by = np.zeros(nb.value + 1, dtype=np.uint8)
+        _check(self._L.bsc_dbsnp_names(self._h, x0, n, pos.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), by.ctypes.data_as(C.c_void_p),
+                                       k.value, nb.value, C.byref(k), C.byref(nb)))
+        return pos, off, by[: nb.value].tobytes()
+
     def name(self, x):
         """(rs_found, name, rs_len as the reference counts it) of position x."""
         buf = C.create_string_buffer(600)

@@ -1,5 +1,6 @@
 """BAM -> BCF through the library, block by block — the reference's four threads in a line (reader: bsc_bam_next_block;
-process: bsc_prepare_templates + the block's reference; calc + print: bsc_block_records on the GPU; output: bsc_bcf_block) —
+process: the block's reference; process + calc + print: bsc_block_bcf_raw on the GPU — pre-processing, calling, record formation and
+the BCF encoding; output: the writer) —
 and the run's JSON report.  An example of the pieces put together for tests and for INTEGRATION.md, not a command-line
 replacement of bs_call: the reference's argument parsing, region / contig selection and FASTA reader are out of scope
 (SURVEY.md section 8)."""
@@ -15,12 +16,14 @@ from .caller import ReadProfile, SiteCaller, gc_bins, prepare_templates
 def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: str = "SAMPLE", report_path: Optional[str] = None,
         caller: Optional[SiteCaller] = None, dbsnp=None, compressed: bool = True, date=None, left_trim=(0, 0), right_trim=(0, 0),
         min_qual: Optional[int] = None, benchmark_mode: bool = False, under_conv: Optional[float] = None, over_conv: Optional[float] = None,
-        host_prep: bool = False, **reader_kw) -> dict:
+        host_prep: bool = False, host_bcf: bool = False, **reader_kw) -> dict:
     """reference: contig name -> uint8 reference codes (0 = N, 1..4 = ACGT; position 1 first).  Returns a summary dict.
     under_conv / over_conv / min_qual (defaults 0.01 / 0.05 / 20, src/init_param.c:26-31) are the MODEL's parameters: without
     `caller` the run builds its SiteCaller from them; with one, they are taken from it and a differing explicit value is an error
     (the header must name the thresholds the genotypes were computed with, src/print_vcf.c:647-692).  host_prep: the read
-    pre-processing on the host (bsc_prepare_templates_profile) instead of the device (round 5's default) — same bytes."""
+    pre-processing on the host (bsc_prepare_templates_profile) instead of the device (round 5's default) — same bytes.  host_bcf:
+    the packed records come back and the host encodes them (bsc_bcf_block) instead of the device's encoder (bsc_block_bcf_raw,
+    round 5's default) — same bytes."""
     own = caller is None
     if own:
         under_conv = 0.01 if under_conv is None else under_conv
@@ -71,14 +74,21 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
                     if host_prep:  # round 4's split: the process thread's per-template work here, then the block
                         tpl, pseq, st = prepare_templates(raw, seq, ms, left_trim, right_trim, min_qual, profile=prof, x=x, ref=ref)
                         recs = c.block_records(tpl, pseq, x, y, ref, reg_stop=len(codes), dbsnp=flags, with_stats=True)
-                    else:  # raw templates up, pre-processing and the read profile on the device (bsc_block_records_raw)
+                    elif host_bcf:  # raw templates up, pre-processing and the read profile on the device (bsc_block_records_raw)
                         recs, st = c.block_records_raw(raw, seq, ms, x, y, ref, left_trim, right_trim, min_qual, reg_stop=len(codes), dbsnp=flags,
                                                        with_stats=True, profile=prof)
+                    else:  # ... and the BCF encoding too: the block's stream comes back (bsc_block_bcf_raw)
+                        names = None if dbsnp is None else dbsnp.names(x, y - x + 1)
+                        blob, n_rec, st = c.block_bcf_raw(raw, seq, ms, x, y, ref, tid, names=names, left_trim=left_trim, right_trim=right_trim,
+                                                          min_qual=min_qual, reg_stop=len(codes), dbsnp=flags, with_stats=True, profile=prof)
+                        recs = None
                     base_filter += np.array([st["base_none"], st["base_trim"], st["base_clip"], st["base_overlap"], st["base_lowqual"]], dtype=np.uint64)
                     passed += np.array([st["reads"], st["read_bases"]], dtype=np.uint64)
-                    yield vcf.bcf_block(recs, tid, dbsnp)
+                    if recs is not None:
+                        blob, n_rec = vcf.bcf_block(recs, tid, dbsnp), len(recs)
+                    yield blob
                     n_blocks += 1
-                    n_records += len(recs)
+                    n_records += n_rec
                 if cur_tid >= 0:
                     per_contig.append((refs[cur_tid][0], c.site_totals() - before))
 

@@ -658,6 +658,41 @@ int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_
                           const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref,
                           const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap,
                           uint64_t *n_out, bsc_prep_stats *prep_stats, bsc_read_profile *profile);
+/*
+ * The BCF stream of a block, encoded ON THE DEVICE (round 5, csrc/bcfdev.hip): what the output thread hands to bcf_write for the block's
+ * written records — the typed values of src/print_vcf.c:160-222,267-378 behind bcf_write's fixed fields, byte for byte what
+ * bsc_bcf_block (host C, the checker) makes of the same packed records — so that the record formation's tail never touches a host core
+ * and ~113 bytes per written record cross PCIe instead of 128.
+ *   bsc_bcf_names            the dbSNP names of the block's flagged positions (host arrays; uploaded with the call): pos[n] ascending
+ *                            1-based positions, off[n + 1] offsets into bytes; bsc_dbsnp_names fills one from the loaded contig.  A
+ *                            record whose rs_found flag is set and whose position the table lists carries that ID (at most 63 bytes of it)
+ *   bsc_bcf_block_device     d_recs[<= max_recs] packed records in HBM, *d_n_recs of them (a device u64: the count bsc_vcf_compact_device
+ *                            left) -> d_out[<= out_cap] bytes; d_totals = two device u64 {length of the stream, records bsc_bcf_record
+ *                            refuses (gt > 9 or n_gl > 6: counted, written with the values clamped)}; a stream longer than out_cap is
+ *                            cut at a 64-record boundary, its full length still in d_totals[0].  Asynchronous on `stream`
+ *   bsc_block_bcf[_raw]      bsc_block_records[_raw] with the encoder behind the packing: out[out_cap] receives the block's BCF bytes,
+ *                            *n_bytes their number (BSC_ERR_ARG and the number needed when out_cap is too small), *n_records the records
+ *                            in them; one wait per block as before
+ */
+typedef struct {
+  const uint32_t *pos;
+  const uint32_t *off;
+  const char *bytes;
+  uint32_t n;
+} bsc_bcf_names;
+/* the names of the flagged positions of x0 .. x0 + n - 1 of the loaded contig, as bsc_dbsnp_name returns them (length = *rs_len);
+ * pos / off / bytes may be NULL to ask for the sizes: *n_names entries, *n_bytes bytes.  BSC_ERR_ARG if a capacity is too small. */
+int bsc_dbsnp_names(const struct bsc_dbsnp *db, uint32_t x0, uint32_t n, uint32_t *pos, uint32_t *off, char *bytes, uint32_t cap_names,
+                    uint64_t cap_bytes, uint32_t *n_names, uint64_t *n_bytes);
+int bsc_bcf_block_device(bsc_context *ctx, const void *d_recs, const void *d_n_recs, uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids,
+                         const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream);
+int bsc_block_bcf(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                  const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids,
+                  const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records);
+int bsc_block_bcf_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, const bsc_misms *misms,
+                      uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
+                      const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out,
+                      uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records, bsc_prep_stats *prep_stats, bsc_read_profile *profile);
 /* x of the block a template list starts: the first template's start - 2, at least 1 (src/process_template.c:22-28) */
 uint32_t bsc_block_start(const bsc_raw_template *first);
 /* get_al_qual (src/al_utils.c:19-35): the score duplicate resolution compares, with the reference's sq[k] indexing */

@@ -5,11 +5,14 @@
  *
  *   reader thread     bsc_bam_next_block            read_input / get_next_align_details
  *   process thread    bsc_block_reference           get_sequence_string
- *   process + calc    bsc_block_records_raw         process_template_vector + meth_profile (on the device since round 5:
- *     + print                                       bsc_prepare_templates_device), call_genotypes_ML, _print_vcf_entry up to the
- *                                                   encoding, the statistics   (BAM2BCF_HOST_PREP: the pre-processing on this thread,
+ *   process + calc    bsc_block_bcf_raw             process_template_vector + meth_profile (on the device since round 5:
+ *     + print                                       bsc_prepare_templates_device), call_genotypes_ML, _print_vcf_entry WITH the
+ *                                                   encoding (the bcf_enc_* calls and bcf_write's fixed fields, csrc/bcfdev.hip), the
+ *                                                   statistics: the block's BCF bytes come back
+ *                                                   (BAM2BCF_HOST_BCF: bsc_block_records_raw, then bsc_bcf_block on this thread;
+ *                                                   BAM2BCF_HOST_PREP: also the pre-processing on this thread,
  *                                                   bsc_prepare_templates_profile + bsc_block_records, as in round 4)
- *   output            bsc_bcf_block                 the bcf_enc_* calls + bcf_write
+ *   output            fwrite                        bcf_write's write
  *   at the end        bsc_report_json               output_stats
  *
  * Not a replacement of the bs_call executable (no option parsing, regions, contig lists, dbSNP, compression): a worked
@@ -48,6 +51,15 @@ static void *xrealloc(void *p, size_t n) {
     exit(1);
   }
   return q;
+}
+
+static void *pinned(size_t n) { /* page-locked: the copy-out is a true DMA, queued behind the kernels */
+  void *p = bsc_alloc_host(n);
+  if (!p) {
+    fprintf(stderr, "out of page-locked memory (%zu bytes)\n", n);
+    exit(1);
+  }
+  return p;
 }
 
 /* the header print_vcf_header assembles in --benchmark-mode (src/print_vcf.c:621-745) */
@@ -141,6 +153,7 @@ int main(int argc, char **argv) {
   int r;
   double t_read = 0, t_ref = 0, t_prep = 0, t_gpu = 0, t_enc = 0, t0 = now(), t1;
   const int host_prep = getenv("BAM2BCF_HOST_PREP") != NULL;
+  const int host_bcf = host_prep || getenv("BAM2BCF_HOST_BCF") != NULL;
   for (;;) {
     r = bsc_bam_next_block(bam, &rpar, &blk);
     t_read += (t1 = now()) - t0;
@@ -174,13 +187,29 @@ int main(int argc, char **argv) {
      * the device prepares them (trims, clips, mate overlap, indels; the read profile) and calls the block.  BAM2BCF_HOST_PREP in the
      * environment keeps round 4's split (bsc_prepare_templates_profile on this thread, then bsc_block_records) for comparison. */
     bsc_prep_stats st;
-    if (n > cap_recs) recs = xrealloc(recs, (cap_recs = (size_t)n * 2) * sizeof *recs);
     const bsc_vcf_params vp = {0, 1, (uint32_t)codes_len};
-    uint64_t n_out = 0;
-    if (!host_prep) {
+    uint64_t n_out = 0, n_bytes = 0;
+    if (!host_bcf) { /* the whole block on the device, the encoding included: room for a record of ordinary length per position */
+      if ((size_t)n * 160 + 4096 > cap_bcf) {
+        bsc_free_host(bcf);
+        bcf = pinned(cap_bcf = ((size_t)n * 160 + 4096) * 2);
+      }
+      int rc = bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 1, blk.tid, &ids,
+                                 NULL, bcf, cap_bcf, &n_bytes, &n_out, &st, &prof);
+      if (rc == BSC_ERR_ARG && n_bytes > cap_bcf) { /* a block of long records: once more with the room it asks for */
+        bsc_free_host(bcf);
+        bcf = pinned(cap_bcf = (size_t)n_bytes + 4096);
+        bsc_prep_stats st2; /* the first pass has counted the block's bases and its profile already */
+        rc = bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 0, blk.tid, &ids, NULL,
+                               bcf, cap_bcf, &n_bytes, &n_out, &st2, NULL);
+      }
+      CHECK(rc);
+    } else if (!host_prep) {
+      if (n > cap_recs) recs = xrealloc(recs, (cap_recs = (size_t)n * 2) * sizeof *recs);
       CHECK(bsc_block_records_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 1, recs,
                                   cap_recs, &n_out, &st, &prof));
     } else {
+      if (n > cap_recs) recs = xrealloc(recs, (cap_recs = (size_t)n * 2) * sizeof *recs);
       uint64_t pad = 0;
       for (uint64_t i = 0; i < blk.n_misms; i++)
         if (blk.misms[i].type == BSC_MISMS_INS) pad += blk.misms[i].size;
@@ -205,15 +234,21 @@ int main(int argc, char **argv) {
     passed_bases += st.read_bases;
     t_gpu += (t1 = now()) - t0;
     t0 = t1;
-    if (n_out * 256 + 64 > cap_bcf) bcf = xrealloc(bcf, cap_bcf = (size_t)(n_out * 256 + 64) * 2);
-    uint64_t done = 0;
-    const long nb = bsc_bcf_block(recs, n_out, blk.tid, &ids, NULL, bcf, cap_bcf, &done);
-    CHECK(nb);
-    if (done != n_out) {
-      fprintf(stderr, "BCF buffer too small\n");
-      return 1;
+    if (host_bcf) {
+      if (n_out * 256 + 64 > cap_bcf) {
+        bsc_free_host(bcf);
+        bcf = pinned(cap_bcf = (size_t)(n_out * 256 + 64) * 2);
+      }
+      uint64_t done = 0;
+      const long nb = bsc_bcf_block(recs, n_out, blk.tid, &ids, NULL, bcf, cap_bcf, &done);
+      CHECK(nb);
+      if (done != n_out) {
+        fprintf(stderr, "BCF buffer too small\n");
+        return 1;
+      }
+      n_bytes = (uint64_t)nb;
     }
-    fwrite(bcf, 1, (size_t)nb, out);
+    fwrite(bcf, 1, (size_t)n_bytes, out);
     n_blocks++;
     n_records += n_out;
     t_enc += (t1 = now()) - t0;
@@ -222,7 +257,9 @@ int main(int argc, char **argv) {
   CHECK(r);
   if (getenv("BAM2BCF_TIMING"))
     fprintf(stderr, "seconds: reader %.3f  reference (FASTA + block) %.3f  pre-processing on the host %.3f  %s %.3f  BCF encode + write %.3f\n",
-            t_read, t_ref, t_prep, host_prep ? "bsc_block_records" : "bsc_block_records_raw (pre-processing on the device)", t_gpu, t_enc);
+            t_read, t_ref, t_prep,
+            host_prep ? "bsc_block_records" : (host_bcf ? "bsc_block_records_raw (pre-processing on the device)" : "bsc_block_bcf_raw (pre-processing and BCF encoding on the device)"),
+            t_gpu, t_enc);
   if (cur_tid >= 0) {
     CHECK(bsc_get_site_totals(ctx, after));
     uint64_t *d = ctot[cur_tid].snps;

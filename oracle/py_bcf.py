@@ -84,9 +84,12 @@ def encode_record(r, rid, rs=b""):
     for key, v in (("DP", r["dp"]), ("MQ", r["mq"]), ("GQ", r["phred"]), ("QD", r["qd"])):
         ind += enc_int1(IDS[key]) + enc_int1(v)
     ind += enc_int1(IDS["GL"]) + enc_vfloat(r["gl"])
-    ind += enc_int1(IDS["MC8"]) + enc_vint(list(r["counts"]))
+    # the packed record's counts are uint32 (a count beyond 2^32 - 1 saturates); the encoder hands them over as int32, and AMQ lists
+    # the classes whose unsigned count is not zero
+    cnt = [int(c) & 0xFFFFFFFF for c in r["counts"]]
+    ind += enc_int1(IDS["MC8"]) + enc_vint([c - (1 << 32) if c >= 1 << 31 else c for c in cnt])
     n_fmt = 11
-    amq = [q for c, q in zip(r["counts"], r["qual"]) if c > 0]
+    amq = [q for c, q in zip(cnt, r["qual"]) if c > 0]
     if amq:
         ind += enc_int1(IDS["AMQ"]) + enc_vint(amq)
         n_fmt += 1

@@ -191,3 +191,26 @@ def test_bcf_records_carry_the_dbsnp_names(index_file):
         name = (pre[pix] + rs).encode()
         assert d["pos"] == pos and d["rid"] == 4 and d["id"] == name + (b"\0" if len(rs) % 2 else b"")
     assert got[-1]["id"] == b""
+
+
+def test_names_of_a_range_are_the_single_lookups(index_file):
+    """bsc_dbsnp_names (the table the device BCF encoder searches, csrc/bcfdev.hip): every flagged position of the range, ascending,
+    with the bytes and the length bsc_dbsnp_name gives for it."""
+    path, ctgs = index_file
+    with DbSnpIndex(path) as db:
+        for name in ("chrA", "chrS", "chrE"):
+            db.load_contig(name)
+            sites = sorted(s[0] for s in ctgs[name])
+            top = sites[-1] + 100
+            a, b, c = sites[min(1, len(sites) - 1)], sites[min(2, len(sites) - 1)], sites[min(5, len(sites) - 1)]
+            for x0, n in ((1, top), (a, 1), (a + 1, 0), (b, c - b + 1), (63, 130), (top, 50)):
+                pos, off, by = db.names(x0, n)
+                want = [p for p in sites if x0 <= p < x0 + n]
+                assert pos.tolist() == want and len(off) == len(want) + 1 and int(off[-1]) == len(by)
+                for i, p in enumerate(want[:: max(1, len(want) // 50)]):
+                    j = want.index(p)
+                    r, nm, ln = db.name(p)
+                    assert by[int(off[j]) : int(off[j + 1])] == (nm.encode() + b"\0")[:ln]
+        db.load_contig("chrUnknown")
+        pos, off, by = db.names(1, 10_000)
+        assert len(pos) == 0 and off.tolist() == [0] and by == b""

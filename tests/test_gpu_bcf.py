@@ -1,0 +1,289 @@
+"""The BCF encoder on the device (csrc/bcfdev.hip: bsc_bcf_block_device, bsc_block_bcf, bsc_block_bcf_raw) against the host
+encoder (csrc/bcf.c, itself pinned to the independent BCF2 encoder / reader of oracle/py_bcf.py by tests/test_bcf.py) and against
+py_bcf directly: random packed records incl. every size class of every typed value, records that are not written, names from a
+table, tiles whose stream does not fit the wave's image (two passes), capacities that are too small, refused records; then whole
+blocks — reads in, BCF bytes out — against bsc_block_records[_raw] + bsc_bcf_block, with a dbSNP index naming records."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import bs_call_amd as B
+from bs_call_amd import _lib, vcf
+from bs_call_amd.abi import VCF_REC
+from oracle import py_bcf
+
+import test_bcf as TB
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def caller():
+    c = B.SiteCaller()
+    yield c
+    c.close()
+
+
+def _host_stream(recs, rid, names=None, ids=None):
+    """bsc_bcf_record over the records, names from the table (rs_found set and position listed), at most 63 bytes of a name"""
+    L = _lib.load()
+    if ids is None:
+        ids = _lib.BcfIds()
+        L.bsc_bcf_default_ids(C.byref(ids))
+    table = {}
+    if names is not None:
+        pos, off, by = names
+        table = {int(p): by[int(off[i]) : int(off[i + 1])][:63] for i, p in enumerate(pos)}
+    buf = (C.c_uint8 * 512)()
+    out = []
+    for r in recs:
+        rs = table.get(int(r["core"]["pos"]), b"") if int(r["rs_found"]) else b""
+        r1 = np.ascontiguousarray(r).reshape(1)
+        n = L.bsc_bcf_record(r1.ctypes.data, rid, rs, len(rs), C.byref(ids), buf, 512)
+        assert 0 <= n <= 512
+        out.append(bytes(buf[:n]))
+    return out
+
+
+def _device_stream(caller, recs, rid, names=None, ids=None, cap=None, n_recs=None, max_recs=None):
+    import torch
+
+    dev = torch.device("cuda:0")
+    raw = np.ascontiguousarray(recs).view(np.uint8).reshape(-1)
+    d_recs = torch.from_numpy(raw.copy()).to(dev) if len(raw) else torch.zeros(128, dtype=torch.uint8, device=dev)
+    n = len(recs) if n_recs is None else n_recs
+    d_n = torch.tensor([n], dtype=torch.int64, device=dev)
+    cap = 336 * max(len(recs), 1) if cap is None else cap
+    d_out = torch.full((max(cap, 1) + 64,), 0xEE, dtype=torch.uint8, device=dev)
+    d_tot = torch.zeros(2, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    caller.bcf_block_device(d_recs.data_ptr(), d_n.data_ptr(), len(recs) if max_recs is None else max_recs, rid, d_out.data_ptr(), cap,
+                            d_tot.data_ptr(), names=names, ids=ids, stream=st)
+    torch.cuda.synchronize()
+    tot = d_tot.cpu().numpy()
+    out = d_out.cpu().numpy()
+    assert (out[cap:] == 0xEE).all(), "bytes behind the capacity were written"
+    return out[:cap], int(tot[0]), int(tot[1])
+
+
+def _random_block(rng, n, named=0.0, long_names=False):
+    recs = np.zeros(n, dtype=VCF_REC)
+    pos = np.sort(rng.choice(np.arange(1, 50 * n + 100), n, replace=False)).astype(np.uint32)
+    for i in range(n):
+        recs[i] = TB._random_rec(rng)
+        recs[i]["core"]["pos"] = pos[i]
+        if rng.random() < 0.12:
+            recs[i]["core"]["emit"] = 0
+        if rng.random() < named:
+            recs[i]["rs_found"] = int(rng.choice([1, 3]))
+        if rng.random() < 0.1:
+            recs[i]["core"]["fs"] = int(rng.choice([-5, 127, 128, 32767, 32768, 2_000_000]))
+            recs[i]["mq"] = int(rng.choice([0, 127, 128, 40000]))
+            recs[i]["core"]["qd"] = int(rng.choice([0, 127, 128, 32768]))
+        if rng.random() < 0.05:
+            recs[i]["counts"] = 0  # no AMQ field
+        if rng.random() < 0.03:
+            recs[i]["counts"][int(rng.integers(0, 8))] = 0xFFFFFFFF  # the saturated count: -1 as the encoder's int32
+    # the table lists most flagged positions, a few that no record has, and leaves some flagged records without a name
+    listed = [int(p) for p, r in zip(pos, recs) if r["rs_found"] and rng.random() < 0.85]
+    listed += [int(p) + 1 for p in pos[:: max(1, n // 7)] if int(p) + 1 not in set(pos.tolist())]
+    listed = sorted(set(listed))
+    names_b, off = [], [0]
+    for p in listed:
+        if long_names:
+            nm = b"rs" + bytes(rng.choice(list(b"0123456789"), int(rng.integers(10, 90))).tolist())
+        else:
+            nm = b"rs%d" % int(rng.integers(1, 10**9))
+            if len(nm) % 2 == 1 and rng.random() < 0.5:
+                nm += b"\0"  # an odd number of digits carries its filler (bsc_dbsnp_name)
+        names_b.append(nm)
+        off.append(off[-1] + len(nm))
+    names = (np.array(listed, dtype=np.uint32), np.array(off, dtype=np.uint32), b"".join(names_b))
+    return recs, names
+
+
+def test_random_records_device_equals_host_and_python(caller):
+    rng = np.random.default_rng(20261004)
+    for trial, n in enumerate((1, 63, 64, 65, 700, 4097)):
+        recs, names = _random_block(rng, n, named=0.3)
+        rid = trial % 25
+        want = _host_stream(recs, rid, names)
+        got, total, bad = _device_stream(caller, recs, rid, names)
+        exp = b"".join(want)
+        assert total == len(exp) and bad == 0
+        assert got[:total].tobytes() == exp, (n, "device stream differs from bsc_bcf_record's")
+        # the independent Python encoder on a sample (the host form is pinned to it record by record in tests/test_bcf.py)
+        table = {int(p): names[2][int(names[1][i]) : int(names[1][i + 1])] for i, p in enumerate(names[0])}
+        for j in range(0, n, max(1, n // 40)):
+            r = recs[j]
+            if not r["core"]["emit"]:
+                assert want[j] == b""
+                continue
+            rs = table.get(int(r["core"]["pos"]), b"") if r["rs_found"] else b""
+            assert want[j] == py_bcf.encode_record(TB._as_dict(r), rid, rs)
+            dec = py_bcf.decode_record(want[j])
+            assert dec["pos"] == int(r["core"]["pos"]) and dec["id"] == rs
+    # without a table no record is named, whatever its flag says
+    recs, names = _random_block(rng, 300, named=0.5)
+    got, total, bad = _device_stream(caller, recs, 3, None)
+    assert got[:total].tobytes() == b"".join(_host_stream(recs, 3, None))
+
+
+def test_long_names_and_wide_dictionary_indices_take_the_two_pass_path(caller):
+    """64 records of > 168 bytes each do not fit the wave's image (10 752 bytes): the tile goes out in two halves"""
+    rng = np.random.default_rng(77)
+    recs, names = _random_block(rng, 1500, named=0.9, long_names=True)
+    recs["core"]["emit"] = 1
+    ids = _lib.BcfIds(*[int(v) for v in rng.choice([5, 127, 128, 300, 32767, 32768, 1_000_000], 17)])
+    want = _host_stream(recs, 24, names, ids)
+    sizes = np.array([len(w) for w in want])
+    assert sizes.max() > 230 and sizes[:64].sum() > 10752
+    got, total, bad = _device_stream(caller, recs, 24, names, ids)
+    assert total == sizes.sum() and bad == 0 and got[:total].tobytes() == b"".join(want)
+
+
+def test_counts_capacities_and_refused_records(caller):
+    rng = np.random.default_rng(5)
+    recs, names = _random_block(rng, 1000, named=0.2)
+    want = _host_stream(recs, 1, names)
+    exp = b"".join(want)
+    # the count on the device decides, not the array's size; nothing is written for n = 0
+    got, total, _ = _device_stream(caller, recs, 1, names, n_recs=333)
+    assert got[:total].tobytes() == b"".join(want[:333])
+    got, total, _ = _device_stream(caller, recs, 1, names, n_recs=5000)  # more than the array holds: clamped
+    assert got[:total].tobytes() == exp
+    got, total, _ = _device_stream(caller, recs, 1, names, n_recs=0)
+    assert total == 0
+    got, total, _ = _device_stream(caller, recs[:0], 1, None, max_recs=0)
+    assert total == 0
+    # a capacity that is too small: the full length is reported, what was written is a prefix cut at a 64-record boundary
+    cap = len(exp) // 2
+    got, total, _ = _device_stream(caller, recs, 1, names, cap=cap)
+    assert total == len(exp)
+    ends = np.cumsum([sum(len(w) for w in want[k : k + 64]) for k in range(0, 1000, 64)])
+    whole = int(ends[ends <= cap].max())
+    assert got[:whole].tobytes() == exp[:whole] and (got[whole:] == 0xEE).all()
+    # records bsc_bcf_record refuses are counted
+    bad = recs.copy()
+    bad["core"]["gt"][10] = 12
+    bad["core"]["n_gl"][500] = 7
+    bad["core"]["emit"][[10, 500]] = 1
+    _, _, n_bad = _device_stream(caller, bad, 1, names)
+    assert n_bad == 2
+    # argument checks
+    with pytest.raises(B.BscError):
+        _device_stream(caller, recs, 1, (names[0][::-1].copy(), names[1], names[2]))  # positions must ascend
+
+
+def _reads_block(seed, x, n, cov):
+    from bs_call_amd.reads import synth_block
+
+    tpl, seq, y = synth_block(seed, x, n, cov)
+    ref = B.synth_ref_host(seed, x, y - x + 3)
+    return tpl, seq, y, ref
+
+
+def test_block_bcf_equals_block_records_then_the_host_encoder(caller):
+    x, n = 20_000, 150_000
+    tpl, seq, y, ref = _reads_block(88172645463325252 + 41, x, n, 30)
+    caller.reset_site_stats()
+    recs = caller.block_records(tpl, seq, x, y, ref, with_stats=True).copy()
+    st_want = caller.site_stats().copy()
+    want = vcf.bcf_block(recs, 7)
+    caller.reset_site_stats()
+    for rep in range(3):  # the first call sizes its copy-out after the wait, the later ones ahead of it
+        got, n_rec = caller.block_bcf(tpl, seq, x, y, ref, 7, with_stats=(rep == 0))
+        assert n_rec == len(recs) > 50_000 and got == want
+    from tests.test_gpu_chain import _same_stats
+
+    _same_stats(caller.site_stats().copy(), st_want)  # (the two methylation profiles are float sums of atomics: equal within 1e-12)
+    # every record decodes; positions ascend
+    o, last, k = 0, 0, 0
+    while o < len(got):
+        ln = 8 + int.from_bytes(got[o : o + 4], "little") + int.from_bytes(got[o + 4 : o + 8], "little")
+        if k % 5000 == 0:
+            d = py_bcf.decode_record(got[o : o + ln])
+            assert d["pos"] > last and d["rid"] == 7
+            last = d["pos"]
+        o += ln
+        k += 1
+    assert o == len(got) and k == n_rec
+    # -A: a record for every position
+    recs_all = caller.block_records(tpl, seq, x, y, ref, all_positions=True)
+    got, n_rec = caller.block_bcf(tpl, seq, x, y, ref, 0, all_positions=True)
+    assert n_rec == len(recs_all) >= y - x and got == vcf.bcf_block(recs_all, 0)
+    # out_cap too small: an error that names the size needed, and the context goes on
+    with pytest.raises(B.BscError, match="bytes, out_cap is"):
+        caller.block_bcf(tpl, seq, x, y, ref, 7, cap=len(want) - 1)
+    got, _ = caller.block_bcf(tpl, seq, x, y, ref, 7, cap=len(want))
+    assert got == want
+    # an empty block
+    got, n_rec = caller.block_bcf(tpl[:0], seq[:0], x, x + 99, ref[:102], 7)
+    assert n_rec == 0 and got == b""
+
+
+def test_block_bcf_names_its_records_from_a_dbsnp_index(caller, tmp_path):
+    from bs_call_amd.dbsnp import DbSnpIndex
+
+    spec = importlib.util.spec_from_file_location("make_dbsnp_index", os.path.join(ROOT, "tools", "make_dbsnp_index.py"))
+    W = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(W)
+    x, n = 5_000, 120_000
+    tpl, seq, y, ref = _reads_block(88172645463325252 + 43, x, n, 20)
+    path = str(tmp_path / "names.idx")
+    sites = W.synthetic_sites(x + n + 500, 40)
+    W.write_index(path, {"ctgN": sites})
+    with DbSnpIndex(path) as db:
+        db.load_contig("ctgN")
+        flags = db.flags(x, y - x + 1)
+        names = db.names(x, y - x + 1)
+        # the table is bsc_dbsnp_name's answer for every flagged position of the range
+        assert len(names[0]) == int((flags != 0).sum()) > 1000
+        for i in range(0, len(names[0]), 97):
+            r, nm, ln = db.name(int(names[0][i]))
+            assert r and names[2][int(names[1][i]) : int(names[1][i + 1])] == (nm.encode() + b"\0")[:ln]
+        recs = caller.block_records(tpl, seq, x, y, ref, dbsnp=flags)
+        want = vcf.bcf_block(recs, 2, db)
+        got, n_rec = caller.block_bcf(tpl, seq, x, y, ref, 2, names=names, dbsnp=flags)
+    assert n_rec == len(recs) and int((recs["rs_found"] != 0).sum()) > 500
+    assert got == want
+    assert b"rs" in got
+
+
+def test_block_bcf_raw_equals_block_records_raw_then_the_host_encoder(caller):
+    import test_prep as T
+    from oracle import py_prep
+
+    rng = np.random.default_rng(1234)
+    ts, p0 = [], 3000
+    for i in range(4000):
+        r0, m0, s0 = T._random_read(rng, 20)
+        r1, m1, s1 = T._random_read(rng, 20)
+        p0 += int(rng.integers(0, 5))
+        t = T.tpl((p0, p0 + int(rng.integers(0, s0 + 40))), (s0, s1), (r0, r1), (m0, m1))
+        t["orientation"] = int(rng.integers(0, 2))
+        t["bs_strand"] = int(rng.integers(1, 3))
+        try:
+            py_prep.prepare([t])
+            ts.append(t)
+        except py_prep.PrepError:
+            pass
+    raw, seq, ms = T.to_arrays(ts)
+    kw = dict(left_trim=(1, 0), right_trim=(0, 2), min_qual=20)
+    x = max(1, int(min(p for p in raw["pos"].ravel() if p)) - 2)
+    y = int((raw["pos"].astype(np.int64) + raw["reference_span"]).max()) + 60
+    ref = B.synth_ref_host(11, x, y - x + 3)
+    caller.reset_site_stats()
+    recs, st = caller.block_records_raw(raw, seq, ms, x, y, ref, with_stats=True, **kw)
+    stats = caller.site_stats().copy()
+    want = vcf.bcf_block(recs, 4)
+    caller.reset_site_stats()
+    got, n_rec, st2 = caller.block_bcf_raw(raw, seq, ms, x, y, ref, 4, with_stats=True, **kw)
+    assert n_rec == len(recs) > 1000 and got == want and st2.tobytes() == st.tobytes()
+    from tests.test_gpu_chain import _same_stats
+
+    _same_stats(caller.site_stats().copy(), stats)

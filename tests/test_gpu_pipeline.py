@@ -94,6 +94,10 @@ def test_bam_to_bcf_equals_the_oracle_chain(tmp_path, oracle, tables, libm_exact
     bcf_h, rep_h = str(tmp_path / "host_prep.bcf"), str(tmp_path / "host_prep.json")
     pipeline.run(bam, reference, bcf_h, sample="S1", report_path=rep_h, date=(3, 10, 2026), compressed=False, host_prep=True)
     assert open(bcf_h, "rb").read() == open(bcf, "rb").read() and open(rep_h).read() == open(rep).read()
+    # ... and the BCF encoding too (bsc_block_bcf_raw); with the packed records encoded on the host, the same bytes
+    bcf_e, rep_e = str(tmp_path / "host_bcf.bcf"), str(tmp_path / "host_bcf.json")
+    pipeline.run(bam, reference, bcf_e, sample="S1", report_path=rep_e, date=(3, 10, 2026), compressed=False, host_bcf=True)
+    assert open(bcf_e, "rb").read() == open(bcf, "rb").read() and open(rep_e).read() == open(rep).read()
     assert res["blocks"] >= 2 and res["records"] > 5_000 and res["contigs"] == ["chrA", "chrB"]
     # ---- the oracle chain, encoded by the independent Python encoder ----
     gc = np.zeros((4096, 101), dtype=np.uint64)
@@ -213,5 +217,10 @@ def test_plain_c_bam2bcf_equals_the_python_pipeline(tmp_path):
     assert all((ref2[k] == reference[k]).all() for k in reference)
     res = pipeline.run(bam, ref2, out_p, sample="S9", report_path=rep_p, date=(1, 1, 2000), compressed=False, benchmark_mode=True)
     assert open(out_c, "rb").read() == open(out_p, "rb").read() and res["records"] > 3_000
+    # the C program with the encoder on its own thread (BAM2BCF_HOST_BCF, round 5's first form) writes the same files
+    out_h, rep_h = str(tmp_path / "h.bcf"), str(tmp_path / "h.json")
+    r = subprocess.run([exe, bam, fa, out_h, rep_h, "S9"], capture_output=True, text=True, timeout=300, env=dict(os.environ, BAM2BCF_HOST_BCF="1"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert open(out_h, "rb").read() == open(out_c, "rb").read() and open(rep_h).read() == open(rep_c).read()
     assert open(rep_c).read() == open(rep_p).read()
     assert r.stdout.strip() == "%d blocks, %d records written" % (res["blocks"], res["records"])
