@@ -17,6 +17,8 @@ Default workload = BASELINE.json configs[1] (synthetic chr22-sized contig, 50 Mb
     (reads -> records in one kernel, neither pile-up nor gt_meth in HBM) over device-resident L-reads of the same contig
     (1 B per base + 16 B per template in; 104 B pile-up, or 1 B reference code in + 64 B record out, per
     position), device time from HIP events around all launches of the stage — measured after the timed region.
+  * roofline_bcf (N = 1): the tail of record formation on the device (csrc/bcfdev.hip) over the packed written records of the reads
+    leg's block: 2 x 128 B read + the BCF bytes written per record, events on the launch stream; first records = the host encoder's.
   * every leg also carries `valu`: the fraction of the VALU issue capacity (1 024 SIMDs, one wave-instruction per 4 cycles) its
     kernels use — SQ_INSTS_VALU and the clock from the committed counter passes (profiles/valu.json), the time from this run.
     SURVEY.md 8d names FP64 VALU as the close second bound; for every kernel but bsc_call_kernel it is the one that binds.
@@ -380,6 +382,7 @@ def reads_rooflines(args, caller):
     m = min(chunk, args.sites)
     keep = (m - 400) if args.sites > m else n
     sample = {"x": x, "m": m, "chunk": chunk, "keep": keep, "pile": d_pile[: keep * 104].cpu().numpy(), "core": d_core[: (keep - 8) * 64].cpu().numpy()}
+    bcf_leg = bcf_roofline(caller, d_tpl, len(tpl), d_seq, seq.size, x, y, d_ref, d_core, n, reps, stream)
     bytes_in = R.algorithmic_bytes_in(tpl, seq)
     a_ms, r_ms = float(np.mean(acc_ms)), float(np.mean(rc_ms))
     a_bytes, r_bytes = bytes_in + n * 104, bytes_in + n + n * 64
@@ -430,7 +433,76 @@ def reads_rooflines(args, caller):
             "fraction of the bound that binds.  traffic / algorithmic bytes: the 48-byte summaries are written by one kernel and read by "
             "the next (round 4: 88 bytes, 2.96 x)",
         },
+        "roofline_bcf": bcf_leg,
         "_reads_sample": sample,
+    }
+
+
+def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, reps, stream):
+    """The tail of record formation on the device (csrc/bcfdev.hip): the block's packed written records -> the BCF stream bcf_write would
+    emit for them (reference src/print_vcf.c:160-222,267-378), timed with events on the launch stream; the first records compared with
+    the host encoder's bytes (csrc/bcf.c, pinned record by record to the independent encoder of oracle/py_bcf.py by tests/test_bcf.py)."""
+    import numpy as np
+    import torch
+
+    import bs_call_amd as B
+    from bs_call_amd import vcf
+
+    dev = d_core.device
+    d_aux = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    caller.reads_chain_device(d_tpl.data_ptr(), nr, d_seq.data_ptr(), seq_bytes, x, y, d_ref.data_ptr(), d_core.data_ptr(), d_aux=d_aux.data_ptr(),
+                              with_stats=False, stream=stream)
+    caller.block_status(stream)
+    cap_rec = int(n * 0.75) + 4096
+    d_rec = torch.empty(cap_rec * 128, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    caller.vcf_compact_device(d_core.data_ptr(), d_aux.data_ptr(), 0, n, d_rec.data_ptr(), cap_rec, d_cnt.data_ptr(), stream=stream)
+    n_rec = int(d_cnt.item())
+    del d_aux
+    if n_rec > cap_rec:
+        return {"skipped": "more written records (%d) than the leg's buffer holds (%d)" % (n_rec, cap_rec)}
+    cap = n_rec * 136 + 4096
+    d_bcf = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_tot = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def launch():
+        caller.bcf_block_device(d_rec.data_ptr(), d_cnt.data_ptr(), cap_rec, 0, d_bcf.data_ptr(), cap, d_tot.data_ptr(), stream=stream)
+
+    for _ in range(4):
+        launch()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for k in range(reps):
+        launch()
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]
+    nbytes, refused = int(d_tot[0].item()), int(d_tot[1].item())
+    m = min(200_000, n_rec)
+    want = vcf.bcf_block(d_rec[: m * 128].cpu().numpy().view(B.VCF_REC), 0)
+    same = nbytes <= cap and refused == 0 and d_bcf[: len(want)].cpu().numpy().tobytes() == want
+    k_ms = float(np.mean(ms))
+    alg = n_rec * 128 * 2 + nbytes  # both kernels read the records, the stream is written once
+    return {
+        "bound": "hbm",
+        "kernel": "bsc_bcf_size_kernel + rocPRIM prefix sum + bsc_bcf_write_kernel (bsc_bcf_block_device)",
+        "what": "packed written records (128 B) -> BCF2 records (typed values of src/print_vcf.c:160-222,267-378 behind bcf_write's fixed fields), "
+        "%d records of the reads leg's block, resident in HBM" % n_rec,
+        "achieved": alg / (k_ms * 1e-3) / 1e9,
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "traffic": None,
+        "algorithmic_bytes_per_launch": alg,
+        "bcf_bytes": nbytes,
+        "bytes_per_record": nbytes / max(n_rec, 1),
+        "stage_ms_avg": k_ms,
+        "stage_ms_min": float(np.min(ms)),
+        "records_per_s": n_rec / (k_ms * 1e-3),
+        "positions_per_s": n / (k_ms * 1e-3),
+        "first_records_equal_host_encoder": bool(same),
+        "note": "events of torch's current stream, which is the stream the launches are queued on; the records are read twice (sizes, then bytes)",
     }
 
 

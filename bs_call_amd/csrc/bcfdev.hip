@@ -31,6 +31,9 @@ enum { BT_INT8 = 1, BT_INT16 = 2, BT_INT32 = 3, BT_FLOAT = 5, BT_CHAR = 7 };
 #define BCF_REC_MAX 336u      /* 32 + shared (3 + 63 + 2 + 4 + 5 + 5 + 6) + per-sample (13 keys x 5 + 136): an upper bound of one record */
 #define BCF_IMG_BYTES 10752u  /* the wave's image: 32 records of the longest kind (10 752 = 32 x 336), or 64 ordinary ones */
 #define BCF_WAVES 4u
+#ifndef BCF_WAVES_PER_EU
+#define BCF_WAVES_PER_EU 3 /* the write kernel in 168 registers: three workgroups a CU, what its 43 KB of LDS allow (tools/build_variant_bcf.sh) */
+#endif
 
 struct bcf_args {
   const uint8_t *recs;                /* bsc_vcf_rec[] */
@@ -308,7 +311,7 @@ extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_kernel(bcf_args a
   }
 }
 
-extern "C" __global__ __launch_bounds__(256) void bsc_bcf_write_kernel(bcf_args a, uint32_t n_tiles, const unsigned long long *__restrict__ tile_off,
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BCF_WAVES_PER_EU, BCF_WAVES_PER_EU))) void bsc_bcf_write_kernel(bcf_args a, uint32_t n_tiles, const unsigned long long *__restrict__ tile_off,
                                                                        uint8_t *__restrict__ out, uint64_t out_cap,
                                                                        unsigned long long *__restrict__ total) {
   __shared__ __attribute__((aligned(16))) uint8_t s_img[BCF_WAVES][BCF_IMG_BYTES + 16u];

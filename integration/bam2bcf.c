@@ -189,10 +189,11 @@ int main(int argc, char **argv) {
     bsc_prep_stats st;
     const bsc_vcf_params vp = {0, 1, (uint32_t)codes_len};
     uint64_t n_out = 0, n_bytes = 0;
-    if (!host_bcf) { /* the whole block on the device, the encoding included: room for a record of ordinary length per position */
-      if ((size_t)n * 160 + 4096 > cap_bcf) {
+    if (!host_bcf) { /* the whole block on the device, the encoding included.  Room for 96 bytes per position: a WGBS block writes a
+                      * record of ~113 bytes for every second position; a block that needs more says so and is run again */
+      if ((size_t)n * 96 + 4096 > cap_bcf) {
         bsc_free_host(bcf);
-        bcf = pinned(cap_bcf = ((size_t)n * 160 + 4096) * 2);
+        bcf = pinned(cap_bcf = (size_t)n * 96 + 4096);
       }
       int rc = bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 1, blk.tid, &ids,
                                  NULL, bcf, cap_bcf, &n_bytes, &n_out, &st, &prof);
