@@ -287,3 +287,53 @@ def test_block_bcf_raw_equals_block_records_raw_then_the_host_encoder(caller):
     from tests.test_gpu_chain import _same_stats
 
     _same_stats(caller.site_stats().copy(), stats)
+
+
+def test_encoder_over_a_whole_contig_of_records(caller):
+    """8 M positions at 30x, everything resident in HBM (pile-up -> calling kernel -> record formation -> packing -> encoder): the stream
+    of ALL records equals the host encoder's; walking it from record to record by the two lengths in front of each ends exactly at its
+    end, positions ascending; every 50 000th record decodes (independent reader) to the packed record's fields."""
+    import torch
+
+    n, x0, cov = 8_000_000, 1_000, 30
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    d_cts = torch.empty((n + 2) * 104, dtype=torch.uint8, device=dev)
+    d_ref = torch.empty(n + 2, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(n * 200, dtype=torch.uint8, device=dev)
+    d_skip = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_vcf = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    d_rec = torch.empty(n * 128, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_tot = torch.zeros(2, dtype=torch.int64, device=dev)
+    caller.synth_device(88172645463325252 + 77, x0, n + 2, cov, d_cts.data_ptr(), d_ref.data_ptr(), 0, st)
+    caller.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 200, st)
+    caller.vcf_records_device(d_out.data_ptr(), 200, d_skip.data_ptr(), d_ref.data_ptr(), n, x0, d_vcf.data_ptr(), stream=st)
+    caller.vcf_compact_device(d_vcf.data_ptr(), d_out.data_ptr(), 200, n, d_rec.data_ptr(), n, d_cnt.data_ptr(), stream=st)
+    n_rec = int(d_cnt.item())
+    assert 0.4 * n < n_rec < 0.7 * n
+    cap = n_rec * 140
+    d_bcf = torch.empty(cap, dtype=torch.uint8, device=dev)
+    caller.bcf_block_device(d_rec.data_ptr(), d_cnt.data_ptr(), n, 5, d_bcf.data_ptr(), cap, d_tot.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    total, bad = int(d_tot[0].item()), int(d_tot[1].item())
+    assert bad == 0 and total <= cap
+    got = d_bcf[:total].cpu().numpy()
+    recs = d_rec[: n_rec * 128].cpu().numpy().view(VCF_REC)
+    del d_cts, d_out, d_vcf, d_rec, d_bcf
+    want = vcf.bcf_block(recs, 5)
+    assert len(want) == total and got.tobytes() == want
+    # the walk
+    buf = got.tobytes()
+    o, k, last = 0, 0, 0
+    while o < total:
+        ln = 8 + int.from_bytes(buf[o : o + 4], "little") + int.from_bytes(buf[o + 4 : o + 8], "little")
+        if k % 50_000 == 0:
+            d = py_bcf.decode_record(buf[o : o + ln])
+            r = recs[k]
+            assert d["pos"] == int(r["core"]["pos"]) > last and d["rid"] == 5 and d["fmt"]["MC8"] == [int(v) for v in r["counts"]]
+            assert d["fmt"]["DP"] == [int(r["core"]["dp"])] and d["fmt"]["MQ"] == [int(r["mq"])] and d["qual"] == float(r["core"]["phred"])
+            last = d["pos"]
+        o += ln
+        k += 1
+    assert o == total and k == n_rec
