@@ -458,12 +458,11 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
     d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     caller.vcf_compact_device(d_core.data_ptr(), d_aux.data_ptr(), 0, n, d_rec.data_ptr(), cap_rec, d_cnt.data_ptr(), stream=stream)
     n_rec = int(d_cnt.item())
-    del d_aux
     if n_rec > cap_rec:
         return {"skipped": "more written records (%d) than the leg's buffer holds (%d)" % (n_rec, cap_rec)}
     cap = n_rec * 136 + 4096
     d_bcf = torch.empty(cap, dtype=torch.uint8, device=dev)
-    d_tot = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_tot = torch.zeros(3, dtype=torch.int64, device=dev)
 
     def launch():
         caller.bcf_block_device(d_rec.data_ptr(), d_cnt.data_ptr(), cap_rec, 0, d_bcf.data_ptr(), cap, d_tot.data_ptr(), stream=stream)
@@ -479,6 +478,27 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
     torch.cuda.synchronize()
     ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]
     nbytes, refused = int(d_tot[0].item()), int(d_tot[1].item())
+
+    # the form bsc_block_bcf runs: straight from the chain's per-position arrays, no packing pass — against packing + encoding
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        e[0].record()
+        for k in range(reps):
+            fn()
+            e[k + 1].record()
+        torch.cuda.synchronize()
+        return float(np.mean([e[k].elapsed_time(e[k + 1]) for k in range(reps)]))
+
+    d_bcf2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_tot2 = torch.zeros(3, dtype=torch.int64, device=dev)
+    sites_ms = timed(lambda: caller.bcf_sites_device(d_core.data_ptr(), d_aux.data_ptr(), n, 0, d_bcf2.data_ptr(), cap, d_tot2.data_ptr(), stream=stream))
+    pack_ms = timed(lambda: caller.vcf_compact_device(d_core.data_ptr(), d_aux.data_ptr(), 0, n, d_rec.data_ptr(), cap_rec, d_cnt.data_ptr(), stream=stream))
+    sites_same = int(d_tot2[0].item()) == nbytes and int(d_tot2[2].item()) == n_rec and bool(torch.equal(d_bcf[:nbytes], d_bcf2[:nbytes]))
+    sites_alg = 2 * (16 * n + 112 * n_rec) + nbytes  # both kernels: 16 B of every position, the other 112 of a written record
+    del d_aux, d_bcf2
     m = min(200_000, n_rec)
     want = vcf.bcf_block(d_rec[: m * 128].cpu().numpy().view(B.VCF_REC), 0)
     same = nbytes <= cap and refused == 0 and d_bcf[: len(want)].cpu().numpy().tobytes() == want
@@ -502,6 +522,16 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
         "records_per_s": n_rec / (k_ms * 1e-3),
         "positions_per_s": n / (k_ms * 1e-3),
         "first_records_equal_host_encoder": bool(same),
+        "sites_form": {
+            "kernel": "the same two kernels over the chain's per-position arrays (bsc_bcf_sites_device: what bsc_block_bcf runs), no packing pass",
+            "stage_ms_avg": sites_ms,
+            "algorithmic_bytes_per_launch": sites_alg,
+            "achieved": sites_alg / (sites_ms * 1e-3) / 1e9,
+            "frac": sites_alg / (sites_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "packing_pass_ms_it_replaces": pack_ms,
+            "packing_plus_encoding_ms": pack_ms + k_ms,
+            "same_stream": bool(sites_same),
+        },
         "note": "events of torch's current stream, which is the stream the launches are queued on; the records are read twice (sizes, then bytes)",
     }
 

@@ -61,6 +61,7 @@ EXPORTS = (
     "bsc_bcf_record",
     "bsc_bcf_block",
     "bsc_bcf_block_device",
+    "bsc_bcf_sites_device",
     "bsc_block_bcf",
     "bsc_block_bcf_raw",
     "bsc_dbsnp_names",
@@ -370,6 +371,8 @@ def load():
                                     C.POINTER(u64), C.POINTER(u64), vp, vp]
     L.bsc_bcf_block_device.restype = i32
     L.bsc_bcf_block_device.argtypes = [vp, vp, vp, u64, i32, C.POINTER(BcfIds), vp, vp, u64, vp, vp]
+    L.bsc_bcf_sites_device.restype = i32
+    L.bsc_bcf_sites_device.argtypes = [vp, vp, vp, u32, i32, C.POINTER(BcfIds), vp, vp, u64, vp, vp]
     L.bsc_dbsnp_names.restype = i32
     L.bsc_dbsnp_names.argtypes = [vp, u32, u32, vp, vp, vp, u32, u64, C.POINTER(u32), C.POINTER(u64)]
     L.bsc_template_walk_flags.restype = u32

@@ -485,6 +485,16 @@ class SiteCaller:
                                             out_cap, d_totals, stream))
         del keep
 
+    def bcf_sites_device(self, d_core, d_aux, n, rid, d_out, out_cap, d_totals, names=None, ids=None, stream=None):
+        """bsc_bcf_sites_device: the per-position arrays of reads_chain_device (d_core, d_aux) -> the BCF stream, no packing pass."""
+        if ids is None:
+            ids = _lib.BcfIds()
+            self._L.bsc_bcf_default_ids(C.byref(ids))
+        nm, keep = self._bcf_names(names)
+        _check(self._L.bsc_bcf_sites_device(self._h, d_core, d_aux, n, rid, C.byref(ids), None if nm is None else C.addressof(nm), d_out, out_cap,
+                                            d_totals, stream))
+        del keep
+
     def blocks_records(self, blocks, ref, out=None, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False,
                        submit_only=False):
         """Several blocks in one launch sequence (bsc_blocks_records): blocks = [(templates, seq, x, y), ...] in genome order;

@@ -15,6 +15,11 @@
  *                          head and tail byte by byte (the neighbouring tiles own the other bytes of those chunks).  A tile whose
  *                          span does not fit the image (> 64 x 160 bytes: long IDs, wide dictionary indices) goes out in two halves.
  *
+ * Two sources: packed records (bsc_vcf_compact_device's output; bsc_bcf_block_device), or the per-position arrays the reads-in chain leaves
+ * (bsc_vcf_core + the 64-byte aux array that is the packed record's second half; bsc_bcf_sites_device, and what bsc_block_bcf runs): the
+ * tiles are then tiles of 64 POSITIONS, a lane whose position writes no record reads its 16 first bytes and has length 0 — the packing
+ * pass (128 bytes written and read again per record) does not run at all.
+ *
  * Names: the dbSNP name of a record whose rs_found flag is set comes from a table of the block's flagged positions (sorted
  * positions, offsets, bytes: bsc_dbsnp_names on the host, uploaded with the block) by binary search; a flagged record the table
  * does not list has no ID, as in bsc_bcf_block when bsc_dbsnp_name finds nothing.
@@ -36,9 +41,10 @@ enum { BT_INT8 = 1, BT_INT16 = 2, BT_INT32 = 3, BT_FLOAT = 5, BT_CHAR = 7 };
 #endif
 
 struct bcf_args {
-  const uint8_t *recs;                /* bsc_vcf_rec[] */
-  const unsigned long long *n_recs;   /* device: how many of them */
-  uint64_t max_recs;                  /* never more than this (the array's size) */
+  const uint8_t *recs;                /* bsc_vcf_rec[] — or NULL: the records are taken where the chain left them, */
+  const uint8_t *core, *aux;          /* bsc_vcf_core[] and the chain's aux array (64 B per position: the second half of a bsc_vcf_rec) */
+  const unsigned long long *n_recs;   /* device: how many records / positions (NULL: max_recs of them) */
+  uint64_t max_recs;                  /* never more than this (the arrays' size) */
   int32_t rid;
   bsc_bcf_ids ids;
   const uint32_t *name_pos;           /* n_names sorted 1-based positions, or NULL */
@@ -244,16 +250,25 @@ __device__ __forceinline__ void bcf_emit_fixed(uint8_t *p, const rec_regs &r, co
   f.le(n_fmt << 24 | 1u, 4u);    /* one sample */
 }
 
-__device__ __forceinline__ void load_rec(rec_regs &r, const uint8_t *recs, uint64_t i) {
-  const uint4 *src = reinterpret_cast<const uint4 *>(recs + i * 128u);
+/* record / position i into registers; false: nothing is written for it (emit == 0).  A position that writes no record costs its
+ * first 16 bytes only. */
+__device__ __forceinline__ bool load_rec(rec_regs &r, const bcf_args &a, uint64_t i) {
+  const uint4 *lo = reinterpret_cast<const uint4 *>(a.recs ? a.recs + i * 128u : a.core + i * 64u);
+  const uint4 v0 = lo[0];
+  r.w[0] = v0.x; r.w[1] = v0.y; r.w[2] = v0.z; r.w[3] = v0.w;
+  if (!(v0.y & 0xffu)) return false; /* bsc_vcf_core.emit */
+  const uint4 *hi = a.recs ? lo + 4 : reinterpret_cast<const uint4 *>(a.aux + i * 64u);
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const uint4 v = src[k];
-    r.w[4 * k] = v.x;
-    r.w[4 * k + 1] = v.y;
-    r.w[4 * k + 2] = v.z;
-    r.w[4 * k + 3] = v.w;
+  for (int k = 1; k < 4; k++) {
+    const uint4 v = lo[k];
+    r.w[4 * k] = v.x; r.w[4 * k + 1] = v.y; r.w[4 * k + 2] = v.z; r.w[4 * k + 3] = v.w;
   }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint4 v = hi[k];
+    r.w[16 + 4 * k] = v.x; r.w[17 + 4 * k] = v.y; r.w[18 + 4 * k] = v.z; r.w[19 + 4 * k] = v.w;
+  }
+  return true;
 }
 
 /* the name of a flagged record: binary search of its position in the block's table */
@@ -274,6 +289,7 @@ __device__ __forceinline__ unsigned find_name(const bcf_args &a, const rec_regs 
 }
 
 __device__ __forceinline__ uint64_t clamp_n(const bcf_args &a) {
+  if (!a.n_recs) return a.max_recs;
   const unsigned long long n = *a.n_recs;
   return n < a.max_recs ? n : a.max_recs;
 }
@@ -284,20 +300,21 @@ __device__ __forceinline__ unsigned rec_len(const bcf_args &a, uint64_t i, uint6
   id_len = 0;
   id = nullptr;
   if (i >= n) return 0u;
-  load_rec(r, a.recs, i);
-  if (!r.byte(4)) return 0u; /* emit */
+  if (!load_rec(r, a, i)) return 0u;
   id_len = find_name(a, r, id);
   count_sink c = {0u};
   (void)bcf_emit_body(c, r, a, id, id_len, bad);
   return 32u + c.len;
 }
 
-/* n_tiles = tiles of max_recs; tile_bytes[n_tiles] = 0 (so that the scan's last output is the stream's length) */
+/* n_tiles = tiles of max_recs; tile_bytes[n_tiles] = 0 (so that the scan's last output is the stream's length); err[0] += records
+ * refused, err[1] += records written */
 extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_kernel(bcf_args a, uint32_t n_tiles, unsigned long long *__restrict__ tile_bytes,
                                                                       unsigned long long *__restrict__ err) {
   const unsigned lane = threadIdx.x & 63u;
   const uint64_t n = clamp_n(a);
   if (blockIdx.x == 0 && threadIdx.x == 0) tile_bytes[n_tiles] = 0ull;
+  unsigned n_written = 0; /* wave-uniform */
   for (uint32_t tile = blockIdx.x * BCF_WAVES + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * BCF_WAVES) {
     rec_regs r;
     const uint8_t *id;
@@ -305,10 +322,12 @@ extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_kernel(bcf_args a
     bool bad;
     unsigned len = rec_len(a, (uint64_t)tile * 64u + lane, n, r, id, id_len, bad);
     if (bad) atomicAdd(err, 1ull);
+    n_written += (unsigned)__popcll(__ballot(len != 0u));
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) len += __shfl_xor(len, d);
     if (lane == 0) tile_bytes[tile] = len;
   }
+  if (lane == 0 && n_written) atomicAdd(err + 1, (unsigned long long)n_written); /* totals[2]: once per wave — one word cannot take an atomic per tile */
 }
 
 extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BCF_WAVES_PER_EU, BCF_WAVES_PER_EU))) void bsc_bcf_write_kernel(bcf_args a, uint32_t n_tiles, const unsigned long long *__restrict__ tile_off,
@@ -375,16 +394,20 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
 extern "C" int bsc_dev_scan_u64(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
 
 /*
- * recs[<= max_recs] packed records, *n_recs of them (device u64) -> out[<= out_cap] BCF bytes; totals[0] = the stream's length
- * (also when it exceeds out_cap: then only the tiles that fit whole are written), totals[1] += records bsc_bcf_record refuses.
- * tile_bytes / tile_off: max_recs / 64 (rounded up) + 1 u64 each; scan_tmp: bsc_dev_scan_tmp_bytes_u64 of that many.
+ * recs[<= max_recs] packed records, *n_recs of them (device u64) — or, recs == NULL, core[max_recs] / aux[max_recs] as the reads-in chain
+ * leaves them (n_recs may then be NULL: every position) — -> out[<= out_cap] BCF bytes; totals[0] = the stream's length (also when it
+ * exceeds out_cap: then only the tiles that fit whole are written), totals[1] += records bsc_bcf_record refuses, totals[2] += records
+ * written.  tile_bytes / tile_off: max_recs / 64 (rounded up) + 1 u64 each; scan_tmp: bsc_dev_scan_tmp_bytes_u64 of that many.
  */
-extern "C" int bsc_dev_launch_bcf(const void *recs, const void *n_recs, uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids, const void *name_pos,
-                                  const void *name_off, const void *name_bytes, uint32_t n_names, void *tile_bytes, void *tile_off, void *scan_tmp,
-                                  size_t scan_tmp_bytes, void *out, uint64_t out_cap, void *totals, int num_cus, void *stream) {
+extern "C" int bsc_dev_launch_bcf(const void *recs, const void *core, const void *aux, const void *n_recs, uint64_t max_recs, int32_t rid,
+                                  const bsc_bcf_ids *ids, const void *name_pos, const void *name_off, const void *name_bytes, uint32_t n_names,
+                                  void *tile_bytes, void *tile_off, void *scan_tmp, size_t scan_tmp_bytes, void *out, uint64_t out_cap, void *totals,
+                                  int num_cus, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   bcf_args a;
   a.recs = (const uint8_t *)recs;
+  a.core = (const uint8_t *)core;
+  a.aux = (const uint8_t *)aux;
   a.n_recs = (const unsigned long long *)n_recs;
   a.max_recs = max_recs;
   a.rid = rid;

@@ -71,9 +71,10 @@ int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq, uint64_t 
                         size_t scan_tmp_bytes, void *tpl_out, void *seq_out, uint64_t seq_out_cap, void *cnt, int num_cus, void *stream,
                         const void *prof_ref, uint32_t prof_x, uint32_t prof_n_ref, uint32_t prof_cap, uint32_t prof_used0, void *prof_table,
                         void *max_pos1, void *used_scan);
-int bsc_dev_launch_bcf(const void *recs, const void *n_recs, uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids, const void *name_pos,
-                       const void *name_off, const void *name_bytes, uint32_t n_names, void *tile_bytes, void *tile_off, void *scan_tmp,
-                       size_t scan_tmp_bytes, void *out, uint64_t out_cap, void *totals, int num_cus, void *stream); /* bcfdev.hip */
+int bsc_dev_launch_bcf(const void *recs, const void *core, const void *aux, const void *n_recs, uint64_t max_recs, int32_t rid,
+                       const bsc_bcf_ids *ids, const void *name_pos, const void *name_off, const void *name_bytes, uint32_t n_names,
+                       void *tile_bytes, void *tile_off, void *scan_tmp, size_t scan_tmp_bytes, void *out, uint64_t out_cap, void *totals,
+                       int num_cus, void *stream); /* bcfdev.hip */
 int bsc_dev_launch_ref_pad(const void *packed, const void *d_blk, uint32_t n_blk, void *padded, uint32_t n_pos, int num_cus, void *stream);
 int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk, uint32_t n_blk,
                                    uint32_t n_bins, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
@@ -1634,30 +1635,31 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
 }
 
 /* ---- the BCF stream of packed records, encoded on the device (bcfdev.hip) ----------------------------------- */
-int bsc_bcf_block_device(bsc_context *ctx, const void *d_recs, const void *d_n_recs, uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids,
-                         const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream) {
-  if (!ctx || !d_n_recs || !ids || !d_totals || (max_recs && !d_recs) || (out_cap && !d_out))
-    return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: NULL argument");
-  if (((uintptr_t)d_recs & 15u) || ((uintptr_t)d_n_recs & 7u) || ((uintptr_t)d_totals & 7u))
-    return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: d_recs must be 16-byte, d_n_recs / d_totals 8-byte aligned");
-  if (max_recs > 0x1fffffffc0ull) return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: more than 2^37 records");
+/* d_recs != NULL: packed records, *d_n_recs of them; else d_core / d_aux: the per-position arrays of the reads-in chain, max_recs positions */
+static int bsc_bcf_encode(bsc_context *ctx, const char *who, const void *d_recs, const void *d_core, const void *d_aux, const void *d_n_recs,
+                          uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, void *d_out, uint64_t out_cap,
+                          void *d_totals, void *stream) {
+  if (!ctx || !ids || !d_totals || (out_cap && !d_out)) return bsc_fail(BSC_ERR_ARG, "%s: NULL argument", who);
+  if (d_recs ? !d_n_recs : (max_recs && (!d_core || !d_aux))) return bsc_fail(BSC_ERR_ARG, "%s: NULL argument", who);
+  if (((uintptr_t)d_recs & 15u) || ((uintptr_t)d_core & 15u) || ((uintptr_t)d_aux & 15u) || ((uintptr_t)d_n_recs & 7u) || ((uintptr_t)d_totals & 7u))
+    return bsc_fail(BSC_ERR_ARG, "%s: the records must be 16-byte, the count and the totals 8-byte aligned", who);
+  if (max_recs > 0x1fffffffc0ull) return bsc_fail(BSC_ERR_ARG, "%s: more than 2^37 records", who);
   uint32_t n_names = 0;
   uint64_t name_bytes = 0;
   if (names && names->n) {
-    if (!names->pos || !names->off || (!names->bytes && names->off[names->n]))
-      return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: a names table with NULL arrays");
+    if (!names->pos || !names->off || (!names->bytes && names->off[names->n])) return bsc_fail(BSC_ERR_ARG, "%s: a names table with NULL arrays", who);
     n_names = names->n;
     name_bytes = names->off[n_names];
     for (uint32_t i = 0; i < n_names; i++) {
       if (names->off[i] > names->off[i + 1] || (i && names->pos[i] <= names->pos[i - 1]))
-        return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: names table entry %u: positions must ascend, offsets must not descend", i);
+        return bsc_fail(BSC_ERR_ARG, "%s: names table entry %u: positions must ascend, offsets must not descend", who, i);
     }
   }
   BSC_ENTER(ctx);
   hipStream_t s = (hipStream_t)stream;
   const uint32_t n_tiles = (uint32_t)((max_recs + 63u) / 64u);
   size_t scan_bytes = 0;
-  if (bsc_dev_scan_tmp_bytes_u64(n_tiles + 1u, &scan_bytes)) return bsc_fail(BSC_ERR_HIP, "bsc_bcf_block_device: scan size query failed");
+  if (bsc_dev_scan_tmp_bytes_u64(n_tiles + 1u, &scan_bytes)) return bsc_fail(BSC_ERR_HIP, "%s: scan size query failed", who);
   int rc;
   if ((rc = bsc_reserve(&ctx->d_btb, &ctx->cap_btb, ((size_t)n_tiles + 1u) * 8u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_bto, &ctx->cap_bto, ((size_t)n_tiles + 1u) * 8u))) return rc;
@@ -1673,11 +1675,24 @@ int bsc_bcf_block_device(bsc_context *ctx, const void *d_recs, const void *d_n_r
     d_off = (char *)ctx->d_bnm + o_off;
     d_nb = (char *)ctx->d_bnm + o_by;
   }
-  HIP_TRY(hipMemsetAsync(d_totals, 0, 2 * sizeof(unsigned long long), s));
-  const int e = bsc_dev_launch_bcf(d_recs, d_n_recs, max_recs, rid, ids, d_pos, d_off, d_nb, n_names, ctx->d_btb, ctx->d_bto, ctx->d_bscn, scan_bytes,
-                                   d_out, out_cap, d_totals, ctx->num_cus, stream);
+  HIP_TRY(hipMemsetAsync(d_totals, 0, 3 * sizeof(unsigned long long), s));
+  const int e = bsc_dev_launch_bcf(d_recs, d_core, d_aux, d_n_recs, max_recs, rid, ids, d_pos, d_off, d_nb, n_names, ctx->d_btb, ctx->d_bto, ctx->d_bscn,
+                                   scan_bytes, d_out, out_cap, d_totals, ctx->num_cus, stream);
   if (e) return bsc_fail(BSC_ERR_HIP, "BCF encoder launch failed: %s", hipGetErrorString((hipError_t)e));
   return BSC_OK;
+}
+
+int bsc_bcf_block_device(bsc_context *ctx, const void *d_recs, const void *d_n_recs, uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids,
+                         const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream) {
+  if (!d_n_recs || (max_recs && !d_recs)) return bsc_fail(BSC_ERR_ARG, "bsc_bcf_block_device: NULL argument");
+  /* (no records at all: the per-position form over zero positions — nothing is read) */
+  return bsc_bcf_encode(ctx, "bsc_bcf_block_device", d_recs, NULL, NULL, d_recs ? d_n_recs : NULL, max_recs, rid, ids, names, d_out, out_cap, d_totals,
+                        stream);
+}
+
+int bsc_bcf_sites_device(bsc_context *ctx, const void *d_core, const void *d_aux, uint32_t n, int32_t rid, const bsc_bcf_ids *ids,
+                         const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream) {
+  return bsc_bcf_encode(ctx, "bsc_bcf_sites_device", NULL, d_core, d_aux, NULL, n, rid, ids, names, d_out, out_cap, d_totals, stream);
 }
 
 /* what bsc_block_bcf asks of bsc_records_queue: the encoder behind the packing, its stream instead of the records on the way back */
@@ -1715,11 +1730,11 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   const uint32_t sz = (uint32_t)sz64;
   BSC_ENTER(ctx);
   int rc;
-  if (bcf) { /* the records stay in HBM (room for one per position); their stream goes back */
+  if (bcf) { /* no packed records at all: the encoder reads the chain's per-position arrays; the block's stream goes back */
     out = NULL;
-    out_cap = sz;
+    out_cap = 0;
     if ((rc = bsc_reserve(&ctx->d_bcf, &ctx->cap_bcf, (size_t)(bcf->out_cap ? bcf->out_cap : 1)))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_btot, &ctx->cap_btot, 2 * sizeof(unsigned long long)))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_btot, &ctx->cap_btot, 3 * sizeof(unsigned long long)))) return rc;
   }
   if (!resident) {
     if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
@@ -1767,16 +1782,16 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
                                   ctx->d_out, s)))
     return rc;
   unsigned long long *d_total = ctx->d_counters + BSC_CNT_RECORDS;
-  if ((rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 0, d_db, sz, ctx->d_recs, out_cap, d_total, s))) return rc;
+  if (!bcf && (rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 0, d_db, sz, ctx->d_recs, out_cap, d_total, s))) return rc;
   /* INEXACT, ERR, RECORDS are consecutive counter words: the verdict and the count in one small copy */
   HIP_TRY(hipMemcpyAsync(ctx->h_cnt, ctx->d_counters + BSC_CNT_INEXACT, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   ctx->rec_out = out;
   ctx->rec_cap = out_cap;
   ctx->rec_sz = sz;
   ctx->bcf_out = NULL;
-  if (bcf) { /* the encoder reads the count where the packing left it; {length, refused} come back behind the verdict */
-    if ((rc = bsc_bcf_block_device(ctx, ctx->d_recs, d_total, sz, bcf->rid, bcf->ids, bcf->names, ctx->d_bcf, bcf->out_cap, ctx->d_btot, s))) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->h_cnt + 4, ctx->d_btot, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  if (bcf) { /* the encoder takes the records where the chain left them (no packing pass); {length, refused, records} come back behind the verdict */
+    if ((rc = bsc_bcf_sites_device(ctx, ctx->d_vout, ctx->d_out, sz, bcf->rid, bcf->ids, bcf->names, ctx->d_bcf, bcf->out_cap, ctx->d_btot, s))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_cnt + 4, ctx->d_btot, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     uint64_t guess = ctx->bcf_share > 0.0 ? (uint64_t)((double)sz * ctx->bcf_share) + 65536u : 0u;
     if (guess > bcf->out_cap) guess = bcf->out_cap;
     if (guess) HIP_TRY(hipMemcpyAsync(bcf->out, ctx->d_bcf, (size_t)guess, hipMemcpyDeviceToHost, s));
@@ -1794,7 +1809,7 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   return BSC_OK;
 }
 
-/* bsc_records_finish for a block whose stream comes back (bsc_block_bcf): h_cnt[4] = its length, h_cnt[5] = records refused */
+/* bsc_records_finish for a block whose stream comes back (bsc_block_bcf): h_cnt[4] = its length, h_cnt[5] = records refused, h_cnt[6] = records */
 static int bsc_bcf_finish(bsc_context *ctx, uint8_t *out, int inexact) {
   const unsigned long long bytes = ctx->h_cnt[4], bad = ctx->h_cnt[5];
   ctx->bcf_bytes = bytes;
@@ -1821,7 +1836,7 @@ static int bsc_records_finish(bsc_context *ctx, uint64_t *n_out) {
   int inexact = 0;
   int rc = bsc_verdict(ctx, ctx->h_cnt, &inexact); /* h_cnt = {INEXACT, ERR, RECORDS} */
   if (rc) return rc; /* an invalid template: the contents of `out` are unspecified */
-  const unsigned long long total = ctx->h_cnt[2];
+  const unsigned long long total = bcf_out ? ctx->h_cnt[6] : ctx->h_cnt[2]; /* the encoder counts the records it writes */
   *n_out = total;
   if (bcf_out) return bsc_bcf_finish(ctx, bcf_out, inexact);
   if (total > ctx->rec_cap)

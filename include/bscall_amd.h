@@ -667,10 +667,12 @@ int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_
  *                            1-based positions, off[n + 1] offsets into bytes; bsc_dbsnp_names fills one from the loaded contig.  A
  *                            record whose rs_found flag is set and whose position the table lists carries that ID (at most 63 bytes of it)
  *   bsc_bcf_block_device     d_recs[<= max_recs] packed records in HBM, *d_n_recs of them (a device u64: the count bsc_vcf_compact_device
- *                            left) -> d_out[<= out_cap] bytes; d_totals = two device u64 {length of the stream, records bsc_bcf_record
- *                            refuses (gt > 9 or n_gl > 6: counted, written with the values clamped)}; a stream longer than out_cap is
- *                            cut at a 64-record boundary, its full length still in d_totals[0].  Asynchronous on `stream`
- *   bsc_block_bcf[_raw]      bsc_block_records[_raw] with the encoder behind the packing: out[out_cap] receives the block's BCF bytes,
+ *                            left) -> d_out[<= out_cap] bytes; d_totals = three device u64 {length of the stream, records bsc_bcf_record
+ *                            refuses (gt > 9 or n_gl > 6: counted, written with the values clamped), records written}; a stream longer
+ *                            than out_cap is cut at a 64-record boundary, its full length still in d_totals[0].  Asynchronous on `stream`
+ *   bsc_bcf_sites_device     the same from the per-position arrays bsc_reads_chain_device leaves — d_core[n] and d_aux[n] (64 bytes each
+ *                            per position, 16-byte aligned) — with no packing pass in between: a position without a record costs 16 bytes
+ *   bsc_block_bcf[_raw]      bsc_block_records[_raw] with the encoder in the packing's place: out[out_cap] receives the block's BCF bytes,
  *                            *n_bytes their number (BSC_ERR_ARG and the number needed when out_cap is too small), *n_records the records
  *                            in them; one wait per block as before
  */
@@ -685,6 +687,8 @@ typedef struct {
 int bsc_dbsnp_names(const struct bsc_dbsnp *db, uint32_t x0, uint32_t n, uint32_t *pos, uint32_t *off, char *bytes, uint32_t cap_names,
                     uint64_t cap_bytes, uint32_t *n_names, uint64_t *n_bytes);
 int bsc_bcf_block_device(bsc_context *ctx, const void *d_recs, const void *d_n_recs, uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids,
+                         const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream);
+int bsc_bcf_sites_device(bsc_context *ctx, const void *d_core, const void *d_aux, uint32_t n, int32_t rid, const bsc_bcf_ids *ids,
                          const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream);
 int bsc_block_bcf(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
                   const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids,

@@ -59,7 +59,7 @@ def _device_stream(caller, recs, rid, names=None, ids=None, cap=None, n_recs=Non
     d_n = torch.tensor([n], dtype=torch.int64, device=dev)
     cap = 336 * max(len(recs), 1) if cap is None else cap
     d_out = torch.full((max(cap, 1) + 64,), 0xEE, dtype=torch.uint8, device=dev)
-    d_tot = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_tot = torch.zeros(3, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     caller.bcf_block_device(d_recs.data_ptr(), d_n.data_ptr(), len(recs) if max_recs is None else max_recs, rid, d_out.data_ptr(), cap,
                             d_tot.data_ptr(), names=names, ids=ids, stream=st)
@@ -226,6 +226,52 @@ def test_block_bcf_equals_block_records_then_the_host_encoder(caller):
     assert n_rec == 0 and got == b""
 
 
+def test_sites_form_equals_packing_then_encoding(caller):
+    """bsc_bcf_sites_device: the per-position arrays the reads-in chain leaves (records + the packed half) -> the stream, no packing pass;
+    the bytes of bsc_vcf_compact_device + bsc_bcf_block_device and of the host encoder over the packed records, with names, for block
+    lengths around the 64-position tiles."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(99)
+    for x, n_sites in ((7_000, 64), (7_000, 1_000), (123_457, 70_001)):
+        tpl, seq, y, ref = _reads_block(88172645463325252 + 47 + n_sites, x, n_sites, 25)
+        n = y - x + 1
+        flags = (rng.random(n) < 0.02).astype(np.uint8) * rng.choice(np.array([1, 3], dtype=np.uint8), n)
+        listed = np.flatnonzero(flags)[::2] + x  # every second flagged position has a name
+        nm = [b"rs%d" % int(v) for v in rng.integers(1, 10**8, len(listed))]
+        off = np.concatenate([[0], np.cumsum([len(b) for b in nm])]).astype(np.uint32)
+        names = (listed.astype(np.uint32), off, b"".join(nm))
+        d_tpl = torch.from_numpy(tpl.view(np.uint8).reshape(-1).copy()).to(dev)
+        d_seq = torch.from_numpy(seq).to(dev)
+        d_ref = torch.from_numpy(ref).to(dev)
+        d_db = torch.from_numpy(flags).to(dev)
+        d_core = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        d_aux = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        caller.reads_chain_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), seq.size, x, y, d_ref.data_ptr(), d_core.data_ptr(), d_aux=d_aux.data_ptr(),
+                                  d_dbsnp=d_db.data_ptr(), stream=st)
+        caller.block_status(st)
+        d_rec = torch.empty(n * 128, dtype=torch.uint8, device=dev)
+        d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        caller.vcf_compact_device(d_core.data_ptr(), d_aux.data_ptr(), 0, n, d_rec.data_ptr(), n, d_cnt.data_ptr(), stream=st)
+        n_rec = int(d_cnt.item())
+        recs = d_rec[: n_rec * 128].cpu().numpy().view(VCF_REC)
+        want = b"".join(_host_stream(recs, 9, names))
+        cap = len(want) + 100
+        d_out = torch.full((cap + 64,), 0xEE, dtype=torch.uint8, device=dev)
+        d_tot = torch.zeros(3, dtype=torch.int64, device=dev)
+        caller.bcf_sites_device(d_core.data_ptr(), d_aux.data_ptr(), n, 9, d_out.data_ptr(), cap, d_tot.data_ptr(), names=names, stream=st)
+        torch.cuda.synchronize()
+        tot = d_tot.cpu().numpy()
+        out = d_out.cpu().numpy()
+        assert int(tot[0]) == len(want) and int(tot[1]) == 0 and int(tot[2]) == n_rec > 0, (n_sites, tot, n_rec)
+        assert out[: len(want)].tobytes() == want and (out[len(want) :] == 0xEE).all(), n_sites
+        assert int((recs["rs_found"] != 0).sum()) > 0 or n_sites < 1000
+        got2, total2, _ = _device_stream(caller, recs, 9, names)
+        assert got2[:total2].tobytes() == want
+
+
 def test_block_bcf_names_its_records_from_a_dbsnp_index(caller, tmp_path):
     from bs_call_amd.dbsnp import DbSnpIndex
 
@@ -305,7 +351,7 @@ def test_encoder_over_a_whole_contig_of_records(caller):
     d_vcf = torch.empty(n * 64, dtype=torch.uint8, device=dev)
     d_rec = torch.empty(n * 128, dtype=torch.uint8, device=dev)
     d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-    d_tot = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_tot = torch.zeros(3, dtype=torch.int64, device=dev)
     caller.synth_device(88172645463325252 + 77, x0, n + 2, cov, d_cts.data_ptr(), d_ref.data_ptr(), 0, st)
     caller.call_sites_device(d_cts.data_ptr(), d_ref.data_ptr(), n, d_out.data_ptr(), d_skip.data_ptr(), 200, st)
     caller.vcf_records_device(d_out.data_ptr(), 200, d_skip.data_ptr(), d_ref.data_ptr(), n, x0, d_vcf.data_ptr(), stream=st)

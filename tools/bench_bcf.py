@@ -44,7 +44,7 @@ with B.SiteCaller() as c:
     del d_out, d_vcf, d_skip
     cap = n_rec * 160 + 4096
     d_bcf = torch.empty(cap, dtype=torch.uint8, device=dev)
-    d_tot = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_tot = torch.zeros(3, dtype=torch.int64, device=dev)
     for _ in range(3):
         c.bcf_block_device(d_rec.data_ptr(), d_cnt.data_ptr(), n, 0, d_bcf.data_ptr(), cap, d_tot.data_ptr(), stream=st)
     torch.cuda.synchronize()
