@@ -438,6 +438,19 @@ def reads_rooflines(args, caller):
     }
 
 
+def bcf_traffic(n_rec):
+    """HBM bytes per launch of the encoder from the committed PMC passes (profiles/traffic.json["bcf"], tools/pmc_bcf.sh): measured per
+    record at configs[1] size, scaled to this block's record count; None once csrc/bcfdev.hip has changed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            v = json.load(f).get("bcf")
+        if not v or v.get("kernel_source_sha256_16") != kernel_source_hash(("bcfdev.hip",)):
+            return None
+        return int(v["hbm_bytes_per_record"] * n_rec)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, reps, stream):
     """The tail of record formation on the device (csrc/bcfdev.hip): the block's packed written records -> the BCF stream bcf_write would
     emit for them (reference src/print_vcf.c:160-222,267-378), timed with events on the launch stream; the first records compared with
@@ -513,7 +526,7 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-        "traffic": None,
+        "traffic": bcf_traffic(n_rec),
         "algorithmic_bytes_per_launch": alg,
         "bcf_bytes": nbytes,
         "bytes_per_record": nbytes / max(n_rec, 1),

@@ -162,6 +162,36 @@ def test_c_abi_rejects_bad_arguments():
         assert L.bsc_block_fetch(h, None, None) == 0 and img.array[: y - x + 1, :200].tobytes() == out2.tobytes()
         img.free()
         sk.free()
+        # round 5's BCF entries: the encoder on the device, from packed records, from the chain's arrays, as a whole block
+        ids = _lib.BcfIds()
+        L.bsc_bcf_default_ids(C.byref(ids))
+        d_rec = torch.zeros(256 * 128 + 64, dtype=torch.uint8, device="cuda:0")
+        d_cntb = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        d_bo = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda:0")
+        BD, BS = L.bsc_bcf_block_device, L.bsc_bcf_sites_device
+        b_ok = (h, d_rec.data_ptr(), d_cntb.data_ptr(), 256, 0, C.byref(ids), None, d_bo.data_ptr(), 1 << 16, d_cntb.data_ptr() + 8, st)
+        assert BD(*b_ok) == 0 and L.bsc_synchronize(h) == 0  # zero records: an empty stream
+        assert BD(h, None, *b_ok[2:]) == -1 and BD(*b_ok[:2], None, *b_ok[3:]) == -1 and BD(*b_ok[:5], None, *b_ok[6:]) == -1
+        assert BD(*b_ok[:7], None, *b_ok[8:]) == -1 and BD(*b_ok[:9], None, st) == -1
+        assert BD(h, d_rec.data_ptr() + 8, *b_ok[2:]) == -1 and "align" in err()
+        assert BD(*b_ok[:2], d_cntb.data_ptr() + 4, *b_ok[3:]) == -1 and "align" in err()
+        bad_names = _lib.BcfNames(None, None, None, 3)
+        assert BD(*b_ok[:6], C.addressof(bad_names), *b_ok[7:]) == -1 and "names table" in err()
+        s_ok = (h, d_core.data_ptr(), d_core.data_ptr(), 100, 0, C.byref(ids), None, d_bo.data_ptr(), 1 << 16, d_cntb.data_ptr() + 8, st)
+        assert BS(h, None, *s_ok[2:]) == -1 and BS(*s_ok[:2], None, *s_ok[3:]) == -1 and BS(h, d_core.data_ptr() + 4, *s_ok[2:]) == -1
+        nb, nrb = C.c_uint64(7), C.c_uint64(7)
+        blob = np.zeros(200 * (y - x + 1), dtype=np.uint8)
+        BB = L.bsc_block_bcf
+        k_ok = (h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, 1, C.byref(ids), None, p(blob), len(blob), C.byref(nb), C.byref(nrb))
+        assert BB(*k_ok) == 0 and nrb.value == cnt.value and 90 * nrb.value < nb.value < 140 * nrb.value
+        assert BB(*k_ok[:12], None, *k_ok[13:]) == -1 and BB(*k_ok[:14], None, *k_ok[15:]) == -1 and BB(*k_ok[:16], None, C.byref(nrb)) == -1
+        assert BB(*k_ok[:7], None, *k_ok[8:]) == -1 and nb.value == 0 and nrb.value == 0  # a refused call leaves no stale sizes behind
+        assert BB(*k_ok[:5], y, x, *k_ok[7:]) == -1 and "y (" in err()
+        assert BB(*k_ok[:15], 1000, C.byref(nb), C.byref(nrb)) == -1 and "out_cap" in err() and nb.value > 1000  # too small: the size needed
+        assert L.bsc_block_records_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec)) == 0
+        assert BB(*k_ok) == -1 and "fetched" in err()  # one block in flight per context
+        assert L.bsc_block_records_fetch(h, C.byref(n_in)) == 0 and n_in.value == cnt.value
+        assert BB(*k_ok) == 0 and nrb.value == cnt.value
         # after all that the context still computes
         got = c.block_records(tpl, seq, x, y, ref2)
         assert len(got) > 0 and (got["core"]["emit"] == 1).all()

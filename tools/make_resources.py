@@ -12,7 +12,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_resources.txt")
 FLAGS = "-O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wno-inline-asm -Wno-unused-variable -Wno-unused-function".split()
-SOURCES = ["kernels.hip", "fused.hip", "accumulate.hip", "vcfcore.hip", "sitestats.hip", "compact.hip", "prepdev.hip"]
+SOURCES = ["kernels.hip", "fused.hip", "accumulate.hip", "vcfcore.hip", "sitestats.hip", "compact.hip", "prepdev.hip", "bcfdev.hip"]
 
 
 def demangle(n):
