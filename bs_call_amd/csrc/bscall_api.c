@@ -43,7 +43,7 @@ int bsc_dev_launch_stream_probe(const void *cts, const void *ref, uint64_t n, vo
                                 void *stream); /* probe.hip */
 int bsc_dev_launch_compact(const void *core, const void *gtm, uint32_t gtm_stride, const void *dbsnp, uint32_t n,
                            void *tile_cnt, void *tile_off, void *scan_tmp, size_t scan_tmp_bytes, void *out,
-                           uint64_t out_cap, void *total, int num_cus, void *stream); /* compact.hip */
+                           uint64_t out_cap, void *total, const void *emit, void *emit_ws, int num_cus, void *stream); /* compact.hip */
 #define BSC_PAIR_BYTES (4ull * 512u * 512u * 8u) /* sitestats_dev.h SS_PAIR_G: [ref / non-ref][all / passed][a < 512][b < 512] u64 */
 #define BSC_OVF_CAP (1u << 20)                   /* sitestats_dev.h SS_OVF_CAP */
 int bsc_dev_launch_vcf(const void *gtm, uint32_t stride, const void *skip, const void *ref, const void *dbsnp, uint32_t n,
@@ -148,6 +148,9 @@ struct bsc_context {
    * many bytes went ahead of the length, the bytes per position the next copy is sized from */
   void *d_btb, *d_bto, *d_bscn, *d_bnm, *d_bcf, *d_btot;
   size_t cap_btb, cap_bto, cap_bscn, cap_bnm, cap_bcf, cap_btot;
+  void *d_emit; /* the chain's emit flags, a byte per position, for the block entries' packing / encoding passes (bsc_records_queue) */
+  size_t cap_emit;
+  const void *emit_hint; /* set around the bsc_vcf_compact_device call of bsc_records_queue: the flags of exactly these arrays */
   uint8_t *bcf_out;
   uint64_t bcf_cap, bcf_copied, bcf_bytes; /* bcf_bytes: the length of the last block's stream (also when it did not fit) */
   double bcf_share;
@@ -457,6 +460,7 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_bnm);
   hipFree(ctx->d_bcf);
   hipFree(ctx->d_btot);
+  hipFree(ctx->d_emit);
   hipFree(ctx->d_mblk);
   hipFree(ctx->d_mtab);
   hipFree(ctx->d_refp);
@@ -1342,7 +1346,7 @@ int bsc_chain_device(bsc_context *ctx, const void *d_cts, const void *d_ref, con
  */
 static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes, uint32_t x,
                                  uint32_t y, const void *d_ref, const void *d_dbsnp, const bsc_vcf_params *params, int with_stats,
-                                 void *d_core, void *d_aux, hipStream_t s) {
+                                 void *d_core, void *d_aux, void *d_emit, hipStream_t s) {
   const uint64_t sz64 = (uint64_t)y - x + 1;
   bsc_window w = {x, (uint32_t)sz64, 0u, (uint32_t)sz64};
   int rc = bsc_window_check("reads chain", &w);
@@ -1352,6 +1356,7 @@ static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t n
   if ((rc = bsc_reserve(&ctx->d_fscr, &ctx->cap_fscr, bsc_dev_chain_scratch_bytes(ctx->num_cus)))) return rc;
   bsc_chain_launch L;
   if ((rc = bsc_chain_fill(ctx, &L, &w, params, with_stats, 1, d_ref, d_dbsnp, d_core, d_aux, s))) return rc;
+  L.emit_out = d_emit; /* (zeroed by the caller) */
   if (ctx->profiling) {
     if (!ctx->ev_rchain[0])
       for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&ctx->ev_rchain[i]));
@@ -1431,7 +1436,7 @@ int bsc_reads_chain_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, con
   ctx->blk_d_tpl = d_tpl;
   ctx->blk_x = x;
   ctx->mb_n = 0;
-  return bsc_reads_chain_queue(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_dbsnp, params, with_stats, d_core, d_aux,
+  return bsc_reads_chain_queue(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_dbsnp, params, with_stats, d_core, d_aux, NULL,
                                (hipStream_t)stream);
 }
 
@@ -1628,8 +1633,14 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
   if ((rc = bsc_reserve(&ctx->d_tcnt, &ctx->cap_tcnt, (size_t)n_tiles * 4u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_toff, &ctx->cap_toff, (size_t)n_tiles * 4u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_scantmp, &ctx->cap_scantmp, scan_bytes ? scan_bytes : 1))) return rc;
+  const void *emit = gtm_stride == 0 ? ctx->emit_hint : NULL;
+  void *emit_ws = NULL;
+  if (gtm_stride == 0 && !emit && !getenv("BSC_NO_EMIT_BYTES")) { /* no flags from the chain kernel: the counting pass leaves them */
+    if ((rc = bsc_reserve(&ctx->d_emit, &ctx->cap_emit, (size_t)n + 64u))) return rc;
+    emit_ws = ctx->d_emit;
+  }
   int e = bsc_dev_launch_compact(d_core, d_gtm, gtm_stride, d_dbsnp, n, ctx->d_tcnt, ctx->d_toff, ctx->d_scantmp, scan_bytes,
-                                 d_out, out_cap, d_count, ctx->num_cus, stream);
+                                 d_out, out_cap, d_count, emit, emit_ws, ctx->num_cus, stream);
   if (e) return bsc_fail(BSC_ERR_HIP, "compact launch failed: %s", hipGetErrorString((hipError_t)e));
   return BSC_OK;
 }
@@ -1778,11 +1789,24 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz + 2, hipMemcpyHostToDevice, s));
   if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, dbsnp, (size_t)sz, hipMemcpyHostToDevice, s));
   void *d_db = dbsnp ? ctx->d_vdb : NULL;
+  /* the chain leaves the records' emit flags once more as a byte per position: the packing pass behind it then counts from 64 bytes a tile
+   * and fetches the records that are written and nothing of the others (20 M positions: 1.08 -> 0.80 ms) */
+  void *d_emit = NULL; /* the packing pass only: the encoder's write kernel is 5 % slower behind a flag byte than behind the record's first
+                        * 16 bytes (profiles/r05_ab_emit_bytes.txt).  BSC_NO_EMIT_BYTES in the environment: without them (the A/B of
+                        * tools/bench_tail.py) */
+  if (!bcf && !getenv("BSC_NO_EMIT_BYTES")) {
+    if ((rc = bsc_reserve(&ctx->d_emit, &ctx->cap_emit, (size_t)sz + 64u))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_emit, 0, (size_t)sz + 64u, s));
+    d_emit = ctx->d_emit;
+  }
   if ((rc = bsc_reads_chain_queue(ctx, ctx->d_tpl, nr, ctx->d_seq, seq_bytes, x, y, ctx->d_ref, d_db, params, with_stats, ctx->d_vout,
-                                  ctx->d_out, s)))
+                                  ctx->d_out, d_emit, s)))
     return rc;
   unsigned long long *d_total = ctx->d_counters + BSC_CNT_RECORDS;
-  if (!bcf && (rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 0, d_db, sz, ctx->d_recs, out_cap, d_total, s))) return rc;
+  ctx->emit_hint = d_emit;
+  rc = bcf ? BSC_OK : bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 0, d_db, sz, ctx->d_recs, out_cap, d_total, s);
+  ctx->emit_hint = NULL;
+  if (rc) return rc;
   /* INEXACT, ERR, RECORDS are consecutive counter words: the verdict and the count in one small copy */
   HIP_TRY(hipMemcpyAsync(ctx->h_cnt, ctx->d_counters + BSC_CNT_INEXACT, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   ctx->rec_out = out;
@@ -2126,6 +2150,13 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
   int e = bsc_dev_launch_bin_reads_multi(ctx->d_tpl, nr, ctx->d_seq, seq_bytes, ctx->d_mblk, n_blocks, P >> 6, ctx->d_tflag, ctx->d_bcnt,
                                          ctx->d_boff, ctx->d_bcur, ctx->d_bscan, scan_bytes, ctx->d_rd, ctx->d_counters, s);
   if (e) return bsc_fail(BSC_ERR_HIP, "read grouping launch failed: %s", hipGetErrorString((hipError_t)e));
+  /* the records' emit flags once more as a byte per position, for the packing pass (bsc_records_queue) */
+  void *d_emit = NULL;
+  if (!getenv("BSC_NO_EMIT_BYTES")) {
+    if ((rc = bsc_reserve(&ctx->d_emit, &ctx->cap_emit, (size_t)P + 64u))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_emit, 0, (size_t)P + 64u, s));
+    d_emit = ctx->d_emit;
+  }
   /* the chain: one launch group per stretch of blocks none of which begins right behind its predecessor */
   bsc_window w = {1u, P, 0u, P};
   size_t cursor = 0;
@@ -2134,6 +2165,7 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
     while (b1 + 1u < n_blocks && blocks[b1 + 1u].x != blocks[b1].y + 1u) b1++;
     bsc_chain_launch L;
     if ((rc = bsc_chain_fill(ctx, &L, &w, params, with_stats, 1, ctx->d_ref, d_db, ctx->d_vout, ctx->d_out, s))) return rc;
+    L.emit_out = d_emit;
     L.rd = ctx->d_rd;
     L.bin_off = ctx->d_boff;
     L.seq = ctx->d_seq;
@@ -2147,7 +2179,10 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
   }
   ctx->sites += sites;
   unsigned long long *d_total = ctx->d_counters + BSC_CNT_RECORDS;
-  if ((rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 0, d_db, P, ctx->d_recs, out_cap, d_total, s))) return rc;
+  ctx->emit_hint = d_emit;
+  rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 0, d_db, P, ctx->d_recs, out_cap, d_total, s);
+  ctx->emit_hint = NULL;
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->h_cnt, ctx->d_counters + BSC_CNT_INEXACT, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(st + o_toff, ctx->d_toff, (size_t)(P >> 6) * 4u, hipMemcpyDeviceToHost, s));
   ctx->mb_toff = (const uint32_t *)(st + o_toff);

@@ -62,6 +62,8 @@ typedef struct bsc_chain_launch {
   void *ev_start, *ev_stop;
   double par_l, par_t, par_lrb, par_lrb1; /* 1 - under_conv, over_conv, lrb, lrb1 of the context's tables */
   void *aux_out; /* NULL, or 64 bytes per position: the second half of a bsc_vcf_rec (MC8 counts, AMQ, MQ, aq, max_gt, rs_found) */
+  void *emit_out; /* NULL, or one byte per position: bsc_vcf_core.emit once more, for the passes behind the chain (packing, BCF
+                     encoding) that want to know which records to fetch without fetching them (zeroed by the caller) */
   /* the reads-in form (rd != NULL): the block's reads grouped by bin instead of cts (accumulate.hip:
    * bsc_dev_launch_bin_reads); first / n may be any window of the block, lc / rc are unused */
   const void *rd, *bin_off, *seq;

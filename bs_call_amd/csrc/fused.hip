@@ -127,6 +127,7 @@ struct bsc_chain_kargs {
   uint32_t *carry_out;
   unsigned long long *stat_words, *pair_cells, *ovf_list;
   uint8_t *aux_out;
+  uint8_t *emit_out;
   bsc_reads_args ra;
   /* MULTI: the launch's segments and, segment by segment, their first runs (n_segs + 1 entries: the last = all runs) */
   const bsc_chain_args *segs;
@@ -940,6 +941,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         const unsigned idx = k * 64u + lane;
         if (idx < nvec) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(so)[idx], dst + idx);
       }
+      uint8_t *const emit_out = K_COLD(emit_out);
+      if (emit_out && lane < nrec) /* the records' emit flags once more, a byte per position: what the packing pass and the BCF encoder
+                                    * look at first (a position without a record then costs them a byte, not a 64-byte sector) */
+        emit_out[(uint64_t)i0 + (MULTI ? a.pos_off : 0u) + lane] = reinterpret_cast<const uint8_t *>(so)[lane * 64u + 4u];
       uint8_t *const aux_out = K_COLD(aux_out);
       if (aux_out) { /* what the encoder of a written record reads besides the core record (src/print_vcf.c:306-359): MC8 counts,
                       * AMQ qualities, MQ, mean quality, max_gt, the dbSNP flag — the second half of a bsc_vcf_rec */
@@ -1291,6 +1296,7 @@ static void chain_common(const bsc_chain_launch *L, uint32_t n_all, bsc_chain_ka
   K.pair_cells = (unsigned long long *)L->pairs;
   K.ovf_list = (unsigned long long *)L->ovf_list;
   K.aux_out = (uint8_t *)L->aux_out;
+  K.emit_out = (uint8_t *)L->emit_out;
 }
 
 template <bool READS, bool SUMM>
