@@ -3,7 +3,7 @@
  * positions [x, y].  Replaces HOT LOOP A of call_genotypes_ML (reference src/call_genotypes.c:178-226),
  * which the reference runs serially on its process thread.
  *
- *   bsc_bin_count_kernel    one thread per template: the reference's asserts on the template; per read the
+ *   bsc_bin_count_kernel    BIN_TPT templates per thread (their loads issued back to back): the reference's asserts on the template; per read the
  *   bsc_bin_scatter_kernel  orientation it is counted with (:187,224, including the reference's quirk that a read 0
  *                           without a countable base does not flip it) and a compact descriptor; the reads grouped by the
  *                           64-position bin of their first base in two passes around a prefix sum (count in an LDS window
@@ -115,18 +115,23 @@ __device__ static __forceinline__ void template_block(const bsc_chain_mblock *__
 }
 
 #ifndef BIN_WG
-#define BIN_WG 256   /* templates per workgroup */
+#define BIN_WG 256   /* threads per workgroup */
 #endif
+#ifndef BIN_TPT
+#define BIN_TPT 4    /* templates per thread: a workgroup's lifetime is a chain of latencies (template load, LDS atomics behind a barrier, global
+                        atomics), and with one template per thread the 29 k workgroups of a 50 Mb block at 30x were what the two passes waited
+                        for — several templates per thread, their loads issued back to back, pay that chain once for all of them */
+#endif
+#define BIN_TPW (BIN_WG * BIN_TPT) /* templates per workgroup */
 #ifndef BIN_WIN
 #define BIN_WIN 1024 /* bins of the workgroup's LDS window: a coordinate-ordered align_list keeps a workgroup's 512 reads
                         within a few dozen bins; reads outside the window take a global atomic each */
 #endif
 
 /* the workgroup's window starts at the lowest bin among its live reads */
-__device__ static __forceinline__ uint32_t wg_min_bin(uint32_t b0, uint32_t b1, uint32_t *s_min) {
+__device__ static __forceinline__ uint32_t wg_min_bin(uint32_t m, uint32_t *s_min) { /* m: the lowest bin among the thread's reads */
   if (threadIdx.x == 0) *s_min = 0xffffffffu;
   __syncthreads();
-  uint32_t m = b0 < b1 ? b0 : b1;
   for (int o = 32; o > 0; o >>= 1) {
     const uint32_t v = __shfl_xor(m, o);
     m = v < m ? v : m;
@@ -137,7 +142,7 @@ __device__ static __forceinline__ uint32_t wg_min_bin(uint32_t b0, uint32_t b1, 
 }
 
 /*
- * Grouping the block's reads by the 64-position bin of their first base, pass 1 of 2 — one thread per template, in the
+ * Grouping the block's reads by the 64-position bin of their first base, pass 1 of 2 — BIN_TPT templates per thread, in the
  * caller's order: the reference's asserts (the lowest index of an invalid template with its first failing check reaches the
  * host through counters[BSC_CNT_ERR]; such a template contributes nothing), whether read 0 was walked (as the host says,
  * bsc_template.flags, or else found out here: one byte of it, almost always; kept in tflag[] for pass 2), the bins of its two reads counted — in an LDS window of the workgroup, one
@@ -154,43 +159,56 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_count_kernel(const 
   __shared__ uint32_t s_cnt[BIN_WIN];
   __shared__ uint32_t s_min;
   for (unsigned i = threadIdx.x; i < BIN_WIN; i += BIN_WG) s_cnt[i] = 0;
-  const uint32_t t = blockIdx.x * BIN_WG + threadIdx.x;
-  uint32_t bin[2] = {0xffffffffu, 0xffffffffu}, span_max = 0;
-  if (t < nr) {
-    const bsc_template_dev tp = tpl[t];
-    uint32_t bin0;
-    template_block(blk, n_blk, t, x, y, bin0);
-    bool walked0 = false;
-    if (tp.flags & TPL_WALK_KNOWN) walked0 = (tp.flags & TPL_WALKED0) != 0; /* the host says (include/bscall_amd.h) */
-    else if (template_error(tp, leftmost(tp.pos[0], tp.pos[1]), x, seq_bytes) == 0) { /* read 0's first countable base */
-      const uint32_t rl = tp.len[0];
-      const uint8_t *sp = seq + tp.off[0];
-      for (uint32_t j = 0; j < rl; j++) {
-        const uint32_t q = (uint32_t)sp[j] >> 2;
-        if (q > 0 && q != 63u) {
-          walked0 = true;
-          break;
+  uint32_t bin[BIN_TPT][2], span_max = 0, bin_lo = 0xffffffffu;
+  bsc_template_dev tps[BIN_TPT];
+#pragma unroll
+  for (int j = 0; j < BIN_TPT; j++) { /* the loads first, back to back */
+    const uint32_t t = blockIdx.x * BIN_TPW + (uint32_t)j * BIN_WG + threadIdx.x;
+    if (t < nr) tps[j] = tpl[t];
+  }
+#pragma unroll
+  for (int j = 0; j < BIN_TPT; j++) {
+    const uint32_t t = blockIdx.x * BIN_TPW + (uint32_t)j * BIN_WG + threadIdx.x;
+    bin[j][0] = bin[j][1] = 0xffffffffu;
+    if (t < nr) {
+      const bsc_template_dev tp = tps[j];
+      uint32_t bin0;
+      template_block(blk, n_blk, t, x, y, bin0);
+      bool walked0 = false;
+      if (tp.flags & TPL_WALK_KNOWN) walked0 = (tp.flags & TPL_WALKED0) != 0; /* the host says (include/bscall_amd.h) */
+      else if (template_error(tp, leftmost(tp.pos[0], tp.pos[1]), x, seq_bytes) == 0) { /* read 0's first countable base */
+        const uint32_t rl = tp.len[0];
+        const uint8_t *sp = seq + tp.off[0];
+        for (uint32_t q_ = 0; q_ < rl; q_++) {
+          const uint32_t q = (uint32_t)sp[q_] >> 2;
+          if (q > 0 && q != 63u) {
+            walked0 = true;
+            break;
+          }
         }
       }
+      tflag[t] = walked0 ? 1 : 0;
+      bsc_read_desc d[2];
+      const uint32_t terr = template_reads(tp, x, y, seq_bytes, walked0, d);
+      if (terr) atomicMin(&counters[BSC_CNT_ERR], ((unsigned long long)t << 8) | terr);
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (d[k].b >= d[k].a) { /* live: x <= a <= b <= y */
+          bin[j][k] = bin0 + ((d[k].a - x) >> ACC_BIN_SHIFT);
+          if (bin[j][k] < bin_lo) bin_lo = bin[j][k];
+          if (d[k].b - d[k].a > span_max) span_max = d[k].b - d[k].a;
+        }
     }
-    tflag[t] = walked0 ? 1 : 0;
-    bsc_read_desc d[2];
-    const uint32_t terr = template_reads(tp, x, y, seq_bytes, walked0, d);
-    if (terr) atomicMin(&counters[BSC_CNT_ERR], ((unsigned long long)t << 8) | terr);
+  }
+  const uint32_t base = wg_min_bin(bin_lo, &s_min); /* also orders the zeroing of s_cnt before its use */
+#pragma unroll
+  for (int j = 0; j < BIN_TPT; j++)
 #pragma unroll
     for (int k = 0; k < 2; k++)
-      if (d[k].b >= d[k].a) { /* live: x <= a <= b <= y */
-        bin[k] = bin0 + ((d[k].a - x) >> ACC_BIN_SHIFT);
-        if (d[k].b - d[k].a > span_max) span_max = d[k].b - d[k].a;
+      if (bin[j][k] != 0xffffffffu) {
+        if (bin[j][k] - base < BIN_WIN) atomicAdd(&s_cnt[bin[j][k] - base], 1u);
+        else atomicAdd(&bin_cnt[bin[j][k]], 1u);
       }
-  }
-  const uint32_t base = wg_min_bin(bin[0], bin[1], &s_min); /* also orders the zeroing of s_cnt before its use */
-#pragma unroll
-  for (int k = 0; k < 2; k++)
-    if (bin[k] != 0xffffffffu) {
-      if (bin[k] - base < BIN_WIN) atomicAdd(&s_cnt[bin[k] - base], 1u);
-      else atomicAdd(&bin_cnt[bin[k]], 1u);
-    }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < BIN_WIN; i += BIN_WG)
     if (s_cnt[i]) atomicAdd(&bin_cnt[base + i], s_cnt[i]);
@@ -222,33 +240,56 @@ extern "C" __global__ __launch_bounds__(BIN_WG) void bsc_bin_scatter_kernel(cons
   __shared__ uint32_t s_cnt[BIN_WIN]; /* reads of the workgroup per bin of its window, then: the first slot they got */
   __shared__ uint32_t s_min;
   for (unsigned i = threadIdx.x; i < BIN_WIN; i += BIN_WG) s_cnt[i] = 0;
-  const uint32_t t = blockIdx.x * BIN_WG + threadIdx.x;
-  uint32_t bin[2] = {0xffffffffu, 0xffffffffu}, rank[2] = {0, 0};
-  bsc_read_desc d[2];
-  acc_dead(d[0]);
-  acc_dead(d[1]);
-  if (t < nr) {
-    uint32_t bin0;
-    template_block(blk, n_blk, t, x, y, bin0);
-    (void)template_reads(tpl[t], x, y, seq_bytes, tflag[t] != 0, d);
+  uint32_t bin[BIN_TPT][2], rank[BIN_TPT][2], bin_lo = 0xffffffffu;
+  bsc_read_desc d[BIN_TPT][2];
+  bsc_template_dev tps[BIN_TPT];
+  uint8_t tf[BIN_TPT];
+#pragma unroll
+  for (int j = 0; j < BIN_TPT; j++) { /* the loads first, back to back */
+    const uint32_t t = blockIdx.x * BIN_TPW + (uint32_t)j * BIN_WG + threadIdx.x;
+    tf[j] = 0;
+    if (t < nr) {
+      tps[j] = tpl[t];
+      tf[j] = tflag[t];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BIN_TPT; j++) {
+    const uint32_t t = blockIdx.x * BIN_TPW + (uint32_t)j * BIN_WG + threadIdx.x;
+    bin[j][0] = bin[j][1] = 0xffffffffu;
+    rank[j][0] = rank[j][1] = 0;
+    acc_dead(d[j][0]);
+    acc_dead(d[j][1]);
+    if (t < nr) {
+      uint32_t bin0;
+      template_block(blk, n_blk, t, x, y, bin0);
+      (void)template_reads(tps[j], x, y, seq_bytes, tf[j] != 0, d[j]);
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (d[j][k].b >= d[j][k].a) {
+          bin[j][k] = bin0 + ((d[j][k].a - x) >> ACC_BIN_SHIFT);
+          if (bin[j][k] < bin_lo) bin_lo = bin[j][k];
+        }
+    }
+  }
+  const uint32_t base = wg_min_bin(bin_lo, &s_min);
+#pragma unroll
+  for (int j = 0; j < BIN_TPT; j++)
 #pragma unroll
     for (int k = 0; k < 2; k++)
-      if (d[k].b >= d[k].a) bin[k] = bin0 + ((d[k].a - x) >> ACC_BIN_SHIFT);
-  }
-  const uint32_t base = wg_min_bin(bin[0], bin[1], &s_min);
-#pragma unroll
-  for (int k = 0; k < 2; k++)
-    if (bin[k] != 0xffffffffu && bin[k] - base < BIN_WIN) rank[k] = atomicAdd(&s_cnt[bin[k] - base], 1u);
+      if (bin[j][k] != 0xffffffffu && bin[j][k] - base < BIN_WIN) rank[j][k] = atomicAdd(&s_cnt[bin[j][k] - base], 1u);
   __syncthreads();
   for (unsigned i = threadIdx.x; i < BIN_WIN; i += BIN_WG)
     if (s_cnt[i]) s_cnt[i] = atomicAdd(&bin_cur[base + i], s_cnt[i]);
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 2; k++)
-    if (bin[k] != 0xffffffffu) {
-      const uint32_t slot = bin[k] - base < BIN_WIN ? s_cnt[bin[k] - base] + rank[k] : atomicAdd(&bin_cur[bin[k]], 1u);
-      rd[slot] = d[k];
-    }
+  for (int j = 0; j < BIN_TPT; j++)
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (bin[j][k] != 0xffffffffu) {
+        const uint32_t slot = bin[j][k] - base < BIN_WIN ? s_cnt[bin[j][k] - base] + rank[j][k] : atomicAdd(&bin_cur[bin[j][k]], 1u);
+        rd[slot] = d[j][k];
+      }
 }
 
 /*
@@ -466,7 +507,7 @@ static int launch_bin_reads(const void *tpl, uint32_t nr, const void *seq, uint6
   if (!nr) return (int)hipMemsetAsync(bin_off, 0, bytes, s); /* no reads: every bin empty */
   hipError_t e = hipMemsetAsync(bin_cnt, 0, bytes, s);
   if (e != hipSuccess) return (int)e;
-  const unsigned g = (nr + BIN_WG - 1u) / BIN_WG; /* nr <= 2^31 - 1 is checked by the caller */
+  const unsigned g = (nr + BIN_TPW - 1u) / BIN_TPW; /* nr <= 2^31 - 1 is checked by the caller */
   hipLaunchKernelGGL(bsc_bin_count_kernel, dim3(g), dim3(BIN_WG), 0, s, (const bsc_template_dev *)tpl, nr, (const uint8_t *)seq,
                      seq_bytes, x, y, (uint8_t *)tflag, (uint32_t *)bin_cnt, (unsigned long long *)counters, blk, n_blk);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
