@@ -282,6 +282,8 @@ def one_dbsnp(rng, d, stats):
                     ix.flags(1, 70000).sum()
                     for x in (1, 63, 64, 1000, 59999):
                         ix.name(x)
+                    pos, off, by = ix.names(1, 70000)  # the table the device BCF encoder searches (bsc_dbsnp_names)
+                    assert len(off) == len(pos) + 1 and int(off[-1]) == len(by) and (np.diff(pos.astype(np.int64)) > 0).all()
         stats["dbsnp_ok"] += 1
     except BscError:
         stats["dbsnp_refused"] += 1
