@@ -36,6 +36,7 @@ enum { BT_INT8 = 1, BT_INT16 = 2, BT_INT32 = 3, BT_FLOAT = 5, BT_CHAR = 7 };
 #define BCF_REC_MAX 336u      /* 32 + shared (3 + 63 + 2 + 4 + 5 + 5 + 6) + per-sample (13 keys x 5 + 136): an upper bound of one record */
 #define BCF_IMG_BYTES 10752u  /* the wave's image: 32 records of the longest kind (10 752 = 32 x 336), or 64 ordinary ones */
 #define BCF_WAVES 4u
+static_assert(BCF_IMG_BYTES >= 32u * BCF_REC_MAX, "half a tile of the longest records must fit the wave's image");
 #ifndef BCF_WAVES_PER_EU
 #define BCF_WAVES_PER_EU 3 /* the write kernel in 168 registers: three workgroups a CU, what its 43 KB of LDS allow (tools/build_variant_bcf.sh) */
 #endif
