@@ -79,6 +79,8 @@ int bsc_dev_launch_ref_pad(const void *packed, const void *d_blk, uint32_t n_blk
 int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk, uint32_t n_blk,
                                    uint32_t n_bins, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
                                    size_t scan_tmp_bytes, void *rd, void *counters, void *stream);
+#define BSC_PREP_CNT_SLOTS 64u                               /* csrc/prepdev.hip: PREP_CNT_SLOTS */
+#define BSC_PREP_CNT_ALL (8u + 8u * BSC_PREP_CNT_SLOTS)     /* the eight shared words and the slots behind them */
 #define BSC_LN10 (2.30258509299404568402) /* the reference's LOG10 literal (include/bs_call.h:36) */
 #define BSC_HOST_CHUNK (4u << 20)         /* sites per host->device round trip (4 Mi sites = 1.2 GiB of records) */
 #define BSC_MAX_LAUNCH (1ull << 31)       /* sites per launch: site indices in the het list are 32-bit */
@@ -1551,7 +1553,7 @@ int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t n
   if ((rc = bsc_reserve(&ctx->d_poff, &ctx->cap_poff, (size_t)n2 * 8u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_pms, &ctx->cap_pms, (size_t)(n_misms ? n_misms : 1) * sizeof(bsc_misms)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_pscan, &ctx->cap_pscan, scan_bytes ? scan_bytes : 1))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_pcnt, &ctx->cap_pcnt, 8 * sizeof(unsigned long long)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_pcnt, &ctx->cap_pcnt, BSC_PREP_CNT_ALL * sizeof(unsigned long long)))) return rc;
   const size_t prof_bytes = pf ? (size_t)pf->cap * 4u * sizeof(unsigned long long) : 0;
   if (pf && nr) {
     if ((rc = bsc_reserve(&ctx->d_pprof, &ctx->cap_pprof, prof_bytes))) return rc;
@@ -1559,7 +1561,7 @@ int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t n
     if ((rc = bsc_reserve(&ctx->d_pused, &ctx->cap_pused, (size_t)nr * 4u))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_pprof, 0, prof_bytes, s));
   }
-  HIP_TRY(hipMemsetAsync(ctx->d_pcnt, 0, 8 * sizeof(unsigned long long), s));
+  HIP_TRY(hipMemsetAsync(ctx->d_pcnt, 0, BSC_PREP_CNT_ALL * sizeof(unsigned long long), s));
   HIP_TRY(hipMemsetAsync(ctx->d_pcnt, 0xff, sizeof(unsigned long long), s));
   int e = bsc_dev_launch_prep(d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, par, ctx->d_pms, ctx->d_pplan, ctx->d_plen, ctx->d_poff,
                               ctx->d_pscan, scan_bytes, d_tpl_out, d_seq_out, seq_out_cap, ctx->d_pcnt, ctx->num_cus, s,
@@ -1569,8 +1571,8 @@ int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t n
     (void)hipStreamSynchronize(s);
     return bsc_fail(BSC_ERR_HIP, "read pre-processing launch failed: %s", hipGetErrorString((hipError_t)e));
   }
-  unsigned long long h[9];
-  HIP_TRY(hipMemcpyAsync(h, ctx->d_pcnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  unsigned long long h[9], hs[BSC_PREP_CNT_ALL];
+  HIP_TRY(hipMemcpyAsync(hs, ctx->d_pcnt, sizeof hs, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(h + 8, (const char *)ctx->d_poff + (size_t)(nr ? 2u * nr : 0u) * 8u, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   uint32_t used_last = 0;
   uint64_t *delta = NULL;
@@ -1587,6 +1589,11 @@ int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t n
   if (se != hipSuccess) {
     free(delta);
     return bsc_fail(BSC_ERR_HIP, "bsc_prepare_templates_device: %s", hipGetErrorString(se));
+  }
+  memcpy(h, hs, 8 * sizeof h[0]);
+  for (unsigned k = 0; k < BSC_PREP_CNT_SLOTS; k++) { /* the plan kernel's wave sums, slot by slot (csrc/prepdev.hip) */
+    h[1] += hs[8u + 8u * k];
+    h[2] += hs[8u + 8u * k + 1u];
   }
   if (h[0] != ~0ull) {
     free(delta);

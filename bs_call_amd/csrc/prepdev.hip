@@ -65,6 +65,8 @@ struct bsc_prep_desc {
 #define PD_SLOW 8u   /* byte by byte from the full plan in plan[]: an edited read, one with a right trim (mirrored bases), one
                         shorter than 4 or longer than 2^20 - 2 bytes, one marked further than 255 bytes in */
 
+#define PREP_CNT_WORDS 8u  /* cnt[]: [0] lowest error, [1] base_clip, [2] base_overlap (both: see the slots), [3..7] the copy kernel's sums */
+#define PREP_CNT_SLOTS 64u /* ... followed by PREP_CNT_SLOTS x 8 words: per slot {base_clip, base_overlap} of the plan kernel's waves */
 /* error codes, in the order csrc/prep.c makes its checks; the low byte of the word the kernels atomicMin */
 #define PE_ORI 1u
 #define PE_READ 2u  /* + k */
@@ -100,18 +102,39 @@ __device__ static __forceinline__ uint32_t d_qual(const uint8_t *sp, uint32_t i,
   return (i < mark_l || i >= rl0 - mark_r) ? FLT_QUAL : (uint32_t)sp[i] >> 2;
 }
 
-/* src/al_utils.c:191-203 over the read's window */
+__device__ static __forceinline__ uint32_t d_ld32(const uint8_t *p);
+/* src/al_utils.c:191-203 over the read's window: the mean of the qualities that are not 63.  The bytes the fixed trims mark carry 63, so
+ * what is summed lies in [max(w0, mark_l), min(w0 + wl, rl0 - mark_r)); four bytes at a time — one unaligned dword load, the qualities
+ * side by side in the dword (6 bits each: bit 7 of a byte is free for "is not 63"), sixteen a load — since overlapping mates of equal span, the common
+ * pair of a short-insert library, come through here twice per template: byte by byte the plan kernel took 17 ms per 7.5 M such
+ * templates (profiles/r05_prep_overlap.txt). */
 __device__ static uint32_t d_mean_qual(const uint8_t *sp, const prep_rd &r, uint32_t rl0, uint32_t mark_l, uint32_t mark_r) {
-  uint32_t tot = 0;
-  int n = 0;
-  for (uint32_t i = 0; i < r.wl; i++) {
-    const uint32_t q = d_qual(sp, r.w0 + i, rl0, mark_l, mark_r);
+  const uint32_t lo = r.w0 > mark_l ? r.w0 : mark_l;
+  const uint32_t e0 = r.w0 + r.wl, e1 = rl0 - mark_r; /* (unsigned, as d_qual's own test) */
+  const uint32_t hi = e0 < e1 ? e0 : e1;
+  uint32_t tot = 0, n = 0, i = lo;
+#define MQ_DWORD(w_)                                                                                                                   \
+  {                                                                                                                                    \
+    const uint32_t q = ((w_) >> 2) & 0x3f3f3f3fu;                                                                                      \
+    const uint32_t nz = ((q ^ 0x3f3f3f3fu) + 0x7f7f7f7fu) & 0x80808080u; /* bit 7 of a byte: its quality is not 63 (no carry leaves a byte) */ \
+    n += (uint32_t)__popc(nz);                                                                                                         \
+    tot = __builtin_amdgcn_sad_u8(q & ((nz >> 7) * 0xffu), 0u, tot); /* + the bytes that count */                                      \
+  }
+  for (; i + 16u <= hi; i += 16u) { /* one (unaligned) 16-byte load: a lane's requests are what the pass is short of, each lane reads its own read */
+    uint4 v;
+    __builtin_memcpy(&v, sp + i, 16);
+    MQ_DWORD(v.x) MQ_DWORD(v.y) MQ_DWORD(v.z) MQ_DWORD(v.w)
+  }
+  for (; i + 4u <= hi; i += 4u) MQ_DWORD(d_ld32(sp + i))
+#undef MQ_DWORD
+  for (; i < hi; i++) {
+    const uint32_t q = (uint32_t)sp[i] >> 2;
     if (q != FLT_QUAL) {
       tot += q;
       n++;
     }
   }
-  return n > 0 ? tot / (uint32_t)n : 0;
+  return n > 0 ? tot / n : 0;
 }
 
 __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_template *__restrict__ raw, uint32_t nr, const uint8_t *__restrict__ seq,
@@ -401,8 +424,11 @@ __global__ __launch_bounds__(256) void bsc_prep_plan_kernel(const bsc_raw_templa
     n_overlap += __shfl_xor(n_overlap, o);
   }
   if ((threadIdx.x & 63u) == 0) {
-    if (n_clip) atomicAdd(&cnt[1], n_clip);
-    if (n_overlap) atomicAdd(&cnt[2], n_overlap);
+    /* 64 slots, a 64-byte line each, behind the eight words the kernels share (the host adds them up): with overlapping mates every
+     * wave has a sum to add, and 117 k atomics on ONE word are 0.7 ms at the memory side (profiles/r05_prep_overlap.txt) */
+    unsigned long long *slot = cnt + PREP_CNT_WORDS + (blockIdx.x & (PREP_CNT_SLOTS - 1u)) * 8u;
+    if (n_clip) atomicAdd(&slot[0], n_clip);
+    if (n_overlap) atomicAdd(&slot[1], n_overlap);
   }
 }
 

@@ -28,6 +28,7 @@ ap.add_argument("--coverage", type=int, default=30)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--indel-every", type=int, default=50)
 ap.add_argument("--profile", action="store_true", help="with the non-CpG read profile (the form the pipeline runs)")
+ap.add_argument("--overlap-every", type=int, default=0, help="every k-th pair's mate moved to 60 bases behind read 0: overlapping mates (handle_overlap runs)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 tpl, seq, y = R.synth_block(88172645463325252 + 2, 1000, args.sites, args.coverage)
@@ -35,6 +36,9 @@ raw = np.zeros(len(tpl), dtype=RAW_TEMPLATE)
 for f in ("pos", "len", "off", "mapq", "orientation", "bs_strand"):
     raw[f] = tpl[f]
 raw["reference_span"] = tpl["len"]
+if args.overlap_every:  # short-insert pairs, as most WGBS libraries have them: the mate starts inside read 0
+    ov = np.nonzero((np.arange(len(raw)) % args.overlap_every == 0) & (raw["len"][:, 0] >= 80) & (raw["len"][:, 1] > 0))[0]
+    raw["pos"][ov, 1] = raw["pos"][ov, 0] + 60
 # every k-th read 0 of at least 60 bases: a deletion from the reference at 20 (INS, 2 bases) and an insertion at 40 (DEL, 1 base)
 sel = np.nonzero((np.arange(len(raw)) % args.indel_every == 0) & (raw["len"][:, 0] >= 60))[0]
 ms = np.zeros(2 * len(sel), dtype=MISMS)
