@@ -283,3 +283,38 @@ def test_read_profile_on_the_device(caller):
         assert pf_d.used == pf_h.used and pf_d.counts[: pf_d.used].tobytes() == pf_h.counts[: pf_h.used].tobytes(), call
         assert not pf_d.counts[pf_d.used :].any()
     assert pf_h.used > 60 and int(pf_h.counts[1 : pf_h.used].sum()) > 1000
+
+
+def test_mates_of_equal_span_are_decided_by_their_mean_qualities(caller):
+    """handle_overlap's tie-break (src/al_utils.c:191-203): overlapping mates of EQUAL span — the common pair of a short-insert library —
+    are decided by the mean of the qualities that are not 63.  The device sums sixteen qualities a load, byte-parallel: read lengths
+    around 4 and 16, qualities 63 and 0 anywhere, fixed trims that mark both ends, means that tie and means one apart."""
+    rng = np.random.default_rng(6363)
+    for trial in range(60):
+        ts = []
+        for _ in range(int(rng.integers(20, 80))):
+            n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 100, 150]))
+            qs = []
+            for k in range(2):
+                mode = rng.random()
+                if mode < 0.25:
+                    q = np.full(n, int(rng.integers(0, 44)))
+                elif mode < 0.5:
+                    q = rng.integers(28, 32, n)  # means that tie or differ by one
+                else:
+                    q = rng.integers(0, 44, n)
+                q = np.where(rng.random(n) < 0.1, 63, q)
+                q = np.where(rng.random(n) < 0.05, 0, q)
+                qs.append(q)
+            r0 = [T.b(int(rng.integers(0, 4)), int(v)) for v in qs[0]]
+            r1 = [T.b(int(rng.integers(0, 4)), int(v)) for v in qs[1]]
+            p0 = int(rng.integers(100, 4000))
+            p1 = p0 + int(rng.integers(-(n - 1), n))  # overlapping, either read first
+            if p1 < 1:
+                p1 = p0
+            t = T.tpl((p0, p1), (n, n), (r0, r1))
+            t["orientation"] = int(rng.integers(0, 2))
+            ts.append(t)
+        lt = (int(rng.integers(0, 6)), int(rng.integers(0, 6)))
+        rt = (int(rng.integers(0, 6)), int(rng.integers(0, 6)))
+        _both(caller, ts, left_trim=lt, right_trim=rt, min_qual=int(rng.choice([0, 13, 20])))
