@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end host + device rate of integration/bam2bcf (BAM + FASTA -> BCF + report, plain C over the C ABI) on a synthetic
-WGBS BAM (tools/make_bam.py wgbs_records: paired 2 x 100 bp, 30x).  Prints one JSON line.  usage: python tools/bench_bam2bcf.py [positions]"""
+WGBS BAM (tools/make_bam.py wgbs_records: paired 2 x 100 bp, 30x).  Prints one JSON line.
+usage: python tools/bench_bam2bcf.py [positions [insert]]   (insert, default 300: the template length — below 200 the mates overlap)"""
 import importlib.util
 import json
 import os
@@ -16,11 +17,12 @@ spec = importlib.util.spec_from_file_location("make_bam", os.path.join(ROOT, "to
 W = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(W)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600_000
+insert = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 rng = np.random.default_rng(5)
 codes = rng.integers(1, 5, n).astype(np.uint8)
 d = tempfile.mkdtemp(prefix="bam2bcf_")
 t0 = time.time()
-recs = W.wgbs_records(rng, codes, 0, n * 30 // 200)
+recs = W.wgbs_records(rng, codes, 0, n * 30 // 200, insert=insert)
 bam, fa = os.path.join(d, "in.bam"), os.path.join(d, "ref.fa")
 W.write_bam(bam, [("chrS", n)], recs)
 with open(fa, "w") as f:
@@ -57,7 +59,7 @@ best = res[(4, "device")][0]
 print(json.dumps({"no_inflate_threads": {"wall_s": round(res[(0, "device")][0], 3), "stages": res[(0, "device")][1]},
                   "bcf_encoding_on_the_host": {"wall_s_best_of_3": round(res[(4, "host_bcf")][0], 3), "stages": res[(4, "host_bcf")][1], "same_bcf_and_report_bytes": True},
                   "host_pre_processing_as_in_round_4": {"wall_s_best_of_3": round(res[(4, "host_prep")][0], 3), "stages": res[(4, "host_prep")][1], "same_bcf_and_report_bytes": True},
-                  "positions": n, "alignments": len(recs), "bam_bytes": os.path.getsize(bam), "bcf_bytes": os.path.getsize(os.path.join(d, "out.bcf")),
+                  "positions": n, "insert": insert, "alignments": len(recs), "bam_bytes": os.path.getsize(bam), "bcf_bytes": os.path.getsize(os.path.join(d, "out.bcf")),
                   "generate_s": round(gen_s, 1), "bam2bcf_wall_s_best_of_3": round(best, 3), "positions_per_s": round(n / best),
                   "alignments_per_s": round(len(recs) / best), "stdout": r.stdout.strip(), "stages": res[(4, "device")][1],
                   "note": "whole process: context creation, BGZF inflate (4 helper threads) + pairing, GPU pre-processing + calling + BCF encoding (bsc_block_bcf_raw), the write, report; one host thread apart from the inflate helpers"}))
