@@ -541,6 +541,10 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
             "algorithmic_bytes_per_launch": sites_alg,
             "achieved": sites_alg / (sites_ms * 1e-3) / 1e9,
             "frac": sites_alg / (sites_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "sector_bytes_per_launch": 2 * 64 * (n + n_rec) + nbytes,
+            "sector_frac": (2 * 64 * (n + n_rec) + nbytes) / (sites_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "sector_note": "what the 16 bytes of a position cost at HBM: its whole 64-byte sector (the records are 64 bytes, one to a sector) — "
+            "`frac` counts the algorithmic 16, `sector_frac` the 64 the memory system moves",
             "packing_pass_ms_it_replaces": pack_ms,
             "packing_plus_encoding_ms": pack_ms + k_ms,
             "same_stream": bool(sites_same),
