@@ -64,6 +64,9 @@ EXPORTS = (
     "bsc_bcf_sites_device",
     "bsc_block_bcf",
     "bsc_block_bcf_raw",
+    "bsc_block_bcf_submit",
+    "bsc_block_bcf_submit_inplace",
+    "bsc_block_bcf_fetch",
     "bsc_dbsnp_names",
     "bsc_fasta_contig",
     "bsc_block_reference",
@@ -369,6 +372,12 @@ def load():
     L.bsc_block_bcf_raw.restype = i32
     L.bsc_block_bcf_raw.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, u32, u32, vp, vp, vp, i32, i32, C.POINTER(BcfIds), vp, vp, u64,
                                     C.POINTER(u64), C.POINTER(u64), vp, vp]
+    L.bsc_block_bcf_submit.restype = i32
+    L.bsc_block_bcf_submit.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, vp, i32, i32, C.POINTER(BcfIds), vp, vp, u64]
+    L.bsc_block_bcf_submit_inplace.restype = i32
+    L.bsc_block_bcf_submit_inplace.argtypes = L.bsc_block_bcf_submit.argtypes
+    L.bsc_block_bcf_fetch.restype = i32
+    L.bsc_block_bcf_fetch.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.bsc_bcf_block_device.restype = i32
     L.bsc_bcf_block_device.argtypes = [vp, vp, vp, u64, i32, C.POINTER(BcfIds), vp, vp, u64, vp, vp]
     L.bsc_bcf_sites_device.restype = i32

@@ -475,6 +475,42 @@ class SiteCaller:
             profile.used = int(pf.used)
         return out[: nb.value].tobytes(), nr.value, st[0]
 
+    def block_bcf_submit(self, templates, seq, x, y, ref, rid, out, names=None, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None,
+                         with_stats=False, ids=None, inplace=False):
+        """bsc_block_bcf_submit: queue the block and return (inputs are staged: the arrays may be reused at once); `out`: a writable uint8
+        array (a PinnedBuffer's, ideally) that receives the stream; block_bcf_fetch() waits and returns (bytes view, n_records)."""
+        templates = np.ascontiguousarray(templates, dtype=TEMPLATE)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        n = int(y) - int(x) + 1
+        if len(ref) != n + 2:
+            raise ValueError("ref must have y - x + 3 entries (x .. y + 2)")
+        db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+        if db is not None and len(db) != n:
+            raise ValueError("dbsnp must have y - x + 1 entries")
+        if not isinstance(out, np.ndarray) or out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]:
+            raise ValueError("out must be a writable C-contiguous uint8 array")
+        if ids is None:
+            ids = _lib.BcfIds()
+            self._L.bsc_bcf_default_ids(C.byref(ids))
+        nm, keep = self._bcf_names(names)
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        fn = self._L.bsc_block_bcf_submit_inplace if inplace else self._L.bsc_block_bcf_submit
+        _check(fn(self._h, _ptr(templates), len(templates), _ptr(seq), seq.size, x, y, _ptr(ref), None if db is None else _ptr(db), C.byref(p),
+                  1 if with_stats else 0, rid, C.byref(ids), None if nm is None else C.addressof(nm), _ptr(out), out.size))
+        del keep
+        self._bcf_out = out
+        self._bcf_in = (templates, seq, ref, db) if inplace else None  # read where they lie until the fetch
+
+    def block_bcf_fetch(self):
+        nb, nr = C.c_uint64(0), C.c_uint64(0)
+        out, self._bcf_out = getattr(self, "_bcf_out", None), None
+        try:
+            _check(self._L.bsc_block_bcf_fetch(self._h, C.byref(nb), C.byref(nr)))
+        finally:
+            self._bcf_in = None
+        return out[: nb.value], nr.value
+
     def bcf_block_device(self, d_recs, d_n_recs, max_recs, rid, d_out, out_cap, d_totals, names=None, ids=None, stream=None):
         """bsc_bcf_block_device: packed records in HBM -> their BCF stream in HBM (asynchronous on `stream`)."""
         if ids is None:

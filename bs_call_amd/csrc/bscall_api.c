@@ -2011,28 +2011,65 @@ int bsc_block_bcf_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr
  * unchanged until the fetch (`out` must stay valid until then either way). */
 static int bsc_records_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
                               uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
-                              bsc_vcf_rec *out, uint64_t out_cap, int stage) {
+                              bsc_vcf_rec *out, uint64_t out_cap, int stage, const bsc_bcf_req *bcf) {
   if (!ctx || !ref || !params || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_submit: NULL argument");
   if (ctx->rec_pending || ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_submit: the previous block has not been fetched");
-  int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, stage, NULL);
+  int rc = bsc_records_queue(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, stage, bcf);
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream); /* nothing may still read the inputs / the staging area after a failed submit */
     return rc;
   }
-  ctx->rec_pending = 1;
+  ctx->rec_pending = bcf ? 3 : 1;
   return BSC_OK;
 }
 
 int bsc_block_records_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
                              uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
                              bsc_vcf_rec *out, uint64_t out_cap) {
-  return bsc_records_submit(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 1);
+  return bsc_records_submit(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 1, NULL);
 }
 
 int bsc_block_records_submit_inplace(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                                      uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params,
                                      int with_stats, bsc_vcf_rec *out, uint64_t out_cap) {
-  return bsc_records_submit(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 0);
+  return bsc_records_submit(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, out, out_cap, 0, NULL);
+}
+
+/* The split form of bsc_block_bcf: the block is queued — inputs through the staging area, so the caller's buffers are free at once; the
+ * names' table is uploaded by the call — and the call returns; bsc_block_bcf_fetch waits for it.  `out` should come from bsc_alloc_host
+ * and must stay valid until the fetch. */
+static int bsc_bcf_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                          const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids,
+                          const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap, int stage) {
+  if (!ids || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf_submit: NULL argument");
+  const bsc_bcf_req req = {rid, ids, names, out, out_cap};
+  if (ctx) ctx->bcf_bytes = 0;
+  return bsc_records_submit(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, NULL, 0, stage, &req);
+}
+
+int bsc_block_bcf_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                         const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids,
+                         const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap) {
+  return bsc_bcf_submit(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, rid, ids, names, out, out_cap, 1);
+}
+
+/* ... with the inputs read where they lie (bsc_alloc_host buffers make the upload a true DMA): they must stay unchanged until the fetch */
+int bsc_block_bcf_submit_inplace(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
+                                 uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid,
+                                 const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap) {
+  return bsc_bcf_submit(ctx, tpl, nr, seq, seq_bytes, x, y, ref, dbsnp, params, with_stats, rid, ids, names, out, out_cap, 0);
+}
+
+int bsc_block_bcf_fetch(bsc_context *ctx, uint64_t *n_bytes, uint64_t *n_records) {
+  if (!ctx || !n_bytes || !n_records) return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf_fetch: NULL argument");
+  *n_bytes = 0;
+  *n_records = 0;
+  if (ctx->rec_pending != 3) return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf_fetch: no block was submitted");
+  ctx->rec_pending = 0;
+  BSC_ENTER(ctx);
+  const int rc = bsc_records_finish(ctx, n_records);
+  *n_bytes = ctx->bcf_bytes;
+  return rc;
 }
 
 int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out) {

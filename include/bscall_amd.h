@@ -693,6 +693,16 @@ int bsc_bcf_sites_device(bsc_context *ctx, const void *d_core, const void *d_aux
 int bsc_block_bcf(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
                   const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids,
                   const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records);
+/* the split form (as bsc_block_records_submit / _submit_inplace / _fetch; one block in flight per context): queue and return, then wait.
+ * _submit copies the inputs into the context's staging area (the caller's buffers are free at once); _submit_inplace reads them where
+ * they lie (page-locked buffers: a true DMA) and they must stay unchanged until the fetch */
+int bsc_block_bcf_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                         const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids,
+                         const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap);
+int bsc_block_bcf_submit_inplace(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x,
+                                 uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid,
+                                 const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap);
+int bsc_block_bcf_fetch(bsc_context *ctx, uint64_t *n_bytes, uint64_t *n_records);
 int bsc_block_bcf_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, const bsc_misms *misms,
                       uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
                       const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out,

@@ -226,6 +226,50 @@ def test_block_bcf_equals_block_records_then_the_host_encoder(caller):
     assert n_rec == 0 and got == b""
 
 
+def test_block_bcf_split_form_and_two_contexts_alternating(caller):
+    """bsc_block_bcf_submit / _fetch: the bytes of the blocking call; one block in flight per context, whichever entry queued it; two
+    contexts alternating from one thread (block k + 1 queued while block k's stream is still on its way back) write the same streams."""
+    blocks = []
+    for k in range(4):
+        x = 50_000 + 90_000 * k
+        tpl, seq, y, ref = _reads_block(88172645463325252 + 60 + k, x, 60_000 + 7_001 * k, 30)
+        blocks.append((tpl, seq, x, y, ref))
+    want = [caller.block_bcf(tpl, seq, x, y, ref, k) for k, (tpl, seq, x, y, ref) in enumerate(blocks)]
+    tpl, seq, x, y, ref = blocks[0]
+    out = B.PinnedBuffer(200 * (y - x + 1), np.uint8)
+    with pytest.raises(B.BscError, match="no block was submitted"):
+        caller.block_bcf_fetch()
+    caller.block_bcf_submit(tpl, seq, x, y, ref, 0, out.array)
+    tpl[:] = 0  # the inputs were staged: the caller's arrays are free at once
+    with pytest.raises(B.BscError, match="fetched"):
+        caller.block_bcf_submit(*blocks[1][:5], 1, out.array)
+    with pytest.raises(B.BscError, match="fetched"):
+        caller.block_records(blocks[1][0], blocks[1][1], blocks[1][2], blocks[1][3], blocks[1][4])
+    with pytest.raises(B.BscError, match="no block was submitted"):
+        caller.block_records_fetch()
+    got, n_rec = caller.block_bcf_fetch()
+    assert (got.tobytes(), n_rec) == want[0]
+    out.free()
+    blocks[0] = _reads_block(88172645463325252 + 60, 50_000, 60_000, 30)
+    blocks[0] = (blocks[0][0], blocks[0][1], 50_000, blocks[0][2], blocks[0][3])
+    with B.SiteCaller() as c2:
+        ctxs = [caller, c2]
+        outs = [B.PinnedBuffer(200 * 100_000, np.uint8), B.PinnedBuffer(200 * 100_000, np.uint8)]
+        got = []
+        for k, (tpl, seq, x, y, ref) in enumerate(blocks):
+            c = ctxs[k & 1]
+            if k >= 2:
+                g, n = c.block_bcf_fetch()
+                got.append((g.tobytes(), n))
+            c.block_bcf_submit(tpl, seq, x, y, ref, k, outs[k & 1].array, inplace=bool(k & 2))  # staged and in place in turn
+        for k in (2, 3):
+            g, n = ctxs[k & 1].block_bcf_fetch()
+            got.append((g.tobytes(), n))
+        for o in outs:
+            o.free()
+    assert got == want
+
+
 def test_sites_form_equals_packing_then_encoding(caller):
     """bsc_bcf_sites_device: the per-position arrays the reads-in chain leaves (records + the packed half) -> the stream, no packing pass;
     the bytes of bsc_vcf_compact_device + bsc_bcf_block_device and of the host encoder over the packed records, with names, for block

@@ -78,3 +78,30 @@ print("pipeline, one host thread, two contexts alternating (submit_inplace k+1 b
     NB, dt * 1e3, NB * nn / dt / 1e6))
 for c in ctxs:
     c.close()
+
+# the same with the BCF stream coming back instead of the packed records (bsc_block_bcf; bsc_block_bcf_submit_inplace / _fetch)
+c = B.SiteCaller()
+pb = bufs[0]
+blob, n_rec = c.block_bcf(pb[0].array, pb[1].array, x, y, pb[2].array, 0)
+outs = [B.PinnedBuffer(len(blob) + 4096, np.uint8), B.PinnedBuffer(len(blob) + 4096, np.uint8)]
+t0 = time.perf_counter()
+for _ in range(REPS):
+    c.block_bcf_submit(pb[0].array, pb[1].array, x, y, pb[2].array, 0, outs[0].array, inplace=True)
+    g, nr_ = c.block_bcf_fetch()
+dt = time.perf_counter() - t0
+assert nr_ == n_rec and len(g) == len(blob)
+print("BCF stream back (%.1f bytes per position), one context: %d blocks in %.1f ms -> %.1f M positions/s" % (len(blob) / nn, REPS, dt * 1e3, REPS * nn / dt / 1e6))
+ctxs = [c, B.SiteCaller()]
+ctxs[1].block_bcf(pb[0].array, pb[1].array, x, y, pb[2].array, 0)
+t0 = time.perf_counter()
+for k in range(NB):
+    ctxs[k & 1].block_bcf_submit(pb[0].array, pb[1].array, x, y, pb[2].array, 0, outs[k & 1].array, inplace=True)
+    if k:
+        g, nr_ = ctxs[(k - 1) & 1].block_bcf_fetch()
+g, nr_ = ctxs[(NB - 1) & 1].block_bcf_fetch()
+dt = time.perf_counter() - t0
+assert nr_ == n_rec and g.tobytes() == blob
+print("BCF stream back, one host thread, two contexts alternating (submit_inplace k+1 before fetch k): %d blocks in %.1f ms -> %.1f M positions/s" % (
+    NB, dt * 1e3, NB * nn / dt / 1e6))
+for cc in ctxs:
+    cc.close()
