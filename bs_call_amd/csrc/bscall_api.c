@@ -10,6 +10,7 @@
 #endif
 #include <hip/hip_runtime_api.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -152,6 +153,8 @@ struct bsc_context {
   size_t cap_btb, cap_bto, cap_bscn, cap_bnm, cap_bcf, cap_btot;
   void *d_emit; /* the chain's emit flags, a byte per position, for the block entries' packing / encoding passes (bsc_records_queue) */
   size_t cap_emit;
+  hipEvent_t ev_h2d; /* recorded behind a block's uploads (bsc_records_queue): the next block of ANY context on this device starts its own
+                        uploads behind it (bsc_h2d_turn) */
   const void *emit_hint; /* set around the bsc_vcf_compact_device call of bsc_records_queue: the flags of exactly these arrays */
   uint8_t *bcf_out;
   uint64_t bcf_cap, bcf_copied, bcf_bytes; /* bcf_bytes: the length of the last block's stream (also when it did not fit) */
@@ -399,6 +402,8 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
   return BSC_OK;
 }
 
+static void bsc_h2d_turn_forget(bsc_context *ctx);
+
 int bsc_destroy(bsc_context *ctx) {
   if (!ctx) return BSC_OK;
   bsc_devguard guard_ __attribute__((cleanup(bsc_devguard_exit), unused)) = {-1};
@@ -463,6 +468,7 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_bcf);
   hipFree(ctx->d_btot);
   hipFree(ctx->d_emit);
+  bsc_h2d_turn_forget(ctx);
   hipFree(ctx->d_mblk);
   hipFree(ctx->d_mtab);
   hipFree(ctx->d_refp);
@@ -1723,6 +1729,53 @@ typedef struct {
 } bsc_bcf_req;
 
 /*
+ * Uploads take turns.  Two contexts driven alternately from one host thread (block k + 1 queued while block k is in flight: the pipelined
+ * use the split forms exist for) fall into step when their uploads start together: both halves of every pair of blocks then share the
+ * link in each direction in turn and finish together, and nothing overlaps (tools/bench_two_contexts.py: 555-570 M positions/s for the BCF
+ * entry, 780 with the turns).  So a block's uploads are queued behind the previous block's — whichever
+ * context of this process and device queued it: its copy-out and kernels then overlap the next block's uploads by construction.  One event
+ * per context, a process-wide pointer to the last one recorded; a context that goes away takes its event out.
+ */
+static pthread_mutex_t bsc_h2d_lock = PTHREAD_MUTEX_INITIALIZER;
+static hipEvent_t bsc_h2d_last = NULL;
+static int bsc_h2d_last_dev = -1;
+static const bsc_context *bsc_h2d_last_ctx = NULL;
+
+static void bsc_h2d_turn_begin(bsc_context *ctx, hipStream_t s) { /* before a block's first upload */
+  if (getenv("BSC_NO_H2D_TURNS")) return;
+  pthread_mutex_lock(&bsc_h2d_lock);
+  if (bsc_h2d_last && bsc_h2d_last_ctx != ctx && bsc_h2d_last_dev == ctx->device) (void)hipStreamWaitEvent(s, bsc_h2d_last, 0);
+  pthread_mutex_unlock(&bsc_h2d_lock);
+}
+
+static void bsc_h2d_turn_end(bsc_context *ctx, hipStream_t s) { /* behind its last upload */
+  if (getenv("BSC_NO_H2D_TURNS")) return;
+  if (!ctx->ev_h2d && hipEventCreateWithFlags(&ctx->ev_h2d, hipEventDisableTiming) != hipSuccess) {
+    ctx->ev_h2d = NULL;
+    (void)hipGetLastError();
+    return;
+  }
+  if (hipEventRecord(ctx->ev_h2d, s) != hipSuccess) return;
+  pthread_mutex_lock(&bsc_h2d_lock);
+  bsc_h2d_last = ctx->ev_h2d;
+  bsc_h2d_last_dev = ctx->device;
+  bsc_h2d_last_ctx = ctx;
+  pthread_mutex_unlock(&bsc_h2d_lock);
+}
+
+static void bsc_h2d_turn_forget(bsc_context *ctx) { /* bsc_destroy */
+  pthread_mutex_lock(&bsc_h2d_lock);
+  if (bsc_h2d_last_ctx == ctx) {
+    bsc_h2d_last = NULL;
+    bsc_h2d_last_ctx = NULL;
+    bsc_h2d_last_dev = -1;
+  }
+  pthread_mutex_unlock(&bsc_h2d_lock);
+  if (ctx->ev_h2d) (void)hipEventDestroy(ctx->ev_h2d);
+  ctx->ev_h2d = NULL;
+}
+
+/*
  * One block, reads in -> packed written records out, on the reads-in chain (bsc_reads_chain_queue): H2D of the block,
  * template checks + ordering, ONE kernel from reads to records (+ the second half of every bsc_vcf_rec), packing, and
  * the copy-out — all queued back to back; the host waits ONCE, for the verdict on the templates, the record count and the
@@ -1789,12 +1842,17 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   ctx->blk_d_tpl = ctx->d_tpl;
   ctx->blk_x = x;
   ctx->mb_n = 0;
+  /* (the BCF entries: 555-570 -> 780 M positions/s with two contexts alternating; the records entries, whose longer copy-out keeps
+   * two contexts apart by itself, lose 3 % behind the wait — 713-724 -> 695-698 — and do not take turns) */
+  const int turns = bcf != NULL && !resident;
+  if (turns) bsc_h2d_turn_begin(ctx, s);
   if (nr && !resident) {
     HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz + 2, hipMemcpyHostToDevice, s));
   if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, dbsnp, (size_t)sz, hipMemcpyHostToDevice, s));
+  if (turns) bsc_h2d_turn_end(ctx, s);
   void *d_db = dbsnp ? ctx->d_vdb : NULL;
   /* the chain leaves the records' emit flags once more as a byte per position: the packing pass behind it then counts from 64 bytes a tile
    * and fetches the records that are written and nothing of the others (20 M positions: 1.08 -> 0.80 ms) */
