@@ -1,0 +1,561 @@
+/*
+ * bamstream.c — the host half of the device BAM reader (round 6): a BAM file as a stream of INFLATED bytes in page-locked slabs, with
+ * the offset of every alignment record, and nothing else.  What is left on the host of the reference's reader thread
+ * (sam_read1 under read_input, src/get_template_vector.c:49-389) is what a GPU cannot start from: the gzip members.
+ *
+ *   file (mmap)  --claim, in file order, under one lock-->  BGZF block k: (payload, isize, crc) and ITS PLACE in a slab
+ *                --N helpers, in parallel-->                inflate straight into the slab (no copy), crc32
+ *                --the same helper, in block order-->       walk the block's records (block_size prefixes) while the bytes are in
+ *                                                           its own cache: the record starts of the slab, a dword each
+ *   slab complete  -->  bsc_bamstream_next: bytes + record starts, ready for one hipMemcpyAsync each
+ *
+ * The walk is a serial chain (a record's start is known from its predecessor's size), but each link is a read of bytes the core has
+ * just written; a helper waits for its predecessor's walk, not for its inflation.  The BAM header (text, reference list) is read at
+ * open by inflating the first blocks on the caller's thread; the stream then starts again from block 0 with the header as bytes to
+ * step over, so that a stream offset is an offset into the inflated file.
+ *
+ * BAM only (SAM text and CRAM go through csrc/bamio.c or not at all).  Layout facts: SAM specification 4.1 (BGZF), 4.2 (BAM).
+ */
+#include <errno.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include "../../include/bscall_amd.h"
+
+int bsc_set_error(int code, const char *fmt, ...);
+
+typedef struct {
+  uint8_t *bytes;     /* page-locked, slab_bytes */
+  uint32_t *rec_off;  /* page-locked: starts of the records that BEGIN in this slab, relative to bytes */
+  uint64_t stream_off; /* inflated-stream offset of bytes[0] */
+  uint32_t n_bytes, n_recs;
+  uint32_t assigned, done; /* BGZF blocks placed here / inflated and walked */
+  int closed;              /* no further block will be placed here */
+  int last;                /* the stream ends with this slab */
+  int state;               /* SL_* */
+} bs_slab;
+enum { SL_FREE, SL_FILLING, SL_READY, SL_OUT };
+
+struct bsc_bamstream {
+  int fd;
+  const uint8_t *map;
+  size_t map_len;
+  /* header */
+  char *text;
+  uint32_t l_text;
+  int32_t n_ref;
+  char **ref_name;
+  uint32_t *ref_len;
+  uint64_t first_rec_off;
+  /* slabs */
+  bs_slab *slab;
+  int n_slabs;
+  size_t slab_bytes;
+  uint32_t rec_cap;
+  /* claim state (mu) */
+  pthread_mutex_t mu;
+  pthread_cond_t cv_free, cv_ready, cv_walk;
+  size_t file_pos;
+  uint64_t stream_pos;
+  uint64_t n_claimed;   /* blocks handed to helpers */
+  uint64_t fill_seq;    /* slab sequence number being filled (slab index = seq % n_slabs) */
+  uint32_t fill_off;
+  int fill_open;        /* slab fill_seq has been opened */
+  int eof, closing, claim_busy;
+  const char *err;      /* first error, raised by the consumer */
+  /* walk chain (mu) */
+  uint64_t walk_next;
+  uint64_t w_skip;
+  uint8_t w_hdr[4];
+  uint32_t w_hdr_n;
+  /* consumer */
+  uint64_t cons_seq;
+  pthread_t *th;
+  int n_threads;
+  uint64_t total_recs, total_bytes;
+};
+
+static uint32_t le32(const uint8_t *p) { return p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
+/* the BGZF block at file offset pos: payload, its length, isize, crc, the block's size.  0 = end of file, 1 = ok, -1 = *err set */
+static int bgzf_parse(const uint8_t *map, size_t len, size_t pos, const uint8_t **payload, uint32_t *clen, uint32_t *isize, uint32_t *crc,
+                      uint32_t *bsize, const char **err) {
+  if (pos == len) return 0;
+  if (len - pos < 18) {
+    *err = "BAM: truncated BGZF header";
+    return -1;
+  }
+  const uint8_t *h = map + pos;
+  if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) {
+    *err = "BAM: not a BGZF block (truncated file or plain gzip)";
+    return -1;
+  }
+  const uint32_t xlen = h[10] | (uint32_t)h[11] << 8;
+  if (len - pos < 12u + xlen) {
+    *err = "BAM: truncated BGZF header";
+    return -1;
+  }
+  uint32_t bs = 0;
+  for (uint32_t p = 0; p + 4 <= xlen;) {
+    const uint8_t *x = h + 12 + p;
+    const uint32_t sl = x[2] | (uint32_t)x[3] << 8;
+    if (x[0] == 'B' && x[1] == 'C' && sl == 2 && p + 6 <= xlen) bs = (x[4] | (uint32_t)x[5] << 8) + 1u;
+    p += 4 + sl;
+  }
+  if (bs < 12 + xlen + 8) {
+    *err = "BAM: BGZF block without a valid BC field";
+    return -1;
+  }
+  if (len - pos < bs) {
+    *err = "BAM: truncated BGZF block";
+    return -1;
+  }
+  *payload = h + 12 + xlen;
+  *clen = bs - 12 - xlen - 8;
+  *crc = le32(h + bs - 8);
+  *isize = le32(h + bs - 4);
+  *bsize = bs;
+  if (*isize > 65536) {
+    *err = "BAM: BGZF block larger than 64 KiB";
+    return -1;
+  }
+  return 1;
+}
+
+static const char *bgzf_inflate_to(const uint8_t *payload, uint32_t clen, uint8_t *dst, uint32_t isize, uint32_t crc) {
+  z_stream z;
+  memset(&z, 0, sizeof z);
+  if (inflateInit2(&z, -15) != Z_OK) return "BAM: zlib initialisation failed";
+  z.next_in = (Bytef *)payload;
+  z.avail_in = clen;
+  z.next_out = dst;
+  z.avail_out = isize;
+  const int r = inflate(&z, Z_FINISH);
+  const uint32_t produced = (uint32_t)z.total_out;
+  inflateEnd(&z);
+  if (r != Z_STREAM_END || produced != isize) return "BAM: corrupt BGZF block";
+  if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, isize) != crc) return "BAM: BGZF checksum mismatch";
+  return NULL;
+}
+
+/* the records that start in p[0 .. n) of slab s (the block lies at s->bytes + boff); the chain's state carries over */
+static const char *walk_block(bsc_bamstream *b, bs_slab *s, uint32_t boff, const uint8_t *p, uint32_t n) {
+  uint32_t o = 0;
+  while (o < n) {
+    if (b->w_skip) {
+      const uint64_t take = b->w_skip < (uint64_t)(n - o) ? b->w_skip : (uint64_t)(n - o);
+      o += (uint32_t)take;
+      b->w_skip -= take;
+      continue;
+    }
+    uint32_t bsz;
+    if (b->w_hdr_n == 0) { /* a record starts here */
+      if (s->n_recs >= b->rec_cap) return "BAM: more records in a slab than its table holds";
+      s->rec_off[s->n_recs++] = boff + o;
+      if (n - o >= 4) {
+        bsz = le32(p + o);
+        o += 4;
+      } else {
+        while (o < n) b->w_hdr[b->w_hdr_n++] = p[o++];
+        break; /* the size's other bytes are the next block's first */
+      }
+    } else {
+      while (b->w_hdr_n < 4 && o < n) b->w_hdr[b->w_hdr_n++] = p[o++];
+      if (b->w_hdr_n < 4) break;
+      bsz = le32(b->w_hdr);
+      b->w_hdr_n = 0;
+    }
+    if (bsz < 32 || bsz > (1u << 29)) return "BAM: implausible record size";
+    b->w_skip = bsz;
+  }
+  return NULL;
+}
+
+static void set_err(bsc_bamstream *b, const char *e) { /* mu held */
+  if (!b->err) b->err = e;
+  b->eof = 1;
+  pthread_cond_broadcast(&b->cv_ready);
+  pthread_cond_broadcast(&b->cv_free);
+  pthread_cond_broadcast(&b->cv_walk);
+}
+
+static void slab_maybe_ready(bsc_bamstream *b, bs_slab *s) { /* mu held */
+  if (s->state == SL_FILLING && s->closed && s->done == s->assigned) {
+    s->state = SL_READY;
+    pthread_cond_broadcast(&b->cv_ready);
+  }
+}
+
+static void close_fill_slab(bsc_bamstream *b, int last) { /* mu held */
+  if (!b->fill_open) return;
+  bs_slab *s = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
+  s->n_bytes = b->fill_off;
+  s->closed = 1;
+  s->last = last;
+  b->fill_open = 0;
+  b->fill_seq++;
+  slab_maybe_ready(b, s);
+}
+
+/* a slab for the fill position: waits for the consumer to hand the ring's next slab back.  mu held; 0 = opened, -1 = closing / error */
+static int open_fill_slab(bsc_bamstream *b) {
+  bs_slab *s0 = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
+  while (s0->state != SL_FREE && !b->closing && !b->err) pthread_cond_wait(&b->cv_free, &b->mu);
+  if (b->closing || b->err) return -1;
+  s0->state = SL_FILLING;
+  s0->stream_off = b->stream_pos;
+  s0->n_bytes = s0->n_recs = s0->assigned = s0->done = 0;
+  s0->closed = 0;
+  s0->last = 0;
+  b->fill_off = 0;
+  b->fill_open = 1;
+  return 0;
+}
+
+static void *helper(void *arg) {
+  bsc_bamstream *b = (bsc_bamstream *)arg;
+  pthread_mutex_lock(&b->mu);
+  for (;;) {
+    /* claim the next block and its place: one helper at a time, so that blocks are numbered and placed in file order even when the
+     * claimer has to wait for a slab */
+    while (b->claim_busy && !b->closing && !b->eof) pthread_cond_wait(&b->cv_free, &b->mu);
+    if (b->closing || b->eof) break;
+    b->claim_busy = 1;
+    const uint8_t *payload;
+    uint32_t clen, isize, crc, bsize;
+    const char *e = NULL;
+    int r;
+    do { /* empty blocks (the end-of-file marker) are stepped over */
+      r = bgzf_parse(b->map, b->map_len, b->file_pos, &payload, &clen, &isize, &crc, &bsize, &e);
+      if (r == 1) b->file_pos += bsize;
+    } while (r == 1 && isize == 0);
+    if (r < 0) {
+      b->claim_busy = 0;
+      set_err(b, e);
+      break;
+    }
+    if (r == 0) { /* the stream ends: with the slab being filled, or with an empty one */
+      if (b->fill_open || open_fill_slab(b) == 0) close_fill_slab(b, 1);
+      b->eof = 1;
+      b->claim_busy = 0;
+      pthread_cond_broadcast(&b->cv_ready);
+      pthread_cond_broadcast(&b->cv_free);
+      break;
+    }
+    if (b->fill_open && (size_t)b->fill_off + isize > b->slab_bytes) close_fill_slab(b, 0);
+    if (!b->fill_open && open_fill_slab(b)) {
+      b->claim_busy = 0;
+      pthread_cond_broadcast(&b->cv_free);
+      break;
+    }
+    bs_slab *s = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
+    const uint32_t boff = b->fill_off;
+    const uint64_t k = b->n_claimed++;
+    b->fill_off += isize;
+    b->stream_pos += isize;
+    s->assigned++;
+    b->claim_busy = 0;
+    pthread_cond_broadcast(&b->cv_free);
+    pthread_mutex_unlock(&b->mu);
+    e = bgzf_inflate_to(payload, clen, s->bytes + boff, isize, crc);
+    pthread_mutex_lock(&b->mu);
+    /* the walk, in block order, on the core that holds the bytes */
+    while (b->walk_next != k && !b->closing) pthread_cond_wait(&b->cv_walk, &b->mu);
+    if (b->closing) break;
+    if (!e && !b->err) {
+      pthread_mutex_unlock(&b->mu); /* only this helper is at its turn: the chain's state is its own until walk_next moves */
+      e = walk_block(b, s, boff, s->bytes + boff, isize);
+      pthread_mutex_lock(&b->mu);
+    }
+    b->walk_next = k + 1;
+    pthread_cond_broadcast(&b->cv_walk);
+    if (e) {
+      set_err(b, e);
+      break;
+    }
+    s->done++;
+    slab_maybe_ready(b, s);
+  }
+  pthread_mutex_unlock(&b->mu);
+  return NULL;
+}
+
+/* ---- the header, read on the caller's thread --------------------------------------------------------------------------- */
+typedef struct {
+  const uint8_t *map;
+  size_t len, pos;
+  uint8_t buf[65536];
+  uint32_t n, o;
+  uint64_t taken;
+} hdr_in;
+
+static int hdr_read(hdr_in *h, void *dst, size_t n) { /* 1, 0 = clean end, -1 = error */
+  uint8_t *d = (uint8_t *)dst;
+  size_t done = 0;
+  while (done < n) {
+    if (h->o == h->n) {
+      const uint8_t *payload;
+      uint32_t clen, isize, crc, bsize;
+      const char *e = NULL;
+      const int r = bgzf_parse(h->map, h->len, h->pos, &payload, &clen, &isize, &crc, &bsize, &e);
+      if (r < 0) return bsc_set_error(BSC_ERR_ARG, "%s", e), -1;
+      if (r == 0) return done ? (bsc_set_error(BSC_ERR_ARG, "BAM: input truncated"), -1) : 0;
+      h->pos += bsize;
+      if ((e = bgzf_inflate_to(payload, clen, h->buf, isize, crc))) return bsc_set_error(BSC_ERR_ARG, "%s", e), -1;
+      h->n = isize;
+      h->o = 0;
+      continue;
+    }
+    const size_t take = n - done < (size_t)(h->n - h->o) ? n - done : (size_t)(h->n - h->o);
+    memcpy(d + done, h->buf + h->o, take);
+    h->o += (uint32_t)take;
+    done += take;
+    h->taken += take;
+  }
+  return 1;
+}
+
+void bsc_bamstream_close(bsc_bamstream *b) {
+  if (!b) return;
+  if (b->n_threads) {
+    pthread_mutex_lock(&b->mu);
+    b->closing = 1;
+    pthread_cond_broadcast(&b->cv_free);
+    pthread_cond_broadcast(&b->cv_ready);
+    pthread_cond_broadcast(&b->cv_walk);
+    pthread_mutex_unlock(&b->mu);
+    for (int i = 0; i < b->n_threads; i++) pthread_join(b->th[i], NULL);
+  }
+  if (b->th) {
+    pthread_mutex_destroy(&b->mu);
+    pthread_cond_destroy(&b->cv_free);
+    pthread_cond_destroy(&b->cv_ready);
+    pthread_cond_destroy(&b->cv_walk);
+  }
+  free(b->th);
+  if (b->slab)
+    for (int i = 0; i < b->n_slabs; i++) {
+      bsc_free_host(b->slab[i].bytes);
+      bsc_free_host(b->slab[i].rec_off);
+    }
+  free(b->slab);
+  if (b->map && b->map != MAP_FAILED) munmap((void *)b->map, b->map_len ? b->map_len : 1);
+  if (b->fd >= 0) close(b->fd);
+  free(b->text);
+  if (b->ref_name)
+    for (int32_t i = 0; i < b->n_ref; i++) free(b->ref_name[i]);
+  free(b->ref_name);
+  free(b->ref_len);
+  free(b);
+}
+
+int bsc_bamstream_default_threads(void) {
+  cpu_set_t set;
+  int n = 0;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+  if (n <= 0) n = (int)sysconf(_SC_NPROCESSORS_ONLN);
+  if (n > 1) n -= 1; /* the caller's thread drives the device */
+  if (n > 32) n = 32;
+  return n < 1 ? 1 : n;
+}
+
+int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int n_slabs, bsc_bamstream **out) {
+  if (!path || !out) return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_open: NULL argument");
+  *out = NULL;
+  if (n_threads <= 0) n_threads = bsc_bamstream_default_threads();
+  if (n_threads > 64) n_threads = 64;
+  if (slab_bytes == 0) slab_bytes = 32u << 20;
+  if (slab_bytes < 65536u) slab_bytes = 65536u;
+  if (slab_bytes > (1ull << 31)) slab_bytes = 1ull << 31;
+  if (n_slabs <= 0) n_slabs = 8;
+  if (n_slabs < 2) n_slabs = 2;
+  bsc_bamstream *b = calloc(1, sizeof *b);
+  if (!b) return bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
+  b->fd = open(path, O_RDONLY);
+  if (b->fd < 0) {
+    const int e = errno;
+    bsc_bamstream_close(b);
+    return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_open: cannot open '%s': %s", path, strerror(e));
+  }
+  struct stat st;
+  if (fstat(b->fd, &st) || !S_ISREG(st.st_mode)) {
+    bsc_bamstream_close(b);
+    return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_open: '%s' is not a regular file", path);
+  }
+  b->map_len = (size_t)st.st_size;
+  b->map = b->map_len ? mmap(NULL, b->map_len, PROT_READ, MAP_PRIVATE, b->fd, 0) : NULL;
+  if (b->map == MAP_FAILED) {
+    b->map = NULL;
+    bsc_bamstream_close(b);
+    return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_open: cannot map '%s'", path);
+  }
+  if (b->map_len) (void)madvise((void *)b->map, b->map_len, MADV_SEQUENTIAL);
+  /* the header: magic, text, reference list.  Counts from the file are not believed before the bytes behind them have arrived. */
+  hdr_in *h = calloc(1, sizeof *h);
+  if (!h) {
+    bsc_bamstream_close(b);
+    return bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
+  }
+  h->map = b->map;
+  h->len = b->map_len;
+  uint8_t w[8];
+  int rc = hdr_read(h, w, 8);
+  if (rc <= 0 || memcmp(w, "BAM\1", 4)) {
+    free(h);
+    bsc_bamstream_close(b);
+    return rc < 0 ? BSC_ERR_ARG : bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_open: '%s' is not a BAM file (SAM text goes through bsc_bam_open)", path);
+  }
+  {
+    const uint32_t l_text = le32(w + 4);
+    size_t cap = 0;
+    while (b->l_text < l_text) {
+      const uint32_t step = l_text - b->l_text < (1u << 20) ? l_text - b->l_text : (1u << 20);
+      if ((size_t)b->l_text + step + 1 > cap) {
+        cap = ((size_t)b->l_text + step) * 2 + 1;
+        if (cap > (size_t)l_text + 1) cap = (size_t)l_text + 1;
+        char *nt = realloc(b->text, cap);
+        if (!nt) goto bad;
+        b->text = nt;
+      }
+      if (hdr_read(h, b->text + b->l_text, step) <= 0) goto bad;
+      b->l_text += step;
+    }
+    if (!b->text && !(b->text = malloc(1))) goto bad;
+    b->text[b->l_text] = 0;
+  }
+  if (hdr_read(h, w, 4) <= 0) goto bad;
+  {
+    const int32_t n_ref = (int32_t)le32(w);
+    if (n_ref < 0) goto bad;
+    size_t ref_cap = (size_t)(n_ref < 1024 ? n_ref : 1024) + 1;
+    b->ref_name = calloc(ref_cap, sizeof *b->ref_name);
+    b->ref_len = calloc(ref_cap, sizeof *b->ref_len);
+    if (!b->ref_name || !b->ref_len) goto bad;
+    for (int32_t i = 0; i < n_ref; i++) {
+      if ((size_t)i + 1 >= ref_cap) {
+        ref_cap *= 2;
+        char **nn = realloc(b->ref_name, ref_cap * sizeof *b->ref_name);
+        if (nn) b->ref_name = nn;
+        uint32_t *nl = realloc(b->ref_len, ref_cap * sizeof *b->ref_len);
+        if (nl) b->ref_len = nl;
+        if (!nn || !nl) goto bad;
+      }
+      if (hdr_read(h, w, 4) <= 0) goto bad;
+      const uint32_t ln = le32(w);
+      if (ln == 0 || ln > 65536) goto bad;
+      char *nm = malloc(ln);
+      if (!nm) goto bad;
+      b->ref_name[i] = nm;
+      b->n_ref = i + 1;
+      if (hdr_read(h, nm, ln) <= 0 || hdr_read(h, w, 4) <= 0) goto bad;
+      nm[ln - 1] = 0;
+      b->ref_len[i] = le32(w);
+    }
+  }
+  b->first_rec_off = h->taken;
+  free(h);
+  h = NULL;
+  /* slabs and helpers */
+  b->slab_bytes = (size_t)slab_bytes;
+  b->n_slabs = n_slabs;
+  b->rec_cap = (uint32_t)(slab_bytes / 36u + 2u);
+  b->slab = calloc((size_t)n_slabs, sizeof *b->slab);
+  if (!b->slab) goto nomem;
+  for (int i = 0; i < n_slabs; i++) {
+    b->slab[i].bytes = bsc_alloc_host(b->slab_bytes);
+    b->slab[i].rec_off = bsc_alloc_host((size_t)b->rec_cap * 4u);
+    if (!b->slab[i].bytes || !b->slab[i].rec_off) goto nomem;
+  }
+  b->w_skip = b->first_rec_off;
+  b->th = calloc((size_t)n_threads, sizeof *b->th);
+  if (!b->th) goto nomem;
+  pthread_mutex_init(&b->mu, NULL);
+  pthread_cond_init(&b->cv_free, NULL);
+  pthread_cond_init(&b->cv_ready, NULL);
+  pthread_cond_init(&b->cv_walk, NULL);
+  for (int i = 0; i < n_threads; i++) {
+    if (pthread_create(&b->th[b->n_threads], NULL, helper, b)) break;
+    b->n_threads++;
+  }
+  if (b->n_threads == 0) {
+    bsc_bamstream_close(b);
+    return bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: no helper thread could be started");
+  }
+  *out = b;
+  return BSC_OK;
+nomem:
+  bsc_bamstream_close(b);
+  return bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of (page-locked) memory");
+bad:
+  free(h);
+  bsc_bamstream_close(b);
+  return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_open: '%s': malformed or truncated BAM header", path);
+}
+
+int bsc_bamstream_n_refs(const bsc_bamstream *b) { return b ? b->n_ref : 0; }
+const char *bsc_bamstream_ref_name(const bsc_bamstream *b, int i) { return (b && i >= 0 && i < b->n_ref) ? b->ref_name[i] : NULL; }
+uint32_t bsc_bamstream_ref_len(const bsc_bamstream *b, int i) { return (b && i >= 0 && i < b->n_ref) ? b->ref_len[i] : 0; }
+const char *bsc_bamstream_header_text(const bsc_bamstream *b) { return b ? b->text : NULL; }
+int bsc_bamstream_threads(const bsc_bamstream *b) { return b ? b->n_threads : 0; }
+
+/* 1 = *out filled (valid until bsc_bamstream_release of it), 0 = the stream has ended, < 0 = error */
+int bsc_bamstream_next(bsc_bamstream *b, bsc_bam_slab *out) {
+  if (!b || !out) return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_next: NULL argument");
+  memset(out, 0, sizeof *out);
+  pthread_mutex_lock(&b->mu);
+  bs_slab *s = &b->slab[b->cons_seq % (uint64_t)b->n_slabs];
+  for (;;) {
+    if (s->state == SL_READY) break;
+    if (b->err) {
+      const char *e = b->err;
+      pthread_mutex_unlock(&b->mu);
+      return bsc_set_error(BSC_ERR_ARG, "%s", e);
+    }
+    if (b->eof && !b->fill_open && b->cons_seq >= b->fill_seq) { /* everything has been handed out */
+      pthread_mutex_unlock(&b->mu);
+      return 0;
+    }
+    pthread_cond_wait(&b->cv_ready, &b->mu);
+  }
+  if (s->last && (b->w_skip || b->w_hdr_n)) {
+    pthread_mutex_unlock(&b->mu);
+    return bsc_set_error(BSC_ERR_ARG, "BAM: input truncated (the last record is incomplete)");
+  }
+  s->state = SL_OUT;
+  out->bytes = s->bytes;
+  out->n_bytes = s->n_bytes;
+  out->stream_off = s->stream_off;
+  out->rec_off = s->rec_off;
+  out->n_recs = s->n_recs;
+  out->last = s->last;
+  out->seq = b->cons_seq;
+  b->cons_seq++;
+  b->total_recs += s->n_recs;
+  b->total_bytes += s->n_bytes;
+  pthread_mutex_unlock(&b->mu);
+  return 1;
+}
+
+int bsc_bamstream_release(bsc_bamstream *b, const bsc_bam_slab *sl) {
+  if (!b || !sl) return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_release: NULL argument");
+  pthread_mutex_lock(&b->mu);
+  bs_slab *s = &b->slab[sl->seq % (uint64_t)b->n_slabs];
+  if (s->state != SL_OUT || s->bytes != sl->bytes) {
+    pthread_mutex_unlock(&b->mu);
+    return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_release: not a slab that is out");
+  }
+  s->state = SL_FREE;
+  pthread_cond_broadcast(&b->cv_free);
+  pthread_mutex_unlock(&b->mu);
+  return BSC_OK;
+}
+
+uint64_t bsc_bamstream_first_record(const bsc_bamstream *b) { return b ? b->first_rec_off : 0; }
