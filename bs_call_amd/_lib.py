@@ -107,6 +107,30 @@ EXPORTS = (
     "bsc_reset_stats",
     "bsc_synth_pileup_device",
     "bsc_synth_pileup_host",
+    "bsc_bamstream_open",
+    "bsc_bamstream_close",
+    "bsc_bamstream_next",
+    "bsc_bamstream_release",
+    "bsc_bamstream_n_refs",
+    "bsc_bamstream_ref_name",
+    "bsc_bamstream_ref_len",
+    "bsc_bamstream_header_text",
+    "bsc_bamstream_first_record",
+    "bsc_bamstream_threads",
+    "bsc_bamstream_default_threads",
+    "bsc_bamdev_open",
+    "bsc_bamdev_close",
+    "bsc_bamdev_n_refs",
+    "bsc_bamdev_ref_name",
+    "bsc_bamdev_ref_len",
+    "bsc_bamdev_header_text",
+    "bsc_bamdev_next_block",
+    "bsc_bamdev_fetch_block",
+    "bsc_bamdev_filter_counts",
+    "bsc_bamdev_malformed",
+    "bsc_bamdev_run_stats",
+    "bsc_block_records_rawdev",
+    "bsc_block_bcf_rawdev",
 )
 
 
@@ -169,6 +193,16 @@ class ReaderParams(C.Structure):
 class ReadBlock(C.Structure):
     _fields_ = [("tid", C.c_int32), ("y", C.c_uint32), ("nr", C.c_uint32), ("tpl", C.c_void_p), ("seq", C.c_void_p),
                 ("seq_bytes", C.c_uint64), ("misms", C.c_void_p), ("n_misms", C.c_uint64)]
+
+
+class BamSlab(C.Structure):
+    _fields_ = [("bytes", C.c_void_p), ("stream_off", C.c_uint64), ("n_bytes", C.c_uint32), ("rec_off", C.c_void_p), ("n_recs", C.c_uint32),
+                ("last", C.c_int32), ("seq", C.c_uint64)]
+
+
+class DevReadBlock(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("x", C.c_uint32), ("y", C.c_uint32), ("nr", C.c_uint32), ("d_tpl", C.c_void_p), ("d_seq", C.c_void_p),
+                ("seq_bytes", C.c_uint64), ("d_misms", C.c_void_p), ("n_misms", C.c_uint64), ("ins_pad", C.c_uint64)]
 
 
 class BcfIds(C.Structure):
@@ -455,5 +489,54 @@ def load():
     L.bsc_synth_pileup_device.argtypes = [vp, u64, u64, u64, u32, u32, vp, vp, vp]
     L.bsc_synth_pileup_host.restype = i32
     L.bsc_synth_pileup_host.argtypes = [u64, u64, u64, u32, u32, vp, vp]
+    L.bsc_bamstream_open.restype = i32
+    L.bsc_bamstream_open.argtypes = [C.c_char_p, i32, u64, i32, C.POINTER(vp)]
+    L.bsc_bamstream_close.restype = None
+    L.bsc_bamstream_close.argtypes = [vp]
+    L.bsc_bamstream_next.restype = i32
+    L.bsc_bamstream_next.argtypes = [vp, C.POINTER(BamSlab)]
+    L.bsc_bamstream_release.restype = i32
+    L.bsc_bamstream_release.argtypes = [vp, C.POINTER(BamSlab)]
+    L.bsc_bamstream_n_refs.restype = i32
+    L.bsc_bamstream_n_refs.argtypes = [vp]
+    L.bsc_bamstream_ref_name.restype = C.c_char_p
+    L.bsc_bamstream_ref_name.argtypes = [vp, i32]
+    L.bsc_bamstream_ref_len.restype = u32
+    L.bsc_bamstream_ref_len.argtypes = [vp, i32]
+    L.bsc_bamstream_header_text.restype = C.c_char_p
+    L.bsc_bamstream_header_text.argtypes = [vp]
+    L.bsc_bamstream_first_record.restype = u64
+    L.bsc_bamstream_first_record.argtypes = [vp]
+    L.bsc_bamstream_threads.restype = i32
+    L.bsc_bamstream_threads.argtypes = [vp]
+    L.bsc_bamstream_default_threads.restype = i32
+    L.bsc_bamstream_default_threads.argtypes = []
+    L.bsc_bamdev_open.restype = i32
+    L.bsc_bamdev_open.argtypes = [vp, C.c_char_p, i32, C.POINTER(vp)]
+    L.bsc_bamdev_close.restype = None
+    L.bsc_bamdev_close.argtypes = [vp]
+    L.bsc_bamdev_n_refs.restype = i32
+    L.bsc_bamdev_n_refs.argtypes = [vp]
+    L.bsc_bamdev_ref_name.restype = C.c_char_p
+    L.bsc_bamdev_ref_name.argtypes = [vp, i32]
+    L.bsc_bamdev_ref_len.restype = u32
+    L.bsc_bamdev_ref_len.argtypes = [vp, i32]
+    L.bsc_bamdev_header_text.restype = C.c_char_p
+    L.bsc_bamdev_header_text.argtypes = [vp]
+    L.bsc_bamdev_next_block.restype = i32
+    L.bsc_bamdev_next_block.argtypes = [vp, C.POINTER(ReaderParams), C.POINTER(DevReadBlock)]
+    L.bsc_bamdev_fetch_block.restype = i32
+    L.bsc_bamdev_fetch_block.argtypes = [vp, C.POINTER(DevReadBlock), vp, vp, vp]
+    L.bsc_bamdev_filter_counts.restype = i32
+    L.bsc_bamdev_filter_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.bsc_bamdev_malformed.restype = u64
+    L.bsc_bamdev_malformed.argtypes = [vp]
+    L.bsc_bamdev_run_stats.restype = None
+    L.bsc_bamdev_run_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double)]
+    L.bsc_block_records_rawdev.restype = i32
+    L.bsc_block_records_rawdev.argtypes = [vp, vp, u32, vp, u64, vp, u64, u64, vp, u32, u32, vp, vp, vp, i32, vp, u64, vp, vp, vp]
+    L.bsc_block_bcf_rawdev.restype = i32
+    L.bsc_block_bcf_rawdev.argtypes = [vp, vp, u32, vp, u64, vp, u64, u64, vp, u32, u32, vp, vp, vp, i32, i32, C.POINTER(BcfIds), vp, vp, u64,
+                                       C.POINTER(u64), C.POINTER(u64), vp, vp]
     _lib = L
     return L

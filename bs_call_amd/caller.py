@@ -475,6 +475,49 @@ class SiteCaller:
             profile.used = int(pf.used)
         return out[: nb.value].tobytes(), nr.value, st[0]
 
+    def block_bcf_rawdev(self, blk, ref, rid, names=None, left_trim=(0, 0), right_trim=(0, 0), min_qual=20, all_positions=False, reg_start=1,
+                         reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False, cap=None, profile=None, ids=None):
+        """bsc_block_bcf_rawdev: a block of the DEVICE reader (bamdev.DeviceBamReader.device_blocks(): raw templates, reads and lists in HBM)
+        -> the block's BCF bytes; nothing of the reads crosses PCIe a second time.  Returns (bytes, n_records, PREP_STATS record)."""
+        from .abi import PREP_PARAMS, PREP_STATS
+
+        x, y = int(blk.x), int(blk.y)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        n = y - x + 1
+        if len(ref) != n + 2:
+            raise ValueError("ref must have y - x + 3 entries (x .. y + 2)")
+        db = None if dbsnp is None else np.ascontiguousarray(dbsnp, dtype=np.uint8)
+        if ids is None:
+            ids = _lib.BcfIds()
+            self._L.bsc_bcf_default_ids(C.byref(ids))
+        nm, keep = self._bcf_names(names)
+        cap_given = cap
+        cap = 64 + 192 * n if cap is None else int(cap)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        par = np.zeros(1, dtype=PREP_PARAMS)
+        par["left_trim"][0], par["right_trim"][0], par["min_qual"][0] = left_trim, right_trim, min_qual
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        nb, nr = C.c_uint64(0), C.c_uint64(0)
+        st = np.zeros(1, dtype=PREP_STATS)
+        pf = None if profile is None else _lib.ReadProfile(None, 0, 0, profile.counts.ctypes.data, profile.counts.shape[0], profile.used)
+
+        def go(stats, st_, pf_):
+            return self._L.bsc_block_bcf_rawdev(self._h, blk.d_tpl, blk.nr, blk.d_seq, blk.seq_bytes, blk.d_misms, blk.n_misms, blk.ins_pad, _ptr(par), x, y,
+                                                _ptr(ref), None if db is None else _ptr(db), C.byref(p), stats, rid, C.byref(ids),
+                                                None if nm is None else C.addressof(nm), _ptr(out), cap, C.byref(nb), C.byref(nr), _ptr(st_),
+                                                None if pf_ is None else C.byref(pf_))
+
+        rc = go(1 if with_stats else 0, st, pf)
+        if rc == -1 and nb.value > cap and cap_given is None:
+            cap = int(nb.value)
+            out = np.empty(cap, dtype=np.uint8)
+            rc = go(0, np.zeros(1, dtype=PREP_STATS), None)
+        _check(rc)
+        del keep
+        if pf is not None:
+            profile.used = int(pf.used)
+        return out[: nb.value].tobytes(), nr.value, st[0]
+
     def block_bcf_submit(self, templates, seq, x, y, ref, rid, out, names=None, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None,
                          with_stats=False, ids=None, inplace=False):
         """bsc_block_bcf_submit: queue the block and return (inputs are staged: the arrays may be reused at once); `out`: a writable uint8

@@ -1,7 +1,7 @@
 /*
  * bamdev_core.h — the statements of the device BAM reader (round 6), written once: included by csrc/bamdev.hip (compiled by hipcc
  * for gfx950: the kernels call these per lane) and by tests/emul/bamdev_emul.cpp (compiled by g++: the SAME statements run by
- * loops on the CPU, so that their logic can be checked against csrc/bamio.c and oracle/py_bam.py in a container without a GPU —
+ * loops on the CPU, so that their logic can be checked against csrc/bamio.c and the test suite's independent Python restatement in a container without a GPU —
  * test infrastructure, never loaded by the product).
  *
  * What is restated, with the reference line each part follows (through csrc/bamio.c, which cites them statement by statement):
@@ -403,10 +403,18 @@ BD_FN void bd_new_slot(const bd_ws &ws, bd_run &r, uint32_t u, uint32_t ix, uint
   ws.slot_list[r.list0 + r.n_slots++] = u;
 }
 
+/* additions to the counters: the parallel path's lanes share them (atomics), the replay's one lane adds to its own block's (plain: they
+ * live in its private memory, which flat atomics must not touch) */
 #if defined(__HIP_DEVICE_COMPILE__)
-#define BD_ADD64(p, v) atomicAdd((p), (unsigned long long)(v))
+#define BD_ADD64(p, v)                                      \
+  do {                                                      \
+    if (r.local) atomicAdd((p), (unsigned long long)(v));   \
+    else *(p) += (unsigned long long)(v);                   \
+  } while (0)
+#define BD_ADD64_SHARED(p, v) atomicAdd((p), (unsigned long long)(v))
 #else
 #define BD_ADD64(p, v) (*(p) += (unsigned long long)(v))
+#define BD_ADD64_SHARED(p, v) (*(p) += (unsigned long long)(v))
 #endif
 
 /*
@@ -719,8 +727,8 @@ BD_FN void bd_f_join(const bd_ws &ws, const bd_params &par, uint32_t u, const ui
 #endif
     return;
   }
-  BD_ADD64(&ws.cts[BD_FLT_PAIR_NOT_FOUND], 1);
-  BD_ADD64(&ws.bases[BD_FLT_PAIR_NOT_FOUND], d.l_seq);
+  BD_ADD64_SHARED(&ws.cts[BD_FLT_PAIR_NOT_FOUND], 1);
+  BD_ADD64_SHARED(&ws.bases[BD_FLT_PAIR_NOT_FOUND], d.l_seq);
   if (par.keep_duplicates && par.keep_unmatched) { /* kept as a template of its own (sorted input: `skip` otherwise) */
     const uint32_t x = (d.fwd > 0 ? d.fwd : d.rev) + d.aln_len;
     if (x > (uint32_t)scan[u]) *irregular = 1; /* it would move max_pos: the segmentation is not the scan's */

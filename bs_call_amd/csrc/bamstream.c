@@ -16,6 +16,7 @@
  *
  * BAM only (SAM text and CRAM go through csrc/bamio.c or not at all).  Layout facts: SAM specification 4.1 (BGZF), 4.2 (BAM).
  */
+#define _GNU_SOURCE
 #include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
@@ -81,6 +82,7 @@ struct bsc_bamstream {
   pthread_t *th;
   int n_threads;
   uint64_t total_recs, total_bytes;
+  int unpinned; /* no device: ordinary memory (the stream is usable without a GPU; uploads from it are staged by the runtime) */
 };
 
 static uint32_t le32(const uint8_t *p) { return p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
@@ -343,8 +345,13 @@ void bsc_bamstream_close(bsc_bamstream *b) {
   free(b->th);
   if (b->slab)
     for (int i = 0; i < b->n_slabs; i++) {
-      bsc_free_host(b->slab[i].bytes);
-      bsc_free_host(b->slab[i].rec_off);
+      if (b->unpinned) {
+        free(b->slab[i].bytes);
+        free(b->slab[i].rec_off);
+      } else {
+        bsc_free_host(b->slab[i].bytes);
+        bsc_free_host(b->slab[i].rec_off);
+      }
     }
   free(b->slab);
   if (b->map && b->map != MAP_FAILED) munmap((void *)b->map, b->map_len ? b->map_len : 1);
@@ -470,8 +477,20 @@ int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int
   b->slab = calloc((size_t)n_slabs, sizeof *b->slab);
   if (!b->slab) goto nomem;
   for (int i = 0; i < n_slabs; i++) {
-    b->slab[i].bytes = bsc_alloc_host(b->slab_bytes);
-    b->slab[i].rec_off = bsc_alloc_host((size_t)b->rec_cap * 4u);
+    if (!b->unpinned) {
+      b->slab[i].bytes = bsc_alloc_host(b->slab_bytes);
+      if (!b->slab[i].bytes && i == 0) b->unpinned = 1; /* no device at all: the stream still works, from ordinary memory */
+      else b->slab[i].rec_off = bsc_alloc_host((size_t)b->rec_cap * 4u);
+    }
+    if (b->unpinned) {
+      void *p1 = NULL, *p2 = NULL;
+      if (posix_memalign(&p1, 4096, b->slab_bytes) || posix_memalign(&p2, 4096, (size_t)b->rec_cap * 4u)) {
+        free(p1);
+        goto nomem;
+      }
+      b->slab[i].bytes = p1;
+      b->slab[i].rec_off = p2;
+    }
     if (!b->slab[i].bytes || !b->slab[i].rec_off) goto nomem;
   }
   b->w_skip = b->first_rec_off;

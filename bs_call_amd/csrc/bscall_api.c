@@ -241,6 +241,10 @@ int bsc_set_error(int code, const char *fmt, ...) {
                                           __FILE__, __LINE__);                                               \
   } while (0)
 
+/* for the library's other translation units (csrc/bamdev.hip) */
+int bsc_ctx_device(const bsc_context *ctx) { return ctx->device; }
+void *bsc_ctx_stream(const bsc_context *ctx) { return (void *)ctx->stream; }
+
 int bsc_abi_version(void) { return BSC_ABI_VERSION; }
 const char *bsc_last_error(void) { return bsc_errbuf; }
 
@@ -1991,6 +1995,39 @@ int bsc_block_bcf(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const 
  * the grouping, the walk and the chain; the process thread's per-template work (src/process_template.c:36-111) never touches a
  * host core.  x .. y: the block as the reader found it (src/get_template_vector.c:141-147; x = bsc_block_start).
  */
+/* the part behind the uploads: raw templates, reads and lists DEVICE-resident (the host entry's own copies, or the device reader's
+ * arrays); cap = room for the prepared reads */
+static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_rseq, uint64_t seq_bytes, const void *d_rms,
+                                     uint64_t n_misms, uint64_t cap, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref,
+                                     const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap,
+                                     uint64_t *n_out, bsc_prep_stats *prep_stats, bsc_read_profile *profile, const bsc_bcf_req *bcf) {
+  int rc;
+  if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)nr * sizeof(bsc_template)))) return rc;
+  if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)cap))) return rc;
+  hipStream_t s = ctx->stream;
+  uint64_t used = 0;
+  bsc_read_profile dp;
+  if (profile) { /* the block's reference codes (x .. y + 2) are what the profile reads: up they go first */
+    const uint64_t n_ref = (uint64_t)y - x + 3;
+    if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)n_ref))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)n_ref, hipMemcpyHostToDevice, s));
+    dp = *profile;
+    dp.ref = ctx->d_ref;
+    dp.x = x;
+    dp.n_ref = (uint32_t)n_ref;
+  }
+  rc = bsc_prepare_templates_device(ctx, d_raw, nr, d_rseq, seq_bytes, d_rms, n_misms, prep, ctx->d_tpl, ctx->d_seq, cap, &used, prep_stats,
+                                    profile ? &dp : NULL, s);
+  if (profile) profile->used = dp.used;
+  if (rc) return rc; /* (it has waited for the stream: nothing reads the caller's buffers any more) */
+  rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 2, bcf);
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
+  return bsc_records_finish(ctx, n_out);
+}
+
 static int bsc_block_records_raw_(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
                                   const bsc_misms *misms, uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref,
                                   const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap,
@@ -2013,33 +2050,58 @@ static int bsc_block_records_raw_(bsc_context *ctx, const bsc_raw_template *raw,
   if ((rc = bsc_reserve(&ctx->d_raw, &ctx->cap_raw, (size_t)nr * sizeof *raw))) return rc;
   if ((rc = bsc_reserve(&ctx->d_rseq, &ctx->cap_rseq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_rms, &ctx->cap_rms, (size_t)(n_misms ? n_misms : 1) * sizeof *misms))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)nr * sizeof(bsc_template)))) return rc;
-  if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)cap))) return rc;
   hipStream_t s = ctx->stream;
   HIP_TRY(hipMemcpyAsync(ctx->d_raw, raw, (size_t)nr * sizeof *raw, hipMemcpyHostToDevice, s));
   if (seq_bytes) HIP_TRY(hipMemcpyAsync(ctx->d_rseq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
   if (n_misms) HIP_TRY(hipMemcpyAsync(ctx->d_rms, misms, (size_t)n_misms * sizeof *misms, hipMemcpyHostToDevice, s));
-  uint64_t used = 0;
-  bsc_read_profile dp;
-  if (profile) { /* the block's reference codes (x .. y + 2) are what the profile reads: up they go first */
-    const uint64_t n_ref = (uint64_t)y - x + 3;
-    if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)n_ref))) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)n_ref, hipMemcpyHostToDevice, s));
-    dp = *profile;
-    dp.ref = ctx->d_ref;
-    dp.x = x;
-    dp.n_ref = (uint32_t)n_ref;
+  return bsc_block_records_rawdev_(ctx, ctx->d_raw, nr, ctx->d_rseq, seq_bytes, ctx->d_rms, n_misms, cap, prep, x, y, ref, dbsnp, params, with_stats, out,
+                                   out_cap, n_out, prep_stats, profile, bcf);
+}
+
+/* the same from device-resident raw templates (the device reader's blocks, bsc_bamdev_next_block) */
+static int bsc_block_rawdev_check(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms,
+                                  uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const bsc_vcf_params *params,
+                                  uint64_t *n_out, const void *out, uint64_t out_cap) {
+  if (!ctx || !ref || !params || !prep || !n_out || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_rawdev: NULL argument");
+  if (y < x) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_rawdev: y (%u) < x (%u)", y, x);
+  if (ctx->rec_pending || ctx->pending_sz) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_rawdev: a submitted block has not been fetched");
+  if (nr && (!d_raw || (seq_bytes && !d_seq) || (n_misms && !d_misms))) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_rawdev: NULL input buffer");
+  if (nr && y - x > 0x0ffffffeu) return bsc_fail(BSC_ERR_ARG, "bsc_block_records_rawdev: block longer than 2^28 - 1 positions");
+  return BSC_OK;
+}
+
+int bsc_block_records_rawdev(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms, uint64_t n_misms,
+                             uint64_t ins_pad, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
+                             const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out, bsc_prep_stats *prep_stats,
+                             bsc_read_profile *profile) {
+  int rc = bsc_block_rawdev_check(ctx, d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, prep, x, y, ref, params, n_out, out, out_cap);
+  if (rc) return rc;
+  *n_out = 0;
+  if (prep_stats) memset(prep_stats, 0, sizeof *prep_stats);
+  if (!nr) return bsc_block_records_(ctx, NULL, 0, NULL, 0, x, y, ref, dbsnp, params, with_stats, out, out_cap, n_out, NULL);
+  BSC_ENTER(ctx);
+  return bsc_block_records_rawdev_(ctx, d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, seq_bytes + ins_pad + 16, prep, x, y, ref, dbsnp, params, with_stats,
+                                   out, out_cap, n_out, prep_stats, profile, NULL);
+}
+
+int bsc_block_bcf_rawdev(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms, uint64_t n_misms,
+                         uint64_t ins_pad, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
+                         const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out,
+                         uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records, bsc_prep_stats *prep_stats, bsc_read_profile *profile) {
+  int rc = bsc_bcf_req_check("bsc_block_bcf_rawdev", ids, out, out_cap, n_bytes, n_records);
+  if (rc) return rc;
+  if ((rc = bsc_block_rawdev_check(ctx, d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, prep, x, y, ref, params, n_records, NULL, 0))) return rc;
+  if (prep_stats) memset(prep_stats, 0, sizeof *prep_stats);
+  const bsc_bcf_req req = {rid, ids, names, out, out_cap};
+  ctx->bcf_bytes = 0;
+  if (!nr) rc = bsc_block_records_(ctx, NULL, 0, NULL, 0, x, y, ref, dbsnp, params, with_stats, NULL, 0, n_records, &req);
+  else {
+    BSC_ENTER(ctx);
+    rc = bsc_block_records_rawdev_(ctx, d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, seq_bytes + ins_pad + 16, prep, x, y, ref, dbsnp, params, with_stats,
+                                   NULL, 0, n_records, prep_stats, profile, &req);
   }
-  rc = bsc_prepare_templates_device(ctx, ctx->d_raw, nr, ctx->d_rseq, seq_bytes, ctx->d_rms, n_misms, prep, ctx->d_tpl, ctx->d_seq, cap, &used,
-                                    prep_stats, profile ? &dp : NULL, s);
-  if (profile) profile->used = dp.used;
-  if (rc) return rc; /* (it has waited for the stream: nothing reads the caller's buffers any more) */
-  rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 2, bcf);
-  if (rc) {
-    (void)hipStreamSynchronize(ctx->stream);
-    return rc;
-  }
-  return bsc_records_finish(ctx, n_out);
+  *n_bytes = ctx->bcf_bytes;
+  return rc;
 }
 
 int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,

@@ -16,14 +16,15 @@ from .caller import ReadProfile, SiteCaller, gc_bins, prepare_templates
 def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: str = "SAMPLE", report_path: Optional[str] = None,
         caller: Optional[SiteCaller] = None, dbsnp=None, compressed: bool = True, date=None, left_trim=(0, 0), right_trim=(0, 0),
         min_qual: Optional[int] = None, benchmark_mode: bool = False, under_conv: Optional[float] = None, over_conv: Optional[float] = None,
-        host_prep: bool = False, host_bcf: bool = False, **reader_kw) -> dict:
+        host_prep: bool = False, host_bcf: bool = False, device_reader: bool = False, **reader_kw) -> dict:
     """reference: contig name -> uint8 reference codes (0 = N, 1..4 = ACGT; position 1 first).  Returns a summary dict.
     under_conv / over_conv / min_qual (defaults 0.01 / 0.05 / 20, src/init_param.c:26-31) are the MODEL's parameters: without
     `caller` the run builds its SiteCaller from them; with one, they are taken from it and a differing explicit value is an error
     (the header must name the thresholds the genotypes were computed with, src/print_vcf.c:647-692).  host_prep: the read
     pre-processing on the host (bsc_prepare_templates_profile) instead of the device (round 5's default) — same bytes.  host_bcf:
     the packed records come back and the host encodes them (bsc_bcf_block) instead of the device's encoder (bsc_block_bcf_raw,
-    round 5's default) — same bytes."""
+    round 5's default) — same bytes.  device_reader: the blocks are formed on the device from the inflated BAM bytes (round 6:
+    bamdev.DeviceBamReader — the host only inflates) and go on to bsc_block_bcf_rawdev where they lie — same bytes."""
     own = caller is None
     if own:
         under_conv = 0.01 if under_conv is None else under_conv
@@ -43,7 +44,15 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
         per_contig = []
         n_blocks = n_records = 0
         c.reset_site_stats()
-        with BamReader(bam_path, **reader_kw) as rd:
+        if device_reader:
+            if host_prep or host_bcf:
+                raise ValueError("device_reader goes with the device pre-processing and encoder")
+            from .bamdev import DeviceBamReader
+
+            reader = DeviceBamReader(c, bam_path, **reader_kw)
+        else:
+            reader = BamReader(bam_path, **reader_kw)
+        with reader as rd:
             refs = rd.refs
             # the header names the run's own thresholds (print_vcf_header, src/print_vcf.c:647-692)
             header = vcf.header_text([(n, l) for n, l in refs], sample, under_conv=under_conv, over_conv=over_conv,
@@ -53,7 +62,12 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
             def block_blobs():
                 nonlocal n_blocks, n_records, base_filter, passed
                 before, cur_tid = c.site_totals(), -1
-                for tid, y, raw, seq, ms in rd.blocks():
+                for item in (rd.device_blocks() if device_reader else rd.blocks()):
+                    if device_reader:
+                        dblk = item
+                        tid, y = int(dblk.tid), int(dblk.y)
+                    else:
+                        tid, y, raw, seq, ms = item
                     name, _ = refs[tid]
                     if tid != cur_tid:
                         if cur_tid >= 0:
@@ -67,11 +81,19 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
                         gc_start, bins = gc_bins(reference[name])
                         c.set_gc_bins_host(bins, gc_start)
                     codes = reference[name]
-                    x = int(raw["pos"][0][0]) or int(raw["pos"][0][1])
-                    x = x - 2 if x > 2 else 1  # process_template_vector, src/process_template.c:22-28
+                    if device_reader:
+                        x = int(dblk.x)
+                    else:
+                        x = int(raw["pos"][0][0]) or int(raw["pos"][0][1])
+                        x = x - 2 if x > 2 else 1  # process_template_vector, src/process_template.c:22-28
                     ref = block_reference(codes, x, y)
                     flags = None if dbsnp is None else dbsnp.flags(x, y - x + 1)
-                    if host_prep:  # round 4's split: the process thread's per-template work here, then the block
+                    if device_reader:  # the block is in HBM already: pre-processing, calling, encoding behind it
+                        names = None if dbsnp is None else dbsnp.names(x, y - x + 1)
+                        blob, n_rec, st = c.block_bcf_rawdev(dblk, ref, tid, names=names, left_trim=left_trim, right_trim=right_trim, min_qual=min_qual,
+                                                             reg_stop=len(codes), dbsnp=flags, with_stats=True, profile=prof)
+                        recs = None
+                    elif host_prep:  # round 4's split: the process thread's per-template work here, then the block
                         tpl, pseq, st = prepare_templates(raw, seq, ms, left_trim, right_trim, min_qual, profile=prof, x=x, ref=ref)
                         recs = c.block_records(tpl, pseq, x, y, ref, reg_stop=len(codes), dbsnp=flags, with_stats=True)
                     elif host_bcf:  # raw templates up, pre-processing and the read profile on the device (bsc_block_records_raw)

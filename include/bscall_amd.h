@@ -776,6 +776,84 @@ void bsc_bam_filter_counts(const bsc_bam *b, uint64_t cts[15], uint64_t bases[15
 uint64_t bsc_bam_malformed(const bsc_bam *b);
 
 /*
+ * The reader ON THE DEVICE (round 6; csrc/bamstream.c + csrc/bamdev.hip): the same blocks as bsc_bam_next_block, formed in HBM from the
+ * inflated bytes of a BAM file — what the reference's reader thread does with a record (get_next_align_details, src/input_sam.c:222-312;
+ * read_input, src/get_template_vector.c:49-389) runs as kernels, the host only inflates.
+ *
+ *   bsc_bamstream_*        the host half, usable on its own: the file as a stream of INFLATED bytes in page-locked slabs, with the offset
+ *                          of every alignment record (hts_open + bgzf_read's inflate + the block_size chain of bam_read1).  n_threads
+ *                          helpers (<= 0: one per core this process may run on, at most 32) inflate straight into the slabs;
+ *                          slab_bytes / n_slabs 0 = 32 MiB x 8.  bsc_bamstream_next: 1 = *out filled (valid until it is released),
+ *                          0 = end of the stream, < 0 = error.  BAM only.
+ *   bsc_bamdev_open        a reader over `path` bound to ctx's device and stream
+ *   bsc_bamdev_next_block  1 = *blk describes the next block, its templates / reads / lists DEVICE-resident (valid until the next call)
+ *                          and laid out as bsc_prepare_templates_device / bsc_block_bcf_rawdev take them; 0 = end of input; < 0 = error.
+ *                          Byte for byte the templates, reads, lists, y and filter counters of bsc_bam_next_block (tests/test_gpu_bamdev.py),
+ *                          read offsets apart (a template's reads lie where their records came, block-relative).  Input the parallel
+ *                          kernels are not exact for (re-used read names, unsorted records ...) goes through a one-lane replay of the
+ *                          reference's loop on the device: slow, same bytes.  Divergences from csrc/bamio.c: a record of one base that a
+ *                          duplicate comparison looks at reads quality 0 for the byte behind it (bamio.c reads its buffer's next byte).
+ *   bsc_bamdev_fetch_block the block's arrays on the host (bsc_read_block's view)
+ *   bsc_block_bcf_rawdev / bsc_block_records_rawdev    bsc_block_bcf_raw / bsc_block_records_raw from device-resident raw templates
+ *                          (d_raw 8-byte, d_misms 4-byte aligned; ins_pad >= the sizes of all BSC_MISMS_INS entries: room for the
+ *                          padded deletions).  ref / dbsnp / names are host arrays as before.
+ */
+typedef struct bsc_bamstream bsc_bamstream;
+typedef struct {
+  const uint8_t *bytes;     /* page-locked */
+  uint64_t stream_off;      /* offset of bytes[0] in the inflated file */
+  uint32_t n_bytes;
+  const uint32_t *rec_off;  /* page-locked: where the records that START in this slab start, relative to bytes */
+  uint32_t n_recs;
+  int32_t last;             /* the stream ends with this slab */
+  uint64_t seq;
+} bsc_bam_slab;
+int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int n_slabs, bsc_bamstream **out);
+void bsc_bamstream_close(bsc_bamstream *b);
+int bsc_bamstream_next(bsc_bamstream *b, bsc_bam_slab *out);
+int bsc_bamstream_release(bsc_bamstream *b, const bsc_bam_slab *slab);
+int bsc_bamstream_n_refs(const bsc_bamstream *b);
+const char *bsc_bamstream_ref_name(const bsc_bamstream *b, int i);
+uint32_t bsc_bamstream_ref_len(const bsc_bamstream *b, int i);
+const char *bsc_bamstream_header_text(const bsc_bamstream *b);
+uint64_t bsc_bamstream_first_record(const bsc_bamstream *b); /* stream offset of the first alignment record */
+int bsc_bamstream_threads(const bsc_bamstream *b);
+int bsc_bamstream_default_threads(void);
+
+typedef struct bsc_bamdev bsc_bamdev;
+typedef struct {
+  int32_t tid;
+  uint32_t x, y;           /* the block as the process thread sees it: x = bsc_block_start of the first template */
+  uint32_t nr;
+  const void *d_tpl;       /* bsc_raw_template[nr] */
+  const void *d_seq;
+  uint64_t seq_bytes;
+  const void *d_misms;     /* bsc_misms[n_misms] */
+  uint64_t n_misms;
+  uint64_t ins_pad;
+} bsc_dev_read_block;
+int bsc_bamdev_open(bsc_context *ctx, const char *path, int n_threads, bsc_bamdev **out);
+void bsc_bamdev_close(bsc_bamdev *r);
+int bsc_bamdev_n_refs(const bsc_bamdev *r);
+const char *bsc_bamdev_ref_name(const bsc_bamdev *r, int i);
+uint32_t bsc_bamdev_ref_len(const bsc_bamdev *r, int i);
+const char *bsc_bamdev_header_text(const bsc_bamdev *r);
+int bsc_bamdev_next_block(bsc_bamdev *r, const bsc_reader_params *par, bsc_dev_read_block *blk);
+int bsc_bamdev_fetch_block(bsc_bamdev *r, const bsc_dev_read_block *blk, bsc_raw_template *tpl, uint8_t *seq, bsc_misms *misms);
+int bsc_bamdev_filter_counts(bsc_bamdev *r, uint64_t cts[15], uint64_t bases[15]);
+uint64_t bsc_bamdev_malformed(bsc_bamdev *r);
+/* counts: {device passes, passes the one-lane replay decided, records parsed, bytes uploaded}; seconds: {waiting for inflated slabs, in device passes} */
+void bsc_bamdev_run_stats(const bsc_bamdev *r, uint64_t counts[4], double seconds[2]);
+int bsc_block_records_rawdev(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms, uint64_t n_misms,
+                             uint64_t ins_pad, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
+                             const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap, uint64_t *n_out, bsc_prep_stats *prep_stats,
+                             bsc_read_profile *profile);
+int bsc_block_bcf_rawdev(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms, uint64_t n_misms,
+                         uint64_t ins_pad, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
+                         const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out,
+                         uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records, bsc_prep_stats *prep_stats, bsc_read_profile *profile);
+
+/*
  * dbSNP index (host C + zlib; csrc/dbsnp.c): the reader of the compressed index bin/dbSNP_idx writes.  In the reference
  * the index never touches the likelihoods: an entry names the record (VCF ID), forces the AA / TT homozygous-reference
  * record of a site flagged in its `fq_mask` to be written (rs_found & 2, src/print_vcf.c:139) and feeds the dbSNP
