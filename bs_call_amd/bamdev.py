@@ -62,6 +62,31 @@ class BamStream:
             yield out
 
 
+def drain_stream(path, threads=0, slab_bytes=0, n_slabs=0):
+    """The streamer alone, nothing copied: (inflated bytes, records, seconds, helper threads) — the host's inflate rate."""
+    import time
+
+    L = _lib.load()
+    h = C.c_void_p()
+    t0 = time.time()
+    _check(L.bsc_bamstream_open(str(path).encode(), int(threads), int(slab_bytes), int(n_slabs), C.byref(h)))
+    sl = _lib.BamSlab()
+    nb = nr = 0
+    try:
+        nth = int(L.bsc_bamstream_threads(h))
+        while True:
+            r = L.bsc_bamstream_next(h, C.byref(sl))
+            _check(min(r, 0))
+            if r == 0:
+                break
+            nb += sl.n_bytes
+            nr += sl.n_recs
+            _check(L.bsc_bamstream_release(h, C.byref(sl)))
+    finally:
+        L.bsc_bamstream_close(h)
+    return nb, nr, time.time() - t0, nth
+
+
 class DeviceBamReader:
     """bsc_bamdev_*: blocks of raw templates formed on the device of `caller` (a SiteCaller)."""
 

@@ -3,7 +3,10 @@
  * BAM file and a FASTA reference to an uncompressed BCF stream and the JSON report, block by block, with nothing but the
  * C ABI of include/bscall_amd.h — what bs_call's four threads do between sam_read1() and bcf_write():
  *
- *   reader thread     bsc_bam_next_block            read_input / get_next_align_details
+ *   reader thread     bsc_bamdev_next_block         read_input / get_next_align_details ON THE DEVICE (round 6): the host inflates the BGZF
+ *                                                   blocks (BAM2BCF_THREADS helpers, default: one per core), the records become blocks of
+ *                                                   raw templates in HBM (csrc/bamdev.hip).  BAM2BCF_HOST_READER: bsc_bam_next_block, the
+ *                                                   host reader of rounds 2-5 (csrc/bamio.c) — same bytes
  *   process thread    bsc_block_reference           get_sequence_string
  *   process + calc    bsc_block_bcf_raw             process_template_vector + meth_profile (on the device since round 5:
  *     + print                                       bsc_prepare_templates_device), call_genotypes_ML, _print_vcf_entry WITH the
@@ -63,7 +66,7 @@ static void *pinned(size_t n) { /* page-locked: the copy-out is a true DMA, queu
 }
 
 /* the header print_vcf_header assembles in --benchmark-mode (src/print_vcf.c:621-745) */
-static void write_header(FILE *f, const bsc_bam *bam, const char *sample) {
+static void write_header(FILE *f, int n_refs, const char *const *names, const uint32_t *lens, const char *sample) {
   static const char *const defs[] = {
       "##INFO=<ID=CX,Number=1,Type=String,Description=\"5 base sequence context (from position -2 to +2 on the positive strand) determined from the reference\">",
       "##FILTER=<ID=fail,Description=\"No sample passed filters\">",
@@ -100,7 +103,7 @@ static void write_header(FILE *f, const bsc_bam *bam, const char *sample) {
     }                                                             \
   } while (0)
   ADD("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n");
-  for (int i = 0; i < bsc_bam_n_refs(bam); i++) ADD("##contig=<ID=%s,length=%u>\n", bsc_bam_ref_name(bam, i), bsc_bam_ref_len(bam, i));
+  for (int i = 0; i < n_refs; i++) ADD("##contig=<ID=%s,length=%u>\n", names[i], lens[i]);
   for (size_t i = 0; i < sizeof defs / sizeof defs[0]; i++) ADD("%s\n", defs[i]);
   ADD("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n", sample);
 #undef ADD
@@ -117,23 +120,43 @@ int main(int argc, char **argv) {
     return 2;
   }
   const char *sample = argc > 5 ? argv[5] : "SAMPLE";
-  bsc_bam *bam;
-  CHECK(bsc_bam_open_threads(argv[1], getenv("BAM2BCF_THREADS") ? atoi(getenv("BAM2BCF_THREADS")) : 4, &bam)); /* BGZF inflate ahead of the parser */
+  const int host_prep = getenv("BAM2BCF_HOST_PREP") != NULL;
+  const int host_bcf = host_prep || getenv("BAM2BCF_HOST_BCF") != NULL;
+  const int host_reader = host_bcf || getenv("BAM2BCF_HOST_READER") != NULL;
+  const double t_start = now();
   bsc_params prm = {0.01, 0.05, 2.0, 20, 0};
   bsc_context *ctx;
   CHECK(bsc_create(&prm, &ctx));
+  const double t_ctx = now() - t_start;
+  bsc_bam *bam = NULL;
+  bsc_bamdev *dev = NULL;
+  if (host_reader) CHECK(bsc_bam_open_threads(argv[1], getenv("BAM2BCF_THREADS") ? atoi(getenv("BAM2BCF_THREADS")) : 4, &bam)); /* BGZF inflate ahead of the parser */
+  else CHECK(bsc_bamdev_open(ctx, argv[1], getenv("BAM2BCF_THREADS") ? atoi(getenv("BAM2BCF_THREADS")) : 0, &dev));
+#define N_REFS() (host_reader ? bsc_bam_n_refs(bam) : bsc_bamdev_n_refs(dev))
+#define REF_NAME(i) (host_reader ? bsc_bam_ref_name(bam, (i)) : bsc_bamdev_ref_name(dev, (i)))
+#define REF_LEN(i) (host_reader ? bsc_bam_ref_len(bam, (i)) : bsc_bamdev_ref_len(dev, (i)))
   FILE *out = fopen(argv[3], "wb");
   if (!out) {
     perror(argv[3]);
     return 1;
   }
-  write_header(out, bam, sample);
+  const int n_ref = N_REFS();
+  {
+    const char **names = calloc((size_t)n_ref + 1, sizeof *names);
+    uint32_t *lens = calloc((size_t)n_ref + 1, sizeof *lens);
+    for (int i = 0; i < n_ref; i++) {
+      names[i] = REF_NAME(i);
+      lens[i] = REF_LEN(i);
+    }
+    write_header(out, n_ref, names, lens, sample);
+    free(names);
+    free(lens);
+  }
   bsc_bcf_ids ids;
   bsc_bcf_default_ids(&ids);
   const bsc_reader_params rpar = {20, 1000, 0, 0, 0, 0, 0, 0}; /* defaults of the reference; no region */
   const bsc_prep_params ppar = {{0, 0}, {0, 0}, 20};
 
-  const int n_ref = bsc_bam_n_refs(bam);
   bsc_contig_totals *ctot = calloc((size_t)n_ref + 1, sizeof *ctot);
   uint64_t prof_counts[4096][4];
   memset(prof_counts, 0, sizeof prof_counts);
@@ -150,12 +173,17 @@ int main(int argc, char **argv) {
   int cur_tid = -1;
   uint64_t n_blocks = 0, n_records = 0;
   bsc_read_block blk;
+  bsc_dev_read_block dblk;
   int r;
   double t_read = 0, t_ref = 0, t_prep = 0, t_gpu = 0, t_enc = 0, t0 = now(), t1;
-  const int host_prep = getenv("BAM2BCF_HOST_PREP") != NULL;
-  const int host_bcf = host_prep || getenv("BAM2BCF_HOST_BCF") != NULL;
   for (;;) {
-    r = bsc_bam_next_block(bam, &rpar, &blk);
+    if (host_reader) r = bsc_bam_next_block(bam, &rpar, &blk);
+    else {
+      r = bsc_bamdev_next_block(dev, &rpar, &dblk);
+      blk.tid = dblk.tid; /* the loop below reads the block's contig, end and first position from blk / x */
+      blk.y = dblk.y;
+      blk.nr = dblk.nr;
+    }
     t_read += (t1 = now()) - t0;
     t0 = t1;
     if (r != 1) break;
@@ -167,10 +195,10 @@ int main(int argc, char **argv) {
         memcpy(before, after, sizeof before);
       }
       cur_tid = blk.tid;
-      ctot[cur_tid].name = bsc_bam_ref_name(bam, cur_tid);
-      const uint64_t want = bsc_bam_ref_len(bam, cur_tid);
+      ctot[cur_tid].name = REF_NAME(cur_tid);
+      const uint64_t want = REF_LEN(cur_tid);
       codes = xrealloc(codes, want);
-      CHECK(bsc_fasta_contig(argv[2], bsc_bam_ref_name(bam, cur_tid), codes, want, &codes_len));
+      CHECK(bsc_fasta_contig(argv[2], REF_NAME(cur_tid), codes, want, &codes_len));
       /* its GC bins, for the report's GC-by-coverage table (load_sequence computes them when a report is asked for) */
       uint32_t gc_start = 0;
       uint64_t n_bins = 0;
@@ -178,7 +206,7 @@ int main(int argc, char **argv) {
       CHECK(bsc_gc_bins(codes, codes_len, &gc_start, gc, codes_len / 100 + 1, &n_bins));
       CHECK(bsc_set_gc_bins_host(ctx, gc, (uint32_t)n_bins, gc_start));
     }
-    const uint32_t x = bsc_block_start(&blk.tpl[0]), y = blk.y, n = y - x + 1;
+    const uint32_t x = host_reader ? bsc_block_start(&blk.tpl[0]) : dblk.x, y = blk.y, n = y - x + 1;
     if (n + 2 > cap_ref) ref = xrealloc(ref, cap_ref = (size_t)(n + 2) * 2);
     CHECK(bsc_block_reference(codes, codes_len, x, n + 2, ref));
     t_ref += (t1 = now()) - t0;
@@ -195,14 +223,18 @@ int main(int argc, char **argv) {
         bsc_free_host(bcf);
         bcf = pinned(cap_bcf = (size_t)n * 96 + 4096);
       }
-      int rc = bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 1, blk.tid, &ids,
-                                 NULL, bcf, cap_bcf, &n_bytes, &n_out, &st, &prof);
+      int rc = host_reader ? bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 1, blk.tid,
+                                               &ids, NULL, bcf, cap_bcf, &n_bytes, &n_out, &st, &prof)
+                           : bsc_block_bcf_rawdev(ctx, dblk.d_tpl, dblk.nr, dblk.d_seq, dblk.seq_bytes, dblk.d_misms, dblk.n_misms, dblk.ins_pad, &ppar, x, y,
+                                                  ref, NULL, &vp, 1, dblk.tid, &ids, NULL, bcf, cap_bcf, &n_bytes, &n_out, &st, &prof);
       if (rc == BSC_ERR_ARG && n_bytes > cap_bcf) { /* a block of long records: once more with the room it asks for */
         bsc_free_host(bcf);
         bcf = pinned(cap_bcf = (size_t)n_bytes + 4096);
         bsc_prep_stats st2; /* the first pass has counted the block's bases and its profile already */
-        rc = bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 0, blk.tid, &ids, NULL,
-                               bcf, cap_bcf, &n_bytes, &n_out, &st2, NULL);
+        rc = host_reader ? bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 0, blk.tid, &ids,
+                                             NULL, bcf, cap_bcf, &n_bytes, &n_out, &st2, NULL)
+                         : bsc_block_bcf_rawdev(ctx, dblk.d_tpl, dblk.nr, dblk.d_seq, dblk.seq_bytes, dblk.d_misms, dblk.n_misms, dblk.ins_pad, &ppar, x, y, ref,
+                                                NULL, &vp, 0, dblk.tid, &ids, NULL, bcf, cap_bcf, &n_bytes, &n_out, &st2, NULL);
       }
       CHECK(rc);
     } else if (!host_prep) {
@@ -256,11 +288,7 @@ int main(int argc, char **argv) {
     t0 = t1;
   }
   CHECK(r);
-  if (getenv("BAM2BCF_TIMING"))
-    fprintf(stderr, "seconds: reader %.3f  reference (FASTA + block) %.3f  pre-processing on the host %.3f  %s %.3f  BCF encode + write %.3f\n",
-            t_read, t_ref, t_prep,
-            host_prep ? "bsc_block_records" : (host_bcf ? "bsc_block_records_raw (pre-processing on the device)" : "bsc_block_bcf_raw (pre-processing and BCF encoding on the device)"),
-            t_gpu, t_enc);
+  const double t_loop_end = now();
   if (cur_tid >= 0) {
     CHECK(bsc_get_site_totals(ctx, after));
     uint64_t *d = ctot[cur_tid].snps;
@@ -278,10 +306,11 @@ int main(int argc, char **argv) {
   rep.mapq_thresh = 20;
   rep.min_qual = 20;
   rep.day = 1, rep.month = 1, rep.year = 2000; /* a fixed date: reproducible output */
-  bsc_bam_filter_counts(bam, rep.filter_cts, rep.filter_bases);
-  if (bsc_bam_malformed(bam))
-    fprintf(stderr, "bam2bcf: warning: %llu BAM records dropped, their CIGAR does not cover the sequence (damaged input?)\n",
-            (unsigned long long)bsc_bam_malformed(bam));
+  if (host_reader) bsc_bam_filter_counts(bam, rep.filter_cts, rep.filter_bases);
+  else CHECK(bsc_bamdev_filter_counts(dev, rep.filter_cts, rep.filter_bases));
+  const unsigned long long malformed = host_reader ? bsc_bam_malformed(bam) : bsc_bamdev_malformed(dev);
+  if (malformed)
+    fprintf(stderr, "bam2bcf: warning: %llu BAM records dropped, their CIGAR does not cover the sequence (damaged input?)\n", malformed);
   rep.filter_cts[0] += passed_reads;
   rep.filter_bases[0] += passed_bases;
   memcpy(rep.base_filter, base_filter, sizeof base_filter);
@@ -311,7 +340,22 @@ int main(int argc, char **argv) {
   fwrite(text, 1, (size_t)need, fr);
   fclose(fr);
   printf("%llu blocks, %llu records written\n", (unsigned long long)n_blocks, (unsigned long long)n_records);
-  bsc_bam_close(bam);
+  if (getenv("BAM2BCF_TIMING")) {
+    uint64_t rc4[4] = {0, 0, 0, 0};
+    double rs[2] = {0, 0};
+    if (dev) bsc_bamdev_run_stats(dev, rc4, rs);
+    fprintf(stderr,
+            "{\"reader\": \"%s\", \"context_s\": %.3f, \"reader_s\": %.3f, \"reference_s\": %.3f, \"host_prep_s\": %.3f, \"block_call\": \"%s\", "
+            "\"block_call_s\": %.3f, \"encode_write_s\": %.3f, \"report_s\": %.3f, \"wall_s\": %.3f, \"wall_without_context_s\": %.3f, "
+            "\"device_reader\": {\"passes\": %llu, \"replay_passes\": %llu, \"records\": %llu, \"inflated_bytes\": %llu, \"waiting_for_inflate_s\": %.3f, "
+            "\"device_passes_s\": %.3f}}\n",
+            host_reader ? "host (csrc/bamio.c)" : "device (csrc/bamstream.c + csrc/bamdev.hip)", t_ctx, t_read, t_ref, t_prep,
+            host_prep ? "bsc_block_records" : (host_bcf ? "bsc_block_records_raw" : (host_reader ? "bsc_block_bcf_raw" : "bsc_block_bcf_rawdev")), t_gpu, t_enc,
+            now() - t_loop_end, now() - t_start, now() - t_start - t_ctx, (unsigned long long)rc4[0], (unsigned long long)rc4[1], (unsigned long long)rc4[2],
+            (unsigned long long)rc4[3], rs[0], rs[1]);
+  }
+  if (bam) bsc_bam_close(bam);
+  if (dev) bsc_bamdev_close(dev);
   bsc_destroy(ctx);
   return 0;
 }

@@ -1,0 +1,342 @@
+/*
+ * make_wgbs_bam.c — a coordinate-sorted synthetic WGBS BAM and its FASTA at BASELINE configs[1]'s size, in seconds (tools/make_bam.py's
+ * wgbs_records, the L-reads of SURVEY.md 8(d), is pure Python: fine for 10^4 records, not for 1.5 * 10^7).  Bench / test input only.
+ *
+ *   gcc -O2 -o make_wgbs_bam tools/make_wgbs_bam.c -lz -lpthread
+ *   make_wgbs_bam out.bam out.fa POSITIONS COVERAGE [seed [threads [level [straddle [contigs]]]]]
+ *
+ * Reference bases uniform over ACGT (syn_ref of csrc/synth.h); paired templates, reads of 100 bases, insert 300, forward starts evenly spaced
+ * so that the mean depth is COVERAGE; bisulfite strand and pair orientation Bernoulli(1/2) per template; C->T on C2T reads / G->A on G2A
+ * reads with p = 120/128 outside CpG and 20 % at CpG; 0.5 % base errors; every 1000th position heterozygous on every other template;
+ * qualities uniform 20..43; MAPQ 60; the strand in an XB:A tag (GEM); names "t%09u".  `contigs` > 1 cuts POSITIONS into that many
+ * contigs of equal length (chrS1 ..).  BGZF blocks are cut at record boundaries as htslib's writer does (bgzf_flush_try); `straddle` 1
+ * cuts them every 0xff00 bytes regardless, as htsjdk's stream does.  Deflate `level` (default 1) on `threads` threads.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include "../bs_call_amd/csrc/synth.h"
+
+#define READ_LEN 100u
+#define INSERT 300u
+#define BLK 0xff00u
+
+typedef struct {
+  uint8_t *data;
+  size_t len, cap;
+} buf;
+static void put(buf *b, const void *p, size_t n) {
+  if (b->len + n > b->cap) {
+    b->cap = (b->len + n) * 2 + 65536;
+    b->data = realloc(b->data, b->cap);
+    if (!b->data) {
+      fprintf(stderr, "out of memory\n");
+      exit(1);
+    }
+  }
+  memcpy(b->data + b->len, p, n);
+  b->len += n;
+}
+static void put32(buf *b, uint32_t v) { put(b, &v, 4); }
+
+/* ---- BGZF: the chunk's blocks deflated in parallel, written in order ---- */
+typedef struct {
+  const uint8_t *src;
+  uint32_t n;
+  uint8_t out[65536 + 1024];
+  uint32_t out_n;
+} blk_job;
+static blk_job *jobs;
+static size_t n_jobs, next_job;
+static pthread_mutex_t job_mu = PTHREAD_MUTEX_INITIALIZER;
+static int g_level = 1;
+
+static void deflate_block(blk_job *j) {
+  z_stream z;
+  memset(&z, 0, sizeof z);
+  deflateInit2(&z, g_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+  z.next_in = (Bytef *)j->src;
+  z.avail_in = j->n;
+  z.next_out = j->out + 18;
+  z.avail_out = sizeof j->out - 18 - 8;
+  if (deflate(&z, Z_FINISH) != Z_STREAM_END) {
+    fprintf(stderr, "deflate failed\n");
+    exit(1);
+  }
+  const uint32_t clen = (uint32_t)z.total_out;
+  deflateEnd(&z);
+  static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+  memcpy(j->out, head, 16);
+  const uint32_t total = 18 + clen + 8;
+  if (total > 65536) {
+    fprintf(stderr, "block does not fit\n");
+    exit(1);
+  }
+  j->out[16] = (uint8_t)((total - 1) & 0xff);
+  j->out[17] = (uint8_t)((total - 1) >> 8);
+  const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), j->src, j->n);
+  memcpy(j->out + 18 + clen, &crc, 4);
+  memcpy(j->out + 18 + clen + 4, &j->n, 4);
+  j->out_n = total;
+}
+static void *worker(void *a) {
+  (void)a;
+  for (;;) {
+    pthread_mutex_lock(&job_mu);
+    const size_t k = next_job < n_jobs ? next_job++ : (size_t)-1;
+    pthread_mutex_unlock(&job_mu);
+    if (k == (size_t)-1) return NULL;
+    deflate_block(&jobs[k]);
+  }
+}
+/* bounds[i] .. bounds[i + 1]: the blocks of the chunk */
+static void write_blocks(FILE *f, const uint8_t *data, const size_t *bounds, size_t nb, int threads) {
+  jobs = malloc(nb * sizeof *jobs);
+  n_jobs = nb;
+  next_job = 0;
+  for (size_t i = 0; i < nb; i++) {
+    jobs[i].src = data + bounds[i];
+    jobs[i].n = (uint32_t)(bounds[i + 1] - bounds[i]);
+  }
+  pthread_t th[64];
+  for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, worker, NULL);
+  for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+  for (size_t i = 0; i < nb; i++) fwrite(jobs[i].out, 1, jobs[i].out_n, f);
+  free(jobs);
+}
+
+/* ---- records ---- */
+typedef struct {
+  uint32_t pos; /* 0-based */
+  uint32_t mpos;
+  uint32_t id;
+  uint8_t rev, c2t, r1, pad;
+} pend;
+
+static uint64_t g_seed;
+static uint32_t g_ctg_len;
+
+static void emit(buf *b, const pend *p, int32_t tid, uint32_t ctg0) {
+  uint8_t rec[512];
+  char name[16];
+  const int l_name = snprintf(name, sizeof name, "t%09u", p->id) + 1;
+  const uint32_t flag = 1u | 2u | (p->rev ? 16u : 32u) | (p->r1 ? 64u : 128u);
+  uint32_t o = 0;
+#define P32(v)              \
+  do {                      \
+    const uint32_t v_ = (v); \
+    memcpy(rec + o, &v_, 4); \
+    o += 4;                 \
+  } while (0)
+  P32((uint32_t)tid);
+  P32(p->pos);
+  rec[o++] = (uint8_t)l_name;
+  rec[o++] = 60;
+  rec[o++] = 0;
+  rec[o++] = 0; /* bin: unused by the readers */
+  rec[o++] = 1;
+  rec[o++] = 0; /* n_cigar_op */
+  rec[o++] = (uint8_t)flag;
+  rec[o++] = (uint8_t)(flag >> 8);
+  P32(READ_LEN);
+  P32((uint32_t)tid);
+  P32(p->mpos);
+  P32(p->rev ? (uint32_t)-(int32_t)INSERT : INSERT);
+  memcpy(rec + o, name, (size_t)l_name);
+  o += (uint32_t)l_name;
+  P32(READ_LEN << 4);
+  /* the read: per template a stream of its own, so that the two mates do not depend on the order they are written in */
+  uint64_t s = syn_mix(g_seed ^ (0xa0761d6478bd642full * ((uint64_t)p->id * 2u + p->rev + 0x51ull)));
+  if (!s) s = 0x2545f4914f6cdd1dull;
+  uint8_t *sq = rec + o, *ql = rec + o + READ_LEN / 2;
+  memset(sq, 0, READ_LEN / 2);
+  for (uint32_t j = 0; j < READ_LEN; j++) {
+    const uint64_t g = (uint64_t)ctg0 + p->pos + j; /* site index of the synthetic genome */
+    const int inside = p->pos + j < g_ctg_len;
+    uint32_t code = inside ? syn_ref(g_seed, g, 0) : 0; /* 1..4 */
+    const uint64_t u = syn_next(&s);
+    uint32_t b = code ? code - 1u : 0u; /* 0..3 = ACGT */
+    if (code && (g + 1) % 1000u == 0 && (p->id & 1u)) b = (b + 1u + (uint32_t)((u >> 50) % 3u)) & 3u; /* het site: every other template */
+    if (code) {
+      const uint32_t conv = (uint32_t)(u >> 32) & 127u;
+      if (p->c2t && b == 1u) {
+        const int cpg = inside && p->pos + j + 1 < g_ctg_len && syn_ref(g_seed, g + 1, 0) == 3u;
+        if (cpg ? (conv % 5u == 0) : (conv < 120u)) b = 3u;
+      } else if (!p->c2t && b == 2u) {
+        const int cpg = (p->pos + j) > 0 && syn_ref(g_seed, g - 1, 0) == 2u;
+        if (cpg ? (conv % 5u == 0) : (conv < 120u)) b = 0u;
+      }
+      if (((u >> 8) & 0xfffu) % 200u == 0) b = (b + 1u + (uint32_t)((u >> 20) % 3u)) & 3u;
+    }
+    const uint32_t nib = code ? (1u << b) : 15u;
+    sq[j >> 1] |= (uint8_t)(nib << ((~j & 1u) << 2));
+    ql[j] = (uint8_t)(20u + (uint32_t)((u >> 40) % 24u));
+  }
+  o += READ_LEN / 2 + READ_LEN;
+  rec[o++] = 'X';
+  rec[o++] = 'B';
+  rec[o++] = 'A';
+  rec[o++] = p->c2t ? 'C' : 'G';
+#undef P32
+  put32(b, o);
+  put(b, rec, o);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 5) {
+    fprintf(stderr, "usage: %s out.bam out.fa POSITIONS COVERAGE [seed [threads [level [straddle [contigs]]]]]\n", argv[0]);
+    return 2;
+  }
+  const uint64_t n_pos = strtoull(argv[3], NULL, 10);
+  const uint32_t cov = (uint32_t)atoi(argv[4]);
+  g_seed = argc > 5 ? strtoull(argv[5], NULL, 10) : 88172645463325253ull;
+  int threads = argc > 6 ? atoi(argv[6]) : 8;
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  g_level = argc > 7 ? atoi(argv[7]) : 1;
+  const int straddle = argc > 8 ? atoi(argv[8]) : 0;
+  const uint32_t n_ctg = argc > 9 && atoi(argv[9]) > 0 ? (uint32_t)atoi(argv[9]) : 1u;
+  g_ctg_len = (uint32_t)(n_pos / n_ctg);
+  if (g_ctg_len < 2 * INSERT) {
+    fprintf(stderr, "contigs too short\n");
+    return 2;
+  }
+  FILE *fb = fopen(argv[1], "wb"), *ff = fopen(argv[2], "w");
+  if (!fb || !ff) {
+    perror("open");
+    return 1;
+  }
+  /* FASTA */
+  {
+    char *line = malloc(61 * 1024);
+    for (uint32_t c = 0; c < n_ctg; c++) {
+      if (n_ctg == 1) fprintf(ff, ">chrS\n");
+      else fprintf(ff, ">chrS%u\n", c + 1);
+      size_t o = 0;
+      for (uint32_t i = 0; i < g_ctg_len; i++) {
+        line[o++] = "NACGT"[syn_ref(g_seed, (uint64_t)c * g_ctg_len + i, 0)];
+        if ((i + 1) % 60 == 0 || i + 1 == g_ctg_len) line[o++] = '\n';
+        if (o >= 60 * 1024) {
+          fwrite(line, 1, o, ff);
+          o = 0;
+        }
+      }
+      fwrite(line, 1, o, ff);
+    }
+    free(line);
+    fclose(ff);
+  }
+  /* BAM header */
+  buf b = {NULL, 0, 0};
+  {
+    char text[1 << 16];
+    size_t l = (size_t)snprintf(text, sizeof text, "@HD\tVN:1.6\tSO:coordinate\n");
+    for (uint32_t c = 0; c < n_ctg; c++) {
+      if (n_ctg == 1) l += (size_t)snprintf(text + l, sizeof text - l, "@SQ\tSN:chrS\tLN:%u\n", g_ctg_len);
+      else l += (size_t)snprintf(text + l, sizeof text - l, "@SQ\tSN:chrS%u\tLN:%u\n", c + 1, g_ctg_len);
+    }
+    put(&b, "BAM\1", 4);
+    put32(&b, (uint32_t)l);
+    put(&b, text, l);
+    put32(&b, n_ctg);
+    for (uint32_t c = 0; c < n_ctg; c++) {
+      char nm[32];
+      const int ln = (n_ctg == 1 ? snprintf(nm, sizeof nm, "chrS") : snprintf(nm, sizeof nm, "chrS%u", c + 1)) + 1;
+      put32(&b, (uint32_t)ln);
+      put(&b, nm, (size_t)ln);
+      put32(&b, g_ctg_len);
+    }
+  }
+  size_t *bounds = NULL;
+  size_t nb = 0, cap_b = 0;
+#define BOUND(x)                                      \
+  do {                                                \
+    if (nb + 2 > cap_b) {                             \
+      cap_b = cap_b * 2 + 1024;                       \
+      bounds = realloc(bounds, cap_b * sizeof *bounds); \
+    }                                                 \
+    bounds[nb++] = (x);                               \
+  } while (0)
+  BOUND(0);
+  size_t blk_start = 0;
+  uint64_t n_rec = 0;
+  uint32_t id = 0;
+  /* pairs per contig: depth = pairs * 2 * READ_LEN / length */
+  const uint64_t pairs = (uint64_t)g_ctg_len * cov / (2u * READ_LEN);
+  const uint32_t span = g_ctg_len - INSERT;
+  pend *q = malloc(sizeof *q * 65536); /* reverse mates waiting for their turn: a ring */
+  for (uint32_t c = 0; c < n_ctg; c++) {
+    const uint32_t ctg0 = c * g_ctg_len;
+    uint32_t qh = 0, qt = 0;
+    for (uint64_t i = 0; i <= pairs; i++) {
+      const uint32_t s = i < pairs ? (uint32_t)(i * span / pairs) : 0xffffffffu;
+      while (qh != qt && q[qh & 65535u].pos < s) { /* mates that start before this forward read go first */
+        const size_t before = b.len;
+        emit(&b, &q[qh & 65535u], (int32_t)c, ctg0);
+        qh++;
+        n_rec++;
+        if (!straddle && b.len - blk_start > BLK) {
+          BOUND(before);
+          blk_start = before;
+        }
+      }
+      if (i == pairs) break;
+      const uint64_t u = syn_mix(g_seed ^ (0x9e3779b97f4a7c15ull * (id + 77ull)));
+      pend f = {s, s + INSERT - READ_LEN, id, 0, (uint8_t)(u & 1u), (uint8_t)((u >> 1) & 1u), 0};
+      pend r = {s + INSERT - READ_LEN, s, id, 1, f.c2t, (uint8_t)!f.r1, 0};
+      id++;
+      const size_t before = b.len;
+      emit(&b, &f, (int32_t)c, ctg0);
+      n_rec++;
+      if (!straddle && b.len - blk_start > BLK) {
+        BOUND(before);
+        blk_start = before;
+      }
+      q[qt & 65535u] = r;
+      qt++;
+      if (qt - qh > 65000u) {
+        fprintf(stderr, "coverage too deep for the mate ring\n");
+        return 1;
+      }
+      /* flush a chunk */
+      if (b.len > (96u << 20)) {
+        size_t upto;
+        if (straddle) {
+          while (blk_start + BLK <= b.len) {
+            blk_start += BLK;
+            BOUND(blk_start);
+          }
+          upto = blk_start;
+        } else {
+          upto = blk_start;
+        }
+        nb--; /* the last bound is the open block's start */
+        write_blocks(fb, b.data, bounds, nb, threads);
+        memmove(b.data, b.data + upto, b.len - upto);
+        b.len -= upto;
+        nb = 0;
+        BOUND(0);
+        blk_start = 0;
+      }
+    }
+  }
+  /* the rest */
+  if (straddle) {
+    while (blk_start + BLK < b.len) {
+      blk_start += BLK;
+      BOUND(blk_start);
+    }
+  }
+  if (b.len > bounds[nb - 1]) BOUND(b.len);
+  write_blocks(fb, b.data, bounds, nb - 1, threads);
+  static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  fwrite(eof, 1, 28, fb);
+  fclose(fb);
+  printf("{\"positions\": %llu, \"contigs\": %u, \"coverage\": %u, \"alignments\": %llu, \"templates\": %u}\n", (unsigned long long)n_pos, n_ctg, cov,
+         (unsigned long long)n_rec, id);
+  return 0;
+}
