@@ -121,7 +121,7 @@ $(LIBDIR)/demo_block: integration/demo_block.c integration/mock_work.h integrati
 # BAM + FASTA -> BCF + JSON report with nothing but the C ABI (the C twin of bs_call_amd/pipeline.py)
 bam2bcf: $(LIBDIR)/bam2bcf
 $(LIBDIR)/bam2bcf: integration/bam2bcf.c include/bscall_amd.h $(LIBDIR)/libbscall_amd.so
-	$(CC) -O2 -Wall -std=gnu11 -Iinclude $< -o $@ -L$(LIBDIR) -lbscall_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
+	$(CC) -O2 -Wall -std=gnu11 -Iinclude $< -o $@ -L$(LIBDIR) -lbscall_amd -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
 
 # Compile check of the two replacement translation units against the reference's own headers.  Only in a
 # container that has /root/reference; the reference's bs_call.h includes three htslib headers for POINTER TYPES only, so

@@ -131,6 +131,8 @@ EXPORTS = (
     "bsc_bamdev_run_stats",
     "bsc_block_records_rawdev",
     "bsc_block_bcf_rawdev",
+    "bsc_block_bcf_rawdev_keep",
+    "bsc_bcf_stream_read",
 )
 
 
@@ -538,5 +540,10 @@ def load():
     L.bsc_block_bcf_rawdev.restype = i32
     L.bsc_block_bcf_rawdev.argtypes = [vp, vp, u32, vp, u64, vp, u64, u64, vp, u32, u32, vp, vp, vp, i32, i32, C.POINTER(BcfIds), vp, vp, u64,
                                        C.POINTER(u64), C.POINTER(u64), vp, vp]
+    L.bsc_block_bcf_rawdev_keep.restype = i32
+    L.bsc_block_bcf_rawdev_keep.argtypes = [vp, vp, u32, vp, u64, vp, u64, u64, vp, u32, u32, vp, vp, vp, i32, i32, C.POINTER(BcfIds), vp, u64,
+                                            C.POINTER(u64), C.POINTER(u64), vp, vp]
+    L.bsc_bcf_stream_read.restype = i32
+    L.bsc_bcf_stream_read.argtypes = [vp, u64, u64, vp]
     _lib = L
     return L

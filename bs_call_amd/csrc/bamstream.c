@@ -62,15 +62,15 @@ struct bsc_bamstream {
   size_t slab_bytes;
   uint32_t rec_cap;
   /* claim state (mu) */
-  pthread_mutex_t mu;
-  pthread_cond_t cv_free, cv_ready, cv_walk;
+  pthread_mutex_t mu, claim_mu;
+  pthread_cond_t cv_free, cv_ready;
   size_t file_pos;
   uint64_t stream_pos;
   uint64_t n_claimed;   /* blocks handed to helpers */
   uint64_t fill_seq;    /* slab sequence number being filled (slab index = seq % n_slabs) */
   uint32_t fill_off;
   int fill_open;        /* slab fill_seq has been opened */
-  int eof, closing, claim_busy;
+  int eof, closing, has_err;
   const char *err;      /* first error, raised by the consumer */
   /* walk chain (mu) */
   uint64_t walk_next;
@@ -184,9 +184,9 @@ static const char *walk_block(bsc_bamstream *b, bs_slab *s, uint32_t boff, const
 static void set_err(bsc_bamstream *b, const char *e) { /* mu held */
   if (!b->err) b->err = e;
   b->eof = 1;
+  __atomic_store_n(&b->has_err, 1, __ATOMIC_RELEASE);
   pthread_cond_broadcast(&b->cv_ready);
   pthread_cond_broadcast(&b->cv_free);
-  pthread_cond_broadcast(&b->cv_walk);
 }
 
 static void slab_maybe_ready(bsc_bamstream *b, bs_slab *s) { /* mu held */
@@ -207,7 +207,8 @@ static void close_fill_slab(bsc_bamstream *b, int last) { /* mu held */
   slab_maybe_ready(b, s);
 }
 
-/* a slab for the fill position: waits for the consumer to hand the ring's next slab back.  mu held; 0 = opened, -1 = closing / error */
+/* a slab for the fill position: waits for the consumer to hand the ring's next slab back.  mu held (and claim_mu: one claimer);
+ * 0 = opened, -1 = closing / error */
 static int open_fill_slab(bsc_bamstream *b) {
   bs_slab *s0 = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
   while (s0->state != SL_FREE && !b->closing && !b->err) pthread_cond_wait(&b->cv_free, &b->mu);
@@ -222,15 +223,23 @@ static int open_fill_slab(bsc_bamstream *b) {
   return 0;
 }
 
+/*
+ * Synchronisation, sized for dozens of helpers: claim_mu serialises the claimers (a futex queue: nobody is woken in vain); mu guards the
+ * slab states and is held for a few instructions per block; the walk's turn is one atomic word that the next helper in line polls
+ * (it waits for its predecessor's WALK, a microsecond, rarely for its inflation); condition variables are signalled once per slab
+ * (ready / free), not per block.  (The first form — one mutex, three broadcast condition variables — did 3.6 GB/s with 16 helpers and
+ * 1.0 with 32: every block woke every waiter.)
+ */
 static void *helper(void *arg) {
   bsc_bamstream *b = (bsc_bamstream *)arg;
-  pthread_mutex_lock(&b->mu);
   for (;;) {
-    /* claim the next block and its place: one helper at a time, so that blocks are numbered and placed in file order even when the
-     * claimer has to wait for a slab */
-    while (b->claim_busy && !b->closing && !b->eof) pthread_cond_wait(&b->cv_free, &b->mu);
-    if (b->closing || b->eof) break;
-    b->claim_busy = 1;
+    pthread_mutex_lock(&b->claim_mu);
+    pthread_mutex_lock(&b->mu);
+    if (b->closing || b->eof) {
+      pthread_mutex_unlock(&b->mu);
+      pthread_mutex_unlock(&b->claim_mu);
+      return NULL;
+    }
     const uint8_t *payload;
     uint32_t clen, isize, crc, bsize;
     const char *e = NULL;
@@ -240,23 +249,24 @@ static void *helper(void *arg) {
       if (r == 1) b->file_pos += bsize;
     } while (r == 1 && isize == 0);
     if (r < 0) {
-      b->claim_busy = 0;
       set_err(b, e);
-      break;
+      pthread_mutex_unlock(&b->mu);
+      pthread_mutex_unlock(&b->claim_mu);
+      return NULL;
     }
     if (r == 0) { /* the stream ends: with the slab being filled, or with an empty one */
       if (b->fill_open || open_fill_slab(b) == 0) close_fill_slab(b, 1);
       b->eof = 1;
-      b->claim_busy = 0;
       pthread_cond_broadcast(&b->cv_ready);
-      pthread_cond_broadcast(&b->cv_free);
-      break;
+      pthread_mutex_unlock(&b->mu);
+      pthread_mutex_unlock(&b->claim_mu);
+      return NULL;
     }
     if (b->fill_open && (size_t)b->fill_off + isize > b->slab_bytes) close_fill_slab(b, 0);
     if (!b->fill_open && open_fill_slab(b)) {
-      b->claim_busy = 0;
-      pthread_cond_broadcast(&b->cv_free);
-      break;
+      pthread_mutex_unlock(&b->mu);
+      pthread_mutex_unlock(&b->claim_mu);
+      return NULL;
     }
     bs_slab *s = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
     const uint32_t boff = b->fill_off;
@@ -264,30 +274,28 @@ static void *helper(void *arg) {
     b->fill_off += isize;
     b->stream_pos += isize;
     s->assigned++;
-    b->claim_busy = 0;
-    pthread_cond_broadcast(&b->cv_free);
     pthread_mutex_unlock(&b->mu);
+    pthread_mutex_unlock(&b->claim_mu);
     e = bgzf_inflate_to(payload, clen, s->bytes + boff, isize, crc);
-    pthread_mutex_lock(&b->mu);
     /* the walk, in block order, on the core that holds the bytes */
-    while (b->walk_next != k && !b->closing) pthread_cond_wait(&b->cv_walk, &b->mu);
-    if (b->closing) break;
-    if (!e && !b->err) {
-      pthread_mutex_unlock(&b->mu); /* only this helper is at its turn: the chain's state is its own until walk_next moves */
-      e = walk_block(b, s, boff, s->bytes + boff, isize);
-      pthread_mutex_lock(&b->mu);
+    for (unsigned spins = 0; __atomic_load_n(&b->walk_next, __ATOMIC_ACQUIRE) != k; spins++) {
+      if (__atomic_load_n(&b->closing, __ATOMIC_RELAXED)) return NULL;
+      if (spins < 64) __builtin_ia32_pause();
+      else sched_yield();
     }
-    b->walk_next = k + 1;
-    pthread_cond_broadcast(&b->cv_walk);
+    if (!e && !__atomic_load_n(&b->has_err, __ATOMIC_ACQUIRE)) e = walk_block(b, s, boff, s->bytes + boff, isize);
+    if (e) __atomic_store_n(&b->has_err, 1, __ATOMIC_RELEASE);
+    __atomic_store_n(&b->walk_next, k + 1, __ATOMIC_RELEASE);
+    pthread_mutex_lock(&b->mu);
     if (e) {
       set_err(b, e);
-      break;
+      pthread_mutex_unlock(&b->mu);
+      return NULL;
     }
     s->done++;
     slab_maybe_ready(b, s);
+    pthread_mutex_unlock(&b->mu);
   }
-  pthread_mutex_unlock(&b->mu);
-  return NULL;
 }
 
 /* ---- the header, read on the caller's thread --------------------------------------------------------------------------- */
@@ -329,18 +337,17 @@ void bsc_bamstream_close(bsc_bamstream *b) {
   if (!b) return;
   if (b->n_threads) {
     pthread_mutex_lock(&b->mu);
-    b->closing = 1;
+    __atomic_store_n(&b->closing, 1, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&b->cv_free);
     pthread_cond_broadcast(&b->cv_ready);
-    pthread_cond_broadcast(&b->cv_walk);
     pthread_mutex_unlock(&b->mu);
     for (int i = 0; i < b->n_threads; i++) pthread_join(b->th[i], NULL);
   }
   if (b->th) {
     pthread_mutex_destroy(&b->mu);
+    pthread_mutex_destroy(&b->claim_mu);
     pthread_cond_destroy(&b->cv_free);
     pthread_cond_destroy(&b->cv_ready);
-    pthread_cond_destroy(&b->cv_walk);
   }
   free(b->th);
   if (b->slab)
@@ -378,7 +385,7 @@ int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int
   if (!path || !out) return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_open: NULL argument");
   *out = NULL;
   if (n_threads <= 0) n_threads = bsc_bamstream_default_threads();
-  if (n_threads > 64) n_threads = 64;
+  if (n_threads > 128) n_threads = 128;
   if (slab_bytes == 0) slab_bytes = 32u << 20;
   if (slab_bytes < 65536u) slab_bytes = 65536u;
   if (slab_bytes > (1ull << 31)) slab_bytes = 1ull << 31;
@@ -497,9 +504,9 @@ int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int
   b->th = calloc((size_t)n_threads, sizeof *b->th);
   if (!b->th) goto nomem;
   pthread_mutex_init(&b->mu, NULL);
+  pthread_mutex_init(&b->claim_mu, NULL);
   pthread_cond_init(&b->cv_free, NULL);
   pthread_cond_init(&b->cv_ready, NULL);
-  pthread_cond_init(&b->cv_walk, NULL);
   for (int i = 0; i < n_threads; i++) {
     if (pthread_create(&b->th[b->n_threads], NULL, helper, b)) break;
     b->n_threads++;

@@ -157,6 +157,7 @@ struct bsc_context {
                         uploads behind it (bsc_h2d_turn) */
   const void *emit_hint; /* set around the bsc_vcf_compact_device call of bsc_records_queue: the flags of exactly these arrays */
   uint8_t *bcf_out;
+  int bcf_blk, bcf_keep; /* the block in flight is a BCF block; its stream stays on the device (bsc_block_bcf_rawdev_keep) */
   uint64_t bcf_cap, bcf_copied, bcf_bytes; /* bcf_bytes: the length of the last block's stream (also when it did not fit) */
   double bcf_share;
   /* bsc_blocks_records_submit / _fetch: the blocks of the launch in flight (their table lives in the staging area), the device
@@ -1887,7 +1888,10 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
     HIP_TRY(hipMemcpyAsync(ctx->h_cnt + 4, ctx->d_btot, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     uint64_t guess = ctx->bcf_share > 0.0 ? (uint64_t)((double)sz * ctx->bcf_share) + 65536u : 0u;
     if (guess > bcf->out_cap) guess = bcf->out_cap;
+    if (!bcf->out) guess = 0; /* the stream stays on the device: the caller reads it in pieces (bsc_bcf_stream_read) */
     if (guess) HIP_TRY(hipMemcpyAsync(bcf->out, ctx->d_bcf, (size_t)guess, hipMemcpyDeviceToHost, s));
+    ctx->bcf_blk = 1;
+    ctx->bcf_keep = bcf->out == NULL;
     ctx->bcf_out = bcf->out;
     ctx->bcf_cap = bcf->out_cap;
     ctx->bcf_copied = guess;
@@ -1911,6 +1915,7 @@ static int bsc_bcf_finish(bsc_context *ctx, uint8_t *out, int inexact) {
   if (bytes > ctx->bcf_cap) {
     return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf: the block's stream has %llu bytes, out_cap is %llu", bytes, (unsigned long long)ctx->bcf_cap);
   }
+  if (ctx->bcf_keep) return bsc_inexact_status(inexact);
   if (bytes > ctx->bcf_copied) { /* first block, or more bytes than the share so far suggested: the rest in a second copy */
     HIP_TRY(hipMemcpyAsync(out + ctx->bcf_copied, (const char *)ctx->d_bcf + ctx->bcf_copied, (size_t)(bytes - ctx->bcf_copied), hipMemcpyDeviceToHost,
                            ctx->stream));
@@ -1924,14 +1929,16 @@ static int bsc_bcf_finish(bsc_context *ctx, uint8_t *out, int inexact) {
 static int bsc_records_finish(bsc_context *ctx, uint64_t *n_out) {
   *n_out = 0;
   uint8_t *const bcf_out = ctx->bcf_out;
+  const int is_bcf = ctx->bcf_blk;
   ctx->bcf_out = NULL;
+  ctx->bcf_blk = 0;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   int inexact = 0;
   int rc = bsc_verdict(ctx, ctx->h_cnt, &inexact); /* h_cnt = {INEXACT, ERR, RECORDS} */
   if (rc) return rc; /* an invalid template: the contents of `out` are unspecified */
-  const unsigned long long total = bcf_out ? ctx->h_cnt[6] : ctx->h_cnt[2]; /* the encoder counts the records it writes */
+  const unsigned long long total = is_bcf ? ctx->h_cnt[6] : ctx->h_cnt[2]; /* the encoder counts the records it writes */
   *n_out = total;
-  if (bcf_out) return bsc_bcf_finish(ctx, bcf_out, inexact);
+  if (is_bcf) return bsc_bcf_finish(ctx, bcf_out, inexact);
   if (total > ctx->rec_cap)
     return bsc_fail(BSC_ERR_ARG, "bsc_block_records: the block has %llu records, out_cap is %llu", total,
                     (unsigned long long)ctx->rec_cap);
@@ -2124,6 +2131,42 @@ int bsc_block_bcf_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr
                               profile, &req);
   if (ctx) *n_bytes = ctx->bcf_bytes;
   return rc;
+}
+
+/* bsc_block_bcf_rawdev with the stream LEFT on the device (dev_cap bytes of room): a whole contig's stream is gigabytes, and page-locking a
+ * host buffer of that size costs more than everything else in the call; the caller reads it in pieces into a small page-locked buffer
+ * (bsc_bcf_stream_read) while a thread of its own writes the previous piece. */
+int bsc_block_bcf_rawdev_keep(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms, uint64_t n_misms,
+                              uint64_t ins_pad, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
+                              const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint64_t dev_cap,
+                              uint64_t *n_bytes, uint64_t *n_records, bsc_prep_stats *prep_stats, bsc_read_profile *profile) {
+  if (!ids || !n_bytes || !n_records) return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf_rawdev_keep: NULL argument");
+  *n_bytes = 0;
+  *n_records = 0;
+  int rc;
+  if ((rc = bsc_block_rawdev_check(ctx, d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, prep, x, y, ref, params, n_records, NULL, 0))) return rc;
+  if (prep_stats) memset(prep_stats, 0, sizeof *prep_stats);
+  const bsc_bcf_req req = {rid, ids, names, NULL, dev_cap};
+  ctx->bcf_bytes = 0;
+  if (!nr) rc = bsc_block_records_(ctx, NULL, 0, NULL, 0, x, y, ref, dbsnp, params, with_stats, NULL, 0, n_records, &req);
+  else {
+    BSC_ENTER(ctx);
+    rc = bsc_block_records_rawdev_(ctx, d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, seq_bytes + ins_pad + 16, prep, x, y, ref, dbsnp, params, with_stats,
+                                   NULL, 0, n_records, prep_stats, profile, &req);
+  }
+  *n_bytes = ctx->bcf_bytes;
+  return rc;
+}
+
+/* bytes [off, off + n) of the last block's stream -> dst (page-locked for a true DMA), queued on the context's stream; the caller waits
+ * with bsc_synchronize before it touches dst */
+int bsc_bcf_stream_read(bsc_context *ctx, uint64_t off, uint64_t n, void *dst) {
+  if (!ctx || (!dst && n)) return bsc_fail(BSC_ERR_ARG, "bsc_bcf_stream_read: NULL argument");
+  if (off + n > ctx->bcf_bytes || off + n > ctx->cap_bcf) return bsc_fail(BSC_ERR_ARG, "bsc_bcf_stream_read: beyond the stream's end");
+  if (!n) return BSC_OK;
+  BSC_ENTER(ctx);
+  HIP_TRY(hipMemcpyAsync(dst, (const char *)ctx->d_bcf + off, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  return BSC_OK;
 }
 
 /* The split form: queue the block and return; bsc_block_records_fetch waits and completes it.  stage != 0: the inputs go

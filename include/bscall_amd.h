@@ -852,6 +852,14 @@ int bsc_block_bcf_rawdev(bsc_context *ctx, const void *d_raw, uint32_t nr, const
                          uint64_t ins_pad, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
                          const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out,
                          uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records, bsc_prep_stats *prep_stats, bsc_read_profile *profile);
+/* bsc_block_bcf_rawdev with the stream left on the device (room: dev_cap bytes; BSC_ERR_ARG and the length needed in *n_bytes when it does
+ * not fit), and bytes [off, off + n) of that stream -> dst, queued on the context's stream (bsc_synchronize before dst is read): a contig-sized
+ * block's stream is gigabytes — read in pieces through a small page-locked buffer it costs no page-locking of its own */
+int bsc_block_bcf_rawdev_keep(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms, uint64_t n_misms,
+                              uint64_t ins_pad, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
+                              const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint64_t dev_cap,
+                              uint64_t *n_bytes, uint64_t *n_records, bsc_prep_stats *prep_stats, bsc_read_profile *profile);
+int bsc_bcf_stream_read(bsc_context *ctx, uint64_t off, uint64_t n, void *dst);
 
 /*
  * dbSNP index (host C + zlib; csrc/dbsnp.c): the reader of the compressed index bin/dbSNP_idx writes.  In the reference

@@ -25,6 +25,7 @@
  *   make bam2bcf && bs_call_amd/lib/bam2bcf in.bam ref.fa out.bcf report.json [sample]
  * The header's date lines are left out (the reference's --benchmark-mode) so that the output is reproducible.
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -63,6 +64,37 @@ static void *pinned(size_t n) { /* page-locked: the copy-out is a true DMA, queu
     exit(1);
   }
   return p;
+}
+
+/* The output thread (bcf_write's write): a block's stream is read from the device in pieces into two page-locked buffers, and while the
+ * device fills one, this thread writes the other.  A contig-sized block's stream is gigabytes: page-locking a host buffer for all of it
+ * costs more than the calling. */
+#define PIECE ((size_t)64 << 20)
+typedef struct {
+  FILE *f;
+  uint8_t *buf[2];
+  size_t n[2];
+  int full[2], quit;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  pthread_t th;
+} out_writer;
+static void *writer_main(void *a) {
+  out_writer *w = a;
+  int i = 0;
+  pthread_mutex_lock(&w->mu);
+  for (;;) {
+    while (!w->full[i] && !w->quit) pthread_cond_wait(&w->cv, &w->mu);
+    if (!w->full[i]) break;
+    pthread_mutex_unlock(&w->mu);
+    fwrite(w->buf[i], 1, w->n[i], w->f);
+    pthread_mutex_lock(&w->mu);
+    w->full[i] = 0;
+    pthread_cond_broadcast(&w->cv);
+    i ^= 1;
+  }
+  pthread_mutex_unlock(&w->mu);
+  return NULL;
 }
 
 /* the header print_vcf_header assembles in --benchmark-mode (src/print_vcf.c:621-745) */
@@ -174,6 +206,8 @@ int main(int argc, char **argv) {
   uint64_t n_blocks = 0, n_records = 0;
   bsc_read_block blk;
   bsc_dev_read_block dblk;
+  static out_writer W;
+  int wi = 0;
   int r;
   double t_read = 0, t_ref = 0, t_prep = 0, t_gpu = 0, t_enc = 0, t0 = now(), t1;
   for (;;) {
@@ -217,24 +251,56 @@ int main(int argc, char **argv) {
     bsc_prep_stats st;
     const bsc_vcf_params vp = {0, 1, (uint32_t)codes_len};
     uint64_t n_out = 0, n_bytes = 0;
-    if (!host_bcf) { /* the whole block on the device, the encoding included.  Room for 96 bytes per position: a WGBS block writes a
+    if (!host_reader) { /* the block is in HBM already; its stream stays there too and comes over in pieces, the output thread writing behind */
+      uint64_t dev_cap = (uint64_t)n * 96 + 4096;
+      int rc = bsc_block_bcf_rawdev_keep(ctx, dblk.d_tpl, dblk.nr, dblk.d_seq, dblk.seq_bytes, dblk.d_misms, dblk.n_misms, dblk.ins_pad, &ppar, x, y, ref, NULL,
+                                         &vp, 1, dblk.tid, &ids, NULL, dev_cap, &n_bytes, &n_out, &st, &prof);
+      if (rc == BSC_ERR_ARG && n_bytes > dev_cap) { /* a block of long records: once more with the room it asks for */
+        bsc_prep_stats st2;
+        dev_cap = n_bytes + 4096;
+        rc = bsc_block_bcf_rawdev_keep(ctx, dblk.d_tpl, dblk.nr, dblk.d_seq, dblk.seq_bytes, dblk.d_misms, dblk.n_misms, dblk.ins_pad, &ppar, x, y, ref, NULL, &vp,
+                                       0, dblk.tid, &ids, NULL, dev_cap, &n_bytes, &n_out, &st2, NULL);
+      }
+      CHECK(rc);
+      t_gpu += (t1 = now()) - t0;
+      t0 = t1;
+      if (!W.buf[0]) {
+        W.f = out;
+        W.buf[0] = pinned(PIECE);
+        W.buf[1] = pinned(PIECE);
+        pthread_mutex_init(&W.mu, NULL);
+        pthread_cond_init(&W.cv, NULL);
+        pthread_create(&W.th, NULL, writer_main, &W);
+      }
+      for (uint64_t off = 0; off < n_bytes; off += PIECE) {
+        const size_t take = n_bytes - off < PIECE ? (size_t)(n_bytes - off) : PIECE;
+        pthread_mutex_lock(&W.mu);
+        while (W.full[wi]) pthread_cond_wait(&W.cv, &W.mu);
+        pthread_mutex_unlock(&W.mu);
+        CHECK(bsc_bcf_stream_read(ctx, off, take, W.buf[wi]));
+        CHECK(bsc_synchronize(ctx));
+        pthread_mutex_lock(&W.mu);
+        W.n[wi] = take;
+        W.full[wi] = 1;
+        pthread_cond_broadcast(&W.cv);
+        pthread_mutex_unlock(&W.mu);
+        wi ^= 1;
+      }
+      n_bytes = 0; /* written by the output thread */
+    } else if (!host_bcf) { /* the whole block on the device, the encoding included.  Room for 96 bytes per position: a WGBS block writes a
                       * record of ~113 bytes for every second position; a block that needs more says so and is run again */
       if ((size_t)n * 96 + 4096 > cap_bcf) {
         bsc_free_host(bcf);
         bcf = pinned(cap_bcf = (size_t)n * 96 + 4096);
       }
-      int rc = host_reader ? bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 1, blk.tid,
-                                               &ids, NULL, bcf, cap_bcf, &n_bytes, &n_out, &st, &prof)
-                           : bsc_block_bcf_rawdev(ctx, dblk.d_tpl, dblk.nr, dblk.d_seq, dblk.seq_bytes, dblk.d_misms, dblk.n_misms, dblk.ins_pad, &ppar, x, y,
-                                                  ref, NULL, &vp, 1, dblk.tid, &ids, NULL, bcf, cap_bcf, &n_bytes, &n_out, &st, &prof);
+      int rc = bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 1, blk.tid, &ids, NULL, bcf,
+                                 cap_bcf, &n_bytes, &n_out, &st, &prof);
       if (rc == BSC_ERR_ARG && n_bytes > cap_bcf) { /* a block of long records: once more with the room it asks for */
         bsc_free_host(bcf);
         bcf = pinned(cap_bcf = (size_t)n_bytes + 4096);
         bsc_prep_stats st2; /* the first pass has counted the block's bases and its profile already */
-        rc = host_reader ? bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 0, blk.tid, &ids,
-                                             NULL, bcf, cap_bcf, &n_bytes, &n_out, &st2, NULL)
-                         : bsc_block_bcf_rawdev(ctx, dblk.d_tpl, dblk.nr, dblk.d_seq, dblk.seq_bytes, dblk.d_misms, dblk.n_misms, dblk.ins_pad, &ppar, x, y, ref,
-                                                NULL, &vp, 0, dblk.tid, &ids, NULL, bcf, cap_bcf, &n_bytes, &n_out, &st2, NULL);
+        rc = bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 0, blk.tid, &ids, NULL, bcf,
+                               cap_bcf, &n_bytes, &n_out, &st2, NULL);
       }
       CHECK(rc);
     } else if (!host_prep) {
@@ -281,13 +347,22 @@ int main(int argc, char **argv) {
       }
       n_bytes = (uint64_t)nb;
     }
-    fwrite(bcf, 1, (size_t)n_bytes, out);
+    if (n_bytes) fwrite(bcf, 1, (size_t)n_bytes, out);
     n_blocks++;
     n_records += n_out;
     t_enc += (t1 = now()) - t0;
     t0 = t1;
   }
   CHECK(r);
+  if (W.buf[0]) { /* the output thread writes what it still holds, then goes */
+    pthread_mutex_lock(&W.mu);
+    W.quit = 1;
+    pthread_cond_broadcast(&W.cv);
+    pthread_mutex_unlock(&W.mu);
+    pthread_join(W.th, NULL);
+    t_enc += (t1 = now()) - t0;
+    t0 = t1;
+  }
   const double t_loop_end = now();
   if (cur_tid >= 0) {
     CHECK(bsc_get_site_totals(ctx, after));

@@ -33,7 +33,7 @@ res = {"positions": n, "coverage": cov, "contigs": contigs, "records_straddle_bg
 from bs_call_amd.bamdev import drain_stream  # noqa: E402
 
 res["host_streamer_alone"] = []
-for th in (4, 8, 16, 32, 0):
+for th in (8, 16, 32, 64, 0):
     nb, nr, dt, nth = drain_stream(bam, threads=th)
     res["host_streamer_alone"].append({"helper_threads": nth, "seconds": round(dt, 3), "inflated_GB_per_s": round(nb / dt / 1e9, 3), "positions_per_s": round(n / dt)})
     res["inflated_bytes"] = nb
