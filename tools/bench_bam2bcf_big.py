@@ -33,12 +33,26 @@ res = {"positions": n, "coverage": cov, "contigs": contigs, "records_straddle_bg
 from bs_call_amd.bamdev import drain_stream  # noqa: E402
 
 res["host_streamer_alone"] = []
-for th in (8, 16, 32, 64, 0):
+for th in (8, 16, 32, 64, 96, 0):
     nb, nr, dt, nth = drain_stream(bam, threads=th)
     res["host_streamer_alone"].append({"helper_threads": nth, "seconds": round(dt, 3), "inflated_GB_per_s": round(nb / dt / 1e9, 3), "positions_per_s": round(n / dt)})
     res["inflated_bytes"] = nb
     print("streamer", res["host_streamer_alone"][-1], flush=True)
 
+if os.environ.get("BENCH_ONLY_STREAMER"):
+    os.environ["BSC_BAMSTREAM_NOWALK"] = "1"
+    for th in (16, 32, 64):
+        nb, nr, dt, nth = drain_stream(bam, threads=th)
+        print("nowalk", nth, round(dt, 3), round(nb / dt / 1e9, 3), "GB/s", flush=True)
+    del os.environ["BSC_BAMSTREAM_NOWALK"]
+    for th in (16, 32, 64):
+        nb, nr, dt, nth = drain_stream(bam, threads=th, slab_bytes=8 << 20, n_slabs=32)
+        print("8MB slabs x32", nth, round(dt, 3), round(nb / dt / 1e9, 3), "GB/s", flush=True)
+    for th in (16, 32, 64):
+        nb, nr, dt, nth = drain_stream(bam, threads=th, slab_bytes=64 << 20, n_slabs=16)
+        print("64MB slabs x16", nth, round(dt, 3), round(nb / dt / 1e9, 3), "GB/s", flush=True)
+    print(json.dumps(res))
+    raise SystemExit(0)
 exe = os.path.join(ROOT, "bs_call_amd", "lib", "bam2bcf")
 runs = {}
 for mode, env_extra, reps in (("device_reader", {}, 3), ("host_reader", {"BAM2BCF_HOST_READER": "1", "BAM2BCF_THREADS": "4"}, 1)):
@@ -46,6 +60,9 @@ for mode, env_extra, reps in (("device_reader", {}, 3), ("host_reader", {"BAM2BC
     for _ in range(reps):
         env = dict(os.environ, BAM2BCF_TIMING="1", **env_extra)
         ob, orp = os.path.join(d, mode + ".bcf"), os.path.join(d, mode + ".json")
+        for f_ in (ob, orp):  # (removing gigabytes of an earlier run's page cache is not this run's work)
+            if os.path.exists(f_):
+                os.remove(f_)
         t0 = time.time()
         r = subprocess.run([exe, bam, fa, ob, orp], capture_output=True, text=True, env=env)
         dt = time.time() - t0
