@@ -5,12 +5,16 @@
  *
  *   file (mmap)  --claim, in file order, under one lock-->  BGZF block k: (payload, isize, crc) and ITS PLACE in a slab
  *                --N helpers, in parallel-->                inflate straight into the slab (no copy), crc32
- *                --the same helper, in block order-->       walk the block's records (block_size prefixes) while the bytes are in
- *                                                           its own cache: the record starts of the slab, a dword each
- *   slab complete  -->  bsc_bamstream_next: bytes + record starts, ready for one hipMemcpyAsync each
+ *                --the same helper, at once-->              walk the block's records (block_size prefixes) while the bytes are in its
+ *                                                           own cache, ASSUMING the block starts where a record starts (htslib's
+ *                                                           writer never cuts a record: bgzf_flush_try): record starts + what hangs over
+ *   slab complete  -->  bsc_bamstream_next: the chain is CHECKED block by block (O(1) each: did the predecessor end where this one
+ *                       assumed?), a block whose assumption failed is walked again from the true state; bytes + record starts, ready
+ *                       for one hipMemcpyAsync each
  *
- * The walk is a serial chain (a record's start is known from its predecessor's size), but each link is a read of bytes the core has
- * just written; a helper waits for its predecessor's walk, not for its inflation.  The BAM header (text, reference list) is read at
+ * The walk is a serial chain (a record's start is known from its predecessor's size); walked speculatively it is parallel for every
+ * file whose blocks start at record boundaries and still exact for the others (their blocks are walked a second time, by the consumer:
+ * slower, same offsets).  The BAM header (text, reference list) is read at
  * open by inflating the first blocks on the caller's thread; the stream then starts again from block 0 with the header as bytes to
  * step over, so that a stream offset is an offset into the inflated file.
  *
@@ -26,6 +30,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -35,20 +40,26 @@ int bsc_set_error(int code, const char *fmt, ...);
 
 #define JOB_RING 16384u /* dispatched blocks not yet walked */
 #define JOB_BATCH 128u
-#define TURN_RING 1024u /* > helpers */
+struct bs_blk { /* a block's place in its slab and what its helper's walk found */
+  uint32_t boff, isize;
+  uint32_t sp_base, sp_n;   /* its record starts: sparse[sp_base .. sp_base + sp_n), relative to the slab */
+  uint32_t exit_skip;       /* bytes of its last record that lie in the following blocks */
+  uint8_t exit_hdr[4], exit_hdr_n; /* ... or a size field cut in two */
+  uint8_t valid;            /* the walk from offset 0 met only plausible sizes */
+};
 struct bs_job {
   uint64_t file_off; /* of the block's deflate payload */
-  uint32_t clen, isize, crc, boff;
+  uint32_t clen, isize, crc;
   struct bs_slab_ *slab;
-};
-struct bs_turn {
-  uint64_t k; /* the block whose turn it is, when it lands in this slot */
-  char pad[56];
+  uint32_t blk_ix;   /* slab->blk[blk_ix] */
 };
 
 typedef struct bs_slab_ {
   uint8_t *bytes;     /* page-locked, slab_bytes */
-  uint32_t *rec_off;  /* page-locked: starts of the records that BEGIN in this slab, relative to bytes */
+  uint32_t *rec_off;  /* page-locked: starts of the records that BEGIN in this slab, relative to bytes (dense: the consumer's) */
+  uint32_t *sparse;   /* the helpers' finds, a region per block */
+  struct bs_blk *blk; /* the slab's blocks in stream order */
+  uint32_t sp_used;
   uint64_t stream_off; /* inflated-stream offset of bytes[0] */
   uint32_t n_bytes, n_recs;
   uint32_t assigned, done; /* BGZF blocks placed here (disp_mu + mu) / inflated and walked (atomic) */
@@ -73,7 +84,7 @@ struct bsc_bamstream {
   bs_slab *slab;
   int n_slabs;
   size_t slab_bytes;
-  uint32_t rec_cap;
+  uint32_t rec_cap, blk_cap, sparse_cap;
   /* dispatch state (disp_mu; the slab states under mu) */
   pthread_mutex_t mu, disp_mu;
   pthread_cond_t cv_free, cv_ready;
@@ -87,9 +98,8 @@ struct bsc_bamstream {
   struct bs_job *job;   /* ring of dispatched blocks */
   uint64_t n_filled;    /* jobs dispatched so far (atomic) */
   uint64_t n_taken;     /* jobs taken by helpers (atomic) */
-  uint64_t n_walked;    /* blocks whose walk is done (atomic; in order) */
-  struct bs_turn *turn; /* the walk's token, a cache line per block in flight */
-  /* walk chain: owned by the helper whose turn it is */
+  uint64_t n_walked;    /* blocks whose helper is done with them (atomic) */
+  /* the true chain state: the consumer's */
   uint64_t w_skip;
   uint8_t w_hdr[4];
   uint32_t w_hdr_n;
@@ -97,7 +107,7 @@ struct bsc_bamstream {
   uint64_t cons_seq;
   pthread_t *th;
   int n_threads;
-  uint64_t total_recs, total_bytes;
+  uint64_t total_recs, total_bytes, n_rewalked;
   int dbg_nowalk; /* measurement only (BSC_BAMSTREAM_NOWALK at open): no record walk, no order — the helpers' raw inflate rate */
   int unpinned; /* no device: ordinary memory (the stream is usable without a GPU; uploads from it are staged by the runtime) */
 };
@@ -249,6 +259,34 @@ static const char *walk_block(bsc_bamstream *b, bs_slab *s, uint32_t boff, const
   return NULL;
 }
 
+/* the helper's walk: the block as if a record started at its first byte */
+static void walk_speculative(struct bs_blk *k, uint32_t *sparse, const uint8_t *p) {
+  const uint32_t n = k->isize;
+  uint32_t o = 0, cnt = 0;
+  k->valid = 1;
+  k->exit_skip = 0;
+  k->exit_hdr_n = 0;
+  while (o < n) {
+    sparse[k->sp_base + cnt++] = k->boff + o;
+    if (n - o < 4) {
+      while (o < n) k->exit_hdr[k->exit_hdr_n++] = p[o++];
+      break;
+    }
+    const uint32_t bsz = le32(p + o);
+    if (bsz < 32 || bsz > (1u << 29)) {
+      k->valid = 0; /* not a record start, if the assumption was wrong; an error, if it was right: the consumer's walk says which */
+      break;
+    }
+    const uint64_t end = (uint64_t)o + 4u + bsz;
+    if (end > n) {
+      k->exit_skip = (uint32_t)(end - n);
+      break;
+    }
+    o = (uint32_t)end;
+  }
+  k->sp_n = cnt;
+}
+
 static void set_err(bsc_bamstream *b, const char *e) { /* mu held */
   if (!b->err) b->err = e;
   b->eof = 1;
@@ -275,15 +313,14 @@ static void close_fill_slab(bsc_bamstream *b, int last) { /* mu held */
   slab_maybe_ready(b, s);
 }
 
-/* a slab for the fill position: waits for the consumer to hand the ring's next slab back.  mu held (and disp_mu: one dispatcher);
- * 0 = opened, -1 = closing / error */
+/* a slab for the fill position, if the consumer has handed the ring's next one back.  mu held (and disp_mu: one dispatcher).  Never
+ * sleeps: a dispatcher asleep with disp_mu would keep helpers from jobs that are already theirs.  0 = opened, -1 = none free */
 static int open_fill_slab(bsc_bamstream *b) {
   bs_slab *s0 = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
-  while (s0->state != SL_FREE && !b->closing && !b->err) pthread_cond_wait(&b->cv_free, &b->mu);
-  if (b->closing || b->err) return -1;
+  if (s0->state != SL_FREE || b->closing || b->err) return -1;
   s0->state = SL_FILLING;
   s0->stream_off = b->stream_pos;
-  s0->n_bytes = s0->n_recs = s0->assigned = 0;
+  s0->n_bytes = s0->n_recs = s0->assigned = s0->sp_used = 0;
   __atomic_store_n(&s0->done, 0, __ATOMIC_RELAXED);
   __atomic_store_n(&s0->closed, 0, __ATOMIC_RELAXED);
   s0->last = 0;
@@ -313,21 +350,16 @@ static unsigned dispatch(bsc_bamstream *b) {
       break;
     }
     if (r == 0) { /* the stream ends: with the slab being filled, or with an empty one */
-      if (b->fill_open || open_fill_slab(b) == 0) close_fill_slab(b, 1);
+      if (!b->fill_open && open_fill_slab(b)) break; /* (no slab free for the empty last one: the next turn) */
+      close_fill_slab(b, 1);
       b->eof = 1;
       pthread_cond_broadcast(&b->cv_ready);
       break;
     }
-    if (b->fill_open && (size_t)b->fill_off + isize > b->slab_bytes) close_fill_slab(b, 0);
-    if (!b->fill_open) {
-      if (n) { /* never sleep on a full slab ring with jobs undelivered: hand them out first */
-        bs_slab *s0 = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
-        if (s0->state != SL_FREE) {
-          b->file_pos -= bsize; /* this block is looked at again by the next turn */
-          break;
-        }
-      }
-      if (open_fill_slab(b)) break;
+    if (b->fill_open && ((size_t)b->fill_off + isize > b->slab_bytes || b->slab[b->fill_seq % (uint64_t)b->n_slabs].assigned >= b->blk_cap)) close_fill_slab(b, 0);
+    if (!b->fill_open && open_fill_slab(b)) {
+      b->file_pos -= bsize; /* the slab ring is full: this block is looked at again by a later turn */
+      break;
     }
     bs_slab *s = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
     struct bs_job *j = &b->job[filled % JOB_RING];
@@ -335,8 +367,15 @@ static unsigned dispatch(bsc_bamstream *b) {
     j->clen = clen;
     j->isize = isize;
     j->crc = crc;
-    j->boff = b->fill_off;
     j->slab = s;
+    j->blk_ix = s->assigned;
+    struct bs_blk *kb = &s->blk[s->assigned];
+    kb->boff = b->fill_off;
+    kb->isize = isize;
+    kb->sp_base = s->sp_used;
+    kb->sp_n = 0;
+    kb->valid = 0;
+    s->sp_used += isize / 36u + 1u; /* a record is 36 bytes at least: no block has more starts than that */
     b->fill_off += isize;
     b->stream_pos += isize;
     s->assigned++;
@@ -349,12 +388,11 @@ static unsigned dispatch(bsc_bamstream *b) {
 
 /*
  * Synchronisation, sized for dozens of helpers.  Blocks are DISPATCHED in batches (whoever finds the job ring empty takes the
- * dispatcher's turn: header parse and placement of the next 128 blocks under one lock), TAKEN with one atomic add, and their walks pass a
- * token from cache line to cache line (block k's helper polls slot k % 1024, which only block k - 1's helper writes): no word is polled by
- * more than one thread, no lock is taken per block but the slab's completion count (an atomic; the lock only for the block that completes
- * its slab).  (First form: one mutex and three broadcast condition variables — 3.6 GB/s with 16 helpers, 1.0 with 32.  Second: a claim mutex
- * and one shared turn word polled by every waiting helper — 4.5 GB/s with 16, 1.1 with 64: every block's hand-over invalidated that line in
- * every poller's cache.)
+ * dispatcher's turn: header parse and placement of the next 128 blocks under one lock), TAKEN with one atomic add, inflated and walked
+ * with no word shared between helpers but the slab's completion count (an atomic; the lock only for the block that completes its slab).
+ * (First form: one mutex and three broadcast condition variables — 3.6 GB/s with 16 helpers, 1.0 with 32.  Second: a claim mutex and a turn
+ * word for the walk, which was done in block order by the helpers — 4.5 GB/s with 16, 1.1 with 64; with the token passed from cache line
+ * to cache line 4.4 / 2.4: in block order every helper waits for the slowest of its predecessors, whatever the hand-over costs.)
  */
 static void *helper(void *arg) {
   bsc_bamstream *b = (bsc_bamstream *)arg;
@@ -386,9 +424,18 @@ static void *helper(void *arg) {
         pthread_mutex_lock(&b->mu);
         over = (b->eof || b->closing) && k >= __atomic_load_n(&b->n_filled, __ATOMIC_ACQUIRE);
         pthread_mutex_unlock(&b->mu);
-        if (!got && !over) { /* the job ring is full, or the slab ring: the others catch up first */
+        if (!got && !over) { /* the job ring is full, or the slab ring: the others (or the consumer) catch up first */
           pthread_mutex_unlock(&b->disp_mu);
-          sched_yield();
+          struct timespec ts;
+          clock_gettime(CLOCK_REALTIME, &ts);
+          ts.tv_nsec += 200000; /* 0.2 ms, or a slab handed back */
+          if (ts.tv_nsec >= 1000000000L) {
+            ts.tv_sec++;
+            ts.tv_nsec -= 1000000000L;
+          }
+          pthread_mutex_lock(&b->mu);
+          if (!b->closing && !b->eof) pthread_cond_timedwait(&b->cv_free, &b->mu, &ts);
+          pthread_mutex_unlock(&b->mu);
           continue;
         }
       }
@@ -400,35 +447,17 @@ static void *helper(void *arg) {
     }
     const struct bs_job j = b->job[k % JOB_RING];
     bs_slab *s = j.slab;
-    const char *e = pread(b->fd, raw, j.clen, (off_t)j.file_off) == (ssize_t)j.clen ? bgzf_inflate_to(raw, j.clen, s->bytes + j.boff, j.isize, j.crc)
+    struct bs_blk *kb = &s->blk[j.blk_ix];
+    const char *e = pread(b->fd, raw, j.clen, (off_t)j.file_off) == (ssize_t)j.clen ? bgzf_inflate_to(raw, j.clen, s->bytes + kb->boff, j.isize, j.crc)
                                                                                      : "BAM: read error";
-    /* the walk, in block order, on the core that holds the bytes: wait for the token */
-    struct bs_turn *t = &b->turn[k % TURN_RING];
-    if (b->dbg_nowalk) {
-      __atomic_fetch_add(&b->n_walked, 1, __ATOMIC_RELEASE);
-      goto walked;
-    }
-    for (unsigned spins = 0; __atomic_load_n(&t->k, __ATOMIC_ACQUIRE) != k; spins++) {
-      if (__atomic_load_n(&b->closing, __ATOMIC_RELAXED)) {
-        free(raw);
-        return NULL;
-      }
-      if (spins < 256) __builtin_ia32_pause();
-      else sched_yield();
-    }
-    if (!e && !__atomic_load_n(&b->has_err, __ATOMIC_ACQUIRE)) e = walk_block(b, s, j.boff, s->bytes + j.boff, j.isize);
-    if (e) __atomic_store_n(&b->has_err, 1, __ATOMIC_RELEASE);
-    __atomic_store_n(&b->n_walked, k + 1, __ATOMIC_RELEASE);
-    __atomic_store_n(&b->turn[(k + 1) % TURN_RING].k, k + 1, __ATOMIC_RELEASE); /* the token goes on */
-  walked:
+    if (!e && !b->dbg_nowalk) walk_speculative(kb, s->sparse, s->bytes + kb->boff);
+    __atomic_fetch_add(&b->n_walked, 1, __ATOMIC_RELEASE);
     if (e) {
       pthread_mutex_lock(&b->mu);
       set_err(b, e);
       pthread_mutex_unlock(&b->mu);
-      {
-        free(raw);
-        return NULL;
-      }
+      free(raw);
+      return NULL;
     }
     const uint32_t d = __atomic_add_fetch(&s->done, 1, __ATOMIC_SEQ_CST);
     if (__atomic_load_n(&s->closed, __ATOMIC_SEQ_CST) && d == s->assigned) { /* (assigned is final once closed is seen) */
@@ -492,9 +521,10 @@ void bsc_bamstream_close(bsc_bamstream *b) {
   }
   free(b->th);
   free(b->job);
-  free(b->turn);
   if (b->slab)
     for (int i = 0; i < b->n_slabs; i++) {
+      free(b->slab[i].sparse);
+      free(b->slab[i].blk);
       if (b->unpinned) {
         free(b->slab[i].bytes);
         free(b->slab[i].rec_off);
@@ -624,6 +654,8 @@ int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int
   b->slab_bytes = (size_t)slab_bytes;
   b->n_slabs = n_slabs;
   b->rec_cap = (uint32_t)(slab_bytes / 36u + 2u);
+  b->blk_cap = (uint32_t)(slab_bytes / 4096u + 64u);
+  b->sparse_cap = b->rec_cap + b->blk_cap;
   b->slab = calloc((size_t)n_slabs, sizeof *b->slab);
   if (!b->slab) goto nomem;
   for (int i = 0; i < n_slabs; i++) {
@@ -641,16 +673,15 @@ int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int
       b->slab[i].bytes = p1;
       b->slab[i].rec_off = p2;
     }
-    if (!b->slab[i].bytes || !b->slab[i].rec_off) goto nomem;
+    b->slab[i].sparse = malloc((size_t)b->sparse_cap * 4u);
+    b->slab[i].blk = malloc((size_t)b->blk_cap * sizeof(struct bs_blk));
+    if (!b->slab[i].bytes || !b->slab[i].rec_off || !b->slab[i].sparse || !b->slab[i].blk) goto nomem;
   }
   b->w_skip = b->first_rec_off;
   b->dbg_nowalk = getenv("BSC_BAMSTREAM_NOWALK") != NULL;
   b->th = calloc((size_t)n_threads, sizeof *b->th);
   b->job = calloc(JOB_RING, sizeof *b->job);
-  if (posix_memalign((void **)&b->turn, 64, TURN_RING * sizeof *b->turn)) b->turn = NULL;
-  if (!b->th || !b->job || !b->turn) goto nomem;
-  memset(b->turn, 0xff, TURN_RING * sizeof *b->turn);
-  b->turn[0].k = 0; /* block 0 holds the token */
+  if (!b->th || !b->job) goto nomem;
   pthread_mutex_init(&b->mu, NULL);
   pthread_mutex_init(&b->disp_mu, NULL);
   pthread_cond_init(&b->cv_free, NULL);
@@ -699,11 +730,27 @@ int bsc_bamstream_next(bsc_bamstream *b, bsc_bam_slab *out) {
     }
     pthread_cond_wait(&b->cv_ready, &b->mu);
   }
-  if (s->last && (b->w_skip || b->w_hdr_n) && !b->dbg_nowalk) {
-    pthread_mutex_unlock(&b->mu);
-    return bsc_set_error(BSC_ERR_ARG, "BAM: input truncated (the last record is incomplete)");
+  s->state = SL_OUT; /* (the helpers are done with it: what follows needs no lock) */
+  pthread_mutex_unlock(&b->mu);
+  /* the chain, block by block: a block whose helper assumed the right entry state (nothing hanging over from its predecessor) keeps its
+   * finds; any other is walked again from the true state */
+  s->n_recs = 0;
+  for (uint32_t i = 0; i < s->assigned && !b->dbg_nowalk; i++) {
+    const struct bs_blk *k = &s->blk[i];
+    if (b->w_skip == 0 && b->w_hdr_n == 0 && k->valid) {
+      memcpy(s->rec_off + s->n_recs, s->sparse + k->sp_base, (size_t)k->sp_n * 4u);
+      s->n_recs += k->sp_n;
+      b->w_skip = k->exit_skip;
+      b->w_hdr_n = k->exit_hdr_n;
+      memcpy(b->w_hdr, k->exit_hdr, 4);
+    } else {
+      const char *e = walk_block(b, s, k->boff, s->bytes + k->boff, k->isize);
+      if (e) return bsc_set_error(BSC_ERR_ARG, "%s", e);
+      b->n_rewalked++;
+    }
   }
-  s->state = SL_OUT;
+  if (s->last && (b->w_skip || b->w_hdr_n) && !b->dbg_nowalk) return bsc_set_error(BSC_ERR_ARG, "BAM: input truncated (the last record is incomplete)");
+  pthread_mutex_lock(&b->mu);
   out->bytes = s->bytes;
   out->n_bytes = s->n_bytes;
   out->stream_off = s->stream_off;
