@@ -3,20 +3,24 @@
  * the offset of every alignment record, and nothing else.  What is left on the host of the reference's reader thread
  * (sam_read1 under read_input, src/get_template_vector.c:49-389) is what a GPU cannot start from: the gzip members.
  *
- *   file (mmap)  --claim, in file order, under one lock-->  BGZF block k: (payload, isize, crc) and ITS PLACE in a slab
- *                --N helpers, in parallel-->                inflate straight into the slab (no copy), crc32
- *                --the same helper, at once-->              walk the block's records (block_size prefixes) while the bytes are in its
- *                                                           own cache, ASSUMING the block starts where a record starts (htslib's
- *                                                           writer never cuts a record: bgzf_flush_try): record starts + what hangs over
- *   slab complete  -->  bsc_bamstream_next: the chain is CHECKED block by block (O(1) each: did the predecessor end where this one
- *                       assumed?), a block whose assumption failed is walked again from the true state; bytes + record starts, ready
- *                       for one hipMemcpyAsync each
+ *   open      the BAM header (text, reference list) from the first blocks; then the INDEX of every BGZF block of the file — offset, sizes,
+ *             checksum — built by all helpers at once: each takes a stretch of the file, finds the first block header in it (the 16 fixed
+ *             bytes every writer emits) and follows the BSIZE chain to the stretch's end; where two stretches meet, the chain of the first
+ *             must end exactly where the second began (else the file is indexed again by one thread, from its first byte).  With the
+ *             index every block's place in the slab sequence is known before the first byte is inflated.
+ *   helpers   take blocks with one atomic add, in file order: read the payload (pread), inflate straight into the block's place in its
+ *             slab (no copy), crc32, and walk the block's records (block_size prefixes) while the bytes are in the core's own cache,
+ *             ASSUMING the block starts where a record starts (htslib's writer never cuts a record: bgzf_flush_try): record starts +
+ *             what hangs over.  No word is shared between helpers but the slab's completion count.
+ *   consumer  bsc_bamstream_next: the slab's blocks CHECKED in order (O(1) each: did the predecessor end where this one assumed?), a
+ *             block whose assumption failed is walked again from the true state (files whose records straddle blocks — htsjdk's — are
+ *             walked by the consumer: slower, same offsets); bytes + record starts, ready for one hipMemcpyAsync each.
  *
- * The walk is a serial chain (a record's start is known from its predecessor's size); walked speculatively it is parallel for every
- * file whose blocks start at record boundaries and still exact for the others (their blocks are walked a second time, by the consumer:
- * slower, same offsets).  The BAM header (text, reference list) is read at
- * open by inflating the first blocks on the caller's thread; the stream then starts again from block 0 with the header as bytes to
- * step over, so that a stream offset is an offset into the inflated file.
+ * What was measured on the way (50 Mb at 30x, 3.07 GB inflated, a 2 x 64-core host): one mutex and three broadcast condition variables
+ * 3.6 GB/s with 16 helpers and 1.0 with 32; the walk in block order by the helpers behind a turn word 4.5 / 1.1 (64 helpers), behind a
+ * token passed from cache line to cache line 4.4 / 2.4 — in block order every helper waits for the slowest of its predecessors; the
+ * speculative walk 5.8 whatever the number of helpers: the one dispatcher's two preads per block (it parsed the headers as it went) were
+ * the ceiling.  Hence the index.
  *
  * BAM only (SAM text and CRAM go through csrc/bamio.c or not at all).  Layout facts: SAM specification 4.1 (BGZF), 4.2 (BAM).
  */
@@ -38,8 +42,7 @@
 
 int bsc_set_error(int code, const char *fmt, ...);
 
-#define JOB_RING 16384u /* dispatched blocks not yet walked */
-#define JOB_BATCH 128u
+#define SEQ_NONE 0xffffffffu
 struct bs_blk { /* a block's place in its slab and what its helper's walk found */
   uint32_t boff, isize;
   uint32_t sp_base, sp_n;   /* its record starts: sparse[sp_base .. sp_base + sp_n), relative to the slab */
@@ -47,11 +50,15 @@ struct bs_blk { /* a block's place in its slab and what its helper's walk found 
   uint8_t exit_hdr[4], exit_hdr_n; /* ... or a size field cut in two */
   uint8_t valid;            /* the walk from offset 0 met only plausible sizes */
 };
-struct bs_job {
-  uint64_t file_off; /* of the block's deflate payload */
+struct bs_ent { /* one BGZF block of the file */
+  uint64_t file_off; /* of its deflate payload */
   uint32_t clen, isize, crc;
-  struct bs_slab_ *slab;
-  uint32_t blk_ix;   /* slab->blk[blk_ix] */
+  uint32_t seq;      /* the slab-load it belongs to (SEQ_NONE: an empty block, stepped over) */
+  uint32_t boff, blk_ix, sp_base;
+};
+struct bs_seq { /* one slab-load of the stream */
+  uint64_t stream_off;
+  uint32_t n_bytes, n_ent, last;
 };
 
 typedef struct bs_slab_ {
@@ -59,20 +66,16 @@ typedef struct bs_slab_ {
   uint32_t *rec_off;  /* page-locked: starts of the records that BEGIN in this slab, relative to bytes (dense: the consumer's) */
   uint32_t *sparse;   /* the helpers' finds, a region per block */
   struct bs_blk *blk; /* the slab's blocks in stream order */
-  uint32_t sp_used;
-  uint64_t stream_off; /* inflated-stream offset of bytes[0] */
-  uint32_t n_bytes, n_recs;
-  uint32_t assigned, done; /* BGZF blocks placed here (disp_mu + mu) / inflated and walked (atomic) */
-  int closed;              /* no further block will be placed here (atomic) */
-  int last;                /* the stream ends with this slab */
-  int state;               /* SL_* */
+  uint32_t n_recs;
+  uint32_t done;      /* blocks inflated and walked (atomic) */
+  uint64_t ready_for; /* sequence number + 1 of the slab-load that is complete in it (under mu) */
+  int out;            /* handed to the consumer, not yet released */
 } bs_slab;
-enum { SL_FREE, SL_FILLING, SL_READY, SL_OUT };
 
 struct bsc_bamstream {
   int fd;
-  const uint8_t *map;
-  size_t map_len;
+  const uint8_t *map; /* the header's blocks only */
+  size_t map_len;     /* the file's length */
   /* header */
   char *text;
   uint32_t l_text;
@@ -80,25 +83,22 @@ struct bsc_bamstream {
   char **ref_name;
   uint32_t *ref_len;
   uint64_t first_rec_off;
+  /* index */
+  struct bs_ent *ent;
+  uint64_t n_ent;
+  struct bs_seq *seq;
+  uint64_t n_seq;
   /* slabs */
   bs_slab *slab;
   int n_slabs;
   size_t slab_bytes;
   uint32_t rec_cap, blk_cap, sparse_cap;
-  /* dispatch state (disp_mu; the slab states under mu) */
-  pthread_mutex_t mu, disp_mu;
-  pthread_cond_t cv_free, cv_ready;
-  size_t file_pos;
-  uint64_t stream_pos;
-  uint64_t fill_seq;    /* slab sequence number being filled (slab index = seq % n_slabs) */
-  uint32_t fill_off;
-  int fill_open;        /* slab fill_seq has been opened */
-  int eof, closing, has_err;
+  pthread_mutex_t mu;
+  pthread_cond_t cv_ready;
+  int closing, has_err;
   const char *err;      /* first error, raised by the consumer */
-  struct bs_job *job;   /* ring of dispatched blocks */
-  uint64_t n_filled;    /* jobs dispatched so far (atomic) */
-  uint64_t n_taken;     /* jobs taken by helpers (atomic) */
-  uint64_t n_walked;    /* blocks whose helper is done with them (atomic) */
+  uint64_t next_ent;    /* the next block to take (atomic) */
+  uint64_t n_released;  /* slab-loads the consumer has handed back (atomic): load q may be filled once q < n_released + n_slabs */
   /* the true chain state: the consumer's */
   uint64_t w_skip;
   uint8_t w_hdr[4];
@@ -108,8 +108,9 @@ struct bsc_bamstream {
   pthread_t *th;
   int n_threads;
   uint64_t total_recs, total_bytes, n_rewalked;
-  int dbg_nowalk; /* measurement only (BSC_BAMSTREAM_NOWALK at open): no record walk, no order — the helpers' raw inflate rate */
-  int unpinned; /* no device: ordinary memory (the stream is usable without a GPU; uploads from it are staged by the runtime) */
+  int dbg_nowalk; /* measurement only (BSC_BAMSTREAM_NOWALK at open): no record walk — the helpers' raw inflate rate */
+  int unpinned;   /* no device: ordinary memory (the stream is usable without a GPU; uploads from it are staged by the runtime) */
+  int idx_threads, idx_serial; /* how the index was built */
 };
 
 static uint32_t le32(const uint8_t *p) { return p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
@@ -289,111 +290,203 @@ static void walk_speculative(struct bs_blk *k, uint32_t *sparse, const uint8_t *
 
 static void set_err(bsc_bamstream *b, const char *e) { /* mu held */
   if (!b->err) b->err = e;
-  b->eof = 1;
   __atomic_store_n(&b->has_err, 1, __ATOMIC_RELEASE);
   pthread_cond_broadcast(&b->cv_ready);
-  pthread_cond_broadcast(&b->cv_free);
 }
 
-static void slab_maybe_ready(bsc_bamstream *b, bs_slab *s) { /* mu held */
-  if (s->state == SL_FILLING && s->closed && __atomic_load_n(&s->done, __ATOMIC_ACQUIRE) == s->assigned) {
-    s->state = SL_READY;
-    pthread_cond_broadcast(&b->cv_ready);
+/* ---- the index ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  bsc_bamstream *b;
+  size_t from, limit; /* the stretch: blocks that START in [first block at or after from, limit) */
+  int first;          /* from is a block start (the file's first stretch) */
+  struct bs_ent *ent;
+  size_t n, cap;
+  size_t start, end;  /* where its chain began / ended (end >= limit) */
+  const char *err;
+  int found;
+} idx_job;
+
+static const uint8_t bgzf_magic[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+
+static void *idx_scan(void *a) {
+  idx_job *j = (idx_job *)a;
+  bsc_bamstream *b = j->b;
+  size_t pos = j->from;
+  j->found = 0;
+  j->err = NULL;
+  j->n = 0;
+  if (!j->first) { /* the first header in the stretch: the fixed bytes, confirmed by the header behind the block they announce */
+    const size_t win = 1u << 18;
+    uint8_t *w = malloc(win + 16);
+    if (!w) {
+      j->err = "BAM: out of memory";
+      return NULL;
+    }
+    int ok = 0;
+    while (pos < j->limit && !ok) {
+      const size_t want = b->map_len - pos < win + 15 ? b->map_len - pos : win + 15;
+      const ssize_t got = pread(b->fd, w, want, (off_t)pos);
+      if (got < 16) break;
+      size_t o = 0;
+      while (o + 16 <= (size_t)got) {
+        const uint8_t *m = memmem(w + o, (size_t)got - o, bgzf_magic, 16);
+        if (!m) break;
+        const size_t c = pos + (size_t)(m - w);
+        if (c >= j->limit) break;
+        uint64_t po;
+        uint32_t cl, is, cr, bs;
+        const char *e = NULL;
+        if (bgzf_peek(b->fd, b->map_len, c, &po, &cl, &is, &cr, &bs, &e) == 1) {
+          const int r2 = c + bs == b->map_len ? 1 : bgzf_peek(b->fd, b->map_len, c + bs, &po, &cl, &is, &cr, &bs, &e);
+          if (r2 == 1) {
+            pos = c;
+            ok = 1;
+            break;
+          }
+        }
+        o = (size_t)(m - w) + 1;
+      }
+      if (!ok) pos += (size_t)got - 15;
+    }
+    free(w);
+    if (!ok) return NULL; /* no block starts in this stretch (or none this scan recognises) */
   }
-}
-
-static void close_fill_slab(bsc_bamstream *b, int last) { /* mu held */
-  if (!b->fill_open) return;
-  bs_slab *s = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
-  s->n_bytes = b->fill_off;
-  s->last = last;
-  __atomic_store_n(&s->closed, 1, __ATOMIC_SEQ_CST);
-  b->fill_open = 0;
-  b->fill_seq++;
-  slab_maybe_ready(b, s);
-}
-
-/* a slab for the fill position, if the consumer has handed the ring's next one back.  mu held (and disp_mu: one dispatcher).  Never
- * sleeps: a dispatcher asleep with disp_mu would keep helpers from jobs that are already theirs.  0 = opened, -1 = none free */
-static int open_fill_slab(bsc_bamstream *b) {
-  bs_slab *s0 = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
-  if (s0->state != SL_FREE || b->closing || b->err) return -1;
-  s0->state = SL_FILLING;
-  s0->stream_off = b->stream_pos;
-  s0->n_bytes = s0->n_recs = s0->assigned = s0->sp_used = 0;
-  __atomic_store_n(&s0->done, 0, __ATOMIC_RELAXED);
-  __atomic_store_n(&s0->closed, 0, __ATOMIC_RELAXED);
-  s0->last = 0;
-  b->fill_off = 0;
-  b->fill_open = 1;
-  return 0;
-}
-
-/* The dispatcher's turn (disp_mu held): the next blocks of the file get their places, JOB_BATCH at most.  Returns the number dispatched;
- * 0 with b->eof set when the file has ended (or the stream is closing / failed). */
-static unsigned dispatch(bsc_bamstream *b) {
-  unsigned n = 0;
-  pthread_mutex_lock(&b->mu);
-  while (n < JOB_BATCH && !b->closing && !b->eof) {
-    const uint64_t filled = __atomic_load_n(&b->n_filled, __ATOMIC_RELAXED);
-    if (filled - __atomic_load_n(&b->n_walked, __ATOMIC_ACQUIRE) >= JOB_RING - 1u) break; /* the ring of jobs is full: the helpers catch up first */
-    uint64_t payload;
-    uint32_t clen, isize, crc, bsize;
+  j->found = 1;
+  j->start = pos;
+  while (pos < j->limit) {
+    uint64_t po;
+    uint32_t cl, is, cr, bs;
     const char *e = NULL;
-    int r;
-    do { /* empty blocks (the end-of-file marker) are stepped over */
-      r = bgzf_peek(b->fd, b->map_len, b->file_pos, &payload, &clen, &isize, &crc, &bsize, &e);
-      if (r == 1) b->file_pos += bsize;
-    } while (r == 1 && isize == 0);
+    const int r = bgzf_peek(b->fd, b->map_len, pos, &po, &cl, &is, &cr, &bs, &e);
+    if (r == 0) break;
     if (r < 0) {
-      set_err(b, e);
+      j->err = e;
       break;
     }
-    if (r == 0) { /* the stream ends: with the slab being filled, or with an empty one */
-      if (!b->fill_open && open_fill_slab(b)) break; /* (no slab free for the empty last one: the next turn) */
-      close_fill_slab(b, 1);
-      b->eof = 1;
-      pthread_cond_broadcast(&b->cv_ready);
-      break;
+    if (j->n == j->cap) {
+      j->cap = j->cap * 2 + 1024;
+      struct bs_ent *ne = realloc(j->ent, j->cap * sizeof *ne);
+      if (!ne) {
+        j->err = "BAM: out of memory";
+        break;
+      }
+      j->ent = ne;
     }
-    if (b->fill_open && ((size_t)b->fill_off + isize > b->slab_bytes || b->slab[b->fill_seq % (uint64_t)b->n_slabs].assigned >= b->blk_cap)) close_fill_slab(b, 0);
-    if (!b->fill_open && open_fill_slab(b)) {
-      b->file_pos -= bsize; /* the slab ring is full: this block is looked at again by a later turn */
-      break;
-    }
-    bs_slab *s = &b->slab[b->fill_seq % (uint64_t)b->n_slabs];
-    struct bs_job *j = &b->job[filled % JOB_RING];
-    j->file_off = payload;
-    j->clen = clen;
-    j->isize = isize;
-    j->crc = crc;
-    j->slab = s;
-    j->blk_ix = s->assigned;
-    struct bs_blk *kb = &s->blk[s->assigned];
-    kb->boff = b->fill_off;
-    kb->isize = isize;
-    kb->sp_base = s->sp_used;
-    kb->sp_n = 0;
-    kb->valid = 0;
-    s->sp_used += isize / 36u + 1u; /* a record is 36 bytes at least: no block has more starts than that */
-    b->fill_off += isize;
-    b->stream_pos += isize;
-    s->assigned++;
-    __atomic_store_n(&b->n_filled, filled + 1, __ATOMIC_RELEASE);
-    n++;
+    struct bs_ent *t = &j->ent[j->n++];
+    t->file_off = po;
+    t->clen = cl;
+    t->isize = is;
+    t->crc = cr;
+    t->seq = SEQ_NONE;
+    pos += bs;
   }
-  pthread_mutex_unlock(&b->mu);
-  return n;
+  j->end = pos;
+  return NULL;
 }
 
-/*
- * Synchronisation, sized for dozens of helpers.  Blocks are DISPATCHED in batches (whoever finds the job ring empty takes the
- * dispatcher's turn: header parse and placement of the next 128 blocks under one lock), TAKEN with one atomic add, inflated and walked
- * with no word shared between helpers but the slab's completion count (an atomic; the lock only for the block that completes its slab).
- * (First form: one mutex and three broadcast condition variables — 3.6 GB/s with 16 helpers, 1.0 with 32.  Second: a claim mutex and a turn
- * word for the walk, which was done in block order by the helpers — 4.5 GB/s with 16, 1.1 with 64; with the token passed from cache line
- * to cache line 4.4 / 2.4: in block order every helper waits for the slowest of its predecessors, whatever the hand-over costs.)
- */
+/* every block of the file -> b->ent, then every block's place.  BSC_OK or an error code (message set) */
+static int build_index(bsc_bamstream *b, int n_threads) {
+  const size_t F = b->map_len;
+  int T = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+  while (T > 1 && F / (size_t)T < (4u << 20)) T--; /* stretches of 4 MiB at least */
+  idx_job *job = calloc((size_t)T, sizeof *job);
+  pthread_t *th = calloc((size_t)T, sizeof *th);
+  if (!job || !th) {
+    free(job);
+    free(th);
+    return bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
+  }
+  const size_t R = F / (size_t)T;
+  for (int i = 0; i < T; i++) {
+    job[i].b = b;
+    job[i].from = (size_t)i * R;
+    job[i].limit = i + 1 == T ? F : (size_t)(i + 1) * R;
+    job[i].first = i == 0;
+  }
+  int started = 0;
+  for (int i = 1; i < T; i++, started++)
+    if (pthread_create(&th[i], NULL, idx_scan, &job[i])) break;
+  idx_scan(&job[0]);
+  for (int i = 1; i <= started; i++) pthread_join(th[i], NULL);
+  int good = started == T - 1;
+  for (int i = 0; i < T && good; i++) {
+    if (job[i].err || !job[i].found) good = 0;
+    else if (i + 1 < T && job[i + 1].found && job[i].end != job[i + 1].start) good = 0; /* the chains do not meet: a false start */
+  }
+  b->idx_threads = T;
+  if (!good && T > 1) { /* one thread, from the file's first byte: the chain itself */
+    for (int i = 1; i < T; i++) {
+      free(job[i].ent);
+      job[i].ent = NULL;
+      job[i].n = 0;
+    }
+    job[0].limit = F;
+    job[0].cap = job[0].n = 0;
+    free(job[0].ent);
+    job[0].ent = NULL;
+    idx_scan(&job[0]);
+    T = 1;
+    b->idx_serial = 1;
+  }
+  int rc = BSC_OK;
+  if (job[0].err && T == 1) rc = bsc_set_error(BSC_ERR_ARG, "%s", job[0].err);
+  size_t total = 0;
+  for (int i = 0; i < T; i++) total += job[i].n;
+  if (!rc) {
+    b->ent = malloc((total + 1) * sizeof *b->ent);
+    if (!b->ent) rc = bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
+  }
+  if (!rc) {
+    size_t o = 0;
+    for (int i = 0; i < T; i++) {
+      if (job[i].n) memcpy(b->ent + o, job[i].ent, job[i].n * sizeof *b->ent);
+      o += job[i].n;
+    }
+    b->n_ent = total;
+  }
+  for (int i = 0; i < T; i++) free(job[i].ent);
+  free(job);
+  free(th);
+  if (rc) return rc;
+  /* every block's place: slab-loads filled in stream order, a block never cut */
+  size_t cap_seq = 0;
+  uint64_t stream = 0;
+  uint32_t fill = 0, nblk = 0, sp = 0;
+  int open_ = 0;
+  for (uint64_t k = 0; k < b->n_ent; k++) {
+    struct bs_ent *e = &b->ent[k];
+    if (e->isize == 0) continue;
+    if (open_ && ((size_t)fill + e->isize > b->slab_bytes || nblk >= b->blk_cap)) open_ = 0;
+    if (!open_) {
+      if (b->n_seq == cap_seq) {
+        cap_seq = cap_seq * 2 + 256;
+        struct bs_seq *ns = realloc(b->seq, cap_seq * sizeof *ns);
+        if (!ns) return bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
+        b->seq = ns;
+      }
+      struct bs_seq *q = &b->seq[b->n_seq++];
+      q->stream_off = stream;
+      q->n_bytes = q->n_ent = q->last = 0;
+      fill = nblk = sp = 0;
+      open_ = 1;
+    }
+    if (b->n_seq > 0xfffffff0ull) return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_open: file too large");
+    struct bs_seq *q = &b->seq[b->n_seq - 1];
+    e->seq = (uint32_t)(b->n_seq - 1);
+    e->boff = fill;
+    e->blk_ix = nblk++;
+    e->sp_base = sp;
+    sp += e->isize / 36u + 1u; /* a record is 36 bytes at least: no block has more starts than that */
+    fill += e->isize;
+    stream += e->isize;
+    q->n_bytes = fill;
+    q->n_ent = nblk;
+  }
+  if (b->n_seq) b->seq[b->n_seq - 1].last = 1;
+  return BSC_OK;
+}
+
+/* ---- the helpers ----------------------------------------------------------------------------------------------------------------- */
 static void *helper(void *arg) {
   bsc_bamstream *b = (bsc_bamstream *)arg;
   uint8_t *raw = malloc(65536 + 64); /* one compressed block */
@@ -404,68 +497,47 @@ static void *helper(void *arg) {
     return NULL;
   }
   for (;;) {
-    const uint64_t k = __atomic_fetch_add(&b->n_taken, 1, __ATOMIC_ACQ_REL);
-    for (unsigned spins = 0; k >= __atomic_load_n(&b->n_filled, __ATOMIC_ACQUIRE); spins++) {
+    const uint64_t k = __atomic_fetch_add(&b->next_ent, 1, __ATOMIC_RELAXED);
+    if (k >= b->n_ent || __atomic_load_n(&b->closing, __ATOMIC_RELAXED) || __atomic_load_n(&b->has_err, __ATOMIC_RELAXED)) break;
+    const struct bs_ent *e = &b->ent[k];
+    if (e->seq == SEQ_NONE) continue;
+    /* its slab: free once the consumer has handed back the load that used it before */
+    for (unsigned spins = 0; (uint64_t)e->seq >= __atomic_load_n(&b->n_released, __ATOMIC_ACQUIRE) + (uint64_t)b->n_slabs; spins++) {
       if (__atomic_load_n(&b->closing, __ATOMIC_RELAXED)) {
         free(raw);
         return NULL;
       }
-      /* nothing dispatched for this helper yet: it takes the dispatcher's turn, or waits for the one who has it */
-      if (spins < 64) {
-        if (pthread_mutex_trylock(&b->disp_mu)) {
-          __builtin_ia32_pause();
-          continue;
-        }
-      } else
-        pthread_mutex_lock(&b->disp_mu);
-      int over = 0;
-      if (k >= __atomic_load_n(&b->n_filled, __ATOMIC_ACQUIRE)) {
-        const unsigned got = dispatch(b);
-        pthread_mutex_lock(&b->mu);
-        over = (b->eof || b->closing) && k >= __atomic_load_n(&b->n_filled, __ATOMIC_ACQUIRE);
-        pthread_mutex_unlock(&b->mu);
-        if (!got && !over) { /* the job ring is full, or the slab ring: the others (or the consumer) catch up first */
-          pthread_mutex_unlock(&b->disp_mu);
-          struct timespec ts;
-          clock_gettime(CLOCK_REALTIME, &ts);
-          ts.tv_nsec += 200000; /* 0.2 ms, or a slab handed back */
-          if (ts.tv_nsec >= 1000000000L) {
-            ts.tv_sec++;
-            ts.tv_nsec -= 1000000000L;
-          }
-          pthread_mutex_lock(&b->mu);
-          if (!b->closing && !b->eof) pthread_cond_timedwait(&b->cv_free, &b->mu, &ts);
-          pthread_mutex_unlock(&b->mu);
-          continue;
-        }
-      }
-      pthread_mutex_unlock(&b->disp_mu);
-      if (over) {
-        free(raw);
-        return NULL;
+      if (spins < 64) __builtin_ia32_pause();
+      else {
+        struct timespec ts = {0, 50000}; /* the consumer is the slower side: nothing to hurry for */
+        nanosleep(&ts, NULL);
       }
     }
-    const struct bs_job j = b->job[k % JOB_RING];
-    bs_slab *s = j.slab;
-    struct bs_blk *kb = &s->blk[j.blk_ix];
-    const char *e = pread(b->fd, raw, j.clen, (off_t)j.file_off) == (ssize_t)j.clen ? bgzf_inflate_to(raw, j.clen, s->bytes + kb->boff, j.isize, j.crc)
-                                                                                     : "BAM: read error";
-    if (!e && !b->dbg_nowalk) walk_speculative(kb, s->sparse, s->bytes + kb->boff);
-    __atomic_fetch_add(&b->n_walked, 1, __ATOMIC_RELEASE);
-    if (e) {
+    bs_slab *s = &b->slab[e->seq % (uint32_t)b->n_slabs];
+    struct bs_blk *kb = &s->blk[e->blk_ix];
+    kb->boff = e->boff;
+    kb->isize = e->isize;
+    kb->sp_base = e->sp_base;
+    kb->sp_n = 0;
+    kb->valid = 0;
+    const char *er = pread(b->fd, raw, e->clen, (off_t)e->file_off) == (ssize_t)e->clen ? bgzf_inflate_to(raw, e->clen, s->bytes + e->boff, e->isize, e->crc)
+                                                                                         : "BAM: read error";
+    if (er) {
       pthread_mutex_lock(&b->mu);
-      set_err(b, e);
+      set_err(b, er);
       pthread_mutex_unlock(&b->mu);
-      free(raw);
-      return NULL;
+      break;
     }
-    const uint32_t d = __atomic_add_fetch(&s->done, 1, __ATOMIC_SEQ_CST);
-    if (__atomic_load_n(&s->closed, __ATOMIC_SEQ_CST) && d == s->assigned) { /* (assigned is final once closed is seen) */
+    if (!b->dbg_nowalk) walk_speculative(kb, s->sparse, s->bytes + e->boff);
+    if (__atomic_add_fetch(&s->done, 1, __ATOMIC_ACQ_REL) == b->seq[e->seq].n_ent) { /* the load is complete */
       pthread_mutex_lock(&b->mu);
-      slab_maybe_ready(b, s);
+      s->ready_for = (uint64_t)e->seq + 1u;
+      pthread_cond_broadcast(&b->cv_ready);
       pthread_mutex_unlock(&b->mu);
     }
   }
+  free(raw);
+  return NULL;
 }
 
 /* ---- the header, read on the caller's thread --------------------------------------------------------------------------- */
@@ -508,19 +580,17 @@ void bsc_bamstream_close(bsc_bamstream *b) {
   if (b->n_threads) {
     pthread_mutex_lock(&b->mu);
     __atomic_store_n(&b->closing, 1, __ATOMIC_RELEASE);
-    pthread_cond_broadcast(&b->cv_free);
     pthread_cond_broadcast(&b->cv_ready);
     pthread_mutex_unlock(&b->mu);
     for (int i = 0; i < b->n_threads; i++) pthread_join(b->th[i], NULL);
   }
   if (b->th) {
     pthread_mutex_destroy(&b->mu);
-    pthread_mutex_destroy(&b->disp_mu);
-    pthread_cond_destroy(&b->cv_free);
     pthread_cond_destroy(&b->cv_ready);
   }
   free(b->th);
-  free(b->job);
+  free(b->ent);
+  free(b->seq);
   if (b->slab)
     for (int i = 0; i < b->n_slabs; i++) {
       free(b->slab[i].sparse);
@@ -550,7 +620,7 @@ int bsc_bamstream_default_threads(void) {
   if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
   if (n <= 0) n = (int)sysconf(_SC_NPROCESSORS_ONLN);
   if (n > 1) n -= 1; /* the caller's thread drives the device */
-  if (n > 32) n = 32;
+  if (n > 64) n = 64;
   return n < 1 ? 1 : n;
 }
 
@@ -658,6 +728,7 @@ int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int
   b->sparse_cap = b->rec_cap + b->blk_cap;
   b->slab = calloc((size_t)n_slabs, sizeof *b->slab);
   if (!b->slab) goto nomem;
+  if (getenv("BSC_BAMSTREAM_UNPINNED")) b->unpinned = 1; /* measurement: ordinary memory */
   for (int i = 0; i < n_slabs; i++) {
     if (!b->unpinned) {
       b->slab[i].bytes = bsc_alloc_host(b->slab_bytes);
@@ -679,12 +750,16 @@ int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int
   }
   b->w_skip = b->first_rec_off;
   b->dbg_nowalk = getenv("BSC_BAMSTREAM_NOWALK") != NULL;
+  {
+    const int rc = build_index(b, n_threads);
+    if (rc) {
+      bsc_bamstream_close(b);
+      return rc;
+    }
+  }
   b->th = calloc((size_t)n_threads, sizeof *b->th);
-  b->job = calloc(JOB_RING, sizeof *b->job);
-  if (!b->th || !b->job) goto nomem;
+  if (!b->th) goto nomem;
   pthread_mutex_init(&b->mu, NULL);
-  pthread_mutex_init(&b->disp_mu, NULL);
-  pthread_cond_init(&b->cv_free, NULL);
   pthread_cond_init(&b->cv_ready, NULL);
   for (int i = 0; i < n_threads; i++) {
     if (pthread_create(&b->th[b->n_threads], NULL, helper, b)) break;
@@ -715,27 +790,27 @@ int bsc_bamstream_threads(const bsc_bamstream *b) { return b ? b->n_threads : 0;
 int bsc_bamstream_next(bsc_bamstream *b, bsc_bam_slab *out) {
   if (!b || !out) return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_next: NULL argument");
   memset(out, 0, sizeof *out);
-  pthread_mutex_lock(&b->mu);
-  bs_slab *s = &b->slab[b->cons_seq % (uint64_t)b->n_slabs];
-  for (;;) {
-    if (s->state == SL_READY) break;
-    if (b->err) {
-      const char *e = b->err;
-      pthread_mutex_unlock(&b->mu);
-      return bsc_set_error(BSC_ERR_ARG, "%s", e);
-    }
-    if (b->eof && !b->fill_open && b->cons_seq >= b->fill_seq) { /* everything has been handed out */
-      pthread_mutex_unlock(&b->mu);
-      return 0;
-    }
-    pthread_cond_wait(&b->cv_ready, &b->mu);
+  if (b->cons_seq >= b->n_seq) {
+    if (b->cons_seq == b->n_seq && !b->dbg_nowalk && (b->w_skip || b->w_hdr_n))
+      return bsc_set_error(BSC_ERR_ARG, "BAM: input truncated (the last record is incomplete)");
+    return 0;
   }
-  s->state = SL_OUT; /* (the helpers are done with it: what follows needs no lock) */
+  const uint64_t q = b->cons_seq;
+  bs_slab *s = &b->slab[q % (uint64_t)b->n_slabs];
+  pthread_mutex_lock(&b->mu);
+  while (s->ready_for != q + 1u && !b->err) pthread_cond_wait(&b->cv_ready, &b->mu);
+  if (s->ready_for != q + 1u) {
+    const char *e = b->err;
+    pthread_mutex_unlock(&b->mu);
+    return bsc_set_error(BSC_ERR_ARG, "%s", e);
+  }
+  s->out = 1;
   pthread_mutex_unlock(&b->mu);
   /* the chain, block by block: a block whose helper assumed the right entry state (nothing hanging over from its predecessor) keeps its
    * finds; any other is walked again from the true state */
+  const struct bs_seq *sq = &b->seq[q];
   s->n_recs = 0;
-  for (uint32_t i = 0; i < s->assigned && !b->dbg_nowalk; i++) {
+  for (uint32_t i = 0; i < sq->n_ent && !b->dbg_nowalk; i++) {
     const struct bs_blk *k = &s->blk[i];
     if (b->w_skip == 0 && b->w_hdr_n == 0 && k->valid) {
       memcpy(s->rec_off + s->n_recs, s->sparse + k->sp_base, (size_t)k->sp_n * 4u);
@@ -749,33 +824,29 @@ int bsc_bamstream_next(bsc_bamstream *b, bsc_bam_slab *out) {
       b->n_rewalked++;
     }
   }
-  if (s->last && (b->w_skip || b->w_hdr_n) && !b->dbg_nowalk) return bsc_set_error(BSC_ERR_ARG, "BAM: input truncated (the last record is incomplete)");
-  pthread_mutex_lock(&b->mu);
+  if (sq->last && (b->w_skip || b->w_hdr_n) && !b->dbg_nowalk) return bsc_set_error(BSC_ERR_ARG, "BAM: input truncated (the last record is incomplete)");
   out->bytes = s->bytes;
-  out->n_bytes = s->n_bytes;
-  out->stream_off = s->stream_off;
+  out->n_bytes = sq->n_bytes;
+  out->stream_off = sq->stream_off;
   out->rec_off = s->rec_off;
   out->n_recs = s->n_recs;
-  out->last = s->last;
-  out->seq = b->cons_seq;
+  out->last = (int32_t)sq->last;
+  out->seq = q;
   b->cons_seq++;
   b->total_recs += s->n_recs;
-  b->total_bytes += s->n_bytes;
-  pthread_mutex_unlock(&b->mu);
+  b->total_bytes += sq->n_bytes;
   return 1;
 }
 
+/* slabs are handed back in the order they were handed out */
 int bsc_bamstream_release(bsc_bamstream *b, const bsc_bam_slab *sl) {
   if (!b || !sl) return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_release: NULL argument");
-  pthread_mutex_lock(&b->mu);
   bs_slab *s = &b->slab[sl->seq % (uint64_t)b->n_slabs];
-  if (s->state != SL_OUT || s->bytes != sl->bytes) {
-    pthread_mutex_unlock(&b->mu);
-    return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_release: not a slab that is out");
-  }
-  s->state = SL_FREE;
-  pthread_cond_broadcast(&b->cv_free);
-  pthread_mutex_unlock(&b->mu);
+  if (!s->out || s->bytes != sl->bytes || sl->seq != __atomic_load_n(&b->n_released, __ATOMIC_RELAXED))
+    return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_release: not the oldest slab that is out");
+  s->out = 0;
+  __atomic_store_n(&s->done, 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&b->n_released, sl->seq + 1u, __ATOMIC_RELEASE);
   return BSC_OK;
 }
 

@@ -157,6 +157,7 @@ struct bsc_context {
                         uploads behind it (bsc_h2d_turn) */
   const void *emit_hint; /* set around the bsc_vcf_compact_device call of bsc_records_queue: the flags of exactly these arrays */
   uint8_t *bcf_out;
+  int stage_timing; /* BSC_STAGE_TIMING in the environment at bsc_create */
   int bcf_blk, bcf_keep; /* the block in flight is a BCF block; its stream stays on the device (bsc_block_bcf_rawdev_keep) */
   uint64_t bcf_cap, bcf_copied, bcf_bytes; /* bcf_bytes: the length of the last block's stream (also when it did not fit) */
   double bcf_share;
@@ -380,6 +381,7 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
   ctx->num_cus = prop.multiProcessorCount;
   ctx->max_launch = BSC_MAX_LAUNCH;
   ctx->rec_share = 0.55; /* WGBS: a record for every C and G and little else */
+  ctx->stage_timing = getenv("BSC_STAGE_TIMING") != NULL;
   {
     const char *ml = getenv("BSC_MAX_LAUNCH_SITES");
     if (ml && *ml) {
@@ -2004,11 +2006,18 @@ int bsc_block_bcf(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const 
  */
 /* the part behind the uploads: raw templates, reads and lists DEVICE-resident (the host entry's own copies, or the device reader's
  * arrays); cap = room for the prepared reads */
+static double bsc_now_s(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_rseq, uint64_t seq_bytes, const void *d_rms,
                                      uint64_t n_misms, uint64_t cap, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref,
                                      const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap,
                                      uint64_t *n_out, bsc_prep_stats *prep_stats, bsc_read_profile *profile, const bsc_bcf_req *bcf) {
   int rc;
+  const int timing = ctx->stage_timing; /* BSC_STAGE_TIMING at bsc_create: where a block's host time goes, to stderr */
+  double t0 = timing ? bsc_now_s() : 0.0, t1;
   if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)nr * sizeof(bsc_template)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)cap))) return rc;
   hipStream_t s = ctx->stream;
@@ -2023,16 +2032,36 @@ static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32
     dp.x = x;
     dp.n_ref = (uint32_t)n_ref;
   }
+  if (timing) {
+    t1 = bsc_now_s();
+    fprintf(stderr, "bsc stage: reserve + reference upload queued %.3f s\n", t1 - t0);
+    t0 = t1;
+  }
   rc = bsc_prepare_templates_device(ctx, d_raw, nr, d_rseq, seq_bytes, d_rms, n_misms, prep, ctx->d_tpl, ctx->d_seq, cap, &used, prep_stats,
                                     profile ? &dp : NULL, s);
   if (profile) profile->used = dp.used;
   if (rc) return rc; /* (it has waited for the stream: nothing reads the caller's buffers any more) */
+  if (timing) {
+    t1 = bsc_now_s();
+    fprintf(stderr, "bsc stage: bsc_prepare_templates_device (waits for the prepared size) %.3f s\n", t1 - t0);
+    t0 = t1;
+  }
   rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 2, bcf);
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream);
     return rc;
   }
-  return bsc_records_finish(ctx, n_out);
+  if (timing) {
+    t1 = bsc_now_s();
+    fprintf(stderr, "bsc stage: bsc_records_queue (reserves, uploads, launches) %.3f s\n", t1 - t0);
+    t0 = t1;
+  }
+  rc = bsc_records_finish(ctx, n_out);
+  if (timing) {
+    t1 = bsc_now_s();
+    fprintf(stderr, "bsc stage: bsc_records_finish (the wait) %.3f s\n", t1 - t0);
+  }
+  return rc;
 }
 
 static int bsc_block_records_raw_(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes,
