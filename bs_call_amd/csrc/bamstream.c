@@ -614,12 +614,38 @@ void bsc_bamstream_close(bsc_bamstream *b) {
   free(b);
 }
 
-int bsc_bamstream_default_threads(void) {
+/* the CPUs this process may really use: its affinity mask, cut down to the container's CFS quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us) —
+ * a GPU box shows every core of the host and gives a job a share of them; helpers beyond the share only get the caller's thread throttled
+ * (measured: 16 helpers 5.5 GB/s of inflated bytes, 32 .. 128 the same, the block call behind them 2.6 x slower) */
+static int cpu_share(void) {
   cpu_set_t set;
   int n = 0;
   if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
   if (n <= 0) n = (int)sysconf(_SC_NPROCESSORS_ONLN);
-  if (n > 1) n -= 1; /* the caller's thread drives the device */
+  long long quota = -1, period = -1;
+  FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f) {
+    char q[64];
+    if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max")) quota = atoll(q);
+    fclose(f);
+  } else {
+    FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+    if (fq && fp && fscanf(fq, "%lld", &quota) == 1 && fscanf(fp, "%lld", &period) == 1) {
+    } else
+      quota = -1;
+    if (fq) fclose(fq);
+    if (fp) fclose(fp);
+  }
+  if (quota > 0 && period > 0) {
+    const int share = (int)((quota + period - 1) / period);
+    if (share >= 1 && share < n) n = share;
+  }
+  return n < 1 ? 1 : n;
+}
+
+int bsc_bamstream_default_threads(void) {
+  int n = cpu_share();
+  if (n > 2) n -= 1; /* the caller's thread drives the device */
   if (n > 64) n = 64;
   return n < 1 ? 1 : n;
 }
@@ -629,10 +655,10 @@ int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int
   *out = NULL;
   if (n_threads <= 0) n_threads = bsc_bamstream_default_threads();
   if (n_threads > 128) n_threads = 128;
-  if (slab_bytes == 0) slab_bytes = 32u << 20;
+  if (slab_bytes == 0) slab_bytes = 16u << 20; /* (page-locking costs ~1 ms per MB: the ring is 6 x 16 MiB, not more) */
   if (slab_bytes < 65536u) slab_bytes = 65536u;
   if (slab_bytes > (1ull << 31)) slab_bytes = 1ull << 31;
-  if (n_slabs <= 0) n_slabs = 8;
+  if (n_slabs <= 0) n_slabs = 6;
   if (n_slabs < 2) n_slabs = 2;
   bsc_bamstream *b = calloc(1, sizeof *b);
   if (!b) return bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");

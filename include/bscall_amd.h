@@ -783,7 +783,7 @@ uint64_t bsc_bam_malformed(const bsc_bam *b);
  *   bsc_bamstream_*        the host half, usable on its own: the file as a stream of INFLATED bytes in page-locked slabs, with the offset
  *                          of every alignment record (hts_open + bgzf_read's inflate + the block_size chain of bam_read1).  n_threads
  *                          helpers (<= 0: one per core this process may run on, at most 64) inflate straight into the slabs;
- *                          slab_bytes / n_slabs 0 = 32 MiB x 8.  bsc_bamstream_next: 1 = *out filled (valid until it is released),
+ *                          slab_bytes / n_slabs 0 = 16 MiB x 6.  bsc_bamstream_next: 1 = *out filled (valid until it is released),
  *                          0 = end of the stream, < 0 = error.  BAM only.
  *   bsc_bamdev_open        a reader over `path` bound to ctx's device and stream
  *   bsc_bamdev_next_block  1 = *blk describes the next block, its templates / reads / lists DEVICE-resident (valid until the next call)

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <bscall_amd.h>
 
@@ -66,35 +67,88 @@ static void *pinned(size_t n) { /* page-locked: the copy-out is a true DMA, queu
   return p;
 }
 
-/* The output thread (bcf_write's write): a block's stream is read from the device in pieces into two page-locked buffers, and while the
- * device fills one, this thread writes the other.  A contig-sized block's stream is gigabytes: page-locking a host buffer for all of it
- * costs more than the calling. */
-#define PIECE ((size_t)64 << 20)
+/* The output threads (bcf_write's write): a block's stream is read from the device in pieces into page-locked buffers, and while the device
+ * fills one, these threads write the others — each piece at its own offset of the file (pwrite), so that several cores fill the page cache
+ * (one thread: 10 GB/s; a contig-sized block's stream is 2.9 GB).  Page-locking a host buffer for a whole stream would cost more than the
+ * calling. */
+#define PIECE ((size_t)32 << 20)
+#define N_PIECE 4
+#define N_WRITER 3
 typedef struct {
-  FILE *f;
-  uint8_t *buf[2];
-  size_t n[2];
-  int full[2], quit;
+  int fd;
+  uint8_t *buf[N_PIECE];
+  size_t n[N_PIECE];
+  uint64_t at[N_PIECE];
+  int full[N_PIECE], busy[N_PIECE], quit, failed;
   pthread_mutex_t mu;
   pthread_cond_t cv;
-  pthread_t th;
+  pthread_t th[N_WRITER];
 } out_writer;
 static void *writer_main(void *a) {
   out_writer *w = a;
-  int i = 0;
   pthread_mutex_lock(&w->mu);
   for (;;) {
-    while (!w->full[i] && !w->quit) pthread_cond_wait(&w->cv, &w->mu);
-    if (!w->full[i]) break;
+    int i = -1;
+    for (int k = 0; k < N_PIECE; k++)
+      if (w->full[k] && !w->busy[k]) {
+        i = k;
+        break;
+      }
+    if (i < 0) {
+      if (w->quit) break;
+      pthread_cond_wait(&w->cv, &w->mu);
+      continue;
+    }
+    w->busy[i] = 1;
     pthread_mutex_unlock(&w->mu);
-    fwrite(w->buf[i], 1, w->n[i], w->f);
+    size_t done = 0;
+    while (done < w->n[i]) {
+      const ssize_t r = pwrite(w->fd, w->buf[i] + done, w->n[i] - done, (off_t)(w->at[i] + done));
+      if (r <= 0) break;
+      done += (size_t)r;
+    }
     pthread_mutex_lock(&w->mu);
-    w->full[i] = 0;
+    if (done < w->n[i]) w->failed = 1;
+    w->full[i] = w->busy[i] = 0;
     pthread_cond_broadcast(&w->cv);
-    i ^= 1;
   }
   pthread_mutex_unlock(&w->mu);
   return NULL;
+}
+
+/* The next contig's reference in the background (load_sequence + the GC bins): a thread of its own reads the FASTA while the reader's helpers
+ * inflate.  One request in flight. */
+typedef struct {
+  const char *fasta, *name;
+  uint64_t want;
+  uint8_t *codes, *gc;
+  uint64_t codes_len, n_bins;
+  uint32_t gc_start;
+  int rc, tid;
+  char err[256];
+  pthread_t th;
+  int running;
+} ref_job;
+static void *ref_main(void *a) {
+  ref_job *j = a;
+  j->codes = malloc(j->want ? j->want : 1);
+  j->gc = NULL;
+  j->rc = j->codes ? bsc_fasta_contig(j->fasta, j->name, j->codes, j->want, &j->codes_len) : -1;
+  if (j->rc >= 0) {
+    j->gc = malloc((size_t)(j->codes_len / 100 + 1));
+    j->rc = j->gc ? bsc_gc_bins(j->codes, j->codes_len, &j->gc_start, j->gc, j->codes_len / 100 + 1, &j->n_bins) : -1;
+  }
+  if (j->rc < 0) snprintf(j->err, sizeof j->err, "%s", bsc_last_error());
+  return NULL;
+}
+static void ref_start(ref_job *j, const char *fasta, const char *name, uint64_t len, int tid) {
+  memset(j, 0, sizeof *j);
+  j->fasta = fasta;
+  j->name = name;
+  j->want = len;
+  j->tid = tid;
+  j->running = pthread_create(&j->th, NULL, ref_main, j) == 0;
+  if (!j->running) ref_main(j);
 }
 
 /* the header print_vcf_header assembles in --benchmark-mode (src/print_vcf.c:621-745) */
@@ -207,7 +261,19 @@ int main(int argc, char **argv) {
   bsc_read_block blk;
   bsc_dev_read_block dblk;
   static out_writer W;
+  static ref_job RJ;
   int wi = 0;
+  uint64_t file_at = 0;
+  if (n_ref > 0) ref_start(&RJ, argv[2], REF_NAME(0), REF_LEN(0), 0); /* the first contig's reference: while the helpers inflate */
+  if (!host_reader) { /* the output pieces too: page-locking them takes its time */
+    fflush(out);
+    file_at = (uint64_t)ftello(out);
+    W.fd = fileno(out);
+    for (int k = 0; k < N_PIECE; k++) W.buf[k] = pinned(PIECE);
+    pthread_mutex_init(&W.mu, NULL);
+    pthread_cond_init(&W.cv, NULL);
+    for (int k = 0; k < N_WRITER; k++) pthread_create(&W.th[k], NULL, writer_main, &W);
+  }
   int r;
   double t_read = 0, t_ref = 0, t_prep = 0, t_gpu = 0, t_enc = 0, t0 = now(), t1;
   for (;;) {
@@ -230,15 +296,29 @@ int main(int argc, char **argv) {
       }
       cur_tid = blk.tid;
       ctot[cur_tid].name = REF_NAME(cur_tid);
-      const uint64_t want = REF_LEN(cur_tid);
-      codes = xrealloc(codes, want);
-      CHECK(bsc_fasta_contig(argv[2], REF_NAME(cur_tid), codes, want, &codes_len));
-      /* its GC bins, for the report's GC-by-coverage table (load_sequence computes them when a report is asked for) */
-      uint32_t gc_start = 0;
-      uint64_t n_bins = 0;
-      gc = xrealloc(gc, (size_t)(codes_len / 100 + 1));
-      CHECK(bsc_gc_bins(codes, codes_len, &gc_start, gc, codes_len / 100 + 1, &n_bins));
-      CHECK(bsc_set_gc_bins_host(ctx, gc, (uint32_t)n_bins, gc_start));
+      /* its sequence and GC bins (for the report's GC-by-coverage table: load_sequence computes them when a report is asked for): loaded in
+       * the background since the previous contig began — or since the program did */
+      if (!RJ.running || RJ.tid != cur_tid) {
+        if (RJ.running) {
+          pthread_join(RJ.th, NULL);
+          free(RJ.codes);
+          free(RJ.gc);
+        }
+        ref_start(&RJ, argv[2], REF_NAME(cur_tid), REF_LEN(cur_tid), cur_tid);
+      }
+      if (RJ.running) pthread_join(RJ.th, NULL);
+      RJ.running = 0;
+      if (RJ.rc < 0) {
+        fprintf(stderr, "reference of %s: %s\n", REF_NAME(cur_tid), RJ.err);
+        return 1;
+      }
+      free(codes);
+      free(gc);
+      codes = RJ.codes;
+      gc = RJ.gc;
+      codes_len = RJ.codes_len;
+      CHECK(bsc_set_gc_bins_host(ctx, gc, (uint32_t)RJ.n_bins, RJ.gc_start));
+      if (cur_tid + 1 < n_ref) ref_start(&RJ, argv[2], REF_NAME(cur_tid + 1), REF_LEN(cur_tid + 1), cur_tid + 1); /* the next one, meanwhile */
     }
     const uint32_t x = host_reader ? bsc_block_start(&blk.tpl[0]) : dblk.x, y = blk.y, n = y - x + 1;
     if (n + 2 > cap_ref) ref = xrealloc(ref, cap_ref = (size_t)(n + 2) * 2);
@@ -264,14 +344,6 @@ int main(int argc, char **argv) {
       CHECK(rc);
       t_gpu += (t1 = now()) - t0;
       t0 = t1;
-      if (!W.buf[0]) {
-        W.f = out;
-        W.buf[0] = pinned(PIECE);
-        W.buf[1] = pinned(PIECE);
-        pthread_mutex_init(&W.mu, NULL);
-        pthread_cond_init(&W.cv, NULL);
-        pthread_create(&W.th, NULL, writer_main, &W);
-      }
       for (uint64_t off = 0; off < n_bytes; off += PIECE) {
         const size_t take = n_bytes - off < PIECE ? (size_t)(n_bytes - off) : PIECE;
         pthread_mutex_lock(&W.mu);
@@ -281,11 +353,13 @@ int main(int argc, char **argv) {
         CHECK(bsc_synchronize(ctx));
         pthread_mutex_lock(&W.mu);
         W.n[wi] = take;
+        W.at[wi] = file_at + off;
         W.full[wi] = 1;
         pthread_cond_broadcast(&W.cv);
         pthread_mutex_unlock(&W.mu);
-        wi ^= 1;
+        wi = (wi + 1) % N_PIECE;
       }
+      file_at += n_bytes;
       n_bytes = 0; /* written by the output thread */
     } else if (!host_bcf) { /* the whole block on the device, the encoding included.  Room for 96 bytes per position: a WGBS block writes a
                       * record of ~113 bytes for every second position; a block that needs more says so and is run again */
@@ -354,12 +428,16 @@ int main(int argc, char **argv) {
     t0 = t1;
   }
   CHECK(r);
-  if (W.buf[0]) { /* the output thread writes what it still holds, then goes */
+  if (W.buf[0]) { /* the output threads write what they still hold, then go */
     pthread_mutex_lock(&W.mu);
     W.quit = 1;
     pthread_cond_broadcast(&W.cv);
     pthread_mutex_unlock(&W.mu);
-    pthread_join(W.th, NULL);
+    for (int k = 0; k < N_WRITER; k++) pthread_join(W.th[k], NULL);
+    if (W.failed) {
+      fprintf(stderr, "writing %s failed\n", argv[3]);
+      return 1;
+    }
     t_enc += (t1 = now()) - t0;
     t0 = t1;
   }
@@ -428,6 +506,11 @@ int main(int argc, char **argv) {
             host_prep ? "bsc_block_records" : (host_bcf ? "bsc_block_records_raw" : (host_reader ? "bsc_block_bcf_raw" : "bsc_block_bcf_rawdev")), t_gpu, t_enc,
             now() - t_loop_end, now() - t_start, now() - t_start - t_ctx, (unsigned long long)rc4[0], (unsigned long long)rc4[1], (unsigned long long)rc4[2],
             (unsigned long long)rc4[3], rs[0], rs[1]);
+  }
+  if (RJ.running) { /* a contig prefetched and never reached */
+    pthread_join(RJ.th, NULL);
+    free(RJ.codes);
+    free(RJ.gc);
   }
   if (bam) bsc_bam_close(bam);
   if (dev) bsc_bamdev_close(dev);
