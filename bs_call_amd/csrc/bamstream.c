@@ -644,8 +644,7 @@ static int cpu_share(void) {
 }
 
 int bsc_bamstream_default_threads(void) {
-  int n = cpu_share();
-  if (n > 2) n -= 1; /* the caller's thread drives the device */
+  int n = cpu_share(); /* all of it: the caller's thread sleeps while the helpers inflate, and drives the device when they are done */
   if (n > 64) n = 64;
   return n < 1 ? 1 : n;
 }
