@@ -383,6 +383,8 @@ def reads_rooflines(args, caller):
     keep = (m - 400) if args.sites > m else n
     sample = {"x": x, "m": m, "chunk": chunk, "keep": keep, "pile": d_pile[: keep * 104].cpu().numpy(), "core": d_core[: (keep - 8) * 64].cpu().numpy()}
     bcf_leg = bcf_roofline(caller, d_tpl, len(tpl), d_seq, seq.size, x, y, d_ref, d_core, n, reps, stream)
+    del d_pile
+    raw_legs = raw_rooflines(args, caller, tpl, seq, d_seq, x, y, ref, reps)
     bytes_in = R.algorithmic_bytes_in(tpl, seq)
     a_ms, r_ms = float(np.mean(acc_ms)), float(np.mean(rc_ms))
     a_bytes, r_bytes = bytes_in + n * 104, bytes_in + n + n * 64
@@ -434,8 +436,177 @@ def reads_rooflines(args, caller):
             "the next (round 4: 88 bytes, 2.96 x)",
         },
         "roofline_bcf": bcf_leg,
+        "roofline_prep": raw_legs["roofline_prep"],
+        "raw_to_bcf": raw_legs["raw_to_bcf"],
         "_reads_sample": sample,
     }
+
+
+def _committed(name, key, sources):
+    """a per-launch figure of profiles/<name>.json[key], valid while the kernel sources it was measured on are unchanged"""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            v = json.load(f).get(key)
+        if not v or v.get("kernel_source_sha256_16") != kernel_source_hash(sources):
+            return None
+        return v
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def raw_rooflines(args, caller, tpl, seq, d_seq, x, y, ref, reps):
+    """Round 5's device stages in the driver-run line (VERDICT r05, row d).
+    roofline_prep: device-resident RAW L-reads of the benchmarked contig (the span is the length; every 50th read 0 carries a 2-base deletion
+    and a 1-base insertion, so that the list logic and the padded copy run) -> prepared reads (bsc_prepare_templates_device, csrc/prepdev.hip:
+    process_template_vector, reference src/process_template.c:36-111), without and with the read profile (meth_profile, src/meth_profile.c:48-77
+    — the form the pipeline runs).  raw_to_bcf: the same block from raw templates resident in HBM to its BCF stream resident in HBM
+    (bsc_block_bcf_rawdev_keep: pre-processing + read profile + grouping + walk + chain + encoder between two events on the library's stream)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    import bs_call_amd as B
+    from bs_call_amd import _lib, vcf
+    from bs_call_amd.abi import MISMS, PREP_PARAMS, PREP_STATS, RAW_TEMPLATE, TEMPLATE
+    from bs_call_amd.caller import ReadProfile, _ptr
+
+    dev = d_seq.device
+    stream = torch.cuda.current_stream().cuda_stream
+    raw = np.zeros(len(tpl), dtype=RAW_TEMPLATE)
+    for f in ("pos", "len", "off", "mapq", "orientation", "bs_strand"):
+        raw[f] = tpl[f]
+    raw["reference_span"] = tpl["len"]
+    sel = np.nonzero((np.arange(len(raw)) % 50 == 0) & (raw["len"][:, 0] >= 60))[0]
+    ms = np.zeros(2 * len(sel), dtype=MISMS)
+    ms["type"][0::2], ms["position"][0::2], ms["size"][0::2] = 1, 20, 2
+    ms["type"][1::2], ms["position"][1::2], ms["size"][1::2] = 2, 40, 1
+    raw["n_misms"][sel, 0] = 2
+    raw["misms_off"][sel, 0] = 2 * np.arange(len(sel))
+    raw["reference_span"][sel, 0] += 1
+    y_raw = int(y) + 1  # a read with the deletion reaches one position further
+    par = np.zeros(1, dtype=PREP_PARAMS)
+    par["min_qual"] = args.min_qual if hasattr(args, "min_qual") else 20
+    ins_pad = 2 * len(sel)
+    cap = int(seq.size) + ins_pad + 16
+    up = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1)).to(dev)
+    d_raw, d_ms = up(raw), up(ms)
+    d_tpl = torch.empty(len(raw) * TEMPLATE.itemsize, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    ref_raw = B.synth_ref_host(SEED + 2, x, y_raw - x + 3)
+    d_ref = up(ref_raw)
+    used, st = C.c_uint64(0), np.zeros(1, dtype=PREP_STATS)
+    L = caller._L
+    alg = int(seq.size) + len(raw) * 72 + len(ms) * 12 + len(raw) * 40  # + the prepared bytes, added below
+    legs = {}
+    for with_profile in (False, True):
+        prof = ReadProfile(cap=4096)
+        pf = _lib.ReadProfile(d_ref.data_ptr(), x, y_raw - x + 3, prof.counts.ctypes.data, prof.counts.shape[0], 0) if with_profile else None
+
+        def call():
+            if pf is not None:
+                pf.used = 0
+            rc = L.bsc_prepare_templates_device(caller._h, d_raw.data_ptr(), len(raw), d_seq.data_ptr(), seq.size, d_ms.data_ptr(), len(ms), _ptr(par),
+                                                d_tpl.data_ptr(), d_out.data_ptr(), cap, C.byref(used), _ptr(st), None if pf is None else C.byref(pf), stream)
+            assert rc == 0, L.bsc_last_error()
+
+        for _ in range(2):
+            call()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps)]
+        for k in range(reps):
+            ev[2 * k].record()
+            call()  # (it waits for the prepared size itself)
+            ev[2 * k + 1].record()
+        torch.cuda.synchronize()
+        msv = [ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(reps)]
+        k_ms = float(np.mean(msv))
+        a = alg + int(used.value)
+        key = "with_read_profile" if with_profile else "plain"
+        prof_v = _committed("traffic.json", "prep_profile" if with_profile else "prep", ("prepdev.hip",))
+        valu_v = _committed("valu.json", "prep_profile" if with_profile else "prep", ("prepdev.hip",))
+        legs[key] = {
+            "stage_ms_avg": k_ms, "stage_ms_min": float(np.min(msv)), "algorithmic_bytes_per_launch": a, "achieved": a / (k_ms * 1e-3) / 1e9,
+            "frac": a / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bases_per_s": seq.size / (k_ms * 1e-3), "positions_per_s": args.sites / (k_ms * 1e-3),
+            "traffic": None if prof_v is None else int(prof_v["hbm_bytes_per_launch"] * (args.sites / prof_v["sites"])),
+            "valu_instructions_per_launch": None if valu_v is None else int(valu_v["valu_insts_per_launch"] * (args.sites / valu_v["sites"])),
+        }
+        if not with_profile:  # the first templates against the host form (csrc/prep.c)
+            from bs_call_amd.caller import prepare_templates
+
+            m = min(100_000, len(raw))
+            h_tpl, h_seq, _ = prepare_templates(raw[:m], seq, ms)
+            legs[key]["first_templates_equal_host_form"] = bool(d_tpl[: m * 40].cpu().numpy().tobytes() == h_tpl.tobytes()
+                                                                 and d_out[: int(h_seq.size)].cpu().numpy().tobytes() == h_seq.tobytes())
+    head = legs["with_read_profile"]
+    prep_leg = {
+        "bound": "valu_issue",
+        "kernel": "bsc_prep_plan_kernel + rocPRIM prefix sum + bsc_prep_copy_kernel<profile> (+ the profile's max-scan) (bsc_prepare_templates_device)",
+        "what": "raw templates + reads + mismatch lists resident in HBM -> prepared templates + reads (trims, soft clips, mate overlap, indel normalisation; the "
+        "base counters; with the read profile as the pipeline runs it): %d templates, %d bases, %d list entries" % (len(raw), seq.size, len(ms)),
+        "achieved": head["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": head["frac"], "traffic": head["traffic"],
+        "stage_ms_avg": head["stage_ms_avg"], "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
+        "algorithmic_bytes_per_position": head["algorithmic_bytes_per_launch"] / args.sites,
+        "with_read_profile": legs["with_read_profile"], "plain": legs["plain"],
+        "note": "torch events of the stream the launches are queued on; each call waits once for the prepared size (one host round trip inside the "
+        "timed region).  The headline is the form with the read profile: what pipeline.run / bam2bcf run",
+    }
+    # ---- raw templates resident -> BCF stream resident ----
+    caller.set_profiling(True)
+    prof = ReadProfile(cap=4096)
+    ids = _lib.BcfIds()
+    L.bsc_bcf_default_ids(C.byref(ids))
+    n = y_raw - x + 1
+    dev_cap = n * 96 + 4096
+    vp = _lib.VcfParams(0, 1, 0xFFFFFFFF)
+    ref_pin = L.bsc_alloc_host(len(ref_raw))  # page-locked: the block's reference codes cross PCIe inside the timed region (1 B per position)
+    C.memmove(ref_pin, ref_raw.ctypes.data, len(ref_raw))
+    nb, nr_ = C.c_uint64(0), C.c_uint64(0)
+    st2 = np.zeros(1, dtype=PREP_STATS)
+    msv, wall = [], []
+    for it in range(2 + reps):
+        pf = _lib.ReadProfile(None, 0, 0, prof.counts.ctypes.data, prof.counts.shape[0], 0)
+        t0 = time.perf_counter()
+        rc = L.bsc_block_bcf_rawdev_keep(caller._h, d_raw.data_ptr(), len(raw), d_seq.data_ptr(), seq.size, d_ms.data_ptr(), len(ms), ins_pad, _ptr(par), x, y_raw,
+                                         ref_pin, None, C.byref(vp), 1 if it == 0 else 0, 0, C.byref(ids), None, dev_cap, C.byref(nb), C.byref(nr_), _ptr(st2),
+                                         C.byref(pf))
+        assert rc >= 0, L.bsc_last_error()
+        dt = time.perf_counter() - t0
+        f = C.c_float(0)
+        assert L.bsc_last_raw_block_ms(caller._h, C.byref(f)) == 0, L.bsc_last_error()
+        if it >= 2:
+            msv.append(f.value)
+            wall.append(dt)
+    caller.set_profiling(False)
+    # the first records: the stream's head against the host encoder over the packed records of the same block
+    head_bytes = min(int(nb.value), 4 << 20)
+    got = np.empty(head_bytes, dtype=np.uint8)
+    assert L.bsc_bcf_stream_read(caller._h, 0, head_bytes, got.ctypes.data) == 0 and L.bsc_synchronize(caller._h) == 0
+    # ... of a sub-block made of the first templates: its records left of where the next template starts are the big block's
+    K = min(40_000, len(raw))
+    p_safe = (int(raw["pos"][K, 0] or raw["pos"][K, 1]) - 10) if K < len(raw) else 1 << 62
+    sub = raw[:K]
+    seq_end = int((sub["off"].astype(np.int64) + sub["len"]).max())
+    n_ms_sub = 2 * int((sel < K).sum())
+    y_sub = int((sub["pos"].astype(np.int64) + sub["reference_span"]).max())
+    recs, _st = caller.block_records_raw(sub, seq[:seq_end], ms[:n_ms_sub], x, y_sub, ref_raw[: y_sub - x + 3], min_qual=int(par["min_qual"][0]), with_stats=False)
+    recs = recs[recs["core"]["pos"] <= p_safe]
+    want = vcf.bcf_block(recs, 0)
+    L.bsc_free_host(ref_pin)
+    k_ms = float(np.mean(msv))
+    raw_leg = {
+        "what": "one block, raw templates + reads + lists resident in HBM -> its BCF stream resident in HBM: pre-processing with the read profile, grouping, "
+        "walk, chain with statistics' kernels, the encoder over the chain's per-position arrays (bsc_block_bcf_rawdev_keep): what the device reader's blocks go "
+        "through; %d positions, %d templates" % (n, len(raw)),
+        "device_ms_avg": k_ms, "device_ms_min": float(np.min(msv)), "call_wall_ms_median": float(np.median(wall)) * 1e3,
+        "positions_per_s": n / (k_ms * 1e-3), "positions_per_s_call_wall": n / float(np.median(wall)),
+        "bcf_bytes": int(nb.value), "records": int(nr_.value), "bytes_out_per_position": int(nb.value) / n,
+        "first_records_equal_host_encoder": bool(0 < len(want) <= head_bytes and got[: len(want)].tobytes() == want),
+        "first_records_compared": int(len(recs)),
+        "note": "HIP events on the library's own stream, first pre-processing launch to the encoder's last (bsc_last_raw_block_ms); inside: two host waits "
+        "(the prepared size, the verdict), the upload of the block's reference codes (1 B per position, page-locked) and the read profile's counts coming back",
+    }
+    return {"roofline_prep": prep_leg, "raw_to_bcf": raw_leg}
 
 
 def bcf_traffic(n_rec):
@@ -517,24 +688,35 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
     same = nbytes <= cap and refused == 0 and d_bcf[: len(want)].cpu().numpy().tobytes() == want
     k_ms = float(np.mean(ms))
     alg = n_rec * 128 * 2 + nbytes  # both kernels read the records, the stream is written once
+    sites_v = _committed("traffic.json", "bcf_sites", ("bcfdev.hip",))
     return {
         "bound": "hbm",
-        "kernel": "bsc_bcf_size_kernel + rocPRIM prefix sum + bsc_bcf_write_kernel (bsc_bcf_block_device)",
-        "what": "packed written records (128 B) -> BCF2 records (typed values of src/print_vcf.c:160-222,267-378 behind bcf_write's fixed fields), "
-        "%d records of the reads leg's block, resident in HBM" % n_rec,
-        "achieved": alg / (k_ms * 1e-3) / 1e9,
+        "kernel": "bsc_bcf_size_kernel + rocPRIM prefix sum + bsc_bcf_write_kernel over the chain's per-position arrays (bsc_bcf_sites_device: the form "
+        "bsc_block_bcf[_raw[dev]] runs; no packing pass)",
+        "what": "the reads-in chain's per-position arrays (64-byte record + 64-byte aux per position) -> BCF2 records (typed values of "
+        "src/print_vcf.c:160-222,267-378 behind bcf_write's fixed fields): %d positions, %d written records, resident in HBM" % (n, n_rec),
+        "achieved": sites_alg / (sites_ms * 1e-3) / 1e9,
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
-        "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-        "traffic": bcf_traffic(n_rec),
-        "algorithmic_bytes_per_launch": alg,
+        "frac": sites_alg / (sites_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "traffic": None if sites_v is None else int(sites_v["hbm_bytes_per_position"] * n),
+        "algorithmic_bytes_per_launch": sites_alg,
         "bcf_bytes": nbytes,
         "bytes_per_record": nbytes / max(n_rec, 1),
-        "stage_ms_avg": k_ms,
-        "stage_ms_min": float(np.min(ms)),
-        "records_per_s": n_rec / (k_ms * 1e-3),
-        "positions_per_s": n / (k_ms * 1e-3),
-        "first_records_equal_host_encoder": bool(same),
+        "stage_ms_avg": sites_ms,
+        "records_per_s": n_rec / (sites_ms * 1e-3),
+        "positions_per_s": n / (sites_ms * 1e-3),
+        "first_records_equal_host_encoder": bool(same and sites_same),
+        "packed_form": {
+            "kernel": "the same two kernels over packed written records (bsc_bcf_block_device, behind bsc_vcf_compact_device): round 5's headline",
+            "stage_ms_avg": k_ms,
+            "stage_ms_min": float(np.min(ms)),
+            "algorithmic_bytes_per_launch": alg,
+            "achieved": alg / (k_ms * 1e-3) / 1e9,
+            "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "traffic": bcf_traffic(n_rec),
+            "records_per_s": n_rec / (k_ms * 1e-3),
+        },
         "sites_form": {
             "kernel": "the same two kernels over the chain's per-position arrays (bsc_bcf_sites_device: what bsc_block_bcf runs), no packing pass",
             "stage_ms_avg": sites_ms,

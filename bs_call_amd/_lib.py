@@ -133,6 +133,7 @@ EXPORTS = (
     "bsc_block_bcf_rawdev",
     "bsc_block_bcf_rawdev_keep",
     "bsc_bcf_stream_read",
+    "bsc_last_raw_block_ms",
 )
 
 
@@ -543,6 +544,8 @@ def load():
     L.bsc_block_bcf_rawdev_keep.restype = i32
     L.bsc_block_bcf_rawdev_keep.argtypes = [vp, vp, u32, vp, u64, vp, u64, u64, vp, u32, u32, vp, vp, vp, i32, i32, C.POINTER(BcfIds), vp, u64,
                                             C.POINTER(u64), C.POINTER(u64), vp, vp]
+    L.bsc_last_raw_block_ms.restype = i32
+    L.bsc_last_raw_block_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsc_bcf_stream_read.restype = i32
     L.bsc_bcf_stream_read.argtypes = [vp, u64, u64, vp]
     _lib = L

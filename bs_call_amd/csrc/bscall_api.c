@@ -181,6 +181,9 @@ struct bsc_context {
   size_t cap_fscr;
   hipEvent_t ev_rchain[2]; /* bsc_set_profiling: the reads-in chain's launches (read descriptors, ordering, tile search, chain) */
   int ev_rchain_valid;
+  hipEvent_t ev_raw[2]; /* bsc_set_profiling: a raw block's launches, pre-processing to encoder (bsc_block_*_rawdev*) */
+  int ev_raw_valid;
+  int ref_resident; /* the block's reference codes are in d_ref already (the read profile's upload): the chain's own upload is skipped */
   hipEvent_t ev_acc[2]; /* bsc_set_profiling: the accumulate stage's launches (prep, ordering, tile search, accumulate) */
   int ev_acc_valid;
   /* host-buffer pipeline of bsc_call_sites: two chunk buffers, copy streams, events */
@@ -475,6 +478,8 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_bcf);
   hipFree(ctx->d_btot);
   hipFree(ctx->d_emit);
+  for (int i = 0; i < 2; i++)
+    if (ctx->ev_raw[i]) hipEventDestroy(ctx->ev_raw[i]);
   bsc_h2d_turn_forget(ctx);
   hipFree(ctx->d_mblk);
   hipFree(ctx->d_mtab);
@@ -1464,6 +1469,18 @@ int bsc_last_reads_chain_ms(bsc_context *ctx, float *ms) {
   return BSC_OK;
 }
 
+/* with bsc_set_profiling: device time of the most recent raw block (bsc_block_records_raw[dev], bsc_block_bcf_raw[dev][_keep]) from the first
+ * pre-processing launch to the last launch the call queued — pre-processing, grouping, walk, chain, packing or encoder — the host's wait for
+ * the prepared size in between included */
+int bsc_last_raw_block_ms(bsc_context *ctx, float *ms) {
+  if (!ctx || !ms) return bsc_fail(BSC_ERR_ARG, "bsc_last_raw_block_ms: NULL argument");
+  if (!ctx->profiling || !ctx->ev_raw_valid) return bsc_fail(BSC_ERR_ARG, "bsc_last_raw_block_ms: no profiled raw block yet");
+  BSC_ENTER(ctx);
+  HIP_TRY(hipEventSynchronize(ctx->ev_raw[1]));
+  HIP_TRY(hipEventElapsedTime(ms, ctx->ev_raw[0], ctx->ev_raw[1]));
+  return BSC_OK;
+}
+
 uint32_t bsc_chain_window_quantum(const bsc_context *ctx) { return ctx ? bsc_dev_chain_quantum(ctx->num_cus) : 0u; }
 uint32_t bsc_chain_window_size(const bsc_context *ctx, uint32_t limit) { return ctx ? bsc_dev_chain_window(ctx->num_cus, limit) : 0u; }
 
@@ -1857,7 +1874,7 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
     HIP_TRY(hipMemcpyAsync(ctx->d_tpl, tpl, (size_t)nr * sizeof(bsc_template), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ctx->d_seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
   }
-  HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz + 2, hipMemcpyHostToDevice, s));
+  if (!(resident && ctx->ref_resident)) HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz + 2, hipMemcpyHostToDevice, s));
   if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, dbsnp, (size_t)sz, hipMemcpyHostToDevice, s));
   if (turns) bsc_h2d_turn_end(ctx, s);
   void *d_db = dbsnp ? ctx->d_vdb : NULL;
@@ -2023,14 +2040,22 @@ static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32
   hipStream_t s = ctx->stream;
   uint64_t used = 0;
   bsc_read_profile dp;
-  if (profile) { /* the block's reference codes (x .. y + 2) are what the profile reads: up they go first */
+  ctx->ref_resident = 0;
+  if (profile) { /* the block's reference codes (x .. y + 2) are what the profile reads: up they go first, once */
     const uint64_t n_ref = (uint64_t)y - x + 3;
     if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)n_ref))) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)n_ref, hipMemcpyHostToDevice, s));
+    ctx->ref_resident = 1;
     dp = *profile;
     dp.ref = ctx->d_ref;
     dp.x = x;
     dp.n_ref = (uint32_t)n_ref;
+  }
+  if (ctx->profiling) { /* the device time of everything from the pre-processing to the encoder (bsc_last_raw_block_ms) */
+    if (!ctx->ev_raw[0])
+      for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&ctx->ev_raw[i]));
+    HIP_TRY(hipEventRecord(ctx->ev_raw[0], s));
+    ctx->ev_raw_valid = 0;
   }
   if (timing) {
     t1 = bsc_now_s();
@@ -2047,10 +2072,12 @@ static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32
     t0 = t1;
   }
   rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 2, bcf);
+  ctx->ref_resident = 0;
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream);
     return rc;
   }
+  if (ctx->profiling && hipEventRecord(ctx->ev_raw[1], s) == hipSuccess) ctx->ev_raw_valid = 1; /* (behind the encoder and the copy-out it queued) */
   if (timing) {
     t1 = bsc_now_s();
     fprintf(stderr, "bsc stage: bsc_records_queue (reserves, uploads, launches) %.3f s\n", t1 - t0);

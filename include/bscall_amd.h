@@ -860,6 +860,9 @@ int bsc_block_bcf_rawdev_keep(bsc_context *ctx, const void *d_raw, uint32_t nr, 
                               const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint64_t dev_cap,
                               uint64_t *n_bytes, uint64_t *n_records, bsc_prep_stats *prep_stats, bsc_read_profile *profile);
 int bsc_bcf_stream_read(bsc_context *ctx, uint64_t off, uint64_t n, void *dst);
+/* with bsc_set_profiling: device time (HIP events on the context's stream) of the most recent raw block — bsc_block_records_raw[dev],
+ * bsc_block_bcf_raw[dev][_keep] — from its first pre-processing launch to the last launch it queued, the host's wait for the prepared size included */
+int bsc_last_raw_block_ms(bsc_context *ctx, float *ms);
 
 /*
  * dbSNP index (host C + zlib; csrc/dbsnp.c): the reader of the compressed index bin/dbSNP_idx writes.  In the reference
