@@ -579,7 +579,7 @@ def raw_rooflines(args, caller, tpl, seq, d_seq, x, y, ref, reps):
             wall.append(dt)
     caller.set_profiling(False)
     # the first records: the stream's head against the host encoder over the packed records of the same block
-    head_bytes = min(int(nb.value), 4 << 20)
+    head_bytes = min(int(nb.value), 8 << 20)
     got = np.empty(head_bytes, dtype=np.uint8)
     assert L.bsc_bcf_stream_read(caller._h, 0, head_bytes, got.ctypes.data) == 0 and L.bsc_synchronize(caller._h) == 0
     # ... of a sub-block made of the first templates: its records left of where the next template starts are the big block's
@@ -601,8 +601,8 @@ def raw_rooflines(args, caller, tpl, seq, d_seq, x, y, ref, reps):
         "device_ms_avg": k_ms, "device_ms_min": float(np.min(msv)), "call_wall_ms_median": float(np.median(wall)) * 1e3,
         "positions_per_s": n / (k_ms * 1e-3), "positions_per_s_call_wall": n / float(np.median(wall)),
         "bcf_bytes": int(nb.value), "records": int(nr_.value), "bytes_out_per_position": int(nb.value) / n,
-        "first_records_equal_host_encoder": bool(0 < len(want) <= head_bytes and got[: len(want)].tobytes() == want),
-        "first_records_compared": int(len(recs)),
+        "first_records_equal_host_encoder": bool(len(want) > 0 and got[: min(len(want), head_bytes)].tobytes() == want[: min(len(want), head_bytes)]),
+        "first_bytes_compared": int(min(len(want), head_bytes)),
         "note": "HIP events on the library's own stream, first pre-processing launch to the encoder's last (bsc_last_raw_block_ms); inside: two host waits "
         "(the prepared size, the verdict), the upload of the block's reference codes (1 B per position, page-locked) and the read profile's counts coming back",
     }
