@@ -108,6 +108,8 @@ EXPORTS = (
     "bsc_synth_pileup_device",
     "bsc_synth_pileup_host",
     "bsc_bamstream_open",
+    "bsc_bamstream_open_contigs",
+    "bsc_bamdev_open_contigs",
     "bsc_bamstream_close",
     "bsc_bamstream_next",
     "bsc_bamstream_release",
@@ -494,6 +496,10 @@ def load():
     L.bsc_synth_pileup_host.argtypes = [u64, u64, u64, u32, u32, vp, vp]
     L.bsc_bamstream_open.restype = i32
     L.bsc_bamstream_open.argtypes = [C.c_char_p, i32, u64, i32, C.POINTER(vp)]
+    L.bsc_bamstream_open_contigs.restype = i32
+    L.bsc_bamstream_open_contigs.argtypes = [C.c_char_p, i32, u64, i32, vp, i32, C.POINTER(vp)]
+    L.bsc_bamdev_open_contigs.restype = i32
+    L.bsc_bamdev_open_contigs.argtypes = [vp, C.c_char_p, i32, vp, i32, C.POINTER(vp)]
     L.bsc_bamstream_close.restype = None
     L.bsc_bamstream_close.argtypes = [vp]
     L.bsc_bamstream_next.restype = i32

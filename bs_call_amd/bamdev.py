@@ -13,10 +13,15 @@ from .caller import _check
 class BamStream:
     """The host half alone (no GPU needed): slabs of inflated bytes with the records' offsets."""
 
-    def __init__(self, path, threads=0, slab_bytes=0, n_slabs=0):
+    def __init__(self, path, threads=0, slab_bytes=0, n_slabs=0, contigs=None):
+        """contigs: None = the whole file; a list of tids (-1 = the unplaced reads at the end): the stretches of the file that hold them"""
         self._L = _lib.load()
         h = C.c_void_p()
-        _check(self._L.bsc_bamstream_open(str(path).encode(), int(threads), int(slab_bytes), int(n_slabs), C.byref(h)))
+        if contigs is None:
+            _check(self._L.bsc_bamstream_open(str(path).encode(), int(threads), int(slab_bytes), int(n_slabs), C.byref(h)))
+        else:
+            t = np.ascontiguousarray(contigs, dtype=np.int32)
+            _check(self._L.bsc_bamstream_open_contigs(str(path).encode(), int(threads), int(slab_bytes), int(n_slabs), t.ctypes.data, len(t), C.byref(h)))
         self._h = h
 
     def close(self):
@@ -91,11 +96,16 @@ class DeviceBamReader:
     """bsc_bamdev_*: blocks of raw templates formed on the device of `caller` (a SiteCaller)."""
 
     def __init__(self, caller, path, mapq_thresh=20, max_template_len=1000, keep_unmatched=False, ignore_duplicates=False, keep_duplicates=False,
-                 threads=0, region=None):
+                 threads=0, region=None, contigs=None):
+        """contigs: None = the whole file; a list of tids (-1 = the unplaced reads): one rank's share of a sharded run"""
         self._L = _lib.load()
         self._c = caller
         h = C.c_void_p()
-        _check(self._L.bsc_bamdev_open(caller._h, str(path).encode(), int(threads), C.byref(h)))
+        if contigs is None:
+            _check(self._L.bsc_bamdev_open(caller._h, str(path).encode(), int(threads), C.byref(h)))
+        else:
+            t = np.ascontiguousarray(contigs, dtype=np.int32)
+            _check(self._L.bsc_bamdev_open_contigs(caller._h, str(path).encode(), int(threads), t.ctypes.data, len(t), C.byref(h)))
         self._h = h
         reg = region or (0, 0, 0)
         self._par = _lib.ReaderParams(mapq_thresh, max_template_len, int(keep_unmatched), int(ignore_duplicates), int(keep_duplicates),

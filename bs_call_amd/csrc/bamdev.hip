@@ -334,6 +334,8 @@ struct bsc_bamdev {
   dev_buf ws_mem; /* the pass's arrays, carved from one allocation */
   dev_buf tmp;    /* rocPRIM scratch */
   dev_buf d_tpl, d_seq, d_ms, d_tab;
+  dev_buf d_keep; /* the contig selection, a byte per contig */
+  bool keep_unplaced = false;
   std::vector<bam_blk> blocks;
   size_t next_blk = 0;
   bool stream_end = false, finished = false;
@@ -743,7 +745,7 @@ extern "C" void bsc_bamdev_close(bsc_bamdev *r) {
     guard g(r->device);
     if (r->s) (void)hipStreamSynchronize(r->s);
     if (r->bs) bsc_bamstream_close(r->bs);
-    dev_buf *all[] = {&r->arena, &r->desc, &r->desc2, &r->recoff, &r->cnt, &r->zero, &r->ws_mem, &r->tmp, &r->d_tpl, &r->d_seq, &r->d_ms, &r->d_tab};
+    dev_buf *all[] = {&r->arena, &r->desc, &r->desc2, &r->recoff, &r->cnt, &r->zero, &r->ws_mem, &r->tmp, &r->d_tpl, &r->d_seq, &r->d_ms, &r->d_tab, &r->d_keep};
     for (dev_buf *b : all) buf_free(*b);
     for (int i = 0; i < 2; i++)
       if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
@@ -751,8 +753,13 @@ extern "C" void bsc_bamdev_close(bsc_bamdev *r) {
   delete r;
 }
 
+extern "C" int bsc_bamdev_open_contigs(bsc_context *ctx, const char *path, int n_threads, const int32_t *tids, int n_tids, bsc_bamdev **out);
 extern "C" int bsc_bamdev_open(bsc_context *ctx, const char *path, int n_threads, bsc_bamdev **out) {
-  if (!ctx || !path || !out) return bsc_set_error(BSC_ERR_ARG, "bsc_bamdev_open: NULL argument");
+  return bsc_bamdev_open_contigs(ctx, path, n_threads, nullptr, -1, out);
+}
+
+extern "C" int bsc_bamdev_open_contigs(bsc_context *ctx, const char *path, int n_threads, const int32_t *tids, int n_tids, bsc_bamdev **out) {
+  if (!ctx || !path || !out || (n_tids > 0 && !tids)) return bsc_set_error(BSC_ERR_ARG, "bsc_bamdev_open: NULL argument");
   *out = nullptr;
   bsc_bamdev *r = new (std::nothrow) bsc_bamdev;
   if (!r) return bsc_set_error(BSC_ERR_NOMEM, "bsc_bamdev_open: out of memory");
@@ -764,10 +771,26 @@ extern "C" int bsc_bamdev_open(bsc_context *ctx, const char *path, int n_threads
   if (pb && atoi(pb) > 0) r->pass_bytes = (uint64_t)atoi(pb) << 20;
   if (pk && atoi(pk) > 0) r->pass_bytes = (uint64_t)atoi(pk) << 10;
   const char *sb = getenv("BSC_BAMDEV_SLAB_KB"); /* tests: small slabs, so that records straddle them */
-  int rc = bsc_bamstream_open(path, n_threads, sb && atoi(sb) > 0 ? (uint64_t)atoi(sb) << 10 : 0, 0, &r->bs);
+  int rc = bsc_bamstream_open_contigs(path, n_threads, sb && atoi(sb) > 0 ? (uint64_t)atoi(sb) << 10 : 0, 0, tids, n_tids, &r->bs);
   if (rc) {
     bsc_bamdev_close(r);
     return rc;
+  }
+  if (n_tids >= 0) { /* the selection as the record parser's filter */
+    const int n_ref = bsc_bamstream_n_refs(r->bs);
+    std::vector<uint8_t> keep((size_t)n_ref + 1, 0);
+    for (int i = 0; i < n_tids; i++) {
+      if (tids[i] >= n_ref) {
+        bsc_bamdev_close(r);
+        return bsc_set_error(BSC_ERR_ARG, "bsc_bamdev_open_contigs: contig %d is not in the header (%d contigs)", tids[i], n_ref);
+      }
+      if (tids[i] < 0) r->keep_unplaced = true;
+      else keep[(size_t)tids[i]] = 1;
+    }
+    if ((rc = buf_reserve(r->d_keep, keep.size())) || hipMemcpy(r->d_keep.p, keep.data(), keep.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      bsc_bamdev_close(r);
+      return rc ? rc : bsc_set_error(BSC_ERR_HIP, "bsc_bamdev_open_contigs: device set-up failed");
+    }
   }
   if ((rc = buf_reserve(r->cnt, sizeof(bam_cnt))) || (rc = buf_reserve(r->zero, 64))) {
     bsc_bamdev_close(r);
@@ -805,6 +828,8 @@ extern "C" int bsc_bamdev_next_block(bsc_bamdev *r, const bsc_reader_params *par
   p.region_start = par->region_start;
   p.region_stop = par->region_stop;
   p.n_ref = bsc_bamstream_n_refs(r->bs);
+  p.tid_keep = (const uint8_t *)r->d_keep.p;
+  p.keep_unplaced = r->keep_unplaced ? 1u : 0u;
   if (r->par_set && memcmp(&p, &r->par, sizeof p)) return bsc_set_error(BSC_ERR_ARG, "bsc_bamdev_next_block: the reader's parameters changed in mid-file");
   r->par = p;
   r->par_set = true;

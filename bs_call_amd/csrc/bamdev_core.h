@@ -48,6 +48,9 @@ typedef struct {
   int32_t region_tid;
   uint32_t region_start, region_stop;
   int32_t n_ref;
+  uint32_t keep_unplaced;  /* with tid_keep: the records without a contig (and with an invalid one) are this reader's too */
+  const uint8_t *tid_keep; /* a selection of contigs (one byte per contig of the header, 1 = this reader's), NULL = all: a sharded run's ranks
+                            * each read the stretches of the file that hold their contigs; a stretch's other records are another rank's */
 } bd_params;
 
 typedef struct {
@@ -171,6 +174,10 @@ BD_FN void bd_parse(const uint8_t *rec, uint64_t avail, uint64_t off, const bd_p
     return;
   }
   d.tid = tid;
+  if (par.tid_keep && !((tid >= 0 && tid < par.n_ref) ? par.tid_keep[tid] != 0 : par.keep_unplaced != 0)) {
+    d.status = BD_ST_ABSENT; /* another reader's */
+    return;
+  }
   d.l_name = (uint8_t)l_name;
   d.n_cigar = (uint16_t)n_cigar;
   d.l_seq = l_seq;

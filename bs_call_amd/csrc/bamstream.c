@@ -49,12 +49,15 @@ struct bs_blk { /* a block's place in its slab and what its helper's walk found 
   uint32_t exit_skip;       /* bytes of its last record that lie in the following blocks */
   uint8_t exit_hdr[4], exit_hdr_n; /* ... or a size field cut in two */
   uint8_t valid;            /* the walk from offset 0 met only plausible sizes */
+  uint8_t restart;          /* the chain starts afresh here (a stretch of a contig selection): entry_skip bytes are stepped over first */
+  uint32_t entry_skip;
 };
 struct bs_ent { /* one BGZF block of the file */
   uint64_t file_off; /* of its deflate payload */
   uint32_t clen, isize, crc;
   uint32_t seq;      /* the slab-load it belongs to (SEQ_NONE: an empty block, stepped over) */
   uint32_t boff, blk_ix, sp_base;
+  uint32_t restart, entry_skip;
 };
 struct bs_seq { /* one slab-load of the stream */
   uint64_t stream_off;
@@ -111,6 +114,8 @@ struct bsc_bamstream {
   int dbg_nowalk; /* measurement only (BSC_BAMSTREAM_NOWALK at open): no record walk — the helpers' raw inflate rate */
   int unpinned;   /* no device: ordinary memory (the stream is usable without a GPU; uploads from it are staged by the runtime) */
   int idx_threads, idx_serial; /* how the index was built */
+  int32_t *sel_tid; /* a selection of contigs (ascending; -1 = the unplaced reads at the file's end), sel_n < 0: the whole file */
+  int sel_n;
 };
 
 static uint32_t le32(const uint8_t *p) { return p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
@@ -378,10 +383,129 @@ static void *idx_scan(void *a) {
     t->isize = is;
     t->crc = cr;
     t->seq = SEQ_NONE;
+    t->restart = t->entry_skip = 0;
     pos += bs;
   }
   j->end = pos;
   return NULL;
+}
+
+/* ---- a selection of contigs: the stretches of the file that hold their records --------------------------------------------------------
+ * The file is sorted by (contig, position), so the contig of a block's FIRST record grows with the block number: a binary search over
+ * blocks, each probe one block inflated, finds where a contig's records begin and end — no index file.  Needs blocks that start at a
+ * record (htslib's writer; checked at every probe).  The stretch of contig c: from the last block whose first record lies before c (it
+ * may hold c's first records) to the last block whose first record is of c or before; stretches that touch are merged; records of other
+ * contigs inside a stretch are dropped by the record parser's contig filter (csrc/bamdev_core.h). */
+static int first_tid_of(bsc_bamstream *b, uint64_t k, uint64_t k_hdr, uint32_t hdr_skip, uint8_t *raw, uint8_t *buf, int64_t *tid) {
+  if (k < k_hdr) {
+    *tid = -2; /* header bytes only: before every contig */
+    return BSC_OK;
+  }
+  const struct bs_ent *e = &b->ent[k];
+  if (e->isize == 0) {
+    *tid = -3; /* an empty block: the caller looks at a neighbour */
+    return BSC_OK;
+  }
+  if (pread(b->fd, raw, e->clen, (off_t)e->file_off) != (ssize_t)e->clen) return bsc_set_error(BSC_ERR_ARG, "BAM: read error");
+  const char *er = bgzf_inflate_to(raw, e->clen, buf, e->isize, e->crc);
+  if (er) return bsc_set_error(BSC_ERR_ARG, "%s", er);
+  const uint32_t o = k == k_hdr ? hdr_skip : 0u;
+  if (o >= e->isize) {
+    *tid = -2;
+    return BSC_OK;
+  }
+  if (e->isize - o < 36) return bsc_set_error(BSC_ERR_ARG, "BAM: records are cut by BGZF block boundaries: a contig selection needs blocks that start at a record");
+  const uint32_t bs = le32(buf + o);
+  const int32_t t = (int32_t)le32(buf + o + 4);
+  const uint32_t l_name = buf[o + 12], n_cig = buf[o + 16] | (uint32_t)buf[o + 17] << 8, l_seq = le32(buf + o + 20);
+  if (bs < 32 || bs > (1u << 29) || t < -1 || t >= b->n_ref || l_name == 0 || 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1) / 2 + l_seq > bs ||
+      (o + 36u + l_name <= e->isize && buf[o + 36 + l_name - 1] != 0))
+    return bsc_set_error(BSC_ERR_ARG, "BAM: records are cut by BGZF block boundaries: a contig selection needs blocks that start at a record");
+  *tid = t < 0 ? (int64_t)1 << 40 : t; /* unplaced reads come last */
+  return BSC_OK;
+}
+
+static int select_contigs(bsc_bamstream *b) {
+  /* the block that holds the first record, and where in it */
+  uint64_t cum = 0, k_hdr = b->n_ent;
+  uint32_t hdr_skip = 0;
+  for (uint64_t k = 0; k < b->n_ent; k++) {
+    if (cum + b->ent[k].isize > b->first_rec_off) {
+      k_hdr = k;
+      hdr_skip = (uint32_t)(b->first_rec_off - cum);
+      break;
+    }
+    cum += b->ent[k].isize;
+  }
+  uint8_t *raw = malloc(65536 + 64), *buf = malloc(65536);
+  struct {
+    uint64_t lo, hi;
+  } *rg = calloc((size_t)b->sel_n + 1, sizeof *rg);
+  int n_rg = 0, rc = BSC_OK;
+  if (!raw || !buf || !rg) rc = bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
+  for (int i = 0; i < b->sel_n && !rc && k_hdr < b->n_ent; i++) {
+    const int64_t c = b->sel_tid[i] < 0 ? (int64_t)1 << 40 : b->sel_tid[i];
+    /* lo: the last block whose first record is before c; hi: the last whose first record is of c or before (both >= k_hdr) */
+    uint64_t bound[2];
+    for (int w = 0; w < 2 && !rc; w++) {
+      uint64_t a = k_hdr, z = b->n_ent; /* invariant: blocks < a satisfy the predicate (or a == k_hdr), blocks >= z do not */
+      while (a + 1 < z && !rc) {
+        uint64_t m = a + (z - a) / 2, mm = m;
+        int64_t t = -3;
+        while (mm < z && !rc) { /* empty blocks have no record to look at: the next one speaks for them */
+          rc = first_tid_of(b, mm, k_hdr, hdr_skip, raw, buf, &t);
+          if (t != -3) break;
+          mm++;
+        }
+        if (rc) break;
+        if (mm >= z || t == -3) {
+          z = m;
+          continue;
+        }
+        const int pred = w == 0 ? t < c : t <= c;
+        if (pred) a = mm;
+        else z = m;
+      }
+      bound[w] = a;
+    }
+    if (rc) break;
+    if (bound[1] < bound[0]) bound[1] = bound[0];
+    if (n_rg && bound[0] <= rg[n_rg - 1].hi + 1) { /* touches the stretch before it */
+      if (bound[1] > rg[n_rg - 1].hi) rg[n_rg - 1].hi = bound[1];
+    } else {
+      rg[n_rg].lo = bound[0];
+      rg[n_rg].hi = bound[1];
+      n_rg++;
+    }
+  }
+  if (!rc) {
+    uint64_t total = 0;
+    for (int i = 0; i < n_rg; i++) total += rg[i].hi - rg[i].lo + 1;
+    struct bs_ent *ne = malloc((total + 1) * sizeof *ne);
+    if (!ne) rc = bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
+    else {
+      uint64_t o = 0;
+      for (int i = 0; i < n_rg; i++) {
+        const uint64_t first = o;
+        for (uint64_t k = rg[i].lo; k <= rg[i].hi; k++) ne[o++] = b->ent[k];
+        /* the stretch's first block with bytes restarts the chain */
+        for (uint64_t q = first; q < o; q++)
+          if (ne[q].isize) {
+            ne[q].restart = 1;
+            ne[q].entry_skip = rg[i].lo == k_hdr && q == first ? hdr_skip : 0u;
+            break;
+          }
+      }
+      free(b->ent);
+      b->ent = ne;
+      b->n_ent = o;
+      b->w_skip = 0; /* every stretch says where it starts */
+    }
+  }
+  free(raw);
+  free(buf);
+  free(rg);
+  return rc;
 }
 
 /* every block of the file -> b->ent, then every block's place.  BSC_OK or an error code (message set) */
@@ -448,6 +572,7 @@ static int build_index(bsc_bamstream *b, int n_threads) {
   free(job);
   free(th);
   if (rc) return rc;
+  if (b->sel_n >= 0 && (rc = select_contigs(b))) return rc;
   /* every block's place: slab-loads filled in stream order, a block never cut */
   size_t cap_seq = 0;
   uint64_t stream = 0;
@@ -520,6 +645,8 @@ static void *helper(void *arg) {
     kb->sp_base = e->sp_base;
     kb->sp_n = 0;
     kb->valid = 0;
+    kb->restart = (uint8_t)e->restart;
+    kb->entry_skip = e->entry_skip;
     const char *er = pread(b->fd, raw, e->clen, (off_t)e->file_off) == (ssize_t)e->clen ? bgzf_inflate_to(raw, e->clen, s->bytes + e->boff, e->isize, e->crc)
                                                                                          : "BAM: read error";
     if (er) {
@@ -591,6 +718,7 @@ void bsc_bamstream_close(bsc_bamstream *b) {
   free(b->th);
   free(b->ent);
   free(b->seq);
+  free(b->sel_tid);
   if (b->slab)
     for (int i = 0; i < b->n_slabs; i++) {
       free(b->slab[i].sparse);
@@ -650,7 +778,11 @@ int bsc_bamstream_default_threads(void) {
 }
 
 int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int n_slabs, bsc_bamstream **out) {
-  if (!path || !out) return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_open: NULL argument");
+  return bsc_bamstream_open_contigs(path, n_threads, slab_bytes, n_slabs, NULL, -1, out);
+}
+
+int bsc_bamstream_open_contigs(const char *path, int n_threads, uint64_t slab_bytes, int n_slabs, const int32_t *tids, int n_tids, bsc_bamstream **out) {
+  if (!path || !out || (n_tids > 0 && !tids)) return bsc_set_error(BSC_ERR_ARG, "bsc_bamstream_open: NULL argument");
   *out = NULL;
   if (n_threads <= 0) n_threads = bsc_bamstream_default_threads();
   if (n_threads > 128) n_threads = 128;
@@ -661,6 +793,23 @@ int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int
   if (n_slabs < 2) n_slabs = 2;
   bsc_bamstream *b = calloc(1, sizeof *b);
   if (!b) return bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
+  b->sel_n = n_tids < 0 ? -1 : n_tids;
+  if (n_tids > 0) {
+    b->sel_tid = malloc((size_t)n_tids * sizeof *b->sel_tid);
+    if (!b->sel_tid) {
+      free(b);
+      return bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
+    }
+    memcpy(b->sel_tid, tids, (size_t)n_tids * sizeof *tids);
+    for (int i = 1; i < n_tids; i++) /* ascending, the unplaced reads (-1) last: the order of the file */
+      for (int j = i; j > 0; j--) {
+        const int64_t x = b->sel_tid[j - 1] < 0 ? (int64_t)1 << 40 : b->sel_tid[j - 1], y = b->sel_tid[j] < 0 ? (int64_t)1 << 40 : b->sel_tid[j];
+        if (x <= y) break;
+        const int32_t t = b->sel_tid[j - 1];
+        b->sel_tid[j - 1] = b->sel_tid[j];
+        b->sel_tid[j] = t;
+      }
+  }
   b->fd = open(path, O_RDONLY);
   if (b->fd < 0) {
     const int e = errno;
@@ -837,6 +986,10 @@ int bsc_bamstream_next(bsc_bamstream *b, bsc_bam_slab *out) {
   s->n_recs = 0;
   for (uint32_t i = 0; i < sq->n_ent && !b->dbg_nowalk; i++) {
     const struct bs_blk *k = &s->blk[i];
+    if (k->restart) { /* a new stretch of the selection: its first block starts at a record (checked when the stretch was chosen) */
+      if (b->w_skip || b->w_hdr_n) return bsc_set_error(BSC_ERR_ARG, "BAM: a record is cut where a selected stretch of the file ends");
+      b->w_skip = k->entry_skip;
+    }
     if (b->w_skip == 0 && b->w_hdr_n == 0 && k->valid) {
       memcpy(s->rec_off + s->n_recs, s->sparse + k->sp_base, (size_t)k->sp_n * 4u);
       s->n_recs += k->sp_n;

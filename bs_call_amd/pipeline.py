@@ -16,7 +16,8 @@ from .caller import ReadProfile, SiteCaller, gc_bins, prepare_templates
 def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: str = "SAMPLE", report_path: Optional[str] = None,
         caller: Optional[SiteCaller] = None, dbsnp=None, compressed: bool = True, date=None, left_trim=(0, 0), right_trim=(0, 0),
         min_qual: Optional[int] = None, benchmark_mode: bool = False, under_conv: Optional[float] = None, over_conv: Optional[float] = None,
-        host_prep: bool = False, host_bcf: bool = False, device_reader: bool = False, **reader_kw) -> dict:
+        host_prep: bool = False, host_bcf: bool = False, device_reader: bool = False, shard_rank: Optional[int] = None, shard_world: int = 1,
+        reduce_device=None, **reader_kw) -> dict:
     """reference: contig name -> uint8 reference codes (0 = N, 1..4 = ACGT; position 1 first).  Returns a summary dict.
     under_conv / over_conv / min_qual (defaults 0.01 / 0.05 / 20, src/init_param.c:26-31) are the MODEL's parameters: without
     `caller` the run builds its SiteCaller from them; with one, they are taken from it and a differing explicit value is an error
@@ -24,7 +25,13 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
     pre-processing on the host (bsc_prepare_templates_profile) instead of the device (round 5's default) — same bytes.  host_bcf:
     the packed records come back and the host encodes them (bsc_bcf_block) instead of the device's encoder (bsc_block_bcf_raw,
     round 5's default) — same bytes.  device_reader: the blocks are formed on the device from the inflated BAM bytes (round 6:
-    bamdev.DeviceBamReader — the host only inflates) and go on to bsc_block_bcf_rawdev where they lie — same bytes."""
+    bamdev.DeviceBamReader — the host only inflates) and go on to bsc_block_bcf_rawdev where they lie — same bytes.
+    shard_rank / shard_world: ONE RANK of a sharded run over one file (SURVEY.md 8e on real input; the reference's unit of parallelism is a
+    process per contig over an indexed file, src/process.c:125, src/get_template_vector.c:69-99): the header's contigs are dealt to the ranks by
+    shard.assign_contigs (longest first), every rank reads the stretches of the file that hold ITS contigs (the device reader's contig
+    selection: no index file), writes each contig's records to a shard beside bcf_path, and at the end the ranks all-reduce what the report
+    sums (torch.distributed's default group: RCCL between GPUs, gloo in the rehearsal; reduce_device = the tensors' device) and rank 0
+    concatenates the shards in contig order behind the header — the bytes of the single run."""
     own = caller is None
     if own:
         under_conv = 0.01 if under_conv is None else under_conv
@@ -44,6 +51,20 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
         per_contig = []
         n_blocks = n_records = 0
         c.reset_site_stats()
+        sharded = shard_rank is not None
+        if sharded:
+            from . import shard as S
+            from .bamdev import BamStream
+
+            device_reader = True
+            with BamStream(bam_path, threads=1, contigs=[]) as hs:  # the header alone
+                all_refs = hs.refs
+            parts = S.assign_contigs([l for _, l in all_refs], shard_world)
+            mine = sorted(parts[shard_rank])
+            if all_refs and len(all_refs) - 1 in parts[shard_rank]:
+                mine = mine + [-1]  # the unplaced reads at the file's end go with the last contig's rank
+            reader_kw = dict(reader_kw, contigs=mine)
+            shard_files = {}
         if device_reader:
             if host_prep or host_bcf:
                 raise ValueError("device_reader goes with the device pre-processing and encoder")
@@ -108,20 +129,85 @@ def run(bam_path: str, reference: Dict[str, np.ndarray], bcf_path: str, sample: 
                     passed += np.array([st["reads"], st["read_bases"]], dtype=np.uint64)
                     if recs is not None:
                         blob, n_rec = vcf.bcf_block(recs, tid, dbsnp), len(recs)
-                    yield blob
+                    if sharded:  # this contig's shard, written as its blocks are formed
+                        if tid not in shard_files:
+                            shard_files[tid] = open("%s.shard%05d" % (bcf_path, tid), "wb")
+                        shard_files[tid].write(blob)
+                    else:
+                        yield blob
                     n_blocks += 1
                     n_records += n_rec
                 if cur_tid >= 0:
                     per_contig.append((refs[cur_tid][0], c.site_totals() - before))
 
-            vcf.write_bcf(bcf_path, header, block_blobs(), compressed)  # blocks go to the writer as they are formed
+            if sharded:
+                for _ in block_blobs():
+                    pass
+                for f_ in shard_files.values():
+                    f_.close()
+            else:
+                vcf.write_bcf(bcf_path, header, block_blobs(), compressed)  # blocks go to the writer as they are formed
             cts, bases = rd.filter_counts()
         cts[0] += int(passed[0])
         bases[0] += int(passed[1])
         c.set_gc_bins_host(None, 0)
-        text = report.render_json(c.site_stats(), gc=c.gc_stats(), min_qual=min_qual, date=date, have_dbsnp=dbsnp is not None, filter_cts=cts, filter_bases=bases,
-                                  base_filter=base_filter.tolist(), read_profile=prof.reported(), contigs=per_contig)
-        if report_path:
+        site_stats, gc = c.site_stats(), c.gc_stats()
+        prof_rows = prof.reported()
+        if sharded:  # everything the report holds is a sum over positions / reads / templates: the ranks' shares add
+            import torch.distributed as dist
+
+            site_stats = S.allreduce_site_stats(site_stats, reduce_device)
+            gc = S.allreduce_counts(gc, reduce_device)
+            small = np.zeros(15 + 15 + 5 + 2 + 1, dtype=np.uint64)
+            small[:15], small[15:30], small[30:35] = cts, bases, base_filter
+            small[35], small[36], small[37] = n_blocks, n_records, 0
+            small = S.allreduce_counts(small, reduce_device)
+            cts, bases, base_filter = [int(v) for v in small[:15]], [int(v) for v in small[15:30]], small[30:35]
+            n_blocks, n_records = int(small[35]), int(small[36])
+            # the read profile: the vectors add; its length is the longest any rank saw
+            used = np.array([prof.used], dtype=np.uint64)
+            rows = S.allreduce_counts(prof.counts, reduce_device)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                import torch
+
+                t = torch.from_numpy(used.view(np.int64).copy())
+                if reduce_device is not None:
+                    t = t.to(reduce_device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                used = t.cpu().numpy().view(np.uint64)
+            prof_rows = rows[: int(used[0])]
+            # per contig: each is one rank's; a sum of the zero-padded table is a gather
+            tab = np.zeros((len(refs), 14), dtype=np.uint64)
+            names = [n for n, _ in refs]
+            for n_, v in per_contig:
+                tab[names.index(n_)] += np.asarray(v, dtype=np.uint64).reshape(-1)
+            tab = S.allreduce_counts(tab, reduce_device)
+            seen = np.zeros(len(refs), dtype=np.uint64)
+            for n_, _v in per_contig:
+                seen[names.index(n_)] = 1
+            seen = S.allreduce_counts(seen, reduce_device)
+            per_contig = [(names[i], tab[i].reshape(7, 2)) for i in range(len(refs)) if seen[i]]
+            if dist.is_available() and dist.is_initialized():
+                dist.barrier()  # every shard is on disk
+        text = report.render_json(site_stats, gc=gc, min_qual=min_qual, date=date, have_dbsnp=dbsnp is not None, filter_cts=cts, filter_bases=bases,
+                                  base_filter=np.asarray(base_filter).tolist(), read_profile=prof_rows, contigs=per_contig)
+        if sharded and shard_rank == 0:  # the header, then the contigs' shards in the header's order
+            import os
+
+            def shards():
+                for tid in range(len(refs)):
+                    p_ = "%s.shard%05d" % (bcf_path, tid)
+                    if os.path.exists(p_):
+                        with open(p_, "rb") as f_:
+                            while True:
+                                b_ = f_.read(1 << 24)
+                                if not b_:
+                                    break
+                                yield b_
+                        os.remove(p_)
+
+            vcf.write_bcf(bcf_path, header, shards(), compressed)
+        if report_path and (not sharded or shard_rank == 0):
             with open(report_path, "w") as f:
                 f.write(text)
         return {"blocks": n_blocks, "records": n_records, "report": text, "filter_cts": cts, "contigs": [n for n, _ in per_contig]}

@@ -809,6 +809,12 @@ typedef struct {
   uint64_t seq;
 } bsc_bam_slab;
 int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int n_slabs, bsc_bamstream **out);
+/* the stream of a SELECTION of contigs (tids of the header's list; -1 = the unplaced reads at the file's end) — what the reference reads through
+ * sam_index_load + sam_itr_queryi per region (src/process.c:125, src/get_template_vector.c:69-99), without an index file: the file is sorted, so a
+ * binary search over its BGZF blocks (one block inflated per probe) finds the stretches that hold the selected contigs' records; records of other
+ * contigs inside a stretch are for the record parser's contig filter (bsc_bamdev_open_contigs applies it).  Needs blocks that start at a record
+ * (htslib's writer); BSC_ERR_ARG otherwise.  n_tids = 0: an empty stream. */
+int bsc_bamstream_open_contigs(const char *path, int n_threads, uint64_t slab_bytes, int n_slabs, const int32_t *tids, int n_tids, bsc_bamstream **out);
 void bsc_bamstream_close(bsc_bamstream *b);
 int bsc_bamstream_next(bsc_bamstream *b, bsc_bam_slab *out);
 int bsc_bamstream_release(bsc_bamstream *b, const bsc_bam_slab *slab);
@@ -833,6 +839,9 @@ typedef struct {
   uint64_t ins_pad;
 } bsc_dev_read_block;
 int bsc_bamdev_open(bsc_context *ctx, const char *path, int n_threads, bsc_bamdev **out);
+/* the reader of a SELECTION of contigs (bsc_bamstream_open_contigs + the record parser's contig filter): what one rank of a sharded run reads —
+ * its blocks and filter counters are exactly the whole file's reader's for those contigs, so the ranks' outputs concatenate and their counters add */
+int bsc_bamdev_open_contigs(bsc_context *ctx, const char *path, int n_threads, const int32_t *tids, int n_tids, bsc_bamdev **out);
 void bsc_bamdev_close(bsc_bamdev *r);
 int bsc_bamdev_n_refs(const bsc_bamdev *r);
 const char *bsc_bamdev_ref_name(const bsc_bamdev *r, int i);

@@ -27,7 +27,7 @@ MISMS_T = np.dtype([("type", "<u4"), ("position", "<u4"), ("size", "<u4")])
 class Params(ctypes.Structure):
     _fields_ = [("mapq_thresh", ctypes.c_uint32), ("keep_unmatched", ctypes.c_uint32), ("ignore_duplicates", ctypes.c_uint32), ("keep_duplicates", ctypes.c_uint32),
                 ("max_template_len", ctypes.c_uint64), ("region_tid", ctypes.c_int32), ("region_start", ctypes.c_uint32), ("region_stop", ctypes.c_uint32),
-                ("n_ref", ctypes.c_int32)]
+                ("n_ref", ctypes.c_int32), ("keep_unplaced", ctypes.c_uint32), ("tid_keep", ctypes.c_void_p)]
 
 
 @pytest.fixture(scope="module")
@@ -61,9 +61,19 @@ class EmulError(Exception):
 
 
 def emul_blocks(lib, path, mode=0, pass_recs=0, region=None, mapq_thresh=20, max_template_len=1000, keep_unmatched=False, ignore_duplicates=False,
-                keep_duplicates=False):
-    raw, offs, n_ref = stream_of(path)
-    par = Params(mapq_thresh, int(keep_unmatched), int(ignore_duplicates), int(keep_duplicates), max_template_len, 0, 0, 0, n_ref)
+                keep_duplicates=False, stream=None, contigs=None):
+    """stream: (inflated bytes, record offsets, n_ref) instead of the whole file's (a contig selection's stretches); contigs: the record parser's
+    contig filter (tids, -1 = the unplaced reads)"""
+    raw, offs, n_ref = stream if stream is not None else stream_of(path)
+    par = Params(mapq_thresh, int(keep_unmatched), int(ignore_duplicates), int(keep_duplicates), max_template_len, 0, 0, 0, n_ref, 0, None)
+    keep = None
+    if contigs is not None:
+        keep = np.zeros(n_ref + 1, dtype=np.uint8)
+        for t in contigs:
+            if t >= 0:
+                keep[t] = 1
+        par.keep_unplaced = int(any(t < 0 for t in contigs))
+        par.tid_keep = keep.ctypes.data
     if region:
         par.region_tid, par.region_start, par.region_stop = region
     buf = (ctypes.c_uint8 * len(raw)).from_buffer_copy(raw)

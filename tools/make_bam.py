@@ -61,13 +61,26 @@ def encode_record(r) -> bytes:
     return struct.pack("<I", len(body)) + body
 
 
-def write_bam(path, refs, records, text=None, block=0xFF00):
+def write_bam(path, refs, records, text=None, block=0xFF00, aligned=False):
+    """aligned: BGZF blocks are cut at record boundaries, as htslib's writer cuts them (bgzf_flush_try) — never through a record"""
     if text is None:
         text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
     t = text.encode()
     data = bytearray(b"BAM\1" + struct.pack("<I", len(t)) + t + struct.pack("<i", len(refs)))
     for name, ln in refs:
         data += struct.pack("<I", len(name) + 1) + name.encode() + b"\0" + struct.pack("<I", ln)
+    if aligned:
+        with open(path, "wb") as f:
+            for r in records:
+                e = encode_record(r)
+                if len(data) and len(data) + len(e) > block:
+                    f.write(bgzf_block(bytes(data)))
+                    data = bytearray()
+                data += e
+            if data:
+                f.write(bgzf_block(bytes(data)))
+            f.write(BGZF_EOF)
+        return
     for r in records:
         data += encode_record(r)
     with open(path, "wb") as f:
