@@ -26,6 +26,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/bscall_amd.h"
 
@@ -392,6 +393,112 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
+/*
+ * Round 6: the two kernels above read every record twice (sizes, then bytes: 2 x (64 B per position + 64 B per written record) for the
+ * per-position form).  ONE kernel with a decoupled look-back (Merrill & Garland's single-pass scan): a wave takes the next tile from a
+ * counter (tiles are therefore started in order: a wave never waits for a tile nobody runs), sums its lanes' record lengths, publishes the
+ * sum, and finds its place in the stream by walking back over its predecessors' published words — a tile's own sum (flag 1) is added and
+ * the walk goes on, a tile's inclusive prefix (flag 2) ends it — then publishes its own inclusive prefix and writes its records as the
+ * write kernel does.  A word = flag << 62 | bytes: one 8-byte store publishes both.  The records are read once.
+ */
+#define BCF_FLAG_SUM (1ull << 62)
+#define BCF_FLAG_PREFIX (2ull << 62)
+#define BCF_VAL_MASK ((1ull << 62) - 1ull)
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BCF_WAVES_PER_EU, BCF_WAVES_PER_EU))) void bsc_bcf_onepass_kernel(
+    bcf_args a, uint32_t n_tiles, unsigned long long *__restrict__ state /* [n_tiles], zeroed */, unsigned int *__restrict__ next_tile /* zeroed */,
+    uint8_t *__restrict__ out, uint64_t out_cap, unsigned long long *__restrict__ totals /* [0] length, [1] += refused, [2] += written */) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[BCF_WAVES][BCF_IMG_BYTES + 16u];
+  const unsigned lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  uint8_t *const img = s_img[wid];
+  const uint64_t n = clamp_n(a);
+  unsigned n_written = 0, n_bad = 0;
+  for (;;) {
+    uint32_t tile = 0;
+    if (lane == 0) tile = atomicAdd(next_tile, 1u);
+    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+    if (tile >= n_tiles) break;
+    rec_regs r;
+    const uint8_t *id;
+    unsigned id_len;
+    bool bad;
+    const unsigned len = rec_len(a, (uint64_t)tile * 64u + lane, n, r, id, id_len, bad);
+    n_bad += (unsigned)__popcll(__ballot(bad));
+    n_written += (unsigned)__popcll(__ballot(len != 0u));
+    unsigned inc = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned v = __shfl_up(inc, d);
+      if (lane >= (unsigned)d) inc += v;
+    }
+    const unsigned excl = inc - len;
+    const unsigned t_all = __shfl(inc, 63);
+    /* the tile's place: its predecessors' bytes */
+    unsigned long long before = 0ull;
+    if (tile == 0u) {
+      if (lane == 0) __hip_atomic_store(&state[0], BCF_FLAG_PREFIX | (unsigned long long)t_all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(&state[tile], BCF_FLAG_SUM | (unsigned long long)t_all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      /* 64 predecessors at a time, lane l looking at tile - 1 - l (- 64 per round): the nearest inclusive prefix ends the walk */
+      int64_t base = (int64_t)tile - 1;
+      for (;;) {
+        const int64_t j = base - (int64_t)lane;
+        unsigned long long w = BCF_FLAG_PREFIX; /* before tile 0: a prefix of nothing */
+        if (j >= 0) {
+          do {
+            w = __hip_atomic_load(&state[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((w >> 62) == 0ull);
+        }
+        const unsigned long long is_prefix = __ballot((w >> 62) == 2ull);
+        const unsigned first = (unsigned)__builtin_ctzll(is_prefix ? is_prefix : 1ull); /* the nearest prefix among these 64 */
+        unsigned long long v = (is_prefix == 0ull || lane <= first) ? (w & BCF_VAL_MASK) : 0ull;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        before += v;
+        if (is_prefix) break;
+        base -= 64;
+      }
+      if (lane == 0) __hip_atomic_store(&state[tile], BCF_FLAG_PREFIX | (before + (unsigned long long)t_all), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tile == n_tiles - 1u && lane == 0) totals[0] = before + (unsigned long long)t_all;
+    const uint64_t g_tile = before;
+    if ((uint64_t)tile * 64u >= n || g_tile + t_all > out_cap) continue; /* nothing to write / the host reports the overflow from totals[0] */
+    const unsigned t_half = __shfl(inc, 31);
+    const unsigned passes = t_all <= BCF_IMG_BYTES ? 1u : 2u;
+    for (unsigned ps = 0; ps < passes; ps++) {
+      const unsigned b0 = ps ? t_half : 0u;
+      const unsigned b1 = passes == 1u ? t_all : (ps ? t_all : t_half);
+      const bool mine = len && excl >= b0 && excl < b1;
+      const uint64_t g0 = g_tile + b0;
+      const unsigned ph = (unsigned)(g0 & 15u);
+      if (mine) {
+        uint8_t *p = img + ph + (excl - b0);
+        lds_sink w = {p + 32u, 0u};
+        bool bad2;
+        const unsigned l_shared = bcf_emit_body(w, r, a, id, id_len, bad2);
+        bcf_emit_fixed(p, r, a, l_shared, w.len - l_shared);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned t = b1 - b0, end = ph + t;
+      uint8_t *const dst = out + (g0 - ph);
+      const unsigned head_end = ph ? (end < 16u ? end : 16u) : 0u;
+      if (lane >= ph && lane < head_end) dst[lane] = img[lane];
+      const unsigned body0 = ph ? 16u : 0u, body1 = end & ~15u;
+      for (unsigned o = body0 + 16u * lane; o < body1; o += 1024u) *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(img + o);
+      const unsigned tail0 = body1 > head_end ? body1 : head_end;
+      if (tail0 + lane < end) dst[tail0 + lane] = img[tail0 + lane];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if (lane == 0) {
+    if (n_bad) atomicAdd(totals + 1, (unsigned long long)n_bad);
+    if (n_written) atomicAdd(totals + 2, (unsigned long long)n_written);
+  }
+}
+
 extern "C" int bsc_dev_scan_u64(const void *in, void *out, uint32_t n, void *tmp, size_t tmp_bytes, void *stream); /* sort.hip */
 
 /*
@@ -423,6 +530,21 @@ extern "C" int bsc_dev_launch_bcf(const void *recs, const void *core, const void
   unsigned grid = (n_tiles + BCF_WAVES - 1u) / BCF_WAVES;
   if (grid > (unsigned)num_cus * 12u) grid = (unsigned)num_cus * 12u;
   if (grid == 0) grid = 1;
+  static int two_pass = -1; /* BSC_BCF_TWO_PASS in the environment: round 5's size + scan + write kernels (the A/B of tools/bench_bcf.py) */
+  if (two_pass < 0) two_pass = getenv("BSC_BCF_TWO_PASS") != nullptr;
+  if (!two_pass) {
+    if (n_tiles == 0) return (int)hipMemsetAsync(totals, 0, sizeof(unsigned long long), s);
+    hipError_t e1 = hipMemsetAsync(tile_off, 0, (size_t)n_tiles * 8u, s);
+    if (e1 == hipSuccess) e1 = hipMemsetAsync(tile_bytes, 0, 8, s);
+    if (e1 != hipSuccess) return (int)e1;
+    /* as many waves as are resident at once: every wave takes tiles until none is left */
+    unsigned g1 = (n_tiles + BCF_WAVES - 1u) / BCF_WAVES;
+    const unsigned cap1 = (unsigned)num_cus * (unsigned)BCF_WAVES_PER_EU;
+    if (g1 > cap1) g1 = cap1;
+    hipLaunchKernelGGL(bsc_bcf_onepass_kernel, dim3(g1), dim3(256), 0, s, a, n_tiles, (unsigned long long *)tile_off, (unsigned int *)tile_bytes, (uint8_t *)out, out_cap,
+                       (unsigned long long *)totals);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(bsc_bcf_size_kernel, dim3(grid), dim3(256), 0, s, a, n_tiles, (unsigned long long *)tile_bytes, (unsigned long long *)totals + 1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
