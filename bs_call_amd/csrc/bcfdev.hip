@@ -332,6 +332,36 @@ extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_kernel(bcf_args a
   if (lane == 0 && n_written) atomicAdd(err + 1, (unsigned long long)n_written); /* totals[2]: once per wave — one word cannot take an atomic per tile */
 }
 
+/* The same sums from the chain kernel's byte per position (csrc/fused.hip, emit_out): 0 = no record, 1 .. 254 = the record's length with
+ * one-byte dictionary indices and no ID — what the launcher has checked the indices to be —, 255 = look at the record (heterozygous calls,
+ * dbSNP-flagged positions: one position in a few hundred).  64 bytes a tile instead of 64 sectors and more. */
+extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_bytes_kernel(bcf_args a, const uint8_t *__restrict__ emit, uint32_t n_tiles,
+                                                                            unsigned long long *__restrict__ tile_bytes, unsigned long long *__restrict__ err) {
+  const unsigned lane = threadIdx.x & 63u;
+  const uint64_t n = clamp_n(a);
+  if (blockIdx.x == 0 && threadIdx.x == 0) tile_bytes[n_tiles] = 0ull;
+  unsigned n_written = 0;
+  for (uint32_t tile = blockIdx.x * BCF_WAVES + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * BCF_WAVES) {
+    const uint64_t i = (uint64_t)tile * 64u + lane;
+    unsigned len = i < n ? emit[i] : 0u;
+    if (__ballot(len == 255u)) { /* wave-uniform branch: most tiles have no such position */
+      if (len == 255u) {
+        rec_regs r;
+        const uint8_t *id;
+        unsigned id_len;
+        bool bad;
+        len = rec_len(a, i, n, r, id, id_len, bad);
+        if (bad) atomicAdd(err, 1ull);
+      }
+    }
+    n_written += (unsigned)__popcll(__ballot(len != 0u));
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) len += __shfl_xor(len, d);
+    if (lane == 0) tile_bytes[tile] = len;
+  }
+  if (lane == 0 && n_written) atomicAdd(err + 1, (unsigned long long)n_written);
+}
+
 extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BCF_WAVES_PER_EU, BCF_WAVES_PER_EU))) void bsc_bcf_write_kernel(bcf_args a, uint32_t n_tiles, const unsigned long long *__restrict__ tile_off,
                                                                        uint8_t *__restrict__ out, uint64_t out_cap,
                                                                        unsigned long long *__restrict__ total) {
@@ -400,6 +430,9 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
  * sum, and finds its place in the stream by walking back over its predecessors' published words — a tile's own sum (flag 1) is added and
  * the walk goes on, a tile's inclusive prefix (flag 2) ends it — then publishes its own inclusive prefix and writes its records as the
  * write kernel does.  A word = flag << 62 | bytes: one 8-byte store publishes both.  The records are read once.
+ * The words are published and polled with RELAXED atomic stores and loads at agent scope (they bypass the XCD's L2, nothing else): a word
+ * carries everything it has to say — nothing else is ordered by it.  (First form: release stores and acquire loads at agent scope —
+ * 31 ms against the two kernels' 0.87 per 10 M records: every publish wrote the XCD's L2 back, every poll invalidated it.)
  */
 #define BCF_FLAG_SUM (1ull << 62)
 #define BCF_FLAG_PREFIX (2ull << 62)
@@ -412,11 +445,14 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
   uint8_t *const img = s_img[wid];
   const uint64_t n = clamp_n(a);
   unsigned n_written = 0, n_bad = 0;
-  for (;;) {
-    uint32_t tile = 0;
-    if (lane == 0) tile = atomicAdd(next_tile, 1u);
-    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-    if (tile >= n_tiles) break;
+  /* Tiles are dealt round-robin over the launch's waves, every wave taking its tiles in rising order: the launch is sized so that all its
+   * waves are resident at once, so the tile a wave waits for is in the hands of a running wave.  (Tried: one atomic counter handing out
+   * single tiles in order — 157 k claims on one word took 23 ns each, the kernel's whole time; the counter handing out chunks of 32 tiles
+   * to a workgroup — a chunk's first tile then waits for ALL of the chunk before it: 318 ms.)  A wave that polls a word far longer than
+   * any launch lasts gives up and says so (next_tile[0] = 1: the host runs the two kernels instead) — a launch that was NOT all resident
+   * (the device shared with another process) must still drain. */
+  bool gave_up = false;
+  for (uint32_t tile = blockIdx.x * BCF_WAVES + wid; tile < n_tiles && !gave_up; tile += gridDim.x * BCF_WAVES) {
     rec_regs r;
     const uint8_t *id;
     unsigned id_len;
@@ -435,18 +471,33 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     /* the tile's place: its predecessors' bytes */
     unsigned long long before = 0ull;
     if (tile == 0u) {
-      if (lane == 0) __hip_atomic_store(&state[0], BCF_FLAG_PREFIX | (unsigned long long)t_all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(&state[0], BCF_FLAG_PREFIX | (unsigned long long)t_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      if (lane == 0) __hip_atomic_store(&state[tile], BCF_FLAG_SUM | (unsigned long long)t_all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(&state[tile], BCF_FLAG_SUM | (unsigned long long)t_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       /* 64 predecessors at a time, lane l looking at tile - 1 - l (- 64 per round): the nearest inclusive prefix ends the walk */
       int64_t base = (int64_t)tile - 1;
       for (;;) {
         const int64_t j = base - (int64_t)lane;
         unsigned long long w = BCF_FLAG_PREFIX; /* before tile 0: a prefix of nothing */
         if (j >= 0) {
-          do {
-            w = __hip_atomic_load(&state[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-          } while ((w >> 62) == 0ull);
+          for (unsigned polls = 0;; polls++) {
+            w = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w >> 62) != 0ull) break;
+            if (polls > (1u << 22)) { /* ~ a second */
+              w = BCF_FLAG_PREFIX;
+              gave_up = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        if (__ballot(gave_up)) {
+          gave_up = true;
+          if (lane == 0) {
+            atomicExch(next_tile, 1u);
+            atomicMax(totals, ~0ull); /* a length no buffer holds: the host's check of totals[0] fails the call */
+          }
+          break;
         }
         const unsigned long long is_prefix = __ballot((w >> 62) == 2ull);
         const unsigned first = (unsigned)__builtin_ctzll(is_prefix ? is_prefix : 1ull); /* the nearest prefix among these 64 */
@@ -457,9 +508,13 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         if (is_prefix) break;
         base -= 64;
       }
-      if (lane == 0) __hip_atomic_store(&state[tile], BCF_FLAG_PREFIX | (before + (unsigned long long)t_all), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(&state[tile], BCF_FLAG_PREFIX | (before + (unsigned long long)t_all), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tile == n_tiles - 1u && lane == 0) totals[0] = before + (unsigned long long)t_all;
+    if (gave_up) {
+      if (lane == 0) __hip_atomic_store(&state[tile], BCF_FLAG_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* nobody waits for this one in vain */
+      break;
+    }
+    if (tile == n_tiles - 1u && lane == 0) atomicMax(totals, before + (unsigned long long)t_all);
     const uint64_t g_tile = before;
     if ((uint64_t)tile * 64u >= n || g_tile + t_all > out_cap) continue; /* nothing to write / the host reports the overflow from totals[0] */
     const unsigned t_half = __shfl(inc, 31);
@@ -510,7 +565,7 @@ extern "C" int bsc_dev_scan_u64(const void *in, void *out, uint32_t n, void *tmp
 extern "C" int bsc_dev_launch_bcf(const void *recs, const void *core, const void *aux, const void *n_recs, uint64_t max_recs, int32_t rid,
                                   const bsc_bcf_ids *ids, const void *name_pos, const void *name_off, const void *name_bytes, uint32_t n_names,
                                   void *tile_bytes, void *tile_off, void *scan_tmp, size_t scan_tmp_bytes, void *out, uint64_t out_cap, void *totals,
-                                  int num_cus, void *stream) {
+                                  int num_cus, void *stream, const void *emit_len) {
   hipStream_t s = (hipStream_t)stream;
   bcf_args a;
   a.recs = (const uint8_t *)recs;
@@ -530,22 +585,41 @@ extern "C" int bsc_dev_launch_bcf(const void *recs, const void *core, const void
   unsigned grid = (n_tiles + BCF_WAVES - 1u) / BCF_WAVES;
   if (grid > (unsigned)num_cus * 12u) grid = (unsigned)num_cus * 12u;
   if (grid == 0) grid = 1;
-  static int two_pass = -1; /* BSC_BCF_TWO_PASS in the environment: round 5's size + scan + write kernels (the A/B of tools/bench_bcf.py) */
-  if (two_pass < 0) two_pass = getenv("BSC_BCF_TWO_PASS") != nullptr;
-  if (!two_pass) {
+  static int one_pass = -1; /* BSC_BCF_ONE_PASS in the environment: the look-back kernel (the A/B of tools/bench_bcf.py; slower, see there) */
+  if (one_pass < 0) one_pass = getenv("BSC_BCF_ONE_PASS") != nullptr;
+  if (one_pass) {
     if (n_tiles == 0) return (int)hipMemsetAsync(totals, 0, sizeof(unsigned long long), s);
     hipError_t e1 = hipMemsetAsync(tile_off, 0, (size_t)n_tiles * 8u, s);
     if (e1 == hipSuccess) e1 = hipMemsetAsync(tile_bytes, 0, 8, s);
     if (e1 != hipSuccess) return (int)e1;
-    /* as many waves as are resident at once: every wave takes tiles until none is left */
+    /* as many workgroups as are resident at once (the look-back's guarantee of progress) */
+    static int per_cu = 0;
+    if (!per_cu) {
+      int nb = 0;
+      const hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bsc_bcf_onepass_kernel, 256, 0);
+      per_cu = (eo == hipSuccess && nb > 0) ? nb : 1;
+      (void)hipGetLastError();
+    }
     unsigned g1 = (n_tiles + BCF_WAVES - 1u) / BCF_WAVES;
-    const unsigned cap1 = (unsigned)num_cus * (unsigned)BCF_WAVES_PER_EU;
+    const unsigned cap1 = (unsigned)num_cus * (unsigned)per_cu;
     if (g1 > cap1) g1 = cap1;
     hipLaunchKernelGGL(bsc_bcf_onepass_kernel, dim3(g1), dim3(256), 0, s, a, n_tiles, (unsigned long long *)tile_off, (unsigned int *)tile_bytes, (uint8_t *)out, out_cap,
                        (unsigned long long *)totals);
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL(bsc_bcf_size_kernel, dim3(grid), dim3(256), 0, s, a, n_tiles, (unsigned long long *)tile_bytes, (unsigned long long *)totals + 1);
+  /* the sizes from the chain's length bytes when they can be trusted: per-position form, no names, every dictionary index in one byte */
+  bool short_ids = true;
+  {
+    const int32_t *iv = &ids->pass;
+    for (size_t k = 0; k < sizeof(bsc_bcf_ids) / sizeof(int32_t); k++) short_ids = short_ids && iv[k] >= 0 && iv[k] <= 127;
+  }
+  static int no_len = -1; /* BSC_BCF_NO_LEN_BYTES: the size pass over the records, as in round 5 (A/B) */
+  if (no_len < 0) no_len = getenv("BSC_BCF_NO_LEN_BYTES") != nullptr;
+  if (emit_len && !recs && short_ids && !a.n_names && !no_len)
+    hipLaunchKernelGGL(bsc_bcf_size_bytes_kernel, dim3(grid), dim3(256), 0, s, a, (const uint8_t *)emit_len, n_tiles, (unsigned long long *)tile_bytes,
+                       (unsigned long long *)totals + 1);
+  else
+    hipLaunchKernelGGL(bsc_bcf_size_kernel, dim3(grid), dim3(256), 0, s, a, n_tiles, (unsigned long long *)tile_bytes, (unsigned long long *)totals + 1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   const int rc = bsc_dev_scan_u64(tile_bytes, tile_off, n_tiles + 1u, scan_tmp, scan_tmp_bytes, stream);

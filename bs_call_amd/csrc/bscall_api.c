@@ -75,7 +75,7 @@ int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq, uint64_t 
 int bsc_dev_launch_bcf(const void *recs, const void *core, const void *aux, const void *n_recs, uint64_t max_recs, int32_t rid,
                        const bsc_bcf_ids *ids, const void *name_pos, const void *name_off, const void *name_bytes, uint32_t n_names,
                        void *tile_bytes, void *tile_off, void *scan_tmp, size_t scan_tmp_bytes, void *out, uint64_t out_cap, void *totals,
-                       int num_cus, void *stream); /* bcfdev.hip */
+                       int num_cus, void *stream, const void *emit_len); /* bcfdev.hip */
 int bsc_dev_launch_ref_pad(const void *packed, const void *d_blk, uint32_t n_blk, void *padded, uint32_t n_pos, int num_cus, void *stream);
 int bsc_dev_launch_bin_reads_multi(const void *tpl, uint32_t nr, const void *seq, uint64_t seq_bytes, const void *d_blk, uint32_t n_blk,
                                    uint32_t n_bins, void *tflag, void *bin_cnt, void *bin_off, void *bin_cur, void *scan_tmp,
@@ -158,6 +158,7 @@ struct bsc_context {
   const void *emit_hint; /* set around the bsc_vcf_compact_device call of bsc_records_queue: the flags of exactly these arrays */
   uint8_t *bcf_out;
   int stage_timing; /* BSC_STAGE_TIMING in the environment at bsc_create */
+  int no_emit_bytes; /* BSC_NO_EMIT_BYTES in the environment at bsc_create (A/B builds) */
   int bcf_blk, bcf_keep; /* the block in flight is a BCF block; its stream stays on the device (bsc_block_bcf_rawdev_keep) */
   uint64_t bcf_cap, bcf_copied, bcf_bytes; /* bcf_bytes: the length of the last block's stream (also when it did not fit) */
   double bcf_share;
@@ -385,6 +386,7 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
   ctx->max_launch = BSC_MAX_LAUNCH;
   ctx->rec_share = 0.55; /* WGBS: a record for every C and G and little else */
   ctx->stage_timing = getenv("BSC_STAGE_TIMING") != NULL;
+  ctx->no_emit_bytes = getenv("BSC_NO_EMIT_BYTES") != NULL;
   {
     const char *ml = getenv("BSC_MAX_LAUNCH_SITES");
     if (ml && *ml) {
@@ -1672,7 +1674,7 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
   if ((rc = bsc_reserve(&ctx->d_scantmp, &ctx->cap_scantmp, scan_bytes ? scan_bytes : 1))) return rc;
   const void *emit = gtm_stride == 0 ? ctx->emit_hint : NULL;
   void *emit_ws = NULL;
-  if (gtm_stride == 0 && !emit && !getenv("BSC_NO_EMIT_BYTES")) { /* no flags from the chain kernel: the counting pass leaves them */
+  if (gtm_stride == 0 && !emit && !ctx->no_emit_bytes) { /* no flags from the chain kernel: the counting pass leaves them */
     if ((rc = bsc_reserve(&ctx->d_emit, &ctx->cap_emit, (size_t)n + 64u))) return rc;
     emit_ws = ctx->d_emit;
   }
@@ -1724,8 +1726,9 @@ static int bsc_bcf_encode(bsc_context *ctx, const char *who, const void *d_recs,
     d_nb = (char *)ctx->d_bnm + o_by;
   }
   HIP_TRY(hipMemsetAsync(d_totals, 0, 3 * sizeof(unsigned long long), s));
+  /* (the per-position form behind the chain: the chain's byte per position holds every record's length, ctx->emit_hint) */
   const int e = bsc_dev_launch_bcf(d_recs, d_core, d_aux, d_n_recs, max_recs, rid, ids, d_pos, d_off, d_nb, n_names, ctx->d_btb, ctx->d_bto, ctx->d_bscn,
-                                   scan_bytes, d_out, out_cap, d_totals, ctx->num_cus, stream);
+                                   scan_bytes, d_out, out_cap, d_totals, ctx->num_cus, stream, d_recs ? NULL : ctx->emit_hint);
   if (e) return bsc_fail(BSC_ERR_HIP, "BCF encoder launch failed: %s", hipGetErrorString((hipError_t)e));
   return BSC_OK;
 }
@@ -1880,10 +1883,10 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   void *d_db = dbsnp ? ctx->d_vdb : NULL;
   /* the chain leaves the records' emit flags once more as a byte per position: the packing pass behind it then counts from 64 bytes a tile
    * and fetches the records that are written and nothing of the others (20 M positions: 1.08 -> 0.80 ms) */
-  void *d_emit = NULL; /* the packing pass only: the encoder's write kernel is 5 % slower behind a flag byte than behind the record's first
-                        * 16 bytes (profiles/r05_ab_emit_bytes.txt).  BSC_NO_EMIT_BYTES in the environment: without them (the A/B of
-                        * tools/bench_tail.py) */
-  if (!bcf && !getenv("BSC_NO_EMIT_BYTES")) {
+  void *d_emit = NULL; /* the packing pass counts and gathers by them; the encoder's SIZE pass reads the record lengths they hold since
+                        * round 6 (its write kernel still starts from the record's first 16 bytes: 5 % slower behind a flag byte,
+                        * profiles/r05_ab_emit_bytes.txt).  BSC_NO_EMIT_BYTES in the environment: without them (the A/B of tools/bench_tail.py) */
+  if (!ctx->no_emit_bytes) {
     if ((rc = bsc_reserve(&ctx->d_emit, &ctx->cap_emit, (size_t)sz + 64u))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_emit, 0, (size_t)sz + 64u, s));
     d_emit = ctx->d_emit;
@@ -1903,7 +1906,10 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   ctx->rec_sz = sz;
   ctx->bcf_out = NULL;
   if (bcf) { /* the encoder takes the records where the chain left them (no packing pass); {length, refused, records} come back behind the verdict */
-    if ((rc = bsc_bcf_sites_device(ctx, ctx->d_vout, ctx->d_out, sz, bcf->rid, bcf->ids, bcf->names, ctx->d_bcf, bcf->out_cap, ctx->d_btot, s))) return rc;
+    ctx->emit_hint = d_emit;
+    rc = bsc_bcf_sites_device(ctx, ctx->d_vout, ctx->d_out, sz, bcf->rid, bcf->ids, bcf->names, ctx->d_bcf, bcf->out_cap, ctx->d_btot, s);
+    ctx->emit_hint = NULL;
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->h_cnt + 4, ctx->d_btot, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     uint64_t guess = ctx->bcf_share > 0.0 ? (uint64_t)((double)sz * ctx->bcf_share) + 65536u : 0u;
     if (guess > bcf->out_cap) guess = bcf->out_cap;
@@ -2415,7 +2421,7 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
   if (e) return bsc_fail(BSC_ERR_HIP, "read grouping launch failed: %s", hipGetErrorString((hipError_t)e));
   /* the records' emit flags once more as a byte per position, for the packing pass (bsc_records_queue) */
   void *d_emit = NULL;
-  if (!getenv("BSC_NO_EMIT_BYTES")) {
+  if (!ctx->no_emit_bytes) {
     if ((rc = bsc_reserve(&ctx->d_emit, &ctx->cap_emit, (size_t)P + 64u))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_emit, 0, (size_t)P + 64u, s));
     d_emit = ctx->d_emit;

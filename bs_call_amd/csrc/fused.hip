@@ -750,6 +750,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
     const uint32_t me = former ? sg[2u + lane] : 0u;
     const uint32_t dp1 = cnt[0] + cnt[1] + cnt[2] + cnt[3], d_inf = cnt[4] + cnt[5] + cnt[6] + cnt[7];
     uint32_t flt = 0;
+    uint32_t ebyte = 0; /* the lane's byte of emit flags: 0 = no record is written for its position */
 #ifdef F_EXPERIMENT_SKIP_RECORD /* timing experiment only (tools/build_variant_fused.sh): the tile's cost without the record formation */
     if (false) {
 #else
@@ -873,6 +874,25 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         od[13] = ngl > 4u ? __float_as_uint(f4) : 0u;
         od[2] |= flt | ((uint32_t)phred << 8) | (ngl << 16);
         od[7] = qd;
+        /* The record's length as BCF2 (csrc/bcfdev.hip bcf_emit_body, with one-byte dictionary indices and no ID), for the byte of emit
+         * flags: the encoder's size pass then reads a byte per position instead of the records (round 6).  255 = "ask the record": a
+         * heterozygous call (FS and its FILTER bits come after the tile), a dbSNP-flagged position (its name), anything longer than 254. */
+        if (K_COLD(emit_out)) {
+          uint32_t cm = cnt[0] > cnt[1] ? cnt[0] : cnt[1], n_amq = 0;
+#pragma unroll
+          for (int k = 2; k < 8; k++) cm = cnt[k] > cm ? cnt[k] : cm;
+#pragma unroll
+          for (int k = 0; k < 8; k++) n_amq += cnt[k] > 0u ? 1u : 0u;
+#define F_PI(v) ((v) <= 127u ? 2u : ((v) <= 32767u ? 3u : 5u)) /* put_int of a non-negative value */
+          const uint32_t fb = flt & 15u;
+          const uint32_t ft_len = ((fb & 1u) ? 4u : 0u) + ((fb & 2u) ? 4u : 0u) + ((fb & 4u) ? 5u : 0u) + ((fb & 8u) ? 5u : 0u) + (uint32_t)__popc(fb) - 1u;
+          const uint32_t ft = fb ? (ft_len >= 15u ? 3u : 1u) + ft_len : 5u;
+          const uint32_t cs = ((0x209u >> gt) & 1u) ? 2u : (((0x72u >> gt) & 1u) + ((0x1A4u >> gt) & 1u));
+          const uint32_t len = 32u + 13u + (aix0 ? 2u : 0u) + (aix1 ? 2u : 0u) + 5u + 2u + ft + 2u + F_PI(dp1) + 2u + F_PI((uint32_t)mq) + 2u + F_PI((uint32_t)phred) + 2u +
+                               F_PI(qd) + 3u + 4u * ngl + 3u + 8u * (cm <= 127u ? 1u : (cm <= 32767u ? 2u : 4u)) + (n_amq ? 3u + n_amq : 0u) + 3u + cs + 4u + 8u;
+#undef F_PI
+          ebyte = (het || rs_found || len > 254u) ? 255u : len;
+        }
       }
       od[1] = d1;
       /* ---- facts for the statistics and for the right neighbour ---- */
@@ -942,9 +962,10 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         if (idx < nvec) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(so)[idx], dst + idx);
       }
       uint8_t *const emit_out = K_COLD(emit_out);
-      if (emit_out && lane < nrec) /* the records' emit flags once more, a byte per position: what the packing pass and the BCF encoder
-                                    * look at first (a position without a record then costs them a byte, not a 64-byte sector) */
-        emit_out[(uint64_t)i0 + (MULTI ? a.pos_off : 0u) + lane] = reinterpret_cast<const uint8_t *>(so)[lane * 64u + 4u];
+      const uint32_t eb_ = (uint32_t)__shfl((int)ebyte, (int)((lane + f0) & 63u)); /* record r of the tile is lane r + f0's */
+      if (emit_out && lane < nrec) /* the records' emit flags once more, a byte per position — 0, or the record's BCF2 length (255: look at
+                                    * the record): what the packing pass and the BCF encoder's size pass read instead of the records */
+        emit_out[(uint64_t)i0 + (MULTI ? a.pos_off : 0u) + lane] = (uint8_t)eb_;
       uint8_t *const aux_out = K_COLD(aux_out);
       if (aux_out) { /* what the encoder of a written record reads besides the core record (src/print_vcf.c:306-359): MC8 counts,
                       * AMQ qualities, MQ, mean quality, max_gt, the dbSNP flag — the second half of a bsc_vcf_rec */
