@@ -678,10 +678,17 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
 
     d_bcf2 = torch.empty(cap, dtype=torch.uint8, device=dev)
     d_tot2 = torch.zeros(3, dtype=torch.int64, device=dev)
-    sites_ms = timed(lambda: caller.bcf_sites_device(d_core.data_ptr(), d_aux.data_ptr(), n, 0, d_bcf2.data_ptr(), cap, d_tot2.data_ptr(), stream=stream))
+    # round 6: the chain leaves the records' BCF2 lengths in a byte per position; the size pass reads those (what the block entries run)
+    d_len = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    caller.reads_chain_len_device(d_tpl.data_ptr(), nr, d_seq.data_ptr(), seq_bytes, x, y, d_ref.data_ptr(), d_core.data_ptr(), d_aux.data_ptr(),
+                                  d_len.data_ptr(), with_stats=False, stream=stream)
+    caller.block_status(stream)
+    sites_rec_ms = timed(lambda: caller.bcf_sites_device(d_core.data_ptr(), d_aux.data_ptr(), n, 0, d_bcf2.data_ptr(), cap, d_tot2.data_ptr(), stream=stream))
+    sites_ms = timed(lambda: caller.bcf_sites_len_device(d_core.data_ptr(), d_aux.data_ptr(), d_len.data_ptr(), n, 0, d_bcf2.data_ptr(), cap, d_tot2.data_ptr(),
+                                                         stream=stream))
     pack_ms = timed(lambda: caller.vcf_compact_device(d_core.data_ptr(), d_aux.data_ptr(), 0, n, d_rec.data_ptr(), cap_rec, d_cnt.data_ptr(), stream=stream))
     sites_same = int(d_tot2[0].item()) == nbytes and int(d_tot2[2].item()) == n_rec and bool(torch.equal(d_bcf[:nbytes], d_bcf2[:nbytes]))
-    sites_alg = 2 * (16 * n + 112 * n_rec) + nbytes  # both kernels: 16 B of every position, the other 112 of a written record
+    sites_alg = n + (16 * n + 112 * n_rec) + nbytes  # a length byte per position; the write kernel: 16 B of every position, the other 112 of a written record
     del d_aux, d_bcf2
     m = min(200_000, n_rec)
     want = vcf.bcf_block(d_rec[: m * 128].cpu().numpy().view(B.VCF_REC), 0)
@@ -723,8 +730,9 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
             "algorithmic_bytes_per_launch": sites_alg,
             "achieved": sites_alg / (sites_ms * 1e-3) / 1e9,
             "frac": sites_alg / (sites_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "sector_bytes_per_launch": 2 * 64 * (n + n_rec) + nbytes,
-            "sector_frac": (2 * 64 * (n + n_rec) + nbytes) / (sites_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "sector_bytes_per_launch": n + 64 * (n + n_rec) + nbytes,
+            "sector_frac": (n + 64 * (n + n_rec) + nbytes) / (sites_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "size_pass_over_the_records_ms": sites_rec_ms,
             "sector_note": "what the 16 bytes of a position cost at HBM: its whole 64-byte sector (the records are 64 bytes, one to a sector) — "
             "`frac` counts the algorithmic 16, `sector_frac` the 64 the memory system moves",
             "packing_pass_ms_it_replaces": pack_ms,

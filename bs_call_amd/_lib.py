@@ -136,6 +136,8 @@ EXPORTS = (
     "bsc_block_bcf_rawdev_keep",
     "bsc_bcf_stream_read",
     "bsc_last_raw_block_ms",
+    "bsc_reads_chain_len_device",
+    "bsc_bcf_sites_len_device",
 )
 
 
@@ -550,6 +552,10 @@ def load():
     L.bsc_block_bcf_rawdev_keep.restype = i32
     L.bsc_block_bcf_rawdev_keep.argtypes = [vp, vp, u32, vp, u64, vp, u64, u64, vp, u32, u32, vp, vp, vp, i32, i32, C.POINTER(BcfIds), vp, u64,
                                             C.POINTER(u64), C.POINTER(u64), vp, vp]
+    L.bsc_reads_chain_len_device.restype = i32
+    L.bsc_reads_chain_len_device.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, C.POINTER(VcfParams), i32, vp, vp, vp, vp]
+    L.bsc_bcf_sites_len_device.restype = i32
+    L.bsc_bcf_sites_len_device.argtypes = [vp, vp, vp, vp, u32, i32, C.POINTER(BcfIds), vp, vp, u64, vp, vp]
     L.bsc_last_raw_block_ms.restype = i32
     L.bsc_last_raw_block_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsc_bcf_stream_read.restype = i32

@@ -308,6 +308,23 @@ class SiteCaller:
         _check(self._L.bsc_reads_chain_device(self._h, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_dbsnp, C.byref(p),
                                               1 if with_stats else 0, d_core, d_aux, stream))
 
+    def reads_chain_len_device(self, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, d_aux, d_len, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF,
+                               d_dbsnp=None, with_stats=False, stream=None):
+        """bsc_reads_chain_len_device: reads_chain_device that also leaves every written record's BCF2 length in d_len (a byte per position)."""
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        _check(self._L.bsc_reads_chain_len_device(self._h, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_dbsnp, C.byref(p), 1 if with_stats else 0, d_core,
+                                                  d_aux, d_len, stream))
+
+    def bcf_sites_len_device(self, d_core, d_aux, d_len, n, rid, d_out, out_cap, d_totals, names=None, ids=None, stream=None):
+        """bsc_bcf_sites_len_device: bcf_sites_device sized from the chain's length bytes (the records are read once)."""
+        if ids is None:
+            ids = _lib.BcfIds()
+            self._L.bsc_bcf_default_ids(C.byref(ids))
+        nm, keep = self._bcf_names(names)
+        _check(self._L.bsc_bcf_sites_len_device(self._h, d_core, d_aux, d_len, n, rid, C.byref(ids), None if nm is None else C.addressof(nm), d_out,
+                                                out_cap, d_totals, stream))
+        del keep
+
     def last_reads_chain_ms(self):
         ms = C.c_float()
         _check(self._L.bsc_last_reads_chain_ms(self._h, C.byref(ms)))

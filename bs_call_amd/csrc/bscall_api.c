@@ -1462,6 +1462,26 @@ int bsc_reads_chain_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, con
                                (hipStream_t)stream);
 }
 
+/* bsc_reads_chain_device with the byte per position the block entries keep to themselves: d_len[y - x + 1] (zeroed by the call) receives 0
+ * for a position without a written record, else the record's BCF2 length (255: longer, heterozygous or dbSNP-flagged — the record itself
+ * says) — what bsc_bcf_sites_len_device sizes the stream from */
+int bsc_reads_chain_len_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                               const void *d_ref, const void *d_dbsnp, const bsc_vcf_params *params, int with_stats, void *d_core, void *d_aux,
+                               void *d_len, void *stream) {
+  if (!ctx || !params || !d_ref || !d_core || !d_len) return bsc_fail(BSC_ERR_ARG, "bsc_reads_chain_len_device: NULL argument");
+  if (y < x) return bsc_fail(BSC_ERR_ARG, "bsc_reads_chain_len_device: y (%u) < x (%u)", y, x);
+  if (nr && (!d_tpl || !d_seq)) return bsc_fail(BSC_ERR_ARG, "bsc_reads_chain_len_device: NULL template or read buffer");
+  if (((uintptr_t)d_core & 15u) || ((uintptr_t)d_aux & 15u) || ((uintptr_t)d_tpl & 7u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_reads_chain_len_device: d_core / d_aux must be 16-byte and d_tpl 8-byte aligned");
+  BSC_ENTER(ctx);
+  ctx->blk_tpl = NULL;
+  ctx->blk_d_tpl = d_tpl;
+  ctx->blk_x = x;
+  ctx->mb_n = 0;
+  HIP_TRY(hipMemsetAsync(d_len, 0, (size_t)y - x + 1u, (hipStream_t)stream));
+  return bsc_reads_chain_queue(ctx, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_dbsnp, params, with_stats, d_core, d_aux, d_len, (hipStream_t)stream);
+}
+
 int bsc_last_reads_chain_ms(bsc_context *ctx, float *ms) {
   if (!ctx || !ms) return bsc_fail(BSC_ERR_ARG, "bsc_last_reads_chain_ms: NULL argument");
   if (!ctx->profiling || !ctx->ev_rchain_valid) return bsc_fail(BSC_ERR_ARG, "bsc_last_reads_chain_ms: no profiled launch yet");
@@ -1744,6 +1764,17 @@ int bsc_bcf_block_device(bsc_context *ctx, const void *d_recs, const void *d_n_r
 int bsc_bcf_sites_device(bsc_context *ctx, const void *d_core, const void *d_aux, uint32_t n, int32_t rid, const bsc_bcf_ids *ids,
                          const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream) {
   return bsc_bcf_encode(ctx, "bsc_bcf_sites_device", NULL, d_core, d_aux, NULL, n, rid, ids, names, d_out, out_cap, d_totals, stream);
+}
+
+/* the same with the chain's byte per position (bsc_reads_chain_len_device): the stream is sized from the lengths in it, the records are read
+ * once, by the write kernel (a names table, or a dictionary index beyond 127, sends the size pass back to the records) */
+int bsc_bcf_sites_len_device(bsc_context *ctx, const void *d_core, const void *d_aux, const void *d_len, uint32_t n, int32_t rid, const bsc_bcf_ids *ids,
+                             const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_bcf_sites_len_device: NULL argument");
+  ctx->emit_hint = d_len;
+  const int rc = bsc_bcf_encode(ctx, "bsc_bcf_sites_len_device", NULL, d_core, d_aux, NULL, n, rid, ids, names, d_out, out_cap, d_totals, stream);
+  ctx->emit_hint = NULL;
+  return rc;
 }
 
 /* what bsc_block_bcf asks of bsc_records_queue: the encoder behind the packing, its stream instead of the records on the way back */

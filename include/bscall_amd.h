@@ -690,6 +690,14 @@ int bsc_bcf_block_device(bsc_context *ctx, const void *d_recs, const void *d_n_r
                          const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream);
 int bsc_bcf_sites_device(bsc_context *ctx, const void *d_core, const void *d_aux, uint32_t n, int32_t rid, const bsc_bcf_ids *ids,
                          const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream);
+/* Round 6: the chain kernel leaves every written record's BCF2 LENGTH in a byte per position (0: no record; 255: heterozygous, dbSNP-flagged or
+ * longer than 254 bytes — ask the record), so that the encoder's size pass reads a byte per position and the records are read once, by the
+ * write kernel (the block entries above do this between themselves).  d_len: y - x + 1 bytes, zeroed by the chain's call. */
+int bsc_reads_chain_len_device(bsc_context *ctx, const void *d_tpl, uint32_t nr, const void *d_seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
+                               const void *d_ref, const void *d_dbsnp, const bsc_vcf_params *params, int with_stats, void *d_core, void *d_aux,
+                               void *d_len, void *stream);
+int bsc_bcf_sites_len_device(bsc_context *ctx, const void *d_core, const void *d_aux, const void *d_len, uint32_t n, int32_t rid, const bsc_bcf_ids *ids,
+                             const bsc_bcf_names *names, void *d_out, uint64_t out_cap, void *d_totals, void *stream);
 int bsc_block_bcf(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x, uint32_t y,
                   const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids,
                   const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records);
