@@ -86,6 +86,10 @@ $(LIBDIR)/bamstream.o: $(CSRC)/bamstream.c include/bscall_amd.h
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
+$(LIBDIR)/inflate_fast.o: $(CSRC)/inflate_fast.c include/bscall_amd.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -O3 -c $< -o $@
+
 $(LIBDIR)/bamdev.o: $(CSRC)/bamdev.hip $(CSRC)/bamdev_core.h include/bscall_amd.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Wno-deprecated-declarations -c $< -o $@
@@ -98,7 +102,7 @@ $(LIBDIR)/synth_reads.o: $(CSRC)/synth_reads.c include/bscall_amd.h $(CSRC)/synt
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/prepdev.o $(LIBDIR)/bcfdev.o $(LIBDIR)/bamdev.o $(LIBDIR)/bscall_api.o $(LIBDIR)/bamstream.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o $(LIBDIR)/dbsnp.o $(LIBDIR)/prep.o $(LIBDIR)/report.o $(LIBDIR)/bcf.o $(LIBDIR)/bamio.o $(LIBDIR)/refseq.o
+$(LIBDIR)/libbscall_amd.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/accumulate.o $(LIBDIR)/sort.o $(LIBDIR)/vcfcore.o $(LIBDIR)/sitestats.o $(LIBDIR)/compact.o $(LIBDIR)/probe.o $(LIBDIR)/prepdev.o $(LIBDIR)/bcfdev.o $(LIBDIR)/bamdev.o $(LIBDIR)/bscall_api.o $(LIBDIR)/bamstream.o $(LIBDIR)/inflate_fast.o $(LIBDIR)/synth_reads.o $(LIBDIR)/vcf_format.o $(LIBDIR)/dbsnp.o $(LIBDIR)/prep.o $(LIBDIR)/report.o $(LIBDIR)/bcf.o $(LIBDIR)/bamio.o $(LIBDIR)/refseq.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lz -lpthread
 
 oracle:
@@ -108,7 +112,7 @@ oracle:
 # are the ordinary ones): what tests/test_host_sanitizers.py and tools/fuzz_host_inputs.py run the readers and the host
 # logic under, on the CPU.  Load it with LD_PRELOAD=<libasan.so>:<libubsan.so> BSCALL_AMD_LIB=$(LIBDIR)/san/libbscall_amd_san.so.
 SANFLAGS = -O1 -g -fPIC -Wall -ffp-contract=off -std=gnu11 -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer
-HOST_C = bscall_api synth_reads vcf_format dbsnp prep report bcf bamio bamstream refseq
+HOST_C = bscall_api synth_reads vcf_format dbsnp prep report bcf bamio bamstream inflate_fast refseq
 san: $(LIBDIR)/libbscall_amd.so
 	@mkdir -p $(LIBDIR)/san
 	for f in $(HOST_C); do $(CC) $(SANFLAGS) -c $(CSRC)/$$f.c -o $(LIBDIR)/san/$$f.o || exit 1; done

@@ -135,6 +135,8 @@ EXPORTS = (
     "bsc_block_bcf_rawdev",
     "bsc_block_bcf_rawdev_keep",
     "bsc_bcf_stream_read",
+    "bsc_inflate_raw",
+    "bsc_crc32",
     "bsc_last_raw_block_ms",
     "bsc_reads_chain_len_device",
     "bsc_bcf_sites_len_device",
@@ -556,6 +558,10 @@ def load():
     L.bsc_reads_chain_len_device.argtypes = [vp, vp, u32, vp, u64, u32, u32, vp, vp, C.POINTER(VcfParams), i32, vp, vp, vp, vp]
     L.bsc_bcf_sites_len_device.restype = i32
     L.bsc_bcf_sites_len_device.argtypes = [vp, vp, vp, vp, u32, i32, C.POINTER(BcfIds), vp, vp, u64, vp, vp]
+    L.bsc_inflate_raw.restype = i32
+    L.bsc_inflate_raw.argtypes = [vp, C.c_size_t, vp, C.c_size_t]
+    L.bsc_crc32.restype = u32
+    L.bsc_crc32.argtypes = [vp, C.c_size_t]
     L.bsc_last_raw_block_ms.restype = i32
     L.bsc_last_raw_block_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsc_bcf_stream_read.restype = i32

@@ -216,7 +216,14 @@ static int bgzf_peek(int fd, size_t len, size_t pos, uint64_t *payload_off, uint
   return 1;
 }
 
+static int use_zlib = -1; /* BSC_BAMSTREAM_ZLIB in the environment: zlib's inflate and crc32 instead of csrc/inflate_fast.c (the A/B) */
 static const char *bgzf_inflate_to(const uint8_t *payload, uint32_t clen, uint8_t *dst, uint32_t isize, uint32_t crc) {
+  if (use_zlib < 0) use_zlib = getenv("BSC_BAMSTREAM_ZLIB") != NULL;
+  if (!use_zlib) {
+    if (bsc_inflate_raw(payload, clen, dst, isize)) return "BAM: corrupt BGZF block";
+    if (bsc_crc32(dst, isize) != crc) return "BAM: BGZF checksum mismatch";
+    return NULL;
+  }
   z_stream z;
   memset(&z, 0, sizeof z);
   if (inflateInit2(&z, -15) != Z_OK) return "BAM: zlib initialisation failed";

@@ -806,6 +806,9 @@ uint64_t bsc_bam_malformed(const bsc_bam *b);
  *                          (d_raw 8-byte, d_misms 4-byte aligned; ins_pad >= the sizes of all BSC_MISMS_INS entries: room for the
  *                          padded deletions).  ref / dbsnp / names are host arrays as before.
  */
+/* csrc/inflate_fast.c: raw DEFLATE of one whole block (in -> exactly out_len bytes; 0, or -1 for an invalid stream) and zlib's CRC-32 */
+int bsc_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);
+uint32_t bsc_crc32(const uint8_t *p, size_t n);
 typedef struct bsc_bamstream bsc_bamstream;
 typedef struct {
   const uint8_t *bytes;     /* page-locked */
