@@ -38,6 +38,8 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../include/bscall_amd.h"
 
 int bsc_set_error(int code, const char *fmt, ...);
@@ -73,6 +75,7 @@ typedef struct bs_slab_ {
   uint32_t done;      /* blocks inflated and walked (atomic) */
   uint64_t ready_for; /* sequence number + 1 of the slab-load that is complete in it (under mu) */
   int out;            /* handed to the consumer, not yet released */
+  int allocated;      /* its buffers exist (atomic: the slabs behind the first are made by a thread of their own while the helpers start) */
 } bs_slab;
 
 struct bsc_bamstream {
@@ -114,6 +117,8 @@ struct bsc_bamstream {
   int dbg_nowalk; /* measurement only (BSC_BAMSTREAM_NOWALK at open): no record walk — the helpers' raw inflate rate */
   int unpinned;   /* no device: ordinary memory (the stream is usable without a GPU; uploads from it are staged by the runtime) */
   int idx_threads, idx_serial; /* how the index was built */
+  pthread_t alloc_th;          /* makes the slabs behind the first (page-locking costs ~1 ms per MB) */
+  int alloc_running, alloc_dev, sync_made;
   int32_t *sel_tid; /* a selection of contigs (ascending; -1 = the unplaced reads at the file's end), sel_n < 0: the whole file */
   int sel_n;
 };
@@ -618,6 +623,42 @@ static int build_index(bsc_bamstream *b, int n_threads) {
   return BSC_OK;
 }
 
+/* one slab's buffers; 0 or -1 */
+static int slab_alloc(bsc_bamstream *b, int i) {
+  bs_slab *s = &b->slab[i];
+  if (!b->unpinned) {
+    s->bytes = bsc_alloc_host(b->slab_bytes);
+    if (!s->bytes && i == 0) b->unpinned = 1; /* no device at all: the stream still works, from ordinary memory */
+    else s->rec_off = bsc_alloc_host((size_t)b->rec_cap * 4u);
+  }
+  if (b->unpinned) {
+    void *p1 = NULL, *p2 = NULL;
+    if (posix_memalign(&p1, 4096, b->slab_bytes) || posix_memalign(&p2, 4096, (size_t)b->rec_cap * 4u)) {
+      free(p1);
+      return -1;
+    }
+    s->bytes = p1;
+    s->rec_off = p2;
+  }
+  s->sparse = malloc((size_t)b->sparse_cap * 4u);
+  s->blk = malloc((size_t)b->blk_cap * sizeof(struct bs_blk));
+  if (!s->bytes || !s->rec_off || !s->sparse || !s->blk) return -1;
+  __atomic_store_n(&s->allocated, 1, __ATOMIC_RELEASE);
+  return 0;
+}
+static void *alloc_main(void *arg) {
+  bsc_bamstream *b = (bsc_bamstream *)arg;
+  if (b->alloc_dev >= 0) (void)hipSetDevice(b->alloc_dev);
+  for (int i = 1; i < b->n_slabs; i++)
+    if (slab_alloc(b, i)) {
+      pthread_mutex_lock(&b->mu);
+      set_err(b, "BAM: out of (page-locked) memory");
+      pthread_mutex_unlock(&b->mu);
+      break;
+    }
+  return NULL;
+}
+
 /* ---- the helpers ----------------------------------------------------------------------------------------------------------------- */
 static void *helper(void *arg) {
   bsc_bamstream *b = (bsc_bamstream *)arg;
@@ -646,6 +687,14 @@ static void *helper(void *arg) {
       }
     }
     bs_slab *s = &b->slab[e->seq % (uint32_t)b->n_slabs];
+    while (!__atomic_load_n(&s->allocated, __ATOMIC_ACQUIRE)) { /* (the first passes over the ring only) */
+      if (__atomic_load_n(&b->closing, __ATOMIC_RELAXED) || __atomic_load_n(&b->has_err, __ATOMIC_RELAXED)) {
+        free(raw);
+        return NULL;
+      }
+      struct timespec ts = {0, 50000};
+      nanosleep(&ts, NULL);
+    }
     struct bs_blk *kb = &s->blk[e->blk_ix];
     kb->boff = e->boff;
     kb->isize = e->isize;
@@ -718,7 +767,8 @@ void bsc_bamstream_close(bsc_bamstream *b) {
     pthread_mutex_unlock(&b->mu);
     for (int i = 0; i < b->n_threads; i++) pthread_join(b->th[i], NULL);
   }
-  if (b->th) {
+  if (b->alloc_running) pthread_join(b->alloc_th, NULL);
+  if (b->sync_made) {
     pthread_mutex_destroy(&b->mu);
     pthread_cond_destroy(&b->cv_ready);
   }
@@ -910,25 +960,17 @@ int bsc_bamstream_open_contigs(const char *path, int n_threads, uint64_t slab_by
   b->slab = calloc((size_t)n_slabs, sizeof *b->slab);
   if (!b->slab) goto nomem;
   if (getenv("BSC_BAMSTREAM_UNPINNED")) b->unpinned = 1; /* measurement: ordinary memory */
-  for (int i = 0; i < n_slabs; i++) {
-    if (!b->unpinned) {
-      b->slab[i].bytes = bsc_alloc_host(b->slab_bytes);
-      if (!b->slab[i].bytes && i == 0) b->unpinned = 1; /* no device at all: the stream still works, from ordinary memory */
-      else b->slab[i].rec_off = bsc_alloc_host((size_t)b->rec_cap * 4u);
-    }
-    if (b->unpinned) {
-      void *p1 = NULL, *p2 = NULL;
-      if (posix_memalign(&p1, 4096, b->slab_bytes) || posix_memalign(&p2, 4096, (size_t)b->rec_cap * 4u)) {
-        free(p1);
-        goto nomem;
-      }
-      b->slab[i].bytes = p1;
-      b->slab[i].rec_off = p2;
-    }
-    b->slab[i].sparse = malloc((size_t)b->sparse_cap * 4u);
-    b->slab[i].blk = malloc((size_t)b->blk_cap * sizeof(struct bs_blk));
-    if (!b->slab[i].bytes || !b->slab[i].rec_off || !b->slab[i].sparse || !b->slab[i].blk) goto nomem;
-  }
+  pthread_mutex_init(&b->mu, NULL);
+  pthread_cond_init(&b->cv_ready, NULL);
+  b->sync_made = 1;
+  if (slab_alloc(b, 0)) goto nomem;
+  b->alloc_dev = -1;
+  (void)hipGetDevice(&b->alloc_dev);
+  (void)hipGetLastError();
+  b->alloc_running = pthread_create(&b->alloc_th, NULL, alloc_main, b) == 0; /* the others: while the index is built and the helpers start */
+  if (!b->alloc_running)
+    for (int i = 1; i < n_slabs; i++)
+      if (slab_alloc(b, i)) goto nomem;
   b->w_skip = b->first_rec_off;
   b->dbg_nowalk = getenv("BSC_BAMSTREAM_NOWALK") != NULL;
   {
@@ -940,8 +982,6 @@ int bsc_bamstream_open_contigs(const char *path, int n_threads, uint64_t slab_by
   }
   b->th = calloc((size_t)n_threads, sizeof *b->th);
   if (!b->th) goto nomem;
-  pthread_mutex_init(&b->mu, NULL);
-  pthread_cond_init(&b->cv_ready, NULL);
   for (int i = 0; i < n_threads; i++) {
     if (pthread_create(&b->th[b->n_threads], NULL, helper, b)) break;
     b->n_threads++;
