@@ -120,7 +120,7 @@ san: $(LIBDIR)/libbscall_amd.so
 
 # a plain-C host program against the C ABI: gcc only, links the shared library like bs_call would
 demo: $(LIBDIR)/demo_block $(LIBDIR)/bam2bcf
-$(LIBDIR)/demo_block: integration/demo_block.c integration/mock_work.h integration/amd_overlap_protocol.h include/bscall_amd.h $(LIBDIR)/libbscall_amd.so
+$(LIBDIR)/demo_block: integration/demo_block.c integration/mock_work.h integration/amd_overlap_protocol.h integration/amd_bcf_protocol.h include/bscall_amd.h $(LIBDIR)/libbscall_amd.so
 	$(CC) -O2 -Wall -std=gnu11 -Iinclude -Iintegration $< -o $@ -L$(LIBDIR) -lbscall_amd -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
 # BAM + FASTA -> BCF + JSON report with nothing but the C ABI (the C twin of bs_call_amd/pipeline.py)
 bam2bcf: $(LIBDIR)/bam2bcf
@@ -138,8 +138,8 @@ glue-check:
 	  printf 'typedef struct bam_hdr_t bam_hdr_t; typedef struct htsFile htsFile; typedef struct hts_idx_t hts_idx_t; typedef struct hts_itr_t hts_itr_t; typedef struct bam1_t bam1_t;\n#define FT_UNKN 0\n#define FT_GZ 1\n#define FT_VCF 2\n#define FT_VCF_GZ 3\n#define FT_BCF 4\n#define FT_BCF_GZ 5\n' > $$d/htslib/sam.h; \
 	  printf 'typedef struct bcf_hdr_t bcf_hdr_t; typedef struct bcf1_t bcf1_t;\n' > $$d/htslib/vcf.h; \
 	  printf 'typedef struct faidx_t faidx_t;\n' > $$d/htslib/faidx.h; \
-	  for f in integration/call_genotypes_amd.c integration/call_genotypes_amd_overlap.c; do \
-	    $(CC) -std=gnu11 -Wall -fsyntax-only -D__LINUX__ -I$$d -I$(REF)/include -I$(REF)/gt/include -Iinclude $$f && echo "glue-check: $$f ok" || exit 1; \
+	  for f in integration/call_genotypes_amd.c integration/call_genotypes_amd_overlap.c integration/call_genotypes_amd_bcf.c; do \
+	    $(CC) -std=gnu11 -Wall -fsyntax-only -D__LINUX__ -DAMD_GLUE_CHECK -I$$d -I$(REF)/include -I$(REF)/gt/include -Iinclude $$f && echo "glue-check: $$f ok" || exit 1; \
 	  done; rm -rf $$d; \
 	else echo "glue-check: $(REF) not present, skipped"; fi
 

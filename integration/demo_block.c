@@ -13,6 +13,9 @@
  *                 for every queued template while this thread, like the reference's process thread, overwrites ref1 for the
  *                 next block the moment the call returns.  BSC_DEMO_PRINT_NS in the environment makes the mock printer as
  *                 slow as a real one (nanoseconds per position) for end-to-end timings.
+ *   bytes         INTEGRATION.md 2b, the protocol of integration/call_genotypes_amd_bcf.c itself (integration/amd_bcf_protocol.h): a call
+ *                 queues its block (bsc_block_bcf_submit_inplace) and returns with it in flight; the next call fetches its stretch of the
+ *                 BCF record stream and hands the BYTES to a writer thread.  Checked against bsc_block_bcf block by block.
  *
  * Both forms must deliver the same bytes: the program compares a running hash of every gt_vcf record in consumption
  * order and fails if they differ.  Then it forms VCF records of the last block and the run statistics, as round 1's
@@ -42,6 +45,13 @@ static const char *GT_NAME[10] = {"AA", "AC", "AG", "AT", "CC", "CG", "CT", "GG"
 
 #include "mock_work.h"
 #include "amd_overlap_protocol.h"
+/* the bytes form: the mock's writer hashes what bgzf_write would be given */
+#define AMD_BCF_WRITE(work, buf, n)                                  \
+  do {                                                               \
+    (work)->bcf_hash = mock_fnv((work)->bcf_hash, (buf), (size_t)(n)); \
+    (work)->bcf_bytes += (n);                                        \
+  } while (0)
+#include "amd_bcf_protocol.h"
 
 /* one block of the run: raw templates as the reader delivers them, prepared templates, extent, reference codes */
 typedef struct {
@@ -174,6 +184,56 @@ int main(int argc, char **argv) {
   if (ws.hash != wo.hash || ws.records != wo.records || ws.covered != wo.covered || ws.ref_hash != wo.ref_hash || wo.mprof_bad) {
     fprintf(stderr, "the overlapped form delivered different records\n");
     return 1;
+  }
+
+  /* ---- the bytes form: the same blocks, their BCF record streams to a writer thread; against bsc_block_bcf ---- */
+  {
+    work_t wb, wr;
+    mock_work_init(&wb);
+    mock_work_init(&wr);
+    bsc_bcf_ids ids;
+    bsc_bcf_default_ids(&ids);
+    const bsc_vcf_params vp0 = {0, 1, 0xffffffffu};
+    uint8_t *one = bsc_alloc_host((uint64_t)max_sz * 128u + 4096u);
+    if (!one) { fprintf(stderr, "%s\n", bsc_last_error()); return 1; }
+    uint64_t n_rec_sync = 0;
+    t0 = now();
+    for (int k = 0; k < nblk; k++) { /* one call per block: upload, kernels, copy-out, wait; then the "write" on this thread */
+      const block_t *b = &blk[k];
+      uint64_t nb = 0, nr = 0;
+      CHECK(bsc_block_bcf(ctx, b->tpl, b->nt, b->seq, b->seq_used, b->x, b->y, b->ref, NULL, &vp0, 0, 3, &ids, NULL, one, (uint64_t)max_sz * 128u + 4096u, &nb, &nr));
+      AMD_BCF_WRITE(&wr, one, nb);
+      n_rec_sync += nr;
+    }
+    const double t_bsync = now() - t0;
+    pthread_t mt2;
+    pthread_create(&mt2, NULL, mock_mprof_thread, &wb);
+    amd_bstats = 0;
+    amd_bcf_init(&wb, ctx);
+    t0 = now();
+    uint64_t positions = 0;
+    for (int k = 0; k < nblk; k++) {
+      const block_t *b = &blk[k];
+      mock_prepare_block(&wb, b->ref, b->sz, (int)b->nt < mprof_cap ? (int)b->nt : mprof_cap);
+      amd_bcf_call(&wb, 3, b->tpl, b->nt, b->seq, b->seq_used, b->x, b->y);
+      positions += b->sz;
+    }
+    amd_bcf_join();
+    const double t_bytes = now() - t0;
+    pthread_mutex_lock(&wb.mprof_mutex);
+    wb.mprof_end = true;
+    pthread_cond_signal(&wb.mprof_cond1);
+    pthread_mutex_unlock(&wb.mprof_mutex);
+    pthread_join(mt2, NULL);
+    printf("bytes form end to end: %.1f M positions/s (%llu records, %llu bytes in %.1f ms; one bsc_block_bcf per block: %.1f ms); streams %s; %llu profiling jobs, %llu found ref1 changed\n",
+           (double)positions / t_bytes * 1e-6, (unsigned long long)amd_brecords, (unsigned long long)amd_bbytes, t_bytes * 1e3, t_bsync * 1e3,
+           wb.bcf_hash == wr.bcf_hash && wb.bcf_bytes == wr.bcf_bytes ? "identical" : "DIFFERENT", (unsigned long long)wb.mprof_jobs,
+           (unsigned long long)wb.mprof_bad);
+    if (wb.bcf_hash != wr.bcf_hash || wb.bcf_bytes != wr.bcf_bytes || amd_brecords != n_rec_sync || !amd_brecords || wb.mprof_bad) {
+      fprintf(stderr, "the bytes form delivered a different stream\n");
+      return 1;
+    }
+    bsc_free_host(one);
   }
 
   /* ---- the last block once more: gt_meth, VCF record fields, run statistics (as the print thread derives them) ---- */

@@ -50,6 +50,7 @@ typedef struct {
   uint64_t hash, records, covered; /* print thread: every byte it would read */
   uint64_t ref_hash;               /* print thread: the reference codes it saw beside each block */
   uint64_t mprof_jobs, mprof_bad;  /* profiling thread: jobs done, jobs that found ref1 changed under them */
+  uint64_t bcf_hash, bcf_bytes;    /* the writer of the bytes form (amd_bcf_protocol.h): every byte it was given, in order */
   long print_ns;                   /* BSC_DEMO_PRINT_NS: what the mock printer spends per position on top of hashing it (the
                                       reference's prints a record in about a microsecond) — to time the hand-over under a slow consumer */
 } work_t;

@@ -12,10 +12,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path, name, *flags):
+def _build(tmp_path, name, *flags, src="overlap_tsan.c"):
     exe = str(tmp_path / name)
     cmd = ["gcc", "-O1", "-g", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "integration"), *flags,
-           os.path.join(ROOT, "integration", "overlap_tsan.c"), "-o", exe, "-lpthread"]
+           os.path.join(ROOT, "integration", src), "-o", exe, "-lpthread"]
     p = subprocess.run(cmd, capture_output=True, text=True)
     if p.returncode != 0 and "tsan" in (p.stderr or "").lower():
         pytest.skip("this gcc has no ThreadSanitizer runtime: " + p.stderr[-200:])
@@ -45,3 +45,15 @@ def test_harness_catches_the_round2_protocol(tmp_path):
     p = subprocess.run([exe, "60"], capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 or "ThreadSanitizer: data race" in p.stderr
     assert "mock_prepare_block" in p.stderr or "saw ref1 change" in p.stdout
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not found")
+def test_bytes_form_protocol_is_tsan_clean(tmp_path):
+    """INTEGRATION.md 2b (integration/amd_bcf_protocol.h, the code of integration/call_genotypes_amd_bcf.c): blocks queued in place, their
+    BCF streams fetched one call later and handed to a writer thread in order; every third block longer than the first buffer"""
+    exe = _build(tmp_path, "bcf_tsan", src="bcf_tsan.c")
+    for n in ("1", "2", "61"):
+        p = subprocess.run([exe, n], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "ThreadSanitizer" not in p.stderr, p.stderr[-2000:]
+        assert "stream hash ok" in p.stdout and " 0 saw ref1 change" in p.stdout

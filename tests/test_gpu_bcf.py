@@ -15,6 +15,7 @@ from bs_call_amd import _lib, vcf
 from bs_call_amd.abi import VCF_REC
 from oracle import py_bcf
 
+import oracle_chain as OC
 import test_bcf as TB
 
 pytestmark = pytest.mark.gpu
@@ -198,6 +199,10 @@ def test_block_bcf_equals_block_records_then_the_host_encoder(caller):
     for rep in range(3):  # the first call sizes its copy-out after the wait, the later ones ahead of it
         got, n_rec = caller.block_bcf(tpl, seq, x, y, ref, 7, with_stats=(rep == 0))
         assert n_rec == len(recs) > 50_000 and got == want
+    # ... and, with no product code in between: the CPU oracle chain's records through the Python encoder
+    core, gtm = OC.records(tpl, seq, x, y, ref)
+    OC.same_records(recs, core, gtm)
+    assert got == OC.bcf_stream(core, gtm, 7)
     from tests.test_gpu_chain import _same_stats
 
     _same_stats(caller.site_stats().copy(), st_want)  # (the two methylation profiles are float sums of atomics: equal within 1e-12)
@@ -216,6 +221,10 @@ def test_block_bcf_equals_block_records_then_the_host_encoder(caller):
     recs_all = caller.block_records(tpl, seq, x, y, ref, all_positions=True)
     got, n_rec = caller.block_bcf(tpl, seq, x, y, ref, 0, all_positions=True)
     assert n_rec == len(recs_all) >= y - x and got == vcf.bcf_block(recs_all, 0)
+    core, gtm = OC.records(tpl, seq, x, y, ref, all_positions=True)
+    OC.same_records(recs_all, core, gtm)
+    head = OC.bcf_stream(core[:20_000], gtm[:20_000], 0)
+    assert got[: len(head)] == head
     # out_cap too small: an error that names the size needed, and the context goes on
     with pytest.raises(B.BscError, match="bytes, out_cap is"):
         caller.block_bcf(tpl, seq, x, y, ref, 7, cap=len(want) - 1)
@@ -314,6 +323,11 @@ def test_sites_form_equals_packing_then_encoding(caller):
         assert int((recs["rs_found"] != 0).sum()) > 0 or n_sites < 1000
         got2, total2, _ = _device_stream(caller, recs, 9, names)
         assert got2[:total2].tobytes() == want
+        # ... and the CPU oracle chain's records (with the same dbSNP flags) through the Python encoder, named from the same list
+        core, gtm = OC.records(tpl, seq, x, y, ref, dbsnp=flags)
+        OC.same_records(recs, core, gtm)
+        name_at = {int(p): b for p, b in zip(listed, nm)}
+        assert want == OC.bcf_stream(core, gtm, 9, lambda pos: name_at.get(pos) if int(flags[pos - x]) else None)
 
 
 def test_block_bcf_names_its_records_from_a_dbsnp_index(caller, tmp_path):
@@ -374,6 +388,12 @@ def test_block_bcf_raw_equals_block_records_raw_then_the_host_encoder(caller):
     caller.reset_site_stats()
     got, n_rec, st2 = caller.block_bcf_raw(raw, seq, ms, x, y, ref, 4, with_stats=True, **kw)
     assert n_rec == len(recs) > 1000 and got == want and st2.tobytes() == st.tobytes()
+    # ... and, with no product code in between: py_prep -> the oracle's accumulate / call / record formation -> the Python encoder
+    o_tpl, o_seq, o_st = OC.prepare(ts, **kw)
+    assert {f: int(st2[f]) for f in st2.dtype.names} == o_st
+    core, gtm = OC.records(o_tpl, o_seq, x, y, ref)
+    OC.same_records(recs, core, gtm)
+    assert got == OC.bcf_stream(core, gtm, 4)
     from tests.test_gpu_chain import _same_stats
 
     _same_stats(caller.site_stats().copy(), stats)

@@ -11,6 +11,7 @@ import bs_call_amd as B
 from bs_call_amd.caller import prepare_templates
 from oracle import py_prep
 
+import oracle_chain as OC
 import test_prep as T  # the hand-worked cases and the generators live with the host form's tests
 
 pytestmark = pytest.mark.gpu
@@ -228,6 +229,10 @@ def test_block_records_from_raw_templates(caller):
     got, st = caller.block_records_raw(raw, seq, ms, x, y, ref, with_stats=True, **kw)
     assert len(want) > 1000 and got.tobytes() == want.tobytes() and st.tobytes() == h_st.tobytes()
     assert caller.site_stats().tobytes() == st_want.tobytes()
+    # ... and, with no product code in between, the records of the CPU oracle chain over the same raw templates
+    o_tpl, o_seq, o_st = OC.prepare(ok, **kw)
+    assert {f: int(st[f]) for f in st.dtype.names} == o_st
+    OC.same_records(got, *OC.records(o_tpl, o_seq, x, y, ref))
     # a template the reference aborts on: refused with the host form's words, and the context goes on
     bad = list(ok[:50]) + [T.tpl((3000, 0), (30, 0), (T.read(30), None), (((3, 5, 4),), ()))] + list(ok[50:60])
     raw2, seq2, ms2 = T.to_arrays(bad)
