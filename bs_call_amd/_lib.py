@@ -99,6 +99,8 @@ EXPORTS = (
     "bsc_dbsnp_name",
     "bsc_set_profiling",
     "bsc_set_reads_fused",
+    "bsc_block_bcf_again",
+    "bsc_debug_fail_summary_alloc",
     "bsc_last_kernel_ms",
     "bsc_kernel_ms_history",
     "bsc_synchronize",
@@ -263,6 +265,9 @@ def _share_torch_hip_runtime():
             pass
 
 
+ABI_VERSION = 2  # BSC_ABI_VERSION of include/bscall_amd.h
+
+
 def load():
     """Load the shared library; raise (never fall back) when it has not been built."""
     global _lib
@@ -300,6 +305,8 @@ def load():
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     L.bsc_abi_version.restype = i32
     L.bsc_abi_version.argtypes = []
+    if L.bsc_abi_version() != ABI_VERSION:  # the structs of abi.py mirror ONE header revision
+        raise ImportError("%s has ABI %d, this package mirrors ABI %d: rebuild with `make`" % (LIB_PATH, L.bsc_abi_version(), ABI_VERSION))
     L.bsc_last_error.restype = C.c_char_p
     L.bsc_last_error.argtypes = []
     L.bsc_params_default.restype = None
@@ -447,6 +454,10 @@ def load():
     L.bsc_dbsnp_name.argtypes = [vp, u32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.bsc_set_reads_fused.restype = i32
     L.bsc_set_reads_fused.argtypes = [vp, i32]
+    L.bsc_block_bcf_again.restype = i32
+    L.bsc_block_bcf_again.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.bsc_debug_fail_summary_alloc.restype = i32
+    L.bsc_debug_fail_summary_alloc.argtypes = [vp, i32]
     L.bsc_set_profiling.restype = i32
     L.bsc_set_profiling.argtypes = [vp, i32]
     L.bsc_last_kernel_ms.restype = i32

@@ -439,10 +439,10 @@ class SiteCaller:
                                          C.byref(nr))
 
         rc = go(1 if with_stats else 0)
-        if rc == -1 and nb.value > cap and cap_given is None:  # longer records than the default room: once more, the statistics are in already
+        if rc == -1 and nb.value > cap and cap_given is None:  # longer records than the default room: the encoder alone once more
             cap = int(nb.value)
             out = np.empty(cap, dtype=np.uint8)
-            rc = go(0)
+            rc = self._L.bsc_block_bcf_again(self._h, _ptr(out), cap, C.byref(nb), C.byref(nr))
         _check(rc)
         del keep
         return out[: nb.value].tobytes(), nr.value
@@ -482,10 +482,10 @@ class SiteCaller:
                                              None if pf_ is None else C.byref(pf_))
 
         rc = go(1 if with_stats else 0, st, pf)
-        if rc == -1 and nb.value > cap and cap_given is None:  # as block_bcf; the first pass has counted the bases and the profile too
+        if rc == -1 and nb.value > cap and cap_given is None:  # as block_bcf
             cap = int(nb.value)
             out = np.empty(cap, dtype=np.uint8)
-            rc = go(0, np.zeros(1, dtype=PREP_STATS), None)
+            rc = self._L.bsc_block_bcf_again(self._h, _ptr(out), cap, C.byref(nb), C.byref(nr))
         _check(rc)
         del keep
         if pf is not None:
@@ -528,7 +528,7 @@ class SiteCaller:
         if rc == -1 and nb.value > cap and cap_given is None:
             cap = int(nb.value)
             out = np.empty(cap, dtype=np.uint8)
-            rc = go(0, np.zeros(1, dtype=PREP_STATS), None)
+            rc = self._L.bsc_block_bcf_again(self._h, _ptr(out), cap, C.byref(nb), C.byref(nr))
         _check(rc)
         del keep
         if pf is not None:
@@ -756,6 +756,10 @@ class SiteCaller:
     def set_reads_fused(self, fused=True):
         """reads -> records in ONE kernel (True) or through a pile-up in HBM (False, the default: faster)."""
         _check(self._L.bsc_set_reads_fused(self._h, 1 if fused else 0))
+
+    def debug_fail_summary_alloc(self, on=True):
+        """test hook: the two-kernel form's summaries cannot be allocated (bsc_debug_fail_summary_alloc)"""
+        _check(self._L.bsc_debug_fail_summary_alloc(self._h, 1 if on else 0))
 
     def set_profiling(self, enable=True):
         _check(self._L.bsc_set_profiling(self._h, 1 if enable else 0))

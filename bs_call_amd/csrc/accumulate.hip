@@ -61,6 +61,7 @@ __device__ static __forceinline__ uint32_t template_error(const bsc_template_dev
   if (tp.bs_strand > 2) return BSC_TERR_STRAND;
   if (tp.len[0] && (tp.off[0] > seq_bytes || tp.len[0] > seq_bytes - tp.off[0])) return BSC_TERR_RANGE0;
   if (tp.len[1] && (tp.off[1] > seq_bytes || tp.len[1] > seq_bytes - tp.off[1])) return BSC_TERR_RANGE1;
+  if (tp.flags & ~(TPL_WALK_KNOWN | TPL_WALKED0)) return BSC_TERR_FLAGS; /* the device trusts the two bits: junk there is refused */
   return 0;
 }
 

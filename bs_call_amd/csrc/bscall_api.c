@@ -151,6 +151,22 @@ struct bsc_context {
    * many bytes went ahead of the length, the bytes per position the next copy is sized from */
   void *d_btb, *d_bto, *d_bscn, *d_bnm, *d_bcf, *d_btot;
   size_t cap_btb, cap_bto, cap_bscn, cap_bnm, cap_bcf, cap_btot;
+  void *h_names; /* page-locked: a block entry's names table on its way up (bsc_names_upload) */
+  size_t cap_hnm;
+  const bsc_bcf_names *names_up; /* set around the encoder's call of a block entry: this table is in d_bnm already */
+  uint32_t names_up_n;
+  uint64_t names_up_bytes;
+  struct { /* the last BCF block's stream was longer than the caller's room: what bsc_block_bcf_again encodes once more, from the per-position
+            * arrays still in d_vout / d_out (nothing of the block is computed or counted a second time) */
+    int valid, have_names, inexact;
+    uint32_t sz, n_names;
+    uint64_t name_bytes;
+    int32_t rid;
+    bsc_bcf_ids ids;
+    const void *emit;
+    bsc_bcf_names names;
+  } again;
+  int no_h2d_turns; /* BSC_NO_H2D_TURNS in the environment when the context was made (the A/B of tools/bench_two_contexts.py) */
   void *d_emit; /* the chain's emit flags, a byte per position, for the block entries' packing / encoding passes (bsc_records_queue) */
   size_t cap_emit;
   hipEvent_t ev_h2d; /* recorded behind a block's uploads (bsc_records_queue): the next block of ANY context on this device starts its own
@@ -177,6 +193,7 @@ struct bsc_context {
   void *d_refp; /* bsc_blocks_submit_to_inplace: the caller's packed reference codes, before bsc_ref_pad_kernel lays them out */
   size_t cap_refp;
   const uint32_t *mb_toff;
+  int dbg_fail_summary; /* bsc_debug_fail_summary_alloc */
   int reads_fused; /* bsc_set_reads_fused: 1 = the one-kernel form always; 0 = site summaries through HBM when they can be allocated */
   void *d_fscr; /* reads-in chain: forward-count scratch lines of the resident waves */
   size_t cap_fscr;
@@ -387,6 +404,7 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
   ctx->rec_share = 0.55; /* WGBS: a record for every C and G and little else */
   ctx->stage_timing = getenv("BSC_STAGE_TIMING") != NULL;
   ctx->no_emit_bytes = getenv("BSC_NO_EMIT_BYTES") != NULL;
+  ctx->no_h2d_turns = getenv("BSC_NO_H2D_TURNS") != NULL;
   {
     const char *ml = getenv("BSC_MAX_LAUNCH_SITES");
     if (ml && *ml) {
@@ -477,6 +495,7 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_bto);
   hipFree(ctx->d_bscn);
   hipFree(ctx->d_bnm);
+  if (ctx->h_names) hipHostFree(ctx->h_names);
   hipFree(ctx->d_bcf);
   hipFree(ctx->d_btot);
   hipFree(ctx->d_emit);
@@ -838,6 +857,9 @@ static int bsc_verdict(bsc_context *ctx, const unsigned long long f[2], int *ine
         return bsc_fail(BSC_ERR_ARG, "accumulate: template %u has orientation %u (reference asserts ori < 2)", i,
                         t->orientation);
       case BSC_TERR_STRAND: return bsc_fail(BSC_ERR_ARG, "accumulate: template %u has bs_strand %u", i, t->bs_strand);
+      case BSC_TERR_FLAGS:
+        return bsc_fail(BSC_ERR_ARG, "accumulate: template %u has flags 0x%x (only BSC_TPL_WALK_KNOWN | BSC_TPL_WALKED0 are defined: ABI %d)", i, t->flags,
+                        BSC_ABI_VERSION);
       default:
         return bsc_fail(BSC_ERR_ARG, "accumulate: read %d of template %u lies outside the read buffer",
                         (int)(f[1] & 0xffu) - BSC_TERR_RANGE0, i);
@@ -980,6 +1002,7 @@ int bsc_vcf_records(bsc_context *ctx, const void *gtm, uint32_t gtm_stride, cons
   if (n == 0) return BSC_OK;
   if (!gtm || !skip || !ref || !out) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_records: NULL buffer");
   BSC_ENTER(ctx);
+  ctx->again.valid = 0; /* (d_out is about to be rewritten) */
   if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)n * gtm_stride))) return rc;
   if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)n))) return rc;
   if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)n + 2))) return rc;
@@ -1007,6 +1030,7 @@ int bsc_block_submit(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, con
   if (y < x) return bsc_fail(BSC_ERR_ARG, "bsc_block_submit: y (%u) < x (%u)", y, x);
   if ((rc = bsc_accumulate_queue2(ctx, tpl, nr, seq, seq_bytes, x, y, ref, 1))) return rc;
   const uint64_t sz = (uint64_t)y - x + 1;
+  ctx->again.valid = 0; /* (d_out is about to be rewritten) */
   if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)sz * out_stride))) return rc;
   if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)sz))) return rc;
   if ((rc = bsc_call_sites_device(ctx, ctx->d_cts, ctx->d_ref, sz, ctx->d_out, out_stride, ctx->d_skip, ctx->stream)))
@@ -1075,6 +1099,7 @@ static int bsc_blocks_submit_to_(bsc_context *ctx, const bsc_block_desc *blocks,
   if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_cts, &ctx->cap_cts, (size_t)P * 104u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)P))) return rc;
+  ctx->again.valid = 0; /* (d_out is about to be rewritten) */
   if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)P * out_stride))) return rc;
   if ((rc = bsc_reserve(&ctx->d_skip, &ctx->cap_skip, (size_t)P))) return rc;
   if ((rc = bsc_reserve(&ctx->d_mblk, &ctx->cap_mblk, (size_t)n_blocks * sizeof(bsc_chain_mblock)))) return rc;
@@ -1197,6 +1222,12 @@ int bsc_block_fetch(bsc_context *ctx, void *out, uint8_t *skip) {
 int bsc_set_reads_fused(bsc_context *ctx, int fused) {
   if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_set_reads_fused: ctx is NULL");
   ctx->reads_fused = fused != 0;
+  return BSC_OK;
+}
+
+int bsc_debug_fail_summary_alloc(bsc_context *ctx, int on) {
+  if (!ctx) return bsc_fail(BSC_ERR_ARG, "bsc_debug_fail_summary_alloc: ctx is NULL");
+  ctx->dbg_fail_summary = on != 0;
   return BSC_OK;
 }
 
@@ -1398,10 +1429,10 @@ static int bsc_reads_chain_queue(bsc_context *ctx, const void *d_tpl, uint32_t n
     /* 48 bytes per position of HBM the one-kernel form does not need (a maximal block of 2^28 positions: 13 GB); kept, grow-only,
      * in the context.  No room: the lean form — silently, and with the runtime's error state cleared (ROCm keeps a failed
      * hipMalloc as its last error, which the launch check below would otherwise report as its own).
-     * BSC_TEST_FAIL_SUMMARY_ALLOC in the environment makes this allocation fail for real (tests/test_gpu_reads_chain.py). */
+     * bsc_debug_fail_summary_alloc makes this allocation fail for real (tests/test_gpu_reads_chain.py). */
     const size_t n_pad = ((size_t)w.n + 63u) / 64u * 64u;
     size_t need = n_pad * bsc_dev_summary_bytes();
-    if (getenv("BSC_TEST_FAIL_SUMMARY_ALLOC")) {
+    if (ctx->dbg_fail_summary) {
       void *never = NULL;
       size_t cap0 = 0;
       if (!bsc_try_reserve(&never, &cap0, (size_t)1 << 60)) need = 0;
@@ -1705,6 +1736,52 @@ int bsc_vcf_compact_device(bsc_context *ctx, const void *d_core, const void *d_g
 }
 
 /* ---- the BCF stream of packed records, encoded on the device (bcfdev.hip) ----------------------------------- */
+static int bsc_names_check(const char *who, const bsc_bcf_names *names, uint32_t *n_names, uint64_t *name_bytes) {
+  *n_names = 0;
+  *name_bytes = 0;
+  if (!names || !names->n) return BSC_OK;
+  if (!names->pos || !names->off || (!names->bytes && names->off[names->n])) return bsc_fail(BSC_ERR_ARG, "%s: a names table with NULL arrays", who);
+  for (uint32_t i = 0; i < names->n; i++) {
+    if (names->off[i] > names->off[i + 1] || (i && names->pos[i] <= names->pos[i - 1]))
+      return bsc_fail(BSC_ERR_ARG, "%s: names table entry %u: positions must ascend, offsets must not descend", who, i);
+  }
+  *n_names = names->n;
+  *name_bytes = names->off[names->n];
+  return BSC_OK;
+}
+
+/* A block entry's names table (bsc_block_bcf*): positions | offsets | bytes copied into a page-locked area of the context's and queued
+ * with the block's other uploads, AHEAD of its kernels — the caller's arrays are free when the call returns, and the submit / fetch
+ * split overlaps for dbSNP runs as well (from ordinary memory behind the kernels, the runtime either staged the copy itself, holding the
+ * call until the kernels were through, or read the arrays after the call had returned).  bsc_bcf_encode finds ctx->names_up == names. */
+static int bsc_names_upload(bsc_context *ctx, const char *who, const bsc_bcf_names *names, hipStream_t s) {
+  ctx->names_up = NULL;
+  uint32_t n = 0;
+  uint64_t nb = 0;
+  int rc;
+  if ((rc = bsc_names_check(who, names, &n, &nb))) return rc;
+  if (!n) return BSC_OK;
+  const size_t o_off = (size_t)n * 4u, o_by = o_off + ((size_t)n + 1u) * 4u, total = o_by + (size_t)nb;
+  if (total + 1u > ctx->cap_hnm) {
+    if (ctx->h_names) hipHostFree(ctx->h_names);
+    ctx->h_names = NULL;
+    ctx->cap_hnm = 0;
+    const size_t sz = total + total / 4 + 4096u;
+    if (hipHostMalloc(&ctx->h_names, sz, hipHostMallocDefault) != hipSuccess) return bsc_fail(BSC_ERR_NOMEM, "%s: hipHostMalloc(%zu) failed", who, sz);
+    ctx->cap_hnm = sz;
+  }
+  if ((rc = bsc_reserve(&ctx->d_bnm, &ctx->cap_bnm, total + 1u))) return rc;
+  char *h = (char *)ctx->h_names;
+  memcpy(h, names->pos, (size_t)n * 4u);
+  memcpy(h + o_off, names->off, ((size_t)n + 1u) * 4u);
+  if (nb) memcpy(h + o_by, names->bytes, (size_t)nb);
+  HIP_TRY(hipMemcpyAsync(ctx->d_bnm, h, total, hipMemcpyHostToDevice, s));
+  ctx->names_up = names;
+  ctx->names_up_n = n;
+  ctx->names_up_bytes = nb;
+  return BSC_OK;
+}
+
 /* d_recs != NULL: packed records, *d_n_recs of them; else d_core / d_aux: the per-position arrays of the reads-in chain, max_recs positions */
 static int bsc_bcf_encode(bsc_context *ctx, const char *who, const void *d_recs, const void *d_core, const void *d_aux, const void *d_n_recs,
                           uint64_t max_recs, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, void *d_out, uint64_t out_cap,
@@ -1713,34 +1790,35 @@ static int bsc_bcf_encode(bsc_context *ctx, const char *who, const void *d_recs,
   if (d_recs ? !d_n_recs : (max_recs && (!d_core || !d_aux))) return bsc_fail(BSC_ERR_ARG, "%s: NULL argument", who);
   if (((uintptr_t)d_recs & 15u) || ((uintptr_t)d_core & 15u) || ((uintptr_t)d_aux & 15u) || ((uintptr_t)d_n_recs & 7u) || ((uintptr_t)d_totals & 7u))
     return bsc_fail(BSC_ERR_ARG, "%s: the records must be 16-byte, the count and the totals 8-byte aligned", who);
+  if ((uintptr_t)d_out & 15u) /* the write kernel owns whole 16-byte pieces of the stream, counted from its start */
+    return bsc_fail(BSC_ERR_ARG, "%s: d_out must be 16-byte aligned (append blocks at multiples of 16, or encode into a buffer of its own)", who);
   if (max_recs > 0x1fffffffc0ull) return bsc_fail(BSC_ERR_ARG, "%s: more than 2^37 records", who);
   uint32_t n_names = 0;
   uint64_t name_bytes = 0;
-  if (names && names->n) {
-    if (!names->pos || !names->off || (!names->bytes && names->off[names->n])) return bsc_fail(BSC_ERR_ARG, "%s: a names table with NULL arrays", who);
-    n_names = names->n;
-    name_bytes = names->off[n_names];
-    for (uint32_t i = 0; i < n_names; i++) {
-      if (names->off[i] > names->off[i + 1] || (i && names->pos[i] <= names->pos[i - 1]))
-        return bsc_fail(BSC_ERR_ARG, "%s: names table entry %u: positions must ascend, offsets must not descend", who, i);
-    }
-  }
+  const int names_up = names && ctx->names_up == names; /* a block entry: checked and uploaded with the block's other inputs (bsc_names_upload) */
+  int rc;
+  if (names_up) {
+    n_names = ctx->names_up_n;
+    name_bytes = ctx->names_up_bytes;
+  } else if ((rc = bsc_names_check(who, names, &n_names, &name_bytes)))
+    return rc;
   BSC_ENTER(ctx);
   hipStream_t s = (hipStream_t)stream;
   const uint32_t n_tiles = (uint32_t)((max_recs + 63u) / 64u);
   size_t scan_bytes = 0;
   if (bsc_dev_scan_tmp_bytes_u64(n_tiles + 1u, &scan_bytes)) return bsc_fail(BSC_ERR_HIP, "%s: scan size query failed", who);
-  int rc;
   if ((rc = bsc_reserve(&ctx->d_btb, &ctx->cap_btb, ((size_t)n_tiles + 1u) * 8u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_bto, &ctx->cap_bto, ((size_t)n_tiles + 1u) * 8u))) return rc;
   if ((rc = bsc_reserve(&ctx->d_bscn, &ctx->cap_bscn, scan_bytes ? scan_bytes : 1))) return rc;
   const void *d_pos = NULL, *d_off = NULL, *d_nb = NULL;
   if (n_names) { /* positions | offsets | bytes in one workspace */
     const size_t o_off = (size_t)n_names * 4u, o_by = o_off + ((size_t)n_names + 1u) * 4u;
-    if ((rc = bsc_reserve(&ctx->d_bnm, &ctx->cap_bnm, o_by + (size_t)name_bytes + 1u))) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->d_bnm, names->pos, (size_t)n_names * 4u, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync((char *)ctx->d_bnm + o_off, names->off, ((size_t)n_names + 1u) * 4u, hipMemcpyHostToDevice, s));
-    if (name_bytes) HIP_TRY(hipMemcpyAsync((char *)ctx->d_bnm + o_by, names->bytes, (size_t)name_bytes, hipMemcpyHostToDevice, s));
+    if (!names_up) { /* the device-level entries: the caller's arrays, on the caller's stream (page-locked arrays make it a true DMA) */
+      if ((rc = bsc_reserve(&ctx->d_bnm, &ctx->cap_bnm, o_by + (size_t)name_bytes + 1u))) return rc;
+      HIP_TRY(hipMemcpyAsync(ctx->d_bnm, names->pos, (size_t)n_names * 4u, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync((char *)ctx->d_bnm + o_off, names->off, ((size_t)n_names + 1u) * 4u, hipMemcpyHostToDevice, s));
+      if (name_bytes) HIP_TRY(hipMemcpyAsync((char *)ctx->d_bnm + o_by, names->bytes, (size_t)name_bytes, hipMemcpyHostToDevice, s));
+    }
     d_pos = ctx->d_bnm;
     d_off = (char *)ctx->d_bnm + o_off;
     d_nb = (char *)ctx->d_bnm + o_by;
@@ -1800,14 +1878,14 @@ static int bsc_h2d_last_dev = -1;
 static const bsc_context *bsc_h2d_last_ctx = NULL;
 
 static void bsc_h2d_turn_begin(bsc_context *ctx, hipStream_t s) { /* before a block's first upload */
-  if (getenv("BSC_NO_H2D_TURNS")) return;
+  if (ctx->no_h2d_turns) return;
   pthread_mutex_lock(&bsc_h2d_lock);
   if (bsc_h2d_last && bsc_h2d_last_ctx != ctx && bsc_h2d_last_dev == ctx->device) (void)hipStreamWaitEvent(s, bsc_h2d_last, 0);
   pthread_mutex_unlock(&bsc_h2d_lock);
 }
 
 static void bsc_h2d_turn_end(bsc_context *ctx, hipStream_t s) { /* behind its last upload */
-  if (getenv("BSC_NO_H2D_TURNS")) return;
+  if (ctx->no_h2d_turns) return;
   if (!ctx->ev_h2d && hipEventCreateWithFlags(&ctx->ev_h2d, hipEventDisableTiming) != hipSuccess) {
     ctx->ev_h2d = NULL;
     (void)hipGetLastError();
@@ -1870,6 +1948,7 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
     if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
   }
   if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)sz + 2))) return rc;
+  ctx->again.valid = 0; /* (d_out is about to be rewritten) */
   if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)sz * 64u))) return rc; /* the chain's aux array */
   if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)sz * sizeof(bsc_vcf_core)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_recs, &ctx->cap_recs, (size_t)(out_cap ? out_cap : 1) * sizeof(bsc_vcf_rec)))) return rc;
@@ -1910,6 +1989,9 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   }
   if (!(resident && ctx->ref_resident)) HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)sz + 2, hipMemcpyHostToDevice, s));
   if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, dbsnp, (size_t)sz, hipMemcpyHostToDevice, s));
+  if (bcf && (rc = bsc_names_upload(ctx, "bsc_block_bcf", bcf->names, s))) return rc;
+  const bsc_bcf_names *const names_ready = ctx->names_up;
+  ctx->names_up = NULL;
   if (turns) bsc_h2d_turn_end(ctx, s);
   void *d_db = dbsnp ? ctx->d_vdb : NULL;
   /* the chain leaves the records' emit flags once more as a byte per position: the packing pass behind it then counts from 64 bytes a tile
@@ -1938,8 +2020,17 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   ctx->bcf_out = NULL;
   if (bcf) { /* the encoder takes the records where the chain left them (no packing pass); {length, refused, records} come back behind the verdict */
     ctx->emit_hint = d_emit;
+    ctx->again.sz = sz;
+    ctx->again.rid = bcf->rid;
+    ctx->again.ids = *bcf->ids;
+    ctx->again.emit = d_emit;
+    ctx->again.have_names = names_ready != NULL;
+    ctx->again.n_names = ctx->names_up_n;
+    ctx->again.name_bytes = ctx->names_up_bytes;
+    ctx->names_up = names_ready;
     rc = bsc_bcf_sites_device(ctx, ctx->d_vout, ctx->d_out, sz, bcf->rid, bcf->ids, bcf->names, ctx->d_bcf, bcf->out_cap, ctx->d_btot, s);
     ctx->emit_hint = NULL;
+    ctx->names_up = NULL;
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->h_cnt + 4, ctx->d_btot, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     uint64_t guess = ctx->bcf_share > 0.0 ? (uint64_t)((double)sz * ctx->bcf_share) + 65536u : 0u;
@@ -1969,6 +2060,8 @@ static int bsc_bcf_finish(bsc_context *ctx, uint8_t *out, int inexact) {
   ctx->bcf_copied = ctx->bcf_copied < bytes ? ctx->bcf_copied : bytes;
   if (bad) return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf: %llu records with a genotype beyond 9 or more than 6 likelihoods", bad);
   if (bytes > ctx->bcf_cap) {
+    ctx->again.valid = 1; /* bsc_block_bcf_again: the encoder alone, into the room it asks for */
+    ctx->again.inexact = inexact;
     return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf: the block's stream has %llu bytes, out_cap is %llu", bytes, (unsigned long long)ctx->bcf_cap);
   }
   if (ctx->bcf_keep) return bsc_inexact_status(inexact);
@@ -1979,6 +2072,39 @@ static int bsc_bcf_finish(bsc_context *ctx, uint8_t *out, int inexact) {
   }
   if (ctx->rec_sz >= 4096u) ctx->bcf_share = (double)bytes / (double)ctx->rec_sz * 1.02;
   return bsc_inexact_status(inexact);
+}
+
+int bsc_block_bcf_again(bsc_context *ctx, uint8_t *out, uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records) {
+  if (!ctx || !n_bytes || !n_records || !out_cap) return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf_again: NULL argument");
+  *n_bytes = *n_records = 0;
+  if (!ctx->again.valid || ctx->rec_pending || ctx->pending_sz)
+    return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf_again: the last call on this context was not a BCF block refused for its out_cap");
+  BSC_ENTER(ctx);
+  hipStream_t s = ctx->stream;
+  int rc;
+  if ((rc = bsc_reserve(&ctx->d_bcf, &ctx->cap_bcf, (size_t)out_cap))) return rc;
+  ctx->again.names.n = ctx->again.n_names; /* (the table itself is in d_bnm since the block's uploads) */
+  ctx->names_up = ctx->again.have_names ? &ctx->again.names : NULL;
+  ctx->names_up_n = ctx->again.n_names;
+  ctx->names_up_bytes = ctx->again.name_bytes;
+  ctx->emit_hint = ctx->again.emit;
+  rc = bsc_bcf_sites_device(ctx, ctx->d_vout, ctx->d_out, ctx->again.sz, ctx->again.rid, &ctx->again.ids, ctx->names_up, ctx->d_bcf, out_cap, ctx->d_btot, s);
+  ctx->emit_hint = NULL;
+  ctx->names_up = NULL;
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->h_cnt + 4, ctx->d_btot, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const unsigned long long bytes = ctx->h_cnt[4];
+  *n_bytes = ctx->bcf_bytes = bytes;
+  *n_records = ctx->h_cnt[6];
+  if (bytes > out_cap) return bsc_fail(BSC_ERR_ARG, "bsc_block_bcf: the block's stream has %llu bytes, out_cap is %llu", bytes, (unsigned long long)out_cap);
+  if (out && bytes) {
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_bcf, (size_t)bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  ctx->bcf_keep = out == NULL;
+  ctx->again.valid = 0;
+  return bsc_inexact_status(ctx->again.inexact);
 }
 
 /* the one wait of a block queued by bsc_records_queue, and what is left to do after it */
@@ -2375,6 +2501,7 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
   if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)(seq_bytes ? seq_bytes : 1)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_ref, &ctx->cap_ref, (size_t)ref64))) return rc;
+  ctx->again.valid = 0; /* (d_out is about to be rewritten) */
   if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)P * 64u))) return rc; /* the chain's aux array */
   if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)P * sizeof(bsc_vcf_core)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_recs, &ctx->cap_recs, (size_t)(out_cap ? out_cap : 1) * sizeof(bsc_vcf_rec)))) return rc;
@@ -2614,6 +2741,7 @@ int bsc_vcf_stats(bsc_context *ctx, const bsc_vcf_core *core, const void *gtm, u
   if (n == 0) return BSC_OK;
   if (!core || !gtm) return bsc_fail(BSC_ERR_ARG, "bsc_vcf_stats: NULL buffer");
   BSC_ENTER(ctx);
+  ctx->again.valid = 0; /* (d_out is about to be rewritten) */
   if ((rc = bsc_reserve(&ctx->d_out, &ctx->cap_out, (size_t)n * gtm_stride))) return rc;
   if ((rc = bsc_reserve(&ctx->d_vout, &ctx->cap_vout, (size_t)n * sizeof(bsc_vcf_core)))) return rc;
   if (dbsnp && (rc = bsc_reserve(&ctx->d_vdb, &ctx->cap_vdb, (size_t)n))) return rc;

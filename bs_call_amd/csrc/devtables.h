@@ -40,6 +40,7 @@ typedef struct {
 #define BSC_TERR_STRAND 3 /* bs_strand > 2 */
 #define BSC_TERR_RANGE0 4 /* read 0 outside the read buffer */
 #define BSC_TERR_RANGE1 5 /* read 1 outside the read buffer */
+#define BSC_TERR_FLAGS 6  /* bits beyond BSC_TPL_WALK_KNOWN | BSC_TPL_WALKED0 in flags (a caller built before the field existed) */
 
 /* arguments of bsc_dev_launch_chain (fused.hip), filled by bsc_chain_device (bscall_api.c) */
 typedef struct bsc_chain_launch {

@@ -64,7 +64,7 @@ typedef struct {
   uint8_t mapq[2];
   uint8_t orientation; /* gt_strand: 0 FORWARD, 1 REVERSE */
   uint8_t bs_strand;   /* gt_bs_strand: 0 NON_CONVERTED, 1 STRAND_C2T, 2 STRAND_G2A */
-  uint32_t flags;      /* 0, or BSC_TPL_* (ABI 2; the field was padding, required to be 0, before) */
+  uint32_t flags;      /* 0, or BSC_TPL_* (ABI 2; the field was padding, required to be 0, before); any other bit: BSC_ERR_ARG */
 } bsc_template;
 
 /*
@@ -557,6 +557,11 @@ int bsc_last_reads_chain_ms(bsc_context *ctx, float *ms);
  * keeps 48 bytes per position of the largest block seen so far in the context (grow-only; 2.4 GB for a 50 M-position block, 13 GB
  * for a maximal one of 2^28) — a context that must stay lean sets 1. */
 int bsc_set_reads_fused(bsc_context *ctx, int fused);
+/* Test hook (tests/test_gpu_reads_chain.py): on != 0 makes the summaries' allocation of the two-kernel form fail for real — an absurd
+ * request the runtime refuses — so that the quiet fall-back to the one-kernel form can be exercised.  Off in every new context; nothing
+ * in the environment switches it (the switches that are read from the environment — BSC_NO_H2D_TURNS, BSC_NO_EMIT_BYTES,
+ * BSC_STAGE_TIMING, BSC_MAX_LAUNCH_SITES: A/B measurements — are read ONCE, by bsc_create). */
+int bsc_debug_fail_summary_alloc(bsc_context *ctx, int on);
 /* Window sizes for a caller that cuts a resident contig into windows of its own choosing (the reference's blocks are data
  * dependent, src/process_template.c:24-28; SURVEY.md 8d fixes 4 Mi).  bsc_chain_window_size: the largest window <= limit in
  * which every resident wave runs the same number of tiles and the main launch covers the window exactly — CUs x waves per
@@ -663,13 +668,19 @@ int bsc_block_records_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_
  * written records — the typed values of src/print_vcf.c:160-222,267-378 behind bcf_write's fixed fields, byte for byte what
  * bsc_bcf_block (host C, the checker) makes of the same packed records — so that the record formation's tail never touches a host core
  * and ~113 bytes per written record cross PCIe instead of 128.
- *   bsc_bcf_names            the dbSNP names of the block's flagged positions (host arrays; uploaded with the call): pos[n] ascending
+ *   bsc_bcf_names            the dbSNP names of the block's flagged positions (host arrays; the block entries — bsc_block_bcf*, the split
+ *                            forms included — copy them into a page-locked area of the context's and upload them with the block's other
+ *                            inputs, ahead of its kernels: the arrays are the caller's again when the call returns; the device-level
+ *                            entries bsc_bcf_block_device / bsc_bcf_sites[_len]_device queue the upload from the caller's arrays on the
+ *                            caller's stream: keep them unchanged until that stream has passed the call, page-locked for a true DMA):
+ *                            pos[n] ascending
  *                            1-based positions, off[n + 1] offsets into bytes; bsc_dbsnp_names fills one from the loaded contig.  A
  *                            record whose rs_found flag is set and whose position the table lists carries that ID (at most 63 bytes of it)
  *   bsc_bcf_block_device     d_recs[<= max_recs] packed records in HBM, *d_n_recs of them (a device u64: the count bsc_vcf_compact_device
  *                            left) -> d_out[<= out_cap] bytes; d_totals = three device u64 {length of the stream, records bsc_bcf_record
  *                            refuses (gt > 9 or n_gl > 6: counted, written with the values clamped), records written}; a stream longer
- *                            than out_cap is cut at a 64-record boundary, its full length still in d_totals[0].  Asynchronous on `stream`
+ *                            than out_cap is cut at a 64-record boundary, its full length still in d_totals[0].  Asynchronous on `stream`.
+ *                            d_out must be 16-byte aligned (BSC_ERR_ARG otherwise): the write kernel owns whole 16-byte pieces of the stream
  *   bsc_bcf_sites_device     the same from the per-position arrays bsc_reads_chain_device leaves — d_core[n] and d_aux[n] (64 bytes each
  *                            per position, 16-byte aligned) — with no packing pass in between: a position without a record costs 16 bytes
  *   bsc_block_bcf[_raw]      bsc_block_records[_raw] with the encoder in the packing's place: out[out_cap] receives the block's BCF bytes,
@@ -711,6 +722,12 @@ int bsc_block_bcf_submit_inplace(bsc_context *ctx, const bsc_template *tpl, uint
                                  uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid,
                                  const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap);
 int bsc_block_bcf_fetch(bsc_context *ctx, uint64_t *n_bytes, uint64_t *n_records);
+/* After a BCF block entry (bsc_block_bcf, _raw, _rawdev[_keep], bsc_block_bcf_fetch) has answered BSC_ERR_ARG with *n_bytes > out_cap — the
+ * block's stream is longer than the room given — and before anything else is asked of the context: the ENCODER alone once more, from the
+ * per-position arrays the block left in HBM, into out[out_cap] (out == NULL: the stream stays on the device, bsc_bcf_stream_read, out_cap
+ * its room there).  Nothing of the block is computed, counted (bsc_get_stats, the site statistics, the read profile) or uploaded a second
+ * time; the status the refused call would have returned (BSC_OK / BSC_WARN_INEXACT) comes back. */
+int bsc_block_bcf_again(bsc_context *ctx, uint8_t *out, uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records);
 int bsc_block_bcf_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, const bsc_misms *misms,
                       uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
                       const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out,

@@ -47,8 +47,6 @@ static struct amd_bslot {
   uint8_t *out;      /* the block's stretch of the stream, page-locked */
   size_t cap_tpl, cap_seq, cap_ref, cap_out;
   uint64_t n_bytes, n_rec;
-  uint32_t nr, x, y;
-  uint64_t seq_bytes;
   int32_t rid;
   int to_write;      /* handed to the writer, not written yet (under amd_bmu) */
 } amd_bslot[2];
@@ -130,11 +128,10 @@ static void amd_bcf_collect(void) {
   if (amd_bflight < 0) return;
   struct amd_bslot *s = &amd_bslot[amd_bflight];
   int rc = bsc_block_bcf_fetch(amd_bctx, &s->n_bytes, &s->n_rec);
-  if (rc == BSC_ERR_ARG && s->n_bytes > s->cap_out) { /* a block of long records (names, -A over multi-allelic sites): once more, in one call,
-                                                          with the room it asks for; the sums were taken the first time */
+  if (rc == BSC_ERR_ARG && s->n_bytes > s->cap_out) { /* a block of long records (names, -A over multi-allelic sites): the encoder alone once
+                                                          more, with the room it asks for */
     s->out = amd_bgrow(s->out, &s->cap_out, (size_t)s->n_bytes + 4096);
-    rc = bsc_block_bcf(amd_bctx, s->tpl, s->nr, s->seq, s->seq_bytes, s->x, s->y, s->ref, NULL, &amd_bvp, 0, s->rid, &amd_bids, NULL, s->out, s->cap_out,
-                       &s->n_bytes, &s->n_rec);
+    rc = bsc_block_bcf_again(amd_bctx, s->out, s->cap_out, &s->n_bytes, &s->n_rec);
   }
   if (rc < 0) amd_bdie("bsc_block_bcf_fetch"); /* BSC_ERR_ARG here = one of the original's asserts (:186,188) on the block */
   if (rc == BSC_WARN_INEXACT) fprintf(stderr, "bscall_amd: %s\n", bsc_last_error());
@@ -163,10 +160,6 @@ static void amd_bcf_call(AMD_WORK_T *const work, int32_t rid, const bsc_template
   memcpy(s->seq, seq, (size_t)nbytes);
   memcpy(s->ref, AMD_REF1(work), (size_t)sz + 2); /* work->ref1: codes of x .. y + 2 */
   s->ref[sz + 2] = 0;
-  s->nr = nr;
-  s->seq_bytes = nbytes;
-  s->x = x;
-  s->y = y;
   s->rid = rid;
   amd_bcf_collect(); /* block k - 1 */
   if (bsc_block_bcf_submit_inplace(amd_bctx, s->tpl, nr, s->seq, nbytes, x, y, s->ref, NULL /* dbSNP flags: bsc_dbsnp_flags */, &amd_bvp, amd_bstats, rid,

@@ -335,11 +335,9 @@ int main(int argc, char **argv) {
       uint64_t dev_cap = (uint64_t)n * 96 + 4096;
       int rc = bsc_block_bcf_rawdev_keep(ctx, dblk.d_tpl, dblk.nr, dblk.d_seq, dblk.seq_bytes, dblk.d_misms, dblk.n_misms, dblk.ins_pad, &ppar, x, y, ref, NULL,
                                          &vp, 1, dblk.tid, &ids, NULL, dev_cap, &n_bytes, &n_out, &st, &prof);
-      if (rc == BSC_ERR_ARG && n_bytes > dev_cap) { /* a block of long records: once more with the room it asks for */
-        bsc_prep_stats st2;
+      if (rc == BSC_ERR_ARG && n_bytes > dev_cap) { /* a block of long records: the encoder alone once more, with the room it asks for */
         dev_cap = n_bytes + 4096;
-        rc = bsc_block_bcf_rawdev_keep(ctx, dblk.d_tpl, dblk.nr, dblk.d_seq, dblk.seq_bytes, dblk.d_misms, dblk.n_misms, dblk.ins_pad, &ppar, x, y, ref, NULL, &vp,
-                                       0, dblk.tid, &ids, NULL, dev_cap, &n_bytes, &n_out, &st2, NULL);
+        rc = bsc_block_bcf_again(ctx, NULL, dev_cap, &n_bytes, &n_out);
       }
       CHECK(rc);
       t_gpu += (t1 = now()) - t0;
@@ -362,19 +360,17 @@ int main(int argc, char **argv) {
       file_at += n_bytes;
       n_bytes = 0; /* written by the output thread */
     } else if (!host_bcf) { /* the whole block on the device, the encoding included.  Room for 96 bytes per position: a WGBS block writes a
-                      * record of ~113 bytes for every second position; a block that needs more says so and is run again */
+                      * record of ~113 bytes for every second position; a block that needs more says so and is encoded again */
       if ((size_t)n * 96 + 4096 > cap_bcf) {
         bsc_free_host(bcf);
         bcf = pinned(cap_bcf = (size_t)n * 96 + 4096);
       }
       int rc = bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 1, blk.tid, &ids, NULL, bcf,
                                  cap_bcf, &n_bytes, &n_out, &st, &prof);
-      if (rc == BSC_ERR_ARG && n_bytes > cap_bcf) { /* a block of long records: once more with the room it asks for */
+      if (rc == BSC_ERR_ARG && n_bytes > cap_bcf) { /* a block of long records: the encoder alone once more, with the room it asks for */
         bsc_free_host(bcf);
         bcf = pinned(cap_bcf = (size_t)n_bytes + 4096);
-        bsc_prep_stats st2; /* the first pass has counted the block's bases and its profile already */
-        rc = bsc_block_bcf_raw(ctx, blk.tpl, blk.nr, blk.seq, blk.seq_bytes, blk.misms, blk.n_misms, &ppar, x, y, ref, NULL, &vp, 0, blk.tid, &ids, NULL, bcf,
-                               cap_bcf, &n_bytes, &n_out, &st2, NULL);
+        rc = bsc_block_bcf_again(ctx, bcf, cap_bcf, &n_bytes, &n_out);
       }
       CHECK(rc);
     } else if (!host_prep) {

@@ -3,8 +3,8 @@
  * of) on the CPU alone, for ThreadSanitizer: the mock work_t and its profiling thread (integration/mock_work.h), and STUB bsc_* entries
  * in this file — bsc_block_bcf_submit_inplace starts a thread that, a little later (the GPU's kernels and copy-out), reads the block's
  * inputs WHERE THEY LIE, as the real entry does, and writes a "stream" that depends on every input byte into the caller's buffer;
- * bsc_block_bcf_fetch joins it.  Every third block answers that its stream is longer than the buffer (the glue must then take the
- * one-call form with the room asked for).  The process thread overwrites work->ref1 and its own template / read buffers the moment a
+ * bsc_block_bcf_fetch joins it.  Every third block answers that its stream is longer than the buffer (the glue must then ask for
+ * the encoder once more, with the room asked for).  The process thread overwrites work->ref1 and its own template / read buffers the moment a
  * call returns.  Exit status 0 = the writer saw the expected bytes in order, no profiling job saw ref1 change under it.
  *
  *   gcc -O1 -g -fsanitize=thread -Iinclude -Iintegration integration/bcf_tsan.c -o /tmp/bcf_tsan -lpthread && /tmp/bcf_tsan
@@ -80,15 +80,12 @@ int bsc_block_bcf_fetch(bsc_context *ctx, uint64_t *n_bytes, uint64_t *n_records
   return ctx->bytes > ctx->cap ? BSC_ERR_ARG : BSC_OK;
 }
 
-int bsc_block_bcf(bsc_context *ctx, const bsc_template *tpl, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, uint32_t x, uint32_t y, const uint8_t *ref,
-                  const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names,
-                  uint8_t *out, uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records) {
-  (void)dbsnp; (void)params; (void)with_stats; (void)rid; (void)ids; (void)names;
-  if (ctx->busy) return BSC_ERR_ARG;
-  *n_bytes = stub_len(x, y, 1); /* (only reached for the long ones) */
-  *n_records = y - x + 1;
+int bsc_block_bcf_again(bsc_context *ctx, uint8_t *out, uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records) {
+  if (ctx->busy || ctx->bytes <= ctx->cap) return BSC_ERR_ARG; /* only after a refusal */
+  *n_bytes = ctx->bytes;
+  *n_records = ctx->recs;
   if (*n_bytes > out_cap) return BSC_ERR_ARG;
-  stub_stream(tpl, nr, seq, seq_bytes, ref, x, y, 1, out);
+  stub_stream(ctx->tpl, ctx->nr, ctx->seq, ctx->seq_bytes, ctx->ref, ctx->x, ctx->y, 1, out); /* (the real one: from what the block left in HBM) */
   return BSC_OK;
 }
 

@@ -217,6 +217,11 @@ def test_device_side_validation(caller, oracle, tables, libm_exact):
     with pytest.raises(B.BscError) as e:
         caller.accumulate(bad, seq, x, y)
     assert "template 900 has bs_strand 7" in str(e.value)
+    # junk in the flags word (a caller built when it was padding): refused — the device trusts the two bits that are defined
+    junk = tpl.copy()
+    junk["flags"][77] |= 0x100
+    with pytest.raises(B.BscError, match="template 77 has flags 0x1"):
+        caller.accumulate(junk, seq, x, y)
     # nothing is written for a bad block
     out = np.full(y - x + 1, 0x5A, dtype=np.uint8).repeat(200).view(B.GT_METH)
     skip = np.full(y - x + 1, 0x5A, dtype=np.uint8)

@@ -358,6 +358,91 @@ def test_block_bcf_names_its_records_from_a_dbsnp_index(caller, tmp_path):
     assert b"rs" in got
 
 
+def test_split_form_with_names_takes_the_table_with_the_uploads(caller, tmp_path):
+    """bsc_block_bcf_submit_inplace with a names table in ordinary memory: the table is the caller's again when the call returns (it is
+    scribbled over before the fetch), the stream is the blocking call's, and the call returns long before the block is through (the table
+    goes up with the block's other inputs, ahead of its kernels — queued behind them from pageable memory it held the call back)."""
+    import time
+
+    rng = np.random.default_rng(5)
+    x, n = 9_000, 1_500_000
+    tpl, seq, y, ref = _reads_block(88172645463325252 + 71, x, n, 30)
+    sz = y - x + 1
+    flags = (rng.random(sz) < 0.03).astype(np.uint8) * 3
+    listed = (np.flatnonzero(flags) + x).astype(np.uint32)
+    nm = [b"rs%d" % int(v) for v in rng.integers(1, 10**9, len(listed))]
+    off = np.concatenate([[0], np.cumsum([len(b) for b in nm])]).astype(np.uint32)
+    names = (listed, off, b"".join(nm))
+    want, n_want = caller.block_bcf(tpl, seq, x, y, ref, 5, names=names, dbsnp=flags)
+    assert n_want > 500_000 and want.count(b"rs") > 10_000
+    ids = _lib.BcfIds()
+    caller._L.bsc_bcf_default_ids(C.byref(ids))
+    p = _lib.VcfParams(0, 1, 0xFFFFFFFF)
+    pin = {k: B.PinnedBuffer(max(1, a.nbytes), np.uint8) for k, a in (("tpl", tpl), ("seq", seq), ("ref", ref), ("db", flags))}
+    for k, a in (("tpl", tpl), ("seq", seq), ("ref", ref), ("db", flags)):
+        pin[k].array[: a.nbytes] = a.view(np.uint8).reshape(-1)
+    out = B.PinnedBuffer(len(want) + 4096, np.uint8)
+    ratios = []
+    for rep in range(3):
+        pos_a, off_a, by_a = listed.copy(), off.copy(), np.frombuffer(names[2] + b"\0", dtype=np.uint8).copy()
+        st = _lib.BcfNames(pos_a.ctypes.data, off_a.ctypes.data, by_a.ctypes.data, len(pos_a))
+        t0 = time.perf_counter()
+        rc = caller._L.bsc_block_bcf_submit_inplace(caller._h, pin["tpl"].array.ctypes.data, len(tpl), pin["seq"].array.ctypes.data, seq.size, x, y,
+                                                    pin["ref"].array.ctypes.data, pin["db"].array.ctypes.data, C.byref(p), 0, 5, C.byref(ids), C.addressof(st),
+                                                    out.array.ctypes.data, out.array.size)
+        t1 = time.perf_counter()
+        assert rc == 0, rc
+        pos_a[:] = 0  # the table was copied by the call
+        off_a[:] = 0
+        by_a[:] = 0x41
+        nb, nr = C.c_uint64(0), C.c_uint64(0)
+        assert caller._L.bsc_block_bcf_fetch(caller._h, C.byref(nb), C.byref(nr)) == 0
+        t2 = time.perf_counter()
+        assert (out.array[: nb.value].tobytes(), nr.value) == (want, n_want)
+        ratios.append((t1 - t0) / (t2 - t0))
+    assert min(ratios[1:]) < 0.5, ratios  # (the first pass sizes workspaces)
+    for b in list(pin.values()) + [out]:
+        b.free()
+
+
+def test_stream_longer_than_the_room_is_encoded_again_not_computed_again(caller):
+    """bsc_block_bcf_again: a block refused for its out_cap is encoded once more from what it left in HBM — the bytes of a call with enough
+    room, and bsc_get_stats / the site statistics count the block ONCE (round 5's callers ran the whole block a second time)."""
+    x, n = 30_000, 120_000
+    tpl, seq, y, ref = _reads_block(88172645463325252 + 73, x, n, 30)
+    caller.reset_site_stats()
+    s0 = caller.stats()
+    want, n_want = caller.block_bcf(tpl, seq, x, y, ref, 6, with_stats=True)
+    s1 = caller.stats()
+    st_want = caller.site_stats().copy()
+    caller.reset_site_stats()
+    ids = _lib.BcfIds()
+    caller._L.bsc_bcf_default_ids(C.byref(ids))
+    p = _lib.VcfParams(0, 1, 0xFFFFFFFF)
+    small = np.empty(len(want) // 3, dtype=np.uint8)
+    nb, nr = C.c_uint64(0), C.c_uint64(0)
+    t8, s8, r8 = np.ascontiguousarray(tpl), np.ascontiguousarray(seq), np.ascontiguousarray(ref)
+    rc = caller._L.bsc_block_bcf(caller._h, t8.ctypes.data, len(t8), s8.ctypes.data, s8.size, x, y, r8.ctypes.data, None, C.byref(p), 1, 6, C.byref(ids), None,
+                                 small.ctypes.data, small.size, C.byref(nb), C.byref(nr))
+    assert rc == -1 and nb.value == len(want)
+    too_small = np.empty(len(want) - 1, dtype=np.uint8)
+    assert caller._L.bsc_block_bcf_again(caller._h, too_small.ctypes.data, too_small.size, C.byref(nb), C.byref(nr)) == -1 and nb.value == len(want)
+    big = np.empty(len(want) + 100, dtype=np.uint8)
+    assert caller._L.bsc_block_bcf_again(caller._h, big.ctypes.data, big.size, C.byref(nb), C.byref(nr)) == 0
+    assert (big[: nb.value].tobytes(), nr.value) == (want, n_want)
+    s2 = caller.stats()
+    for k in ("sites", "covered", "het_calls"):
+        assert s2[k] - s1[k] == s1[k] - s0[k] > 0, k
+    from tests.test_gpu_chain import _same_stats
+
+    _same_stats(caller.site_stats().copy(), st_want)
+    # nothing to encode again now; and not after another kind of block either
+    assert caller._L.bsc_block_bcf_again(caller._h, big.ctypes.data, big.size, C.byref(nb), C.byref(nr)) == -1
+    # the Python mirror takes that path by itself when the default room is too small (-A over a block: ~190 bytes per position would fit; force it)
+    got, n_got = caller.block_bcf(tpl, seq, x, y, ref, 6)
+    assert (got, n_got) == (want, n_want)
+
+
 def test_block_bcf_raw_equals_block_records_raw_then_the_host_encoder(caller):
     import test_prep as T
     from oracle import py_prep

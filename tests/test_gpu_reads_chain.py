@@ -156,14 +156,14 @@ def test_reads_chain_many_heterozygous_calls_per_wave(caller, oracle, tables, li
 def test_summary_workspace_that_cannot_be_allocated_falls_back_quietly(oracle, tables, libm_exact, monkeypatch):
     """The two-kernel form wants 88 bytes per position of HBM; when that allocation fails the call must run the one-kernel form —
     with the same records, no error, and no stale "out of memory" surfacing at the next launch check (a failed hipMalloc stays
-    behind as the runtime's last error).  BSC_TEST_FAIL_SUMMARY_ALLOC makes the allocation fail for real."""
+    behind as the runtime's last error).  bsc_debug_fail_summary_alloc makes the allocation fail for real."""
     tpl, seq, x, y = _block(SEED + 91, 4_000, 30_000, 30)
     ref2 = B.synth_ref_host(SEED + 91, x, y - x + 3)
     with B.SiteCaller() as c:
         want = _reads_chain(c, tpl, seq, x, y, ref2)
-        monkeypatch.setenv("BSC_TEST_FAIL_SUMMARY_ALLOC", "1")
+        c.debug_fail_summary_alloc(True)
         got = _reads_chain(c, tpl, seq, x, y, ref2)
-        monkeypatch.delenv("BSC_TEST_FAIL_SUMMARY_ALLOC")
+        c.debug_fail_summary_alloc(False)
         again = _reads_chain(c, tpl, seq, x, y, ref2)
     for a in (got, again):
         assert a[0].tobytes() == want[0].tobytes() and a[1].tobytes() == want[1].tobytes()
