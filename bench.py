@@ -541,7 +541,7 @@ def raw_rooflines(args, caller, tpl, seq, d_seq, x, y, ref, reps):
     head = legs["with_read_profile"]
     prep_leg = {
         "bound": "valu_issue",
-        "kernel": "bsc_prep_plan_kernel + rocPRIM prefix sum + bsc_prep_copy_kernel<profile> (+ the profile's max-scan) (bsc_prepare_templates_device)",
+        "kernel": "bsc_prep_plan_kernel + rocPRIM prefix sum + bsc_prep_copy_kernel + the read profile's pass (max-scan, bsc_prep_refmask_kernel, bsc_prep_profile_kernel) (bsc_prepare_templates_device)",
         "what": "raw templates + reads + mismatch lists resident in HBM -> prepared templates + reads (trims, soft clips, mate overlap, indel normalisation; the "
         "base counters; with the read profile as the pipeline runs it): %d templates, %d bases, %d list entries" % (len(raw), seq.size, len(ms)),
         "achieved": head["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": head["frac"], "traffic": head["traffic"],
@@ -603,8 +603,8 @@ def raw_rooflines(args, caller, tpl, seq, d_seq, x, y, ref, reps):
         "bcf_bytes": int(nb.value), "records": int(nr_.value), "bytes_out_per_position": int(nb.value) / n,
         "first_records_equal_host_encoder": bool(len(want) > 0 and got[: min(len(want), head_bytes)].tobytes() == want[: min(len(want), head_bytes)]),
         "first_bytes_compared": int(min(len(want), head_bytes)),
-        "note": "HIP events on the library's own stream, first pre-processing launch to the encoder's last (bsc_last_raw_block_ms); inside: two host waits "
-        "(the prepared size, the verdict), the upload of the block's reference codes (1 B per position, page-locked) and the read profile's counts coming back",
+        "note": "HIP events on the library's own stream, first pre-processing launch to the encoder's last (bsc_last_raw_block_ms); inside: ONE host wait "
+        "(the block's end; round 5 waited for the prepared size as well), the upload of the block's reference codes (1 B per position, page-locked) and the read profile's counts coming back",
     }
     return {"roofline_prep": prep_leg, "raw_to_bcf": raw_leg}
 

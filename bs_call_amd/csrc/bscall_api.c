@@ -71,7 +71,7 @@ int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq, uint64_t 
                         const bsc_prep_params *par, void *ms_work, void *plan, void *out_len, void *out_off, void *scan_tmp,
                         size_t scan_tmp_bytes, void *tpl_out, void *seq_out, uint64_t seq_out_cap, void *cnt, int num_cus, void *stream,
                         const void *prof_ref, uint32_t prof_x, uint32_t prof_n_ref, uint32_t prof_cap, uint32_t prof_used0, void *prof_table,
-                        void *max_pos1, void *used_scan);
+                        void *max_pos1, void *used_scan, void *prof_mask);
 int bsc_dev_launch_bcf(const void *recs, const void *core, const void *aux, const void *n_recs, uint64_t max_recs, int32_t rid,
                        const bsc_bcf_ids *ids, const void *name_pos, const void *name_off, const void *name_bytes, uint32_t n_names,
                        void *tile_bytes, void *tile_off, void *scan_tmp, size_t scan_tmp_bytes, void *out, uint64_t out_cap, void *totals,
@@ -188,6 +188,10 @@ struct bsc_context {
    * host-buffer entry bsc_block_records_raw, the raw templates / reads / lists on the device */
   void *d_pplan, *d_plen, *d_poff, *d_pms, *d_pscan, *d_pcnt, *d_raw, *d_rseq, *d_rms;
   size_t cap_pplan, cap_plen, cap_poff, cap_pms, cap_pscan, cap_pcnt, cap_raw, cap_rseq, cap_rms;
+  unsigned long long *h_prep; /* page-locked: what the pre-processing hands the host (bsc_prep_queue) */
+  size_t cap_hprep;
+  void *d_pmask; /* the read profile's byte per reference code of the block */
+  size_t cap_pmask;
   void *d_pprof, *d_pmax, *d_pused; /* the read profile's counts of one call, the templates' last read positions, their running maximum */
   size_t cap_pprof, cap_pmax, cap_pused;
   void *d_refp; /* bsc_blocks_submit_to_inplace: the caller's packed reference codes, before bsc_ref_pad_kernel lays them out */
@@ -517,6 +521,8 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_pprof);
   hipFree(ctx->d_pmax);
   hipFree(ctx->d_pused);
+  hipFree(ctx->d_pmask);
+  if (ctx->h_prep) hipHostFree(ctx->h_prep);
   hipFree(ctx->d_carry);
   hipFree(ctx->d_logp);
   hipFree(ctx->d_vout);
@@ -1613,20 +1619,12 @@ static int bsc_prep_device_error(bsc_context *ctx, unsigned long long word, cons
   return bsc_fail(rc, "%s (template %u)", msg, ti);
 }
 
-int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms,
-                                 uint64_t n_misms, const bsc_prep_params *par, void *d_tpl_out, void *d_seq_out, uint64_t seq_out_cap,
-                                 uint64_t *seq_out_used, bsc_prep_stats *stats, bsc_read_profile *pf, void *stream) {
-  if (pf && (!pf->ref || !pf->counts || pf->used > pf->cap || !pf->cap)) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: bad read profile");
-  if (!ctx || !par || !seq_out_used || (nr && (!d_raw || !d_tpl_out))) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: NULL argument");
-  if ((seq_bytes && !d_seq) || (n_misms && !d_misms) || (seq_out_cap && !d_seq_out))
-    return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: NULL buffer");
-  if (nr > 0x7fffffffu) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: more than 2^31 - 1 templates in one call");
-  if (((uintptr_t)d_raw & 7u) || ((uintptr_t)d_tpl_out & 7u) || ((uintptr_t)d_misms & 3u))
-    return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: d_raw / d_tpl_out must be 8-byte, d_misms 4-byte aligned");
-  *seq_out_used = 0;
-  if (stats) memset(stats, 0, sizeof *stats);
-  BSC_ENTER(ctx);
-  hipStream_t s = (hipStream_t)stream;
+/* The pre-processing in two halves: everything queued on `s` — the kernels, and the copies of what the host wants of them (the error word and the
+ * base counters, the prepared size, this call's profile counts and the vector's new length) into a page-locked area of the context's —
+ * and, behind a wait that is the CALLER's, their reading.  bsc_prepare_templates_device waits in between; the block entries queue the whole
+ * reads -> records chain behind the first half and wait once, at the block's end (round 6: a block paid a second wait for its prepared size). */
+static int bsc_prep_queue(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms, uint64_t n_misms,
+                          const bsc_prep_params *par, void *d_tpl_out, void *d_seq_out, uint64_t seq_out_cap, const bsc_read_profile *pf, hipStream_t s) {
   int rc;
   size_t scan_bytes = 0;
   const uint32_t n2 = 2u * nr + 1u;
@@ -1637,60 +1635,65 @@ int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t n
   if ((rc = bsc_reserve(&ctx->d_pms, &ctx->cap_pms, (size_t)(n_misms ? n_misms : 1) * sizeof(bsc_misms)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_pscan, &ctx->cap_pscan, scan_bytes ? scan_bytes : 1))) return rc;
   if ((rc = bsc_reserve(&ctx->d_pcnt, &ctx->cap_pcnt, BSC_PREP_CNT_ALL * sizeof(unsigned long long)))) return rc;
-  const size_t prof_bytes = pf ? (size_t)pf->cap * 4u * sizeof(unsigned long long) : 0;
-  if (pf && nr) {
+  const size_t prof_bytes = pf && nr ? (size_t)pf->cap * 4u * sizeof(unsigned long long) : 0;
+  const size_t h_need = (BSC_PREP_CNT_ALL + 2u) * sizeof(unsigned long long) + prof_bytes; /* counters | prepared size | vector length | counts */
+  if (h_need > ctx->cap_hprep) {
+    if (ctx->h_prep) hipHostFree(ctx->h_prep);
+    ctx->h_prep = NULL;
+    ctx->cap_hprep = 0;
+    if (hipHostMalloc((void **)&ctx->h_prep, h_need, hipHostMallocDefault) != hipSuccess)
+      return bsc_fail(BSC_ERR_NOMEM, "bsc_prepare_templates_device: hipHostMalloc(%zu) failed", h_need);
+    ctx->cap_hprep = h_need;
+  }
+  if (prof_bytes) {
     if ((rc = bsc_reserve(&ctx->d_pprof, &ctx->cap_pprof, prof_bytes))) return rc;
     if ((rc = bsc_reserve(&ctx->d_pmax, &ctx->cap_pmax, (size_t)nr * 4u))) return rc;
     if ((rc = bsc_reserve(&ctx->d_pused, &ctx->cap_pused, (size_t)nr * 4u))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_pmask, &ctx->cap_pmask, (size_t)pf->n_ref + 20u))) return rc; /* a byte per code of the block (csrc/prepdev.hip) */
     HIP_TRY(hipMemsetAsync(ctx->d_pprof, 0, prof_bytes, s));
   }
   HIP_TRY(hipMemsetAsync(ctx->d_pcnt, 0, BSC_PREP_CNT_ALL * sizeof(unsigned long long), s));
   HIP_TRY(hipMemsetAsync(ctx->d_pcnt, 0xff, sizeof(unsigned long long), s));
   int e = bsc_dev_launch_prep(d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, par, ctx->d_pms, ctx->d_pplan, ctx->d_plen, ctx->d_poff,
                               ctx->d_pscan, scan_bytes, d_tpl_out, d_seq_out, seq_out_cap, ctx->d_pcnt, ctx->num_cus, s,
-                              pf && nr ? pf->ref : NULL, pf ? pf->x : 0u, pf ? pf->n_ref : 0u, pf ? pf->cap : 0u, pf ? pf->used : 0u,
-                              ctx->d_pprof, ctx->d_pmax, ctx->d_pused);
+                              prof_bytes ? pf->ref : NULL, pf ? pf->x : 0u, pf ? pf->n_ref : 0u, pf ? pf->cap : 0u, pf ? pf->used : 0u,
+                              ctx->d_pprof, ctx->d_pmax, ctx->d_pused, ctx->d_pmask);
   if (e) {
     (void)hipStreamSynchronize(s);
     return bsc_fail(BSC_ERR_HIP, "read pre-processing launch failed: %s", hipGetErrorString((hipError_t)e));
   }
-  unsigned long long h[9], hs[BSC_PREP_CNT_ALL];
-  HIP_TRY(hipMemcpyAsync(hs, ctx->d_pcnt, sizeof hs, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h + 8, (const char *)ctx->d_poff + (size_t)(nr ? 2u * nr : 0u) * 8u, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  uint32_t used_last = 0;
-  uint64_t *delta = NULL;
-  if (pf && nr) { /* this call's counts and the vector's new length */
-    delta = malloc(prof_bytes);
-    if (!delta) {
-      (void)hipStreamSynchronize(s);
-      return bsc_fail(BSC_ERR_NOMEM, "bsc_prepare_templates_device: out of memory");
-    }
-    (void)hipMemcpyAsync(delta, ctx->d_pprof, prof_bytes, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(&used_last, (const char *)ctx->d_pused + (size_t)(nr - 1u) * 4u, 4, hipMemcpyDeviceToHost, s);
+  unsigned long long *h = ctx->h_prep;
+  h[BSC_PREP_CNT_ALL + 1u] = 0; /* the vector's length after the last template (a u32 lands in it) */
+  HIP_TRY(hipMemcpyAsync(h, ctx->d_pcnt, BSC_PREP_CNT_ALL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h + BSC_PREP_CNT_ALL, (const char *)ctx->d_poff + (size_t)(nr ? 2u * nr : 0u) * 8u, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  if (prof_bytes) { /* this call's counts and the vector's new length */
+    HIP_TRY(hipMemcpyAsync(h + BSC_PREP_CNT_ALL + 2u, ctx->d_pprof, prof_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h + BSC_PREP_CNT_ALL + 1u, (const char *)ctx->d_pused + (size_t)(nr - 1u) * 4u, 4, hipMemcpyDeviceToHost, s));
   }
-  hipError_t se = hipStreamSynchronize(s);
-  if (se != hipSuccess) {
-    free(delta);
-    return bsc_fail(BSC_ERR_HIP, "bsc_prepare_templates_device: %s", hipGetErrorString(se));
-  }
-  memcpy(h, hs, 8 * sizeof h[0]);
+  return BSC_OK;
+}
+
+/* ... and what came back, once the stream has passed the copies */
+static int bsc_prep_finish(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, const void *d_misms, const bsc_prep_params *par,
+                           uint64_t *seq_out_used, bsc_prep_stats *stats, bsc_read_profile *pf) {
+  const unsigned long long *hs = ctx->h_prep;
+  unsigned long long h[8];
+  memcpy(h, hs, sizeof h);
   for (unsigned k = 0; k < BSC_PREP_CNT_SLOTS; k++) { /* the plan kernel's wave sums, slot by slot (csrc/prepdev.hip) */
     h[1] += hs[8u + 8u * k];
     h[2] += hs[8u + 8u * k + 1u];
   }
-  if (h[0] != ~0ull) {
-    free(delta);
-    return bsc_prep_device_error(ctx, h[0], d_raw, d_seq, d_misms, par);
-  }
-  if (delta) {
+  if (h[0] != ~0ull) return bsc_prep_device_error(ctx, h[0], d_raw, d_seq, d_misms, par);
+  if (pf && nr) {
+    const uint32_t used_last = (uint32_t)hs[BSC_PREP_CNT_ALL + 1u];
+    const unsigned long long *delta = hs + BSC_PREP_CNT_ALL + 2u;
     if (used_last > pf->used) { /* growing the vector clears everything behind its old end (csrc/prep.c) */
       memset(pf->counts + (size_t)pf->used * 4u, 0, (size_t)(pf->cap - pf->used) * 4u * sizeof(uint64_t));
       pf->used = used_last;
     }
     for (size_t i = 0; i < (size_t)pf->cap * 4u; i++) pf->counts[i] += delta[i];
-    free(delta);
   }
-  *seq_out_used = h[8];
+  if (seq_out_used) *seq_out_used = hs[BSC_PREP_CNT_ALL];
   if (stats) {
     stats->base_clip = h[1];
     stats->base_overlap = h[2];
@@ -1701,6 +1704,34 @@ int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t n
     stats->read_bases = h[7];
   }
   return BSC_OK;
+}
+
+static int bsc_prep_args_check(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms, uint64_t n_misms,
+                               const bsc_prep_params *par, void *d_tpl_out, void *d_seq_out, uint64_t seq_out_cap, const bsc_read_profile *pf) {
+  if (pf && (!pf->ref || !pf->counts || pf->used > pf->cap || !pf->cap)) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: bad read profile");
+  if (!ctx || !par || (nr && (!d_raw || !d_tpl_out))) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: NULL argument");
+  if ((seq_bytes && !d_seq) || (n_misms && !d_misms) || (seq_out_cap && !d_seq_out))
+    return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: NULL buffer");
+  if (nr > 0x7fffffffu) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: more than 2^31 - 1 templates in one call");
+  if (((uintptr_t)d_raw & 7u) || ((uintptr_t)d_tpl_out & 7u) || ((uintptr_t)d_misms & 3u))
+    return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: d_raw / d_tpl_out must be 8-byte, d_misms 4-byte aligned");
+  return BSC_OK;
+}
+
+int bsc_prepare_templates_device(bsc_context *ctx, const void *d_raw, uint32_t nr, const void *d_seq, uint64_t seq_bytes, const void *d_misms,
+                                 uint64_t n_misms, const bsc_prep_params *par, void *d_tpl_out, void *d_seq_out, uint64_t seq_out_cap,
+                                 uint64_t *seq_out_used, bsc_prep_stats *stats, bsc_read_profile *pf, void *stream) {
+  if (!seq_out_used) return bsc_fail(BSC_ERR_ARG, "bsc_prepare_templates_device: NULL argument");
+  int rc = bsc_prep_args_check(ctx, d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, par, d_tpl_out, d_seq_out, seq_out_cap, pf);
+  if (rc) return rc;
+  *seq_out_used = 0;
+  if (stats) memset(stats, 0, sizeof *stats);
+  BSC_ENTER(ctx);
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = bsc_prep_queue(ctx, d_raw, nr, d_seq, seq_bytes, d_misms, n_misms, par, d_tpl_out, d_seq_out, seq_out_cap, pf, s))) return rc;
+  const hipError_t se = hipStreamSynchronize(s);
+  if (se != hipSuccess) return bsc_fail(BSC_ERR_HIP, "bsc_prepare_templates_device: %s", hipGetErrorString(se));
+  return bsc_prep_finish(ctx, d_raw, nr, d_seq, d_misms, par, seq_out_used, stats, pf);
 }
 
 /* ---- written records, packed ------------------------------------------------------------------------------ */
@@ -2201,7 +2232,6 @@ static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32
   if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)nr * sizeof(bsc_template)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_seq, &ctx->cap_seq, (size_t)cap))) return rc;
   hipStream_t s = ctx->stream;
-  uint64_t used = 0;
   bsc_read_profile dp;
   ctx->ref_resident = 0;
   if (profile) { /* the block's reference codes (x .. y + 2) are what the profile reads: up they go first, once */
@@ -2225,16 +2255,21 @@ static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32
     fprintf(stderr, "bsc stage: reserve + reference upload queued %.3f s\n", t1 - t0);
     t0 = t1;
   }
-  rc = bsc_prepare_templates_device(ctx, d_raw, nr, d_rseq, seq_bytes, d_rms, n_misms, prep, ctx->d_tpl, ctx->d_seq, cap, &used, prep_stats,
-                                    profile ? &dp : NULL, s);
-  if (profile) profile->used = dp.used;
-  if (rc) return rc; /* (it has waited for the stream: nothing reads the caller's buffers any more) */
+  /* the pre-processing and everything behind it are queued back to back: the chain takes the room for the prepared reads as the bound of
+   * its read buffer (the device checks every template against it; what the pre-processing wrote lies inside), so the prepared SIZE is not
+   * waited for — one wait per block, at its end */
+  if ((rc = bsc_prep_args_check(ctx, d_raw, nr, d_rseq, seq_bytes, d_rms, n_misms, prep, ctx->d_tpl, ctx->d_seq, cap, profile ? &dp : NULL))) return rc;
+  if (prep_stats) memset(prep_stats, 0, sizeof *prep_stats);
+  if ((rc = bsc_prep_queue(ctx, d_raw, nr, d_rseq, seq_bytes, d_rms, n_misms, prep, ctx->d_tpl, ctx->d_seq, cap, profile ? &dp : NULL, s))) {
+    (void)hipStreamSynchronize(s);
+    return rc;
+  }
   if (timing) {
     t1 = bsc_now_s();
-    fprintf(stderr, "bsc stage: bsc_prepare_templates_device (waits for the prepared size) %.3f s\n", t1 - t0);
+    fprintf(stderr, "bsc stage: pre-processing queued %.3f s\n", t1 - t0);
     t0 = t1;
   }
-  rc = bsc_records_queue(ctx, NULL, nr, NULL, used, x, y, ref, dbsnp, params, with_stats, out, out_cap, 2, bcf);
+  rc = bsc_records_queue(ctx, NULL, nr, NULL, cap, x, y, ref, dbsnp, params, with_stats, out, out_cap, 2, bcf);
   ctx->ref_resident = 0;
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -2246,10 +2281,26 @@ static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32
     fprintf(stderr, "bsc stage: bsc_records_queue (reserves, uploads, launches) %.3f s\n", t1 - t0);
     t0 = t1;
   }
+  const hipError_t se = hipStreamSynchronize(s);
+  if (se != hipSuccess) return bsc_fail(BSC_ERR_HIP, "bsc_block_records_raw: %s", hipGetErrorString(se));
+  if (timing) {
+    t1 = bsc_now_s();
+    fprintf(stderr, "bsc stage: the wait %.3f s\n", t1 - t0);
+    t0 = t1;
+  }
+  /* the pre-processing's verdict first: where the reference aborts on a template, the chain behind it ran over what was left of the block —
+   * checked template by template on the device, its output never looked at */
+  rc = bsc_prep_finish(ctx, d_raw, nr, d_rseq, d_rms, prep, NULL, prep_stats, profile ? &dp : NULL);
+  if (profile) profile->used = dp.used;
+  if (rc) {
+    ctx->bcf_out = NULL;
+    ctx->bcf_blk = 0;
+    return rc;
+  }
   rc = bsc_records_finish(ctx, n_out);
   if (timing) {
     t1 = bsc_now_s();
-    fprintf(stderr, "bsc stage: bsc_records_finish (the wait) %.3f s\n", t1 - t0);
+    fprintf(stderr, "bsc stage: bsc_records_finish %.3f s\n", t1 - t0);
   }
   return rc;
 }

@@ -510,27 +510,41 @@ __device__ static __forceinline__ uint32_t d_ld32(const uint8_t *p) {
 }
 __device__ static __forceinline__ void d_st32(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
-struct prep_prof_rd { /* the read profile's view of one read (wave-uniform) */
-  uint32_t used_t, strand;
-  int64_t v0; /* index of output byte 0 in F.ref, one lower for a read at the block's first position */
-  int32_t pc;
-  bool on;
-};
 struct prep_slow_ret {
   uint32_t c63, cge; /* this lane's bytes of quality 63 / of quality >= mq among those that count */
   uint32_t walked;
 };
 
-template <bool PROF>
+/* output byte j of a read that goes the long way -> its index in the read's window, or `pad` (a padded deletion: no byte of the read):
+ * the list's edits undone, last first — INS (a deletion from the reference) padded `size` zeros in at ix1, DEL (an insertion) cut `size`
+ * bytes out at ix1 */
+__device__ static __forceinline__ uint32_t prep_slow_src(const bsc_prep_plan &P, const bsc_misms *__restrict__ ms, bool edited, uint32_t j, bool &pad) {
+  uint32_t s = j;
+  pad = false;
+  if (edited) {
+    for (uint32_t z = P.nm; z-- > 0;) {
+      const bsc_misms m = ms[z];
+      if (m.type == BSC_MISMS_INS) {
+        if (s >= m.position) {
+          if (s - m.position < m.size) {
+            pad = true;
+            break;
+          }
+          s -= m.size;
+        }
+      } else if (m.type == BSC_MISMS_DEL) {
+        if (s >= m.position) s += m.size;
+      }
+    }
+  }
+  return s;
+}
+
 __device__ __noinline__ static prep_slow_ret prep_slow_read(const bsc_prep_plan *__restrict__ plan_r, uint32_t flags, uint8_t *__restrict__ dp,
-                                                            const uint8_t *__restrict__ seq, const bsc_misms *__restrict__ ms_work, uint32_t mq,
-                                                            uint32_t k, const bsc_prep_prof F, uint32_t *s_prof, const prep_prof_rd pr) {
+                                                            const uint8_t *__restrict__ seq, const bsc_misms *__restrict__ ms_work, uint32_t mq) {
   const unsigned lane = threadIdx.x & 63u;
   prep_slow_ret r = {0u, 0u, 0u};
   const bsc_prep_plan P = *plan_r;
-  struct {
-    uint32_t out_len;
-  } d = {P.out_len};
   const uint8_t *const sp = seq + P.src;
   const bool edited = (flags & PD_EDITED) != 0;
   if (edited) { /* the base counters run over the window, before the normalisation (src/process_template.c:50-59) */
@@ -545,29 +559,11 @@ __device__ __noinline__ static prep_slow_ret prep_slow_read(const bsc_prep_plan 
   }
   const bsc_misms *const ms = ms_work + P.ms;
   bool walked = false;
-  for (uint32_t j0 = 0; j0 < d.out_len; j0 += 64u) {
+  for (uint32_t j0 = 0; j0 < P.out_len; j0 += 64u) {
     const uint32_t j = j0 + lane;
-    if (j < d.out_len) {
-      /* the list's edits undone, last first: INS (a deletion from the reference) padded `size` zeros in at ix1, DEL (an
-       * insertion) cut `size` bytes out at ix1 */
-      uint32_t s = j;
-      bool pad = false;
-      if (edited) {
-        for (uint32_t z = P.nm; z-- > 0;) {
-          const bsc_misms m = ms[z];
-          if (m.type == BSC_MISMS_INS) {
-            if (s >= m.position) {
-              if (s - m.position < m.size) {
-                pad = true;
-                break;
-              }
-              s -= m.size;
-            }
-          } else if (m.type == BSC_MISMS_DEL) {
-            if (s >= m.position) s += m.size;
-          }
-        }
-      }
+    if (j < P.out_len) {
+      bool pad;
+      const uint32_t s = prep_slow_src(P, ms, edited, j, pad);
       const uint32_t byte = pad ? 0u : d_marked(sp, P.w0 + s, P.rl0, P.mark_l, P.mark_r);
       const uint32_t q = byte >> 2;
       if (!edited) { /* nothing cut or padded: the output IS the window, counted as it passes */
@@ -576,26 +572,18 @@ __device__ __noinline__ static prep_slow_ret prep_slow_read(const bsc_prep_plan 
       }
       walked |= q != 0 && q != FLT_QUAL;
       dp[j] = (uint8_t)byte; /* (a read that does not fit the output never gets here) */
-      if (PROF && pr.on && !pad) d_prof_base(F, s_prof, pr.strand, pr.used_t, pr.v0 + j, k ? pr.pc - (int32_t)s : pr.pc + (int32_t)s, byte);
     }
   }
   r.walked = __any(walked) ? 1u : 0u;
   return r;
 }
 
-template <bool PROF>
 __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bsc_prep_plan *__restrict__ plan,
                                                                         const bsc_prep_desc *__restrict__ desc, uint32_t nr,
                                                                         const uint8_t *__restrict__ seq, const bsc_misms *__restrict__ ms_work,
                                                                         const unsigned long long *__restrict__ out_off, int32_t min_qual,
                                                                         bsc_template *__restrict__ tpl_out, uint8_t *__restrict__ seq_out,
-                                                                        uint64_t seq_out_cap, unsigned long long *__restrict__ cnt,
-                                                                        const bsc_prep_prof F) {
-  __shared__ uint32_t s_prof[PROF ? PROF_LDS * 4u : 4u];
-  if (PROF) {
-    for (unsigned i = threadIdx.x; i < PROF_LDS * 4u; i += 64 * PREP_WAVES) s_prof[i] = 0;
-    __syncthreads();
-  }
+                                                                        uint64_t seq_out_cap, unsigned long long *__restrict__ cnt) {
   const unsigned lane = threadIdx.x & 63u, lane4 = lane * 4u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * PREP_WAVES + (threadIdx.x >> 6)));
   const uint32_t n_waves = gridDim.x * PREP_WAVES;
@@ -611,7 +599,6 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
     const uint32_t ri = g0 + (lane < n ? lane : 0u), my_ti = ri >> 1, my_k = ri & 1u;
     bsc_prep_desc L = desc[ri];
     const unsigned long long l_off = out_off[ri];
-    uint32_t l_used = 0, l_pos = 0, l_strand = 0;
     if (lane >= n) L.pk = 0;
     if (lane < n) {
       const uint32_t fl = L.pk >> 28;
@@ -630,29 +617,15 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
         l_reads++;
         l_bases += wl;
       }
-      if (PROF && (fl & PD_PRESENT) && ol != 0) { /* this read's place in the block's codes, its template's share of the vector */
-        const uint32_t before = my_ti ? (F.used_scan[my_ti - 1u] > F.used0 ? F.used_scan[my_ti - 1u] : F.used0) : F.used0;
-        l_used = F.used_scan[my_ti] > before ? F.used_scan[my_ti] : before;
-        /* growing the vector past its capacity is where the host form gives up (csrc/prep.c) */
-        if (l_used > before && (unsigned long long)l_used + 1ull > F.cap) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_CAP);
-        l_strand = tpl_out[my_ti].bs_strand;
-        l_pos = tpl_out[my_ti].pos[my_k];
-        const bool in_ref = l_pos >= F.x && (uint64_t)l_pos - F.x + ol + 1u <= F.n_ref;
-        if (!in_ref) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_RANGE);
-        /* "this read is profiled": inside the block's codes (else the call fails anyway), on a strand that has a profile
-         * (src/init_param.c:57-70: bs_strand 0 .. 2) */
-        if (in_ref && l_strand <= 2u) l_strand |= 0x100u;
-      }
     }
     /* ---- what the walk needs of a read, made here once per lane so that the walk itself is short: every instruction of the
      * walk — vector or scalar — is an issue slot of the wave, and the issue slots are what this kernel runs out of ----
      * l_ctl: length (20 bits) | left mark << 20 (8 bits) | kind << 28 | edited << 30;  kind 0: nothing to do,
-     * KIND_LEAN: the window as it stands, at most 256 bytes, no mark (without the read profile), KIND_FAST: the window, any
-     * length, marked below ml, KIND_SLOW: byte by byte from the full plan */
+     * KIND_LEAN: the window as it stands, at most 256 bytes, no mark, KIND_FAST: the window, any length, marked below ml,
+     * KIND_SLOW: byte by byte from the full plan */
     enum : uint32_t { KIND_LEAN = 1u, KIND_FAST = 2u, KIND_SLOW = 3u };
     const uint32_t my_len = L.pk & 0xfffffu, my_ml = (L.pk >> 20) & 0xffu;
-    const uint32_t my_kind =
-        my_len == 0 ? 0u : ((L.pk >> 28) & PD_SLOW ? KIND_SLOW : ((!PROF && my_len <= 256u && my_ml == 0) ? KIND_LEAN : KIND_FAST));
+    const uint32_t my_kind = my_len == 0 ? 0u : ((L.pk >> 28) & PD_SLOW ? KIND_SLOW : ((my_len <= 256u && my_ml == 0) ? KIND_LEAN : KIND_FAST));
     const uint32_t l_ctl = (L.pk & 0x0fffffffu) | (my_kind << 28) | (((L.pk >> 28) & PD_EDITED) ? 1u << 30 : 0u);
     const bool my_fetch = my_kind == KIND_LEAN || my_kind == KIND_FAST; /* (then my_len >= 4) */
     /* where the read's bytes start, as an offset from desc[] (a pointer the compiler knows to be global memory; a broadcast
@@ -678,7 +651,7 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
         const uint32_t ctl = d_bcast(l_ctl, l), kind = (ctl >> 28) & 3u, len = ctl & 0xfffffu;
         if (kind == 0) continue;
         uint8_t *const dp = seq_out + d_bcast64(l_off, l);
-        if (!PROF && kind == KIND_LEAN) {
+        if (kind == KIND_LEAN) {
           const bool act = lane4 < len;
           const uint32_t o = lane4 < len - 4u ? lane4 : len - 4u, w = v[i];
           /* bytes this lane shares with its neighbour (the low ones of a last, overlapping dword) do not count twice: shifted
@@ -694,17 +667,8 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
           if (k == 0 && walked) walked_mask |= 1ull << l;
           continue;
         }
-        prep_prof_rd pr = {0u, 0u, 0, 0, false};
-        if (PROF) {
-          const uint32_t st = d_bcast(l_strand, l), pos = d_bcast(l_pos, l);
-          pr.on = (st & 0x100u) != 0;
-          pr.strand = st & 0xffu;
-          pr.used_t = d_bcast(l_used, l);
-          pr.v0 = pos > F.x ? (int64_t)(pos - F.x) : -1;
-          pr.pc = (int32_t)d_bcast((uint32_t)L.pc, l);
-        }
         if (kind == KIND_SLOW) {
-          const prep_slow_ret r = prep_slow_read<PROF>(plan + g0 + l, (ctl >> 30) & 1u ? PD_EDITED : 0u, dp, seq, ms_work, mq, k, F, s_prof, pr);
+          const prep_slow_ret r = prep_slow_read(plan + g0 + l, (ctl >> 30) & 1u ? PD_EDITED : 0u, dp, seq, ms_work, mq);
           c63 += r.c63;
           cge += r.cge;
           if (k == 0 && r.walked) walked_mask |= 1ull << l;
@@ -731,46 +695,6 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
           cge += (uint32_t)__popc((qh - mq4) & 0x80808080u);
           if (k == 0) walked |= __any((q1 & 0x3e3e3e3eu) != 0u) != 0;
           if (act) d_st32(dp + o, w);
-          if (PROF && pr.on && act) {
-            /* the read profile (see d_prof_base): a base counts iff its quality is in [20, 63) and either it reads C / T (base
-             * code odd) over a reference C followed by A, C or T, or it reads A / G over a reference G preceded by A, G or T.  Four
-             * bases at a time: the reference codes before, at and behind them are three byte-shifted views of 8 code bytes */
-            const int64_t bq = pr.v0 + (int64_t)o - 1; /* index in F.ref of the code BEFORE this dword's first base */
-            if (bq >= 0 && bq + 8 <= (int64_t)F.n_ref) {
-              const uint32_t lo = d_ld32(F.ref + bq) & 0x07070707u, hi = d_ld32(F.ref + bq + 4) & 0x07070707u;
-              const uint32_t r_at = __builtin_amdgcn_alignbyte(hi, lo, 1u), r_next = __builtin_amdgcn_alignbyte(hi, lo, 2u);
-#define PROF_NE(x, c) ((((x) ^ ((c) * 0x01010101u)) + 0x7f7f7f7fu) & 0x80808080u) /* bit 7 of every byte: the code (< 8) is not c */
-              const uint32_t over_c = ~PROF_NE(r_at, 2u) & PROF_NE(r_next, 0u) & PROF_NE(r_next, 3u); /* C, then A / C / T */
-              const uint32_t over_g = ~PROF_NE(r_at, 3u) & PROF_NE(lo, 0u) & PROF_NE(lo, 2u);         /* G, after A / G / T */
-#undef PROF_NE
-              const uint32_t odd = (w & 0x01010101u) << 7;
-              const uint32_t qf = ((w >> 2) & 0x3f3f3f3fu) | 0x80808080u; /* 0x80 + quality (of ALL four bytes: w, not wc) */
-              const uint32_t q_ok = (qf - 20u * 0x01010101u) & ~((qf + 0x01010101u) << 1) & 0x80808080u; /* >= 20 and not 63 */
-              /* the bytes that are this lane's own (an overlapping last dword: not the low ones) */
-              uint32_t hits = ((odd & over_c) | (~odd & over_g)) & q_ok & (0x80808080u << (8u * (nominal - o)));
-              const uint32_t coltab = pr.strand == 0 ? 0xebu : (pr.strand == 1 ? 0x63u : 0xc9u); /* xx & 3 by base code, two bits each */
-              const uint32_t lim = pr.used_t < F.cap ? pr.used_t : F.cap; /* positions that are kept (wave-uniform) */
-              const int32_t ix0 = (k ? pr.pc - (int32_t)o : pr.pc + (int32_t)o) + 1, step = k ? -1 : 1;
-              if (__any(hits != 0u)) {
-#pragma unroll
-                for (uint32_t t = 0; t < 4u; t++) {
-                  const uint32_t ix = (uint32_t)(ix0 + step * (int32_t)t);
-                  if (((hits >> (8u * t + 7u)) & 1u) && ix < lim) {
-                    const uint32_t col = (coltab >> (2u * ((w >> (8u * t)) & 3u))) & 3u;
-                    if (ix < PROF_LDS) atomicAdd(&s_prof[col * PROF_LDS + ix], 1u);
-                    else atomicAdd(&F.table[(uint64_t)ix * 4u + col], 1ull);
-                  }
-                }
-              }
-            } else { /* at the block's first position or its last few: base by base */
-#pragma unroll
-              for (uint32_t t = 0; t < 4u; t++)
-                if (t >= nominal - o) {
-                  const uint32_t j = o + t;
-                  d_prof_base(F, s_prof, pr.strand, pr.used_t, pr.v0 + j, k ? pr.pc - (int32_t)j : pr.pc + (int32_t)j, (w >> (8u * t)) & 0xffu);
-                }
-            }
-          }
         }
         if (k == 0 && walked) walked_mask |= 1ull << l;
       }
@@ -786,11 +710,6 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
     }
     if (lane < n && my_k == 0) tpl_out[my_ti].flags = BSC_TPL_WALK_KNOWN | (((walked_mask >> lane) & 1ull) ? BSC_TPL_WALKED0 : 0u);
   }
-  if (PROF) {
-    __syncthreads();
-    for (unsigned i = threadIdx.x; i < PROF_LDS * 4u; i += 64 * PREP_WAVES)
-      if (s_prof[i] && i % PROF_LDS < F.cap) atomicAdd(&F.table[(uint64_t)(i % PROF_LDS) * 4u + i / PROF_LDS], (unsigned long long)s_prof[i]);
-  }
   unsigned long long w[5] = {l_total, c63, cge, l_reads, l_bases};
   for (int i = 0; i < 5; i++)
     for (int o = 32; o > 0; o >>= 1) w[i] += __shfl_xor(w[i], o);
@@ -804,6 +723,232 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
     if (w[3]) atomicAdd(&cnt[6], w[3]);
     if (w[4]) atomicAdd(&cnt[7], w[4]);
   }
+}
+
+/*
+ * The read profile, a pass of its own behind the copy (round 6; inside the copy kernel — an LDS atomic per counted base, and the walk held
+ * to the slower of its two forms — it made that kernel 4.7 ms against 1.2).  What counts is a property of (reference position, base,
+ * quality); where it counts is the base's position in the ORIGINAL read.  So:
+ *   bsc_prep_refmask_kernel  once per call, a byte per reference position: 4 = a C followed by A / C / T, 8 = a G preceded by A / G / T
+ *                            (PROF_REF over the two pairs of codes around it, 0 where the walk has no code behind it), 8 bytes of
+ *                            zeros in front and behind, so that a dword of it can be fetched anywhere near the block.
+ *   bsc_prep_profile_kernel  lanes own READ POSITIONS, not output bytes: lane h holds positions 4h .. 4h + 3 of every read it sees and
+ *                            keeps their counts in registers — four bytes side by side in a dword per base code, flushed to the
+ *                            workgroup's table in LDS every 255 reads — so a counted base costs a byte-parallel add and no atomic.  The
+ *                            prepared bytes of those positions are one unaligned dword (byte-swapped for read 1, whose positions run
+ *                            against its bytes), the mask bytes another.  Reads of up to 128 positions (pc + length) go two to a wave,
+ *                            one per half; up to 256, one to a wave; the rest — and the reads the list cut or padded, whose bytes are
+ *                            not at a fixed distance from their positions, and strand 0 — byte by byte with atomics as before.
+ * bs_strand 2 counts a base in the column bs_strand 1 counts its complement in (src/init_param.c:57-70: {11,4,10,5} / {9,6,8,7}), so the
+ * registers are kept by base code (complemented for strand 2) and the column is looked up at the flush.
+ */
+__global__ __launch_bounds__(256) void bsc_prep_refmask_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref, uint8_t *__restrict__ mask) {
+  const uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u; /* mask[i .. i + 3]: positions v = i - 8 .. (the arrays' starts are 4-byte aligned) */
+  if (i >= (uint64_t)n_ref + 16u) return;
+  uint32_t m = 0;
+  if (i >= 12u && i - 8u + 7u <= n_ref) { /* codes v - 1 .. v + 6 exist: four positions at once, byte-parallel */
+    const uint64_t v = i - 8u;
+    const uint32_t lo = d_ld32(ref + v - 1u) & 0x07070707u, hi = d_ld32(ref + v + 3u) & 0x07070707u;
+    const uint32_t r_at = __builtin_amdgcn_alignbyte(hi, lo, 1u), r_next = __builtin_amdgcn_alignbyte(hi, lo, 2u);
+#define PROF_NE(x, c) ((((x) ^ ((c) * 0x01010101u)) + 0x7f7f7f7fu) & 0x80808080u) /* bit 7 of every byte: the code (< 8) is not c */
+    const uint32_t over_c = ~PROF_NE(r_at, 2u) & PROF_NE(r_next, 0u) & PROF_NE(r_next, 3u) & 0x80808080u; /* C, then A / C / T */
+    const uint32_t over_g = ~PROF_NE(r_at, 3u) & PROF_NE(lo, 0u) & PROF_NE(lo, 2u) & 0x80808080u;         /* G, after A / G / T */
+#undef PROF_NE
+    m = (over_c >> 5) | (over_g >> 4);
+  } else {
+    for (uint32_t t = 0; t < 4u; t++) {
+      const uint64_t it = i + t;
+      if (it >= 8u && it - 8u + 1u < n_ref) {
+        const uint64_t v = it - 8u;
+        const uint32_t ra = v >= 1 ? ref[v - 1] : 0u, rb = ref[v], rc = ref[v + 1];
+        m |= ((PROF_REF[((rb << 3) | rc) & 63u] & 4u) | (PROF_REF[((ra << 3) | rb) & 63u] & 8u)) << (8u * t);
+      }
+    }
+  }
+  __builtin_memcpy(mask + i, &m, 4); /* (the workspace is n_ref + 16 bytes rounded up to 4) */
+}
+
+__global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_profile_kernel(const bsc_prep_plan *__restrict__ plan, const bsc_prep_desc *__restrict__ desc,
+                                                                           uint32_t nr, const bsc_misms *__restrict__ ms_work,
+                                                                           const unsigned long long *__restrict__ out_off,
+                                                                           const bsc_template *__restrict__ tpl_out, const uint8_t *__restrict__ seq_out,
+                                                                           uint64_t seq_out_cap, unsigned long long *__restrict__ cnt,
+                                                                           const uint8_t *__restrict__ mask, const bsc_prep_prof F) {
+  __shared__ uint32_t s_prof[PROF_LDS * 4u];
+  for (unsigned i = threadIdx.x; i < PROF_LDS * 4u; i += 64 * PREP_WAVES) s_prof[i] = 0;
+  __syncthreads();
+  const unsigned lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * PREP_WAVES + (threadIdx.x >> 6)));
+  const uint32_t n_waves = gridDim.x * PREP_WAVES;
+  const uint32_t n_reads2 = 2u * nr, n_groups = (n_reads2 + 63u) / 64u;
+  uint32_t acc[4] = {0u, 0u, 0u, 0u}; /* by base code: counts of this lane's four positions, a byte each */
+  uint32_t acc_n = 0;                 /* reads since the last flush (wave-uniform) */
+  bool acc_half = true;               /* whose positions the registers hold: 4 (lane & 31) .. or 4 lane .. */
+  auto flush = [&]() {
+    const uint32_t p0 = 4u * (acc_half ? (lane & 31u) : lane);
+#pragma unroll
+    for (uint32_t b = 0; b < 4u; b++) {
+      const uint32_t col = (0x63u >> (2u * b)) & 3u; /* strand 1's column of base code b */
+#pragma unroll
+      for (uint32_t t = 0; t < 4u; t++) {
+        const uint32_t c = (acc[b] >> (8u * t)) & 0xffu;
+        if (c) atomicAdd(&s_prof[col * PROF_LDS + p0 + t + 1u], c); /* (p0 + t + 1 <= 256 < PROF_LDS; kept positions only: see lim) */
+      }
+      acc[b] = 0u;
+    }
+    acc_n = 0;
+  };
+  for (uint32_t g = wave; g < n_groups; g += n_waves) {
+    const uint32_t g0 = g * 64u, n = n_reads2 - g0 < 64u ? n_reads2 - g0 : 64u;
+    /* ---- lane r: read g0 + r ---- */
+    const uint32_t ri = g0 + (lane < n ? lane : 0u), my_ti = ri >> 1, my_k = ri & 1u;
+    const bsc_prep_desc L = desc[ri];
+    const unsigned long long l_off = out_off[ri];
+    /* (asked for whether the read turns out to be profiled or not: one wait for the six loads of a lane instead of two in a row) */
+    const uint32_t us_prev = my_ti ? F.used_scan[my_ti - 1u] : 0u, us_mine = F.used_scan[my_ti];
+    const uint32_t t_strand = tpl_out[my_ti].bs_strand, t_pos = tpl_out[my_ti].pos[my_k];
+    /* c1: index of output byte 0 in the codes + 1 (0: a read at the block's first position, whose walk starts a code late);
+     * kind: 0 nothing, 1 in registers, 2 the long way */
+    uint32_t c1 = 0, kind = 0, l_used = 0, l_strand = 0, l_ol = 0, top = 0;
+    if (lane < n) {
+      const uint32_t fl = L.pk >> 28;
+      uint32_t ol = L.pk & 0xfffffu;
+      if (fl & PD_SLOW) ol = plan[ri].out_len;
+      const bool fits = !(l_off > seq_out_cap || seq_out_cap - l_off < ol); /* (else the copy kernel refused it: the call fails) */
+      if ((fl & PD_PRESENT) && ol != 0 && fits) { /* this read's place in the block's codes, its template's share of the vector */
+        const uint32_t before = my_ti ? (us_prev > F.used0 ? us_prev : F.used0) : F.used0;
+        l_used = us_mine > before ? us_mine : before;
+        /* growing the vector past its capacity is where the host form gives up (csrc/prep.c) */
+        if (l_used > before && (unsigned long long)l_used + 1ull > F.cap) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_CAP);
+        l_strand = t_strand;
+        const uint32_t pos = t_pos;
+        l_ol = ol;
+        const bool in_ref = pos >= F.x && (uint64_t)pos - F.x + ol + 1u <= F.n_ref;
+        if (!in_ref) atomicMin(&cnt[0], ((unsigned long long)my_ti << 8) | PE_PROF_RANGE);
+        /* "this read is profiled": inside the block's codes (else the call fails anyway), on a strand that has a profile
+         * (src/init_param.c:57-70: bs_strand 0 .. 2) */
+        if (in_ref && l_strand <= 2u) {
+          const uint32_t lim = l_used < F.cap ? l_used : F.cap; /* positions (+ 1) that are kept */
+          const int32_t pc = L.pc;
+          top = my_k ? (uint32_t)(pc < 0 ? 0 : pc) : (uint32_t)pc + ol - 1u; /* the read's highest position */
+          /* in registers: bytes at a fixed distance from their positions, a strand whose column follows from the base, every position of
+           * the read inside the window of 256 and kept (top + 1 < lim: the vector only cuts reads while it still grows), and a dword
+           * three bytes to either side of the read inside the buffer */
+          const bool regs = !(fl & PD_SLOW) && l_strand != 0u && ol <= 256u && pc >= 0 && pc < 512 && top < 256u && top + 1u < lim && l_off >= 4u &&
+                            seq_out_cap - l_off - ol >= 4u;
+          kind = regs ? 1u : 2u;
+          c1 = pos > F.x ? pos - F.x + 1u : 0u;
+        }
+      }
+    }
+    /* ---- the reads whose counts stay in registers ---- */
+    unsigned long long m_regs = __ballot(kind == 1u);
+    if (m_regs) {
+      /* what a round needs of a read, two words a lane fetches from the read's own lane: where its first code's byte lies in mask[]
+       * (29 bits) | strand 2 << 29 | 1 << 31;  length - 1 (8 bits) | pc << 8 (9 bits) | its place, from the group's lowest << 17 */
+      const uint32_t first = (uint32_t)__builtin_ctzll(m_regs);
+      const unsigned long long obase = d_bcast64(l_off, first); /* (the places ascend with the reads) */
+      const unsigned long long orel = l_off - obase;
+      if (kind == 1u && orel >= (1ull << 15)) kind = 2u; /* (far from the group's first — long reads in between: the long way) */
+      const uint32_t A1 = kind == 1u ? (c1 + 7u) | (l_strand == 2u ? 1u << 29 : 0u) | (1u << 31) : 0u; /* code index v = c1 - 1 lies at mask[v + 8] */
+      const uint32_t A2 = kind == 1u ? (l_ol - 1u) | ((uint32_t)L.pc << 8) | ((uint32_t)orel << 17) : 0u;
+      const bool half = __ballot(kind == 1u && top >= 128u) == 0ull;
+      if (half != acc_half) {
+        flush();
+        acc_half = half;
+      }
+      const uint8_t *const sb = seq_out + obase - 4u; /* obase >= 4 */
+      const uint32_t h = half ? (lane & 31u) : lane;
+      const int32_t p0 = (int32_t)(4u * h);
+      const uint32_t hsel = half ? (lane & 32u) : 0u, rounds = half ? 32u : 64u;
+      constexpr uint32_t B = 4u; /* rounds in flight: their loads are asked for a batch ahead */
+      struct rnd {
+        uint32_t a1, w, mw;
+        int32_t jc, len4; /* len4 = 4 - the read's length */
+      };
+      /* reads alternate read 0 / read 1 of their templates, in both forms of the rounds: REV is a round's parity */
+      auto ask = [&](uint32_t i, rnd &r) {
+        const int src = (int)(hsel | (i & (rounds - 1u)));
+        r.a1 = (uint32_t)__shfl((int)A1, src);
+        const uint32_t a2 = (uint32_t)__shfl((int)A2, src);
+        const int32_t len = (int32_t)(a2 & 0xffu) + 1;
+        r.len4 = 4 - len;
+        const int32_t pc = (int32_t)((a2 >> 8) & 0x1ffu);
+        /* output byte of this lane's lowest-addressed position: read 0: j = p - pc, ascending; read 1: j = pc - p, descending */
+        const int32_t j0 = (i & 1u) ? pc - p0 - 3 : p0 - pc;
+        const bool some = (int32_t)r.a1 < 0 && (uint32_t)(j0 + 3) < (uint32_t)(len + 3);
+        r.jc = some ? j0 : 0;
+        r.w = d_ld32(sb + ((a2 >> 17) + (uint32_t)(r.jc + 4)));
+        /* a round that is not this lane's (no read there, or none of its bytes at this lane's positions): mask bytes that are 0 — the
+         * pad in front of the codes — and whatever the other load brings counts nothing */
+        r.mw = d_ld32(mask + (some ? (r.a1 & 0x1fffffffu) + (uint32_t)j0 : 0u));
+      };
+      auto count = [&](uint32_t i, const rnd &r) {
+        const int32_t lo = r.jc < 0 ? -r.jc : 0, hi = r.jc + r.len4 > 0 ? r.jc + r.len4 : 0; /* bytes of the dword in front of / behind the read: <= 3 */
+        uint32_t w = r.w & (0xffffffffu << (8 * lo)) & (0xffffffffu >> (8 * hi)); /* not the read's: quality 0, never counted */
+        uint32_t mw = r.mw;
+        if (i & 1u) { /* positions ascend as the bytes descend */
+          w = __builtin_bswap32(w);
+          mw = __builtin_bswap32(mw);
+        }
+        /* a base counts iff its quality is in [20, 63) and either it reads C / T (base code odd) over mask 4, or A / G over mask 8 */
+        const uint32_t odd = w << 7;
+        const uint32_t qf = ((w >> 2) & 0x3f3f3f3fu) | 0x80808080u;
+        const uint32_t q_ok = (qf - 20u * 0x01010101u) & ~((qf + 0x01010101u) << 1) & 0x80808080u;
+        const uint32_t hb = (((odd & (mw << 5)) | (~odd & (mw << 4))) & q_ok) >> 7;
+        const uint32_t wb = (r.a1 >> 29) & 1u ? ~w : w; /* strand 2: by the complement */
+        const uint32_t t1 = hb & (wb >> 1), t0 = hb ^ t1, t3 = t1 & wb, t2 = t0 & wb;
+        acc[3] += t3;
+        acc[2] += t1 ^ t3;
+        acc[1] += t2;
+        acc[0] += t0 ^ t2;
+      };
+      rnd ra[B], rb[B];
+#pragma unroll
+      for (uint32_t u = 0; u < B; u++) ask(u, ra[u]);
+      for (uint32_t i0 = 0; i0 < rounds; i0 += 2u * B) { /* (a batch past the last wraps round to the first reads: loads of bytes that exist, unused) */
+        if (acc_n + 2u * B > 255u) flush();
+#pragma unroll
+        for (uint32_t u = 0; u < B; u++) ask(i0 + B + u, rb[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < B; u++) count(u, ra[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < B; u++) ask(i0 + 2u * B + u, ra[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < B; u++) count(B + u, rb[u]);
+        acc_n += 2u * B;
+      }
+    }
+    /* ---- the others, one at a time, a byte per lane ---- */
+    unsigned long long m_long = __ballot(kind == 2u);
+    while (m_long) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(m_long);
+      m_long &= m_long - 1ull;
+      const uint32_t ol = d_bcast(l_ol, l), k = l & 1u, strand = d_bcast(l_strand, l), used_t = d_bcast(l_used, l);
+      const int32_t pc = (int32_t)d_bcast((uint32_t)L.pc, l);
+      const int64_t v0 = (int64_t)d_bcast(c1, l) - 1;
+      const uint8_t *const dp = seq_out + d_bcast64(l_off, l);
+      const bool slow = (d_bcast(L.pk, l) >> 28) & PD_SLOW;
+      bsc_prep_plan P;
+      bool edited = false;
+      if (slow) {
+        P = plan[g0 + l];
+        edited = (d_bcast(L.pk, l) >> 28) & PD_EDITED;
+      }
+      for (uint32_t jb = 0; jb < ol; jb += 64u) {
+        const uint32_t j = jb + lane;
+        if (j < ol) {
+          bool pad = false;
+          const uint32_t s = slow ? prep_slow_src(P, ms_work + P.ms, edited, j, pad) : j;
+          if (!pad) d_prof_base(F, s_prof, strand, used_t, v0 + j, k ? pc - (int32_t)s : pc + (int32_t)s, dp[j]);
+        }
+      }
+    }
+  }
+  flush();
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < PROF_LDS * 4u; i += 64 * PREP_WAVES)
+    if (s_prof[i] && i % PROF_LDS < F.cap) atomicAdd(&F.table[(uint64_t)(i % PROF_LDS) * 4u + i / PROF_LDS], (unsigned long long)s_prof[i]);
 }
 
 /* ---- launcher ------------------------------------------------------------------------------------------------------------------ */
@@ -824,7 +969,7 @@ extern "C" int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq
                                    const bsc_prep_params *par, void *ms_work, void *plan, void *out_len, void *out_off, void *scan_tmp,
                                    size_t scan_tmp_bytes, void *tpl_out, void *seq_out, uint64_t seq_out_cap, void *cnt, int num_cus,
                                    void *stream, const void *prof_ref, uint32_t prof_x, uint32_t prof_n_ref, uint32_t prof_cap,
-                                   uint32_t prof_used0, void *prof_table, void *max_pos1, void *used_scan) {
+                                   uint32_t prof_used0, void *prof_table, void *max_pos1, void *used_scan, void *prof_mask) {
   hipStream_t s = (hipStream_t)stream;
   bsc_prep_desc *const desc = (bsc_prep_desc *)((bsc_prep_plan *)plan + 2ull * nr); /* the descriptors lie behind the plans */
   if (!nr) return (int)hipMemsetAsync(out_off, 0, sizeof(unsigned long long), s);
@@ -851,19 +996,28 @@ extern "C" int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq
   /* as many workgroups as are resident at once: every wave strides over the groups of reads, one that starts late would do its
    * whole share after the others have finished */
   static int per_cu[2] = {0, 0};
-  const int pv = prof_ref ? 1 : 0;
-  if (!per_cu[pv]) {
-    int nb = 0;
-    const hipError_t eo = pv ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bsc_prep_copy_kernel<true>, 64 * PREP_WAVES, 0)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bsc_prep_copy_kernel<false>, 64 * PREP_WAVES, 0);
-    per_cu[pv] = (eo == hipSuccess && nb > 0) ? nb : 4;
-    (void)hipGetLastError();
+  for (int pv = 0; pv < (prof_ref ? 2 : 1); pv++)
+    if (!per_cu[pv]) {
+      int nb = 0;
+      const hipError_t eo = pv ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bsc_prep_profile_kernel, 64 * PREP_WAVES, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bsc_prep_copy_kernel, 64 * PREP_WAVES, 0);
+      per_cu[pv] = (eo == hipSuccess && nb > 0) ? nb : 4;
+      (void)hipGetLastError();
+    }
+  unsigned gc = g, gp = g;
+  if (gc > (unsigned)num_cus * (unsigned)per_cu[0]) gc = (unsigned)num_cus * (unsigned)per_cu[0];
+  hipLaunchKernelGGL(bsc_prep_copy_kernel, dim3(gc), dim3(64 * PREP_WAVES), 0, s, (const bsc_prep_plan *)plan, (const bsc_prep_desc *)desc, nr,
+                     (const uint8_t *)seq, (const bsc_misms *)ms_work, (const unsigned long long *)out_off, par->min_qual, (bsc_template *)tpl_out,
+                     (uint8_t *)seq_out, seq_out_cap, (unsigned long long *)cnt);
+  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  if (prof_ref) { /* the read profile: a pass of its own over the prepared bytes */
+    hipLaunchKernelGGL(bsc_prep_refmask_kernel, dim3((unsigned)(((uint64_t)prof_n_ref + 16u + 1023u) / 1024u)), dim3(256), 0, s, (const uint8_t *)prof_ref,
+                       prof_n_ref, (uint8_t *)prof_mask);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    if (gp > (unsigned)num_cus * (unsigned)per_cu[1]) gp = (unsigned)num_cus * (unsigned)per_cu[1];
+    hipLaunchKernelGGL(bsc_prep_profile_kernel, dim3(gp), dim3(64 * PREP_WAVES), 0, s, (const bsc_prep_plan *)plan, (const bsc_prep_desc *)desc, nr,
+                       (const bsc_misms *)ms_work, (const unsigned long long *)out_off, (const bsc_template *)tpl_out, (const uint8_t *)seq_out,
+                       seq_out_cap, (unsigned long long *)cnt, (const uint8_t *)prof_mask, F);
   }
-  const unsigned cap = (unsigned)num_cus * (unsigned)per_cu[pv];
-  if (g > cap) g = cap;
-  hipLaunchKernelGGL(prof_ref ? bsc_prep_copy_kernel<true> : bsc_prep_copy_kernel<false>, dim3(g), dim3(64 * PREP_WAVES), 0, s,
-                     (const bsc_prep_plan *)plan, (const bsc_prep_desc *)desc, nr, (const uint8_t *)seq,
-                     (const bsc_misms *)ms_work, (const unsigned long long *)out_off, par->min_qual, (bsc_template *)tpl_out,
-                     (uint8_t *)seq_out, seq_out_cap, (unsigned long long *)cnt, F);
   return (int)hipGetLastError();
 }

@@ -290,6 +290,65 @@ def test_read_profile_on_the_device(caller):
     assert pf_h.used > 60 and int(pf_h.counts[1 : pf_h.used].sum()) > 1000
 
 
+@pytest.mark.parametrize("lengths", [(100, 100), (4, 5, 7, 100, 127), (128, 129, 130, 150), (100, 150, 255, 256), (100, 257, 300, 700), (3, 2, 1, 100)])
+def test_read_profile_by_read_length(caller, lengths):
+    """The profile pass keeps the counts of a read's positions in registers — two reads to a wave up to 128 positions, one up to 256, byte
+    by byte beyond — and switches between the forms from one group of 64 reads to the next: plain reads (nothing cut or padded) of lengths
+    around every one of those limits, both reads of a template, the three strands, random qualities (below 20 and 63 among them), fixed
+    trims that move the positions, soft clips, overlapping mates, a block that starts AT its first read; several calls that grow the vector."""
+    from bs_call_amd.caller import ReadProfile
+
+    rng = np.random.default_rng(4242 + sum(lengths))
+    pf_h, pf_d = ReadProfile(cap=2048), ReadProfile(cap=2048)
+    n_counts = 0
+    for call in range(5):
+        ts, p0 = [], 300
+        n_t = int(rng.integers(40, 700))
+        for i in range(n_t):
+            la, lb = int(rng.choice(lengths)), int(rng.choice(lengths))
+            if call == 0:
+                la, lb = min(la, 60), min(lb, 60)  # the vector grows in the later calls
+            mk = lambda n: [T.b(int(v), int(q)) for v, q in zip(rng.integers(0, 4, n), rng.choice([5, 19, 20, 21, 30, 40, 62, 63, 0], n))]
+            r0, r1 = mk(la), mk(lb)
+            p0 += int(rng.integers(0, 7))
+            m0 = m1 = ()
+            if rng.random() < 0.1 and la > 12:  # a soft clip at the read's start: the positions shift
+                c = int(rng.integers(1, 6))
+                m0 = ([T.SOFT, 0, c],)
+                sa = la - c
+            else:
+                sa = la
+            kind = rng.random()
+            if kind < 0.15:
+                t = T.tpl((p0, 0), (sa, 0), (r0, None), (m0, ()))
+            elif kind < 0.3:
+                t = T.tpl((0, p0), (0, lb), (None, r1), ((), m1))
+            else:
+                t = T.tpl((p0, p0 + int(rng.integers(0, sa + 40))), (sa, lb), (r0, r1), (m0, m1))
+            t["orientation"] = int(rng.integers(0, 2))
+            t["bs_strand"] = int(rng.integers(0, 3)) if rng.random() < 0.3 else int(rng.integers(1, 3))
+            try:
+                py_prep.prepare([t])
+                ts.append(t)
+            except py_prep.PrepError:
+                pass
+        raw, seq, ms = T.to_arrays(ts)
+        kw = dict(left_trim=(int(rng.integers(0, 4)), int(rng.integers(0, 3))), right_trim=(0, int(rng.integers(0, 3)) if call % 2 else 0))
+        h_tpl, h_seq, _ = prepare_templates(raw, seq, ms, **kw)
+        x = max(1, int(min(p for p in h_tpl["pos"].ravel() if p)) - (0 if call % 2 == 0 else 2))
+        y = int((h_tpl["pos"].astype(np.int64) + h_tpl["len"]).max()) + 3
+        ref = rng.integers(0, 5, size=y - x + 3).astype(np.uint8)
+        ref[rng.random(len(ref)) < 0.5] = 2  # plenty of C ...
+        ref[rng.random(len(ref)) < 0.3] = 3  # ... and G
+        prepare_templates(raw, seq, ms, profile=pf_h, x=x, ref=ref, **kw)
+        d_tpl, d_seq, d_st = caller.prepare_templates_device(raw, seq, ms, profile=pf_d, x=x, ref=ref, **kw)
+        assert d_tpl.tobytes() == h_tpl.tobytes() and d_seq.tobytes() == h_seq.tobytes()
+        assert pf_d.used == pf_h.used and pf_d.counts[: pf_d.used].tobytes() == pf_h.counts[: pf_h.used].tobytes(), (call, lengths)
+        assert not pf_d.counts[pf_d.used :].any()
+        n_counts = int(pf_h.counts[1 : pf_h.used].sum())
+    assert n_counts > 2000 and pf_h.used >= min(max(lengths), 128)
+
+
 def test_mates_of_equal_span_are_decided_by_their_mean_qualities(caller):
     """handle_overlap's tie-break (src/al_utils.c:191-203): overlapping mates of EQUAL span — the common pair of a short-insert library —
     are decided by the mean of the qualities that are not 63.  The device sums sixteen qualities a load, byte-parallel: read lengths

@@ -1,12 +1,9 @@
 #!/usr/bin/env python3
-"""Print a rocprofv3 kernel_stats.csv compactly: usage tools/kstats.py <file-or-dir> [min_us]"""
-import csv, glob, os, re, sys
-p = sys.argv[1]
-fs = [p] if os.path.isfile(p) else glob.glob(os.path.join(p, "**", "*kernel_stats.csv"), recursive=True)
-for f in fs:
-    print("#", f)
-    for r in csv.DictReader(open(f)):
-        n = r["Name"]
-        n = re.sub(r"rocprim::ROCPRIM_\d+_NS::", "", n)
-        n = re.sub(r"\(.*", "", n)[:90]
-        print("%-92s calls %4s  avg %10.1f us  min %10.1f  total %8.2f ms" % (n, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+"""rocprofv3's kernel_stats.csv as a short table: tools/kstats.py FILE [n]"""
+import csv
+import sys
+
+for k, r in enumerate(csv.DictReader(open(sys.argv[1]))):
+    if k >= (int(sys.argv[2]) if len(sys.argv) > 2 else 12):
+        break
+    print("%-44s calls %-4s avg %10.1f us  min %10.1f  max %10.1f" % (r["Name"].split("(")[0][-44:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
