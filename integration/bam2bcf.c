@@ -23,6 +23,15 @@
  * write the same bytes.
  *
  *   make bam2bcf && bs_call_amd/lib/bam2bcf in.bam ref.fa out.bcf report.json [sample]
+ *
+ * A sharded run over ONE file (SURVEY.md 8e on real input; the reference's unit of parallelism is a process per contig set, README.md): rank r of n
+ *   bam2bcf --rank r --world n in.bam ref.fa out.bcf report.json [sample]
+ * takes its share of the contigs (whole contigs, longest first to the least loaded rank: bs_call_amd/shard.py's assignment), reads the
+ * stretches of the file that hold them (bsc_bamdev_open_contigs: no index file), writes every contig's records to out.bcf.shardNNNNN and what
+ * the report sums over to out.bcf.rankNNNNN.sums; no rank talks to another.  When all have finished,
+ *   bam2bcf --merge n in.bam ref.fa out.bcf report.json [sample]
+ * writes the header, the shards behind it in the header's contig order, and the report from the ranks' sums — the bytes of the single run
+ * (tests/test_gpu_shard_bam.py).  tools/bam2bcf_sharded.sh starts the ranks, one per GPU, and merges.
  * The header's date lines are left out (the reference's --benchmark-mode) so that the output is reproducible.
  */
 #include <pthread.h>
@@ -200,15 +209,181 @@ static void write_header(FILE *f, int n_refs, const char *const *names, const ui
   free(t);
 }
 
+/* ---- the sharded run ------------------------------------------------------------------------------------------------------------- */
+#define PROF_CAP 4096
+typedef struct { /* what a rank hands the merge: everything the report adds up */
+  uint64_t magic, n_ref, n_blocks, n_records, malformed;
+  uint64_t filter_cts[15], filter_bases[15], base_filter[5];
+  uint64_t prof_used, prof[PROF_CAP][4];
+  bsc_site_stats total;
+  /* followed by: gc[BSC_COV_CAP * 101], then per contig {seen, totals[14]} x n_ref */
+} rank_sums;
+#define SUMS_MAGIC 0x3173635f6d756273ull
+
+/* whole contigs to ranks, longest first, each to the least loaded rank (ties: the lower index) — bs_call_amd/shard.py assign_contigs */
+static int *assign_contigs(const uint32_t *len, int n_ref, int world) {
+  int *owner = calloc((size_t)n_ref + 1, sizeof *owner), *order = calloc((size_t)n_ref + 1, sizeof *order);
+  uint64_t *load = calloc((size_t)world, sizeof *load);
+  for (int i = 0; i < n_ref; i++) order[i] = i;
+  for (int i = 1; i < n_ref; i++) { /* by (-length, index): an insertion sort keeps equal lengths in index order */
+    const int v = order[i];
+    int j = i;
+    while (j > 0 && len[order[j - 1]] < len[v]) {
+      order[j] = order[j - 1];
+      j--;
+    }
+    order[j] = v;
+  }
+  for (int k = 0; k < n_ref; k++) {
+    int best = 0;
+    for (int r = 1; r < world; r++)
+      if (load[r] < load[best]) best = r;
+    owner[order[k]] = best;
+    load[best] += len[order[k]];
+  }
+  free(order);
+  free(load);
+  return owner;
+}
+
+static void header_of(const char *bam_path, int *n_ref, const char ***names, uint32_t **lens, bsc_bamstream **keep) {
+  bsc_bamstream *h = NULL;
+  CHECK(bsc_bamstream_open_contigs(bam_path, 1, 0, 0, NULL, 0, &h)); /* no contig at all: the header alone */
+  *n_ref = bsc_bamstream_n_refs(h);
+  *names = calloc((size_t)*n_ref + 1, sizeof **names);
+  *lens = calloc((size_t)*n_ref + 1, sizeof **lens);
+  for (int i = 0; i < *n_ref; i++) {
+    (*names)[i] = bsc_bamstream_ref_name(h, i);
+    (*lens)[i] = bsc_bamstream_ref_len(h, i);
+  }
+  *keep = h; /* (the names live in it) */
+}
+
+static void write_header(FILE *f, int n_refs, const char *const *names, const uint32_t *lens, const char *sample);
+
+static int merge_main(int world, char **argv, const char *sample) {
+  int n_ref;
+  const char **names;
+  uint32_t *lens;
+  bsc_bamstream *hs;
+  header_of(argv[1], &n_ref, &names, &lens, &hs);
+  FILE *out = fopen(argv[3], "wb");
+  if (!out) {
+    perror(argv[3]);
+    return 1;
+  }
+  write_header(out, n_ref, names, lens, sample);
+  char *path = malloc(strlen(argv[3]) + 64), *buf = malloc(1 << 24);
+  for (int t = 0; t < n_ref; t++) { /* the contigs' shards in the header's order */
+    sprintf(path, "%s.shard%05d", argv[3], t);
+    FILE *f = fopen(path, "rb");
+    if (!f) continue;
+    size_t n;
+    while ((n = fread(buf, 1, 1 << 24, f)) > 0) fwrite(buf, 1, n, out);
+    fclose(f);
+    remove(path);
+  }
+  fclose(out);
+  /* the report: every number in it is a sum over positions / reads / templates, the read profile's length the longest any rank saw */
+  rank_sums *acc = calloc(1, sizeof *acc), *one = malloc(sizeof *one);
+  uint64_t *gc = calloc((size_t)BSC_COV_CAP * 101, 8), *gc1 = malloc((size_t)BSC_COV_CAP * 101 * 8);
+  uint64_t *ct = calloc((size_t)n_ref * 15 + 1, 8), *ct1 = malloc(((size_t)n_ref * 15 + 1) * 8);
+  for (int r = 0; r < world; r++) {
+    sprintf(path, "%s.rank%05d.sums", argv[3], r);
+    FILE *f = fopen(path, "rb");
+    if (!f || fread(one, sizeof *one, 1, f) != 1 || one->magic != SUMS_MAGIC || one->n_ref != (uint64_t)n_ref ||
+        fread(gc1, 8, (size_t)BSC_COV_CAP * 101, f) != (size_t)BSC_COV_CAP * 101 || fread(ct1, 8, (size_t)n_ref * 15, f) != (size_t)n_ref * 15) {
+      fprintf(stderr, "bam2bcf --merge: %s is missing or not a rank's sums of this input\n", path);
+      return 1;
+    }
+    fclose(f);
+    remove(path);
+    acc->n_blocks += one->n_blocks;
+    acc->n_records += one->n_records;
+    acc->malformed += one->malformed;
+    for (int i = 0; i < 15; i++) acc->filter_cts[i] += one->filter_cts[i], acc->filter_bases[i] += one->filter_bases[i];
+    for (int i = 0; i < 5; i++) acc->base_filter[i] += one->base_filter[i];
+    if (one->prof_used > acc->prof_used) acc->prof_used = one->prof_used;
+    for (int i = 0; i < PROF_CAP * 4; i++) (&acc->prof[0][0])[i] += (&one->prof[0][0])[i];
+    { /* bsc_site_stats: the leading words are counters, the last 4 x 101 doubles (include/bscall_amd.h) */
+      const size_t n_int = (sizeof(bsc_site_stats) - 404 * sizeof(double)) / 8;
+      uint64_t *a = (uint64_t *)&acc->total;
+      const uint64_t *b = (const uint64_t *)&one->total;
+      for (size_t i = 0; i < n_int; i++) a[i] += b[i];
+      double *ad = (double *)(a + n_int);
+      const double *bd = (const double *)(b + n_int);
+      for (int i = 0; i < 404; i++) ad[i] += bd[i];
+    }
+    for (size_t i = 0; i < (size_t)BSC_COV_CAP * 101; i++) gc[i] += gc1[i];
+    for (size_t i = 0; i < (size_t)n_ref * 15; i++) ct[i] += ct1[i];
+  }
+  if (acc->malformed)
+    fprintf(stderr, "bam2bcf: warning: %llu BAM records dropped, their CIGAR does not cover the sequence (damaged input?)\n", (unsigned long long)acc->malformed);
+  bsc_report rep;
+  memset(&rep, 0, sizeof rep);
+  rep.under_conv = 0.01;
+  rep.over_conv = 0.05;
+  rep.mapq_thresh = 20;
+  rep.min_qual = 20;
+  rep.day = 1, rep.month = 1, rep.year = 2000;
+  memcpy(rep.filter_cts, acc->filter_cts, sizeof rep.filter_cts);
+  memcpy(rep.filter_bases, acc->filter_bases, sizeof rep.filter_bases);
+  memcpy(rep.base_filter, acc->base_filter, sizeof rep.base_filter);
+  rep.total = &acc->total;
+  rep.gc = gc;
+  rep.read_profile = &acc->prof[0][0];
+  rep.n_read_profile = (uint32_t)acc->prof_used;
+  bsc_contig_totals *listed = calloc((size_t)n_ref + 1, sizeof *listed);
+  uint32_t nl = 0;
+  for (int i = 0; i < n_ref; i++)
+    if (ct[(size_t)i * 15]) {
+      listed[nl].name = names[i];
+      memcpy(listed[nl].snps, ct + (size_t)i * 15 + 1, 14 * 8);
+      nl++;
+    }
+  rep.contigs = listed;
+  rep.n_contigs = nl;
+  const long need = bsc_report_json(&rep, NULL, 0);
+  CHECK(need);
+  char *text = xrealloc(NULL, (size_t)need + 1);
+  bsc_report_json(&rep, text, (size_t)need + 1);
+  FILE *fr = fopen(argv[4], "w");
+  if (!fr) {
+    perror(argv[4]);
+    return 1;
+  }
+  fwrite(text, 1, (size_t)need, fr);
+  fclose(fr);
+  printf("%llu blocks, %llu records written\n", (unsigned long long)acc->n_blocks, (unsigned long long)acc->n_records);
+  bsc_bamstream_close(hs);
+  return 0;
+}
+
 int main(int argc, char **argv) {
-  if (argc < 5) {
-    fprintf(stderr, "usage: %s in.bam ref.fa out.bcf report.json [sample]\n", argv[0]);
+  int rank = -1, world = 1, merge = 0;
+  while (argc > 2 && argv[1][0] == '-' && argv[1][1] == '-') { /* --rank r --world n | --merge n */
+    if (!strcmp(argv[1], "--rank")) rank = atoi(argv[2]);
+    else if (!strcmp(argv[1], "--world")) world = atoi(argv[2]);
+    else if (!strcmp(argv[1], "--merge")) merge = atoi(argv[2]);
+    else break;
+    argv[2] = argv[0];
+    argv += 2;
+    argc -= 2;
+  }
+  if (argc < 5 || world < 1 || (rank >= 0 && rank >= world)) {
+    fprintf(stderr, "usage: %s [--rank r --world n | --merge n] in.bam ref.fa out.bcf report.json [sample]\n", argv[0]);
     return 2;
   }
   const char *sample = argc > 5 ? argv[5] : "SAMPLE";
+  if (merge > 0) return merge_main(merge, argv, sample);
+  const int sharded = rank >= 0;
   const int host_prep = getenv("BAM2BCF_HOST_PREP") != NULL;
   const int host_bcf = host_prep || getenv("BAM2BCF_HOST_BCF") != NULL;
   const int host_reader = host_bcf || getenv("BAM2BCF_HOST_READER") != NULL;
+  if (sharded && host_reader) {
+    fprintf(stderr, "bam2bcf: a sharded run reads through the device reader (its contig selection)\n");
+    return 2;
+  }
   const double t_start = now();
   bsc_params prm = {0.01, 0.05, 2.0, 20, 0};
   bsc_context *ctx;
@@ -217,17 +392,36 @@ int main(int argc, char **argv) {
   bsc_bam *bam = NULL;
   bsc_bamdev *dev = NULL;
   if (host_reader) CHECK(bsc_bam_open_threads(argv[1], getenv("BAM2BCF_THREADS") ? atoi(getenv("BAM2BCF_THREADS")) : 4, &bam)); /* BGZF inflate ahead of the parser */
-  else CHECK(bsc_bamdev_open(ctx, argv[1], getenv("BAM2BCF_THREADS") ? atoi(getenv("BAM2BCF_THREADS")) : 0, &dev));
+  else if (!sharded) CHECK(bsc_bamdev_open(ctx, argv[1], getenv("BAM2BCF_THREADS") ? atoi(getenv("BAM2BCF_THREADS")) : 0, &dev));
+  else { /* this rank's contigs: the stretches of the file that hold them */
+    int nr_, *owner;
+    const char **nm_;
+    uint32_t *ln_;
+    bsc_bamstream *hs_;
+    header_of(argv[1], &nr_, &nm_, &ln_, &hs_);
+    owner = assign_contigs(ln_, nr_, world);
+    int32_t *mine = calloc((size_t)nr_ + 2, sizeof *mine);
+    uint32_t n_mine = 0;
+    for (int i = 0; i < nr_; i++)
+      if (owner[i] == rank) mine[n_mine++] = i;
+    if (nr_ && owner[nr_ - 1] == rank) mine[n_mine++] = -1; /* the unplaced reads at the file's end go with the last contig's rank */
+    CHECK(bsc_bamdev_open_contigs(ctx, argv[1], getenv("BAM2BCF_THREADS") ? atoi(getenv("BAM2BCF_THREADS")) : 0, mine, n_mine, &dev));
+    free(mine);
+    free(owner);
+    free(nm_);
+    free(ln_);
+    bsc_bamstream_close(hs_);
+  }
 #define N_REFS() (host_reader ? bsc_bam_n_refs(bam) : bsc_bamdev_n_refs(dev))
 #define REF_NAME(i) (host_reader ? bsc_bam_ref_name(bam, (i)) : bsc_bamdev_ref_name(dev, (i)))
 #define REF_LEN(i) (host_reader ? bsc_bam_ref_len(bam, (i)) : bsc_bamdev_ref_len(dev, (i)))
-  FILE *out = fopen(argv[3], "wb");
-  if (!out) {
+  FILE *out = sharded ? NULL : fopen(argv[3], "wb");
+  if (!out && !sharded) {
     perror(argv[3]);
     return 1;
   }
   const int n_ref = N_REFS();
-  {
+  if (!sharded) {
     const char **names = calloc((size_t)n_ref + 1, sizeof *names);
     uint32_t *lens = calloc((size_t)n_ref + 1, sizeof *lens);
     for (int i = 0; i < n_ref; i++) {
@@ -244,7 +438,7 @@ int main(int argc, char **argv) {
   const bsc_prep_params ppar = {{0, 0}, {0, 0}, 20};
 
   bsc_contig_totals *ctot = calloc((size_t)n_ref + 1, sizeof *ctot);
-  uint64_t prof_counts[4096][4];
+  static uint64_t prof_counts[PROF_CAP][4];
   memset(prof_counts, 0, sizeof prof_counts);
   bsc_read_profile prof = {NULL, 0, 0, &prof_counts[0][0], 4096, 0};
   uint64_t base_filter[5] = {0, 0, 0, 0, 0}, passed_reads = 0, passed_bases = 0, before[14], after[14];
@@ -266,9 +460,11 @@ int main(int argc, char **argv) {
   uint64_t file_at = 0;
   if (n_ref > 0) ref_start(&RJ, argv[2], REF_NAME(0), REF_LEN(0), 0); /* the first contig's reference: while the helpers inflate */
   if (!host_reader) { /* the output pieces too: page-locking them takes its time */
-    fflush(out);
-    file_at = (uint64_t)ftello(out);
-    W.fd = fileno(out);
+    if (out) {
+      fflush(out);
+      file_at = (uint64_t)ftello(out);
+      W.fd = fileno(out);
+    } else W.fd = -1; /* a rank of a sharded run: a file per contig, opened when the contig begins */
     for (int k = 0; k < N_PIECE; k++) W.buf[k] = pinned(PIECE);
     pthread_mutex_init(&W.mu, NULL);
     pthread_cond_init(&W.cv, NULL);
@@ -296,6 +492,24 @@ int main(int argc, char **argv) {
       }
       cur_tid = blk.tid;
       ctot[cur_tid].name = REF_NAME(cur_tid);
+      if (sharded) { /* this contig's shard: what the output thread still holds belongs to the one before */
+        pthread_mutex_lock(&W.mu);
+        for (int k = 0; k < N_PIECE; k++)
+          while (W.full[k]) pthread_cond_wait(&W.cv, &W.mu);
+        pthread_mutex_unlock(&W.mu);
+        if (W.fd >= 0) close(W.fd);
+        char *sp = malloc(strlen(argv[3]) + 32);
+        sprintf(sp, "%s.shard%05d", argv[3], cur_tid);
+        FILE *sf = fopen(sp, "wb");
+        if (!sf) {
+          perror(sp);
+          return 1;
+        }
+        W.fd = dup(fileno(sf));
+        fclose(sf);
+        free(sp);
+        file_at = 0;
+      }
       /* its sequence and GC bins (for the report's GC-by-coverage table: load_sequence computes them when a report is asked for): loaded in
        * the background since the previous contig began — or since the program did */
       if (!RJ.running || RJ.tid != cur_tid) {
@@ -443,7 +657,8 @@ int main(int argc, char **argv) {
     uint64_t *d = ctot[cur_tid].snps;
     for (int i = 0; i < 14; i++) d[i] += after[i] - before[i];
   }
-  fclose(out);
+  if (out) fclose(out);
+  else if (W.fd >= 0) close(W.fd);
 
   /* the report */
   static bsc_site_stats total;
@@ -477,18 +692,48 @@ int main(int argc, char **argv) {
     if (ctot[i].name) listed[nl++] = ctot[i];
   rep.contigs = listed;
   rep.n_contigs = nl;
-  const long need = bsc_report_json(&rep, NULL, 0);
-  CHECK(need);
-  char *text = xrealloc(NULL, (size_t)need + 1);
-  bsc_report_json(&rep, text, (size_t)need + 1);
-  FILE *fr = fopen(argv[4], "w");
-  if (!fr) {
-    perror(argv[4]);
-    return 1;
+  if (sharded) { /* this rank's share of every sum, for bam2bcf --merge */
+    rank_sums *rs_ = calloc(1, sizeof *rs_);
+    rs_->magic = SUMS_MAGIC;
+    rs_->n_ref = (uint64_t)n_ref;
+    rs_->n_blocks = n_blocks;
+    rs_->n_records = n_records;
+    rs_->malformed = malformed;
+    memcpy(rs_->filter_cts, rep.filter_cts, sizeof rs_->filter_cts);
+    memcpy(rs_->filter_bases, rep.filter_bases, sizeof rs_->filter_bases);
+    memcpy(rs_->base_filter, base_filter, sizeof rs_->base_filter);
+    rs_->prof_used = prof.used;
+    memcpy(rs_->prof, prof_counts, sizeof rs_->prof);
+    rs_->total = total;
+    uint64_t *ct = calloc((size_t)n_ref * 15 + 1, 8);
+    for (int i = 0; i < n_ref; i++)
+      if (ctot[i].name) {
+        ct[(size_t)i * 15] = 1;
+        memcpy(ct + (size_t)i * 15 + 1, ctot[i].snps, 14 * 8);
+      }
+    char *sp = malloc(strlen(argv[3]) + 32);
+    sprintf(sp, "%s.rank%05d.sums", argv[3], rank);
+    FILE *fs = fopen(sp, "wb");
+    if (!fs || fwrite(rs_, sizeof *rs_, 1, fs) != 1 || fwrite(gc_table, 8, (size_t)BSC_COV_CAP * 101, fs) != (size_t)BSC_COV_CAP * 101 ||
+        fwrite(ct, 8, (size_t)n_ref * 15, fs) != (size_t)n_ref * 15 || fclose(fs)) {
+      perror(sp);
+      return 1;
+    }
+    printf("rank %d of %d: %llu blocks, %llu records written\n", rank, world, (unsigned long long)n_blocks, (unsigned long long)n_records);
+  } else {
+    const long need = bsc_report_json(&rep, NULL, 0);
+    CHECK(need);
+    char *text = xrealloc(NULL, (size_t)need + 1);
+    bsc_report_json(&rep, text, (size_t)need + 1);
+    FILE *fr = fopen(argv[4], "w");
+    if (!fr) {
+      perror(argv[4]);
+      return 1;
+    }
+    fwrite(text, 1, (size_t)need, fr);
+    fclose(fr);
+    printf("%llu blocks, %llu records written\n", (unsigned long long)n_blocks, (unsigned long long)n_records);
   }
-  fwrite(text, 1, (size_t)need, fr);
-  fclose(fr);
-  printf("%llu blocks, %llu records written\n", (unsigned long long)n_blocks, (unsigned long long)n_records);
   if (getenv("BAM2BCF_TIMING")) {
     uint64_t rc4[4] = {0, 0, 0, 0};
     double rs[2] = {0, 0};

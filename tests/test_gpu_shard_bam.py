@@ -69,3 +69,43 @@ def test_two_ranks_write_the_single_runs_bytes(tmp_path):
     assert open(tmp_path / "sharded.json").read() == open(tmp_path / "single.json").read()
     assert single["records"] > 20_000 and single["contigs"] == ["chrA", "chrB", "chrD"]
     assert not [f for f in os.listdir(tmp_path) if ".shard" in f]  # the shards are gone
+
+
+def test_plain_c_ranks_and_merge_write_the_single_runs_bytes(tmp_path):
+    """integration/bam2bcf --rank r --world n / --merge n (tools/bam2bcf_sharded.sh): the C twin of the sharded pipeline — ranks that never
+    talk to each other, their shards and sums on disk, one merge: the single run's BCF and report bytes; for 2 and for 3 ranks (one of them
+    gets the contig without reads, or nothing but it)."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "bs_call_amd", "lib", "bam2bcf")
+    assert os.path.exists(exe), "run `make demo`"
+    reference = _reference()
+    refs = [(k, len(v)) for k, v in reference.items()]
+    rng = np.random.default_rng(19)
+    recs = []
+    for tid, (name, n) in enumerate(refs):
+        if name == "chrC":
+            continue
+        recs += W.wgbs_records(rng, reference[name], tid, n * 20 // 200, het_every=700)
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    bam, fa = str(tmp_path / "in.bam"), str(tmp_path / "ref.fa")
+    W.write_bam(bam, refs, recs, aligned=True)
+    with open(fa, "w") as f:
+        for name, codes in reference.items():
+            f.write(">%s\n" % name)
+            s = "".join("NACGT"[c] for c in codes)
+            for o in range(0, len(s), 70):
+                f.write(s[o : o + 70] + "\n")
+    r = subprocess.run([exe, bam, fa, str(tmp_path / "one.bcf"), str(tmp_path / "one.json"), "S3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    want = (open(tmp_path / "one.bcf", "rb").read(), open(tmp_path / "one.json").read(), r.stdout.strip())
+    assert len(want[0]) > 1_000_000
+    for world in (2, 3):
+        out, rep = str(tmp_path / ("w%d.bcf" % world)), str(tmp_path / ("w%d.json" % world))
+        r = subprocess.run([os.path.join(ROOT, "tools", "bam2bcf_sharded.sh"), str(world), bam, fa, out, rep, "S3"], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, BAM2BCF_ONE_GPU="1"))
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert open(out, "rb").read() == want[0], world
+        assert open(rep).read() == want[1], world
+        assert r.stdout.strip().splitlines()[-1] == want[2]
+        assert not [f for f in os.listdir(tmp_path) if ".shard" in f or ".sums" in f]
