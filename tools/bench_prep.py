@@ -78,6 +78,7 @@ with B.SiteCaller() as c:
             wall.append(time.perf_counter() - t0)
     w = float(np.median(wall))
     res["read_profile"] = bool(args.profile)
+    res["calls"] = 2 + args.steps  # of bsc_prepare_templates_device in this process (tools/make_r06_json.py divides the PMC sums by it)
     res.update(wall_ms=w * 1e3, templates_per_s=len(raw) / w, bases_per_s=seq.size / w, positions_per_s=args.sites / w,
                bytes_in_plus_out=int(seq.size + used.value + len(raw) * (72 + 40) + len(ms) * 12),
                GBps=(seq.size + used.value + len(raw) * 112 + len(ms) * 12) / w / 1e9, prepared_bytes=int(used.value))
