@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r05_resources.txt: per kernel of the library, what the compiler made of HEAD's sources — VGPRs, spilled VGPRs / SGPRs,
+"""profiles/r06_resources.txt: per kernel of the library, what the compiler made of HEAD's sources — VGPRs, spilled VGPRs / SGPRs,
 scratch bytes per lane, LDS bytes per workgroup (-Rpass-analysis=kernel-resource-usage), code bytes, and the static counts of
 v_readlane / v_writelane / scratch_* instructions in the listing.  Every resource figure quoted in DESIGN.md comes from this
 file; regenerate it after touching a kernel.  usage: python tools/make_resources.py [out-file]"""
@@ -10,9 +10,9 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_resources.txt")
+out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_resources.txt")
 FLAGS = "-O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wno-inline-asm -Wno-unused-variable -Wno-unused-function".split()
-SOURCES = ["kernels.hip", "fused.hip", "accumulate.hip", "vcfcore.hip", "sitestats.hip", "compact.hip", "prepdev.hip", "bcfdev.hip"]
+SOURCES = ["kernels.hip", "fused.hip", "accumulate.hip", "vcfcore.hip", "sitestats.hip", "compact.hip", "prepdev.hip", "bcfdev.hip", "bamdev.hip"]
 
 
 def demangle(n):
