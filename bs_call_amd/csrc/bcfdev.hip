@@ -329,37 +329,75 @@ extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_kernel(bcf_args a
     for (int d = 1; d < 64; d <<= 1) len += __shfl_xor(len, d);
     if (lane == 0) tile_bytes[tile] = len;
   }
-  if (lane == 0 && n_written) atomicAdd(err + 1, (unsigned long long)n_written); /* totals[2]: once per wave — one word cannot take an atomic per tile */
+  /* totals[2]: once per workgroup (n_written is wave-uniform) — atomics on one word are served one after the other, 23 ns each */
+  __shared__ unsigned s_written;
+  if (threadIdx.x == 0) s_written = 0;
+  __syncthreads();
+  if (lane == 0 && n_written) atomicAdd(&s_written, n_written);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_written) atomicAdd(err + 1, (unsigned long long)s_written);
 }
 
 /* The same sums from the chain kernel's byte per position (csrc/fused.hip, emit_out): 0 = no record, 1 .. 254 = the record's length with
- * one-byte dictionary indices and no ID — what the launcher has checked the indices to be —, 255 = look at the record (heterozygous calls,
- * dbSNP-flagged positions: one position in a few hundred).  64 bytes a tile instead of 64 sectors and more. */
+ * one-byte dictionary indices and no ID — what the launcher has checked the indices to be —, 255 = look at the record (dbSNP-flagged
+ * positions, records longer than 254 bytes).  64 bytes a tile instead of 64 sectors and more. */
 extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_bytes_kernel(bcf_args a, const uint8_t *__restrict__ emit, uint32_t n_tiles,
                                                                             unsigned long long *__restrict__ tile_bytes, unsigned long long *__restrict__ err) {
-  const unsigned lane = threadIdx.x & 63u;
+  /* a THREAD per tile (round 6, second form; the first was a wave per tile, a byte per lane and six shuffles): the tile's 64 bytes are four
+   * 16-byte loads of a lane, summed four at a time (v_sad_u8), 4 KB a wave instruction: 30 us per 50 M positions */
   const uint64_t n = clamp_n(a);
   if (blockIdx.x == 0 && threadIdx.x == 0) tile_bytes[n_tiles] = 0ull;
   unsigned n_written = 0;
-  for (uint32_t tile = blockIdx.x * BCF_WAVES + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * BCF_WAVES) {
-    const uint64_t i = (uint64_t)tile * 64u + lane;
-    unsigned len = i < n ? emit[i] : 0u;
-    if (__ballot(len == 255u)) { /* wave-uniform branch: most tiles have no such position */
-      if (len == 255u) {
-        rec_regs r;
-        const uint8_t *id;
-        unsigned id_len;
-        bool bad;
-        len = rec_len(a, i, n, r, id, id_len, bad);
-        if (bad) atomicAdd(err, 1ull);
+  for (uint64_t tile = (uint64_t)blockIdx.x * 256u + threadIdx.x; tile < n_tiles; tile += (uint64_t)gridDim.x * 256u) {
+    const uint64_t i0 = tile * 64u;
+    uint32_t w[16];
+    if (i0 + 64u <= n) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) __builtin_memcpy(&w[4 * q], emit + i0 + 16u * q, 16);
+    } else { /* the block's last, ragged tile */
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        w[q] = 0u;
+        for (int t = 0; t < 4; t++)
+          if (i0 + 4u * q + t < n) w[q] |= (uint32_t)emit[i0 + 4u * q + t] << (8 * t);
       }
     }
-    n_written += (unsigned)__popcll(__ballot(len != 0u));
+    uint32_t len = 0, any255 = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) len += __shfl_xor(len, d);
-    if (lane == 0) tile_bytes[tile] = len;
+    for (int q = 0; q < 16; q++) {
+      const uint32_t x = w[q];
+      len = __builtin_amdgcn_sad_u8(x, 0u, len);
+      n_written += (uint32_t)__popc((x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u); /* bytes that are not 0 */
+      any255 |= x & (x << 1) & (x << 2) & (x << 3) & (x << 4) & (x << 5) & (x << 6) & (x << 7) & 0x80808080u; /* bit 7 of a byte that is all ones */
+    }
+    if (any255) { /* look at those records: dbSNP-flagged positions, records longer than 254 bytes (the heterozygous calls' bytes are final too since
+                     the chain kernel writes them again behind Fisher's test: with every het call a 255, a tile in five had one and this
+                     branch was the kernel's whole 0.2 ms) */
+      for (int q = 0; q < 16; q++)
+        for (int t = 0; t < 4; t++)
+          if (((w[q] >> (8 * t)) & 0xffu) == 0xffu) {
+            rec_regs r;
+            const uint8_t *id;
+            unsigned id_len;
+            bool bad;
+            const unsigned l = rec_len(a, i0 + 4u * q + t, n, r, id, id_len, bad);
+            if (bad) atomicAdd(err, 1ull);
+            len += l - 255u;
+            if (l == 0u) n_written--; /* (a 255 whose record is not written after all: cannot happen, kept consistent) */
+          }
+    }
+    tile_bytes[tile] = len;
   }
-  if (lane == 0 && n_written) atomicAdd(err + 1, (unsigned long long)n_written);
+  /* totals[2]: once per WORKGROUP, and few workgroups — atomics on one word are served one after the other, 23 ns each: one per wave of
+   * 12 288 waves was the whole 0.25 ms of the first form of this kernel */
+  __shared__ unsigned s_written;
+  if (threadIdx.x == 0) s_written = 0;
+  __syncthreads();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) n_written += __shfl_xor(n_written, d);
+  if ((threadIdx.x & 63u) == 0 && n_written) atomicAdd(&s_written, n_written);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_written) atomicAdd(err + 1, (unsigned long long)s_written);
 }
 
 extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BCF_WAVES_PER_EU, BCF_WAVES_PER_EU))) void bsc_bcf_write_kernel(bcf_args a, uint32_t n_tiles, const unsigned long long *__restrict__ tile_off,
@@ -616,8 +654,13 @@ extern "C" int bsc_dev_launch_bcf(const void *recs, const void *core, const void
   static int no_len = -1; /* BSC_BCF_NO_LEN_BYTES: the size pass over the records, as in round 5 (A/B) */
   if (no_len < 0) no_len = getenv("BSC_BCF_NO_LEN_BYTES") != nullptr;
   if (emit_len && !recs && short_ids && !a.n_names && !no_len)
-    hipLaunchKernelGGL(bsc_bcf_size_bytes_kernel, dim3(grid), dim3(256), 0, s, a, (const uint8_t *)emit_len, n_tiles, (unsigned long long *)tile_bytes,
+  {
+    unsigned gb = (n_tiles + 255u) / 256u; /* a thread per tile */
+    if (gb > (unsigned)num_cus * 2u) gb = (unsigned)num_cus * 2u; /* (few: each ends in an atomic on one word) */
+    if (gb == 0) gb = 1;
+    hipLaunchKernelGGL(bsc_bcf_size_bytes_kernel, dim3(gb), dim3(256), 0, s, a, (const uint8_t *)emit_len, n_tiles, (unsigned long long *)tile_bytes,
                        (unsigned long long *)totals + 1);
+  }
   else
     hipLaunchKernelGGL(bsc_bcf_size_kernel, dim3(grid), dim3(256), 0, s, a, n_tiles, (unsigned long long *)tile_bytes, (unsigned long long *)totals + 1);
   hipError_t e = hipGetLastError();

@@ -286,7 +286,7 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
                                                         const uint8_t *__restrict__ dbsnp, const bsc_chain_args &a,
                                                         uint8_t *__restrict__ core_out, const double *__restrict__ s_lf, const double *s_logtab,
                                                         const unsigned long long *s_exptab, uint32_t *h,
-                                                        unsigned long long *__restrict__ stat_words) {
+                                                        unsigned long long *__restrict__ stat_words, uint8_t *__restrict__ emit_p) {
   f_facts F;
   F.called = F.emit = F.pass = F.het = F.rs = F.cpg_site = F.ref_cpg = F.pair = F.pair_pass = F.fs_ok = F.do_meth = false;
   F.phred = F.flt = F.qd = F.fsv = F.mqv = F.cdp = F.cinf = F.m_a = F.m_b = 0;
@@ -337,6 +337,25 @@ __device__ static __forceinline__ void f_fisher_pending(uint32_t pend_e, unsigne
         if (mq < 40) flt |= 8;
         if (!flt && het && f_mac1(gt, c)) flt |= 128;
         rec[8] = (uint8_t)flt;
+        if (emit_p) { /* the record's BCF2 length (see the tile's own computation of it): FS and the FILTER bits it decides are known now, so the
+                         encoder's size pass need not look at this record either — unless it carries a name */
+          uint32_t cm = c[0] > c[1] ? c[0] : c[1], n_amq = 0;
+#pragma unroll
+          for (int k = 2; k < 8; k++) cm = c[k] > cm ? c[k] : cm;
+#pragma unroll
+          for (int k = 0; k < 8; k++) n_amq += c[k] > 0u ? 1u : 0u;
+#define F_PI(v) ((v) <= 127u ? 2u : ((v) <= 32767u ? 3u : 5u)) /* put_int of a non-negative value */
+          const uint32_t fb = flt & 15u, ngl = (c0.z >> 16) & 0xffu, dp1 = *reinterpret_cast<const uint32_t *>(rec + 32);
+          const uint32_t ft_len = ((fb & 1u) ? 4u : 0u) + ((fb & 2u) ? 4u : 0u) + ((fb & 4u) ? 5u : 0u) + ((fb & 8u) ? 5u : 0u) + (uint32_t)__popc(fb) - 1u;
+          const uint32_t ft = fb ? (ft_len >= 15u ? 3u : 1u) + ft_len : 5u;
+          const uint32_t cs = ((0x209u >> gt) & 1u) ? 2u : (((0x72u >> gt) & 1u) + ((0x1A4u >> gt) & 1u));
+          const uint32_t len = 32u + 13u + ((c0.w & 0xffu) ? 2u : 0u) + ((c0.w & 0xff00u) ? 2u : 0u) + 5u + 2u + ft + 2u + F_PI(dp1) + 2u + F_PI((uint32_t)mq) + 2u + F_PI(phred) +
+                               2u + F_PI(qd) + 3u + 4u * ngl + 3u + 8u * (cm <= 127u ? 1u : (cm <= 32767u ? 2u : 4u)) + (n_amq ? 3u + n_amq : 0u) + 3u + cs + 4u + 8u +
+                               (((0x16Eu >> gt) & 1u) ? 2u + F_PI((uint32_t)fs) : 0u);
+#undef F_PI
+          const bool named = dbsnp ? dbsnp[i] != 0 : false;
+          emit_p[i] = (uint8_t)((named || len > 254u || fs < 0 || gt > 9 || ngl > 6u) ? 255u : len);
+        }
       }
       const uint32_t d_inf = c[4] + c[5] + c[6] + c[7], dpt = c[0] + c[1] + c[2] + c[3] + d_inf;
       F.called = true;
@@ -876,7 +895,8 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
         od[7] = qd;
         /* The record's length as BCF2 (csrc/bcfdev.hip bcf_emit_body, with one-byte dictionary indices and no ID), for the byte of emit
          * flags: the encoder's size pass then reads a byte per position instead of the records (round 6).  255 = "ask the record": a
-         * heterozygous call (FS and its FILTER bits come after the tile), a dbSNP-flagged position (its name), anything longer than 254. */
+         * heterozygous call (FS and its FILTER bits come after the tile: f_fisher_pending writes the byte again when it has them), a dbSNP-flagged
+         * position (its name), anything longer than 254. */
         if (K_COLD(emit_out)) {
           uint32_t cm = cnt[0] > cnt[1] ? cnt[0] : cnt[1], n_amq = 0;
 #pragma unroll
@@ -1137,7 +1157,7 @@ __global__ __launch_bounds__(64 * FW, FW / 4) void bsc_chain_kernel_t(const bsc_
       const unsigned nb = n_pend - k0 < 64u ? n_pend - k0 : 64u;
       const uint32_t *ent = wl + (uint64_t)(k0 + lane0) * (READS ? F_HET_DW : 1u);
       const uint32_t e = lane0 < nb ? __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      f_fisher_pending<READS, SUMM>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_base, K_COLD(tb)->lfact, s_logtab, s_exptab, h, stat_words);
+      f_fisher_pending<READS, SUMM>(e, nb, lane0, READS ? ent : cts, dbsnp, a, core_base, K_COLD(tb)->lfact, s_logtab, s_exptab, h, stat_words, K_COLD(emit_out));
     }
   }
   if (run >= n_runs_all) break; /* wave-uniform */
