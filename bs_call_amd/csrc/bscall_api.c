@@ -1649,7 +1649,7 @@ static int bsc_prep_queue(bsc_context *ctx, const void *d_raw, uint32_t nr, cons
     if ((rc = bsc_reserve(&ctx->d_pprof, &ctx->cap_pprof, prof_bytes))) return rc;
     if ((rc = bsc_reserve(&ctx->d_pmax, &ctx->cap_pmax, (size_t)nr * 4u))) return rc;
     if ((rc = bsc_reserve(&ctx->d_pused, &ctx->cap_pused, (size_t)nr * 4u))) return rc;
-    if ((rc = bsc_reserve(&ctx->d_pmask, &ctx->cap_pmask, (size_t)pf->n_ref + 20u))) return rc; /* a byte per code of the block (csrc/prepdev.hip) */
+    if ((rc = bsc_reserve(&ctx->d_pmask, &ctx->cap_pmask, (size_t)pf->n_ref + 28u))) return rc; /* a byte per code of the block (csrc/prepdev.hip) */
     HIP_TRY(hipMemsetAsync(ctx->d_pprof, 0, prof_bytes, s));
   }
   HIP_TRY(hipMemsetAsync(ctx->d_pcnt, 0, BSC_PREP_CNT_ALL * sizeof(unsigned long long), s));

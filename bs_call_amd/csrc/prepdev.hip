@@ -732,19 +732,20 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
  *   bsc_prep_refmask_kernel  once per call, a byte per reference position: 4 = a C followed by A / C / T, 8 = a G preceded by A / G / T
  *                            (PROF_REF over the two pairs of codes around it, 0 where the walk has no code behind it), 8 bytes of
  *                            zeros in front and behind, so that a dword of it can be fetched anywhere near the block.
- *   bsc_prep_profile_kernel  lanes own READ POSITIONS, not output bytes: lane h holds positions 4h .. 4h + 3 of every read it sees and
- *                            keeps their counts in registers — four bytes side by side in a dword per base code, flushed to the
- *                            workgroup's table in LDS every 255 reads — so a counted base costs a byte-parallel add and no atomic.  The
- *                            prepared bytes of those positions are one unaligned dword (byte-swapped for read 1, whose positions run
- *                            against its bytes), the mask bytes another.  Reads of up to 128 positions (pc + length) go two to a wave,
- *                            one per half; up to 256, one to a wave; the rest — and the reads the list cut or padded, whose bytes are
- *                            not at a fixed distance from their positions, and strand 0 — byte by byte with atomics as before.
+ *   bsc_prep_profile_kernel  lanes own READ POSITIONS, not output bytes: lane h holds positions 8h .. 8h + 7 of every read it sees and
+ *                            keeps their counts in registers — four bytes side by side in a dword, two dwords per base code, flushed to
+ *                            the workgroup's table in LDS every 255 reads — so a counted base costs a byte-parallel add and no atomic.
+ *                            The prepared bytes of those positions are one unaligned 8-byte load (byte-swapped for read 1, whose
+ *                            positions run against its bytes), the mask bytes another.  Reads of up to 128 positions (pc + length) go
+ *                            four to a wave, sixteen lanes each; up to 256, two to a wave; the rest — and the reads the list cut or
+ *                            padded, whose bytes are not at a fixed distance from their positions, and strand 0 — byte by byte with
+ *                            atomics as before.  (First form: four bytes a lane, two / one reads to a wave: 0.87 ms against 0.76.)
  * bs_strand 2 counts a base in the column bs_strand 1 counts its complement in (src/init_param.c:57-70: {11,4,10,5} / {9,6,8,7}), so the
  * registers are kept by base code (complemented for strand 2) and the column is looked up at the flush.
  */
 __global__ __launch_bounds__(256) void bsc_prep_refmask_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref, uint8_t *__restrict__ mask) {
   const uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u; /* mask[i .. i + 3]: positions v = i - 8 .. (the arrays' starts are 4-byte aligned) */
-  if (i >= (uint64_t)n_ref + 16u) return;
+  if (i >= (uint64_t)n_ref + 24u) return;
   uint32_t m = 0;
   if (i >= 12u && i - 8u + 7u <= n_ref) { /* codes v - 1 .. v + 6 exist: four positions at once, byte-parallel */
     const uint64_t v = i - 8u;
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(256) void bsc_prep_refmask_kernel(const uint8_t *__
       }
     }
   }
-  __builtin_memcpy(mask + i, &m, 4); /* (the workspace is n_ref + 16 bytes rounded up to 4) */
+  __builtin_memcpy(mask + i, &m, 4); /* (the workspace is n_ref + 24 bytes rounded up to 4: 8 bytes of zeros in front, 16 behind) */
 }
 
 __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_profile_kernel(const bsc_prep_plan *__restrict__ plan, const bsc_prep_desc *__restrict__ desc,
@@ -781,20 +782,20 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_profile_kernel(const
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * PREP_WAVES + (threadIdx.x >> 6)));
   const uint32_t n_waves = gridDim.x * PREP_WAVES;
   const uint32_t n_reads2 = 2u * nr, n_groups = (n_reads2 + 63u) / 64u;
-  uint32_t acc[4] = {0u, 0u, 0u, 0u}; /* by base code: counts of this lane's four positions, a byte each */
+  uint32_t acc[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}}; /* by base code: counts of this lane's eight positions, a byte each */
   uint32_t acc_n = 0;                 /* reads since the last flush (wave-uniform) */
-  bool acc_half = true;               /* whose positions the registers hold: 4 (lane & 31) .. or 4 lane .. */
+  bool acc_quarter = true;            /* whose positions the registers hold: 8 (lane & 15) .. or 8 (lane & 31) .. */
   auto flush = [&]() {
-    const uint32_t p0 = 4u * (acc_half ? (lane & 31u) : lane);
+    const uint32_t p0 = 8u * (acc_quarter ? (lane & 15u) : (lane & 31u));
 #pragma unroll
     for (uint32_t b = 0; b < 4u; b++) {
       const uint32_t col = (0x63u >> (2u * b)) & 3u; /* strand 1's column of base code b */
 #pragma unroll
-      for (uint32_t t = 0; t < 4u; t++) {
-        const uint32_t c = (acc[b] >> (8u * t)) & 0xffu;
+      for (uint32_t t = 0; t < 8u; t++) {
+        const uint32_t c = (acc[b][t >> 2] >> (8u * (t & 3u))) & 0xffu;
         if (c) atomicAdd(&s_prof[col * PROF_LDS + p0 + t + 1u], c); /* (p0 + t + 1 <= 256 < PROF_LDS; kept positions only: see lim) */
       }
-      acc[b] = 0u;
+      acc[b][0] = acc[b][1] = 0u;
     }
     acc_n = 0;
   };
@@ -832,10 +833,10 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_profile_kernel(const
           const int32_t pc = L.pc;
           top = my_k ? (uint32_t)(pc < 0 ? 0 : pc) : (uint32_t)pc + ol - 1u; /* the read's highest position */
           /* in registers: bytes at a fixed distance from their positions, a strand whose column follows from the base, every position of
-           * the read inside the window of 256 and kept (top + 1 < lim: the vector only cuts reads while it still grows), and a dword
-           * three bytes to either side of the read inside the buffer */
-          const bool regs = !(fl & PD_SLOW) && l_strand != 0u && ol <= 256u && pc >= 0 && pc < 512 && top < 256u && top + 1u < lim && l_off >= 4u &&
-                            seq_out_cap - l_off - ol >= 4u;
+           * the read inside the window of 256 and kept (top + 1 < lim: the vector only cuts reads while it still grows), and eight bytes
+           * seven to either side of the read inside the buffer */
+          const bool regs = !(fl & PD_SLOW) && l_strand != 0u && ol <= 256u && pc >= 0 && pc < 512 && top < 256u && top + 1u < lim && l_off >= 8u &&
+                            seq_out_cap - l_off - ol >= 8u;
           kind = regs ? 1u : 2u;
           c1 = pos > F.x ? pos - F.x + 1u : 0u;
         }
@@ -852,19 +853,20 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_profile_kernel(const
       if (kind == 1u && orel >= (1ull << 15)) kind = 2u; /* (far from the group's first — long reads in between: the long way) */
       const uint32_t A1 = kind == 1u ? (c1 + 7u) | (l_strand == 2u ? 1u << 29 : 0u) | (1u << 31) : 0u; /* code index v = c1 - 1 lies at mask[v + 8] */
       const uint32_t A2 = kind == 1u ? (l_ol - 1u) | ((uint32_t)L.pc << 8) | ((uint32_t)orel << 17) : 0u;
-      const bool half = __ballot(kind == 1u && top >= 128u) == 0ull;
-      if (half != acc_half) {
+      const bool quarter = __ballot(kind == 1u && top >= 128u) == 0ull;
+      if (quarter != acc_quarter) {
         flush();
-        acc_half = half;
+        acc_quarter = quarter;
       }
-      const uint8_t *const sb = seq_out + obase - 4u; /* obase >= 4 */
-      const uint32_t h = half ? (lane & 31u) : lane;
-      const int32_t p0 = (int32_t)(4u * h);
-      const uint32_t hsel = half ? (lane & 32u) : 0u, rounds = half ? 32u : 64u;
-      constexpr uint32_t B = 4u; /* rounds in flight: their loads are asked for a batch ahead */
+      const uint8_t *const sb = seq_out + obase - 8u; /* obase >= 8 */
+      const uint32_t h = quarter ? (lane & 15u) : (lane & 31u);
+      const int32_t p0 = (int32_t)(8u * h);
+      const uint32_t hsel = quarter ? (lane & 48u) : (lane & 32u), rounds = quarter ? 16u : 32u;
+      constexpr uint32_t B = 2u; /* rounds in flight: their loads are asked for a batch ahead */
       struct rnd {
-        uint32_t a1, w, mw;
-        int32_t jc, len4; /* len4 = 4 - the read's length */
+        uint32_t a1;
+        unsigned long long w, mw;
+        int32_t jc, len8; /* len8 = 8 - the read's length */
       };
       /* reads alternate read 0 / read 1 of their templates, in both forms of the rounds: REV is a round's parity */
       auto ask = [&](uint32_t i, rnd &r) {
@@ -872,36 +874,41 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_profile_kernel(const
         r.a1 = (uint32_t)__shfl((int)A1, src);
         const uint32_t a2 = (uint32_t)__shfl((int)A2, src);
         const int32_t len = (int32_t)(a2 & 0xffu) + 1;
-        r.len4 = 4 - len;
+        r.len8 = 8 - len;
         const int32_t pc = (int32_t)((a2 >> 8) & 0x1ffu);
         /* output byte of this lane's lowest-addressed position: read 0: j = p - pc, ascending; read 1: j = pc - p, descending */
-        const int32_t j0 = (i & 1u) ? pc - p0 - 3 : p0 - pc;
-        const bool some = (int32_t)r.a1 < 0 && (uint32_t)(j0 + 3) < (uint32_t)(len + 3);
+        const int32_t j0 = (i & 1u) ? pc - p0 - 7 : p0 - pc;
+        const bool some = (int32_t)r.a1 < 0 && (uint32_t)(j0 + 7) < (uint32_t)(len + 7);
         r.jc = some ? j0 : 0;
-        r.w = d_ld32(sb + ((a2 >> 17) + (uint32_t)(r.jc + 4)));
+        __builtin_memcpy(&r.w, sb + ((a2 >> 17) + (uint32_t)(r.jc + 8)), 8);
         /* a round that is not this lane's (no read there, or none of its bytes at this lane's positions): mask bytes that are 0 — the
          * pad in front of the codes — and whatever the other load brings counts nothing */
-        r.mw = d_ld32(mask + (some ? (r.a1 & 0x1fffffffu) + (uint32_t)j0 : 0u));
+        __builtin_memcpy(&r.mw, mask + (some ? (r.a1 & 0x1fffffffu) + (uint32_t)j0 : 0u), 8);
       };
       auto count = [&](uint32_t i, const rnd &r) {
-        const int32_t lo = r.jc < 0 ? -r.jc : 0, hi = r.jc + r.len4 > 0 ? r.jc + r.len4 : 0; /* bytes of the dword in front of / behind the read: <= 3 */
-        uint32_t w = r.w & (0xffffffffu << (8 * lo)) & (0xffffffffu >> (8 * hi)); /* not the read's: quality 0, never counted */
-        uint32_t mw = r.mw;
+        const int32_t lo = r.jc < 0 ? -r.jc : 0, hi = r.jc + r.len8 > 0 ? r.jc + r.len8 : 0; /* bytes of the eight in front of / behind the read: <= 7 */
+        unsigned long long w8 = r.w & (~0ull << (8 * lo)) & (~0ull >> (8 * hi)); /* not the read's: quality 0, never counted */
+        unsigned long long m8 = r.mw;
         if (i & 1u) { /* positions ascend as the bytes descend */
-          w = __builtin_bswap32(w);
-          mw = __builtin_bswap32(mw);
+          w8 = __builtin_bswap64(w8);
+          m8 = __builtin_bswap64(m8);
         }
-        /* a base counts iff its quality is in [20, 63) and either it reads C / T (base code odd) over mask 4, or A / G over mask 8 */
-        const uint32_t odd = w << 7;
-        const uint32_t qf = ((w >> 2) & 0x3f3f3f3fu) | 0x80808080u;
-        const uint32_t q_ok = (qf - 20u * 0x01010101u) & ~((qf + 0x01010101u) << 1) & 0x80808080u;
-        const uint32_t hb = (((odd & (mw << 5)) | (~odd & (mw << 4))) & q_ok) >> 7;
-        const uint32_t wb = (r.a1 >> 29) & 1u ? ~w : w; /* strand 2: by the complement */
-        const uint32_t t1 = hb & (wb >> 1), t0 = hb ^ t1, t3 = t1 & wb, t2 = t0 & wb;
-        acc[3] += t3;
-        acc[2] += t1 ^ t3;
-        acc[1] += t2;
-        acc[0] += t0 ^ t2;
+        const uint32_t sx = (r.a1 >> 29) & 1u ? 0xffffffffu : 0u; /* strand 2: by the complement */
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+          const uint32_t w = (uint32_t)(w8 >> (32 * d)), mw = (uint32_t)(m8 >> (32 * d));
+          /* a base counts iff its quality is in [20, 63) and either it reads C / T (base code odd) over mask 4, or A / G over mask 8 */
+          const uint32_t odd = w << 7;
+          const uint32_t qf = ((w >> 2) & 0x3f3f3f3fu) | 0x80808080u;
+          const uint32_t q_ok = (qf - 20u * 0x01010101u) & ~((qf + 0x01010101u) << 1) & 0x80808080u;
+          const uint32_t hb = (((odd & (mw << 5)) | (~odd & (mw << 4))) & q_ok) >> 7;
+          const uint32_t wb = w ^ sx;
+          const uint32_t t1 = hb & (wb >> 1), t0 = hb ^ t1, t3 = t1 & wb, t2 = t0 & wb;
+          acc[3][d] += t3;
+          acc[2][d] += t1 ^ t3;
+          acc[1][d] += t2;
+          acc[0][d] += t0 ^ t2;
+        }
       };
       rnd ra[B], rb[B];
 #pragma unroll
@@ -1011,7 +1018,7 @@ extern "C" int bsc_dev_launch_prep(const void *raw, uint32_t nr, const void *seq
                      (uint8_t *)seq_out, seq_out_cap, (unsigned long long *)cnt);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   if (prof_ref) { /* the read profile: a pass of its own over the prepared bytes */
-    hipLaunchKernelGGL(bsc_prep_refmask_kernel, dim3((unsigned)(((uint64_t)prof_n_ref + 16u + 1023u) / 1024u)), dim3(256), 0, s, (const uint8_t *)prof_ref,
+    hipLaunchKernelGGL(bsc_prep_refmask_kernel, dim3((unsigned)(((uint64_t)prof_n_ref + 24u + 1023u) / 1024u)), dim3(256), 0, s, (const uint8_t *)prof_ref,
                        prof_n_ref, (uint8_t *)prof_mask);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     if (gp > (unsigned)num_cus * (unsigned)per_cu[1]) gp = (unsigned)num_cus * (unsigned)per_cu[1];
