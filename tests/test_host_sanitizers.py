@@ -1,4 +1,4 @@
-"""The library's HOST C code (csrc/bamio.c, prep.c, dbsnp.c, bcf.c, report.c, vcf_format.c, refseq.c, bscall_api.c's argument
+"""The library's HOST C code (csrc/bamio.c, bamstream.c, inflate_fast.c, prep.c, dbsnp.c, bcf.c, report.c, vcf_format.c, refseq.c, bscall_api.c's argument
 checks) under AddressSanitizer + UndefinedBehaviorSanitizer on the CPU (`make san`: gcc's runtimes; GPU sanitizers are not
 available on the pool): (1) the host-layer tests of this directory once more against the sanitized build, (2) the
 corrupted-input fuzz of the readers (tools/fuzz_host_inputs.py: damaged BAM / SAM / FASTA / dbSNP files must be read or
@@ -42,7 +42,7 @@ def _clean(p):
 
 
 def test_host_layer_tests_under_asan_ubsan(san_env):
-    files = ["test_bam.py", "test_prep.py", "test_dbsnp.py", "test_bcf.py", "test_report.py", "test_abi_exports.py"]
+    files = ["test_bam.py", "test_prep.py", "test_dbsnp.py", "test_bcf.py", "test_report.py", "test_abi_exports.py", "test_bamstream.py", "test_inflate_fast.py"]
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", *[os.path.join(ROOT, "tests", f) for f in files]],
                        cwd=ROOT, env=san_env, capture_output=True, text=True, timeout=1500)
     _clean(p)

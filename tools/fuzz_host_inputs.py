@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Corrupted-input fuzz of the library's HOST readers (csrc/bamio.c: BAM / SAM text / FASTA; csrc/dbsnp.c: the dbSNP index;
+"""Corrupted-input fuzz of the library's HOST readers (csrc/bamio.c: BAM / SAM text / FASTA; csrc/bamstream.c + csrc/inflate_fast.c: the
+device reader's host half over the same damaged BAM files; csrc/dbsnp.c: the dbSNP index;
 csrc/prep.c behind the reader): valid files written by tools/make_bam.py / tools/make_dbsnp_index.py are damaged — bytes of
 the UNCOMPRESSED payload flipped, 32-bit fields set to extreme values, pieces cut out or repeated, then compressed again so
 the damage reaches the parsers and not only the inflate / CRC checks; and the same damage done to the compressed files — and
@@ -126,6 +127,25 @@ def drain_reader(path, prep=None, **kw):
         return "refused"
 
 
+def drain_stream(path, rng):
+    """the device reader's host half (csrc/bamstream.c + csrc/inflate_fast.c: the BGZF block index, the helpers' own inflate and CRC-32, the
+    speculative record walk and its check) over the same damaged file, whole or by contig: every slab touched; BscError = a clean refusal"""
+    from bs_call_amd.bamdev import BamStream
+
+    try:
+        kw = {}
+        if rng.random() < 0.3:
+            kw["contigs"] = [int(v) for v in rng.choice([-1, 0, 1, 2, 7], size=int(rng.integers(0, 3)), replace=False)]
+        with BamStream(path, threads=int(rng.integers(1, 4)), slab_bytes=int(rng.choice([0, 65536, 1 << 20])), n_slabs=int(rng.choice([0, 2, 3])), **kw) as s:
+            n = 0
+            for off, data, offs, last in s.slabs():
+                n += len(data) + int(offs.sum() & 1)
+            _ = s.refs, s.header_text, s.first_record
+        return "ok"
+    except BscError:
+        return "refused"
+
+
 def prep_step(rng, stats):
     """bsc_prepare_templates (csrc/prep.c) on a block as read, then with the block's arrays damaged: offsets, lengths, mismatch
     lists and positions are the caller's, and the entry must refuse what does not fit its buffers"""
@@ -196,6 +216,7 @@ def one_bam(rng, d, stats):
     else:  # a record cut by a block boundary at every possible place: small blocks
         write_bgzf(p, damage(rng, data), int(rng.integers(30, 400)))
     stats["bam_" + drain_reader(p, prep=prep_step(rng, stats), threads=int(rng.integers(0, 3)))] += 1
+    stats["bamstream_" + drain_stream(p, rng)] += 1
 
 
 def one_sam(rng, d, stats):
