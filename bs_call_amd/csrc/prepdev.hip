@@ -591,7 +591,6 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
   /* per lane: bytes that count, those of quality 63, those of quality >= mq; reads, their bases */
   unsigned long long l_total = 0, l_bases = 0;
   uint32_t c63 = 0, cge = 0, l_reads = 0;
-  constexpr uint32_t R = 2u * PREP_BATCH;
   const uint32_t n_reads2 = 2u * nr, n_groups = (n_reads2 + 63u) / 64u;
   for (uint32_t g = wave; g < n_groups; g += n_waves) {
     const uint32_t g0 = g * 64u, n = n_reads2 - g0 < 64u ? n_reads2 - g0 : 64u;
@@ -631,83 +630,117 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void bsc_prep_copy_kernel(const bs
     /* where the read's bytes start, as an offset from desc[] (a pointer the compiler knows to be global memory; a broadcast
      * pointer would be a generic one); a read that is not fetched: desc[] itself, four bytes that exist */
     const unsigned long long l_src = my_fetch ? (unsigned long long)(seq + L.srcw) - (unsigned long long)desc : 0ull;
-    const uint32_t l_last = my_fetch ? my_len - 4u : 0u;
     unsigned long long walked_mask = 0; /* bit r: read r (an even one: a template's read 0) was walked */
-    /* the first 256 bytes of R reads at a time, asked for one round ahead: a round's loads are in flight while the round
-     * before it is counted and stored (and do not queue behind its stores).  No branch around a load: the wait for a round's
-     * loads can then leave the next round's in flight.  (A round past the group's last wraps round to its first lanes: loads
-     * of bytes that exist, unused.) */
-    auto fetch = [&](uint32_t i0, uint32_t(&vv)[R]) {
+    /* EIGHT READS A ROUND, sixteen bytes a lane (round 6, second form of this loop; before: one read a round, four bytes a lane — 25 of 64
+     * lanes carrying a 100-base read's bytes, 52 instructions a read, and the issue slots were what the kernel ran out of): lanes 8 s .. 8 s + 7
+     * take read 8 s + i in round i, lane h of them bytes 16 h .. 16 h + 15 with ONE byte-unaligned 16-byte load and store — the last lane of
+     * a length that is no multiple of sixteen moves the read's last sixteen bytes, overlapping its neighbour (same values twice; the bytes
+     * it shares are masked out of the counters).  For the reads that move as they stand and are 16 .. 128 bytes long; the others (longer,
+     * shorter, marked by a left trim, or byte by byte from their plan) follow one at a time, the whole wave on each.  What a round needs of a
+     * read comes from the read's own lane by ds_bpermute: length | its place from the group's lowest << 8, and where its bytes start from
+     * the group's lowest source.  R rounds' loads are asked for a batch ahead of the batch being counted and stored (two register buffers in
+     * turn, no branch around a load). */
+    const unsigned long long obase = d_bcast64(l_off, 0);                       /* (the places ascend with the reads) */
+    const unsigned long long m_w0 = __ballot(my_kind == KIND_LEAN && my_len >= 16u && my_len <= 128u);
+    const unsigned long long sbase = m_w0 ? d_bcast64(L.srcw, (uint32_t)__builtin_ctzll(m_w0)) : 0ull;
+    const unsigned long long orel = l_off - obase, srel = L.srcw - sbase;
+    const bool my_wide = my_kind == KIND_LEAN && my_len >= 16u && my_len <= 128u && orel < (1ull << 24) && srel < (1ull << 31);
+    const uint32_t w_a = my_wide ? my_len | ((uint32_t)orel << 8) : 0u, w_s = my_wide ? (uint32_t)srel : 0u;
+    const uint32_t l16 = (lane & 7u) * 16u, sub = lane & 56u;
+    const uint8_t *const sp_w = seq + sbase;
+    uint8_t *const dp_w = seq_out + obase;
+    uint32_t walk_bits = 0; /* bit i: this lane saw a byte of its round-i read with a quality that is neither 0 nor 63 */
+    constexpr uint32_t RW = 2u; /* rounds in a batch */
+    auto fetch8 = [&](uint32_t i0, uint4(&vv)[RW]) {
 #pragma unroll
-      for (uint32_t i = 0; i < R; i++) {
-        const uint32_t l = i0 + i, last = d_bcast(l_last, l);
-        vv[i] = d_ld32((const uint8_t *)desc + d_bcast64(l_src, l) + (lane4 < last ? lane4 : last)); /* (idle lanes fetch the read's last dword) */
+      for (uint32_t i = 0; i < RW; i++) {
+        const int src = (int)(sub | ((i0 + i) & 7u));
+        const uint32_t len = (uint32_t)__shfl((int)w_a, src) & 0xffu, so = (uint32_t)__shfl((int)w_s, src);
+        const uint32_t last = len ? len - 16u : 0u;
+        __builtin_memcpy(&vv[i], sp_w + (so + (l16 < last ? l16 : last)), 16); /* (idle lanes fetch the read's last sixteen bytes; no read: the group's first) */
       }
     };
-    auto process = [&](const uint32_t i0, const uint32_t(&v)[R]) {
+    auto process8 = [&](const uint32_t i0, const uint4(&v)[RW]) {
 #pragma unroll
-      for (uint32_t i = 0; i < R; i++) {
-        const uint32_t l = i0 + i, k = i & 1u; /* (g0 and i0 are even) */
-        const uint32_t ctl = d_bcast(l_ctl, l), kind = (ctl >> 28) & 3u, len = ctl & 0xfffffu;
-        if (kind == 0) continue;
-        uint8_t *const dp = seq_out + d_bcast64(l_off, l);
-        if (kind == KIND_LEAN) {
-          const bool act = lane4 < len;
-          const uint32_t o = lane4 < len - 4u ? lane4 : len - 4u, w = v[i];
-          /* bytes this lane shares with its neighbour (the low ones of a last, overlapping dword) do not count twice: shifted
-           * out; what comes in is quality 0, base 0 — neither 63 nor walked nor (mq > 0) >= mq — like an idle lane's zero */
-          const uint32_t wc = act ? w >> (8u * (lane4 - o)) : 0u;
+      for (uint32_t i = 0; i < RW; i++) {
+        const uint32_t l = i0 + i;
+        const int src = (int)(sub | l);
+        const uint32_t a_ = (uint32_t)__shfl((int)w_a, src), len = a_ & 0xffu;
+        const bool act = l16 < len;
+        const uint32_t o = l16 < len - 16u ? l16 : len - 16u, dup = act ? l16 - o : 16u; /* bytes this lane shares with its neighbour: not counted twice */
+        const uint32_t w4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        uint32_t any = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < 4u; d++) {
+          /* bytes whose index in the sixteen is below dup: out (an idle lane: all of them) — what is left in their place is quality 0,
+           * base 0: neither 63 nor walked nor (mq > 0) >= mq */
+          const uint32_t ge = (((0x83828180u + 0x04040404u * d) - dup * 0x01010101u) >> 7) & 0x01010101u; /* 1: index >= dup */
+          const uint32_t wc = w4[d] & (ge * 0xffu);
           const uint32_t qh = ((wc >> 2) & 0x3f3f3f3fu) | 0x80808080u; /* 0x80 + quality, byte by byte */
           const uint32_t q1 = qh + 0x01010101u;                        /* bit 6: quality 63; bits 1..5 clear: quality 0 or 63 */
           c63 += (uint32_t)__popc(q1 & 0x40404040u);
           cge += (uint32_t)__popc((qh - mq4) & 0x80808080u);           /* bit 7: quality >= mq */
-          /* was read 0 walked: a quality that is neither 0 nor 63 (src/call_genotypes.c:198-211) */
-          const bool walked = k == 0 && __any((q1 & 0x3e3e3e3eu) != 0u) != 0;
-          if (act) d_st32(dp + o, w);
-          if (k == 0 && walked) walked_mask |= 1ull << l;
-          continue;
+          any |= q1 & 0x3e3e3e3eu;
         }
-        if (kind == KIND_SLOW) {
-          const prep_slow_ret r = prep_slow_read(plan + g0 + l, (ctl >> 30) & 1u ? PD_EDITED : 0u, dp, seq, ms_work, mq);
-          c63 += r.c63;
-          cge += r.cge;
-          if (k == 0 && r.walked) walked_mask |= 1ull << l;
-          continue;
-        }
-        const uint32_t ml = (ctl >> 20) & 0xffu;
-        bool walked = false;
-        for (uint32_t base = 0; base < len; base += 256u) {
-          const uint32_t nominal = base + lane4;
-          const bool act = nominal < len;
-          const uint32_t o = nominal < len - 4u ? nominal : len - 4u;
-          uint32_t w = v[i];
-          if (base) w = act ? d_ld32((const uint8_t *)desc + d_bcast64(l_src, l) + o) : 0u;
-          if (ml + 3u > base) { /* the left trim's mark: quality 63 on bytes below ml (a last, overlapping dword reaches up to
-                                   three bytes back into the round before: they must be stored as that round marked them) */
-            const uint32_t nmk = act && ml > o ? (ml - o < 4u ? ml - o : 4u) : 0u;
-            const uint32_t mm = nmk >= 4u ? 0xffffffffu : (1u << (8u * nmk)) - 1u;
-            w = (w & ~mm) | (((w & 0x03030303u) | 0xfcfcfcfcu) & mm);
-          }
-          const uint32_t wc = act ? w >> (8u * (nominal - o)) : 0u; /* (as above; an idle lane counts like a zero) */
-          const uint32_t qh = ((wc >> 2) & 0x3f3f3f3fu) | 0x80808080u;
-          const uint32_t q1 = qh + 0x01010101u;
-          c63 += (uint32_t)__popc(q1 & 0x40404040u);
-          cge += (uint32_t)__popc((qh - mq4) & 0x80808080u);
-          if (k == 0) walked |= __any((q1 & 0x3e3e3e3eu) != 0u) != 0;
-          if (act) d_st32(dp + o, w);
-        }
-        if (k == 0 && walked) walked_mask |= 1ull << l;
+        if (any) walk_bits |= 1u << l;
+        if (act) __builtin_memcpy(dp_w + ((a_ >> 8) + o), &v[i], 16);
       }
     };
-    /* two buffers in turn: no register is copied, so nothing waits for a round's loads before that round's turn */
-    uint32_t va[R], vb[R];
-    fetch(0, va);
-    for (uint32_t i0 = 0; i0 < n; i0 += 2u * R) { /* (n is even and so is R: reads past n are of kind 0) */
-      fetch(i0 + R, vb);
-      process(i0, va);
-      fetch(i0 + 2u * R, va);
-      if (i0 + R < n) process(i0 + R, vb);
+    /* one read, the whole wave, four bytes a lane: longer than 128 bytes or shorter than 16, marked by a left trim, or byte by byte from its plan */
+    auto one = [&](const uint32_t l) {
+      const uint32_t k = l & 1u;
+      const uint32_t ctl = d_bcast(l_ctl, l), kind = (ctl >> 28) & 3u, len = ctl & 0xfffffu;
+      uint8_t *const dp = seq_out + d_bcast64(l_off, l);
+      if (kind == KIND_SLOW) {
+        const prep_slow_ret r = prep_slow_read(plan + g0 + l, (ctl >> 30) & 1u ? PD_EDITED : 0u, dp, seq, ms_work, mq);
+        c63 += r.c63;
+        cge += r.cge;
+        if (k == 0 && r.walked) walked_mask |= 1ull << l;
+        return;
+      }
+      const uint32_t ml = (ctl >> 20) & 0xffu;
+      bool walked = false;
+      for (uint32_t base = 0; base < len; base += 256u) {
+        const uint32_t nominal = base + lane4;
+        const bool act = nominal < len;
+        const uint32_t o = nominal < len - 4u ? nominal : len - 4u;
+        uint32_t w = act ? d_ld32((const uint8_t *)desc + d_bcast64(l_src, l) + o) : 0u;
+        if (ml + 3u > base) { /* the left trim's mark: quality 63 on bytes below ml (a last, overlapping dword reaches up to
+                                 three bytes back into the round before: they must be stored as that round marked them) */
+          const uint32_t nmk = act && ml > o ? (ml - o < 4u ? ml - o : 4u) : 0u;
+          const uint32_t mm = nmk >= 4u ? 0xffffffffu : (1u << (8u * nmk)) - 1u;
+          w = (w & ~mm) | (((w & 0x03030303u) | 0xfcfcfcfcu) & mm);
+        }
+        /* bytes this lane shares with its neighbour (the low ones of a last, overlapping dword) do not count twice: shifted out; what
+         * comes in is quality 0, like an idle lane's zero */
+        const uint32_t wc = act ? w >> (8u * (nominal - o)) : 0u;
+        const uint32_t qh = ((wc >> 2) & 0x3f3f3f3fu) | 0x80808080u;
+        const uint32_t q1 = qh + 0x01010101u;
+        c63 += (uint32_t)__popc(q1 & 0x40404040u);
+        cge += (uint32_t)__popc((qh - mq4) & 0x80808080u);
+        if (k == 0) walked |= __any((q1 & 0x3e3e3e3eu) != 0u) != 0; /* was read 0 walked (src/call_genotypes.c:198-211) */
+        if (act) d_st32(dp + o, w);
+      }
+      if (k == 0 && walked) walked_mask |= 1ull << l;
+    };
+    if (__ballot(my_wide)) {
+      /* two buffers in turn: no register is copied, so nothing waits for a round's loads before that round's turn */
+      uint4 va[RW], vb[RW];
+      fetch8(0, va);
+#pragma unroll
+      for (uint32_t i0 = 0; i0 < 8u; i0 += 2u * RW) {
+        fetch8(i0 + RW, vb);
+        process8(i0, va);
+        fetch8(i0 + 2u * RW, va);
+        process8(i0 + RW, vb);
+      }
+      /* was read r walked: some lane of its eight saw such a byte in round r & 7 */
+      walk_bits |= (uint32_t)__shfl_xor((int)walk_bits, 1);
+      walk_bits |= (uint32_t)__shfl_xor((int)walk_bits, 2);
+      walk_bits |= (uint32_t)__shfl_xor((int)walk_bits, 4);
+      walked_mask |= __ballot((walk_bits >> (lane & 7u)) & 1u);
     }
+    for (unsigned long long rest = __ballot(my_kind != 0u && !my_wide); rest; rest &= rest - 1ull) one((uint32_t)__builtin_ctzll(rest));
     if (lane < n && my_k == 0) tpl_out[my_ti].flags = BSC_TPL_WALK_KNOWN | (((walked_mask >> lane) & 1ull) ? BSC_TPL_WALKED0 : 0u);
   }
   unsigned long long w[5] = {l_total, c63, cge, l_reads, l_bases};
