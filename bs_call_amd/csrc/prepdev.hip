@@ -15,16 +15,20 @@
  *                          Per read a 16-byte descriptor (where its bytes start, length, left mark, flags); the full 56-byte plan
  *                          only for the reads that need it (the list cuts or pads, a right trim, very short / very long).
  *   bsc_prep_copy_kernel   one wave per 64 reads at a time: lane r fetches read r's descriptor and place and does the per-read
- *                          bookkeeping, then the wave walks the reads, descriptors broadcast lane by lane.  A read whose output is
- *                          its window moves as dwords — lane l one unaligned 4-byte load and store, eight reads' loads in flight a
- *                          round ahead of the round being stored; the left trim's mark (quality 63) and the base counters of the
- *                          statistics (:50-59) are byte-parallel arithmetic on the dword, bsc_template.flags (was read 0 walked,
- *                          src/call_genotypes.c:198-211) one lane vote.  The other reads go byte by byte: output byte j from the
- *                          inverse of the list's edits — walked backwards, a padded deletion gives 0, everything else an index
- *                          into the window — through the fixed trims' marks (the right trim takes the BASE of the byte mirrored at
- *                          the read's other end, as the reference's loop does).
- * Measured (tools/bench_prep.py, 50 Mb at 30x, 7.5 M templates, 1.48 G bases, every 50th read with an indel pair): plan 0.36 ms,
- * prefix sum 0.1 ms, copy 1.5 ms (2 x 1.5 GB of read bytes + 0.5 GB of descriptors and places at 2.8 TB/s; VALU issue 57 %).
+ *                          bookkeeping; then the reads whose output is their window as it stands (16 .. 128 bytes: nearly all) move EIGHT
+ *                          A ROUND, sixteen bytes a lane — one byte-unaligned 16-byte load and store per lane, what a round needs of a
+ *                          read fetched from the read's own lane by ds_bpermute, two rounds' loads in flight ahead of the rounds being
+ *                          stored (round 6; round 5: one read a round, four bytes a lane); the left trim's mark (quality 63) and the
+ *                          base counters of the statistics (:50-59) are byte-parallel arithmetic on the dwords, bsc_template.flags (was
+ *                          read 0 walked, src/call_genotypes.c:198-211) a bit per round OR-ed over a read's lanes.  The other reads
+ *                          follow one at a time: longer / shorter / marked ones four bytes a lane, edited ones byte by byte — output
+ *                          byte j from the inverse of the list's edits (walked backwards, a padded deletion gives 0, everything else
+ *                          an index into the window) through the fixed trims' marks (the right trim takes the BASE of the byte
+ *                          mirrored at the read's other end, as the reference's loop does).
+ *   bsc_prep_refmask_kernel / bsc_prep_profile_kernel (round 6)   the non-CpG read profile as a pass of its own over the prepared bytes.
+ * Measured (tools/bench_prep.py, 50 Mb at 30x, 7.5 M templates, 1.48 G bases, every 50th read with an indel pair): plan 0.22 ms,
+ * prefix sum 0.11 ms, copy 1.11 ms (2 x 1.5 GB of read bytes + 0.5 GB of descriptors and places at 3.8 TB/s), with the read profile
+ * + 0.04 + 0.74 ms (profiles/r06_prep_profile_kernels_timed_3.txt).
  * The round-5 form it replaces — one wave per template, its plan through the scalar cache, a byte per lane — took 0.9 + 6.4 ms:
  * profiles/r05_prep.json.
  * Where the reference aborts (an illegal soft clip ...) the lowest offending template and its first failing check come back
@@ -490,14 +494,12 @@ __device__ static __forceinline__ void d_prof_base(const bsc_prep_prof &F, uint3
 
 /*
  * One wave per 64 reads (32 templates) at a time.  Lane r fetches read r's descriptor and place (coalesced; streaming them through
- * the scalar cache instead holds the whole kernel to 0.5 TB/s) and does the per-read bookkeeping.  The wave then walks the reads
- * four at a time, their descriptors broadcast lane by lane, so everything about a read is wave-uniform: lane l moves bytes
- * 4l .. 4l + 3 of the read with ONE unaligned dword load and one dword store — the last lane of a length that is no multiple of
- * four moves the read's last four bytes, overlapping its neighbour (same values twice) — so a read of up to 256 bases is one load
- * and one store instruction; the loads of the four reads are in flight together.  The base counters are byte-parallel arithmetic
- * on the dword (qualities are 6 bits: bit 6 / bit 7 of every byte are free for the carries) and per-lane population counts.
- * Reads the list cuts or pads, reads with a right trim (mirrored bases), reads shorter than four bytes and reads that do not fit
- * the output go the long way, byte by byte (prep_slow_read).
+ * the scalar cache instead holds the whole kernel to 0.5 TB/s) and does the per-read bookkeeping.  The reads then move eight a round,
+ * sixteen bytes a lane (the loop's own comment in bsc_prep_copy_kernel); the base counters are byte-parallel arithmetic on the dwords
+ * (qualities are 6 bits: bit 6 / bit 7 of every byte are free for the carries) and per-lane population counts.  Reads longer than 128
+ * or shorter than 16 bytes and reads a left trim marks move one at a time, four bytes a lane, their descriptors broadcast by
+ * v_readlane; reads the list cuts or pads, reads with a right trim (mirrored bases), reads shorter than four bytes and reads that do
+ * not fit the output go the long way, byte by byte (prep_slow_read).
  */
 __device__ static __forceinline__ uint32_t d_bcast(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ static __forceinline__ unsigned long long d_bcast64(unsigned long long v, uint32_t l) {
