@@ -100,6 +100,10 @@ EXPORTS = (
     "bsc_set_profiling",
     "bsc_set_reads_fused",
     "bsc_block_bcf_again",
+    "bsc_bcf_stream_detach",
+    "bsc_detached_read",
+    "bsc_detached_wait",
+    "bsc_detached_free",
     "bsc_debug_fail_summary_alloc",
     "bsc_last_kernel_ms",
     "bsc_kernel_ms_history",
@@ -454,6 +458,14 @@ def load():
     L.bsc_dbsnp_name.argtypes = [vp, u32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.bsc_set_reads_fused.restype = i32
     L.bsc_set_reads_fused.argtypes = [vp, i32]
+    L.bsc_bcf_stream_detach.restype = i32
+    L.bsc_bcf_stream_detach.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.bsc_detached_read.restype = i32
+    L.bsc_detached_read.argtypes = [vp, vp, u64, u64, vp]
+    L.bsc_detached_wait.restype = i32
+    L.bsc_detached_wait.argtypes = [vp]
+    L.bsc_detached_free.restype = i32
+    L.bsc_detached_free.argtypes = [vp, vp]
     L.bsc_block_bcf_again.restype = i32
     L.bsc_block_bcf_again.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.bsc_debug_fail_summary_alloc.restype = i32

@@ -151,6 +151,15 @@ struct bsc_context {
    * many bytes went ahead of the length, the bytes per position the next copy is sized from */
   void *d_btb, *d_bto, *d_bscn, *d_bnm, *d_bcf, *d_btot;
   size_t cap_btb, cap_bto, cap_bscn, cap_bnm, cap_bcf, cap_btot;
+  struct { /* streams handed to the caller (bsc_bcf_stream_detach) come back here (bsc_detached_free) and are taken again by the next block:
+            * no hipMalloc / hipFree — a device-wide wait — in the steady state of a run that writes behind the calling */
+    void *p[4];
+    size_t cap[4];
+  } bcf_pool;
+  pthread_mutex_t pool_mu;
+  int pool_mu_made;
+  void *det_ptr[4]; /* the buffers that are out, by pool slot */
+  hipStream_t s_det; /* the detached streams' copies out: another thread's, beside the context's own stream */
   void *h_names; /* page-locked: a block entry's names table on its way up (bsc_names_upload) */
   size_t cap_hnm;
   const bsc_bcf_names *names_up; /* set around the encoder's call of a block entry: this table is in d_bnm already */
@@ -500,6 +509,10 @@ int bsc_destroy(bsc_context *ctx) {
   hipFree(ctx->d_bscn);
   hipFree(ctx->d_bnm);
   if (ctx->h_names) hipHostFree(ctx->h_names);
+  for (int k = 0; k < 4; k++)
+    if (ctx->bcf_pool.p[k]) hipFree(ctx->bcf_pool.p[k]);
+  if (ctx->s_det) hipStreamDestroy(ctx->s_det);
+  if (ctx->pool_mu_made) pthread_mutex_destroy(&ctx->pool_mu);
   hipFree(ctx->d_bcf);
   hipFree(ctx->d_btot);
   hipFree(ctx->d_emit);
@@ -1886,6 +1899,7 @@ int bsc_bcf_sites_len_device(bsc_context *ctx, const void *d_core, const void *d
   return rc;
 }
 
+static void bsc_bcf_pool_take(bsc_context *ctx, size_t need);
 /* what bsc_block_bcf asks of bsc_records_queue: the encoder behind the packing, its stream instead of the records on the way back */
 typedef struct {
   int32_t rid;
@@ -1971,6 +1985,7 @@ static int bsc_records_queue(bsc_context *ctx, const bsc_template *tpl, uint32_t
   if (bcf) { /* no packed records at all: the encoder reads the chain's per-position arrays; the block's stream goes back */
     out = NULL;
     out_cap = 0;
+    bsc_bcf_pool_take(ctx, (size_t)(bcf->out_cap ? bcf->out_cap : 1));
     if ((rc = bsc_reserve(&ctx->d_bcf, &ctx->cap_bcf, (size_t)(bcf->out_cap ? bcf->out_cap : 1)))) return rc;
     if ((rc = bsc_reserve(&ctx->d_btot, &ctx->cap_btot, 3 * sizeof(unsigned long long)))) return rc;
   }
@@ -2426,6 +2441,85 @@ int bsc_block_bcf_rawdev_keep(bsc_context *ctx, const void *d_raw, uint32_t nr, 
   }
   *n_bytes = ctx->bcf_bytes;
   return rc;
+}
+
+/* ---- a block's stream handed over: the caller reads it out (on another thread, another stream) while the context goes on ---------------- */
+static void bsc_bcf_pool_take(bsc_context *ctx, size_t need) { /* before d_bcf is reserved: a buffer that came back, if the context has none */
+  if (ctx->d_bcf || !ctx->pool_mu_made) return;
+  pthread_mutex_lock(&ctx->pool_mu);
+  int best = -1;
+  for (int k = 0; k < 4; k++)
+    if (ctx->bcf_pool.p[k] && (best < 0 || ctx->bcf_pool.cap[k] > ctx->bcf_pool.cap[best])) best = k;
+  if (best >= 0 && ctx->bcf_pool.cap[best] >= need) {
+    ctx->d_bcf = ctx->bcf_pool.p[best];
+    ctx->cap_bcf = ctx->bcf_pool.cap[best];
+    ctx->bcf_pool.p[best] = NULL;
+    ctx->bcf_pool.cap[best] = 0;
+  }
+  pthread_mutex_unlock(&ctx->pool_mu);
+}
+
+int bsc_bcf_stream_detach(bsc_context *ctx, void **d_stream, uint64_t *n_bytes) {
+  if (!ctx || !d_stream || !n_bytes) return bsc_fail(BSC_ERR_ARG, "bsc_bcf_stream_detach: NULL argument");
+  *d_stream = NULL;
+  *n_bytes = 0;
+  if (!ctx->bcf_keep || ctx->rec_pending || !ctx->d_bcf) return bsc_fail(BSC_ERR_ARG, "bsc_bcf_stream_detach: the last call left no stream on the device");
+  BSC_ENTER(ctx);
+  if (!ctx->pool_mu_made) {
+    pthread_mutex_init(&ctx->pool_mu, NULL);
+    ctx->pool_mu_made = 1;
+  }
+  if (!ctx->s_det) HIP_TRY(hipStreamCreateWithFlags(&ctx->s_det, hipStreamNonBlocking));
+  *d_stream = ctx->d_bcf;
+  *n_bytes = ctx->bcf_bytes;
+  /* its capacity travels in front of nothing: kept in the pool's bookkeeping when it comes back — remember it beside the pointer */
+  pthread_mutex_lock(&ctx->pool_mu);
+  for (int k = 0; k < 4; k++)
+    if (!ctx->bcf_pool.p[k] && !ctx->bcf_pool.cap[k]) { /* a slot that remembers the capacity of a buffer that is out */
+      ctx->bcf_pool.cap[k] = ctx->cap_bcf | ((size_t)1 << 63);
+      ctx->det_ptr[k] = ctx->d_bcf;
+      break;
+    }
+  pthread_mutex_unlock(&ctx->pool_mu);
+  ctx->d_bcf = NULL;
+  ctx->cap_bcf = 0;
+  ctx->bcf_keep = 0;
+  ctx->bcf_bytes = 0;
+  return BSC_OK;
+}
+
+int bsc_detached_read(bsc_context *ctx, const void *d_stream, uint64_t off, uint64_t n, void *dst) {
+  if (!ctx || !d_stream || (!dst && n) || !ctx->s_det) return bsc_fail(BSC_ERR_ARG, "bsc_detached_read: NULL argument");
+  if (!n) return BSC_OK;
+  BSC_ENTER(ctx);
+  HIP_TRY(hipMemcpyAsync(dst, (const char *)d_stream + off, (size_t)n, hipMemcpyDeviceToHost, ctx->s_det));
+  return BSC_OK;
+}
+
+int bsc_detached_wait(bsc_context *ctx) {
+  if (!ctx || !ctx->s_det) return bsc_fail(BSC_ERR_ARG, "bsc_detached_wait: nothing was detached");
+  BSC_ENTER(ctx);
+  HIP_TRY(hipStreamSynchronize(ctx->s_det));
+  return BSC_OK;
+}
+
+int bsc_detached_free(bsc_context *ctx, void *d_stream) {
+  if (!ctx || !d_stream || !ctx->pool_mu_made) return bsc_fail(BSC_ERR_ARG, "bsc_detached_free: NULL argument");
+  pthread_mutex_lock(&ctx->pool_mu);
+  int found = 0;
+  for (int k = 0; k < 4 && !found; k++)
+    if (ctx->det_ptr[k] == d_stream && (ctx->bcf_pool.cap[k] >> 63)) { /* back in its slot, for the next block to take */
+      ctx->bcf_pool.p[k] = d_stream;
+      ctx->bcf_pool.cap[k] &= ~((size_t)1 << 63);
+      ctx->det_ptr[k] = NULL;
+      found = 1;
+    }
+  pthread_mutex_unlock(&ctx->pool_mu);
+  if (!found) { /* more than four out at once: this one was not booked — given back to the runtime (a device-wide wait) */
+    BSC_ENTER(ctx);
+    HIP_TRY(hipFree(d_stream));
+  }
+  return BSC_OK;
 }
 
 /* bytes [off, off + n) of the last block's stream -> dst (page-locked for a true DMA), queued on the context's stream; the caller waits

@@ -728,6 +728,16 @@ int bsc_block_bcf_fetch(bsc_context *ctx, uint64_t *n_bytes, uint64_t *n_records
  * its room there).  Nothing of the block is computed, counted (bsc_get_stats, the site statistics, the read profile) or uploaded a second
  * time; the status the refused call would have returned (BSC_OK / BSC_WARN_INEXACT) comes back. */
 int bsc_block_bcf_again(bsc_context *ctx, uint8_t *out, uint64_t out_cap, uint64_t *n_bytes, uint64_t *n_records);
+/* A stream left on the device (bsc_block_bcf_rawdev_keep) handed over to the caller, so that it can be read out and written WHILE the context
+ * calls the next block: _detach (on the thread that drives the context, after the _keep call has returned) gives the buffer and its length
+ * and the context forgets it; _read queues a copy of bytes [off, off + n) to dst (page-locked for a true DMA) on a stream of the context's
+ * that nothing else uses, _wait waits for the copies queued so far, _free gives the buffer back — to a small pool the next blocks take
+ * their buffers from, so a run in its steady state neither allocates nor frees device memory (both are device-wide waits).  _read / _wait /
+ * _free may be called from ONE other thread, concurrently with the driving thread's calls; at most four streams out at a time are pooled. */
+int bsc_bcf_stream_detach(bsc_context *ctx, void **d_stream, uint64_t *n_bytes);
+int bsc_detached_read(bsc_context *ctx, const void *d_stream, uint64_t off, uint64_t n, void *dst);
+int bsc_detached_wait(bsc_context *ctx);
+int bsc_detached_free(bsc_context *ctx, void *d_stream);
 int bsc_block_bcf_raw(bsc_context *ctx, const bsc_raw_template *raw, uint32_t nr, const uint8_t *seq, uint64_t seq_bytes, const bsc_misms *misms,
                       uint64_t n_misms, const bsc_prep_params *prep, uint32_t x, uint32_t y, const uint8_t *ref, const uint8_t *dbsnp,
                       const bsc_vcf_params *params, int with_stats, int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out,

@@ -76,53 +76,87 @@ static void *pinned(size_t n) { /* page-locked: the copy-out is a true DMA, queu
   return p;
 }
 
-/* The output thread (bcf_write's write): a block's stream is read from the device in pieces into page-locked buffers, and while the device
- * fills one, this thread writes the others, each at its own offset of the file.  ONE thread: three of them writing pieces of one file in
- * parallel were 2.5 x slower (0.70 s against 0.28 for the 2.9 GB of a contig-sized block: writes to one inode take turns anyway).
- * Page-locking a host buffer for a whole stream would cost more than the calling. */
+/* The output thread (bcf_write's write).  A block's stream stays on the device (bsc_block_bcf_rawdev_keep) and is HANDED to this thread
+ * (bsc_bcf_stream_detach): it reads it out in pieces of 32 MB — two page-locked buffers, the next piece's copy in flight on a stream of
+ * its own while the last is written — and writes each at its offset of its file, then gives the buffer back (bsc_detached_free: the next
+ * blocks take theirs from what came back).  The main thread meanwhile pulls the next block out of the reader and calls it: on a file of
+ * several contigs the inflate (the reader's bound) and the write (this thread's: ~10 GB/s into the page cache) overlap instead of taking
+ * turns — round 6's first form read the pieces on the main thread, which therefore waited for this one with the reader's slabs full.
+ * ONE writer: three of them writing pieces of one file in parallel were 2.5 x slower (0.70 s against 0.28 for the 2.9 GB of a contig-sized
+ * block: writes to one inode take turns anyway).  Page-locking a host buffer for a whole stream would cost more than the calling. */
 #define PIECE ((size_t)32 << 20)
-#define N_PIECE 4
-#define N_WRITER 1
+#define N_JOB 3
 typedef struct {
-  int fd;
-  uint8_t *buf[N_PIECE];
-  size_t n[N_PIECE];
-  uint64_t at[N_PIECE];
-  int full[N_PIECE], busy[N_PIECE], quit, failed;
+  void *d;        /* the stream on the device; NULL: only close_fd */
+  uint64_t n, at; /* its length, where it goes in the file */
+  int fd, close_fd;
+} out_job;
+typedef struct {
+  bsc_context *ctx;
+  uint8_t *buf[2];
+  out_job job[N_JOB];
+  int head, count, quit, failed, started;
+  double t_wait, t_write, t_idle; /* the output thread's own account (BAM2BCF_TIMING) */
   pthread_mutex_t mu;
   pthread_cond_t cv;
-  pthread_t th[N_WRITER];
+  pthread_t th;
 } out_writer;
+static double now(void);
 static void *writer_main(void *a) {
   out_writer *w = a;
-  pthread_mutex_lock(&w->mu);
   for (;;) {
-    int i = -1;
-    for (int k = 0; k < N_PIECE; k++)
-      if (w->full[k] && !w->busy[k]) {
-        i = k;
-        break;
-      }
-    if (i < 0) {
-      if (w->quit) break;
-      pthread_cond_wait(&w->cv, &w->mu);
-      continue;
-    }
-    w->busy[i] = 1;
-    pthread_mutex_unlock(&w->mu);
-    size_t done = 0;
-    while (done < w->n[i]) {
-      const ssize_t r = pwrite(w->fd, w->buf[i] + done, w->n[i] - done, (off_t)(w->at[i] + done));
-      if (r <= 0) break;
-      done += (size_t)r;
-    }
+    double t0 = now(), t1;
     pthread_mutex_lock(&w->mu);
-    if (done < w->n[i]) w->failed = 1;
-    w->full[i] = w->busy[i] = 0;
+    while (!w->count && !w->quit) pthread_cond_wait(&w->cv, &w->mu);
+    w->t_idle += (t1 = now()) - t0;
+    if (!w->count) {
+      pthread_mutex_unlock(&w->mu);
+      return NULL;
+    }
+    const out_job j = w->job[w->head];
+    pthread_mutex_unlock(&w->mu);
+    int bad = 0;
+    if (j.d) {
+      uint64_t off = 0;
+      int k = 0;
+      size_t take = j.n < PIECE ? (size_t)j.n : PIECE;
+      if (take && bsc_detached_read(w->ctx, j.d, 0, take, w->buf[0]) < 0) bad = 1;
+      while (off < j.n && !bad) {
+        t0 = now();
+        if (bsc_detached_wait(w->ctx) < 0) bad = 1; /* piece k is here */
+        w->t_wait += (t1 = now()) - t0;
+        const uint64_t next = off + take;
+        const size_t take2 = j.n - next < PIECE ? (size_t)(j.n - next) : PIECE;
+        if (!bad && take2 && bsc_detached_read(w->ctx, j.d, next, take2, w->buf[k ^ 1]) < 0) bad = 1; /* the next one: while this one is written */
+        size_t done = 0;
+        while (done < take && !bad) {
+          const ssize_t r = pwrite(j.fd, w->buf[k] + done, take - done, (off_t)(j.at + off + done));
+          if (r <= 0) bad = 1;
+          else done += (size_t)r;
+        }
+        w->t_write += now() - t1;
+        off = next;
+        take = take2;
+        k ^= 1;
+      }
+      if (bsc_detached_free(w->ctx, j.d) < 0) bad = 1;
+    }
+    if (j.close_fd && j.fd >= 0) close(j.fd);
+    pthread_mutex_lock(&w->mu);
+    if (bad) w->failed = 1;
+    w->head = (w->head + 1) % N_JOB;
+    w->count--;
     pthread_cond_broadcast(&w->cv);
+    pthread_mutex_unlock(&w->mu);
   }
+}
+static void writer_push(out_writer *w, out_job j) {
+  pthread_mutex_lock(&w->mu);
+  while (w->count == N_JOB) pthread_cond_wait(&w->cv, &w->mu);
+  w->job[(w->head + w->count) % N_JOB] = j;
+  w->count++;
+  pthread_cond_broadcast(&w->cv);
   pthread_mutex_unlock(&w->mu);
-  return NULL;
 }
 
 /* The next contig's reference in the background (load_sequence + the GC bins): a thread of its own reads the FASTA while the reader's helpers
@@ -456,19 +490,21 @@ int main(int argc, char **argv) {
   bsc_dev_read_block dblk;
   static out_writer W;
   static ref_job RJ;
-  int wi = 0;
+  int out_fd = -1;
   uint64_t file_at = 0;
   if (n_ref > 0) ref_start(&RJ, argv[2], REF_NAME(0), REF_LEN(0), 0); /* the first contig's reference: while the helpers inflate */
   if (!host_reader) { /* the output pieces too: page-locking them takes its time */
     if (out) {
       fflush(out);
       file_at = (uint64_t)ftello(out);
-      W.fd = fileno(out);
-    } else W.fd = -1; /* a rank of a sharded run: a file per contig, opened when the contig begins */
-    for (int k = 0; k < N_PIECE; k++) W.buf[k] = pinned(PIECE);
+      out_fd = fileno(out);
+    } /* else a rank of a sharded run: a file per contig, opened when the contig begins */
+    W.ctx = ctx;
+    for (int k = 0; k < 2; k++) W.buf[k] = pinned(PIECE);
     pthread_mutex_init(&W.mu, NULL);
     pthread_cond_init(&W.cv, NULL);
-    for (int k = 0; k < N_WRITER; k++) pthread_create(&W.th[k], NULL, writer_main, &W);
+    pthread_create(&W.th, NULL, writer_main, &W);
+    W.started = 1;
   }
   int r;
   double t_read = 0, t_ref = 0, t_prep = 0, t_gpu = 0, t_enc = 0, t0 = now(), t1;
@@ -492,12 +528,11 @@ int main(int argc, char **argv) {
       }
       cur_tid = blk.tid;
       ctot[cur_tid].name = REF_NAME(cur_tid);
-      if (sharded) { /* this contig's shard: what the output thread still holds belongs to the one before */
-        pthread_mutex_lock(&W.mu);
-        for (int k = 0; k < N_PIECE; k++)
-          while (W.full[k]) pthread_cond_wait(&W.cv, &W.mu);
-        pthread_mutex_unlock(&W.mu);
-        if (W.fd >= 0) close(W.fd);
+      if (sharded) { /* this contig's shard; the one before is closed by the output thread behind its last piece */
+        if (out_fd >= 0) {
+          const out_job cj = {NULL, 0, 0, out_fd, 1};
+          writer_push(&W, cj);
+        }
         char *sp = malloc(strlen(argv[3]) + 32);
         sprintf(sp, "%s.shard%05d", argv[3], cur_tid);
         FILE *sf = fopen(sp, "wb");
@@ -505,7 +540,7 @@ int main(int argc, char **argv) {
           perror(sp);
           return 1;
         }
-        W.fd = dup(fileno(sf));
+        out_fd = dup(fileno(sf));
         fclose(sf);
         free(sp);
         file_at = 0;
@@ -556,20 +591,12 @@ int main(int argc, char **argv) {
       CHECK(rc);
       t_gpu += (t1 = now()) - t0;
       t0 = t1;
-      for (uint64_t off = 0; off < n_bytes; off += PIECE) {
-        const size_t take = n_bytes - off < PIECE ? (size_t)(n_bytes - off) : PIECE;
-        pthread_mutex_lock(&W.mu);
-        while (W.full[wi]) pthread_cond_wait(&W.cv, &W.mu);
-        pthread_mutex_unlock(&W.mu);
-        CHECK(bsc_bcf_stream_read(ctx, off, take, W.buf[wi]));
-        CHECK(bsc_synchronize(ctx));
-        pthread_mutex_lock(&W.mu);
-        W.n[wi] = take;
-        W.at[wi] = file_at + off;
-        W.full[wi] = 1;
-        pthread_cond_broadcast(&W.cv);
-        pthread_mutex_unlock(&W.mu);
-        wi = (wi + 1) % N_PIECE;
+      if (n_bytes) { /* the stream changes hands: the output thread reads it out and writes it while this one goes on to the next block */
+        void *d_stream = NULL;
+        uint64_t n_det = 0;
+        CHECK(bsc_bcf_stream_detach(ctx, &d_stream, &n_det));
+        const out_job j = {d_stream, n_det, file_at, out_fd, 0};
+        writer_push(&W, j);
       }
       file_at += n_bytes;
       n_bytes = 0; /* written by the output thread */
@@ -638,12 +665,12 @@ int main(int argc, char **argv) {
     t0 = t1;
   }
   CHECK(r);
-  if (W.buf[0]) { /* the output threads write what they still hold, then go */
+  if (W.started) { /* the output thread writes what it still holds, then goes */
     pthread_mutex_lock(&W.mu);
     W.quit = 1;
     pthread_cond_broadcast(&W.cv);
     pthread_mutex_unlock(&W.mu);
-    for (int k = 0; k < N_WRITER; k++) pthread_join(W.th[k], NULL);
+    pthread_join(W.th, NULL);
     if (W.failed) {
       fprintf(stderr, "writing %s failed\n", argv[3]);
       return 1;
@@ -658,7 +685,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 14; i++) d[i] += after[i] - before[i];
   }
   if (out) fclose(out);
-  else if (W.fd >= 0) close(W.fd);
+  else if (out_fd >= 0) close(out_fd);
 
   /* the report */
   static bsc_site_stats total;
@@ -742,11 +769,11 @@ int main(int argc, char **argv) {
             "{\"reader\": \"%s\", \"context_s\": %.3f, \"reader_s\": %.3f, \"reference_s\": %.3f, \"host_prep_s\": %.3f, \"block_call\": \"%s\", "
             "\"block_call_s\": %.3f, \"encode_write_s\": %.3f, \"report_s\": %.3f, \"wall_s\": %.3f, \"wall_without_context_s\": %.3f, "
             "\"device_reader\": {\"passes\": %llu, \"replay_passes\": %llu, \"records\": %llu, \"inflated_bytes\": %llu, \"waiting_for_inflate_s\": %.3f, "
-            "\"device_passes_s\": %.3f}}\n",
+            "\"device_passes_s\": %.3f}, \"output_thread\": {\"waiting_for_a_block_s\": %.3f, \"waiting_for_copies_s\": %.3f, \"pwrite_s\": %.3f}}\n",
             host_reader ? "host (csrc/bamio.c)" : "device (csrc/bamstream.c + csrc/bamdev.hip)", t_ctx, t_read, t_ref, t_prep,
             host_prep ? "bsc_block_records" : (host_bcf ? "bsc_block_records_raw" : (host_reader ? "bsc_block_bcf_raw" : "bsc_block_bcf_rawdev")), t_gpu, t_enc,
             now() - t_loop_end, now() - t_start, now() - t_start - t_ctx, (unsigned long long)rc4[0], (unsigned long long)rc4[1], (unsigned long long)rc4[2],
-            (unsigned long long)rc4[3], rs[0], rs[1]);
+            (unsigned long long)rc4[3], rs[0], rs[1], W.t_idle, W.t_wait, W.t_write);
   }
   if (RJ.running) { /* a contig prefetched and never reached */
     pthread_join(RJ.th, NULL);
