@@ -55,6 +55,8 @@ python3 tools/kstats.py $(ls $O/bam2bcf_trace/*/*_kernel_stats.csv | head -1) 40
 rm -rf $T
 timeout -k 10 400 python3 tools/bench_bam2bcf_big.py 50000000 30 $O/bam2bcf_50Mb.json > $O/bam2bcf_50Mb.log 2>&1 || { tail -5 $O/bam2bcf_50Mb.log; exit 1; }
 tail -1 $O/bam2bcf_50Mb.log | cut -c1-400
+timeout -k 10 400 python3 tools/bench_bam2bcf_big.py 50000000 30 $O/bam2bcf_50Mb_8contigs.json 8 > $O/bam2bcf_50Mb_8contigs.log 2>&1 || { tail -5 $O/bam2bcf_50Mb_8contigs.log; exit 1; }
+grep "^device_reader" $O/bam2bcf_50Mb_8contigs.log | cut -c1-330
 # 5
 tools/r06_glue.sh > $O/glue_demo.txt 2>&1 || { tail -5 $O/glue_demo.txt; exit 1; }
 grep "end to end" $O/glue_demo.txt
