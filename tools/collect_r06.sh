@@ -10,6 +10,14 @@ if [ -n "$1" ] && [ -d gpurun_out/$1 ]; then
   cp $O/prep_profile_kernels_timed.txt $P/r06_prep_profile_kernels_timed.txt
   cp $O/bcf_sites_kernels_timed.txt $P/r06_bcf_sites_kernels_timed.txt
   cp $O/r06_json.txt $P/r06_prep_bcf_traffic.txt
+  python3 - $O <<'PY'
+import json, sys
+for name, keys in (("traffic.json", ("prep", "prep_profile", "bcf_sites")), ("valu.json", ("prep", "prep_profile"))):
+    cur, new = json.load(open("profiles/" + name)), json.load(open(sys.argv[1] + "/" + name))
+    for k in keys:
+        if k in new: cur[k] = new[k]
+    json.dump(cur, open("profiles/" + name, "w"), indent=1)
+PY
   hdr $P/r06_prep_bcf_traffic.txt "tools/make_r06_json.py: HBM bytes ((2 x FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes) and VALU wave-instructions per call of the round's legs, 50 M positions at 30x; the entries of traffic.json / valu.json"
   { echo "# rocprofv3 --kernel-trace --stats -- bs_call_amd/lib/bam2bcf over a 50 Mb / 30x BAM (15 M alignments, one contig): every kernel of the run, file to file"; cat $O/bam2bcf_kernels.txt; grep -h "^{" $O/bam2bcf_trace.err | tail -1; } > $P/r06_bam2bcf_kernels.txt
   cp $O/bam2bcf_50Mb.json $P/r06_bam2bcf_50Mb.json
