@@ -310,10 +310,6 @@ __global__ __launch_bounds__(64 * ACC_WAVES) void bsc_accumulate_kernel_t(
     uint32_t x, uint32_t y, uint32_t min_qual, uint32_t *__restrict__ cts, unsigned long long *__restrict__ counters,
     const bsc_chain_mblock *__restrict__ blk, uint32_t n_blk) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_slot[ACC_WAVES][SLOT_DW];
-#ifdef ACC_EXPERIMENT_LDS_PAD /* timing experiments only: fewer workgroups to a CU (how much do the waves that hide latency matter?) */
-  __shared__ uint32_t lds_pad[ACC_EXPERIMENT_LDS_PAD];
-  if (n_blk == 0x7fffffffu) lds_pad[threadIdx.x] = n_bins;
-#endif
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t *slot = lds_slot[wid];
