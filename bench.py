@@ -688,7 +688,7 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
                                                          stream=stream))
     pack_ms = timed(lambda: caller.vcf_compact_device(d_core.data_ptr(), d_aux.data_ptr(), 0, n, d_rec.data_ptr(), cap_rec, d_cnt.data_ptr(), stream=stream))
     sites_same = int(d_tot2[0].item()) == nbytes and int(d_tot2[2].item()) == n_rec and bool(torch.equal(d_bcf[:nbytes], d_bcf2[:nbytes]))
-    sites_alg = n + (16 * n + 112 * n_rec) + nbytes  # a length byte per position; the write kernel: 16 B of every position, the other 112 of a written record
+    sites_alg = n + (n + 128 * n_rec) + nbytes  # size pass: the chain's byte per position; write kernel: that byte again, 128 B of a written record, the stream
     del d_aux, d_bcf2
     m = min(200_000, n_rec)
     want = vcf.bcf_block(d_rec[: m * 128].cpu().numpy().view(B.VCF_REC), 0)
@@ -698,8 +698,8 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
     sites_v = _committed("traffic.json", "bcf_sites", ("bcfdev.hip",))
     return {
         "bound": "hbm",
-        "kernel": "bsc_bcf_size_kernel + rocPRIM prefix sum + bsc_bcf_write_kernel over the chain's per-position arrays (bsc_bcf_sites_device: the form "
-        "bsc_block_bcf[_raw[dev]] runs; no packing pass)",
+        "kernel": "bsc_bcf_size_bytes_kernel + rocPRIM prefix sum + bsc_bcf_write_kernel_t over the chain's per-position arrays, gated and sized by the "
+        "chain's byte per position (bsc_bcf_sites_len_device: the form bsc_block_bcf[_raw[dev]] runs; no packing pass)",
         "what": "the reads-in chain's per-position arrays (64-byte record + 64-byte aux per position) -> BCF2 records (typed values of "
         "src/print_vcf.c:160-222,267-378 behind bcf_write's fixed fields): %d positions, %d written records, resident in HBM" % (n, n_rec),
         "achieved": sites_alg / (sites_ms * 1e-3) / 1e9,
@@ -730,16 +730,17 @@ def bcf_roofline(caller, d_tpl, nr, d_seq, seq_bytes, x, y, d_ref, d_core, n, re
             "algorithmic_bytes_per_launch": sites_alg,
             "achieved": sites_alg / (sites_ms * 1e-3) / 1e9,
             "frac": sites_alg / (sites_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "sector_bytes_per_launch": n + 64 * (n + n_rec) + nbytes,
-            "sector_frac": (n + 64 * (n + n_rec) + nbytes) / (sites_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "size_pass_over_the_records_ms": sites_rec_ms,
-            "sector_note": "what the 16 bytes of a position cost at HBM: its whole 64-byte sector (the records are 64 bytes, one to a sector) — "
-            "`frac` counts the algorithmic 16, `sector_frac` the 64 the memory system moves",
+            "sector_bytes_per_launch": sites_alg,
+            "sector_frac": sites_alg / (sites_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "sector_note": "with the chain's byte per position a position without a record is not touched (before: the 64-byte sector around its first 16 "
+            "bytes), and a written record is two whole sectors: what the memory system moves is the algorithmic bytes, `sector_frac` = `frac`",
             "packing_pass_ms_it_replaces": pack_ms,
             "packing_plus_encoding_ms": pack_ms + k_ms,
             "same_stream": bool(sites_same),
         },
-        "note": "events of torch's current stream, which is the stream the launches are queued on; the records are read twice (sizes, then bytes)",
+        "note": "events of torch's current stream, which is the stream the launches are queued on; the written records are read once (the size pass reads "
+        "a byte per position); packed_form reads them twice (sizes, then bytes)",
     }
 
 

@@ -800,6 +800,7 @@ extern "C" int bsc_bamdev_open_contigs(bsc_context *ctx, const char *path, int n
   memset(&h, 0, sizeof h);
   h.first_err = ~0ull;
   if (hipMemcpy(r->cnt.p, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess || hipMemset(r->zero.p, 0, 64) != hipSuccess ||
+      hipStreamSynchronize(nullptr) != hipSuccess || /* (the memset is done before the reader's stream, which does not wait for the null stream, reads it) */
       hipEventCreateWithFlags(&r->ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->ev[1], hipEventDisableTiming) != hipSuccess) {
     bsc_bamdev_close(r);
     return bsc_set_error(BSC_ERR_HIP, "bsc_bamdev_open: device set-up failed");

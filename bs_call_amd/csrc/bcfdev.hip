@@ -9,16 +9,20 @@
  *   bsc_bcf_size_kernel    one wave per tile of 64 records: every lane the length of its record (the emitter below over a sink
  *                          that only counts), the tile's sum -> tile_bytes[tile] (u64); records beyond *n_recs count 0
  *   (exclusive scan of the tile sums, rocPRIM u64: sort.hip; one more entry behind the last tile = the stream's length)
- *   bsc_bcf_write_kernel   one wave per tile: lane offsets from a wave prefix sum, every lane writes its record into the wave's LDS
- *                          image of the tile's span of the stream (byte stores; the image starts at the span's phase within 16
- *                          bytes), then the wave copies the image out — whole 16-byte chunks as one dwordx4 store per lane, the ragged
- *                          head and tail byte by byte (the neighbouring tiles own the other bytes of those chunks).  A tile whose
- *                          span does not fit the image (> 64 x 160 bytes: long IDs, wide dictionary indices) goes out in two halves.
+ *   bsc_bcf_write_kernel_t one wave per tile: lane offsets from a wave prefix sum, every lane writes its record into the wave's LDS
+ *                          image of the tile's span of the stream — field by field, a key and its value composed as one word in
+ *                          registers (see "sinks" below); the image starts at the span's phase within 16 bytes — then the wave copies
+ *                          the image out: whole 16-byte chunks as one dwordx4 store per lane, the ragged head and tail byte by byte
+ *                          (the neighbouring tiles own the other bytes of those chunks).  A tile whose span does not fit the image
+ *                          (8 KB: long IDs, wide dictionary indices, deep counts) goes out in 2, 4 or 8 parts.
  *
  * Two sources: packed records (bsc_vcf_compact_device's output; bsc_bcf_block_device), or the per-position arrays the reads-in chain leaves
  * (bsc_vcf_core + the 64-byte aux array that is the packed record's second half; bsc_bcf_sites_device, and what bsc_block_bcf runs): the
- * tiles are then tiles of 64 POSITIONS, a lane whose position writes no record reads its 16 first bytes and has length 0 — the packing
- * pass (128 bytes written and read again per record) does not run at all.
+ * tiles are then tiles of 64 POSITIONS and the packing pass (128 bytes written and read again per record) does not run at all.  With the
+ * chain's byte per position (bsc_bcf_sites_len_device; 0 = no record, 1 .. 254 = the record's BCF2 length, 255 = ask the record) neither
+ * kernel touches a position that writes nothing, the write kernel fetches that byte a tile ahead, issues a record's eight loads together
+ * and runs the emitter once (the length is the byte); without it a lane reads its position's first 16 bytes to learn whether there is a
+ * record, and the emitter runs twice (over the counting sink for the lane offsets, then over the writing one).
  *
  * Names: the dbSNP name of a record whose rs_found flag is set comes from a table of the block's flagged positions (sorted
  * positions, offsets, bytes: bsc_dbsnp_names on the host, uploaded with the block) by binary search; a flagged record the table
@@ -35,11 +39,24 @@ static_assert(sizeof(bsc_vcf_rec) == 128, "bsc_vcf_rec is 128 bytes");
 enum { BT_INT8 = 1, BT_INT16 = 2, BT_INT32 = 3, BT_FLOAT = 5, BT_CHAR = 7 };
 #define BCF_ID_MAX 63u        /* bsc_bcf_block's rs[64] */
 #define BCF_REC_MAX 336u      /* 32 + shared (3 + 63 + 2 + 4 + 5 + 5 + 6) + per-sample (13 keys x 5 + 136): an upper bound of one record */
-#define BCF_IMG_BYTES 10752u  /* the wave's image: 32 records of the longest kind (10 752 = 32 x 336), or 64 ordinary ones */
+#define BCF_IMG_BYTES 10752u  /* the one-pass kernel's image per wave: 32 records of the longest kind (10 752 = 32 x 336), or 64 ordinary ones */
 #define BCF_WAVES 4u
 static_assert(BCF_IMG_BYTES >= 32u * BCF_REC_MAX, "half a tile of the longest records must fit the wave's image");
-#ifndef BCF_WAVES_PER_EU
-#define BCF_WAVES_PER_EU 3 /* the write kernel in 168 registers: three workgroups a CU, what its 43 KB of LDS allow (tools/build_variant_bcf.sh) */
+#define BCF_ONEPASS_WAVES_PER_EU 3
+/* The write kernel's image per wave and the waves a SIMD is to hold, by form (tools/r06_ab_bcf_words.sh: the A/B of these).  A tile of the
+ * per-position form carries ~32 records of ~113 bytes at WGBS densities (3.6 KB; every position written: 7.2 KB, two parts); a tile of
+ * packed records 64 of them. */
+#ifndef BCF_IMG_SITES
+#define BCF_IMG_SITES 8192u
+#endif
+#ifndef BCF_WPE_SITES
+#define BCF_WPE_SITES 4
+#endif
+#ifndef BCF_IMG_PACKED
+#define BCF_IMG_PACKED 8192u
+#endif
+#ifndef BCF_WPE_PACKED
+#define BCF_WPE_PACKED 4
 #endif
 
 struct bcf_args {
@@ -53,14 +70,28 @@ struct bcf_args {
   const uint32_t *name_off;           /* n_names + 1 offsets into name_bytes */
   const uint8_t *name_bytes;
   uint32_t n_names;
+  const uint8_t *gate;                /* per-position form: the chain's byte per position (0 = no record) or NULL — a position without a record
+                                       * then costs that byte, not the 64-byte sector around its first 16 bytes; with one-byte dictionary
+                                       * indices a byte of 1 .. 254 is the record's length (fused.hip: ebyte) */
 };
 
-/* ---- sinks: the emitter runs over one that counts and one that writes ---- */
+/* ---- sinks: the emitter runs over one that counts and one that writes ----
+ * Round 6 (second form): the writer composes FIELDS, not bytes — a key and its value are one 64-bit word in registers and two dword
+ * stores.  The first form stored byte by byte (p[len++] = ...): 1 144 vector instructions and 99 LDS stores per tile of 64 positions, the
+ * kernel at 0.70 of VALU issue (profiles/r06_bcf_write_sq_counters_before.txt; now 537 and 43, r06_bcf_write_sq_counters.txt: the LDS's
+ * busy cycles are the nearest bound).  The LDS takes stores at any byte address (gfx950 under HSA: unaligned access mode; the compiler
+ * emits ds_write_b16 / b32 for align-1 copies), and a store may write MORE bytes than the field has (put_n always writes 8): what follows
+ * in the record overwrites the excess, and the excess behind a record's LAST field (<= 7 bytes) falls into the next lane's 32 fixed
+ * bytes, which every lane writes AFTER all bodies are written (a wave barrier between; the image has 32 spare bytes behind the last
+ * record). */
 struct count_sink {
   unsigned len;
   __device__ __forceinline__ void u8(unsigned) { len++; }
   __device__ __forceinline__ void le(uint32_t, unsigned bytes) { len += bytes; }
-  __device__ __forceinline__ void skip(unsigned bytes) { len += bytes; }
+  __device__ __forceinline__ void put_n(uint64_t, unsigned n) { len += n; }
+  __device__ __forceinline__ void put_w(uint32_t) { len += 4u; }
+  __device__ __forceinline__ void words6(const uint32_t *, unsigned n_used) { len += 4u * n_used; }
+  __device__ __forceinline__ void cond8(unsigned, bool adv) { len += adv ? 1u : 0u; }
 };
 struct lds_sink {
   uint8_t *p;
@@ -69,7 +100,30 @@ struct lds_sink {
   __device__ __forceinline__ void le(uint32_t v, unsigned bytes) {
     for (unsigned k = 0; k < bytes; k++) p[len++] = (uint8_t)(v >> (8u * k));
   }
-  __device__ __forceinline__ void skip(unsigned bytes) { len += bytes; }
+  /* the low n bytes of bits (n <= 8); eight bytes are written, as two dwords (one store of eight bytes at an odd address measured
+   * slower: 1.62 against 1.58 ms, and slower still for the fixed fields — profiles/r06_ab_bcf_words.txt), four when the compiler
+   * knows that n <= 4 */
+  __device__ __forceinline__ void put_n(uint64_t bits, unsigned n) {
+    const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+    __builtin_memcpy(p + len, &lo, 4);
+    if (!(__builtin_constant_p(n) && n <= 4u)) __builtin_memcpy(p + len + 4u, &hi, 4);
+    len += n;
+  }
+  __device__ __forceinline__ void put_w(uint32_t v) {
+    __builtin_memcpy(p + len, &v, 4);
+    len += 4u;
+  }
+  /* the first n_used of six dwords; all six are written */
+  __device__ __forceinline__ void words6(const uint32_t *w, unsigned n_used) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) __builtin_memcpy(p + len + 4u * (unsigned)k, &w[k], 4);
+    len += 4u * n_used;
+  }
+  /* a byte that stays only if adv (the next one lands on it otherwise) */
+  __device__ __forceinline__ void cond8(unsigned v, bool adv) {
+    p[len] = (uint8_t)v;
+    len += adv ? 1u : 0u;
+  }
 };
 
 __device__ __forceinline__ int int_type(int32_t lo, int32_t hi) {
@@ -79,11 +133,52 @@ __device__ __forceinline__ int int_type(int32_t lo, int32_t hi) {
 }
 __device__ __forceinline__ unsigned type_bytes(int t) { return t == BT_INT8 ? 1u : (t == BT_INT16 ? 2u : 4u); }
 
+/* a typed single integer as the low n bytes of a word: the descriptor, then the value in 1 / 2 / 4 bytes (nothing above them) */
+__device__ __forceinline__ uint64_t enc_int(int32_t v, unsigned &n) {
+  const bool i8 = v <= 127 && v >= -120, i16 = v <= 32767 && v >= -32760;
+  const uint32_t t = i8 ? (uint32_t)BT_INT8 : (i16 ? (uint32_t)BT_INT16 : (uint32_t)BT_INT32);
+  const uint32_t val = i8 ? ((uint32_t)v & 0xffu) : (i16 ? ((uint32_t)v & 0xffffu) : (uint32_t)v);
+  n = i8 ? 2u : (i16 ? 3u : 5u);
+  return (uint64_t)(0x10u | t) | (uint64_t)val << 8;
+}
 template <class S>
 __device__ __forceinline__ void put_int(S &s, int32_t v) { /* a typed single integer */
-  const int t = int_type(v, v);
-  s.u8(1u << 4 | (unsigned)t);
-  s.le((uint32_t)v, type_bytes(t));
+  unsigned n;
+  const uint64_t b = enc_int(v, n);
+  s.put_n(b, n);
+}
+/* a dictionary index as a typed integer; SHORT: every index of the block is known to be 0 .. 127 (the launcher looked), two bytes */
+template <bool SHORT>
+__device__ __forceinline__ uint64_t enc_key(int32_t key, unsigned &n) {
+  if (SHORT) {
+    n = 2u;
+    return (uint64_t)((1u << 4 | (uint32_t)BT_INT8) | (uint32_t)key << 8);
+  }
+  return enc_int(key, n);
+}
+/* two typed integers (a key and its value), one store when they fit a word */
+template <bool SHORT, class S>
+__device__ __forceinline__ void put_int2(S &s, int32_t key, int32_t v) {
+  unsigned n1, n2;
+  const uint64_t b1 = enc_key<SHORT>(key, n1), b2 = enc_int(v, n2);
+  if (n1 + n2 <= 8u)
+    s.put_n(b1 | b2 << (8u * n1), n1 + n2);
+  else {
+    s.put_n(b1, n1);
+    s.put_n(b2, n2);
+  }
+}
+/* a typed integer key, then n (<= 6) bytes that are already encoded */
+template <bool SHORT, class S>
+__device__ __forceinline__ void put_key_then(S &s, int32_t key, uint64_t bits, unsigned n) {
+  unsigned n1;
+  const uint64_t b1 = enc_key<SHORT>(key, n1);
+  if (n1 + n <= 8u)
+    s.put_n(b1 | bits << (8u * n1), n1 + n);
+  else {
+    s.put_n(b1, n1);
+    s.put_n(bits, n);
+  }
 }
 template <class S>
 __device__ __forceinline__ void put_descriptor(S &s, uint32_t n, int type) {
@@ -102,7 +197,7 @@ struct rec_regs {
 
 /* Everything behind the 32 fixed bytes, in the reference's order; returns l_shared (the per-sample block follows it in the sink).
  * id / id_len: the record's name (global memory).  bad: set for a record bsc_bcf_record refuses (gt > 9, n_gl > 6). */
-template <class S>
+template <bool SHORT, class S>
 __device__ __forceinline__ unsigned bcf_emit_body(S &s, const rec_regs &r, const bcf_args &a, const uint8_t *id, unsigned id_len, bool &bad) {
   const unsigned gt_raw = r.byte(5), n_gl_raw = r.byte(10);
   bad = gt_raw > 9u || n_gl_raw > 6u;
@@ -112,66 +207,74 @@ __device__ __forceinline__ unsigned bcf_emit_body(S &s, const rec_regs &r, const
   const bool het = (0x16Eu >> gt) & 1u; /* gt_het {0,1,1,1,0,1,1,0,1,0} (src/init_param.c:16) */
   const unsigned s0 = s.len;
   /* ---- shared: ID, REF, ALT, FILTER, INFO CX (:165-221) ---- */
-  put_descriptor(s, id_len, BT_CHAR);
-  for (unsigned k = 0; k < id_len; k++) s.u8(id[k]);
-  s.u8(1u << 4 | BT_CHAR);
-  s.u8(r.byte(16)); /* REF = cx_ref[2] */
-  if (alt0) {
-    s.u8(1u << 4 | BT_CHAR);
-    s.u8(alt0);
-    if (alt1) {
-      s.u8(1u << 4 | BT_CHAR);
-      s.u8(alt1);
+  {
+    uint64_t bits;
+    unsigned n;
+    if (id_len) { /* a dbSNP name: byte by byte from the table */
+      put_descriptor(s, id_len, BT_CHAR);
+      for (unsigned k = 0; k < id_len; k++) s.u8(id[k]);
+      bits = 0ull;
+      n = 0u;
+    } else { /* no ID: an empty string */
+      bits = (uint64_t)(0u << 4 | BT_CHAR);
+      n = 1u;
+    }
+    bits |= (uint64_t)((1u << 4 | BT_CHAR) | (uint32_t)r.byte(16) << 8) << (8u * n); /* REF = cx_ref[2] */
+    n += 2u;
+    if (alt0) {
+      bits |= (uint64_t)((1u << 4 | BT_CHAR) | alt0 << 8) << (8u * n);
+      n += 2u;
+      if (alt1) {
+        bits |= (uint64_t)((1u << 4 | BT_CHAR) | alt1 << 8) << (8u * n);
+        n += 2u;
+      }
+    }
+    s.put_n(bits, n); /* <= 7 bytes */
+  }
+  {
+    unsigned n1, n2;
+    const uint64_t b1 = enc_key<SHORT>(flt == 0u ? a.ids.pass : ((flt & 128u) ? a.ids.mac1 : a.ids.fail), n1), b2 = enc_key<SHORT>(a.ids.info_cx, n2);
+    if (n1 + n2 <= 8u)
+      s.put_n(b1 | b2 << (8u * n1), n1 + n2);
+    else {
+      s.put_n(b1, n1);
+      s.put_n(b2, n2);
     }
   }
-  put_int(s, flt == 0u ? a.ids.pass : ((flt & 128u) ? a.ids.mac1 : a.ids.fail));
-  put_int(s, a.ids.info_cx);
-  s.u8(5u << 4 | BT_CHAR);
-#pragma unroll
-  for (unsigned k = 0; k < 5u; k++) s.u8(r.byte(14u + k));
+  /* five characters: bytes 14 .. 18 of the record */
+  s.put_n((uint64_t)(5u << 4 | BT_CHAR) | (uint64_t)(r.w[3] >> 16) << 8 | (uint64_t)(r.w[4] & 0xffffffu) << 24, 6u);
   const unsigned l_shared = s.len - s0;
   /* ---- per sample: GT FT DP MQ GQ QD GL MC8 [AMQ] CS CG CX [FS] (:267-378) ---- */
-  put_int(s, a.ids.fmt_gt);
-  s.u8(2u << 4 | BT_INT8); /* two allele codes below 16 */
-  s.u8(gt_enc >> 4);
-  s.u8(gt_enc & 15u);
-  put_int(s, a.ids.fmt_ft);
+  put_key_then<SHORT>(s, a.ids.fmt_gt, (uint64_t)(2u << 4 | BT_INT8) | (uint64_t)(gt_enc >> 4) << 8 | (uint64_t)(gt_enc & 15u) << 16, 3u); /* two allele codes below 16 */
   if (flt & 15u) { /* each name WITH its terminator, ';' between (:283-296): "q20\0;qd2\0" */
     const unsigned nf = (unsigned)__popc(flt & 15u);
     const unsigned ft_len = ((flt & 1u) ? 4u : 0u) + ((flt & 2u) ? 4u : 0u) + ((flt & 4u) ? 5u : 0u) + ((flt & 8u) ? 5u : 0u) + nf - 1u;
+    {
+      unsigned n1;
+      const uint64_t b1 = enc_key<SHORT>(a.ids.fmt_ft, n1);
+      s.put_n(b1, n1);
+    }
     put_descriptor(s, ft_len, BT_CHAR);
     bool first = true;
-#define FT_NAME(bit, c0, c1, c2, c3, n) \
-  if (flt & (bit)) {                    \
-    if (!first) s.u8(';');              \
-    first = false;                      \
-    s.u8(c0); s.u8(c1); s.u8(c2);       \
-    if ((n) == 4) s.u8(c3);             \
-    s.u8(0);                            \
+#define FT_NAME(bit, c0, c1, c2, c3, n)                                                                                                   \
+  if (flt & (bit)) {                                                                                                                      \
+    const uint64_t nm = (uint64_t)(c0) | (uint64_t)(c1) << 8 | (uint64_t)(c2) << 16 | ((n) == 4 ? (uint64_t)(c3) << 24 : 0ull); /* + '\0' */ \
+    s.put_n(first ? nm : ((uint64_t)';' | nm << 8), (n) + (first ? 1u : 2u));                                                              \
+    first = false;                                                                                                                        \
   }
     FT_NAME(1u, 'q', '2', '0', 0, 3)
     FT_NAME(2u, 'q', 'd', '2', 0, 3)
     FT_NAME(4u, 'f', 's', '6', '0', 4)
     FT_NAME(8u, 'm', 'q', '4', '0', 4)
 #undef FT_NAME
-  } else {
-    s.u8(4u << 4 | BT_CHAR);
-    s.u8('P'); s.u8('A'); s.u8('S'); s.u8('S');
-  }
-  put_int(s, a.ids.fmt_dp);
-  put_int(s, (int32_t)r.w[8]);  /* dp */
-  put_int(s, a.ids.fmt_mq);
-  put_int(s, (int32_t)r.w[26]); /* mq */
-  put_int(s, a.ids.fmt_gq);
-  put_int(s, (int32_t)phred);
-  put_int(s, a.ids.fmt_qd);
-  put_int(s, (int32_t)r.w[7]);  /* qd */
-  put_int(s, a.ids.fmt_gl);
-  s.u8(n_gl << 4 | BT_FLOAT);
-#pragma unroll
-  for (unsigned k = 0; k < 6u; k++)
-    if (k < n_gl) s.le(r.w[9u + k], 4u);
-  put_int(s, a.ids.fmt_mc8);
+  } else
+    put_key_then<SHORT>(s, a.ids.fmt_ft, (uint64_t)(4u << 4 | BT_CHAR) | (uint64_t)'P' << 8 | (uint64_t)'A' << 16 | (uint64_t)'S' << 24 | (uint64_t)'S' << 32, 5u);
+  put_int2<SHORT>(s, a.ids.fmt_dp, (int32_t)r.w[8]);  /* dp */
+  put_int2<SHORT>(s, a.ids.fmt_mq, (int32_t)r.w[26]); /* mq */
+  put_int2<SHORT>(s, a.ids.fmt_gq, (int32_t)phred);
+  put_int2<SHORT>(s, a.ids.fmt_qd, (int32_t)r.w[7]);  /* qd */
+  put_key_then<SHORT>(s, a.ids.fmt_gl, (uint64_t)(n_gl << 4 | BT_FLOAT), 1u);
+  s.words6(&r.w[9], n_gl); /* (the dwords behind the n_gl-th are overwritten: at least 27 bytes of this record follow) */
   {
     int32_t lo = (int32_t)r.w[16], hi = lo;
 #pragma unroll
@@ -181,9 +284,18 @@ __device__ __forceinline__ unsigned bcf_emit_body(S &s, const rec_regs &r, const
       hi = v > hi ? v : hi;
     }
     const int t = int_type(lo, hi);
-    s.u8(8u << 4 | (unsigned)t);
+    put_key_then<SHORT>(s, a.ids.fmt_mc8, (uint64_t)(8u << 4 | (unsigned)t), 1u);
+    if (t == BT_INT8) { /* eight counts below 128: one word */
+      const uint32_t b0 = (r.w[16] & 0xffu) | (r.w[17] & 0xffu) << 8 | (r.w[18] & 0xffu) << 16 | r.w[19] << 24;
+      const uint32_t b1 = (r.w[20] & 0xffu) | (r.w[21] & 0xffu) << 8 | (r.w[22] & 0xffu) << 16 | r.w[23] << 24;
+      s.put_n((uint64_t)b0 | (uint64_t)b1 << 32, 8u);
+    } else if (t == BT_INT16) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) s.le(r.w[16 + k], type_bytes(t));
+      for (int k = 0; k < 8; k += 2) s.put_w((r.w[16 + k] & 0xffffu) | r.w[17 + k] << 16);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s.put_w(r.w[16 + k]);
+    }
   }
   {
     unsigned n_amq = 0;
@@ -197,37 +309,28 @@ __device__ __forceinline__ unsigned bcf_emit_body(S &s, const rec_regs &r, const
         hi = q > hi ? q : hi;
       }
     if (n_amq) {
-      put_int(s, a.ids.fmt_amq);
       const int t = int_type(lo, hi);
-      s.u8(n_amq << 4 | (unsigned)t); /* one element: put_int's descriptor is the same byte */
+      put_key_then<SHORT>(s, a.ids.fmt_amq, (uint64_t)(n_amq << 4 | (unsigned)t), 1u); /* one element: put_int's descriptor is the same byte */
+      if (t == BT_INT8) { /* every byte is stored where the stream stands; it stays if its count is not 0 (a CS key follows: >= 4 bytes) */
 #pragma unroll
-      for (int k = 0; k < 8; k++)
-        if (r.w[16 + k] > 0u) s.le(r.byte(96u + (unsigned)k), type_bytes(t));
+        for (int k = 0; k < 8; k++) s.cond8(r.byte(96u + (unsigned)k), r.w[16 + k] > 0u);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (r.w[16 + k] > 0u) s.le(r.byte(96u + (unsigned)k), type_bytes(t));
+      }
     }
   }
-  put_int(s, a.ids.fmt_cs);
   { /* cs_str {"NA","+","-","NA","+","+-","+","-","-","NA"} (src/print_vcf.c:58-59) */
     const bool na = (0x209u >> gt) & 1u, plus = (0x72u >> gt) & 1u, minus = (0x1A4u >> gt) & 1u;
-    if (na) {
-      s.u8(2u << 4 | BT_CHAR);
-      s.u8('N'); s.u8('A');
-    } else {
-      s.u8(((plus ? 1u : 0u) + (minus ? 1u : 0u)) << 4 | BT_CHAR);
-      if (plus) s.u8('+');
-      if (minus) s.u8('-');
-    }
+    const uint64_t str = na ? ((uint64_t)(2u << 4 | BT_CHAR) | (uint64_t)'N' << 8 | (uint64_t)'A' << 16)
+                            : ((uint64_t)(((plus ? 1u : 0u) + (minus ? 1u : 0u)) << 4 | BT_CHAR) | (uint64_t)(plus ? '+' : '-') << 8 | (uint64_t)'-' << 16);
+    put_key_then<SHORT>(s, a.ids.fmt_cs, str, na ? 3u : 1u + (plus ? 1u : 0u) + (minus ? 1u : 0u));
   }
-  put_int(s, a.ids.fmt_cg);
-  s.u8(1u << 4 | BT_CHAR);
-  s.u8(r.byte(11));
-  put_int(s, a.ids.fmt_cx);
-  s.u8(5u << 4 | BT_CHAR);
-#pragma unroll
-  for (unsigned k = 0; k < 5u; k++) s.u8(r.byte(19u + k));
-  if (het) {
-    put_int(s, a.ids.fmt_fs);
-    put_int(s, (int32_t)r.w[6]);
-  }
+  put_key_then<SHORT>(s, a.ids.fmt_cg, (uint64_t)(1u << 4 | BT_CHAR) | (uint64_t)r.byte(11) << 8, 2u);
+  /* five characters: bytes 19 .. 23 of the record */
+  put_key_then<SHORT>(s, a.ids.fmt_cx, (uint64_t)(5u << 4 | BT_CHAR) | (uint64_t)(r.w[4] >> 24) << 8 | (uint64_t)r.w[5] << 16, 6u);
+  if (het) put_int2<SHORT>(s, a.ids.fmt_fs, (int32_t)r.w[6]);
   return l_shared;
 }
 
@@ -242,23 +345,25 @@ __device__ __forceinline__ void bcf_emit_fixed(uint8_t *p, const rec_regs &r, co
   const uint32_t n_fmt = 11u + (amq ? 1u : 0u) + (((0x16Eu >> gt) & 1u) ? 1u : 0u);
   const float qual = (float)r.byte(9);
   lds_sink f = {p, 0u};
-  f.le(l_shared + 24u, 4u);
-  f.le(l_indiv, 4u);
-  f.le((uint32_t)a.rid, 4u);
-  f.le(r.w[0] - 1u, 4u);
-  f.le(1u, 4u); /* rlen */
-  f.le(__float_as_uint(qual), 4u);
-  f.le(n_allele << 16 | 1u, 4u); /* one INFO field */
-  f.le(n_fmt << 24 | 1u, 4u);    /* one sample */
+  f.put_w(l_shared + 24u);
+  f.put_w(l_indiv);
+  f.put_w((uint32_t)a.rid);
+  f.put_w(r.w[0] - 1u);
+  f.put_w(1u); /* rlen */
+  f.put_w(__float_as_uint(qual));
+  f.put_w(n_allele << 16 | 1u); /* one INFO field */
+  f.put_w(n_fmt << 24 | 1u);    /* one sample */
 }
 
-/* record / position i into registers; false: nothing is written for it (emit == 0).  A position that writes no record costs its
- * first 16 bytes only. */
-__device__ __forceinline__ bool load_rec(rec_regs &r, const bcf_args &a, uint64_t i) {
+/* record / position i into registers; false: nothing is written for it (emit == 0).  Without the chain's byte (gate < 0) the flag is in
+ * the record's first 16 bytes: a position that writes no record costs those (their 64-byte sector), and a record's other loads wait for
+ * them.  With it (gate: the byte) a position without a record costs nothing more, and a record's eight loads leave together. */
+__device__ __forceinline__ bool load_rec(rec_regs &r, const bcf_args &a, uint64_t i, int gate = -1) {
+  if (gate == 0) return false;
   const uint4 *lo = reinterpret_cast<const uint4 *>(a.recs ? a.recs + i * 128u : a.core + i * 64u);
   const uint4 v0 = lo[0];
   r.w[0] = v0.x; r.w[1] = v0.y; r.w[2] = v0.z; r.w[3] = v0.w;
-  if (!(v0.y & 0xffu)) return false; /* bsc_vcf_core.emit */
+  if (gate < 0 && !(v0.y & 0xffu)) return false; /* bsc_vcf_core.emit */
   const uint4 *hi = a.recs ? lo + 4 : reinterpret_cast<const uint4 *>(a.aux + i * 64u);
 #pragma unroll
   for (int k = 1; k < 4; k++) {
@@ -296,16 +401,20 @@ __device__ __forceinline__ uint64_t clamp_n(const bcf_args &a) {
   return n < a.max_recs ? n : a.max_recs;
 }
 
-/* length of record i (0 beyond n, 0 for a record that is not written) */
-__device__ __forceinline__ unsigned rec_len(const bcf_args &a, uint64_t i, uint64_t n, rec_regs &r, const uint8_t *&id, unsigned &id_len, bool &bad) {
+/* length of record i (0 beyond n, 0 for a record that is not written).  gate: the chain's byte of the position, or -1; len_known: a byte
+ * of 1 .. 254 IS the length (SHORT indices, and the chain gives 255 to every record with a name or one the encoder refuses) */
+template <bool SHORT>
+__device__ __forceinline__ unsigned rec_len(const bcf_args &a, uint64_t i, uint64_t n, rec_regs &r, const uint8_t *&id, unsigned &id_len, bool &bad,
+                                            int gate = -1, bool len_known = false) {
   bad = false;
   id_len = 0;
   id = nullptr;
   if (i >= n) return 0u;
-  if (!load_rec(r, a, i)) return 0u;
+  if (!load_rec(r, a, i, gate)) return 0u;
+  if (len_known && gate > 0 && gate != 255) return (unsigned)gate;
   id_len = find_name(a, r, id);
   count_sink c = {0u};
-  (void)bcf_emit_body(c, r, a, id, id_len, bad);
+  (void)bcf_emit_body<SHORT>(c, r, a, id, id_len, bad);
   return 32u + c.len;
 }
 
@@ -322,7 +431,7 @@ extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_kernel(bcf_args a
     const uint8_t *id;
     unsigned id_len;
     bool bad;
-    unsigned len = rec_len(a, (uint64_t)tile * 64u + lane, n, r, id, id_len, bad);
+    unsigned len = rec_len<false>(a, (uint64_t)tile * 64u + lane, n, r, id, id_len, bad);
     if (bad) atomicAdd(err, 1ull);
     n_written += (unsigned)__popcll(__ballot(len != 0u));
 #pragma unroll
@@ -380,7 +489,7 @@ extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_bytes_kernel(bcf_
             const uint8_t *id;
             unsigned id_len;
             bool bad;
-            const unsigned l = rec_len(a, i0 + 4u * q + t, n, r, id, id_len, bad);
+            const unsigned l = rec_len<false>(a, i0 + 4u * q + t, n, r, id, id_len, bad);
             if (bad) atomicAdd(err, 1ull);
             len += l - 255u;
             if (l == 0u) n_written--; /* (a 255 whose record is not written after all: cannot happen, kept consistent) */
@@ -400,21 +509,36 @@ extern "C" __global__ __launch_bounds__(256) void bsc_bcf_size_bytes_kernel(bcf_
   if (threadIdx.x == 0 && s_written) atomicAdd(err + 1, (unsigned long long)s_written);
 }
 
-extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BCF_WAVES_PER_EU, BCF_WAVES_PER_EU))) void bsc_bcf_write_kernel(bcf_args a, uint32_t n_tiles, const unsigned long long *__restrict__ tile_off,
-                                                                       uint8_t *__restrict__ out, uint64_t out_cap,
-                                                                       unsigned long long *__restrict__ total) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_img[BCF_WAVES][BCF_IMG_BYTES + 16u];
+/* SHORT: every dictionary index is 0 .. 127 (bcf_emit_body); IMG: the wave's image of its part of the stream, bytes.  A tile whose span
+ * does not fit the image goes out in 2, 4 or 8 parts of 32, 16 or 8 lanes (8 records of the longest kind always fit: IMG >= 8 x 336). */
+template <bool SHORT, unsigned IMG, unsigned WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void bsc_bcf_write_kernel_t(
+    bcf_args a, uint32_t n_tiles, const unsigned long long *__restrict__ tile_off, uint8_t *__restrict__ out, uint64_t out_cap,
+    unsigned long long *__restrict__ total) {
+  static_assert(IMG >= 8u * BCF_REC_MAX && IMG % 16u == 0u, "an eighth of a tile of the longest records must fit the wave's image");
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[BCF_WAVES][IMG + 32u]; /* 15 bytes of phase in front, 7 of a last field's excess behind */
   const unsigned lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   uint8_t *const img = s_img[wid];
   const uint64_t n = clamp_n(a);
   if (blockIdx.x == 0 && threadIdx.x == 0) *total = tile_off[n_tiles];
-  for (uint32_t tile = blockIdx.x * BCF_WAVES + wid; tile < n_tiles; tile += gridDim.x * BCF_WAVES) {
+  /* the chain's byte of a position (0: no record; with SHORT indices 1 .. 254: the record's length) is fetched a tile ahead: the record
+   * loads then wait for nothing but themselves, and all eight leave together */
+  const uint32_t tile0 = blockIdx.x * BCF_WAVES + wid;
+  int gate_next = -1;
+  if (a.gate && tile0 < n_tiles && (uint64_t)tile0 * 64u + lane < n) gate_next = a.gate[(uint64_t)tile0 * 64u + lane];
+  for (uint32_t tile = tile0; tile < n_tiles; tile += gridDim.x * BCF_WAVES) {
     if ((uint64_t)tile * 64u >= n) break; /* wave-uniform; later tiles of this wave lie further out still */
+    const int gate = gate_next;
+    {
+      const uint64_t nt = (uint64_t)tile + (uint64_t)gridDim.x * BCF_WAVES;
+      gate_next = -1;
+      if (a.gate && nt < n_tiles && nt * 64u + lane < n) gate_next = a.gate[nt * 64u + lane];
+    }
     rec_regs r;
     const uint8_t *id;
     unsigned id_len;
     bool bad;
-    const unsigned len = rec_len(a, (uint64_t)tile * 64u + lane, n, r, id, id_len, bad);
+    const unsigned len = rec_len<SHORT>(a, (uint64_t)tile * 64u + lane, n, r, id, id_len, bad, gate, SHORT);
     /* exclusive prefix of the lengths over the wave */
     unsigned inc = len;
 #pragma unroll
@@ -423,25 +547,43 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
       if (lane >= (unsigned)d) inc += v;
     }
     const unsigned excl = inc - len;
-    const unsigned t_all = __shfl(inc, 63);
+    const unsigned t_all = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
     const uint64_t g_tile = tile_off[tile];
     if (g_tile + t_all > out_cap) continue; /* the host reports the overflow from *total */
-    /* one pass when the tile's span fits the image, else lanes 0..31 and 32..63 apart (32 records always fit) */
-    const unsigned t_half = __shfl(inc, 31);
-    const unsigned passes = t_all <= BCF_IMG_BYTES ? 1u : 2u;
-    for (unsigned ps = 0; ps < passes; ps++) {
-      const unsigned b0 = ps ? t_half : 0u;                                  /* the pass's first byte within the tile */
-      const unsigned b1 = passes == 1u ? t_all : (ps ? t_all : t_half);      /* one past its last */
+    /* one part when the tile's span fits the image (the usual case), else the fewest parts of equal lane counts that do */
+    unsigned parts = 1u;
+    if (t_all > IMG) {
+      for (parts = 2u; parts < 8u; parts <<= 1) {
+        const unsigned step = 64u / parts;
+        bool fits = true;
+        unsigned prev = 0u;
+        for (unsigned q = 0; q < parts; q++) {
+          const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)inc, (int)(step * (q + 1u) - 1u));
+          fits = fits && e - prev <= IMG;
+          prev = e;
+        }
+        if (fits) break;
+      }
+    }
+    const unsigned step = 64u / parts;
+    unsigned b0 = 0u; /* the part's first byte within the tile */
+    for (unsigned ps = 0; ps < parts; ps++) {
+      const unsigned b1 = (unsigned)__builtin_amdgcn_readlane((int)inc, (int)(step * (ps + 1u) - 1u)); /* one past its last */
       const bool mine = len && excl >= b0 && excl < b1;
       const uint64_t g0 = g_tile + b0;
       const unsigned ph = (unsigned)(g0 & 15u);
+      uint8_t *const p = img + ph + (excl - b0);
+      lds_sink w = {p + 32u, 0u};
+      unsigned l_shared = 0u;
       if (mine) {
-        uint8_t *p = img + ph + (excl - b0);
-        lds_sink w = {p + 32u, 0u};
         bool bad2;
-        const unsigned l_shared = bcf_emit_body(w, r, a, id, id_len, bad2);
-        bcf_emit_fixed(p, r, a, l_shared, w.len - l_shared);
+        l_shared = bcf_emit_body<SHORT>(w, r, a, id, id_len, bad2);
       }
+      /* every body before any of the fixed fields: a body's last store may reach into the next record's first bytes */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (mine) bcf_emit_fixed(p, r, a, l_shared, w.len - l_shared);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -457,6 +599,7 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      b0 = b1;
     }
   }
 }
@@ -475,10 +618,10 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
 #define BCF_FLAG_SUM (1ull << 62)
 #define BCF_FLAG_PREFIX (2ull << 62)
 #define BCF_VAL_MASK ((1ull << 62) - 1ull)
-extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BCF_WAVES_PER_EU, BCF_WAVES_PER_EU))) void bsc_bcf_onepass_kernel(
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BCF_ONEPASS_WAVES_PER_EU, BCF_ONEPASS_WAVES_PER_EU))) void bsc_bcf_onepass_kernel(
     bcf_args a, uint32_t n_tiles, unsigned long long *__restrict__ state /* [n_tiles], zeroed */, unsigned int *__restrict__ next_tile /* zeroed */,
     uint8_t *__restrict__ out, uint64_t out_cap, unsigned long long *__restrict__ totals /* [0] length, [1] += refused, [2] += written */) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_img[BCF_WAVES][BCF_IMG_BYTES + 16u];
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[BCF_WAVES][BCF_IMG_BYTES + 32u]; /* 15 bytes of phase in front, 7 of a last field's excess behind */
   const unsigned lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   uint8_t *const img = s_img[wid];
   const uint64_t n = clamp_n(a);
@@ -495,7 +638,7 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     const uint8_t *id;
     unsigned id_len;
     bool bad;
-    const unsigned len = rec_len(a, (uint64_t)tile * 64u + lane, n, r, id, id_len, bad);
+    const unsigned len = rec_len<false>(a, (uint64_t)tile * 64u + lane, n, r, id, id_len, bad);
     n_bad += (unsigned)__popcll(__ballot(bad));
     n_written += (unsigned)__popcll(__ballot(len != 0u));
     unsigned inc = len;
@@ -563,13 +706,18 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
       const bool mine = len && excl >= b0 && excl < b1;
       const uint64_t g0 = g_tile + b0;
       const unsigned ph = (unsigned)(g0 & 15u);
+      uint8_t *const p = img + ph + (excl - b0);
+      lds_sink w = {p + 32u, 0u};
+      unsigned l_shared = 0u;
       if (mine) {
-        uint8_t *p = img + ph + (excl - b0);
-        lds_sink w = {p + 32u, 0u};
         bool bad2;
-        const unsigned l_shared = bcf_emit_body(w, r, a, id, id_len, bad2);
-        bcf_emit_fixed(p, r, a, l_shared, w.len - l_shared);
+        l_shared = bcf_emit_body<false>(w, r, a, id, id_len, bad2);
       }
+      /* every body before any of the fixed fields: a body's last store may reach into the next record's first bytes */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (mine) bcf_emit_fixed(p, r, a, l_shared, w.len - l_shared);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -617,6 +765,7 @@ extern "C" int bsc_dev_launch_bcf(const void *recs, const void *core, const void
   a.name_off = (const uint32_t *)name_off;
   a.name_bytes = (const uint8_t *)name_bytes;
   a.n_names = name_pos ? n_names : 0u;
+  a.gate = nullptr;
   const uint64_t nt64 = (max_recs + 63u) / 64u;
   if (nt64 > 0x7fffffffull) return (int)hipErrorInvalidValue;
   const uint32_t n_tiles = (uint32_t)nt64;
@@ -667,7 +816,24 @@ extern "C" int bsc_dev_launch_bcf(const void *recs, const void *core, const void
   if (e != hipSuccess) return (int)e;
   const int rc = bsc_dev_scan_u64(tile_bytes, tile_off, n_tiles + 1u, scan_tmp, scan_tmp_bytes, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(bsc_bcf_write_kernel, dim3(grid), dim3(256), 0, s, a, n_tiles, (const unsigned long long *)tile_off, (uint8_t *)out, out_cap,
-                     (unsigned long long *)totals);
+  static int no_gate = -1; /* BSC_BCF_NO_GATE: the write kernel finds a position's flag in its record, as before the gate (A/B) */
+  if (no_gate < 0) no_gate = getenv("BSC_BCF_NO_GATE") != nullptr;
+  if (emit_len && !recs && !no_len && !no_gate) a.gate = (const uint8_t *)emit_len; /* not 0 <=> bsc_vcf_core.emit (fused.hip: ebyte) */
+#define BCF_LAUNCH_WRITE(SH, IMG, WPE)                                                                                                      \
+  hipLaunchKernelGGL((bsc_bcf_write_kernel_t<SH, IMG, WPE>), dim3(grid), dim3(256), 0, s, a, n_tiles, (const unsigned long long *)tile_off, \
+                     (uint8_t *)out, out_cap, (unsigned long long *)totals)
+  if (a.gate) {
+    grid = (n_tiles + BCF_WAVES - 1u) / BCF_WAVES;
+    if (grid > (unsigned)num_cus * 4u * BCF_WPE_SITES) grid = (unsigned)num_cus * 4u * BCF_WPE_SITES;
+    if (grid == 0) grid = 1;
+    if (short_ids)
+      BCF_LAUNCH_WRITE(true, BCF_IMG_SITES, BCF_WPE_SITES);
+    else
+      BCF_LAUNCH_WRITE(false, BCF_IMG_SITES, BCF_WPE_SITES);
+  } else if (short_ids)
+    BCF_LAUNCH_WRITE(true, BCF_IMG_PACKED, BCF_WPE_PACKED);
+  else
+    BCF_LAUNCH_WRITE(false, BCF_IMG_PACKED, BCF_WPE_PACKED);
+#undef BCF_LAUNCH_WRITE
   return (int)hipGetLastError();
 }

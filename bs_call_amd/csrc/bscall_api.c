@@ -436,7 +436,11 @@ int bsc_create(const bsc_params *params, bsc_context **out) {
       hipMalloc(&ctx->d_tables, sizeof(bsc_dev_tables)) != hipSuccess ||
       hipMalloc((void **)&ctx->d_counters, BSC_CNT_WORDS * sizeof(unsigned long long)) != hipSuccess ||
       hipMemcpy(ctx->d_tables, &ctx->host_tables, sizeof(bsc_dev_tables), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemset(ctx->d_counters, 0, BSC_CNT_WORDS * sizeof(unsigned long long)) != hipSuccess) {
+      hipMemset(ctx->d_counters, 0, BSC_CNT_WORDS * sizeof(unsigned long long)) != hipSuccess ||
+      /* hipMemset of device memory returns before the bytes are written, and the context's stream does not wait for the null stream: without
+       * this wait the zeroes could land behind the first block's "no error" word (all ones) — once in ~2 400 fresh contexts in
+       * tools/fuzz_block.py, "read -4 of template 0 lies outside the read buffer" (the word read back as 0) */
+      hipStreamSynchronize(NULL) != hipSuccess) {
     rc = bsc_fail(BSC_ERR_HIP, "bsc_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
     bsc_destroy(ctx);
     return rc;
@@ -2914,7 +2918,7 @@ int bsc_get_site_stats(bsc_context *ctx, bsc_site_stats *out) {
   unsigned long long n_ovf = 0;
   HIP_TRY(hipMemcpy(&n_ovf, ctx->d_counters + BSC_CNT_OVF, sizeof n_ovf, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(ctx->d_counters + BSC_CNT_OVF, 0, sizeof n_ovf));
-  HIP_TRY(hipMemcpy(out, ctx->d_sstats, sizeof *out, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, ctx->d_sstats, sizeof *out, hipMemcpyDeviceToHost)); /* (synchronous, behind the memset on the null stream: the word is zero when this returns) */
   if (n_ovf > BSC_OVF_CAP)
     return bsc_fail(BSC_ERR_RANGE, "bsc_get_site_stats: %llu CpG cytosines with 512 or more informative reads of one kind since the "
                                    "statistics were last read, %u can be listed: their share of the methylation profiles is missing",
@@ -2933,6 +2937,7 @@ int bsc_set_gc_bins(bsc_context *ctx, const void *d_gc, uint32_t n_bins, uint32_
       return bsc_fail(BSC_ERR_NOMEM, "bsc_set_gc_bins: device allocation failed");
     }
     HIP_TRY(hipMemset(ctx->d_gc_table, 0, BSC_GC_BYTES));
+    HIP_TRY(hipStreamSynchronize(NULL)); /* the memset is done before any stream adds to the table (see bsc_create) */
   }
   ctx->d_gc_bins = d_gc;
   ctx->gc_n_bins = d_gc ? n_bins : 0;
@@ -3010,6 +3015,7 @@ int bsc_reset_site_stats(bsc_context *ctx) {
   HIP_TRY(hipMemset(ctx->d_counters + BSC_CNT_OVF, 0, sizeof(unsigned long long)));
   if (ctx->d_gc_table) HIP_TRY(hipMemset(ctx->d_gc_table, 0, BSC_GC_BYTES));
   HIP_TRY(hipMemset(ctx->d_carry, 0, 4 * sizeof(uint32_t)));
+  HIP_TRY(hipStreamSynchronize(NULL)); /* the memsets are done before the next block's kernels add to what they cleared (see bsc_create) */
   ctx->carry_slot = 0;
   return BSC_OK;
 }
@@ -3033,6 +3039,7 @@ int bsc_reset_stats(bsc_context *ctx) {
   BSC_ENTER(ctx);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(ctx->d_counters, 0, BSC_CNT_WORDS * sizeof(unsigned long long)));
+  HIP_TRY(hipStreamSynchronize(NULL)); /* (see bsc_create) */
   ctx->sites = 0;
   return BSC_OK;
 }

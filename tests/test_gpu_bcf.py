@@ -135,7 +135,7 @@ def test_random_records_device_equals_host_and_python(caller):
 
 
 def test_long_names_and_wide_dictionary_indices_take_the_two_pass_path(caller):
-    """64 records of > 168 bytes each do not fit the wave's image (10 752 bytes): the tile goes out in two halves"""
+    """64 records of > 168 bytes each do not fit the wave's image (8 192 bytes): the tile goes out in two halves"""
     rng = np.random.default_rng(77)
     recs, names = _random_block(rng, 1500, named=0.9, long_names=True)
     recs["core"]["emit"] = 1
@@ -143,6 +143,40 @@ def test_long_names_and_wide_dictionary_indices_take_the_two_pass_path(caller):
     want = _host_stream(recs, 24, names, ids)
     sizes = np.array([len(w) for w in want])
     assert sizes.max() > 230 and sizes[:64].sum() > 10752
+    got, total, bad = _device_stream(caller, recs, 24, names, ids)
+    assert total == sizes.sum() and bad == 0 and got[:total].tobytes() == b"".join(want)
+
+
+def test_tiles_of_the_longest_records_go_out_in_four_parts(caller):
+    """the wave's image is 8 KB: 32 records of ~310 bytes do not fit it, 16 do — four parts of 16 lanes (eight parts exist for smaller images
+    only: 16 x 336 < 8 192).  Every size class at its widest: 63-byte names, four-byte dictionary indices, counts beyond 32 767, all four
+    filter names, six likelihoods, two ALT alleles, a heterozygous call's FS; a stretch of short records in between, so that the parts of
+    one tile differ in what they hold.  (The per-position form's tiles take the same code.)"""
+    rng = np.random.default_rng(4242)
+    recs, _ = _random_block(rng, 900, named=1.0, long_names=True)
+    recs["core"]["emit"] = 1
+    recs["rs_found"] = 1
+    recs["core"]["gt"] = 1          # heterozygous: FS is written
+    recs["core"]["gt_enc"] = 0x24
+    recs["core"]["flt"] = 15        # q20;qd2;fs60;mq40
+    recs["core"]["n_gl"] = 6
+    recs["core"]["alt"] = b"CT"
+    recs["core"]["fs"] = 2_000_000
+    recs["core"]["qd"] = 40000
+    recs["core"]["dp"] = 100000
+    recs["mq"] = 40000
+    recs["counts"] = 70000 + np.arange(8, dtype=np.uint32)
+    recs["qual"] = 43
+    recs["counts"][200:230] = 5
+    recs["core"]["n_gl"][200:230] = 1
+    listed = np.sort(recs["core"]["pos"]).astype(np.uint32)  # every record named: the longest name the encoder keeps, and longer ones (cut at 63)
+    nm = [b"rs" + bytes(rng.choice(list(b"0123456789"), int(rng.integers(61, 90))).tolist()) for _ in listed]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in nm])]).astype(np.uint32)
+    names = (listed, off, b"".join(nm))
+    ids = _lib.BcfIds(*[1_000_000 + k for k in range(17)])
+    want = _host_stream(recs, 24, names, ids)
+    sizes = np.array([len(w) for w in want])
+    assert sizes.max() <= 336 and sizes[:32].sum() > 8192 and sizes[:16].sum() <= 8192
     got, total, bad = _device_stream(caller, recs, 24, names, ids)
     assert total == sizes.sum() and bad == 0 and got[:total].tobytes() == b"".join(want)
 

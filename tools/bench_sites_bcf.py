@@ -50,5 +50,9 @@ with B.SiteCaller() as c:
     torch.cuda.synchronize()
     ms = [ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(a.steps)]
     tot = d_tot.cpu().numpy()
-print(json.dumps({"sites": n, "coverage": a.coverage, "records": int(tot[2]), "bcf_bytes": int(tot[0]), "refused": int(tot[1]), "stage_ms_avg": float(np.mean(ms)),
-                  "stage_ms_min": float(np.min(ms)), "algorithmic_bytes": int(n + 16 * n + 112 * int(tot[2]) + int(tot[0]))}))
+    nb = int(tot[0])
+    # a checksum of the stream, on the device (position-weighted, so that moved bytes show): for A/B runs of two forms of the encoder
+    w = d_out[: nb - nb % 8].view(torch.int64)
+    out_sum = int((w * (torch.arange(w.numel(), device=dev, dtype=torch.int64) | 1)).sum().item()) if nb >= 8 else 0
+print(json.dumps({"out_sum": out_sum, "sites": n, "coverage": a.coverage, "records": int(tot[2]), "bcf_bytes": int(tot[0]), "refused": int(tot[1]), "stage_ms_avg": float(np.mean(ms)),
+                  "stage_ms_min": float(np.min(ms)), "algorithmic_bytes": int(n + n + 128 * int(tot[2]) + int(tot[0]))}))

@@ -43,7 +43,7 @@ with B.SiteCaller() as c:
         assert total == len(exp) and bad == 0, (seed, total, len(exp), bad)
         assert got[:total].tobytes() == exp, (seed, "device stream differs from the host encoder's")
         sizes = [len(w) for w in want]
-        two_pass += int(any(sum(sizes[k : k + 64]) > 10752 for k in range(0, n, 64)))
+        two_pass += int(any(sum(sizes[k : k + 64]) > 8192 for k in range(0, n, 64)))  # the wave image of the packed form (BCF_IMG_PACKED)
         if ids is None:  # the Python encoder knows the default dictionary only
             table = {} if use_names is None else {int(p): names[2][int(names[1][i]) : int(names[1][i + 1])][:63] for i, p in enumerate(names[0])}
             for j in range(0, n, max(1, n // 25)):
@@ -55,5 +55,5 @@ with B.SiteCaller() as c:
         recs_done += n
         seed += 1
         if ran % 50 == 0:
-            print("fuzz_bcf: %d blocks, %d records, %d with a two-pass tile, seed %d" % (ran, recs_done, two_pass, seed), flush=True)
-print("fuzz_bcf: %d blocks (%d records, %d blocks with a two-pass tile) equal to the host and the Python encoder; seeds %d .. %d" % (ran, recs_done, two_pass, args.seed, seed - 1))
+            print("fuzz_bcf: %d blocks, %d records, %d with a tile in several parts, seed %d" % (ran, recs_done, two_pass, seed), flush=True)
+print("fuzz_bcf: %d blocks (%d records, %d blocks with a tile in several parts) equal to the host and the Python encoder; seeds %d .. %d" % (ran, recs_done, two_pass, args.seed, seed - 1))
