@@ -26,6 +26,7 @@ def per_call(sub, counter, calls):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == counter:
                 kn = r["Kernel_Name"].split("(")[0]
+                kn = kn[5:] if kn.startswith("void ") else kn  # a template instance's name: "void bsc_bcf_write_kernel_t<true, 8192u, 4u>"
                 kn = "rocprim scan" if "rocprim" in kn.lower() else kn
                 agg[kn] = agg.get(kn, 0.0) + float(r["Counter_Value"])
     return {k: v / calls for k, v in agg.items()}
