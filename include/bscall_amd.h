@@ -14,6 +14,27 @@
  * process thread; calls on one context must be ordered on one stream (the context owns a heterozygous-site list and
  * counters that successive launches reuse).  Independent work = independent contexts (e.g. one per GPU).
  * There is NO CPU fallback: without a usable gfx950 device bsc_create() fails with BSC_ERR_NO_DEVICE.
+ *
+ * MAP OF THE ENTRIES.  A caller picks ONE level — where a block enters the library and what comes back; the other ~120 names are the same
+ * computation cut at another place, fed from another kind of memory, or the readers / writers / counters around it.
+ *
+ *   level                          in -> out                                            entry                                   replaces (reference)
+ *   1   the calc threads           pileup[] -> gt_meth[] / gt_vcf[]                      bsc_call_sites                          call_thread's loop (src/call_genotypes.c:43-115)
+ *   2a  + the accumulate loop      templates + reads -> gt_vcf[]                         bsc_call_block                          call_genotypes_ML (:155-273)
+ *       ... the printer's records  templates + reads -> written records, packed          bsc_block_records                       + _print_vcf_entry up to the encoding (src/print_vcf.c:32-594)
+ *   2b  + the print thread         templates + reads -> the block's BCF bytes            bsc_block_bcf                           + bcf_enc_* / bcf_write (:160-222,267-378)
+ *   3   + the process thread       raw templates + mismatch lists -> BCF bytes           bsc_block_bcf_raw                       + process_template (src/process_template.c:36-111)
+ *   4   + the reader thread        a BAM file -> blocks in HBM -> BCF bytes              bsc_bamdev_next_block + bsc_block_bcf_rawdev[_keep]   + read_input (src/get_template_vector.c:49-389)
+ *
+ *   The suffixes say WHERE THE BUFFERS LIVE and WHEN THE CALL RETURNS, nothing else: (none) the caller's ordinary memory, staged by the
+ *   library, results on return; _inplace: the caller's page-locked memory (bsc_alloc_host), no staging copy; _submit / _fetch: the call in two
+ *   halves, the host thread returns while the GPU works (one block in flight per context, as the reference hands a block to its calc
+ *   threads); _to: results into caller-provided page-locked memory; _device: everything HBM-resident, asynchronous on the caller's stream;
+ *   bsc_blocks_*: several small blocks in one launch sequence.
+ *   Below the levels: their device-resident pieces for callers that keep whole contigs in HBM (bsc_accumulate_device, bsc_chain_device,
+ *   bsc_reads_chain[_len]_device, bsc_vcf_*_device, bsc_bcf_*_device: what bench.py and bs_call_amd/genome.py drive); host-side readers and
+ *   writers (bsc_bam_*, bsc_bamstream_*, bsc_dbsnp_*, bsc_fasta_contig, bsc_prepare_templates, bsc_bcf_record, bsc_vcf_format,
+ *   bsc_report_json); statistics and inspection (bsc_get_*, bsc_reset_*, bsc_last_*_ms).  INTEGRATION.md section 1 lists every name.
  */
 #ifndef BSCALL_AMD_H
 #define BSCALL_AMD_H
