@@ -60,6 +60,8 @@ struct bs_ent { /* one BGZF block of the file */
   uint32_t seq;      /* the slab-load it belongs to (SEQ_NONE: an empty block, stepped over) */
   uint32_t boff, blk_ix, sp_base;
   uint32_t restart, entry_skip;
+  uint32_t full;     /* not 0: the block inflates to this many bytes and only its first isize go into the stream (the end of a selected stretch
+                        whose last record reaches into this block: the bytes up to the block's first record start) */
 };
 struct bs_seq { /* one slab-load of the stream */
   uint64_t stream_off;
@@ -395,7 +397,7 @@ static void *idx_scan(void *a) {
     t->isize = is;
     t->crc = cr;
     t->seq = SEQ_NONE;
-    t->restart = t->entry_skip = 0;
+    t->restart = t->entry_skip = t->full = 0;
     pos += bs;
   }
   j->end = pos;
@@ -403,12 +405,48 @@ static void *idx_scan(void *a) {
 }
 
 /* ---- a selection of contigs: the stretches of the file that hold their records --------------------------------------------------------
- * The file is sorted by (contig, position), so the contig of a block's FIRST record grows with the block number: a binary search over
- * blocks, each probe one block inflated, finds where a contig's records begin and end — no index file.  Needs blocks that start at a
- * record (htslib's writer; checked at every probe).  The stretch of contig c: from the last block whose first record lies before c (it
- * may hold c's first records) to the last block whose first record is of c or before; stretches that touch are merged; records of other
- * contigs inside a stretch are dropped by the record parser's contig filter (csrc/bamdev_core.h). */
-static int first_tid_of(bsc_bamstream *b, uint64_t k, uint64_t k_hdr, uint32_t hdr_skip, uint8_t *raw, uint8_t *buf, int64_t *tid) {
+ * The file is sorted by (contig, position), so the contig of the first record that STARTS in a block grows with the block number: a binary
+ * search over blocks, each probe one block inflated, finds where a contig's records begin and end — no index file.  htslib's writer starts
+ * every block at a record (offset 0 is the answer at once); htsjdk's cuts records wherever a block is full, so the first record start of a
+ * block is FOUND: the first offset from which a chain of record headers — each checked field by field against what a BAM record can hold —
+ * runs to the block's end.  The stretch of contig c: from the last block whose first record lies before c (it may hold c's first records;
+ * the bytes in front of that record belong to a record of an earlier contig and are stepped over) to the last block whose first record is
+ * of c or before, plus the bytes of the following block(s) up to their first record start (the tail of c's last record, when it is cut);
+ * stretches that touch are merged; records of other contigs inside a stretch are dropped by the record parser's contig filter
+ * (csrc/bamdev_core.h). */
+static int plausible_record(const bsc_bamstream *b, const uint8_t *p, uint32_t avail) { /* avail >= 36 bytes from the record's size field on */
+  const uint32_t bs = le32(p);
+  const int32_t t = (int32_t)le32(p + 4), pos = (int32_t)le32(p + 8), mt = (int32_t)le32(p + 24), mpos = (int32_t)le32(p + 28); /* refID, pos, next_refID, next_pos */
+  const uint32_t l_name = p[12], n_cig = p[16] | (uint32_t)p[17] << 8, l_seq = le32(p + 20);
+  if (bs < 32 || bs > (1u << 29) || t < -1 || t >= b->n_ref || mt < -1 || mt >= b->n_ref || l_name == 0 || pos < -1 || mpos < -1) return 0;
+  if (t >= 0 && pos >= 0 && (uint32_t)pos > b->ref_len[t]) return 0;
+  if (mt >= 0 && mpos >= 0 && (uint32_t)mpos > b->ref_len[mt]) return 0;
+  if (32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1) / 2 + l_seq > bs) return 0;
+  /* the name: printable characters and its terminator, as far as the bytes at hand show it */
+  for (uint32_t i = 0; i < l_name && 36u + i < avail; i++) {
+    const uint8_t c = p[36 + i];
+    if (i + 1 == l_name ? c != 0 : (c < 33 || c > 126)) return 0;
+  }
+  return 1;
+}
+/* the offset of the first record that starts in buf[0 .. n), or -1 (none whose fixed fields lie inside the block: a neighbour speaks) */
+static int64_t first_record_in(const bsc_bamstream *b, const uint8_t *buf, uint32_t n) {
+  for (uint32_t o = 0; o + 36u <= n; o++) {
+    if (!plausible_record(b, buf + o, n - o)) continue;
+    /* the chain from o: every header that still lies inside the block */
+    uint64_t q = (uint64_t)o + 4u + le32(buf + o);
+    int ok = 1;
+    for (int hops = 0; hops < 6 && ok && q + 36u <= n; hops++) {
+      ok = plausible_record(b, buf + q, n - (uint32_t)q);
+      q += 4ull + le32(buf + q);
+    }
+    if (ok) return o;
+  }
+  return -1;
+}
+/* *tid: the contig of the first record that starts in block k (-2: header bytes only, -3: no record starts in it); *at: where it starts */
+static int first_tid_of(bsc_bamstream *b, uint64_t k, uint64_t k_hdr, uint32_t hdr_skip, uint8_t *raw, uint8_t *buf, int64_t *tid, uint32_t *at) {
+  *at = 0;
   if (k < k_hdr) {
     *tid = -2; /* header bytes only: before every contig */
     return BSC_OK;
@@ -421,18 +459,25 @@ static int first_tid_of(bsc_bamstream *b, uint64_t k, uint64_t k_hdr, uint32_t h
   if (pread(b->fd, raw, e->clen, (off_t)e->file_off) != (ssize_t)e->clen) return bsc_set_error(BSC_ERR_ARG, "BAM: read error");
   const char *er = bgzf_inflate_to(raw, e->clen, buf, e->isize, e->crc);
   if (er) return bsc_set_error(BSC_ERR_ARG, "%s", er);
-  const uint32_t o = k == k_hdr ? hdr_skip : 0u;
-  if (o >= e->isize) {
-    *tid = -2;
+  int64_t o;
+  if (k == k_hdr) { /* the first record of the file: behind the header, wherever that ends */
+    if (hdr_skip >= e->isize) {
+      *tid = -2;
+      return BSC_OK;
+    }
+    if (e->isize - hdr_skip < 36u) { /* (its fixed fields are cut: the next block's first record speaks, this block stays in front of everything) */
+      *tid = -2;
+      *at = hdr_skip;
+      return BSC_OK;
+    }
+    if (!plausible_record(b, buf + hdr_skip, e->isize - hdr_skip)) return bsc_set_error(BSC_ERR_ARG, "BAM: malformed first record");
+    o = hdr_skip;
+  } else if ((o = first_record_in(b, buf, e->isize)) < 0) {
+    *tid = -3;
     return BSC_OK;
   }
-  if (e->isize - o < 36) return bsc_set_error(BSC_ERR_ARG, "BAM: records are cut by BGZF block boundaries: a contig selection needs blocks that start at a record");
-  const uint32_t bs = le32(buf + o);
   const int32_t t = (int32_t)le32(buf + o + 4);
-  const uint32_t l_name = buf[o + 12], n_cig = buf[o + 16] | (uint32_t)buf[o + 17] << 8, l_seq = le32(buf + o + 20);
-  if (bs < 32 || bs > (1u << 29) || t < -1 || t >= b->n_ref || l_name == 0 || 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1) / 2 + l_seq > bs ||
-      (o + 36u + l_name <= e->isize && buf[o + 36 + l_name - 1] != 0))
-    return bsc_set_error(BSC_ERR_ARG, "BAM: records are cut by BGZF block boundaries: a contig selection needs blocks that start at a record");
+  *at = (uint32_t)o;
   *tid = t < 0 ? (int64_t)1 << 40 : t; /* unplaced reads come last */
   return BSC_OK;
 }
@@ -464,8 +509,9 @@ static int select_contigs(bsc_bamstream *b) {
       while (a + 1 < z && !rc) {
         uint64_t m = a + (z - a) / 2, mm = m;
         int64_t t = -3;
+        uint32_t at_unused;
         while (mm < z && !rc) { /* empty blocks have no record to look at: the next one speaks for them */
-          rc = first_tid_of(b, mm, k_hdr, hdr_skip, raw, buf, &t);
+          rc = first_tid_of(b, mm, k_hdr, hdr_skip, raw, buf, &t, &at_unused);
           if (t != -3) break;
           mm++;
         }
@@ -493,25 +539,71 @@ static int select_contigs(bsc_bamstream *b) {
   if (!rc) {
     uint64_t total = 0;
     for (int i = 0; i < n_rg; i++) total += rg[i].hi - rg[i].lo + 1;
-    struct bs_ent *ne = malloc((total + 1) * sizeof *ne);
+    /* (+ the blocks behind a stretch that hold the tail of its last record: as many as lie in front of the next record start — one, unless a
+     * record is longer than a block) */
+    uint64_t cap = total + (uint64_t)n_rg * 2u + 1u;
+    struct bs_ent *ne = malloc(cap * sizeof *ne);
     if (!ne) rc = bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
     else {
       uint64_t o = 0;
-      for (int i = 0; i < n_rg; i++) {
+      for (int i = 0; i < n_rg && !rc; i++) {
         const uint64_t first = o;
-        for (uint64_t k = rg[i].lo; k <= rg[i].hi; k++) ne[o++] = b->ent[k];
-        /* the stretch's first block with bytes restarts the chain */
-        for (uint64_t q = first; q < o; q++)
-          if (ne[q].isize) {
-            ne[q].restart = 1;
-            ne[q].entry_skip = rg[i].lo == k_hdr && q == first ? hdr_skip : 0u;
+        if (o + (rg[i].hi - rg[i].lo + 1) + 2u > cap) { /* (the tails behind the stretches before took more than was set aside) */
+          cap = o + (rg[i].hi - rg[i].lo + 1) + total + 16u;
+          struct bs_ent *nn = realloc(ne, cap * sizeof *ne);
+          if (!nn) {
+            rc = bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
             break;
           }
+          ne = nn;
+        }
+        for (uint64_t k = rg[i].lo; k <= rg[i].hi; k++) ne[o++] = b->ent[k];
+        /* the stretch's first block with bytes restarts the chain: at the header's end, or at the block's first record start (what lies in
+         * front of it is the tail of a record of an earlier contig) */
+        for (uint64_t q = first; q < o && !rc; q++)
+          if (ne[q].isize) {
+            int64_t t;
+            uint32_t at = 0;
+            rc = first_tid_of(b, rg[i].lo + (q - first), k_hdr, hdr_skip, raw, buf, &t, &at);
+            ne[q].restart = 1;
+            ne[q].entry_skip = t == -3 ? ne[q].isize : at; /* (no record starts in it: all of it is that tail) */
+            break;
+          }
+        /* the tail of the stretch's last record, when a block boundary cuts it: the bytes of the following blocks up to their first record start */
+        const uint64_t stop = i + 1 < n_rg ? rg[i + 1].lo : b->n_ent;
+        for (uint64_t k = rg[i].hi + 1; k < stop && !rc; k++) {
+          if (b->ent[k].isize == 0) continue;
+          int64_t t;
+          uint32_t at = 0;
+          rc = first_tid_of(b, k, k_hdr, hdr_skip, raw, buf, &t, &at);
+          if (rc) break;
+          if (t != -3 && at == 0) break; /* starts at a record (htslib's writer: always) */
+          if (o + 1 >= cap) {
+            cap = cap * 2u + 16u;
+            struct bs_ent *nn = realloc(ne, cap * sizeof *ne);
+            if (!nn) {
+              rc = bsc_set_error(BSC_ERR_NOMEM, "bsc_bamstream_open: out of memory");
+              break;
+            }
+            ne = nn;
+          }
+          ne[o] = b->ent[k];
+          if (t != -3) { /* up to its first record start, then the stretch is over */
+            ne[o].full = ne[o].isize;
+            ne[o].isize = at;
+            o++;
+            break;
+          }
+          o++; /* no record starts in it: all of it, and on */
+        }
       }
-      free(b->ent);
-      b->ent = ne;
-      b->n_ent = o;
-      b->w_skip = 0; /* every stretch says where it starts */
+      if (rc) free(ne);
+      else {
+        free(b->ent);
+        b->ent = ne;
+        b->n_ent = o;
+        b->w_skip = 0; /* every stretch says where it starts */
+      }
     }
   }
   free(raw);
@@ -703,8 +795,15 @@ static void *helper(void *arg) {
     kb->valid = 0;
     kb->restart = (uint8_t)e->restart;
     kb->entry_skip = e->entry_skip;
-    const char *er = pread(b->fd, raw, e->clen, (off_t)e->file_off) == (ssize_t)e->clen ? bgzf_inflate_to(raw, e->clen, s->bytes + e->boff, e->isize, e->crc)
-                                                                                         : "BAM: read error";
+    const char *er;
+    if (pread(b->fd, raw, e->clen, (off_t)e->file_off) != (ssize_t)e->clen) er = "BAM: read error";
+    else if (!e->full) er = bgzf_inflate_to(raw, e->clen, s->bytes + e->boff, e->isize, e->crc);
+    else { /* the end of a selected stretch: the whole block is inflated (and checked), its first isize bytes are the stream's */
+      uint8_t *tmp = malloc(65536);
+      er = tmp ? bgzf_inflate_to(raw, e->clen, tmp, e->full, e->crc) : "BAM: out of memory";
+      if (!er) memcpy(s->bytes + e->boff, tmp, e->isize);
+      free(tmp);
+    }
     if (er) {
       pthread_mutex_lock(&b->mu);
       set_err(b, er);

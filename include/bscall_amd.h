@@ -871,8 +871,9 @@ int bsc_bamstream_open(const char *path, int n_threads, uint64_t slab_bytes, int
 /* the stream of a SELECTION of contigs (tids of the header's list; -1 = the unplaced reads at the file's end) — what the reference reads through
  * sam_index_load + sam_itr_queryi per region (src/process.c:125, src/get_template_vector.c:69-99), without an index file: the file is sorted, so a
  * binary search over its BGZF blocks (one block inflated per probe) finds the stretches that hold the selected contigs' records; records of other
- * contigs inside a stretch are for the record parser's contig filter (bsc_bamdev_open_contigs applies it).  Needs blocks that start at a record
- * (htslib's writer); BSC_ERR_ARG otherwise.  n_tids = 0: an empty stream. */
+ * contigs inside a stretch are for the record parser's contig filter (bsc_bamdev_open_contigs applies it).  Blocks need not start at a record
+ * (htsjdk's writer cuts records where a block is full): the first record start of a probed block is found by a chain of checked record headers, a
+ * stretch begins there and ends with the tail of its last record in the following block(s).  n_tids = 0: an empty stream. */
 int bsc_bamstream_open_contigs(const char *path, int n_threads, uint64_t slab_bytes, int n_slabs, const int32_t *tids, int n_tids, bsc_bamstream **out);
 void bsc_bamstream_close(bsc_bamstream *b);
 int bsc_bamstream_next(bsc_bamstream *b, bsc_bam_slab *out);

@@ -109,3 +109,11 @@ def test_plain_c_ranks_and_merge_write_the_single_runs_bytes(tmp_path):
         assert open(rep).read() == want[1], world
         assert r.stdout.strip().splitlines()[-1] == want[2]
         assert not [f for f in os.listdir(tmp_path) if ".shard" in f or ".sums" in f]
+    # the same records in a file whose BGZF blocks cut records (htsjdk's writer): the ranks find the record starts themselves — same bytes
+    cut = str(tmp_path / "cut.bam")
+    W.write_bam(cut, refs, recs, aligned=False, block=3000)
+    out, rep = str(tmp_path / "cut.bcf"), str(tmp_path / "cut.json")
+    r = subprocess.run([os.path.join(ROOT, "tools", "bam2bcf_sharded.sh"), "3", cut, fa, out, rep, "S3"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, BAM2BCF_ONE_GPU="1"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert open(out, "rb").read() == want[0] and open(rep).read() == want[1]

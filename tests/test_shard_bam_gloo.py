@@ -130,9 +130,24 @@ def test_selections_stretches_and_refusals(tmp_path):
     for sel in ([0, 2], [3, 1], [0, 1, 2, 3, 4, -1], []):  # stretches apart, touching, everything, nothing
         (blocks, _, _), _ = TE.emul_blocks(lib, path, stream=stream_of_contigs(path, sel), contigs=sel)
         assert blocks == [b for t in sorted(set(sel) - {-1}) for b in by_tid(want, t)]
-    # records cut by block boundaries: a selection is refused (the whole file still streams)
-    cut = str(tmp_path / "cut.bam")
-    make_file(cut, seed=9, aligned=False, block=777)
-    with pytest.raises(BscError, match="cut by BGZF block"):
-        stream_of_contigs(cut, [1])
-    assert len(stream_of_contigs(cut, None)[1]) == len(stream_of_contigs(path, None)[1])
+    # records cut by block boundaries (htsjdk's writer; here blocks of 777, 100 and 5000 bytes — a record over several blocks, several records in
+    # one): the first record START of a block is found (a chain of plausible record headers), a stretch begins there and ends with the bytes of
+    # the following block(s) up to their first record start — the same blocks and counters as from the file whose blocks start at records
+    for block in (777, 100, 5000):
+        cut = str(tmp_path / ("cut%d.bam" % block))
+        make_file(cut, seed=9, aligned=False, block=block)
+        want_c, cts_c, bases_c = TE.TB.c_blocks(cut)
+        assert want_c == want and cts_c == cts and bases_c == bases
+        sums = np.zeros(30, dtype=np.uint64)
+        whole_bytes = len(stream_of_contigs(cut, None)[0])
+        for sel in ([0], [1], [2], [3], [4, -1]):
+            st = stream_of_contigs(cut, sel)
+            (blocks, c1, b1), _ = TE.emul_blocks(lib, cut, stream=st, contigs=sel)
+            assert blocks == [b for t in sel for b in by_tid(want, t)], (block, sel)
+            sums += np.array(c1 + b1, dtype=np.uint64)
+            assert len(st[0]) < whole_bytes
+        assert sums.tolist() == cts + bases, block
+        for sel in ([0, 2], [3, 1], [0, 1, 2, 3, 4, -1], []):
+            (blocks, _, _), _ = TE.emul_blocks(lib, cut, stream=stream_of_contigs(cut, sel), contigs=sel)
+            assert blocks == [b for t in sorted(set(sel) - {-1}) for b in by_tid(want, t)], (block, sel)
+        assert len(stream_of_contigs(cut, None)[1]) == len(stream_of_contigs(path, None)[1])
