@@ -10,11 +10,13 @@
  *             index every block's place in the slab sequence is known before the first byte is inflated.
  *   helpers   take blocks with one atomic add, in file order: read the payload (pread), inflate straight into the block's place in its
  *             slab (no copy), crc32, and walk the block's records (block_size prefixes) while the bytes are in the core's own cache,
- *             ASSUMING the block starts where a record starts (htslib's writer never cuts a record: bgzf_flush_try): record starts +
- *             what hangs over.  No word is shared between helpers but the slab's completion count.
- *   consumer  bsc_bamstream_next: the slab's blocks CHECKED in order (O(1) each: did the predecessor end where this one assumed?), a
- *             block whose assumption failed is walked again from the true state (files whose records straddle blocks — htsjdk's — are
- *             walked by the consumer: slower, same offsets); bytes + record starts, ready for one hipMemcpyAsync each.
+ *             from the block's first record start AS THE HELPER FINDS IT: offset 0 when a record header stands there (htslib's writer never
+ *             cuts a record: bgzf_flush_try — one check), else the first offset from which a chain of checked record headers runs on
+ *             (htsjdk's writer cuts records where a block is full): record starts + what hangs over.  No word is shared between helpers
+ *             but the slab's completion count.
+ *   consumer  bsc_bamstream_next: the slab's blocks CHECKED in order (O(1) each: did the predecessor's last record end where this one's
+ *             walk began?), a block whose helper guessed wrong (or whose size field is cut in two) is walked again from the true state;
+ *             bytes + record starts, ready for one hipMemcpyAsync each.
  *
  * What was measured on the way (50 Mb at 30x, 3.07 GB inflated, a 2 x 64-core host): one mutex and three broadcast condition variables
  * 3.6 GB/s with 16 helpers and 1.0 with 32; the walk in block order by the helpers behind a turn word 4.5 / 1.1 (64 helpers), behind a
@@ -50,7 +52,9 @@ struct bs_blk { /* a block's place in its slab and what its helper's walk found 
   uint32_t sp_base, sp_n;   /* its record starts: sparse[sp_base .. sp_base + sp_n), relative to the slab */
   uint32_t exit_skip;       /* bytes of its last record that lie in the following blocks */
   uint8_t exit_hdr[4], exit_hdr_n; /* ... or a size field cut in two */
-  uint8_t valid;            /* the walk from offset 0 met only plausible sizes */
+  uint32_t lead;            /* where the helper's walk began: the block's first record start as the helper found it (0: the block starts at a
+                               record — htslib's writer —; more: the tail of a record cut by the block boundary lies in front — htsjdk's) */
+  uint8_t valid;            /* the walk from there met only plausible sizes */
   uint8_t restart;          /* the chain starts afresh here (a stretch of a contig selection): entry_skip bytes are stepped over first */
   uint32_t entry_skip;
 };
@@ -280,12 +284,27 @@ static const char *walk_block(bsc_bamstream *b, bs_slab *s, uint32_t boff, const
 }
 
 /* the helper's walk: the block as if a record started at its first byte */
-static void walk_speculative(struct bs_blk *k, uint32_t *sparse, const uint8_t *p) {
+static int64_t first_record_in(const bsc_bamstream *b, const uint8_t *buf, uint32_t n);
+/* The helper's walk of its own block, without knowing what hangs over from the block before: from the block's first record start — offset 0
+ * when a record header stands there (one check: every block of an htslib-written file), else the first offset from which a chain of checked
+ * headers runs on (first_record_in: files whose writer cuts records at block ends) — the consumer accepts the finds if the predecessor's
+ * overhang ends exactly there. */
+static void walk_speculative(const bsc_bamstream *b, struct bs_blk *k, uint32_t *sparse, const uint8_t *p) {
   const uint32_t n = k->isize;
   uint32_t o = 0, cnt = 0;
   k->valid = 1;
   k->exit_skip = 0;
   k->exit_hdr_n = 0;
+  k->lead = 0;
+  k->sp_n = 0;
+  if (n >= 36u) {
+    const int64_t f = first_record_in(b, p, n);
+    if (f < 0) { /* no record header inside: the middle of a long record, or damage — the consumer's walk says which */
+      k->valid = 0;
+      return;
+    }
+    k->lead = o = (uint32_t)f;
+  }
   while (o < n) {
     sparse[k->sp_base + cnt++] = k->boff + o;
     if (n - o < 4) {
@@ -792,6 +811,7 @@ static void *helper(void *arg) {
     kb->isize = e->isize;
     kb->sp_base = e->sp_base;
     kb->sp_n = 0;
+    kb->lead = 0;
     kb->valid = 0;
     kb->restart = (uint8_t)e->restart;
     kb->entry_skip = e->entry_skip;
@@ -810,7 +830,7 @@ static void *helper(void *arg) {
       pthread_mutex_unlock(&b->mu);
       break;
     }
-    if (!b->dbg_nowalk) walk_speculative(kb, s->sparse, s->bytes + e->boff);
+    if (!b->dbg_nowalk) walk_speculative(b, kb, s->sparse, s->bytes + e->boff);
     if (__atomic_add_fetch(&s->done, 1, __ATOMIC_ACQ_REL) == b->seq[e->seq].n_ent) { /* the load is complete */
       pthread_mutex_lock(&b->mu);
       s->ready_for = (uint64_t)e->seq + 1u;
@@ -1136,7 +1156,7 @@ int bsc_bamstream_next(bsc_bamstream *b, bsc_bam_slab *out) {
       if (b->w_skip || b->w_hdr_n) return bsc_set_error(BSC_ERR_ARG, "BAM: a record is cut where a selected stretch of the file ends");
       b->w_skip = k->entry_skip;
     }
-    if (b->w_skip == 0 && b->w_hdr_n == 0 && k->valid) {
+    if (b->w_hdr_n == 0 && k->valid && b->w_skip == k->lead) { /* the predecessor's record ends where the helper's walk began */
       memcpy(s->rec_off + s->n_recs, s->sparse + k->sp_base, (size_t)k->sp_n * 4u);
       s->n_recs += k->sp_n;
       b->w_skip = k->exit_skip;
