@@ -829,11 +829,11 @@ extern "C" int bsc_dev_launch_bcf(const void *recs, const void *core, const void
     if (short_ids)
       BCF_LAUNCH_WRITE(true, BCF_IMG_SITES, BCF_WPE_SITES);
     else
-      BCF_LAUNCH_WRITE(false, BCF_IMG_SITES, BCF_WPE_SITES);
+      BCF_LAUNCH_WRITE(false, BCF_IMG_SITES, 3); /* (wide dictionary indices: the general emitter needs 168 registers to stay out of scratch) */
   } else if (short_ids)
     BCF_LAUNCH_WRITE(true, BCF_IMG_PACKED, BCF_WPE_PACKED);
   else
-    BCF_LAUNCH_WRITE(false, BCF_IMG_PACKED, BCF_WPE_PACKED);
+    BCF_LAUNCH_WRITE(false, BCF_IMG_PACKED, 3);
 #undef BCF_LAUNCH_WRITE
   return (int)hipGetLastError();
 }
