@@ -578,6 +578,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       if (mine) {
         bool bad2;
         l_shared = bcf_emit_body<SHORT>(w, r, a, id, id_len, bad2);
+        /* the length the lane offsets were made of (the chain's byte, or the counting run) is the length written: anything else would be a
+         * stream with a hole or an overlap — counted with the refused records, so the block fails instead (never seen; the chain's formula
+         * and this emitter are two statements of one rule) */
+        if (32u + w.len != len) atomicAdd(total + 1, 1ull);
       }
       /* every body before any of the fixed fields: a body's last store may reach into the next record's first bytes */
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -745,7 +749,7 @@ extern "C" int bsc_dev_scan_u64(const void *in, void *out, uint32_t n, void *tmp
 /*
  * recs[<= max_recs] packed records, *n_recs of them (device u64) — or, recs == NULL, core[max_recs] / aux[max_recs] as the reads-in chain
  * leaves them (n_recs may then be NULL: every position) — -> out[<= out_cap] BCF bytes; totals[0] = the stream's length (also when it
- * exceeds out_cap: then only the tiles that fit whole are written), totals[1] += records bsc_bcf_record refuses, totals[2] += records
+ * exceeds out_cap: then only the tiles that fit whole are written), totals[1] += records bsc_bcf_record refuses (and records whose written length is not the length they were placed by: never seen), totals[2] += records
  * written.  tile_bytes / tile_off: max_recs / 64 (rounded up) + 1 u64 each; scan_tmp: bsc_dev_scan_tmp_bytes_u64 of that many.
  */
 extern "C" int bsc_dev_launch_bcf(const void *recs, const void *core, const void *aux, const void *n_recs, uint64_t max_recs, int32_t rid,
