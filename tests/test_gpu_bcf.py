@@ -566,3 +566,55 @@ def test_encoder_over_a_whole_contig_of_records(caller):
         o += ln
         k += 1
     assert o == total and k == n_rec
+
+
+def test_length_bytes_entries_and_a_length_that_lies(caller):
+    """The device-level pair behind the block entries (bsc_reads_chain_len_device, bsc_bcf_sites_len_device: the chain's byte per position gates and
+    sizes the encoder) writes the stream of bsc_bcf_sites_device (sizes from the records) — plain, with every position written (-A), and with wide
+    dictionary indices (the bytes are then a gate only) — and a byte that does NOT hold its record's length makes the block fail: the record is
+    counted with the refused ones (a stream with a hole or an overlap is never handed out silently)."""
+    import torch
+    from bs_call_amd import reads as R
+
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    x, n_pos, cov = 5000, 300_000, 25
+    tpl, seq, y = R.synth_block(77, x, n_pos, cov)
+    ref = B.synth_ref_host(77, x, y - x + 3)
+    n = y - x + 1
+    up = lambda v: torch.from_numpy(v.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_tpl, d_seq, d_ref = up(tpl), up(seq), up(ref)
+    for all_positions, ids in ((False, None), (True, None), (False, _lib.BcfIds(*[300 + k for k in range(17)]))):
+        d_core = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        d_aux = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        d_len = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+        caller.reads_chain_len_device(d_tpl.data_ptr(), len(tpl), d_seq.data_ptr(), seq.size, x, y, d_ref.data_ptr(), d_core.data_ptr(), d_aux.data_ptr(),
+                                      d_len.data_ptr(), all_positions=all_positions, stream=st)
+        caller.block_status(st)
+        cap = n * 130 + 4096
+        outs = []
+        for with_len in (False, True):
+            d_out = torch.full((cap,), 0xEE, dtype=torch.uint8, device=dev)
+            d_tot = torch.zeros(3, dtype=torch.int64, device=dev)
+            if with_len:
+                caller.bcf_sites_len_device(d_core.data_ptr(), d_aux.data_ptr(), d_len.data_ptr(), n, 3, d_out.data_ptr(), cap, d_tot.data_ptr(), ids=ids, stream=st)
+            else:
+                caller.bcf_sites_device(d_core.data_ptr(), d_aux.data_ptr(), n, 3, d_out.data_ptr(), cap, d_tot.data_ptr(), ids=ids, stream=st)
+            torch.cuda.synchronize()
+            tot = d_tot.cpu().numpy()
+            assert tot[1] == 0 and tot[2] > (n // 3 if not all_positions else n * 9 // 10)
+            outs.append((int(tot[0]), int(tot[2]), d_out[: int(tot[0])].cpu().numpy().tobytes()))
+        assert outs[0] == outs[1], (all_positions, ids is not None)
+        if ids is None and not all_positions:
+            # a byte is not 0 exactly where a record is written
+            core = d_core.cpu().numpy().view(B.VCF_CORE)
+            lens = d_len[:n].cpu().numpy()
+            assert ((lens != 0) == (core["emit"] != 0)).all()
+            # one byte lies about its record by one: the block is refused
+            k = int(np.flatnonzero((lens > 0) & (lens < 250))[1000])
+            d_len[k] += 1
+            d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+            d_tot = torch.zeros(3, dtype=torch.int64, device=dev)
+            caller.bcf_sites_len_device(d_core.data_ptr(), d_aux.data_ptr(), d_len.data_ptr(), n, 3, d_out.data_ptr(), cap, d_tot.data_ptr(), stream=st)
+            torch.cuda.synchronize()
+            assert int(d_tot[1].item()) == 1 and int(d_tot[0].item()) == outs[1][0] + 1
