@@ -67,6 +67,9 @@ EXPORTS = (
     "bsc_block_bcf_submit",
     "bsc_block_bcf_submit_inplace",
     "bsc_block_bcf_fetch",
+    "bsc_blocks_bcf_submit",
+    "bsc_blocks_bcf_submit_inplace",
+    "bsc_blocks_bcf_fetch",
     "bsc_dbsnp_names",
     "bsc_fasta_contig",
     "bsc_block_reference",
@@ -432,6 +435,12 @@ def load():
     L.bsc_block_bcf_submit_inplace.argtypes = L.bsc_block_bcf_submit.argtypes
     L.bsc_block_bcf_fetch.restype = i32
     L.bsc_block_bcf_fetch.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.bsc_blocks_bcf_submit.restype = i32
+    L.bsc_blocks_bcf_submit.argtypes = [vp, vp, u32, vp, vp, u64, vp, vp, vp, i32, i32, C.POINTER(BcfIds), vp, vp, u64]
+    L.bsc_blocks_bcf_submit_inplace.restype = i32
+    L.bsc_blocks_bcf_submit_inplace.argtypes = L.bsc_blocks_bcf_submit.argtypes
+    L.bsc_blocks_bcf_fetch.restype = i32
+    L.bsc_blocks_bcf_fetch.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.bsc_bcf_block_device.restype = i32
     L.bsc_bcf_block_device.argtypes = [vp, vp, vp, u64, i32, C.POINTER(BcfIds), vp, vp, u64, vp, vp]
     L.bsc_bcf_sites_device.restype = i32

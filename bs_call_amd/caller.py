@@ -630,6 +630,50 @@ class SiteCaller:
         self._pending_blocks = (out, len(desc))
         return None if submit_only else self.blocks_records_fetch()
 
+    def blocks_bcf(self, blocks, ref, rid, names=None, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None, with_stats=False, cap=None, ids=None,
+                   inplace=False):
+        """Several blocks in one launch sequence, their BCF bytes back as ONE stream (bsc_blocks_bcf_submit[_inplace] + _fetch): blocks, ref and
+        dbsnp as blocks_records takes them; names = the table of all the blocks' flagged positions.  Returns (bytes, n_records): the streams of
+        block_bcf() called on the blocks one after another, concatenated."""
+        from .abi import BLOCK_DESC
+
+        tpls, seqs, desc, off = [], [], np.zeros(len(blocks), dtype=BLOCK_DESC), 0
+        for i, (t, sq, x, y) in enumerate(blocks):
+            t = np.array(t, dtype=TEMPLATE)
+            sq = np.ascontiguousarray(sq, dtype=np.uint8)
+            t["off"] += np.uint64(off)
+            off += sq.size
+            tpls.append(t)
+            seqs.append(sq)
+            desc[i] = (x, y, len(t), 0)
+        tpl = np.concatenate(tpls) if tpls else np.zeros(0, dtype=TEMPLATE)
+        seq = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
+        sizes = [int(y) - int(x) + 1 for _, _, x, y in blocks]
+        refs = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint8) for r in ref]) if isinstance(ref, (list, tuple)) else ref, dtype=np.uint8)
+        db = None
+        if dbsnp is not None:
+            db = np.ascontiguousarray(np.concatenate([np.asarray(d, dtype=np.uint8) for d in dbsnp]) if isinstance(dbsnp, (list, tuple)) else dbsnp, dtype=np.uint8)
+        if ids is None:
+            ids = _lib.BcfIds()
+            self._L.bsc_bcf_default_ids(C.byref(ids))
+        nm, keep = self._bcf_names(names)
+        cap_given = cap
+        cap = 64 + 192 * max(sum(sizes), 1) if cap is None else int(cap)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        p = _lib.VcfParams(1 if all_positions else 0, reg_start, reg_stop)
+        nb, nr = C.c_uint64(0), C.c_uint64(0)
+        fn = self._L.bsc_blocks_bcf_submit_inplace if inplace else self._L.bsc_blocks_bcf_submit
+        _check(fn(self._h, _ptr(desc), len(desc), _ptr(tpl), _ptr(seq), seq.size, _ptr(refs), None if db is None else _ptr(db), C.byref(p),
+                  1 if with_stats else 0, rid, C.byref(ids), None if nm is None else C.addressof(nm), _ptr(out), cap))
+        rc = self._L.bsc_blocks_bcf_fetch(self._h, C.byref(nb), C.byref(nr))
+        if rc == -1 and nb.value > cap and cap_given is None:
+            cap = int(nb.value)
+            out = np.empty(cap, dtype=np.uint8)
+            rc = self._L.bsc_block_bcf_again(self._h, _ptr(out), cap, C.byref(nb), C.byref(nr))
+        _check(rc)
+        del keep, tpl, seq, refs, db, desc
+        return out[: nb.value].tobytes(), nr.value
+
     def blocks_records_joined(self, desc, tpl, seq, ref, out, all_positions=False, reg_start=1, reg_stop=0xFFFFFFFF, dbsnp=None,
                               with_stats=False, inplace=False, submit_only=False):
         """bsc_blocks_records_submit[_inplace] on arrays that are already joined as the C ABI wants them (what a C host that

@@ -2623,7 +2623,7 @@ int bsc_block_records_fetch(bsc_context *ctx, uint64_t *n_out) {
  */
 static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
                             uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
-                            bsc_vcf_rec *out, uint64_t out_cap, int stage) {
+                            bsc_vcf_rec *out, uint64_t out_cap, int stage, const bsc_bcf_req *bcf) {
   if (ctx->pending_sz || ctx->rec_pending)
     return bsc_fail(BSC_ERR_ARG, "a submitted block has not been fetched (bsc_block_fetch / bsc_block_records_fetch first)");
   if (n_blocks == 0 || n_blocks > 65536u) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records: n_blocks must be 1 .. 65536, got %u", n_blocks);
@@ -2645,6 +2645,13 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
   BSC_ENTER(ctx);
   int rc;
   size_t scan_bytes = 0;
+  if (bcf) { /* no packed records: the encoder reads the chain's per-position arrays of all the blocks, ONE stream goes back (bsc_blocks_bcf) */
+    out = NULL;
+    out_cap = 0;
+    bsc_bcf_pool_take(ctx, (size_t)(bcf->out_cap ? bcf->out_cap : 1));
+    if ((rc = bsc_reserve(&ctx->d_bcf, &ctx->cap_bcf, (size_t)(bcf->out_cap ? bcf->out_cap : 1)))) return rc;
+    if ((rc = bsc_reserve(&ctx->d_btot, &ctx->cap_btot, 3 * sizeof(unsigned long long)))) return rc;
+  }
   if ((rc = bsc_accumulate_reserve(ctx, nr, 1u, P, &scan_bytes))) return rc; /* P positions = P / 64 bins */
   if ((rc = bsc_reserve(&ctx->d_fscr, &ctx->cap_fscr, bsc_dev_chain_scratch_bytes(ctx->num_cus)))) return rc;
   if ((rc = bsc_reserve(&ctx->d_tpl, &ctx->cap_tpl, (size_t)(nr ? nr : 1) * sizeof(bsc_template)))) return rc;
@@ -2719,6 +2726,9 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
   HIP_TRY(hipMemcpyAsync(ctx->d_ref, ref, (size_t)ref64, hipMemcpyHostToDevice, s));
   if (dbsnp) HIP_TRY(hipMemcpyAsync(ctx->d_vdb, st + o_db, b_db, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->d_mblk, mb, b_blk, hipMemcpyHostToDevice, s));
+  if (bcf && (rc = bsc_names_upload(ctx, "bsc_blocks_bcf", bcf->names, s))) return rc;
+  const bsc_bcf_names *const names_ready = ctx->names_up;
+  ctx->names_up = NULL;
   void *d_db = dbsnp ? ctx->d_vdb : NULL;
   /* template checks + grouping of all blocks' reads (SPAN, INEXACT = 0 and ERR = all ones first, as bsc_reads_prepare) */
   HIP_TRY(hipMemsetAsync(ctx->d_counters + BSC_CNT_SPAN, 0, 2 * sizeof(unsigned long long), s));
@@ -2755,6 +2765,38 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
   }
   ctx->sites += sites;
   unsigned long long *d_total = ctx->d_counters + BSC_CNT_RECORDS;
+  if (bcf) { /* as bsc_records_queue's tail, over the P positions of all the blocks (the positions between two blocks write no record) */
+    HIP_TRY(hipMemcpyAsync(ctx->h_cnt, ctx->d_counters + BSC_CNT_INEXACT, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    ctx->rec_out = NULL;
+    ctx->rec_cap = 0;
+    ctx->rec_sz = sites > 0xffffffffull ? 0xffffffffu : (uint32_t)sites;
+    ctx->emit_hint = d_emit;
+    ctx->again.sz = P;
+    ctx->again.rid = bcf->rid;
+    ctx->again.ids = *bcf->ids;
+    ctx->again.emit = d_emit;
+    ctx->again.have_names = names_ready != NULL;
+    ctx->again.n_names = ctx->names_up_n;
+    ctx->again.name_bytes = ctx->names_up_bytes;
+    ctx->names_up = names_ready;
+    rc = bsc_bcf_sites_device(ctx, ctx->d_vout, ctx->d_out, P, bcf->rid, bcf->ids, bcf->names, ctx->d_bcf, bcf->out_cap, ctx->d_btot, s);
+    ctx->emit_hint = NULL;
+    ctx->names_up = NULL;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_cnt + 4, ctx->d_btot, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    uint64_t guess = ctx->bcf_share > 0.0 ? (uint64_t)((double)sites * ctx->bcf_share) + 65536u : 0u;
+    if (guess > bcf->out_cap) guess = bcf->out_cap;
+    if (!bcf->out) guess = 0;
+    if (guess) HIP_TRY(hipMemcpyAsync(bcf->out, ctx->d_bcf, (size_t)guess, hipMemcpyDeviceToHost, s));
+    ctx->bcf_blk = 1;
+    ctx->bcf_keep = bcf->out == NULL;
+    ctx->bcf_out = bcf->out;
+    ctx->bcf_cap = bcf->out_cap;
+    ctx->bcf_copied = guess;
+    ctx->rec_copied = 0;
+    ctx->mb_toff = NULL;
+    return BSC_OK;
+  }
   ctx->emit_hint = d_emit;
   rc = bsc_vcf_compact_device(ctx, ctx->d_vout, ctx->d_out, 0, d_db, P, ctx->d_recs, out_cap, d_total, s);
   ctx->emit_hint = NULL;
@@ -2775,11 +2817,12 @@ static int bsc_blocks_queue(bsc_context *ctx, const bsc_block_desc *blocks, uint
 
 static int bsc_blocks_submit(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
                              uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
-                             bsc_vcf_rec *out, uint64_t out_cap, int stage) {
+                             bsc_vcf_rec *out, uint64_t out_cap, int stage, const bsc_bcf_req *bcf) {
   if (!ctx || !blocks || !ref || !params || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records_submit: NULL argument");
-  int rc = bsc_blocks_queue(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap, stage);
+  int rc = bsc_blocks_queue(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap, stage, bcf);
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream); /* nothing may still read the inputs / the staging area after a failed submit */
+    ctx->bcf_blk = 0;
     return rc;
   }
   ctx->rec_pending = 2;
@@ -2789,19 +2832,19 @@ static int bsc_blocks_submit(bsc_context *ctx, const bsc_block_desc *blocks, uin
 int bsc_blocks_records_submit(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
                               uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
                               bsc_vcf_rec *out, uint64_t out_cap) {
-  return bsc_blocks_submit(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap, 1);
+  return bsc_blocks_submit(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap, 1, NULL);
 }
 
 int bsc_blocks_records_submit_inplace(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl,
                                       const uint8_t *seq, uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp,
                                       const bsc_vcf_params *params, int with_stats, bsc_vcf_rec *out, uint64_t out_cap) {
-  return bsc_blocks_submit(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap, 0);
+  return bsc_blocks_submit(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap, 0, NULL);
 }
 
 int bsc_blocks_records_fetch(bsc_context *ctx, uint64_t *n_out, uint64_t *block_counts) {
   if (!ctx || !n_out) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records_fetch: NULL argument");
   *n_out = 0;
-  if (ctx->rec_pending != 2) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records_fetch: no blocks were submitted");
+  if (ctx->rec_pending != 2 || ctx->bcf_blk) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_records_fetch: no blocks were submitted by bsc_blocks_records_submit");
   ctx->rec_pending = 0;
   BSC_ENTER(ctx);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -2826,6 +2869,38 @@ int bsc_blocks_records(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t 
   int rc = bsc_blocks_records_submit(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, out, out_cap);
   if (rc) return rc;
   return bsc_blocks_records_fetch(ctx, n_out, block_counts);
+}
+
+/* Several blocks in one launch sequence, their BCF bytes back as ONE stream (the blocks' records in the blocks' order: what bsc_block_bcf
+ * gives block after block, concatenated): bsc_blocks_records' launch sequence with the encoder over the chain's arrays instead of the
+ * packing pass.  All blocks lie on one contig (rid), in genome order; a names table lists the flagged positions of all of them. */
+static int bsc_blocks_bcf_submit_(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                                  uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid,
+                                  const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap, int stage) {
+  if (!ids || (!out && out_cap)) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_bcf_submit: NULL argument");
+  const bsc_bcf_req req = {rid, ids, names, out, out_cap};
+  if (ctx) ctx->bcf_bytes = 0;
+  return bsc_blocks_submit(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, NULL, 0, stage, &req);
+}
+int bsc_blocks_bcf_submit(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                          uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid,
+                          const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap) {
+  return bsc_blocks_bcf_submit_(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, rid, ids, names, out, out_cap, 1);
+}
+int bsc_blocks_bcf_submit_inplace(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                                  uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                                  int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap) {
+  return bsc_blocks_bcf_submit_(ctx, blocks, n_blocks, tpl, seq, seq_bytes, ref, dbsnp, params, with_stats, rid, ids, names, out, out_cap, 0);
+}
+int bsc_blocks_bcf_fetch(bsc_context *ctx, uint64_t *n_bytes, uint64_t *n_records) {
+  if (!ctx || !n_bytes || !n_records) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_bcf_fetch: NULL argument");
+  *n_bytes = *n_records = 0;
+  if (ctx->rec_pending != 2 || !ctx->bcf_blk) return bsc_fail(BSC_ERR_ARG, "bsc_blocks_bcf_fetch: no blocks were submitted by bsc_blocks_bcf_submit");
+  ctx->rec_pending = 0;
+  BSC_ENTER(ctx);
+  const int rc = bsc_records_finish(ctx, n_records);
+  *n_bytes = ctx->bcf_bytes;
+  return rc;
 }
 
 /* ---- site statistics -------------------------------------------------------------------------------------- */

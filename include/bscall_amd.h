@@ -743,6 +743,19 @@ int bsc_block_bcf_submit_inplace(bsc_context *ctx, const bsc_template *tpl, uint
                                  uint32_t y, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid,
                                  const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap);
 int bsc_block_bcf_fetch(bsc_context *ctx, uint64_t *n_bytes, uint64_t *n_records);
+/* SEVERAL blocks in one launch sequence, their BCF bytes back as ONE stream (round 6; bsc_blocks_records' block list and joined arrays, see
+ * there): the records of the blocks in the blocks' order — what bsc_block_bcf gives block after block, concatenated — for a caller whose blocks
+ * are small (the reference's unit is a run of overlapping templates, 10^2 .. 10^7 positions; a launch sequence costs ~0.2 ms whatever its size).
+ * The blocks lie on ONE contig (rid) in genome order; `names` lists the flagged positions of all of them.  _submit stages the inputs (the
+ * caller's buffers are free on return), _submit_inplace reads them where they lie (page-locked: bsc_alloc_host) until the fetch; one submission in
+ * flight per context.  A stream longer than out_cap: BSC_ERR_ARG with *n_bytes = the room needed, then bsc_block_bcf_again. */
+int bsc_blocks_bcf_submit(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                          uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats, int32_t rid,
+                          const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap);
+int bsc_blocks_bcf_submit_inplace(bsc_context *ctx, const bsc_block_desc *blocks, uint32_t n_blocks, const bsc_template *tpl, const uint8_t *seq,
+                                  uint64_t seq_bytes, const uint8_t *ref, const uint8_t *dbsnp, const bsc_vcf_params *params, int with_stats,
+                                  int32_t rid, const bsc_bcf_ids *ids, const bsc_bcf_names *names, uint8_t *out, uint64_t out_cap);
+int bsc_blocks_bcf_fetch(bsc_context *ctx, uint64_t *n_bytes, uint64_t *n_records);
 /* After a BCF block entry (bsc_block_bcf, _raw, _rawdev[_keep], bsc_block_bcf_fetch) has answered BSC_ERR_ARG with *n_bytes > out_cap — the
  * block's stream is longer than the room given — and before anything else is asked of the context: the ENCODER alone once more, from the
  * per-position arrays the block left in HBM, into out[out_cap] (out == NULL: the stream stays on the device, bsc_bcf_stream_read, out_cap

@@ -212,3 +212,57 @@ def test_blocks_submit_to_equals_block_by_block(caller, oracle, tables, libm_exa
     with pytest.raises(B.BscError, match="bs_strand 9"):
         caller.blocks_submit_to(blocks[:3] + [(bad,) + blocks[3][1:]] + blocks[4:], refs, inplace=True)
     assert caller.blocks_submit_to(blocks[:2], refs[:2], inplace=True)[1][: blocks[0][3] - blocks[0][2] + 1].tobytes() == single[0][0].tobytes()
+
+
+def test_blocks_bcf_is_the_blocks_streams_one_after_another(caller):
+    """bsc_blocks_bcf_submit[_inplace] / _fetch: several blocks in ONE launch sequence, ONE BCF stream back = the streams of bsc_block_bcf called on
+    the blocks one after another (itself pinned to the host encoder over the oracle chain's records, tests/test_gpu_bcf.py): random blocks incl.
+    adjacent ones cut at a CpG; sizes around the tile geometry with dbSNP flags, a names table over all the blocks, every position written, a
+    region; a room that is too small answered by bsc_block_bcf_again; and the fetches do not take each other's submissions."""
+    from bs_call_amd.caller import BscError
+
+    rng = np.random.default_rng(77)
+    raw = _random_blocks(rng, 120, 50, 9000, split_every=7)
+    blocks = [(t, s, x, y) for t, s, x, y, _ in raw]
+    refs = [r for _, _, _, _, r in raw]
+    want = [caller.block_bcf(t, s, x, y, refs[i], 5) for i, (t, s, x, y) in enumerate(blocks)]
+    exp, n_exp = b"".join(w[0] for w in want), sum(w[1] for w in want)
+    for inplace in (False, True):
+        got, n = caller.blocks_bcf(blocks, refs, 5, inplace=inplace)
+        assert n == n_exp and got == exp, inplace
+    # tile-geometry sizes, dbSNP flags and names
+    sizes = [1, 2, 59, 60, 61, 62, 63, 64, 65, 127, 128, 129, 40_000, 7, 3000]
+    blocks, pos = [], 500
+    for i, n in enumerate(sizes):
+        tpl, seq, x, y = _block(SEED + 41_000 + i, pos + 150, n, 30)
+        blocks.append((tpl, seq, x, y))
+        pos = y
+    blocks.append((blocks[0][0][:0], blocks[0][1], pos + 10, pos + 300))  # a block without reads
+    refs = [B.synth_ref_host(SEED + 41_000 + i, x, y - x + 3) for i, (_, _, x, y) in enumerate(blocks)]
+    dbs = [rng.choice([0, 1, 3], size=y - x + 1, p=[0.9, 0.05, 0.05]).astype(np.uint8) for _, _, x, y in blocks]
+    flagged = np.concatenate([np.flatnonzero(d) + x for d, (_, _, x, _) in zip(dbs, blocks)]).astype(np.uint32)
+    listed = flagged[rng.random(len(flagged)) < 0.8]
+    nm = [b"rs%d" % int(v) for v in rng.integers(1, 10**9, len(listed))]
+    off = np.concatenate([[0], np.cumsum([len(v) for v in nm])]).astype(np.uint32)
+    names = (listed, off, b"".join(nm))
+    for kw in (dict(), dict(all_positions=True), dict(reg_start=blocks[5][2], reg_stop=blocks[-3][3] - 1000)):
+        want = [caller.block_bcf(t, s, x, y, refs[i], 2, names=names, dbsnp=dbs[i], **kw) for i, (t, s, x, y) in enumerate(blocks)]
+        got, n = caller.blocks_bcf(blocks, refs, 2, names=names, dbsnp=dbs, **kw)
+        assert n == sum(w[1] for w in want) and got == b"".join(w[0] for w in want), kw
+    exp = b"".join(w[0] for w in want)
+    # too little room: refused with the length needed, then the encoder alone once more (the wrapper does that when cap is its own)
+    with pytest.raises(BscError, match="stream has"):
+        caller.blocks_bcf(blocks, refs, 2, names=names, dbsnp=dbs, cap=len(exp) // 2, **kw)
+    got, n = caller.blocks_bcf(blocks, refs, 2, names=names, dbsnp=dbs, **kw)
+    assert got == exp
+    # a records fetch does not take a BCF submission, and the other way round
+    import ctypes as C
+
+    from bs_call_amd import _lib
+
+    L = _lib.load()
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    assert L.bsc_blocks_bcf_fetch(caller._h, C.byref(a), C.byref(b)) == -1
+    caller.blocks_records(blocks, refs, dbsnp=dbs, submit_only=True)
+    assert L.bsc_blocks_bcf_fetch(caller._h, C.byref(a), C.byref(b)) == -1 and b"bsc_blocks_bcf_submit" in L.bsc_last_error()
+    caller.blocks_records_fetch()
