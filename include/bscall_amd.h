@@ -30,7 +30,7 @@
  *   library, results on return; _inplace: the caller's page-locked memory (bsc_alloc_host), no staging copy; _submit / _fetch: the call in two
  *   halves, the host thread returns while the GPU works (one block in flight per context, as the reference hands a block to its calc
  *   threads); _to: results into caller-provided page-locked memory; _device: everything HBM-resident, asynchronous on the caller's stream;
- *   bsc_blocks_*: several small blocks in one launch sequence.
+ *   bsc_blocks_*: several small blocks in one launch sequence (records, gt_vcf images, or — bsc_blocks_bcf_* — one BCF stream).
  *   Below the levels: their device-resident pieces for callers that keep whole contigs in HBM (bsc_accumulate_device, bsc_chain_device,
  *   bsc_reads_chain[_len]_device, bsc_vcf_*_device, bsc_bcf_*_device: what bench.py and bs_call_amd/genome.py drive); host-side readers and
  *   writers (bsc_bam_*, bsc_bamstream_*, bsc_dbsnp_*, bsc_fasta_contig, bsc_prepare_templates, bsc_bcf_record, bsc_vcf_format,

@@ -6,11 +6,12 @@
  * and a writer thread of this file hands the bytes to bgzf_write.  For BCF output (param->out_file_type & FT_BCF, src/print_vcf.c:633-
  * 636) only: htslib renders text VCF from a bcf1_t, which this level no longer builds.
  *
- *   call k     block k is flattened into page-locked buffers and queued (bsc_block_bcf_submit_inplace); block k - 1, in flight since
- *              the last call, is fetched and its bytes given to the writer; the meth profiling thread is waited for; the call returns
- *              with block k in flight (integration/amd_bcf_protocol.h — the same code runs in integration/demo_block.c against a mock
- *              of work_t, checked against bsc_block_bcf block by block, with its end-to-end rate)
- *   join       the last block fetched and written; bs_stats filled once from the device's sums (src/stats.c:19-298 reads work->stats)
+ *   call k     block k is flattened and appended to the batch in the page-locked slot being filled; the meth profiling thread is waited for.
+ *              A batch of 250 000 positions (a larger block alone) is handed over: the batch in flight is fetched and its bytes given to
+ *              the writer, the new one queued (bsc_blocks_bcf_submit_inplace: one launch sequence for all its blocks) — the GPU works on
+ *              it while the process thread reads the next one's blocks (integration/amd_bcf_protocol.h — the same code runs in
+ *              integration/demo_block.c against a mock of work_t, checked against bsc_block_bcf block by block, with its end-to-end rate)
+ *   join       the last batch handed over, fetched and written; bs_stats filled once from the device's sums (src/stats.c:19-298 reads work->stats)
  *
  * The reference's print thread is left as it is: it is never handed a block (work->vcf_n stays 0) and ends on print_end.  What a
  * maintainer adds beside this file: nothing in process.c; in main(), the output must be BCF.  dbSNP: the flags and names of a block come
