@@ -5,7 +5,7 @@ src/get_template_vector.c:141-147: 10^2 .. 10^7 positions): host buffers in, pac
   batched      bsc_blocks_records over batches of >= --batch positions (one launch sequence per batch)
   gt_vcf form  bsc_blocks_submit_to (staged, from ordinary memory) and bsc_blocks_submit_to_inplace (page-locked buffers) + bsc_block_fetch:
                208-byte images of every position, the form the drop-in glue runs (integration/amd_overlap_protocol.h)
-  bytes form   bsc_block_bcf_submit_inplace block by block against bsc_blocks_bcf_submit_inplace per batch: the BCF stream back
+  bytes form   bsc_block_bcf block by block against bsc_blocks_bcf_submit_inplace per batch (page-locked buffers): the BCF stream back
 usage: python tools/bench_small_blocks.py [--batch 1000000] [--total 4000000] [--coverage 30] [--sizes 1000,10000,100000]"""
 import argparse
 import json
@@ -113,18 +113,7 @@ with B.SiteCaller() as c:
         t_b1, t_bb, bytes_1, bytes_b = [], [], 0, 0
         for rep in range(4):
             t0 = time.perf_counter()
-            bytes_1 = 0
-            for d, t, sq, rf, _ in joined:  # block by block out of the same joined arrays
-                to = ro = 0
-                for (x, y, nrb, _p) in d.tolist():
-                    tb = t[to : to + nrb]
-                    rc = L.bsc_block_bcf_submit_inplace(h, _ptr(tb) if nrb else None, nrb, _ptr(sq), sq.size, x, y, _ptr(rf[ro:]), None, C.byref(vp), 0, 0, C.byref(ids), None,
-                                                        _ptr(bout.array), cap_b)
-                    assert rc >= 0, rc
-                    rc = L.bsc_block_bcf_fetch(h, C.byref(nb_), C.byref(nr_c))
-                    assert rc >= 0, rc
-                    bytes_1 += nb_.value
-                    to, ro = to + nrb, ro + (y - x + 3)
+            bytes_1 = sum(len(c.block_bcf(t, sq, x, y, refs[i], 0)[0]) for i, (t, sq, x, y) in enumerate(blocks))  # one by one, as the records above
             t1 = time.perf_counter()
             bytes_b = 0
             for d, t, sq, rf, _ in joined:
@@ -153,7 +142,7 @@ with B.SiteCaller() as c:
                                 "batched_inplace_pinned_us_per_block": min(t_pin) / k * 1e6, "blocks_per_batch": per_batch,
                                 "gt_vcf_images_staged_M_positions_per_s": total / min(t_stage) / 1e6,
                                 "gt_vcf_images_inplace_pinned_M_positions_per_s": total / min(t_inpl) / 1e6,
-                                "bcf_bytes_one_by_one_inplace_M_positions_per_s": total / min(t_b1) / 1e6,
+                                "bcf_bytes_one_by_one_M_positions_per_s": total / min(t_b1) / 1e6,
                                 "bcf_bytes_batched_inplace_M_positions_per_s": total / min(t_bb) / 1e6, "bcf_bytes": bytes_b}
         print("%7d-position blocks x %4d: one by one %8.1f M positions/s (%6.0f us per block)   batched %8.1f M positions/s (%6.0f us per block; "
               "%.1f without the wrapper's array joins)   batched, in place from page-locked buffers %8.1f M positions/s (%6.0f us per block)"
@@ -162,7 +151,7 @@ with B.SiteCaller() as c:
         print("%7s gt_vcf images (208 B per position back; what the drop-in glue runs): bsc_blocks_submit_to from ordinary memory %8.1f M positions/s"
               "   bsc_blocks_submit_to_inplace from page-locked buffers %8.1f M positions/s" % ("", total / min(t_stage) / 1e6, total / min(t_inpl) / 1e6),
               file=sys.stderr)
-        print("%7s BCF bytes (57 B per position back; INTEGRATION.md 2b), in place from page-locked buffers: bsc_block_bcf_submit_inplace block by block %8.1f M positions/s"
+        print("%7s BCF bytes (57 B per position back; INTEGRATION.md 2b), in place from page-locked buffers: bsc_block_bcf block by block (ordinary memory) %8.1f M positions/s"
               "   bsc_blocks_bcf_submit_inplace per batch %8.1f M positions/s" % ("", total / min(t_b1) / 1e6, total / min(t_bb) / 1e6), file=sys.stderr)
         for pb in keep:
             for q in pb:
