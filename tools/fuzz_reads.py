@@ -4,7 +4,8 @@ restatement): random blocks (1 .. 60 000 positions, 5x .. 400x, odd sizes around
 random printing parameters and dbSNP flags, through
   * bsc_block_records in its two-kernel form (accumulate kernel's summary form -> chain kernel's summary-in form),
   * bsc_block_records in its one-kernel form (reads-in chain; bsc_set_reads_fused),
-  * bsc_blocks_records (several blocks in one launch sequence) — against the two above block by block, the statistics included.
+  * bsc_blocks_records (several blocks in one launch sequence) — against the two above block by block, the statistics included —
+    and bsc_blocks_bcf_submit / _fetch (the same launch sequence, one BCF stream back) against the host encoder over those records.
 Prints a progress line per round; stops at the first difference with the seed that reproduces it.
 usage: python tools/fuzz_reads.py [--minutes M] [--seed S]"""
 import argparse
@@ -17,6 +18,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 import bs_call_amd as B
+from bs_call_amd import vcf
 from oracle import loader as O
 from tests import test_gpu_blocks as T
 
@@ -74,6 +76,9 @@ while time.time() < t_end:
             sel = core["emit"] == 1
             ok = ok and rc == 0 and one[i]["core"].tobytes() == core[sel].tobytes() and (one[i]["counts"] == gtm["counts"][sel]).all() \
                 and (one[i]["mq"] == gtm["mq"][sel]).all() and (one[i]["qual"] == gtm["qual"][sel]).all()
+    if ok:  # ... and the bytes form of the batch (bsc_blocks_bcf_*): ONE stream = the host encoder (csrc/bcf.c) over the records above, in order
+        stream, n_rec = c2.blocks_bcf(blocks, refs, 7, dbsnp=db, **kw)
+        ok = n_rec == len(got) and stream == vcf.bcf_block(got, 7)
     if not ok:
         print("DIFFERENCE at seed %d (round %d): %d blocks, %s, dbsnp=%s" % (seed, rounds, nb, kw, use_db), flush=True)
         sys.exit(1)
