@@ -2,7 +2,7 @@
 """File to file at BASELINE configs[1]'s size: a synthetic coordinate-sorted WGBS BAM (tools/make_wgbs_bam.c) + FASTA -> BCF + report through
 integration/bam2bcf, with the reader on the device (round 6: the host only inflates) and, for the same bytes, with the host reader of rounds 2-5.
 Also the host streamer alone (its inflate rate by helper count) and the device reader alone (blocks formed, nothing called).
-usage: python tools/bench_bam2bcf_big.py [positions [coverage [out.json [contigs [straddle]]]]]     (writes its files under /tmp)"""
+usage: python tools/bench_bam2bcf_big.py [positions [coverage [out.json [contigs [straddle [poisson]]]]]]     (writes its files under /tmp)"""
 import hashlib
 import json
 import os
@@ -17,16 +17,17 @@ cov = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 out_json = sys.argv[3] if len(sys.argv) > 3 else None
 contigs = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 straddle = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+poisson = int(sys.argv[6]) if len(sys.argv) > 6 else 0  # forward starts as a Poisson process: coverage gaps, hence many blocks, at low depth
 d = os.environ.get("BENCH_TMP", "/tmp/bam2bcf_big")
 os.makedirs(d, exist_ok=True)
 gen = os.path.join(d, "make_wgbs_bam")
-subprocess.check_call(["gcc", "-O2", "-o", gen, os.path.join(ROOT, "tools", "make_wgbs_bam.c"), "-lz", "-lpthread"])
+subprocess.check_call(["gcc", "-O2", "-o", gen, os.path.join(ROOT, "tools", "make_wgbs_bam.c"), "-lz", "-lpthread", "-lm"])
 bam, fa = os.path.join(d, "in.bam"), os.path.join(d, "ref.fa")
 t0 = time.time()
-ginfo = json.loads(subprocess.check_output([gen, bam, fa, str(n), str(cov), "88172645463325253", str(min(32, os.cpu_count() or 8)), "1", str(straddle), str(contigs)]))
+ginfo = json.loads(subprocess.check_output([gen, bam, fa, str(n), str(cov), "88172645463325253", str(min(32, os.cpu_count() or 8)), "1", str(straddle), str(contigs), str(poisson)]))
 gen_s = time.time() - t0
 print("generated", ginfo, round(gen_s, 1), "s", os.path.getsize(bam), "bytes", flush=True)
-res = {"positions": n, "coverage": cov, "contigs": contigs, "records_straddle_bgzf_blocks": bool(straddle), "alignments": ginfo["alignments"],
+res = {"positions": n, "coverage": cov, "contigs": contigs, "records_straddle_bgzf_blocks": bool(straddle), "poisson_starts": bool(poisson), "alignments": ginfo["alignments"],
        "bam_bytes": os.path.getsize(bam), "generate_s": round(gen_s, 1), "host_cpus": os.cpu_count(),
        "host_cpus_usable": len(os.sched_getaffinity(0))}
 

@@ -2,8 +2,8 @@
  * make_wgbs_bam.c — a coordinate-sorted synthetic WGBS BAM and its FASTA at BASELINE configs[1]'s size, in seconds (tools/make_bam.py's
  * wgbs_records, the L-reads of SURVEY.md 8(d), is pure Python: fine for 10^4 records, not for 1.5 * 10^7).  Bench / test input only.
  *
- *   gcc -O2 -o make_wgbs_bam tools/make_wgbs_bam.c -lz -lpthread
- *   make_wgbs_bam out.bam out.fa POSITIONS COVERAGE [seed [threads [level [straddle [contigs]]]]]
+ *   gcc -O2 -o make_wgbs_bam tools/make_wgbs_bam.c -lz -lpthread -lm
+ *   make_wgbs_bam out.bam out.fa POSITIONS COVERAGE [seed [threads [level [straddle [contigs [poisson]]]]]]
  *
  * Reference bases uniform over ACGT (syn_ref of csrc/synth.h); paired templates, reads of 100 bases, insert 300, forward starts evenly spaced
  * so that the mean depth is COVERAGE; bisulfite strand and pair orientation Bernoulli(1/2) per template; C->T on C2T reads / G->A on G2A
@@ -12,6 +12,7 @@
  * contigs of equal length (chrS1 ..).  BGZF blocks are cut at record boundaries as htslib's writer does (bgzf_flush_try); `straddle` 1
  * cuts them every 0xff00 bytes regardless, as htsjdk's stream does.  Deflate `level` (default 1) on `threads` threads.
  */
+#include <math.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -188,7 +189,7 @@ static void emit(buf *b, const pend *p, int32_t tid, uint32_t ctg0) {
 
 int main(int argc, char **argv) {
   if (argc < 5) {
-    fprintf(stderr, "usage: %s out.bam out.fa POSITIONS COVERAGE [seed [threads [level [straddle [contigs]]]]]\n", argv[0]);
+    fprintf(stderr, "usage: %s out.bam out.fa POSITIONS COVERAGE [seed [threads [level [straddle [contigs [poisson]]]]]]\n", argv[0]);
     return 2;
   }
   const uint64_t n_pos = strtoull(argv[3], NULL, 10);
@@ -200,6 +201,7 @@ int main(int argc, char **argv) {
   g_level = argc > 7 ? atoi(argv[7]) : 1;
   const int straddle = argc > 8 ? atoi(argv[8]) : 0;
   const uint32_t n_ctg = argc > 9 && atoi(argv[9]) > 0 ? (uint32_t)atoi(argv[9]) : 1u;
+  const int poisson = argc > 10 ? atoi(argv[10]) : 0;
   g_ctg_len = (uint32_t)(n_pos / n_ctg);
   if (g_ctg_len < 2 * INSERT) {
     fprintf(stderr, "contigs too short\n");
@@ -272,8 +274,15 @@ int main(int argc, char **argv) {
   for (uint32_t c = 0; c < n_ctg; c++) {
     const uint32_t ctg0 = c * g_ctg_len;
     uint32_t qh = 0, qt = 0;
+    double at = 0.0; /* poisson: the forward starts are a Poisson process of the same mean spacing — coverage gaps, hence many blocks, at low depth */
     for (uint64_t i = 0; i <= pairs; i++) {
-      const uint32_t s = i < pairs ? (uint32_t)(i * span / pairs) : 0xffffffffu;
+      uint32_t s = i < pairs ? (uint32_t)(i * span / pairs) : 0xffffffffu;
+      if (poisson && i < pairs) {
+        const uint64_t r = syn_mix(g_seed ^ (0xd1342543de82ef95ull * (i + 1ull + (uint64_t)c * pairs)));
+        at += -log(((double)(r >> 11) + 1.0) / 9007199254740993.0) * (double)span / (double)pairs;
+        s = at < (double)span ? (uint32_t)at : 0xffffffffu;
+        if (s == 0xffffffffu) i = pairs; /* the contig is full: the waiting mates go out, then the next contig */
+      }
       while (qh != qt && q[qh & 65535u].pos < s) { /* mates that start before this forward read go first */
         const size_t before = b.len;
         emit(&b, &q[qh & 65535u], (int32_t)c, ctg0);

@@ -48,7 +48,7 @@ cp profiles/valu.json $O/valu.json
 # 4
 T=/tmp/r06_bam
 mkdir -p $T
-[ -x $T/make_wgbs_bam ] || gcc -O2 -o $T/make_wgbs_bam tools/make_wgbs_bam.c -lz -lpthread
+[ -x $T/make_wgbs_bam ] || gcc -O2 -o $T/make_wgbs_bam tools/make_wgbs_bam.c -lz -lpthread -lm
 $T/make_wgbs_bam $T/in.bam $T/ref.fa 50000000 30 7 16 1 > $O/bam_generated.txt
 (cd /tmp && BAM2BCF_TIMING=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bam2bcf_trace -- $ROOT/bs_call_amd/lib/bam2bcf $T/in.bam $T/ref.fa $T/out.bcf $T/rep.json > $O/bam2bcf_trace.out 2> $O/bam2bcf_trace.err) || { tail -5 $O/bam2bcf_trace.err; exit 1; }
 python3 tools/kstats.py $(ls $O/bam2bcf_trace/*/*_kernel_stats.csv | head -1) 40 > $O/bam2bcf_kernels.txt; cat $O/bam2bcf_kernels.txt
