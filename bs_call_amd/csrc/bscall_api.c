@@ -2271,7 +2271,7 @@ static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32
   }
   if (timing) {
     t1 = bsc_now_s();
-    fprintf(stderr, "bsc stage: reserve + reference upload queued %.3f s\n", t1 - t0);
+    fprintf(stderr, "bsc stage: reserve + reference upload queued %.1f us\n", (t1 - t0) * 1e6);
     t0 = t1;
   }
   /* the pre-processing and everything behind it are queued back to back: the chain takes the room for the prepared reads as the bound of
@@ -2285,7 +2285,7 @@ static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32
   }
   if (timing) {
     t1 = bsc_now_s();
-    fprintf(stderr, "bsc stage: pre-processing queued %.3f s\n", t1 - t0);
+    fprintf(stderr, "bsc stage: pre-processing queued %.1f us\n", (t1 - t0) * 1e6);
     t0 = t1;
   }
   rc = bsc_records_queue(ctx, NULL, nr, NULL, cap, x, y, ref, dbsnp, params, with_stats, out, out_cap, 2, bcf);
@@ -2297,14 +2297,14 @@ static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32
   if (ctx->profiling && hipEventRecord(ctx->ev_raw[1], s) == hipSuccess) ctx->ev_raw_valid = 1; /* (behind the encoder and the copy-out it queued) */
   if (timing) {
     t1 = bsc_now_s();
-    fprintf(stderr, "bsc stage: bsc_records_queue (reserves, uploads, launches) %.3f s\n", t1 - t0);
+    fprintf(stderr, "bsc stage: bsc_records_queue (reserves, uploads, launches) %.1f us\n", (t1 - t0) * 1e6);
     t0 = t1;
   }
   const hipError_t se = hipStreamSynchronize(s);
   if (se != hipSuccess) return bsc_fail(BSC_ERR_HIP, "bsc_block_records_raw: %s", hipGetErrorString(se));
   if (timing) {
     t1 = bsc_now_s();
-    fprintf(stderr, "bsc stage: the wait %.3f s\n", t1 - t0);
+    fprintf(stderr, "bsc stage: the wait %.1f us\n", (t1 - t0) * 1e6);
     t0 = t1;
   }
   /* the pre-processing's verdict first: where the reference aborts on a template, the chain behind it ran over what was left of the block —
@@ -2319,7 +2319,7 @@ static int bsc_block_records_rawdev_(bsc_context *ctx, const void *d_raw, uint32
   rc = bsc_records_finish(ctx, n_out);
   if (timing) {
     t1 = bsc_now_s();
-    fprintf(stderr, "bsc stage: bsc_records_finish %.3f s\n", t1 - t0);
+    fprintf(stderr, "bsc stage: bsc_records_finish %.1f us\n", (t1 - t0) * 1e6);
   }
   return rc;
 }
