@@ -1,7 +1,8 @@
 #!/bin/bash
 # A/B on one box, interleaved: the BCF write kernel of the library (fields composed as words, the chain's byte per position as gate and
 # length, BCF_WPE_SITES waves a SIMD) against variants built next to it (bs_call_amd/lib/variants/lib_<name>.so: tools/build_variant_bcf.sh;
-# lib_bcf_head.so = the byte-by-byte form of the commit before); the streams' checksums must agree.
+# lib_bcf_head.so = the byte-by-byte form of the commit before: `git show 53f79b9^:bs_call_amd/csrc/bcfdev.hip` compiled and linked as
+# build_variant_bcf.sh does); the streams' checksums must agree.
 # usage: bash tools/r06_ab_bcf_words.sh <tag> [variant names ...]
 set -e
 O=$GRAFT_REPO_ROOT/gpurun_out/$1
